@@ -1,0 +1,282 @@
+"""ctypes binding of the CPU oracle (oracle/storm_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/, bench.py's cpu_baseline leg and
+__graft_entry__.smoke(); never by anything under stormruler_amd/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATHS = {"strict": os.path.join(_HERE, "liboracle.so"),
+              "fma": os.path.join(_HERE, "liboracle_fma.so")}
+
+f64p = C.POINTER(C.c_double)
+i64p = C.POINTER(C.c_int64)
+
+
+def build(force: bool = False) -> None:
+    """Compile both oracle variants (strict: -ffp-contract=off; fma: contraction allowed)."""
+    src = os.path.join(_HERE, "storm_oracle.c")
+    stale = [p for p in _LIB_PATHS.values()
+             if force or not os.path.exists(p) or os.path.getmtime(p) < os.path.getmtime(src)]
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "all"], stdout=subprocess.DEVNULL)
+
+
+class _Mesh(C.Structure):
+    _fields_ = [("n_cells", C.c_int64), ("n_faces", C.c_int64), ("n_bfaces", C.c_int64),
+                ("dim", C.c_int32),
+                ("inner", i64p), ("outer", i64p), ("area", f64p), ("center", f64p),
+                ("volume", f64p), ("b_cell", i64p), ("b_area", f64p), ("b_center", f64p),
+                ("b_ghost", f64p)]
+
+
+class _StencilOp(C.Structure):
+    _fields_ = [("mesh", C.POINTER(_Mesh)), ("alpha", C.c_double), ("beta", C.c_double),
+                ("conv", C.c_double), ("vel", C.c_double * 3)]
+
+
+class _CsrOp(C.Structure):
+    _fields_ = [("n", C.c_int64), ("row_ptr", i64p), ("col", i64p), ("val", f64p)]
+
+
+class _Params(C.Structure):
+    _fields_ = [("num_iterations", C.c_int64), ("absolute_error_tolerance", C.c_double),
+                ("relative_error_tolerance", C.c_double), ("num_inner_iterations", C.c_int64)]
+
+
+class _Result(C.Structure):
+    _fields_ = [("iterations", C.c_int64), ("absolute_error", C.c_double),
+                ("relative_error", C.c_double), ("initial_error", C.c_double),
+                ("converged", C.c_int32), ("num_applies", C.c_int64)]
+
+
+APPLY_FN = C.CFUNCTYPE(None, C.c_void_p, f64p, f64p)
+
+_libs = {}
+
+
+def lib(variant: str = "strict"):
+    if variant not in _libs:
+        build()
+        L = _libs[variant] = C.CDLL(_LIB_PATHS[variant])
+        L.oracle_safe_divide.restype = C.c_double
+        L.oracle_safe_divide.argtypes = [C.c_double, C.c_double]
+        L.oracle_sym_ortho.argtypes = [C.c_double, C.c_double, f64p, f64p, f64p]
+        for name in ("oracle_norm2", "oracle_sum", "oracle_norm1", "oracle_norm_inf"):
+            getattr(L, name).restype = C.c_double
+            getattr(L, name).argtypes = [C.c_int64, f64p]
+        L.oracle_dot.restype = C.c_double
+        L.oracle_dot.argtypes = [C.c_int64, f64p, f64p]
+        L.oracle_copy.argtypes = [C.c_int64, f64p, f64p]
+        L.oracle_fill.argtypes = [C.c_int64, f64p, C.c_double]
+        L.oracle_axpy.argtypes = [C.c_int64, f64p, C.c_double, f64p]
+        L.oracle_axmy.argtypes = [C.c_int64, f64p, C.c_double, f64p]
+        L.oracle_xpay.argtypes = [C.c_int64, f64p, f64p, C.c_double]
+        L.oracle_bicg_p.argtypes = [C.c_int64, f64p, f64p, C.c_double, C.c_double, f64p]
+        L.oracle_sub_from.argtypes = [C.c_int64, f64p, f64p]
+        L.oracle_div_scalar.argtypes = [C.c_int64, f64p, C.c_double]
+        L.oracle_mul_scalar.argtypes = [C.c_int64, f64p, C.c_double]
+        L.oracle_expr1.argtypes = [C.c_int64, f64p, f64p, C.c_double, f64p, f64p]
+        L.oracle_divgrad.argtypes = [C.POINTER(_Mesh), f64p, C.c_double, f64p]
+        L.oracle_convection.argtypes = [C.POINTER(_Mesh), f64p, C.c_double, f64p, f64p]
+        L.oracle_stencil_apply.argtypes = [C.c_void_p, f64p, f64p]
+        L.oracle_csr_apply.argtypes = [C.c_void_p, f64p, f64p]
+        for name in ("oracle_solve_cg", "oracle_solve_bicgstab", "oracle_solve_gmres"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int64, f64p, f64p,
+                                         C.POINTER(_Params), C.POINTER(_Result), f64p]
+    return _libs[variant]
+
+
+def _p(a: np.ndarray):
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    return a.ctypes.data_as(f64p)
+
+
+def _pi(a: np.ndarray):
+    assert a.dtype == np.int64 and a.flags.c_contiguous
+    return a.ctypes.data_as(i64p)
+
+
+def f64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+# --- BLAS-1 ---------------------------------------------------------------------------
+def dot(a, b) -> float:
+    a, b = f64(a).ravel(), f64(b).ravel()
+    return lib().oracle_dot(a.size, _p(a), _p(b))
+
+
+def norm2(a) -> float:
+    a = f64(a).ravel()
+    return lib().oracle_norm2(a.size, _p(a))
+
+
+def vsum(a) -> float:
+    a = f64(a).ravel()
+    return lib().oracle_sum(a.size, _p(a))
+
+
+def norm1(a) -> float:
+    a = f64(a).ravel()
+    return lib().oracle_norm1(a.size, _p(a))
+
+
+def norm_inf(a) -> float:
+    a = f64(a).ravel()
+    return lib().oracle_norm_inf(a.size, _p(a))
+
+
+def safe_divide(x: float, y: float) -> float:
+    return lib().oracle_safe_divide(x, y)
+
+
+def sym_ortho(a: float, b: float):
+    cs, sn, rr = C.c_double(), C.c_double(), C.c_double()
+    lib().oracle_sym_ortho(a, b, C.byref(cs), C.byref(sn), C.byref(rr))
+    return cs.value, sn.value, rr.value
+
+
+def axpy(y, a, x):
+    lib().oracle_axpy(y.size, _p(y), a, _p(x))
+
+
+def axmy(y, a, x):
+    lib().oracle_axmy(y.size, _p(y), a, _p(x))
+
+
+def xpay(y, x, b):
+    lib().oracle_xpay(y.size, _p(y), _p(x), b)
+
+
+def bicg_p(p, r, b, w, v):
+    lib().oracle_bicg_p(p.size, _p(p), _p(r), b, w, _p(v))
+
+
+def sub_from(r, b):
+    lib().oracle_sub_from(r.size, _p(r), _p(b))
+
+
+def div_scalar(y, s):
+    lib().oracle_div_scalar(y.size, _p(y), s)
+
+
+def mul_scalar(y, s):
+    lib().oracle_mul_scalar(y.size, _p(y), s)
+
+
+def expr1(a, s, b, c) -> np.ndarray:
+    a, b, c = f64(a).ravel(), f64(b).ravel(), f64(c).ravel()
+    out = np.empty_like(a)
+    lib().oracle_expr1(a.size, _p(out), _p(a), s, _p(b), _p(c))
+    return out
+
+
+# --- operators ------------------------------------------------------------------------
+class Mesh:
+    """Keeps the numpy arrays alive behind an ``oracle_mesh`` struct."""
+
+    def __init__(self, g, ghost: Optional[np.ndarray] = None):
+        self.g = g
+        self._keep = dict(
+            inner=np.ascontiguousarray(g.inner, np.int64), outer=np.ascontiguousarray(g.outer, np.int64),
+            area=f64(g.area), center=f64(g.center), volume=f64(g.volume),
+            b_cell=np.ascontiguousarray(g.b_cell, np.int64), b_area=f64(g.b_area),
+            b_center=f64(g.b_center))
+        k = self._keep
+        self.c = _Mesh(g.n_total, g.n_faces, g.n_bfaces, g.dim, _pi(k["inner"]), _pi(k["outer"]),
+                       _p(k["area"]), _p(k["center"]), _p(k["volume"]), _pi(k["b_cell"]),
+                       _p(k["b_area"]), _p(k["b_center"]), None)
+        if ghost is not None:
+            k["ghost"] = f64(ghost)
+            self.c.b_ghost = _p(k["ghost"])
+
+
+class StencilOperator:
+    """``y = beta*x + alpha*L(x) [+ conv*C_v(x)]`` through the reference-order face loops."""
+
+    def __init__(self, g, alpha: float, beta: float, conv: float = 0.0, vel=(0.0, 0.0, 0.0),
+                 variant: str = "strict"):
+        self.variant = variant
+        self.mesh = Mesh(g)
+        self.n = g.n_total
+        v = (C.c_double * 3)(*[float(t) for t in vel])
+        self.c = _StencilOp(C.pointer(self.mesh.c), alpha, beta, conv, v)
+        self.fn = C.cast(lib(variant).oracle_stencil_apply, C.c_void_p)
+        self.ctx = C.cast(C.pointer(self.c), C.c_void_p)
+
+    def apply(self, x: np.ndarray) -> np.ndarray:
+        x = f64(x)
+        y = np.empty_like(x)
+        lib(self.variant).oracle_stencil_apply(self.ctx, _p(y), _p(x))
+        return y
+
+
+class CsrOperator:
+    def __init__(self, a):
+        a = a.tocsr()
+        self.n = a.shape[0]
+        self._keep = (np.ascontiguousarray(a.indptr, np.int64), np.ascontiguousarray(a.indices, np.int64),
+                      f64(a.data))
+        self.c = _CsrOp(self.n, _pi(self._keep[0]), _pi(self._keep[1]), _p(self._keep[2]))
+        self.fn = C.cast(lib().oracle_csr_apply, C.c_void_p)
+        self.ctx = C.cast(C.pointer(self.c), C.c_void_p)
+
+    def apply(self, x):
+        x = f64(x)
+        y = np.empty_like(x)
+        lib().oracle_csr_apply(self.ctx, _p(y), _p(x))
+        return y
+
+
+class CallbackOperator:
+    """Operator whose ``mul`` is a Python callable (used by the 2-rank gloo tests)."""
+
+    def __init__(self, n: int, fn):
+        self.n = n
+
+        def _cb(_ctx, yp, xp):
+            x = np.ctypeslib.as_array(xp, shape=(n,))
+            y = np.ctypeslib.as_array(yp, shape=(n,))
+            y[:] = fn(x)
+
+        self._cb = APPLY_FN(_cb)
+        self.fn = C.cast(self._cb, C.c_void_p)
+        self.ctx = None
+
+
+@dataclass
+class SolveResult:
+    x: np.ndarray
+    iterations: int
+    absolute_error: float
+    relative_error: float
+    initial_error: float
+    converged: bool
+    num_applies: int
+    history: np.ndarray
+
+
+def solve(kind: str, op, b, x0=None, num_iterations: int = 2000, abs_tol: float = 1e-6,
+          rel_tol: float = 1e-6, num_inner_iterations: int = 50,
+          variant: str = "strict") -> SolveResult:
+    """``solve<XSolver>(x, b, op)`` of Solvers/Solver.hpp:261-265 with the reference defaults."""
+    b = f64(b)
+    x = np.zeros_like(b) if x0 is None else f64(x0).copy()
+    p = _Params(num_iterations, abs_tol, rel_tol, num_inner_iterations)
+    r = _Result()
+    hist = np.full(num_iterations + 1, np.nan)
+    L = lib(variant)
+    fn = {"cg": L.oracle_solve_cg, "bicgstab": L.oracle_solve_bicgstab,
+          "gmres": L.oracle_solve_gmres}[kind]
+    fn(op.fn, op.ctx, b.size, _p(x), _p(b), C.byref(p), C.byref(r), _p(hist))
+    return SolveResult(x, r.iterations, r.absolute_error, r.relative_error, r.initial_error,
+                       bool(r.converged), r.num_applies, hist[: r.iterations + 1].copy())

@@ -1,0 +1,586 @@
+/*
+ * storm_oracle.c -- CPU restatement of the StormRuler Krylov hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, bench.py's
+ * cpu_baseline leg and __graft_entry__.smoke() may load it, and only as the
+ * checker / the timed CPU baseline.  Nothing under stormruler_amd/ or include/
+ * links, imports or calls it.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - BLAS-1 (dot / norm_2 / axpy-type expressions): PINNED by the reference's
+ *     own unit tests tests/unit/BitternReductions.cpp:59-76,99-115 and
+ *     tests/unit/BitternMath.cpp:136-189 (tests/test_oracle_kat.py).
+ *   - stencil apply and the CG / BiCGStab / GMRES loops: PARITY UNPINNED by the
+ *     reference's own tests (it has none for Storm::Solvers / stormDivGrad) and
+ *     the reference cannot be built in this image without stand-ins for
+ *     spdlog/fmt (Storm/Base.hpp -> Crow/Base/Log.hpp:23-24), which this repo
+ *     does not write.  The restatement is cross-checked against the values the
+ *     survey recorded from the reference in BASELINE.md section 2 (iteration
+ *     counts, x[centre]) and against closed-form / scipy answers.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * the reference root).  Arithmetic order is kept exactly as in the reference:
+ * sequential left-to-right sums, one rounding per written operation; compile
+ * with -ffp-contract=off so no FMA is formed that the source does not spell.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORACLE_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------ */
+/* Scalar helpers.                                                           */
+
+/* source/Storm/Crow/MathUtils.hpp:49-52 -- y == 0 ? 0 : x / y. */
+ORACLE_API double oracle_safe_divide(double x, double y) {
+  return (y == 0.0) ? 0.0 : (x / y);
+}
+
+/* source/Storm/Crow/MathUtils.hpp:164-179 -- Givens rotation via hypot. */
+ORACLE_API void oracle_sym_ortho(double a, double b, double *cs, double *sn,
+                                 double *rr) {
+  *rr = hypot(a, b);
+  if (*rr > 0.0) {
+    *cs = a / *rr, *sn = b / *rr;
+  } else {
+    *cs = 1.0, *sn = 0.0;
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* BLAS-1: the Bittern element loops a solver statement lowers to.           */
+/* source/Storm/Bittern/MatrixAlgorithms.hpp:58-81 (matrix_for_each, one     */
+/* sequential loop over rows; NumVars == 1 so cols == 1, Field.hpp:77-79).   */
+
+/* dot_product: MatrixAlgorithms.hpp:310-317 -> reduce :191-205, init 0.0,   */
+/* strictly sequential; real DotProduct = a * b (Crow/MathUtils.hpp:90-95).  */
+ORACLE_API double oracle_dot(int64_t n, const double *a, const double *b) {
+  double s = 0.0;
+  for (int64_t i = 0; i < n; ++i) s = s + a[i] * b[i];
+  return s;
+}
+
+/* norm_2: MatrixAlgorithms.hpp:262-270: sqrt(sum |a_i|^2), AbsSquared =     */
+/* real(a * conj(a)) (Crow/FunctionalUtils.hpp:488-496).                     */
+ORACLE_API double oracle_norm2(int64_t n, const double *a) {
+  double s = 0.0;
+  for (int64_t i = 0; i < n; ++i) s = s + a[i] * a[i];
+  return sqrt(s);
+}
+
+/* sum / norm_1 / norm_inf: MatrixAlgorithms.hpp:214-300 (used by the KATs). */
+ORACLE_API double oracle_sum(int64_t n, const double *a) {
+  double s = 0.0;
+  for (int64_t i = 0; i < n; ++i) s = s + a[i];
+  return s;
+}
+ORACLE_API double oracle_norm1(int64_t n, const double *a) {
+  double s = 0.0;
+  for (int64_t i = 0; i < n; ++i) s = s + fabs(a[i]);
+  return s;
+}
+ORACLE_API double oracle_norm_inf(int64_t n, const double *a) {
+  double s = 0.0;
+  for (int64_t i = 0; i < n; ++i) s = fmax(s, fabs(a[i]));
+  return s;
+}
+
+/* y <<= x            MatrixAlgorithms.hpp:120-124 */
+ORACLE_API void oracle_copy(int64_t n, double *y, const double *x) {
+  for (int64_t i = 0; i < n; ++i) y[i] = x[i];
+}
+/* fill_with(y, v)    (ADL hook, Solver.hpp:281) */
+ORACLE_API void oracle_fill(int64_t n, double *y, double v) {
+  for (int64_t i = 0; i < n; ++i) y[i] = v;
+}
+/* y += a * x         MatrixTarget.hpp:108-113 with MatrixMath.hpp:247-256 */
+ORACLE_API void oracle_axpy(int64_t n, double *y, double a, const double *x) {
+  for (int64_t i = 0; i < n; ++i) y[i] += a * x[i];
+}
+/* y -= a * x         MatrixTarget.hpp:114-119 */
+ORACLE_API void oracle_axmy(int64_t n, double *y, double a, const double *x) {
+  for (int64_t i = 0; i < n; ++i) y[i] -= a * x[i];
+}
+/* y <<= x + b * y    SolverCg.hpp:123 */
+ORACLE_API void oracle_xpay(int64_t n, double *y, const double *x, double b) {
+  for (int64_t i = 0; i < n; ++i) y[i] = x[i] + b * y[i];
+}
+/* p <<= r + b * (p - w * v)   SolverBiCgStab.hpp:119 */
+ORACLE_API void oracle_bicg_p(int64_t n, double *p, const double *r, double b,
+                              double w, const double *v) {
+  for (int64_t i = 0; i < n; ++i) p[i] = r[i] + b * (p[i] - w * v[i]);
+}
+/* r <<= b - r        Operator.hpp:98 */
+ORACLE_API void oracle_sub_from(int64_t n, double *r, const double *b) {
+  for (int64_t i = 0; i < n; ++i) r[i] = b[i] - r[i];
+}
+/* y /= s ; y *= s    SolverGmres.hpp:88,162,242 (plain, not safe, divide) */
+ORACLE_API void oracle_div_scalar(int64_t n, double *y, double s) {
+  for (int64_t i = 0; i < n; ++i) y[i] /= s;
+}
+ORACLE_API void oracle_mul_scalar(int64_t n, double *y, double s) {
+  for (int64_t i = 0; i < n; ++i) y[i] *= s;
+}
+/* out <<= a + s * (b - c)   tests/unit/BitternMath.cpp:146-151 (KAT expr-1) */
+ORACLE_API void oracle_expr1(int64_t n, double *out, const double *a, double s,
+                             const double *b, const double *c) {
+  for (int64_t i = 0; i < n; ++i) out[i] = a[i] + s * (b[i] - c[i]);
+}
+
+/* ------------------------------------------------------------------------ */
+/* The face graph: what stormDivGrad reads through the Mallard accessors     */
+/* (Mesh.hpp:240-282 FaceView::inner_cell/outer_cell/area, :290-323          */
+/* CellView::volume/center; interior_faces() = label-0 range, :453-455).     */
+
+typedef struct oracle_mesh {
+  int64_t n_cells, n_faces, n_bfaces;
+  int32_t dim;
+  const int64_t *inner;   /* [F] face -> inner cell (lower id side)          */
+  const int64_t *outer;   /* [F] face -> outer cell                          */
+  const double *area;     /* [F]                                             */
+  const double *center;   /* [N * dim] cell centres                          */
+  const double *volume;   /* [N]                                             */
+  /* Dirichlet boundary faces (ghost-state pattern of             */
+  /* Feathers/ConvectionScheme.hpp:95-106).  The ghost value sits at the     */
+  /* face centre, i.e. at distance |x_f - x_c| from the cell centre.         */
+  const int64_t *b_cell;  /* [B] boundary face -> its single (inner) cell    */
+  const double *b_area;   /* [B]                                             */
+  const double *b_center; /* [B * dim] face centres                          */
+  const double *b_ghost;  /* [B] ghost values, or NULL for homogeneous 0     */
+} oracle_mesh;
+
+/* length(a - b): MatrixAlgorithms.hpp:303-305 -> norm_2 :262-270, i.e.      */
+/* sqrt(0 + d0*d0 + d1*d1 (+ d2*d2)) summed left to right.                   */
+static inline double center_dist(const double *a, const double *b, int dim) {
+  double s = 0.0;
+  for (int k = 0; k < dim; ++k) {
+    const double d = a[k] - b[k];
+    s = s + d * d;
+  }
+  return sqrt(s);
+}
+
+/*
+ * u += dt * div(grad(c))      source_apps/playground/Playground.cpp:115-131
+ *
+ *   for each interior face (in face order):
+ *     flux = dt * (c[out] - c[in]) / length(center(out) - center(in))   :126-127
+ *     u[in]  += (area / volume(in))  * flux                             :128
+ *     u[out] -= (area / volume(out)) * flux                             :129
+ *
+ * Geometry is recomputed on every apply, exactly as the reference does.
+ * Boundary faces: the reference loop visits interior_faces() only (:119), a
+ * pure-Neumann operator.  The Poisson configs need Dirichlet walls, so a
+ * second loop adds the flux to a ghost state g_b held at the face centre
+ * (loop shape of Feathers/ConvectionScheme.hpp:95-106); with n_bfaces == 0
+ * this function is the reference stencil verbatim.
+ */
+ORACLE_API void oracle_divgrad(const oracle_mesh *m, double *u, double dt,
+                               const double *c) {
+  const int dim = m->dim;
+  for (int64_t f = 0; f < m->n_faces; ++f) {
+    const int64_t ci = m->inner[f], co = m->outer[f];
+    const double flux =
+        dt * (c[co] - c[ci]) /
+        center_dist(m->center + co * dim, m->center + ci * dim, dim);
+    u[ci] += (m->area[f] / m->volume[ci]) * flux;
+    u[co] -= (m->area[f] / m->volume[co]) * flux;
+  }
+  for (int64_t b = 0; b < m->n_bfaces; ++b) {
+    const int64_t ci = m->b_cell[b];
+    const double g = m->b_ghost ? m->b_ghost[b] : 0.0;
+    const double flux =
+        dt * (g - c[ci]) /
+        center_dist(m->b_center + b * dim, m->center + ci * dim, dim);
+    u[ci] += (m->b_area[b] / m->volume[ci]) * flux;
+  }
+}
+
+/*
+ * First-order upwind convection, u += dt * div(v c), constant velocity v.
+ * Loop shape of Feathers/ConvectionScheme.hpp:80-107: interior faces (:83-92)
+ * take the upwind cell's state, flux added to inner / subtracted from outer
+ * scaled by area/volume; boundary faces (:95-106) use the ghost state when the
+ * flow enters.  `normal` is the unit normal pointing inner -> outer, taken
+ * from the cell centres as in stormDivGrad.  (SURVEY 8f rank 1 operator; the
+ * reference has no scalar convection definition -- Playground.cpp:161-165 is
+ * a commented-out call site -- so this is the build's own definition.)
+ */
+ORACLE_API void oracle_convection(const oracle_mesh *m, double *u, double dt,
+                                  const double *c, const double *vel) {
+  const int dim = m->dim;
+  for (int64_t f = 0; f < m->n_faces; ++f) {
+    const int64_t ci = m->inner[f], co = m->outer[f];
+    const double *xo = m->center + co * dim, *xi = m->center + ci * dim;
+    const double d = center_dist(xo, xi, dim);
+    double vn = 0.0;
+    for (int k = 0; k < dim; ++k) vn = vn + vel[k] * ((xo[k] - xi[k]) / d);
+    const double flux = dt * (vn > 0.0 ? vn * c[ci] : vn * c[co]);
+    u[ci] -= (m->area[f] / m->volume[ci]) * flux;
+    u[co] += (m->area[f] / m->volume[co]) * flux;
+  }
+  for (int64_t b = 0; b < m->n_bfaces; ++b) {
+    const int64_t ci = m->b_cell[b];
+    const double *xf = m->b_center + b * dim, *xi = m->center + ci * dim;
+    const double d = center_dist(xf, xi, dim);
+    double vn = 0.0;
+    for (int k = 0; k < dim; ++k) vn = vn + vel[k] * ((xf[k] - xi[k]) / d);
+    const double g = m->b_ghost ? m->b_ghost[b] : 0.0;
+    const double flux = dt * (vn > 0.0 ? vn * c[ci] : vn * g);
+    u[ci] -= (m->b_area[b] / m->volume[ci]) * flux;
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Operators.  `Operator::mul(y, x)`  Solvers/Operator.hpp:74.               */
+
+typedef void (*oracle_apply_fn)(void *ctx, double *y, const double *x);
+
+/*
+ * The face-graph operator used by every config:
+ *     y = beta * x + alpha * L(x)  [ + conv * C_v(x) ]
+ * built the way the playground lambda builds its operator
+ * (Playground.cpp:153-167): y <<= beta * x, then stormDivGrad(y, alpha, x).
+ * Poisson:   alpha = -1, beta = 0.  Helmholtz: beta = 1, alpha = -kappa.
+ * Conv-diff: alpha = -nu, beta = 0, conv = 1 (A = -nu L + C(v)).
+ */
+typedef struct oracle_stencil_op {
+  const oracle_mesh *mesh;
+  double alpha, beta;
+  double conv;          /* 0 => no convection term */
+  double vel[3];
+} oracle_stencil_op;
+
+ORACLE_API void oracle_stencil_apply(void *ctx, double *y, const double *x) {
+  const oracle_stencil_op *op = (const oracle_stencil_op *)ctx;
+  const int64_t n = op->mesh->n_cells;
+  for (int64_t i = 0; i < n; ++i) y[i] = op->beta * x[i];
+  oracle_divgrad(op->mesh, y, op->alpha, x);
+  if (op->conv != 0.0) oracle_convection(op->mesh, y, op->conv, x, op->vel);
+}
+
+/* Plain CSR operator (1-D KATs, cross-checks).  y_i = sum_k val_k x[col_k]. */
+typedef struct oracle_csr_op {
+  int64_t n;
+  const int64_t *row_ptr, *col;
+  const double *val;
+} oracle_csr_op;
+
+ORACLE_API void oracle_csr_apply(void *ctx, double *y, const double *x) {
+  const oracle_csr_op *op = (const oracle_csr_op *)ctx;
+  for (int64_t i = 0; i < op->n; ++i) {
+    double s = 0.0;
+    for (int64_t k = op->row_ptr[i]; k < op->row_ptr[i + 1]; ++k)
+      s = s + op->val[k] * x[op->col[k]];
+    y[i] = s;
+  }
+}
+
+/* Operator::Residual  Operator.hpp:95-99: mul(r, x); r <<= b - r. */
+static void op_residual(oracle_apply_fn apply, void *ctx, int64_t n, double *r,
+                        const double *b, const double *x) {
+  apply(ctx, r, x);
+  oracle_sub_from(n, r, b);
+}
+
+/* ------------------------------------------------------------------------ */
+/* Solvers.                                                                  */
+
+/* Public knobs of IterativeSolver, Solvers/Solver.hpp:66-72,158-159. */
+typedef struct oracle_params {
+  int64_t num_iterations;           /* default 2000 */
+  double absolute_error_tolerance;  /* default 1e-6 */
+  double relative_error_tolerance;  /* default 1e-6 */
+  int64_t num_inner_iterations;     /* GMRES restart, default 50 */
+} oracle_params;
+
+typedef struct oracle_result {
+  int64_t iterations;  /* IterativeSolver::iteration after solve()        */
+  double absolute_error, relative_error, initial_error;
+  int32_t converged;
+  int64_t num_applies; /* operator applications (init + iterations)       */
+} oracle_result;
+
+typedef struct solver_vt {
+  double (*init)(void *s, const double *x, const double *b);
+  double (*iterate)(void *s, double *x, const double *b);
+  void (*finalize)(void *s, double *x, const double *b);
+} solver_vt;
+
+typedef struct solver_base {
+  oracle_apply_fn apply;
+  void *op;
+  int64_t n;
+  int64_t iteration; /* IterativeSolver::iteration, Solver.hpp:66 */
+  int64_t applies;
+  double *history;   /* optional [num_iterations + 1] residual norms */
+} solver_base;
+
+static void op_mul(solver_base *s, double *y, const double *x) {
+  s->apply(s->op, y, x);
+  s->applies++;
+}
+
+/*
+ * IterativeSolver::solve   Solvers/Solver.hpp:116-147.
+ *  - initial_error = init(); absolute_error = initial_error;
+ *  - early exit iff abs_tol > 0 && abs_err < abs_tol (finalize, return true)
+ *  - for (iteration = 0; !converged && iteration < num_iterations; ++iteration)
+ *      abs = iterate(); rel = abs / initial;
+ *      converged |= abs_tol > 0 && abs < abs_tol;
+ *      converged |= rel_tol > 0 && rel < rel_tol;
+ *  - finalize; `iteration` ends as the number of iterate() calls.
+ */
+static void iterative_solve(solver_base *sb, const solver_vt *vt, void *s,
+                            double *x, const double *b, const oracle_params *p,
+                            oracle_result *res) {
+  sb->applies = 0;
+  const double initial_error = vt->init(s, x, b);
+  res->initial_error = initial_error;
+  res->absolute_error = initial_error;
+  res->relative_error = 0.0;
+  res->iterations = 0;
+  if (sb->history) sb->history[0] = initial_error;
+  if (p->absolute_error_tolerance > 0.0 &&
+      res->absolute_error < p->absolute_error_tolerance) {
+    if (vt->finalize) vt->finalize(s, x, b);
+    res->converged = 1;
+    res->num_applies = sb->applies;
+    return;
+  }
+  int converged = 0;
+  for (sb->iteration = 0; !converged && (sb->iteration < p->num_iterations);
+       ++sb->iteration) {
+    res->absolute_error = vt->iterate(s, x, b);
+    res->relative_error = res->absolute_error / initial_error;
+    if (sb->history) sb->history[sb->iteration + 1] = res->absolute_error;
+    converged |= (p->absolute_error_tolerance > 0.0) &&
+                 (res->absolute_error < p->absolute_error_tolerance);
+    converged |= (p->relative_error_tolerance > 0.0) &&
+                 (res->relative_error < p->relative_error_tolerance);
+  }
+  if (vt->finalize) vt->finalize(s, x, b);
+  res->iterations = sb->iteration;
+  res->converged = converged;
+  res->num_applies = sb->applies;
+}
+
+/* Field::assign(other, copy) ignores `copy` and value-initialises a new     */
+/* field: Feathers/Field.hpp:82-84.  calloc reproduces the zero fill.        */
+static double *new_vec(int64_t n) {
+  return (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double));
+}
+
+/* ---- CG: Solvers/SolverCg.hpp:47-128 (pre_op == nullptr branches) ------- */
+typedef struct cg_state {
+  solver_base b;
+  double gamma;
+  double *p, *r, *z;
+} cg_state;
+
+/* SolverCg.hpp:54-84 */
+static double cg_init(void *sv, const double *x, const double *b) {
+  cg_state *s = (cg_state *)sv;
+  const int64_t n = s->b.n;
+  s->p = new_vec(n), s->r = new_vec(n), s->z = new_vec(n); /* :57-59 */
+  s->b.applies++;
+  op_residual(s->b.apply, s->b.op, n, s->r, b, x);          /* :75 */
+  oracle_copy(n, s->p, s->r);                               /* :81 */
+  s->gamma = oracle_dot(n, s->r, s->r);                     /* :82 */
+  return sqrt(s->gamma);                                    /* :85 */
+}
+/* SolverCg.hpp:86-126 */
+static double cg_iterate(void *sv, double *x, const double *b) {
+  (void)b;
+  cg_state *s = (cg_state *)sv;
+  const int64_t n = s->b.n;
+  op_mul(&s->b, s->z, s->p);                                              /* :96 */
+  const double alpha = oracle_safe_divide(s->gamma, oracle_dot(n, s->p, s->z)); /* :97 */
+  oracle_axpy(n, x, alpha, s->p);                                         /* :98 */
+  oracle_axmy(n, s->r, alpha, s->z);                                      /* :99 */
+  const double gamma_bar = s->gamma;                                      /* :110 */
+  s->gamma = oracle_dot(n, s->r, s->r);                                   /* :115 */
+  const double beta = oracle_safe_divide(s->gamma, gamma_bar);            /* :122 */
+  oracle_xpay(n, s->p, s->r, beta);                                       /* :123 */
+  return sqrt(s->gamma);                                                  /* :125 */
+}
+
+ORACLE_API void oracle_solve_cg(oracle_apply_fn apply, void *op, int64_t n,
+                                double *x, const double *b,
+                                const oracle_params *p, oracle_result *res,
+                                double *history) {
+  cg_state s;
+  memset(&s, 0, sizeof s);
+  s.b.apply = apply, s.b.op = op, s.b.n = n, s.b.history = history;
+  const solver_vt vt = {cg_init, cg_iterate, NULL};
+  iterative_solve(&s.b, &vt, &s, x, b, p, res);
+  free(s.p), free(s.r), free(s.z);
+}
+
+/* ---- BiCGStab: Solvers/SolverBiCgStab.hpp:52-167 (no preconditioner) ---- */
+typedef struct bicg_state {
+  solver_base b;
+  double alpha, rho, omega;
+  double *p, *r, *rt, *t, *v;
+} bicg_state;
+
+/* SolverBiCgStab.hpp:59-91 */
+static double bicg_init(void *sv, const double *x, const double *b) {
+  bicg_state *s = (bicg_state *)sv;
+  const int64_t n = s->b.n;
+  s->p = new_vec(n), s->r = new_vec(n), s->rt = new_vec(n); /* :65-70 */
+  s->t = new_vec(n), s->v = new_vec(n);
+  s->alpha = s->omega = 0.0; /* members are uninitialised in the reference;
+                                they are written before first use (:139,:159) */
+  s->b.applies++;
+  op_residual(s->b.apply, s->b.op, n, s->r, b, x);          /* :82 */
+  oracle_copy(n, s->rt, s->r);                              /* :87 */
+  s->rho = oracle_dot(n, s->rt, s->r);                      /* :88 */
+  return sqrt(s->rho);                                      /* :90 */
+}
+/* SolverBiCgStab.hpp:93-165 */
+static double bicg_iterate(void *sv, double *x, const double *b) {
+  (void)b;
+  bicg_state *s = (bicg_state *)sv;
+  const int64_t n = s->b.n;
+  const int first_iteration = s->b.iteration == 0;                    /* :112 */
+  if (first_iteration) {
+    oracle_copy(n, s->p, s->r);                                       /* :114 */
+  } else {
+    const double rho_bar = s->rho;                                    /* :116-117 */
+    s->rho = oracle_dot(n, s->rt, s->r);
+    const double beta =
+        oracle_safe_divide(s->alpha * s->rho, s->omega * rho_bar);    /* :118 */
+    oracle_bicg_p(n, s->p, s->r, beta, s->omega, s->v);               /* :119 */
+  }
+  op_mul(&s->b, s->v, s->p);                                          /* :137 */
+  s->alpha = oracle_safe_divide(s->rho, oracle_dot(n, s->rt, s->v));  /* :139 */
+  oracle_axpy(n, x, s->alpha, s->p);                                  /* :140 */
+  oracle_axmy(n, s->r, s->alpha, s->v);                               /* :141 */
+  op_mul(&s->b, s->t, s->r);                                          /* :158 */
+  s->omega = oracle_safe_divide(oracle_dot(n, s->t, s->r),
+                                oracle_dot(n, s->t, s->t));           /* :159-160 */
+  oracle_axpy(n, x, s->omega, s->r);                                  /* :161 */
+  oracle_axmy(n, s->r, s->omega, s->t);                               /* :162 */
+  return oracle_norm2(n, s->r);                                       /* :164 */
+}
+
+ORACLE_API void oracle_solve_bicgstab(oracle_apply_fn apply, void *op,
+                                      int64_t n, double *x, const double *b,
+                                      const oracle_params *p,
+                                      oracle_result *res, double *history) {
+  bicg_state s;
+  memset(&s, 0, sizeof s);
+  s.b.apply = apply, s.b.op = op, s.b.n = n, s.b.history = history;
+  const solver_vt vt = {bicg_init, bicg_iterate, NULL};
+  iterative_solve(&s.b, &vt, &s, x, b, p, res);
+  free(s.p), free(s.r), free(s.rt), free(s.t), free(s.v);
+}
+
+/* ---- GMRES(m): Solvers/SolverGmres.hpp:41-255 (Flexible = false, no       */
+/* preconditioner) under InnerOuterIterativeSolver, Solver.hpp:154-259. ---- */
+typedef struct gmres_state {
+  solver_base b;
+  int64_t m;               /* num_inner_iterations */
+  int64_t inner_iteration; /* Solver.hpp:158 */
+  double *beta, *cs, *sn;  /* [m+1], [m], [m]          SolverGmres.hpp:45 */
+  double *H;               /* (m+1) x m, row-major     SolverGmres.hpp:46 */
+  double **q;              /* m+1 basis vectors        SolverGmres.hpp:47 */
+} gmres_state;
+
+#define H_(s, i, j) ((s)->H[(i) * (s)->m + (j)])
+
+/* outer_init :51-91 and inner_init :93-117 share this body. */
+static void gmres_start(gmres_state *s, const double *x, const double *b) {
+  const int64_t n = s->b.n;
+  s->b.applies++;
+  op_residual(s->b.apply, s->b.op, n, s->q[0], b, x); /* :82 / :110 */
+  s->beta[0] = oracle_norm2(n, s->q[0]);              /* :87 / :115 */
+  oracle_div_scalar(n, s->q[0], s->beta[0]);          /* :88 / :116 */
+}
+
+static double gmres_outer_init(void *sv, const double *x, const double *b) {
+  gmres_state *s = (gmres_state *)sv;
+  const int64_t m = s->m, n = s->b.n;
+  s->beta = (double *)calloc((size_t)m + 1, sizeof(double)); /* :56-58 */
+  s->cs = (double *)calloc((size_t)m, sizeof(double));
+  s->sn = (double *)calloc((size_t)m, sizeof(double));
+  s->H = (double *)calloc((size_t)((m + 1) * m), sizeof(double));
+  s->q = (double **)calloc((size_t)m + 1, sizeof(double *)); /* :60-61 */
+  for (int64_t i = 0; i <= m; ++i) s->q[i] = new_vec(n);
+  gmres_start(s, x, b);
+  return s->beta[0]; /* :90 */
+}
+
+/* inner_iterate :119-192 */
+static double gmres_inner_iterate(gmres_state *s) {
+  const int64_t n = s->b.n, k = s->inner_iteration;
+  op_mul(&s->b, s->q[k + 1], s->q[k]);                     /* :155 */
+  for (int64_t i = 0; i <= k; ++i) {                       /* :157-160 MGS */
+    H_(s, i, k) = oracle_dot(n, s->q[k + 1], s->q[i]);
+    oracle_axmy(n, s->q[k + 1], H_(s, i, k), s->q[i]);
+  }
+  H_(s, k + 1, k) = oracle_norm2(n, s->q[k + 1]);          /* :161 */
+  oracle_div_scalar(n, s->q[k + 1], H_(s, k + 1, k));      /* :162 */
+  for (int64_t i = 0; i < k; ++i) {                        /* :176-180 */
+    const double chi = s->cs[i] * H_(s, i, k) + s->sn[i] * H_(s, i + 1, k);
+    H_(s, i + 1, k) = -s->sn[i] * H_(s, i, k) + s->cs[i] * H_(s, i + 1, k);
+    H_(s, i, k) = chi;
+  }
+  double rr;
+  oracle_sym_ortho(H_(s, k, k), H_(s, k + 1, k), &s->cs[k], &s->sn[k], &rr); /* :181 */
+  H_(s, k, k) = s->cs[k] * H_(s, k, k) + s->sn[k] * H_(s, k + 1, k);  /* :182 */
+  H_(s, k + 1, k) = 0.0;                                              /* :183 */
+  s->beta[k + 1] = -s->sn[k] * s->beta[k];                            /* :189 */
+  s->beta[k] *= s->cs[k];
+  return fabs(s->beta[k + 1]);                                        /* :191 */
+}
+
+/* inner_finalize :194-249 (not right-preconditioned branch :233-236) */
+static void gmres_inner_finalize(gmres_state *s, double *x) {
+  const int64_t n = s->b.n, k = s->inner_iteration;
+  for (int64_t i = k; i >= 0; --i) {                        /* :207-212 */
+    for (int64_t j = i + 1; j <= k; ++j) s->beta[i] -= H_(s, i, j) * s->beta[j];
+    s->beta[i] /= H_(s, i, i);
+  }
+  for (int64_t i = 0; i <= k; ++i) oracle_axpy(n, x, s->beta[i], s->q[i]); /* :234-236 */
+}
+
+/* InnerOuterIterativeSolver::iterate  Solver.hpp:236-248 */
+static double gmres_iterate(void *sv, double *x, const double *b) {
+  gmres_state *s = (gmres_state *)sv;
+  s->inner_iteration = s->b.iteration % s->m;               /* :239 */
+  if (s->inner_iteration == 0) {                            /* :240-242 */
+    /* NB: on the very first iteration this recomputes what outer_init just
+       did (the reference has the same duplication, SolverGmres.hpp:66-67). */
+    gmres_start(s, x, b);
+  }
+  const double rn = gmres_inner_iterate(s);                 /* :243 */
+  if (s->inner_iteration == s->m - 1) gmres_inner_finalize(s, x); /* :244-246 */
+  return rn;
+}
+/* InnerOuterIterativeSolver::finalize  Solver.hpp:250-257 */
+static void gmres_finalize(void *sv, double *x, const double *b) {
+  (void)b;
+  gmres_state *s = (gmres_state *)sv;
+  if (s->inner_iteration != s->m - 1) gmres_inner_finalize(s, x);
+}
+
+ORACLE_API void oracle_solve_gmres(oracle_apply_fn apply, void *op, int64_t n,
+                                   double *x, const double *b,
+                                   const oracle_params *p, oracle_result *res,
+                                   double *history) {
+  gmres_state s;
+  memset(&s, 0, sizeof s);
+  s.b.apply = apply, s.b.op = op, s.b.n = n, s.b.history = history;
+  s.m = p->num_inner_iterations;
+  const solver_vt vt = {gmres_outer_init, gmres_iterate, gmres_finalize};
+  iterative_solve(&s.b, &vt, &s, x, b, p, res);
+  for (int64_t i = 0; i <= s.m; ++i) free(s.q[i]);
+  free(s.q), free(s.beta), free(s.cs), free(s.sn), free(s.H);
+}
+
+ORACLE_API int oracle_abi_version(void) { return 1; }

@@ -1,0 +1,140 @@
+"""Pin the CPU oracle: the reference's own unit-test known answers (BLAS-1) and the reference
+outputs recorded in BASELINE.md section 2 (solver loops + stencil)."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from stormruler_amd import mesh
+
+
+def _cpu_has_fma() -> bool:
+    try:
+        with open("/proc/cpuinfo") as f:
+            flags = f.read()
+        return " fma " in flags and " avx2 " in flags
+    except OSError:
+        return False
+
+
+def test_real_matrix_reductions(golden):
+    k = golden["unit_tests"]["real_matrix"]
+    m = np.array(k["mat"])
+    assert oracle.vsum(m) == k["sum"]
+    assert oracle.norm1(m) == k["norm_1"]
+    assert oracle.norm_inf(m) == k["norm_inf"]
+    # CHECK_NEAR = doctest::Approx(expected).epsilon(eps)  (tests/unit/_UnitTests.hpp)
+    assert abs(oracle.norm2(m) - k["norm_2"]) <= k["norm_2_eps"] * abs(k["norm_2"])
+
+
+def test_dot_product(golden):
+    k = golden["unit_tests"]["dot_product"]
+    assert oracle.dot(k["mat1"], k["mat2"]) == k["dot"]
+    assert oracle.dot(k["mat2"], k["mat1"]) == k["dot"]
+
+
+def test_axpy_type_expression(golden):
+    k = golden["unit_tests"]["expr_1"]
+    out = oracle.expr1(k["mat1"], k["scale"], k["mat2"], k["mat3"])
+    assert np.array_equal(out, np.array(k["result"]))
+
+
+def test_normalize_and_safe_divide(golden):
+    k = golden["unit_tests"]["normalize"]
+    m = np.array(k["mat"])
+    assert oracle.norm2(m) == k["norm"]
+    # normalize(0) == 0 pins safe_inverse / safe_divide (Crow/MathUtils.hpp:49-58)
+    assert oracle.safe_divide(1.0, 0.0) == 0.0
+    assert oracle.safe_divide(0.0, 0.0) == 0.0
+    assert oracle.safe_divide(3.0, 2.0) == 1.5
+
+
+def test_sym_ortho():
+    cs, sn, rr = oracle.sym_ortho(3.0, 4.0)
+    assert (cs, sn, rr) == (0.6, 0.8, 5.0)
+    assert oracle.sym_ortho(0.0, 0.0) == (1.0, 0.0, 0.0)
+
+
+def test_sequential_sum_order():
+    # reduce() is a strict left-to-right sum (MatrixAlgorithms.hpp:191-205): 1e16 + 1 + 1 ... loses
+    # every 1; a tree sum would not.
+    a = np.array([1e16] + [1.0] * 8)
+    assert oracle.dot(a, np.ones_like(a)) == 1e16
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2, 3])
+def test_baseline_md_recorded_reference_outputs(golden, idx):
+    case = golden["baseline_md_probe"]["cases"][idx]
+    if not _cpu_has_fma():
+        pytest.skip("recorded values were produced with FMA contraction; host has no FMA")
+    n = case["n"]
+    g = mesh.structured_box(n)
+    g.validate()
+    op = oracle.StencilOperator(g, alpha=-1.0, beta=0.0, variant="fma")
+    r = oracle.solve(case["solver"], op, np.ones(g.n_cells), variant="fma",
+                     num_inner_iterations=case.get("restart", 50))
+    assert r.converged
+    assert r.iterations == case["iterations"]
+    assert r.num_applies == case["applies"]
+    c = (n // 2 * n + n // 2) * n + n // 2
+    # recorded to 7 / 13 significant digits
+    assert abs(r.relative_error - case["rel"]) <= 5e-7 * case["rel"]
+    assert abs(r.x[c] - case["x_centre"]) <= 5e-13 * abs(case["x_centre"])
+
+
+@pytest.mark.parametrize("solver,restart", [("cg", 50), ("bicgstab", 50), ("gmres", 30)])
+def test_strict_build_agrees_with_recorded_iteration_counts(golden, solver, restart):
+    """The -ffp-contract=off build (the parity checker) gives the same iteration counts."""
+    want = {c["solver"]: c for c in golden["baseline_md_probe"]["cases"] if c["n"] == 64 or c["solver"] == "cg"}
+    n = 32 if solver == "cg" else 64
+    if solver != "cg" and restart == 30:
+        n = 64
+    g = mesh.structured_box(n)
+    op = oracle.StencilOperator(g, -1.0, 0.0)
+    r = oracle.solve(solver, op, np.ones(g.n_cells), num_inner_iterations=restart)
+    ref = [c for c in golden["baseline_md_probe"]["cases"] if c["solver"] == solver and c["n"] == n][0]
+    assert r.iterations == ref["iterations"] and r.num_applies == ref["applies"]
+    c = (n // 2 * n + n // 2) * n + n // 2
+    assert abs(r.x[c] - ref["x_centre"]) <= 1e-6 * abs(ref["x_centre"])
+
+
+def test_1d_poisson_closed_form():
+    """-u'' = 1 on 64 points, Dirichlet via the 2/-1 stencil: x_31 = 528 exactly (SURVEY 8c KAT)."""
+    import scipy.sparse as sp
+
+    n = 64
+    a = sp.diags([-np.ones(n - 1), 2 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1]).tocsr()
+    op = oracle.CsrOperator(a)
+    for kind in ("cg", "gmres", "bicgstab"):
+        r = oracle.solve(kind, op, np.ones(n), abs_tol=1e-10, rel_tol=1e-12)
+        assert r.converged
+        assert abs(r.x[31] - 528.0) < 1e-6, (kind, r.x[31])
+        if kind in ("cg", "gmres"):
+            assert r.iterations == 32
+
+
+def test_face_loop_matches_assembled_matrix():
+    g = mesh.structured_box(6, 5, 4)
+    x = np.sin(0.37 * np.arange(g.n_cells))
+    for alpha, beta in ((-1.0, 0.0), (-1e-2, 1.0)):
+        y = oracle.StencilOperator(g, alpha, beta).apply(x)
+        a = mesh.assemble_csr(g, alpha, beta)
+        assert np.allclose(a @ x, y, rtol=0, atol=1e-12 * np.abs(y).max())
+    # diagonal (6 + #walls)/h^2, off-diagonals -1/h^2 on the cube
+    gc = mesh.structured_box(4)
+    a = mesh.assemble_csr(gc, -1.0, 0.0).toarray()
+    assert np.isclose(a[0, 0], 9 * 16) and np.isclose(a[0, 1], -16)
+    i = (1 * 4 + 1) * 4 + 1
+    assert np.isclose(a[i, i], 6 * 16)
+
+
+def test_convergence_rule_edges():
+    """Solver.hpp:124-140: early exit only on abs tol; tolerances <= 0 disable a test."""
+    g = mesh.structured_box(8)
+    op = oracle.StencilOperator(g, -1.0, 0.0)
+    b = np.ones(g.n_cells)
+    r = oracle.solve("cg", op, b, num_iterations=7, abs_tol=0.0, rel_tol=0.0)
+    assert r.iterations == 7 and not r.converged
+    r = oracle.solve("cg", op, b * 1e-9)  # initial error < abs tol -> 0 iterations, converged
+    assert r.iterations == 0 and r.converged and r.num_applies == 1
+    r = oracle.solve("cg", op, b, abs_tol=0.0, rel_tol=1e-3)
+    assert r.converged and r.relative_error < 1e-3
