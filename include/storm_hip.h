@@ -1,0 +1,228 @@
+/*
+ * storm_hip.h -- C ABI of the MI355X-native Krylov backend for StormRuler.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, opaque
+ * handles, `int` status returns, no exceptions, no torch / C++ types.  Every
+ * entry point names the reference interface it stands in for (paths relative
+ * to the reference root).  The C++ header `storm_hip/Storm.hpp` maps the
+ * reference's `Storm::Operator / Vector / Solver` template interface onto
+ * these calls; INTEGRATION.md shows the binding a StormRuler maintainer adds.
+ *
+ * Conventions
+ *  - Status: 0 = ok; negative = error (STORM_HIP_E_*); text of the last error
+ *    of the calling thread via storm_hip_last_error().
+ *  - Ownership: the caller owns every handle it creates and destroys it; the
+ *    library copies host arrays passed to *_create_* (the caller may free them
+ *    on return) and never frees caller memory.
+ *  - Threading: as the reference (single-threaded, stateful solver objects,
+ *    Solvers/Solver.hpp:66-76) -- one host thread per context; a context owns
+ *    its HIP streams; calls on one context are not re-entrant.
+ *  - Multi-GPU: one process (context) per GPU.  Vectors hold `n_owned` rows
+ *    followed by `n_halo` ghost rows; reductions are summed over all ranks.
+ *  - All arithmetic is fp64 (`real_t = double`, Crow/Base/Types.hpp:38);
+ *    indices cross the ABI as int64 (the reference's Index wraps size_t,
+ *    Utils/Index.hpp:41) and are narrowed to int32 on the device after a
+ *    range check.
+ */
+#ifndef STORM_HIP_H_
+#define STORM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* every declaration below is an exported symbol of libstorm_hip.so */
+#pragma GCC visibility push(default)
+
+#define STORM_HIP_ABI_VERSION 1
+
+enum {
+  STORM_HIP_OK = 0,
+  STORM_HIP_E_INVALID = -1,   /* bad argument (null handle, size mismatch, index out of range) */
+  STORM_HIP_E_HIP = -2,       /* a HIP runtime call failed */
+  STORM_HIP_E_NO_DEVICE = -3, /* no usable gfx950 device */
+  STORM_HIP_E_COMM = -4,      /* RCCL failure / communicator misuse */
+  STORM_HIP_E_ALLOC = -5,
+  STORM_HIP_E_UNSUPPORTED = -6
+};
+
+typedef struct storm_hip_ctx storm_hip_ctx;
+typedef struct storm_hip_vec storm_hip_vec;
+typedef struct storm_hip_op storm_hip_op;
+
+int storm_hip_abi_version(void);
+const char *storm_hip_last_error(void);
+
+/* ---- context -------------------------------------------------------------
+ * Nothing in the reference (it has no device, SURVEY.md headline fact 1). */
+int storm_hip_ctx_create(int device_id, storm_hip_ctx **out);
+int storm_hip_ctx_destroy(storm_hip_ctx *ctx);
+int storm_hip_ctx_sync(storm_hip_ctx *ctx);
+/* name: >= 64 bytes. */
+int storm_hip_ctx_info(storm_hip_ctx *ctx, char *name, int name_len, int *num_cus,
+                       int64_t *total_mem_bytes);
+
+/* HIP-event stopwatch on the context's compute stream (the stream every
+ * kernel of this library is launched on). */
+int storm_hip_timer_start(storm_hip_ctx *ctx);
+int storm_hip_timer_stop(storm_hip_ctx *ctx, float *elapsed_ms);
+
+/* ---- communicator (RCCL over xGMI) -------------------------
+ * rank 0 fills a 128-byte id, the host distributes it (torch.distributed /
+ * MPI / a file), every rank calls comm_init.  n_ranks == 1 needs neither. */
+int storm_hip_comm_unique_id(void *id128);
+int storm_hip_ctx_comm_init(storm_hip_ctx *ctx, const void *id128, int n_ranks, int rank);
+int storm_hip_ctx_comm_size(storm_hip_ctx *ctx, int *n_ranks, int *rank);
+
+/* ---- vectors -------------------------------------------------------------
+ * `Feathers::Field` as the solver `Vector` (Feathers/Field.hpp:60-114):
+ * contiguous doubles, one per cell.  create == `assign(other, false)`, which
+ * value-initialises (zero-fills) a new field (Field.hpp:82-84). */
+int storm_hip_vec_create(storm_hip_ctx *ctx, int64_t n_owned, int64_t n_halo, storm_hip_vec **out);
+int storm_hip_vec_create_like(const storm_hip_vec *other, storm_hip_vec **out);
+int storm_hip_vec_destroy(storm_hip_vec *v);
+int storm_hip_vec_size(const storm_hip_vec *v, int64_t *n_owned, int64_t *n_halo);
+int storm_hip_vec_upload(storm_hip_vec *v, const double *host, int64_t n);
+int storm_hip_vec_download(const storm_hip_vec *v, double *host, int64_t n);
+/* Raw device pointer (n_owned + n_halo doubles), for zero-copy interop. */
+int storm_hip_vec_device_ptr(storm_hip_vec *v, void **dev_ptr);
+
+/* ---- BLAS-1 --------------------------------------------------------------
+ * One call per Bittern expression statement the solver bodies execute
+ * (overload census); each is one kernel over the owned rows.
+ * Reference loops: Bittern/MatrixAlgorithms.hpp:58-81 (matrix_for_each),
+ * :162-205 (reduce).  Reductions return the sum over all ranks. */
+int storm_hip_fill(storm_hip_vec *y, double value);                        /* fill_with(y, v)   Solver.hpp:281 */
+int storm_hip_copy(storm_hip_vec *y, const storm_hip_vec *x);              /* y <<= x           MatrixAlgorithms.hpp:120-124 */
+int storm_hip_scale(storm_hip_vec *y, double s);                           /* y *= s            MatrixTarget.hpp:96-99 */
+int storm_hip_div_scalar(storm_hip_vec *y, double s);                      /* y /= s            MatrixTarget.hpp:101-105, SolverGmres.hpp:88 */
+int storm_hip_axpy(storm_hip_vec *y, double a, const storm_hip_vec *x);    /* y += a*x (a<0: y -= |a|*x)  SolverCg.hpp:98-99 */
+int storm_hip_xpay(storm_hip_vec *y, const storm_hip_vec *x, double b);    /* y <<= x + b*y     SolverCg.hpp:123 */
+/* y <<= a*x + b*z  (covers r <<= b - r, Operator.hpp:98; y may alias x or z) */
+int storm_hip_axpbz(storm_hip_vec *y, double a, const storm_hip_vec *x, double b, const storm_hip_vec *z);
+/* p <<= r + beta*(p - omega*v)   SolverBiCgStab.hpp:119 */
+int storm_hip_bicgstab_p(storm_hip_vec *p, const storm_hip_vec *r, double beta, double omega,
+                         const storm_hip_vec *v);
+/* dot_product(a, b)  MatrixAlgorithms.hpp:310-317;  norm_2(a)  :262-270 */
+int storm_hip_dot(const storm_hip_vec *a, const storm_hip_vec *b, double *result);
+int storm_hip_norm2(const storm_hip_vec *a, double *result);
+/* out[i] = <a, bs[i]>, i < k: the Arnoldi multi-dot (SolverGmres.hpp:157-160 batched). */
+int storm_hip_multi_dot(const storm_hip_vec *a, const storm_hip_vec *const *bs, int k, double *out);
+/* y += sum_i coefs[i] * xs[i]  (SolverGmres.hpp:233-236 batched) */
+int storm_hip_multi_axpy(storm_hip_vec *y, const double *coefs, const storm_hip_vec *const *xs, int k);
+
+/* ---- operators -----------------------------------------------------------
+ * The matrix-free FVM stencil `stormDivGrad` (source_apps/playground/
+ * Playground.cpp:115-131) precomputed into gather form.  Applying an operator
+ * computes   y = beta * x + alpha * M(x)   on the owned rows, where for the
+ * face-graph constructors
+ *     M(x)_i = sum_{faces f of i} w_if * (x_other(f) - x_i) + diag_extra_i * x_i .
+ * `alpha = -1, beta = 0` is the Poisson operator -L; `alpha = -kappa, beta = 1`
+ * the Helmholtz operator of the playground lambda (Playground.cpp:153-167).
+ *
+ * Row i's entries are summed in face order, the order in which the
+ * reference's face loop accumulates into u[i].
+ */
+
+/* Diffusion operator from the mesh quantities the reference reads:
+ *   inner/outer[F]   face -> cells (FaceView::inner_cell/outer_cell, Mallard/Mesh.hpp:269-280),
+ *                    local ids in [0, n_owned + n_halo);
+ *   coef[F]          A_f / |x_outer - x_inner|   (Playground.cpp:126-128);
+ *   b_cell/b_coef[B] Dirichlet boundary faces: owning cell and A_b / |x_face - x_cell|
+ *                    (ghost value 0 at the face; loop shape of Feathers/ConvectionScheme.hpp:95-106);
+ *   volume[n_owned + n_halo]  cell volumes (CellView::volume, Mallard/Mesh.hpp:304).
+ * w_if = coef_f / volume_i;  diag_extra_i = -sum_b b_coef_b / volume_i. */
+int storm_hip_op_create_from_faces(storm_hip_ctx *ctx, int64_t n_owned, int64_t n_halo,
+                                   int64_t n_faces, const int64_t *inner, const int64_t *outer,
+                                   const double *coef, int64_t n_bfaces, const int64_t *b_cell,
+                                   const double *b_coef, const double *volume, storm_hip_op **out);
+
+/* General (non-symmetric) face-graph operator: row inner[f] gets weight
+ * w_inner[f] on (x_outer - x_inner), row outer[f] gets w_outer[f] on
+ * (x_inner - x_outer); diag_extra[n_owned] may be NULL (zeros).  This is the
+ * form the upwind convection face loop (Feathers/ConvectionScheme.hpp:80-107)
+ * lowers to. */
+int storm_hip_op_create_from_face_weights(storm_hip_ctx *ctx, int64_t n_owned, int64_t n_halo,
+                                          int64_t n_faces, const int64_t *inner,
+                                          const int64_t *outer, const double *w_inner,
+                                          const double *w_outer, const double *diag_extra,
+                                          storm_hip_op **out);
+
+/* Assembled CSR rows (n_rows owned rows, columns in [0, n_rows + n_halo)). */
+int storm_hip_op_create_csr(storm_hip_ctx *ctx, int64_t n_rows, int64_t n_halo,
+                            const int64_t *row_ptr, const int64_t *col, const double *val,
+                            storm_hip_op **out);
+
+/* Build knobs, set before create (0 = library default):
+ *   ell_cap: rows longer than this spill their remaining entries to the CSR tail. */
+int storm_hip_ctx_set_option(storm_hip_ctx *ctx, const char *key, int64_t value);
+
+/* Halo plan of a row-partitioned operator.  For neighbour q
+ * (rank nbr_rank[q]) the owned rows send_idx[send_ptr[q] .. send_ptr[q+1]) are
+ * sent, and the halo rows n_owned + [recv_ptr[q] .. recv_ptr[q+1]) received;
+ * both sides order a segment by global cell id. */
+int storm_hip_op_set_halo(storm_hip_op *op, int n_nbrs, const int32_t *nbr_rank,
+                          const int64_t *send_ptr, const int64_t *send_idx,
+                          const int64_t *recv_ptr);
+
+/* `Operator::mul(y, x)`  Solvers/Operator.hpp:74:  y = beta*x + alpha*M(x).
+ * Exchanges x's halo first when a halo plan is set.  x and y must not alias. */
+int storm_hip_op_apply(const storm_hip_op *op, double alpha, double beta, const storm_hip_vec *x,
+                       storm_hip_vec *y);
+
+typedef struct storm_hip_op_stats {
+  int64_t n_rows, n_cols, nnz_offdiag;  /* off-diagonal entries (2F for a face graph) */
+  int64_t ell_slots;                    /* stored ELL slots incl. padding */
+  int64_t tail_nnz, tail_rows;          /* CSR tail */
+  int64_t n_slices, max_row_len;
+  int64_t n_interior_slices;            /* slices whose rows reference no halo column */
+  int64_t device_bytes;
+} storm_hip_op_stats;
+int storm_hip_op_get_stats(const storm_hip_op *op, storm_hip_op_stats *stats);
+int storm_hip_op_destroy(storm_hip_op *op);
+
+/* ---- whole-solver entry points --------------------------------------------
+ * `solve<XSolver>(x, b, op)`  Solvers/Solver.hpp:261-265 for the operator
+ * A = beta*I + alpha*M, with the reference's public knobs (Solver.hpp:66-72,
+ * 158-159) and exactly its convergence rule (Solver.hpp:116-147): early exit
+ * iff abs_tol > 0 && |r0| < abs_tol; then per iteration converged iff
+ * (abs_tol > 0 && abs < abs_tol) || (rel_tol > 0 && abs/|r0| < rel_tol);
+ * `iterations` = number of iterate() calls.  The loops run device-resident:
+ * scalars (alpha, beta, rho, omega, Givens) never visit the host, and the
+ * host polls the device's `done` flag `check_lag` iterations behind. */
+typedef struct storm_hip_solver_params {
+  int64_t num_iterations;           /* default 2000  (Solver.hpp:67) */
+  double absolute_error_tolerance;  /* default 1e-6  (Solver.hpp:71) */
+  double relative_error_tolerance;  /* default 1e-6  (Solver.hpp:72) */
+  int64_t num_inner_iterations;     /* GMRES restart m, default 50 (Solver.hpp:159) */
+  int32_t check_lag;                /* 0 = default (4) */
+  int32_t gram_schmidt;             /* GMRES: 0 = modified (reference, SolverGmres.hpp:157-160), 1 = classical x2 */
+} storm_hip_solver_params;
+
+typedef struct storm_hip_solver_result {
+  int64_t iterations;
+  double absolute_error, relative_error, initial_error;
+  int32_t converged;
+  int64_t num_applies;
+} storm_hip_solver_result;
+
+void storm_hip_solver_params_default(storm_hip_solver_params *p);
+
+/* history: NULL or room for num_iterations + 1 residual norms (entry 0 = initial). */
+int storm_hip_solve_cg(const storm_hip_op *op, double alpha, double beta, const storm_hip_vec *b,
+                       storm_hip_vec *x, const storm_hip_solver_params *params,
+                       storm_hip_solver_result *result, double *history);       /* SolverCg.hpp:47-128 */
+int storm_hip_solve_bicgstab(const storm_hip_op *op, double alpha, double beta, const storm_hip_vec *b,
+                             storm_hip_vec *x, const storm_hip_solver_params *params,
+                             storm_hip_solver_result *result, double *history); /* SolverBiCgStab.hpp:52-167 */
+int storm_hip_solve_gmres(const storm_hip_op *op, double alpha, double beta, const storm_hip_vec *b,
+                          storm_hip_vec *x, const storm_hip_solver_params *params,
+                          storm_hip_solver_result *result, double *history);    /* SolverGmres.hpp:41-255 */
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif /* STORM_HIP_H_ */

@@ -1,0 +1,120 @@
+"""ctypes binding of libstorm_hip.so -- the C ABI declared in include/storm_hip.h.
+
+There is no CPU fallback: if the HIP library is missing or fails to load, importing this
+module raises.  (``torch`` is imported first, when present, so that the process uses one HIP
+runtime -- torch's bundled libamdhip64.so.7 has the same SONAME as ROCm's.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+try:  # plumbing only: fixes the HIP runtime load order, provides torch.distributed
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - torch is optional for single-GPU use
+    torch = None
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstorm_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(or `make -C stormruler_amd/csrc`).  stormruler_amd has no CPU fallback.")
+
+lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+f64p = C.POINTER(C.c_double)
+i64p = C.POINTER(C.c_int64)
+i32p = C.POINTER(C.c_int32)
+vp = C.c_void_p
+
+
+class SolverParams(C.Structure):
+    _fields_ = [("num_iterations", C.c_int64), ("absolute_error_tolerance", C.c_double),
+                ("relative_error_tolerance", C.c_double), ("num_inner_iterations", C.c_int64),
+                ("check_lag", C.c_int32), ("gram_schmidt", C.c_int32)]
+
+
+class SolverResult(C.Structure):
+    _fields_ = [("iterations", C.c_int64), ("absolute_error", C.c_double), ("relative_error", C.c_double),
+                ("initial_error", C.c_double), ("converged", C.c_int32), ("num_applies", C.c_int64)]
+
+
+class OpStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("n_rows", "n_cols", "nnz_offdiag", "ell_slots", "tail_nnz",
+                                          "tail_rows", "n_slices", "max_row_len", "n_interior_slices",
+                                          "device_bytes")]
+
+
+# name -> (restype, argtypes); every symbol include/storm_hip.h declares.
+SIGNATURES = {
+    "storm_hip_abi_version": (C.c_int, []),
+    "storm_hip_last_error": (C.c_char_p, []),
+    "storm_hip_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "storm_hip_ctx_destroy": (C.c_int, [vp]),
+    "storm_hip_ctx_sync": (C.c_int, [vp]),
+    "storm_hip_ctx_info": (C.c_int, [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), i64p]),
+    "storm_hip_ctx_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
+    "storm_hip_timer_start": (C.c_int, [vp]),
+    "storm_hip_timer_stop": (C.c_int, [vp, C.POINTER(C.c_float)]),
+    "storm_hip_comm_unique_id": (C.c_int, [vp]),
+    "storm_hip_ctx_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int]),
+    "storm_hip_ctx_comm_size": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "storm_hip_vec_create": (C.c_int, [vp, C.c_int64, C.c_int64, C.POINTER(vp)]),
+    "storm_hip_vec_create_like": (C.c_int, [vp, C.POINTER(vp)]),
+    "storm_hip_vec_destroy": (C.c_int, [vp]),
+    "storm_hip_vec_size": (C.c_int, [vp, i64p, i64p]),
+    "storm_hip_vec_upload": (C.c_int, [vp, f64p, C.c_int64]),
+    "storm_hip_vec_download": (C.c_int, [vp, f64p, C.c_int64]),
+    "storm_hip_vec_device_ptr": (C.c_int, [vp, C.POINTER(vp)]),
+    "storm_hip_fill": (C.c_int, [vp, C.c_double]),
+    "storm_hip_copy": (C.c_int, [vp, vp]),
+    "storm_hip_scale": (C.c_int, [vp, C.c_double]),
+    "storm_hip_div_scalar": (C.c_int, [vp, C.c_double]),
+    "storm_hip_axpy": (C.c_int, [vp, C.c_double, vp]),
+    "storm_hip_xpay": (C.c_int, [vp, vp, C.c_double]),
+    "storm_hip_axpbz": (C.c_int, [vp, C.c_double, vp, C.c_double, vp]),
+    "storm_hip_bicgstab_p": (C.c_int, [vp, vp, C.c_double, C.c_double, vp]),
+    "storm_hip_dot": (C.c_int, [vp, vp, f64p]),
+    "storm_hip_norm2": (C.c_int, [vp, f64p]),
+    "storm_hip_multi_dot": (C.c_int, [vp, C.POINTER(vp), C.c_int, f64p]),
+    "storm_hip_multi_axpy": (C.c_int, [vp, f64p, C.POINTER(vp), C.c_int]),
+    "storm_hip_op_create_from_faces": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int64, i64p, i64p, f64p,
+                                                 C.c_int64, i64p, f64p, f64p, C.POINTER(vp)]),
+    "storm_hip_op_create_from_face_weights": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int64, i64p, i64p,
+                                                        f64p, f64p, f64p, C.POINTER(vp)]),
+    "storm_hip_op_create_csr": (C.c_int, [vp, C.c_int64, C.c_int64, i64p, i64p, f64p, C.POINTER(vp)]),
+    "storm_hip_op_set_halo": (C.c_int, [vp, C.c_int, i32p, i64p, i64p, i64p]),
+    "storm_hip_op_apply": (C.c_int, [vp, C.c_double, C.c_double, vp, vp]),
+    "storm_hip_op_get_stats": (C.c_int, [vp, C.POINTER(OpStats)]),
+    "storm_hip_op_destroy": (C.c_int, [vp]),
+    "storm_hip_solver_params_default": (None, [C.POINTER(SolverParams)]),
+    "storm_hip_solve_cg": (C.c_int, [vp, C.c_double, C.c_double, vp, vp, C.POINTER(SolverParams),
+                                     C.POINTER(SolverResult), f64p]),
+    "storm_hip_solve_bicgstab": (C.c_int, [vp, C.c_double, C.c_double, vp, vp, C.POINTER(SolverParams),
+                                           C.POINTER(SolverResult), f64p]),
+    "storm_hip_solve_gmres": (C.c_int, [vp, C.c_double, C.c_double, vp, vp, C.POINTER(SolverParams),
+                                        C.POINTER(SolverResult), f64p]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here == the library does not export the symbol
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+if lib.storm_hip_abi_version() != 1:
+    raise ImportError("libstorm_hip.so ABI version mismatch")
+
+
+class StormHipError(RuntimeError):
+    """A nonzero C-ABI status (the C++ adapter throws std::runtime_error the same way)."""
+
+    def __init__(self, status: int, what: str):
+        super().__init__(f"storm_hip status {status}: {what}")
+        self.status = status
+
+
+def check(status: int) -> None:
+    if status != 0:
+        raise StormHipError(status, (lib.storm_hip_last_error() or b"").decode(errors="replace"))

@@ -1,0 +1,732 @@
+"""Host-side mirror of the reference's Operator / Vector / Solver interface over the C ABI.
+
+Same names, argument meaning and error behaviour as the reference so tests read like code
+written against ``Storm::``:
+
+* ``DeviceVector``           <- ``Feathers::Field`` as the solver ``Vector`` (Feathers/Field.hpp:60-114)
+* ``Operator`` / ``FunctionalOperator`` / ``make_operator`` / ``make_symmetric_operator``
+                             <- Solvers/Operator.hpp:66-200
+* ``IterativeSolver`` / ``InnerOuterIterativeSolver`` / ``CgSolver`` / ``BiCgStabSolver`` / ``GmresSolver``
+  / ``solve``                <- Solvers/Solver.hpp:43-292, SolverCg.hpp, SolverBiCgStab.hpp, SolverGmres.hpp
+* ``dot_product`` / ``norm_2`` / ``fill_with``   <- Bittern/MatrixAlgorithms.hpp:262-317
+
+Every vector statement a solver body executes (``x += alpha * p``, ``p <<= r + beta * p`` ...)
+lowers to exactly one C-ABI call; an expression form without a kernel raises instead of
+falling back to a host loop.  With a :class:`HipStencilOperator` and no preconditioner the
+solver classes hand the whole solve to the device-resident entry points
+(``storm_hip_solve_*``); with any other ``Operator`` (e.g. a Python lambda through
+``make_operator``) they run the reference's statement sequence over the BLAS-1 calls.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+from .mesh import FaceGraph, face_coefficients
+
+real_t = float
+
+# ---------------------------------------------------------------------------------------------
+
+
+class Context:
+    """One GPU, its streams and reduction workspace (one per process / rank)."""
+
+    def __init__(self, device: int = 0):
+        h = C.c_void_p()
+        check(lib.storm_hip_ctx_create(device, C.byref(h)))
+        self._h = h
+        self.n_ranks, self.rank = 1, 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.storm_hip_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(lib.storm_hip_ctx_sync(self._h))
+
+    def info(self):
+        name = C.create_string_buffer(128)
+        cus, mem = C.c_int(), C.c_int64()
+        check(lib.storm_hip_ctx_info(self._h, name, 128, C.byref(cus), C.byref(mem)))
+        return {"name": name.value.decode(), "num_cus": cus.value, "total_mem": mem.value}
+
+    def set_option(self, key: str, value: int):
+        check(lib.storm_hip_ctx_set_option(self._h, key.encode(), int(value)))
+
+    def timer_start(self):
+        check(lib.storm_hip_timer_start(self._h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        check(lib.storm_hip_timer_stop(self._h, C.byref(ms)))
+        return ms.value
+
+    # -- multi-GPU ---------------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        check(lib.storm_hip_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id: Optional[bytes], n_ranks: int, rank: int):
+        buf = C.create_string_buffer(unique_id, 128) if unique_id is not None else None
+        check(lib.storm_hip_ctx_comm_init(self._h, buf, n_ranks, rank))
+        self.n_ranks, self.rank = n_ranks, rank
+
+
+# ---------------------------------------------------------------------------------------------
+# Expression nodes (the build's counterparts of Bittern's lazy MapMatrixView nodes,
+# Bittern/MatrixMath.hpp:44-105,247-285): just enough structure for one kernel per statement.
+
+
+class _Scaled:  # a * v
+    def __init__(self, a: float, v: "DeviceVector"):
+        self.a, self.v = float(a), v
+
+
+class _Lin2:  # a*x + b*z
+    def __init__(self, a, x, b, z):
+        self.a, self.x, self.b, self.z = float(a), x, float(b), z
+
+    def __rmul__(self, s):
+        return _ScaledLin2(float(s), self)
+
+
+class _ScaledLin2:  # s * (a*x + b*z)
+    def __init__(self, s, lin):
+        self.s, self.lin = s, lin
+
+
+class _Lin3:  # r + s * (a*x + b*z)
+    def __init__(self, r, s, lin):
+        self.r, self.s, self.lin = r, s, lin
+
+
+class DeviceVector:
+    """N doubles in HBM (+ halo tail); the solver ``Vector`` (concept legacy_vector_like,
+    Solvers/Operator.hpp:39-45)."""
+
+    def __init__(self, ctx: Optional[Context] = None, n_owned: int = 0, n_halo: int = 0):
+        self.ctx = ctx
+        self._h = None
+        if ctx is not None:
+            h = C.c_void_p()
+            check(lib.storm_hip_vec_create(ctx._h, n_owned, n_halo, C.byref(h)))
+            self._h = h
+        self.n_owned, self.n_halo = n_owned, n_halo
+
+    # Field::assign(other, copy): allocate like `other`, zero-initialised; `copy` is ignored by the
+    # reference (Feathers/Field.hpp:82-84) and therefore here.
+    def assign(self, other: "DeviceVector", copy: bool = True) -> None:
+        self._free()
+        h = C.c_void_p()
+        check(lib.storm_hip_vec_create_like(other._h, C.byref(h)))
+        self._h, self.ctx = h, other.ctx
+        self.n_owned, self.n_halo = other.n_owned, other.n_halo
+
+    def shape(self):
+        return (self.n_owned, 1)  # Field::shape() = {N, NumVars}, Field.hpp:77-79
+
+    def _free(self):
+        if getattr(self, "_h", None):
+            lib.storm_hip_vec_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self._free()
+        except Exception:
+            pass
+
+    @classmethod
+    def from_numpy(cls, ctx: Context, a: np.ndarray, n_halo: int = 0) -> "DeviceVector":
+        a = np.ascontiguousarray(a, np.float64)
+        v = cls(ctx, a.size, n_halo)
+        check(lib.storm_hip_vec_upload(v._h, a.ctypes.data_as(_lib.f64p), a.size))
+        return v
+
+    def upload(self, a: np.ndarray) -> None:
+        a = np.ascontiguousarray(a, np.float64)
+        check(lib.storm_hip_vec_upload(self._h, a.ctypes.data_as(_lib.f64p), a.size))
+
+    def to_numpy(self, with_halo: bool = False) -> np.ndarray:
+        n = self.n_owned + (self.n_halo if with_halo else 0)
+        out = np.empty(n, np.float64)
+        check(lib.storm_hip_vec_download(self._h, out.ctypes.data_as(_lib.f64p), n))
+        return out
+
+    # -- expression builders ---------------------------------------------------------------
+    def __rmul__(self, a):  # alpha * v          MatrixMath.hpp:247-256
+        return _Scaled(a, self)
+
+    def __add__(self, o):  # MatrixMath.hpp:273-279
+        if isinstance(o, DeviceVector):
+            return _Lin2(1.0, self, 1.0, o)
+        if isinstance(o, _Scaled):
+            return _Lin2(1.0, self, o.a, o.v)
+        if isinstance(o, _ScaledLin2):
+            return _Lin3(self, o.s, o.lin)
+        return NotImplemented
+
+    def __sub__(self, o):  # MatrixMath.hpp:280-285
+        if isinstance(o, DeviceVector):
+            return _Lin2(1.0, self, -1.0, o)
+        if isinstance(o, _Scaled):
+            return _Lin2(1.0, self, -o.a, o.v)
+        return NotImplemented
+
+    # -- targets (TargetMatrixInterface, Bittern/MatrixTarget.hpp:53-136) -------------------
+    def __ilshift__(self, e):  # out <<= expr     MatrixAlgorithms.hpp:120-124
+        if isinstance(e, DeviceVector):
+            check(lib.storm_hip_copy(self._h, e._h))
+        elif isinstance(e, _Scaled):
+            check(lib.storm_hip_axpbz(self._h, e.a, e.v._h, 0.0, e.v._h))
+        elif isinstance(e, _Lin2):
+            check(lib.storm_hip_axpbz(self._h, e.a, e.x._h, e.b, e.z._h))
+        elif isinstance(e, _Lin3) and e.lin.x is self and e.lin.a == 1.0:
+            # p <<= r + beta * (p - omega * v)     SolverBiCgStab.hpp:119
+            check(lib.storm_hip_bicgstab_p(self._h, e.r._h, e.s, -e.lin.b, e.lin.z._h))
+        else:
+            raise NotImplementedError(f"no device kernel for `<<=` of {type(e).__name__}")
+        return self
+
+    def __iadd__(self, e):  # MatrixTarget.hpp:108-113
+        if isinstance(e, _Scaled):
+            check(lib.storm_hip_axpy(self._h, e.a, e.v._h))
+        elif isinstance(e, DeviceVector):
+            check(lib.storm_hip_axpy(self._h, 1.0, e._h))
+        else:
+            raise NotImplementedError(f"no device kernel for `+=` of {type(e).__name__}")
+        return self
+
+    def __isub__(self, e):  # MatrixTarget.hpp:114-119
+        if isinstance(e, _Scaled):
+            check(lib.storm_hip_axpy(self._h, -e.a, e.v._h))
+        elif isinstance(e, DeviceVector):
+            check(lib.storm_hip_axpy(self._h, -1.0, e._h))
+        else:
+            raise NotImplementedError(f"no device kernel for `-=` of {type(e).__name__}")
+        return self
+
+    def __imul__(self, s):  # MatrixTarget.hpp:96-99
+        check(lib.storm_hip_scale(self._h, float(s)))
+        return self
+
+    def __itruediv__(self, s):  # MatrixTarget.hpp:101-105
+        check(lib.storm_hip_div_scalar(self._h, float(s)))
+        return self
+
+
+def dot_product(a: DeviceVector, b: DeviceVector) -> float:
+    """Bittern/MatrixAlgorithms.hpp:310-317 (summed over all ranks)."""
+    out = C.c_double()
+    check(lib.storm_hip_dot(a._h, b._h, C.byref(out)))
+    return out.value
+
+
+def norm_2(a: DeviceVector) -> float:
+    """Bittern/MatrixAlgorithms.hpp:262-270."""
+    out = C.c_double()
+    check(lib.storm_hip_norm2(a._h, C.byref(out)))
+    return out.value
+
+
+def fill_with(a: DeviceVector, value: float) -> None:
+    """ADL hook the solver bodies call (Solvers/Solver.hpp:281, SolverBiCgStab.hpp:224)."""
+    check(lib.storm_hip_fill(a._h, float(value)))
+
+
+def multi_dot(a: DeviceVector, bs: Sequence[DeviceVector]) -> np.ndarray:
+    k = len(bs)
+    arr = (C.c_void_p * k)(*[b._h for b in bs])
+    out = np.empty(k)
+    check(lib.storm_hip_multi_dot(a._h, arr, k, out.ctypes.data_as(_lib.f64p)))
+    return out
+
+
+def multi_axpy(y: DeviceVector, coefs: Sequence[float], xs: Sequence[DeviceVector]) -> None:
+    k = len(xs)
+    arr = (C.c_void_p * k)(*[x._h for x in xs])
+    cf = np.ascontiguousarray(coefs, np.float64)
+    check(lib.storm_hip_multi_axpy(y._h, cf.ctypes.data_as(_lib.f64p), arr, k))
+
+
+def safe_divide(x: float, y: float) -> float:
+    """Crow/MathUtils.hpp:49-52."""
+    return 0.0 if y == 0.0 else x / y
+
+
+def sym_ortho(a: float, b: float):
+    """Crow/MathUtils.hpp:164-179."""
+    rr = math.hypot(a, b)
+    if rr > 0.0:
+        return a / rr, b / rr, rr
+    return 1.0, 0.0, rr
+
+
+# ---------------------------------------------------------------------------------------------
+# Operators (Solvers/Operator.hpp)
+
+
+class Operator:
+    """Abstract operator y <- A(x)  (Operator.hpp:66-120)."""
+
+    def mul(self, y_vec: DeviceVector, x_vec: DeviceVector) -> None:  # :74
+        raise NotImplementedError
+
+    def mul_chain(self, z_vec, y_vec, other_op: "Operator", x_vec) -> None:  # :82-88
+        other_op.mul(y_vec, x_vec)
+        self.mul(z_vec, y_vec)
+
+    def Residual(self, r_vec: DeviceVector, b_vec: DeviceVector, x_vec: DeviceVector) -> None:  # :95-99
+        self.mul(r_vec, x_vec)
+        r_vec <<= b_vec - r_vec
+
+    def ResidualNorm(self, b_vec: DeviceVector, x_vec: DeviceVector) -> float:  # :105-110
+        r_vec = DeviceVector()
+        r_vec.assign(b_vec, False)
+        self.Residual(r_vec, b_vec, x_vec)
+        return norm_2(r_vec)
+
+    def conj_mul(self, x_vec, y_vec) -> None:  # :116-118
+        raise RuntimeError("`Operator::conj_mul` was not overriden")
+
+
+class FunctionalOperator(Operator):
+    """Operator.hpp:125-168."""
+
+    def __init__(self, mat_vec_func: Callable, conj_mat_vec_func: Optional[Callable] = None):
+        assert mat_vec_func is not None
+        self._mat_vec, self._conj = mat_vec_func, conj_mat_vec_func
+
+    def mul(self, y_vec, x_vec):
+        self._mat_vec(y_vec, x_vec)
+
+    def conj_mul(self, x_vec, y_vec):
+        if self._conj is None:
+            raise RuntimeError("`FunctionalOperator::conj_mul` conjugate product function was not set.")
+        self._conj(x_vec, y_vec)
+
+
+def make_operator(mat_vec_func, conj_mat_vec_func=None) -> FunctionalOperator:  # Operator.hpp:177-190
+    return FunctionalOperator(mat_vec_func, conj_mat_vec_func)
+
+
+def make_symmetric_operator(mat_vec_func) -> FunctionalOperator:  # Operator.hpp:196-200
+    return FunctionalOperator(mat_vec_func, mat_vec_func)
+
+
+class StencilMatrix:
+    """The device-resident face-graph operator M (sliced ELL + CSR tail); owns the handle."""
+
+    def __init__(self, ctx: Context, handle):
+        self.ctx, self._h = ctx, handle
+
+    @classmethod
+    def from_face_graph(cls, ctx: Context, g: FaceGraph) -> "StencilMatrix":
+        """Diffusion stencil of ``stormDivGrad`` (Playground.cpp:115-131) from mesh quantities."""
+        coef, b_coef = face_coefficients(g)
+        h = C.c_void_p()
+        i64, f64 = _lib.i64p, _lib.f64p
+        inner = np.ascontiguousarray(g.inner, np.int64)
+        outer = np.ascontiguousarray(g.outer, np.int64)
+        b_cell = np.ascontiguousarray(g.b_cell, np.int64)
+        vol = np.ascontiguousarray(g.volume, np.float64)
+        coef = np.ascontiguousarray(coef)
+        b_coef = np.ascontiguousarray(b_coef)
+        check(lib.storm_hip_op_create_from_faces(
+            ctx._h, g.n_cells, g.n_halo, g.n_faces, inner.ctypes.data_as(i64), outer.ctypes.data_as(i64),
+            coef.ctypes.data_as(f64), g.n_bfaces, b_cell.ctypes.data_as(i64), b_coef.ctypes.data_as(f64),
+            vol.ctypes.data_as(f64), C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_face_weights(cls, ctx: Context, n_owned: int, n_halo: int, inner, outer, w_inner, w_outer,
+                          diag_extra=None) -> "StencilMatrix":
+        h = C.c_void_p()
+        i64, f64 = _lib.i64p, _lib.f64p
+        inner = np.ascontiguousarray(inner, np.int64)
+        outer = np.ascontiguousarray(outer, np.int64)
+        w_inner = np.ascontiguousarray(w_inner, np.float64)
+        w_outer = np.ascontiguousarray(w_outer, np.float64)
+        de = None if diag_extra is None else np.ascontiguousarray(diag_extra, np.float64)
+        check(lib.storm_hip_op_create_from_face_weights(
+            ctx._h, n_owned, n_halo, inner.size, inner.ctypes.data_as(i64), outer.ctypes.data_as(i64),
+            w_inner.ctypes.data_as(f64), w_outer.ctypes.data_as(f64),
+            None if de is None else de.ctypes.data_as(f64), C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_csr(cls, ctx: Context, a, n_halo: int = 0) -> "StencilMatrix":
+        a = a.tocsr()
+        rp = np.ascontiguousarray(a.indptr, np.int64)
+        col = np.ascontiguousarray(a.indices, np.int64)
+        val = np.ascontiguousarray(a.data, np.float64)
+        h = C.c_void_p()
+        check(lib.storm_hip_op_create_csr(ctx._h, a.shape[0], n_halo, rp.ctypes.data_as(_lib.i64p),
+                                          col.ctypes.data_as(_lib.i64p), val.ctypes.data_as(_lib.f64p), C.byref(h)))
+        return cls(ctx, h)
+
+    def set_halo(self, nbr_rank, send_ptr, send_idx, recv_ptr) -> None:
+        nbr = np.ascontiguousarray(nbr_rank, np.int32)
+        sp = np.ascontiguousarray(send_ptr, np.int64)
+        si = np.ascontiguousarray(send_idx, np.int64)
+        rp = np.ascontiguousarray(recv_ptr, np.int64)
+        check(lib.storm_hip_op_set_halo(self._h, nbr.size, nbr.ctypes.data_as(_lib.i32p), sp.ctypes.data_as(_lib.i64p),
+                                        si.ctypes.data_as(_lib.i64p), rp.ctypes.data_as(_lib.i64p)))
+
+    def stats(self) -> dict:
+        s = _lib.OpStats()
+        check(lib.storm_hip_op_get_stats(self._h, C.byref(s)))
+        return {n: getattr(s, n) for n, _ in s._fields_}
+
+    def apply(self, alpha: float, beta: float, x: DeviceVector, y: DeviceVector) -> None:
+        check(lib.storm_hip_op_apply(self._h, alpha, beta, x._h, y._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.storm_hip_op_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HipStencilOperator(Operator):
+    """``A = beta*I + alpha*M`` as an ``Operator<DeviceVector>``."""
+
+    def __init__(self, matrix: StencilMatrix, alpha: float = -1.0, beta: float = 0.0):
+        self.matrix, self.alpha, self.beta = matrix, float(alpha), float(beta)
+
+    def mul(self, y_vec: DeviceVector, x_vec: DeviceVector) -> None:
+        self.matrix.apply(self.alpha, self.beta, x_vec, y_vec)
+
+    def conj_mul(self, x_vec, y_vec):
+        raise RuntimeError("`Operator::conj_mul` was not overriden")
+
+
+# ---------------------------------------------------------------------------------------------
+# Solvers (Solvers/Solver.hpp)
+
+
+class PreconditionerSide:  # Preconditioner.hpp:39-58
+    Left, Right, Symmetric = range(3)
+
+
+class Preconditioner(Operator):  # Preconditioner.hpp:63-78
+    def build(self, x_vec, b_vec, any_op) -> None:
+        pass
+
+
+class IdentityPreconditioner(Preconditioner):  # Preconditioner.hpp:84-97
+    def mul(self, y_vec, x_vec):
+        y_vec <<= x_vec
+
+    def conj_mul(self, x_vec, y_vec):
+        x_vec <<= y_vec
+
+
+class Solver:  # Solver.hpp:43-57
+    def solve(self, x_vec: DeviceVector, b_vec: DeviceVector, any_op: Operator) -> bool:
+        raise NotImplementedError
+
+
+class IterativeSolver(Solver):
+    """Solver.hpp:62-149 -- same public knobs, defaults and convergence rule."""
+
+    _native = None  # name of the whole-solver C entry point, if any
+
+    def __init__(self):
+        self.iteration = 0
+        self.num_iterations = 2000
+        self.absolute_error = 0.0
+        self.relative_error = 0.0
+        self.absolute_error_tolerance = 1.0e-6
+        self.relative_error_tolerance = 1.0e-6
+        self.pre_side = PreconditionerSide.Right
+        self.pre_op: Optional[Preconditioner] = None
+        self.name = ""
+        # extras of this build
+        self.check_lag = 0
+        self.record_history = False
+        self.history: Optional[np.ndarray] = None
+        self.num_applies = 0
+        self.initial_error = 0.0
+
+    def init(self, x_vec, b_vec, any_op, pre_op) -> float:
+        raise NotImplementedError
+
+    def iterate(self, x_vec, b_vec, any_op, pre_op) -> float:
+        raise NotImplementedError
+
+    def finalize(self, x_vec, b_vec, any_op, pre_op) -> None:
+        pass
+
+    def _params(self) -> _lib.SolverParams:
+        p = _lib.SolverParams()
+        lib.storm_hip_solver_params_default(C.byref(p))
+        p.num_iterations = self.num_iterations
+        p.absolute_error_tolerance = self.absolute_error_tolerance
+        p.relative_error_tolerance = self.relative_error_tolerance
+        p.check_lag = self.check_lag
+        return p
+
+    def _solve_native(self, x_vec, b_vec, op: HipStencilOperator) -> bool:
+        p = self._params()
+        r = _lib.SolverResult()
+        hist = np.zeros(self.num_iterations + 1) if self.record_history else None
+        fn = getattr(lib, self._native)
+        check(fn(op.matrix._h, op.alpha, op.beta, b_vec._h, x_vec._h, C.byref(p), C.byref(r),
+                 None if hist is None else hist.ctypes.data_as(_lib.f64p)))
+        self.iteration = r.iterations
+        self.absolute_error, self.relative_error = r.absolute_error, r.relative_error
+        self.initial_error, self.num_applies = r.initial_error, r.num_applies
+        self.history = None if hist is None else hist[: r.iterations + 1]
+        return bool(r.converged)
+
+    def solve(self, x_vec, b_vec, any_op) -> bool:  # Solver.hpp:116-147
+        if self._native and isinstance(any_op, HipStencilOperator) and self.pre_op is None:
+            return self._solve_native(x_vec, b_vec, any_op)
+        if self.pre_op is not None:
+            self.pre_op.build(x_vec, b_vec, any_op)
+        initial_error = self.init(x_vec, b_vec, any_op, self.pre_op)
+        self.initial_error = initial_error
+        self.absolute_error = initial_error
+        hist = [initial_error]
+        if self.absolute_error_tolerance > 0.0 and self.absolute_error < self.absolute_error_tolerance:
+            self.finalize(x_vec, b_vec, any_op, self.pre_op)
+            self.history = np.array(hist)
+            return True
+        converged = False
+        self.iteration = 0
+        while (not converged) and self.iteration < self.num_iterations:
+            self.absolute_error = self.iterate(x_vec, b_vec, any_op, self.pre_op)
+            self.relative_error = self.absolute_error / initial_error
+            hist.append(self.absolute_error)
+            converged |= (self.absolute_error_tolerance > 0.0) and (self.absolute_error < self.absolute_error_tolerance)
+            converged |= (self.relative_error_tolerance > 0.0) and (self.relative_error < self.relative_error_tolerance)
+            self.iteration += 1
+        self.finalize(x_vec, b_vec, any_op, self.pre_op)
+        self.history = np.array(hist)
+        return converged
+
+
+class InnerOuterIterativeSolver(IterativeSolver):
+    """Solver.hpp:154-259."""
+
+    def __init__(self):
+        super().__init__()
+        self.inner_iteration = 0
+        self.num_inner_iterations = 50
+
+    def _params(self):
+        p = super()._params()
+        p.num_inner_iterations = self.num_inner_iterations
+        return p
+
+    def outer_init(self, x_vec, b_vec, any_op, pre_op) -> float:
+        raise NotImplementedError
+
+    def inner_init(self, x_vec, b_vec, any_op, pre_op) -> None:
+        pass
+
+    def inner_iterate(self, x_vec, b_vec, any_op, pre_op) -> float:
+        raise NotImplementedError
+
+    def inner_finalize(self, x_vec, b_vec, any_op, pre_op) -> None:
+        pass
+
+    def outer_finalize(self, x_vec, b_vec, any_op, pre_op) -> None:
+        pass
+
+    def init(self, x_vec, b_vec, any_op, pre_op):  # :230-234
+        return self.outer_init(x_vec, b_vec, any_op, pre_op)
+
+    def iterate(self, x_vec, b_vec, any_op, pre_op):  # :236-248
+        self.inner_iteration = self.iteration % self.num_inner_iterations
+        if self.inner_iteration == 0:
+            self.inner_init(x_vec, b_vec, any_op, pre_op)
+        residual_norm = self.inner_iterate(x_vec, b_vec, any_op, pre_op)
+        if self.inner_iteration == self.num_inner_iterations - 1:
+            self.inner_finalize(x_vec, b_vec, any_op, pre_op)
+        return residual_norm
+
+    def finalize(self, x_vec, b_vec, any_op, pre_op):  # :250-257
+        if self.inner_iteration != self.num_inner_iterations - 1:
+            self.inner_finalize(x_vec, b_vec, any_op, pre_op)
+        self.outer_finalize(x_vec, b_vec, any_op, pre_op)
+
+
+class CgSolver(IterativeSolver):
+    """SolverCg.hpp:47-128."""
+
+    _native = "storm_hip_solve_cg"
+
+    def init(self, x_vec, b_vec, lin_op, pre_op):  # :54-84
+        self._p_vec, self._r_vec, self._z_vec = DeviceVector(), DeviceVector(), DeviceVector()
+        self._p_vec.assign(x_vec, False)
+        self._r_vec.assign(x_vec, False)
+        self._z_vec.assign(x_vec, False)
+        lin_op.Residual(self._r_vec, b_vec, x_vec)
+        if pre_op is not None:
+            pre_op.mul(self._z_vec, self._r_vec)
+            self._p_vec <<= self._z_vec
+            self._gamma = dot_product(self._r_vec, self._z_vec)
+        else:
+            self._p_vec <<= self._r_vec
+            self._gamma = dot_product(self._r_vec, self._r_vec)
+        return norm_2(self._r_vec) if pre_op is not None else math.sqrt(self._gamma)
+
+    def iterate(self, x_vec, b_vec, lin_op, pre_op):  # :86-126
+        lin_op.mul(self._z_vec, self._p_vec)
+        alpha = safe_divide(self._gamma, dot_product(self._p_vec, self._z_vec))
+        x_vec += alpha * self._p_vec
+        self._r_vec -= alpha * self._z_vec
+        gamma_bar = self._gamma
+        if pre_op is not None:
+            pre_op.mul(self._z_vec, self._r_vec)
+            self._gamma = dot_product(self._r_vec, self._z_vec)
+        else:
+            self._gamma = dot_product(self._r_vec, self._r_vec)
+        beta = safe_divide(self._gamma, gamma_bar)
+        self._p_vec <<= (self._z_vec if pre_op is not None else self._r_vec) + beta * self._p_vec
+        return norm_2(self._r_vec) if pre_op is not None else math.sqrt(self._gamma)
+
+
+class BiCgStabSolver(IterativeSolver):
+    """SolverBiCgStab.hpp:52-167 (unpreconditioned and right/left preconditioned branches)."""
+
+    _native = "storm_hip_solve_bicgstab"
+
+    def init(self, x_vec, b_vec, lin_op, pre_op):  # :59-91
+        left_pre = pre_op is not None and self.pre_side == PreconditionerSide.Left
+        names = ["_p_vec", "_r_vec", "_r_tilde_vec", "_t_vec", "_v_vec"] + (["_z_vec"] if pre_op is not None else [])
+        for nme in names:
+            v = DeviceVector()
+            v.assign(x_vec, False)
+            setattr(self, nme, v)
+        lin_op.Residual(self._r_vec, b_vec, x_vec)
+        if left_pre:
+            self._z_vec, self._r_vec = self._r_vec, self._z_vec
+            pre_op.mul(self._r_vec, self._z_vec)
+        self._r_tilde_vec <<= self._r_vec
+        self._rho = dot_product(self._r_tilde_vec, self._r_vec)
+        self._alpha = self._omega = 0.0
+        return math.sqrt(self._rho)
+
+    def iterate(self, x_vec, b_vec, lin_op, pre_op):  # :93-165
+        left_pre = pre_op is not None and self.pre_side == PreconditionerSide.Left
+        right_pre = pre_op is not None and self.pre_side == PreconditionerSide.Right
+        if self.iteration == 0:
+            self._p_vec <<= self._r_vec
+        else:
+            rho_bar, self._rho = self._rho, dot_product(self._r_tilde_vec, self._r_vec)
+            beta = safe_divide(self._alpha * self._rho, self._omega * rho_bar)
+            self._p_vec <<= self._r_vec + beta * (self._p_vec - self._omega * self._v_vec)
+        if left_pre:
+            pre_op.mul_chain(self._v_vec, self._z_vec, lin_op, self._p_vec)
+        elif right_pre:
+            lin_op.mul_chain(self._v_vec, self._z_vec, pre_op, self._p_vec)
+        else:
+            lin_op.mul(self._v_vec, self._p_vec)
+        self._alpha = safe_divide(self._rho, dot_product(self._r_tilde_vec, self._v_vec))
+        x_vec += self._alpha * (self._z_vec if right_pre else self._p_vec)
+        self._r_vec -= self._alpha * self._v_vec
+        if left_pre:
+            pre_op.mul_chain(self._t_vec, self._z_vec, lin_op, self._r_vec)
+        elif right_pre:
+            lin_op.mul_chain(self._t_vec, self._z_vec, pre_op, self._r_vec)
+        else:
+            lin_op.mul(self._t_vec, self._r_vec)
+        self._omega = safe_divide(dot_product(self._t_vec, self._r_vec), dot_product(self._t_vec, self._t_vec))
+        x_vec += self._omega * (self._z_vec if right_pre else self._r_vec)
+        self._r_vec -= self._omega * self._t_vec
+        return norm_2(self._r_vec)
+
+
+class GmresSolver(InnerOuterIterativeSolver):
+    """SolverGmres.hpp:41-255, Flexible = false, no preconditioner in the host-statement path."""
+
+    _native = "storm_hip_solve_gmres"
+
+    def __init__(self):
+        super().__init__()
+        self.gram_schmidt = 0  # 0: modified (reference); 1: classical x2 (batched reductions)
+
+    def _params(self):
+        p = super()._params()
+        p.gram_schmidt = self.gram_schmidt
+        return p
+
+    def _start(self, x_vec, b_vec, lin_op):
+        lin_op.Residual(self._q_vecs[0], b_vec, x_vec)
+        self._beta[0] = norm_2(self._q_vecs[0])
+        self._q_vecs[0] /= self._beta[0]
+
+    def outer_init(self, x_vec, b_vec, lin_op, pre_op):  # :51-91
+        if pre_op is not None:
+            raise NotImplementedError("preconditioned GMRES is not part of the hot path (SURVEY.md 8f rank 3)")
+        m = self.num_inner_iterations
+        self._beta = np.zeros(m + 1)
+        self._cs, self._sn = np.zeros(m), np.zeros(m)
+        self._H = np.zeros((m + 1, m))
+        self._q_vecs: List[DeviceVector] = []
+        for _ in range(m + 1):
+            q = DeviceVector()
+            q.assign(x_vec, False)
+            self._q_vecs.append(q)
+        self._start(x_vec, b_vec, lin_op)
+        return self._beta[0]
+
+    def inner_init(self, x_vec, b_vec, lin_op, pre_op):  # :93-117
+        self._start(x_vec, b_vec, lin_op)
+
+    def inner_iterate(self, x_vec, b_vec, lin_op, pre_op):  # :119-192
+        k, H, q = self.inner_iteration, self._H, self._q_vecs
+        lin_op.mul(q[k + 1], q[k])
+        for i in range(k + 1):
+            H[i, k] = dot_product(q[k + 1], q[i])
+            q[k + 1] -= H[i, k] * q[i]
+        H[k + 1, k] = norm_2(q[k + 1])
+        q[k + 1] /= H[k + 1, k]
+        cs, sn, beta = self._cs, self._sn, self._beta
+        for i in range(k):
+            chi = cs[i] * H[i, k] + sn[i] * H[i + 1, k]
+            H[i + 1, k] = -sn[i] * H[i, k] + cs[i] * H[i + 1, k]
+            H[i, k] = chi
+        cs[k], sn[k], _ = sym_ortho(H[k, k], H[k + 1, k])
+        H[k, k] = cs[k] * H[k, k] + sn[k] * H[k + 1, k]
+        H[k + 1, k] = 0.0
+        beta[k + 1] = -sn[k] * beta[k]
+        beta[k] *= cs[k]
+        return abs(beta[k + 1])
+
+    def inner_finalize(self, x_vec, b_vec, lin_op, pre_op):  # :194-249
+        k, H, beta = self.inner_iteration, self._H, self._beta
+        for i in range(k, -1, -1):
+            for j in range(i + 1, k + 1):
+                beta[i] -= H[i, j] * beta[j]
+            beta[i] /= H[i, i]
+        for i in range(k + 1):
+            x_vec += beta[i] * self._q_vecs[i]
+
+
+def solve(solver_cls, x_vec: DeviceVector, b_vec: DeviceVector, any_op: Operator) -> bool:
+    """``solve<Solver>(x, b, op)``  Solver.hpp:261-265."""
+    return solver_cls().solve(x_vec, b_vec, any_op)

@@ -1,0 +1,171 @@
+// Multi-GPU plumbing: RCCL over xGMI.
+//
+// One process per GPU.  Two communicators per context so the two traffic classes never
+// queue behind each other: `halo` carries the point-to-point halo planes on the comm stream
+// (overlapped with the interior rows of the SpMV on the compute stream), `red` carries the
+// 8..400-byte dot-product all-reduces on the compute stream (latency-bound, so reductions
+// are batched by the solvers: BiCGStab's (<t,r>,<t,t>) and (|r|^2,<rt,r>) are one call each).
+#include <rccl/rccl.h>
+
+#include <cstring>
+
+#include "common.hpp"
+
+namespace storm {
+
+struct Comm {
+  ncclComm_t halo = nullptr;
+  ncclComm_t red = nullptr;
+};
+
+#define NCCL_TRY(expr)                                                                          \
+  do {                                                                                          \
+    ncclResult_t r_ = (expr);                                                                   \
+    if (r_ != ncclSuccess)                                                                      \
+      STORM_FAIL(STORM_HIP_E_COMM, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), __FILE__, \
+                 __LINE__);                                                                     \
+  } while (0)
+
+int comm_allreduce_sum(storm_hip_ctx *c, double *d_buf, int count) {
+  if (c->n_ranks <= 1) return STORM_HIP_OK;
+  STORM_REQUIRE(c->comm && c->comm->red, "all-reduce without an initialised communicator");
+  NCCL_TRY(ncclAllReduce(d_buf, d_buf, (size_t)count, ncclDouble, ncclSum, c->comm->red, c->stream));
+  return STORM_HIP_OK;
+}
+
+__global__ __launch_bounds__(kBlock) void halo_pack_kernel(int64_t n, const int *__restrict__ idx,
+                                                           const double *__restrict__ x,
+                                                           double *__restrict__ buf) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) buf[i] = x[idx[i]];
+}
+
+int comm_halo_exchange_begin(const storm_hip_op *op, double *x) {
+  storm_hip_ctx *c = op->ctx;
+  const HaloPlan &h = op->halo;
+  if (h.n_nbrs == 0 || c->n_ranks <= 1) return STORM_HIP_OK;
+  STORM_REQUIRE(c->comm && c->comm->halo, "halo exchange without an initialised communicator");
+  // x must be complete before it is packed
+  HIP_TRY(hipEventRecord(c->ev_x_ready, c->stream));
+  HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_x_ready, 0));
+  if (h.n_send > 0) {
+    const int64_t need = (h.n_send + kBlock - 1) / kBlock;
+    const int nb = (int)(need > 1024 ? 1024 : need);
+    hipLaunchKernelGGL(halo_pack_kernel, dim3(nb), dim3(kBlock), 0, c->comm_stream, h.n_send, h.d_send_idx, x,
+                       h.d_sendbuf);
+    HIP_TRY(hipGetLastError());
+  }
+  NCCL_TRY(ncclGroupStart());
+  for (int q = 0; q < h.n_nbrs; ++q) {
+    const int64_t ns = h.send_ptr[q + 1] - h.send_ptr[q], nr = h.recv_ptr[q + 1] - h.recv_ptr[q];
+    if (ns > 0)
+      NCCL_TRY(ncclSend(h.d_sendbuf + h.send_ptr[q], (size_t)ns, ncclDouble, h.nbr_rank[q], c->comm->halo,
+                        c->comm_stream));
+    if (nr > 0)
+      NCCL_TRY(ncclRecv(x + op->n_rows + h.recv_ptr[q], (size_t)nr, ncclDouble, h.nbr_rank[q], c->comm->halo,
+                        c->comm_stream));
+  }
+  NCCL_TRY(ncclGroupEnd());
+  HIP_TRY(hipEventRecord(c->ev_halo_done, c->comm_stream));
+  return STORM_HIP_OK;
+}
+
+int comm_halo_exchange_end(const storm_hip_op *op) {
+  storm_hip_ctx *c = op->ctx;
+  if (op->halo.n_nbrs == 0 || c->n_ranks <= 1) return STORM_HIP_OK;
+  HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_halo_done, 0));
+  return STORM_HIP_OK;
+}
+
+void comm_destroy(storm_hip_ctx *c) {
+  if (!c->comm) return;
+  if (c->comm->red && c->comm->red != c->comm->halo) (void)ncclCommDestroy(c->comm->red);
+  if (c->comm->halo) (void)ncclCommDestroy(c->comm->halo);
+  delete c->comm;
+  c->comm = nullptr;
+}
+
+}  // namespace storm
+
+using namespace storm;
+
+extern "C" {
+
+int storm_hip_comm_unique_id(void *id128) {
+  STORM_REQUIRE(id128, "comm_unique_id: null buffer");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+  ncclUniqueId id;
+  NCCL_TRY(ncclGetUniqueId(&id));
+  memcpy(id128, &id, sizeof id);
+  return STORM_HIP_OK;
+}
+
+int storm_hip_ctx_comm_init(storm_hip_ctx *c, const void *id128, int n_ranks, int rank) {
+  STORM_REQUIRE(c, "comm_init: null context");
+  STORM_REQUIRE(n_ranks >= 1 && rank >= 0 && rank < n_ranks, "comm_init: rank %d of %d", rank, n_ranks);
+  STORM_REQUIRE(c->comm == nullptr, "comm_init: communicator already initialised");
+  c->n_ranks = n_ranks;
+  c->rank = rank;
+  if (n_ranks == 1 && id128 == nullptr) return STORM_HIP_OK;
+  STORM_REQUIRE(id128, "comm_init: null unique id with %d ranks", n_ranks);
+  HIP_TRY(hipSetDevice(c->device));
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof id);
+  auto *cm = new Comm();
+  ncclResult_t r = ncclCommInitRank(&cm->halo, n_ranks, id, rank);
+  if (r != ncclSuccess) {
+    delete cm;
+    c->n_ranks = 1, c->rank = 0;
+    STORM_FAIL(STORM_HIP_E_COMM, "ncclCommInitRank failed: %s", ncclGetErrorString(r));
+  }
+  // Second communicator for the reductions; fall back to sharing one if the split is refused.
+  r = ncclCommSplit(cm->halo, 0, rank, &cm->red, nullptr);
+  if (r != ncclSuccess || cm->red == nullptr) cm->red = cm->halo;
+  c->comm = cm;
+  return STORM_HIP_OK;
+}
+
+int storm_hip_ctx_comm_size(storm_hip_ctx *c, int *n_ranks, int *rank) {
+  STORM_REQUIRE(c, "comm_size: null context");
+  if (n_ranks) *n_ranks = c->n_ranks;
+  if (rank) *rank = c->rank;
+  return STORM_HIP_OK;
+}
+
+int storm_hip_op_set_halo(storm_hip_op *op, int n_nbrs, const int32_t *nbr_rank, const int64_t *send_ptr,
+                          const int64_t *send_idx, const int64_t *recv_ptr) {
+  STORM_REQUIRE(op, "op_set_halo: null operator");
+  STORM_REQUIRE(n_nbrs >= 0, "op_set_halo: negative neighbour count");
+  STORM_REQUIRE(op->halo.n_nbrs == 0 && op->halo.d_send_idx == nullptr, "op_set_halo: plan already set");
+  if (n_nbrs == 0) return STORM_HIP_OK;
+  STORM_REQUIRE(nbr_rank && send_ptr && send_idx && recv_ptr, "op_set_halo: null array");
+  storm_hip_ctx *c = op->ctx;
+  HaloPlan &h = op->halo;
+  STORM_REQUIRE(send_ptr[0] == 0 && recv_ptr[0] == 0, "op_set_halo: offsets must start at 0");
+  for (int q = 0; q < n_nbrs; ++q) {
+    STORM_REQUIRE(nbr_rank[q] >= 0 && nbr_rank[q] < c->n_ranks && nbr_rank[q] != c->rank,
+                  "op_set_halo: neighbour %d is rank %d (this is rank %d of %d)", q, nbr_rank[q], c->rank, c->n_ranks);
+    STORM_REQUIRE(send_ptr[q + 1] >= send_ptr[q] && recv_ptr[q + 1] >= recv_ptr[q], "op_set_halo: offsets not monotone");
+  }
+  STORM_REQUIRE(recv_ptr[n_nbrs] == op->n_halo, "op_set_halo: plan receives %lld rows, operator has %lld halo rows",
+                (long long)recv_ptr[n_nbrs], (long long)op->n_halo);
+  const int64_t n_send = send_ptr[n_nbrs];
+  std::vector<int> idx((size_t)n_send);
+  for (int64_t i = 0; i < n_send; ++i) {
+    STORM_REQUIRE(send_idx[i] >= 0 && send_idx[i] < op->n_rows, "op_set_halo: send index %lld outside the owned rows",
+                  (long long)send_idx[i]);
+    idx[(size_t)i] = (int)send_idx[i];
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMalloc((void **)&h.d_send_idx, sizeof(int) * (size_t)(n_send ? n_send : 1)));
+  HIP_TRY(hipMalloc((void **)&h.d_sendbuf, sizeof(double) * (size_t)(n_send ? n_send : 1)));
+  if (n_send) HIP_TRY(hipMemcpy(h.d_send_idx, idx.data(), sizeof(int) * (size_t)n_send, hipMemcpyHostToDevice));
+  h.n_nbrs = n_nbrs;
+  h.n_send = n_send;
+  h.nbr_rank.assign(nbr_rank, nbr_rank + n_nbrs);
+  h.send_ptr.assign(send_ptr, send_ptr + n_nbrs + 1);
+  h.recv_ptr.assign(recv_ptr, recv_ptr + n_nbrs + 1);
+  return op_upload_slice_lists(op);
+}
+
+}  // extern "C"

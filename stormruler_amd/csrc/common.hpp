@@ -1,0 +1,199 @@
+// Internal declarations shared by the translation units of libstorm_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/storm_hip.h"
+
+namespace storm {
+
+// ---- error plumbing -------------------------------------------------------
+void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+
+#define STORM_FAIL(code, ...)        \
+  do {                               \
+    ::storm::set_error(__VA_ARGS__); \
+    return (code);                   \
+  } while (0)
+
+#define STORM_REQUIRE(cond, ...) \
+  do {                           \
+    if (!(cond)) STORM_FAIL(STORM_HIP_E_INVALID, __VA_ARGS__); \
+  } while (0)
+
+#define HIP_TRY(expr)                                                               \
+  do {                                                                              \
+    hipError_t e_ = (expr);                                                         \
+    if (e_ != hipSuccess)                                                           \
+      STORM_FAIL(STORM_HIP_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                 __FILE__, __LINE__);                                               \
+  } while (0)
+
+#define STORM_TRY(expr)        \
+  do {                         \
+    int s_ = (expr);           \
+    if (s_ != 0) return s_;    \
+  } while (0)
+
+// ---- launch geometry --------------------------------------------------------
+constexpr int kWave = 64;            // CDNA wavefront
+constexpr int kBlock = 256;          // 4 waves, one per SIMD
+constexpr int kNumXcd = 8;           // MI355X: 8 XCDs, blocks dealt round-robin
+constexpr int kMaxReduceBlocks = 2048;  // 256 CUs x 8 resident 256-thread blocks
+constexpr int kMaxMulti = 64;        // widest multi-dot / multi-axpy in one launch
+constexpr int kSlab = 256;           // doubles in the device scalar slab
+
+// Device-resident solver state: every scalar a Krylov loop carries, so no
+// alpha/beta/omega/Givens value ever visits the host (SURVEY.md section 7
+// "Reduction latency").  One instance lives in each context.
+struct SolverState {
+  double s[kSlab];          // named slots, see solvers.hip
+  double initial_error;
+  double absolute_error;
+  double relative_error;
+  double abs_tol, rel_tol;
+  long long iteration;      // IterativeSolver::iteration (Solver.hpp:66)
+  long long num_iterations;
+  int done;                 // set by the device when converged or out of iterations
+  int converged;
+  double *history;          // device buffer [num_iterations + 1] or null
+};
+
+struct Comm;  // comm.hip
+
+}  // namespace storm
+
+struct storm_hip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;       // compute stream: every kernel runs here
+  hipStream_t comm_stream = nullptr;  // halo pack + RCCL send/recv
+  hipEvent_t ev_x_ready = nullptr, ev_halo_done = nullptr;
+  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+  int num_cus = 0;
+  std::string name;
+  int64_t total_mem = 0;
+  // reduction workspace
+  double *d_partials = nullptr;       // [kMaxReduceBlocks * kMaxMulti]
+  double *d_scalars = nullptr;        // [kMaxMulti] results of host-visible reductions
+  double *h_scalars = nullptr;        // pinned mirror
+  const double **d_ptrs = nullptr;    // [kMaxMulti] pointer table for multi-dot / multi-axpy
+  double *d_coefs = nullptr;          // [kMaxMulti]
+  storm::SolverState *d_state = nullptr;
+  storm::SolverState *h_state = nullptr;  // pinned ring, [kStateRing]
+  std::vector<hipEvent_t> ev_ring;
+  // options
+  int64_t opt_ell_cap = 0;
+  int64_t opt_spmv_variant = 0;
+  int64_t opt_nt = 1;
+  // communicator
+  storm::Comm *comm = nullptr;
+  int n_ranks = 1, rank = 0;
+};
+
+struct storm_hip_vec {
+  storm_hip_ctx *ctx = nullptr;
+  int64_t n_owned = 0, n_halo = 0;
+  double *d = nullptr;
+};
+
+namespace storm {
+
+constexpr int kStateRing = 64;
+
+struct HaloPlan {
+  int n_nbrs = 0;
+  std::vector<int> nbr_rank;
+  std::vector<int64_t> send_ptr, recv_ptr;  // [n_nbrs + 1]
+  int *d_send_idx = nullptr;                // [send_ptr.back()]
+  double *d_sendbuf = nullptr;
+  int64_t n_send = 0;
+};
+
+}  // namespace storm
+
+// Sliced ELL (slices of one wavefront = 64 rows, column-major inside a slice)
+// plus a CSR tail for the entries of rows longer than the slice's width.
+struct storm_hip_op {
+  storm_hip_ctx *ctx = nullptr;
+  int64_t n_rows = 0, n_halo = 0;
+  int64_t n_slices = 0, n_interior_slices = 0;
+  int64_t nnz = 0, ell_slots = 0, max_row_len = 0;
+  int64_t *d_slice_ptr = nullptr;  // [n_slices + 1] element offset of each slice (multiple of 64)
+  int *d_col = nullptr;            // [ell_slots]
+  double *d_val = nullptr;         // [ell_slots]
+  double *d_ext = nullptr;         // [n_rows] extra diagonal
+  // tail
+  int64_t tail_rows = 0, tail_nnz = 0;
+  int *d_tail_row = nullptr;       // [tail_rows]
+  int64_t *d_tail_ptr = nullptr;   // [tail_rows + 1]
+  int *d_tail_col = nullptr;
+  double *d_tail_val = nullptr;
+  int uniform_width = 0;           // > 0 when every slice has this width
+  // slices whose rows read no halo column (overlap the halo exchange) / the rest
+  std::vector<int> h_interior, h_boundary;
+  int *d_interior = nullptr, *d_boundary = nullptr;
+  int64_t n_interior = 0, n_boundary = 0;
+  int64_t device_bytes = 0;
+  storm::HaloPlan halo;
+};
+
+namespace storm {
+
+// ---- internal cross-TU API ----------------------------------------------------
+// Where a kernel reads a scalar from: a host value or a slot of the device slab
+// (optionally negated / transformed on the fly).
+struct Scal {
+  const double *p;  // device pointer or null
+  double v;         // host value when p == null
+  double sign;      // multiplies the loaded value
+};
+static inline Scal host_scal(double v) { return Scal{nullptr, v, 1.0}; }
+static inline Scal dev_scal(const double *p, double sign = 1.0) { return Scal{p, 0.0, sign}; }
+
+// blas1.hip -- all asynchronous on ctx->stream, owned rows only.
+// `done` (nullable): device flag; kernels return immediately when it is set.
+int k_fill(storm_hip_ctx *c, double *y, int64_t n, double v);
+int k_copy(storm_hip_ctx *c, double *y, const double *x, int64_t n, const int *done);
+int k_scale(storm_hip_ctx *c, double *y, int64_t n, Scal s, bool divide, const int *done);
+// y = a*x + b*z
+int k_axpbz(storm_hip_ctx *c, double *y, Scal a, const double *x, Scal b, const double *z,
+            int64_t n, const int *done);
+// p = r + beta*(p - omega*v)
+int k_bicg_p(storm_hip_ctx *c, double *p, const double *r, Scal beta, Scal omega, const double *v,
+             int64_t n, const int *done);
+// out[j] = <a, bs[j]> for j < k, written to d_out (device); local sums only.
+int k_multi_dot(storm_hip_ctx *c, const double *a, const double *const *bs, int k, int64_t n,
+                double *d_out, const int *done);
+// y += sum_j coef[j] * xs[j]; coefficients from device memory (d_coef, sign applied).
+int k_multi_axpy(storm_hip_ctx *c, double *y, const double *d_coef, double sign,
+                 const double *const *xs, int k, int64_t n, const int *done);
+// Final pass over per-block partials: out[j] = sum_b partials[j * nblocks + b].
+int k_reduce_final(storm_hip_ctx *c, const double *partials, int nblocks, int k, double *d_out,
+                   const int *done);
+
+// spmv.hip
+// y = beta*x + alpha*M x over slices [s0, s1); when dot_w != null also writes
+// per-block partials of <dot_w, y> (and <y, y> when dot_yy) into partials.
+struct SpmvDot {
+  const double *w = nullptr;   // partial of <w, y>
+  bool yy = false;             // also partial of <y, y>
+  double *partials = nullptr;  // [2 * nblocks] layout: [<w,y> blocks..., <y,y> blocks...]
+  int *nblocks_out = nullptr;  // host out: number of partial blocks written
+};
+int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, double *y,
+                const SpmvDot *dot, const int *done);
+int spmv_grid_blocks(const storm_hip_op *op);
+int op_upload_slice_lists(storm_hip_op *op);
+
+// comm.hip
+int comm_allreduce_sum(storm_hip_ctx *c, double *d_buf, int count);  // in place, on ctx->stream
+int comm_halo_exchange_begin(const storm_hip_op *op, double *x);      // pack + send/recv on comm stream
+int comm_halo_exchange_end(const storm_hip_op *op);                   // compute stream waits
+void comm_destroy(storm_hip_ctx *c);
+
+}  // namespace storm

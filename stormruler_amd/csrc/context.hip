@@ -1,0 +1,209 @@
+// Context, vectors, error plumbing of libstorm_hip.so.
+#include <cstdarg>
+#include <cstring>
+
+#include "common.hpp"
+
+namespace storm {
+
+static thread_local char g_error[1024] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_error, sizeof g_error, fmt, ap);
+  va_end(ap);
+}
+
+}  // namespace storm
+
+using namespace storm;
+
+extern "C" {
+
+int storm_hip_abi_version(void) { return STORM_HIP_ABI_VERSION; }
+
+const char *storm_hip_last_error(void) { return storm::g_error; }
+
+int storm_hip_ctx_create(int device_id, storm_hip_ctx **out) {
+  STORM_REQUIRE(out != nullptr, "ctx_create: out is null");
+  *out = nullptr;
+  int n_dev = 0;
+  hipError_t e = hipGetDeviceCount(&n_dev);
+  if (e != hipSuccess || n_dev <= 0)
+    STORM_FAIL(STORM_HIP_E_NO_DEVICE, "no HIP device available (%s)",
+               e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+  STORM_REQUIRE(device_id >= 0 && device_id < n_dev, "ctx_create: device %d out of range [0,%d)",
+                device_id, n_dev);
+  HIP_TRY(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    STORM_FAIL(STORM_HIP_E_NO_DEVICE, "device %d is %s; this library carries gfx950 code only",
+               device_id, prop.gcnArchName);
+  auto *c = new storm_hip_ctx();
+  c->device = device_id;
+  c->num_cus = prop.multiProcessorCount;
+  c->name = prop.name;
+  c->total_mem = (int64_t)prop.totalGlobalMem;
+  HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_x_ready, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_halo_done, hipEventDisableTiming));
+  HIP_TRY(hipEventCreate(&c->ev_t0));
+  HIP_TRY(hipEventCreate(&c->ev_t1));
+  HIP_TRY(hipMalloc(&c->d_partials, sizeof(double) * kMaxReduceBlocks * kMaxMulti));
+  HIP_TRY(hipMalloc(&c->d_scalars, sizeof(double) * kMaxMulti));
+  HIP_TRY(hipHostMalloc((void **)&c->h_scalars, sizeof(double) * kMaxMulti, hipHostMallocDefault));
+  HIP_TRY(hipMalloc((void **)&c->d_ptrs, sizeof(double *) * kMaxMulti));
+  HIP_TRY(hipMalloc(&c->d_coefs, sizeof(double) * kMaxMulti));
+  HIP_TRY(hipMalloc((void **)&c->d_state, sizeof(SolverState)));
+  HIP_TRY(hipMemset(c->d_state, 0, sizeof(SolverState)));
+  HIP_TRY(hipHostMalloc((void **)&c->h_state, sizeof(SolverState) * kStateRing, hipHostMallocDefault));
+  c->ev_ring.resize(kStateRing);
+  for (auto &ev : c->ev_ring) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  *out = c;
+  return STORM_HIP_OK;
+}
+
+int storm_hip_ctx_destroy(storm_hip_ctx *c) {
+  if (!c) return STORM_HIP_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  comm_destroy(c);
+  for (auto &ev : c->ev_ring) (void)hipEventDestroy(ev);
+  (void)hipFree(c->d_partials);
+  (void)hipFree(c->d_scalars);
+  (void)hipHostFree(c->h_scalars);
+  (void)hipFree((void *)c->d_ptrs);
+  (void)hipFree(c->d_coefs);
+  (void)hipFree(c->d_state);
+  (void)hipHostFree(c->h_state);
+  (void)hipEventDestroy(c->ev_x_ready);
+  (void)hipEventDestroy(c->ev_halo_done);
+  (void)hipEventDestroy(c->ev_t0);
+  (void)hipEventDestroy(c->ev_t1);
+  (void)hipStreamDestroy(c->stream);
+  (void)hipStreamDestroy(c->comm_stream);
+  delete c;
+  return STORM_HIP_OK;
+}
+
+int storm_hip_ctx_sync(storm_hip_ctx *c) {
+  STORM_REQUIRE(c, "ctx_sync: null context");
+  HIP_TRY(hipStreamSynchronize(c->comm_stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return STORM_HIP_OK;
+}
+
+int storm_hip_ctx_info(storm_hip_ctx *c, char *name, int name_len, int *num_cus,
+                       int64_t *total_mem_bytes) {
+  STORM_REQUIRE(c, "ctx_info: null context");
+  if (name && name_len > 0) {
+    strncpy(name, c->name.c_str(), (size_t)name_len - 1);
+    name[name_len - 1] = 0;
+  }
+  if (num_cus) *num_cus = c->num_cus;
+  if (total_mem_bytes) *total_mem_bytes = c->total_mem;
+  return STORM_HIP_OK;
+}
+
+int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
+  STORM_REQUIRE(c && key, "ctx_set_option: null argument");
+  if (!strcmp(key, "ell_cap")) c->opt_ell_cap = value;
+  else if (!strcmp(key, "spmv_variant")) c->opt_spmv_variant = value;
+  else if (!strcmp(key, "nontemporal")) c->opt_nt = value;
+  else STORM_FAIL(STORM_HIP_E_INVALID, "ctx_set_option: unknown key '%s'", key);
+  return STORM_HIP_OK;
+}
+
+int storm_hip_timer_start(storm_hip_ctx *c) {
+  STORM_REQUIRE(c, "timer_start: null context");
+  HIP_TRY(hipEventRecord(c->ev_t0, c->stream));
+  return STORM_HIP_OK;
+}
+
+int storm_hip_timer_stop(storm_hip_ctx *c, float *elapsed_ms) {
+  STORM_REQUIRE(c && elapsed_ms, "timer_stop: null argument");
+  HIP_TRY(hipEventRecord(c->ev_t1, c->stream));
+  HIP_TRY(hipEventSynchronize(c->ev_t1));
+  HIP_TRY(hipEventElapsedTime(elapsed_ms, c->ev_t0, c->ev_t1));
+  return STORM_HIP_OK;
+}
+
+// ---- vectors ---------------------------------------------------------------------
+
+int storm_hip_vec_create(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, storm_hip_vec **out) {
+  STORM_REQUIRE(c && out, "vec_create: null argument");
+  *out = nullptr;
+  STORM_REQUIRE(n_owned >= 0 && n_halo >= 0, "vec_create: negative size");
+  STORM_REQUIRE(n_owned + n_halo < (int64_t)INT32_MAX, "vec_create: %lld rows exceed int32 indexing",
+                (long long)(n_owned + n_halo));
+  auto *v = new storm_hip_vec();
+  v->ctx = c;
+  v->n_owned = n_owned;
+  v->n_halo = n_halo;
+  // Round the allocation up so 16-byte vector accesses of the last rows stay in bounds.
+  const size_t bytes = sizeof(double) * (size_t)((n_owned + n_halo + 3) / 4 * 4 + 4);
+  hipError_t e = hipMalloc(&v->d, bytes);
+  if (e != hipSuccess) {
+    delete v;
+    STORM_FAIL(STORM_HIP_E_ALLOC, "vec_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  }
+  // Field::assign value-initialises (Feathers/Field.hpp:82-84): zero fill.
+  e = hipMemsetAsync(v->d, 0, bytes, c->stream);
+  if (e != hipSuccess) {
+    (void)hipFree(v->d);
+    delete v;
+    STORM_FAIL(STORM_HIP_E_HIP, "vec_create: memset failed: %s", hipGetErrorString(e));
+  }
+  *out = v;
+  return STORM_HIP_OK;
+}
+
+int storm_hip_vec_create_like(const storm_hip_vec *other, storm_hip_vec **out) {
+  STORM_REQUIRE(other, "vec_create_like: null vector");
+  return storm_hip_vec_create(other->ctx, other->n_owned, other->n_halo, out);
+}
+
+int storm_hip_vec_destroy(storm_hip_vec *v) {
+  if (!v) return STORM_HIP_OK;
+  (void)hipStreamSynchronize(v->ctx->stream);
+  (void)hipFree(v->d);
+  delete v;
+  return STORM_HIP_OK;
+}
+
+int storm_hip_vec_size(const storm_hip_vec *v, int64_t *n_owned, int64_t *n_halo) {
+  STORM_REQUIRE(v, "vec_size: null vector");
+  if (n_owned) *n_owned = v->n_owned;
+  if (n_halo) *n_halo = v->n_halo;
+  return STORM_HIP_OK;
+}
+
+int storm_hip_vec_upload(storm_hip_vec *v, const double *host, int64_t n) {
+  STORM_REQUIRE(v && (host || n == 0), "vec_upload: null argument");
+  STORM_REQUIRE(n == v->n_owned, "vec_upload: %lld values for a vector of %lld owned rows",
+                (long long)n, (long long)v->n_owned);
+  HIP_TRY(hipMemcpyAsync(v->d, host, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, v->ctx->stream));
+  HIP_TRY(hipStreamSynchronize(v->ctx->stream));
+  return STORM_HIP_OK;
+}
+
+int storm_hip_vec_download(const storm_hip_vec *v, double *host, int64_t n) {
+  STORM_REQUIRE(v && (host || n == 0), "vec_download: null argument");
+  STORM_REQUIRE(n == v->n_owned || n == v->n_owned + v->n_halo,
+                "vec_download: %lld values requested from a vector of %lld(+%lld) rows", (long long)n,
+                (long long)v->n_owned, (long long)v->n_halo);
+  HIP_TRY(hipMemcpyAsync(host, v->d, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, v->ctx->stream));
+  HIP_TRY(hipStreamSynchronize(v->ctx->stream));
+  return STORM_HIP_OK;
+}
+
+int storm_hip_vec_device_ptr(storm_hip_vec *v, void **dev_ptr) {
+  STORM_REQUIRE(v && dev_ptr, "vec_device_ptr: null argument");
+  *dev_ptr = v->d;
+  return STORM_HIP_OK;
+}
+
+}  // extern "C"

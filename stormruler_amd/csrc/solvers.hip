@@ -1,0 +1,691 @@
+// Device-resident Krylov loops: CG, BiCGStab, GMRES(m).
+//
+// Restates Solvers/Solver.hpp:116-147 (IterativeSolver::solve), :236-257
+// (InnerOuterIterativeSolver), SolverCg.hpp:54-126, SolverBiCgStab.hpp:59-165 and
+// SolverGmres.hpp:51-249 for the operator A = beta*I + alpha*M on the device.
+//
+// Design: every scalar of the recurrences (gamma, alpha, beta, rho, omega, the Hessenberg
+// column, Givens rotations, the residual norm, the iteration counter and the convergence
+// verdict) lives in a SolverState in HBM.  Kernels read them from there, the last pass of
+// each reduction is followed by a one-thread "step" that evaluates the reference's scalar
+// statements (safe_divide, sqrt, sym_ortho, the convergence rule) on the device.  The host
+// never waits for a scalar: it enqueues iterations ahead and looks at a pinned copy of the
+// state `check_lag` iterations behind; once the device has set `done`, every later kernel
+// returns at its first instruction, so the result is exactly the reference's: same
+// iteration count, x frozen at the iteration that met the tolerance.
+#include <cmath>
+#include <cstddef>
+#include <cstring>
+
+#include "common.hpp"
+
+namespace storm {
+
+// named slots of SolverState::s
+enum Slot {
+  S_GAMMA = 0, S_PZ, S_GAMMA_NEW, S_BETA, S_ALPHA,
+  S_RHO, S_RTV, S_TR, S_TT, S_OMEGA, S_RR, S_RHO_NEW,  // (TR,TT) and (RR,RHO_NEW) stay adjacent: one all-reduce each
+  S_TMP, S_HN,
+  S_SCRATCH = 32,
+};
+
+// Crow/MathUtils.hpp:49-52
+__device__ __forceinline__ double safe_divide(double x, double y) { return (y == 0.0) ? 0.0 : (x / y); }
+
+// The body of the for loop in IterativeSolver::solve, Solver.hpp:132-140.
+__device__ void advance(SolverState *st, double abs_err) {
+  st->absolute_error = abs_err;
+  st->relative_error = abs_err / st->initial_error;
+  bool conv = false;
+  conv |= (st->abs_tol > 0.0) && (st->absolute_error < st->abs_tol);
+  conv |= (st->rel_tol > 0.0) && (st->relative_error < st->rel_tol);
+  st->iteration += 1;
+  if (st->history) st->history[st->iteration] = abs_err;
+  if (conv) st->converged = 1;
+  if (conv || st->iteration >= st->num_iterations) st->done = 1;
+}
+
+// After init(): Solver.hpp:122-128.
+__device__ void begin(SolverState *st, double initial_error) {
+  st->initial_error = initial_error;
+  st->absolute_error = initial_error;
+  st->relative_error = 0.0;
+  st->iteration = 0;
+  st->converged = 0;
+  st->done = 0;
+  if (st->history) st->history[0] = initial_error;
+  if (st->abs_tol > 0.0 && initial_error < st->abs_tol) st->converged = 1, st->done = 1;
+  if (st->num_iterations <= 0) st->done = 1;
+}
+
+enum StepKind {
+  STEP_NONE = 0,
+  STEP_CG_INIT,    // gamma = <r,r>; begin(sqrt(gamma))
+  STEP_CG_RR,      // gamma_new -> beta, gamma; advance(sqrt(gamma))
+  STEP_BICG_INIT,  // rho = <rt,r>; begin(sqrt(rho))
+  STEP_BICG_ALPHA, // alpha = rho / <rt,v>
+  STEP_BICG_OMEGA, // omega = <t,r> / <t,t>
+  STEP_BICG_END,   // err = sqrt(<r,r>); beta from rho_new; advance
+  STEP_GMRES_BETA0_OUTER, // beta[0] = sqrt(tmp); begin(beta[0])
+  STEP_GMRES_BETA0,       // beta[0] = sqrt(tmp)
+  STEP_GMRES_HN,          // hn = sqrt(tmp)
+};
+
+struct GmresDev {
+  double *H, *beta, *cs, *sn;  // device arrays: (m+1) x m row-major, m+1, m, m
+  int m;
+};
+
+__device__ void do_step(int kind, SolverState *st, GmresDev g) {
+  double *s = st->s;
+  switch (kind) {
+    case STEP_CG_INIT:  // SolverCg.hpp:82,85
+      begin(st, sqrt(s[S_GAMMA]));
+      break;
+    case STEP_CG_RR: {  // SolverCg.hpp:110-125
+      const double gamma_bar = s[S_GAMMA];
+      s[S_GAMMA] = s[S_GAMMA_NEW];
+      s[S_BETA] = safe_divide(s[S_GAMMA], gamma_bar);
+      advance(st, sqrt(s[S_GAMMA]));
+    } break;
+    case STEP_BICG_INIT:  // SolverBiCgStab.hpp:88-90
+      begin(st, sqrt(s[S_RHO]));
+      break;
+    case STEP_BICG_ALPHA:  // SolverBiCgStab.hpp:139
+      s[S_ALPHA] = safe_divide(s[S_RHO], s[S_RTV]);
+      break;
+    case STEP_BICG_OMEGA:  // SolverBiCgStab.hpp:159-160
+      s[S_OMEGA] = safe_divide(s[S_TR], s[S_TT]);
+      break;
+    case STEP_BICG_END: {  // :164 then, for the next iteration, :116-118
+      const double rho_bar = s[S_RHO];
+      s[S_RHO] = s[S_RHO_NEW];
+      s[S_BETA] = safe_divide(s[S_ALPHA] * s[S_RHO], s[S_OMEGA] * rho_bar);
+      advance(st, sqrt(s[S_RR]));
+    } break;
+    case STEP_GMRES_BETA0_OUTER:  // SolverGmres.hpp:87,90
+      g.beta[0] = sqrt(s[S_TMP]);
+      s[S_HN] = g.beta[0];
+      begin(st, g.beta[0]);
+      break;
+    case STEP_GMRES_BETA0:  // SolverGmres.hpp:115
+      g.beta[0] = sqrt(s[S_TMP]);
+      s[S_HN] = g.beta[0];
+      break;
+    case STEP_GMRES_HN:  // SolverGmres.hpp:161
+      s[S_HN] = sqrt(s[S_TMP]);
+      break;
+    default: break;
+  }
+}
+
+__device__ __forceinline__ double block_sum256(double v, double *lds4) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) lds4[wave] = v;
+  __syncthreads();
+  return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+}
+
+struct OutSlots {
+  double *p[4];
+};
+
+// Final pass of up to 4 simultaneous reductions + (single rank) the scalar step.
+__global__ __launch_bounds__(kBlock) void reduce_step_kernel(const double *__restrict__ partials, int nblocks,
+                                                             int k, OutSlots out, int step, SolverState *st,
+                                                             GmresDev g, bool force) {
+  if (!force && st->done) return;
+  __shared__ double lds4[4];
+  for (int j = 0; j < k; ++j) {
+    const double *p = partials + (int64_t)j * nblocks;
+    double v = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += kBlock) v += p[i];
+    const double sum = block_sum256(v, lds4);
+    if (threadIdx.x == 0) *out.p[j] = sum;
+  }
+  if (step != STEP_NONE && threadIdx.x == 0) do_step(step, st, g);
+}
+
+__global__ void step_kernel(int step, SolverState *st, GmresDev g, bool force) {
+  if (!force && st->done) return;
+  do_step(step, st, g);
+}
+
+// ---- fused vector kernels ------------------------------------------------------------------------
+static inline int vec_blocks(const storm_hip_ctx *c, int64_t n) {
+  const int64_t need = (n / 2 + kBlock * 2 - 1) / (kBlock * 2);
+  const int64_t cap = (int64_t)c->num_cus * 4;
+  return (int)(need < 1 ? 1 : (need > cap ? cap : need));
+}
+
+// r <<= b - r (Operator.hpp:98); p <<= r (SolverCg.hpp:81 / SolverBiCgStab.hpp:87 for rt);
+// partial <r, r>.
+__global__ __launch_bounds__(kBlock) void init_residual_kernel(int64_t n, double *__restrict__ r,
+                                                               const double *__restrict__ b,
+                                                               double *__restrict__ copy_to,
+                                                               double *__restrict__ partials) {
+  __shared__ double lds4[4];
+  double acc = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const double v = b[i] - r[i];
+    r[i] = v;
+    if (copy_to) copy_to[i] = v;
+    acc += v * v;
+  }
+  const double s = block_sum256(acc, lds4);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// x += alpha p; r -= alpha z; partial <r,r>        SolverCg.hpp:97-99,115
+__global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, SolverState *st, double *__restrict__ x,
+                                                           double *__restrict__ r, const double *__restrict__ p,
+                                                           const double *__restrict__ z,
+                                                           double *__restrict__ partials) {
+  if (st->done) return;
+  __shared__ double lds4[4];
+  const double alpha = safe_divide(st->s[S_GAMMA], st->s[S_PZ]);
+  double acc = 0.0;
+  const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * kBlock;
+  double2 *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r);
+  const double2 *p2 = reinterpret_cast<const double2 *>(p), *z2 = reinterpret_cast<const double2 *>(z);
+#pragma unroll 2
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
+    double2 vx = x2[i], vr = r2[i];
+    const double2 vp = p2[i], vz = z2[i];
+    vx.x += alpha * vp.x, vx.y += alpha * vp.y;
+    vr.x -= alpha * vz.x, vr.y -= alpha * vz.y;
+    x2[i] = vx, r2[i] = vr;
+    acc += vr.x * vr.x;
+    acc += vr.y * vr.y;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    x[i] += alpha * p[i];
+    const double vr = r[i] - alpha * z[i];
+    r[i] = vr;
+    acc += vr * vr;
+  }
+  const double s = block_sum256(acc, lds4);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// x += a u; r -= a w; optionally partials of <r,r> and <rt,r>.
+// BiCGStab :140-141 (a = alpha, u = p, w = v) and :161-162 (a = omega, u = r_old, w = t).
+template <bool SECOND>
+__global__ __launch_bounds__(kBlock) void bicg_update_kernel(int64_t n, SolverState *st, double *__restrict__ x,
+                                                             double *__restrict__ r, const double *__restrict__ u,
+                                                             const double *__restrict__ w,
+                                                             const double *__restrict__ rt,
+                                                             double *__restrict__ partials) {
+  if (st->done) return;
+  __shared__ double lds4[4];
+  const double a = SECOND ? st->s[S_OMEGA] : st->s[S_ALPHA];
+  double acc_rr = 0.0, acc_rho = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const double ui = SECOND ? r[i] : u[i];  // second half-step adds omega * (old) r
+    x[i] += a * ui;
+    const double vr = r[i] - a * w[i];
+    r[i] = vr;
+    if (SECOND) {
+      acc_rr += vr * vr;
+      acc_rho += rt[i] * vr;
+    }
+  }
+  if (SECOND) {
+    const double s0 = block_sum256(acc_rr, lds4);
+    const double s1 = block_sum256(acc_rho, lds4);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s0, partials[gridDim.x + blockIdx.x] = s1;
+  }
+}
+
+// GMRES: Givens update of column k and the beta recurrence, SolverGmres.hpp:176-191.
+__global__ void gmres_givens_kernel(SolverState *st, GmresDev g, int k) {
+  if (st->done) return;
+  const int m = g.m;
+#define H_(i, j) g.H[(i) * m + (j)]
+  H_(k + 1, k) = st->s[S_HN];
+  for (int i = 0; i < k; ++i) {
+    const double chi = g.cs[i] * H_(i, k) + g.sn[i] * H_(i + 1, k);
+    H_(i + 1, k) = -g.sn[i] * H_(i, k) + g.cs[i] * H_(i + 1, k);
+    H_(i, k) = chi;
+  }
+  // sym_ortho, Crow/MathUtils.hpp:164-179
+  const double a = H_(k, k), b = H_(k + 1, k);
+  const double rr = hypot(a, b);
+  double cs, sn;
+  if (rr > 0.0) cs = a / rr, sn = b / rr;
+  else cs = 1.0, sn = 0.0;
+  g.cs[k] = cs, g.sn[k] = sn;
+  H_(k, k) = cs * H_(k, k) + sn * H_(k + 1, k);
+  H_(k + 1, k) = 0.0;
+  g.beta[k + 1] = -sn * g.beta[k];
+  g.beta[k] *= cs;
+  advance(st, fabs(g.beta[k + 1]));
+#undef H_
+}
+
+// Classical Gram-Schmidt x2: H(0:k, k) = h_pass0 + h_pass1.
+__global__ void gmres_cgs2_combine_kernel(SolverState *st, GmresDev g, int k) {
+  if (st->done) return;
+  for (int i = 0; i <= k; ++i) g.H[i * g.m + k] = st->s[S_SCRATCH + i] + st->s[S_SCRATCH + kMaxMulti + i];
+}
+
+// GMRES: back substitution, SolverGmres.hpp:207-212.
+__global__ void gmres_backsolve_kernel(SolverState *st, GmresDev g, int k, bool force) {
+  if (!force && st->done) return;
+  const int m = g.m;
+  for (int i = k; i >= 0; --i) {
+    for (int j = i + 1; j <= k; ++j) g.beta[i] -= g.H[i * m + j] * g.beta[j];
+    g.beta[i] /= g.H[i * m + i];
+  }
+}
+
+// ---- host-side driver helpers -------------------------------------------------------------------------
+struct Driver {
+  storm_hip_ctx *c;
+  const storm_hip_op *op;
+  double alpha, beta;
+  int64_t n;
+  SolverState *st;
+  const int *done;
+  GmresDev g{nullptr, nullptr, nullptr, nullptr, 0};
+  int lag;
+  double *d_history = nullptr;
+
+  double *slot(int i) const { return &st->s[i]; }
+
+  // partials -> slots (+ all-reduce over ranks) -> scalar step
+  int finish(int nblocks, int k, const int *slots, int step, bool force = false) {
+    OutSlots out{};
+    double *contiguous = slot(slots[0]);
+    bool contig = true;
+    for (int j = 0; j < k; ++j) {
+      out.p[j] = slot(slots[j]);
+      contig &= (slots[j] == slots[0] + j);
+    }
+    return finish_ptrs(nblocks, k, out, contig ? contiguous : nullptr, step, force);
+  }
+  int finish_ptrs(int nblocks, int k, OutSlots out, double *contiguous, int step, bool force = false) {
+    if (c->n_ranks == 1) {
+      hipLaunchKernelGGL(reduce_step_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->d_partials, nblocks, k,
+                         out, step, st, g, force);
+      HIP_TRY(hipGetLastError());
+      return STORM_HIP_OK;
+    }
+    hipLaunchKernelGGL(reduce_step_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->d_partials, nblocks, k, out,
+                       (int)STEP_NONE, st, g, force);
+    HIP_TRY(hipGetLastError());
+    if (contiguous) {
+      STORM_TRY(comm_allreduce_sum(c, contiguous, k));
+    } else {
+      for (int j = 0; j < k; ++j) STORM_TRY(comm_allreduce_sum(c, out.p[j], 1));
+    }
+    if (step != STEP_NONE) {
+      hipLaunchKernelGGL(step_kernel, dim3(1), dim3(1), 0, c->stream, step, st, g, force);
+      HIP_TRY(hipGetLastError());
+    }
+    return STORM_HIP_OK;
+  }
+
+  // y = A x, optionally with fused <w, y> / <y, y> partials.  Returns nblocks of partials (0 = not fused).
+  int apply(const double *x, double *y, const double *dot_w, bool dot_yy, int *nblocks, bool predicated = true) {
+    SpmvDot sd;
+    sd.w = dot_w;
+    sd.yy = dot_yy;
+    sd.partials = c->d_partials;
+    sd.nblocks_out = nblocks;
+    const bool want = dot_w != nullptr || dot_yy;
+    return spmv_launch(op, host_scal(alpha), host_scal(beta), x, y, want ? &sd : nullptr,
+                       predicated ? done : nullptr);
+  }
+};
+
+static int prepare_state(Driver &d, const storm_hip_solver_params *p, double *history) {
+  storm_hip_ctx *c = d.c;
+  STORM_REQUIRE(p->num_iterations >= 0, "solve: num_iterations < 0");
+  SolverState h;
+  memset(&h, 0, sizeof h);
+  h.abs_tol = p->absolute_error_tolerance;
+  h.rel_tol = p->relative_error_tolerance;
+  h.num_iterations = p->num_iterations;
+  h.history = nullptr;
+  if (history) {
+    HIP_TRY(hipMalloc(&d.d_history, sizeof(double) * (size_t)(p->num_iterations + 1)));
+    HIP_TRY(hipMemsetAsync(d.d_history, 0, sizeof(double) * (size_t)(p->num_iterations + 1), c->stream));
+    h.history = d.d_history;
+  }
+  c->h_state[0] = h;
+  HIP_TRY(hipMemcpyAsync(c->d_state, &c->h_state[0], sizeof(SolverState), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // h_state[0] is reused by the ring below
+  d.lag = p->check_lag > 0 ? p->check_lag : 4;
+  if (d.lag > kStateRing - 1) d.lag = kStateRing - 1;
+  return STORM_HIP_OK;
+}
+
+constexpr size_t kStatusOff = offsetof(SolverState, initial_error);
+constexpr size_t kStatusBytes = sizeof(SolverState) - kStatusOff;
+
+// Post a status snapshot for iteration `it`; returns true in *stop when the snapshot of
+// iteration it - lag says the device is done.
+static int post_and_poll(Driver &d, int64_t it, bool *stop) {
+  storm_hip_ctx *c = d.c;
+  const int slot = (int)(it % kStateRing);
+  HIP_TRY(hipMemcpyAsync(reinterpret_cast<char *>(&c->h_state[slot]) + kStatusOff,
+                         reinterpret_cast<const char *>(c->d_state) + kStatusOff, kStatusBytes,
+                         hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipEventRecord(c->ev_ring[slot], c->stream));
+  *stop = false;
+  if (it >= d.lag) {
+    const int old = (int)((it - d.lag) % kStateRing);
+    HIP_TRY(hipEventSynchronize(c->ev_ring[old]));
+    if (c->h_state[old].done) *stop = true;
+  }
+  return STORM_HIP_OK;
+}
+
+static int collect(Driver &d, storm_hip_solver_result *res, double *history, int64_t applies_fn(int64_t, int64_t),
+                   int64_t m) {
+  storm_hip_ctx *c = d.c;
+  HIP_TRY(hipMemcpyAsync(&c->h_state[0], c->d_state, sizeof(SolverState), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const SolverState &h = c->h_state[0];
+  res->iterations = h.iteration;
+  res->absolute_error = h.absolute_error;
+  res->relative_error = h.relative_error;
+  res->initial_error = h.initial_error;
+  res->converged = h.converged;
+  res->num_applies = applies_fn(h.iteration, m);
+  if (history && d.d_history) {
+    HIP_TRY(hipMemcpy(history, d.d_history, sizeof(double) * (size_t)(h.iteration + 1), hipMemcpyDeviceToHost));
+  }
+  if (d.d_history) (void)hipFree(d.d_history), d.d_history = nullptr;
+  return STORM_HIP_OK;
+}
+
+static int check_solve_args(const storm_hip_op *op, const storm_hip_vec *b, storm_hip_vec *x,
+                            const storm_hip_solver_params *p, storm_hip_solver_result *r) {
+  STORM_REQUIRE(op && b && x && p && r, "solve: null argument");
+  STORM_REQUIRE(b->ctx == op->ctx && x->ctx == op->ctx, "solve: context mismatch");
+  STORM_REQUIRE(b->n_owned == op->n_rows && x->n_owned == op->n_rows, "solve: operator has %lld rows, b %lld, x %lld",
+                (long long)op->n_rows, (long long)b->n_owned, (long long)x->n_owned);
+  STORM_REQUIRE(x->n_halo >= op->n_halo, "solve: x has %lld halo rows, operator needs %lld", (long long)x->n_halo,
+                (long long)op->n_halo);
+  STORM_REQUIRE(b != x, "solve: b and x must not alias");
+  return STORM_HIP_OK;
+}
+
+struct VecPool {  // work vectors: re-assigned (zeroed) on every solve like SolverCg.hpp:57-59
+  std::vector<storm_hip_vec *> v;
+  ~VecPool() {
+    for (auto *p : v) storm_hip_vec_destroy(p);
+  }
+  int make(const storm_hip_vec *like, int count) {
+    for (int i = 0; i < count; ++i) {
+      storm_hip_vec *p = nullptr;
+      STORM_TRY(storm_hip_vec_create_like(like, &p));
+      v.push_back(p);
+    }
+    return STORM_HIP_OK;
+  }
+};
+
+static int64_t applies_cg(int64_t it, int64_t) { return 1 + it; }
+static int64_t applies_bicg(int64_t it, int64_t) { return 1 + 2 * it; }
+static int64_t applies_gmres(int64_t it, int64_t m) { return 1 + it + (it + m - 1) / m; }
+
+}  // namespace storm
+
+using namespace storm;
+
+extern "C" {
+
+void storm_hip_solver_params_default(storm_hip_solver_params *p) {
+  if (!p) return;
+  p->num_iterations = 2000;            // Solver.hpp:67
+  p->absolute_error_tolerance = 1e-6;  // Solver.hpp:71
+  p->relative_error_tolerance = 1e-6;  // Solver.hpp:72
+  p->num_inner_iterations = 50;        // Solver.hpp:159
+  p->check_lag = 0;
+  p->gram_schmidt = 0;
+}
+
+int storm_hip_solve_cg(const storm_hip_op *op, double alpha, double beta, const storm_hip_vec *b,
+                       storm_hip_vec *x, const storm_hip_solver_params *params,
+                       storm_hip_solver_result *result, double *history) {
+  STORM_TRY(check_solve_args(op, b, x, params, result));
+  storm_hip_ctx *c = op->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  const int64_t n = op->n_rows;
+  Driver d{c, op, alpha, beta, n, c->d_state, &c->d_state->done};
+  STORM_TRY(prepare_state(d, params, history));
+  VecPool pool;
+  STORM_TRY(pool.make(x, 3));
+  double *p = pool.v[0]->d, *r = pool.v[1]->d, *z = pool.v[2]->d;
+  const int nbv = vec_blocks(c, n);
+
+  // init: r = b - A x; p = r; gamma = <r,r>          SolverCg.hpp:75-85
+  int nb = 0;
+  STORM_TRY(d.apply(x->d, r, nullptr, false, &nb, false));
+  hipLaunchKernelGGL(init_residual_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, r, b->d, p, c->d_partials);
+  HIP_TRY(hipGetLastError());
+  {
+    const int slots[1] = {S_GAMMA};
+    STORM_TRY(d.finish(nbv, 1, slots, STEP_CG_INIT, true));
+  }
+  for (int64_t it = 0; it < params->num_iterations; ++it) {
+    // z = A p, <p,z>                                  SolverCg.hpp:96-97
+    STORM_TRY(d.apply(p, z, p, false, &nb));
+    if (nb == 0) {  // operator has a CSR tail: separate dot
+      const double *bs[1] = {z};
+      STORM_TRY(k_multi_dot(c, p, bs, 1, n, d.slot(S_PZ), d.done));
+      if (c->n_ranks > 1) STORM_TRY(comm_allreduce_sum(c, d.slot(S_PZ), 1));
+    } else {
+      const int slots[1] = {S_PZ};
+      STORM_TRY(d.finish(nb, 1, slots, STEP_NONE));
+    }
+    // x += alpha p; r -= alpha z; gamma = <r,r>       SolverCg.hpp:98-99,115
+    hipLaunchKernelGGL(cg_update_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, x->d, r, p, z,
+                       c->d_partials);
+    HIP_TRY(hipGetLastError());
+    {
+      const int slots[1] = {S_GAMMA_NEW};
+      STORM_TRY(d.finish(nbv, 1, slots, STEP_CG_RR));
+    }
+    // p = r + beta p                                  SolverCg.hpp:123
+    STORM_TRY(k_axpbz(c, p, host_scal(1.0), r, dev_scal(d.slot(S_BETA)), p, n, d.done));
+    bool stop = false;
+    STORM_TRY(post_and_poll(d, it, &stop));
+    if (stop) break;
+  }
+  return collect(d, result, history, applies_cg, 0);
+}
+
+int storm_hip_solve_bicgstab(const storm_hip_op *op, double alpha, double beta, const storm_hip_vec *b,
+                             storm_hip_vec *x, const storm_hip_solver_params *params,
+                             storm_hip_solver_result *result, double *history) {
+  STORM_TRY(check_solve_args(op, b, x, params, result));
+  storm_hip_ctx *c = op->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  const int64_t n = op->n_rows;
+  Driver d{c, op, alpha, beta, n, c->d_state, &c->d_state->done};
+  STORM_TRY(prepare_state(d, params, history));
+  VecPool pool;
+  STORM_TRY(pool.make(x, 5));
+  double *p = pool.v[0]->d, *r = pool.v[1]->d, *rt = pool.v[2]->d, *t = pool.v[3]->d, *v = pool.v[4]->d;
+  const int nbv = vec_blocks(c, n);
+  int nb = 0;
+
+  // init: r = b - A x; rt = r; rho = <rt,r>           SolverBiCgStab.hpp:82-90
+  STORM_TRY(d.apply(x->d, r, nullptr, false, &nb, false));
+  hipLaunchKernelGGL(init_residual_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, r, b->d, rt, c->d_partials);
+  HIP_TRY(hipGetLastError());
+  {
+    const int slots[1] = {S_RHO};
+    STORM_TRY(d.finish(nbv, 1, slots, STEP_BICG_INIT, true));
+  }
+  for (int64_t it = 0; it < params->num_iterations; ++it) {
+    if (it == 0) {
+      STORM_TRY(k_copy(c, p, r, n, d.done));  // :114
+    } else {
+      // rho, beta were formed by STEP_BICG_END of the previous iteration (same r): :116-119
+      STORM_TRY(k_bicg_p(c, p, r, dev_scal(d.slot(S_BETA)), dev_scal(d.slot(S_OMEGA)), v, n, d.done));
+    }
+    // v = A p; alpha = rho / <rt,v>                   :137-139
+    STORM_TRY(d.apply(p, v, rt, false, &nb));
+    if (nb == 0) {
+      const double *bs[1] = {v};
+      STORM_TRY(k_multi_dot(c, rt, bs, 1, n, d.slot(S_RTV), d.done));
+      if (c->n_ranks > 1) STORM_TRY(comm_allreduce_sum(c, d.slot(S_RTV), 1));
+      hipLaunchKernelGGL(step_kernel, dim3(1), dim3(1), 0, c->stream, (int)STEP_BICG_ALPHA, d.st, d.g, false);
+      HIP_TRY(hipGetLastError());
+    } else {
+      const int slots[1] = {S_RTV};
+      STORM_TRY(d.finish(nb, 1, slots, STEP_BICG_ALPHA));
+    }
+    // x += alpha p; r -= alpha v                      :140-141
+    hipLaunchKernelGGL(bicg_update_kernel<false>, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, x->d, r, p, v,
+                       rt, c->d_partials);
+    HIP_TRY(hipGetLastError());
+    // t = A r; omega = <t,r> / <t,t>                  :158-160
+    STORM_TRY(d.apply(r, t, r, true, &nb));
+    if (nb == 0) {
+      const double *bs[2] = {r, t};
+      STORM_TRY(k_multi_dot(c, t, bs, 2, n, d.slot(S_TR), d.done));
+      if (c->n_ranks > 1) STORM_TRY(comm_allreduce_sum(c, d.slot(S_TR), 2));
+      hipLaunchKernelGGL(step_kernel, dim3(1), dim3(1), 0, c->stream, (int)STEP_BICG_OMEGA, d.st, d.g, false);
+      HIP_TRY(hipGetLastError());
+    } else {
+      const int slots[2] = {S_TR, S_TT};
+      STORM_TRY(d.finish(nb, 2, slots, STEP_BICG_OMEGA));
+    }
+    // x += omega r; r -= omega t; |r|, <rt,r>         :161-164 (+ :116 of the next iteration)
+    hipLaunchKernelGGL(bicg_update_kernel<true>, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, x->d, r,
+                       (const double *)nullptr, t, rt, c->d_partials);
+    HIP_TRY(hipGetLastError());
+    {
+      const int slots[2] = {S_RR, S_RHO_NEW};
+      STORM_TRY(d.finish(nbv, 2, slots, STEP_BICG_END));
+    }
+    bool stop = false;
+    STORM_TRY(post_and_poll(d, it, &stop));
+    if (stop) break;
+  }
+  return collect(d, result, history, applies_bicg, 0);
+}
+
+int storm_hip_solve_gmres(const storm_hip_op *op, double alpha, double beta, const storm_hip_vec *b,
+                          storm_hip_vec *x, const storm_hip_solver_params *params,
+                          storm_hip_solver_result *result, double *history) {
+  STORM_TRY(check_solve_args(op, b, x, params, result));
+  storm_hip_ctx *c = op->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  const int64_t n = op->n_rows;
+  const int m = (int)params->num_inner_iterations;
+  STORM_REQUIRE(m >= 1 && m < kMaxMulti, "solve_gmres: num_inner_iterations = %d outside [1, %d)", m, kMaxMulti);
+  Driver d{c, op, alpha, beta, n, c->d_state, &c->d_state->done};
+  STORM_TRY(prepare_state(d, params, history));
+  VecPool pool;
+  STORM_TRY(pool.make(x, m + 1));  // q_0 .. q_m                     SolverGmres.hpp:60-61
+  std::vector<const double *> q(m + 1);
+  for (int i = 0; i <= m; ++i) q[i] = pool.v[i]->d;
+  // H, beta, cs, sn                                                  SolverGmres.hpp:56-58
+  const size_t gm_doubles = (size_t)(m + 1) * m + (m + 1) + m + m;
+  double *d_gm = nullptr;
+  HIP_TRY(hipMalloc(&d_gm, sizeof(double) * gm_doubles));
+  struct Free {
+    double *p;
+    ~Free() { (void)hipFree(p); }
+  } free_gm{d_gm};
+  HIP_TRY(hipMemsetAsync(d_gm, 0, sizeof(double) * gm_doubles, c->stream));
+  d.g = GmresDev{d_gm, d_gm + (size_t)(m + 1) * m, d_gm + (size_t)(m + 1) * m + (m + 1),
+                 d_gm + (size_t)(m + 1) * m + (m + 1) + m, m};
+  const int nbv = vec_blocks(c, n);
+  int nb = 0;
+
+  // q0 = b - A x; beta0 = |q0|; q0 /= beta0        (outer_init :82-88 and inner_init :110-116)
+  auto start = [&](bool outer) -> int {
+    double *q0 = const_cast<double *>(q[0]);
+    STORM_TRY(d.apply(x->d, q0, nullptr, false, &nb, !outer));
+    if (outer) {
+      hipLaunchKernelGGL(init_residual_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, q0, b->d,
+                         (double *)nullptr, c->d_partials);
+      HIP_TRY(hipGetLastError());
+      const int slots[1] = {S_TMP};
+      STORM_TRY(d.finish(nbv, 1, slots, STEP_GMRES_BETA0_OUTER, true));
+      STORM_TRY(k_scale(c, q0, n, dev_scal(d.slot(S_HN)), true, nullptr));
+    } else {
+      STORM_TRY(k_axpbz(c, q0, host_scal(1.0), b->d, host_scal(-1.0), q0, n, d.done));
+      const double *bs[1] = {q0};
+      STORM_TRY(k_multi_dot(c, q0, bs, 1, n, d.slot(S_TMP), d.done));
+      if (c->n_ranks > 1) STORM_TRY(comm_allreduce_sum(c, d.slot(S_TMP), 1));
+      hipLaunchKernelGGL(step_kernel, dim3(1), dim3(1), 0, c->stream, (int)STEP_GMRES_BETA0, d.st, d.g, false);
+      HIP_TRY(hipGetLastError());
+      STORM_TRY(k_scale(c, q0, n, dev_scal(d.slot(S_HN)), true, d.done));
+    }
+    return STORM_HIP_OK;
+  };
+  // x += sum_i beta_i q_i after the back substitution        inner_finalize :207-236
+  auto finalize = [&](int k, bool force) -> int {
+    hipLaunchKernelGGL(gmres_backsolve_kernel, dim3(1), dim3(1), 0, c->stream, d.st, d.g, k, force);
+    HIP_TRY(hipGetLastError());
+    return k_multi_axpy(c, x->d, d.g.beta, 1.0, q.data(), k + 1, n, force ? nullptr : d.done);
+  };
+
+  STORM_TRY(start(true));
+  for (int64_t it = 0; it < params->num_iterations; ++it) {
+    const int k = (int)(it % m);                         // Solver.hpp:239
+    if (k == 0) STORM_TRY(start(false));                 // Solver.hpp:240-242
+    double *qn = const_cast<double *>(q[k + 1]);
+    STORM_TRY(d.apply(q[k], qn, nullptr, false, &nb));   // SolverGmres.hpp:155
+    if (params->gram_schmidt == 0) {
+      // modified Gram-Schmidt, one dependent dot -> axpy pair per basis vector   :157-160
+      for (int i = 0; i <= k; ++i) {
+        double *h = &d.g.H[i * m + k];
+        const double *bs[1] = {q[i]};
+        STORM_TRY(k_multi_dot(c, qn, bs, 1, n, h, d.done));
+        if (c->n_ranks > 1) STORM_TRY(comm_allreduce_sum(c, h, 1));
+        STORM_TRY(k_axpbz(c, qn, host_scal(1.0), qn, dev_scal(h, -1.0), q[i], n, d.done));
+      }
+    } else {
+      // classical Gram-Schmidt applied twice: two multi-dots + two multi-axpys, the second
+      // pass's coefficients are added to the first's (same span, batched reductions).
+      double *h0 = d.slot(S_SCRATCH);  // k + 1 <= 63 scratch slots
+      for (int pass = 0; pass < 2; ++pass) {
+        STORM_TRY(k_multi_dot(c, qn, q.data(), k + 1, n, h0 + pass * kMaxMulti, d.done));
+        if (c->n_ranks > 1) STORM_TRY(comm_allreduce_sum(c, h0 + pass * kMaxMulti, k + 1));
+        STORM_TRY(k_multi_axpy(c, qn, h0 + pass * kMaxMulti, -1.0, q.data(), k + 1, n, d.done));
+      }
+      hipLaunchKernelGGL(gmres_cgs2_combine_kernel, dim3(1), dim3(1), 0, c->stream, d.st, d.g, k);
+      HIP_TRY(hipGetLastError());
+    }
+    {
+      const double *bs[1] = {qn};
+      STORM_TRY(k_multi_dot(c, qn, bs, 1, n, d.slot(S_TMP), d.done));                           // :161
+      if (c->n_ranks > 1) STORM_TRY(comm_allreduce_sum(c, d.slot(S_TMP), 1));
+      hipLaunchKernelGGL(step_kernel, dim3(1), dim3(1), 0, c->stream, (int)STEP_GMRES_HN, d.st, d.g, false);
+      HIP_TRY(hipGetLastError());
+      STORM_TRY(k_scale(c, qn, n, dev_scal(d.slot(S_HN)), true, d.done));                       // :162
+    }
+    hipLaunchKernelGGL(gmres_givens_kernel, dim3(1), dim3(1), 0, c->stream, d.st, d.g, k);    // :176-191
+    HIP_TRY(hipGetLastError());
+    if (k == m - 1) STORM_TRY(finalize(k, false));       // Solver.hpp:244-246
+    bool stop = false;
+    STORM_TRY(post_and_poll(d, it, &stop));
+    if (stop) break;
+  }
+  // InnerOuterIterativeSolver::finalize, Solver.hpp:250-257.  The in-loop finalize of the very
+  // last iteration was skipped by the `done` predicate, so it always runs here.  (When no
+  // iterate() ran the reference's finalize divides by H(0,0) = 0; that is not reproduced.)
+  HIP_TRY(hipMemcpyAsync(&c->h_state[0], c->d_state, sizeof(SolverState), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const int64_t iters = c->h_state[0].iteration;
+  if (iters > 0) STORM_TRY(finalize((int)((iters - 1) % m), true));
+  return collect(d, result, history, applies_gmres, m);
+}
+
+}  // extern "C"

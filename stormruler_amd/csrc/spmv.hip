@@ -1,0 +1,522 @@
+// The operator-apply hot path: stormDivGrad (source_apps/playground/Playground.cpp:115-131)
+// as a gather-form SpMV on a sliced-ELL / CSR-tail hybrid.
+//
+// Layout in HBM (built once per operator on the host, slot order = face order):
+//   slice s = rows [64 s, 64 s + 64): one wavefront.  Its entries are stored
+//   column-major:  slot k of row r sits at  slice_ptr[s] + 64 k + (r mod 64),
+//   so the 64 lanes of a wave read 64 consecutive int32 columns (256 B) and 64
+//   consecutive fp64 weights (512 B) per slot -- fully coalesced.
+//   Width of a slice = min(longest row in it, ell_cap); what does not fit goes
+//   to a CSR tail handled by a wave-per-row kernel with a __shfl_down reduction.
+//   Padding slots carry weight 0 and the row's own index as column.
+// Arithmetic:  y_i = beta x_i + alpha ( sum_k w_ik (x[col_ik] - x_i) + ext_i x_i )
+//   -- the difference form of the reference's flux  (c[out] - c[in]), which keeps
+//   the cancellation behaviour of the face loop (no large diagonal * x_i term).
+// Algorithmic bytes per apply: 8N (x) + 8N (y) + 8N (ext) + 12 nnz.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+#include "common.hpp"
+
+namespace storm {
+
+__device__ __forceinline__ double ld_scal2(const Scal &s) { return s.p ? (*s.p) * s.sign : s.v; }
+
+struct SellArgs {
+  const int64_t *__restrict__ slice_ptr;
+  const int *__restrict__ col;
+  const double *__restrict__ val;
+  const double *__restrict__ ext;
+  int64_t n_rows;
+};
+
+struct DotArgs {
+  const double *w;   // partial of <w, y>, may be null
+  double *partials;  // [<w,y> per block | <y,y> per block]
+  int yy;
+  int nblocks_total;  // stride between the two partial arrays
+  int block_offset;   // where this launch's blocks start
+};
+
+// Blocks are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8), each with a
+// private 4 MiB L2.  Remap so every XCD walks one contiguous run of slices: the x rows a
+// slice gathers from neighbouring slices are then found in the same L2.
+__device__ __forceinline__ int xcd_remap(int b, int nb) {
+  const int q = nb / kNumXcd, r = nb % kNumXcd;
+  const int x = b % kNumXcd, j = b / kNumXcd;
+  return x * q + (x < r ? x : r) + j;
+}
+
+template <bool NT>
+__device__ __forceinline__ int ld_i(const int *p) {
+  return NT ? __builtin_nontemporal_load(p) : *p;
+}
+template <bool NT>
+__device__ __forceinline__ double ld_d(const double *p) {
+  return NT ? __builtin_nontemporal_load(p) : *p;
+}
+
+constexpr int kChunk = 8;  // slots whose (col, val) loads are issued before the first gather
+
+// VARIANT 0: gathers straight from global memory (L1/L2 serve the reuse).
+// VARIANT 1: the block's own 256 x rows are staged in LDS and in-window gathers read LDS.
+template <bool NT, bool DOT, int VARIANT, bool XCD>
+__global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SellArgs A, Scal alpha_s, Scal beta_s,
+                                                           const double *__restrict__ x,
+                                                           double *__restrict__ y,
+                                                           const int *__restrict__ slice_list,
+                                                           int64_t n_launch_slices, DotArgs dot,
+                                                           const int *done) {
+  if (done && *done) return;
+  __shared__ double lds4[4];
+  __shared__ double xwin[VARIANT == 1 ? kBlock : 1];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const int lb = XCD ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int64_t sl = (int64_t)lb * (kBlock / kWave) + wave;
+  const bool wave_active = sl < n_launch_slices;
+  const double alpha = ld_scal2(alpha_s), beta = ld_scal2(beta_s);
+
+  double yi = 0.0, wi = 0.0;
+  int64_t row = 0;
+  bool valid = false;
+  double xi = 0.0;
+  int64_t slice = 0;
+  if (wave_active) {
+    slice = slice_list ? (int64_t)slice_list[sl] : sl;
+    row = slice * kWave + lane;
+    valid = row < A.n_rows;
+    xi = valid ? x[row] : 0.0;
+  }
+  int64_t row0 = 0;
+  if (VARIANT == 1) {
+    // Only meaningful when the block's 4 slices are consecutive (no slice list).
+    row0 = (int64_t)lb * kBlock;
+    xwin[threadIdx.x] = xi;
+    __syncthreads();
+  }
+  if (wave_active) {
+    const int64_t base = A.slice_ptr[slice];
+    const int width = (int)((A.slice_ptr[slice + 1] - base) >> 6);
+    const int *cp = A.col + base + lane;
+    const double *vp = A.val + base + lane;
+    const double ext = valid ? ld_d<NT>(A.ext + row) : 0.0;
+    double acc = 0.0;
+    for (int k0 = 0; k0 < width; k0 += kChunk) {
+      int c[kChunk];
+      double v[kChunk];
+#pragma unroll
+      for (int k = 0; k < kChunk; ++k) {
+        if (k0 + k < width) {
+          c[k] = ld_i<NT>(cp + (int64_t)(k0 + k) * kWave);
+          v[k] = ld_d<NT>(vp + (int64_t)(k0 + k) * kWave);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kChunk; ++k) {
+        if (k0 + k < width) {
+          double xc;
+          if (VARIANT == 1) {
+            const int64_t d = (int64_t)c[k] - row0;
+            xc = ((uint64_t)d < (uint64_t)kBlock) ? xwin[d] : x[c[k]];
+          } else {
+            xc = x[c[k]];
+          }
+          acc += v[k] * (xc - xi);
+        }
+      }
+    }
+    yi = beta * xi + alpha * (acc + ext * xi);
+    if (valid) {
+      if (NT) __builtin_nontemporal_store(yi, y + row);
+      else y[row] = yi;
+      if (DOT && dot.w) wi = dot.w[row];
+    } else {
+      yi = 0.0;
+    }
+  }
+  if (DOT) {
+    // block_sum inlined twice (fixed order) -- partials of <w, y> and <y, y>.
+    double a = dot.w ? wi * yi : 0.0, b = dot.yy ? yi * yi : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      a += __shfl_down(a, off, kWave);
+      b += __shfl_down(b, off, kWave);
+    }
+    __shared__ double lds4b[4];
+    if (lane == 0) lds4[wave] = a, lds4b[wave] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int slot = dot.block_offset + blockIdx.x;
+      dot.partials[slot] = (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+      if (dot.yy) dot.partials[dot.nblocks_total + slot] = (lds4b[0] + lds4b[1]) + (lds4b[2] + lds4b[3]);
+    }
+  }
+}
+
+// CSR tail: one wavefront per overflowing row; the lanes' partial products are folded
+// with __shfl_down and lane 0 adds the row's remainder to y.
+__global__ __launch_bounds__(kBlock) void spmv_tail_kernel(int64_t n_tail, const int *__restrict__ tail_row,
+                                                           const int64_t *__restrict__ tail_ptr,
+                                                           const int *__restrict__ tail_col,
+                                                           const double *__restrict__ tail_val,
+                                                           Scal alpha_s, const double *__restrict__ x,
+                                                           double *__restrict__ y, const int *done) {
+  if (done && *done) return;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t t = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  if (t >= n_tail) return;
+  const double alpha = ld_scal2(alpha_s);
+  const int r = tail_row[t];
+  const double xi = x[r];
+  double acc = 0.0;
+  for (int64_t k = tail_ptr[t] + lane; k < tail_ptr[t + 1]; k += kWave)
+    acc += tail_val[k] * (x[tail_col[k]] - xi);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, kWave);
+  if (lane == 0) y[r] += alpha * acc;
+}
+
+template <bool NT, bool DOT, int VARIANT>
+static void launch_sell(const storm_hip_op *op, int nb, Scal alpha, Scal beta, const double *x, double *y,
+                        const int *slice_list, int64_t n_launch, DotArgs dot, const int *done) {
+  SellArgs A{op->d_slice_ptr, op->d_col, op->d_val, op->d_ext, op->n_rows};
+  // The XCD remap only helps when consecutive logical blocks are consecutive slices.
+  if (slice_list == nullptr)
+    hipLaunchKernelGGL((spmv_sell_kernel<NT, DOT, VARIANT, true>), dim3(nb), dim3(kBlock), 0,
+                       op->ctx->stream, A, alpha, beta, x, y, slice_list, n_launch, dot, done);
+  else
+    hipLaunchKernelGGL((spmv_sell_kernel<NT, DOT, 0, false>), dim3(nb), dim3(kBlock), 0, op->ctx->stream,
+                       A, alpha, beta, x, y, slice_list, n_launch, dot, done);
+}
+
+static int launch_range(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, double *y,
+                        const int *slice_list, int64_t n_launch, DotArgs dot, bool want_dot,
+                        const int *done) {
+  if (n_launch <= 0) return STORM_HIP_OK;
+  const int nb = (int)((n_launch + 3) / 4);
+  const bool nt = op->ctx->opt_nt != 0;
+  const int variant = (int)op->ctx->opt_spmv_variant;
+#define SPMV_GO(NT_, DOT_, VAR_) \
+  launch_sell<NT_, DOT_, VAR_>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done)
+  if (variant == 1) {
+    if (nt) { if (want_dot) SPMV_GO(true, true, 1); else SPMV_GO(true, false, 1); }
+    else    { if (want_dot) SPMV_GO(false, true, 1); else SPMV_GO(false, false, 1); }
+  } else {
+    if (nt) { if (want_dot) SPMV_GO(true, true, 0); else SPMV_GO(true, false, 0); }
+    else    { if (want_dot) SPMV_GO(false, true, 0); else SPMV_GO(false, false, 0); }
+  }
+#undef SPMV_GO
+  HIP_TRY(hipGetLastError());
+  return STORM_HIP_OK;
+}
+
+int spmv_grid_blocks(const storm_hip_op *op) { return (int)((op->n_slices + 3) / 4); }
+
+int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, double *y,
+                const SpmvDot *sd, const int *done) {
+  storm_hip_ctx *c = op->ctx;
+  const bool fuse_dot = sd != nullptr && op->tail_rows == 0;
+  const bool split = op->halo.n_nbrs > 0 && c->n_ranks > 1;
+  DotArgs dot{nullptr, nullptr, 0, 0, 0};
+  int nb_total = 0;
+  const int nb_int = split ? (int)((op->n_interior + 3) / 4) : spmv_grid_blocks(op);
+  const int nb_bnd = split ? (int)((op->n_boundary + 3) / 4) : 0;
+  nb_total = nb_int + nb_bnd;
+  if (fuse_dot) {
+    STORM_REQUIRE(2 * (int64_t)nb_total <= (int64_t)kMaxReduceBlocks * kMaxMulti,
+                  "spmv: %d blocks exceed the partials workspace", nb_total);
+    dot = DotArgs{sd->w, sd->partials, sd->yy ? 1 : 0, nb_total, 0};
+  }
+  if (sd && sd->nblocks_out) *sd->nblocks_out = fuse_dot ? nb_total : 0;
+
+  if (!split) {
+    STORM_TRY(launch_range(op, alpha, beta, x, y, nullptr, op->n_slices, dot, fuse_dot, done));
+  } else {
+    // interior rows overlap the halo exchange running on the comm stream
+    STORM_TRY(comm_halo_exchange_begin(op, const_cast<double *>(x)));
+    STORM_TRY(launch_range(op, alpha, beta, x, y, op->d_interior, op->n_interior, dot, fuse_dot, done));
+    STORM_TRY(comm_halo_exchange_end(op));
+    dot.block_offset = nb_int;
+    STORM_TRY(launch_range(op, alpha, beta, x, y, op->d_boundary, op->n_boundary, dot, fuse_dot, done));
+  }
+  if (op->tail_rows > 0) {
+    const int nb = (int)((op->tail_rows + 3) / 4);
+    hipLaunchKernelGGL(spmv_tail_kernel, dim3(nb), dim3(kBlock), 0, c->stream, op->tail_rows,
+                       op->d_tail_row, op->d_tail_ptr, op->d_tail_col, op->d_tail_val, alpha, x, y, done);
+    HIP_TRY(hipGetLastError());
+  }
+  return STORM_HIP_OK;
+}
+
+// ---- host-side build ----------------------------------------------------------------------------
+
+}  // namespace storm
+
+namespace storm {
+
+template <class T>
+static int upload(T **dst, const std::vector<T> &src, int64_t *bytes) {
+  const size_t nbytes = sizeof(T) * (src.size() ? src.size() : 1);
+  hipError_t e = hipMalloc((void **)dst, nbytes);
+  if (e != hipSuccess) STORM_FAIL(STORM_HIP_E_ALLOC, "hipMalloc(%zu) failed: %s", nbytes, hipGetErrorString(e));
+  if (!src.empty()) HIP_TRY(hipMemcpy(*dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice));
+  *bytes += (int64_t)nbytes;
+  return STORM_HIP_OK;
+}
+
+// Build from off-diagonal CSR rows (entries already in the order they must be summed).
+static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vector<int64_t> &row_ptr,
+                    const std::vector<int> &col, const std::vector<double> &val,
+                    const std::vector<double> &ext, storm_hip_op **out) {
+  HIP_TRY(hipSetDevice(c->device));
+  auto *op = new storm_hip_op();
+  op->ctx = c;
+  op->n_rows = n;
+  op->n_halo = n_halo;
+  op->nnz = row_ptr[n];
+  const int64_t n_slices = (n + kWave - 1) / kWave;
+  op->n_slices = n_slices;
+  int64_t max_len = 0;
+  for (int64_t i = 0; i < n; ++i) max_len = std::max(max_len, row_ptr[i + 1] - row_ptr[i]);
+  op->max_row_len = max_len;
+  int64_t cap = c->opt_ell_cap;
+  if (cap <= 0) {
+    const double mean = n > 0 ? (double)op->nnz / (double)n : 0.0;
+    cap = std::max<int64_t>(8, (int64_t)std::ceil(2.0 * mean));
+  }
+  std::vector<int64_t> slice_ptr(n_slices + 1, 0);
+  std::vector<int> width(n_slices, 0);
+  bool uniform = true;
+  for (int64_t s = 0; s < n_slices; ++s) {
+    int64_t w = 0;
+    const int64_t r1 = std::min<int64_t>(n, (s + 1) * kWave);
+    for (int64_t r = s * kWave; r < r1; ++r) w = std::max(w, row_ptr[r + 1] - row_ptr[r]);
+    w = std::min(w, cap);
+    width[s] = (int)w;
+    slice_ptr[s + 1] = slice_ptr[s] + w * kWave;
+    if (s > 0 && width[s] != width[0]) uniform = false;
+  }
+  op->uniform_width = (uniform && n_slices > 0) ? width[0] : 0;
+  op->ell_slots = slice_ptr[n_slices];
+  std::vector<int> ecol((size_t)op->ell_slots);
+  std::vector<double> eval((size_t)op->ell_slots, 0.0);
+  std::vector<int> tail_row, tail_col;
+  std::vector<int64_t> tail_ptr(1, 0);
+  std::vector<double> tail_val;
+  for (int64_t s = 0; s < n_slices; ++s) {
+    bool touches_halo = false;
+    for (int l = 0; l < kWave; ++l) {
+      const int64_t r = s * kWave + l;
+      const int64_t pad_col = r < n ? r : (n > 0 ? n - 1 : 0);
+      const int64_t b = r < n ? row_ptr[r] : 0, e = r < n ? row_ptr[r + 1] : 0;
+      for (int k = 0; k < width[s]; ++k) {
+        const size_t at = (size_t)(slice_ptr[s] + (int64_t)k * kWave + l);
+        if (b + k < e) {
+          ecol[at] = col[(size_t)(b + k)];
+          eval[at] = val[(size_t)(b + k)];
+          touches_halo |= ecol[at] >= n;
+        } else {
+          ecol[at] = (int)pad_col;
+        }
+      }
+      if (e - b > width[s]) {
+        tail_row.push_back((int)r);
+        for (int64_t k = b + width[s]; k < e; ++k) {
+          tail_col.push_back(col[(size_t)k]);
+          tail_val.push_back(val[(size_t)k]);
+          touches_halo |= col[(size_t)k] >= n;
+        }
+        tail_ptr.push_back((int64_t)tail_col.size());
+      }
+    }
+    (touches_halo ? op->h_boundary : op->h_interior).push_back((int)s);
+  }
+  op->tail_rows = (int64_t)tail_row.size();
+  op->tail_nnz = (int64_t)tail_col.size();
+  op->n_interior_slices = (int64_t)op->h_interior.size();
+
+  int st = STORM_HIP_OK;
+  int64_t bytes = 0;
+  if ((st = upload(&op->d_slice_ptr, slice_ptr, &bytes)) || (st = upload(&op->d_col, ecol, &bytes)) ||
+      (st = upload(&op->d_val, eval, &bytes)) || (st = upload(&op->d_ext, ext, &bytes)) ||
+      (st = upload(&op->d_tail_row, tail_row, &bytes)) || (st = upload(&op->d_tail_ptr, tail_ptr, &bytes)) ||
+      (st = upload(&op->d_tail_col, tail_col, &bytes)) || (st = upload(&op->d_tail_val, tail_val, &bytes))) {
+    storm_hip_op_destroy(op);
+    return st;
+  }
+  op->device_bytes = bytes;
+  *out = op;
+  return STORM_HIP_OK;
+}
+
+// Called from op_set_halo (comm.hip): upload the interior / boundary slice lists.
+int op_upload_slice_lists(storm_hip_op *op) {
+  if (op->d_interior || op->d_boundary) return STORM_HIP_OK;
+  int64_t bytes = 0;
+  STORM_TRY(upload(&op->d_interior, op->h_interior, &bytes));
+  STORM_TRY(upload(&op->d_boundary, op->h_boundary, &bytes));
+  op->n_interior = (int64_t)op->h_interior.size();
+  op->n_boundary = (int64_t)op->h_boundary.size();
+  op->device_bytes += bytes;
+  return STORM_HIP_OK;
+}
+
+}  // namespace storm
+
+using namespace storm;
+
+extern "C" {
+
+int storm_hip_op_create_from_face_weights(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo,
+                                          int64_t n_faces, const int64_t *inner, const int64_t *outer,
+                                          const double *w_inner, const double *w_outer,
+                                          const double *diag_extra, storm_hip_op **out) {
+  STORM_REQUIRE(c && out, "op_create: null argument");
+  *out = nullptr;
+  STORM_REQUIRE(n_owned >= 0 && n_halo >= 0 && n_faces >= 0, "op_create: negative size");
+  STORM_REQUIRE(n_faces == 0 || (inner && outer && w_inner && w_outer), "op_create: null face array");
+  const int64_t nt = n_owned + n_halo;
+  STORM_REQUIRE(nt < (int64_t)INT32_MAX, "op_create: %lld cells exceed int32 indexing", (long long)nt);
+  // Validate on the host once, instead of the reference's per-access STORM_ASSERT bounds checks
+  // (Utils/Table.hpp:150-154, Feathers/Field.hpp:93-101): a bad index must never reach a kernel.
+  std::vector<int64_t> row_ptr((size_t)n_owned + 1, 0);
+  for (int64_t f = 0; f < n_faces; ++f) {
+    const int64_t a = inner[f], b = outer[f];
+    STORM_REQUIRE(a >= 0 && a < nt && b >= 0 && b < nt, "op_create: face %lld joins cells (%lld, %lld) outside [0, %lld)",
+                  (long long)f, (long long)a, (long long)b, (long long)nt);
+    STORM_REQUIRE(a != b, "op_create: face %lld joins cell %lld to itself", (long long)f, (long long)a);
+    if (a < n_owned) row_ptr[(size_t)a + 1]++;
+    if (b < n_owned) row_ptr[(size_t)b + 1]++;
+  }
+  for (int64_t i = 0; i < n_owned; ++i) row_ptr[(size_t)i + 1] += row_ptr[(size_t)i];
+  std::vector<int> col((size_t)row_ptr[(size_t)n_owned]);
+  std::vector<double> val(col.size());
+  std::vector<int64_t> fill(row_ptr.begin(), row_ptr.end() - 1);
+  for (int64_t f = 0; f < n_faces; ++f) {  // face order == the reference's accumulation order
+    const int64_t a = inner[f], b = outer[f];
+    if (a < n_owned) {
+      const size_t at = (size_t)fill[(size_t)a]++;
+      col[at] = (int)b, val[at] = w_inner[f];
+    }
+    if (b < n_owned) {
+      const size_t at = (size_t)fill[(size_t)b]++;
+      col[at] = (int)a, val[at] = w_outer[f];
+    }
+  }
+  std::vector<double> ext((size_t)n_owned, 0.0);
+  if (diag_extra) std::copy(diag_extra, diag_extra + n_owned, ext.begin());
+  return build_op(c, n_owned, n_halo, row_ptr, col, val, ext, out);
+}
+
+int storm_hip_op_create_from_faces(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, int64_t n_faces,
+                                   const int64_t *inner, const int64_t *outer, const double *coef,
+                                   int64_t n_bfaces, const int64_t *b_cell, const double *b_coef,
+                                   const double *volume, storm_hip_op **out) {
+  STORM_REQUIRE(c && out, "op_create_from_faces: null argument");
+  *out = nullptr;
+  STORM_REQUIRE(n_owned >= 0 && n_halo >= 0 && n_faces >= 0 && n_bfaces >= 0, "op_create_from_faces: negative size");
+  STORM_REQUIRE(volume && (n_faces == 0 || (inner && outer && coef)) && (n_bfaces == 0 || (b_cell && b_coef)),
+                "op_create_from_faces: null array");
+  const int64_t nt = n_owned + n_halo;
+  for (int64_t i = 0; i < nt; ++i)
+    STORM_REQUIRE(volume[i] > 0.0, "op_create_from_faces: cell %lld has volume %g", (long long)i, volume[i]);
+  std::vector<double> wi((size_t)n_faces), wo((size_t)n_faces);
+  for (int64_t f = 0; f < n_faces; ++f) {
+    const int64_t a = inner[f], b = outer[f];
+    STORM_REQUIRE(a >= 0 && a < nt && b >= 0 && b < nt, "op_create_from_faces: face %lld joins cells (%lld, %lld) outside [0, %lld)",
+                  (long long)f, (long long)a, (long long)b, (long long)nt);
+    wi[(size_t)f] = coef[f] / volume[a];  // (A_f / d_f) / V_in   Playground.cpp:126-128
+    wo[(size_t)f] = coef[f] / volume[b];  // (A_f / d_f) / V_out  Playground.cpp:126-129
+  }
+  std::vector<double> ext((size_t)n_owned, 0.0);
+  for (int64_t k = 0; k < n_bfaces; ++k) {  // flux to a zero ghost state at the wall
+    const int64_t i = b_cell[k];
+    STORM_REQUIRE(i >= 0 && i < n_owned, "op_create_from_faces: boundary face %lld on cell %lld outside [0, %lld)",
+                  (long long)k, (long long)i, (long long)n_owned);
+    ext[(size_t)i] -= b_coef[k] / volume[i];
+  }
+  return storm_hip_op_create_from_face_weights(c, n_owned, n_halo, n_faces, inner, outer, wi.data(), wo.data(),
+                                               ext.data(), out);
+}
+
+int storm_hip_op_create_csr(storm_hip_ctx *c, int64_t n_rows, int64_t n_halo, const int64_t *row_ptr,
+                            const int64_t *col, const double *val, storm_hip_op **out) {
+  STORM_REQUIRE(c && out && row_ptr, "op_create_csr: null argument");
+  *out = nullptr;
+  STORM_REQUIRE(n_rows >= 0 && n_halo >= 0, "op_create_csr: negative size");
+  const int64_t nt = n_rows + n_halo;
+  STORM_REQUIRE(nt < (int64_t)INT32_MAX, "op_create_csr: %lld columns exceed int32 indexing", (long long)nt);
+  STORM_REQUIRE(row_ptr[0] == 0, "op_create_csr: row_ptr[0] != 0");
+  std::vector<int64_t> rp((size_t)n_rows + 1, 0);
+  std::vector<int> oc;
+  std::vector<double> ov;
+  std::vector<double> ext((size_t)n_rows, 0.0);
+  oc.reserve((size_t)row_ptr[n_rows]);
+  ov.reserve((size_t)row_ptr[n_rows]);
+  for (int64_t i = 0; i < n_rows; ++i) {
+    STORM_REQUIRE(row_ptr[i + 1] >= row_ptr[i], "op_create_csr: row_ptr not monotone at row %lld", (long long)i);
+    double rowsum = 0.0;  // M x = sum_j a_ij (x_j - x_i) + (sum_j a_ij) x_i
+    for (int64_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k) {
+      STORM_REQUIRE(col[k] >= 0 && col[k] < nt, "op_create_csr: column %lld of row %lld outside [0, %lld)",
+                    (long long)col[k], (long long)i, (long long)nt);
+      rowsum += val[k];
+      if (col[k] != i) {
+        oc.push_back((int)col[k]);
+        ov.push_back(val[k]);
+      }
+    }
+    ext[(size_t)i] = rowsum;
+    rp[(size_t)i + 1] = (int64_t)oc.size();
+  }
+  return build_op(c, n_rows, n_halo, rp, oc, ov, ext, out);
+}
+
+int storm_hip_op_apply(const storm_hip_op *op, double alpha, double beta, const storm_hip_vec *x,
+                       storm_hip_vec *y) {
+  STORM_REQUIRE(op && x && y, "op_apply: null argument");
+  STORM_REQUIRE(x->ctx == op->ctx && y->ctx == op->ctx, "op_apply: context mismatch");
+  STORM_REQUIRE(x != y && x->d != y->d, "op_apply: x and y must not alias");
+  STORM_REQUIRE(x->n_owned == op->n_rows && y->n_owned == op->n_rows, "op_apply: operator has %lld rows, x %lld, y %lld",
+                (long long)op->n_rows, (long long)x->n_owned, (long long)y->n_owned);
+  STORM_REQUIRE(x->n_halo >= op->n_halo, "op_apply: x has %lld halo rows, operator needs %lld", (long long)x->n_halo,
+                (long long)op->n_halo);
+  return spmv_launch(op, host_scal(alpha), host_scal(beta), x->d, y->d, nullptr, nullptr);
+}
+
+int storm_hip_op_get_stats(const storm_hip_op *op, storm_hip_op_stats *s) {
+  STORM_REQUIRE(op && s, "op_get_stats: null argument");
+  s->n_rows = op->n_rows;
+  s->n_cols = op->n_rows + op->n_halo;
+  s->nnz_offdiag = op->nnz;
+  s->ell_slots = op->ell_slots;
+  s->tail_nnz = op->tail_nnz;
+  s->tail_rows = op->tail_rows;
+  s->n_slices = op->n_slices;
+  s->max_row_len = op->max_row_len;
+  s->n_interior_slices = op->n_interior_slices;
+  s->device_bytes = op->device_bytes;
+  return STORM_HIP_OK;
+}
+
+int storm_hip_op_destroy(storm_hip_op *op) {
+  if (!op) return STORM_HIP_OK;
+  if (op->ctx) (void)storm_hip_ctx_sync(op->ctx);
+  (void)hipFree(op->d_interior);
+  (void)hipFree(op->d_boundary);
+  (void)hipFree(op->d_slice_ptr);
+  (void)hipFree(op->d_col);
+  (void)hipFree(op->d_val);
+  (void)hipFree(op->d_ext);
+  (void)hipFree(op->d_tail_row);
+  (void)hipFree(op->d_tail_ptr);
+  (void)hipFree(op->d_tail_col);
+  (void)hipFree(op->d_tail_val);
+  (void)hipFree(op->halo.d_send_idx);
+  (void)hipFree(op->halo.d_sendbuf);
+  delete op;
+  return STORM_HIP_OK;
+}
+
+}  // extern "C"
