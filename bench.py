@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Headline benchmark: CG iterations/sec + SpMV achieved HBM GB/s, 256^3 Poisson (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one CG iteration (one pass of the hot path: stencil SpMV + the BLAS-1 ops of
+SolverCg.hpp:96-123) on the per-GPU 256^3 7-point Poisson block of BASELINE.json configs[1]
+(synthetic structured-as-unstructured face graph, b = 1, x0 = 0, fp64, tolerances disabled so
+exactly K iterations run).  For N > 1 (launched by torch.distributed.run, one rank per GPU)
+the global mesh is 256 x 256 x (256 N) row-partitioned in z-slabs (weak scaling): halo planes
+and dot-product all-reduces go over RCCL inside libstorm_hip.so.
+
+Prints ONE JSON line on rank 0.  `value` = 256^3-block CG iterations per second summed over the
+GPUs (N x the global iteration rate; at N = 1 plain CG it/s).  `roofline` prices the dominant
+kernel (sliced-ELL SpMV with the fused <p, Ap> epilogue) from HIP-event pairs recorded around
+every launch on the library's compute stream during a second, identical solve.  `cpu_baseline`
+times the CPU oracle (single thread, the reference is single-threaded) on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n", type=int, default=256, help="cells per edge of the per-GPU block")
+    ap.add_argument("--cpu-iters", type=int, default=12, help="CPU-baseline sample (CG iterations); 0 = skip")
+    ap.add_argument("--ordering", default="natural", choices=["natural", "tile"])
+    ap.add_argument("--variant", type=int, default=-1, help="SpMV kernel variant override")
+    ap.add_argument("--nontemporal", type=int, default=-1)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    from stormruler_amd import api, dist, mesh, partition
+
+    rank, local_rank, world = dist.env_rank()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with "
+                  f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...`",
+                  file=sys.stderr)
+        return 2
+    if not torch.cuda.is_available():
+        print("bench.py needs an MI355X; the HIP path has no CPU fallback", file=sys.stderr)
+        return 3
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl")
+
+    n, K, W = args.n, args.steps, args.warmup
+    t_setup = time.time()
+    if world == 1:
+        g = mesh.structured_box(n)
+        plan = None
+    else:
+        g, plan = partition.slab_partition(n, n, n, world, rank)
+    perm = None
+    if args.ordering == "tile" and world == 1:
+        perm = mesh.tile_ordering(n, n, n, 16, 16)
+        g = mesh.permute_cells(g, perm)
+
+    ctx = api.Context(local_rank)
+    if args.variant >= 0:
+        ctx.set_option("spmv_variant", args.variant)
+    if args.nontemporal >= 0:
+        ctx.set_option("nontemporal", args.nontemporal)
+    dist.connect(ctx)
+    mat = api.StencilMatrix.from_face_graph(ctx, g)
+    if plan is not None and plan.n_nbrs:
+        mat.set_halo(plan.nbr_rank, plan.send_ptr, plan.send_idx, plan.recv_ptr)
+    st = mat.stats()
+    op = api.HipStencilOperator(mat, alpha=-1.0, beta=0.0)  # A = -L, SPD
+    N = g.n_cells
+    b = api.DeviceVector(ctx, N, g.n_halo)
+    api.fill_with(b, 1.0)
+    t_setup = time.time() - t_setup
+
+    def run(iters: int):
+        x = api.DeviceVector(ctx, N, g.n_halo)
+        s = api.CgSolver()
+        s.num_iterations = iters
+        s.absolute_error_tolerance = 0.0  # both tests disabled (Solver.hpp:136-139): exactly `iters` steps
+        s.relative_error_tolerance = 0.0
+        s.solve(x, b, op)
+        assert s.iteration == iters, (s.iteration, iters)
+        return s, x
+
+    if W > 0:
+        run(W)
+    ctx.sync()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s, x = run(K)
+    ctx.sync()
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = dist.allreduce_max(time.perf_counter() - t0)
+    final_residual = s.absolute_error
+
+    # ---- roofline of the dominant kernel: HIP-event pairs around every SpMV launch ------------
+    ctx.set_option("profile_spmv", 1)
+    run(max(K, 20))
+    launches, total_ms, min_ms = ctx.spmv_profile()
+    ctx.set_option("profile_spmv", 0)
+    spmv_ms = total_ms / max(launches, 1)
+    b_spmv = 24 * N + 12 * st["nnz_offdiag"]  # x + y + ext + (int32 col + f64 val) per entry
+    achieved = b_spmv / (spmv_ms * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "spmv_hbm_traffic.json")
+    if os.path.exists(tfile) and n == 256 and world == 1:
+        try:
+            traffic = json.load(open(tfile)).get("traffic_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    # a measured device-copy ceiling in the same run (achievable HBM rate, for context)
+    copy_gbs = None
+    try:
+        src = api.DeviceVector(ctx, N)
+        dst = api.DeviceVector(ctx, N)
+        for _ in range(3):
+            dst <<= src
+        ctx.timer_start()
+        reps = 20
+        for _ in range(reps):
+            dst <<= src
+        copy_gbs = 16.0 * N * reps / (ctx.timer_stop() * 1e-3) / 1e9
+    except Exception:
+        pass
+
+    # ---- CPU baseline: the oracle (port of the reference path), 1 thread, bounded sample -------
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_iters > 0:
+        from oracle import oracle
+
+        g_cpu = g if perm is None else mesh.structured_box(n)
+        o_op = oracle.StencilOperator(g_cpu, -1.0, 0.0)
+        tc = time.perf_counter()
+        r = oracle.solve("cg", o_op, np.ones(g_cpu.n_cells), num_iterations=args.cpu_iters, abs_tol=0.0, rel_tol=0.0)
+        tc = time.perf_counter() - tc
+        # the init apply counts as work: iterations + 1 applies were done
+        cpu = {"value": args.cpu_iters / tc, "unit": "iter/s", "cores": 1, "kind": "port",
+               "sample": f"{args.cpu_iters} CG iterations (+ init residual) of the same {n}^3 Poisson problem, "
+                         f"oracle/liboracle.so (gcc -O2 -ffp-contract=off), host has {os.cpu_count()} cpus",
+               "seconds": tc}
+        # parity spot check at bench size: same iteration count of CG from the same start gives the
+        # same residual (GPU sums in a different order: tolerance, not bits)
+        sg, _ = run(args.cpu_iters)
+        cpu["gpu_vs_cpu_residual_rel_diff"] = abs(sg.absolute_error - r.absolute_error) / r.absolute_error
+
+    if rank == 0:
+        value = world * K / elapsed
+        out = {
+            "metric": "CG iterations/sec, 256^3 Poisson per GPU (+ SpMV achieved HBM GB/s in `roofline`)",
+            "value": value,
+            "unit": "iter/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"3D 7-point Poisson {n}^3 per GPU (structured-as-unstructured FVM face graph), fp64 CG, "
+                            f"no preconditioner, b=1, x0=0 [BASELINE.json configs[1]]",
+                "cells_per_gpu": N, "interior_faces_per_gpu": g.n_faces, "ordering": args.ordering,
+                "partition": "single GPU" if world == 1 else f"z-slabs, {world} ranks, RCCL halo + all-reduce",
+                "value_definition": "n_gpus x K / max-over-ranks wall time of a K-iteration solve (init residual included)",
+            },
+            "roofline": {
+                "kernel": "spmv_sell_kernel (sliced-ELL gather SpMV + fused <p,Ap> partials)",
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": b_spmv, "avg_launch_ms": spmv_ms, "min_launch_ms": min_ms,
+                "launches_timed": launches, "measured_copy_GBs": copy_gbs,
+            },
+            "cpu_baseline": cpu,
+            "cg": {"iterations_per_sec_global": K / elapsed,
+                   "algorithmic_bytes_per_iteration": b_spmv + 96 * N,
+                   "effective_GBs_reference_op_list": (b_spmv + 96 * N) * K / elapsed / 1e9,
+                   "final_residual": final_residual},
+            "op_stats": st,
+            "device": ctx.info()["name"],
+            "setup_seconds": t_setup,
+        }
+        print(json.dumps(out))
+    dist.barrier()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

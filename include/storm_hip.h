@@ -69,6 +69,12 @@ int storm_hip_ctx_info(storm_hip_ctx *ctx, char *name, int name_len, int *num_cu
 int storm_hip_timer_start(storm_hip_ctx *ctx);
 int storm_hip_timer_stop(storm_hip_ctx *ctx, float *elapsed_ms);
 
+/* With option "profile_spmv" = 1 every launch of the dominant kernel (the sliced-ELL SpMV)
+ * is bracketed by a HIP-event pair on the compute stream; this returns and resets the
+ * accumulated launch count and durations (synchronises the stream). */
+int storm_hip_ctx_get_spmv_profile(storm_hip_ctx *ctx, int64_t *launches, double *total_ms,
+                                   double *min_ms);
+
 /* ---- communicator (RCCL over xGMI) -------------------------
  * rank 0 fills a 128-byte id, the host distributes it (torch.distributed /
  * MPI / a file), every rank calls comm_init.  n_ranks == 1 needs neither. */

@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import weakref
 from typing import Callable, List, Optional, Sequence
 
 import numpy as np
@@ -42,9 +43,13 @@ class Context:
         check(lib.storm_hip_ctx_create(device, C.byref(h)))
         self._h = h
         self.n_ranks, self.rank = 1, 0
+        self._children = weakref.WeakSet()  # vectors / operators living on this context
 
     def close(self):
+        """Destroy the context after every vector and operator created on it."""
         if getattr(self, "_h", None):
+            for child in list(self._children):
+                child._free()
             lib.storm_hip_ctx_destroy(self._h)
             self._h = None
 
@@ -65,6 +70,12 @@ class Context:
 
     def set_option(self, key: str, value: int):
         check(lib.storm_hip_ctx_set_option(self._h, key.encode(), int(value)))
+
+    def spmv_profile(self):
+        """(launches, total_ms, min_ms) of the SpMV kernel since the last call (option profile_spmv)."""
+        n, tot, mn = C.c_int64(), C.c_double(), C.c_double()
+        check(lib.storm_hip_ctx_get_spmv_profile(self._h, C.byref(n), C.byref(tot), C.byref(mn)))
+        return n.value, tot.value, mn.value
 
     def timer_start(self):
         check(lib.storm_hip_timer_start(self._h))
@@ -126,6 +137,7 @@ class DeviceVector:
             h = C.c_void_p()
             check(lib.storm_hip_vec_create(ctx._h, n_owned, n_halo, C.byref(h)))
             self._h = h
+            ctx._children.add(self)
         self.n_owned, self.n_halo = n_owned, n_halo
 
     # Field::assign(other, copy): allocate like `other`, zero-initialised; `copy` is ignored by the
@@ -135,6 +147,7 @@ class DeviceVector:
         h = C.c_void_p()
         check(lib.storm_hip_vec_create_like(other._h, C.byref(h)))
         self._h, self.ctx = h, other.ctx
+        self.ctx._children.add(self)
         self.n_owned, self.n_halo = other.n_owned, other.n_halo
 
     def shape(self):
@@ -334,6 +347,10 @@ class StencilMatrix:
 
     def __init__(self, ctx: Context, handle):
         self.ctx, self._h = ctx, handle
+        ctx._children.add(self)
+
+    def _free(self):
+        self.close()
 
     @classmethod
     def from_face_graph(cls, ctx: Context, g: FaceGraph) -> "StencilMatrix":

@@ -90,6 +90,9 @@ struct storm_hip_ctx {
   int64_t opt_ell_cap = 0;
   int64_t opt_spmv_variant = 0;
   int64_t opt_nt = 1;
+  int64_t opt_profile_spmv = 0;
+  std::vector<hipEvent_t> prof_events;  // pairs (start, stop), grown on demand
+  size_t prof_used = 0;
   // communicator
   storm::Comm *comm = nullptr;
   int n_ranks = 1, rank = 0;

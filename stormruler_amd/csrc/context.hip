@@ -72,6 +72,7 @@ int storm_hip_ctx_destroy(storm_hip_ctx *c) {
   (void)hipDeviceSynchronize();
   comm_destroy(c);
   for (auto &ev : c->ev_ring) (void)hipEventDestroy(ev);
+  for (auto &ev : c->prof_events) (void)hipEventDestroy(ev);
   (void)hipFree(c->d_partials);
   (void)hipFree(c->d_scalars);
   (void)hipHostFree(c->h_scalars);
@@ -113,7 +114,26 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   if (!strcmp(key, "ell_cap")) c->opt_ell_cap = value;
   else if (!strcmp(key, "spmv_variant")) c->opt_spmv_variant = value;
   else if (!strcmp(key, "nontemporal")) c->opt_nt = value;
+  else if (!strcmp(key, "profile_spmv")) c->opt_profile_spmv = value;
   else STORM_FAIL(STORM_HIP_E_INVALID, "ctx_set_option: unknown key '%s'", key);
+  return STORM_HIP_OK;
+}
+
+int storm_hip_ctx_get_spmv_profile(storm_hip_ctx *c, int64_t *launches, double *total_ms, double *min_ms) {
+  STORM_REQUIRE(c, "get_spmv_profile: null context");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  double total = 0.0, mn = 0.0;
+  const size_t pairs = c->prof_used / 2;
+  for (size_t i = 0; i < pairs; ++i) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->prof_events[2 * i], c->prof_events[2 * i + 1]));
+    total += ms;
+    if (i == 0 || ms < mn) mn = ms;
+  }
+  if (launches) *launches = (int64_t)pairs;
+  if (total_ms) *total_ms = total;
+  if (min_ms) *min_ms = mn;
+  c->prof_used = 0;
   return STORM_HIP_OK;
 }
 

@@ -195,6 +195,16 @@ static int launch_range(const storm_hip_op *op, Scal alpha, Scal beta, const dou
                         const int *slice_list, int64_t n_launch, DotArgs dot, bool want_dot,
                         const int *done) {
   if (n_launch <= 0) return STORM_HIP_OK;
+  storm_hip_ctx *c = op->ctx;
+  const bool prof = c->opt_profile_spmv != 0;
+  if (prof) {
+    while (c->prof_events.size() < c->prof_used + 2) {
+      hipEvent_t ev;
+      HIP_TRY(hipEventCreate(&ev));
+      c->prof_events.push_back(ev);
+    }
+    HIP_TRY(hipEventRecord(c->prof_events[c->prof_used], c->stream));
+  }
   const int nb = (int)((n_launch + 3) / 4);
   const bool nt = op->ctx->opt_nt != 0;
   const int variant = (int)op->ctx->opt_spmv_variant;
@@ -209,6 +219,10 @@ static int launch_range(const storm_hip_op *op, Scal alpha, Scal beta, const dou
   }
 #undef SPMV_GO
   HIP_TRY(hipGetLastError());
+  if (prof) {
+    HIP_TRY(hipEventRecord(c->prof_events[c->prof_used + 1], c->stream));
+    c->prof_used += 2;
+  }
   return STORM_HIP_OK;
 }
 

@@ -1,0 +1,85 @@
+"""One process per GPU: bootstrap the library's RCCL communicators through torch.distributed.
+
+torch.distributed is plumbing only (rendezvous, the id broadcast, barriers, the max-over-ranks
+of timings).  The data path -- halo planes and dot-product all-reduces -- runs inside
+libstorm_hip.so on its own RCCL communicators over xGMI (csrc/comm.hip).
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+
+def env_rank() -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) as torch.distributed.run exports them."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_process_group(backend: Optional[str] = None):
+    """Initialise torch.distributed from the environment (MASTER_ADDR defaults to 127.0.0.1)."""
+    import torch
+    import torch.distributed as td
+
+    rank, local_rank, world = env_rank()
+    if world == 1 and "MASTER_ADDR" not in os.environ:
+        return None
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+    if not td.is_initialized():
+        td.init_process_group(backend=backend, rank=rank, world_size=world)
+    return td
+
+
+def broadcast_bytes(payload: Optional[bytes], n: int, src: int = 0) -> bytes:
+    """Broadcast ``n`` bytes from ``src`` over the default process group (any backend)."""
+    import torch
+    import torch.distributed as td
+
+    dev = torch.device("cuda", torch.cuda.current_device()) if td.get_backend() == "nccl" else torch.device("cpu")
+    if td.get_rank() == src:
+        t = torch.tensor(list(payload), dtype=torch.uint8, device=dev)
+    else:
+        t = torch.zeros(n, dtype=torch.uint8, device=dev)
+    td.broadcast(t, src=src)
+    return bytes(t.cpu().numpy().tobytes())
+
+
+def connect(ctx) -> None:
+    """Give ``ctx`` its RCCL communicators: rank 0 draws the unique id, everyone joins."""
+    import torch.distributed as td
+
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+        ctx.comm_init(None, 1, 0)
+        return
+    from .api import Context
+
+    rank, world = td.get_rank(), td.get_world_size()
+    uid = Context.comm_unique_id() if rank == 0 else None
+    uid = broadcast_bytes(uid, 128, src=0)
+    ctx.comm_init(uid, world, rank)
+
+
+def allreduce_max(value: float) -> float:
+    import torch
+    import torch.distributed as td
+
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+        return value
+    dev = torch.device("cuda", torch.cuda.current_device()) if td.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    td.all_reduce(t, op=td.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier() -> None:
+    import torch.distributed as td
+
+    if td.is_available() and td.is_initialized() and td.get_world_size() > 1:
+        td.barrier()

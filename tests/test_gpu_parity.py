@@ -412,14 +412,25 @@ def test_full_size_properties_256(api, ctx, oracle):
     r = at.to_numpy().reshape(n, n, n)
     assert np.all(r[1:-1, 1:-1, 1:-1] == 0.0)
     assert np.isclose(r[0, 0, 0], 3 * 2.0 * n * n) and np.isclose(r[0, 5, 5], 2.0 * n * n)
-    # positive definiteness proxy + CG makes progress at full size
+    # CG at full size: the recurrence residual the solver reports equals the true residual
+    # |b - A x| recomputed from x, and the A-norm of the error decreases (x^T b grows monotonically
+    # for x0 = 0: phi(x) = x^T A x / 2 - x^T b is minimised over a growing Krylov space).
     b = api.DeviceVector(ctx, N)
     api.fill_with(b, 1.0)
-    xs = api.DeviceVector(ctx, N)
-    s = api.CgSolver()
-    s.num_iterations = 25
-    s.record_history = True
-    s.solve(xs, b, api.HipStencilOperator(mat, -1.0, 0.0))
-    assert s.iteration == 25 and s.history[-1] < s.history[0]
-    # first residual = |b| = sqrt(N)
-    assert np.isclose(s.history[0], np.sqrt(N), rtol=1e-14)
+    op = api.HipStencilOperator(mat, -1.0, 0.0)
+    prev_phi = 0.0
+    for iters in (5, 25):
+        xs = api.DeviceVector(ctx, N)
+        s = api.CgSolver()
+        s.num_iterations = iters
+        s.absolute_error_tolerance = s.relative_error_tolerance = 0.0
+        s.record_history = True
+        assert not s.solve(xs, b, op)
+        assert s.iteration == iters and s.num_applies == iters + 1
+        assert np.isclose(s.history[0], np.sqrt(N), rtol=1e-14)  # |b - A 0| = sqrt(N)
+        true_res = op.ResidualNorm(b, xs)
+        assert abs(true_res - s.history[-1]) <= 1e-9 * s.history[0]
+        op.mul(at, xs)
+        phi = 0.5 * api.dot_product(xs, at) - api.dot_product(xs, b)
+        assert phi < prev_phi
+        prev_phi = phi
