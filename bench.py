@@ -41,6 +41,7 @@ def main() -> int:
     ap.add_argument("--ordering", default="natural", choices=["natural", "tile"])
     ap.add_argument("--variant", type=int, default=-1, help="SpMV kernel variant override")
     ap.add_argument("--nontemporal", type=int, default=-1)
+    ap.add_argument("--opt", action="append", default=[], help="library option key=value (repeatable)")
     args = ap.parse_args()
 
     import numpy as np
@@ -79,6 +80,9 @@ def main() -> int:
         ctx.set_option("spmv_variant", args.variant)
     if args.nontemporal >= 0:
         ctx.set_option("nontemporal", args.nontemporal)
+    for kv in args.opt:
+        k_, v_ = kv.split("=")
+        ctx.set_option(k_, int(v_))
     dist.connect(ctx)
     mat = api.StencilMatrix.from_face_graph(ctx, g)
     if plan is not None and plan.n_nbrs:

@@ -27,7 +27,7 @@ struct EwPtrs {
 };
 
 template <class F>
-__global__ __launch_bounds__(kBlock) void ew_kernel(int64_t n, EwPtrs p, F f, const int *done) {
+__global__ __launch_bounds__(kBlock) void ew_kernel(int64_t n, EwPtrs p, F f, const int *done, int rev) {
   if (done && *done) return;
   f.prepare();
   const int64_t n2 = n >> 1;
@@ -36,7 +36,8 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(int64_t n, EwPtrs p, F f, co
   const double2 *__restrict__ a2 = reinterpret_cast<const double2 *>(p.x0);
   const double2 *__restrict__ b2 = reinterpret_cast<const double2 *>(p.x1);
 #pragma unroll 2
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
+  for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < n2; i0 += stride) {
+    const int64_t i = rev ? n2 - 1 - i0 : i0;
     double2 vy = make_double2(0, 0), va = make_double2(0, 0), vb = make_double2(0, 0);
     if (F::reads_y) vy = y2[i];
     if (F::nin > 0) va = a2[i];
@@ -99,7 +100,8 @@ struct BicgPF {
 template <class F>
 static int launch_ew(storm_hip_ctx *c, int64_t n, EwPtrs p, F f, const int *done) {
   if (n <= 0) return STORM_HIP_OK;
-  hipLaunchKernelGGL(ew_kernel<F>, dim3(ew_blocks(c, n)), dim3(kBlock), 0, c->stream, n, p, f, done);
+  hipLaunchKernelGGL(ew_kernel<F>, dim3(ew_blocks(c, n)), dim3(kBlock), 0, c->stream, n, p, f, done,
+                     c->next_dir());
   HIP_TRY(hipGetLastError());
   return STORM_HIP_OK;
 }

@@ -47,6 +47,7 @@ constexpr int kNumXcd = 8;           // MI355X: 8 XCDs, blocks dealt round-robin
 constexpr int kMaxReduceBlocks = 2048;  // 256 CUs x 8 resident 256-thread blocks
 constexpr int kMaxMulti = 64;        // widest multi-dot / multi-axpy in one launch
 constexpr int kSlab = 256;           // doubles in the device scalar slab
+constexpr int kStage2 = 128;         // blocks of the first pass of a two-pass final reduction
 
 // Device-resident solver state: every scalar a Krylov loop carries, so no
 // alpha/beta/omega/Givens value ever visits the host (SURVEY.md section 7
@@ -78,7 +79,9 @@ struct storm_hip_ctx {
   std::string name;
   int64_t total_mem = 0;
   // reduction workspace
-  double *d_partials = nullptr;       // [kMaxReduceBlocks * kMaxMulti]
+  double *d_partials = nullptr;       // [partials_capacity] per-block partial sums
+  int64_t partials_capacity = 0;
+  double *d_partials2 = nullptr;      // [kMaxMulti * kStage2] second-stage partials
   double *d_scalars = nullptr;        // [kMaxMulti] results of host-visible reductions
   double *h_scalars = nullptr;        // pinned mirror
   const double **d_ptrs = nullptr;    // [kMaxMulti] pointer table for multi-dot / multi-axpy
@@ -88,9 +91,18 @@ struct storm_hip_ctx {
   std::vector<hipEvent_t> ev_ring;
   // options
   int64_t opt_ell_cap = 0;
-  int64_t opt_spmv_variant = 0;
+  int64_t opt_spmv_variant = 0;      // 0 gathers from global (default), 1 + LDS x window
+  int64_t opt_spmv_xcd_remap = 0;    // 1: contiguous slice run per XCD (measured slower)
   int64_t opt_nt = 1;
   int64_t opt_profile_spmv = 0;
+  // Zig-zag sweeps: consecutive streaming kernels walk the rows in opposite directions, so each
+  // one starts on the bytes its predecessor touched last, which are still in the 256 MiB
+  // Infinity Cache (a vector is 134 MB at 256^3; same-direction sweeps would evict every line
+  // just before its reuse).
+  int64_t opt_zigzag = 0;   // measured: no gain on MI355X (profiles/r01_notes.md); off by default
+  int64_t opt_fuse_dot = 1;  // 0: reductions after an SpMV run as separate kernels (A/B knob)
+  int sweep_dir = 0;
+  int next_dir() { if (!opt_zigzag) return 0; sweep_dir ^= 1; return sweep_dir; }
   std::vector<hipEvent_t> prof_events;  // pairs (start, stop), grown on demand
   size_t prof_used = 0;
   // communicator
@@ -126,10 +138,8 @@ struct storm_hip_op {
   int64_t n_rows = 0, n_halo = 0;
   int64_t n_slices = 0, n_interior_slices = 0;
   int64_t nnz = 0, ell_slots = 0, max_row_len = 0;
-  int64_t *d_slice_ptr = nullptr;  // [n_slices + 1] element offset of each slice (multiple of 64)
-  int *d_col = nullptr;            // [ell_slots]
-  double *d_val = nullptr;         // [ell_slots]
-  double *d_ext = nullptr;         // [n_rows] extra diagonal
+  int64_t *d_slice_off = nullptr;  // [n_slices + 1] byte offset of each slice record
+  char *d_pack = nullptr;          // slice records: [ext 64 f64][col W*64 i32][val W*64 f64]
   // tail
   int64_t tail_rows = 0, tail_nnz = 0;
   int *d_tail_row = nullptr;       // [tail_rows]

@@ -52,7 +52,9 @@ int storm_hip_ctx_create(int device_id, storm_hip_ctx **out) {
   HIP_TRY(hipEventCreateWithFlags(&c->ev_halo_done, hipEventDisableTiming));
   HIP_TRY(hipEventCreate(&c->ev_t0));
   HIP_TRY(hipEventCreate(&c->ev_t1));
-  HIP_TRY(hipMalloc(&c->d_partials, sizeof(double) * kMaxReduceBlocks * kMaxMulti));
+  c->partials_capacity = (int64_t)kMaxReduceBlocks * kMaxMulti;
+  HIP_TRY(hipMalloc(&c->d_partials, sizeof(double) * (size_t)c->partials_capacity));
+  HIP_TRY(hipMalloc(&c->d_partials2, sizeof(double) * kMaxMulti * kStage2));
   HIP_TRY(hipMalloc(&c->d_scalars, sizeof(double) * kMaxMulti));
   HIP_TRY(hipHostMalloc((void **)&c->h_scalars, sizeof(double) * kMaxMulti, hipHostMallocDefault));
   HIP_TRY(hipMalloc((void **)&c->d_ptrs, sizeof(double *) * kMaxMulti));
@@ -74,6 +76,7 @@ int storm_hip_ctx_destroy(storm_hip_ctx *c) {
   for (auto &ev : c->ev_ring) (void)hipEventDestroy(ev);
   for (auto &ev : c->prof_events) (void)hipEventDestroy(ev);
   (void)hipFree(c->d_partials);
+  (void)hipFree(c->d_partials2);
   (void)hipFree(c->d_scalars);
   (void)hipHostFree(c->h_scalars);
   (void)hipFree((void *)c->d_ptrs);
@@ -114,7 +117,10 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   if (!strcmp(key, "ell_cap")) c->opt_ell_cap = value;
   else if (!strcmp(key, "spmv_variant")) c->opt_spmv_variant = value;
   else if (!strcmp(key, "nontemporal")) c->opt_nt = value;
+  else if (!strcmp(key, "spmv_xcd_remap")) c->opt_spmv_xcd_remap = value;
   else if (!strcmp(key, "profile_spmv")) c->opt_profile_spmv = value;
+  else if (!strcmp(key, "zigzag")) c->opt_zigzag = value;
+  else if (!strcmp(key, "fuse_dot")) c->opt_fuse_dot = value;
   else STORM_FAIL(STORM_HIP_E_INVALID, "ctx_set_option: unknown key '%s'", key);
   return STORM_HIP_OK;
 }

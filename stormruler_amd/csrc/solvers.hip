@@ -149,6 +149,23 @@ __global__ __launch_bounds__(kBlock) void reduce_step_kernel(const double *__res
   if (step != STEP_NONE && threadIdx.x == 0) do_step(step, st, g);
 }
 
+// First pass of a two-pass final reduction (used when a kernel left > 4096 partials, e.g. the
+// 65 536 per-block partials of a 256^3 SpMV): kStage2 blocks fold the k arrays to kStage2 each.
+__global__ __launch_bounds__(kBlock) void reduce_stage1_kernel(const double *__restrict__ partials, int nblocks,
+                                                               double *__restrict__ out, const SolverState *st,
+                                                               bool force) {
+  if (!force && st->done) return;
+  __shared__ double lds4[4];
+  const int j = blockIdx.y, g = blockIdx.x;
+  const int chunk = (nblocks + gridDim.x - 1) / gridDim.x;
+  const int i0 = g * chunk, i1 = min(i0 + chunk, nblocks);
+  const double *p = partials + (int64_t)j * nblocks;
+  double v = 0.0;
+  for (int i = i0 + threadIdx.x; i < i1; i += kBlock) v += p[i];
+  const double sum = block_sum256(v, lds4);
+  if (threadIdx.x == 0) out[j * gridDim.x + g] = sum;
+}
+
 __global__ void step_kernel(int step, SolverState *st, GmresDev g, bool force) {
   if (!force && st->done) return;
   do_step(step, st, g);
@@ -184,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void init_residual_kernel(int64_t n, double
 __global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, SolverState *st, double *__restrict__ x,
                                                            double *__restrict__ r, const double *__restrict__ p,
                                                            const double *__restrict__ z,
-                                                           double *__restrict__ partials) {
+                                                           double *__restrict__ partials, int rev) {
   if (st->done) return;
   __shared__ double lds4[4];
   const double alpha = safe_divide(st->s[S_GAMMA], st->s[S_PZ]);
@@ -193,7 +210,8 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, SolverStat
   double2 *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r);
   const double2 *p2 = reinterpret_cast<const double2 *>(p), *z2 = reinterpret_cast<const double2 *>(z);
 #pragma unroll 2
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
+  for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < n2; i0 += stride) {
+    const int64_t i = rev ? n2 - 1 - i0 : i0;
     double2 vx = x2[i], vr = r2[i];
     const double2 vp = p2[i], vz = z2[i];
     vx.x += alpha * vp.x, vx.y += alpha * vp.y;
@@ -311,13 +329,21 @@ struct Driver {
     return finish_ptrs(nblocks, k, out, contig ? contiguous : nullptr, step, force);
   }
   int finish_ptrs(int nblocks, int k, OutSlots out, double *contiguous, int step, bool force = false) {
+    const double *partials = c->d_partials;
+    if (nblocks > 4096) {
+      hipLaunchKernelGGL(reduce_stage1_kernel, dim3(kStage2, k), dim3(kBlock), 0, c->stream, c->d_partials,
+                         nblocks, c->d_partials2, st, force);
+      HIP_TRY(hipGetLastError());
+      partials = c->d_partials2;
+      nblocks = kStage2;
+    }
     if (c->n_ranks == 1) {
-      hipLaunchKernelGGL(reduce_step_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->d_partials, nblocks, k,
+      hipLaunchKernelGGL(reduce_step_kernel, dim3(1), dim3(kBlock), 0, c->stream, partials, nblocks, k,
                          out, step, st, g, force);
       HIP_TRY(hipGetLastError());
       return STORM_HIP_OK;
     }
-    hipLaunchKernelGGL(reduce_step_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->d_partials, nblocks, k, out,
+    hipLaunchKernelGGL(reduce_step_kernel, dim3(1), dim3(kBlock), 0, c->stream, partials, nblocks, k, out,
                        (int)STEP_NONE, st, g, force);
     HIP_TRY(hipGetLastError());
     if (contiguous) {
@@ -339,7 +365,8 @@ struct Driver {
     sd.yy = dot_yy;
     sd.partials = c->d_partials;
     sd.nblocks_out = nblocks;
-    const bool want = dot_w != nullptr || dot_yy;
+    const bool want = (dot_w != nullptr || dot_yy) && c->opt_fuse_dot != 0;
+    if (!want && nblocks) *nblocks = 0;
     return spmv_launch(op, host_scal(alpha), host_scal(beta), x, y, want ? &sd : nullptr,
                        predicated ? done : nullptr);
   }
@@ -490,7 +517,7 @@ int storm_hip_solve_cg(const storm_hip_op *op, double alpha, double beta, const 
     }
     // x += alpha p; r -= alpha z; gamma = <r,r>       SolverCg.hpp:98-99,115
     hipLaunchKernelGGL(cg_update_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, x->d, r, p, z,
-                       c->d_partials);
+                       c->d_partials, c->next_dir());
     HIP_TRY(hipGetLastError());
     {
       const int slots[1] = {S_GAMMA_NEW};

@@ -2,16 +2,20 @@
 // as a gather-form SpMV on a sliced-ELL / CSR-tail hybrid.
 //
 // Layout in HBM (built once per operator on the host, slot order = face order):
-//   slice s = rows [64 s, 64 s + 64): one wavefront.  Its entries are stored
-//   column-major:  slot k of row r sits at  slice_ptr[s] + 64 k + (r mod 64),
-//   so the 64 lanes of a wave read 64 consecutive int32 columns (256 B) and 64
-//   consecutive fp64 weights (512 B) per slot -- fully coalesced.
-//   Width of a slice = min(longest row in it, ell_cap); what does not fit goes
-//   to a CSR tail handled by a wave-per-row kernel with a __shfl_down reduction.
-//   Padding slots carry weight 0 and the row's own index as column.
+//   slice s = rows [64 s, 64 s + 64): one wavefront.  Everything the slice streams is ONE
+//   contiguous record at byte offset slice_off[s]:
+//        [ ext : 64 x f64 ][ col : W x 64 x i32 ][ val : W x 64 x f64 ]      (512 + 768 W bytes)
+//   column-major inside the record, so the 64 lanes of a wave read 64 consecutive columns
+//   (256 B) and 64 consecutive weights (512 B) per slot.  Packing ext/col/val of a slice
+//   into one record leaves the kernel three DRAM streams (records, x, y) instead of five;
+//   on MI355X the number of concurrent streams, not L2 locality, decided the rate (measured:
+//   profiles/r01_notes.md).
+//   W = min(longest row of the slice, ell_cap); what does not fit goes to a CSR tail handled
+//   by a wave-per-row kernel with a __shfl_down reduction.  Padding slots carry weight 0 and
+//   the row's own index as column.
 // Arithmetic:  y_i = beta x_i + alpha ( sum_k w_ik (x[col_ik] - x_i) + ext_i x_i )
-//   -- the difference form of the reference's flux  (c[out] - c[in]), which keeps
-//   the cancellation behaviour of the face loop (no large diagonal * x_i term).
+//   -- the difference form of the reference's flux  (c[out] - c[in]), which keeps the
+//   cancellation behaviour of the face loop (no large diagonal * x_i term).
 // Algorithmic bytes per apply: 8N (x) + 8N (y) + 8N (ext) + 12 nnz.
 #include <algorithm>
 #include <cmath>
@@ -24,12 +28,14 @@ namespace storm {
 
 __device__ __forceinline__ double ld_scal2(const Scal &s) { return s.p ? (*s.p) * s.sign : s.v; }
 
+constexpr int kExtBytes = kWave * 8;      // 512
+constexpr int kSlotBytes = kWave * 12;    // 768: one ELL slot of a slice (64 cols + 64 vals)
+
 struct SellArgs {
-  const int64_t *__restrict__ slice_ptr;
-  const int *__restrict__ col;
-  const double *__restrict__ val;
-  const double *__restrict__ ext;
+  const char *__restrict__ pack;          // slice records
+  const int64_t *__restrict__ slice_off;  // [n_slices + 1] byte offsets
   int64_t n_rows;
+  int uniform_width;                      // > 0: every slice has this width, slice_off is not read
 };
 
 struct DotArgs {
@@ -40,9 +46,11 @@ struct DotArgs {
   int block_offset;   // where this launch's blocks start
 };
 
-// Blocks are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8), each with a
-// private 4 MiB L2.  Remap so every XCD walks one contiguous run of slices: the x rows a
-// slice gathers from neighbouring slices are then found in the same L2.
+// Blocks are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8), each with a private
+// 4 MiB L2.  The remap gives every XCD one contiguous run of slices (neighbour rows of x then
+// hit that XCD's L2).  Measured on the 256^3 problem it LOSES 7 %: eight XCDs walking eight
+// distant regions means 8x the concurrent DRAM streams, and the x re-reads it avoids are served
+// by the 256 MiB Infinity Cache anyway.  Kept as an option (spmv_xcd_remap), off by default.
 __device__ __forceinline__ int xcd_remap(int b, int nb) {
   const int q = nb / kNumXcd, r = nb % kNumXcd;
   const int x = b % kNumXcd, j = b / kNumXcd;
@@ -58,22 +66,48 @@ __device__ __forceinline__ double ld_d(const double *p) {
   return NT ? __builtin_nontemporal_load(p) : *p;
 }
 
+// 64-lane sum with DPP moves (VALU only; __shfl_down compiles to ds_bpermute, which costs a
+// trip through the LDS crossbar per step).  The total lands in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_to_lane63(double v) {
+  v += dpp_mov<0xb1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4e, 0xf>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x114, 0xf>(v);  // row_shr:4
+  v += dpp_mov<0x118, 0xf>(v);  // row_shr:8   -> lanes 12..15 of each row hold the row sum
+  v += dpp_mov<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_mov<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+  return v;
+}
+
 constexpr int kChunk = 8;  // slots whose (col, val) loads are issued before the first gather
 
-// VARIANT 0: gathers straight from global memory (L1/L2 serve the reuse).
-// VARIANT 1: the block's own 256 x rows are staged in LDS and in-window gathers read LDS.
+// One wavefront per slice, one row per lane, 4 slices per 256-thread block.
+//   NT      : record / y traffic marked non-temporal so it does not evict x from L2 (+15 %).
+//   DOT     : epilogue writes per-block partials of <w, y> and <y, y> (fused reductions).
+//   VARIANT : 0 gathers x straight from global memory (L1/L2/Infinity Cache serve the reuse);
+//             1 stages the block's own 256 x rows in LDS and reads in-window neighbours there
+//               (measured: no gain over 0 -- the +-1 neighbours already hit L1).
 template <bool NT, bool DOT, int VARIANT, bool XCD>
 __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SellArgs A, Scal alpha_s, Scal beta_s,
                                                            const double *__restrict__ x,
                                                            double *__restrict__ y,
                                                            const int *__restrict__ slice_list,
                                                            int64_t n_launch_slices, DotArgs dot,
-                                                           const int *done) {
-  if (done && *done) return;
-  __shared__ double lds4[4];
+                                                           const int *done, int rev) {
+  // The `done` predicate is only needed before the first store: issue its (scalar) load now and
+  // test it after the gathers, so it never sits at the head of a wave's dependency chain.
+  const int done_flag = done ? *done : 0;
   __shared__ double xwin[VARIANT == 1 ? kBlock : 1];
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-  const int lb = XCD ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: slice math runs on the SALU
+  const int bidx = rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;  // zig-zag sweep direction
+  const int lb = XCD ? xcd_remap(bidx, gridDim.x) : bidx;
   const int64_t sl = (int64_t)lb * (kBlock / kWave) + wave;
   const bool wave_active = sl < n_launch_slices;
   const double alpha = ld_scal2(alpha_s), beta = ld_scal2(beta_s);
@@ -88,6 +122,7 @@ __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SellArgs A, Scal alph
     row = slice * kWave + lane;
     valid = row < A.n_rows;
     xi = valid ? x[row] : 0.0;
+    if (DOT && dot.w) wi = (dot.w == x) ? xi : (valid ? dot.w[row] : 0.0);  // early: off the tail of the chain
   }
   int64_t row0 = 0;
   if (VARIANT == 1) {
@@ -97,11 +132,20 @@ __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SellArgs A, Scal alph
     __syncthreads();
   }
   if (wave_active) {
-    const int64_t base = A.slice_ptr[slice];
-    const int width = (int)((A.slice_ptr[slice + 1] - base) >> 6);
-    const int *cp = A.col + base + lane;
-    const double *vp = A.val + base + lane;
-    const double ext = valid ? ld_d<NT>(A.ext + row) : 0.0;
+    int64_t base;
+    int width;
+    if (A.uniform_width > 0) {
+      width = A.uniform_width;
+      base = slice * (int64_t)(kExtBytes + kSlotBytes * width);
+    } else {
+      base = A.slice_off[slice];
+      width = (int)((A.slice_off[slice + 1] - base - kExtBytes) / kSlotBytes);
+    }
+    const char *rec = A.pack + base;
+    const double *ep = reinterpret_cast<const double *>(rec) + lane;
+    const int *cp = reinterpret_cast<const int *>(rec + kExtBytes) + lane;
+    const double *vp = reinterpret_cast<const double *>(rec + kExtBytes + (int64_t)width * (kWave * 4)) + lane;
+    const double ext = ld_d<NT>(ep);
     double acc = 0.0;
     for (int k0 = 0; k0 < width; k0 += kChunk) {
       int c[kChunk];
@@ -109,8 +153,8 @@ __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SellArgs A, Scal alph
 #pragma unroll
       for (int k = 0; k < kChunk; ++k) {
         if (k0 + k < width) {
-          c[k] = ld_i<NT>(cp + (int64_t)(k0 + k) * kWave);
-          v[k] = ld_d<NT>(vp + (int64_t)(k0 + k) * kWave);
+          c[k] = ld_i<NT>(cp + (k0 + k) * kWave);
+          v[k] = ld_d<NT>(vp + (k0 + k) * kWave);
         }
       }
 #pragma unroll
@@ -128,29 +172,25 @@ __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SellArgs A, Scal alph
       }
     }
     yi = beta * xi + alpha * (acc + ext * xi);
-    if (valid) {
+    if (valid && !done_flag) {
       if (NT) __builtin_nontemporal_store(yi, y + row);
       else y[row] = yi;
-      if (DOT && dot.w) wi = dot.w[row];
-    } else {
-      yi = 0.0;
     }
+    if (!valid) yi = 0.0;
   }
+  if (done_flag) return;  // block-uniform
   if (DOT) {
-    // block_sum inlined twice (fixed order) -- partials of <w, y> and <y, y>.
+    // One partial per WAVE (64-lane DPP tree, lane 63 stores): no LDS, no block barrier.
+    // (A per-block partial with __syncthreads cost 6 % of the kernel: every wave of a block had
+    // to outlive its slowest sibling.)  The 4x longer partial arrays are folded by the two-pass
+    // final reduction in solvers.hip.
     double a = dot.w ? wi * yi : 0.0, b = dot.yy ? yi * yi : 0.0;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      a += __shfl_down(a, off, kWave);
-      b += __shfl_down(b, off, kWave);
-    }
-    __shared__ double lds4b[4];
-    if (lane == 0) lds4[wave] = a, lds4b[wave] = b;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const int slot = dot.block_offset + blockIdx.x;
-      dot.partials[slot] = (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
-      if (dot.yy) dot.partials[dot.nblocks_total + slot] = (lds4b[0] + lds4b[1]) + (lds4b[2] + lds4b[3]);
+    a = wave_sum_to_lane63(a);
+    if (dot.yy) b = wave_sum_to_lane63(b);
+    if (lane == kWave - 1) {
+      const int slot = dot.block_offset + (int)blockIdx.x * (kBlock / kWave) + wave;
+      dot.partials[slot] = a;
+      if (dot.yy) dot.partials[dot.nblocks_total + slot] = b;
     }
   }
 }
@@ -181,15 +221,22 @@ __global__ __launch_bounds__(kBlock) void spmv_tail_kernel(int64_t n_tail, const
 template <bool NT, bool DOT, int VARIANT>
 static void launch_sell(const storm_hip_op *op, int nb, Scal alpha, Scal beta, const double *x, double *y,
                         const int *slice_list, int64_t n_launch, DotArgs dot, const int *done) {
-  SellArgs A{op->d_slice_ptr, op->d_col, op->d_val, op->d_ext, op->n_rows};
-  // The XCD remap only helps when consecutive logical blocks are consecutive slices.
-  if (slice_list == nullptr)
-    hipLaunchKernelGGL((spmv_sell_kernel<NT, DOT, VARIANT, true>), dim3(nb), dim3(kBlock), 0,
-                       op->ctx->stream, A, alpha, beta, x, y, slice_list, n_launch, dot, done);
-  else
-    hipLaunchKernelGGL((spmv_sell_kernel<NT, DOT, 0, false>), dim3(nb), dim3(kBlock), 0, op->ctx->stream,
-                       A, alpha, beta, x, y, slice_list, n_launch, dot, done);
+  SellArgs A{op->d_pack, op->d_slice_off, op->n_rows, op->uniform_width};
+  hipStream_t st = op->ctx->stream;
+  const int rev = op->ctx->next_dir();
+  if (slice_list == nullptr && op->ctx->opt_spmv_xcd_remap != 0) {
+    hipLaunchKernelGGL((spmv_sell_kernel<NT, DOT, VARIANT, true>), dim3(nb), dim3(kBlock), 0, st, A, alpha,
+                       beta, x, y, slice_list, n_launch, dot, done, rev);
+  } else if (slice_list == nullptr) {
+    hipLaunchKernelGGL((spmv_sell_kernel<NT, DOT, VARIANT, false>), dim3(nb), dim3(kBlock), 0, st, A, alpha,
+                       beta, x, y, slice_list, n_launch, dot, done, rev);
+  } else {  // listed slices are not consecutive: the LDS window does not apply
+    hipLaunchKernelGGL((spmv_sell_kernel<NT, DOT, 0, false>), dim3(nb), dim3(kBlock), 0, st, A, alpha, beta,
+                       x, y, slice_list, n_launch, dot, done, rev);
+  }
 }
+
+static inline int blocks_for(int64_t n_launch_slices) { return (int)((n_launch_slices + 3) / 4); }
 
 static int launch_range(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, double *y,
                         const int *slice_list, int64_t n_launch, DotArgs dot, bool want_dot,
@@ -205,18 +252,18 @@ static int launch_range(const storm_hip_op *op, Scal alpha, Scal beta, const dou
     }
     HIP_TRY(hipEventRecord(c->prof_events[c->prof_used], c->stream));
   }
-  const int nb = (int)((n_launch + 3) / 4);
-  const bool nt = op->ctx->opt_nt != 0;
-  const int variant = (int)op->ctx->opt_spmv_variant;
+  const int nb = blocks_for(n_launch);
+  const bool nt = c->opt_nt != 0;
 #define SPMV_GO(NT_, DOT_, VAR_) \
   launch_sell<NT_, DOT_, VAR_>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done)
-  if (variant == 1) {
-    if (nt) { if (want_dot) SPMV_GO(true, true, 1); else SPMV_GO(true, false, 1); }
-    else    { if (want_dot) SPMV_GO(false, true, 1); else SPMV_GO(false, false, 1); }
-  } else {
-    if (nt) { if (want_dot) SPMV_GO(true, true, 0); else SPMV_GO(true, false, 0); }
-    else    { if (want_dot) SPMV_GO(false, true, 0); else SPMV_GO(false, false, 0); }
-  }
+#define SPMV_VAR(VAR_)                                                                      \
+  do {                                                                                      \
+    if (nt) { if (want_dot) SPMV_GO(true, true, VAR_); else SPMV_GO(true, false, VAR_); }   \
+    else    { if (want_dot) SPMV_GO(false, true, VAR_); else SPMV_GO(false, false, VAR_); } \
+  } while (0)
+  if (c->opt_spmv_variant == 1) SPMV_VAR(1);
+  else SPMV_VAR(0);
+#undef SPMV_VAR
 #undef SPMV_GO
   HIP_TRY(hipGetLastError());
   if (prof) {
@@ -226,7 +273,7 @@ static int launch_range(const storm_hip_op *op, Scal alpha, Scal beta, const dou
   return STORM_HIP_OK;
 }
 
-int spmv_grid_blocks(const storm_hip_op *op) { return (int)((op->n_slices + 3) / 4); }
+int spmv_grid_blocks(const storm_hip_op *op) { return blocks_for(op->n_slices); }
 
 int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, double *y,
                 const SpmvDot *sd, const int *done) {
@@ -234,16 +281,15 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
   const bool fuse_dot = sd != nullptr && op->tail_rows == 0;
   const bool split = op->halo.n_nbrs > 0 && c->n_ranks > 1;
   DotArgs dot{nullptr, nullptr, 0, 0, 0};
-  int nb_total = 0;
-  const int nb_int = split ? (int)((op->n_interior + 3) / 4) : spmv_grid_blocks(op);
-  const int nb_bnd = split ? (int)((op->n_boundary + 3) / 4) : 0;
-  nb_total = nb_int + nb_bnd;
+  const int nb_int = split ? blocks_for(op->n_interior) : spmv_grid_blocks(op);
+  const int nb_bnd = split ? blocks_for(op->n_boundary) : 0;
+  const int nb_total = nb_int + nb_bnd;
   if (fuse_dot) {
-    STORM_REQUIRE(2 * (int64_t)nb_total <= (int64_t)kMaxReduceBlocks * kMaxMulti,
+    STORM_REQUIRE(8 * (int64_t)nb_total <= c->partials_capacity,
                   "spmv: %d blocks exceed the partials workspace", nb_total);
-    dot = DotArgs{sd->w, sd->partials, sd->yy ? 1 : 0, nb_total, 0};
+    dot = DotArgs{sd->w, sd->partials, sd->yy ? 1 : 0, 4 * nb_total, 0};  // one partial per wave
   }
-  if (sd && sd->nblocks_out) *sd->nblocks_out = fuse_dot ? nb_total : 0;
+  if (sd && sd->nblocks_out) *sd->nblocks_out = fuse_dot ? 4 * nb_total : 0;
 
   if (!split) {
     STORM_TRY(launch_range(op, alpha, beta, x, y, nullptr, op->n_slices, dot, fuse_dot, done));
@@ -252,7 +298,7 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
     STORM_TRY(comm_halo_exchange_begin(op, const_cast<double *>(x)));
     STORM_TRY(launch_range(op, alpha, beta, x, y, op->d_interior, op->n_interior, dot, fuse_dot, done));
     STORM_TRY(comm_halo_exchange_end(op));
-    dot.block_offset = nb_int;
+    dot.block_offset = 4 * nb_int;
     STORM_TRY(launch_range(op, alpha, beta, x, y, op->d_boundary, op->n_boundary, dot, fuse_dot, done));
   }
   if (op->tail_rows > 0) {
@@ -300,7 +346,7 @@ static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vect
     const double mean = n > 0 ? (double)op->nnz / (double)n : 0.0;
     cap = std::max<int64_t>(8, (int64_t)std::ceil(2.0 * mean));
   }
-  std::vector<int64_t> slice_ptr(n_slices + 1, 0);
+  std::vector<int64_t> slice_off(n_slices + 1, 0);  // bytes
   std::vector<int> width(n_slices, 0);
   bool uniform = true;
   for (int64_t s = 0; s < n_slices; ++s) {
@@ -309,30 +355,35 @@ static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vect
     for (int64_t r = s * kWave; r < r1; ++r) w = std::max(w, row_ptr[r + 1] - row_ptr[r]);
     w = std::min(w, cap);
     width[s] = (int)w;
-    slice_ptr[s + 1] = slice_ptr[s] + w * kWave;
+    slice_off[s + 1] = slice_off[s] + kExtBytes + w * kSlotBytes;
     if (s > 0 && width[s] != width[0]) uniform = false;
+    op->ell_slots += w * kWave;
   }
-  op->uniform_width = (uniform && n_slices > 0) ? width[0] : 0;
-  op->ell_slots = slice_ptr[n_slices];
-  std::vector<int> ecol((size_t)op->ell_slots);
-  std::vector<double> eval((size_t)op->ell_slots, 0.0);
+  op->uniform_width = (uniform && n_slices > 0 && width[0] > 0) ? width[0] : 0;
+  std::vector<char> pack((size_t)slice_off[n_slices], 0);
   std::vector<int> tail_row, tail_col;
   std::vector<int64_t> tail_ptr(1, 0);
   std::vector<double> tail_val;
   for (int64_t s = 0; s < n_slices; ++s) {
+    char *rec = pack.data() + slice_off[s];
+    double *e_ = reinterpret_cast<double *>(rec);
+    int *c_ = reinterpret_cast<int *>(rec + kExtBytes);
+    double *v_ = reinterpret_cast<double *>(rec + kExtBytes + (int64_t)width[s] * (kWave * 4));
     bool touches_halo = false;
     for (int l = 0; l < kWave; ++l) {
       const int64_t r = s * kWave + l;
       const int64_t pad_col = r < n ? r : (n > 0 ? n - 1 : 0);
       const int64_t b = r < n ? row_ptr[r] : 0, e = r < n ? row_ptr[r + 1] : 0;
+      e_[l] = r < n ? ext[(size_t)r] : 0.0;
       for (int k = 0; k < width[s]; ++k) {
-        const size_t at = (size_t)(slice_ptr[s] + (int64_t)k * kWave + l);
+        const int at = k * kWave + l;
         if (b + k < e) {
-          ecol[at] = col[(size_t)(b + k)];
-          eval[at] = val[(size_t)(b + k)];
-          touches_halo |= ecol[at] >= n;
+          c_[at] = col[(size_t)(b + k)];
+          v_[at] = val[(size_t)(b + k)];
+          touches_halo |= c_[at] >= n;
         } else {
-          ecol[at] = (int)pad_col;
+          c_[at] = (int)pad_col;
+          v_[at] = 0.0;
         }
       }
       if (e - b > width[s]) {
@@ -353,14 +404,23 @@ static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vect
 
   int st = STORM_HIP_OK;
   int64_t bytes = 0;
-  if ((st = upload(&op->d_slice_ptr, slice_ptr, &bytes)) || (st = upload(&op->d_col, ecol, &bytes)) ||
-      (st = upload(&op->d_val, eval, &bytes)) || (st = upload(&op->d_ext, ext, &bytes)) ||
+  if ((st = upload(&op->d_slice_off, slice_off, &bytes)) || (st = upload(&op->d_pack, pack, &bytes)) ||
       (st = upload(&op->d_tail_row, tail_row, &bytes)) || (st = upload(&op->d_tail_ptr, tail_ptr, &bytes)) ||
       (st = upload(&op->d_tail_col, tail_col, &bytes)) || (st = upload(&op->d_tail_val, tail_val, &bytes))) {
     storm_hip_op_destroy(op);
     return st;
   }
   op->device_bytes = bytes;
+  // fused-dot partials: two per SpMV block
+  const int64_t need = 8 * (int64_t)blocks_for(n_slices) + 16 + 2 * kMaxMulti;
+  if (need > c->partials_capacity) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    double *bigger = nullptr;
+    HIP_TRY(hipMalloc(&bigger, sizeof(double) * (size_t)need));
+    (void)hipFree(c->d_partials);
+    c->d_partials = bigger;
+    c->partials_capacity = need;
+  }
   *out = op;
   return STORM_HIP_OK;
 }
@@ -519,10 +579,8 @@ int storm_hip_op_destroy(storm_hip_op *op) {
   if (op->ctx) (void)storm_hip_ctx_sync(op->ctx);
   (void)hipFree(op->d_interior);
   (void)hipFree(op->d_boundary);
-  (void)hipFree(op->d_slice_ptr);
-  (void)hipFree(op->d_col);
-  (void)hipFree(op->d_val);
-  (void)hipFree(op->d_ext);
+  (void)hipFree(op->d_slice_off);
+  (void)hipFree(op->d_pack);
   (void)hipFree(op->d_tail_row);
   (void)hipFree(op->d_tail_ptr);
   (void)hipFree(op->d_tail_col);
