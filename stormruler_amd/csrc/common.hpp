@@ -92,7 +92,7 @@ struct storm_hip_ctx {
   // options
   int64_t opt_ell_cap = 0;
   int64_t opt_spmv_variant = 0;      // 0 gathers from global (default), 1 + LDS x window
-  int64_t opt_spmv_xcd_remap = 0;    // 1: contiguous slice run per XCD (measured slower)
+  int64_t opt_spmv_xcd_remap = 8;    // 0 off; 1 one contiguous run per XCD (slower); G > 1: runs of G tiles per XCD
   int64_t opt_nt = 1;
   int64_t opt_profile_spmv = 0;
   // Zig-zag sweeps: consecutive streaming kernels walk the rows in opposite directions, so each

@@ -36,6 +36,7 @@ struct SellArgs {
   const int64_t *__restrict__ slice_off;  // [n_slices + 1] byte offsets
   int64_t n_rows;
   int uniform_width;                      // > 0: every slice has this width, slice_off is not read
+  int xcd_group;                          // tiles per XCD run (<= 1: one contiguous run per XCD)
 };
 
 struct DotArgs {
@@ -55,6 +56,15 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
   const int q = nb / kNumXcd, r = nb % kNumXcd;
   const int x = b % kNumXcd, j = b / kNumXcd;
   return x * q + (x < r ? x : r) + j;
+}
+// Grouped remap: XCD x takes runs of G consecutive tiles, the 8 XCDs' runs interleaved.  All XCDs
+// then stream one shared window of 8 G tiles (few DRAM streams, like a plain copy) while most
+// neighbour rows of a tile are processed by -- and cached in the L2 of -- the same XCD.
+__device__ __forceinline__ int xcd_remap_grouped(int b, int nb, int G) {
+  const int span = kNumXcd * G;
+  if (b >= (nb / span) * span) return b;  // ragged tail: identity
+  const int x = b % kNumXcd, j = b / kNumXcd;
+  return ((j / G) * kNumXcd + x) * G + (j % G);
 }
 
 template <bool NT>
@@ -107,7 +117,8 @@ __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SellArgs A, Scal alph
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: slice math runs on the SALU
   const int bidx = rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;  // zig-zag sweep direction
-  const int lb = XCD ? xcd_remap(bidx, gridDim.x) : bidx;
+  const int lb = XCD ? (A.xcd_group > 1 ? xcd_remap_grouped(bidx, gridDim.x, A.xcd_group) : xcd_remap(bidx, gridDim.x))
+                     : bidx;
   const int64_t sl = (int64_t)lb * (kBlock / kWave) + wave;
   const bool wave_active = sl < n_launch_slices;
   const double alpha = ld_scal2(alpha_s), beta = ld_scal2(beta_s);
@@ -221,7 +232,7 @@ __global__ __launch_bounds__(kBlock) void spmv_tail_kernel(int64_t n_tail, const
 template <bool NT, bool DOT, int VARIANT>
 static void launch_sell(const storm_hip_op *op, int nb, Scal alpha, Scal beta, const double *x, double *y,
                         const int *slice_list, int64_t n_launch, DotArgs dot, const int *done) {
-  SellArgs A{op->d_pack, op->d_slice_off, op->n_rows, op->uniform_width};
+  SellArgs A{op->d_pack, op->d_slice_off, op->n_rows, op->uniform_width, (int)op->ctx->opt_spmv_xcd_remap};
   hipStream_t st = op->ctx->stream;
   const int rev = op->ctx->next_dir();
   if (slice_list == nullptr && op->ctx->opt_spmv_xcd_remap != 0) {
