@@ -1,0 +1,112 @@
+// A solver driver written the way StormRuler's playground writes one
+// (source_apps/playground/Playground.cpp:151-167): build the mesh quantities, wrap the stencil in
+// an operator, call solve<XSolver>(x, b, op).  Compiled against include/storm_hip/Storm.hpp only.
+//
+//   poisson_driver <n> <cg|bicgstab|gmres> <native|lambda> [restart]
+//
+// prints one JSON line.  "lambda" passes the operator through make_operator (forcing the
+// statement-by-statement solver templates over the BLAS-1 ABI); "native" passes a
+// HipStencilOperator (whole solve on the device).
+#include <storm_hip/Storm.hpp>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace Storm;
+
+struct BoxMesh {
+  std::vector<int64_t> inner, outer, b_cell;
+  std::vector<real_t> coef, b_coef, volume;
+  size_t n_cells = 0;
+};
+
+// n^3 unit cube, cell id (k*n + j)*n + i, faces cell-major +x,+y,+z, wall faces -x,+x,-y,+y,-z,+z
+// (same synthetic mesh as stormruler_amd.mesh.structured_box / SURVEY.md 8d).
+static BoxMesh make_box(int n) {
+  BoxMesh m;
+  const real_t h = 1.0 / n;
+  m.n_cells = (size_t)n * n * n;
+  m.volume.assign(m.n_cells, h * h * h);
+  auto center = [&](int i) { return (i + 0.5) * h; };
+  auto dist = [&](real_t a, real_t b) {  // length(a - b) of Bittern: sqrt(0 + d*d)
+    const real_t d = a - b;
+    real_t s = 0.0;
+    s = s + d * d;
+    return std::sqrt(s);
+  };
+  const real_t area = h * h;
+  for (int k = 0; k < n; ++k)
+    for (int j = 0; j < n; ++j)
+      for (int i = 0; i < n; ++i) {
+        const int64_t c = ((int64_t)k * n + j) * n + i;
+        if (i < n - 1) m.inner.push_back(c), m.outer.push_back(c + 1), m.coef.push_back(area / dist(center(i + 1), center(i)));
+        if (j < n - 1) m.inner.push_back(c), m.outer.push_back(c + n), m.coef.push_back(area / dist(center(j + 1), center(j)));
+        if (k < n - 1) m.inner.push_back(c), m.outer.push_back(c + (int64_t)n * n), m.coef.push_back(area / dist(center(k + 1), center(k)));
+        const int idx[3] = {i, j, k};
+        for (int ax = 0; ax < 3; ++ax) {
+          if (idx[ax] == 0) m.b_cell.push_back(c), m.b_coef.push_back(area / dist(center(0) - 0.5 * h, center(0)));
+          if (idx[ax] == n - 1) m.b_cell.push_back(c), m.b_coef.push_back(area / dist(center(n - 1) + 0.5 * h, center(n - 1)));
+        }
+      }
+  return m;
+}
+
+template<template<class> class SolverT>
+static int run(int n, bool native, size_t restart) {
+  Context ctx(0);
+  const BoxMesh mesh = make_box(n);
+  const StencilMatrix matrix = StencilMatrix::from_faces(ctx, mesh.n_cells, 0, mesh.inner, mesh.outer, mesh.coef,
+                                                         mesh.b_cell, mesh.b_coef, mesh.volume);
+  DeviceVector b(ctx, mesh.n_cells), x(ctx, mesh.n_cells);
+  fill_with(b, 1.0);
+
+  SolverT<DeviceVector> solver;
+  if constexpr (std::is_base_of_v<InnerOuterIterativeSolver<DeviceVector>, SolverT<DeviceVector>>)
+    solver.num_inner_iterations = restart;
+  bool converged;
+  if (native) {
+    const HipStencilOperator op(matrix, -1.0, 0.0);  // A = -L
+    converged = solver.solve(x, b, op);
+  } else {
+    const auto op = make_operator<DeviceVector>(
+        [&](DeviceVector& y_vec, const DeviceVector& x_vec) { matrix.apply(-1.0, 0.0, x_vec, y_vec); });
+    converged = solver.solve(x, b, *op);
+  }
+  const std::vector<real_t> xh = x.to_host();
+  const size_t c = ((size_t)(n / 2) * n + n / 2) * n + n / 2;
+  std::printf("{\"n\": %d, \"converged\": %s, \"iterations\": %zu, \"absolute_error\": %.17g, "
+              "\"relative_error\": %.17g, \"x_centre\": %.17g, \"x_norm2\": %.17g, \"x0\": %.17g}\n",
+              n, converged ? "true" : "false", solver.iteration, solver.absolute_error, solver.relative_error,
+              xh[c], norm_2(x), xh[0]);
+  // error conventions: conj_mul of a plain operator throws std::runtime_error (Operator.hpp:116-118)
+  try {
+    make_operator<DeviceVector>([](DeviceVector&, const DeviceVector&) {})->conj_mul(x, b);
+    return 3;
+  } catch (const std::runtime_error&) {
+  }
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 4) {
+    std::fprintf(stderr, "usage: %s <n> <cg|bicgstab|gmres> <native|lambda> [restart]\n", argv[0]);
+    return 2;
+  }
+  const int n = std::atoi(argv[1]);
+  const std::string kind = argv[2];
+  const bool native = std::strcmp(argv[3], "native") == 0;
+  const size_t restart = argc > 4 ? (size_t)std::atoi(argv[4]) : 50;
+  try {
+    if (kind == "cg") return run<CgSolver>(n, native, restart);
+    if (kind == "bicgstab") return run<BiCgStabSolver>(n, native, restart);
+    if (kind == "gmres") return run<GmresSolver>(n, native, restart);
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "error: %s\n", e.what());
+    return 1;
+  }
+  return 2;
+}

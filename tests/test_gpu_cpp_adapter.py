@@ -1,0 +1,50 @@
+"""The C++ adapter (include/storm_hip/Storm.hpp): a driver written against the reference's
+`solve<XSolver>(x, b, op)` interface, compiled by g++ and linked to libstorm_hip.so only."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "tests", "cpp", "poisson_driver")
+
+
+def _run(*args):
+    if not os.path.exists(DRIVER):
+        import __graft_entry__ as ge
+
+        ge.build()
+    out = subprocess.run([DRIVER, *map(str, args)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("kind,restart,tol", [("cg", 50, 1e-8), ("bicgstab", 50, 2e-6), ("gmres", 30, 5e-6)])
+@pytest.mark.parametrize("mode", ["native", "lambda"])
+def test_cpp_driver_matches_oracle(kind, restart, tol, mode):
+    from oracle import oracle
+    from stormruler_amd import mesh
+
+    n = 24
+    got = _run(n, kind, mode, restart)
+    g = mesh.structured_box(n)
+    ref = oracle.solve(kind, oracle.StencilOperator(g, -1.0, 0.0), np.ones(g.n_cells), num_inner_iterations=restart)
+    assert got["converged"] and ref.converged
+    assert abs(got["iterations"] - ref.iterations) <= max(2, int(0.05 * ref.iterations))
+    c = (n // 2 * n + n // 2) * n + n // 2
+    assert abs(got["x_centre"] - ref.x[c]) <= tol * abs(ref.x[c]) * 10
+    assert abs(got["x_norm2"] - np.linalg.norm(ref.x)) <= tol * np.linalg.norm(ref.x)
+    assert got["relative_error"] < 1e-6
+
+
+def test_cpp_driver_reproduces_recorded_reference_case(golden):
+    # 32^3 CG -> 64 iterations, x[centre] = 5.612935319258e-02
+    case = [c for c in golden["baseline_md_probe"]["cases"] if c["n"] == 32 and c["solver"] == "cg"][0]
+    for mode in ("native", "lambda"):
+        got = _run(32, "cg", mode)
+        assert got["iterations"] == case["iterations"]
+        assert abs(got["x_centre"] - case["x_centre"]) <= 1e-9 * case["x_centre"]
