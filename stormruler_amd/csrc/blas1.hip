@@ -315,7 +315,7 @@ static int check_pair(const storm_hip_vec *a, const storm_hip_vec *b, const char
 
 // Finish a host-visible reduction: sum over ranks, copy k scalars to the host.
 static int finish_reduction(storm_hip_ctx *c, int k, double *out) {
-  if (c->n_ranks > 1) STORM_TRY(comm_allreduce_sum(c, c->d_scalars, k));
+  if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, c->d_scalars, k));
   HIP_TRY(hipMemcpyAsync(c->h_scalars, c->d_scalars, sizeof(double) * (size_t)k, hipMemcpyDeviceToHost,
                          c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));

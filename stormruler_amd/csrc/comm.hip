@@ -27,7 +27,7 @@ struct Comm {
   } while (0)
 
 int comm_allreduce_sum(storm_hip_ctx *c, double *d_buf, int count) {
-  if (c->n_ranks <= 1) return STORM_HIP_OK;
+  if (c->comm == nullptr) return STORM_HIP_OK;
   STORM_REQUIRE(c->comm && c->comm->red, "all-reduce without an initialised communicator");
   NCCL_TRY(ncclAllReduce(d_buf, d_buf, (size_t)count, ncclDouble, ncclSum, c->comm->red, c->stream));
   return STORM_HIP_OK;
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(kBlock) void halo_pack_kernel(int64_t n, const int 
 int comm_halo_exchange_begin(const storm_hip_op *op, double *x) {
   storm_hip_ctx *c = op->ctx;
   const HaloPlan &h = op->halo;
-  if (h.n_nbrs == 0 || c->n_ranks <= 1) return STORM_HIP_OK;
+  if (h.n_nbrs == 0 || c->comm == nullptr) return STORM_HIP_OK;
   STORM_REQUIRE(c->comm && c->comm->halo, "halo exchange without an initialised communicator");
   // x must be complete before it is packed
   HIP_TRY(hipEventRecord(c->ev_x_ready, c->stream));
@@ -72,7 +72,7 @@ int comm_halo_exchange_begin(const storm_hip_op *op, double *x) {
 
 int comm_halo_exchange_end(const storm_hip_op *op) {
   storm_hip_ctx *c = op->ctx;
-  if (op->halo.n_nbrs == 0 || c->n_ranks <= 1) return STORM_HIP_OK;
+  if (op->halo.n_nbrs == 0 || c->comm == nullptr) return STORM_HIP_OK;
   HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_halo_done, 0));
   return STORM_HIP_OK;
 }
@@ -143,7 +143,7 @@ int storm_hip_op_set_halo(storm_hip_op *op, int n_nbrs, const int32_t *nbr_rank,
   HaloPlan &h = op->halo;
   STORM_REQUIRE(send_ptr[0] == 0 && recv_ptr[0] == 0, "op_set_halo: offsets must start at 0");
   for (int q = 0; q < n_nbrs; ++q) {
-    STORM_REQUIRE(nbr_rank[q] >= 0 && nbr_rank[q] < c->n_ranks && nbr_rank[q] != c->rank,
+    STORM_REQUIRE(nbr_rank[q] >= 0 && nbr_rank[q] < c->n_ranks,  // a self-neighbour is a periodic boundary
                   "op_set_halo: neighbour %d is rank %d (this is rank %d of %d)", q, nbr_rank[q], c->rank, c->n_ranks);
     STORM_REQUIRE(send_ptr[q + 1] >= send_ptr[q] && recv_ptr[q + 1] >= recv_ptr[q], "op_set_halo: offsets not monotone");
   }

@@ -337,7 +337,7 @@ struct Driver {
       partials = c->d_partials2;
       nblocks = kStage2;
     }
-    if (c->n_ranks == 1) {
+    if (c->comm == nullptr) {
       hipLaunchKernelGGL(reduce_step_kernel, dim3(1), dim3(kBlock), 0, c->stream, partials, nblocks, k,
                          out, step, st, g, force);
       HIP_TRY(hipGetLastError());
@@ -510,7 +510,7 @@ int storm_hip_solve_cg(const storm_hip_op *op, double alpha, double beta, const 
     if (nb == 0) {  // operator has a CSR tail: separate dot
       const double *bs[1] = {z};
       STORM_TRY(k_multi_dot(c, p, bs, 1, n, d.slot(S_PZ), d.done));
-      if (c->n_ranks > 1) STORM_TRY(comm_allreduce_sum(c, d.slot(S_PZ), 1));
+      if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, d.slot(S_PZ), 1));
     } else {
       const int slots[1] = {S_PZ};
       STORM_TRY(d.finish(nb, 1, slots, STEP_NONE));
@@ -567,7 +567,7 @@ int storm_hip_solve_bicgstab(const storm_hip_op *op, double alpha, double beta, 
     if (nb == 0) {
       const double *bs[1] = {v};
       STORM_TRY(k_multi_dot(c, rt, bs, 1, n, d.slot(S_RTV), d.done));
-      if (c->n_ranks > 1) STORM_TRY(comm_allreduce_sum(c, d.slot(S_RTV), 1));
+      if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, d.slot(S_RTV), 1));
       hipLaunchKernelGGL(step_kernel, dim3(1), dim3(1), 0, c->stream, (int)STEP_BICG_ALPHA, d.st, d.g, false);
       HIP_TRY(hipGetLastError());
     } else {
@@ -583,7 +583,7 @@ int storm_hip_solve_bicgstab(const storm_hip_op *op, double alpha, double beta, 
     if (nb == 0) {
       const double *bs[2] = {r, t};
       STORM_TRY(k_multi_dot(c, t, bs, 2, n, d.slot(S_TR), d.done));
-      if (c->n_ranks > 1) STORM_TRY(comm_allreduce_sum(c, d.slot(S_TR), 2));
+      if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, d.slot(S_TR), 2));
       hipLaunchKernelGGL(step_kernel, dim3(1), dim3(1), 0, c->stream, (int)STEP_BICG_OMEGA, d.st, d.g, false);
       HIP_TRY(hipGetLastError());
     } else {
@@ -649,7 +649,7 @@ int storm_hip_solve_gmres(const storm_hip_op *op, double alpha, double beta, con
       STORM_TRY(k_axpbz(c, q0, host_scal(1.0), b->d, host_scal(-1.0), q0, n, d.done));
       const double *bs[1] = {q0};
       STORM_TRY(k_multi_dot(c, q0, bs, 1, n, d.slot(S_TMP), d.done));
-      if (c->n_ranks > 1) STORM_TRY(comm_allreduce_sum(c, d.slot(S_TMP), 1));
+      if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, d.slot(S_TMP), 1));
       hipLaunchKernelGGL(step_kernel, dim3(1), dim3(1), 0, c->stream, (int)STEP_GMRES_BETA0, d.st, d.g, false);
       HIP_TRY(hipGetLastError());
       STORM_TRY(k_scale(c, q0, n, dev_scal(d.slot(S_HN)), true, d.done));
@@ -675,7 +675,7 @@ int storm_hip_solve_gmres(const storm_hip_op *op, double alpha, double beta, con
         double *h = &d.g.H[i * m + k];
         const double *bs[1] = {q[i]};
         STORM_TRY(k_multi_dot(c, qn, bs, 1, n, h, d.done));
-        if (c->n_ranks > 1) STORM_TRY(comm_allreduce_sum(c, h, 1));
+        if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, h, 1));
         STORM_TRY(k_axpbz(c, qn, host_scal(1.0), qn, dev_scal(h, -1.0), q[i], n, d.done));
       }
     } else {
@@ -684,7 +684,7 @@ int storm_hip_solve_gmres(const storm_hip_op *op, double alpha, double beta, con
       double *h0 = d.slot(S_SCRATCH);  // k + 1 <= 63 scratch slots
       for (int pass = 0; pass < 2; ++pass) {
         STORM_TRY(k_multi_dot(c, qn, q.data(), k + 1, n, h0 + pass * kMaxMulti, d.done));
-        if (c->n_ranks > 1) STORM_TRY(comm_allreduce_sum(c, h0 + pass * kMaxMulti, k + 1));
+        if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, h0 + pass * kMaxMulti, k + 1));
         STORM_TRY(k_multi_axpy(c, qn, h0 + pass * kMaxMulti, -1.0, q.data(), k + 1, n, d.done));
       }
       hipLaunchKernelGGL(gmres_cgs2_combine_kernel, dim3(1), dim3(1), 0, c->stream, d.st, d.g, k);
@@ -693,7 +693,7 @@ int storm_hip_solve_gmres(const storm_hip_op *op, double alpha, double beta, con
     {
       const double *bs[1] = {qn};
       STORM_TRY(k_multi_dot(c, qn, bs, 1, n, d.slot(S_TMP), d.done));                           // :161
-      if (c->n_ranks > 1) STORM_TRY(comm_allreduce_sum(c, d.slot(S_TMP), 1));
+      if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, d.slot(S_TMP), 1));
       hipLaunchKernelGGL(step_kernel, dim3(1), dim3(1), 0, c->stream, (int)STEP_GMRES_HN, d.st, d.g, false);
       HIP_TRY(hipGetLastError());
       STORM_TRY(k_scale(c, qn, n, dev_scal(d.slot(S_HN)), true, d.done));                       // :162

@@ -290,7 +290,9 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
                 const SpmvDot *sd, const int *done) {
   storm_hip_ctx *c = op->ctx;
   const bool fuse_dot = sd != nullptr && op->tail_rows == 0;
-  const bool split = op->halo.n_nbrs > 0 && c->n_ranks > 1;
+  STORM_REQUIRE(op->halo.n_nbrs == 0 || c->comm != nullptr,
+                "operator has a halo plan but the context has no communicator (call storm_hip_ctx_comm_init)");
+  const bool split = op->halo.n_nbrs > 0;
   DotArgs dot{nullptr, nullptr, 0, 0, 0};
   const int nb_int = split ? blocks_for(op->n_interior) : spmv_grid_blocks(op);
   const int nb_bnd = split ? blocks_for(op->n_boundary) : 0;

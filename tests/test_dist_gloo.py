@@ -1,0 +1,148 @@
+"""World-size-2 (and 3) run of the N > 1 path on CPU over gloo.
+
+What is shared with the GPU path and therefore covered here: stormruler_amd.partition (slab
+generator, halo plans), stormruler_amd.dist (rendezvous on 127.0.0.1, id broadcast, max-reduce,
+barrier) and the exchange protocol itself (who sends which rows to whom, in which order, into which
+halo segment; reductions summed over ranks).  The local compute is done by the CPU oracle -- the
+HIP kernels need a GPU -- and the distributed CG below follows SolverCg.hpp:54-126 statement by
+statement with the same places for the halo exchange and the all-reduces as csrc/solvers.hip.
+"""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent(
+    """
+    import os, sys, json
+    import numpy as np
+    sys.path.insert(0, {root!r})
+    import torch
+    import torch.distributed as td
+    from stormruler_amd import dist, partition, mesh
+    from oracle import oracle
+
+    td_mod = dist.init_process_group("gloo")
+    rank, world = td.get_rank(), td.get_world_size()
+    nx, ny, nzl = {nx}, {ny}, {nzl}
+
+    # id broadcast as dist.connect() does it (128 opaque bytes from rank 0)
+    payload = bytes(range(128)) if rank == 0 else None
+    got = dist.broadcast_bytes(payload, 128, src=0)
+    assert got == bytes(range(128))
+    assert dist.allreduce_max(float(rank)) == float(world - 1)
+
+    g, plan = partition.slab_partition(nx, ny, nzl, world, rank)
+    n = g.n_cells
+    op = oracle.StencilOperator(g, -1.0, 0.0)
+
+    def exchange(x_full):
+        # rows send_idx[send_ptr[q]:send_ptr[q+1]] -> neighbour q; its rows arrive in our halo segment q
+        reqs, bufs = [], []
+        for q, nbr in enumerate(plan.nbr_rank):
+            sb = torch.from_numpy(np.ascontiguousarray(x_full[plan.send_idx[plan.send_ptr[q]:plan.send_ptr[q + 1]]]))
+            rb = torch.empty(int(plan.recv_ptr[q + 1] - plan.recv_ptr[q]), dtype=torch.float64)
+            reqs.append(td.isend(sb, int(nbr)))
+            reqs.append(td.irecv(rb, int(nbr)))
+            bufs.append((q, rb, sb))
+        for r in reqs:
+            r.wait()
+        for q, rb, _ in bufs:
+            x_full[n + plan.recv_ptr[q]: n + plan.recv_ptr[q + 1]] = rb.numpy()
+
+    def apply(x_owned):
+        xf = np.zeros(g.n_total)
+        xf[:n] = x_owned
+        exchange(xf)
+        return op.apply(xf)[:n]
+
+    def gsum(v):
+        t = torch.tensor([v], dtype=torch.float64)
+        td.all_reduce(t)
+        return float(t.item())
+
+    def gdot(a, b):
+        return gsum(oracle.dot(a, b))
+
+    # CG, SolverCg.hpp:54-126 / Solver.hpp:116-147, defaults
+    b = np.ones(n)
+    x = np.zeros(n)
+    r = b - apply(x)
+    p = r.copy()
+    gamma = gdot(r, r)
+    init = np.sqrt(gamma)
+    it, conv = 0, False
+    while not conv and it < 2000:
+        z = apply(p)
+        alpha = oracle.safe_divide(gamma, gdot(p, z))
+        x += alpha * p
+        r -= alpha * z
+        gamma_bar, gamma = gamma, gdot(r, r)
+        beta = oracle.safe_divide(gamma, gamma_bar)
+        p = r + beta * p
+        err = np.sqrt(gamma)
+        conv = (err < 1e-6) or (err / init < 1e-6)
+        it += 1
+    dist.barrier()
+    np.save({out!r} + f".{{rank}}.npy", np.concatenate([[it], g.global_id[:n].astype(float), x]))
+    td.destroy_process_group()
+    """
+)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_rank_cg_matches_single_rank_oracle(tmp_path, world):
+    from oracle import oracle
+    from stormruler_amd import mesh
+
+    nx, ny, nzl = 10, 8, 5
+    out = str(tmp_path / "x")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, nx=nx, ny=ny, nzl=nzl, out=out))
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+
+    nzg = nzl * world
+    g = mesh.structured_box(nx, ny, nzg, lengths=(1.0, ny / nx, nzg / nx))
+    ref = oracle.solve("cg", oracle.StencilOperator(g, -1.0, 0.0), np.ones(g.n_cells))
+    x = np.empty(g.n_cells)
+    for rank in range(world):
+        d = np.load(out + f".{rank}.npy")
+        n = (d.size - 1) // 2
+        assert abs(int(d[0]) - ref.iterations) <= 2
+        x[d[1:1 + n].astype(np.int64)] = d[1 + n:]
+    assert np.linalg.norm(x - ref.x) <= 1e-8 * np.linalg.norm(ref.x)
+
+
+def test_env_rank_defaults(monkeypatch):
+    from stormruler_amd import dist
+
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    assert dist.env_rank() == (0, 0, 1)
+    monkeypatch.setenv("RANK", "3")
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    assert dist.env_rank() == (3, 1, 8)
