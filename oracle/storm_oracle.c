@@ -219,8 +219,8 @@ ORACLE_API void oracle_convection(const oracle_mesh *m, double *u, double dt,
     double vn = 0.0;
     for (int k = 0; k < dim; ++k) vn = vn + vel[k] * ((xo[k] - xi[k]) / d);
     const double flux = dt * (vn > 0.0 ? vn * c[ci] : vn * c[co]);
-    u[ci] -= (m->area[f] / m->volume[ci]) * flux;
-    u[co] += (m->area[f] / m->volume[co]) * flux;
+    u[ci] += (m->area[f] / m->volume[ci]) * flux;   /* ConvectionScheme.hpp:90 */
+    u[co] -= (m->area[f] / m->volume[co]) * flux;   /* ConvectionScheme.hpp:91 */
   }
   for (int64_t b = 0; b < m->n_bfaces; ++b) {
     const int64_t ci = m->b_cell[b];
@@ -230,7 +230,7 @@ ORACLE_API void oracle_convection(const oracle_mesh *m, double *u, double dt,
     for (int k = 0; k < dim; ++k) vn = vn + vel[k] * ((xf[k] - xi[k]) / d);
     const double g = m->b_ghost ? m->b_ghost[b] : 0.0;
     const double flux = dt * (vn > 0.0 ? vn * c[ci] : vn * g);
-    u[ci] -= (m->b_area[b] / m->volume[ci]) * flux;
+    u[ci] += (m->b_area[b] / m->volume[ci]) * flux;  /* ConvectionScheme.hpp:104 */
   }
 }
 

@@ -241,7 +241,12 @@ static void launch_sell(const storm_hip_op *op, int nb, Scal alpha, Scal beta, c
   } else if (slice_list == nullptr) {
     hipLaunchKernelGGL((spmv_sell_kernel<NT, DOT, VARIANT, false>), dim3(nb), dim3(kBlock), 0, st, A, alpha,
                        beta, x, y, slice_list, n_launch, dot, done, rev);
-  } else {  // listed slices are not consecutive: the LDS window does not apply
+  } else if (op->ctx->opt_spmv_xcd_remap != 0) {
+    // listed slices (interior / boundary sets of a partitioned operator): the LDS window does not
+    // apply, the XCD grouping still does -- the interior list is consecutive but for a few gaps
+    hipLaunchKernelGGL((spmv_sell_kernel<NT, DOT, 0, true>), dim3(nb), dim3(kBlock), 0, st, A, alpha, beta,
+                       x, y, slice_list, n_launch, dot, done, rev);
+  } else {
     hipLaunchKernelGGL((spmv_sell_kernel<NT, DOT, 0, false>), dim3(nb), dim3(kBlock), 0, st, A, alpha, beta,
                        x, y, slice_list, n_launch, dot, done, rev);
   }

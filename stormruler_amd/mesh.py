@@ -31,6 +31,7 @@ __all__ = [
     "rcm_ordering",
     "permute_cells",
     "face_coefficients",
+    "convection_diffusion_weights",
     "assemble_csr",
 ]
 
@@ -103,6 +104,38 @@ def face_coefficients(g: FaceGraph) -> Tuple[np.ndarray, np.ndarray]:
     else:
         b_coef = np.zeros(0)
     return coef, b_coef
+
+
+def convection_diffusion_weights(g: FaceGraph, nu: float, vel: Sequence[float]):
+    """Face weights of ``A = -nu L + C(v)`` (BASELINE config 4), for ``StencilMatrix.from_face_weights``.
+
+    ``C(v)`` is the first-order upwind divergence of ``v c`` with constant velocity: the interior /
+    boundary face loops of ``UpwindConvectionScheme`` (Feathers/ConvectionScheme.hpp:80-107) with the
+    flux ``vn > 0 ? vn c_in : vn c_out``, ``vn = v . n``, ``n`` the unit vector inner -> outer, and a zero
+    ghost state on inflow walls.  Written in the device operator's difference form
+    ``(A x)_i = sum_f w_if (x_other - x_i) + diag_extra_i x_i``; apply with ``alpha = 1, beta = 0``.
+    Returns ``(w_inner[F], w_outer[F], diag_extra[n_cells])``.
+    """
+    n = g.n_cells
+    vel = np.asarray(vel, np.float64)[: g.dim]
+    coef, b_coef = face_coefficients(g)
+    d = g.center[g.outer] - g.center[g.inner]
+    dist = g.area / coef
+    vn = (d @ vel) / dist
+    a_in = g.area / g.volume[g.inner]
+    a_out = g.area / g.volume[g.outer]
+    w_inner = -nu * coef / g.volume[g.inner] + a_in * np.minimum(vn, 0.0)
+    w_outer = -nu * coef / g.volume[g.outer] - a_out * np.maximum(vn, 0.0)
+    diag = np.zeros(g.n_total)
+    np.add.at(diag, g.inner, a_in * vn)
+    np.add.at(diag, g.outer, -a_out * vn)
+    if g.n_bfaces:
+        db = g.b_center - g.center[g.b_cell]
+        bdist = g.b_area / b_coef
+        bvn = (db @ vel) / bdist
+        np.add.at(diag, g.b_cell, nu * b_coef / g.volume[g.b_cell]
+                  + (g.b_area / g.volume[g.b_cell]) * np.maximum(bvn, 0.0))
+    return w_inner, w_outer, diag[:n].copy()
 
 
 def _box_faces(nx: int, ny: int, nz: int, k0: int, k1: int, nz_glob: int,
