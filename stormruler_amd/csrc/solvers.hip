@@ -186,11 +186,22 @@ __global__ __launch_bounds__(kBlock) void init_residual_kernel(int64_t n, double
                                                                double *__restrict__ partials) {
   __shared__ double lds4[4];
   double acc = 0.0;
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    const double v = b[i] - r[i];
-    r[i] = v;
-    if (copy_to) copy_to[i] = v;
+  const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * kBlock;
+  double2 *r2 = reinterpret_cast<double2 *>(r), *c2 = reinterpret_cast<double2 *>(copy_to);
+  const double2 *b2 = reinterpret_cast<const double2 *>(b);
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
+    const double2 vb = b2[i], vr = r2[i];
+    double2 v;
+    v.x = vb.x - vr.x, v.y = vb.y - vr.y;
+    r2[i] = v;
+    if (copy_to) c2[i] = v;
+    acc += v.x * v.x;
+    acc += v.y * v.y;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const double v = b[n - 1] - r[n - 1];
+    r[n - 1] = v;
+    if (copy_to) copy_to[n - 1] = v;
     acc += v * v;
   }
   const double s = block_sum256(acc, lds4);
@@ -243,9 +254,29 @@ __global__ __launch_bounds__(kBlock) void bicg_update_kernel(int64_t n, SolverSt
   __shared__ double lds4[4];
   const double a = SECOND ? st->s[S_OMEGA] : st->s[S_ALPHA];
   double acc_rr = 0.0, acc_rho = 0.0;
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    const double ui = SECOND ? r[i] : u[i];  // second half-step adds omega * (old) r
+  const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * kBlock;
+  double2 *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r);
+  const double2 *u2 = reinterpret_cast<const double2 *>(u), *w2 = reinterpret_cast<const double2 *>(w);
+  const double2 *rt2 = reinterpret_cast<const double2 *>(rt);
+#pragma unroll 2
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
+    double2 vx = x2[i], vr = r2[i];
+    const double2 vw = w2[i];
+    const double2 vu = SECOND ? vr : u2[i];  // second half-step adds omega * (old) r
+    vx.x += a * vu.x, vx.y += a * vu.y;
+    vr.x -= a * vw.x, vr.y -= a * vw.y;
+    x2[i] = vx, r2[i] = vr;
+    if (SECOND) {
+      const double2 vt = rt2[i];
+      acc_rr += vr.x * vr.x;
+      acc_rr += vr.y * vr.y;
+      acc_rho += vt.x * vr.x;
+      acc_rho += vt.y * vr.y;
+    }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    const double ui = SECOND ? r[i] : u[i];
     x[i] += a * ui;
     const double vr = r[i] - a * w[i];
     r[i] = vr;

@@ -5,8 +5,9 @@
 //   slice s = rows [64 s, 64 s + 64): one wavefront.  Everything the slice streams is ONE
 //   contiguous record at byte offset slice_off[s]:
 //        [ ext : 64 x f64 ][ col : W x 64 x i32 ][ val : W x 64 x f64 ]      (512 + 768 W bytes)
-//   column-major inside the record, so the 64 lanes of a wave read 64 consecutive columns
-//   (256 B) and 64 consecutive weights (512 B) per slot.  Packing ext/col/val of a slice
+//   Inside col / val the slots are stored in PAIRS, lane-major: lane l finds (slot 2p, slot 2p+1)
+//   of its row as one int2 / one double2, so a wave reads 512 B of columns and 1 KiB of weights
+//   per instruction (8- and 16-byte accesses per lane; an odd last slot follows column-major).  Packing ext/col/val of a slice
 //   into one record leaves the kernel three DRAM streams (records, x, y) instead of five;
 //   on MI355X the number of concurrent streams, not L2 locality, decided the rate (measured:
 //   profiles/r01_notes.md).
@@ -27,6 +28,9 @@
 namespace storm {
 
 __device__ __forceinline__ double ld_scal2(const Scal &s) { return s.p ? (*s.p) * s.sign : s.v; }
+
+typedef int int2v __attribute__((ext_vector_type(2)));
+typedef double double2v __attribute__((ext_vector_type(2)));
 
 constexpr int kExtBytes = kWave * 8;      // 512
 constexpr int kSlotBytes = kWave * 12;    // 768: one ELL slot of a slice (64 cols + 64 vals)
@@ -153,34 +157,42 @@ __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SellArgs A, Scal alph
       width = (int)((A.slice_off[slice + 1] - base - kExtBytes) / kSlotBytes);
     }
     const char *rec = A.pack + base;
-    const double *ep = reinterpret_cast<const double *>(rec) + lane;
-    const int *cp = reinterpret_cast<const int *>(rec + kExtBytes) + lane;
-    const double *vp = reinterpret_cast<const double *>(rec + kExtBytes + (int64_t)width * (kWave * 4)) + lane;
-    const double ext = ld_d<NT>(ep);
+    const int npair = width >> 1;
+    const double ext = ld_d<NT>(reinterpret_cast<const double *>(rec) + lane);
+    const int2v *cp2 = reinterpret_cast<const int2v *>(rec + kExtBytes) + lane;
+    const char *vbase = rec + kExtBytes + (int64_t)width * (kWave * 4);
+    const double2v *vp2 = reinterpret_cast<const double2v *>(vbase) + lane;
     double acc = 0.0;
-    for (int k0 = 0; k0 < width; k0 += kChunk) {
-      int c[kChunk];
-      double v[kChunk];
+    auto gather = [&](int c) -> double {
+      if (VARIANT == 1) {
+        const int64_t d = (int64_t)c - row0;
+        return ((uint64_t)d < (uint64_t)kBlock) ? xwin[d] : x[c];
+      }
+      return x[c];
+    };
+    for (int p0 = 0; p0 < npair; p0 += kChunk / 2) {
+      int2v c[kChunk / 2];
+      double2v v[kChunk / 2];
 #pragma unroll
-      for (int k = 0; k < kChunk; ++k) {
-        if (k0 + k < width) {
-          c[k] = ld_i<NT>(cp + (k0 + k) * kWave);
-          v[k] = ld_d<NT>(vp + (k0 + k) * kWave);
+      for (int q = 0; q < kChunk / 2; ++q) {
+        if (p0 + q < npair) {
+          c[q] = NT ? __builtin_nontemporal_load(cp2 + (p0 + q) * kWave) : cp2[(p0 + q) * kWave];
+          v[q] = NT ? __builtin_nontemporal_load(vp2 + (p0 + q) * kWave) : vp2[(p0 + q) * kWave];
         }
       }
 #pragma unroll
-      for (int k = 0; k < kChunk; ++k) {
-        if (k0 + k < width) {
-          double xc;
-          if (VARIANT == 1) {
-            const int64_t d = (int64_t)c[k] - row0;
-            xc = ((uint64_t)d < (uint64_t)kBlock) ? xwin[d] : x[c[k]];
-          } else {
-            xc = x[c[k]];
-          }
-          acc += v[k] * (xc - xi);
+      for (int q = 0; q < kChunk / 2; ++q) {
+        if (p0 + q < npair) {
+          const double x0 = gather(c[q].x), x1 = gather(c[q].y);
+          acc += v[q].x * (x0 - xi);
+          acc += v[q].y * (x1 - xi);
         }
       }
+    }
+    if (width & 1) {  // odd width: the last slot is stored unpaired
+      const int ct = ld_i<NT>(reinterpret_cast<const int *>(rec + kExtBytes + (int64_t)npair * (kWave * 8)) + lane);
+      const double vt = ld_d<NT>(reinterpret_cast<const double *>(vbase + (int64_t)npair * (kWave * 16)) + lane);
+      acc += vt * (gather(ct) - xi);
     }
     yi = beta * xi + alpha * (acc + ext * xi);
     if (valid && !done_flag) {
@@ -393,8 +405,11 @@ static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vect
       const int64_t pad_col = r < n ? r : (n > 0 ? n - 1 : 0);
       const int64_t b = r < n ? row_ptr[r] : 0, e = r < n ? row_ptr[r + 1] : 0;
       e_[l] = r < n ? ext[(size_t)r] : 0.0;
+      const int np2 = width[s] >> 1;
       for (int k = 0; k < width[s]; ++k) {
-        const int at = k * kWave + l;
+        // slots are stored in pairs: lane l reads (slot 2p, slot 2p+1) as one 8-byte column pair and
+        // one 16-byte weight pair; an odd last slot is stored column-major behind the pairs
+        const int at = (k < 2 * np2) ? ((k >> 1) * kWave + l) * 2 + (k & 1) : np2 * 2 * kWave + l;
         if (b + k < e) {
           c_[at] = col[(size_t)(b + k)];
           v_[at] = val[(size_t)(b + k)];
