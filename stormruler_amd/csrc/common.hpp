@@ -47,6 +47,7 @@ constexpr int kNumXcd = 8;           // MI355X: 8 XCDs, blocks dealt round-robin
 constexpr int kMaxReduceBlocks = 2048;  // 256 CUs x 8 resident 256-thread blocks
 constexpr int kMaxMulti = 64;        // widest multi-dot / multi-axpy in one launch
 constexpr int kSlab = 256;           // doubles in the device scalar slab
+constexpr int kStateRing = 64;       // iterations the host may run ahead of the device's verdict
 constexpr int kStage2 = 128;         // blocks of the first pass of a two-pass final reduction
 
 // Device-resident solver state: every scalar a Krylov loop carries, so no
@@ -63,6 +64,7 @@ struct SolverState {
   int done;                 // set by the device when converged or out of iterations
   int converged;
   double *history;          // device buffer [num_iterations + 1] or null
+  int *done_ring;           // device alias of a pinned host ring: done flag after iteration i at [i % kStateRing]
 };
 
 struct Comm;  // comm.hip
@@ -87,7 +89,9 @@ struct storm_hip_ctx {
   const double **d_ptrs = nullptr;    // [kMaxMulti] pointer table for multi-dot / multi-axpy
   double *d_coefs = nullptr;          // [kMaxMulti]
   storm::SolverState *d_state = nullptr;
-  storm::SolverState *h_state = nullptr;  // pinned ring, [kStateRing]
+  storm::SolverState *h_state = nullptr;  // pinned staging copy of the state
+  int *h_done_ring = nullptr;             // pinned, written by the device's step kernels
+  int *d_done_ring = nullptr;             // device pointer to the same memory
   std::vector<hipEvent_t> ev_ring;
   // options
   int64_t opt_ell_cap = 0;
@@ -117,8 +121,6 @@ struct storm_hip_vec {
 };
 
 namespace storm {
-
-constexpr int kStateRing = 64;
 
 struct HaloPlan {
   int n_nbrs = 0;

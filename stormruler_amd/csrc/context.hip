@@ -61,7 +61,9 @@ int storm_hip_ctx_create(int device_id, storm_hip_ctx **out) {
   HIP_TRY(hipMalloc(&c->d_coefs, sizeof(double) * kMaxMulti));
   HIP_TRY(hipMalloc((void **)&c->d_state, sizeof(SolverState)));
   HIP_TRY(hipMemset(c->d_state, 0, sizeof(SolverState)));
-  HIP_TRY(hipHostMalloc((void **)&c->h_state, sizeof(SolverState) * kStateRing, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void **)&c->h_state, sizeof(SolverState), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void **)&c->h_done_ring, sizeof(int) * kStateRing, hipHostMallocMapped));
+  HIP_TRY(hipHostGetDevicePointer((void **)&c->d_done_ring, c->h_done_ring, 0));
   c->ev_ring.resize(kStateRing);
   for (auto &ev : c->ev_ring) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   *out = c;
@@ -83,6 +85,7 @@ int storm_hip_ctx_destroy(storm_hip_ctx *c) {
   (void)hipFree(c->d_coefs);
   (void)hipFree(c->d_state);
   (void)hipHostFree(c->h_state);
+  (void)hipHostFree(c->h_done_ring);
   (void)hipEventDestroy(c->ev_x_ready);
   (void)hipEventDestroy(c->ev_halo_done);
   (void)hipEventDestroy(c->ev_t0);

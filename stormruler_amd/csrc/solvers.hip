@@ -43,6 +43,9 @@ __device__ void advance(SolverState *st, double abs_err) {
   if (st->history) st->history[st->iteration] = abs_err;
   if (conv) st->converged = 1;
   if (conv || st->iteration >= st->num_iterations) st->done = 1;
+  // Tell the host (it polls this pinned ring `check_lag` iterations behind; the event it waits on
+  // is recorded after this kernel, so the store is visible by then).
+  if (st->done_ring) st->done_ring[(st->iteration - 1) % kStateRing] = st->done;
 }
 
 // After init(): Solver.hpp:122-128.
@@ -56,6 +59,8 @@ __device__ void begin(SolverState *st, double initial_error) {
   if (st->history) st->history[0] = initial_error;
   if (st->abs_tol > 0.0 && initial_error < st->abs_tol) st->converged = 1, st->done = 1;
   if (st->num_iterations <= 0) st->done = 1;
+  if (st->done && st->done_ring)  // no iterate() will run: every poll must see it
+    for (int i = 0; i < kStateRing; ++i) st->done_ring[i] = 1;
 }
 
 enum StepKind {
@@ -412,6 +417,8 @@ static int prepare_state(Driver &d, const storm_hip_solver_params *p, double *hi
   h.rel_tol = p->relative_error_tolerance;
   h.num_iterations = p->num_iterations;
   h.history = nullptr;
+  h.done_ring = c->d_done_ring;
+  for (int i = 0; i < kStateRing; ++i) c->h_done_ring[i] = 0;
   if (history) {
     HIP_TRY(hipMalloc(&d.d_history, sizeof(double) * (size_t)(p->num_iterations + 1)));
     HIP_TRY(hipMemsetAsync(d.d_history, 0, sizeof(double) * (size_t)(p->num_iterations + 1), c->stream));
@@ -425,23 +432,18 @@ static int prepare_state(Driver &d, const storm_hip_solver_params *p, double *hi
   return STORM_HIP_OK;
 }
 
-constexpr size_t kStatusOff = offsetof(SolverState, initial_error);
-constexpr size_t kStatusBytes = sizeof(SolverState) - kStatusOff;
-
 // Post a status snapshot for iteration `it`; returns true in *stop when the snapshot of
 // iteration it - lag says the device is done.
 static int post_and_poll(Driver &d, int64_t it, bool *stop) {
   storm_hip_ctx *c = d.c;
   const int slot = (int)(it % kStateRing);
-  HIP_TRY(hipMemcpyAsync(reinterpret_cast<char *>(&c->h_state[slot]) + kStatusOff,
-                         reinterpret_cast<const char *>(c->d_state) + kStatusOff, kStatusBytes,
-                         hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipEventRecord(c->ev_ring[slot], c->stream));
   *stop = false;
   if (it >= d.lag) {
     const int old = (int)((it - d.lag) % kStateRing);
     HIP_TRY(hipEventSynchronize(c->ev_ring[old]));
-    if (c->h_state[old].done) *stop = true;
+    if (*(volatile int *)&c->h_done_ring[old]) *stop = true;
+    c->h_done_ring[old] = 0;  // slot is reused kStateRing iterations later
   }
   return STORM_HIP_OK;
 }
