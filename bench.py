@@ -134,17 +134,20 @@ def main() -> int:
             traffic = None
 
     # a measured device-copy ceiling in the same run (achievable HBM rate, for context)
+    # (two 1 GiB buffers: far beyond the 256 MiB Infinity Cache, so this is an HBM number)
     copy_gbs = None
     try:
-        src = api.DeviceVector(ctx, N)
-        dst = api.DeviceVector(ctx, N)
-        for _ in range(3):
+        nc = 1 << 27
+        src = api.DeviceVector(ctx, nc)
+        dst = api.DeviceVector(ctx, nc)
+        for _ in range(2):
             dst <<= src
         ctx.timer_start()
-        reps = 20
+        reps = 10
         for _ in range(reps):
             dst <<= src
-        copy_gbs = 16.0 * N * reps / (ctx.timer_stop() * 1e-3) / 1e9
+        copy_gbs = 16.0 * nc * reps / (ctx.timer_stop() * 1e-3) / 1e9
+        del src, dst
     except Exception:
         pass
 
@@ -167,6 +170,36 @@ def main() -> int:
         # same residual (GPU sums in a different order: tolerance, not bits)
         sg, _ = run(args.cpu_iters)
         cpu["gpu_vs_cpu_residual_rel_diff"] = abs(sg.absolute_error - r.absolute_error) / r.absolute_error
+        # the same sample with FMA contraction allowed (the reference's Release build is -Ofast,
+        # CMakeLists.txt:194-195); reported beside the strict build, SURVEY.md 8d
+        try:
+            o_fma = oracle.StencilOperator(g_cpu, -1.0, 0.0, variant="fma")
+            tf = time.perf_counter()
+            oracle.solve("cg", o_fma, np.ones(g_cpu.n_cells), num_iterations=args.cpu_iters, abs_tol=0.0,
+                         rel_tol=0.0, variant="fma")
+            cpu["value_fma_build"] = args.cpu_iters / (time.perf_counter() - tf)
+        except Exception:
+            pass
+        # BASELINE config 1 (the reference's CPU-runnable case): 64^3, full solve to the default
+        # tolerances, CPU oracle vs this library -- iteration counts and solutions must agree
+        g64 = mesh.structured_box(64)
+        t64 = time.perf_counter()
+        r64 = oracle.solve("cg", oracle.StencilOperator(g64, -1.0, 0.0), np.ones(g64.n_cells))
+        t64 = time.perf_counter() - t64
+        m64 = api.StencilMatrix.from_face_graph(ctx, g64)
+        b64, x64 = api.DeviceVector(ctx, g64.n_cells), api.DeviceVector(ctx, g64.n_cells)
+        api.fill_with(b64, 1.0)
+        s64 = api.CgSolver()
+        ctx.sync()
+        tg = time.perf_counter()
+        s64.solve(x64, b64, api.HipStencilOperator(m64, -1.0, 0.0))
+        ctx.sync()
+        tg = time.perf_counter() - tg
+        xg = x64.to_numpy()
+        cpu["config1_64cubed"] = {
+            "cpu_iterations": r64.iterations, "gpu_iterations": s64.iteration, "cpu_seconds": t64, "gpu_seconds": tg,
+            "solution_rel_diff": float(np.linalg.norm(xg - r64.x) / np.linalg.norm(r64.x))}
+        m64.close()
 
     if rank == 0:
         value = world * K / elapsed

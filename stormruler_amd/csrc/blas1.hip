@@ -1,23 +1,23 @@
 // BLAS-1 kernels: the element loops and reductions the Krylov bodies run on
 // (reference: Bittern/MatrixAlgorithms.hpp:58-81 matrix_for_each, :162-205 reduce).
 //
-// All kernels are HBM-bound streams: 16-byte (double2) accesses per lane, a
-// grid capped at a few resident blocks per CU with a grid-stride loop, and --
-// for reductions -- per-lane partial sums folded with 64-wide __shfl_down,
-// then across the 4 waves of a block through LDS, then one fixed-order final
-// pass over the per-block partials.  The summation tree depends only on
-// (n, grid), so results are bitwise reproducible run to run.
+// All kernels are HBM-bound streams.  Shape (measured, tools/stream_bench.hip): one trip per
+// thread, 4 independent 16-byte accesses per stream in flight per lane, non-temporal loads and
+// stores, grid = ceil(n / 2048) blocks.  Reductions fold per-lane partials with a 64-wide
+// __shfl_down tree, then across the 4 waves of a block through LDS, then a fixed-order final
+// pass over the per-block partials (two passes when there are more than 4096 of them).  The
+// summation tree depends only on n, so results are bitwise reproducible run to run.
 #include "common.hpp"
 
 namespace storm {
 
-__device__ __forceinline__ double ld_scal(const Scal &s) { return s.p ? (*s.p) * s.sign : s.v; }
+typedef double double2v __attribute__((ext_vector_type(2)));
 
-static inline int ew_blocks(const storm_hip_ctx *c, int64_t n) {
-  // each thread moves double2 x 2 per trip
-  const int64_t need = (n / 2 + kBlock * 2 - 1) / (kBlock * 2);
-  const int64_t cap = (int64_t)c->num_cus * 8;
-  return (int)(need < 1 ? 1 : (need > cap ? cap : need));
+__device__ __forceinline__ double ld_scal(const Scal &s) { return s.p ? (*s.p) * s.sign : s.v; }
+__device__ __forceinline__ double2v ld2(const double2v *p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ void st2(double2v *p, double2v v, bool nt) {
+  if (nt) __builtin_nontemporal_store(v, p);
+  else *p = v;
 }
 
 // ---- elementwise ---------------------------------------------------------------------
@@ -27,25 +27,35 @@ struct EwPtrs {
 };
 
 template <class F>
-__global__ __launch_bounds__(kBlock) void ew_kernel(int64_t n, EwPtrs p, F f, const int *done, int rev) {
+__global__ __launch_bounds__(kBlock) void ew_kernel(int64_t n, EwPtrs p, F f, const int *done, int nt) {
   if (done && *done) return;
   f.prepare();
   const int64_t n2 = n >> 1;
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  double2 *__restrict__ y2 = reinterpret_cast<double2 *>(p.y);
-  const double2 *__restrict__ a2 = reinterpret_cast<const double2 *>(p.x0);
-  const double2 *__restrict__ b2 = reinterpret_cast<const double2 *>(p.x1);
-#pragma unroll 2
-  for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < n2; i0 += stride) {
-    const int64_t i = rev ? n2 - 1 - i0 : i0;
-    double2 vy = make_double2(0, 0), va = make_double2(0, 0), vb = make_double2(0, 0);
-    if (F::reads_y) vy = y2[i];
-    if (F::nin > 0) va = a2[i];
-    if (F::nin > 1) vb = b2[i];
-    double2 o;
-    o.x = f(vy.x, va.x, vb.x);
-    o.y = f(vy.y, va.y, vb.y);
-    y2[i] = o;
+  double2v *__restrict__ y2 = reinterpret_cast<double2v *>(p.y);
+  const double2v *__restrict__ a2 = reinterpret_cast<const double2v *>(p.x0);
+  const double2v *__restrict__ b2 = reinterpret_cast<const double2v *>(p.x1);
+  for (int64_t base = (int64_t)blockIdx.x * (kBlock * kUnroll) + threadIdx.x; base < n2;
+       base += (int64_t)gridDim.x * (kBlock * kUnroll)) {
+    double2v vy[kUnroll], va[kUnroll], vb[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t i = base + u * kBlock;
+      if (i < n2) {
+        if (F::reads_y) vy[u] = ld2(y2 + i, nt);
+        if (F::nin > 0) va[u] = ld2(a2 + i, nt);
+        if (F::nin > 1) vb[u] = ld2(b2 + i, nt);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t i = base + u * kBlock;
+      if (i < n2) {
+        double2v o;
+        o.x = f(F::reads_y ? vy[u].x : 0.0, F::nin > 0 ? va[u].x : 0.0, F::nin > 1 ? vb[u].x : 0.0);
+        o.y = f(F::reads_y ? vy[u].y : 0.0, F::nin > 0 ? va[u].y : 0.0, F::nin > 1 ? vb[u].y : 0.0);
+        st2(y2 + i, o, nt);
+      }
+    }
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const int64_t i = n - 1;
@@ -100,8 +110,8 @@ struct BicgPF {
 template <class F>
 static int launch_ew(storm_hip_ctx *c, int64_t n, EwPtrs p, F f, const int *done) {
   if (n <= 0) return STORM_HIP_OK;
-  hipLaunchKernelGGL(ew_kernel<F>, dim3(ew_blocks(c, n)), dim3(kBlock), 0, c->stream, n, p, f, done,
-                     c->next_dir());
+  hipLaunchKernelGGL(ew_kernel<F>, dim3(stream_blocks(n)), dim3(kBlock), 0, c->stream, n, p, f, done,
+                     (int)(c->opt_blas1_nt != 0));
   HIP_TRY(hipGetLastError());
   return STORM_HIP_OK;
 }
@@ -145,23 +155,40 @@ struct DotPtrs {
 template <int KB>
 __global__ __launch_bounds__(kBlock) void multi_dot_kernel(int64_t n, const double *__restrict__ a,
                                                            DotPtrs bs, double *__restrict__ partials,
-                                                           const int *done) {
+                                                           const int *done, int nt) {
   if (done && *done) return;
   __shared__ double lds4[4];
   double acc[KB];
 #pragma unroll
   for (int j = 0; j < KB; ++j) acc[j] = 0.0;
   const int64_t n2 = n >> 1;
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  const double2 *__restrict__ a2 = reinterpret_cast<const double2 *>(a);
-#pragma unroll 2
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
-    const double2 va = a2[i];
+  const double2v *__restrict__ a2 = reinterpret_cast<const double2v *>(a);
+  constexpr int U = KB <= 2 ? kUnroll : 2;  // keep the in-flight registers bounded for wide KB
+  for (int64_t base = (int64_t)blockIdx.x * (kBlock * kUnroll) + threadIdx.x; base < n2;
+       base += (int64_t)gridDim.x * (kBlock * kUnroll)) {
 #pragma unroll
-    for (int j = 0; j < KB; ++j) {
-      const double2 vb = reinterpret_cast<const double2 *>(bs.b[j])[i];
-      acc[j] += va.x * vb.x;
-      acc[j] += va.y * vb.y;
+    for (int u0 = 0; u0 < kUnroll; u0 += U) {
+      double2v va[U], vb[U][KB];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = base + (u0 + u) * kBlock;
+        if (i < n2) {
+          va[u] = ld2(a2 + i, nt);
+#pragma unroll
+          for (int j = 0; j < KB; ++j) vb[u][j] = ld2(reinterpret_cast<const double2v *>(bs.b[j]) + i, nt);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = base + (u0 + u) * kBlock;
+        if (i < n2) {
+#pragma unroll
+          for (int j = 0; j < KB; ++j) {
+            acc[j] += va[u].x * vb[u][j].x;
+            acc[j] += va[u].y * vb[u][j].y;
+          }
+        }
+      }
     }
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -188,16 +215,31 @@ __global__ __launch_bounds__(kBlock) void reduce_final_kernel(const double *__re
   if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 
-static inline int reduce_blocks(const storm_hip_ctx *c, int64_t n) {
-  const int64_t need = (n / 2 + kBlock * 4 - 1) / (kBlock * 4);
-  const int64_t cap = (int64_t)c->num_cus * 4;
-  int64_t b = need < 1 ? 1 : (need > cap ? cap : need);
-  if (b > kMaxReduceBlocks) b = kMaxReduceBlocks;
-  return (int)b;
+// First pass when a kernel left many partials: kStage2 blocks per array fold it to kStage2 values.
+__global__ __launch_bounds__(kBlock) void reduce_stage1_plain_kernel(const double *__restrict__ partials,
+                                                                     int nblocks, double *__restrict__ out,
+                                                                     const int *done) {
+  if (done && *done) return;
+  __shared__ double lds4[4];
+  const int j = blockIdx.y, g = blockIdx.x;
+  const int chunk = (nblocks + gridDim.x - 1) / gridDim.x;
+  const int i0 = g * chunk, i1 = min(i0 + chunk, nblocks);
+  const double *p = partials + (int64_t)j * nblocks;
+  double v = 0.0;
+  for (int i = i0 + threadIdx.x; i < i1; i += kBlock) v += p[i];
+  const double s = block_sum(v, lds4);
+  if (threadIdx.x == 0) out[j * gridDim.x + g] = s;
 }
 
 int k_reduce_final(storm_hip_ctx *c, const double *partials, int nblocks, int k, double *d_out,
                    const int *done) {
+  if (nblocks > 4096) {
+    hipLaunchKernelGGL(reduce_stage1_plain_kernel, dim3(kStage2, k), dim3(kBlock), 0, c->stream, partials,
+                       nblocks, c->d_partials2, done);
+    HIP_TRY(hipGetLastError());
+    partials = c->d_partials2;
+    nblocks = kStage2;
+  }
   hipLaunchKernelGGL(reduce_final_kernel, dim3(k), dim3(kBlock), 0, c->stream, partials, nblocks,
                      d_out, done);
   HIP_TRY(hipGetLastError());
@@ -207,7 +249,9 @@ int k_reduce_final(storm_hip_ctx *c, const double *partials, int nblocks, int k,
 int k_multi_dot(storm_hip_ctx *c, const double *a, const double *const *bs, int k, int64_t n,
                 double *d_out, const int *done) {
   STORM_REQUIRE(k >= 1 && k <= kMaxMulti, "multi_dot: k = %d outside [1, %d]", k, kMaxMulti);
-  const int nb = reduce_blocks(c, n);
+  int nb = stream_blocks(n);
+  if ((int64_t)nb * k > c->partials_capacity) nb = (int)(c->partials_capacity / k);  // grid-stride covers the rest
+  const int nt = (int)(c->opt_blas1_nt != 0);
   for (int j0 = 0; j0 < k; j0 += kDotChunk) {
     const int kb = (k - j0) < kDotChunk ? (k - j0) : kDotChunk;
     DotPtrs ptrs;
@@ -215,14 +259,14 @@ int k_multi_dot(storm_hip_ctx *c, const double *a, const double *const *bs, int 
     double *part = c->d_partials + (int64_t)j0 * nb;
     const dim3 g(nb), b(kBlock);
     switch (kb) {
-      case 1: hipLaunchKernelGGL(multi_dot_kernel<1>, g, b, 0, c->stream, n, a, ptrs, part, done); break;
-      case 2: hipLaunchKernelGGL(multi_dot_kernel<2>, g, b, 0, c->stream, n, a, ptrs, part, done); break;
-      case 3: hipLaunchKernelGGL(multi_dot_kernel<3>, g, b, 0, c->stream, n, a, ptrs, part, done); break;
-      case 4: hipLaunchKernelGGL(multi_dot_kernel<4>, g, b, 0, c->stream, n, a, ptrs, part, done); break;
-      case 5: hipLaunchKernelGGL(multi_dot_kernel<5>, g, b, 0, c->stream, n, a, ptrs, part, done); break;
-      case 6: hipLaunchKernelGGL(multi_dot_kernel<6>, g, b, 0, c->stream, n, a, ptrs, part, done); break;
-      case 7: hipLaunchKernelGGL(multi_dot_kernel<7>, g, b, 0, c->stream, n, a, ptrs, part, done); break;
-      default: hipLaunchKernelGGL(multi_dot_kernel<8>, g, b, 0, c->stream, n, a, ptrs, part, done); break;
+      case 1: hipLaunchKernelGGL(multi_dot_kernel<1>, g, b, 0, c->stream, n, a, ptrs, part, done, nt); break;
+      case 2: hipLaunchKernelGGL(multi_dot_kernel<2>, g, b, 0, c->stream, n, a, ptrs, part, done, nt); break;
+      case 3: hipLaunchKernelGGL(multi_dot_kernel<3>, g, b, 0, c->stream, n, a, ptrs, part, done, nt); break;
+      case 4: hipLaunchKernelGGL(multi_dot_kernel<4>, g, b, 0, c->stream, n, a, ptrs, part, done, nt); break;
+      case 5: hipLaunchKernelGGL(multi_dot_kernel<5>, g, b, 0, c->stream, n, a, ptrs, part, done, nt); break;
+      case 6: hipLaunchKernelGGL(multi_dot_kernel<6>, g, b, 0, c->stream, n, a, ptrs, part, done, nt); break;
+      case 7: hipLaunchKernelGGL(multi_dot_kernel<7>, g, b, 0, c->stream, n, a, ptrs, part, done, nt); break;
+      default: hipLaunchKernelGGL(multi_dot_kernel<8>, g, b, 0, c->stream, n, a, ptrs, part, done, nt); break;
     }
     HIP_TRY(hipGetLastError());
   }
@@ -240,24 +284,41 @@ struct AxpyArgs {
 
 template <int KB>
 __global__ __launch_bounds__(kBlock) void multi_axpy_kernel(int64_t n, double *__restrict__ y,
-                                                            AxpyArgs a, const int *done) {
+                                                            AxpyArgs a, const int *done, int nt) {
   if (done && *done) return;
   double cf[KB];
 #pragma unroll
   for (int j = 0; j < KB; ++j) cf[j] = a.dc ? a.dc[j] * a.sign : a.c[j];
   const int64_t n2 = n >> 1;
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  double2 *__restrict__ y2 = reinterpret_cast<double2 *>(y);
-#pragma unroll 2
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
-    double2 vy = y2[i];
+  double2v *__restrict__ y2 = reinterpret_cast<double2v *>(y);
+  constexpr int U = KB <= 2 ? kUnroll : 2;
+  for (int64_t base = (int64_t)blockIdx.x * (kBlock * kUnroll) + threadIdx.x; base < n2;
+       base += (int64_t)gridDim.x * (kBlock * kUnroll)) {
 #pragma unroll
-    for (int j = 0; j < KB; ++j) {
-      const double2 vx = reinterpret_cast<const double2 *>(a.x[j])[i];
-      vy.x += cf[j] * vx.x;
-      vy.y += cf[j] * vx.y;
+    for (int u0 = 0; u0 < kUnroll; u0 += U) {
+      double2v vy[U], vx[U][KB];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = base + (u0 + u) * kBlock;
+        if (i < n2) {
+          vy[u] = ld2(y2 + i, nt);
+#pragma unroll
+          for (int j = 0; j < KB; ++j) vx[u][j] = ld2(reinterpret_cast<const double2v *>(a.x[j]) + i, nt);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = base + (u0 + u) * kBlock;
+        if (i < n2) {
+#pragma unroll
+          for (int j = 0; j < KB; ++j) {
+            vy[u].x += cf[j] * vx[u][j].x;
+            vy[u].y += cf[j] * vx[u][j].y;
+          }
+          st2(y2 + i, vy[u], nt);
+        }
+      }
     }
-    y2[i] = vy;
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     double vy = y[n - 1];
@@ -270,7 +331,8 @@ __global__ __launch_bounds__(kBlock) void multi_axpy_kernel(int64_t n, double *_
 static int multi_axpy_impl(storm_hip_ctx *c, double *y, const double *h_coef, const double *d_coef,
                            double sign, const double *const *xs, int k, int64_t n, const int *done) {
   if (n <= 0 || k <= 0) return STORM_HIP_OK;
-  const dim3 g(ew_blocks(c, n)), b(kBlock);
+  const dim3 g(stream_blocks(n)), b(kBlock);
+  const int nt = (int)(c->opt_blas1_nt != 0);
   for (int j0 = 0; j0 < k; j0 += kAxpyChunk) {
     const int kb = (k - j0) < kAxpyChunk ? (k - j0) : kAxpyChunk;
     AxpyArgs a;
@@ -281,14 +343,14 @@ static int multi_axpy_impl(storm_hip_ctx *c, double *y, const double *h_coef, co
     a.dc = d_coef ? d_coef + j0 : nullptr;
     a.sign = sign;
     switch (kb) {
-      case 1: hipLaunchKernelGGL(multi_axpy_kernel<1>, g, b, 0, c->stream, n, y, a, done); break;
-      case 2: hipLaunchKernelGGL(multi_axpy_kernel<2>, g, b, 0, c->stream, n, y, a, done); break;
-      case 3: hipLaunchKernelGGL(multi_axpy_kernel<3>, g, b, 0, c->stream, n, y, a, done); break;
-      case 4: hipLaunchKernelGGL(multi_axpy_kernel<4>, g, b, 0, c->stream, n, y, a, done); break;
-      case 5: hipLaunchKernelGGL(multi_axpy_kernel<5>, g, b, 0, c->stream, n, y, a, done); break;
-      case 6: hipLaunchKernelGGL(multi_axpy_kernel<6>, g, b, 0, c->stream, n, y, a, done); break;
-      case 7: hipLaunchKernelGGL(multi_axpy_kernel<7>, g, b, 0, c->stream, n, y, a, done); break;
-      default: hipLaunchKernelGGL(multi_axpy_kernel<8>, g, b, 0, c->stream, n, y, a, done); break;
+      case 1: hipLaunchKernelGGL(multi_axpy_kernel<1>, g, b, 0, c->stream, n, y, a, done, nt); break;
+      case 2: hipLaunchKernelGGL(multi_axpy_kernel<2>, g, b, 0, c->stream, n, y, a, done, nt); break;
+      case 3: hipLaunchKernelGGL(multi_axpy_kernel<3>, g, b, 0, c->stream, n, y, a, done, nt); break;
+      case 4: hipLaunchKernelGGL(multi_axpy_kernel<4>, g, b, 0, c->stream, n, y, a, done, nt); break;
+      case 5: hipLaunchKernelGGL(multi_axpy_kernel<5>, g, b, 0, c->stream, n, y, a, done, nt); break;
+      case 6: hipLaunchKernelGGL(multi_axpy_kernel<6>, g, b, 0, c->stream, n, y, a, done, nt); break;
+      case 7: hipLaunchKernelGGL(multi_axpy_kernel<7>, g, b, 0, c->stream, n, y, a, done, nt); break;
+      default: hipLaunchKernelGGL(multi_axpy_kernel<8>, g, b, 0, c->stream, n, y, a, done, nt); break;
     }
     HIP_TRY(hipGetLastError());
   }

@@ -104,6 +104,7 @@ struct storm_hip_ctx {
   // Infinity Cache (a vector is 134 MB at 256^3; same-direction sweeps would evict every line
   // just before its reuse).
   int64_t opt_zigzag = 0;   // measured: no gain on MI355X (profiles/r01_notes.md); off by default
+  int64_t opt_blas1_nt = 1;  // non-temporal loads/stores in the streaming kernels
   int64_t opt_fuse_dot = 1;  // 0: reductions after an SpMV run as separate kernels (A/B knob)
   int sweep_dir = 0;
   int next_dir() { if (!opt_zigzag) return 0; sweep_dir ^= 1; return sweep_dir; }
@@ -169,6 +170,19 @@ struct Scal {
 };
 static inline Scal host_scal(double v) { return Scal{nullptr, v, 1.0}; }
 static inline Scal dev_scal(const double *p, double sign = 1.0) { return Scal{p, 0.0, sign}; }
+
+// Shape of every streaming (BLAS-1) kernel, from tools/stream_bench.hip on MI355X (1 GiB copy):
+// a grid capped at 8 blocks/CU with a grid-stride loop reaches 4.96 TB/s; one trip per thread
+// with 4 independent 16-byte accesses per stream in flight, non-temporal loads and stores,
+// 6.47 TB/s.  So: blocks = ceil(n / 2048), each thread moves 4 double2 per stream.
+constexpr int kUnroll = 4;
+constexpr int kStreamBlockElems = kBlock * kUnroll * 2;  // doubles per block and stream
+static inline int stream_blocks(int64_t n) {
+  int64_t b = (n + kStreamBlockElems - 1) / kStreamBlockElems;
+  if (b < 1) b = 1;
+  if (b > 32768) b = 32768;  // beyond: grid-stride (keeps the partial arrays bounded)
+  return (int)b;
+}
 
 // blas1.hip -- all asynchronous on ctx->stream, owned rows only.
 // `done` (nullable): device flag; kernels return immediately when it is set.

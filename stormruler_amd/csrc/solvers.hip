@@ -177,31 +177,48 @@ __global__ void step_kernel(int step, SolverState *st, GmresDev g, bool force) {
 }
 
 // ---- fused vector kernels ------------------------------------------------------------------------
-static inline int vec_blocks(const storm_hip_ctx *c, int64_t n) {
-  const int64_t need = (n / 2 + kBlock * 2 - 1) / (kBlock * 2);
-  const int64_t cap = (int64_t)c->num_cus * 4;
-  return (int)(need < 1 ? 1 : (need > cap ? cap : need));
+// Same streaming shape as blas1.hip: one trip per thread, kUnroll x 16 bytes per stream in flight.
+typedef double double2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2v ldv(const double2v *p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ void stv(double2v *p, double2v v, bool nt) {
+  if (nt) __builtin_nontemporal_store(v, p);
+  else *p = v;
 }
+static inline int vec_blocks(const storm_hip_ctx *, int64_t n) { return stream_blocks(n); }
+
+#define STORM_STREAM_FOR(base, n2) \
+  for (int64_t base = (int64_t)blockIdx.x * (kBlock * kUnroll) + threadIdx.x; base < (n2); \
+       base += (int64_t)gridDim.x * (kBlock * kUnroll))
 
 // r <<= b - r (Operator.hpp:98); p <<= r (SolverCg.hpp:81 / SolverBiCgStab.hpp:87 for rt);
 // partial <r, r>.
 __global__ __launch_bounds__(kBlock) void init_residual_kernel(int64_t n, double *__restrict__ r,
                                                                const double *__restrict__ b,
                                                                double *__restrict__ copy_to,
-                                                               double *__restrict__ partials) {
+                                                               double *__restrict__ partials, int nt) {
   __shared__ double lds4[4];
   double acc = 0.0;
-  const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * kBlock;
-  double2 *r2 = reinterpret_cast<double2 *>(r), *c2 = reinterpret_cast<double2 *>(copy_to);
-  const double2 *b2 = reinterpret_cast<const double2 *>(b);
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
-    const double2 vb = b2[i], vr = r2[i];
-    double2 v;
-    v.x = vb.x - vr.x, v.y = vb.y - vr.y;
-    r2[i] = v;
-    if (copy_to) c2[i] = v;
-    acc += v.x * v.x;
-    acc += v.y * v.y;
+  const int64_t n2 = n >> 1;
+  double2v *r2 = reinterpret_cast<double2v *>(r), *c2 = reinterpret_cast<double2v *>(copy_to);
+  const double2v *b2 = reinterpret_cast<const double2v *>(b);
+  STORM_STREAM_FOR(base, n2) {
+    double2v vb[kUnroll], vr[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t i = base + u * kBlock;
+      if (i < n2) vb[u] = ldv(b2 + i, nt), vr[u] = ldv(r2 + i, nt);
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t i = base + u * kBlock;
+      if (i < n2) {
+        const double2v v = vb[u] - vr[u];
+        stv(r2 + i, v, nt);
+        if (copy_to) stv(c2 + i, v, nt);
+        acc += v.x * v.x;
+        acc += v.y * v.y;
+      }
+    }
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const double v = b[n - 1] - r[n - 1];
@@ -217,24 +234,33 @@ __global__ __launch_bounds__(kBlock) void init_residual_kernel(int64_t n, double
 __global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, SolverState *st, double *__restrict__ x,
                                                            double *__restrict__ r, const double *__restrict__ p,
                                                            const double *__restrict__ z,
-                                                           double *__restrict__ partials, int rev) {
+                                                           double *__restrict__ partials, int nt) {
   if (st->done) return;
   __shared__ double lds4[4];
   const double alpha = safe_divide(st->s[S_GAMMA], st->s[S_PZ]);
   double acc = 0.0;
-  const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * kBlock;
-  double2 *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r);
-  const double2 *p2 = reinterpret_cast<const double2 *>(p), *z2 = reinterpret_cast<const double2 *>(z);
-#pragma unroll 2
-  for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < n2; i0 += stride) {
-    const int64_t i = rev ? n2 - 1 - i0 : i0;
-    double2 vx = x2[i], vr = r2[i];
-    const double2 vp = p2[i], vz = z2[i];
-    vx.x += alpha * vp.x, vx.y += alpha * vp.y;
-    vr.x -= alpha * vz.x, vr.y -= alpha * vz.y;
-    x2[i] = vx, r2[i] = vr;
-    acc += vr.x * vr.x;
-    acc += vr.y * vr.y;
+  const int64_t n2 = n >> 1;
+  double2v *x2 = reinterpret_cast<double2v *>(x), *r2 = reinterpret_cast<double2v *>(r);
+  const double2v *p2 = reinterpret_cast<const double2v *>(p), *z2 = reinterpret_cast<const double2v *>(z);
+  STORM_STREAM_FOR(base, n2) {
+    double2v vx[kUnroll], vr[kUnroll], vp[kUnroll], vz[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t i = base + u * kBlock;
+      if (i < n2) vx[u] = ldv(x2 + i, nt), vr[u] = ldv(r2 + i, nt), vp[u] = ldv(p2 + i, nt), vz[u] = ldv(z2 + i, nt);
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t i = base + u * kBlock;
+      if (i < n2) {
+        vx[u] += alpha * vp[u];
+        vr[u] -= alpha * vz[u];
+        stv(x2 + i, vx[u], nt);
+        stv(r2 + i, vr[u], nt);
+        acc += vr[u].x * vr[u].x;
+        acc += vr[u].y * vr[u].y;
+      }
+    }
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const int64_t i = n - 1;
@@ -254,29 +280,42 @@ __global__ __launch_bounds__(kBlock) void bicg_update_kernel(int64_t n, SolverSt
                                                              double *__restrict__ r, const double *__restrict__ u,
                                                              const double *__restrict__ w,
                                                              const double *__restrict__ rt,
-                                                             double *__restrict__ partials) {
+                                                             double *__restrict__ partials, int nt) {
   if (st->done) return;
   __shared__ double lds4[4];
   const double a = SECOND ? st->s[S_OMEGA] : st->s[S_ALPHA];
   double acc_rr = 0.0, acc_rho = 0.0;
-  const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * kBlock;
-  double2 *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r);
-  const double2 *u2 = reinterpret_cast<const double2 *>(u), *w2 = reinterpret_cast<const double2 *>(w);
-  const double2 *rt2 = reinterpret_cast<const double2 *>(rt);
-#pragma unroll 2
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
-    double2 vx = x2[i], vr = r2[i];
-    const double2 vw = w2[i];
-    const double2 vu = SECOND ? vr : u2[i];  // second half-step adds omega * (old) r
-    vx.x += a * vu.x, vx.y += a * vu.y;
-    vr.x -= a * vw.x, vr.y -= a * vw.y;
-    x2[i] = vx, r2[i] = vr;
-    if (SECOND) {
-      const double2 vt = rt2[i];
-      acc_rr += vr.x * vr.x;
-      acc_rr += vr.y * vr.y;
-      acc_rho += vt.x * vr.x;
-      acc_rho += vt.y * vr.y;
+  const int64_t n2 = n >> 1;
+  double2v *x2 = reinterpret_cast<double2v *>(x), *r2 = reinterpret_cast<double2v *>(r);
+  const double2v *u2 = reinterpret_cast<const double2v *>(u), *w2 = reinterpret_cast<const double2v *>(w);
+  const double2v *rt2 = reinterpret_cast<const double2v *>(rt);
+  STORM_STREAM_FOR(base, n2) {
+    double2v vx[kUnroll], vr[kUnroll], vw[kUnroll], vu[kUnroll], vt[kUnroll];
+#pragma unroll
+    for (int q = 0; q < kUnroll; ++q) {
+      const int64_t i = base + q * kBlock;
+      if (i < n2) {
+        vx[q] = ldv(x2 + i, nt), vr[q] = ldv(r2 + i, nt), vw[q] = ldv(w2 + i, nt);
+        if (!SECOND) vu[q] = ldv(u2 + i, nt);
+        if (SECOND) vt[q] = ldv(rt2 + i, nt);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kUnroll; ++q) {
+      const int64_t i = base + q * kBlock;
+      if (i < n2) {
+        const double2v uu = SECOND ? vr[q] : vu[q];  // second half-step adds omega * (old) r
+        vx[q] += a * uu;
+        vr[q] -= a * vw[q];
+        stv(x2 + i, vx[q], nt);
+        stv(r2 + i, vr[q], nt);
+        if (SECOND) {
+          acc_rr += vr[q].x * vr[q].x;
+          acc_rr += vr[q].y * vr[q].y;
+          acc_rho += vt[q].x * vr[q].x;
+          acc_rho += vt[q].y * vr[q].y;
+        }
+      }
     }
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -531,7 +570,8 @@ int storm_hip_solve_cg(const storm_hip_op *op, double alpha, double beta, const 
   // init: r = b - A x; p = r; gamma = <r,r>          SolverCg.hpp:75-85
   int nb = 0;
   STORM_TRY(d.apply(x->d, r, nullptr, false, &nb, false));
-  hipLaunchKernelGGL(init_residual_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, r, b->d, p, c->d_partials);
+  hipLaunchKernelGGL(init_residual_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, r, b->d, p, c->d_partials,
+                     (int)(c->opt_blas1_nt != 0));
   HIP_TRY(hipGetLastError());
   {
     const int slots[1] = {S_GAMMA};
@@ -550,7 +590,7 @@ int storm_hip_solve_cg(const storm_hip_op *op, double alpha, double beta, const 
     }
     // x += alpha p; r -= alpha z; gamma = <r,r>       SolverCg.hpp:98-99,115
     hipLaunchKernelGGL(cg_update_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, x->d, r, p, z,
-                       c->d_partials, c->next_dir());
+                       c->d_partials, (int)(c->opt_blas1_nt != 0));
     HIP_TRY(hipGetLastError());
     {
       const int slots[1] = {S_GAMMA_NEW};
@@ -582,7 +622,8 @@ int storm_hip_solve_bicgstab(const storm_hip_op *op, double alpha, double beta, 
 
   // init: r = b - A x; rt = r; rho = <rt,r>           SolverBiCgStab.hpp:82-90
   STORM_TRY(d.apply(x->d, r, nullptr, false, &nb, false));
-  hipLaunchKernelGGL(init_residual_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, r, b->d, rt, c->d_partials);
+  hipLaunchKernelGGL(init_residual_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, r, b->d, rt, c->d_partials,
+                     (int)(c->opt_blas1_nt != 0));
   HIP_TRY(hipGetLastError());
   {
     const int slots[1] = {S_RHO};
@@ -609,7 +650,7 @@ int storm_hip_solve_bicgstab(const storm_hip_op *op, double alpha, double beta, 
     }
     // x += alpha p; r -= alpha v                      :140-141
     hipLaunchKernelGGL(bicg_update_kernel<false>, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, x->d, r, p, v,
-                       rt, c->d_partials);
+                       rt, c->d_partials, (int)(c->opt_blas1_nt != 0));
     HIP_TRY(hipGetLastError());
     // t = A r; omega = <t,r> / <t,t>                  :158-160
     STORM_TRY(d.apply(r, t, r, true, &nb));
@@ -625,7 +666,7 @@ int storm_hip_solve_bicgstab(const storm_hip_op *op, double alpha, double beta, 
     }
     // x += omega r; r -= omega t; |r|, <rt,r>         :161-164 (+ :116 of the next iteration)
     hipLaunchKernelGGL(bicg_update_kernel<true>, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, x->d, r,
-                       (const double *)nullptr, t, rt, c->d_partials);
+                       (const double *)nullptr, t, rt, c->d_partials, (int)(c->opt_blas1_nt != 0));
     HIP_TRY(hipGetLastError());
     {
       const int slots[2] = {S_RR, S_RHO_NEW};
@@ -673,7 +714,7 @@ int storm_hip_solve_gmres(const storm_hip_op *op, double alpha, double beta, con
     STORM_TRY(d.apply(x->d, q0, nullptr, false, &nb, !outer));
     if (outer) {
       hipLaunchKernelGGL(init_residual_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, q0, b->d,
-                         (double *)nullptr, c->d_partials);
+                         (double *)nullptr, c->d_partials, (int)(c->opt_blas1_nt != 0));
       HIP_TRY(hipGetLastError());
       const int slots[1] = {S_TMP};
       STORM_TRY(d.finish(nbv, 1, slots, STEP_GMRES_BETA0_OUTER, true));
