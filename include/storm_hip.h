@@ -111,6 +111,9 @@ int storm_hip_axpbz(storm_hip_vec *y, double a, const storm_hip_vec *x, double b
 /* p <<= r + beta*(p - omega*v)   SolverBiCgStab.hpp:119 */
 int storm_hip_bicgstab_p(storm_hip_vec *p, const storm_hip_vec *r, double beta, double omega,
                          const storm_hip_vec *v);
+/* y += s * (a .* b), elementwise.  Not in the solver census: the nonlinear term a time-step
+ * driver forms between solves (cf. `f <<= map(dF_dc, c)`, Playground.cpp:148). */
+int storm_hip_vmul_add(storm_hip_vec *y, double s, const storm_hip_vec *a, const storm_hip_vec *b);
 /* dot_product(a, b)  MatrixAlgorithms.hpp:310-317;  norm_2(a)  :262-270 */
 int storm_hip_dot(const storm_hip_vec *a, const storm_hip_vec *b, double *result);
 int storm_hip_norm2(const storm_hip_vec *a, double *result);

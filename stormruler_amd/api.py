@@ -262,6 +262,11 @@ def fill_with(a: DeviceVector, value: float) -> None:
     check(lib.storm_hip_fill(a._h, float(value)))
 
 
+def vmul_add(y: DeviceVector, s: float, a: DeviceVector, b: DeviceVector) -> None:
+    """``y += s * (a .* b)`` elementwise (nonlinear terms of a time-step driver)."""
+    check(lib.storm_hip_vmul_add(y._h, float(s), a._h, b._h))
+
+
 def multi_dot(a: DeviceVector, bs: Sequence[DeviceVector]) -> np.ndarray:
     k = len(bs)
     arr = (C.c_void_p * k)(*[b._h for b in bs])

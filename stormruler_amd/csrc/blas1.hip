@@ -107,6 +107,15 @@ struct BicgPF {
   __device__ double operator()(double p, double r, double v) const { return r + bv * (p - wv * v); }
 };
 
+// y += s * (x0 .* x1)
+struct VmulAddF {
+  static constexpr bool reads_y = true;
+  static constexpr int nin = 2;
+  double s;
+  __device__ void prepare() {}
+  __device__ double operator()(double y, double a, double b) const { return y + s * (a * b); }
+};
+
 template <class F>
 static int launch_ew(storm_hip_ctx *c, int64_t n, EwPtrs p, F f, const int *done) {
   if (n <= 0) return STORM_HIP_OK;
@@ -421,6 +430,13 @@ int storm_hip_axpbz(storm_hip_vec *y, double a, const storm_hip_vec *x, double b
   STORM_TRY(check_pair(y, x, "axpbz"));
   STORM_TRY(check_pair(y, z, "axpbz"));
   return k_axpbz(y->ctx, y->d, host_scal(a), x->d, host_scal(b), z->d, y->n_owned, nullptr);
+}
+
+int storm_hip_vmul_add(storm_hip_vec *y, double s, const storm_hip_vec *a, const storm_hip_vec *b) {
+  STORM_TRY(check_pair(y, a, "vmul_add"));
+  STORM_TRY(check_pair(y, b, "vmul_add"));
+  if (y->n_owned <= 0) return STORM_HIP_OK;
+  return launch_ew(y->ctx, y->n_owned, EwPtrs{y->d, a->d, b->d}, VmulAddF{s}, nullptr);
 }
 
 int storm_hip_bicgstab_p(storm_hip_vec *p, const storm_hip_vec *r, double beta, double omega,

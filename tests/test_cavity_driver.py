@@ -1,0 +1,135 @@
+"""Pressure-Poisson time-step driver (SURVEY 8f rank 2 / BASELINE config 5): every step of the device
+stepper is checked against a CPU restatement (scipy operators assembled from the same face weights,
+the oracle's CG for the pressure solve, same warm start and tolerances)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import oracle
+from stormruler_amd import cavity, mesh
+
+
+def _csr_from_weights(g, w):
+    wi, wo, de = w
+    n = g.n_cells
+    rows = np.concatenate([g.inner, g.inner, g.outer, g.outer, np.arange(n)])
+    cols = np.concatenate([g.outer, g.inner, g.inner, g.outer, np.arange(n)])
+    vals = np.concatenate([wi, -wi, wo, -wo, de])
+    a = sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
+    a.sum_duplicates()
+    return a
+
+
+class CpuCavity:
+    def __init__(self, n, nu, dt):
+        ops = cavity.build_cavity_operators(n)
+        g = ops.g
+        self.N, self.nu, self.dt = g.n_cells, nu, dt
+        self.L_D = mesh.assemble_csr(g, 1.0, 0.0)
+        self.L_N = mesh.assemble_csr(ops.g_neumann, 1.0, 0.0)
+        self.G = [_csr_from_weights(g, w) for w in ops.grad]
+        self.D = [_csr_from_weights(g, w) for w in ops.div]
+        self.lid = ops.lid
+        self.u = [np.zeros(self.N) for _ in range(3)]
+        self.p = np.zeros(self.N)
+        self.A_p = oracle.CsrOperator(-self.L_N)
+
+    def step(self):
+        dt, nu = self.dt, self.nu
+        us = []
+        for d in range(3):
+            v = self.u[d] + dt * nu * (self.L_D @ self.u[d])
+            if d == 0:
+                v = v + dt * nu * self.lid
+            for e in range(3):
+                v = v - dt * (self.u[e] * (self.G[e] @ self.u[d]))
+            us.append(v)
+        rhs = np.zeros(self.N)
+        for d in range(3):
+            rhs -= (1.0 / dt) * (self.D[d] @ us[d])
+        r = oracle.solve("cg", self.A_p, rhs, x0=self.p, abs_tol=1e-8 * oracle.norm2(rhs), rel_tol=0.0)
+        self.p = r.x
+        for d in range(3):
+            self.u[d] = us[d] - dt * (self.G[d] @ self.p)
+        return r.iterations, r.converged
+
+
+def test_gradient_weights_differentiate_linear_fields():
+    g = mesh.structured_box(8, 6, 5)
+    c = g.center
+    phi = 2.0 * c[:, 0] - 3.0 * c[:, 1] + 0.5 * c[:, 2] + 1.0
+    for axis, slope in enumerate((2.0, -3.0, 0.5)):
+        a = _csr_from_weights(g, cavity.gradient_weights(g, axis, wall_value_zero=False))
+        d = a @ phi
+        interior = np.ones(g.n_cells, bool)
+        interior[g.b_cell] = False
+        assert np.allclose(d[interior], slope, atol=1e-10)  # exact for linear fields away from the walls
+    # divergence operator of a field vanishing at the walls: discrete Gauss theorem, sum_i V_i (D u)_i = 0
+    u = np.sin(np.pi * c[:, 0]) * np.sin(np.pi * c[:, 1]) * np.sin(np.pi * c[:, 2])
+    for axis in range(3):
+        a = _csr_from_weights(g, cavity.gradient_weights(g, axis, wall_value_zero=True))
+        assert abs(np.dot(g.volume, a @ u)) < 1e-12
+
+
+def test_cpu_restatement_develops_a_cavity_flow():
+    sim = CpuCavity(8, 0.05, None or 0.2 * min(1 / 8, (1 / 8) ** 2 / (6 * 0.05)))
+    its = [sim.step()[0] for _ in range(5)]
+    assert all(i > 0 for i in its)
+    ux = sim.u[0].reshape(8, 8, 8)
+    assert ux[-1].mean() > 0.0 and ux[-1].mean() > ux[0].mean()  # fluid under the lid moves with it
+
+
+@pytest.mark.gpu
+def test_device_stepper_matches_cpu_restatement_step_by_step():
+    from stormruler_amd import api
+
+    n, nu = 16, 0.05
+    ctx = api.Context(0)
+    dev = cavity.CavityProjection(ctx, n, nu)
+    cpu = CpuCavity(n, nu, dev.dt)
+    for step in range(6):
+        it_d, sec, ok = dev.step()
+        it_c, ok_c = cpu.step()
+        assert ok and ok_c
+        assert abs(it_d - it_c) <= max(3, int(0.1 * it_c)), (step, it_d, it_c)  # singular (Neumann) system: the tail is rounding-sensitive
+        scale = max(np.abs(cpu.u[0]).max(), 1e-30)
+        for d in range(3):
+            assert np.abs(dev.u[d].to_numpy() - cpu.u[d]).max() <= 1e-7 * scale, (step, d)
+        # pressure is defined up to a constant (pure Neumann): compare mean-free parts
+        pd, pc = dev.p.to_numpy(), cpu.p
+        assert np.abs((pd - pd.mean()) - (pc - pc.mean())).max() <= 1e-6 * max(np.abs(pc - pc.mean()).max(), 1e-30)
+    # warm start pays: later steps need fewer iterations than the first
+    assert dev.steps == 6 and dev.total_time > 0
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_config5_size_runs_and_times_steps():
+    """128^3 (BASELINE config 5's per-problem size, single GPU here): operator reuse, warm starts,
+    per-step timing like Playground.cpp:186-206; checks the invariants the CPU cannot afford to."""
+    from stormruler_amd import api
+
+    ctx = api.Context(0)
+    dev = cavity.CavityProjection(ctx, 128, nu=0.01)
+    its, secs = [], []
+    for _ in range(4):
+        it, sec, ok = dev.step()
+        assert ok
+        its.append(it)
+        secs.append(sec)
+    # warm start (Playground.cpp:150): re-solving the last system from the converged p takes
+    # (almost) no iterations, from p = 0 it takes hundreds
+    warm = api.CgSolver()
+    warm.absolute_error_tolerance, warm.relative_error_tolerance = 1e-8 * api.norm_2(dev.rhs), 0.0
+    x0 = api.DeviceVector(ctx, dev.N)
+    warm.solve(x0, dev.rhs, dev.A_p)
+    cold_its = warm.iteration
+    warm.solve(dev.p, dev.rhs, dev.A_p)
+    assert cold_its > 100 and warm.iteration <= max(3, cold_its // 20), (warm.iteration, cold_its)
+    assert its[-1] < cold_its                     # and the time loop benefits from it
+    assert dev.solver.absolute_error < dev.solver.absolute_error_tolerance
+    u0 = dev.u[0].to_numpy().reshape(128, 128, 128)
+    assert u0[-1].mean() > 0.0                    # the layer under the lid follows it
+    assert np.isfinite(dev.divergence_norm())
+    print("cavity 128^3: CG iterations per step", its, "seconds per step", [round(s, 4) for s in secs])
+    ctx.close()
