@@ -111,6 +111,10 @@ int storm_hip_axpbz(storm_hip_vec *y, double a, const storm_hip_vec *x, double b
 /* p <<= r + beta*(p - omega*v)   SolverBiCgStab.hpp:119 */
 int storm_hip_bicgstab_p(storm_hip_vec *p, const storm_hip_vec *r, double beta, double omega,
                          const storm_hip_vec *v);
+/* y <<= r + s*(a*x + b*z): the nested three-term updates -- BiCGStab's p (above) and CGS's
+ * `p <<= u + beta*(q + beta*p)`, SolverCgs.hpp:122.  y may alias any operand. */
+int storm_hip_lin3(storm_hip_vec *y, const storm_hip_vec *r, double s, double a, const storm_hip_vec *x,
+                   double b, const storm_hip_vec *z);
 /* y += s * (a .* b), elementwise.  Not in the solver census: the nonlinear term a time-step
  * driver forms between solves (cf. `f <<= map(dF_dc, c)`, Playground.cpp:148). */
 int storm_hip_vmul_add(storm_hip_vec *y, double s, const storm_hip_vec *a, const storm_hip_vec *b);

@@ -168,10 +168,9 @@ inline DeviceVector& operator<<=(DeviceVector& out, const expr::Lin2& e) {
   return out;
 }
 inline DeviceVector& operator<<=(DeviceVector& out, const expr::Lin3& e) {
-  // only the BiCGStab form  p <<= r + beta * (p - omega * v)  (SolverBiCgStab.hpp:119) has a kernel
-  if (e.e.x != &out || e.e.a != 1.0)
-    throw std::logic_error("storm_hip: no device kernel for this three-term expression");
-  detail::check(storm_hip_bicgstab_p(out.handle(), e.r->handle(), e.s, -e.e.b, e.e.z->handle()));
+  // p <<= r + beta * (p - omega * v)  (SolverBiCgStab.hpp:119) and  p <<= u + beta * (q + beta * p)
+  // (SolverCgs.hpp:122): one kernel that evaluates r + s * (a x + b z) in this nesting
+  detail::check(storm_hip_lin3(out.handle(), e.r->handle(), e.s, e.e.a, e.e.x->handle(), e.e.b, e.e.z->handle()));
   return out;
 }
 
@@ -584,6 +583,171 @@ private:
     return norm_2(_r_vec);
   }
 };
+
+/// Richardson iteration with a fixed relaxation factor (SolverRichardson.hpp:41-98).
+template<class Vector>
+class RichardsonSolver final : public IterativeSolver<Vector> {
+public:
+  real_t relaxation_factor = 1.0e-4;
+
+private:
+  Vector _r_vec, _z_vec;
+
+  void precondition(const Preconditioner<Vector>* pre_op) {
+    if (pre_op != nullptr) {
+      std::swap(_z_vec, _r_vec);
+      pre_op->mul(_r_vec, _z_vec);
+    }
+  }
+  real_t init(const Vector& x_vec, const Vector& b_vec, const Operator<Vector>& lin_op,
+              const Preconditioner<Vector>* pre_op) override {
+    _r_vec.assign(x_vec, false);
+    if (pre_op != nullptr) _z_vec.assign(x_vec, false);
+    lin_op.Residual(_r_vec, b_vec, x_vec);
+    precondition(pre_op);
+    return norm_2(_r_vec);
+  }
+  real_t iterate(Vector& x_vec, const Vector& b_vec, const Operator<Vector>& lin_op,
+                 const Preconditioner<Vector>* pre_op) override {
+    x_vec += relaxation_factor * _r_vec;
+    lin_op.Residual(_r_vec, b_vec, x_vec);
+    precondition(pre_op);
+    return norm_2(_r_vec);
+  }
+};
+
+/// Conjugate Gradients Squared (SolverCgs.hpp:50-176).
+template<class Vector>
+class CgsSolver final : public IterativeSolver<Vector> {
+private:
+  real_t _rho{};
+  Vector _p_vec, _q_vec, _r_vec, _r_tilde_vec, _u_vec, _v_vec;
+
+  real_t init(const Vector& x_vec, const Vector& b_vec, const Operator<Vector>& lin_op,
+              const Preconditioner<Vector>* pre_op) override {
+    const bool left_pre = (pre_op != nullptr) && (this->pre_side == PreconditionerSide::Left);
+    for (Vector* v : {&_p_vec, &_q_vec, &_r_vec, &_r_tilde_vec, &_u_vec, &_v_vec}) v->assign(x_vec, false);
+    lin_op.Residual(_r_vec, b_vec, x_vec);
+    if (left_pre) {
+      std::swap(_u_vec, _r_vec);
+      pre_op->mul(_r_vec, _u_vec);
+    }
+    _r_tilde_vec <<= _r_vec;
+    _rho = dot_product(_r_tilde_vec, _r_vec);
+    return std::sqrt(_rho);
+  }
+  real_t iterate(Vector& x_vec, const Vector& /*b_vec*/, const Operator<Vector>& lin_op,
+                 const Preconditioner<Vector>* pre_op) override {
+    const bool left_pre = (pre_op != nullptr) && (this->pre_side == PreconditionerSide::Left);
+    const bool right_pre = (pre_op != nullptr) && (this->pre_side == PreconditionerSide::Right);
+    if (this->iteration == 0) {
+      _u_vec <<= _r_vec;
+      _p_vec <<= _u_vec;
+    } else {
+      const real_t rho_bar = std::exchange(_rho, dot_product(_r_tilde_vec, _r_vec));
+      const real_t beta = safe_divide(_rho, rho_bar);
+      _u_vec <<= _r_vec + beta * _q_vec;
+      _p_vec <<= _u_vec + beta * (_q_vec + beta * _p_vec);
+    }
+    if (left_pre) pre_op->mul(_v_vec, _q_vec, lin_op, _p_vec);
+    else if (right_pre) lin_op.mul(_v_vec, _q_vec, *pre_op, _p_vec);
+    else lin_op.mul(_v_vec, _p_vec);
+    const real_t alpha = safe_divide(_rho, dot_product(_r_tilde_vec, _v_vec));
+    _q_vec <<= _u_vec - alpha * _v_vec;
+    _v_vec <<= _u_vec + _q_vec;
+    if (left_pre) {
+      x_vec += alpha * _v_vec;
+      pre_op->mul(_v_vec, _u_vec, lin_op, _v_vec);
+      _r_vec -= alpha * _v_vec;
+    } else if (right_pre) {
+      lin_op.mul(_v_vec, _u_vec, *pre_op, _v_vec);
+      x_vec += alpha * _u_vec;
+      _r_vec -= alpha * _v_vec;
+    } else {
+      lin_op.mul(_u_vec, _v_vec);
+      x_vec += alpha * _v_vec;
+      _r_vec -= alpha * _u_vec;
+    }
+    return norm_2(_r_vec);
+  }
+};
+
+/// Transpose-free QMR, with the 2-norm (L1 = false) or 1-norm-like (L1 = true) quasi-minimisation
+/// (SolverTfqmr.hpp:37-206).
+template<class Vector, bool L1>
+class BaseTfqmrSolver : public IterativeSolver<Vector> {
+private:
+  real_t _rho{}, _tau{};
+  Vector _d_vec, _r_tilde_vec, _u_vec, _v_vec, _y_vec, _s_vec, _z_vec;
+
+  void apply(const Operator<Vector>& lin_op, const Preconditioner<Vector>* pre_op) {  // s <- A y (preconditioned)
+    const bool left_pre = (pre_op != nullptr) && (this->pre_side == PreconditionerSide::Left);
+    const bool right_pre = (pre_op != nullptr) && (this->pre_side == PreconditionerSide::Right);
+    if (left_pre) pre_op->mul(_s_vec, _z_vec, lin_op, _y_vec);
+    else if (right_pre) lin_op.mul(_s_vec, _z_vec, *pre_op, _y_vec);
+    else lin_op.mul(_s_vec, _y_vec);
+  }
+  real_t init(const Vector& x_vec, const Vector& b_vec, const Operator<Vector>& lin_op,
+              const Preconditioner<Vector>* pre_op) override {
+    const bool left_pre = (pre_op != nullptr) && (this->pre_side == PreconditionerSide::Left);
+    for (Vector* v : {&_d_vec, &_r_tilde_vec, &_u_vec, &_v_vec, &_y_vec, &_s_vec}) v->assign(x_vec, false);
+    if (pre_op != nullptr) _z_vec.assign(x_vec, false);
+    if constexpr (L1) _d_vec <<= x_vec;
+    else fill_with(_d_vec, 0.0);
+    lin_op.Residual(_y_vec, b_vec, x_vec);
+    if (left_pre) {
+      std::swap(_z_vec, _y_vec);
+      pre_op->mul(_y_vec, _z_vec);
+    }
+    _u_vec <<= _y_vec;
+    _r_tilde_vec <<= _u_vec;
+    _rho = dot_product(_r_tilde_vec, _u_vec), _tau = std::sqrt(_rho);
+    return _tau;
+  }
+  real_t iterate(Vector& x_vec, const Vector& /*b_vec*/, const Operator<Vector>& lin_op,
+                 const Preconditioner<Vector>* pre_op) override {
+    const bool right_pre = (pre_op != nullptr) && (this->pre_side == PreconditionerSide::Right);
+    if (this->iteration == 0) {
+      apply(lin_op, pre_op);
+      _v_vec <<= _s_vec;
+    } else {
+      const real_t rho_bar = std::exchange(_rho, dot_product(_r_tilde_vec, _u_vec));
+      const real_t beta = safe_divide(_rho, rho_bar);
+      _v_vec <<= _s_vec + beta * _v_vec;
+      _y_vec <<= _u_vec + beta * _y_vec;
+      apply(lin_op, pre_op);
+      _v_vec <<= _s_vec + beta * _v_vec;
+    }
+    const real_t alpha = safe_divide(_rho, dot_product(_r_tilde_vec, _v_vec));
+    for (std::size_t m = 0; m <= 1; ++m) {
+      _u_vec -= alpha * _s_vec;
+      _d_vec += alpha * (right_pre ? _z_vec : _y_vec);
+      const real_t omega = norm_2(_u_vec);
+      if constexpr (L1) {
+        if (omega < _tau) _tau = omega, x_vec <<= _d_vec;
+      } else {
+        const auto rot = sym_ortho(_tau, omega);
+        _tau = omega * rot[0];
+        x_vec += std::pow(rot[0], 2) * _d_vec;
+        _d_vec *= std::pow(rot[1], 2);
+      }
+      if (m == 0) {
+        _y_vec -= alpha * _v_vec;
+        apply(lin_op, pre_op);
+      }
+    }
+    real_t tau_tilde = _tau;
+    if constexpr (!L1) tau_tilde *= std::sqrt(2.0 * (real_t)this->iteration + 3.0);
+    return tau_tilde;
+  }
+
+protected:
+  BaseTfqmrSolver() = default;
+};
+template<class Vector>
+class TfqmrSolver final : public BaseTfqmrSolver<Vector, false> {};
+template<class Vector>
+class Tfqmr1Solver final : public BaseTfqmrSolver<Vector, true> {};
 
 /// GMRES(m) (SolverGmres.hpp:41-255, non-flexible).  The host-statement path implements the
 /// unpreconditioned and left/right preconditioned variants over dense host arrays for H, beta,

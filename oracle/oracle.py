@@ -49,7 +49,8 @@ class _CsrOp(C.Structure):
 
 class _Params(C.Structure):
     _fields_ = [("num_iterations", C.c_int64), ("absolute_error_tolerance", C.c_double),
-                ("relative_error_tolerance", C.c_double), ("num_inner_iterations", C.c_int64)]
+                ("relative_error_tolerance", C.c_double), ("num_inner_iterations", C.c_int64),
+                ("relaxation_factor", C.c_double)]
 
 
 class _Result(C.Structure):
@@ -89,7 +90,8 @@ def lib(variant: str = "strict"):
         L.oracle_convection.argtypes = [C.POINTER(_Mesh), f64p, C.c_double, f64p, f64p]
         L.oracle_stencil_apply.argtypes = [C.c_void_p, f64p, f64p]
         L.oracle_csr_apply.argtypes = [C.c_void_p, f64p, f64p]
-        for name in ("oracle_solve_cg", "oracle_solve_bicgstab", "oracle_solve_gmres"):
+        for name in ("oracle_solve_cg", "oracle_solve_bicgstab", "oracle_solve_gmres", "oracle_solve_richardson",
+                     "oracle_solve_cgs", "oracle_solve_tfqmr", "oracle_solve_tfqmr1"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int64, f64p, f64p,
                                          C.POINTER(_Params), C.POINTER(_Result), f64p]
     return _libs[variant]
@@ -266,17 +268,18 @@ class SolveResult:
 
 
 def solve(kind: str, op, b, x0=None, num_iterations: int = 2000, abs_tol: float = 1e-6,
-          rel_tol: float = 1e-6, num_inner_iterations: int = 50,
+          rel_tol: float = 1e-6, num_inner_iterations: int = 50, relaxation_factor: float = 1e-4,
           variant: str = "strict") -> SolveResult:
     """``solve<XSolver>(x, b, op)`` of Solvers/Solver.hpp:261-265 with the reference defaults."""
     b = f64(b)
     x = np.zeros_like(b) if x0 is None else f64(x0).copy()
-    p = _Params(num_iterations, abs_tol, rel_tol, num_inner_iterations)
+    p = _Params(num_iterations, abs_tol, rel_tol, num_inner_iterations, relaxation_factor)
     r = _Result()
     hist = np.full(num_iterations + 1, np.nan)
     L = lib(variant)
-    fn = {"cg": L.oracle_solve_cg, "bicgstab": L.oracle_solve_bicgstab,
-          "gmres": L.oracle_solve_gmres}[kind]
+    fn = {"cg": L.oracle_solve_cg, "bicgstab": L.oracle_solve_bicgstab, "gmres": L.oracle_solve_gmres,
+          "richardson": L.oracle_solve_richardson, "cgs": L.oracle_solve_cgs, "tfqmr": L.oracle_solve_tfqmr,
+          "tfqmr1": L.oracle_solve_tfqmr1}[kind]
     fn(op.fn, op.ctx, b.size, _p(x), _p(b), C.byref(p), C.byref(r), _p(hist))
     return SolveResult(x, r.iterations, r.absolute_error, r.relative_error, r.initial_error,
                        bool(r.converged), r.num_applies, hist[: r.iterations + 1].copy())

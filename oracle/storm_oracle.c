@@ -295,6 +295,7 @@ typedef struct oracle_params {
   double absolute_error_tolerance;  /* default 1e-6 */
   double relative_error_tolerance;  /* default 1e-6 */
   int64_t num_inner_iterations;     /* GMRES restart, default 50 */
+  double relaxation_factor;         /* Richardson, default 1e-4 (SolverRichardson.hpp:45) */
 } oracle_params;
 
 typedef struct oracle_result {
@@ -583,4 +584,169 @@ ORACLE_API void oracle_solve_gmres(oracle_apply_fn apply, void *op, int64_t n,
   free(s.q), free(s.beta), free(s.cs), free(s.sn), free(s.H);
 }
 
-ORACLE_API int oracle_abi_version(void) { return 1; }
+/* ---- Richardson: Solvers/SolverRichardson.hpp:41-98 (no preconditioner) --- */
+typedef struct rich_state {
+  solver_base b;
+  double omega;
+  double *r;
+} rich_state;
+
+static double rich_init(void *sv, const double *x, const double *b) {
+  rich_state *s = (rich_state *)sv;
+  s->r = new_vec(s->b.n);                                   /* :53 */
+  s->b.applies++;
+  op_residual(s->b.apply, s->b.op, s->b.n, s->r, b, x);     /* :65 */
+  return oracle_norm2(s->b.n, s->r);                        /* :71 */
+}
+static double rich_iterate(void *sv, double *x, const double *b) {
+  rich_state *s = (rich_state *)sv;
+  oracle_axpy(s->b.n, x, s->omega, s->r);                   /* :88  x += omega r */
+  s->b.applies++;
+  op_residual(s->b.apply, s->b.op, s->b.n, s->r, b, x);     /* :89 */
+  return oracle_norm2(s->b.n, s->r);                        /* :95 */
+}
+ORACLE_API void oracle_solve_richardson(oracle_apply_fn apply, void *op, int64_t n, double *x,
+                                        const double *b, const oracle_params *p, oracle_result *res,
+                                        double *history) {
+  rich_state s;
+  memset(&s, 0, sizeof s);
+  s.b.apply = apply, s.b.op = op, s.b.n = n, s.b.history = history;
+  s.omega = p->relaxation_factor;
+  const solver_vt vt = {rich_init, rich_iterate, NULL};
+  iterative_solve(&s.b, &vt, &s, x, b, p, res);
+  free(s.r);
+}
+
+/* ---- CGS: Solvers/SolverCgs.hpp:50-176 (no preconditioner) -------------- */
+typedef struct cgs_state {
+  solver_base b;
+  double rho;
+  double *p, *q, *r, *rt, *u, *v;
+} cgs_state;
+
+static double cgs_init(void *sv, const double *x, const double *b) {
+  cgs_state *s = (cgs_state *)sv;
+  const int64_t n = s->b.n;
+  s->p = new_vec(n), s->q = new_vec(n), s->r = new_vec(n);  /* :62-67 */
+  s->rt = new_vec(n), s->u = new_vec(n), s->v = new_vec(n);
+  s->b.applies++;
+  op_residual(s->b.apply, s->b.op, n, s->r, b, x);          /* :80 */
+  oracle_copy(n, s->rt, s->r);                              /* :85 */
+  s->rho = oracle_dot(n, s->rt, s->r);                      /* :86 */
+  return sqrt(s->rho);                                      /* :88 */
+}
+static double cgs_iterate(void *sv, double *x, const double *b) {
+  (void)b;
+  cgs_state *s = (cgs_state *)sv;
+  const int64_t n = s->b.n;
+  if (s->b.iteration == 0) {                                /* :113-116 */
+    oracle_copy(n, s->u, s->r);
+    oracle_copy(n, s->p, s->u);
+  } else {
+    const double rho_bar = s->rho;                          /* :118-119 */
+    s->rho = oracle_dot(n, s->rt, s->r);
+    const double beta = oracle_safe_divide(s->rho, rho_bar); /* :120 */
+    for (int64_t i = 0; i < n; ++i) s->u[i] = s->r[i] + beta * s->q[i];                 /* :121 */
+    for (int64_t i = 0; i < n; ++i) s->p[i] = s->u[i] + beta * (s->q[i] + beta * s->p[i]); /* :122 */
+  }
+  op_mul(&s->b, s->v, s->p);                                /* :139 */
+  const double alpha = oracle_safe_divide(s->rho, oracle_dot(n, s->rt, s->v)); /* :140 */
+  for (int64_t i = 0; i < n; ++i) s->q[i] = s->u[i] - alpha * s->v[i];  /* :141 */
+  for (int64_t i = 0; i < n; ++i) s->v[i] = s->u[i] + s->q[i];          /* :142 */
+  op_mul(&s->b, s->u, s->v);                                /* :167 */
+  oracle_axpy(n, x, alpha, s->v);                           /* :168 */
+  oracle_axmy(n, s->r, alpha, s->u);                        /* :169 */
+  return oracle_norm2(n, s->r);                             /* :172 */
+}
+ORACLE_API void oracle_solve_cgs(oracle_apply_fn apply, void *op, int64_t n, double *x, const double *b,
+                                 const oracle_params *p, oracle_result *res, double *history) {
+  cgs_state s;
+  memset(&s, 0, sizeof s);
+  s.b.apply = apply, s.b.op = op, s.b.n = n, s.b.history = history;
+  const solver_vt vt = {cgs_init, cgs_iterate, NULL};
+  iterative_solve(&s.b, &vt, &s, x, b, p, res);
+  free(s.p), free(s.q), free(s.r), free(s.rt), free(s.u), free(s.v);
+}
+
+/* ---- TFQMR / TFQMR1: Solvers/SolverTfqmr.hpp:37-265 (no preconditioner) -- */
+typedef struct tfqmr_state {
+  solver_base b;
+  int l1;
+  double rho, tau;
+  double *d, *rt, *u, *v, *y, *s;
+} tfqmr_state;
+
+static double tfqmr_init(void *sv, const double *x, const double *b) {
+  tfqmr_state *s = (tfqmr_state *)sv;
+  const int64_t n = s->b.n;
+  s->d = new_vec(n), s->rt = new_vec(n), s->u = new_vec(n);  /* :49-55 */
+  s->v = new_vec(n), s->y = new_vec(n), s->s = new_vec(n);
+  if (s->l1) oracle_copy(n, s->d, x);                       /* :73-77 */
+  else oracle_fill(n, s->d, 0.0);
+  s->b.applies++;
+  op_residual(s->b.apply, s->b.op, n, s->y, b, x);          /* :78 */
+  oracle_copy(n, s->u, s->y);                               /* :83 */
+  oracle_copy(n, s->rt, s->u);                              /* :84 */
+  s->rho = oracle_dot(n, s->rt, s->u);                      /* :85 */
+  s->tau = sqrt(s->rho);
+  return s->tau;                                            /* :87 */
+}
+static double tfqmr_iterate(void *sv, double *x, const double *b) {
+  (void)b;
+  tfqmr_state *s = (tfqmr_state *)sv;
+  const int64_t n = s->b.n;
+  if (s->b.iteration == 0) {                                /* :121-126 */
+    op_mul(&s->b, s->s, s->y);
+    oracle_copy(n, s->v, s->s);
+  } else {
+    const double rho_bar = s->rho;                          /* :128-129 */
+    s->rho = oracle_dot(n, s->rt, s->u);
+    const double beta = oracle_safe_divide(s->rho, rho_bar); /* :130 */
+    oracle_xpay(n, s->v, s->s, beta);                       /* :131  v <<= s + beta v */
+    oracle_xpay(n, s->y, s->u, beta);                       /* :132  y <<= u + beta y */
+    op_mul(&s->b, s->s, s->y);                              /* :133-135 */
+    oracle_xpay(n, s->v, s->s, beta);                       /* :136 */
+  }
+  const double alpha = oracle_safe_divide(s->rho, oracle_dot(n, s->rt, s->v)); /* :166 */
+  for (int m = 0; m <= 1; ++m) {                            /* :167-189 */
+    oracle_axmy(n, s->u, alpha, s->s);                      /* :168 */
+    oracle_axpy(n, s->d, alpha, s->y);                      /* :169 */
+    const double omega = oracle_norm2(n, s->u);             /* :170 */
+    if (s->l1) {
+      if (omega < s->tau) s->tau = omega, oracle_copy(n, x, s->d); /* :172 */
+    } else {
+      double cs, sn, rr;
+      oracle_sym_ortho(s->tau, omega, &cs, &sn, &rr);       /* :174 */
+      s->tau = omega * cs;                                  /* :175 */
+      oracle_axpy(n, x, pow(cs, 2), s->d);                  /* :176 */
+      oracle_mul_scalar(n, s->d, pow(sn, 2));               /* :177 */
+    }
+    if (m == 0) {
+      oracle_axmy(n, s->y, alpha, s->v);                    /* :180 */
+      op_mul(&s->b, s->s, s->y);                            /* :181-183 */
+    }
+  }
+  double tau_tilde = s->tau;                                /* :199-204 */
+  if (!s->l1) tau_tilde *= sqrt(2.0 * (double)s->b.iteration + 3.0);
+  return tau_tilde;
+}
+static void tfqmr_solve(int l1, oracle_apply_fn apply, void *op, int64_t n, double *x, const double *b,
+                        const oracle_params *p, oracle_result *res, double *history) {
+  tfqmr_state s;
+  memset(&s, 0, sizeof s);
+  s.b.apply = apply, s.b.op = op, s.b.n = n, s.b.history = history;
+  s.l1 = l1;
+  const solver_vt vt = {tfqmr_init, tfqmr_iterate, NULL};
+  iterative_solve(&s.b, &vt, &s, x, b, p, res);
+  free(s.d), free(s.rt), free(s.u), free(s.v), free(s.y), free(s.s);
+}
+ORACLE_API void oracle_solve_tfqmr(oracle_apply_fn apply, void *op, int64_t n, double *x, const double *b,
+                                   const oracle_params *p, oracle_result *res, double *history) {
+  tfqmr_solve(0, apply, op, n, x, b, p, res, history);
+}
+ORACLE_API void oracle_solve_tfqmr1(oracle_apply_fn apply, void *op, int64_t n, double *x, const double *b,
+                                    const oracle_params *p, oracle_result *res, double *history) {
+  tfqmr_solve(1, apply, op, n, x, b, p, res, history);
+}
+
+ORACLE_API int oracle_abi_version(void) { return 2; }

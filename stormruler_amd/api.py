@@ -209,9 +209,10 @@ class DeviceVector:
             check(lib.storm_hip_axpbz(self._h, e.a, e.v._h, 0.0, e.v._h))
         elif isinstance(e, _Lin2):
             check(lib.storm_hip_axpbz(self._h, e.a, e.x._h, e.b, e.z._h))
-        elif isinstance(e, _Lin3) and e.lin.x is self and e.lin.a == 1.0:
-            # p <<= r + beta * (p - omega * v)     SolverBiCgStab.hpp:119
-            check(lib.storm_hip_bicgstab_p(self._h, e.r._h, e.s, -e.lin.b, e.lin.z._h))
+        elif isinstance(e, _Lin3):
+            # p <<= r + beta * (p - omega * v)  (SolverBiCgStab.hpp:119),  p <<= u + beta * (q + beta * p)
+            # (SolverCgs.hpp:122): one kernel evaluating r + s * (a x + b z) in that nesting
+            check(lib.storm_hip_lin3(self._h, e.r._h, e.s, e.lin.a, e.lin.x._h, e.lin.b, e.lin.z._h))
         else:
             raise NotImplementedError(f"no device kernel for `<<=` of {type(e).__name__}")
         return self
@@ -747,6 +748,137 @@ class GmresSolver(InnerOuterIterativeSolver):
             beta[i] /= H[i, i]
         for i in range(k + 1):
             x_vec += beta[i] * self._q_vecs[i]
+
+
+class RichardsonSolver(IterativeSolver):
+    """SolverRichardson.hpp:41-98 (x += omega r with the fixed ``relaxation_factor``)."""
+
+    def __init__(self):
+        super().__init__()
+        self.relaxation_factor = 1.0e-4  # :45
+
+    def _apply_pre(self, pre_op):
+        if pre_op is not None:
+            self._z_vec, self._r_vec = self._r_vec, self._z_vec
+            pre_op.mul(self._r_vec, self._z_vec)
+
+    def init(self, x_vec, b_vec, lin_op, pre_op):
+        self._r_vec, self._z_vec = DeviceVector(), DeviceVector()
+        self._r_vec.assign(x_vec, False)
+        if pre_op is not None:
+            self._z_vec.assign(x_vec, False)
+        lin_op.Residual(self._r_vec, b_vec, x_vec)
+        self._apply_pre(pre_op)
+        return norm_2(self._r_vec)
+
+    def iterate(self, x_vec, b_vec, lin_op, pre_op):
+        x_vec += self.relaxation_factor * self._r_vec
+        lin_op.Residual(self._r_vec, b_vec, x_vec)
+        self._apply_pre(pre_op)
+        return norm_2(self._r_vec)
+
+
+class CgsSolver(IterativeSolver):
+    """SolverCgs.hpp:50-176, unpreconditioned branch."""
+
+    def init(self, x_vec, b_vec, lin_op, pre_op):
+        if pre_op is not None:
+            raise NotImplementedError("preconditioned CGS is not part of the hot path")
+        for nme in ("_p_vec", "_q_vec", "_r_vec", "_r_tilde_vec", "_u_vec", "_v_vec"):
+            v = DeviceVector()
+            v.assign(x_vec, False)
+            setattr(self, nme, v)
+        lin_op.Residual(self._r_vec, b_vec, x_vec)
+        self._r_tilde_vec <<= self._r_vec
+        self._rho = dot_product(self._r_tilde_vec, self._r_vec)
+        return math.sqrt(self._rho)
+
+    def iterate(self, x_vec, b_vec, lin_op, pre_op):
+        p, q, r, u, v = self._p_vec, self._q_vec, self._r_vec, self._u_vec, self._v_vec
+        if self.iteration == 0:
+            u <<= r
+            p <<= u
+        else:
+            rho_bar, self._rho = self._rho, dot_product(self._r_tilde_vec, r)
+            beta = safe_divide(self._rho, rho_bar)
+            u <<= r + beta * q
+            p <<= u + beta * (q + beta * p)
+        lin_op.mul(v, p)
+        alpha = safe_divide(self._rho, dot_product(self._r_tilde_vec, v))
+        q <<= u - alpha * v
+        v <<= u + q
+        lin_op.mul(u, v)
+        x_vec += alpha * v
+        r -= alpha * u
+        return norm_2(r)
+
+
+class _BaseTfqmrSolver(IterativeSolver):
+    """SolverTfqmr.hpp:37-206, unpreconditioned branch; ``_L1`` selects TFQMR1."""
+
+    _L1 = False
+
+    def init(self, x_vec, b_vec, lin_op, pre_op):
+        if pre_op is not None:
+            raise NotImplementedError("preconditioned TFQMR is not part of the hot path")
+        for nme in ("_d_vec", "_r_tilde_vec", "_u_vec", "_v_vec", "_y_vec", "_s_vec"):
+            v = DeviceVector()
+            v.assign(x_vec, False)
+            setattr(self, nme, v)
+        if self._L1:
+            self._d_vec <<= x_vec
+        else:
+            fill_with(self._d_vec, 0.0)
+        lin_op.Residual(self._y_vec, b_vec, x_vec)
+        self._u_vec <<= self._y_vec
+        self._r_tilde_vec <<= self._u_vec
+        self._rho = dot_product(self._r_tilde_vec, self._u_vec)
+        self._tau = math.sqrt(self._rho)
+        return self._tau
+
+    def iterate(self, x_vec, b_vec, lin_op, pre_op):
+        d, u, v, y, s = self._d_vec, self._u_vec, self._v_vec, self._y_vec, self._s_vec
+        if self.iteration == 0:
+            lin_op.mul(s, y)
+            v <<= s
+        else:
+            rho_bar, self._rho = self._rho, dot_product(self._r_tilde_vec, u)
+            beta = safe_divide(self._rho, rho_bar)
+            v <<= s + beta * v
+            y <<= u + beta * y
+            lin_op.mul(s, y)
+            v <<= s + beta * v
+        alpha = safe_divide(self._rho, dot_product(self._r_tilde_vec, v))
+        for m in range(2):
+            u -= alpha * s
+            d += alpha * y
+            omega = norm_2(u)
+            if self._L1:
+                if omega < self._tau:
+                    self._tau = omega
+                    x_vec <<= d
+            else:
+                cs, sn, _ = sym_ortho(self._tau, omega)
+                self._tau = omega * cs
+                x_vec += (cs ** 2) * d
+                d *= sn ** 2
+            if m == 0:
+                y -= alpha * v
+                lin_op.mul(s, y)
+        tau_tilde = self._tau
+        if not self._L1:
+            tau_tilde *= math.sqrt(2.0 * self.iteration + 3.0)
+        return tau_tilde
+
+
+class TfqmrSolver(_BaseTfqmrSolver):
+    """SolverTfqmr.hpp:235-237."""
+
+
+class Tfqmr1Solver(_BaseTfqmrSolver):
+    """SolverTfqmr.hpp:262-264."""
+
+    _L1 = True
 
 
 def solve(solver_cls, x_vec: DeviceVector, b_vec: DeviceVector, any_op: Operator) -> bool:

@@ -143,6 +143,30 @@ int k_bicg_p(storm_hip_ctx *c, double *p, const double *r, Scal beta, Scal omega
   return launch_ew(c, n, EwPtrs{p, r, v}, BicgPF{beta, omega, 0.0, 0.0}, done);
 }
 
+// y = r + s*(a*x + b*z), evaluated in exactly this nesting (operands may alias y).
+__global__ __launch_bounds__(kBlock) void lin3_kernel(int64_t n, double *y, const double *r, double s, double a,
+                                                      const double *x, double b, const double *z, int nt) {
+  const int64_t n2 = n >> 1;
+  double2v *y2 = reinterpret_cast<double2v *>(y);
+  const double2v *r2 = reinterpret_cast<const double2v *>(r), *x2 = reinterpret_cast<const double2v *>(x),
+                 *z2 = reinterpret_cast<const double2v *>(z);
+  for (int64_t base = (int64_t)blockIdx.x * (kBlock * kUnroll) + threadIdx.x; base < n2;
+       base += (int64_t)gridDim.x * (kBlock * kUnroll)) {
+    double2v vr[kUnroll], vx[kUnroll], vz[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t i = base + u * kBlock;
+      if (i < n2) vr[u] = ld2(r2 + i, nt), vx[u] = ld2(x2 + i, nt), vz[u] = ld2(z2 + i, nt);
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t i = base + u * kBlock;
+      if (i < n2) st2(y2 + i, vr[u] + s * (a * vx[u] + b * vz[u]), nt);
+    }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = r[n - 1] + s * (a * x[n - 1] + b * z[n - 1]);
+}
+
 // ---- reductions -------------------------------------------------------------------------
 
 // Sum over the 256 threads of a block, fixed order; result valid in thread 0.
@@ -430,6 +454,19 @@ int storm_hip_axpbz(storm_hip_vec *y, double a, const storm_hip_vec *x, double b
   STORM_TRY(check_pair(y, x, "axpbz"));
   STORM_TRY(check_pair(y, z, "axpbz"));
   return k_axpbz(y->ctx, y->d, host_scal(a), x->d, host_scal(b), z->d, y->n_owned, nullptr);
+}
+
+int storm_hip_lin3(storm_hip_vec *y, const storm_hip_vec *r, double s, double a, const storm_hip_vec *x, double b,
+                   const storm_hip_vec *z) {
+  STORM_TRY(check_pair(y, r, "lin3"));
+  STORM_TRY(check_pair(y, x, "lin3"));
+  STORM_TRY(check_pair(y, z, "lin3"));
+  if (y->n_owned <= 0) return STORM_HIP_OK;
+  storm_hip_ctx *c = y->ctx;
+  hipLaunchKernelGGL(lin3_kernel, dim3(stream_blocks(y->n_owned)), dim3(kBlock), 0, c->stream, y->n_owned, y->d,
+                     r->d, s, a, x->d, b, z->d, (int)(c->opt_blas1_nt != 0));
+  HIP_TRY(hipGetLastError());
+  return STORM_HIP_OK;
 }
 
 int storm_hip_vmul_add(storm_hip_vec *y, double s, const storm_hip_vec *a, const storm_hip_vec *b) {

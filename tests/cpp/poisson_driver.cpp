@@ -104,6 +104,9 @@ int main(int argc, char** argv) {
     if (kind == "cg") return run<CgSolver>(n, native, restart);
     if (kind == "bicgstab") return run<BiCgStabSolver>(n, native, restart);
     if (kind == "gmres") return run<GmresSolver>(n, native, restart);
+    if (kind == "cgs") return run<CgsSolver>(n, native, restart);
+    if (kind == "tfqmr") return run<TfqmrSolver>(n, native, restart);
+    if (kind == "tfqmr1") return run<Tfqmr1Solver>(n, native, restart);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "error: %s\n", e.what());
     return 1;
