@@ -101,6 +101,76 @@ __device__ __forceinline__ double wave_sum_to_lane63(double v) {
 
 constexpr int kChunk = 8;  // slots whose (col, val) loads are issued before the first gather
 
+// x[c], or the block's LDS copy of it when VARIANT == 1 and c lies in the block's own 256 rows.
+template <int VARIANT>
+__device__ __forceinline__ double gather_x(const double *__restrict__ x, int c, const double *xwin, int64_t row0) {
+  if (VARIANT == 1) {
+    const int64_t d = (int64_t)c - row0;
+    return ((uint64_t)d < (uint64_t)kBlock) ? xwin[d] : x[c];
+  }
+  return x[c];
+}
+
+// sum_k w_k (x[col_k] - x_i) over slots [S0, S0 + W) of a record whose slice has `width` slots
+// (W compile-time, S0 even).  Pairs are read as int2 / double2, an odd last slot unpaired.
+template <bool NT, int VARIANT, int W>
+__device__ __forceinline__ double row_sum(const char *rec, int width, int lane, const double *__restrict__ x,
+                                          double xi, const double *xwin, int64_t row0, int s0 = 0) {
+  constexpr int NP = W / 2;
+  const int npair_total = width >> 1;
+  const int2v *cp2 = reinterpret_cast<const int2v *>(rec + kExtBytes) + lane + (s0 >> 1) * kWave;
+  const char *vbase = rec + kExtBytes + (int64_t)width * (kWave * 4);
+  const double2v *vp2 = reinterpret_cast<const double2v *>(vbase) + lane + (s0 >> 1) * kWave;
+  int2v c[NP > 0 ? NP : 1];
+  double2v v[NP > 0 ? NP : 1];
+  int ct = 0;
+  double vt = 0.0;
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    c[q] = NT ? __builtin_nontemporal_load(cp2 + q * kWave) : cp2[q * kWave];
+    v[q] = NT ? __builtin_nontemporal_load(vp2 + q * kWave) : vp2[q * kWave];
+  }
+  if (W & 1) {  // the slice's unpaired last slot
+    ct = ld_i<NT>(reinterpret_cast<const int *>(rec + kExtBytes + (int64_t)npair_total * (kWave * 8)) + lane);
+    vt = ld_d<NT>(reinterpret_cast<const double *>(vbase + (int64_t)npair_total * (kWave * 16)) + lane);
+  }
+  double xg[W > 0 ? W : 1];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    xg[2 * q] = gather_x<VARIANT>(x, c[q].x, xwin, row0);
+    xg[2 * q + 1] = gather_x<VARIANT>(x, c[q].y, xwin, row0);
+  }
+  if (W & 1) xg[W - 1] = gather_x<VARIANT>(x, ct, xwin, row0);
+  double acc = 0.0;
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    acc += v[q].x * (xg[2 * q] - xi);
+    acc += v[q].y * (xg[2 * q + 1] - xi);
+  }
+  if (W & 1) acc += vt * (xg[W - 1] - xi);
+  return acc;
+}
+
+// Rows wider than 8 slots: chunks of 8, then the remainder.
+template <bool NT, int VARIANT>
+__device__ __forceinline__ double row_sum_wide(const char *rec, int width, int lane, const double *__restrict__ x,
+                                               double xi, const double *xwin, int64_t row0) {
+  double acc = 0.0;
+  int s0 = 0;
+  for (; s0 + 8 <= width; s0 += 8) acc += row_sum<NT, VARIANT, 8>(rec, width, lane, x, xi, xwin, row0, s0);
+  switch (width - s0) {
+    case 1: acc += row_sum<NT, VARIANT, 1>(rec, width, lane, x, xi, xwin, row0, s0); break;
+    case 2: acc += row_sum<NT, VARIANT, 2>(rec, width, lane, x, xi, xwin, row0, s0); break;
+    case 3: acc += row_sum<NT, VARIANT, 3>(rec, width, lane, x, xi, xwin, row0, s0); break;
+    case 4: acc += row_sum<NT, VARIANT, 4>(rec, width, lane, x, xi, xwin, row0, s0); break;
+    case 5: acc += row_sum<NT, VARIANT, 5>(rec, width, lane, x, xi, xwin, row0, s0); break;
+    case 6: acc += row_sum<NT, VARIANT, 6>(rec, width, lane, x, xi, xwin, row0, s0); break;
+    case 7: acc += row_sum<NT, VARIANT, 7>(rec, width, lane, x, xi, xwin, row0, s0); break;
+    default: break;
+  }
+  return acc;
+}
+
 // One wavefront per slice, one row per lane, 4 slices per 256-thread block.
 //   NT      : record / y traffic marked non-temporal so it does not evict x from L2 (+15 %).
 //   DOT     : epilogue writes per-block partials of <w, y> and <y, y> (fused reductions).
@@ -157,42 +227,22 @@ __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SellArgs A, Scal alph
       width = (int)((A.slice_off[slice + 1] - base - kExtBytes) / kSlotBytes);
     }
     const char *rec = A.pack + base;
-    const int npair = width >> 1;
     const double ext = ld_d<NT>(reinterpret_cast<const double *>(rec) + lane);
-    const int2v *cp2 = reinterpret_cast<const int2v *>(rec + kExtBytes) + lane;
-    const char *vbase = rec + kExtBytes + (int64_t)width * (kWave * 4);
-    const double2v *vp2 = reinterpret_cast<const double2v *>(vbase) + lane;
-    double acc = 0.0;
-    auto gather = [&](int c) -> double {
-      if (VARIANT == 1) {
-        const int64_t d = (int64_t)c - row0;
-        return ((uint64_t)d < (uint64_t)kBlock) ? xwin[d] : x[c];
-      }
-      return x[c];
-    };
-    for (int p0 = 0; p0 < npair; p0 += kChunk / 2) {
-      int2v c[kChunk / 2];
-      double2v v[kChunk / 2];
-#pragma unroll
-      for (int q = 0; q < kChunk / 2; ++q) {
-        if (p0 + q < npair) {
-          c[q] = NT ? __builtin_nontemporal_load(cp2 + (p0 + q) * kWave) : cp2[(p0 + q) * kWave];
-          v[q] = NT ? __builtin_nontemporal_load(vp2 + (p0 + q) * kWave) : vp2[(p0 + q) * kWave];
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < kChunk / 2; ++q) {
-        if (p0 + q < npair) {
-          const double x0 = gather(c[q].x), x1 = gather(c[q].y);
-          acc += v[q].x * (x0 - xi);
-          acc += v[q].y * (x1 - xi);
-        }
-      }
-    }
-    if (width & 1) {  // odd width: the last slot is stored unpaired
-      const int ct = ld_i<NT>(reinterpret_cast<const int *>(rec + kExtBytes + (int64_t)npair * (kWave * 8)) + lane);
-      const double vt = ld_d<NT>(reinterpret_cast<const double *>(vbase + (int64_t)npair * (kWave * 16)) + lane);
-      acc += vt * (gather(ct) - xi);
+    double acc;
+    // The width is wave-uniform: dispatch to a body with the width as a compile-time constant,
+    // so all (col, val) loads of the row are issued back to back, then all gathers, then the
+    // FMAs -- no branch (and no s_waitcnt) between the gathers of one row.
+    switch (width) {
+      case 0: acc = 0.0; break;
+      case 1: acc = row_sum<NT, VARIANT, 1>(rec, 1, lane, x, xi, xwin, row0); break;
+      case 2: acc = row_sum<NT, VARIANT, 2>(rec, 2, lane, x, xi, xwin, row0); break;
+      case 3: acc = row_sum<NT, VARIANT, 3>(rec, 3, lane, x, xi, xwin, row0); break;
+      case 4: acc = row_sum<NT, VARIANT, 4>(rec, 4, lane, x, xi, xwin, row0); break;
+      case 5: acc = row_sum<NT, VARIANT, 5>(rec, 5, lane, x, xi, xwin, row0); break;
+      case 6: acc = row_sum<NT, VARIANT, 6>(rec, 6, lane, x, xi, xwin, row0); break;
+      case 7: acc = row_sum<NT, VARIANT, 7>(rec, 7, lane, x, xi, xwin, row0); break;
+      case 8: acc = row_sum<NT, VARIANT, 8>(rec, 8, lane, x, xi, xwin, row0); break;
+      default: acc = row_sum_wide<NT, VARIANT>(rec, width, lane, x, xi, xwin, row0); break;
     }
     yi = beta * xi + alpha * (acc + ext * xi);
     if (valid && !done_flag) {
