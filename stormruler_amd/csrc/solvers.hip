@@ -336,6 +336,50 @@ __global__ __launch_bounds__(kBlock) void bicg_update_kernel(int64_t n, SolverSt
   }
 }
 
+// One modified-Gram-Schmidt step fused with the next reduction (SolverGmres.hpp:157-161):
+//   w -= h * qa;  partial <w, qb>   (qb == nullptr: partial <w, w>, the norm of :161)
+// Same values as the reference's dot -> axpy -> dot chain, one pass over w instead of two.
+__global__ __launch_bounds__(kBlock) void mgs_step_kernel(int64_t n, const SolverState *st, double *__restrict__ w,
+                                                          const double *h, const double *__restrict__ qa,
+                                                          const double *qb, double *__restrict__ partials, int nt) {
+  if (st->done) return;
+  __shared__ double lds4[4];
+  const double hv = *h;
+  double acc = 0.0;
+  const int64_t n2 = n >> 1;
+  double2v *w2 = reinterpret_cast<double2v *>(w);
+  const double2v *a2 = reinterpret_cast<const double2v *>(qa), *b2 = reinterpret_cast<const double2v *>(qb);
+  STORM_STREAM_FOR(base, n2) {
+    double2v vw[kUnroll], va[kUnroll], vb[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t i = base + u * kBlock;
+      if (i < n2) {
+        vw[u] = ldv(w2 + i, nt), va[u] = ldv(a2 + i, nt);
+        if (qb) vb[u] = ldv(b2 + i, nt);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t i = base + u * kBlock;
+      if (i < n2) {
+        vw[u] -= hv * va[u];
+        stv(w2 + i, vw[u], nt);
+        const double2v o = qb ? vb[u] : vw[u];
+        acc += vw[u].x * o.x;
+        acc += vw[u].y * o.y;
+      }
+    }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const double v = w[n - 1] - hv * qa[n - 1];
+    w[n - 1] = v;
+    acc += v * (qb ? qb[n - 1] : v);
+  }
+  const double s = block_sum256(acc, lds4);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
 // GMRES: Givens update of column k and the beta recurrence, SolverGmres.hpp:176-191.
 __global__ void gmres_givens_kernel(SolverState *st, GmresDev g, int k) {
   if (st->done) return;
@@ -744,13 +788,22 @@ int storm_hip_solve_gmres(const storm_hip_op *op, double alpha, double beta, con
     double *qn = const_cast<double *>(q[k + 1]);
     STORM_TRY(d.apply(q[k], qn, nullptr, false, &nb));   // SolverGmres.hpp:155
     if (params->gram_schmidt == 0) {
-      // modified Gram-Schmidt, one dependent dot -> axpy pair per basis vector   :157-160
+      // modified Gram-Schmidt (:157-160): H(0,k) = <w,q_0>; then each step applies  w -= H(i,k) q_i
+      // and already accumulates the next reduction (<w,q_{i+1}>, or <w,w> for the norm of :161)
+      {
+        const double *bs[1] = {q[0]};
+        STORM_TRY(k_multi_dot(c, qn, bs, 1, n, &d.g.H[0 * m + k], d.done));
+        if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, &d.g.H[0 * m + k], 1));
+      }
       for (int i = 0; i <= k; ++i) {
         double *h = &d.g.H[i * m + k];
-        const double *bs[1] = {q[i]};
-        STORM_TRY(k_multi_dot(c, qn, bs, 1, n, h, d.done));
-        if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, h, 1));
-        STORM_TRY(k_axpbz(c, qn, host_scal(1.0), qn, dev_scal(h, -1.0), q[i], n, d.done));
+        const double *qb = i < k ? q[i + 1] : nullptr;
+        double *out = i < k ? &d.g.H[(i + 1) * m + k] : d.slot(S_TMP);
+        hipLaunchKernelGGL(mgs_step_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, qn, h, q[i], qb,
+                           c->d_partials, (int)(c->opt_blas1_nt != 0));
+        HIP_TRY(hipGetLastError());
+        STORM_TRY(k_reduce_final(c, c->d_partials, nbv, 1, out, d.done));
+        if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, out, 1));
       }
     } else {
       // classical Gram-Schmidt applied twice: two multi-dots + two multi-axpys, the second
@@ -765,9 +818,11 @@ int storm_hip_solve_gmres(const storm_hip_op *op, double alpha, double beta, con
       HIP_TRY(hipGetLastError());
     }
     {
-      const double *bs[1] = {qn};
-      STORM_TRY(k_multi_dot(c, qn, bs, 1, n, d.slot(S_TMP), d.done));                           // :161
-      if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, d.slot(S_TMP), 1));
+      if (params->gram_schmidt != 0) {  // (the fused MGS chain already left <w,w> in S_TMP)
+        const double *bs[1] = {qn};
+        STORM_TRY(k_multi_dot(c, qn, bs, 1, n, d.slot(S_TMP), d.done));                         // :161
+        if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, d.slot(S_TMP), 1));
+      }
       hipLaunchKernelGGL(step_kernel, dim3(1), dim3(1), 0, c->stream, (int)STEP_GMRES_HN, d.st, d.g, false);
       HIP_TRY(hipGetLastError());
       STORM_TRY(k_scale(c, qn, n, dev_scal(d.slot(S_HN)), true, d.done));                       // :162
