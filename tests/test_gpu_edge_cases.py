@@ -1,0 +1,131 @@
+"""Edge cases the domain has: empty and one-row vectors / operators, ragged sizes around the
+wavefront / slice / block granularities, rows with no neighbours, isolated components, very long
+rows, repeated solves on one context, vectors of mismatched contexts."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    from oracle import oracle
+    from stormruler_amd import api, mesh
+
+    ctx = api.Context(0)
+    yield api, mesh, oracle, ctx
+    ctx.close()
+
+
+def test_empty_vectors_and_operator(env):
+    api, mesh, oracle, ctx = env
+    a, b = api.DeviceVector(ctx, 0), api.DeviceVector(ctx, 0)
+    assert api.dot_product(a, b) == 0.0 and api.norm_2(a) == 0.0
+    a += 2.0 * b
+    a <<= b
+    api.fill_with(a, 1.0)
+    assert a.to_numpy().size == 0
+    mat = api.StencilMatrix.from_csr(ctx, sp.csr_matrix((0, 0)))
+    mat.apply(1.0, 0.0, a, b)
+    s = api.CgSolver()
+    assert s.solve(a, b, api.HipStencilOperator(mat, 1.0, 0.0)) and s.iteration == 0
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1023, 1025, 2047, 2049])
+def test_ragged_sizes_1d_chain(env, n):
+    """1-D Laplacian chains of every awkward length: slices, blocks and the 2048-element streaming
+    tiles all have ragged tails here."""
+    api, mesh, oracle, ctx = env
+    main = 2.0 * np.ones(n)
+    a = sp.diags([-np.ones(max(n - 1, 0)), main, -np.ones(max(n - 1, 0))], [-1, 0, 1], shape=(n, n)).tocsr()
+    mat = api.StencilMatrix.from_csr(ctx, a)
+    x = np.sin(0.3 * np.arange(n)) + 0.1
+    xv, yv = api.DeviceVector.from_numpy(ctx, x), api.DeviceVector(ctx, n)
+    mat.apply(1.0, 0.0, xv, yv)
+    ref = oracle.CsrOperator(a).apply(x)
+    assert np.abs(yv.to_numpy() - ref).max() <= 1e-14 * max(np.abs(ref).max(), 1.0)
+    s = api.CgSolver()
+    s.absolute_error_tolerance, s.relative_error_tolerance = 1e-12, 0.0
+    b = api.DeviceVector.from_numpy(ctx, np.ones(n))
+    xs = api.DeviceVector(ctx, n)
+    assert s.solve(xs, b, api.HipStencilOperator(mat, 1.0, 0.0))
+    r = oracle.solve("cg", oracle.CsrOperator(a), np.ones(n), abs_tol=1e-12, rel_tol=0.0)
+    assert abs(s.iteration - r.iterations) <= 2
+    assert np.linalg.norm(xs.to_numpy() - r.x) <= 1e-9 * np.linalg.norm(r.x)
+
+
+def test_rows_without_neighbours_and_isolated_components(env):
+    api, mesh, oracle, ctx = env
+    n = 300
+    rng = np.random.default_rng(1)
+    a = sp.lil_matrix((n, n))
+    a.setdiag(3.0 + rng.random(n))
+    for i in range(0, 100, 2):       # a few 2-cycles; rows 100.. are purely diagonal
+        a[i, i + 1] = a[i + 1, i] = -1.0
+    a = a.tocsr()
+    mat = api.StencilMatrix.from_csr(ctx, a)
+    st = mat.stats()
+    assert st["max_row_len"] == 1
+    x = rng.standard_normal(n)
+    xv, yv = api.DeviceVector.from_numpy(ctx, x), api.DeviceVector(ctx, n)
+    mat.apply(2.0, -1.0, xv, yv)
+    assert np.allclose(yv.to_numpy(), 2.0 * (a @ x) - x, rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("width", [1, 2, 3, 4, 5, 7, 8, 9, 11, 16, 17])
+def test_every_slice_width(env, width):
+    """Rows of exactly `width` entries exercise each case of the width dispatch (odd tails, > 8 chunks)."""
+    api, mesh, oracle, ctx = env
+    c2 = api.Context(0)
+    c2.set_option("ell_cap", 32)
+    n = 200
+    rng = np.random.default_rng(width)
+    rows, cols, vals = [], [], []
+    for i in range(n):
+        cs = rng.choice([j for j in range(n) if j != i], width, replace=False)
+        rows += [i] * width
+        cols += list(cs)
+        vals += list(rng.standard_normal(width))
+    a = (sp.coo_matrix((vals, (rows, cols)), shape=(n, n)) + sp.eye(n) * 5.0).tocsr()
+    mat = api.StencilMatrix.from_csr(c2, a)
+    st = mat.stats()
+    assert st["max_row_len"] == width and st["tail_nnz"] == 0
+    x = rng.standard_normal(n)
+    xv, yv = api.DeviceVector.from_numpy(c2, x), api.DeviceVector(c2, n)
+    mat.apply(1.0, 0.0, xv, yv)
+    ref = oracle.CsrOperator(a).apply(x)
+    assert np.abs(yv.to_numpy() - ref).max() <= 1e-13 * np.abs(ref).max()
+    mat.close()
+    c2.close()
+
+
+def test_repeated_solves_reuse_the_context(env):
+    api, mesh, oracle, ctx = env
+    g = mesh.structured_box(12)
+    mat = api.StencilMatrix.from_face_graph(ctx, g)
+    op = api.HipStencilOperator(mat, -1.0, 0.0)
+    ref = oracle.solve("cg", oracle.StencilOperator(g, -1.0, 0.0), np.ones(g.n_cells))
+    b = api.DeviceVector.from_numpy(ctx, np.ones(g.n_cells))
+    first = None
+    for kind in (api.CgSolver, api.BiCgStabSolver, api.CgSolver, api.GmresSolver, api.CgSolver):
+        x = api.DeviceVector(ctx, g.n_cells)
+        s = kind()
+        assert s.solve(x, b, op)
+        if kind is api.CgSolver:
+            xs = x.to_numpy()
+            assert s.iteration == ref.iterations
+            if first is None:
+                first = xs
+            assert np.array_equal(xs, first)  # bitwise reproducible run to run
+
+
+def test_vectors_of_two_contexts_do_not_mix(env):
+    api, mesh, oracle, ctx = env
+    c2 = api.Context(0)
+    a, b = api.DeviceVector(ctx, 8), api.DeviceVector(c2, 8)
+    with pytest.raises(api._lib.StormHipError):
+        api.dot_product(a, b)
+    with pytest.raises(api._lib.StormHipError):
+        a += 1.0 * b
+    c2.close()
