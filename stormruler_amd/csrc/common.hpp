@@ -86,8 +86,6 @@ struct storm_hip_ctx {
   double *d_partials2 = nullptr;      // [kMaxMulti * kStage2] second-stage partials
   double *d_scalars = nullptr;        // [kMaxMulti] results of host-visible reductions
   double *h_scalars = nullptr;        // pinned mirror
-  const double **d_ptrs = nullptr;    // [kMaxMulti] pointer table for multi-dot / multi-axpy
-  double *d_coefs = nullptr;          // [kMaxMulti]
   storm::SolverState *d_state = nullptr;
   storm::SolverState *h_state = nullptr;  // pinned staging copy of the state
   int *h_done_ring = nullptr;             // pinned, written by the device's step kernels
@@ -99,15 +97,8 @@ struct storm_hip_ctx {
   int64_t opt_spmv_xcd_remap = 8;    // 0 off; 1 one contiguous run per XCD (slower); G > 1: runs of G tiles per XCD
   int64_t opt_nt = 1;
   int64_t opt_profile_spmv = 0;
-  // Zig-zag sweeps: consecutive streaming kernels walk the rows in opposite directions, so each
-  // one starts on the bytes its predecessor touched last, which are still in the 256 MiB
-  // Infinity Cache (a vector is 134 MB at 256^3; same-direction sweeps would evict every line
-  // just before its reuse).
-  int64_t opt_zigzag = 0;   // measured: no gain on MI355X (profiles/r01_notes.md); off by default
   int64_t opt_blas1_nt = 1;  // non-temporal loads/stores in the streaming kernels
   int64_t opt_fuse_dot = 1;  // 0: reductions after an SpMV run as separate kernels (A/B knob)
-  int sweep_dir = 0;
-  int next_dir() { if (!opt_zigzag) return 0; sweep_dir ^= 1; return sweep_dir; }
   std::vector<hipEvent_t> prof_events;  // pairs (start, stop), grown on demand
   size_t prof_used = 0;
   // communicator

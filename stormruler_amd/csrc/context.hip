@@ -57,8 +57,6 @@ int storm_hip_ctx_create(int device_id, storm_hip_ctx **out) {
   HIP_TRY(hipMalloc(&c->d_partials2, sizeof(double) * kMaxMulti * kStage2));
   HIP_TRY(hipMalloc(&c->d_scalars, sizeof(double) * kMaxMulti));
   HIP_TRY(hipHostMalloc((void **)&c->h_scalars, sizeof(double) * kMaxMulti, hipHostMallocDefault));
-  HIP_TRY(hipMalloc((void **)&c->d_ptrs, sizeof(double *) * kMaxMulti));
-  HIP_TRY(hipMalloc(&c->d_coefs, sizeof(double) * kMaxMulti));
   HIP_TRY(hipMalloc((void **)&c->d_state, sizeof(SolverState)));
   HIP_TRY(hipMemset(c->d_state, 0, sizeof(SolverState)));
   HIP_TRY(hipHostMalloc((void **)&c->h_state, sizeof(SolverState), hipHostMallocDefault));
@@ -81,8 +79,6 @@ int storm_hip_ctx_destroy(storm_hip_ctx *c) {
   (void)hipFree(c->d_partials2);
   (void)hipFree(c->d_scalars);
   (void)hipHostFree(c->h_scalars);
-  (void)hipFree((void *)c->d_ptrs);
-  (void)hipFree(c->d_coefs);
   (void)hipFree(c->d_state);
   (void)hipHostFree(c->h_state);
   (void)hipHostFree(c->h_done_ring);
@@ -122,7 +118,6 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "nontemporal")) c->opt_nt = value;
   else if (!strcmp(key, "spmv_xcd_remap")) c->opt_spmv_xcd_remap = value;
   else if (!strcmp(key, "profile_spmv")) c->opt_profile_spmv = value;
-  else if (!strcmp(key, "zigzag")) c->opt_zigzag = value;
   else if (!strcmp(key, "fuse_dot")) c->opt_fuse_dot = value;
   else if (!strcmp(key, "blas1_nt")) c->opt_blas1_nt = value;
   else STORM_FAIL(STORM_HIP_E_INVALID, "ctx_set_option: unknown key '%s'", key);

@@ -183,14 +183,14 @@ __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SellArgs A, Scal alph
                                                            double *__restrict__ y,
                                                            const int *__restrict__ slice_list,
                                                            int64_t n_launch_slices, DotArgs dot,
-                                                           const int *done, int rev) {
+                                                           const int *done) {
   // The `done` predicate is only needed before the first store: issue its (scalar) load now and
   // test it after the gathers, so it never sits at the head of a wave's dependency chain.
   const int done_flag = done ? *done : 0;
   __shared__ double xwin[VARIANT == 1 ? kBlock : 1];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: slice math runs on the SALU
-  const int bidx = rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;  // zig-zag sweep direction
+  const int bidx = (int)blockIdx.x;
   const int lb = XCD ? (A.xcd_group > 1 ? xcd_remap_grouped(bidx, gridDim.x, A.xcd_group) : xcd_remap(bidx, gridDim.x))
                      : bidx;
   const int64_t sl = (int64_t)lb * (kBlock / kWave) + wave;
@@ -296,21 +296,20 @@ static void launch_sell(const storm_hip_op *op, int nb, Scal alpha, Scal beta, c
                         const int *slice_list, int64_t n_launch, DotArgs dot, const int *done) {
   SellArgs A{op->d_pack, op->d_slice_off, op->n_rows, op->uniform_width, (int)op->ctx->opt_spmv_xcd_remap};
   hipStream_t st = op->ctx->stream;
-  const int rev = op->ctx->next_dir();
   if (slice_list == nullptr && op->ctx->opt_spmv_xcd_remap != 0) {
     hipLaunchKernelGGL((spmv_sell_kernel<NT, DOT, VARIANT, true>), dim3(nb), dim3(kBlock), 0, st, A, alpha,
-                       beta, x, y, slice_list, n_launch, dot, done, rev);
+                       beta, x, y, slice_list, n_launch, dot, done);
   } else if (slice_list == nullptr) {
     hipLaunchKernelGGL((spmv_sell_kernel<NT, DOT, VARIANT, false>), dim3(nb), dim3(kBlock), 0, st, A, alpha,
-                       beta, x, y, slice_list, n_launch, dot, done, rev);
+                       beta, x, y, slice_list, n_launch, dot, done);
   } else if (op->ctx->opt_spmv_xcd_remap != 0) {
     // listed slices (interior / boundary sets of a partitioned operator): the LDS window does not
     // apply, the XCD grouping still does -- the interior list is consecutive but for a few gaps
     hipLaunchKernelGGL((spmv_sell_kernel<NT, DOT, 0, true>), dim3(nb), dim3(kBlock), 0, st, A, alpha, beta,
-                       x, y, slice_list, n_launch, dot, done, rev);
+                       x, y, slice_list, n_launch, dot, done);
   } else {
     hipLaunchKernelGGL((spmv_sell_kernel<NT, DOT, 0, false>), dim3(nb), dim3(kBlock), 0, st, A, alpha, beta,
-                       x, y, slice_list, n_launch, dot, done, rev);
+                       x, y, slice_list, n_launch, dot, done);
   }
 }
 
