@@ -118,6 +118,13 @@ int storm_hip_lin3(storm_hip_vec *y, const storm_hip_vec *r, double s, double a,
 /* y += s * (a .* b), elementwise.  Not in the solver census: the nonlinear term a time-step
  * driver forms between solves (cf. `f <<= map(dF_dc, c)`, Playground.cpp:148). */
 int storm_hip_vmul_add(storm_hip_vec *y, double s, const storm_hip_vec *a, const storm_hip_vec *b);
+/* fill_randomly(y)  Bittern/MatrixAlgorithms.hpp:140-153: uniform [0, 1) numbers from a
+ * function-static std::mt19937_64{} (default seed, state persists across calls), drawn
+ * sequentially on the host in row order and uploaded -- the same engine, distribution and
+ * standard library the reference uses, hence the same numbers.  Single rank only.
+ * storm_hip_rng_reset() restarts the engine (what a fresh process is to the reference). */
+int storm_hip_fill_randomly(storm_hip_vec *y);
+void storm_hip_rng_reset(void);
 /* dot_product(a, b)  MatrixAlgorithms.hpp:310-317;  norm_2(a)  :262-270 */
 int storm_hip_dot(const storm_hip_vec *a, const storm_hip_vec *b, double *result);
 int storm_hip_norm2(const storm_hip_vec *a, double *result);

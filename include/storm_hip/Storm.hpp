@@ -86,6 +86,7 @@ struct Scaled { real_t a; const DeviceVector* v; };                          // 
 struct Lin2 { real_t a; const DeviceVector* x; real_t b; const DeviceVector* z; };  // a x + b z
 struct ScaledLin2 { real_t s; Lin2 e; };                                      // s (a x + b z)
 struct Lin3 { const DeviceVector* r; real_t s; Lin2 e; };                     // r + s (a x + b z)
+struct Quot { const DeviceVector* v; real_t s; };                             // v / s (true division)
 }  // namespace expr
 
 /// N doubles in HBM (+ halo rows in multi-GPU runs): the solver `Vector`.
@@ -151,6 +152,8 @@ inline expr::Lin2 operator+(const DeviceVector& x, const expr::Scaled& s) { retu
 inline expr::Lin2 operator-(const DeviceVector& x, const expr::Scaled& s) { return {1.0, &x, -s.a, s.v}; }
 inline expr::Lin2 operator+(const DeviceVector& x, const DeviceVector& z) { return {1.0, &x, 1.0, &z}; }
 inline expr::Lin2 operator-(const DeviceVector& x, const DeviceVector& z) { return {1.0, &x, -1.0, &z}; }
+inline expr::Lin2 operator+(const expr::Scaled& a, const expr::Scaled& b) { return {a.a, a.v, b.a, b.v}; }
+inline expr::Quot operator/(const DeviceVector& v, real_t s) { return {&v, s}; }
 inline expr::ScaledLin2 operator*(real_t s, const expr::Lin2& e) { return {s, e}; }
 inline expr::Lin3 operator+(const DeviceVector& r, const expr::ScaledLin2& e) { return {&r, e.s, e.e}; }
 
@@ -173,6 +176,15 @@ inline DeviceVector& operator<<=(DeviceVector& out, const expr::Lin3& e) {
   detail::check(storm_hip_lin3(out.handle(), e.r->handle(), e.s, e.e.a, e.e.x->handle(), e.e.b, e.e.z->handle()));
   return out;
 }
+
+inline DeviceVector& operator<<=(DeviceVector& out, const expr::Quot& e) {  // p <<= r / phi, SolverIdrs.hpp:131
+  if (e.v != &out) detail::check(storm_hip_copy(out.handle(), e.v->handle()));
+  detail::check(storm_hip_div_scalar(out.handle(), e.s));
+  return out;
+}
+
+/// Bittern/MatrixAlgorithms.hpp:140-153: the reference's engine, distribution and sequence.
+inline void fill_randomly(DeviceVector& a) { detail::check(storm_hip_fill_randomly(a.handle())); }
 
 /// Bittern/MatrixAlgorithms.hpp:310-317 (global sum over all ranks).
 inline real_t dot_product(const DeviceVector& a, const DeviceVector& b) {
@@ -748,6 +760,186 @@ template<class Vector>
 class TfqmrSolver final : public BaseTfqmrSolver<Vector, false> {};
 template<class Vector>
 class Tfqmr1Solver final : public BaseTfqmrSolver<Vector, true> {};
+
+/// BiCGStab(l) (SolverBiCgStab.hpp:184-383); `num_inner_iterations` is l (default 2).
+template<class Vector>
+class BiCgStabLSolver final : public InnerOuterIterativeSolver<Vector> {
+private:
+  real_t _alpha{}, _rho{}, _omega{};
+  std::vector<real_t> _gamma, _gamma_bar, _gamma_bbar, _sigma, _tau;  // tau is (l+1) x (l+1)
+  Vector _r_tilde_vec, _z_vec;
+  std::vector<Vector> _r_vecs, _u_vecs;
+
+  real_t& tau(std::size_t i, std::size_t j) { return _tau[i * (this->num_inner_iterations + 1) + j]; }
+
+  void apply(Vector& out, const Vector& in, const Operator<Vector>& lin_op, const Preconditioner<Vector>* pre_op) {
+    if (pre_op != nullptr) pre_op->mul(out, _z_vec, lin_op, in);
+    else lin_op.mul(out, in);
+  }
+  real_t outer_init(const Vector& x_vec, const Vector& b_vec, const Operator<Vector>& lin_op,
+                    const Preconditioner<Vector>* pre_op) override {
+    const std::size_t l = this->num_inner_iterations;
+    _gamma.assign(l + 1, 0.0), _gamma_bar.assign(l + 1, 0.0), _gamma_bbar.assign(l + 1, 0.0);
+    _sigma.assign(l + 1, 0.0), _tau.assign((l + 1) * (l + 1), 0.0);
+    _r_tilde_vec.assign(x_vec, false);
+    if (pre_op != nullptr) _z_vec.assign(x_vec, false);
+    _r_vecs.clear(), _u_vecs.clear();
+    _r_vecs.resize(l + 1), _u_vecs.resize(l + 1);
+    for (Vector& r_vec : _r_vecs) r_vec.assign(x_vec, false);
+    for (Vector& u_vec : _u_vecs) u_vec.assign(x_vec, false);
+    fill_with(_u_vecs[0], 0.0);
+    lin_op.Residual(_r_vecs[0], b_vec, x_vec);
+    if (pre_op != nullptr) {
+      std::swap(_z_vec, _r_vecs[0]);
+      pre_op->mul(_r_vecs[0], _z_vec);
+    }
+    _r_tilde_vec <<= _r_vecs[0];
+    _rho = dot_product(_r_tilde_vec, _r_vecs[0]);
+    return std::sqrt(_rho);
+  }
+  real_t inner_iterate(Vector& x_vec, const Vector& /*b_vec*/, const Operator<Vector>& lin_op,
+                       const Preconditioner<Vector>* pre_op) override {
+    const std::size_t l = this->num_inner_iterations, j = this->inner_iteration;
+    if (this->iteration == 0) {
+      _u_vecs[0] <<= _r_vecs[0];
+    } else {
+      const real_t rho_bar = std::exchange(_rho, dot_product(_r_tilde_vec, _r_vecs[j]));
+      const real_t beta = safe_divide(_alpha * _rho, rho_bar);
+      for (std::size_t i = 0; i <= j; ++i) _u_vecs[i] <<= _r_vecs[i] - beta * _u_vecs[i];
+    }
+    apply(_u_vecs[j + 1], _u_vecs[j], lin_op, pre_op);
+    _alpha = safe_divide(_rho, dot_product(_r_tilde_vec, _u_vecs[j + 1]));
+    for (std::size_t i = 0; i <= j; ++i) _r_vecs[i] -= _alpha * _u_vecs[i + 1];
+    x_vec += _alpha * _u_vecs[0];
+    apply(_r_vecs[j + 1], _r_vecs[j], lin_op, pre_op);
+    if (j == l - 1) {
+      for (std::size_t jj = 1; jj <= l; ++jj) {  // modified Gram-Schmidt on r_1..r_l
+        for (std::size_t i = 1; i < jj; ++i) {
+          tau(i, jj) = safe_divide(dot_product(_r_vecs[i], _r_vecs[jj]), _sigma[i]);
+          _r_vecs[jj] -= tau(i, jj) * _r_vecs[i];
+        }
+        _sigma[jj] = dot_product(_r_vecs[jj], _r_vecs[jj]);
+        _gamma_bar[jj] = safe_divide(dot_product(_r_vecs[0], _r_vecs[jj]), _sigma[jj]);
+      }
+      _omega = _gamma[l] = _gamma_bar[l], _rho *= -_omega;
+      for (std::size_t jj = l - 1; jj != 0; --jj) {
+        _gamma[jj] = _gamma_bar[jj];
+        for (std::size_t i = jj + 1; i <= l; ++i) _gamma[jj] -= tau(jj, i) * _gamma[i];
+      }
+      for (std::size_t jj = 1; jj < l; ++jj) {
+        _gamma_bbar[jj] = _gamma[jj + 1];
+        for (std::size_t i = jj + 1; i < l; ++i) _gamma_bbar[jj] += tau(jj, i) * _gamma[i + 1];
+      }
+      x_vec += _gamma[1] * _r_vecs[0];
+      _r_vecs[0] -= _gamma_bar[l] * _r_vecs[l];
+      _u_vecs[0] -= _gamma[l] * _u_vecs[l];
+      for (std::size_t jj = 1; jj < l; ++jj) {
+        x_vec += _gamma_bbar[jj] * _r_vecs[jj];
+        _r_vecs[0] -= _gamma_bar[jj] * _r_vecs[jj];
+        _u_vecs[0] -= _gamma[jj] * _u_vecs[jj];
+      }
+    }
+    return norm_2(_r_vecs[0]);
+  }
+
+public:
+  BiCgStabLSolver() { this->num_inner_iterations = 2; }
+};
+
+/// IDR(s) (SolverIdrs.hpp:52-291); `num_inner_iterations` is s (default 4).
+template<class Vector>
+class IdrsSolver final : public InnerOuterIterativeSolver<Vector> {
+private:
+  real_t _omega{};
+  std::vector<real_t> _phi, _gamma, _mu;  // mu is s x s
+  Vector _r_vec, _v_vec, _z_vec;
+  std::vector<Vector> _p_vecs, _u_vecs, _g_vecs;
+
+  real_t& mu(std::size_t i, std::size_t j) { return _mu[i * this->num_inner_iterations + j]; }
+
+  real_t outer_init(const Vector& x_vec, const Vector& b_vec, const Operator<Vector>& lin_op,
+                    const Preconditioner<Vector>* pre_op) override {
+    const std::size_t s = this->num_inner_iterations;
+    const bool left_pre = (pre_op != nullptr) && (this->pre_side == PreconditionerSide::Left);
+    _phi.assign(s, 0.0), _gamma.assign(s, 0.0), _mu.assign(s * s, 0.0);
+    _r_vec.assign(x_vec, false), _v_vec.assign(x_vec, false);
+    if (pre_op != nullptr) _z_vec.assign(x_vec, false);
+    _p_vecs.clear(), _u_vecs.clear(), _g_vecs.clear();
+    _p_vecs.resize(s), _u_vecs.resize(s), _g_vecs.resize(s);
+    for (Vector& v : _p_vecs) v.assign(x_vec, false);
+    for (Vector& v : _u_vecs) v.assign(x_vec, false);
+    for (Vector& v : _g_vecs) v.assign(x_vec, false);
+    lin_op.Residual(_r_vec, b_vec, x_vec);
+    if (left_pre) {
+      std::swap(_z_vec, _r_vec);
+      pre_op->mul(_r_vec, _z_vec);
+    }
+    _phi[0] = norm_2(_r_vec);
+    return _phi[0];
+  }
+  void inner_init(const Vector& /*x_vec*/, const Vector& /*b_vec*/, const Operator<Vector>& /*lin_op*/,
+                  const Preconditioner<Vector>* /*pre_op*/) override {
+    const std::size_t s = this->num_inner_iterations;
+    if (this->iteration == 0) {
+      _omega = mu(0, 0) = 1.0;
+      _p_vecs[0] <<= _r_vec / _phi[0];
+      for (std::size_t i = 1; i < s; ++i) {
+        mu(i, i) = 1.0, _phi[i] = 0.0;
+        fill_randomly(_p_vecs[i]);
+        for (std::size_t j = 0; j < i; ++j) {
+          mu(i, j) = 0.0;
+          _p_vecs[i] -= dot_product(_p_vecs[i], _p_vecs[j]) * _p_vecs[j];
+        }
+        _p_vecs[i] /= norm_2(_p_vecs[i]);
+      }
+    } else {
+      for (std::size_t i = 0; i < s; ++i) _phi[i] = dot_product(_p_vecs[i], _r_vec);
+    }
+  }
+  real_t inner_iterate(Vector& x_vec, const Vector& /*b_vec*/, const Operator<Vector>& lin_op,
+                       const Preconditioner<Vector>* pre_op) override {
+    const std::size_t s = this->num_inner_iterations, k = this->inner_iteration;
+    const bool left_pre = (pre_op != nullptr) && (this->pre_side == PreconditionerSide::Left);
+    const bool right_pre = (pre_op != nullptr) && (this->pre_side == PreconditionerSide::Right);
+    for (std::size_t i = k; i < s; ++i) {  // lower-triangular solve for gamma_k..gamma_{s-1}
+      _gamma[i] = _phi[i];
+      for (std::size_t j = k; j < i; ++j) _gamma[i] -= mu(i, j) * _gamma[j];
+      _gamma[i] /= mu(i, i);
+    }
+    _v_vec <<= _r_vec - _gamma[k] * _g_vecs[k];
+    for (std::size_t i = k + 1; i < s; ++i) _v_vec -= _gamma[i] * _g_vecs[i];
+    if (right_pre) {
+      std::swap(_z_vec, _v_vec);
+      pre_op->mul(_v_vec, _z_vec);
+    }
+    _u_vecs[k] <<= _omega * _v_vec + _gamma[k] * _u_vecs[k];
+    for (std::size_t i = k + 1; i < s; ++i) _u_vecs[k] += _gamma[i] * _u_vecs[i];
+    if (left_pre) pre_op->mul(_g_vecs[k], _z_vec, lin_op, _u_vecs[k]);
+    else lin_op.mul(_g_vecs[k], _u_vecs[k]);
+    for (std::size_t i = 0; i < k; ++i) {
+      const real_t alpha = safe_divide(dot_product(_p_vecs[i], _g_vecs[k]), mu(i, i));
+      _u_vecs[k] -= alpha * _u_vecs[i];
+      _g_vecs[k] -= alpha * _g_vecs[i];
+    }
+    for (std::size_t i = k; i < s; ++i) mu(i, k) = dot_product(_p_vecs[i], _g_vecs[k]);
+    const real_t beta = safe_divide(_phi[k], mu(k, k));
+    x_vec += beta * _u_vecs[k];
+    _r_vec -= beta * _g_vecs[k];
+    for (std::size_t i = k + 1; i < s; ++i) _phi[i] -= beta * mu(i, k);
+    if (k == s - 1) {
+      if (left_pre) pre_op->mul(_v_vec, _z_vec, lin_op, _r_vec);
+      else if (right_pre) lin_op.mul(_v_vec, _z_vec, *pre_op, _r_vec);
+      else lin_op.mul(_v_vec, _r_vec);
+      _omega = safe_divide(dot_product(_v_vec, _r_vec), dot_product(_v_vec, _v_vec));
+      x_vec += _omega * (right_pre ? _z_vec : _r_vec);
+      _r_vec -= _omega * _v_vec;
+    }
+    return norm_2(_r_vec);
+  }
+
+public:
+  IdrsSolver() { this->num_inner_iterations = 4; }
+};
 
 /// GMRES(m) (SolverGmres.hpp:41-255, non-flexible).  The host-statement path implements the
 /// unpreconditioned and left/right preconditioned variants over dense host arrays for H, beta,

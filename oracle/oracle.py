@@ -86,12 +86,15 @@ def lib(variant: str = "strict"):
         L.oracle_div_scalar.argtypes = [C.c_int64, f64p, C.c_double]
         L.oracle_mul_scalar.argtypes = [C.c_int64, f64p, C.c_double]
         L.oracle_expr1.argtypes = [C.c_int64, f64p, f64p, C.c_double, f64p, f64p]
+        L.oracle_rng_next.restype = C.c_uint64
+        L.oracle_fill_randomly.argtypes = [C.c_int64, f64p]
         L.oracle_divgrad.argtypes = [C.POINTER(_Mesh), f64p, C.c_double, f64p]
         L.oracle_convection.argtypes = [C.POINTER(_Mesh), f64p, C.c_double, f64p, f64p]
         L.oracle_stencil_apply.argtypes = [C.c_void_p, f64p, f64p]
         L.oracle_csr_apply.argtypes = [C.c_void_p, f64p, f64p]
         for name in ("oracle_solve_cg", "oracle_solve_bicgstab", "oracle_solve_gmres", "oracle_solve_richardson",
-                     "oracle_solve_cgs", "oracle_solve_tfqmr", "oracle_solve_tfqmr1"):
+                     "oracle_solve_cgs", "oracle_solve_tfqmr", "oracle_solve_tfqmr1", "oracle_solve_bicgstabl",
+                     "oracle_solve_idrs"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int64, f64p, f64p,
                                          C.POINTER(_Params), C.POINTER(_Result), f64p]
     return _libs[variant]
@@ -135,6 +138,17 @@ def norm1(a) -> float:
 def norm_inf(a) -> float:
     a = f64(a).ravel()
     return lib().oracle_norm_inf(a.size, _p(a))
+
+
+def rng_reset(variant: str = "strict") -> None:
+    """Restart the oracle's function-static mt19937_64 (a fresh process in the reference's terms)."""
+    lib(variant).oracle_rng_reset()
+
+
+def fill_randomly(n: int) -> np.ndarray:
+    out = np.empty(n)
+    lib().oracle_fill_randomly(n, _p(out))
+    return out
 
 
 def safe_divide(x: float, y: float) -> float:
@@ -279,7 +293,7 @@ def solve(kind: str, op, b, x0=None, num_iterations: int = 2000, abs_tol: float 
     L = lib(variant)
     fn = {"cg": L.oracle_solve_cg, "bicgstab": L.oracle_solve_bicgstab, "gmres": L.oracle_solve_gmres,
           "richardson": L.oracle_solve_richardson, "cgs": L.oracle_solve_cgs, "tfqmr": L.oracle_solve_tfqmr,
-          "tfqmr1": L.oracle_solve_tfqmr1}[kind]
+          "tfqmr1": L.oracle_solve_tfqmr1, "bicgstabl": L.oracle_solve_bicgstabl, "idrs": L.oracle_solve_idrs}[kind]
     fn(op.fn, op.ctx, b.size, _p(x), _p(b), C.byref(p), C.byref(r), _p(hist))
     return SolveResult(x, r.iterations, r.absolute_error, r.relative_error, r.initial_error,
                        bool(r.converged), r.num_applies, hist[: r.iterations + 1].copy())

@@ -749,4 +749,227 @@ ORACLE_API void oracle_solve_tfqmr1(oracle_apply_fn apply, void *op, int64_t n, 
   tfqmr_solve(1, apply, op, n, x, b, p, res, history);
 }
 
-ORACLE_API int oracle_abi_version(void) { return 2; }
+/* ---- fill_randomly: Bittern/MatrixAlgorithms.hpp:140-153 -------------------
+ * A function-static std::mt19937_64{} (default seed 5489; state persists across calls) feeding
+ * std::uniform_real_distribution(0, 1).  MT19937-64 is the published Matsumoto-Nishimura
+ * generator (the C++ standard fixes its parameters and its 10000th output,
+ * 9981545732273789042); libstdc++'s distribution draws ONE 64-bit word per double and returns
+ * double(word) / 2^64, clipped below 1 (bits/random.tcc, generate_canonical). */
+#define MT_NN 312
+#define MT_MM 156
+static uint64_t mt_state[MT_NN];
+static int mt_index = MT_NN + 1;
+
+ORACLE_API void oracle_rng_reset(void) {
+  mt_state[0] = 5489ULL;
+  for (int i = 1; i < MT_NN; ++i)
+    mt_state[i] = 6364136223846793005ULL * (mt_state[i - 1] ^ (mt_state[i - 1] >> 62)) + (uint64_t)i;
+  mt_index = MT_NN;
+}
+ORACLE_API uint64_t oracle_rng_next(void) {
+  if (mt_index > MT_NN) oracle_rng_reset();
+  if (mt_index == MT_NN) {
+    for (int i = 0; i < MT_NN; ++i) {
+      const uint64_t x = (mt_state[i] & 0xFFFFFFFF80000000ULL) | (mt_state[(i + 1) % MT_NN] & 0x7FFFFFFFULL);
+      mt_state[i] = mt_state[(i + MT_MM) % MT_NN] ^ (x >> 1) ^ ((x & 1ULL) ? 0xB5026F5AA96619E9ULL : 0ULL);
+    }
+    mt_index = 0;
+  }
+  uint64_t x = mt_state[mt_index++];
+  x ^= (x >> 29) & 0x5555555555555555ULL;
+  x ^= (x << 17) & 0x71D67FFFEDA60000ULL;
+  x ^= (x << 37) & 0xFFF7EEE000000000ULL;
+  x ^= (x >> 43);
+  return x;
+}
+ORACLE_API void oracle_fill_randomly(int64_t n, double *y) {
+  for (int64_t i = 0; i < n; ++i) {
+    double r = (double)oracle_rng_next() / 18446744073709551616.0;
+    if (r >= 1.0) r = nextafter(1.0, 0.0);
+    y[i] = r;
+  }
+}
+
+/* ---- BiCGStab(l): Solvers/SolverBiCgStab.hpp:184-383 (no preconditioner) -- */
+typedef struct bicgl_state {
+  solver_base b;
+  int64_t l;
+  double alpha, rho, omega;
+  double *gamma, *gamma_bar, *gamma_bbar, *sigma, *tau; /* tau is (l+1) x (l+1) */
+  double *rt;
+  double **r, **u;
+} bicgl_state;
+#define TAU_(s, i, j) ((s)->tau[(i) * ((s)->l + 1) + (j)])
+
+static double bicgl_init(void *sv, const double *x, const double *b) {
+  bicgl_state *s = (bicgl_state *)sv;
+  const int64_t n = s->b.n, l = s->l;
+  s->gamma = (double *)calloc((size_t)l + 1, sizeof(double));       /* :202-206 */
+  s->gamma_bar = (double *)calloc((size_t)l + 1, sizeof(double));
+  s->gamma_bbar = (double *)calloc((size_t)l + 1, sizeof(double));
+  s->sigma = (double *)calloc((size_t)l + 1, sizeof(double));
+  s->tau = (double *)calloc((size_t)((l + 1) * (l + 1)), sizeof(double));
+  s->rt = new_vec(n);
+  s->r = (double **)calloc((size_t)l + 1, sizeof(double *));
+  s->u = (double **)calloc((size_t)l + 1, sizeof(double *));
+  for (int64_t i = 0; i <= l; ++i) s->r[i] = new_vec(n), s->u[i] = new_vec(n);
+  oracle_fill(n, s->u[0], 0.0);                                      /* :224 */
+  s->b.applies++;
+  op_residual(s->b.apply, s->b.op, n, s->r[0], b, x);                /* :225 */
+  oracle_copy(n, s->rt, s->r[0]);                                    /* :230 */
+  s->rho = oracle_dot(n, s->rt, s->r[0]);                            /* :231 */
+  return sqrt(s->rho);
+}
+static double bicgl_iterate(void *sv, double *x, const double *b) {
+  (void)b;
+  bicgl_state *s = (bicgl_state *)sv;
+  const int64_t n = s->b.n, l = s->l;
+  const int64_t j = s->b.iteration % l;                              /* Solver.hpp:239 */
+  if (s->b.iteration == 0) {
+    oracle_copy(n, s->u[0], s->r[0]);                                /* :264 */
+  } else {
+    const double rho_bar = s->rho;                                   /* :266-267 */
+    s->rho = oracle_dot(n, s->rt, s->r[j]);
+    const double beta = oracle_safe_divide(s->alpha * s->rho, rho_bar); /* :268 */
+    for (int64_t i = 0; i <= j; ++i)                                 /* :269-271 */
+      for (int64_t q = 0; q < n; ++q) s->u[i][q] = s->r[i][q] - beta * s->u[i][q];
+  }
+  op_mul(&s->b, s->u[j + 1], s->u[j]);                               /* :276 */
+  s->alpha = oracle_safe_divide(s->rho, oracle_dot(n, s->rt, s->u[j + 1])); /* :278 */
+  for (int64_t i = 0; i <= j; ++i) oracle_axmy(n, s->r[i], s->alpha, s->u[i + 1]); /* :279-281 */
+  oracle_axpy(n, x, s->alpha, s->u[0]);                              /* :291 */
+  op_mul(&s->b, s->r[j + 1], s->r[j]);                               /* :295 */
+  if (j == l - 1) {                                                  /* :298-365 */
+    for (int64_t jj = 1; jj <= l; ++jj) {
+      for (int64_t i = 1; i < jj; ++i) {
+        TAU_(s, i, jj) = oracle_safe_divide(oracle_dot(n, s->r[i], s->r[jj]), s->sigma[i]);
+        oracle_axmy(n, s->r[jj], TAU_(s, i, jj), s->r[i]);
+      }
+      s->sigma[jj] = oracle_dot(n, s->r[jj], s->r[jj]);
+      s->gamma_bar[jj] = oracle_safe_divide(oracle_dot(n, s->r[0], s->r[jj]), s->sigma[jj]);
+    }
+    s->omega = s->gamma[l] = s->gamma_bar[l];
+    s->rho *= -s->omega;
+    for (int64_t jj = l - 1; jj != 0; --jj) {
+      s->gamma[jj] = s->gamma_bar[jj];
+      for (int64_t i = jj + 1; i <= l; ++i) s->gamma[jj] -= TAU_(s, jj, i) * s->gamma[i];
+    }
+    for (int64_t jj = 1; jj < l; ++jj) {
+      s->gamma_bbar[jj] = s->gamma[jj + 1];
+      for (int64_t i = jj + 1; i < l; ++i) s->gamma_bbar[jj] += TAU_(s, jj, i) * s->gamma[i + 1];
+    }
+    oracle_axpy(n, x, s->gamma[1], s->r[0]);
+    oracle_axmy(n, s->r[0], s->gamma_bar[l], s->r[l]);
+    oracle_axmy(n, s->u[0], s->gamma[l], s->u[l]);
+    for (int64_t jj = 1; jj < l; ++jj) {
+      oracle_axpy(n, x, s->gamma_bbar[jj], s->r[jj]);
+      oracle_axmy(n, s->r[0], s->gamma_bar[jj], s->r[jj]);
+      oracle_axmy(n, s->u[0], s->gamma[jj], s->u[jj]);
+    }
+  }
+  return oracle_norm2(n, s->r[0]);                                   /* :367 */
+}
+ORACLE_API void oracle_solve_bicgstabl(oracle_apply_fn apply, void *op, int64_t n, double *x, const double *b,
+                                       const oracle_params *p, oracle_result *res, double *history) {
+  bicgl_state s;
+  memset(&s, 0, sizeof s);
+  s.b.apply = apply, s.b.op = op, s.b.n = n, s.b.history = history;
+  s.l = p->num_inner_iterations;  /* default 2, :379-381 */
+  const solver_vt vt = {bicgl_init, bicgl_iterate, NULL};
+  iterative_solve(&s.b, &vt, &s, x, b, p, res);
+  for (int64_t i = 0; i <= s.l; ++i) free(s.r[i]), free(s.u[i]);
+  free(s.r), free(s.u), free(s.rt), free(s.gamma), free(s.gamma_bar), free(s.gamma_bbar), free(s.sigma), free(s.tau);
+}
+
+/* ---- IDR(s): Solvers/SolverIdrs.hpp:52-291 (no preconditioner) ----------- */
+typedef struct idrs_state {
+  solver_base b;
+  int64_t s;
+  double omega;
+  double *phi, *gamma, *mu; /* mu is s x s */
+  double *r, *v;
+  double **p, **u, **g;
+} idrs_state;
+#define MU_(st, i, j) ((st)->mu[(i) * (st)->s + (j)])
+
+static double idrs_init(void *sv, const double *x, const double *b) {
+  idrs_state *st = (idrs_state *)sv;
+  const int64_t n = st->b.n, s = st->s;
+  st->phi = (double *)calloc((size_t)s, sizeof(double));            /* :73-75 */
+  st->gamma = (double *)calloc((size_t)s, sizeof(double));
+  st->mu = (double *)calloc((size_t)(s * s), sizeof(double));
+  st->r = new_vec(n), st->v = new_vec(n);
+  st->p = (double **)calloc((size_t)s, sizeof(double *));
+  st->u = (double **)calloc((size_t)s, sizeof(double *));
+  st->g = (double **)calloc((size_t)s, sizeof(double *));
+  for (int64_t i = 0; i < s; ++i) st->p[i] = new_vec(n), st->u[i] = new_vec(n), st->g[i] = new_vec(n);
+  st->b.applies++;
+  op_residual(st->b.apply, st->b.op, n, st->r, b, x);               /* :99 */
+  st->phi[0] = oracle_norm2(n, st->r);                               /* :104 */
+  return st->phi[0];
+}
+static void idrs_inner_init(idrs_state *st) {                        /* :109-156 */
+  const int64_t n = st->b.n, s = st->s;
+  if (st->b.iteration == 0) {
+    st->omega = MU_(st, 0, 0) = 1.0;
+    for (int64_t q = 0; q < n; ++q) st->p[0][q] = st->r[q] / st->phi[0]; /* :131 */
+    for (int64_t i = 1; i < s; ++i) {
+      MU_(st, i, i) = 1.0, st->phi[i] = 0.0;
+      oracle_fill_randomly(n, st->p[i]);                             /* :135 */
+      for (int64_t j = 0; j < i; ++j) {
+        MU_(st, i, j) = 0.0;
+        oracle_axmy(n, st->p[i], oracle_dot(n, st->p[i], st->p[j]), st->p[j]); /* :138 */
+      }
+      oracle_div_scalar(n, st->p[i], oracle_norm2(n, st->p[i]));     /* :140 */
+    }
+  } else {
+    for (int64_t i = 0; i < s; ++i) st->phi[i] = oracle_dot(n, st->p[i], st->r); /* :143-145 */
+  }
+}
+static double idrs_iterate(void *sv, double *x, const double *b) {
+  (void)b;
+  idrs_state *st = (idrs_state *)sv;
+  const int64_t n = st->b.n, s = st->s;
+  const int64_t k = st->b.iteration % s;                             /* Solver.hpp:239 */
+  if (k == 0) idrs_inner_init(st);                                   /* Solver.hpp:240-242 */
+  for (int64_t i = k; i < s; ++i) {                                  /* :182-188 */
+    st->gamma[i] = st->phi[i];
+    for (int64_t j = k; j < i; ++j) st->gamma[i] -= MU_(st, i, j) * st->gamma[j];
+    st->gamma[i] /= MU_(st, i, i);
+  }
+  for (int64_t q = 0; q < n; ++q) st->v[q] = st->r[q] - st->gamma[k] * st->g[k][q];   /* :200 */
+  for (int64_t i = k + 1; i < s; ++i) oracle_axmy(n, st->v, st->gamma[i], st->g[i]); /* :201-203 */
+  for (int64_t q = 0; q < n; ++q) st->u[k][q] = st->omega * st->v[q] + st->gamma[k] * st->u[k][q]; /* :208 */
+  for (int64_t i = k + 1; i < s; ++i) oracle_axpy(n, st->u[k], st->gamma[i], st->u[i]);           /* :209-211 */
+  op_mul(&st->b, st->g[k], st->u[k]);                                /* :215 */
+  for (int64_t i = 0; i < k; ++i) {                                  /* :230-235 */
+    const double alpha = oracle_safe_divide(oracle_dot(n, st->p[i], st->g[k]), MU_(st, i, i));
+    oracle_axmy(n, st->u[k], alpha, st->u[i]);
+    oracle_axmy(n, st->g[k], alpha, st->g[i]);
+  }
+  for (int64_t i = k; i < s; ++i) MU_(st, i, k) = oracle_dot(n, st->p[i], st->g[k]); /* :236-238 */
+  const double beta = oracle_safe_divide(st->phi[k], MU_(st, k, k)); /* :250 */
+  oracle_axpy(n, x, beta, st->u[k]);
+  oracle_axmy(n, st->r, beta, st->g[k]);
+  for (int64_t i = k + 1; i < s; ++i) st->phi[i] -= beta * MU_(st, i, k);
+  if (k == s - 1) {                                                  /* :256-279 */
+    op_mul(&st->b, st->v, st->r);
+    st->omega = oracle_safe_divide(oracle_dot(n, st->v, st->r), oracle_dot(n, st->v, st->v));
+    oracle_axpy(n, x, st->omega, st->r);
+    oracle_axmy(n, st->r, st->omega, st->v);
+  }
+  return oracle_norm2(n, st->r);                                     /* :281 */
+}
+ORACLE_API void oracle_solve_idrs(oracle_apply_fn apply, void *op, int64_t n, double *x, const double *b,
+                                  const oracle_params *p, oracle_result *res, double *history) {
+  idrs_state st;
+  memset(&st, 0, sizeof st);
+  st.b.apply = apply, st.b.op = op, st.b.n = n, st.b.history = history;
+  st.s = p->num_inner_iterations;  /* default 4, :287-289 */
+  const solver_vt vt = {idrs_init, idrs_iterate, NULL};
+  iterative_solve(&st.b, &vt, &st, x, b, p, res);
+  for (int64_t i = 0; i < st.s; ++i) free(st.p[i]), free(st.u[i]), free(st.g[i]);
+  free(st.p), free(st.u), free(st.g), free(st.r), free(st.v), free(st.phi), free(st.gamma), free(st.mu);
+}
+
+ORACLE_API int oracle_abi_version(void) { return 3; }

@@ -77,6 +77,8 @@ SIGNATURES = {
     "storm_hip_xpay": (C.c_int, [vp, vp, C.c_double]),
     "storm_hip_axpbz": (C.c_int, [vp, C.c_double, vp, C.c_double, vp]),
     "storm_hip_bicgstab_p": (C.c_int, [vp, vp, C.c_double, C.c_double, vp]),
+    "storm_hip_fill_randomly": (C.c_int, [vp]),
+    "storm_hip_rng_reset": (None, []),
     "storm_hip_lin3": (C.c_int, [vp, vp, C.c_double, C.c_double, vp, C.c_double, vp]),
     "storm_hip_vmul_add": (C.c_int, [vp, C.c_double, vp, vp]),
     "storm_hip_dot": (C.c_int, [vp, vp, f64p]),

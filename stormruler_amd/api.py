@@ -107,6 +107,16 @@ class _Scaled:  # a * v
     def __init__(self, a: float, v: "DeviceVector"):
         self.a, self.v = float(a), v
 
+    def __add__(self, o):  # omega * v + gamma * u   (SolverIdrs.hpp:208)
+        if isinstance(o, _Scaled):
+            return _Lin2(self.a, self.v, o.a, o.v)
+        return NotImplemented
+
+
+class _Quot:  # v / s  (true elementwise division, SolverIdrs.hpp:131)
+    def __init__(self, v: "DeviceVector", s: float):
+        self.v, self.s = v, float(s)
+
 
 class _Lin2:  # a*x + b*z
     def __init__(self, a, x, b, z):
@@ -129,6 +139,8 @@ class _Lin3:  # r + s * (a*x + b*z)
 class DeviceVector:
     """N doubles in HBM (+ halo tail); the solver ``Vector`` (concept legacy_vector_like,
     Solvers/Operator.hpp:39-45)."""
+
+    __array_ufunc__ = None  # numpy scalars defer to __rmul__ instead of broadcasting over the object
 
     def __init__(self, ctx: Optional[Context] = None, n_owned: int = 0, n_halo: int = 0):
         self.ctx = ctx
@@ -194,6 +206,9 @@ class DeviceVector:
             return _Lin3(self, o.s, o.lin)
         return NotImplemented
 
+    def __truediv__(self, s):
+        return _Quot(self, s)
+
     def __sub__(self, o):  # MatrixMath.hpp:280-285
         if isinstance(o, DeviceVector):
             return _Lin2(1.0, self, -1.0, o)
@@ -209,6 +224,10 @@ class DeviceVector:
             check(lib.storm_hip_axpbz(self._h, e.a, e.v._h, 0.0, e.v._h))
         elif isinstance(e, _Lin2):
             check(lib.storm_hip_axpbz(self._h, e.a, e.x._h, e.b, e.z._h))
+        elif isinstance(e, _Quot):
+            if e.v is not self:
+                check(lib.storm_hip_copy(self._h, e.v._h))
+            check(lib.storm_hip_div_scalar(self._h, e.s))
         elif isinstance(e, _Lin3):
             # p <<= r + beta * (p - omega * v)  (SolverBiCgStab.hpp:119),  p <<= u + beta * (q + beta * p)
             # (SolverCgs.hpp:122): one kernel evaluating r + s * (a x + b z) in that nesting
@@ -266,6 +285,15 @@ def fill_with(a: DeviceVector, value: float) -> None:
 def vmul_add(y: DeviceVector, s: float, a: DeviceVector, b: DeviceVector) -> None:
     """``y += s * (a .* b)`` elementwise (nonlinear terms of a time-step driver)."""
     check(lib.storm_hip_vmul_add(y._h, float(s), a._h, b._h))
+
+
+def fill_randomly(a: DeviceVector) -> None:
+    """Bittern/MatrixAlgorithms.hpp:140-153 (same engine / distribution / sequence as the reference)."""
+    check(lib.storm_hip_fill_randomly(a._h))
+
+
+def rng_reset() -> None:
+    lib.storm_hip_rng_reset()
 
 
 def multi_dot(a: DeviceVector, bs: Sequence[DeviceVector]) -> np.ndarray:
@@ -879,6 +907,158 @@ class Tfqmr1Solver(_BaseTfqmrSolver):
     """SolverTfqmr.hpp:262-264."""
 
     _L1 = True
+
+
+class FgmresSolver(GmresSolver):
+    """SolverGmres.hpp:306-308: flexible GMRES.  Without a preconditioner it is GMRES (the flexible
+    branches only differ in where the preconditioned vectors are kept)."""
+
+
+class BiCgStabLSolver(InnerOuterIterativeSolver):
+    """SolverBiCgStab.hpp:184-383, unpreconditioned branch; ``num_inner_iterations`` is l (default 2)."""
+
+    def __init__(self):
+        super().__init__()
+        self.num_inner_iterations = 2  # :379-381
+
+    def outer_init(self, x_vec, b_vec, lin_op, pre_op):
+        if pre_op is not None:
+            raise NotImplementedError("preconditioned BiCGStab(l) is not part of the hot path")
+        l = self.num_inner_iterations
+        self._gamma, self._gamma_bar = np.zeros(l + 1), np.zeros(l + 1)
+        self._gamma_bbar, self._sigma = np.zeros(l + 1), np.zeros(l + 1)
+        self._tau = np.zeros((l + 1, l + 1))
+        mk = lambda: _like(x_vec)  # noqa: E731
+        self._r_tilde_vec = mk()
+        self._r_vecs = [mk() for _ in range(l + 1)]
+        self._u_vecs = [mk() for _ in range(l + 1)]
+        fill_with(self._u_vecs[0], 0.0)
+        lin_op.Residual(self._r_vecs[0], b_vec, x_vec)
+        self._r_tilde_vec <<= self._r_vecs[0]
+        self._rho = dot_product(self._r_tilde_vec, self._r_vecs[0])
+        self._alpha = self._omega = 0.0
+        return math.sqrt(self._rho)
+
+    def inner_iterate(self, x_vec, b_vec, lin_op, pre_op):
+        l, j = self.num_inner_iterations, self.inner_iteration
+        r, u = self._r_vecs, self._u_vecs
+        if self.iteration == 0:
+            u[0] <<= r[0]
+        else:
+            rho_bar, self._rho = self._rho, dot_product(self._r_tilde_vec, r[j])
+            beta = safe_divide(self._alpha * self._rho, rho_bar)
+            for i in range(j + 1):
+                u[i] <<= r[i] - beta * u[i]
+        lin_op.mul(u[j + 1], u[j])
+        self._alpha = safe_divide(self._rho, dot_product(self._r_tilde_vec, u[j + 1]))
+        for i in range(j + 1):
+            r[i] -= self._alpha * u[i + 1]
+        x_vec += self._alpha * u[0]
+        lin_op.mul(r[j + 1], r[j])
+        if j == l - 1:
+            tau, sigma, g, gb, gbb = self._tau, self._sigma, self._gamma, self._gamma_bar, self._gamma_bbar
+            for jj in range(1, l + 1):
+                for i in range(1, jj):
+                    tau[i, jj] = safe_divide(dot_product(r[i], r[jj]), sigma[i])
+                    r[jj] -= tau[i, jj] * r[i]
+                sigma[jj] = dot_product(r[jj], r[jj])
+                gb[jj] = safe_divide(dot_product(r[0], r[jj]), sigma[jj])
+            self._omega = g[l] = gb[l]
+            self._rho *= -self._omega
+            for jj in range(l - 1, 0, -1):
+                g[jj] = gb[jj]
+                for i in range(jj + 1, l + 1):
+                    g[jj] -= tau[jj, i] * g[i]
+            for jj in range(1, l):
+                gbb[jj] = g[jj + 1]
+                for i in range(jj + 1, l):
+                    gbb[jj] += tau[jj, i] * g[i + 1]
+            x_vec += g[1] * r[0]
+            r[0] -= gb[l] * r[l]
+            u[0] -= g[l] * u[l]
+            for jj in range(1, l):
+                x_vec += gbb[jj] * r[jj]
+                r[0] -= gb[jj] * r[jj]
+                u[0] -= g[jj] * u[jj]
+        return norm_2(r[0])
+
+
+class IdrsSolver(InnerOuterIterativeSolver):
+    """SolverIdrs.hpp:52-291, unpreconditioned branch; ``num_inner_iterations`` is s (default 4)."""
+
+    def __init__(self):
+        super().__init__()
+        self.num_inner_iterations = 4  # :287-289
+
+    def outer_init(self, x_vec, b_vec, lin_op, pre_op):
+        if pre_op is not None:
+            raise NotImplementedError("preconditioned IDR(s) is not part of the hot path")
+        s = self.num_inner_iterations
+        self._phi, self._gamma, self._mu = np.zeros(s), np.zeros(s), np.zeros((s, s))
+        mk = lambda: _like(x_vec)  # noqa: E731
+        self._r_vec, self._v_vec = mk(), mk()
+        self._p_vecs = [mk() for _ in range(s)]
+        self._u_vecs = [mk() for _ in range(s)]
+        self._g_vecs = [mk() for _ in range(s)]
+        lin_op.Residual(self._r_vec, b_vec, x_vec)
+        self._phi[0] = norm_2(self._r_vec)
+        return self._phi[0]
+
+    def inner_init(self, x_vec, b_vec, lin_op, pre_op):
+        s, p, phi, mu = self.num_inner_iterations, self._p_vecs, self._phi, self._mu
+        if self.iteration == 0:
+            self._omega = mu[0, 0] = 1.0
+            p[0] <<= self._r_vec / phi[0]
+            for i in range(1, s):
+                mu[i, i], phi[i] = 1.0, 0.0
+                fill_randomly(p[i])
+                for j in range(i):
+                    mu[i, j] = 0.0
+                    p[i] -= dot_product(p[i], p[j]) * p[j]
+                p[i] /= norm_2(p[i])
+        else:
+            for i in range(s):
+                phi[i] = dot_product(p[i], self._r_vec)
+
+    def inner_iterate(self, x_vec, b_vec, lin_op, pre_op):
+        s, k = self.num_inner_iterations, self.inner_iteration
+        phi, gamma, mu = self._phi, self._gamma, self._mu
+        p, u, g, r, v = self._p_vecs, self._u_vecs, self._g_vecs, self._r_vec, self._v_vec
+        for i in range(k, s):
+            gamma[i] = phi[i]
+            for j in range(k, i):
+                gamma[i] -= mu[i, j] * gamma[j]
+            gamma[i] /= mu[i, i]
+        v <<= r - gamma[k] * g[k]
+        for i in range(k + 1, s):
+            v -= gamma[i] * g[i]
+        u[k] <<= self._omega * v + gamma[k] * u[k]
+        for i in range(k + 1, s):
+            u[k] += gamma[i] * u[i]
+        lin_op.mul(g[k], u[k])
+        for i in range(k):
+            alpha = safe_divide(dot_product(p[i], g[k]), mu[i, i])
+            u[k] -= alpha * u[i]
+            g[k] -= alpha * g[i]
+        for i in range(k, s):
+            mu[i, k] = dot_product(p[i], g[k])
+        beta = safe_divide(phi[k], mu[k, k])
+        x_vec += beta * u[k]
+        r -= beta * g[k]
+        for i in range(k + 1, s):
+            phi[i] -= beta * mu[i, k]
+        if k == s - 1:
+            lin_op.mul(v, r)
+            self._omega = safe_divide(dot_product(v, r), dot_product(v, v))
+            x_vec += self._omega * r
+            r -= self._omega * v
+        return norm_2(r)
+
+
+def _like(v: DeviceVector) -> DeviceVector:
+    w = DeviceVector()
+    w.assign(v, False)
+    return w
 
 
 def solve(solver_cls, x_vec: DeviceVector, b_vec: DeviceVector, any_op: Operator) -> bool:

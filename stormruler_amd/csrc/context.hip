@@ -1,6 +1,7 @@
 // Context, vectors, error plumbing of libstorm_hip.so.
 #include <cstdarg>
 #include <cstring>
+#include <random>
 
 #include "common.hpp"
 
@@ -223,6 +224,22 @@ int storm_hip_vec_download(const storm_hip_vec *v, double *host, int64_t n) {
   HIP_TRY(hipMemcpyAsync(host, v->d, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, v->ctx->stream));
   HIP_TRY(hipStreamSynchronize(v->ctx->stream));
   return STORM_HIP_OK;
+}
+
+static std::mt19937_64 &random_engine() {
+  static std::mt19937_64 engine{};  // MatrixAlgorithms.hpp:145
+  return engine;
+}
+
+void storm_hip_rng_reset(void) { random_engine() = std::mt19937_64{}; }
+
+int storm_hip_fill_randomly(storm_hip_vec *v) {
+  STORM_REQUIRE(v, "fill_randomly: null vector");
+  STORM_REQUIRE(v->ctx->n_ranks == 1, "fill_randomly: the sequential generator is defined for a single rank only");
+  std::uniform_real_distribution<double> distribution{0.0, 1.0};  // :146
+  std::vector<double> host((size_t)v->n_owned);
+  for (double &value : host) value = distribution(random_engine());
+  return storm_hip_vec_upload(v, host.data(), v->n_owned);
 }
 
 int storm_hip_vec_device_ptr(storm_hip_vec *v, void **dev_ptr) {

@@ -104,6 +104,8 @@ int main(int argc, char** argv) {
     if (kind == "cg") return run<CgSolver>(n, native, restart);
     if (kind == "bicgstab") return run<BiCgStabSolver>(n, native, restart);
     if (kind == "gmres") return run<GmresSolver>(n, native, restart);
+    if (kind == "bicgstabl") return run<BiCgStabLSolver>(n, native, restart);
+    if (kind == "idrs") return run<IdrsSolver>(n, native, restart);
     if (kind == "cgs") return run<CgsSolver>(n, native, restart);
     if (kind == "tfqmr") return run<TfqmrSolver>(n, native, restart);
     if (kind == "tfqmr1") return run<Tfqmr1Solver>(n, native, restart);

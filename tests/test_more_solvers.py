@@ -84,3 +84,132 @@ def test_cpp_adapter_solvers(kind):
     ref = oracle.solve(kind, oracle.StencilOperator(g, -1.0, 0.0), np.ones(g.n_cells))
     assert got["converged"] and abs(got["iterations"] - ref.iterations) <= max(2, int(0.05 * ref.iterations))
     assert abs(got["x_norm2"] - np.linalg.norm(ref.x)) <= 5e-6 * np.linalg.norm(ref.x)
+
+
+# ---- BiCGStab(l), IDR(s), fill_randomly -----------------------------------------------------------
+
+def test_oracle_mt19937_64_matches_the_standard():
+    """The C++ standard fixes the 10000th output of a default-constructed mt19937_64."""
+    L = oracle.lib()
+    oracle.rng_reset()
+    for _ in range(9999):
+        L.oracle_rng_next()
+    assert L.oracle_rng_next() == 9981545732273789042
+    oracle.rng_reset()
+    v = oracle.fill_randomly(1000)
+    assert np.all((v >= 0.0) & (v < 1.0)) and abs(v.mean() - 0.5) < 0.05
+
+
+def test_oracle_bicgstabl_and_idrs_converge():
+    g = mesh.structured_box(12)
+    op = oracle.StencilOperator(g, -1.0, 0.0)
+    b = np.ones(g.n_cells)
+    ref = oracle.solve("cg", op, b, rel_tol=1e-10, abs_tol=0.0)
+    for kind, m in (("bicgstabl", 2), ("bicgstabl", 4), ("idrs", 4), ("idrs", 1), ("idrs", 8)):
+        oracle.rng_reset()
+        r = oracle.solve(kind, op, b, num_inner_iterations=m)
+        assert r.converged and np.linalg.norm(r.x - ref.x) <= 1e-5 * np.linalg.norm(ref.x), (kind, m)
+    # IDR(s) consumes the function-static engine: a second solve in the same "process" sees other numbers
+    oracle.rng_reset()
+    r1 = oracle.solve("idrs", op, b, num_inner_iterations=4)
+    r2 = oracle.solve("idrs", op, b, num_inner_iterations=4)
+    oracle.rng_reset()
+    r3 = oracle.solve("idrs", op, b, num_inner_iterations=4)
+    assert np.array_equal(r1.x, r3.x) and not np.array_equal(r1.x, r2.x)
+
+
+@pytest.mark.gpu
+def test_fill_randomly_is_the_reference_sequence():
+    from stormruler_amd import api
+
+    ctx = api.Context(0)
+    api.rng_reset()
+    oracle.rng_reset()
+    a, b = api.DeviceVector(ctx, 1000), api.DeviceVector(ctx, 37)
+    api.fill_randomly(a)
+    api.fill_randomly(b)  # the engine's state persists across calls (function-static in the reference)
+    want = oracle.fill_randomly(1037)
+    assert np.array_equal(a.to_numpy(), want[:1000]) and np.array_equal(b.to_numpy(), want[1000:])
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,m", [("bicgstabl", 2), ("bicgstabl", 3), ("idrs", 4), ("idrs", 2)])
+def test_hip_bicgstabl_idrs_match_oracle(kind, m):
+    from stormruler_amd import api
+
+    g = mesh.structured_box(18, 14, 11)
+    ctx = api.Context(0)
+    mat = api.StencilMatrix.from_face_graph(ctx, g)
+    op = api.HipStencilOperator(mat, -1.0, 0.0)
+    b_host = np.cos(0.01 * np.arange(g.n_cells)) + 0.5
+    s = (api.BiCgStabLSolver if kind == "bicgstabl" else api.IdrsSolver)()
+    s.num_inner_iterations = m
+    b, x = api.DeviceVector.from_numpy(ctx, b_host), api.DeviceVector(ctx, g.n_cells)
+    api.rng_reset()
+    oracle.rng_reset()
+    ok = s.solve(x, b, op)
+    ref = oracle.solve(kind, oracle.StencilOperator(g, -1.0, 0.0), b_host, num_inner_iterations=m)
+    assert ok and ref.converged
+    assert abs(s.iteration - ref.iterations) <= max(2, int(0.1 * ref.iterations))
+    assert np.linalg.norm(x.to_numpy() - ref.x) <= 1e-5 * np.linalg.norm(ref.x)
+    k = min(len(s.history), len(ref.history), 6)
+    assert np.allclose(s.history[:k], ref.history[:k], rtol=1e-7)
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,m", [("bicgstabl", 2), ("idrs", 4)])
+def test_cpp_adapter_bicgstabl_idrs(kind, m):
+    driver = os.path.join(ROOT, "tests", "cpp", "poisson_driver")
+    out = subprocess.run([driver, "16", kind, "lambda", str(m)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    g = mesh.structured_box(16)
+    oracle.rng_reset()
+    ref = oracle.solve(kind, oracle.StencilOperator(g, -1.0, 0.0), np.ones(g.n_cells), num_inner_iterations=m)
+    assert got["converged"] and abs(got["iterations"] - ref.iterations) <= max(2, int(0.1 * ref.iterations))
+    assert abs(got["x_norm2"] - np.linalg.norm(ref.x)) <= 1e-5 * np.linalg.norm(ref.x)
+
+
+@pytest.mark.gpu
+def test_preconditioner_hook_sides():
+    """pre_op / pre_side (Solver.hpp:74-75): the identity preconditioner must not change the iterates;
+    a Jacobi-like diagonal scaling (one elementwise product per application) must still converge."""
+    from stormruler_amd import api
+
+    g = mesh.structured_box(12)
+    ctx = api.Context(0)
+    mat = api.StencilMatrix.from_face_graph(ctx, g)
+    lam = api.make_operator(lambda y, x: mat.apply(-1.0, 0.0, x, y))
+    b = api.DeviceVector.from_numpy(ctx, np.ones(g.n_cells))
+    base = {}
+    for cls in (api.CgSolver, api.BiCgStabSolver):
+        x = api.DeviceVector(ctx, g.n_cells)
+        s = cls()
+        assert s.solve(x, b, lam)
+        base[cls] = (s.iteration, x.to_numpy())
+    for cls in (api.CgSolver, api.BiCgStabSolver):
+        for side in (api.PreconditionerSide.Right, api.PreconditionerSide.Left):
+            x = api.DeviceVector(ctx, g.n_cells)
+            s = cls()
+            s.pre_op, s.pre_side = api.IdentityPreconditioner(), side
+            assert s.solve(x, b, lam)
+            assert s.iteration == base[cls][0]
+            assert np.linalg.norm(x.to_numpy() - base[cls][1]) <= 1e-12 * np.linalg.norm(base[cls][1])
+    # diagonal preconditioner M^-1 = 1/diag(A)
+    import scipy.sparse as sp  # noqa: F401
+    diag = mesh.assemble_csr(g, -1.0, 0.0).diagonal()
+    dinv = api.DeviceVector.from_numpy(ctx, 1.0 / diag)
+
+    class Jacobi(api.Preconditioner):
+        def mul(self, y, x):
+            api.fill_with(y, 0.0)
+            api.vmul_add(y, 1.0, dinv, x)
+
+    x = api.DeviceVector(ctx, g.n_cells)
+    s = api.CgSolver()
+    s.pre_op = Jacobi()
+    assert s.solve(x, b, lam)
+    assert np.linalg.norm(x.to_numpy() - base[api.CgSolver][1]) <= 1e-5 * np.linalg.norm(base[api.CgSolver][1])
+    ctx.close()
