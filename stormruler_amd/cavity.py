@@ -52,11 +52,17 @@ def gradient_weights(g: FaceGraph, axis: int, wall_value_zero: bool) -> Tuple[np
     return w_inner, w_outer, diag[: g.n_cells].copy()
 
 
-def lid_source(g: FaceGraph, lid_axis: int = 2, u_lid: float = 1.0) -> np.ndarray:
-    """Diffusive flux from the moving lid (the wall at max ``lid_axis``) into the tangential velocity:
-    ``(A_b / d_b) u_lid / V_i`` on lid cells (the Dirichlet ghost value of the lid faces)."""
+def lid_source(g: FaceGraph, lid_axis: int = 2, u_lid: float = 1.0, lid_coord: float = None) -> np.ndarray:
+    """Diffusive flux from the moving lid (the wall at ``lid_coord`` along ``lid_axis``; default: the
+    largest wall coordinate of ``g``) into the tangential velocity: ``(A_b / d_b) u_lid / V_i`` on lid
+    cells (the Dirichlet ghost value of the lid faces).  On a partitioned mesh pass the global
+    ``lid_coord``: only the ranks that own lid cells get a non-zero source."""
     _, b_coef = face_coefficients(g)
-    top = np.isclose(g.b_center[:, lid_axis], g.b_center[:, lid_axis].max())
+    if g.n_bfaces == 0:
+        return np.zeros(g.n_cells)
+    if lid_coord is None:
+        lid_coord = g.b_center[:, lid_axis].max()
+    top = np.isclose(g.b_center[:, lid_axis], lid_coord)
     s = np.zeros(g.n_cells)
     np.add.at(s, g.b_cell[top], b_coef[top] * u_lid / g.volume[g.b_cell[top]])
     return s
@@ -73,36 +79,44 @@ class CavityOperators:
     lid: np.ndarray
 
 
-def build_cavity_operators(n: int) -> CavityOperators:
-    g = structured_box(n)
+def build_cavity_operators(n: int, graph: FaceGraph = None, lid_coord: float = 1.0) -> CavityOperators:
+    """Operators of the unit-cube cavity; ``graph`` = a rank's local face graph of that cube (owned +
+    halo cells, e.g. from ``partition.slab_partition``/``partition_graph``) for a partitioned run."""
+    g = structured_box(n) if graph is None else graph
     gn = FaceGraph(g.n_cells, g.dim, g.inner, g.outer, g.area, g.center, g.volume,
-                   b_center=np.zeros((0, g.dim)))
+                   b_center=np.zeros((0, g.dim)), n_halo=g.n_halo, global_id=g.global_id,
+                   halo_owner=g.halo_owner)
     grad = [gradient_weights(g, e, wall_value_zero=False) for e in range(3)]
     div = [gradient_weights(g, e, wall_value_zero=True) for e in range(3)]
-    return CavityOperators(g, gn, grad, div, lid_source(g))
+    return CavityOperators(g, gn, grad, div, lid_source(g, lid_coord=lid_coord))
 
 
 class CavityProjection:
     """Device-resident projection stepper.  ``step()`` returns (cg_iterations, seconds)."""
 
-    def __init__(self, ctx, n: int, nu: float = 0.01, dt: float = None):
+    def __init__(self, ctx, n: int, nu: float = 0.01, dt: float = None, graph: FaceGraph = None, plan=None):
+        """``graph``/``plan``: this rank's local face graph and halo plan (``stormruler_amd.partition``)
+        for a row-partitioned run (config 5 is 4 GPUs); ``ctx`` must then carry a communicator."""
         from . import api
 
         self.api, self.ctx, self.n, self.nu = api, ctx, n, nu
         h = 1.0 / n
         self.dt = dt if dt is not None else 0.2 * min(h, h * h / (6.0 * nu))
-        ops = build_cavity_operators(n)
+        ops = build_cavity_operators(n, graph)
         self.ops = ops
         g = ops.g
         N = g.n_cells
         self.N = N
         self.L_D = api.StencilMatrix.from_face_graph(ctx, g)
         self.L_N = api.StencilMatrix.from_face_graph(ctx, ops.g_neumann)
-        mk = lambda w: api.StencilMatrix.from_face_weights(ctx, N, 0, g.inner, g.outer, *w)  # noqa: E731
+        mk = lambda w: api.StencilMatrix.from_face_weights(ctx, N, g.n_halo, g.inner, g.outer, *w)  # noqa: E731
         self.G = [mk(w) for w in ops.grad]
         self.D = [mk(w) for w in ops.div]
-        self.lid = api.DeviceVector.from_numpy(ctx, ops.lid)
-        vec = lambda: api.DeviceVector(ctx, N)  # noqa: E731
+        if plan is not None and plan.n_nbrs:
+            for m in [self.L_D, self.L_N, *self.G, *self.D]:
+                m.set_halo(plan.nbr_rank, plan.send_ptr, plan.send_idx, plan.recv_ptr)
+        self.lid = api.DeviceVector.from_numpy(ctx, ops.lid, n_halo=g.n_halo)
+        vec = lambda: api.DeviceVector(ctx, N, g.n_halo)  # noqa: E731
         self.u = [vec() for _ in range(3)]
         self.us = [vec() for _ in range(3)]
         self.p, self.rhs, self.t1, self.t2 = vec(), vec(), vec(), vec()
