@@ -98,6 +98,7 @@ struct storm_hip_ctx {
   int64_t opt_nt = 1;
   int64_t opt_profile_spmv = 0;
   int64_t opt_blas1_nt = 1;  // non-temporal loads/stores in the streaming kernels
+  int64_t opt_graph = 0;     // replay CG / BiCGStab iterations from a captured hipGraph: measured slower than eager launches (profiles/r01_notes.md), off
   int64_t opt_fuse_dot = 1;  // 0: reductions after an SpMV run as separate kernels (A/B knob)
   std::vector<hipEvent_t> prof_events;  // pairs (start, stop), grown on demand
   size_t prof_used = 0;

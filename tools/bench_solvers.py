@@ -31,8 +31,12 @@ def timed(ctx, make_solver, x_factory, b, op, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--which", default="cg64,cg128,cg256,bicgstab256,gmres128cd,gmres128cd_cgs2")
+    ap.add_argument("--opt", action="append", default=[])
     args = ap.parse_args()
     ctx = api.Context(0)
+    for kv in args.opt:
+        k_, v_ = kv.split("=")
+        ctx.set_option(k_, int(v_))
     cache = {}
 
     def poisson(n):
