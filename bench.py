@@ -42,6 +42,8 @@ def main() -> int:
     ap.add_argument("--variant", type=int, default=-1, help="SpMV kernel variant override")
     ap.add_argument("--nontemporal", type=int, default=-1)
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (repeatable)")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="take the multi-rank code path (process group, RCCL communicator, all-reduces) even at N = 1")
     args = ap.parse_args()
 
     import numpy as np
@@ -60,12 +62,14 @@ def main() -> int:
         print("bench.py needs an MI355X; the HIP path has no CPU fallback", file=sys.stderr)
         return 3
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_comm:
+        os.environ.setdefault("RANK", "0"), os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"), os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl")
 
     n, K, W = args.n, args.steps, args.warmup
     t_setup = time.time()
-    if world == 1:
+    if world == 1 and not args.force_comm:
         g = mesh.structured_box(n)
         plan = None
     else:
@@ -83,7 +87,10 @@ def main() -> int:
     for kv in args.opt:
         k_, v_ = kv.split("=")
         ctx.set_option(k_, int(v_))
-    dist.connect(ctx)
+    if args.force_comm and world == 1:
+        ctx.comm_init(api.Context.comm_unique_id(), 1, 0)
+    else:
+        dist.connect(ctx)
     mat = api.StencilMatrix.from_face_graph(ctx, g)
     if plan is not None and plan.n_nbrs:
         mat.set_halo(plan.nbr_rank, plan.send_ptr, plan.send_idx, plan.recv_ptr)
@@ -200,8 +207,17 @@ def main() -> int:
             "device": ctx.info()["name"],
             "setup_seconds": t_setup,
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     dist.barrier()
+    try:  # leave no dangling process group / communicator behind
+        mat.close()
+        ctx.close()
+        import torch.distributed as td
+
+        if td.is_available() and td.is_initialized():
+            td.destroy_process_group()
+    except Exception:
+        pass
     return 0
 
 
