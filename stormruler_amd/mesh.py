@@ -313,10 +313,25 @@ def tile_ordering(nx: int, ny: int, nz: int, ty: int = 16, tz: int = 16) -> np.n
 
 
 def rcm_ordering(g: FaceGraph) -> np.ndarray:
-    """Reverse Cuthill-McKee on the owned-cell graph (bandwidth reduction for gathers)."""
+    """Reverse Cuthill-McKee on the owned-cell graph (bandwidth reduction for gathers).
+
+    Small graphs use the build's own BFS below; past 200k cells the same algorithm from
+    ``scipy.sparse.csgraph`` (compiled) is used when scipy is importable -- host preprocessing in the
+    role METIS plays in the north star (METIS itself is not in this image)."""
     n = g.n_cells
-    # BFS from a minimum-degree vertex of each component, neighbours by increasing degree.
     m = (g.inner < n) & (g.outer < n)
+    if n > 200_000:
+        try:
+            import scipy.sparse as sp
+            from scipy.sparse.csgraph import reverse_cuthill_mckee
+
+            i, o = g.inner[m], g.outer[m]
+            adj = sp.coo_matrix((np.ones(2 * i.size, np.int8), (np.concatenate([i, o]), np.concatenate([o, i]))),
+                                shape=(n, n)).tocsr()
+            return reverse_cuthill_mckee(adj, symmetric_mode=True).astype(np.int64)
+        except ImportError:  # pragma: no cover
+            pass
+    # BFS from a minimum-degree vertex of each component, neighbours by increasing degree.
     a = np.concatenate([g.inner[m], g.outer[m]])
     b = np.concatenate([g.outer[m], g.inner[m]])
     order = np.argsort(a, kind="stable")
