@@ -273,43 +273,48 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, SolverStat
   if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
-// x += a u; r -= a w; optionally partials of <r,r> and <rt,r>.
-// BiCGStab :140-141 (a = alpha, u = p, w = v) and :161-162 (a = omega, u = r_old, w = t).
+// The two half-steps of a BiCGStab iteration (SolverBiCgStab.hpp:140-141 and :161-164).
+//   FIRST : r -= alpha v.  The reference's  x += alpha p  is deferred: nothing reads x before the
+//           second half-step, and doing it there saves one read + write of x per iteration.
+//   SECOND: x = (x + alpha p) + omega r  (the same two roundings, in the reference's order),
+//           r -= omega t, partials of <r,r> and <rt,r>.
 template <bool SECOND>
 __global__ __launch_bounds__(kBlock) void bicg_update_kernel(int64_t n, SolverState *st, double *__restrict__ x,
-                                                             double *__restrict__ r, const double *__restrict__ u,
+                                                             double *__restrict__ r, const double *__restrict__ p,
                                                              const double *__restrict__ w,
                                                              const double *__restrict__ rt,
                                                              double *__restrict__ partials, int nt) {
   if (st->done) return;
   __shared__ double lds4[4];
-  const double a = SECOND ? st->s[S_OMEGA] : st->s[S_ALPHA];
+  const double alpha = st->s[S_ALPHA], omega = st->s[S_OMEGA];
   double acc_rr = 0.0, acc_rho = 0.0;
   const int64_t n2 = n >> 1;
   double2v *x2 = reinterpret_cast<double2v *>(x), *r2 = reinterpret_cast<double2v *>(r);
-  const double2v *u2 = reinterpret_cast<const double2v *>(u), *w2 = reinterpret_cast<const double2v *>(w);
+  const double2v *p2 = reinterpret_cast<const double2v *>(p), *w2 = reinterpret_cast<const double2v *>(w);
   const double2v *rt2 = reinterpret_cast<const double2v *>(rt);
   STORM_STREAM_FOR(base, n2) {
-    double2v vx[kUnroll], vr[kUnroll], vw[kUnroll], vu[kUnroll], vt[kUnroll];
+    double2v vx[kUnroll], vr[kUnroll], vw[kUnroll], vp[kUnroll], vt[kUnroll];
 #pragma unroll
     for (int q = 0; q < kUnroll; ++q) {
       const int64_t i = base + q * kBlock;
       if (i < n2) {
-        vx[q] = ldv(x2 + i, nt), vr[q] = ldv(r2 + i, nt), vw[q] = ldv(w2 + i, nt);
-        if (!SECOND) vu[q] = ldv(u2 + i, nt);
-        if (SECOND) vt[q] = ldv(rt2 + i, nt);
+        vr[q] = ldv(r2 + i, nt), vw[q] = ldv(w2 + i, nt);
+        if (SECOND) vx[q] = ldv(x2 + i, nt), vp[q] = ldv(p2 + i, nt), vt[q] = ldv(rt2 + i, nt);
       }
     }
 #pragma unroll
     for (int q = 0; q < kUnroll; ++q) {
       const int64_t i = base + q * kBlock;
       if (i < n2) {
-        const double2v uu = SECOND ? vr[q] : vu[q];  // second half-step adds omega * (old) r
-        vx[q] += a * uu;
-        vr[q] -= a * vw[q];
-        stv(x2 + i, vx[q], nt);
-        stv(r2 + i, vr[q], nt);
-        if (SECOND) {
+        if (!SECOND) {
+          vr[q] -= alpha * vw[q];
+          stv(r2 + i, vr[q], nt);
+        } else {
+          vx[q] += alpha * vp[q];
+          vx[q] += omega * vr[q];
+          vr[q] -= omega * vw[q];
+          stv(x2 + i, vx[q], nt);
+          stv(r2 + i, vr[q], nt);
           acc_rr += vr[q].x * vr[q].x;
           acc_rr += vr[q].y * vr[q].y;
           acc_rho += vt[q].x * vr[q].x;
@@ -320,11 +325,13 @@ __global__ __launch_bounds__(kBlock) void bicg_update_kernel(int64_t n, SolverSt
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const int64_t i = n - 1;
-    const double ui = SECOND ? r[i] : u[i];
-    x[i] += a * ui;
-    const double vr = r[i] - a * w[i];
-    r[i] = vr;
-    if (SECOND) {
+    if (!SECOND) {
+      r[i] -= alpha * w[i];
+    } else {
+      double vx = x[i] + alpha * p[i];
+      vx += omega * r[i];
+      const double vr = r[i] - omega * w[i];
+      x[i] = vx, r[i] = vr;
       acc_rr += vr * vr;
       acc_rho += rt[i] * vr;
     }
@@ -726,7 +733,7 @@ int storm_hip_solve_bicgstab(const storm_hip_op *op, double alpha, double beta, 
       const int slots[1] = {S_RTV};
       STORM_TRY(d.finish(nb, 1, slots, STEP_BICG_ALPHA));
     }
-    // x += alpha p; r -= alpha v                      :140-141
+    // r -= alpha v   (x += alpha p is applied in the second half-step)      :140-141
     hipLaunchKernelGGL(bicg_update_kernel<false>, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, x->d, r, p, v,
                        rt, c->d_partials, (int)(c->opt_blas1_nt != 0));
     HIP_TRY(hipGetLastError());
@@ -742,9 +749,9 @@ int storm_hip_solve_bicgstab(const storm_hip_op *op, double alpha, double beta, 
       const int slots[2] = {S_TR, S_TT};
       STORM_TRY(d.finish(nb, 2, slots, STEP_BICG_OMEGA));
     }
-    // x += omega r; r -= omega t; |r|, <rt,r>         :161-164 (+ :116 of the next iteration)
+    // x = (x + alpha p) + omega r; r -= omega t; |r|, <rt,r>    :140, :161-164 (+ :116 of the next iteration)
     hipLaunchKernelGGL(bicg_update_kernel<true>, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, x->d, r,
-                       (const double *)nullptr, t, rt, c->d_partials, (int)(c->opt_blas1_nt != 0));
+                       p, t, rt, c->d_partials, (int)(c->opt_blas1_nt != 0));
     HIP_TRY(hipGetLastError());
     {
       const int slots[2] = {S_RR, S_RHO_NEW};
