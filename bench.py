@@ -42,6 +42,7 @@ def main() -> int:
     ap.add_argument("--variant", type=int, default=-1, help="SpMV kernel variant override")
     ap.add_argument("--nontemporal", type=int, default=-1)
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (repeatable)")
+    ap.add_argument("--spinup-seconds", type=float, default=1.5, help="untimed device spin-up before the warmup steps")
     ap.add_argument("--force-comm", action="store_true",
                     help="take the multi-rank code path (process group, RCCL communicator, all-reduces) even at N = 1")
     args = ap.parse_args()
@@ -111,6 +112,13 @@ def main() -> int:
         assert s.iteration == iters, (s.iteration, iters)
         return s, x
 
+    # Device spin-up (untimed, before the W warmup steps): the first process on an idle MI355X runs
+    # ~20 % slow for its first several hundred milliseconds (clocks / memory power state); 10 ms of
+    # warmup steps do not cover that.  Same work as the timed region, nothing is cached from it.
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < args.spinup_seconds:
+        run(100)
+        ctx.sync()
     if W > 0:
         run(W)
     ctx.sync()

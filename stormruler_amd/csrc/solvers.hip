@@ -230,32 +230,36 @@ __global__ __launch_bounds__(kBlock) void init_residual_kernel(int64_t n, double
   if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
-// x += alpha p; r -= alpha z; partial <r,r>        SolverCg.hpp:97-99,115
-__global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, SolverState *st, double *__restrict__ x,
-                                                           double *__restrict__ r, const double *__restrict__ p,
-                                                           const double *__restrict__ z,
-                                                           double *__restrict__ partials, int nt) {
+// CG iteration, vector part, in two kernels around the <r,r> reduction (SolverCg.hpp:97-123):
+//   cg_r_kernel : alpha = safe_divide(gamma, <p,z>);  r -= alpha z;  partial <r,r>
+//   cg_xp_kernel: x += alpha p;  p = r + beta p
+// The reference's `x += alpha p` (:98) is moved behind the reduction next to the p update, where p
+// is read anyway: same values, 64N instead of 72N bytes per iteration.  cg_xp must apply the x
+// update of the iteration in which the solver converged (p no longer matters then), so it is
+// keyed on the iteration counter, not on `done`.
+__global__ __launch_bounds__(kBlock) void cg_r_kernel(int64_t n, SolverState *st, double *__restrict__ r,
+                                                      const double *__restrict__ z,
+                                                      double *__restrict__ partials, int nt) {
   if (st->done) return;
   __shared__ double lds4[4];
   const double alpha = safe_divide(st->s[S_GAMMA], st->s[S_PZ]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) st->s[S_ALPHA] = alpha;  // for cg_xp_kernel of this iteration
   double acc = 0.0;
   const int64_t n2 = n >> 1;
-  double2v *x2 = reinterpret_cast<double2v *>(x), *r2 = reinterpret_cast<double2v *>(r);
-  const double2v *p2 = reinterpret_cast<const double2v *>(p), *z2 = reinterpret_cast<const double2v *>(z);
+  double2v *r2 = reinterpret_cast<double2v *>(r);
+  const double2v *z2 = reinterpret_cast<const double2v *>(z);
   STORM_STREAM_FOR(base, n2) {
-    double2v vx[kUnroll], vr[kUnroll], vp[kUnroll], vz[kUnroll];
+    double2v vr[kUnroll], vz[kUnroll];
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       const int64_t i = base + u * kBlock;
-      if (i < n2) vx[u] = ldv(x2 + i, nt), vr[u] = ldv(r2 + i, nt), vp[u] = ldv(p2 + i, nt), vz[u] = ldv(z2 + i, nt);
+      if (i < n2) vr[u] = ldv(r2 + i, nt), vz[u] = ldv(z2 + i, nt);
     }
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       const int64_t i = base + u * kBlock;
       if (i < n2) {
-        vx[u] += alpha * vp[u];
         vr[u] -= alpha * vz[u];
-        stv(x2 + i, vx[u], nt);
         stv(r2 + i, vr[u], nt);
         acc += vr[u].x * vr[u].x;
         acc += vr[u].y * vr[u].y;
@@ -263,14 +267,48 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, SolverStat
     }
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-    const int64_t i = n - 1;
-    x[i] += alpha * p[i];
-    const double vr = r[i] - alpha * z[i];
-    r[i] = vr;
+    const double vr = r[n - 1] - alpha * z[n - 1];
+    r[n - 1] = vr;
     acc += vr * vr;
   }
   const double s = block_sum256(acc, lds4);
   if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(kBlock) void cg_xp_kernel(int64_t n, const SolverState *st, long long my_iteration,
+                                                       double *__restrict__ x, double *__restrict__ p,
+                                                       const double *__restrict__ r, int nt) {
+  if (st->iteration < my_iteration) return;  // enqueued past convergence: this iteration never ran
+  const bool update_p = !st->done;
+  const double alpha = st->s[S_ALPHA], beta = st->s[S_BETA];
+  const int64_t n2 = n >> 1;
+  double2v *x2 = reinterpret_cast<double2v *>(x), *p2 = reinterpret_cast<double2v *>(p);
+  const double2v *r2 = reinterpret_cast<const double2v *>(r);
+  STORM_STREAM_FOR(base, n2) {
+    double2v vx[kUnroll], vp[kUnroll], vr[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t i = base + u * kBlock;
+      if (i < n2) {
+        vx[u] = ldv(x2 + i, nt), vp[u] = ldv(p2 + i, nt);
+        if (update_p) vr[u] = ldv(r2 + i, nt);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t i = base + u * kBlock;
+      if (i < n2) {
+        vx[u] += alpha * vp[u];
+        stv(x2 + i, vx[u], nt);
+        if (update_p) stv(p2 + i, vr[u] + beta * vp[u], nt);
+      }
+    }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    x[i] += alpha * p[i];
+    if (update_p) p[i] = r[i] + beta * p[i];
+  }
 }
 
 // The two half-steps of a BiCGStab iteration (SolverBiCgStab.hpp:140-141 and :161-164).
@@ -661,7 +699,8 @@ int storm_hip_solve_cg(const storm_hip_op *op, double alpha, double beta, const 
     const int slots[1] = {S_GAMMA};
     STORM_TRY(d.finish(nbv, 1, slots, STEP_CG_INIT, true));
   }
-  // One iteration's launches (all arguments are iteration-invariant: the scalars live in the slab).
+  // One iteration's launches (the scalars live in the slab; only the iteration index varies).
+  int64_t cur_it = 0;
   auto enqueue_iteration = [&]() -> int {
     // z = A p, <p,z>                                  SolverCg.hpp:96-97
     STORM_TRY(d.apply(p, z, p, false, &nb));
@@ -673,21 +712,23 @@ int storm_hip_solve_cg(const storm_hip_op *op, double alpha, double beta, const 
       const int slots[1] = {S_PZ};
       STORM_TRY(d.finish(nb, 1, slots, STEP_NONE));
     }
-    // x += alpha p; r -= alpha z; gamma = <r,r>       SolverCg.hpp:98-99,115
-    hipLaunchKernelGGL(cg_update_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, x->d, r, p, z,
-                       c->d_partials, (int)(c->opt_blas1_nt != 0));
+    // r -= alpha z; gamma = <r,r>                     SolverCg.hpp:97,99,115
+    hipLaunchKernelGGL(cg_r_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, r, z, c->d_partials,
+                       (int)(c->opt_blas1_nt != 0));
     HIP_TRY(hipGetLastError());
     {
       const int slots[1] = {S_GAMMA_NEW};
       STORM_TRY(d.finish(nbv, 1, slots, STEP_CG_RR));
     }
-    // p = r + beta p                                  SolverCg.hpp:123
-    return k_axpbz(c, p, host_scal(1.0), r, dev_scal(d.slot(S_BETA)), p, n, d.done);
+    // x += alpha p; p = r + beta p                    SolverCg.hpp:98,123
+    hipLaunchKernelGGL(cg_xp_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, (long long)(cur_it + 1), x->d,
+                       p, r, (int)(c->opt_blas1_nt != 0));
+    HIP_TRY(hipGetLastError());
+    return STORM_HIP_OK;
   };
-  IterationGraph graph;
-  STORM_TRY(graph.capture(c, params->num_iterations, enqueue_iteration));
   for (int64_t it = 0; it < params->num_iterations; ++it) {
-    STORM_TRY(graph.launch_or(c, enqueue_iteration));
+    cur_it = it;
+    STORM_TRY(enqueue_iteration());
     bool stop = false;
     STORM_TRY(post_and_poll(d, it, &stop));
     if (stop) break;
