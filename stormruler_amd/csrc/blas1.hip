@@ -243,6 +243,7 @@ __global__ __launch_bounds__(kBlock) void reduce_final_kernel(const double *__re
   __shared__ double lds4[4];
   const double *p = partials + (int64_t)blockIdx.x * nblocks;
   double v = 0.0;
+#pragma unroll 8
   for (int i = threadIdx.x; i < nblocks; i += kBlock) v += p[i];
   const double s = block_sum(v, lds4);
   if (threadIdx.x == 0) out[blockIdx.x] = s;
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(kBlock) void reduce_stage1_plain_kernel(const doubl
 
 int k_reduce_final(storm_hip_ctx *c, const double *partials, int nblocks, int k, double *d_out,
                    const int *done) {
-  if (nblocks > 4096) {
+  if (nblocks > 8192) {
     hipLaunchKernelGGL(reduce_stage1_plain_kernel, dim3(kStage2, k), dim3(kBlock), 0, c->stream, partials,
                        nblocks, c->d_partials2, done);
     HIP_TRY(hipGetLastError());

@@ -147,6 +147,7 @@ __global__ __launch_bounds__(kBlock) void reduce_step_kernel(const double *__res
   for (int j = 0; j < k; ++j) {
     const double *p = partials + (int64_t)j * nblocks;
     double v = 0.0;
+#pragma unroll 8
     for (int i = threadIdx.x; i < nblocks; i += kBlock) v += p[i];
     const double sum = block_sum256(v, lds4);
     if (threadIdx.x == 0) *out.p[j] = sum;
@@ -494,7 +495,7 @@ struct Driver {
   }
   int finish_ptrs(int nblocks, int k, OutSlots out, double *contiguous, int step, bool force = false) {
     const double *partials = c->d_partials;
-    if (nblocks > 4096) {
+    if (nblocks > 8192) {
       hipLaunchKernelGGL(reduce_stage1_kernel, dim3(kStage2, k), dim3(kBlock), 0, c->stream, c->d_partials,
                          nblocks, c->d_partials2, st, force);
       HIP_TRY(hipGetLastError());

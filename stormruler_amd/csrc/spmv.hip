@@ -99,7 +99,6 @@ __device__ __forceinline__ double wave_sum_to_lane63(double v) {
   return v;
 }
 
-constexpr int kChunk = 8;  // slots whose (col, val) loads are issued before the first gather
 
 // x[c], or the block's LDS copy of it when VARIANT == 1 and c lies in the block's own 256 rows.
 template <int VARIANT>
