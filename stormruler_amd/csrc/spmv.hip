@@ -23,6 +23,8 @@
 #include <cstring>
 #include <numeric>
 
+#include <hip/hip_ext.h>
+
 #include "common.hpp"
 
 namespace storm {
@@ -292,22 +294,23 @@ __global__ __launch_bounds__(kBlock) void spmv_tail_kernel(int64_t n_tail, const
 
 template <bool NT, bool DOT, int VARIANT>
 static void launch_sell(const storm_hip_op *op, int nb, Scal alpha, Scal beta, const double *x, double *y,
-                        const int *slice_list, int64_t n_launch, DotArgs dot, const int *done) {
+                        const int *slice_list, int64_t n_launch, DotArgs dot, const int *done, hipEvent_t ev0,
+                        hipEvent_t ev1) {
   SellArgs A{op->d_pack, op->d_slice_off, op->n_rows, op->uniform_width, (int)op->ctx->opt_spmv_xcd_remap};
   hipStream_t st = op->ctx->stream;
   if (slice_list == nullptr && op->ctx->opt_spmv_xcd_remap != 0) {
-    hipLaunchKernelGGL((spmv_sell_kernel<NT, DOT, VARIANT, true>), dim3(nb), dim3(kBlock), 0, st, A, alpha,
+    hipExtLaunchKernelGGL((spmv_sell_kernel<NT, DOT, VARIANT, true>), dim3(nb), dim3(kBlock), 0, st, ev0, ev1, 0, A, alpha,
                        beta, x, y, slice_list, n_launch, dot, done);
   } else if (slice_list == nullptr) {
-    hipLaunchKernelGGL((spmv_sell_kernel<NT, DOT, VARIANT, false>), dim3(nb), dim3(kBlock), 0, st, A, alpha,
+    hipExtLaunchKernelGGL((spmv_sell_kernel<NT, DOT, VARIANT, false>), dim3(nb), dim3(kBlock), 0, st, ev0, ev1, 0, A, alpha,
                        beta, x, y, slice_list, n_launch, dot, done);
   } else if (op->ctx->opt_spmv_xcd_remap != 0) {
     // listed slices (interior / boundary sets of a partitioned operator): the LDS window does not
     // apply, the XCD grouping still does -- the interior list is consecutive but for a few gaps
-    hipLaunchKernelGGL((spmv_sell_kernel<NT, DOT, 0, true>), dim3(nb), dim3(kBlock), 0, st, A, alpha, beta,
+    hipExtLaunchKernelGGL((spmv_sell_kernel<NT, DOT, 0, true>), dim3(nb), dim3(kBlock), 0, st, ev0, ev1, 0, A, alpha, beta,
                        x, y, slice_list, n_launch, dot, done);
   } else {
-    hipLaunchKernelGGL((spmv_sell_kernel<NT, DOT, 0, false>), dim3(nb), dim3(kBlock), 0, st, A, alpha, beta,
+    hipExtLaunchKernelGGL((spmv_sell_kernel<NT, DOT, 0, false>), dim3(nb), dim3(kBlock), 0, st, ev0, ev1, 0, A, alpha, beta,
                        x, y, slice_list, n_launch, dot, done);
   }
 }
@@ -320,18 +323,21 @@ static int launch_range(const storm_hip_op *op, Scal alpha, Scal beta, const dou
   if (n_launch <= 0) return STORM_HIP_OK;
   storm_hip_ctx *c = op->ctx;
   const bool prof = c->opt_profile_spmv != 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (prof) {
     while (c->prof_events.size() < c->prof_used + 2) {
       hipEvent_t ev;
       HIP_TRY(hipEventCreate(&ev));
       c->prof_events.push_back(ev);
     }
-    HIP_TRY(hipEventRecord(c->prof_events[c->prof_used], c->stream));
+    // the events are attached to the kernel dispatch itself (hipExtLaunchKernelGGL): they are
+    // stamped at the kernel's begin and end, the quantity rocprofv3's kernel trace reports
+    ev0 = c->prof_events[c->prof_used], ev1 = c->prof_events[c->prof_used + 1];
   }
   const int nb = blocks_for(n_launch);
   const bool nt = c->opt_nt != 0;
 #define SPMV_GO(NT_, DOT_, VAR_) \
-  launch_sell<NT_, DOT_, VAR_>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done)
+  launch_sell<NT_, DOT_, VAR_>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1)
 #define SPMV_VAR(VAR_)                                                                      \
   do {                                                                                      \
     if (nt) { if (want_dot) SPMV_GO(true, true, VAR_); else SPMV_GO(true, false, VAR_); }   \
@@ -342,10 +348,7 @@ static int launch_range(const storm_hip_op *op, Scal alpha, Scal beta, const dou
 #undef SPMV_VAR
 #undef SPMV_GO
   HIP_TRY(hipGetLastError());
-  if (prof) {
-    HIP_TRY(hipEventRecord(c->prof_events[c->prof_used + 1], c->stream));
-    c->prof_used += 2;
-  }
+  if (prof) c->prof_used += 2;
   return STORM_HIP_OK;
 }
 
