@@ -37,7 +37,7 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--n", type=int, default=256, help="cells per edge of the per-GPU block")
-    ap.add_argument("--cpu-iters", type=int, default=12, help="CPU-baseline sample (CG iterations); 0 = skip")
+    ap.add_argument("--cpu-iters", type=int, default=20, help="CPU-baseline sample (CG iterations); 0 = skip")
     ap.add_argument("--ordering", default="natural", choices=["natural", "tile"])
     ap.add_argument("--variant", type=int, default=-1, help="SpMV kernel variant override")
     ap.add_argument("--nontemporal", type=int, default=-1)
