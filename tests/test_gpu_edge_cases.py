@@ -129,3 +129,32 @@ def test_vectors_of_two_contexts_do_not_mix(env):
     with pytest.raises(api._lib.StormHipError):
         a += 1.0 * b
     c2.close()
+
+
+def test_no_device_memory_leak():
+    """Create / solve / destroy in a loop: the device's free memory must come back (operators, work
+    vectors of the three native solvers, GMRES's Hessenberg buffers, history buffers, contexts)."""
+    import torch
+
+    from stormruler_amd import api, mesh
+
+    g = mesh.structured_box(40)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for rep in range(12):
+        ctx = api.Context(0)
+        mat = api.StencilMatrix.from_face_graph(ctx, g)
+        op = api.HipStencilOperator(mat, -1.0, 0.0)
+        b = api.DeviceVector.from_numpy(ctx, np.ones(g.n_cells))
+        for cls in (api.CgSolver, api.BiCgStabSolver, api.GmresSolver):
+            x = api.DeviceVector(ctx, g.n_cells)
+            s = cls()
+            s.record_history = True
+            assert s.solve(x, b, op)
+        ctx.close()  # frees every vector / operator created on it
+        if rep == 1:
+            torch.cuda.synchronize()
+            free1, _ = torch.cuda.mem_get_info()
+    torch.cuda.synchronize()
+    free2, _ = torch.cuda.mem_get_info()
+    assert abs(free2 - free1) < 64 << 20, (free0, free1, free2)
