@@ -15,7 +15,7 @@ import numpy as np
 
 from .mesh import FaceGraph, structured_box_slab
 
-__all__ = ["HaloPlan", "partition_graph", "halo_plan", "slab_partition", "slab_ranges"]
+__all__ = ["HaloPlan", "partition_graph", "halo_plan", "slab_partition", "slab_ranges", "rcb_partition"]
 
 
 @dataclass
@@ -101,3 +101,30 @@ def slab_partition(nx: int, ny: int, nz_per_rank: int, n_ranks: int, rank: int, 
     g = structured_box_slab(nx, ny, nz_glob, k0, k1, lengths, dirichlet,
                             rank_of_k=lambda k: k // nz_per_rank)
     return g, halo_plan(g, rank)
+
+
+def rcb_partition(center: np.ndarray, n_parts: int) -> np.ndarray:
+    """Recursive coordinate bisection of the cell centres into ``n_parts`` balanced parts.
+
+    The build's own k-way partitioner for general meshes (METIS is not available): split
+    the longest axis of the bounding box at the weighted median, recurse.  Part sizes differ by at most
+    one cell per level; works for any ``n_parts`` (the split is proportional, not only powers of two).
+    Returns the cell -> rank map for :func:`partition_graph`.
+    """
+    n = center.shape[0]
+    part = np.zeros(n, np.int64)
+
+    def split(idx: np.ndarray, first: int, count: int) -> None:
+        if count == 1:
+            part[idx] = first
+            return
+        left_parts = count // 2
+        pts = center[idx]
+        axis = int(np.argmax(pts.max(axis=0) - pts.min(axis=0)))
+        k = (idx.size * left_parts) // count
+        order = np.argsort(pts[:, axis], kind="stable")
+        split(idx[order[:k]], first, left_parts)
+        split(idx[order[k:]], first + left_parts, count - left_parts)
+
+    split(np.arange(n, dtype=np.int64), 0, int(n_parts))
+    return part

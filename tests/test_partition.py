@@ -74,3 +74,32 @@ def test_orderings_are_permutations():
     bw0 = np.abs(gs.inner - gs.outer).max()
     gr = mesh.permute_cells(gs, mesh.rcm_ordering(gs))
     assert np.abs(gr.inner - gr.outer).max() < bw0 / 2
+
+
+@pytest.mark.parametrize("n_parts", [2, 3, 5, 8])
+def test_rcb_partition_on_the_unstructured_reference_mesh(n_parts):
+    """General meshes: recursive coordinate bisection + the generic partitioner on the reference's own
+    Triangle mesh; balanced parts, pairing halo plans, partitioned apply == global apply."""
+    import os
+
+    from stormruler_amd import io_triangle
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = io_triangle.read_triangle(os.path.join(root, "tests", "golden", "mesh", "square_nb.1."))
+    part = partition.rcb_partition(g.center, n_parts)
+    sizes = np.bincount(part, minlength=n_parts)
+    assert sizes.sum() == g.n_cells and sizes.max() - sizes.min() <= n_parts
+    x = np.sin(3 * g.center[:, 0]) * np.cos(7 * g.center[:, 1])
+    y_glob = oracle.StencilOperator(g, -1e-2, 1.0).apply(x)
+    y = np.empty_like(x)
+    cut = 0
+    for r in range(n_parts):
+        loc = partition.partition_graph(g, part, r)
+        loc.validate()
+        plan = partition.halo_plan(loc, r)
+        assert plan.recv_ptr[-1] == loc.n_halo and np.all(plan.nbr_rank != r)
+        cut += loc.n_halo
+        yl = oracle.StencilOperator(loc, -1e-2, 1.0).apply(x[loc.global_id])
+        y[loc.global_id[: loc.n_cells]] = yl[: loc.n_cells]
+    assert np.abs(y - y_glob).max() <= 1e-13 * np.abs(y_glob).max()
+    assert cut < 0.25 * g.n_cells  # geometric cuts keep the halo small
