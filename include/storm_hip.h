@@ -118,6 +118,10 @@ int storm_hip_lin3(storm_hip_vec *y, const storm_hip_vec *r, double s, double a,
 /* y += s * (a .* b), elementwise.  Not in the solver census: the nonlinear term a time-step
  * driver forms between solves (cf. `f <<= map(dF_dc, c)`, Playground.cpp:148). */
 int storm_hip_vmul_add(storm_hip_vec *y, double s, const storm_hip_vec *a, const storm_hip_vec *b);
+/* y = a .* b, elementwise: `Preconditioner::mul` of a diagonal (Jacobi) preconditioner behind the
+ * pre_op hook of Solvers/Solver.hpp:74-75 (the reference ships only IdentityPreconditioner,
+ * Preconditioner.hpp:84-97).  y may alias a or b. */
+int storm_hip_vmul(storm_hip_vec *y, const storm_hip_vec *a, const storm_hip_vec *b);
 /* fill_randomly(y)  Bittern/MatrixAlgorithms.hpp:140-153: uniform [0, 1) numbers from a
  * function-static std::mt19937_64{} (default seed, state persists across calls), drawn
  * sequentially on the host in row order and uploaded -- the same engine, distribution and
@@ -191,6 +195,11 @@ int storm_hip_op_set_halo(storm_hip_op *op, int n_nbrs, const int32_t *nbr_rank,
  * Exchanges x's halo first when a halo plan is set.  x and y must not alias. */
 int storm_hip_op_apply(const storm_hip_op *op, double alpha, double beta, const storm_hip_vec *x,
                        storm_hip_vec *y);
+
+/* d_i = diagonal entry i of beta*I + alpha*M; with invert != 0 its safe inverse (0 -> 0,
+ * Crow/MathUtils.hpp:54-58).  What `Preconditioner::build(x, b, op)` (Preconditioner.hpp:70-72) of a
+ * Jacobi preconditioner needs from the operator. */
+int storm_hip_op_get_diagonal(const storm_hip_op *op, double alpha, double beta, int invert, storm_hip_vec *d);
 
 typedef struct storm_hip_op_stats {
   int64_t n_rows, n_cols, nnz_offdiag;  /* off-diagonal entries (2F for a face graph) */

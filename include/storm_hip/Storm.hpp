@@ -30,6 +30,7 @@
 #include <cmath>
 #include <cstddef>
 #include <functional>
+#include <limits>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -176,6 +177,13 @@ inline DeviceVector& operator<<=(DeviceVector& out, const expr::Lin3& e) {
   detail::check(storm_hip_lin3(out.handle(), e.r->handle(), e.s, e.e.a, e.e.x->handle(), e.e.b, e.e.z->handle()));
   return out;
 }
+inline DeviceVector& operator<<=(DeviceVector& out, const expr::ScaledLin2& e) {
+  // z <<= delta_inverse * (z - w)  (SolverNewton.hpp:148): the inner sum is rounded before the
+  // scaling, as the reference's expression tree evaluates it
+  detail::check(storm_hip_axpbz(out.handle(), e.e.a, e.e.x->handle(), e.e.b, e.e.z->handle()));
+  detail::check(storm_hip_scale(out.handle(), e.s));
+  return out;
+}
 
 inline DeviceVector& operator<<=(DeviceVector& out, const expr::Quot& e) {  // p <<= r / phi, SolverIdrs.hpp:131
   if (e.v != &out) detail::check(storm_hip_copy(out.handle(), e.v->handle()));
@@ -185,6 +193,11 @@ inline DeviceVector& operator<<=(DeviceVector& out, const expr::Quot& e) {  // p
 
 /// Bittern/MatrixAlgorithms.hpp:140-153: the reference's engine, distribution and sequence.
 inline void fill_randomly(DeviceVector& a) { detail::check(storm_hip_fill_randomly(a.handle())); }
+
+/// y = a .* b elementwise (a diagonal preconditioner's `mul`).
+inline void vmul(DeviceVector& y, const DeviceVector& a, const DeviceVector& b) {
+  detail::check(storm_hip_vmul(y.handle(), a.handle(), b.handle()));
+}
 
 /// Bittern/MatrixAlgorithms.hpp:310-317 (global sum over all ranks).
 inline real_t dot_product(const DeviceVector& a, const DeviceVector& b) {
@@ -353,6 +366,26 @@ template<class Vector>
 class IdentityPreconditioner final : public Preconditioner<Vector> {
   void mul(Vector& y_vec, const Vector& x_vec) const override { y_vec <<= x_vec; }
   void conj_mul(Vector& x_vec, const Vector& y_vec) const override { x_vec <<= y_vec; }
+};
+
+/// Diagonal preconditioner P = diag(A)^-1 of a HipStencilOperator, entirely on the device: the
+/// build's own addition behind the reference's pre_op hook (Solver.hpp:74-75).  `build`
+/// (Preconditioner.hpp:70-72) reads the diagonal of the operator it is given.
+class JacobiPreconditioner final : public Preconditioner<DeviceVector> {
+public:
+  void build(const DeviceVector& x_vec, const DeviceVector& /*b_vec*/,
+             const Operator<DeviceVector>& any_op) override {
+    const auto* hip_op = dynamic_cast<const HipStencilOperator*>(&any_op);
+    if (hip_op == nullptr) throw std::runtime_error("JacobiPreconditioner needs a HipStencilOperator");
+    _dinv.assign(x_vec, false);
+    detail::check(storm_hip_op_get_diagonal(hip_op->matrix().handle(), hip_op->alpha(), hip_op->beta(), 1,
+                                            _dinv.handle()));
+  }
+  void mul(DeviceVector& y_vec, const DeviceVector& x_vec) const override { vmul(y_vec, _dinv, x_vec); }
+  void conj_mul(DeviceVector& x_vec, const DeviceVector& y_vec) const override { vmul(x_vec, _dinv, y_vec); }
+
+private:
+  DeviceVector _dinv;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -941,16 +974,17 @@ public:
   IdrsSolver() { this->num_inner_iterations = 4; }
 };
 
-/// GMRES(m) (SolverGmres.hpp:41-255, non-flexible).  The host-statement path implements the
-/// unpreconditioned and left/right preconditioned variants over dense host arrays for H, beta,
-/// cs, sn (the reference's DenseMatrix helpers, Solvers/MatrixDense.hpp:43-170, are replaced by
-/// std::vector here).
-template<class Vector>
-class GmresSolver final : public InnerOuterIterativeSolver<Vector> {
+/// GMRES(m) / FGMRES(m) (SolverGmres.hpp:41-255, `BaseGmresSolver<Vector, Flexible>`).  The
+/// host-statement path implements the unpreconditioned, left/right preconditioned and flexible
+/// (always right, :98-99; one z vector per inner iteration) variants over dense host arrays for H,
+/// beta, cs, sn (the reference's DenseMatrix helpers, Solvers/MatrixDense.hpp:43-170, are replaced
+/// by std::vector here).
+template<class Vector, bool Flexible>
+class BaseGmresSolver : public InnerOuterIterativeSolver<Vector> {
 private:
   std::vector<real_t> _beta, _cs, _sn, _H;  // H is (m+1) x m, row-major
   std::vector<Vector> _q_vecs;
-  std::array<Vector, 1> _z_vecs;
+  std::vector<Vector> _z_vecs;              // m if Flexible, else 1 (SolverGmres.hpp:48-49)
 
   real_t& H(std::size_t i, std::size_t j) { return _H[i * this->num_inner_iterations + j]; }
 
@@ -958,7 +992,7 @@ private:
 
   void start(const Vector& x_vec, const Vector& b_vec, const Operator<Vector>& lin_op,
              const Preconditioner<Vector>* pre_op) {
-    const bool left_pre = (pre_op != nullptr) && (this->pre_side == PreconditionerSide::Left);
+    const bool left_pre = (pre_op != nullptr) && (!Flexible) && (this->pre_side == PreconditionerSide::Left);
     lin_op.Residual(_q_vecs[0], b_vec, x_vec);
     if (left_pre) {
       std::swap(_z_vecs[0], _q_vecs[0]);
@@ -977,7 +1011,11 @@ private:
     _q_vecs.clear();
     _q_vecs.resize(m + 1);
     for (Vector& q_vec : _q_vecs) q_vec.assign(x_vec, false);
-    if (pre_op != nullptr) _z_vecs[0].assign(x_vec, false);
+    _z_vecs.clear();
+    if (pre_op != nullptr) {
+      _z_vecs.resize(Flexible ? m : 1);
+      for (Vector& z_vec : _z_vecs) z_vec.assign(x_vec, false);
+    }
     start(x_vec, b_vec, lin_op, pre_op);
     return _beta[0];
   }
@@ -990,10 +1028,10 @@ private:
   real_t inner_iterate(Vector& /*x_vec*/, const Vector& /*b_vec*/, const Operator<Vector>& lin_op,
                        const Preconditioner<Vector>* pre_op) override {
     const std::size_t k = this->inner_iteration;
-    const bool left_pre = (pre_op != nullptr) && (this->pre_side == PreconditionerSide::Left);
-    const bool right_pre = (pre_op != nullptr) && (this->pre_side == PreconditionerSide::Right);
+    const bool left_pre = (pre_op != nullptr) && (!Flexible && (this->pre_side == PreconditionerSide::Left));
+    const bool right_pre = (pre_op != nullptr) && (Flexible || (this->pre_side == PreconditionerSide::Right));
     if (left_pre) pre_op->mul(_q_vecs[k + 1], _z_vecs[0], lin_op, _q_vecs[k]);
-    else if (right_pre) lin_op.mul(_q_vecs[k + 1], _z_vecs[0], *pre_op, _q_vecs[k]);
+    else if (right_pre) lin_op.mul(_q_vecs[k + 1], _z_vecs[Flexible ? k : 0], *pre_op, _q_vecs[k]);
     else lin_op.mul(_q_vecs[k + 1], _q_vecs[k]);
     for (std::size_t i = 0; i <= k; ++i) {  // modified Gram-Schmidt
       H(i, k) = dot_product(_q_vecs[k + 1], _q_vecs[i]);
@@ -1018,13 +1056,15 @@ private:
   void inner_finalize(Vector& x_vec, const Vector& /*b_vec*/, const Operator<Vector>& /*lin_op*/,
                       const Preconditioner<Vector>* pre_op) override {
     const std::size_t k = this->inner_iteration;
-    const bool right_pre = (pre_op != nullptr) && (this->pre_side == PreconditionerSide::Right);
+    const bool right_pre = (pre_op != nullptr) && (Flexible || (this->pre_side == PreconditionerSide::Right));
     for (std::size_t i = k; i != SIZE_MAX; --i) {  // back substitution
       for (std::size_t j = i + 1; j <= k; ++j) _beta[i] -= H(i, j) * _beta[j];
       _beta[i] /= H(i, i);
     }
     if (!right_pre) {
       for (std::size_t i = 0; i <= k; ++i) x_vec += _beta[i] * _q_vecs[i];
+    } else if constexpr (Flexible) {
+      for (std::size_t i = 0; i <= k; ++i) x_vec += _beta[i] * _z_vecs[i];
     } else {
       _q_vecs[0] *= _beta[0];
       for (std::size_t i = 1; i <= k; ++i) _q_vecs[0] += _beta[i] * _q_vecs[i];
@@ -1032,6 +1072,79 @@ private:
       x_vec += _z_vecs[0];
     }
   }
+
+protected:
+  BaseGmresSolver() = default;
+};
+
+/// SolverGmres.hpp:281-283.
+template<class Vector>
+class GmresSolver final : public BaseGmresSolver<Vector, false> {};
+
+/// SolverGmres.hpp:306-308: keeps every preconditioned vector so the preconditioner may vary between
+/// iterations; without a preconditioner it is GMRES (and runs natively).
+template<class Vector>
+class FgmresSolver final : public BaseGmresSolver<Vector, true> {};
+
+/// SolverNewton.hpp:55-72: declared but unimplemented in the reference (STORM_ABORT); here the same
+/// message arrives as an exception instead of std::abort().
+template<class Vector>
+class NewtonSolver : public IterativeSolver<Vector> {
+  real_t init(const Vector&, const Vector&, const Operator<Vector>&, const Preconditioner<Vector>*) final {
+    throw std::runtime_error("Newton solver is not implemented yet!");
+  }
+  real_t iterate(Vector&, const Vector&, const Operator<Vector>&, const Preconditioner<Vector>*) final {
+    throw std::runtime_error("Newton solver is not implemented yet!");
+  }
+};
+
+/// SolverNewton.hpp:101-173: first-order Jacobian-free Newton-Krylov; `any_op` may be nonlinear.
+/// Each iteration solves J(x) t = r with a BiCGStab (1e-8 tolerances, :133-135) on the
+/// finite-difference Jacobian-vector product (A(x + delta y) - A(x)) / delta (:136-148).
+template<class Vector>
+class JfnkSolver final : public IterativeSolver<Vector> {
+private:
+  Vector _s_vec, _t_vec, _r_vec, _w_vec;
+
+  real_t init(const Vector& x_vec, const Vector& b_vec, const Operator<Vector>& any_op,
+              const Preconditioner<Vector>* /*pre_op*/) override {
+    _s_vec.assign(x_vec, false);
+    _t_vec.assign(x_vec, false);
+    _r_vec.assign(x_vec, false);
+    _w_vec.assign(x_vec, false);
+    inner_iterations = 0;
+    any_op.mul(_w_vec, x_vec);
+    _r_vec <<= b_vec - _w_vec;
+    return norm_2(_r_vec);
+  }
+
+  real_t iterate(Vector& x_vec, const Vector& b_vec, const Operator<Vector>& any_op,
+                 const Preconditioner<Vector>* /*pre_op*/) override {
+    static const real_t sqrt_of_epsilon = std::sqrt(std::numeric_limits<real_t>::epsilon());
+    const real_t mu = sqrt_of_epsilon * std::sqrt(1.0 + norm_2(x_vec));
+    _t_vec <<= _r_vec;
+    {
+      BiCgStabSolver<Vector> solver{};
+      solver.absolute_error_tolerance = 1.0e-8;
+      solver.relative_error_tolerance = 1.0e-8;
+      auto op = make_operator<Vector>([&](Vector& z_vec, const Vector& y_vec) {
+        const real_t delta = safe_divide(mu, norm_2(y_vec));
+        _s_vec <<= x_vec + delta * y_vec;
+        any_op.mul(z_vec, _s_vec);
+        const real_t delta_inverse = safe_divide(1.0, delta);
+        z_vec <<= delta_inverse * (z_vec - _w_vec);
+      });
+      solver.solve(_t_vec, _r_vec, *op);
+      inner_iterations += solver.iteration;
+    }
+    x_vec += _t_vec;
+    any_op.mul(_w_vec, x_vec);
+    _r_vec <<= b_vec - _w_vec;
+    return norm_2(_r_vec);
+  }
+
+public:
+  std::size_t inner_iterations{0};  ///< total BiCGStab iterations of the last solve (diagnostic)
 };
 
 }  // namespace Storm

@@ -97,6 +97,12 @@ def lib(variant: str = "strict"):
                      "oracle_solve_idrs"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int64, f64p, f64p,
                                          C.POINTER(_Params), C.POINTER(_Result), f64p]
+        L.oracle_solve_jfnk.restype = C.c_int64
+        L.oracle_solve_jfnk.argtypes = L.oracle_solve_cg.argtypes
+        L.oracle_solve_gmres_pre.restype = C.c_int64
+        L.oracle_solve_gmres_pre.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                             C.c_int64, f64p, f64p, C.POINTER(_Params), C.POINTER(_Result), f64p]
+        L.oracle_diag_apply.argtypes = [C.c_void_p, f64p, f64p]
     return _libs[variant]
 
 
@@ -269,6 +275,21 @@ class CallbackOperator:
         self.ctx = None
 
 
+class _DiagOp(C.Structure):
+    _fields_ = [("n", C.c_int64), ("d", f64p)]
+
+
+class DiagOperator:
+    """``y = d .* x`` (a Jacobi preconditioner passes ``d = 1 / diag(A)``)."""
+
+    def __init__(self, d, variant: str = "strict"):
+        self.d = f64(d)
+        self.n = self.d.size
+        self.c = _DiagOp(self.n, _p(self.d))
+        self.fn = C.cast(lib(variant).oracle_diag_apply, C.c_void_p)
+        self.ctx = C.cast(C.pointer(self.c), C.c_void_p)
+
+
 @dataclass
 class SolveResult:
     x: np.ndarray
@@ -297,3 +318,38 @@ def solve(kind: str, op, b, x0=None, num_iterations: int = 2000, abs_tol: float 
     fn(op.fn, op.ctx, b.size, _p(x), _p(b), C.byref(p), C.byref(r), _p(hist))
     return SolveResult(x, r.iterations, r.absolute_error, r.relative_error, r.initial_error,
                        bool(r.converged), r.num_applies, hist[: r.iterations + 1].copy())
+
+
+SIDES = {"left": 0, "right": 1, "symmetric": 2}
+
+
+def solve_gmres_pre(op, pre, b, x0=None, side: str = "right", flexible: bool = False, num_iterations: int = 2000,
+                    abs_tol: float = 1e-6, rel_tol: float = 1e-6, num_inner_iterations: int = 50,
+                    variant: str = "strict"):
+    """Preconditioned GMRES / FGMRES (SolverGmres.hpp, the ``pre_op != nullptr`` branches).  ``pre`` is any
+    operator object (``DiagOperator``, ``CallbackOperator`` ...) or ``None``.  Returns
+    ``(SolveResult, n_preconditioner_applies)``."""
+    b = f64(b)
+    x = np.zeros_like(b) if x0 is None else f64(x0).copy()
+    p = _Params(num_iterations, abs_tol, rel_tol, num_inner_iterations, 1e-4)
+    r = _Result()
+    hist = np.full(num_iterations + 1, np.nan)
+    n_pre = lib(variant).oracle_solve_gmres_pre(op.fn, op.ctx, pre.fn if pre is not None else None,
+                                                pre.ctx if pre is not None else None, SIDES[side], int(flexible),
+                                                b.size, _p(x), _p(b), C.byref(p), C.byref(r), _p(hist))
+    return SolveResult(x, r.iterations, r.absolute_error, r.relative_error, r.initial_error,
+                       bool(r.converged), r.num_applies, hist[: r.iterations + 1].copy()), n_pre
+
+
+def solve_jfnk(op, b, x0=None, num_iterations: int = 2000, abs_tol: float = 1e-6, rel_tol: float = 1e-6,
+               variant: str = "strict"):
+    """``solve<JfnkSolver>`` (SolverNewton.hpp:101-173); ``op`` may be nonlinear.  Returns
+    ``(SolveResult, total inner BiCGStab iterations)``."""
+    b = f64(b)
+    x = np.zeros_like(b) if x0 is None else f64(x0).copy()
+    p = _Params(num_iterations, abs_tol, rel_tol, 50, 1e-4)
+    r = _Result()
+    hist = np.full(num_iterations + 1, np.nan)
+    inner = lib(variant).oracle_solve_jfnk(op.fn, op.ctx, b.size, _p(x), _p(b), C.byref(p), C.byref(r), _p(hist))
+    return SolveResult(x, r.iterations, r.absolute_error, r.relative_error, r.initial_error,
+                       bool(r.converged), r.num_applies, hist[: r.iterations + 1].copy()), inner

@@ -481,8 +481,10 @@ ORACLE_API void oracle_solve_bicgstab(oracle_apply_fn apply, void *op,
   free(s.p), free(s.r), free(s.rt), free(s.t), free(s.v);
 }
 
-/* ---- GMRES(m): Solvers/SolverGmres.hpp:41-255 (Flexible = false, no       */
-/* preconditioner) under InnerOuterIterativeSolver, Solver.hpp:154-259. ---- */
+/* ---- GMRES(m) / FGMRES(m): Solvers/SolverGmres.hpp:41-255,281-308 under    */
+/* InnerOuterIterativeSolver, Solver.hpp:154-259.  `pre == NULL` is the       */
+/* unpreconditioned hot path; otherwise `side` picks the left (0) or right    */
+/* (1) branches and `flexible` the FGMRES ones (always right, :98-99).  ----- */
 typedef struct gmres_state {
   solver_base b;
   int64_t m;               /* num_inner_iterations */
@@ -490,7 +492,20 @@ typedef struct gmres_state {
   double *beta, *cs, *sn;  /* [m+1], [m], [m]          SolverGmres.hpp:45 */
   double *H;               /* (m+1) x m, row-major     SolverGmres.hpp:46 */
   double **q;              /* m+1 basis vectors        SolverGmres.hpp:47 */
+  oracle_apply_fn pre;     /* Preconditioner::mul, or NULL */
+  void *pre_ctx;
+  int side, flexible;
+  int64_t nz;              /* m if flexible, else 1    SolverGmres.hpp:48-49,63 */
+  double **z;
+  int64_t pre_applies;
 } gmres_state;
+
+static int gmres_left_pre(const gmres_state *s) { return s->pre && !s->flexible && s->side == 0; }
+static int gmres_right_pre(const gmres_state *s) { return s->pre && (s->flexible || s->side == 1); }
+static void gmres_pre_mul(gmres_state *s, double *y, const double *x) {
+  s->pre(s->pre_ctx, y, x);
+  s->pre_applies++;
+}
 
 #define H_(s, i, j) ((s)->H[(i) * (s)->m + (j)])
 
@@ -499,6 +514,11 @@ static void gmres_start(gmres_state *s, const double *x, const double *b) {
   const int64_t n = s->b.n;
   s->b.applies++;
   op_residual(s->b.apply, s->b.op, n, s->q[0], b, x); /* :82 / :110 */
+  if (gmres_left_pre(s)) {                            /* :83-86 / :111-114 */
+    double *t = s->z[0];
+    s->z[0] = s->q[0], s->q[0] = t;
+    gmres_pre_mul(s, s->q[0], s->z[0]);
+  }
   s->beta[0] = oracle_norm2(n, s->q[0]);              /* :87 / :115 */
   oracle_div_scalar(n, s->q[0], s->beta[0]);          /* :88 / :116 */
 }
@@ -512,6 +532,11 @@ static double gmres_outer_init(void *sv, const double *x, const double *b) {
   s->H = (double *)calloc((size_t)((m + 1) * m), sizeof(double));
   s->q = (double **)calloc((size_t)m + 1, sizeof(double *)); /* :60-61 */
   for (int64_t i = 0; i <= m; ++i) s->q[i] = new_vec(n);
+  if (s->pre) {                                              /* :62-65 */
+    s->nz = s->flexible ? m : 1;
+    s->z = (double **)calloc((size_t)s->nz, sizeof(double *));
+    for (int64_t i = 0; i < s->nz; ++i) s->z[i] = new_vec(n);
+  }
   gmres_start(s, x, b);
   return s->beta[0]; /* :90 */
 }
@@ -519,7 +544,16 @@ static double gmres_outer_init(void *sv, const double *x, const double *b) {
 /* inner_iterate :119-192 */
 static double gmres_inner_iterate(gmres_state *s) {
   const int64_t n = s->b.n, k = s->inner_iteration;
-  op_mul(&s->b, s->q[k + 1], s->q[k]);                     /* :155 */
+  if (gmres_left_pre(s)) {                                 /* :148-149, chained mul Operator.hpp:82-88 */
+    op_mul(&s->b, s->z[0], s->q[k]);
+    gmres_pre_mul(s, s->q[k + 1], s->z[0]);
+  } else if (gmres_right_pre(s)) {                         /* :150-152 */
+    const int64_t j = s->flexible ? k : 0;
+    gmres_pre_mul(s, s->z[j], s->q[k]);
+    op_mul(&s->b, s->q[k + 1], s->z[j]);
+  } else {
+    op_mul(&s->b, s->q[k + 1], s->q[k]);                   /* :155 */
+  }
   for (int64_t i = 0; i <= k; ++i) {                       /* :157-160 MGS */
     H_(s, i, k) = oracle_dot(n, s->q[k + 1], s->q[i]);
     oracle_axmy(n, s->q[k + 1], H_(s, i, k), s->q[i]);
@@ -547,7 +581,16 @@ static void gmres_inner_finalize(gmres_state *s, double *x) {
     for (int64_t j = i + 1; j <= k; ++j) s->beta[i] -= H_(s, i, j) * s->beta[j];
     s->beta[i] /= H_(s, i, i);
   }
-  for (int64_t i = 0; i <= k; ++i) oracle_axpy(n, x, s->beta[i], s->q[i]); /* :234-236 */
+  if (!gmres_right_pre(s)) {
+    for (int64_t i = 0; i <= k; ++i) oracle_axpy(n, x, s->beta[i], s->q[i]); /* :234-236 */
+  } else if (s->flexible) {
+    for (int64_t i = 0; i <= k; ++i) oracle_axpy(n, x, s->beta[i], s->z[i]); /* :238-240 */
+  } else {                                                                   /* :242-247 */
+    oracle_mul_scalar(n, s->q[0], s->beta[0]);
+    for (int64_t i = 1; i <= k; ++i) oracle_axpy(n, s->q[0], s->beta[i], s->q[i]);
+    gmres_pre_mul(s, s->z[0], s->q[0]);
+    oracle_axpy(n, x, 1.0, s->z[0]);
+  }
 }
 
 /* InnerOuterIterativeSolver::iterate  Solver.hpp:236-248 */
@@ -570,18 +613,42 @@ static void gmres_finalize(void *sv, double *x, const double *b) {
   if (s->inner_iteration != s->m - 1) gmres_inner_finalize(s, x);
 }
 
-ORACLE_API void oracle_solve_gmres(oracle_apply_fn apply, void *op, int64_t n,
-                                   double *x, const double *b,
-                                   const oracle_params *p, oracle_result *res,
-                                   double *history) {
+/* side: 0 = Left, 1 = Right (PreconditionerSide, Preconditioner.hpp:39-60; Symmetric takes neither
+   branch in GMRES, i.e. runs unpreconditioned except for the allocation).  Returns the number of
+   preconditioner applications. */
+ORACLE_API int64_t oracle_solve_gmres_pre(oracle_apply_fn apply, void *op, oracle_apply_fn pre,
+                                          void *pre_ctx, int side, int flexible, int64_t n,
+                                          double *x, const double *b, const oracle_params *p,
+                                          oracle_result *res, double *history) {
   gmres_state s;
   memset(&s, 0, sizeof s);
   s.b.apply = apply, s.b.op = op, s.b.n = n, s.b.history = history;
   s.m = p->num_inner_iterations;
+  s.pre = pre, s.pre_ctx = pre_ctx, s.side = side, s.flexible = flexible;
   const solver_vt vt = {gmres_outer_init, gmres_iterate, gmres_finalize};
   iterative_solve(&s.b, &vt, &s, x, b, p, res);
   for (int64_t i = 0; i <= s.m; ++i) free(s.q[i]);
-  free(s.q), free(s.beta), free(s.cs), free(s.sn), free(s.H);
+  for (int64_t i = 0; i < s.nz; ++i) free(s.z[i]);
+  free(s.q), free(s.z), free(s.beta), free(s.cs), free(s.sn), free(s.H);
+  return s.pre_applies;
+}
+
+ORACLE_API void oracle_solve_gmres(oracle_apply_fn apply, void *op, int64_t n,
+                                   double *x, const double *b,
+                                   const oracle_params *p, oracle_result *res,
+                                   double *history) {
+  (void)oracle_solve_gmres_pre(apply, op, NULL, NULL, 1, 0, n, x, b, p, res, history);
+}
+
+/* Diagonal preconditioner y = d .* x (a Jacobi P = diag(A)^-1 passes d = 1 / diag). */
+typedef struct oracle_diag_op {
+  int64_t n;
+  const double *d;
+} oracle_diag_op;
+
+ORACLE_API void oracle_diag_apply(void *ctx, double *y, const double *x) {
+  const oracle_diag_op *op = (const oracle_diag_op *)ctx;
+  for (int64_t i = 0; i < op->n; ++i) y[i] = op->d[i] * x[i];
 }
 
 /* ---- Richardson: Solvers/SolverRichardson.hpp:41-98 (no preconditioner) --- */
@@ -973,3 +1040,65 @@ ORACLE_API void oracle_solve_idrs(oracle_apply_fn apply, void *op, int64_t n, do
 }
 
 ORACLE_API int oracle_abi_version(void) { return 3; }
+
+/* ---- JFNK: Solvers/SolverNewton.hpp:101-173.  `apply` is the (possibly     */
+/* nonlinear) operator A(x); every outer iteration solves J(x) t = r with the  */
+/* reference's inner BiCGStab (tolerances 1e-8, default 2000 iterations,       */
+/* :133-135) where J(x) y = (A(x + delta y) - A(x)) / delta, :136-148. ------ */
+typedef struct jfnk_state {
+  solver_base b;
+  double *s, *t, *r, *w;
+  const double *x; /* current iterate, read by the Jacobian-vector product */
+  double mu;
+  int64_t inner_iterations;
+} jfnk_state;
+
+static void jfnk_jacobian_apply(void *ctx, double *z, const double *y) {
+  jfnk_state *st = (jfnk_state *)ctx;
+  const int64_t n = st->b.n;
+  const double delta = oracle_safe_divide(st->mu, oracle_norm2(n, y));      /* :144 */
+  for (int64_t i = 0; i < n; ++i) st->s[i] = st->x[i] + delta * y[i];       /* :145 */
+  op_mul(&st->b, z, st->s);                                                 /* :146 */
+  const double delta_inverse = oracle_safe_divide(1.0, delta);              /* :147 */
+  for (int64_t i = 0; i < n; ++i) z[i] = delta_inverse * (z[i] - st->w[i]); /* :148 */
+}
+
+static double jfnk_init(void *sv, const double *x, const double *b) {
+  jfnk_state *st = (jfnk_state *)sv;
+  const int64_t n = st->b.n;
+  st->s = new_vec(n), st->t = new_vec(n), st->r = new_vec(n), st->w = new_vec(n); /* :108-111 */
+  op_mul(&st->b, st->w, x);                                                 /* :118 */
+  for (int64_t i = 0; i < n; ++i) st->r[i] = b[i] - st->w[i];               /* :119 */
+  return oracle_norm2(n, st->r);
+}
+
+static double jfnk_iterate(void *sv, double *x, const double *b) {
+  jfnk_state *st = (jfnk_state *)sv;
+  const int64_t n = st->b.n;
+  st->mu = sqrt(2.220446049250313e-16) * sqrt(1.0 + oracle_norm2(n, x));   /* :128-130 */
+  oracle_copy(n, st->t, st->r);                                             /* :131 */
+  st->x = x;
+  oracle_params ip = {2000, 1.0e-8, 1.0e-8, 50, 1.0e-4};                    /* :133-135 */
+  oracle_result ir;
+  const int64_t outer_applies = st->b.applies; /* the inner solve counts its own; fold them in */
+  oracle_solve_bicgstab(jfnk_jacobian_apply, st, n, st->t, st->r, &ip, &ir, NULL);
+  (void)outer_applies;
+  st->inner_iterations += ir.iterations;
+  oracle_axpy(n, x, 1.0, st->t);                                            /* :156 */
+  op_mul(&st->b, st->w, x);                                                 /* :157 */
+  for (int64_t i = 0; i < n; ++i) st->r[i] = b[i] - st->w[i];               /* :158 */
+  return oracle_norm2(n, st->r);
+}
+
+/* Returns the total number of inner BiCGStab iterations. */
+ORACLE_API int64_t oracle_solve_jfnk(oracle_apply_fn apply, void *op, int64_t n, double *x,
+                                     const double *b, const oracle_params *p, oracle_result *res,
+                                     double *history) {
+  jfnk_state st;
+  memset(&st, 0, sizeof st);
+  st.b.apply = apply, st.b.op = op, st.b.n = n, st.b.history = history;
+  const solver_vt vt = {jfnk_init, jfnk_iterate, NULL};
+  iterative_solve(&st.b, &vt, &st, x, b, p, res);
+  free(st.s), free(st.t), free(st.r), free(st.w);
+  return st.inner_iterations;
+}

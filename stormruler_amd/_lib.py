@@ -81,6 +81,7 @@ SIGNATURES = {
     "storm_hip_rng_reset": (None, []),
     "storm_hip_lin3": (C.c_int, [vp, vp, C.c_double, C.c_double, vp, C.c_double, vp]),
     "storm_hip_vmul_add": (C.c_int, [vp, C.c_double, vp, vp]),
+    "storm_hip_vmul": (C.c_int, [vp, vp, vp]),
     "storm_hip_dot": (C.c_int, [vp, vp, f64p]),
     "storm_hip_norm2": (C.c_int, [vp, f64p]),
     "storm_hip_multi_dot": (C.c_int, [vp, C.POINTER(vp), C.c_int, f64p]),
@@ -92,6 +93,7 @@ SIGNATURES = {
     "storm_hip_op_create_csr": (C.c_int, [vp, C.c_int64, C.c_int64, i64p, i64p, f64p, C.POINTER(vp)]),
     "storm_hip_op_set_halo": (C.c_int, [vp, C.c_int, i32p, i64p, i64p, i64p]),
     "storm_hip_op_apply": (C.c_int, [vp, C.c_double, C.c_double, vp, vp]),
+    "storm_hip_op_get_diagonal": (C.c_int, [vp, C.c_double, C.c_double, C.c_int, vp]),
     "storm_hip_op_get_stats": (C.c_int, [vp, C.POINTER(OpStats)]),
     "storm_hip_op_destroy": (C.c_int, [vp]),
     "storm_hip_solver_params_default": (None, [C.POINTER(SolverParams)]),

@@ -232,6 +232,11 @@ class DeviceVector:
             # p <<= r + beta * (p - omega * v)  (SolverBiCgStab.hpp:119),  p <<= u + beta * (q + beta * p)
             # (SolverCgs.hpp:122): one kernel evaluating r + s * (a x + b z) in that nesting
             check(lib.storm_hip_lin3(self._h, e.r._h, e.s, e.lin.a, e.lin.x._h, e.lin.b, e.lin.z._h))
+        elif isinstance(e, _ScaledLin2):
+            # z <<= delta_inverse * (z - w)  (SolverNewton.hpp:148): the inner sum is rounded before
+            # the scaling, as the reference's expression tree evaluates it
+            check(lib.storm_hip_axpbz(self._h, e.lin.a, e.lin.x._h, e.lin.b, e.lin.z._h))
+            check(lib.storm_hip_scale(self._h, e.s))
         else:
             raise NotImplementedError(f"no device kernel for `<<=` of {type(e).__name__}")
         return self
@@ -285,6 +290,11 @@ def fill_with(a: DeviceVector, value: float) -> None:
 def vmul_add(y: DeviceVector, s: float, a: DeviceVector, b: DeviceVector) -> None:
     """``y += s * (a .* b)`` elementwise (nonlinear terms of a time-step driver)."""
     check(lib.storm_hip_vmul_add(y._h, float(s), a._h, b._h))
+
+
+def vmul(y: DeviceVector, a: DeviceVector, b: DeviceVector) -> None:
+    """``y = a .* b`` elementwise (a diagonal preconditioner's ``mul``)."""
+    check(lib.storm_hip_vmul(y._h, a._h, b._h))
 
 
 def fill_randomly(a: DeviceVector) -> None:
@@ -447,6 +457,10 @@ class StencilMatrix:
     def apply(self, alpha: float, beta: float, x: DeviceVector, y: DeviceVector) -> None:
         check(lib.storm_hip_op_apply(self._h, alpha, beta, x._h, y._h))
 
+    def diagonal(self, alpha: float, beta: float, d: DeviceVector, invert: bool = False) -> None:
+        """``d`` <- the diagonal of ``beta*I + alpha*M`` (its safe inverse with ``invert``)."""
+        check(lib.storm_hip_op_get_diagonal(self._h, float(alpha), float(beta), int(invert), d._h))
+
     def close(self):
         if getattr(self, "_h", None):
             lib.storm_hip_op_destroy(self._h)
@@ -484,6 +498,9 @@ class Preconditioner(Operator):  # Preconditioner.hpp:63-78
     def build(self, x_vec, b_vec, any_op) -> None:
         pass
 
+    def add_secant(self, y_vec, s_vec) -> None:  # :76
+        pass
+
 
 class IdentityPreconditioner(Preconditioner):  # Preconditioner.hpp:84-97
     def mul(self, y_vec, x_vec):
@@ -491,6 +508,28 @@ class IdentityPreconditioner(Preconditioner):  # Preconditioner.hpp:84-97
 
     def conj_mul(self, x_vec, y_vec):
         x_vec <<= y_vec
+
+
+class JacobiPreconditioner(Preconditioner):
+    """Diagonal preconditioner ``P = diag(A)^-1`` for a :class:`HipStencilOperator`, entirely on the
+    device.  The build's own addition behind the reference's ``pre_op`` hook (the reference ships only
+    the identity, Preconditioner.hpp:84-97): ``build`` (:70-72) reads the diagonal of the operator it is
+    given, ``mul`` is one elementwise product."""
+
+    def __init__(self):
+        self._dinv: Optional[DeviceVector] = None
+
+    def build(self, x_vec, b_vec, any_op) -> None:
+        if not isinstance(any_op, HipStencilOperator):
+            raise TypeError("JacobiPreconditioner needs a HipStencilOperator to read the diagonal from")
+        self._dinv = _like(x_vec)
+        any_op.matrix.diagonal(any_op.alpha, any_op.beta, self._dinv, invert=True)
+
+    def mul(self, y_vec, x_vec):
+        vmul(y_vec, self._dinv, x_vec)
+
+    def conj_mul(self, x_vec, y_vec):
+        vmul(x_vec, self._dinv, y_vec)
 
 
 class Solver:  # Solver.hpp:43-57
@@ -712,9 +751,12 @@ class BiCgStabSolver(IterativeSolver):
 
 
 class GmresSolver(InnerOuterIterativeSolver):
-    """SolverGmres.hpp:41-255, Flexible = false, no preconditioner in the host-statement path."""
+    """SolverGmres.hpp:41-255 (``BaseGmresSolver<Vector, Flexible>``): the unpreconditioned branches run
+    natively on the device; with a ``pre_op`` the statement-level path below takes the reference's
+    left / right (``Flexible = false``) or flexible (always right, :98-99) branches."""
 
     _native = "storm_hip_solve_gmres"
+    _flexible = False
 
     def __init__(self):
         super().__init__()
@@ -725,32 +767,45 @@ class GmresSolver(InnerOuterIterativeSolver):
         p.gram_schmidt = self.gram_schmidt
         return p
 
-    def _start(self, x_vec, b_vec, lin_op):
-        lin_op.Residual(self._q_vecs[0], b_vec, x_vec)
-        self._beta[0] = norm_2(self._q_vecs[0])
-        self._q_vecs[0] /= self._beta[0]
+    def _left_pre(self, pre_op) -> bool:
+        return pre_op is not None and not self._flexible and self.pre_side == PreconditionerSide.Left
+
+    def _right_pre(self, pre_op) -> bool:
+        return pre_op is not None and (self._flexible or self.pre_side == PreconditionerSide.Right)
+
+    def _start(self, x_vec, b_vec, lin_op, pre_op):  # :66-90 == :93-117
+        q, z = self._q_vecs, self._z_vecs
+        lin_op.Residual(q[0], b_vec, x_vec)
+        if self._left_pre(pre_op):
+            z[0], q[0] = q[0], z[0]
+            pre_op.mul(q[0], z[0])
+        self._beta[0] = norm_2(q[0])
+        q[0] /= self._beta[0]
 
     def outer_init(self, x_vec, b_vec, lin_op, pre_op):  # :51-91
-        if pre_op is not None:
-            raise NotImplementedError("preconditioned GMRES is not part of the hot path (SURVEY.md 8f rank 3)")
         m = self.num_inner_iterations
         self._beta = np.zeros(m + 1)
         self._cs, self._sn = np.zeros(m), np.zeros(m)
         self._H = np.zeros((m + 1, m))
-        self._q_vecs: List[DeviceVector] = []
-        for _ in range(m + 1):
-            q = DeviceVector()
-            q.assign(x_vec, False)
-            self._q_vecs.append(q)
-        self._start(x_vec, b_vec, lin_op)
+        self._q_vecs: List[DeviceVector] = [_like(x_vec) for _ in range(m + 1)]
+        self._z_vecs: List[DeviceVector] = []
+        if pre_op is not None:  # :62-65
+            self._z_vecs = [_like(x_vec) for _ in range(m if self._flexible else 1)]
+        self._start(x_vec, b_vec, lin_op, pre_op)
         return self._beta[0]
 
     def inner_init(self, x_vec, b_vec, lin_op, pre_op):  # :93-117
-        self._start(x_vec, b_vec, lin_op)
+        self._start(x_vec, b_vec, lin_op, pre_op)
 
     def inner_iterate(self, x_vec, b_vec, lin_op, pre_op):  # :119-192
-        k, H, q = self.inner_iteration, self._H, self._q_vecs
-        lin_op.mul(q[k + 1], q[k])
+        k, H, q, z = self.inner_iteration, self._H, self._q_vecs, self._z_vecs
+        if self._left_pre(pre_op):  # :148-149
+            pre_op.mul_chain(q[k + 1], z[0], lin_op, q[k])
+        elif self._right_pre(pre_op):  # :150-152
+            j = k if self._flexible else 0
+            lin_op.mul_chain(q[k + 1], z[j], pre_op, q[k])
+        else:
+            lin_op.mul(q[k + 1], q[k])
         for i in range(k + 1):
             H[i, k] = dot_product(q[k + 1], q[i])
             q[k + 1] -= H[i, k] * q[i]
@@ -769,13 +824,23 @@ class GmresSolver(InnerOuterIterativeSolver):
         return abs(beta[k + 1])
 
     def inner_finalize(self, x_vec, b_vec, lin_op, pre_op):  # :194-249
-        k, H, beta = self.inner_iteration, self._H, self._beta
+        k, H, beta, q, z = self.inner_iteration, self._H, self._beta, self._q_vecs, self._z_vecs
         for i in range(k, -1, -1):
             for j in range(i + 1, k + 1):
                 beta[i] -= H[i, j] * beta[j]
             beta[i] /= H[i, i]
-        for i in range(k + 1):
-            x_vec += beta[i] * self._q_vecs[i]
+        if not self._right_pre(pre_op):  # :233-236
+            for i in range(k + 1):
+                x_vec += beta[i] * q[i]
+        elif self._flexible:  # :237-240
+            for i in range(k + 1):
+                x_vec += beta[i] * z[i]
+        else:  # :241-247
+            q[0] *= beta[0]
+            for i in range(1, k + 1):
+                q[0] += beta[i] * q[i]
+            pre_op.mul(z[0], q[0])
+            x_vec += z[0]
 
 
 class RichardsonSolver(IterativeSolver):
@@ -910,8 +975,55 @@ class Tfqmr1Solver(_BaseTfqmrSolver):
 
 
 class FgmresSolver(GmresSolver):
-    """SolverGmres.hpp:306-308: flexible GMRES.  Without a preconditioner it is GMRES (the flexible
-    branches only differ in where the preconditioned vectors are kept)."""
+    """SolverGmres.hpp:306-308: flexible GMRES -- keeps every preconditioned vector z_k so the
+    preconditioner may change between iterations; right preconditioning only.  Without a
+    preconditioner it is GMRES and runs natively."""
+
+    _flexible = True
+
+
+class NewtonSolver(IterativeSolver):
+    """SolverNewton.hpp:55-72: declared but unimplemented in the reference (``STORM_ABORT``)."""
+
+    def init(self, x_vec, b_vec, any_op, pre_op):
+        raise NotImplementedError("Newton solver is not implemented yet!")  # :61
+
+    def iterate(self, x_vec, b_vec, any_op, pre_op):
+        raise NotImplementedError("Newton solver is not implemented yet!")  # :67
+
+
+class JfnkSolver(IterativeSolver):
+    """SolverNewton.hpp:101-173: first-order Jacobian-free Newton-Krylov.  ``any_op`` may be nonlinear;
+    each iteration solves ``J(x) t = r`` with a BiCGStab (1e-8 tolerances, :133-135) on the
+    finite-difference Jacobian-vector product ``(A(x + delta y) - A(x)) / delta`` (:136-148)."""
+
+    def init(self, x_vec, b_vec, any_op, pre_op):  # :106-122
+        self._s_vec, self._t_vec, self._r_vec, self._w_vec = (_like(x_vec) for _ in range(4))
+        self.inner_iterations = 0
+        any_op.mul(self._w_vec, x_vec)
+        self._r_vec <<= b_vec - self._w_vec
+        return norm_2(self._r_vec)
+
+    def iterate(self, x_vec, b_vec, any_op, pre_op):  # :124-161
+        mu = math.sqrt(np.finfo(np.float64).eps) * math.sqrt(1.0 + norm_2(x_vec))
+        self._t_vec <<= self._r_vec
+        solver = BiCgStabSolver()
+        solver.absolute_error_tolerance = 1.0e-8
+        solver.relative_error_tolerance = 1.0e-8
+
+        def jacobian_vector_product(z_vec, y_vec):  # :136-148
+            delta = safe_divide(mu, norm_2(y_vec))
+            self._s_vec <<= x_vec + delta * y_vec
+            any_op.mul(z_vec, self._s_vec)
+            delta_inverse = safe_divide(1.0, delta)
+            z_vec <<= delta_inverse * (z_vec - self._w_vec)
+
+        solver.solve(self._t_vec, self._r_vec, make_operator(jacobian_vector_product))
+        self.inner_iterations += solver.iteration
+        x_vec += self._t_vec
+        any_op.mul(self._w_vec, x_vec)
+        self._r_vec <<= b_vec - self._w_vec
+        return norm_2(self._r_vec)
 
 
 class BiCgStabLSolver(InnerOuterIterativeSolver):

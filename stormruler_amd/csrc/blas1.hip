@@ -116,6 +116,14 @@ struct VmulAddF {
   __device__ double operator()(double y, double a, double b) const { return y + s * (a * b); }
 };
 
+// y = x0 .* x1
+struct VmulF {
+  static constexpr bool reads_y = false;
+  static constexpr int nin = 2;
+  __device__ void prepare() {}
+  __device__ double operator()(double, double a, double b) const { return a * b; }
+};
+
 template <class F>
 static int launch_ew(storm_hip_ctx *c, int64_t n, EwPtrs p, F f, const int *done) {
   if (n <= 0) return STORM_HIP_OK;
@@ -475,6 +483,13 @@ int storm_hip_vmul_add(storm_hip_vec *y, double s, const storm_hip_vec *a, const
   STORM_TRY(check_pair(y, b, "vmul_add"));
   if (y->n_owned <= 0) return STORM_HIP_OK;
   return launch_ew(y->ctx, y->n_owned, EwPtrs{y->d, a->d, b->d}, VmulAddF{s}, nullptr);
+}
+
+int storm_hip_vmul(storm_hip_vec *y, const storm_hip_vec *a, const storm_hip_vec *b) {
+  STORM_TRY(check_pair(y, a, "vmul"));
+  STORM_TRY(check_pair(y, b, "vmul"));
+  if (y->n_owned <= 0) return STORM_HIP_OK;
+  return launch_ew(y->ctx, y->n_owned, EwPtrs{y->d, a->d, b->d}, VmulF{}, nullptr);
 }
 
 int storm_hip_bicgstab_p(storm_hip_vec *p, const storm_hip_vec *r, double beta, double omega,

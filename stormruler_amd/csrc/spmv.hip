@@ -391,6 +391,44 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
   return STORM_HIP_OK;
 }
 
+// ---- diagonal of beta*I + alpha*M (for a Jacobi preconditioner) -----------------------------------
+// In the difference form  (Mx)_i = sum_k w_ik (x_col - x_i) + ext_i x_i  the coefficient of x_i is
+// ext_i - sum_k w_ik (no slot has col == i: build_op receives off-diagonal entries only, and padding
+// slots carry w = 0).  One lane per row, same slot addressing as build_op; not a hot kernel.
+__global__ __launch_bounds__(kBlock) void diag_sell_kernel(const char *__restrict__ pack,
+                                                           const int64_t *__restrict__ slice_off, int64_t n_rows,
+                                                           double alpha, double beta, double *__restrict__ d) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t s = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  const int64_t r = s * kWave + lane;
+  if (r >= n_rows) return;
+  const char *rec = pack + slice_off[s];
+  const int w = (int)((slice_off[s + 1] - slice_off[s] - kExtBytes) / kSlotBytes);
+  const double *val = reinterpret_cast<const double *>(rec + kExtBytes + (int64_t)w * (kWave * 4));
+  const int np2 = w >> 1;
+  double sum = 0.0;
+  for (int k = 0; k < w; ++k) {
+    const int at = (k < 2 * np2) ? ((k >> 1) * kWave + lane) * 2 + (k & 1) : np2 * 2 * kWave + lane;
+    sum += val[at];
+  }
+  d[r] = beta + alpha * (reinterpret_cast<const double *>(rec)[lane] - sum);
+}
+
+__global__ void diag_tail_kernel(int64_t n_tail, const int *__restrict__ tail_row,
+                                 const int64_t *__restrict__ tail_ptr, const double *__restrict__ tail_val,
+                                 double alpha, double *__restrict__ d) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tail) return;
+  double sum = 0.0;
+  for (int64_t k = tail_ptr[t]; k < tail_ptr[t + 1]; ++k) sum += tail_val[k];
+  d[tail_row[t]] -= alpha * sum;  // each overflowing row appears once in the tail
+}
+
+__global__ void safe_invert_kernel(int64_t n, double *__restrict__ d) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) d[i] = d[i] == 0.0 ? 0.0 : 1.0 / d[i];  // safe_inverse, Crow/MathUtils.hpp:54-58
+}
+
 // ---- host-side build ----------------------------------------------------------------------------
 
 }  // namespace storm
@@ -641,6 +679,27 @@ int storm_hip_op_apply(const storm_hip_op *op, double alpha, double beta, const 
   STORM_REQUIRE(x->n_halo >= op->n_halo, "op_apply: x has %lld halo rows, operator needs %lld", (long long)x->n_halo,
                 (long long)op->n_halo);
   return spmv_launch(op, host_scal(alpha), host_scal(beta), x->d, y->d, nullptr, nullptr);
+}
+
+int storm_hip_op_get_diagonal(const storm_hip_op *op, double alpha, double beta, int invert, storm_hip_vec *d) {
+  STORM_REQUIRE(op && d, "op_get_diagonal: null argument");
+  STORM_REQUIRE(d->ctx == op->ctx, "op_get_diagonal: context mismatch");
+  STORM_REQUIRE(d->n_owned == op->n_rows, "op_get_diagonal: operator has %lld rows, d %lld", (long long)op->n_rows,
+                (long long)d->n_owned);
+  if (op->n_rows == 0) return STORM_HIP_OK;
+  storm_hip_ctx *c = op->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  const int nb = (int)((op->n_slices + (kBlock / kWave) - 1) / (kBlock / kWave));
+  hipLaunchKernelGGL(diag_sell_kernel, dim3(nb), dim3(kBlock), 0, c->stream, op->d_pack, op->d_slice_off, op->n_rows,
+                     alpha, beta, d->d);
+  if (op->tail_rows > 0)
+    hipLaunchKernelGGL(diag_tail_kernel, dim3((int)((op->tail_rows + 255) / 256)), dim3(256), 0, c->stream,
+                       op->tail_rows, op->d_tail_row, op->d_tail_ptr, op->d_tail_val, alpha, d->d);
+  if (invert)
+    hipLaunchKernelGGL(safe_invert_kernel, dim3((int)((op->n_rows + 255) / 256)), dim3(256), 0, c->stream, op->n_rows,
+                       d->d);
+  HIP_TRY(hipGetLastError());
+  return STORM_HIP_OK;
 }
 
 int storm_hip_op_get_stats(const storm_hip_op *op, storm_hip_op_stats *s) {

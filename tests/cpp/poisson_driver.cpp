@@ -2,11 +2,12 @@
 // (source_apps/playground/Playground.cpp:151-167): build the mesh quantities, wrap the stencil in
 // an operator, call solve<XSolver>(x, b, op).  Compiled against include/storm_hip/Storm.hpp only.
 //
-//   poisson_driver <n> <cg|bicgstab|gmres> <native|lambda> [restart]
+//   poisson_driver <n> <cg|bicgstab|gmres|fgmres|jfnk|...> <native|lambda|jacobi|jacobi-left> [restart]
 //
 // prints one JSON line.  "lambda" passes the operator through make_operator (forcing the
 // statement-by-statement solver templates over the BLAS-1 ABI); "native" passes a
-// HipStencilOperator (whole solve on the device).
+// HipStencilOperator (whole solve on the device); "jacobi[-left]" adds the device-side diagonal
+// preconditioner through the reference's pre_op / pre_side hook (Solver.hpp:74-75).
 #include <storm_hip/Storm.hpp>
 
 #include <cmath>
@@ -56,7 +57,8 @@ static BoxMesh make_box(int n) {
 }
 
 template<template<class> class SolverT>
-static int run(int n, bool native, size_t restart) {
+static int run(int n, const std::string& mode, size_t restart) {
+  const bool native = mode != "lambda";
   Context ctx(0);
   const BoxMesh mesh = make_box(n);
   const StencilMatrix matrix = StencilMatrix::from_faces(ctx, mesh.n_cells, 0, mesh.inner, mesh.outer, mesh.coef,
@@ -67,6 +69,10 @@ static int run(int n, bool native, size_t restart) {
   SolverT<DeviceVector> solver;
   if constexpr (std::is_base_of_v<InnerOuterIterativeSolver<DeviceVector>, SolverT<DeviceVector>>)
     solver.num_inner_iterations = restart;
+  if (mode == "jacobi" || mode == "jacobi-left") {
+    solver.pre_op = std::make_unique<JacobiPreconditioner>();
+    solver.pre_side = mode == "jacobi" ? PreconditionerSide::Right : PreconditionerSide::Left;
+  }
   bool converged;
   if (native) {
     const HipStencilOperator op(matrix, -1.0, 0.0);  // A = -L
@@ -93,17 +99,19 @@ static int run(int n, bool native, size_t restart) {
 
 int main(int argc, char** argv) {
   if (argc < 4) {
-    std::fprintf(stderr, "usage: %s <n> <cg|bicgstab|gmres> <native|lambda> [restart]\n", argv[0]);
+    std::fprintf(stderr, "usage: %s <n> <solver> <native|lambda|jacobi|jacobi-left> [restart]\n", argv[0]);
     return 2;
   }
   const int n = std::atoi(argv[1]);
   const std::string kind = argv[2];
-  const bool native = std::strcmp(argv[3], "native") == 0;
+  const std::string native = argv[3];
   const size_t restart = argc > 4 ? (size_t)std::atoi(argv[4]) : 50;
   try {
     if (kind == "cg") return run<CgSolver>(n, native, restart);
     if (kind == "bicgstab") return run<BiCgStabSolver>(n, native, restart);
     if (kind == "gmres") return run<GmresSolver>(n, native, restart);
+    if (kind == "fgmres") return run<FgmresSolver>(n, native, restart);
+    if (kind == "jfnk") return run<JfnkSolver>(n, native, restart);
     if (kind == "bicgstabl") return run<BiCgStabLSolver>(n, native, restart);
     if (kind == "idrs") return run<IdrsSolver>(n, native, restart);
     if (kind == "cgs") return run<CgsSolver>(n, native, restart);

@@ -138,3 +138,62 @@ def test_convergence_rule_edges():
     assert r.iterations == 0 and r.converged and r.num_applies == 1
     r = oracle.solve("cg", op, b, abs_tol=0.0, rel_tol=1e-3)
     assert r.converged and r.relative_error < 1e-3
+
+
+def _tridiag(n=64):
+    import scipy.sparse as sp
+
+    return sp.diags([-np.ones(n - 1), 2.0 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1]).tocsr()
+
+
+def test_preconditioned_gmres_branches():
+    """SolverGmres.hpp pre_op != nullptr branches: an identity preconditioner on the left, and FGMRES with
+    one, repeat the unpreconditioned arithmetic bit for bit; on the right (non-flexible) x is assembled
+    through q_0 (:242-247) so only the values agree.  All reach the 1-D KAT x_31 = 528."""
+    a = _tridiag()
+    op, b = oracle.CsrOperator(a), np.ones(64)
+    ident = oracle.DiagOperator(np.ones(64))
+    plain = oracle.solve("gmres", op, b, num_inner_iterations=50)
+    assert plain.iterations == 32 and abs(plain.x[31] - 528.0) < 1e-6
+    for side, flexible, exact in (("left", False, True), ("right", True, True), ("left", True, True),
+                                  ("right", False, False)):
+        r, n_pre = oracle.solve_gmres_pre(op, ident, b, side=side, flexible=flexible, num_inner_iterations=50)
+        assert r.iterations == plain.iterations and np.array_equal(r.history, plain.history)
+        assert np.array_equal(r.x, plain.x) if exact else np.allclose(r.x, plain.x, rtol=1e-12)
+        # applications: left = 1 per start + 1 per iteration; flexible = 1 per iteration;
+        # right = 1 per iteration + 1 per finalize
+        starts = 2  # outer_init + inner_init of the first cycle (SolverGmres.hpp:66-67 duplication)
+        want = {("left", False): starts + r.iterations, ("right", False): r.iterations + 1}.get((side, flexible),
+                                                                                               r.iterations)
+        assert n_pre == want
+    # symmetric side: neither branch is taken (SolverGmres.hpp:121-128) -> plain GMRES
+    r, n_pre = oracle.solve_gmres_pre(op, ident, b, side="symmetric", num_inner_iterations=50)
+    assert n_pre == 0 and np.array_equal(r.x, plain.x)
+    # a real preconditioner on a badly scaled system cuts the iteration count
+    d = np.linspace(1.0, 1e3, 64)
+    import scipy.sparse as sp
+
+    op2 = oracle.CsrOperator((sp.diags(d) @ a).tocsr())
+    bad = oracle.solve("gmres", op2, d, num_inner_iterations=50, num_iterations=500)
+    good, _ = oracle.solve_gmres_pre(op2, oracle.DiagOperator(1.0 / d), d, side="left", num_inner_iterations=50,
+                                     num_iterations=500)
+    assert good.converged and good.iterations == 32  # D^-1 (D A) = A again
+    assert (not bad.converged) or bad.iterations > good.iterations
+    assert abs(good.x[31] - 528.0) < 1e-3
+
+
+def test_jfnk_linear_and_nonlinear():
+    """SolverNewton.hpp:101-173.  On a linear operator the finite-difference Jacobian is exact up to rounding,
+    so one Newton step (one inner BiCGStab solve to 1e-8) lands on the KAT; on a cubic perturbation the
+    residual history contracts quadratically near the root."""
+    a = _tridiag()
+    r, inner = oracle.solve_jfnk(oracle.CsrOperator(a), np.ones(64))
+    assert r.converged and r.iterations <= 2 and abs(r.x[31] - 528.0) < 1e-4
+    assert inner >= 32 and r.num_applies >= inner * 2
+    shifted = (a + 4.0 * __import__("scipy.sparse").sparse.identity(64)).tocsr()
+    f = lambda v: shifted @ v + 0.2 * v ** 3  # noqa: E731
+    r, inner = oracle.solve_jfnk(oracle.CallbackOperator(64, f), np.ones(64))
+    assert r.converged and 2 <= r.iterations <= 8
+    assert np.abs(f(r.x) - 1.0).max() < 1e-6
+    h = r.history
+    assert h[-1] < 1e-3 * h[-2] or h[-1] < 1e-9  # fast final contraction
