@@ -115,8 +115,10 @@ def main() -> int:
     # Device spin-up (untimed, before the W warmup steps): the first process on an idle MI355X runs
     # ~20 % slow for its first several hundred milliseconds (clocks / memory power state); 10 ms of
     # warmup steps do not cover that.  Same work as the timed region, nothing is cached from it.
+    # The loop count must be the same on every rank (each run() holds collectives), so the elapsed
+    # time that decides it is the max over ranks.
     t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < args.spinup_seconds:
+    while args.spinup_seconds > 0 and dist.allreduce_max(time.perf_counter() - t_spin) < args.spinup_seconds:
         run(100)
         ctx.sync()
     if W > 0:
