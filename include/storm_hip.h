@@ -180,7 +180,12 @@ int storm_hip_op_create_csr(storm_hip_ctx *ctx, int64_t n_rows, int64_t n_halo,
                             storm_hip_op **out);
 
 /* Build knobs, set before create (0 = library default):
- *   ell_cap: rows longer than this spill their remaining entries to the CSR tail. */
+ *   ell_cap:   rows longer than this spill their remaining entries to the CSR tail;
+ *   spmv_dict: >= 1 stores the weights of an operator whose ext / weight values take at most 256
+ *              distinct fp64 bit patterns (and whose rows have at most 7 neighbours) as byte indices
+ *              into that dictionary -- lossless, half the bytes per row; 2 (default) does the same
+ *              for the column offsets col - row when they take at most 256 distinct values (a third
+ *              of the bytes per row); 0 always stores fp64 weights and int32 columns. */
 int storm_hip_ctx_set_option(storm_hip_ctx *ctx, const char *key, int64_t value);
 
 /* Halo plan of a row-partitioned operator.  For neighbour q
@@ -208,6 +213,9 @@ typedef struct storm_hip_op_stats {
   int64_t n_slices, max_row_len;
   int64_t n_interior_slices;            /* slices whose rows reference no halo column */
   int64_t device_bytes;
+  int64_t record_bytes;                 /* bytes of slice records one apply streams */
+  int64_t value_dictionary_size;        /* > 0: weights stored as byte indices into this many distinct values */
+  int64_t offset_dictionary_size;       /* > 0: columns stored as byte indices into this many distinct col - row */
 } storm_hip_op_stats;
 int storm_hip_op_get_stats(const storm_hip_op *op, storm_hip_op_stats *stats);
 int storm_hip_op_destroy(storm_hip_op *op);

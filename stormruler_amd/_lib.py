@@ -44,7 +44,8 @@ class SolverResult(C.Structure):
 class OpStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("n_rows", "n_cols", "nnz_offdiag", "ell_slots", "tail_nnz",
                                           "tail_rows", "n_slices", "max_row_len", "n_interior_slices",
-                                          "device_bytes")]
+                                          "device_bytes", "record_bytes", "value_dictionary_size",
+                                          "offset_dictionary_size")]
 
 
 # name -> (restype, argtypes); every symbol include/storm_hip.h declares.

@@ -94,6 +94,8 @@ struct storm_hip_ctx {
   // options
   int64_t opt_ell_cap = 0;
   int64_t opt_spmv_variant = 0;      // 0 gathers from global (default), 1 + LDS x window
+  int64_t opt_spmv_dict = 2;         // dictionary records whenever an operator qualifies (lossless): 2 values + column offsets, 1 values only, 0 never
+  int64_t opt_spmv_spw = 0;          // slices per wave of the dictionary kernel: 1, 2 or 4 (0 = default)
   int64_t opt_spmv_xcd_remap = 8;    // 0 off; 1 one contiguous run per XCD (slower); G > 1: runs of G tiles per XCD
   int64_t opt_nt = 1;
   int64_t opt_profile_spmv = 0;
@@ -135,6 +137,12 @@ struct storm_hip_op {
   int64_t nnz = 0, ell_slots = 0, max_row_len = 0;
   int64_t *d_slice_off = nullptr;  // [n_slices + 1] byte offset of each slice record
   char *d_pack = nullptr;          // slice records: [ext 64 f64][col W*64 i32][val W*64 f64]
+  double *d_dict = nullptr;        // value-dictionary records: the 256-entry table (spmv.hip)
+  int dict_size = 0;               // > 0: records are [idx 64 u64][col W*64 i32]
+  int *d_offs = nullptr;           // format 2: the 256-entry column-offset table
+  int offs_size = 0;               // > 0: records are 64 x 16-byte words (values + offsets as byte indices)
+  int64_t pack_bytes = 0;
+  int64_t spw = 1;                 // slices per wavefront of the uniform-width dictionary kernel
   // tail
   int64_t tail_rows = 0, tail_nnz = 0;
   int *d_tail_row = nullptr;       // [tail_rows]

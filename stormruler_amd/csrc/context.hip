@@ -118,6 +118,8 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "spmv_variant")) c->opt_spmv_variant = value;
   else if (!strcmp(key, "nontemporal")) c->opt_nt = value;
   else if (!strcmp(key, "spmv_xcd_remap")) c->opt_spmv_xcd_remap = value;
+  else if (!strcmp(key, "spmv_dict")) c->opt_spmv_dict = value;
+  else if (!strcmp(key, "spmv_spw")) c->opt_spmv_spw = value;
   else if (!strcmp(key, "profile_spmv")) c->opt_profile_spmv = value;
   else if (!strcmp(key, "fuse_dot")) c->opt_fuse_dot = value;
   else if (!strcmp(key, "graph")) c->opt_graph = value;

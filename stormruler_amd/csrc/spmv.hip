@@ -14,6 +14,20 @@
 //   W = min(longest row of the slice, ell_cap); what does not fit goes to a CSR tail handled
 //   by a wave-per-row kernel with a __shfl_down reduction.  Padding slots carry weight 0 and
 //   the row's own index as column.
+// Value-dictionary records (VARIANT 2, chosen at build time when it is lossless): when ext and the
+//   weights of the whole operator take at most 256 distinct fp64 values and no slice is wider than
+//   7 slots -- any mesh made of a few repeated cell shapes, the 256^3 box of the benchmark being the
+//   extreme case -- a slice stores, instead of 8 (W + 1) bytes of fp64 per row, ONE 8-byte word per
+//   row holding W + 1 byte indices into a dictionary of the distinct values (bit patterns, so the
+//   arithmetic is unchanged):
+//        [ idx : 64 x u64 (byte 0 = ext, byte k+1 = slot k) ][ col : W x 64 x i32 ]   (512 + 256 W bytes)
+//   The kernel keeps the dictionary in LDS (2 KiB per block).  At W = 6 a row then streams
+//   24 + 8 + 8 + 8 = 48 bytes instead of 96.  Operators that do not qualify keep the fp64 records.
+// Value + offset dictionaries (format 2): if, in addition, the column offsets col - row take at most
+//   256 distinct values (a mesh numbered block-wise: the box has 7 -- 0, +-1, +-nx, +-nx ny -- a z-slab of
+//   it with halo planes a few more), the columns become byte indices as well and a row is ONE 16-byte word
+//        byte 0 = ext, bytes 1..7 = weight of slot 0..6, bytes 8..14 = offset of slot 0..6
+//   so a slice is a 1 KiB record whatever its width, and a row streams 16 + 8 + 8 = 32 bytes.
 // Arithmetic:  y_i = beta x_i + alpha ( sum_k w_ik (x[col_ik] - x_i) + ext_i x_i )
 //   -- the difference form of the reference's flux  (c[out] - c[in]), which keeps the
 //   cancellation behaviour of the face loop (no large diagonal * x_i term).
@@ -43,7 +57,14 @@ struct SellArgs {
   int64_t n_rows;
   int uniform_width;                      // > 0: every slice has this width, slice_off is not read
   int xcd_group;                          // tiles per XCD run (<= 1: one contiguous run per XCD)
+  const double *__restrict__ dict;        // VARIANT 2: the 256-entry value dictionary
+  int dict_size;
+  const int *__restrict__ offs;           // format 2: the column-offset dictionary
+  int offs_size;
 };
+
+constexpr int kDictSize = 256;
+constexpr int kColSlotBytes = kWave * 4;  // 256: one slot of a value-dictionary record (columns only)
 
 struct DotArgs {
   const double *w;   // partial of <w, y>, may be null
@@ -172,6 +193,31 @@ __device__ __forceinline__ double row_sum_wide(const char *rec, int width, int l
   return acc;
 }
 
+// Value-dictionary record: columns as in row_sum, the weight of slot k is dict[byte k + 1 of iw] (LDS).
+template <bool NT, int W>
+__device__ __forceinline__ double row_sum_cv(const char *rec, int width, int lane, const double *__restrict__ x,
+                                             double xi, uint64_t iw, const double *dict) {
+  constexpr int NP = W / 2;
+  const int npair_total = width >> 1;
+  const int2v *cp2 = reinterpret_cast<const int2v *>(rec + kExtBytes) + lane;
+  int2v c[NP > 0 ? NP : 1];
+  int ct = 0;
+#pragma unroll
+  for (int q = 0; q < NP; ++q) c[q] = NT ? __builtin_nontemporal_load(cp2 + q * kWave) : cp2[q * kWave];
+  if (W & 1) ct = ld_i<NT>(reinterpret_cast<const int *>(rec + kExtBytes + (int64_t)npair_total * (kWave * 8)) + lane);
+  double xg[W > 0 ? W : 1];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    xg[2 * q] = x[c[q].x];
+    xg[2 * q + 1] = x[c[q].y];
+  }
+  if (W & 1) xg[W - 1] = x[ct];
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < W; ++k) acc += dict[(unsigned)(iw >> (8 * (k + 1))) & 0xffu] * (xg[k] - xi);
+  return acc;
+}
+
 // One wavefront per slice, one row per lane, 4 slices per 256-thread block.
 //   NT      : record / y traffic marked non-temporal so it does not evict x from L2 (+15 %).
 //   DOT     : epilogue writes per-block partials of <w, y> and <y, y> (fused reductions).
@@ -189,6 +235,12 @@ __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SellArgs A, Scal alph
   // test it after the gathers, so it never sits at the head of a wave's dependency chain.
   const int done_flag = done ? *done : 0;
   __shared__ double xwin[VARIANT == 1 ? kBlock : 1];
+  __shared__ double dict_s[VARIANT == 2 ? kDictSize : 1];
+  if (VARIANT == 2) {
+    static_assert(kDictSize == kBlock, "one dictionary entry per thread");
+    dict_s[threadIdx.x] = A.dict[threadIdx.x];
+    __syncthreads();
+  }
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: slice math runs on the SALU
   const int bidx = (int)blockIdx.x;
@@ -218,18 +270,34 @@ __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SellArgs A, Scal alph
     __syncthreads();
   }
   if (wave_active) {
+    constexpr int kSlot = (VARIANT == 2) ? kColSlotBytes : kSlotBytes;
     int64_t base;
     int width;
     if (A.uniform_width > 0) {
       width = A.uniform_width;
-      base = slice * (int64_t)(kExtBytes + kSlotBytes * width);
+      base = slice * (int64_t)(kExtBytes + kSlot * width);
     } else {
       base = A.slice_off[slice];
-      width = (int)((A.slice_off[slice + 1] - base - kExtBytes) / kSlotBytes);
+      width = (int)((A.slice_off[slice + 1] - base - kExtBytes) / kSlot);
     }
     const char *rec = A.pack + base;
-    const double ext = ld_d<NT>(reinterpret_cast<const double *>(rec) + lane);
-    double acc;
+    double ext, acc;
+    if (VARIANT == 2) {
+      const uint64_t *ip = reinterpret_cast<const uint64_t *>(rec) + lane;
+      const uint64_t iw = NT ? __builtin_nontemporal_load(ip) : *ip;
+      ext = dict_s[(unsigned)iw & 0xffu];
+      switch (width) {  // build_op guarantees width <= 7 for these records
+        case 0: acc = 0.0; break;
+        case 1: acc = row_sum_cv<NT, 1>(rec, 1, lane, x, xi, iw, dict_s); break;
+        case 2: acc = row_sum_cv<NT, 2>(rec, 2, lane, x, xi, iw, dict_s); break;
+        case 3: acc = row_sum_cv<NT, 3>(rec, 3, lane, x, xi, iw, dict_s); break;
+        case 4: acc = row_sum_cv<NT, 4>(rec, 4, lane, x, xi, iw, dict_s); break;
+        case 5: acc = row_sum_cv<NT, 5>(rec, 5, lane, x, xi, iw, dict_s); break;
+        case 6: acc = row_sum_cv<NT, 6>(rec, 6, lane, x, xi, iw, dict_s); break;
+        default: acc = row_sum_cv<NT, 7>(rec, 7, lane, x, xi, iw, dict_s); break;
+      }
+    } else {
+    ext = ld_d<NT>(reinterpret_cast<const double *>(rec) + lane);
     // The width is wave-uniform: dispatch to a body with the width as a compile-time constant,
     // so all (col, val) loads of the row are issued back to back, then all gathers, then the
     // FMAs -- no branch (and no s_waitcnt) between the gathers of one row.
@@ -244,6 +312,7 @@ __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SellArgs A, Scal alph
       case 7: acc = row_sum<NT, VARIANT, 7>(rec, 7, lane, x, xi, xwin, row0); break;
       case 8: acc = row_sum<NT, VARIANT, 8>(rec, 8, lane, x, xi, xwin, row0); break;
       default: acc = row_sum_wide<NT, VARIANT>(rec, width, lane, x, xi, xwin, row0); break;
+    }
     }
     yi = beta * xi + alpha * (acc + ext * xi);
     if (valid && !done_flag) {
@@ -265,6 +334,116 @@ __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SellArgs A, Scal alph
       const int slot = dot.block_offset + (int)blockIdx.x * (kBlock / kWave) + wave;
       dot.partials[slot] = a;
       if (dot.yy) dot.partials[dot.nblocks_total + slot] = b;
+    }
+  }
+}
+
+// Value-dictionary records of one uniform width W: SPW consecutive slices per wavefront.
+// Compared with the general kernel above: (i) every wave keeps its own copy of the dictionary in LDS
+// (written and read by the same wave: no block barrier between the record loads and the lookups);
+// (ii) all record loads of the wave's SPW slices are issued first, then all SPW x W gathers, then
+// the lookups and FMAs -- with half the bytes per row the kernel is bound by memory-level
+// parallelism per wave rather than by HBM, and a wave with one slice had too little in flight;
+// (iii) one fused-dot partial per wave covers SPW slices.
+// FMT 1: [idx u64][columns i32] records; FMT 2: one 16-byte word per row, columns = row + offs[byte].
+template <bool DOT, int W, int SPW, int FMT>
+__global__ __launch_bounds__(kBlock) void spmv_dict_kernel(SellArgs A, Scal alpha_s, Scal beta_s,
+                                                           const double *__restrict__ x, double *__restrict__ y,
+                                                           const int *__restrict__ slice_list,
+                                                           int64_t n_launch_slices, DotArgs dot, const int *done) {
+  constexpr int NP = W / 2;
+  constexpr int64_t kRec = FMT == 2 ? (int64_t)kWave * 16 : kExtBytes + (int64_t)kColSlotBytes * W;
+  const int done_flag = done ? *done : 0;
+  __shared__ double dict_s[kBlock / kWave][kDictSize];
+  __shared__ int offs_s[FMT == 2 ? kBlock / kWave : 1][FMT == 2 ? kDictSize : 1];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double *dw = dict_s[wave];
+  for (int e = lane; e < A.dict_size; e += kWave) dw[e] = A.dict[e];
+  int *ow = offs_s[FMT == 2 ? wave : 0];
+  if (FMT == 2)
+    for (int e = lane; e < A.offs_size; e += kWave) ow[e] = A.offs[e];
+  const int bidx = (int)blockIdx.x;
+  const int lb = A.xcd_group > 1 ? xcd_remap_grouped(bidx, gridDim.x, A.xcd_group)
+                                 : (A.xcd_group == 1 ? xcd_remap(bidx, gridDim.x) : bidx);
+  const int64_t sl0 = ((int64_t)lb * (kBlock / kWave) + wave) * SPW;
+  const double alpha = ld_scal2(alpha_s), beta = ld_scal2(beta_s);
+
+  uint64_t iw[SPW], jw[SPW];
+  int2v c[SPW][NP > 0 ? NP : 1];
+  int ct[SPW];
+  double xi[SPW], wi[SPW];
+  int64_t row[SPW];
+  bool valid[SPW];
+#pragma unroll
+  for (int u = 0; u < SPW; ++u) {
+    const int64_t sl = sl0 + u;
+    const bool active = sl < n_launch_slices;  // wave-uniform
+    const int64_t slice = active ? (slice_list ? (int64_t)slice_list[sl] : sl) : 0;
+    row[u] = slice * kWave + lane;
+    valid[u] = active && row[u] < A.n_rows;
+    const char *rec = A.pack + slice * kRec;
+    ct[u] = 0;
+    jw[u] = 0;
+    if (FMT == 2) {
+      typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+      const u64x2 word = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(rec) + lane);
+      iw[u] = word.x, jw[u] = word.y;
+    } else {
+      iw[u] = __builtin_nontemporal_load(reinterpret_cast<const uint64_t *>(rec) + lane);
+      const int2v *cp2 = reinterpret_cast<const int2v *>(rec + kExtBytes) + lane;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) c[u][q] = __builtin_nontemporal_load(cp2 + q * kWave);
+      if (W & 1)
+        ct[u] = __builtin_nontemporal_load(reinterpret_cast<const int *>(rec + kExtBytes + NP * (kWave * 8)) + lane);
+    }
+    xi[u] = valid[u] ? x[row[u]] : 0.0;
+    wi[u] = 0.0;
+    if (DOT && dot.w) wi[u] = (dot.w == x) ? xi[u] : (valid[u] ? dot.w[row[u]] : 0.0);
+  }
+  double xg[SPW][W > 0 ? W : 1];
+  if (FMT == 2) __builtin_amdgcn_wave_barrier();  // the wave's offset table is complete (same-wave LDS order)
+#pragma unroll
+  for (int u = 0; u < SPW; ++u) {
+    if (FMT == 2) {
+      // a padding slot has offset 0 (its own row) and weight 0; an out-of-range row reads row 0's word
+      const double *xr = x + (valid[u] ? row[u] : 0);
+#pragma unroll
+      for (int k = 0; k < W; ++k) xg[u][k] = xr[valid[u] ? ow[(unsigned)(jw[u] >> (8 * k)) & 0xffu] : 0];
+    } else {
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        xg[u][2 * q] = x[c[u][q].x];
+        xg[u][2 * q + 1] = x[c[u][q].y];
+      }
+      if (W & 1) xg[u][W - 1] = x[ct[u]];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();  // the wave's dictionary copy is complete (same-wave LDS order)
+  double da = 0.0, db = 0.0;
+#pragma unroll
+  for (int u = 0; u < SPW; ++u) {
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) acc += dw[(unsigned)(iw[u] >> (8 * (k + 1))) & 0xffu] * (xg[u][k] - xi[u]);
+    const double ext = dw[(unsigned)iw[u] & 0xffu];
+    double yi = beta * xi[u] + alpha * (acc + ext * xi[u]);
+    if (valid[u] && !done_flag) __builtin_nontemporal_store(yi, y + row[u]);
+    if (!valid[u]) yi = 0.0;
+    if (DOT) {
+      da += wi[u] * yi;
+      db += yi * yi;
+    }
+  }
+  if (done_flag) return;
+  if (DOT) {
+    double a = dot.w ? da : 0.0;
+    a = wave_sum_to_lane63(a);
+    if (dot.yy) db = wave_sum_to_lane63(db);
+    if (lane == kWave - 1) {
+      const int slot = dot.block_offset + (int)blockIdx.x * (kBlock / kWave) + wave;
+      dot.partials[slot] = a;
+      if (dot.yy) dot.partials[dot.nblocks_total + slot] = db;
     }
   }
 }
@@ -296,7 +475,9 @@ template <bool NT, bool DOT, int VARIANT>
 static void launch_sell(const storm_hip_op *op, int nb, Scal alpha, Scal beta, const double *x, double *y,
                         const int *slice_list, int64_t n_launch, DotArgs dot, const int *done, hipEvent_t ev0,
                         hipEvent_t ev1) {
-  SellArgs A{op->d_pack, op->d_slice_off, op->n_rows, op->uniform_width, (int)op->ctx->opt_spmv_xcd_remap};
+  SellArgs A{op->d_pack, op->d_slice_off, op->n_rows, op->uniform_width, (int)op->ctx->opt_spmv_xcd_remap, op->d_dict, op->dict_size,
+             op->d_offs, op->offs_size};
+  constexpr int LV = (VARIANT == 2) ? 2 : 0;  // listed slices: no LDS window, but the record format stays
   hipStream_t st = op->ctx->stream;
   if (slice_list == nullptr && op->ctx->opt_spmv_xcd_remap != 0) {
     hipExtLaunchKernelGGL((spmv_sell_kernel<NT, DOT, VARIANT, true>), dim3(nb), dim3(kBlock), 0, st, ev0, ev1, 0, A, alpha,
@@ -307,15 +488,52 @@ static void launch_sell(const storm_hip_op *op, int nb, Scal alpha, Scal beta, c
   } else if (op->ctx->opt_spmv_xcd_remap != 0) {
     // listed slices (interior / boundary sets of a partitioned operator): the LDS window does not
     // apply, the XCD grouping still does -- the interior list is consecutive but for a few gaps
-    hipExtLaunchKernelGGL((spmv_sell_kernel<NT, DOT, 0, true>), dim3(nb), dim3(kBlock), 0, st, ev0, ev1, 0, A, alpha, beta,
+    hipExtLaunchKernelGGL((spmv_sell_kernel<NT, DOT, LV, true>), dim3(nb), dim3(kBlock), 0, st, ev0, ev1, 0, A, alpha, beta,
                        x, y, slice_list, n_launch, dot, done);
   } else {
-    hipExtLaunchKernelGGL((spmv_sell_kernel<NT, DOT, 0, false>), dim3(nb), dim3(kBlock), 0, st, ev0, ev1, 0, A, alpha, beta,
+    hipExtLaunchKernelGGL((spmv_sell_kernel<NT, DOT, LV, false>), dim3(nb), dim3(kBlock), 0, st, ev0, ev1, 0, A, alpha, beta,
                        x, y, slice_list, n_launch, dot, done);
   }
 }
 
-static inline int blocks_for(int64_t n_launch_slices) { return (int)((n_launch_slices + 3) / 4); }
+// Slices per wave: SPW for the uniform-width value-dictionary kernel, 1 otherwise.
+static inline int op_spw(const storm_hip_op *op) {
+  return (op->dict_size > 0 && op->uniform_width > 0) ? (int)op->spw : 1;
+}
+static inline int blocks_for(const storm_hip_op *op, int64_t n_launch_slices) {
+  const int64_t per_block = (kBlock / kWave) * op_spw(op);
+  return (int)((n_launch_slices + per_block - 1) / per_block);
+}
+
+template <bool DOT, int SPW>
+static void launch_dict(const storm_hip_op *op, int nb, Scal alpha, Scal beta, const double *x, double *y,
+                        const int *slice_list, int64_t n_launch, DotArgs dot, const int *done, hipEvent_t ev0,
+                        hipEvent_t ev1) {
+  // slice lists (interior / boundary sets) are not contiguous: no XCD grouping there
+  const int group = slice_list ? 0 : (int)op->ctx->opt_spmv_xcd_remap;
+  SellArgs A{op->d_pack, op->d_slice_off, op->n_rows, op->uniform_width, group, op->d_dict, op->dict_size,
+             op->d_offs, op->offs_size};
+  hipStream_t st = op->ctx->stream;
+#define DICT_GO(W_)                                                                                                 \
+  do {                                                                                                              \
+    if (op->offs_size > 0)                                                                                          \
+      hipExtLaunchKernelGGL((spmv_dict_kernel<DOT, W_, SPW, 2>), dim3(nb), dim3(kBlock), 0, st, ev0, ev1, 0, A,     \
+                            alpha, beta, x, y, slice_list, n_launch, dot, done);                                    \
+    else                                                                                                            \
+      hipExtLaunchKernelGGL((spmv_dict_kernel<DOT, W_, SPW, 1>), dim3(nb), dim3(kBlock), 0, st, ev0, ev1, 0, A,     \
+                            alpha, beta, x, y, slice_list, n_launch, dot, done);                                    \
+  } while (0)
+  switch (op->uniform_width) {
+    case 1: DICT_GO(1); break;
+    case 2: DICT_GO(2); break;
+    case 3: DICT_GO(3); break;
+    case 4: DICT_GO(4); break;
+    case 5: DICT_GO(5); break;
+    case 6: DICT_GO(6); break;
+    default: DICT_GO(7); break;
+  }
+#undef DICT_GO
+}
 
 static int launch_range(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, double *y,
                         const int *slice_list, int64_t n_launch, DotArgs dot, bool want_dot,
@@ -334,8 +552,21 @@ static int launch_range(const storm_hip_op *op, Scal alpha, Scal beta, const dou
     // stamped at the kernel's begin and end, the quantity rocprofv3's kernel trace reports
     ev0 = c->prof_events[c->prof_used], ev1 = c->prof_events[c->prof_used + 1];
   }
-  const int nb = blocks_for(n_launch);
+  const int nb = blocks_for(op, n_launch);
   const bool nt = c->opt_nt != 0;
+  if (op_spw(op) >= 1 && op->dict_size > 0 && op->uniform_width > 0) {
+    switch (op_spw(op)) {
+      case 1: if (want_dot) launch_dict<true, 1>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1);
+              else launch_dict<false, 1>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1); break;
+      case 2: if (want_dot) launch_dict<true, 2>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1);
+              else launch_dict<false, 2>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1); break;
+      default: if (want_dot) launch_dict<true, 4>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1);
+               else launch_dict<false, 4>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1); break;
+    }
+    HIP_TRY(hipGetLastError());
+    if (prof) c->prof_used += 2;
+    return STORM_HIP_OK;
+  }
 #define SPMV_GO(NT_, DOT_, VAR_) \
   launch_sell<NT_, DOT_, VAR_>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1)
 #define SPMV_VAR(VAR_)                                                                      \
@@ -343,7 +574,8 @@ static int launch_range(const storm_hip_op *op, Scal alpha, Scal beta, const dou
     if (nt) { if (want_dot) SPMV_GO(true, true, VAR_); else SPMV_GO(true, false, VAR_); }   \
     else    { if (want_dot) SPMV_GO(false, true, VAR_); else SPMV_GO(false, false, VAR_); } \
   } while (0)
-  if (c->opt_spmv_variant == 1) SPMV_VAR(1);
+  if (op->dict_size > 0) SPMV_VAR(2);
+  else if (c->opt_spmv_variant == 1) SPMV_VAR(1);
   else SPMV_VAR(0);
 #undef SPMV_VAR
 #undef SPMV_GO
@@ -352,7 +584,7 @@ static int launch_range(const storm_hip_op *op, Scal alpha, Scal beta, const dou
   return STORM_HIP_OK;
 }
 
-int spmv_grid_blocks(const storm_hip_op *op) { return blocks_for(op->n_slices); }
+int spmv_grid_blocks(const storm_hip_op *op) { return blocks_for(op, op->n_slices); }
 
 int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, double *y,
                 const SpmvDot *sd, const int *done) {
@@ -362,8 +594,8 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
                 "operator has a halo plan but the context has no communicator (call storm_hip_ctx_comm_init)");
   const bool split = op->halo.n_nbrs > 0;
   DotArgs dot{nullptr, nullptr, 0, 0, 0};
-  const int nb_int = split ? blocks_for(op->n_interior) : spmv_grid_blocks(op);
-  const int nb_bnd = split ? blocks_for(op->n_boundary) : 0;
+  const int nb_int = split ? blocks_for(op, op->n_interior) : spmv_grid_blocks(op);
+  const int nb_bnd = split ? blocks_for(op, op->n_boundary) : 0;
   const int nb_total = nb_int + nb_bnd;
   if (fuse_dot) {
     STORM_REQUIRE(8 * (int64_t)nb_total <= c->partials_capacity,
@@ -397,12 +629,21 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
 // slots carry w = 0).  One lane per row, same slot addressing as build_op; not a hot kernel.
 __global__ __launch_bounds__(kBlock) void diag_sell_kernel(const char *__restrict__ pack,
                                                            const int64_t *__restrict__ slice_off, int64_t n_rows,
-                                                           double alpha, double beta, double *__restrict__ d) {
+                                                           const double *__restrict__ dict, int fmt2, double alpha,
+                                                           double beta, double *__restrict__ d) {
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t s = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
   const int64_t r = s * kWave + lane;
   if (r >= n_rows) return;
   const char *rec = pack + slice_off[s];
+  if (dict) {  // value-dictionary record (format 2: 16-byte words, weights in bytes 1..7 of the first half)
+    const int w = fmt2 ? 7 : (int)((slice_off[s + 1] - slice_off[s] - kExtBytes) / kColSlotBytes);
+    const uint64_t iw = reinterpret_cast<const uint64_t *>(rec)[fmt2 ? 2 * lane : lane];
+    double sum = 0.0;
+    for (int k = 0; k < w; ++k) sum += dict[(unsigned)(iw >> (8 * (k + 1))) & 0xffu];
+    d[r] = beta + alpha * (dict[(unsigned)iw & 0xffu] - sum);
+    return;
+  }
   const int w = (int)((slice_off[s + 1] - slice_off[s] - kExtBytes) / kSlotBytes);
   const double *val = reinterpret_cast<const double *>(rec + kExtBytes + (int64_t)w * (kWave * 4));
   const int np2 = w >> 1;
@@ -445,6 +686,37 @@ static int upload(T **dst, const std::vector<T> &src, int64_t *bytes) {
   return STORM_HIP_OK;
 }
 
+// The distinct fp64 bit patterns of an operator, while there are at most 256 of them.
+struct ValueDict {
+  std::vector<uint64_t> values;               // index -> bit pattern
+  std::vector<std::pair<uint64_t, int>> tab;  // open-addressing hash, 1024 buckets
+  uint64_t last_bits = ~0ull;
+  int last_idx = -1;
+  ValueDict() : tab(1024, {0, -1}) {}
+  static uint64_t bits(double v) {
+    uint64_t b;
+    memcpy(&b, &v, 8);
+    return b;
+  }
+  int find(uint64_t b, bool insert) {
+    if (b == last_bits) return last_idx;
+    size_t h = (size_t)((b * 0x9E3779B97F4A7C15ull) >> 54);
+    for (;; h = (h + 1) & 1023) {
+      if (tab[h].second < 0) {
+        if (!insert || values.size() >= (size_t)kDictSize) return -1;
+        tab[h] = {b, (int)values.size()};
+        values.push_back(b);
+      }
+      if (tab[h].first == b && tab[h].second >= 0) {
+        last_bits = b, last_idx = tab[h].second;
+        return last_idx;
+      }
+    }
+  }
+  bool add(double v) { return find(bits(v), true) >= 0; }
+  int index(double v) { return find(bits(v), false); }
+};
+
 // Build from off-diagonal CSR rows (entries already in the order they must be summed).
 static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vector<int64_t> &row_ptr,
                     const std::vector<int> &col, const std::vector<double> &val,
@@ -465,6 +737,26 @@ static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vect
     const double mean = n > 0 ? (double)op->nnz / (double)n : 0.0;
     cap = std::max<int64_t>(8, (int64_t)std::ceil(2.0 * mean));
   }
+  // Value dictionary (see the header comment): lossless, so taken whenever the operator qualifies.
+  ValueDict vd;
+  bool cv = c->opt_spmv_dict != 0 && std::min(max_len, cap) <= 7;
+  if (cv) {
+    cv = vd.add(0.0);  // padding slots
+    for (int64_t i = 0; cv && i < n; ++i) cv = vd.add(ext[(size_t)i]);
+    for (size_t k = 0; cv && k < val.size(); ++k) cv = vd.add(val[k]);
+  }
+  // ... and the column offsets of the ELL part (format 2)
+  const int64_t w_op = std::min(max_len, cap);
+  ValueDict od;
+  bool co = cv && c->opt_spmv_dict >= 2 && w_op > 0 && n + n_halo < (int64_t)INT32_MAX;
+  if (co) {
+    co = od.find(0, true) >= 0;  // padding slots point at their own row
+    for (int64_t r = 0; co && r < n; ++r) {
+      const int64_t e = std::min(row_ptr[r + 1], row_ptr[r] + w_op);
+      for (int64_t k = row_ptr[r]; co && k < e; ++k) co = od.find((uint64_t)((int64_t)col[(size_t)k] - r), true) >= 0;
+    }
+  }
+  const int64_t slot_bytes = cv ? kColSlotBytes : kSlotBytes;
   std::vector<int64_t> slice_off(n_slices + 1, 0);  // bytes
   std::vector<int> width(n_slices, 0);
   bool uniform = true;
@@ -473,8 +765,9 @@ static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vect
     const int64_t r1 = std::min<int64_t>(n, (s + 1) * kWave);
     for (int64_t r = s * kWave; r < r1; ++r) w = std::max(w, row_ptr[r + 1] - row_ptr[r]);
     w = std::min(w, cap);
+    if (co) w = w_op;  // 16-byte words: every slice is padded to the operator's width
     width[s] = (int)w;
-    slice_off[s + 1] = slice_off[s] + kExtBytes + w * kSlotBytes;
+    slice_off[s + 1] = slice_off[s] + (co ? (int64_t)kWave * 16 : kExtBytes + w * slot_bytes);
     if (s > 0 && width[s] != width[0]) uniform = false;
     op->ell_slots += w * kWave;
   }
@@ -486,6 +779,7 @@ static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vect
   for (int64_t s = 0; s < n_slices; ++s) {
     char *rec = pack.data() + slice_off[s];
     double *e_ = reinterpret_cast<double *>(rec);
+    uint64_t *i_ = reinterpret_cast<uint64_t *>(rec);  // cv: the index words take the place of ext
     int *c_ = reinterpret_cast<int *>(rec + kExtBytes);
     double *v_ = reinterpret_cast<double *>(rec + kExtBytes + (int64_t)width[s] * (kWave * 4));
     bool touches_halo = false;
@@ -493,21 +787,31 @@ static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vect
       const int64_t r = s * kWave + l;
       const int64_t pad_col = r < n ? r : (n > 0 ? n - 1 : 0);
       const int64_t b = r < n ? row_ptr[r] : 0, e = r < n ? row_ptr[r + 1] : 0;
-      e_[l] = r < n ? ext[(size_t)r] : 0.0;
+      uint64_t iw = 0, jw = 0;
+      if (cv) iw = (uint64_t)vd.index(r < n ? ext[(size_t)r] : 0.0);
+      else e_[l] = r < n ? ext[(size_t)r] : 0.0;
+      if (co) {
+        for (int k = 0; k < width[s]; ++k) {
+          const bool real = b + k < e;
+          iw |= (uint64_t)vd.index(real ? val[(size_t)(b + k)] : 0.0) << (8 * (k + 1));
+          jw |= (uint64_t)od.find(real ? (uint64_t)((int64_t)col[(size_t)(b + k)] - r) : 0, false) << (8 * k);
+          touches_halo |= real && col[(size_t)(b + k)] >= n;
+        }
+        i_[2 * l] = iw, i_[2 * l + 1] = jw;
+      }
       const int np2 = width[s] >> 1;
-      for (int k = 0; k < width[s]; ++k) {
+      for (int k = 0; k < (co ? 0 : width[s]); ++k) {
         // slots are stored in pairs: lane l reads (slot 2p, slot 2p+1) as one 8-byte column pair and
         // one 16-byte weight pair; an odd last slot is stored column-major behind the pairs
         const int at = (k < 2 * np2) ? ((k >> 1) * kWave + l) * 2 + (k & 1) : np2 * 2 * kWave + l;
-        if (b + k < e) {
-          c_[at] = col[(size_t)(b + k)];
-          v_[at] = val[(size_t)(b + k)];
-          touches_halo |= c_[at] >= n;
-        } else {
-          c_[at] = (int)pad_col;
-          v_[at] = 0.0;
-        }
+        const bool real = b + k < e;
+        c_[at] = real ? col[(size_t)(b + k)] : (int)pad_col;
+        const double w_k = real ? val[(size_t)(b + k)] : 0.0;
+        if (cv) iw |= (uint64_t)vd.index(w_k) << (8 * (k + 1));
+        else v_[at] = w_k;
+        touches_halo |= real && c_[at] >= n;
       }
+      if (cv && !co) i_[l] = iw;
       if (e - b > width[s]) {
         tail_row.push_back((int)r);
         for (int64_t k = b + width[s]; k < e; ++k) {
@@ -526,6 +830,26 @@ static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vect
 
   int st = STORM_HIP_OK;
   int64_t bytes = 0;
+  if (cv) {
+    std::vector<double> table((size_t)kDictSize, 0.0);
+    for (size_t k = 0; k < vd.values.size(); ++k) memcpy(&table[k], &vd.values[k], 8);
+    op->dict_size = (int)vd.values.size();
+    if ((st = upload(&op->d_dict, table, &bytes))) {
+      storm_hip_op_destroy(op);
+      return st;
+    }
+  }
+  if (co) {
+    std::vector<int> table((size_t)kDictSize, 0);
+    for (size_t k = 0; k < od.values.size(); ++k) table[k] = (int)(int64_t)od.values[k];
+    op->offs_size = (int)od.values.size();
+    if ((st = upload(&op->d_offs, table, &bytes))) {
+      storm_hip_op_destroy(op);
+      return st;
+    }
+  }
+  op->pack_bytes = (int64_t)pack.size();
+  op->spw = (c->opt_spmv_spw == 1 || c->opt_spmv_spw == 2 || c->opt_spmv_spw == 4) ? c->opt_spmv_spw : 2;
   if ((st = upload(&op->d_slice_off, slice_off, &bytes)) || (st = upload(&op->d_pack, pack, &bytes)) ||
       (st = upload(&op->d_tail_row, tail_row, &bytes)) || (st = upload(&op->d_tail_ptr, tail_ptr, &bytes)) ||
       (st = upload(&op->d_tail_col, tail_col, &bytes)) || (st = upload(&op->d_tail_val, tail_val, &bytes))) {
@@ -534,7 +858,7 @@ static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vect
   }
   op->device_bytes = bytes;
   // fused-dot partials: two per SpMV block
-  const int64_t need = 8 * (int64_t)blocks_for(n_slices) + 16 + 2 * kMaxMulti;
+  const int64_t need = 8 * ((n_slices + 3) / 4) + 16 + 2 * kMaxMulti;
   if (need > c->partials_capacity) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     double *bigger = nullptr;
@@ -691,7 +1015,7 @@ int storm_hip_op_get_diagonal(const storm_hip_op *op, double alpha, double beta,
   HIP_TRY(hipSetDevice(c->device));
   const int nb = (int)((op->n_slices + (kBlock / kWave) - 1) / (kBlock / kWave));
   hipLaunchKernelGGL(diag_sell_kernel, dim3(nb), dim3(kBlock), 0, c->stream, op->d_pack, op->d_slice_off, op->n_rows,
-                     alpha, beta, d->d);
+                     op->d_dict, (int)(op->offs_size > 0), alpha, beta, d->d);
   if (op->tail_rows > 0)
     hipLaunchKernelGGL(diag_tail_kernel, dim3((int)((op->tail_rows + 255) / 256)), dim3(256), 0, c->stream,
                        op->tail_rows, op->d_tail_row, op->d_tail_ptr, op->d_tail_val, alpha, d->d);
@@ -714,6 +1038,9 @@ int storm_hip_op_get_stats(const storm_hip_op *op, storm_hip_op_stats *s) {
   s->max_row_len = op->max_row_len;
   s->n_interior_slices = op->n_interior_slices;
   s->device_bytes = op->device_bytes;
+  s->record_bytes = op->pack_bytes;
+  s->value_dictionary_size = op->dict_size;
+  s->offset_dictionary_size = op->offs_size;
   return STORM_HIP_OK;
 }
 
@@ -724,6 +1051,8 @@ int storm_hip_op_destroy(storm_hip_op *op) {
   (void)hipFree(op->d_boundary);
   (void)hipFree(op->d_slice_off);
   (void)hipFree(op->d_pack);
+  (void)hipFree(op->d_dict);
+  (void)hipFree(op->d_offs);
   (void)hipFree(op->d_tail_row);
   (void)hipFree(op->d_tail_ptr);
   (void)hipFree(op->d_tail_col);
