@@ -181,6 +181,9 @@ int storm_hip_op_create_csr(storm_hip_ctx *ctx, int64_t n_rows, int64_t n_halo,
 
 /* Build knobs, set before create (0 = library default):
  *   ell_cap:   rows longer than this spill their remaining entries to the CSR tail;
+ *   pool_bytes: vector storage released by vec_destroy is kept (up to this many bytes, default
+ *              16 GiB) for the next vec_create of the same size, so the work vectors a solve
+ *              allocates on entry cost nothing from the second solve on; 0 frees immediately;
  *   spmv_dict: >= 1 stores the weights of an operator whose ext / weight values take at most 256
  *              distinct fp64 bit patterns (and whose rows have at most 7 neighbours) as byte indices
  *              into that dictionary -- lossless, half the bytes per row; 2 (default) does the same

@@ -102,6 +102,13 @@ struct storm_hip_ctx {
   int64_t opt_blas1_nt = 1;  // non-temporal loads/stores in the streaming kernels
   int64_t opt_graph = 0;     // replay CG / BiCGStab iterations from a captured hipGraph: measured slower than eager launches (profiles/r01_notes.md), off
   int64_t opt_fuse_dot = 1;  // 0: reductions after an SpMV run as separate kernels (A/B knob)
+  // Vector storage released by vec_destroy, kept for the next vec_create of the same size: a solve
+  // allocates its work vectors on entry and frees them on return (the reference re-assigns them in
+  // every init, SolverCg.hpp:57-59); hipMalloc + hipFree of three 134 MB vectors cost ~7 ms per solve.
+  // Reuse is ordered by the compute stream.  Bounded by opt_pool_bytes; freed with the context.
+  std::vector<std::pair<size_t, double *>> pool;
+  size_t pool_bytes = 0;
+  int64_t opt_pool_bytes = (int64_t)16 << 30;
   std::vector<hipEvent_t> prof_events;  // pairs (start, stop), grown on demand
   size_t prof_used = 0;
   // communicator
@@ -113,6 +120,7 @@ struct storm_hip_vec {
   storm_hip_ctx *ctx = nullptr;
   int64_t n_owned = 0, n_halo = 0;
   double *d = nullptr;
+  size_t bytes = 0;  // allocation size (pool key)
 };
 
 namespace storm {

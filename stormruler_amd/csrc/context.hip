@@ -76,6 +76,7 @@ int storm_hip_ctx_destroy(storm_hip_ctx *c) {
   comm_destroy(c);
   for (auto &ev : c->ev_ring) (void)hipEventDestroy(ev);
   for (auto &ev : c->prof_events) (void)hipEventDestroy(ev);
+  for (auto &pb : c->pool) (void)hipFree(pb.second);
   (void)hipFree(c->d_partials);
   (void)hipFree(c->d_partials2);
   (void)hipFree(c->d_scalars);
@@ -119,6 +120,14 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "nontemporal")) c->opt_nt = value;
   else if (!strcmp(key, "spmv_xcd_remap")) c->opt_spmv_xcd_remap = value;
   else if (!strcmp(key, "spmv_dict")) c->opt_spmv_dict = value;
+  else if (!strcmp(key, "pool_bytes")) {
+    c->opt_pool_bytes = value;
+    if ((int64_t)c->pool_bytes > value) {  // trim now
+      (void)hipStreamSynchronize(c->stream);
+      for (auto &pb : c->pool) (void)hipFree(pb.second);
+      c->pool.clear(), c->pool_bytes = 0;
+    }
+  }
   else if (!strcmp(key, "spmv_spw")) c->opt_spmv_spw = value;
   else if (!strcmp(key, "profile_spmv")) c->opt_profile_spmv = value;
   else if (!strcmp(key, "fuse_dot")) c->opt_fuse_dot = value;
@@ -174,7 +183,26 @@ int storm_hip_vec_create(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, stor
   v->n_halo = n_halo;
   // Round the allocation up so 16-byte vector accesses of the last rows stay in bounds.
   const size_t bytes = sizeof(double) * (size_t)((n_owned + n_halo + 3) / 4 * 4 + 4);
-  hipError_t e = hipMalloc(&v->d, bytes);
+  v->bytes = bytes;
+  hipError_t e = hipSuccess;
+  for (size_t i = 0; i < c->pool.size(); ++i) {
+    if (c->pool[i].first == bytes) {
+      v->d = c->pool[i].second;
+      c->pool_bytes -= bytes;
+      c->pool[i] = c->pool.back();
+      c->pool.pop_back();
+      break;
+    }
+  }
+  if (v->d == nullptr) {
+    e = hipMalloc(&v->d, bytes);
+    if (e != hipSuccess && !c->pool.empty()) {  // give the pooled storage back and retry
+      (void)hipStreamSynchronize(c->stream);
+      for (auto &pb : c->pool) (void)hipFree(pb.second);
+      c->pool.clear(), c->pool_bytes = 0;
+      e = hipMalloc(&v->d, bytes);
+    }
+  }
   if (e != hipSuccess) {
     delete v;
     STORM_FAIL(STORM_HIP_E_ALLOC, "vec_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
@@ -197,8 +225,16 @@ int storm_hip_vec_create_like(const storm_hip_vec *other, storm_hip_vec **out) {
 
 int storm_hip_vec_destroy(storm_hip_vec *v) {
   if (!v) return STORM_HIP_OK;
-  (void)hipStreamSynchronize(v->ctx->stream);
-  (void)hipFree(v->d);
+  storm_hip_ctx *c = v->ctx;
+  if (v->d && (int64_t)(c->pool_bytes + v->bytes) <= c->opt_pool_bytes) {
+    // later users of this storage are ordered behind its pending kernels by the compute stream; the
+    // comm stream only touches a vector between two events of one SpMV (comm.hip)
+    c->pool.emplace_back(v->bytes, v->d);
+    c->pool_bytes += v->bytes;
+  } else {
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(v->d);
+  }
   delete v;
   return STORM_HIP_OK;
 }

@@ -346,6 +346,8 @@ __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SellArgs A, Scal alph
 // parallelism per wave rather than by HBM, and a wave with one slice had too little in flight;
 // (iii) one fused-dot partial per wave covers SPW slices.
 // FMT 1: [idx u64][columns i32] records; FMT 2: one 16-byte word per row, columns = row + offs[byte].
+// Branch-free but for the store: rows past the end (ragged last slice) and slices past the launch are
+// redirected to valid memory (row n-1, slice 0) and masked at the store / in the partials.
 template <bool DOT, int W, int SPW, int FMT>
 __global__ __launch_bounds__(kBlock) void spmv_dict_kernel(SellArgs A, Scal alpha_s, Scal beta_s,
                                                            const double *__restrict__ x, double *__restrict__ y,
@@ -359,15 +361,15 @@ __global__ __launch_bounds__(kBlock) void spmv_dict_kernel(SellArgs A, Scal alph
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double *dw = dict_s[wave];
-  for (int e = lane; e < A.dict_size; e += kWave) dw[e] = A.dict[e];
   int *ow = offs_s[FMT == 2 ? wave : 0];
-  if (FMT == 2)
-    for (int e = lane; e < A.offs_size; e += kWave) ow[e] = A.offs[e];
   const int bidx = (int)blockIdx.x;
   const int lb = A.xcd_group > 1 ? xcd_remap_grouped(bidx, gridDim.x, A.xcd_group)
                                  : (A.xcd_group == 1 ? xcd_remap(bidx, gridDim.x) : bidx);
   const int64_t sl0 = ((int64_t)lb * (kBlock / kWave) + wave) * SPW;
   const double alpha = ld_scal2(alpha_s), beta = ld_scal2(beta_s);
+  const int64_t last_row = A.n_rows - 1;
+  const bool w_is_x = DOT && dot.w == x;
+  const bool w_load = DOT && dot.w != nullptr && !w_is_x;
 
   uint64_t iw[SPW], jw[SPW];
   int2v c[SPW][NP > 0 ? NP : 1];
@@ -379,9 +381,10 @@ __global__ __launch_bounds__(kBlock) void spmv_dict_kernel(SellArgs A, Scal alph
   for (int u = 0; u < SPW; ++u) {
     const int64_t sl = sl0 + u;
     const bool active = sl < n_launch_slices;  // wave-uniform
-    const int64_t slice = active ? (slice_list ? (int64_t)slice_list[sl] : sl) : 0;
-    row[u] = slice * kWave + lane;
-    valid[u] = active && row[u] < A.n_rows;
+    const int64_t slice = slice_list ? (int64_t)slice_list[active ? sl : 0] : (active ? sl : 0);
+    const int64_t r = slice * kWave + lane;
+    valid[u] = active && r <= last_row;
+    row[u] = r <= last_row ? r : last_row;
     const char *rec = A.pack + slice * kRec;
     ct[u] = 0;
     jw[u] = 0;
@@ -397,19 +400,36 @@ __global__ __launch_bounds__(kBlock) void spmv_dict_kernel(SellArgs A, Scal alph
       if (W & 1)
         ct[u] = __builtin_nontemporal_load(reinterpret_cast<const int *>(rec + kExtBytes + NP * (kWave * 8)) + lane);
     }
-    xi[u] = valid[u] ? x[row[u]] : 0.0;
+    xi[u] = x[row[u]];
     wi[u] = 0.0;
-    if (DOT && dot.w) wi[u] = (dot.w == x) ? xi[u] : (valid[u] ? dot.w[row[u]] : 0.0);
+    if (w_load) wi[u] = dot.w[row[u]];  // (w == x, CG's <p, Ap>, reuses xi at the end: no copy here, a
+  }                                      //  copy would wait for xi in the middle of the load issue)
+  // The wave's own copy of the tables, requested AFTER the record loads (memory returns in order, so
+  // the copy costs no extra round trip).  The tables are allocated with kDictSize entries: the first
+  // 64 are copied unconditionally, the rest under a scalar branch that operators with a handful of
+  // distinct values never take.
+  {
+    const int o0 = FMT == 2 ? A.offs[lane] : 0;
+    const double d0 = A.dict[lane];
+    if (FMT == 2) ow[lane] = o0;
+    dw[lane] = d0;
+    if (A.dict_size > kWave || A.offs_size > kWave) {
+#pragma unroll
+      for (int j = 1; j < kDictSize / kWave; ++j) {
+        if (FMT == 2) ow[lane + j * kWave] = A.offs[lane + j * kWave];
+        dw[lane + j * kWave] = A.dict[lane + j * kWave];
+      }
+    }
   }
   double xg[SPW][W > 0 ? W : 1];
   if (FMT == 2) __builtin_amdgcn_wave_barrier();  // the wave's offset table is complete (same-wave LDS order)
 #pragma unroll
   for (int u = 0; u < SPW; ++u) {
     if (FMT == 2) {
-      // a padding slot has offset 0 (its own row) and weight 0; an out-of-range row reads row 0's word
-      const double *xr = x + (valid[u] ? row[u] : 0);
+      // padding slots (and every slot of a row past the end) carry offset 0 and weight 0
+      const double *xr = x + row[u];
 #pragma unroll
-      for (int k = 0; k < W; ++k) xg[u][k] = xr[valid[u] ? ow[(unsigned)(jw[u] >> (8 * k)) & 0xffu] : 0];
+      for (int k = 0; k < W; ++k) xg[u][k] = xr[ow[(unsigned)(jw[u] >> (8 * k)) & 0xffu]];
     } else {
 #pragma unroll
       for (int q = 0; q < NP; ++q) {
@@ -429,9 +449,9 @@ __global__ __launch_bounds__(kBlock) void spmv_dict_kernel(SellArgs A, Scal alph
     const double ext = dw[(unsigned)iw[u] & 0xffu];
     double yi = beta * xi[u] + alpha * (acc + ext * xi[u]);
     if (valid[u] && !done_flag) __builtin_nontemporal_store(yi, y + row[u]);
-    if (!valid[u]) yi = 0.0;
+    yi = valid[u] ? yi : 0.0;
     if (DOT) {
-      da += wi[u] * yi;
+      da += (w_is_x ? xi[u] : wi[u]) * yi;
       db += yi * yi;
     }
   }

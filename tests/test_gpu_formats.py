@@ -1,0 +1,213 @@
+"""The three record formats of the SpMV (fp64 weights + int32 columns; byte-indexed weights; byte-indexed
+weights and column offsets) are lossless re-encodings: every format must give bit-identical results, the
+library must pick them only when the operator qualifies, and every code path around the kernel (fused dot
+products, slice lists of a partitioned operator, CSR tail, diagonal extraction, ragged last slice, non-uniform
+widths) must hold for each of them."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FORMATS = [(0, 1), (1, 1), (1, 2), (2, 1), (2, 2), (2, 4)]  # (spmv_dict, spmv_spw)
+
+
+@pytest.fixture(scope="module")
+def env():
+    from oracle import oracle
+    from stormruler_amd import api, mesh
+
+    ctx = api.Context(0)
+    ctx.comm_init(api.Context.comm_unique_id(), 1, 0)  # lets the self-halo (periodic) case run
+    yield api, mesh, oracle, ctx
+    ctx.set_option("spmv_dict", 2)
+    ctx.set_option("spmv_spw", 0)
+    ctx.close()
+
+
+def _build(ctx, fmt, make):
+    ctx.set_option("spmv_dict", fmt[0])
+    ctx.set_option("spmv_spw", fmt[1])
+    m = make()
+    ctx.set_option("spmv_dict", 2)
+    ctx.set_option("spmv_spw", 0)
+    return m
+
+
+def _apply(api, ctx, mat, x, n_halo=0, alpha=-0.7, beta=0.3):
+    xv = api.DeviceVector.from_numpy(ctx, x, n_halo=n_halo) if n_halo else api.DeviceVector.from_numpy(ctx, x)
+    yv = api.DeviceVector(ctx, x.size, n_halo) if n_halo else api.DeviceVector(ctx, x.size)
+    mat.apply(alpha, beta, xv, yv)
+    return yv.to_numpy()
+
+
+@pytest.mark.parametrize("shape", [(33, 20, 17), (7, 5, 3), (64, 2, 2), (3, 1, 1)])
+def test_box_all_formats_bitwise_equal_and_match_oracle(env, shape):
+    api, mesh, oracle, ctx = env
+    g = mesh.structured_box(*shape)
+    x = np.sin(0.37 * np.arange(g.n_cells))
+    y_ref = oracle.StencilOperator(g, -0.7, 0.3).apply(x)
+    ys = {}
+    for fmt in FORMATS:
+        mat = _build(ctx, fmt, lambda: api.StencilMatrix.from_face_graph(ctx, g))
+        st = mat.stats()
+        assert (st["value_dictionary_size"] > 0) == (fmt[0] >= 1)
+        assert (st["offset_dictionary_size"] > 0) == (fmt[0] >= 2)
+        if fmt[0] == 2:
+            assert st["record_bytes"] == 1024 * st["n_slices"]  # one 16-byte word per row
+        ys[fmt] = _apply(api, ctx, mat, x)
+        # the diagonal read back from every format is the same
+        d = api.DeviceVector(ctx, g.n_cells)
+        mat.diagonal(-0.7, 0.3, d)
+        ys[fmt + ("d",)] = d.to_numpy()
+        mat.close()
+    for fmt in FORMATS[1:]:
+        assert np.array_equal(ys[fmt], ys[FORMATS[0]]), fmt
+        assert np.array_equal(ys[fmt + ("d",)], ys[FORMATS[0] + ("d",)]), fmt
+    assert np.abs(ys[FORMATS[0]] - y_ref).max() <= 1e-13 * np.abs(y_ref).max()
+
+
+def test_operators_that_do_not_qualify_keep_fp64_records(env):
+    """Distinct weights everywhere (the reference's Triangle mesh; a box with random volumes): no dictionary;
+    a permuted box keeps the value dictionary but has far too many column offsets for the second one."""
+    import os
+
+    api, mesh, oracle, ctx = env
+    from stormruler_amd import io_triangle
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tri = io_triangle.read_triangle(os.path.join(root, "tests", "golden", "mesh", "square_nb.1."))
+    box = mesh.structured_box(12)
+    rng = np.random.default_rng(3)
+    graded = mesh.structured_box(12)
+    graded.volume = graded.volume * (0.5 + rng.random(graded.n_total))
+    scrambled = mesh.permute_cells(box, mesh.random_permutation(box.n_cells))
+    for g, want_v, want_o in ((tri, False, False), (graded, False, False), (scrambled, True, False), (box, True, True)):
+        mat = api.StencilMatrix.from_face_graph(ctx, g)
+        st = mat.stats()
+        assert (st["value_dictionary_size"] > 0) == want_v and (st["offset_dictionary_size"] > 0) == want_o
+        x = np.cos(0.11 * np.arange(g.n_cells))
+        y = _apply(api, ctx, mat, x, alpha=-1.0, beta=0.0)
+        y_ref = oracle.StencilOperator(g, -1.0, 0.0).apply(x)
+        assert np.abs(y - y_ref).max() <= 1e-13 * np.abs(y_ref).max()
+        mat.close()
+
+
+def test_more_than_256_distinct_values_falls_back(env):
+    import scipy.sparse as sp
+
+    api, mesh, oracle, ctx = env
+    n = 4096
+    for distinct, want in ((200, True), (300, False)):
+        vals = 1.0 + (np.arange(n - 1) % distinct) / 1024.0
+        a = sp.diags([vals, vals], [-1, 1], shape=(n, n), format="csr")
+        mat = api.StencilMatrix.from_csr(ctx, a)
+        # ext (row sums) adds its own distinct values; keep them few by checking what was chosen
+        st = mat.stats()
+        if not want:
+            assert st["value_dictionary_size"] == 0
+        x = np.sin(0.37 * np.arange(n))
+        y = _apply(api, ctx, mat, x, alpha=1.0, beta=0.0)
+        assert np.abs(y - a @ x).max() <= 1e-13 * np.abs(a @ x).max()
+        mat.close()
+
+
+def test_non_uniform_widths_and_wide_rows(env):
+    """Value dictionary with slices of different widths (the general kernel's dictionary path), and rows with
+    more than 7 neighbours (no dictionary: an index word holds 7 slots)."""
+    import scipy.sparse as sp
+
+    api, mesh, oracle, ctx = env
+    n = 1000
+    x = np.sin(0.37 * np.arange(n))
+    # rows 0..255: 2 neighbours, rest: 4 neighbours, all weights 1 or 2
+    rows, cols, vals = [], [], []
+    for i in range(n):
+        for o, v in ((-1, 1.0), (1, 1.0)) + (((-7, 2.0), (7, 2.0)) if i >= 256 else ()):
+            if 0 <= i + o < n:
+                rows.append(i), cols.append(i + o), vals.append(v)
+    a = sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
+    ys = {}
+    for fmt in FORMATS:
+        mat = _build(ctx, fmt, lambda: api.StencilMatrix.from_csr(ctx, a))
+        ys[fmt] = _apply(api, ctx, mat, x, alpha=1.0, beta=0.0)
+        if fmt[0] >= 1:
+            assert mat.stats()["value_dictionary_size"] > 0
+        mat.close()
+    for fmt in FORMATS[1:]:
+        assert np.array_equal(ys[fmt], ys[FORMATS[0]]), fmt
+    assert np.abs(ys[FORMATS[0]] - a @ x).max() <= 1e-13 * np.abs(a @ x).max()
+    wide = sp.diags([np.ones(n - abs(o)) for o in range(-5, 6) if o], [o for o in range(-5, 6) if o], format="csr")
+    mat = api.StencilMatrix.from_csr(ctx, wide)
+    assert mat.stats()["value_dictionary_size"] == 0 and mat.stats()["max_row_len"] == 10
+    y = _apply(api, ctx, mat, x, alpha=1.0, beta=0.0)
+    assert np.abs(y - wide @ x).max() <= 1e-13 * np.abs(wide @ x).max()
+    mat.close()
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_csr_tail_with_every_format(env, fmt):
+    api, mesh, oracle, ctx = env
+    g = mesh.structured_box(10, 9, 8)
+    ctx.set_option("ell_cap", 3)
+    mat = _build(ctx, fmt, lambda: api.StencilMatrix.from_face_graph(ctx, g))
+    ctx.set_option("ell_cap", 0)
+    st = mat.stats()
+    assert st["tail_rows"] > 0 and (st["value_dictionary_size"] > 0) == (fmt[0] >= 1)
+    x = np.sin(0.37 * np.arange(g.n_cells))
+    y_ref = oracle.StencilOperator(g, -0.7, 0.3).apply(x)
+    assert np.abs(_apply(api, ctx, mat, x) - y_ref).max() <= 1e-13 * np.abs(y_ref).max()
+    d = api.DeviceVector(ctx, g.n_cells)
+    mat.diagonal(-0.7, 0.3, d)
+    ref_d = 0.3 - 0.7 * mesh.assemble_csr(g, 1.0, 0.0).diagonal()
+    assert np.abs(d.to_numpy() - ref_d).max() <= 1e-13 * np.abs(ref_d).max()
+    mat.close()
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_solvers_and_fused_dots_with_every_format(env, fmt):
+    """CG / BiCGStab / GMRES on the device loop (fused <p, Ap> partials: one per wave, so their count depends on
+    the slices per wave) -- iteration counts and solutions identical across formats."""
+    api, mesh, oracle, ctx = env
+    g = mesh.structured_box(24, 20, 18)
+    mat = _build(ctx, fmt, lambda: api.StencilMatrix.from_face_graph(ctx, g))
+    op = api.HipStencilOperator(mat, -1.0, 0.0)
+    b = api.DeviceVector(ctx, g.n_cells)
+    api.fill_with(b, 1.0)
+    ref_op = oracle.StencilOperator(g, -1.0, 0.0)
+    for cls, kind in ((api.CgSolver, "cg"), (api.BiCgStabSolver, "bicgstab"), (api.GmresSolver, "gmres")):
+        x = api.DeviceVector(ctx, g.n_cells)
+        s = cls()
+        assert s.solve(x, b, op)
+        ref = oracle.solve(kind, ref_op, np.ones(g.n_cells))
+        assert abs(s.iteration - ref.iterations) <= max(2, int(0.05 * ref.iterations)), (kind, s.iteration, ref.iterations)
+        assert np.linalg.norm(x.to_numpy() - ref.x) <= 1e-6 * np.linalg.norm(ref.x)
+    mat.close()
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_partitioned_operator_with_every_format(env, fmt):
+    """Interior / boundary slice lists + halo columns (offsets into the halo tail) through the RCCL self-exchange."""
+    from test_gpu_comm import _periodic_z_local_graph
+
+    api, mesh, oracle, ctx = env
+    loc, send_idx = _periodic_z_local_graph(20, 12, 9)
+    mat = _build(ctx, fmt, lambda: api.StencilMatrix.from_face_graph(ctx, loc))
+    st = mat.stats()
+    assert (st["offset_dictionary_size"] > 0) == (fmt[0] >= 2)
+    n2p = loc.n_halo
+    mat.set_halo([0], [0, n2p], send_idx, [0, n2p])
+    x = np.sin(0.37 * np.arange(loc.n_cells))
+    y = _apply(api, ctx, mat, x, n_halo=loc.n_halo, alpha=-1.0, beta=0.05)
+    xf = np.concatenate([x, x[send_idx]])
+    y_ref = oracle.StencilOperator(loc, -1.0, 0.05).apply(xf)[: loc.n_cells]
+    assert np.abs(y - y_ref).max() <= 1e-13 * np.abs(y_ref).max()
+    # CG through the split SpMV with fused dots
+    b = api.DeviceVector(ctx, loc.n_cells, loc.n_halo)
+    api.fill_with(b, 1.0)
+    xs = api.DeviceVector(ctx, loc.n_cells, loc.n_halo)
+    s = api.CgSolver()
+    assert s.solve(xs, b, api.HipStencilOperator(mat, -1.0, 0.05))
+    r = api.DeviceVector(ctx, loc.n_cells, loc.n_halo)
+    api.HipStencilOperator(mat, -1.0, 0.05).Residual(r, b, xs)
+    assert api.norm_2(r) <= 2e-6 * np.sqrt(loc.n_cells)
+    mat.close()

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc output: per kernel and counter, the number of dispatches and the mean value.
+
+    python tools/pmc_summary.py <dir with *_counter_collection.csv> [...]
+
+Also writes profiles/spmv_hbm_traffic.json when --traffic-json is given: FETCH_SIZE (KiB; doubled, the
+gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md) + WRITE_SIZE (KiB) of the SpMV kernel with the
+fused-dot epilogue, per launch."""
+import argparse
+import csv
+import glob
+import json
+import os
+import re
+from collections import defaultdict
+
+
+def short(name: str) -> str:
+    return re.sub(r"\(.*", "", name).strip()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("dirs", nargs="+")
+    ap.add_argument("--traffic-json", default=None)
+    ap.add_argument("--record-format", default=None)
+    ap.add_argument("--algorithmic-bytes", type=float, default=None)
+    args = ap.parse_args()
+    acc = defaultdict(lambda: [0, 0.0])
+    for d in args.dirs:
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            with open(f, newline="") as fh:
+                for row in csv.DictReader(fh):
+                    k = (row["Counter_Name"], short(row["Kernel_Name"]))
+                    acc[k][0] += 1
+                    acc[k][1] += float(row["Counter_Value"])
+    lines = []
+    for (counter, kern), (n, tot) in sorted(acc.items()):
+        lines.append(f"{counter} | {kern} | n={n} | avg={tot / n:.1f}")
+    print("\n".join(lines))
+    if args.traffic_json:
+        def avg(counter, pred):
+            sel = [(n, t) for (c, k), (n, t) in acc.items() if c == counter and pred(k)]
+            n = sum(a for a, _ in sel)
+            return sum(t for _, t in sel) / n if n else None
+
+        # the launches of a CG solve: the fused-dot instantiation <true, ...> of either SpMV kernel
+        is_spmv = lambda k: ("spmv_dict_kernel<true" in k) or ("spmv_sell_kernel<true, true" in k)  # noqa: E731
+        fetch, write = avg("FETCH_SIZE", is_spmv), avg("WRITE_SIZE", is_spmv)
+        if fetch is not None and write is not None:
+            traffic = (2.0 * fetch + write) * 1024.0
+            out = {"traffic_bytes_per_launch": traffic, "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB": write,
+                   "record_format": args.record_format,
+                   "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950)"}
+            if args.algorithmic_bytes:
+                out["ratio_to_algorithmic_bytes"] = traffic / args.algorithmic_bytes
+            with open(args.traffic_json, "w") as fh:
+                json.dump(out, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()
