@@ -209,6 +209,11 @@ int storm_hip_op_apply(const storm_hip_op *op, double alpha, double beta, const 
  * Jacobi preconditioner needs from the operator. */
 int storm_hip_op_get_diagonal(const storm_hip_op *op, double alpha, double beta, int invert, storm_hip_vec *d);
 
+/* `stormDivGrad(mesh, u, dt, c)`  source_apps/playground/Playground.cpp:115-131 in its own form:
+ * u += dt * M(c)  (y += alpha*M(x)); what the playground's operator lambda calls twice per apply
+ * (:153-167).  Exchanges x's halo first when a halo plan is set.  x and y must not alias. */
+int storm_hip_op_apply_add(const storm_hip_op *op, double alpha, const storm_hip_vec *x, storm_hip_vec *y);
+
 typedef struct storm_hip_op_stats {
   int64_t n_rows, n_cols, nnz_offdiag;  /* off-diagonal entries (2F for a face graph) */
   int64_t ell_slots;                    /* stored ELL slots incl. padding */

@@ -328,11 +328,24 @@ public:
   void apply(real_t alpha, real_t beta, const DeviceVector& x, DeviceVector& y) const {
     detail::check(storm_hip_op_apply(_h, alpha, beta, x.handle(), y.handle()));
   }
+  /// y += alpha M(x)
+  void apply_add(real_t alpha, const DeviceVector& x, DeviceVector& y) const {
+    detail::check(storm_hip_op_apply_add(_h, alpha, x.handle(), y.handle()));
+  }
   storm_hip_op* handle() const noexcept { return _h; }
 
 private:
   storm_hip_op* _h = nullptr;
 };
+
+/// `stormDivGrad(mesh, u, dt, c)` (source_apps/playground/Playground.cpp:115-131): u += dt * div grad c,
+/// with `matrix` holding what the face loop reads from `mesh`.  The playground's operator lambda
+/// (:153-167) is then, statement for statement,
+///     w_hat <<= f + sigma * (c_in - c);  stormDivGrad(L, w_hat, -Gamma, c_in);
+///     c_hat <<= c_in;                    stormDivGrad(L, c_hat, -tau, w_hat);
+inline void stormDivGrad(const StencilMatrix& matrix, DeviceVector& u, real_t dt, const DeviceVector& c) {
+  matrix.apply_add(dt, c, u);
+}
 
 /// A = beta I + alpha M as an Operator<DeviceVector> (the caller keeps `matrix` alive, as the
 /// reference's operator lambdas capture the mesh by reference, Playground.cpp:152-167).

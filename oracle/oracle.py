@@ -103,6 +103,8 @@ def lib(variant: str = "strict"):
         L.oracle_solve_gmres_pre.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                              C.c_int64, f64p, f64p, C.POINTER(_Params), C.POINTER(_Result), f64p]
         L.oracle_diag_apply.argtypes = [C.c_void_p, f64p, f64p]
+        L.oracle_ch_dF_dc.argtypes = [C.c_int64, f64p, f64p]
+        L.oracle_ch_apply.argtypes = [C.c_void_p, f64p, f64p]
     return _libs[variant]
 
 
@@ -353,3 +355,27 @@ def solve_jfnk(op, b, x0=None, num_iterations: int = 2000, abs_tol: float = 1e-6
     inner = lib(variant).oracle_solve_jfnk(op.fn, op.ctx, b.size, _p(x), _p(b), C.byref(p), C.byref(r), _p(hist))
     return SolveResult(x, r.iterations, r.absolute_error, r.relative_error, r.initial_error,
                        bool(r.converged), r.num_applies, hist[: r.iterations + 1].copy()), inner
+
+
+class _ChOp(C.Structure):
+    _fields_ = [("mesh", C.POINTER(_Mesh)), ("f", f64p), ("c", f64p), ("w_hat", f64p),
+                ("tau", C.c_double), ("Gamma", C.c_double), ("sigma", C.c_double)]
+
+
+def ch_operator_apply(g_or_mesh, f, c, c_in, tau: float = 1.0e-3, Gamma: float = 1.0e-4, sigma: float = 2.0):
+    """One application of the playground's operator lambda (Playground.cpp:153-167, constants of :113):
+    returns ``(c_hat, w_hat)``."""
+    m = g_or_mesh if isinstance(g_or_mesh, Mesh) else Mesh(g_or_mesh)
+    f, c, c_in = f64(f), f64(c), f64(c_in)
+    c_hat, w_hat = np.empty_like(c), np.empty_like(c)
+    op = _ChOp(C.pointer(m.c), _p(f), _p(c), _p(w_hat), tau, Gamma, sigma)
+    lib().oracle_ch_apply(C.byref(op), _p(c_hat), _p(c_in))
+    return c_hat, w_hat
+
+
+def dF_dc(c):
+    """``map(dF_dc, c)``, Playground.cpp:142-148."""
+    c = f64(c)
+    f = np.empty_like(c)
+    lib().oracle_ch_dF_dc(c.size, _p(f), _p(c))
+    return f

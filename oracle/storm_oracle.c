@@ -1102,3 +1102,29 @@ ORACLE_API int64_t oracle_solve_jfnk(oracle_apply_fn apply, void *op, int64_t n,
   free(st.s), free(st.t), free(st.r), free(st.w);
   return st.inner_iterations;
 }
+
+/* ---- The operator the reference's only caller hands to CG: the lambda of       */
+/* source_apps/playground/Playground.cpp:153-167: two           */
+/* stormDivGrad calls and two element loops per application.  Only the             */
+/* application is restated (parity of the composite apply); the Cahn-Hilliard      */
+/* time stepping around it is app physics, out of scope. ------------------------ */
+typedef struct oracle_ch_op {
+  const oracle_mesh *mesh;
+  const double *f, *c;
+  double *w_hat;
+  double tau, Gamma, sigma;
+} oracle_ch_op;
+
+ORACLE_API void oracle_ch_apply(void *ctx, double *c_hat, const double *c_in) {
+  const oracle_ch_op *op = (const oracle_ch_op *)ctx;
+  const int64_t n = op->mesh->n_cells;
+  for (int64_t i = 0; i < n; ++i) op->w_hat[i] = op->f[i] + op->sigma * (c_in[i] - op->c[i]); /* :155 */
+  oracle_divgrad(op->mesh, op->w_hat, -op->Gamma, c_in);                                        /* :157 */
+  for (int64_t i = 0; i < n; ++i) c_hat[i] = c_in[i];                                           /* :161 */
+  oracle_divgrad(op->mesh, c_hat, -op->tau, op->w_hat);                                         /* :164 */
+}
+
+/* f <<= map(dF_dc, c), :142-148 */
+ORACLE_API void oracle_ch_dF_dc(int64_t n, double *f, const double *c) {
+  for (int64_t i = 0; i < n; ++i) f[i] = 2.0 * c[i] * (c[i] - 1.0) * (2.0 * c[i] - 1.0);
+}

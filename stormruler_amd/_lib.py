@@ -94,6 +94,7 @@ SIGNATURES = {
     "storm_hip_op_create_csr": (C.c_int, [vp, C.c_int64, C.c_int64, i64p, i64p, f64p, C.POINTER(vp)]),
     "storm_hip_op_set_halo": (C.c_int, [vp, C.c_int, i32p, i64p, i64p, i64p]),
     "storm_hip_op_apply": (C.c_int, [vp, C.c_double, C.c_double, vp, vp]),
+    "storm_hip_op_apply_add": (C.c_int, [vp, C.c_double, vp, vp]),
     "storm_hip_op_get_diagonal": (C.c_int, [vp, C.c_double, C.c_double, C.c_int, vp]),
     "storm_hip_op_get_stats": (C.c_int, [vp, C.POINTER(OpStats)]),
     "storm_hip_op_destroy": (C.c_int, [vp]),

@@ -457,6 +457,10 @@ class StencilMatrix:
     def apply(self, alpha: float, beta: float, x: DeviceVector, y: DeviceVector) -> None:
         check(lib.storm_hip_op_apply(self._h, alpha, beta, x._h, y._h))
 
+    def apply_add(self, alpha: float, x: DeviceVector, y: DeviceVector) -> None:
+        """``y += alpha * M(x)``: ``stormDivGrad(mesh, y, alpha, x)`` (Playground.cpp:115-131) in its own form."""
+        check(lib.storm_hip_op_apply_add(self._h, float(alpha), x._h, y._h))
+
     def diagonal(self, alpha: float, beta: float, d: DeviceVector, invert: bool = False) -> None:
         """``d`` <- the diagonal of ``beta*I + alpha*M`` (its safe inverse with ``invert``)."""
         check(lib.storm_hip_op_get_diagonal(self._h, float(alpha), float(beta), int(invert), d._h))
@@ -508,6 +512,12 @@ class IdentityPreconditioner(Preconditioner):  # Preconditioner.hpp:84-97
 
     def conj_mul(self, x_vec, y_vec):
         x_vec <<= y_vec
+
+
+def stormDivGrad(matrix: StencilMatrix, u: DeviceVector, dt: float, c: DeviceVector) -> None:
+    """``stormDivGrad(mesh, u, dt, c)``, source_apps/playground/Playground.cpp:115-131: ``u += dt * div grad c``
+    (``matrix`` holds what the face loop reads from ``mesh``)."""
+    matrix.apply_add(dt, c, u)
 
 
 class JacobiPreconditioner(Preconditioner):

@@ -223,7 +223,7 @@ struct SpmvDot {
   int *nblocks_out = nullptr;  // host out: number of partial blocks written
 };
 int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, double *y,
-                const SpmvDot *dot, const int *done);
+                const SpmvDot *dot, const int *done, bool accumulate = false);
 int spmv_grid_blocks(const storm_hip_op *op);
 int op_upload_slice_lists(storm_hip_op *op);
 

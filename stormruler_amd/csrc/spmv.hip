@@ -61,6 +61,7 @@ struct SellArgs {
   int dict_size;
   const int *__restrict__ offs;           // format 2: the column-offset dictionary
   int offs_size;
+  int accumulate;                         // y += alpha*M(x) (stormDivGrad's own form) instead of y = beta*x + alpha*M(x)
 };
 
 constexpr int kDictSize = 256;
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SellArgs A, Scal alph
       default: acc = row_sum_wide<NT, VARIANT>(rec, width, lane, x, xi, xwin, row0); break;
     }
     }
-    yi = beta * xi + alpha * (acc + ext * xi);
+    yi = (A.accumulate ? (valid ? y[row] : 0.0) : beta * xi) + alpha * (acc + ext * xi);
     if (valid && !done_flag) {
       if (NT) __builtin_nontemporal_store(yi, y + row);
       else y[row] = yi;
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(kBlock) void spmv_dict_kernel(SellArgs A, Scal alph
   uint64_t iw[SPW], jw[SPW];
   int2v c[SPW][NP > 0 ? NP : 1];
   int ct[SPW];
-  double xi[SPW], wi[SPW];
+  double xi[SPW], wi[SPW], yo[SPW];
   int64_t row[SPW];
   bool valid[SPW];
 #pragma unroll
@@ -402,6 +403,8 @@ __global__ __launch_bounds__(kBlock) void spmv_dict_kernel(SellArgs A, Scal alph
     }
     xi[u] = x[row[u]];
     wi[u] = 0.0;
+    yo[u] = 0.0;
+    if (A.accumulate) yo[u] = y[row[u]];
     if (w_load) wi[u] = dot.w[row[u]];  // (w == x, CG's <p, Ap>, reuses xi at the end: no copy here, a
   }                                      //  copy would wait for xi in the middle of the load issue)
   // The wave's own copy of the tables, requested AFTER the record loads (memory returns in order, so
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(kBlock) void spmv_dict_kernel(SellArgs A, Scal alph
 #pragma unroll
     for (int k = 0; k < W; ++k) acc += dw[(unsigned)(iw[u] >> (8 * (k + 1))) & 0xffu] * (xg[u][k] - xi[u]);
     const double ext = dw[(unsigned)iw[u] & 0xffu];
-    double yi = beta * xi[u] + alpha * (acc + ext * xi[u]);
+    double yi = (A.accumulate ? yo[u] : beta * xi[u]) + alpha * (acc + ext * xi[u]);
     if (valid[u] && !done_flag) __builtin_nontemporal_store(yi, y + row[u]);
     yi = valid[u] ? yi : 0.0;
     if (DOT) {
@@ -494,9 +497,9 @@ __global__ __launch_bounds__(kBlock) void spmv_tail_kernel(int64_t n_tail, const
 template <bool NT, bool DOT, int VARIANT>
 static void launch_sell(const storm_hip_op *op, int nb, Scal alpha, Scal beta, const double *x, double *y,
                         const int *slice_list, int64_t n_launch, DotArgs dot, const int *done, hipEvent_t ev0,
-                        hipEvent_t ev1) {
+                        hipEvent_t ev1, bool accumulate) {
   SellArgs A{op->d_pack, op->d_slice_off, op->n_rows, op->uniform_width, (int)op->ctx->opt_spmv_xcd_remap, op->d_dict, op->dict_size,
-             op->d_offs, op->offs_size};
+             op->d_offs, op->offs_size, (int)accumulate};
   constexpr int LV = (VARIANT == 2) ? 2 : 0;  // listed slices: no LDS window, but the record format stays
   hipStream_t st = op->ctx->stream;
   if (slice_list == nullptr && op->ctx->opt_spmv_xcd_remap != 0) {
@@ -528,11 +531,11 @@ static inline int blocks_for(const storm_hip_op *op, int64_t n_launch_slices) {
 template <bool DOT, int SPW>
 static void launch_dict(const storm_hip_op *op, int nb, Scal alpha, Scal beta, const double *x, double *y,
                         const int *slice_list, int64_t n_launch, DotArgs dot, const int *done, hipEvent_t ev0,
-                        hipEvent_t ev1) {
+                        hipEvent_t ev1, bool accumulate) {
   // slice lists (interior / boundary sets) are not contiguous: no XCD grouping there
   const int group = slice_list ? 0 : (int)op->ctx->opt_spmv_xcd_remap;
   SellArgs A{op->d_pack, op->d_slice_off, op->n_rows, op->uniform_width, group, op->d_dict, op->dict_size,
-             op->d_offs, op->offs_size};
+             op->d_offs, op->offs_size, (int)accumulate};
   hipStream_t st = op->ctx->stream;
 #define DICT_GO(W_)                                                                                                 \
   do {                                                                                                              \
@@ -557,7 +560,7 @@ static void launch_dict(const storm_hip_op *op, int nb, Scal alpha, Scal beta, c
 
 static int launch_range(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, double *y,
                         const int *slice_list, int64_t n_launch, DotArgs dot, bool want_dot,
-                        const int *done) {
+                        const int *done, bool accumulate) {
   if (n_launch <= 0) return STORM_HIP_OK;
   storm_hip_ctx *c = op->ctx;
   const bool prof = c->opt_profile_spmv != 0;
@@ -576,19 +579,19 @@ static int launch_range(const storm_hip_op *op, Scal alpha, Scal beta, const dou
   const bool nt = c->opt_nt != 0;
   if (op_spw(op) >= 1 && op->dict_size > 0 && op->uniform_width > 0) {
     switch (op_spw(op)) {
-      case 1: if (want_dot) launch_dict<true, 1>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1);
-              else launch_dict<false, 1>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1); break;
-      case 2: if (want_dot) launch_dict<true, 2>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1);
-              else launch_dict<false, 2>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1); break;
-      default: if (want_dot) launch_dict<true, 4>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1);
-               else launch_dict<false, 4>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1); break;
+      case 1: if (want_dot) launch_dict<true, 1>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1, accumulate);
+              else launch_dict<false, 1>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1, accumulate); break;
+      case 2: if (want_dot) launch_dict<true, 2>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1, accumulate);
+              else launch_dict<false, 2>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1, accumulate); break;
+      default: if (want_dot) launch_dict<true, 4>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1, accumulate);
+               else launch_dict<false, 4>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1, accumulate); break;
     }
     HIP_TRY(hipGetLastError());
     if (prof) c->prof_used += 2;
     return STORM_HIP_OK;
   }
 #define SPMV_GO(NT_, DOT_, VAR_) \
-  launch_sell<NT_, DOT_, VAR_>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1)
+  launch_sell<NT_, DOT_, VAR_>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1, accumulate)
 #define SPMV_VAR(VAR_)                                                                      \
   do {                                                                                      \
     if (nt) { if (want_dot) SPMV_GO(true, true, VAR_); else SPMV_GO(true, false, VAR_); }   \
@@ -607,7 +610,7 @@ static int launch_range(const storm_hip_op *op, Scal alpha, Scal beta, const dou
 int spmv_grid_blocks(const storm_hip_op *op) { return blocks_for(op, op->n_slices); }
 
 int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, double *y,
-                const SpmvDot *sd, const int *done) {
+                const SpmvDot *sd, const int *done, bool accumulate) {
   storm_hip_ctx *c = op->ctx;
   const bool fuse_dot = sd != nullptr && op->tail_rows == 0;
   STORM_REQUIRE(op->halo.n_nbrs == 0 || c->comm != nullptr,
@@ -625,14 +628,14 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
   if (sd && sd->nblocks_out) *sd->nblocks_out = fuse_dot ? 4 * nb_total : 0;
 
   if (!split) {
-    STORM_TRY(launch_range(op, alpha, beta, x, y, nullptr, op->n_slices, dot, fuse_dot, done));
+    STORM_TRY(launch_range(op, alpha, beta, x, y, nullptr, op->n_slices, dot, fuse_dot, done, accumulate));
   } else {
     // interior rows overlap the halo exchange running on the comm stream
     STORM_TRY(comm_halo_exchange_begin(op, const_cast<double *>(x)));
-    STORM_TRY(launch_range(op, alpha, beta, x, y, op->d_interior, op->n_interior, dot, fuse_dot, done));
+    STORM_TRY(launch_range(op, alpha, beta, x, y, op->d_interior, op->n_interior, dot, fuse_dot, done, accumulate));
     STORM_TRY(comm_halo_exchange_end(op));
     dot.block_offset = 4 * nb_int;
-    STORM_TRY(launch_range(op, alpha, beta, x, y, op->d_boundary, op->n_boundary, dot, fuse_dot, done));
+    STORM_TRY(launch_range(op, alpha, beta, x, y, op->d_boundary, op->n_boundary, dot, fuse_dot, done, accumulate));
   }
   if (op->tail_rows > 0) {
     const int nb = (int)((op->tail_rows + 3) / 4);
@@ -1023,6 +1026,17 @@ int storm_hip_op_apply(const storm_hip_op *op, double alpha, double beta, const 
   STORM_REQUIRE(x->n_halo >= op->n_halo, "op_apply: x has %lld halo rows, operator needs %lld", (long long)x->n_halo,
                 (long long)op->n_halo);
   return spmv_launch(op, host_scal(alpha), host_scal(beta), x->d, y->d, nullptr, nullptr);
+}
+
+int storm_hip_op_apply_add(const storm_hip_op *op, double alpha, const storm_hip_vec *x, storm_hip_vec *y) {
+  STORM_REQUIRE(op && x && y, "op_apply_add: null argument");
+  STORM_REQUIRE(x->ctx == op->ctx && y->ctx == op->ctx, "op_apply_add: context mismatch");
+  STORM_REQUIRE(x != y && x->d != y->d, "op_apply_add: x and y must not alias");
+  STORM_REQUIRE(x->n_owned == op->n_rows && y->n_owned == op->n_rows, "op_apply_add: operator has %lld rows, x %lld, y %lld",
+                (long long)op->n_rows, (long long)x->n_owned, (long long)y->n_owned);
+  STORM_REQUIRE(x->n_halo >= op->n_halo, "op_apply_add: x has %lld halo rows, operator needs %lld", (long long)x->n_halo,
+                (long long)op->n_halo);
+  return spmv_launch(op, host_scal(alpha), host_scal(0.0), x->d, y->d, nullptr, nullptr, true);
 }
 
 int storm_hip_op_get_diagonal(const storm_hip_op *op, double alpha, double beta, int invert, storm_hip_vec *d) {

@@ -211,3 +211,82 @@ def test_partitioned_operator_with_every_format(env, fmt):
     api.HipStencilOperator(mat, -1.0, 0.05).Residual(r, b, xs)
     assert api.norm_2(r) <= 2e-6 * np.sqrt(loc.n_cells)
     mat.close()
+
+
+@pytest.mark.parametrize("fmt", [(0, 1), (1, 2), (2, 2)])
+@pytest.mark.parametrize("mesh_kind", ["box", "triangle", "periodic"])
+def test_stormDivGrad_accumulate_form(env, fmt, mesh_kind):
+    """``u += dt * div grad c`` (Playground.cpp:115-131, `storm_hip_op_apply_add`) on every record format,
+    an unstructured mesh, and through the halo exchange."""
+    import os
+
+    api, mesh, oracle, ctx = env
+    send_idx = None
+    if mesh_kind == "box":
+        g = mesh.structured_box(21, 13, 10)
+    elif mesh_kind == "triangle":
+        from stormruler_amd import io_triangle
+
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        g = io_triangle.read_triangle(os.path.join(root, "tests", "golden", "mesh", "square_nb.1."))
+    else:
+        from test_gpu_comm import _periodic_z_local_graph
+
+        g, send_idx = _periodic_z_local_graph(20, 12, 9)
+    mat = _build(ctx, fmt, lambda: api.StencilMatrix.from_face_graph(ctx, g))
+    if send_idx is not None:
+        mat.set_halo([0], [0, g.n_halo], send_idx, [0, g.n_halo])
+    n = g.n_cells
+    c = np.sin(0.37 * np.arange(n))
+    u0 = np.cos(0.11 * np.arange(n))
+    cv = api.DeviceVector.from_numpy(ctx, c, n_halo=g.n_halo) if g.n_halo else api.DeviceVector.from_numpy(ctx, c)
+    uv = api.DeviceVector.from_numpy(ctx, u0, n_halo=g.n_halo) if g.n_halo else api.DeviceVector.from_numpy(ctx, u0)
+    api.stormDivGrad(mat, uv, -1.0e-3, cv)
+    api.stormDivGrad(mat, uv, 2.5e-4, cv)  # accumulates
+    cf = c if send_idx is None else np.concatenate([c, c[send_idx]])
+    lc = oracle.StencilOperator(g, 1.0, 0.0).apply(cf)[:n]  # M(c) through the reference-order face loops
+    ref = u0 + (-1.0e-3) * lc + 2.5e-4 * lc
+    assert np.abs(uv.to_numpy() - ref).max() <= 1e-13 * max(1.0, np.abs(ref).max())
+    mat.close()
+
+
+def test_playground_operator_lambda(env):
+    """the operator the reference's only caller hands to CG (Playground.cpp:153-167), written
+    statement for statement on the device interface, against the oracle's restatement of the same lambda; and
+    `f <<= map(dF_dc, c)` (:142-148) from elementwise kernels, bit for bit."""
+    import os
+
+    from stormruler_amd import io_triangle
+
+    api, mesh, oracle, ctx = env
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = io_triangle.read_triangle(os.path.join(root, "tests", "golden", "mesh", "square_nb.1."))
+    tau, Gamma, sigma = 1.0e-3, 1.0e-4, 2.0  # Playground.cpp:113
+    n = g.n_cells
+    rng = np.random.default_rng(1)
+    c_host, c_in_host = rng.random(n), rng.random(n)
+    mat = api.StencilMatrix.from_face_graph(ctx, g)
+    c, c_in = api.DeviceVector.from_numpy(ctx, c_host), api.DeviceVector.from_numpy(ctx, c_in_host)
+    ones, t1, t2, f = (api.DeviceVector(ctx, n) for _ in range(4))
+    api.fill_with(ones, 1.0)
+    # f = 2.0 * c * (c - 1.0) * (2.0 * c - 1.0), evaluated left to right like the reference's lambda
+    t1 <<= c - ones
+    t2 <<= 2.0 * c + (-1.0) * ones  # 2c is exact, so this is the reference's (2.0 * c - 1.0) to the bit
+    f <<= 2.0 * c
+    api.vmul(f, f, t1)
+    api.vmul(f, f, t2)
+    assert np.array_equal(f.to_numpy(), oracle.dF_dc(c_host))
+    w_hat, c_hat = api.DeviceVector(ctx, n), api.DeviceVector(ctx, n)
+
+    def op(c_hat_out, c_in_vec):  # Playground.cpp:153-167
+        nonlocal w_hat
+        w_hat <<= f + sigma * (c_in_vec - c)
+        api.stormDivGrad(mat, w_hat, -Gamma, c_in_vec)
+        c_hat_out <<= c_in_vec
+        api.stormDivGrad(mat, c_hat_out, -tau, w_hat)
+
+    api.make_operator(op).mul(c_hat, c_in)
+    ref_c_hat, ref_w_hat = oracle.ch_operator_apply(g, oracle.dF_dc(c_host), c_host, c_in_host, tau, Gamma, sigma)
+    assert np.abs(w_hat.to_numpy() - ref_w_hat).max() <= 1e-13 * np.abs(ref_w_hat).max()
+    assert np.abs(c_hat.to_numpy() - ref_c_hat).max() <= 1e-12 * np.abs(ref_c_hat).max()
+    mat.close()
