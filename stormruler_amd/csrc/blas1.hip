@@ -315,6 +315,17 @@ int k_multi_dot(storm_hip_ctx *c, const double *a, const double *const *bs, int 
   return k_reduce_final(c, c->d_partials, nb, k, d_out, done);
 }
 
+// Per-block partials of <a, b> without the final pass (the consumer folds them: solvers.hip, fused MGS).
+int k_dot_partials(storm_hip_ctx *c, const double *a, const double *b, int64_t n, double *partials, int nb,
+                   const int *done) {
+  DotPtrs ptrs;
+  for (int j = 0; j < kDotChunk; ++j) ptrs.b[j] = b;
+  hipLaunchKernelGGL(multi_dot_kernel<1>, dim3(nb), dim3(kBlock), 0, c->stream, n, a, ptrs, partials, done,
+                     (int)(c->opt_blas1_nt != 0));
+  HIP_TRY(hipGetLastError());
+  return STORM_HIP_OK;
+}
+
 // ---- multi-axpy ------------------------------------------------------------------------------
 constexpr int kAxpyChunk = 8;
 struct AxpyArgs {

@@ -101,6 +101,7 @@ struct storm_hip_ctx {
   int64_t opt_profile_spmv = 0;
   int64_t opt_blas1_nt = 1;  // non-temporal loads/stores in the streaming kernels
   int64_t opt_graph = 0;     // replay CG / BiCGStab iterations from a captured hipGraph: measured slower than eager launches (profiles/r01_notes.md), off
+  int64_t opt_fuse_mgs = 1;  // GMRES/MGS on one rank, <= 2048 blocks: each step folds the previous step's partials itself (no final-reduction launch in between)
   int64_t opt_fuse_dot = 1;  // 0: reductions after an SpMV run as separate kernels (A/B knob)
   // Vector storage released by vec_destroy, kept for the next vec_create of the same size: a solve
   // allocates its work vectors on entry and frees them on return (the reference re-assigns them in
@@ -210,6 +211,8 @@ int k_multi_dot(storm_hip_ctx *c, const double *a, const double *const *bs, int 
 int k_multi_axpy(storm_hip_ctx *c, double *y, const double *d_coef, double sign,
                  const double *const *xs, int k, int64_t n, const int *done);
 // Final pass over per-block partials: out[j] = sum_b partials[j * nblocks + b].
+int k_dot_partials(storm_hip_ctx *c, const double *a, const double *b, int64_t n, double *partials, int nb,
+                   const int *done);
 int k_reduce_final(storm_hip_ctx *c, const double *partials, int nblocks, int k, double *d_out,
                    const int *done);
 

@@ -385,12 +385,26 @@ __global__ __launch_bounds__(kBlock) void bicg_update_kernel(int64_t n, SolverSt
 // One modified-Gram-Schmidt step fused with the next reduction (SolverGmres.hpp:157-161):
 //   w -= h * qa;  partial <w, qb>   (qb == nullptr: partial <w, w>, the norm of :161)
 // Same values as the reference's dot -> axpy -> dot chain, one pass over w instead of two.
+// h comes either from memory (*h) or, on a single rank with few blocks, from the previous kernel's
+// per-block partials: every block folds them itself in the same fixed order (so all blocks hold the
+// same h) and block 0 stores it into the Hessenberg -- the separate final-reduction launch between two
+// steps disappears, which is what a 128^3 problem (launch-bound MGS chain) is made of.
 __global__ __launch_bounds__(kBlock) void mgs_step_kernel(int64_t n, const SolverState *st, double *__restrict__ w,
-                                                          const double *h, const double *__restrict__ qa,
+                                                          const double *h, const double *__restrict__ in_partials,
+                                                          int n_in, double *h_store,
+                                                          const double *__restrict__ qa,
                                                           const double *qb, double *__restrict__ partials, int nt) {
   if (st->done) return;
   __shared__ double lds4[4];
-  const double hv = *h;
+  double hv;
+  if (in_partials) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n_in; i += kBlock) v += in_partials[i];
+    hv = block_sum256(v, lds4);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *h_store = hv;
+  } else {
+    hv = *h;
+  }
   double acc = 0.0;
   const int64_t n2 = n >> 1;
   double2v *w2 = reinterpret_cast<double2v *>(w);
@@ -889,6 +903,22 @@ int storm_hip_solve_gmres(const storm_hip_op *op, double alpha, double beta, con
     if (params->gram_schmidt == 0) {
       // modified Gram-Schmidt (:157-160): H(0,k) = <w,q_0>; then each step applies  w -= H(i,k) q_i
       // and already accumulates the next reduction (<w,q_{i+1}>, or <w,w> for the norm of :161)
+      const bool fold_in_consumer = c->comm == nullptr && nbv <= 2048 && 2 * (int64_t)nbv <= c->partials_capacity &&
+                                    c->opt_fuse_mgs != 0;
+      if (fold_in_consumer) {
+        // partials ping-pong between two halves of the workspace: step i folds what step i-1 wrote
+        double *cur = c->d_partials, *nxt = c->d_partials + nbv;
+        STORM_TRY(k_dot_partials(c, qn, q[0], n, cur, nbv, d.done));
+        for (int i = 0; i <= k; ++i) {
+          const double *qb = i < k ? q[i + 1] : nullptr;
+          hipLaunchKernelGGL(mgs_step_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, qn,
+                             (const double *)nullptr, cur, nbv, &d.g.H[i * m + k], q[i], qb, nxt,
+                             (int)(c->opt_blas1_nt != 0));
+          HIP_TRY(hipGetLastError());
+          std::swap(cur, nxt);
+        }
+        STORM_TRY(k_reduce_final(c, cur, nbv, 1, d.slot(S_TMP), d.done));  // <w, w>
+      } else {
       {
         const double *bs[1] = {q[0]};
         STORM_TRY(k_multi_dot(c, qn, bs, 1, n, &d.g.H[0 * m + k], d.done));
@@ -898,11 +928,13 @@ int storm_hip_solve_gmres(const storm_hip_op *op, double alpha, double beta, con
         double *h = &d.g.H[i * m + k];
         const double *qb = i < k ? q[i + 1] : nullptr;
         double *out = i < k ? &d.g.H[(i + 1) * m + k] : d.slot(S_TMP);
-        hipLaunchKernelGGL(mgs_step_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, qn, h, q[i], qb,
-                           c->d_partials, (int)(c->opt_blas1_nt != 0));
+        hipLaunchKernelGGL(mgs_step_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, qn, h,
+                           (const double *)nullptr, 0, (double *)nullptr, q[i], qb, c->d_partials,
+                           (int)(c->opt_blas1_nt != 0));
         HIP_TRY(hipGetLastError());
         STORM_TRY(k_reduce_final(c, c->d_partials, nbv, 1, out, d.done));
         if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, out, 1));
+      }
       }
     } else {
       // classical Gram-Schmidt applied twice: two multi-dots + two multi-axpys, the second
