@@ -158,3 +158,45 @@ def test_no_device_memory_leak():
     torch.cuda.synchronize()
     free2, _ = torch.cuda.mem_get_info()
     assert abs(free2 - free1) < 64 << 20, (free0, free1, free2)
+
+
+def test_vector_storage_pool_reuse_is_invisible():
+    """vec_destroy keeps the allocation for the next vec_create of the same size (context-owned pool): the new
+    vector must still be value-initialised (Field::assign semantics, Field.hpp:82-84), pending kernels of the
+    old owner must not leak into it, and `pool_bytes = 0` switches the pool off."""
+    import torch
+
+    from stormruler_amd import api
+
+    ctx = api.Context(0)
+    n = 1 << 20
+    a = api.DeviceVector(ctx, n)
+    api.fill_with(a, 7.0)
+    b = api.DeviceVector(ctx, n)
+    b <<= 3.0 * a        # a kernel reading `a` is still queued when `a` is released
+    a._free()
+    c = api.DeviceVector(ctx, n)   # reuses a's storage
+    assert np.array_equal(c.to_numpy(), np.zeros(n))
+    assert np.array_equal(b.to_numpy(), np.full(n, 21.0))
+    # solves in a loop reuse their work vectors: free memory stays flat after the first one
+    from stormruler_amd import mesh
+
+    g = mesh.structured_box(48)
+    mat = api.StencilMatrix.from_face_graph(ctx, g)
+    op = api.HipStencilOperator(mat, -1.0, 0.0)
+    rhs = api.DeviceVector.from_numpy(ctx, np.ones(g.n_cells))
+    frees = []
+    for _ in range(4):
+        x = api.DeviceVector(ctx, g.n_cells)
+        assert api.GmresSolver().solve(x, rhs, op)
+        x._free()
+        torch.cuda.synchronize()
+        frees.append(torch.cuda.mem_get_info()[0])
+    assert frees[1] == frees[2] == frees[3]
+    ctx.set_option("pool_bytes", 0)   # trims and disables
+    d = api.DeviceVector(ctx, n)
+    api.fill_with(d, 1.0)
+    d._free()
+    e = api.DeviceVector(ctx, n)
+    assert np.array_equal(e.to_numpy(), np.zeros(n))
+    ctx.close()
