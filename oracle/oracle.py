@@ -97,6 +97,8 @@ def lib(variant: str = "strict"):
                      "oracle_solve_idrs"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int64, f64p, f64p,
                                          C.POINTER(_Params), C.POINTER(_Result), f64p]
+        L.oracle_set_preconditioner.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.oracle_last_pre_applies.restype = C.c_int64
         L.oracle_solve_jfnk.restype = C.c_int64
         L.oracle_solve_jfnk.argtypes = L.oracle_solve_cg.argtypes
         L.oracle_solve_gmres_pre.restype = C.c_int64
@@ -306,8 +308,10 @@ class SolveResult:
 
 def solve(kind: str, op, b, x0=None, num_iterations: int = 2000, abs_tol: float = 1e-6,
           rel_tol: float = 1e-6, num_inner_iterations: int = 50, relaxation_factor: float = 1e-4,
-          variant: str = "strict") -> SolveResult:
-    """``solve<XSolver>(x, b, op)`` of Solvers/Solver.hpp:261-265 with the reference defaults."""
+          variant: str = "strict", pre=None, side: str = "right") -> SolveResult:
+    """``solve<XSolver>(x, b, op)`` of Solvers/Solver.hpp:261-265 with the reference defaults; ``pre`` /
+    ``side`` are the solver's ``pre_op`` / ``pre_side`` members (:74-75).  The number of preconditioner
+    applications of the last solve is ``last_pre_applies()``."""
     b = f64(b)
     x = np.zeros_like(b) if x0 is None else f64(x0).copy()
     p = _Params(num_iterations, abs_tol, rel_tol, num_inner_iterations, relaxation_factor)
@@ -317,9 +321,15 @@ def solve(kind: str, op, b, x0=None, num_iterations: int = 2000, abs_tol: float 
     fn = {"cg": L.oracle_solve_cg, "bicgstab": L.oracle_solve_bicgstab, "gmres": L.oracle_solve_gmres,
           "richardson": L.oracle_solve_richardson, "cgs": L.oracle_solve_cgs, "tfqmr": L.oracle_solve_tfqmr,
           "tfqmr1": L.oracle_solve_tfqmr1, "bicgstabl": L.oracle_solve_bicgstabl, "idrs": L.oracle_solve_idrs}[kind]
+    if pre is not None:
+        L.oracle_set_preconditioner(pre.fn, pre.ctx, {"left": 0, "right": 1, "symmetric": 2}[side])
     fn(op.fn, op.ctx, b.size, _p(x), _p(b), C.byref(p), C.byref(r), _p(hist))
     return SolveResult(x, r.iterations, r.absolute_error, r.relative_error, r.initial_error,
                        bool(r.converged), r.num_applies, hist[: r.iterations + 1].copy())
+
+
+def last_pre_applies(variant: str = "strict") -> int:
+    return lib(variant).oracle_last_pre_applies()
 
 
 SIDES = {"left": 0, "right": 1, "symmetric": 2}

@@ -318,11 +318,50 @@ typedef struct solver_base {
   int64_t iteration; /* IterativeSolver::iteration, Solver.hpp:66 */
   int64_t applies;
   double *history;   /* optional [num_iterations + 1] residual norms */
+  oracle_apply_fn pre; /* IterativeSolver::pre_op (Solver.hpp:75), or NULL */
+  void *pre_ctx;
+  int side;          /* IterativeSolver::pre_side (Solver.hpp:74): 0 Left, 1 Right, 2 Symmetric */
+  int64_t pre_applies;
 } solver_base;
+
+/* The preconditioner of the NEXT solve (pre_op / pre_side are members the caller sets before
+ * solve(), Solver.hpp:74-75); every oracle_solve_* picks it up and clears it. */
+static oracle_apply_fn g_pre = NULL;
+static void *g_pre_ctx = NULL;
+static int g_pre_side = 1;
+static int64_t g_last_pre_applies = 0;
+ORACLE_API void oracle_set_preconditioner(oracle_apply_fn pre, void *pre_ctx, int side) {
+  g_pre = pre, g_pre_ctx = pre_ctx, g_pre_side = side;
+}
+ORACLE_API int64_t oracle_last_pre_applies(void) { return g_last_pre_applies; }
+static void take_preconditioner(solver_base *sb) {
+  sb->pre = g_pre, sb->pre_ctx = g_pre_ctx, sb->side = g_pre_side, sb->pre_applies = 0;
+  g_pre = NULL, g_pre_ctx = NULL, g_pre_side = 1;
+}
+#define LEFT_PRE(sb) ((sb)->pre != NULL && (sb)->side == 0)
+#define RIGHT_PRE(sb) ((sb)->pre != NULL && (sb)->side == 1)
 
 static void op_mul(solver_base *s, double *y, const double *x) {
   s->apply(s->op, y, x);
   s->applies++;
+}
+static void pre_mul(solver_base *s, double *y, const double *x) {
+  s->pre(s->pre_ctx, y, x);
+  s->pre_applies++;
+}
+/* The three-way dispatch every preconditioned solver body repeats (e.g. SolverBiCgStab.hpp:134-137),
+ * with the chained `mul(z, y, other, x)` of Operator.hpp:82-88 (other.mul(y, x); mul(z, y)):
+ *   left : z = P(y = A x);   right: z = A(y = P x);   else: z = A x.   y may alias x only on the left. */
+static void side_mul(solver_base *s, double *z, double *y, const double *x) {
+  if (LEFT_PRE(s)) {
+    op_mul(s, y, x);
+    pre_mul(s, z, y);
+  } else if (RIGHT_PRE(s)) {
+    pre_mul(s, y, x);
+    op_mul(s, z, y);
+  } else {
+    op_mul(s, z, x);
+  }
 }
 
 /*
@@ -350,6 +389,7 @@ static void iterative_solve(solver_base *sb, const solver_vt *vt, void *s,
     if (vt->finalize) vt->finalize(s, x, b);
     res->converged = 1;
     res->num_applies = sb->applies;
+    g_last_pre_applies = sb->pre_applies;
     return;
   }
   int converged = 0;
@@ -367,6 +407,7 @@ static void iterative_solve(solver_base *sb, const solver_vt *vt, void *s,
   res->iterations = sb->iteration;
   res->converged = converged;
   res->num_applies = sb->applies;
+  g_last_pre_applies = sb->pre_applies;
 }
 
 /* Field::assign(other, copy) ignores `copy` and value-initialises a new     */
@@ -375,7 +416,7 @@ static double *new_vec(int64_t n) {
   return (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double));
 }
 
-/* ---- CG: Solvers/SolverCg.hpp:47-128 (pre_op == nullptr branches) ------- */
+/* ---- CG: Solvers/SolverCg.hpp:47-128 (both branches; CG ignores pre_side) - */
 typedef struct cg_state {
   solver_base b;
   double gamma;
@@ -389,6 +430,12 @@ static double cg_init(void *sv, const double *x, const double *b) {
   s->p = new_vec(n), s->r = new_vec(n), s->z = new_vec(n); /* :57-59 */
   s->b.applies++;
   op_residual(s->b.apply, s->b.op, n, s->r, b, x);          /* :75 */
+  if (s->b.pre) {                                           /* :76-79 */
+    pre_mul(&s->b, s->z, s->r);
+    oracle_copy(n, s->p, s->z);
+    s->gamma = oracle_dot(n, s->r, s->z);
+    return oracle_norm2(n, s->r);                           /* :85 */
+  }
   oracle_copy(n, s->p, s->r);                               /* :81 */
   s->gamma = oracle_dot(n, s->r, s->r);                     /* :82 */
   return sqrt(s->gamma);                                    /* :85 */
@@ -403,6 +450,13 @@ static double cg_iterate(void *sv, double *x, const double *b) {
   oracle_axpy(n, x, alpha, s->p);                                         /* :98 */
   oracle_axmy(n, s->r, alpha, s->z);                                      /* :99 */
   const double gamma_bar = s->gamma;                                      /* :110 */
+  if (s->b.pre) {                                                         /* :111-113 */
+    pre_mul(&s->b, s->z, s->r);
+    s->gamma = oracle_dot(n, s->r, s->z);
+    const double beta_p = oracle_safe_divide(s->gamma, gamma_bar);        /* :122 */
+    oracle_xpay(n, s->p, s->z, beta_p);                                   /* :123 */
+    return oracle_norm2(n, s->r);                                         /* :125 */
+  }
   s->gamma = oracle_dot(n, s->r, s->r);                                   /* :115 */
   const double beta = oracle_safe_divide(s->gamma, gamma_bar);            /* :122 */
   oracle_xpay(n, s->p, s->r, beta);                                       /* :123 */
@@ -416,16 +470,17 @@ ORACLE_API void oracle_solve_cg(oracle_apply_fn apply, void *op, int64_t n,
   cg_state s;
   memset(&s, 0, sizeof s);
   s.b.apply = apply, s.b.op = op, s.b.n = n, s.b.history = history;
+  take_preconditioner(&s.b);
   const solver_vt vt = {cg_init, cg_iterate, NULL};
   iterative_solve(&s.b, &vt, &s, x, b, p, res);
   free(s.p), free(s.r), free(s.z);
 }
 
-/* ---- BiCGStab: Solvers/SolverBiCgStab.hpp:52-167 (no preconditioner) ---- */
+/* ---- BiCGStab: Solvers/SolverBiCgStab.hpp:52-167 ------------------------ */
 typedef struct bicg_state {
   solver_base b;
   double alpha, rho, omega;
-  double *p, *r, *rt, *t, *v;
+  double *p, *r, *rt, *t, *v, *z;
 } bicg_state;
 
 /* SolverBiCgStab.hpp:59-91 */
@@ -437,7 +492,13 @@ static double bicg_init(void *sv, const double *x, const double *b) {
   s->alpha = s->omega = 0.0; /* members are uninitialised in the reference;
                                 they are written before first use (:139,:159) */
   s->b.applies++;
+  if (s->b.pre) s->z = new_vec(n);                          /* :70 */
   op_residual(s->b.apply, s->b.op, n, s->r, b, x);          /* :82 */
+  if (LEFT_PRE(&s->b)) {                                    /* :83-86 */
+    double *t_ = s->z;
+    s->z = s->r, s->r = t_;
+    pre_mul(&s->b, s->r, s->z);
+  }
   oracle_copy(n, s->rt, s->r);                              /* :87 */
   s->rho = oracle_dot(n, s->rt, s->r);                      /* :88 */
   return sqrt(s->rho);                                      /* :90 */
@@ -457,14 +518,15 @@ static double bicg_iterate(void *sv, double *x, const double *b) {
         oracle_safe_divide(s->alpha * s->rho, s->omega * rho_bar);    /* :118 */
     oracle_bicg_p(n, s->p, s->r, beta, s->omega, s->v);               /* :119 */
   }
-  op_mul(&s->b, s->v, s->p);                                          /* :137 */
+  const int right_pre = RIGHT_PRE(&s->b);
+  side_mul(&s->b, s->v, s->z, s->p);                                  /* :134-137 */
   s->alpha = oracle_safe_divide(s->rho, oracle_dot(n, s->rt, s->v));  /* :139 */
-  oracle_axpy(n, x, s->alpha, s->p);                                  /* :140 */
+  oracle_axpy(n, x, s->alpha, right_pre ? s->z : s->p);               /* :140 */
   oracle_axmy(n, s->r, s->alpha, s->v);                               /* :141 */
-  op_mul(&s->b, s->t, s->r);                                          /* :158 */
+  side_mul(&s->b, s->t, s->z, s->r);                                  /* :155-158 */
   s->omega = oracle_safe_divide(oracle_dot(n, s->t, s->r),
                                 oracle_dot(n, s->t, s->t));           /* :159-160 */
-  oracle_axpy(n, x, s->omega, s->r);                                  /* :161 */
+  oracle_axpy(n, x, s->omega, right_pre ? s->z : s->r);               /* :161 */
   oracle_axmy(n, s->r, s->omega, s->t);                               /* :162 */
   return oracle_norm2(n, s->r);                                       /* :164 */
 }
@@ -476,9 +538,10 @@ ORACLE_API void oracle_solve_bicgstab(oracle_apply_fn apply, void *op,
   bicg_state s;
   memset(&s, 0, sizeof s);
   s.b.apply = apply, s.b.op = op, s.b.n = n, s.b.history = history;
+  take_preconditioner(&s.b);
   const solver_vt vt = {bicg_init, bicg_iterate, NULL};
   iterative_solve(&s.b, &vt, &s, x, b, p, res);
-  free(s.p), free(s.r), free(s.rt), free(s.t), free(s.v);
+  free(s.p), free(s.r), free(s.rt), free(s.t), free(s.v), free(s.z);
 }
 
 /* ---- GMRES(m) / FGMRES(m): Solvers/SolverGmres.hpp:41-255,281-308 under    */
@@ -623,13 +686,16 @@ ORACLE_API int64_t oracle_solve_gmres_pre(oracle_apply_fn apply, void *op, oracl
   gmres_state s;
   memset(&s, 0, sizeof s);
   s.b.apply = apply, s.b.op = op, s.b.n = n, s.b.history = history;
+  take_preconditioner(&s.b);
   s.m = p->num_inner_iterations;
+  if (pre == NULL && s.b.pre != NULL) pre = s.b.pre, pre_ctx = s.b.pre_ctx, side = s.b.side;  /* staged by oracle_set_preconditioner */
   s.pre = pre, s.pre_ctx = pre_ctx, s.side = side, s.flexible = flexible;
   const solver_vt vt = {gmres_outer_init, gmres_iterate, gmres_finalize};
   iterative_solve(&s.b, &vt, &s, x, b, p, res);
   for (int64_t i = 0; i <= s.m; ++i) free(s.q[i]);
   for (int64_t i = 0; i < s.nz; ++i) free(s.z[i]);
   free(s.q), free(s.z), free(s.beta), free(s.cs), free(s.sn), free(s.H);
+  g_last_pre_applies = s.pre_applies;
   return s.pre_applies;
 }
 
@@ -651,18 +717,27 @@ ORACLE_API void oracle_diag_apply(void *ctx, double *y, const double *x) {
   for (int64_t i = 0; i < op->n; ++i) y[i] = op->d[i] * x[i];
 }
 
-/* ---- Richardson: Solvers/SolverRichardson.hpp:41-98 (no preconditioner) --- */
+/* ---- Richardson: Solvers/SolverRichardson.hpp:41-98 (ignores pre_side) --- */
 typedef struct rich_state {
   solver_base b;
   double omega;
-  double *r;
+  double *r, *z;
 } rich_state;
 
+static void rich_precondition(rich_state *s) {              /* :66-69 == :90-93 */
+  if (s->b.pre) {
+    double *t_ = s->z;
+    s->z = s->r, s->r = t_;
+    pre_mul(&s->b, s->r, s->z);
+  }
+}
 static double rich_init(void *sv, const double *x, const double *b) {
   rich_state *s = (rich_state *)sv;
   s->r = new_vec(s->b.n);                                   /* :53 */
+  if (s->b.pre) s->z = new_vec(s->b.n);                     /* :54 */
   s->b.applies++;
   op_residual(s->b.apply, s->b.op, s->b.n, s->r, b, x);     /* :65 */
+  rich_precondition(s);
   return oracle_norm2(s->b.n, s->r);                        /* :71 */
 }
 static double rich_iterate(void *sv, double *x, const double *b) {
@@ -670,6 +745,7 @@ static double rich_iterate(void *sv, double *x, const double *b) {
   oracle_axpy(s->b.n, x, s->omega, s->r);                   /* :88  x += omega r */
   s->b.applies++;
   op_residual(s->b.apply, s->b.op, s->b.n, s->r, b, x);     /* :89 */
+  rich_precondition(s);
   return oracle_norm2(s->b.n, s->r);                        /* :95 */
 }
 ORACLE_API void oracle_solve_richardson(oracle_apply_fn apply, void *op, int64_t n, double *x,
@@ -678,13 +754,14 @@ ORACLE_API void oracle_solve_richardson(oracle_apply_fn apply, void *op, int64_t
   rich_state s;
   memset(&s, 0, sizeof s);
   s.b.apply = apply, s.b.op = op, s.b.n = n, s.b.history = history;
+  take_preconditioner(&s.b);
   s.omega = p->relaxation_factor;
   const solver_vt vt = {rich_init, rich_iterate, NULL};
   iterative_solve(&s.b, &vt, &s, x, b, p, res);
-  free(s.r);
+  free(s.r), free(s.z);
 }
 
-/* ---- CGS: Solvers/SolverCgs.hpp:50-176 (no preconditioner) -------------- */
+/* ---- CGS: Solvers/SolverCgs.hpp:50-176 ---------------------------------- */
 typedef struct cgs_state {
   solver_base b;
   double rho;
@@ -698,6 +775,11 @@ static double cgs_init(void *sv, const double *x, const double *b) {
   s->rt = new_vec(n), s->u = new_vec(n), s->v = new_vec(n);
   s->b.applies++;
   op_residual(s->b.apply, s->b.op, n, s->r, b, x);          /* :80 */
+  if (LEFT_PRE(&s->b)) {                                    /* :81-84 */
+    double *t_ = s->u;
+    s->u = s->r, s->r = t_;
+    pre_mul(&s->b, s->r, s->u);
+  }
   oracle_copy(n, s->rt, s->r);                              /* :85 */
   s->rho = oracle_dot(n, s->rt, s->r);                      /* :86 */
   return sqrt(s->rho);                                      /* :88 */
@@ -716,13 +798,25 @@ static double cgs_iterate(void *sv, double *x, const double *b) {
     for (int64_t i = 0; i < n; ++i) s->u[i] = s->r[i] + beta * s->q[i];                 /* :121 */
     for (int64_t i = 0; i < n; ++i) s->p[i] = s->u[i] + beta * (s->q[i] + beta * s->p[i]); /* :122 */
   }
-  op_mul(&s->b, s->v, s->p);                                /* :139 */
+  side_mul(&s->b, s->v, s->q, s->p);                        /* :137-139 */
   const double alpha = oracle_safe_divide(s->rho, oracle_dot(n, s->rt, s->v)); /* :140 */
   for (int64_t i = 0; i < n; ++i) s->q[i] = s->u[i] - alpha * s->v[i];  /* :141 */
   for (int64_t i = 0; i < n; ++i) s->v[i] = s->u[i] + s->q[i];          /* :142 */
-  op_mul(&s->b, s->u, s->v);                                /* :167 */
-  oracle_axpy(n, x, alpha, s->v);                           /* :168 */
-  oracle_axmy(n, s->r, alpha, s->u);                        /* :169 */
+  if (LEFT_PRE(&s->b)) {                                    /* :159-162 */
+    oracle_axpy(n, x, alpha, s->v);
+    op_mul(&s->b, s->u, s->v);                              /* pre_op->mul(v, u, lin_op, v) */
+    pre_mul(&s->b, s->v, s->u);
+    oracle_axmy(n, s->r, alpha, s->v);
+  } else if (RIGHT_PRE(&s->b)) {                            /* :163-166 */
+    pre_mul(&s->b, s->u, s->v);                             /* lin_op.mul(v, u, *pre_op, v) */
+    op_mul(&s->b, s->v, s->u);
+    oracle_axpy(n, x, alpha, s->u);
+    oracle_axmy(n, s->r, alpha, s->v);
+  } else {
+    op_mul(&s->b, s->u, s->v);                              /* :167 */
+    oracle_axpy(n, x, alpha, s->v);                         /* :168 */
+    oracle_axmy(n, s->r, alpha, s->u);                      /* :169 */
+  }
   return oracle_norm2(n, s->r);                             /* :172 */
 }
 ORACLE_API void oracle_solve_cgs(oracle_apply_fn apply, void *op, int64_t n, double *x, const double *b,
@@ -730,17 +824,18 @@ ORACLE_API void oracle_solve_cgs(oracle_apply_fn apply, void *op, int64_t n, dou
   cgs_state s;
   memset(&s, 0, sizeof s);
   s.b.apply = apply, s.b.op = op, s.b.n = n, s.b.history = history;
+  take_preconditioner(&s.b);
   const solver_vt vt = {cgs_init, cgs_iterate, NULL};
   iterative_solve(&s.b, &vt, &s, x, b, p, res);
   free(s.p), free(s.q), free(s.r), free(s.rt), free(s.u), free(s.v);
 }
 
-/* ---- TFQMR / TFQMR1: Solvers/SolverTfqmr.hpp:37-265 (no preconditioner) -- */
+/* ---- TFQMR / TFQMR1: Solvers/SolverTfqmr.hpp:37-265 --------------------- */
 typedef struct tfqmr_state {
   solver_base b;
   int l1;
   double rho, tau;
-  double *d, *rt, *u, *v, *y, *s;
+  double *d, *rt, *u, *v, *y, *s, *z;
 } tfqmr_state;
 
 static double tfqmr_init(void *sv, const double *x, const double *b) {
@@ -751,7 +846,13 @@ static double tfqmr_init(void *sv, const double *x, const double *b) {
   if (s->l1) oracle_copy(n, s->d, x);                       /* :73-77 */
   else oracle_fill(n, s->d, 0.0);
   s->b.applies++;
+  if (s->b.pre) s->z = new_vec(n);                          /* :56 */
   op_residual(s->b.apply, s->b.op, n, s->y, b, x);          /* :78 */
+  if (LEFT_PRE(&s->b)) {                                    /* :79-82 */
+    double *t_ = s->z;
+    s->z = s->y, s->y = t_;
+    pre_mul(&s->b, s->y, s->z);
+  }
   oracle_copy(n, s->u, s->y);                               /* :83 */
   oracle_copy(n, s->rt, s->u);                              /* :84 */
   s->rho = oracle_dot(n, s->rt, s->u);                      /* :85 */
@@ -762,8 +863,9 @@ static double tfqmr_iterate(void *sv, double *x, const double *b) {
   (void)b;
   tfqmr_state *s = (tfqmr_state *)sv;
   const int64_t n = s->b.n;
+  const int right_pre = RIGHT_PRE(&s->b);
   if (s->b.iteration == 0) {                                /* :121-126 */
-    op_mul(&s->b, s->s, s->y);
+    side_mul(&s->b, s->s, s->z, s->y);
     oracle_copy(n, s->v, s->s);
   } else {
     const double rho_bar = s->rho;                          /* :128-129 */
@@ -771,13 +873,13 @@ static double tfqmr_iterate(void *sv, double *x, const double *b) {
     const double beta = oracle_safe_divide(s->rho, rho_bar); /* :130 */
     oracle_xpay(n, s->v, s->s, beta);                       /* :131  v <<= s + beta v */
     oracle_xpay(n, s->y, s->u, beta);                       /* :132  y <<= u + beta y */
-    op_mul(&s->b, s->s, s->y);                              /* :133-135 */
+    side_mul(&s->b, s->s, s->z, s->y);                      /* :133-135 */
     oracle_xpay(n, s->v, s->s, beta);                       /* :136 */
   }
   const double alpha = oracle_safe_divide(s->rho, oracle_dot(n, s->rt, s->v)); /* :166 */
   for (int m = 0; m <= 1; ++m) {                            /* :167-189 */
     oracle_axmy(n, s->u, alpha, s->s);                      /* :168 */
-    oracle_axpy(n, s->d, alpha, s->y);                      /* :169 */
+    oracle_axpy(n, s->d, alpha, right_pre ? s->z : s->y);   /* :169 */
     const double omega = oracle_norm2(n, s->u);             /* :170 */
     if (s->l1) {
       if (omega < s->tau) s->tau = omega, oracle_copy(n, x, s->d); /* :172 */
@@ -790,7 +892,7 @@ static double tfqmr_iterate(void *sv, double *x, const double *b) {
     }
     if (m == 0) {
       oracle_axmy(n, s->y, alpha, s->v);                    /* :180 */
-      op_mul(&s->b, s->s, s->y);                            /* :181-183 */
+      side_mul(&s->b, s->s, s->z, s->y);                    /* :181-183 */
     }
   }
   double tau_tilde = s->tau;                                /* :199-204 */
@@ -802,10 +904,11 @@ static void tfqmr_solve(int l1, oracle_apply_fn apply, void *op, int64_t n, doub
   tfqmr_state s;
   memset(&s, 0, sizeof s);
   s.b.apply = apply, s.b.op = op, s.b.n = n, s.b.history = history;
+  take_preconditioner(&s.b);
   s.l1 = l1;
   const solver_vt vt = {tfqmr_init, tfqmr_iterate, NULL};
   iterative_solve(&s.b, &vt, &s, x, b, p, res);
-  free(s.d), free(s.rt), free(s.u), free(s.v), free(s.y), free(s.s);
+  free(s.d), free(s.rt), free(s.u), free(s.v), free(s.y), free(s.s), free(s.z);
 }
 ORACLE_API void oracle_solve_tfqmr(oracle_apply_fn apply, void *op, int64_t n, double *x, const double *b,
                                    const oracle_params *p, oracle_result *res, double *history) {
@@ -857,13 +960,14 @@ ORACLE_API void oracle_fill_randomly(int64_t n, double *y) {
   }
 }
 
-/* ---- BiCGStab(l): Solvers/SolverBiCgStab.hpp:184-383 (no preconditioner) -- */
+/* ---- BiCGStab(l): Solvers/SolverBiCgStab.hpp:184-383 (a preconditioner is  */
+/* always applied on the left, whatever pre_side says) ---------------------- */
 typedef struct bicgl_state {
   solver_base b;
   int64_t l;
   double alpha, rho, omega;
   double *gamma, *gamma_bar, *gamma_bbar, *sigma, *tau; /* tau is (l+1) x (l+1) */
-  double *rt;
+  double *rt, *z;
   double **r, **u;
 } bicgl_state;
 #define TAU_(s, i, j) ((s)->tau[(i) * ((s)->l + 1) + (j)])
@@ -882,7 +986,13 @@ static double bicgl_init(void *sv, const double *x, const double *b) {
   for (int64_t i = 0; i <= l; ++i) s->r[i] = new_vec(n), s->u[i] = new_vec(n);
   oracle_fill(n, s->u[0], 0.0);                                      /* :224 */
   s->b.applies++;
+  if (s->b.pre) s->z = new_vec(n);                                   /* :217 */
   op_residual(s->b.apply, s->b.op, n, s->r[0], b, x);                /* :225 */
+  if (s->b.pre) {                                                    /* :226-229 */
+    double *t_ = s->z;
+    s->z = s->r[0], s->r[0] = t_;
+    pre_mul(&s->b, s->r[0], s->z);
+  }
   oracle_copy(n, s->rt, s->r[0]);                                    /* :230 */
   s->rho = oracle_dot(n, s->rt, s->r[0]);                            /* :231 */
   return sqrt(s->rho);
@@ -901,11 +1011,21 @@ static double bicgl_iterate(void *sv, double *x, const double *b) {
     for (int64_t i = 0; i <= j; ++i)                                 /* :269-271 */
       for (int64_t q = 0; q < n; ++q) s->u[i][q] = s->r[i][q] - beta * s->u[i][q];
   }
-  op_mul(&s->b, s->u[j + 1], s->u[j]);                               /* :276 */
+  if (s->b.pre) {                                                    /* :273-274 */
+    op_mul(&s->b, s->z, s->u[j]);
+    pre_mul(&s->b, s->u[j + 1], s->z);
+  } else {
+    op_mul(&s->b, s->u[j + 1], s->u[j]);                             /* :276 */
+  }
   s->alpha = oracle_safe_divide(s->rho, oracle_dot(n, s->rt, s->u[j + 1])); /* :278 */
   for (int64_t i = 0; i <= j; ++i) oracle_axmy(n, s->r[i], s->alpha, s->u[i + 1]); /* :279-281 */
   oracle_axpy(n, x, s->alpha, s->u[0]);                              /* :291 */
-  op_mul(&s->b, s->r[j + 1], s->r[j]);                               /* :295 */
+  if (s->b.pre) {                                                    /* :292-293 */
+    op_mul(&s->b, s->z, s->r[j]);
+    pre_mul(&s->b, s->r[j + 1], s->z);
+  } else {
+    op_mul(&s->b, s->r[j + 1], s->r[j]);                             /* :295 */
+  }
   if (j == l - 1) {                                                  /* :298-365 */
     for (int64_t jj = 1; jj <= l; ++jj) {
       for (int64_t i = 1; i < jj; ++i) {
@@ -941,20 +1061,21 @@ ORACLE_API void oracle_solve_bicgstabl(oracle_apply_fn apply, void *op, int64_t 
   bicgl_state s;
   memset(&s, 0, sizeof s);
   s.b.apply = apply, s.b.op = op, s.b.n = n, s.b.history = history;
+  take_preconditioner(&s.b);
   s.l = p->num_inner_iterations;  /* default 2, :379-381 */
   const solver_vt vt = {bicgl_init, bicgl_iterate, NULL};
   iterative_solve(&s.b, &vt, &s, x, b, p, res);
   for (int64_t i = 0; i <= s.l; ++i) free(s.r[i]), free(s.u[i]);
-  free(s.r), free(s.u), free(s.rt), free(s.gamma), free(s.gamma_bar), free(s.gamma_bbar), free(s.sigma), free(s.tau);
+  free(s.r), free(s.u), free(s.rt), free(s.z), free(s.gamma), free(s.gamma_bar), free(s.gamma_bbar), free(s.sigma), free(s.tau);
 }
 
-/* ---- IDR(s): Solvers/SolverIdrs.hpp:52-291 (no preconditioner) ----------- */
+/* ---- IDR(s): Solvers/SolverIdrs.hpp:52-291 ------------------------------- */
 typedef struct idrs_state {
   solver_base b;
   int64_t s;
   double omega;
   double *phi, *gamma, *mu; /* mu is s x s */
-  double *r, *v;
+  double *r, *v, *z;
   double **p, **u, **g;
 } idrs_state;
 #define MU_(st, i, j) ((st)->mu[(i) * (st)->s + (j)])
@@ -971,7 +1092,13 @@ static double idrs_init(void *sv, const double *x, const double *b) {
   st->g = (double **)calloc((size_t)s, sizeof(double *));
   for (int64_t i = 0; i < s; ++i) st->p[i] = new_vec(n), st->u[i] = new_vec(n), st->g[i] = new_vec(n);
   st->b.applies++;
+  if (st->b.pre) st->z = new_vec(n);                                 /* :79 */
   op_residual(st->b.apply, st->b.op, n, st->r, b, x);               /* :99 */
+  if (LEFT_PRE(&st->b)) {                                            /* :100-103 */
+    double *t_ = st->z;
+    st->z = st->r, st->r = t_;
+    pre_mul(&st->b, st->r, st->z);
+  }
   st->phi[0] = oracle_norm2(n, st->r);                               /* :104 */
   return st->phi[0];
 }
@@ -1006,9 +1133,19 @@ static double idrs_iterate(void *sv, double *x, const double *b) {
   }
   for (int64_t q = 0; q < n; ++q) st->v[q] = st->r[q] - st->gamma[k] * st->g[k][q];   /* :200 */
   for (int64_t i = k + 1; i < s; ++i) oracle_axmy(n, st->v, st->gamma[i], st->g[i]); /* :201-203 */
+  if (RIGHT_PRE(&st->b)) {                                           /* :204-207 */
+    double *t_ = st->z;
+    st->z = st->v, st->v = t_;
+    pre_mul(&st->b, st->v, st->z);
+  }
   for (int64_t q = 0; q < n; ++q) st->u[k][q] = st->omega * st->v[q] + st->gamma[k] * st->u[k][q]; /* :208 */
   for (int64_t i = k + 1; i < s; ++i) oracle_axpy(n, st->u[k], st->gamma[i], st->u[i]);           /* :209-211 */
-  op_mul(&st->b, st->g[k], st->u[k]);                                /* :215 */
+  if (LEFT_PRE(&st->b)) {                                            /* :212-213 */
+    op_mul(&st->b, st->z, st->u[k]);
+    pre_mul(&st->b, st->g[k], st->z);
+  } else {
+    op_mul(&st->b, st->g[k], st->u[k]);                              /* :215 */
+  }
   for (int64_t i = 0; i < k; ++i) {                                  /* :230-235 */
     const double alpha = oracle_safe_divide(oracle_dot(n, st->p[i], st->g[k]), MU_(st, i, i));
     oracle_axmy(n, st->u[k], alpha, st->u[i]);
@@ -1020,9 +1157,9 @@ static double idrs_iterate(void *sv, double *x, const double *b) {
   oracle_axmy(n, st->r, beta, st->g[k]);
   for (int64_t i = k + 1; i < s; ++i) st->phi[i] -= beta * MU_(st, i, k);
   if (k == s - 1) {                                                  /* :256-279 */
-    op_mul(&st->b, st->v, st->r);
+    side_mul(&st->b, st->v, st->z, st->r);                           /* :270-272 */
     st->omega = oracle_safe_divide(oracle_dot(n, st->v, st->r), oracle_dot(n, st->v, st->v));
-    oracle_axpy(n, x, st->omega, st->r);
+    oracle_axpy(n, x, st->omega, RIGHT_PRE(&st->b) ? st->z : st->r); /* :276 */
     oracle_axmy(n, st->r, st->omega, st->v);
   }
   return oracle_norm2(n, st->r);                                     /* :281 */
@@ -1032,11 +1169,12 @@ ORACLE_API void oracle_solve_idrs(oracle_apply_fn apply, void *op, int64_t n, do
   idrs_state st;
   memset(&st, 0, sizeof st);
   st.b.apply = apply, st.b.op = op, st.b.n = n, st.b.history = history;
+  take_preconditioner(&st.b);
   st.s = p->num_inner_iterations;  /* default 4, :287-289 */
   const solver_vt vt = {idrs_init, idrs_iterate, NULL};
   iterative_solve(&st.b, &vt, &st, x, b, p, res);
   for (int64_t i = 0; i < st.s; ++i) free(st.p[i]), free(st.u[i]), free(st.g[i]);
-  free(st.p), free(st.u), free(st.g), free(st.r), free(st.v), free(st.phi), free(st.gamma), free(st.mu);
+  free(st.p), free(st.u), free(st.g), free(st.r), free(st.v), free(st.z), free(st.phi), free(st.gamma), free(st.mu);
 }
 
 ORACLE_API int oracle_abi_version(void) { return 3; }
@@ -1097,6 +1235,7 @@ ORACLE_API int64_t oracle_solve_jfnk(oracle_apply_fn apply, void *op, int64_t n,
   jfnk_state st;
   memset(&st, 0, sizeof st);
   st.b.apply = apply, st.b.op = op, st.b.n = n, st.b.history = history;
+  take_preconditioner(&st.b);
   const solver_vt vt = {jfnk_init, jfnk_iterate, NULL};
   iterative_solve(&st.b, &vt, &st, x, b, p, res);
   free(st.s), free(st.t), free(st.r), free(st.w);

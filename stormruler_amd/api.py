@@ -881,22 +881,35 @@ class RichardsonSolver(IterativeSolver):
         return norm_2(self._r_vec)
 
 
-class CgsSolver(IterativeSolver):
-    """SolverCgs.hpp:50-176, unpreconditioned branch."""
+def _side_mul(solver, pre_op, lin_op, z_vec, y_vec, x_vec) -> None:
+    """The three-way dispatch every preconditioned solver body repeats (e.g. SolverBiCgStab.hpp:134-137):
+    left ``z = P(y = A x)``, right ``z = A(y = P x)``, otherwise ``z = A x``."""
+    if pre_op is not None and solver.pre_side == PreconditionerSide.Left:
+        pre_op.mul_chain(z_vec, y_vec, lin_op, x_vec)
+    elif pre_op is not None and solver.pre_side == PreconditionerSide.Right:
+        lin_op.mul_chain(z_vec, y_vec, pre_op, x_vec)
+    else:
+        lin_op.mul(z_vec, x_vec)
 
-    def init(self, x_vec, b_vec, lin_op, pre_op):
-        if pre_op is not None:
-            raise NotImplementedError("preconditioned CGS is not part of the hot path")
+
+class CgsSolver(IterativeSolver):
+    """SolverCgs.hpp:50-176 (unpreconditioned, left and right preconditioned branches)."""
+
+    def init(self, x_vec, b_vec, lin_op, pre_op):  # :57-90
+        left_pre = pre_op is not None and self.pre_side == PreconditionerSide.Left
         for nme in ("_p_vec", "_q_vec", "_r_vec", "_r_tilde_vec", "_u_vec", "_v_vec"):
-            v = DeviceVector()
-            v.assign(x_vec, False)
-            setattr(self, nme, v)
+            setattr(self, nme, _like(x_vec))
         lin_op.Residual(self._r_vec, b_vec, x_vec)
+        if left_pre:  # :81-84
+            self._u_vec, self._r_vec = self._r_vec, self._u_vec
+            pre_op.mul(self._r_vec, self._u_vec)
         self._r_tilde_vec <<= self._r_vec
         self._rho = dot_product(self._r_tilde_vec, self._r_vec)
         return math.sqrt(self._rho)
 
-    def iterate(self, x_vec, b_vec, lin_op, pre_op):
+    def iterate(self, x_vec, b_vec, lin_op, pre_op):  # :92-174
+        left_pre = pre_op is not None and self.pre_side == PreconditionerSide.Left
+        right_pre = pre_op is not None and self.pre_side == PreconditionerSide.Right
         p, q, r, u, v = self._p_vec, self._q_vec, self._r_vec, self._u_vec, self._v_vec
         if self.iteration == 0:
             u <<= r
@@ -906,55 +919,66 @@ class CgsSolver(IterativeSolver):
             beta = safe_divide(self._rho, rho_bar)
             u <<= r + beta * q
             p <<= u + beta * (q + beta * p)
-        lin_op.mul(v, p)
+        _side_mul(self, pre_op, lin_op, v, q, p)  # :137-139
         alpha = safe_divide(self._rho, dot_product(self._r_tilde_vec, v))
         q <<= u - alpha * v
         v <<= u + q
-        lin_op.mul(u, v)
-        x_vec += alpha * v
-        r -= alpha * u
+        if left_pre:  # :159-162
+            x_vec += alpha * v
+            pre_op.mul_chain(v, u, lin_op, v)
+            r -= alpha * v
+        elif right_pre:  # :163-166
+            lin_op.mul_chain(v, u, pre_op, v)
+            x_vec += alpha * u
+            r -= alpha * v
+        else:  # :167-169
+            lin_op.mul(u, v)
+            x_vec += alpha * v
+            r -= alpha * u
         return norm_2(r)
 
 
 class _BaseTfqmrSolver(IterativeSolver):
-    """SolverTfqmr.hpp:37-206, unpreconditioned branch; ``_L1`` selects TFQMR1."""
+    """SolverTfqmr.hpp:37-206 (unpreconditioned, left and right preconditioned); ``_L1`` selects TFQMR1."""
 
     _L1 = False
 
-    def init(self, x_vec, b_vec, lin_op, pre_op):
-        if pre_op is not None:
-            raise NotImplementedError("preconditioned TFQMR is not part of the hot path")
+    def init(self, x_vec, b_vec, lin_op, pre_op):  # :45-88
+        left_pre = pre_op is not None and self.pre_side == PreconditionerSide.Left
         for nme in ("_d_vec", "_r_tilde_vec", "_u_vec", "_v_vec", "_y_vec", "_s_vec"):
-            v = DeviceVector()
-            v.assign(x_vec, False)
-            setattr(self, nme, v)
+            setattr(self, nme, _like(x_vec))
+        self._z_vec = _like(x_vec) if pre_op is not None else None
         if self._L1:
             self._d_vec <<= x_vec
         else:
             fill_with(self._d_vec, 0.0)
         lin_op.Residual(self._y_vec, b_vec, x_vec)
+        if left_pre:  # :79-82
+            self._z_vec, self._y_vec = self._y_vec, self._z_vec
+            pre_op.mul(self._y_vec, self._z_vec)
         self._u_vec <<= self._y_vec
         self._r_tilde_vec <<= self._u_vec
         self._rho = dot_product(self._r_tilde_vec, self._u_vec)
         self._tau = math.sqrt(self._rho)
         return self._tau
 
-    def iterate(self, x_vec, b_vec, lin_op, pre_op):
-        d, u, v, y, s = self._d_vec, self._u_vec, self._v_vec, self._y_vec, self._s_vec
+    def iterate(self, x_vec, b_vec, lin_op, pre_op):  # :90-206
+        right_pre = pre_op is not None and self.pre_side == PreconditionerSide.Right
+        d, u, v, y, s, z = self._d_vec, self._u_vec, self._v_vec, self._y_vec, self._s_vec, self._z_vec
         if self.iteration == 0:
-            lin_op.mul(s, y)
+            _side_mul(self, pre_op, lin_op, s, z, y)
             v <<= s
         else:
             rho_bar, self._rho = self._rho, dot_product(self._r_tilde_vec, u)
             beta = safe_divide(self._rho, rho_bar)
             v <<= s + beta * v
             y <<= u + beta * y
-            lin_op.mul(s, y)
+            _side_mul(self, pre_op, lin_op, s, z, y)
             v <<= s + beta * v
         alpha = safe_divide(self._rho, dot_product(self._r_tilde_vec, v))
         for m in range(2):
             u -= alpha * s
-            d += alpha * y
+            d += alpha * (z if right_pre else y)  # :169
             omega = norm_2(u)
             if self._L1:
                 if omega < self._tau:
@@ -967,7 +991,7 @@ class _BaseTfqmrSolver(IterativeSolver):
                 d *= sn ** 2
             if m == 0:
                 y -= alpha * v
-                lin_op.mul(s, y)
+                _side_mul(self, pre_op, lin_op, s, z, y)
         tau_tilde = self._tau
         if not self._L1:
             tau_tilde *= math.sqrt(2.0 * self.iteration + 3.0)
@@ -1037,15 +1061,14 @@ class JfnkSolver(IterativeSolver):
 
 
 class BiCgStabLSolver(InnerOuterIterativeSolver):
-    """SolverBiCgStab.hpp:184-383, unpreconditioned branch; ``num_inner_iterations`` is l (default 2)."""
+    """SolverBiCgStab.hpp:184-383; ``num_inner_iterations`` is l (default 2).  A preconditioner is always
+    applied on the left, whatever ``pre_side`` says (:226-229, :273-274, :292-293)."""
 
     def __init__(self):
         super().__init__()
         self.num_inner_iterations = 2  # :379-381
 
     def outer_init(self, x_vec, b_vec, lin_op, pre_op):
-        if pre_op is not None:
-            raise NotImplementedError("preconditioned BiCGStab(l) is not part of the hot path")
         l = self.num_inner_iterations
         self._gamma, self._gamma_bar = np.zeros(l + 1), np.zeros(l + 1)
         self._gamma_bbar, self._sigma = np.zeros(l + 1), np.zeros(l + 1)
@@ -1054,8 +1077,12 @@ class BiCgStabLSolver(InnerOuterIterativeSolver):
         self._r_tilde_vec = mk()
         self._r_vecs = [mk() for _ in range(l + 1)]
         self._u_vecs = [mk() for _ in range(l + 1)]
+        self._z_vec = mk() if pre_op is not None else None
         fill_with(self._u_vecs[0], 0.0)
         lin_op.Residual(self._r_vecs[0], b_vec, x_vec)
+        if pre_op is not None:  # :226-229
+            self._z_vec, self._r_vecs[0] = self._r_vecs[0], self._z_vec
+            pre_op.mul(self._r_vecs[0], self._z_vec)
         self._r_tilde_vec <<= self._r_vecs[0]
         self._rho = dot_product(self._r_tilde_vec, self._r_vecs[0])
         self._alpha = self._omega = 0.0
@@ -1071,12 +1098,18 @@ class BiCgStabLSolver(InnerOuterIterativeSolver):
             beta = safe_divide(self._alpha * self._rho, rho_bar)
             for i in range(j + 1):
                 u[i] <<= r[i] - beta * u[i]
-        lin_op.mul(u[j + 1], u[j])
+        if pre_op is not None:
+            pre_op.mul_chain(u[j + 1], self._z_vec, lin_op, u[j])
+        else:
+            lin_op.mul(u[j + 1], u[j])
         self._alpha = safe_divide(self._rho, dot_product(self._r_tilde_vec, u[j + 1]))
         for i in range(j + 1):
             r[i] -= self._alpha * u[i + 1]
         x_vec += self._alpha * u[0]
-        lin_op.mul(r[j + 1], r[j])
+        if pre_op is not None:
+            pre_op.mul_chain(r[j + 1], self._z_vec, lin_op, r[j])
+        else:
+            lin_op.mul(r[j + 1], r[j])
         if j == l - 1:
             tau, sigma, g, gb, gbb = self._tau, self._sigma, self._gamma, self._gamma_bar, self._gamma_bbar
             for jj in range(1, l + 1):
@@ -1106,15 +1139,14 @@ class BiCgStabLSolver(InnerOuterIterativeSolver):
 
 
 class IdrsSolver(InnerOuterIterativeSolver):
-    """SolverIdrs.hpp:52-291, unpreconditioned branch; ``num_inner_iterations`` is s (default 4)."""
+    """SolverIdrs.hpp:52-291 (unpreconditioned, left and right preconditioned); ``num_inner_iterations`` is s
+    (default 4)."""
 
     def __init__(self):
         super().__init__()
         self.num_inner_iterations = 4  # :287-289
 
     def outer_init(self, x_vec, b_vec, lin_op, pre_op):
-        if pre_op is not None:
-            raise NotImplementedError("preconditioned IDR(s) is not part of the hot path")
         s = self.num_inner_iterations
         self._phi, self._gamma, self._mu = np.zeros(s), np.zeros(s), np.zeros((s, s))
         mk = lambda: _like(x_vec)  # noqa: E731
@@ -1122,7 +1154,11 @@ class IdrsSolver(InnerOuterIterativeSolver):
         self._p_vecs = [mk() for _ in range(s)]
         self._u_vecs = [mk() for _ in range(s)]
         self._g_vecs = [mk() for _ in range(s)]
+        self._z_vec = mk() if pre_op is not None else None
         lin_op.Residual(self._r_vec, b_vec, x_vec)
+        if pre_op is not None and self.pre_side == PreconditionerSide.Left:  # :100-103
+            self._z_vec, self._r_vec = self._r_vec, self._z_vec
+            pre_op.mul(self._r_vec, self._z_vec)
         self._phi[0] = norm_2(self._r_vec)
         return self._phi[0]
 
@@ -1145,6 +1181,8 @@ class IdrsSolver(InnerOuterIterativeSolver):
     def inner_iterate(self, x_vec, b_vec, lin_op, pre_op):
         s, k = self.num_inner_iterations, self.inner_iteration
         phi, gamma, mu = self._phi, self._gamma, self._mu
+        left_pre = pre_op is not None and self.pre_side == PreconditionerSide.Left
+        right_pre = pre_op is not None and self.pre_side == PreconditionerSide.Right
         p, u, g, r, v = self._p_vecs, self._u_vecs, self._g_vecs, self._r_vec, self._v_vec
         for i in range(k, s):
             gamma[i] = phi[i]
@@ -1154,10 +1192,17 @@ class IdrsSolver(InnerOuterIterativeSolver):
         v <<= r - gamma[k] * g[k]
         for i in range(k + 1, s):
             v -= gamma[i] * g[i]
+        if right_pre:  # :204-207
+            self._z_vec, self._v_vec = self._v_vec, self._z_vec
+            v = self._v_vec
+            pre_op.mul(v, self._z_vec)
         u[k] <<= self._omega * v + gamma[k] * u[k]
         for i in range(k + 1, s):
             u[k] += gamma[i] * u[i]
-        lin_op.mul(g[k], u[k])
+        if left_pre:  # :212-213
+            pre_op.mul_chain(g[k], self._z_vec, lin_op, u[k])
+        else:
+            lin_op.mul(g[k], u[k])
         for i in range(k):
             alpha = safe_divide(dot_product(p[i], g[k]), mu[i, i])
             u[k] -= alpha * u[i]
@@ -1169,10 +1214,10 @@ class IdrsSolver(InnerOuterIterativeSolver):
         r -= beta * g[k]
         for i in range(k + 1, s):
             phi[i] -= beta * mu[i, k]
-        if k == s - 1:
-            lin_op.mul(v, r)
+        if k == s - 1:  # :268-279
+            _side_mul(self, pre_op, lin_op, v, self._z_vec, r)
             self._omega = safe_divide(dot_product(v, r), dot_product(v, v))
-            x_vec += self._omega * r
+            x_vec += self._omega * (self._z_vec if right_pre else r)
             r -= self._omega * v
         return norm_2(r)
 

@@ -261,3 +261,72 @@ def test_cpp_adapter_jfnk_and_fgmres_native():
     ref = oracle.solve("gmres", ref_op, np.ones(g.n_cells), num_inner_iterations=30)
     assert got["converged"] and abs(got["iterations"] - ref.iterations) <= 2
     assert abs(got["x_norm2"] - np.linalg.norm(ref.x)) <= 1e-6 * np.linalg.norm(ref.x)
+
+
+ALL_KINDS = [("cg", "CgSolver"), ("bicgstab", "BiCgStabSolver"), ("cgs", "CgsSolver"), ("tfqmr", "TfqmrSolver"),
+             ("tfqmr1", "Tfqmr1Solver"), ("bicgstabl", "BiCgStabLSolver"), ("idrs", "IdrsSolver"),
+             ("richardson", "RichardsonSolver")]
+
+
+@pytest.mark.parametrize("side", ["left", "right"])
+@pytest.mark.parametrize("kind,cls", ALL_KINDS)
+def test_every_solver_with_jacobi_matches_oracle(env, kind, cls, side):
+    """The left / right preconditioned branches of every driver (the reference's `pre_op` / `pre_side` members,
+    Solver.hpp:74-75) against the oracle's restatement of the same branches, with the device-side Jacobi."""
+    api, mesh, oracle, ctx = env
+    spd = kind in ("cg", "richardson")
+    if spd:  # uniform box: symmetric; its diagonal still varies (6, 7, 8, 9 / h^2)
+        g = mesh.structured_box(14)
+        mat = api.StencilMatrix.from_face_graph(ctx, g)
+        op, ref_op = api.HipStencilOperator(mat, -1.0, 0.0), oracle.StencilOperator(g, -1.0, 0.0)
+        alpha_beta = (-1.0, 0.0)
+    else:
+        g, mat, op, ref_op, _ = _problem(env, 14)
+        alpha_beta = (1.0, 0.0)
+    d = api.DeviceVector(ctx, g.n_cells)
+    mat.diagonal(alpha_beta[0], alpha_beta[1], d, invert=True)
+    dinv = d.to_numpy()
+    b_host = np.ones(g.n_cells)
+    b, x = api.DeviceVector.from_numpy(ctx, b_host), api.DeviceVector(ctx, g.n_cells)
+    s = getattr(api, cls)()
+    kw = {}
+    if kind == "richardson":  # omega = 1 with Jacobi = damped Jacobi iteration; converges slowly but surely
+        s.relaxation_factor, kw["relaxation_factor"] = 0.9, 0.9
+        s.num_iterations, kw["num_iterations"] = 4000, 4000
+        s.relative_error_tolerance = s.absolute_error_tolerance = 1e-3
+        kw["abs_tol"] = kw["rel_tol"] = 1e-3
+    if kind in ("bicgstabl", "idrs"):
+        kw["num_inner_iterations"] = s.num_inner_iterations
+    s.pre_op = api.JacobiPreconditioner()
+    s.pre_side = api.PreconditionerSide.Left if side == "left" else api.PreconditionerSide.Right
+    api.rng_reset()
+    oracle.lib().oracle_rng_reset()
+    assert s.solve(x, b, op)
+    ref = oracle.solve(kind, ref_op, b_host, pre=oracle.DiagOperator(dinv), side=side, **kw)
+    assert ref.converged
+    tol_it = max(2, int(0.1 * ref.iterations))  # the short recurrences amplify rounding differences
+    assert abs(s.iteration - ref.iterations) <= tol_it, (s.iteration, ref.iterations)
+    assert np.linalg.norm(x.to_numpy() - ref.x) <= (2e-3 if kind == "richardson" else 2e-5) * np.linalg.norm(ref.x)
+    m = min(len(s.history), len(ref.history), 6)
+    assert np.allclose(s.history[:m], ref.history[:m], rtol=1e-6)
+    mat.close()
+
+
+@pytest.mark.parametrize("kind", ["cg", "bicgstab", "cgs", "tfqmr", "tfqmr1", "bicgstabl", "idrs"])
+@pytest.mark.parametrize("mode,side", [("jacobi", "right"), ("jacobi-left", "left")])
+def test_cpp_adapter_every_solver_with_jacobi(kind, mode, side):
+    """The same branches in the C++ restatement of the class templates (include/storm_hip/Storm.hpp)."""
+    from oracle import oracle
+    from stormruler_amd import mesh
+
+    n = 16
+    restart = {"bicgstabl": 2, "idrs": 4}.get(kind, 50)
+    got = _run(n, kind, mode, restart)
+    g = mesh.structured_box(n)
+    a = mesh.assemble_csr(g, -1.0, 0.0)
+    oracle.lib().oracle_rng_reset()
+    ref = oracle.solve(kind, oracle.StencilOperator(g, -1.0, 0.0), np.ones(g.n_cells),
+                       pre=oracle.DiagOperator(1.0 / a.diagonal()), side=side, num_inner_iterations=restart)
+    assert got["converged"] and ref.converged
+    assert abs(got["iterations"] - ref.iterations) <= max(2, int(0.1 * ref.iterations)), (got["iterations"], ref.iterations)
+    assert abs(got["x_norm2"] - np.linalg.norm(ref.x)) <= 1e-5 * np.linalg.norm(ref.x)

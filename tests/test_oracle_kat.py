@@ -197,3 +197,38 @@ def test_jfnk_linear_and_nonlinear():
     assert np.abs(f(r.x) - 1.0).max() < 1e-6
     h = r.history
     assert h[-1] < 1e-3 * h[-2] or h[-1] < 1e-9  # fast final contraction
+
+
+@pytest.mark.parametrize("kind", ["cg", "bicgstab", "cgs", "tfqmr", "tfqmr1", "bicgstabl", "idrs", "gmres", "richardson"])
+def test_preconditioned_branches_of_every_solver(kind):
+    """pre_op / pre_side (Solver.hpp:74-75) in every restated driver: an identity preconditioner on the LEFT
+    repeats the unpreconditioned arithmetic bit for bit (the left branches only insert `r <- P r`), and a real
+    diagonal preconditioner on a badly row-scaled system converges to the 1-D KAT from either side."""
+    import scipy.sparse as sp
+
+    n = 64
+    a = _tridiag(n)
+    b = np.ones(n)
+    kw = {"num_inner_iterations": {"bicgstabl": 2, "idrs": 4}.get(kind, 50)}
+    if kind == "richardson":
+        kw.update(relaxation_factor=0.4, num_iterations=300, abs_tol=0.0, rel_tol=0.0)
+    op = oracle.CsrOperator(a)
+    oracle.lib().oracle_rng_reset()
+    plain = oracle.solve(kind, op, b, **kw)
+    oracle.lib().oracle_rng_reset()
+    ident = oracle.solve(kind, op, b, pre=oracle.DiagOperator(np.ones(n)), side="left", **kw)
+    assert ident.iterations == plain.iterations and np.array_equal(ident.x, plain.x)
+    assert oracle.last_pre_applies() > 0 or kind == "gmres"
+    if kind == "richardson":
+        return
+    d = np.linspace(1.0, 200.0, n)
+    scaled = (sp.diags(d) @ a).tocsr() if kind != "cg" else (sp.diags(np.sqrt(d)) @ a @ sp.diags(np.sqrt(d))).tocsr()
+    rhs = d.copy() if kind != "cg" else np.sqrt(d) * b
+    sop = oracle.CsrOperator(scaled)
+    pre = oracle.DiagOperator(1.0 / scaled.diagonal())
+    for side in ("left", "right"):
+        oracle.lib().oracle_rng_reset()
+        r = oracle.solve(kind, sop, rhs, pre=pre, side=side, abs_tol=1e-9, rel_tol=1e-11, **kw)
+        assert r.converged, (kind, side)
+        x = r.x if kind != "cg" else np.sqrt(d) * r.x   # undo the symmetric scaling
+        assert abs(x[31] - 528.0) < 1e-5 * 528.0, (kind, side, x[31])
