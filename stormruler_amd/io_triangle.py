@@ -29,10 +29,15 @@ __all__ = ["read_triangle"]
 
 
 def _tokens(path: str) -> List[str]:
+    opener = open
+    if not os.path.exists(path) and os.path.exists(path + ".gz"):  # fixtures are stored compressed
+        import gzip
+
+        path, opener = path + ".gz", lambda p: gzip.open(p, "rt")
     if not os.path.exists(path):
         raise RuntimeError(f"Cannot open the file '{path}'!")  # STORM_THROW_IO -> std::runtime_error
     out: List[str] = []
-    with open(path) as f:
+    with opener(path) as f:
         for line in f:
             out.extend(line.split("#", 1)[0].split())
     return out
