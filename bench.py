@@ -49,6 +49,7 @@ def main() -> int:
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (repeatable)")
     ap.add_argument("--spinup-seconds", type=float, default=1.5, help="untimed device spin-up before the warmup steps")
     ap.add_argument("--skip-general", action="store_true", help="skip the fp64-record repeat of the measurement")
+    ap.add_argument("--skip-blas1", action="store_true", help="skip the per-kernel BLAS-1 rates")
     ap.add_argument("--force-comm", action="store_true",
                     help="take the multi-rank code path (process group, RCCL communicator, all-reduces) even at N = 1")
     args = ap.parse_args()
@@ -209,6 +210,14 @@ def main() -> int:
     except Exception:
         pass
 
+    # ---- BLAS-1 rates at this size ("plus BLAS-1 GB/s per kernel") ------------------
+    blas1 = None
+    if rank == 0 and not args.skip_blas1:
+        try:
+            blas1 = blas1_rates(api, ctx, N)
+        except Exception as e:
+            blas1 = {"error": repr(e)}
+
     # ---- CPU baseline: the oracle (port of the reference path), 1 thread, bounded sample -------
     cpu = None
     if rank == 0 and world == 1 and args.cpu_iters > 0:
@@ -255,6 +264,7 @@ def main() -> int:
                         "same measurement on fp64 records",
             },
             "general_mesh_path": general,
+            "blas1": blas1,
             "cpu_baseline": cpu,
             "cg": {"iterations_per_sec_global": K / elapsed,
                    "algorithmic_bytes_per_iteration": roof["algorithmic_bytes_per_launch"] + 96 * N,
@@ -276,6 +286,42 @@ def main() -> int:
     except Exception:
         pass
     return 0
+
+
+def blas1_rates(api, ctx, N, reps=20):
+    """Algorithmic GB/s of each BLAS-1 statement of the solver bodies at N elements (SURVEY.md 8d byte counts),
+    HIP events around `reps` back-to-back calls on the library's stream.  dot / norm2 / multi_dot return their
+    result to the host, so their figure includes the final reduction pass and the 8-byte copy per call."""
+    from stormruler_amd._lib import check, lib
+
+    v = [api.DeviceVector(ctx, N) for _ in range(10)]
+    for i, w in enumerate(v):
+        api.fill_with(w, 1.0 + 0.001 * i)
+    a, b, c = v[0], v[1], v[2]
+
+    def t(fn, bytes_per_elt):
+        for _ in range(3):
+            fn()
+        ctx.timer_start()
+        for _ in range(reps):
+            fn()
+        ms = ctx.timer_stop() / reps
+        gbs = bytes_per_elt * N / (ms * 1e-3) / 1e9
+        return {"ms": ms, "bytes_per_element": bytes_per_elt, "GBs": gbs, "frac_of_peak": gbs / HBM_PEAK_GBS}
+
+    out = {"n": N}
+    out["copy (a <<= b)"] = t(lambda: a.__ilshift__(b), 16)
+    out["fill"] = t(lambda: api.fill_with(a, 1.0), 8)
+    out["scale (a *= s)"] = t(lambda: a.__imul__(1.0000001), 16)
+    out["axpy (a += s b)"] = t(lambda: a.__iadd__(1e-9 * b), 24)
+    out["xpay (a <<= b + s a)"] = t(lambda: a.__ilshift__(b + 0.5 * a), 24)
+    out["sub (a <<= b - c)"] = t(lambda: a.__ilshift__(b - c), 24)
+    out["bicgstab p (a <<= b + s (a - w c))"] = t(lambda: check(lib.storm_hip_bicgstab_p(a._h, b._h, 0.5, 0.25, c._h)), 32)
+    out["dot"] = t(lambda: api.dot_product(a, b), 16)
+    out["norm2"] = t(lambda: api.norm_2(a), 8)
+    out["multi_dot k=8"] = t(lambda: api.multi_dot(a, v[1:9]), 8 * 9)
+    out["multi_axpy k=8"] = t(lambda: api.multi_axpy(a, [1e-9] * 8, v[1:9]), 8 * 10)
+    return out
 
 
 def cpu_baseline(args, n, g, perm, run, ctx):
