@@ -26,6 +26,9 @@ def build(force: bool = False) -> None:
     src = os.path.join(_HERE, "storm_oracle.c")
     stale = [p for p in _LIB_PATHS.values()
              if force or not os.path.exists(p) or os.path.getmtime(p) < os.path.getmtime(src)]
+    omp_so, omp_src = os.path.join(_HERE, "liboracle_omp.so"), os.path.join(_HERE, "storm_oracle_omp.c")
+    if force or not os.path.exists(omp_so) or os.path.getmtime(omp_so) < os.path.getmtime(omp_src):
+        stale.append(omp_so)
     if stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "all"], stdout=subprocess.DEVNULL)
 
@@ -389,3 +392,42 @@ def dF_dc(c):
     f = np.empty_like(c)
     lib().oracle_ch_dF_dc(c.size, _p(f), _p(c))
     return f
+
+
+_omp_lib = None
+
+
+def _omp():
+    global _omp_lib
+    if _omp_lib is None:
+        build()
+        _omp_lib = C.CDLL(os.path.join(_HERE, "liboracle_omp.so"))
+        _omp_lib.oracle_omp_cg.restype = C.c_double
+        _omp_lib.oracle_omp_cg.argtypes = [C.c_int64, i64p, C.POINTER(C.c_int32), f64p, f64p, f64p, C.c_int64, C.c_int]
+        _omp_lib.oracle_omp_cg_box.restype = C.c_double
+        _omp_lib.oracle_omp_cg_box.argtypes = [C.c_int, C.c_int64, C.c_int, f64p]
+    return _omp_lib
+
+
+def omp_cg_box(n: int, iterations: int, threads: int = 0):
+    """``iterations`` OpenMP CG steps on the n^3 Dirichlet box (b = 1, x0 = 0), matrix built inside with
+    first-touch placement.  Returns ``(|r| after the last step, seconds of the iteration loop, threads)``."""
+    L = _omp()
+    sec = C.c_double(0.0)
+    res = L.oracle_omp_cg_box(int(n), int(iterations), int(threads), C.byref(sec))
+    return res, sec.value, (threads if threads > 0 else L.oracle_omp_max_threads())
+
+
+def omp_cg(a_csr, b, iterations: int, threads: int = 0):
+    """OpenMP-parallel CG sample on assembled CSR rows (oracle/storm_oracle_omp.c: NOT the reference's loop
+    order; the optional "what the host CPU could do" line of bench.py).  Returns ``(x, |r|, threads used)``."""
+    _omp()
+    a = a_csr.tocsr()
+    rp = np.ascontiguousarray(a.indptr, np.int64)
+    col = np.ascontiguousarray(a.indices, np.int32)
+    val = f64(a.data)
+    b = f64(b)
+    x = np.zeros_like(b)
+    res = _omp_lib.oracle_omp_cg(a.shape[0], _pi(rp), col.ctypes.data_as(C.POINTER(C.c_int32)), _p(val), _p(x), _p(b),
+                                 int(iterations), int(threads))
+    return x, res, (threads if threads > 0 else _omp_lib.oracle_omp_max_threads())

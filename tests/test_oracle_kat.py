@@ -232,3 +232,22 @@ def test_preconditioned_branches_of_every_solver(kind):
         assert r.converged, (kind, side)
         x = r.x if kind != "cg" else np.sqrt(d) * r.x   # undo the symmetric scaling
         assert abs(x[31] - 528.0) < 1e-5 * 528.0, (kind, side, x[31])
+
+
+def test_openmp_port_agrees_with_the_sequential_oracle():
+    """oracle/storm_oracle_omp.c (bench.py's optional parallel CPU line) is the same mathematics: the residual
+    after K CG steps on the Dirichlet box equals the sequential port's to rounding, for any thread count."""
+    from stormruler_amd import mesh
+
+    n, k = 20, 25
+    g = mesh.structured_box(n)
+    r = oracle.solve("cg", oracle.StencilOperator(g, -1.0, 0.0), np.ones(g.n_cells), num_iterations=k, abs_tol=0.0,
+                     rel_tol=0.0)
+    for threads in (1, 3):
+        res, sec, used = oracle.omp_cg_box(n, k, threads)
+        assert used == threads and sec > 0.0
+        assert abs(res - r.absolute_error) <= 1e-10 * r.absolute_error
+    a = mesh.assemble_csr(g, -1.0, 0.0)
+    x, res, _ = oracle.omp_cg(a, np.ones(g.n_cells), k, 2)
+    assert abs(res - r.absolute_error) <= 1e-10 * r.absolute_error
+    assert np.abs(x - r.x).max() <= 1e-10 * np.abs(r.x).max()
