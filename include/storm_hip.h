@@ -81,6 +81,19 @@ int storm_hip_ctx_get_spmv_profile(storm_hip_ctx *ctx, int64_t *launches, double
 int storm_hip_comm_unique_id(void *id128);
 int storm_hip_ctx_comm_init(storm_hip_ctx *ctx, const void *id128, int n_ranks, int rank);
 int storm_hip_ctx_comm_size(storm_hip_ctx *ctx, int *n_ranks, int *rank);
+/* Host-staged transport: the same multi-rank protocol (halo planes before the boundary rows of an SpMV,
+ * global sums behind every reduction) with the bytes moved by the host program's own messaging layer
+ * instead of RCCL -- for hosts that already run MPI / gloo, and for putting several ranks on ONE device.
+ *   allreduce(user, buf, count): in-place sum of `count` doubles over all ranks (host memory);
+ *   exchange(user, n_nbrs, nbr_rank, send_ptr, send, recv_ptr, recv): deliver send[send_ptr[q]..send_ptr[q+1])
+ *     to rank nbr_rank[q] and fill recv[recv_ptr[q]..recv_ptr[q+1]) with what that rank sent here.
+ * Both return 0 on success.  Synchronous (no overlap with the interior rows).  Nothing in the reference
+ * corresponds to it (single process); SURVEY.md 8e. */
+typedef int (*storm_hip_allreduce_fn)(void *user, double *buf, int count);
+typedef int (*storm_hip_exchange_fn)(void *user, int n_nbrs, const int32_t *nbr_rank, const int64_t *send_ptr,
+                                     const double *send, const int64_t *recv_ptr, double *recv);
+int storm_hip_ctx_comm_init_host(storm_hip_ctx *ctx, int n_ranks, int rank, storm_hip_allreduce_fn allreduce,
+                                 storm_hip_exchange_fn exchange, void *user);
 
 /* ---- vectors -------------------------------------------------------------
  * `Feathers::Field` as the solver `Vector` (Feathers/Field.hpp:60-114):

@@ -48,6 +48,10 @@ class OpStats(C.Structure):
                                           "offset_dictionary_size")]
 
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int64),
+                          C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double))
+
 # name -> (restype, argtypes); every symbol include/storm_hip.h declares.
 SIGNATURES = {
     "storm_hip_abi_version": (C.c_int, []),
@@ -62,6 +66,7 @@ SIGNATURES = {
     "storm_hip_timer_stop": (C.c_int, [vp, C.POINTER(C.c_float)]),
     "storm_hip_comm_unique_id": (C.c_int, [vp]),
     "storm_hip_ctx_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int]),
+    "storm_hip_ctx_comm_init_host": (C.c_int, [vp, C.c_int, C.c_int, ALLREDUCE_FN, EXCHANGE_FN, vp]),
     "storm_hip_ctx_comm_size": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "storm_hip_vec_create": (C.c_int, [vp, C.c_int64, C.c_int64, C.POINTER(vp)]),
     "storm_hip_vec_create_like": (C.c_int, [vp, C.POINTER(vp)]),

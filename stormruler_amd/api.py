@@ -97,6 +97,41 @@ class Context:
         check(lib.storm_hip_ctx_comm_init(self._h, buf, n_ranks, rank))
         self.n_ranks, self.rank = n_ranks, rank
 
+    def comm_init_host(self, n_ranks: int, rank: int, allreduce, exchange):
+        """Host-staged transport (``storm_hip_ctx_comm_init_host``): ``allreduce(buf)`` sums a float64 array over
+        the ranks in place; ``exchange(nbr_rank, sends, recvs)`` delivers ``sends[q]`` to rank ``nbr_rank[q]``
+        and fills ``recvs[q]`` with what that rank sent here (lists of float64 arrays)."""
+
+        def _allreduce(_user, buf, count):
+            try:
+                allreduce(np.ctypeslib.as_array(buf, shape=(count,)))
+                return 0
+            except Exception:  # never unwind through the C frames
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        def _exchange(_user, n_nbrs, nbr_rank, send_ptr, send, recv_ptr, recv):
+            try:
+                sp = np.ctypeslib.as_array(send_ptr, shape=(n_nbrs + 1,))
+                rp = np.ctypeslib.as_array(recv_ptr, shape=(n_nbrs + 1,))
+                nb = np.ctypeslib.as_array(nbr_rank, shape=(n_nbrs,))
+                sbuf = np.ctypeslib.as_array(send, shape=(max(int(sp[-1]), 1),))
+                rbuf = np.ctypeslib.as_array(recv, shape=(max(int(rp[-1]), 1),))
+                exchange([int(r) for r in nb], [sbuf[sp[q]:sp[q + 1]] for q in range(n_nbrs)],
+                         [rbuf[rp[q]:rp[q + 1]] for q in range(n_nbrs)])
+                return 0
+            except Exception:
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        self._host_cbs = (_lib.ALLREDUCE_FN(_allreduce), _lib.EXCHANGE_FN(_exchange))  # keep alive
+        check(lib.storm_hip_ctx_comm_init_host(self._h, n_ranks, rank, self._host_cbs[0], self._host_cbs[1], None))
+        self.n_ranks, self.rank = n_ranks, rank
+
 
 # ---------------------------------------------------------------------------------------------
 # Expression nodes (the build's counterparts of Bittern's lazy MapMatrixView nodes,

@@ -16,7 +16,25 @@ namespace storm {
 struct Comm {
   ncclComm_t halo = nullptr;
   ncclComm_t red = nullptr;
+  // Host-staged transport (storm_hip_ctx_comm_init_host): the same protocol with the bytes carried by
+  // callbacks of the host program (MPI, gloo, ...) instead of RCCL.  Synchronous; for hosts without a usable
+  // RCCL and for running the multi-rank path with several ranks on ONE device (tests/test_gpu_two_ranks.py).
+  storm_hip_allreduce_fn host_allreduce = nullptr;
+  storm_hip_exchange_fn host_exchange = nullptr;
+  void *host_user = nullptr;
+  double *h_stage = nullptr;  // pinned: [send | recv] halo values, or the reduction scalars
+  int64_t h_stage_len = 0;
 };
+
+static int host_stage(storm_hip_ctx *c, int64_t len) {
+  Comm *cm = c->comm;
+  if (len <= cm->h_stage_len) return STORM_HIP_OK;
+  if (cm->h_stage) (void)hipHostFree(cm->h_stage);
+  cm->h_stage = nullptr, cm->h_stage_len = 0;
+  HIP_TRY(hipHostMalloc((void **)&cm->h_stage, sizeof(double) * (size_t)len, hipHostMallocDefault));
+  cm->h_stage_len = len;
+  return STORM_HIP_OK;
+}
 
 #define NCCL_TRY(expr)                                                                          \
   do {                                                                                          \
@@ -28,6 +46,17 @@ struct Comm {
 
 int comm_allreduce_sum(storm_hip_ctx *c, double *d_buf, int count) {
   if (c->comm == nullptr) return STORM_HIP_OK;
+  if (c->comm->host_allreduce) {
+    STORM_TRY(host_stage(c, count));
+    double *h = c->comm->h_stage;
+    HIP_TRY(hipMemcpyAsync(h, d_buf, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int rc = c->comm->host_allreduce(c->comm->host_user, h, count);
+    if (rc != 0) STORM_FAIL(STORM_HIP_E_COMM, "host all-reduce callback returned %d", rc);
+    HIP_TRY(hipMemcpyAsync(d_buf, h, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // h is reused by the next call
+    return STORM_HIP_OK;
+  }
   STORM_REQUIRE(c->comm && c->comm->red, "all-reduce without an initialised communicator");
   NCCL_TRY(ncclAllReduce(d_buf, d_buf, (size_t)count, ncclDouble, ncclSum, c->comm->red, c->stream));
   return STORM_HIP_OK;
@@ -44,6 +73,28 @@ int comm_halo_exchange_begin(const storm_hip_op *op, double *x) {
   storm_hip_ctx *c = op->ctx;
   const HaloPlan &h = op->halo;
   if (h.n_nbrs == 0 || c->comm == nullptr) return STORM_HIP_OK;
+  if (c->comm->host_exchange) {
+    // host-staged: pack on the compute stream, copy out, let the host program move the bytes, copy the
+    // received planes into x's halo tail; nothing overlaps, the interior launch simply follows
+    const int64_t n_recv = h.recv_ptr[h.n_nbrs];
+    STORM_TRY(host_stage(c, h.n_send + n_recv));
+    double *hs = c->comm->h_stage, *hr = hs + h.n_send;
+    if (h.n_send > 0) {
+      const int64_t need = (h.n_send + kBlock - 1) / kBlock;
+      hipLaunchKernelGGL(halo_pack_kernel, dim3((int)(need > 1024 ? 1024 : need)), dim3(kBlock), 0, c->stream, h.n_send,
+                         h.d_send_idx, x, h.d_sendbuf);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(hs, h.d_sendbuf, sizeof(double) * (size_t)h.n_send, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int rc = c->comm->host_exchange(c->comm->host_user, h.n_nbrs, h.nbr_rank.data(), h.send_ptr.data(), hs,
+                                          h.recv_ptr.data(), hr);
+    if (rc != 0) STORM_FAIL(STORM_HIP_E_COMM, "host halo-exchange callback returned %d", rc);
+    if (n_recv > 0)
+      HIP_TRY(hipMemcpyAsync(x + op->n_rows, hr, sizeof(double) * (size_t)n_recv, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // the staging buffer is reused by the next exchange
+    return STORM_HIP_OK;
+  }
   STORM_REQUIRE(c->comm && c->comm->halo, "halo exchange without an initialised communicator");
   // x must be complete before it is packed
   HIP_TRY(hipEventRecord(c->ev_x_ready, c->stream));
@@ -72,7 +123,7 @@ int comm_halo_exchange_begin(const storm_hip_op *op, double *x) {
 
 int comm_halo_exchange_end(const storm_hip_op *op) {
   storm_hip_ctx *c = op->ctx;
-  if (op->halo.n_nbrs == 0 || c->comm == nullptr) return STORM_HIP_OK;
+  if (op->halo.n_nbrs == 0 || c->comm == nullptr || c->comm->host_exchange) return STORM_HIP_OK;
   HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_halo_done, 0));
   return STORM_HIP_OK;
 }
@@ -81,6 +132,7 @@ void comm_destroy(storm_hip_ctx *c) {
   if (!c->comm) return;
   if (c->comm->red && c->comm->red != c->comm->halo) (void)ncclCommDestroy(c->comm->red);
   if (c->comm->halo) (void)ncclCommDestroy(c->comm->halo);
+  if (c->comm->h_stage) (void)hipHostFree(c->comm->h_stage);
   delete c->comm;
   c->comm = nullptr;
 }
@@ -121,6 +173,19 @@ int storm_hip_ctx_comm_init(storm_hip_ctx *c, const void *id128, int n_ranks, in
   // Second communicator for the reductions; fall back to sharing one if the split is refused.
   r = ncclCommSplit(cm->halo, 0, rank, &cm->red, nullptr);
   if (r != ncclSuccess || cm->red == nullptr) cm->red = cm->halo;
+  c->comm = cm;
+  return STORM_HIP_OK;
+}
+
+int storm_hip_ctx_comm_init_host(storm_hip_ctx *c, int n_ranks, int rank, storm_hip_allreduce_fn allreduce,
+                                 storm_hip_exchange_fn exchange, void *user) {
+  STORM_REQUIRE(c, "comm_init_host: null context");
+  STORM_REQUIRE(n_ranks >= 1 && rank >= 0 && rank < n_ranks, "comm_init_host: rank %d of %d", rank, n_ranks);
+  STORM_REQUIRE(c->comm == nullptr, "comm_init_host: communicator already initialised");
+  STORM_REQUIRE(allreduce && exchange, "comm_init_host: null callback");
+  auto *cm = new Comm();
+  cm->host_allreduce = allreduce, cm->host_exchange = exchange, cm->host_user = user;
+  c->n_ranks = n_ranks, c->rank = rank;
   c->comm = cm;
   return STORM_HIP_OK;
 }

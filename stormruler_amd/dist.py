@@ -66,6 +66,33 @@ def connect(ctx) -> None:
     ctx.comm_init(uid, world, rank)
 
 
+def connect_host_staged(ctx) -> None:
+    """Give ``ctx`` the host-staged transport over the default torch.distributed group (any backend that moves
+    CPU tensors, i.e. gloo): halo planes and reduction scalars travel through host memory.  Lets several ranks
+    share ONE device (tests/test_gpu_two_ranks.py) and serves hosts without a usable RCCL."""
+    import torch
+    import torch.distributed as td
+
+    rank, world = td.get_rank(), td.get_world_size()
+
+    def allreduce(buf: np.ndarray) -> None:
+        t = torch.from_numpy(buf)  # shares memory: reduced in place
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+
+    def exchange(nbr_rank, sends, recvs) -> None:
+        reqs = []
+        for q, peer in enumerate(nbr_rank):
+            if recvs[q].size:
+                reqs.append(td.irecv(torch.from_numpy(recvs[q]), src=peer, tag=17))
+        for q, peer in enumerate(nbr_rank):
+            if sends[q].size:
+                reqs.append(td.isend(torch.from_numpy(np.ascontiguousarray(sends[q])), dst=peer, tag=17))
+        for r in reqs:
+            r.wait()
+
+    ctx.comm_init_host(world, rank, allreduce, exchange)
+
+
 def allreduce_max(value: float) -> float:
     import torch
     import torch.distributed as td

@@ -1,0 +1,38 @@
+"""The multi-rank device path with several ranks on ONE GPU (multi-GPU-vs-1-GPU parity).
+
+`gpurun` boxes have one MI355X and RCCL refuses two ranks on the same device, so the ranks here use the library's
+host-staged transport (`storm_hip_ctx_comm_init_host`: halo planes and reduction scalars travel through gloo) --
+the partition, the halo plans, the interior/boundary split of the SpMV, the placement of every all-reduce in the
+three device-resident solver loops and the rank-consistent convergence decision are exactly the ones of the
+8-GPU run; only the bytes take another road.  The RCCL calls themselves are covered by tests/test_gpu_comm.py."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world,dims", [(2, (16, 12, 8)), (3, (20, 8, 5)), (4, (12, 12, 4))])
+def test_partitioned_device_path_matches_the_global_oracle(world, dims, tmp_path):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "multi_rank_worker.py"), *map(str, dims)]
+    env = dict(os.environ, OMP_NUM_THREADS="1", STORM_REPORT_DIR=str(tmp_path))
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-3000:]
+    reports = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(world)]
+    assert sorted(r["rank"] for r in reports) == list(range(world))
+    for r in reports:  # interior ranks talk to two neighbours, the end ranks to one
+        assert len(r["nbrs"]) == (1 if r["rank"] in (0, world - 1) else 2)
