@@ -36,3 +36,17 @@ def test_partitioned_device_path_matches_the_global_oracle(world, dims, tmp_path
     assert sorted(r["rank"] for r in reports) == list(range(world))
     for r in reports:  # interior ranks talk to two neighbours, the end ranks to one
         assert len(r["nbrs"]) == (1 if r["rank"] in (0, world - 1) else 2)
+
+
+def test_cavity_on_four_ranks(tmp_path):
+    """BASELINE config 5's shape -- lid-driven cavity, pressure-Poisson CG each step, 4 ranks -- on one GPU."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "multi_rank_cavity_worker.py"), "16", "4"]
+    env = dict(os.environ, OMP_NUM_THREADS="1", STORM_REPORT_DIR=str(tmp_path))
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-3000:]
+    reports = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(4)]
+    assert all(len(r["steps"]) == 4 for r in reports)
+    # every rank saw the same CG iteration counts
+    assert all(r["steps"][k][0] == reports[0]["steps"][k][0] for r in reports for k in range(4))
