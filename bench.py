@@ -41,7 +41,9 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--n", type=int, default=256, help="cells per edge of the per-GPU block")
+    ap.add_argument("--n", "--edge", dest="n", type=int, default=256,
+                    help="cells per edge of the per-GPU block (use --edge under torch.distributed.run, whose own parser "
+                         "claims the abbreviation --n)")
     ap.add_argument("--cpu-iters", type=int, default=20, help="CPU-baseline sample (CG iterations); 0 = skip")
     ap.add_argument("--ordering", default="natural", choices=["natural", "tile"])
     ap.add_argument("--variant", type=int, default=-1, help="SpMV kernel variant override")
@@ -50,6 +52,9 @@ def main() -> int:
     ap.add_argument("--spinup-seconds", type=float, default=1.5, help="untimed device spin-up before the warmup steps")
     ap.add_argument("--skip-general", action="store_true", help="skip the fp64-record repeat of the measurement")
     ap.add_argument("--skip-blas1", action="store_true", help="skip the per-kernel BLAS-1 rates")
+    ap.add_argument("--shared-device", action="store_true",
+                    help="debug: all ranks on device 0 over the host-staged transport (gloo); exercises the N > 1 "
+                         "code path of this script on a one-GPU box -- the rates it prints mean nothing")
     ap.add_argument("--force-comm", action="store_true",
                     help="take the multi-rank code path (process group, RCCL communicator, all-reduces) even at N = 1")
     args = ap.parse_args()
@@ -69,11 +74,13 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("bench.py needs an MI355X; the HIP path has no CPU fallback", file=sys.stderr)
         return 3
+    if args.shared_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1 or args.force_comm:
         os.environ.setdefault("RANK", "0"), os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"), os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl")
+        dist.init_process_group("gloo" if args.shared_device else "nccl")
 
     n, K, W = args.n, args.steps, args.warmup
     t_setup = time.time()
@@ -95,7 +102,9 @@ def main() -> int:
     for kv in args.opt:
         k_, v_ = kv.split("=")
         ctx.set_option(k_, int(v_))
-    if args.force_comm and world == 1:
+    if args.shared_device and world > 1:
+        dist.connect_host_staged(ctx)
+    elif args.force_comm and world == 1:
         ctx.comm_init(api.Context.comm_unique_id(), 1, 0)
     else:
         dist.connect(ctx)
@@ -212,7 +221,7 @@ def main() -> int:
 
     # ---- BLAS-1 rates at this size ("plus BLAS-1 GB/s per kernel") ------------------
     blas1 = None
-    if rank == 0 and not args.skip_blas1:
+    if world == 1 and not args.skip_blas1:  # (dots on a context with a communicator are collective calls)
         try:
             blas1 = blas1_rates(api, ctx, N)
         except Exception as e:
@@ -245,7 +254,9 @@ def main() -> int:
                 "workload": f"3D 7-point Poisson {n}^3 per GPU (structured-as-unstructured FVM face graph), fp64 CG, "
                             f"no preconditioner, b=1, x0=0 [BASELINE.json configs[1]]",
                 "cells_per_gpu": N, "interior_faces_per_gpu": g.n_faces, "ordering": args.ordering,
-                "partition": "single GPU" if world == 1 else f"z-slabs, {world} ranks, RCCL halo + all-reduce",
+                "partition": "single GPU" if world == 1 else
+                             (f"z-slabs, {world} ranks, RCCL halo + all-reduce" if not args.shared_device else
+                              f"DEBUG: {world} ranks sharing one device over the host-staged transport"),
                 "value_definition": "n_gpus x K / max-over-ranks wall time of a K-iteration solve (init residual included)",
             },
             "roofline": {
