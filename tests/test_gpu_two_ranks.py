@@ -68,3 +68,18 @@ def test_bench_script_multi_rank_path(world):
     out = json.loads(lines[0])
     assert out["n_gpus"] == world and out["steps"] == 20 and out["value"] > 0 and out["scaling"] == "weak"
     assert out["roofline"]["launches_timed"] == 2 * (max(20, 20) + 1)  # interior + boundary launch per apply
+
+
+@pytest.mark.parametrize("world", [3, 5])
+def test_unstructured_partition_reproduces_the_recorded_reference_run(world, tmp_path):
+    """General meshes: RCB parts of the reference's Triangle mesh, general halo plans."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "multi_rank_unstructured_worker.py")]
+    env = dict(os.environ, OMP_NUM_THREADS="1", STORM_REPORT_DIR=str(tmp_path))
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-3000:]
+    reports = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(world)]
+    assert sum(r["n_local"] for r in reports) == 6252
+    assert len({r["iterations"] for r in reports}) == 1
+    assert max(len(r["nbrs"]) for r in reports) >= 2  # not a chain of slabs
