@@ -168,7 +168,8 @@ def main() -> int:
     # ---- roofline of the SpMV: HIP-event pairs around every launch --------------------------------
     prof_iters = max(K, 20)
     roof = spmv_roofline(op, st, prof_iters)
-    fmt_name = ("byte-indexed weights + column offsets (16 B/row)" if st["offset_dictionary_size"] else
+    fmt_name = ("paired rows: byte-indexed weights + shared column offsets (12 B/row)" if st["paired_rows"] else
+                "byte-indexed weights + column offsets (16 B/row)" if st["offset_dictionary_size"] else
                 "byte-indexed weights (8 B/row + int32 columns)" if st["value_dictionary_size"] else
                 "fp64 weights + int32 columns")
     traffic = None
@@ -187,7 +188,7 @@ def main() -> int:
         try:
             ctx.set_option("spmv_dict", 0)
             mat0 = api.StencilMatrix.from_face_graph(ctx, g)
-            ctx.set_option("spmv_dict", 2)
+            ctx.set_option("spmv_dict", 3)
             op0 = api.HipStencilOperator(mat0, alpha=-1.0, beta=0.0)
             run(max(W, 20), op0)
             ctx.sync()
@@ -260,7 +261,8 @@ def main() -> int:
                 "value_definition": "n_gpus x K / max-over-ranks wall time of a K-iteration solve (init residual included)",
             },
             "roofline": {
-                "kernel": ("spmv_dict_kernel" if st["value_dictionary_size"] else "spmv_sell_kernel") +
+                "kernel": ("spmv_pair_kernel" if st["paired_rows"] else
+                           "spmv_dict_kernel" if st["value_dictionary_size"] else "spmv_sell_kernel") +
                           " (sliced-ELL gather SpMV + fused <p,Ap> partials)",
                 "bound": "hbm", "achieved": roof["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": roof["frac"], "traffic": traffic,

@@ -45,7 +45,7 @@ class OpStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("n_rows", "n_cols", "nnz_offdiag", "ell_slots", "tail_nnz",
                                           "tail_rows", "n_slices", "max_row_len", "n_interior_slices",
                                           "device_bytes", "record_bytes", "value_dictionary_size",
-                                          "offset_dictionary_size")]
+                                          "offset_dictionary_size", "paired_rows")]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)

@@ -182,36 +182,43 @@ int storm_hip_vec_create(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, stor
   v->ctx = c;
   v->n_owned = n_owned;
   v->n_halo = n_halo;
-  // Round the allocation up so 16-byte vector accesses of the last rows stay in bounds.
-  const size_t bytes = sizeof(double) * (size_t)((n_owned + n_halo + 3) / 4 * 4 + 4);
+  // Round the allocation up so 16-byte vector accesses of the last rows stay in bounds, and keep a
+  // zero-filled guard of kVecGuard doubles IN FRONT of element 0 (256 bytes: the alignment of `d` is
+  // unchanged): the paired-row SpMV reads x[col], x[col + 1] with one 16-byte load per slot, and where one
+  // row of a pair has no neighbour in a slot (weight 0) that load may touch x[-1] or x[n].  The guard and
+  // the tail padding are zero and never written, so such a term is exactly 0 * (0 - x_i).
+  const size_t bytes = sizeof(double) * (size_t)(kVecGuard + (n_owned + n_halo + 3) / 4 * 4 + 4);
   v->bytes = bytes;
   hipError_t e = hipSuccess;
+  double *base = nullptr;
   for (size_t i = 0; i < c->pool.size(); ++i) {
     if (c->pool[i].first == bytes) {
-      v->d = c->pool[i].second;
+      base = c->pool[i].second;
       c->pool_bytes -= bytes;
       c->pool[i] = c->pool.back();
       c->pool.pop_back();
       break;
     }
   }
-  if (v->d == nullptr) {
-    e = hipMalloc(&v->d, bytes);
+  if (base == nullptr) {
+    e = hipMalloc(&base, bytes);
     if (e != hipSuccess && !c->pool.empty()) {  // give the pooled storage back and retry
       (void)hipStreamSynchronize(c->stream);
       for (auto &pb : c->pool) (void)hipFree(pb.second);
       c->pool.clear(), c->pool_bytes = 0;
-      e = hipMalloc(&v->d, bytes);
+      e = hipMalloc(&base, bytes);
     }
   }
   if (e != hipSuccess) {
     delete v;
     STORM_FAIL(STORM_HIP_E_ALLOC, "vec_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
   }
+  v->base = base;
+  v->d = base + kVecGuard;
   // Field::assign value-initialises (Feathers/Field.hpp:82-84): zero fill.
-  e = hipMemsetAsync(v->d, 0, bytes, c->stream);
+  e = hipMemsetAsync(v->base, 0, bytes, c->stream);
   if (e != hipSuccess) {
-    (void)hipFree(v->d);
+    (void)hipFree(v->base);
     delete v;
     STORM_FAIL(STORM_HIP_E_HIP, "vec_create: memset failed: %s", hipGetErrorString(e));
   }
@@ -227,14 +234,14 @@ int storm_hip_vec_create_like(const storm_hip_vec *other, storm_hip_vec **out) {
 int storm_hip_vec_destroy(storm_hip_vec *v) {
   if (!v) return STORM_HIP_OK;
   storm_hip_ctx *c = v->ctx;
-  if (v->d && (int64_t)(c->pool_bytes + v->bytes) <= c->opt_pool_bytes) {
+  if (v->base && (int64_t)(c->pool_bytes + v->bytes) <= c->opt_pool_bytes) {
     // later users of this storage are ordered behind its pending kernels by the compute stream; the
     // comm stream only touches a vector between two events of one SpMV (comm.hip)
-    c->pool.emplace_back(v->bytes, v->d);
+    c->pool.emplace_back(v->bytes, v->base);
     c->pool_bytes += v->bytes;
   } else {
     (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(v->d);
+    (void)hipFree(v->base);
   }
   delete v;
   return STORM_HIP_OK;

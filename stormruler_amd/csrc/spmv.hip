@@ -28,6 +28,18 @@
 //   it with halo planes a few more), the columns become byte indices as well and a row is ONE 16-byte word
 //        byte 0 = ext, bytes 1..7 = weight of slot 0..6, bytes 8..14 = offset of slot 0..6
 //   so a slice is a 1 KiB record whatever its width, and a row streams 16 + 8 + 8 = 32 bytes.
+// Paired rows (format 3, the default when it applies): with a third of the bytes the format-2 kernel is no
+//   longer HBM-bound but bound by the number of vector-memory instructions a row costs (one 8-byte gather per
+//   neighbour through the texture-address path; halving that count in a diagnostic build took 16 % off the
+//   kernel).  Format 3 gives each LANE two consecutive rows (2p, 2p+1) whose neighbour lists are merged into
+//   one list of column offsets (the shortest common supersequence of the two rows' offset lists, <= 7 long;
+//   a row that lacks an offset of the merged list gets weight 0 there, which leaves its sum unchanged): one
+//   16-byte load then fetches x[2p + off], x[2p + 1 + off] -- the neighbour of BOTH rows -- and x_i, y_i move
+//   as 16-byte pairs too.  Record of a 128-row group: [64 x (weights of row 2p : u64, of row 2p+1 : u64)]
+//   [64 x offsets : u64], index bytes pre-scaled (value index * 8, offset index * 4) so a bit-field extract is
+//   the LDS byte address; 12 + 8 + 8 = 28 bytes per row and 10 instead of 18 vector-memory instructions per
+//   row pair.  Needs <= 32 distinct values, <= 64 distinct offsets, < 2^28 columns, and every 16-byte gather in
+//   bounds of [-kVecGuard, n + 3] (vectors carry a zero guard in front and zero padding behind).
 // Arithmetic:  y_i = beta x_i + alpha ( sum_k w_ik (x[col_ik] - x_i) + ext_i x_i )
 //   -- the difference form of the reference's flux  (c[out] - c[in]), which keeps the
 //   cancellation behaviour of the face loop (no large diagonal * x_i term).
@@ -65,6 +77,7 @@ struct SellArgs {
 };
 
 constexpr int kDictSize = 256;
+constexpr int kPairRecBytes = 2 * kWave * 8 + kWave * 8;  // format 3: 64 x (u64, u64) weights + 64 x u64 offsets per 128 rows
 constexpr int kColSlotBytes = kWave * 4;  // 256: one slot of a value-dictionary record (columns only)
 
 struct DotArgs {
@@ -471,6 +484,92 @@ __global__ __launch_bounds__(kBlock) void spmv_dict_kernel(SellArgs A, Scal alph
   }
 }
 
+// Format 3: one lane = rows (2p, 2p + 1), one wave = 128 rows.  See the header comment.
+template <bool DOT, int W>
+__global__ __launch_bounds__(kBlock) void spmv_pair_kernel(SellArgs A, Scal alpha_s, Scal beta_s,
+                                                           const double *__restrict__ x, double *__restrict__ y,
+                                                           const int *__restrict__ slice_list,
+                                                           int64_t n_launch_slices, DotArgs dot, const int *done) {
+  const int done_flag = done ? *done : 0;
+  __shared__ double dict_sh[32];
+  __shared__ int offs_sh[64];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int bidx = (int)blockIdx.x;
+  const int lb = A.xcd_group > 1 ? xcd_remap_grouped(bidx, gridDim.x, A.xcd_group)
+                                 : (A.xcd_group == 1 ? xcd_remap(bidx, gridDim.x) : bidx);
+  const int64_t sl = (int64_t)lb * (kBlock / kWave) + wave;
+  const bool active = sl < n_launch_slices;  // wave-uniform
+  const uint32_t slice = (uint32_t)(slice_list ? slice_list[active ? sl : 0] : (active ? sl : 0));
+  const double alpha = ld_scal2(alpha_s), beta = ld_scal2(beta_s);
+  const uint32_t last_row = (uint32_t)(A.n_rows - 1);
+  const bool w_is_x = DOT && dot.w == x;
+  const bool w_load = DOT && dot.w != nullptr && !w_is_x;
+  const char *xb = reinterpret_cast<const char *>(x);
+  const char *xg_base = xb - (size_t)kVecGuard * 8;  // start of the zero guard in front of x
+  char *yb = reinterpret_cast<char *>(y);
+
+  const uint32_t r0 = slice * (2 * kWave) + 2 * lane;  // row A; row B = r0 + 1
+  const bool valid_a = active && r0 <= last_row, valid_b = active && r0 + 1 <= last_row;
+  const uint32_t rc = r0 <= last_row ? r0 : (last_row & ~1u);  // pairs past the end re-read the last pair
+  const char *rec = A.pack + (size_t)slice * kPairRecBytes;
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  const u64x2 vw = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(rec) + lane);
+  const uint64_t jw = __builtin_nontemporal_load(reinterpret_cast<const uint64_t *>(rec + 2 * kWave * 8) + lane);
+  const double2v xi = *reinterpret_cast<const double2v *>(xb + (size_t)(rc << 3));
+  double2v yo = {0.0, 0.0}, wi = {0.0, 0.0};
+  if (A.accumulate) yo = *reinterpret_cast<const double2v *>(yb + (size_t)(rc << 3));
+  if (w_load) wi = *reinterpret_cast<const double2v *>(reinterpret_cast<const char *>(dot.w) + (size_t)(rc << 3));
+  {
+    // tables: <= 64 entries each, one load per lane (the allocations hold kDictSize entries).  One copy per
+    // block at a fixed LDS address; every wave stores the same words before it reads them: no barrier.
+    const int o0 = A.offs[lane];
+    const double d0 = A.dict[lane & 31];
+    offs_sh[lane] = o0;
+    if (lane < 32) dict_sh[lane] = d0;
+  }
+  __builtin_amdgcn_wave_barrier();  // this wave's copy of the tables is complete (same-wave LDS order)
+  double2v xg[W > 0 ? W : 1];
+#pragma unroll
+  for (int k = 0; k < W; ++k) {
+    const unsigned ob = (unsigned)(jw >> (8 * k)) & 0xffu;  // = offset index * 4
+    const int off = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(offs_sh) + ob);
+    // both rows' neighbour.  The index is biased by the guard so that it is never negative (the host checked
+    // rc + off >= -kVecGuard): the address is a uniform base plus an UNSIGNED 32-bit byte offset.
+    xg[k] = *reinterpret_cast<const double2v *>(xg_base + (size_t)((rc + (uint32_t)(off + kVecGuard)) << 3));
+  }
+  double acc_a = 0.0, acc_b = 0.0;
+#pragma unroll
+  for (int k = 0; k < W; ++k) {
+    const unsigned ba = (unsigned)(vw.x >> (8 * (k + 1))) & 0xffu, bb = (unsigned)(vw.y >> (8 * (k + 1))) & 0xffu;
+    acc_a += *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + ba) * (xg[k].x - xi.x);
+    acc_b += *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + bb) * (xg[k].y - xi.y);
+  }
+  const double ext_a = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + ((unsigned)vw.x & 0xffu));
+  const double ext_b = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + ((unsigned)vw.y & 0xffu));
+  double2v yi;
+  yi.x = (A.accumulate ? yo.x : beta * xi.x) + alpha * (acc_a + ext_a * xi.x);
+  yi.y = (A.accumulate ? yo.y : beta * xi.y) + alpha * (acc_b + ext_b * xi.y);
+  if (!done_flag) {
+    if (valid_b) __builtin_nontemporal_store(yi, reinterpret_cast<double2v *>(yb + (size_t)(rc << 3)));
+    else if (valid_a) y[rc] = yi.x;  // the odd last row
+  }
+  if (done_flag) return;
+  if (DOT) {
+    yi.x = valid_a ? yi.x : 0.0;
+    yi.y = valid_b ? yi.y : 0.0;
+    double a = dot.w ? (w_is_x ? xi.x : wi.x) * yi.x + (w_is_x ? xi.y : wi.y) * yi.y : 0.0;
+    double b = yi.x * yi.x + yi.y * yi.y;
+    a = wave_sum_to_lane63(a);
+    if (dot.yy) b = wave_sum_to_lane63(b);
+    if (lane == kWave - 1) {
+      const int slot = dot.block_offset + (int)blockIdx.x * (kBlock / kWave) + wave;
+      dot.partials[slot] = a;
+      if (dot.yy) dot.partials[dot.nblocks_total + slot] = b;
+    }
+  }
+}
+
 // CSR tail: one wavefront per overflowing row; the lanes' partial products are folded
 // with __shfl_down and lane 0 adds the row's remainder to y.
 __global__ __launch_bounds__(kBlock) void spmv_tail_kernel(int64_t n_tail, const int *__restrict__ tail_row,
@@ -521,7 +620,31 @@ static void launch_sell(const storm_hip_op *op, int nb, Scal alpha, Scal beta, c
 
 // Slices per wave: SPW for the uniform-width value-dictionary kernel, 1 otherwise.
 static inline int op_spw(const storm_hip_op *op) {
+  if (op->pair) return 1;  // a "slice" of a format-3 operator is a 128-row group, one per wave
   return (op->dict_size > 0 && op->uniform_width > 0) ? (int)op->spw : 1;
+}
+
+template <bool DOT>
+static void launch_pair(const storm_hip_op *op, int nb, Scal alpha, Scal beta, const double *x, double *y,
+                        const int *slice_list, int64_t n_launch, DotArgs dot, const int *done, hipEvent_t ev0,
+                        hipEvent_t ev1, bool accumulate) {
+  const int group = slice_list ? 0 : (int)op->ctx->opt_spmv_xcd_remap;
+  SellArgs A{op->d_pack, op->d_slice_off, op->n_rows, op->uniform_width, group, op->d_dict, op->dict_size,
+             op->d_offs, op->offs_size, (int)accumulate};
+  hipStream_t st = op->ctx->stream;
+#define PAIR_GO(W_)                                                                                              \
+  hipExtLaunchKernelGGL((spmv_pair_kernel<DOT, W_>), dim3(nb), dim3(kBlock), 0, st, ev0, ev1, 0, A, alpha, beta, \
+                        x, y, slice_list, n_launch, dot, done)
+  switch (op->uniform_width) {
+    case 1: PAIR_GO(1); break;
+    case 2: PAIR_GO(2); break;
+    case 3: PAIR_GO(3); break;
+    case 4: PAIR_GO(4); break;
+    case 5: PAIR_GO(5); break;
+    case 6: PAIR_GO(6); break;
+    default: PAIR_GO(7); break;
+  }
+#undef PAIR_GO
 }
 static inline int blocks_for(const storm_hip_op *op, int64_t n_launch_slices) {
   const int64_t per_block = (kBlock / kWave) * op_spw(op);
@@ -577,6 +700,13 @@ static int launch_range(const storm_hip_op *op, Scal alpha, Scal beta, const dou
   }
   const int nb = blocks_for(op, n_launch);
   const bool nt = c->opt_nt != 0;
+  if (op->pair) {
+    if (want_dot) launch_pair<true>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1, accumulate);
+    else launch_pair<false>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1, accumulate);
+    HIP_TRY(hipGetLastError());
+    if (prof) c->prof_used += 2;
+    return STORM_HIP_OK;
+  }
   if (op_spw(op) >= 1 && op->dict_size > 0 && op->uniform_width > 0) {
     switch (op_spw(op)) {
       case 1: if (want_dot) launch_dict<true, 1>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1, accumulate);
@@ -658,6 +788,13 @@ __global__ __launch_bounds__(kBlock) void diag_sell_kernel(const char *__restric
   const int64_t s = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
   const int64_t r = s * kWave + lane;
   if (r >= n_rows) return;
+  if (fmt2 == 3) {  // paired rows: 128-row groups, weights of row r in word (r % 128), bytes pre-scaled by 8
+    const uint64_t iw = reinterpret_cast<const uint64_t *>(pack + (r >> 7) * kPairRecBytes)[r & 127];
+    double sum = 0.0;
+    for (int k = 0; k < 7; ++k) sum += dict[((unsigned)(iw >> (8 * (k + 1))) & 0xffu) >> 3];
+    d[r] = beta + alpha * (dict[((unsigned)iw & 0xffu) >> 3] - sum);
+    return;
+  }
   const char *rec = pack + slice_off[s];
   if (dict) {  // value-dictionary record (format 2: 16-byte words, weights in bytes 1..7 of the first half)
     const int w = fmt2 ? 7 : (int)((slice_off[s + 1] - slice_off[s] - kExtBytes) / kColSlotBytes);
@@ -740,6 +877,22 @@ struct ValueDict {
   int index(double v) { return find(bits(v), false); }
 };
 
+// Shortest common supersequence of two short offset lists (format 3: the merged neighbour list of a row pair).
+// Returns its length (<= na + nb), the sequence in out[], and where each input element landed in pa[] / pb[].
+static int merge_offsets(const int64_t *a, int na, const int64_t *b, int nb, int64_t *out, int *pa, int *pb) {
+  int L[9][9];  // LCS of the suffixes a[i..], b[j..]
+  for (int i = na; i >= 0; --i)
+    for (int j = nb; j >= 0; --j)
+      L[i][j] = (i == na || j == nb) ? 0 : (a[i] == b[j] ? 1 + L[i + 1][j + 1] : std::max(L[i + 1][j], L[i][j + 1]));
+  int i = 0, j = 0, m = 0;
+  while (i < na || j < nb) {
+    if (i < na && j < nb && a[i] == b[j]) pa[i] = pb[j] = m, out[m++] = a[i], ++i, ++j;
+    else if (j == nb || (i < na && L[i + 1][j] >= L[i][j + 1])) pa[i] = m, out[m++] = a[i], ++i;
+    else pb[j] = m, out[m++] = b[j], ++j;
+  }
+  return m;
+}
+
 // Build from off-diagonal CSR rows (entries already in the order they must be summed).
 static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vector<int64_t> &row_ptr,
                     const std::vector<int> &col, const std::vector<double> &val,
@@ -778,6 +931,99 @@ static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vect
       const int64_t e = std::min(row_ptr[r + 1], row_ptr[r] + w_op);
       for (int64_t k = row_ptr[r]; co && k < e; ++k) co = od.find((uint64_t)((int64_t)col[(size_t)k] - r), true) >= 0;
     }
+  }
+  // ... and whether consecutive rows can share their gathers (format 3, see the header comment)
+  bool pr = co && c->opt_spmv_dict >= 3 && max_len <= std::min<int64_t>(7, cap) && vd.values.size() <= 32 && od.values.size() <= 64 &&
+            n + n_halo < ((int64_t)1 << 28);
+  const int64_t n_groups = (n + 2 * kWave - 1) / (2 * kWave);
+  std::vector<char> pair_pack;
+  int pair_width = 0;
+  if (pr) {
+    pair_pack.assign((size_t)n_groups * kPairRecBytes, 0);
+    const uint64_t zero_v = (uint64_t)vd.index(0.0) << 3, zero_o = (uint64_t)od.find(0, false) << 2;
+    const int64_t n_total = n + n_halo;
+    for (int64_t p = 0; pr && 2 * p < n_groups * 2 * kWave; ++p) {
+      const int64_t ra = 2 * p, rb = 2 * p + 1;
+      int64_t oa[8], ob[8], merged[16];
+      int pa[8], pb[8], na = 0, nb2 = 0;
+      if (ra < n) for (int64_t k = row_ptr[ra]; k < row_ptr[ra + 1]; ++k) oa[na++] = (int64_t)col[(size_t)k] - ra;
+      if (rb < n) for (int64_t k = row_ptr[rb]; k < row_ptr[rb + 1]; ++k) ob[nb2++] = (int64_t)col[(size_t)k] - rb;
+      const int m = merge_offsets(oa, na, ob, nb2, merged, pa, pb);
+      if (m > 7) { pr = false; break; }
+      pair_width = std::max(pair_width, m);
+      for (int k = 0; k < m; ++k)  // every 16-byte gather must stay inside [guard, padding]
+        if (ra + merged[k] < -(int64_t)kVecGuard || rb + merged[k] > n_total + 3) pr = false;
+      uint64_t wa = ra < n ? ((uint64_t)vd.index(ext[(size_t)ra]) << 3) : zero_v;
+      uint64_t wb = rb < n ? ((uint64_t)vd.index(ext[(size_t)rb]) << 3) : zero_v;
+      uint64_t jw = 0;
+      for (int k = 0; k < 7; ++k) {
+        wa |= zero_v << (8 * (k + 1)), wb |= zero_v << (8 * (k + 1));
+        jw |= (k < m ? ((uint64_t)od.find((uint64_t)merged[k], false) << 2) : zero_o) << (8 * k);
+      }
+      for (int k = 0; k < na; ++k) {
+        wa &= ~(0xffull << (8 * (pa[k] + 1)));
+        wa |= ((uint64_t)vd.index(val[(size_t)(row_ptr[ra] + k)]) << 3) << (8 * (pa[k] + 1));
+      }
+      for (int k = 0; k < nb2; ++k) {
+        wb &= ~(0xffull << (8 * (pb[k] + 1)));
+        wb |= ((uint64_t)vd.index(val[(size_t)(row_ptr[rb] + k)]) << 3) << (8 * (pb[k] + 1));
+      }
+      char *rec = pair_pack.data() + (p / kWave) * kPairRecBytes;
+      const int l = (int)(p % kWave);
+      reinterpret_cast<uint64_t *>(rec)[2 * l] = wa;
+      reinterpret_cast<uint64_t *>(rec)[2 * l + 1] = wb;
+      reinterpret_cast<uint64_t *>(rec + 2 * kWave * 8)[l] = jw;
+    }
+    pr = pr && pair_width > 0;
+  }
+  if (pr) {
+    // format 3 it is: a "slice" of this operator is a 128-row group
+    op->pair = 1;
+    op->n_slices = n_groups;
+    op->uniform_width = pair_width;
+    op->ell_slots = n_groups * 2 * kWave * pair_width;
+    std::vector<int64_t> goff((size_t)n_groups + 1);
+    for (int64_t s = 0; s <= n_groups; ++s) goff[(size_t)s] = s * kPairRecBytes;
+    for (int64_t s = 0; s < n_groups; ++s) {
+      bool touches_halo = false;
+      const int64_t r1 = std::min<int64_t>(n, (s + 1) * 2 * kWave);
+      for (int64_t r = s * 2 * kWave; r < r1 && !touches_halo; ++r)
+        for (int64_t k = row_ptr[r]; k < row_ptr[r + 1]; ++k) touches_halo |= col[(size_t)k] >= n;
+      (touches_halo ? op->h_boundary : op->h_interior).push_back((int)s);
+    }
+    op->n_interior_slices = (int64_t)op->h_interior.size();
+    int st3 = STORM_HIP_OK;
+    int64_t bytes3 = 0;
+    std::vector<double> vtab((size_t)kDictSize, 0.0);
+    for (size_t k = 0; k < vd.values.size(); ++k) memcpy(&vtab[k], &vd.values[k], 8);
+    std::vector<int> otab((size_t)kDictSize, 0);
+    for (size_t k = 0; k < od.values.size(); ++k) otab[k] = (int)(int64_t)od.values[k];
+    op->dict_size = (int)vd.values.size();
+    op->offs_size = (int)od.values.size();
+    op->pack_bytes = (int64_t)pair_pack.size();
+    op->spw = 1;
+    std::vector<int> no_i;
+    std::vector<int64_t> one_zero(1, 0);
+    std::vector<double> no_d;
+    if ((st3 = upload(&op->d_dict, vtab, &bytes3)) || (st3 = upload(&op->d_offs, otab, &bytes3)) ||
+        (st3 = upload(&op->d_slice_off, goff, &bytes3)) || (st3 = upload(&op->d_pack, pair_pack, &bytes3)) ||
+        (st3 = upload(&op->d_tail_row, no_i, &bytes3)) || (st3 = upload(&op->d_tail_ptr, one_zero, &bytes3)) ||
+        (st3 = upload(&op->d_tail_col, no_i, &bytes3)) || (st3 = upload(&op->d_tail_val, no_d, &bytes3))) {
+      storm_hip_op_destroy(op);
+      return st3;
+    }
+    op->device_bytes = bytes3;
+    const int64_t need3 = 8 * ((n_slices + 3) / 4) + 16 + 2 * kMaxMulti;
+    if (need3 > c->partials_capacity) {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      double *bigger = nullptr;
+      HIP_TRY(hipMalloc(&bigger, sizeof(double) * (size_t)need3));
+      (void)hipFree(c->d_partials);
+      c->d_partials = bigger;
+      c->partials_capacity = need3;
+    }
+    *out = op;
+    return STORM_HIP_OK;
   }
   const int64_t slot_bytes = cv ? kColSlotBytes : kSlotBytes;
   std::vector<int64_t> slice_off(n_slices + 1, 0);  // bytes
@@ -1047,9 +1293,10 @@ int storm_hip_op_get_diagonal(const storm_hip_op *op, double alpha, double beta,
   if (op->n_rows == 0) return STORM_HIP_OK;
   storm_hip_ctx *c = op->ctx;
   HIP_TRY(hipSetDevice(c->device));
-  const int nb = (int)((op->n_slices + (kBlock / kWave) - 1) / (kBlock / kWave));
+  const int64_t n64 = (op->n_rows + kWave - 1) / kWave;  // the kernel walks 64-row groups whatever the format
+  const int nb = (int)((n64 + (kBlock / kWave) - 1) / (kBlock / kWave));
   hipLaunchKernelGGL(diag_sell_kernel, dim3(nb), dim3(kBlock), 0, c->stream, op->d_pack, op->d_slice_off, op->n_rows,
-                     op->d_dict, (int)(op->offs_size > 0), alpha, beta, d->d);
+                     op->d_dict, op->pair ? 3 : (int)(op->offs_size > 0), alpha, beta, d->d);
   if (op->tail_rows > 0)
     hipLaunchKernelGGL(diag_tail_kernel, dim3((int)((op->tail_rows + 255) / 256)), dim3(256), 0, c->stream,
                        op->tail_rows, op->d_tail_row, op->d_tail_ptr, op->d_tail_val, alpha, d->d);
@@ -1075,6 +1322,7 @@ int storm_hip_op_get_stats(const storm_hip_op *op, storm_hip_op_stats *s) {
   s->record_bytes = op->pack_bytes;
   s->value_dictionary_size = op->dict_size;
   s->offset_dictionary_size = op->offs_size;
+  s->paired_rows = op->pair;
   return STORM_HIP_OK;
 }
 

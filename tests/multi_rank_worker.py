@@ -40,12 +40,13 @@ def main():
     y_ref = ref_op.apply(x_glob)
     report = {"rank": rank, "world": world, "n_local": int(n), "n_halo": int(loc.n_halo), "nbrs": [int(r) for r in plan.nbr_rank]}
 
-    for fmt in (0, 2):
+    for fmt in (0, 2, 3):
         ctx.set_option("spmv_dict", fmt)
         mat = api.StencilMatrix.from_face_graph(ctx, loc)
-        ctx.set_option("spmv_dict", 2)
+        ctx.set_option("spmv_dict", 3)
         st = mat.stats()
-        assert (st["offset_dictionary_size"] > 0) == (fmt == 2), st
+        assert (st["offset_dictionary_size"] > 0) == (fmt >= 2), st
+        assert (fmt == 3 or not st["paired_rows"]) and (st["paired_rows"] or fmt != 3 or nx % 2 == 1), st
         mat.set_halo(plan.nbr_rank, plan.send_ptr, plan.send_idx, plan.recv_ptr)
         assert 0 < st["n_interior_slices"] <= st["n_slices"]
         op = api.HipStencilOperator(mat, -1.0, 0.0)

@@ -1,5 +1,5 @@
-"""The three record formats of the SpMV (fp64 weights + int32 columns; byte-indexed weights; byte-indexed
-weights and column offsets) are lossless re-encodings: every format must give bit-identical results, the
+"""The record formats of the SpMV (fp64 weights + int32 columns; byte-indexed weights; byte-indexed weights and
+column offsets; the same with two rows per lane sharing their gathers) are lossless re-encodings: every format must give bit-identical results, the
 library must pick them only when the operator qualifies, and every code path around the kernel (fused dot
 products, slice lists of a partitioned operator, CSR tail, diagonal extraction, ragged last slice, non-uniform
 widths) must hold for each of them."""
@@ -8,7 +8,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-FORMATS = [(0, 1), (1, 1), (1, 2), (2, 1), (2, 2), (2, 4)]  # (spmv_dict, spmv_spw)
+FORMATS = [(0, 1), (1, 1), (1, 2), (2, 1), (2, 2), (2, 4), (3, 0)]  # (spmv_dict, spmv_spw)
 
 
 @pytest.fixture(scope="module")
@@ -19,7 +19,7 @@ def env():
     ctx = api.Context(0)
     ctx.comm_init(api.Context.comm_unique_id(), 1, 0)  # lets the self-halo (periodic) case run
     yield api, mesh, oracle, ctx
-    ctx.set_option("spmv_dict", 2)
+    ctx.set_option("spmv_dict", 3)
     ctx.set_option("spmv_spw", 0)
     ctx.close()
 
@@ -28,7 +28,7 @@ def _build(ctx, fmt, make):
     ctx.set_option("spmv_dict", fmt[0])
     ctx.set_option("spmv_spw", fmt[1])
     m = make()
-    ctx.set_option("spmv_dict", 2)
+    ctx.set_option("spmv_dict", 3)
     ctx.set_option("spmv_spw", 0)
     return m
 
@@ -40,7 +40,7 @@ def _apply(api, ctx, mat, x, n_halo=0, alpha=-0.7, beta=0.3):
     return yv.to_numpy()
 
 
-@pytest.mark.parametrize("shape", [(33, 20, 17), (7, 5, 3), (64, 2, 2), (3, 1, 1)])
+@pytest.mark.parametrize("shape", [(33, 20, 17), (7, 5, 3), (64, 2, 2), (3, 1, 1), (16, 10, 6), (130, 3, 2)])
 def test_box_all_formats_bitwise_equal_and_match_oracle(env, shape):
     api, mesh, oracle, ctx = env
     g = mesh.structured_box(*shape)
@@ -53,7 +53,13 @@ def test_box_all_formats_bitwise_equal_and_match_oracle(env, shape):
         assert (st["value_dictionary_size"] > 0) == (fmt[0] >= 1)
         assert (st["offset_dictionary_size"] > 0) == (fmt[0] >= 2)
         if fmt[0] == 2:
-            assert st["record_bytes"] == 1024 * st["n_slices"]  # one 16-byte word per row
+            assert st["record_bytes"] == 1024 * st["n_slices"] and not st["paired_rows"]  # one 16-byte word per row
+        if fmt[0] == 3:
+            # rows always pair up when nx is even (a pair never straddles two grid lines); with an odd nx only
+            # if the merged neighbour lists still fit 7 slots -- otherwise format 2 is kept
+            assert st["paired_rows"] or shape[0] % 2 == 1, st
+            if st["paired_rows"]:
+                assert st["record_bytes"] == 1536 * st["n_slices"] and st["n_slices"] == (g.n_cells + 127) // 128
         ys[fmt] = _apply(api, ctx, mat, x)
         # the diagonal read back from every format is the same
         d = api.DeviceVector(ctx, g.n_cells)
@@ -85,6 +91,7 @@ def test_operators_that_do_not_qualify_keep_fp64_records(env):
         mat = api.StencilMatrix.from_face_graph(ctx, g)
         st = mat.stats()
         assert (st["value_dictionary_size"] > 0) == want_v and (st["offset_dictionary_size"] > 0) == want_o
+        assert bool(st["paired_rows"]) == (g is box)
         x = np.cos(0.11 * np.arange(g.n_cells))
         y = _apply(api, ctx, mat, x, alpha=-1.0, beta=0.0)
         y_ref = oracle.StencilOperator(g, -1.0, 0.0).apply(x)
@@ -213,7 +220,7 @@ def test_partitioned_operator_with_every_format(env, fmt):
     mat.close()
 
 
-@pytest.mark.parametrize("fmt", [(0, 1), (1, 2), (2, 2)])
+@pytest.mark.parametrize("fmt", [(0, 1), (1, 2), (2, 2), (3, 0)])
 @pytest.mark.parametrize("mesh_kind", ["box", "triangle", "periodic"])
 def test_stormDivGrad_accumulate_form(env, fmt, mesh_kind):
     """``u += dt * div grad c`` (Playground.cpp:115-131, `storm_hip_op_apply_add`) on every record format,
@@ -223,7 +230,7 @@ def test_stormDivGrad_accumulate_form(env, fmt, mesh_kind):
     api, mesh, oracle, ctx = env
     send_idx = None
     if mesh_kind == "box":
-        g = mesh.structured_box(21, 13, 10)
+        g = mesh.structured_box(22, 13, 10)
     elif mesh_kind == "triangle":
         from stormruler_amd import io_triangle
 

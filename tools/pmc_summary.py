@@ -45,7 +45,7 @@ def main():
             return sum(t for _, t in sel) / n if n else None
 
         # the launches of a CG solve: the fused-dot instantiation <true, ...> of either SpMV kernel
-        is_spmv = lambda k: ("spmv_dict_kernel<true" in k) or ("spmv_sell_kernel<true, true" in k)  # noqa: E731
+        is_spmv = lambda k: ("spmv_pair_kernel<true" in k) or ("spmv_dict_kernel<true" in k) or ("spmv_sell_kernel<true, true" in k)  # noqa: E731
         fetch, write = avg("FETCH_SIZE", is_spmv), avg("WRITE_SIZE", is_spmv)
         if fetch is not None and write is not None:
             traffic = (2.0 * fetch + write) * 1024.0
