@@ -39,7 +39,9 @@
 //   [64 x offsets : u64], index bytes pre-scaled (value index * 8, offset index * 4) so a bit-field extract is
 //   the LDS byte address; 12 + 8 + 8 = 28 bytes per row and 10 instead of 18 vector-memory instructions per
 //   row pair.  Needs <= 32 distinct values, <= 64 distinct offsets, < 2^28 columns, and every 16-byte gather in
-//   bounds of [-kVecGuard, n + 3] (vectors carry a zero guard in front and zero padding behind).
+//   bounds of [-kVecGuard, n + 3] (vectors carry a zero guard in front and zero padding behind).  A weight-0
+//   slot still reads its partner's neighbour, so it contributes 0 * (x_nb - x_i): exact for finite x; a
+//   non-finite x_nb reaches one more row than the face loop would carry it to.
 // Arithmetic:  y_i = beta x_i + alpha ( sum_k w_ik (x[col_ik] - x_i) + ext_i x_i )
 //   -- the difference form of the reference's flux  (c[out] - c[in]), which keeps the
 //   cancellation behaviour of the face loop (no large diagonal * x_i term).
