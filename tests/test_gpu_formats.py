@@ -297,3 +297,44 @@ def test_playground_operator_lambda(env):
     assert np.abs(w_hat.to_numpy() - ref_w_hat).max() <= 1e-13 * np.abs(ref_w_hat).max()
     assert np.abs(c_hat.to_numpy() - ref_c_hat).max() <= 1e-12 * np.abs(ref_c_hat).max()
     mat.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_structured_patterns_fuzz(env, seed):
+    """Fuzz of the format selection and the pair merge (shortest common supersequence of two rows' offset lists):
+    rows take random subsets of a small offset set IN RANDOM ORDER with weights from a small value set.  Whatever
+    the builder picks -- pairs when every merged list fits 7 slots, one row per lane otherwise -- every format must
+    reproduce the fp64-record result bit for bit, and that result the assembled matrix."""
+    import scipy.sparse as sp
+
+    api, mesh, oracle, ctx = env
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(130, 700))
+    offsets = np.array([-9, -4, -1, 1, 2, 6, 13])
+    max_per_row = int(rng.integers(2, 6))
+    rp, cols, vals = [0], [], []
+    for i in range(n):
+        k = int(rng.integers(0, max_per_row + 1))
+        cand = [o for o in rng.permutation(offsets) if 0 <= i + o < n][:k]
+        if seed % 2 == 0:
+            cand = sorted(cand)  # even seeds: ascending lists (the mesh-like case); odd seeds: arbitrary order
+        cols += [i + int(o) for o in cand]
+        vals += [float(rng.integers(1, 4)) for _ in cand]
+        rp.append(len(cols))
+    a = sp.csr_matrix((np.array(vals), np.array(cols, dtype=np.int64), np.array(rp, dtype=np.int64)), shape=(n, n))
+    x = np.sin(0.37 * np.arange(n)) + 0.1 * rng.standard_normal(n)
+    ys, kinds = {}, {}
+    for fmt in [(0, 1), (1, 2), (2, 2), (3, 0)]:
+        mat = _build(ctx, fmt, lambda: api.StencilMatrix.from_csr(ctx, a))
+        st = mat.stats()
+        kinds[fmt] = (st["value_dictionary_size"] > 0, st["offset_dictionary_size"] > 0, bool(st["paired_rows"]))
+        ys[fmt] = _apply(api, ctx, mat, x, alpha=1.0, beta=0.0)
+        d = api.DeviceVector(ctx, n)
+        mat.diagonal(1.0, 0.0, d)
+        assert np.abs(d.to_numpy() - a.diagonal()).max() <= 1e-13 * max(1.0, np.abs(a.diagonal()).max())
+        mat.close()
+    assert kinds[(0, 1)] == (False, False, False) and kinds[(2, 2)][:2] == (True, True)
+    for fmt in list(ys)[1:]:
+        assert np.array_equal(ys[fmt], ys[(0, 1)]), (fmt, kinds)
+    ref = a @ x
+    assert np.abs(ys[(0, 1)] - ref).max() <= 1e-13 * np.abs(ref).max()
