@@ -334,6 +334,8 @@ def test_random_structured_patterns_fuzz(env, seed):
         assert np.abs(d.to_numpy() - a.diagonal()).max() <= 1e-13 * max(1.0, np.abs(a.diagonal()).max())
         mat.close()
     assert kinds[(0, 1)] == (False, False, False) and kinds[(2, 2)][:2] == (True, True)
+    if seed % 2 == 0:  # ascending lists over 7 offsets always merge into <= 7 slots
+        assert kinds[(3, 0)][2]
     for fmt in list(ys)[1:]:
         assert np.array_equal(ys[fmt], ys[(0, 1)]), (fmt, kinds)
     ref = a @ x
