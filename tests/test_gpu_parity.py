@@ -59,6 +59,18 @@ def test_blas1_reference_kats(api, ctx, golden):
     out = api.DeviceVector(ctx, 4)
     out <<= a + e["scale"] * t
     assert np.array_equal(out.to_numpy(), np.array(e["result"]))
+    # -mat1 * mat2 * 0.5 + mat3 / 0.01 == result, exact (BitternMath.cpp:153-158): elementwise product, scale,
+    # true division by a scalar, sum
+    e2 = k["expr_2"]
+    a2 = api.DeviceVector.from_numpy(ctx, np.array(e2["mat1"]))
+    b2 = api.DeviceVector.from_numpy(ctx, np.array(e2["mat2"]))
+    c2 = api.DeviceVector.from_numpy(ctx, np.array(e2["mat3"]))
+    prod, quot = api.DeviceVector(ctx, 4), api.DeviceVector(ctx, 4)
+    api.vmul(prod, a2, b2)
+    prod *= -e2["half"]                  # (-mat1 * mat2) * 0.5: exact on these values in any association
+    quot <<= c2 / e2["hundredth"]
+    prod += quot
+    assert np.array_equal(prod.to_numpy(), np.array(e2["result"]))
     # normalize(0) = 0 -> safe_divide
     assert api.safe_divide(1.0, 0.0) == 0.0
 

@@ -38,6 +38,17 @@ def test_axpy_type_expression(golden):
     assert np.array_equal(out, np.array(k["result"]))
 
 
+def test_product_and_quotient_expression(golden):
+    """BitternMath.cpp:153-158 on the oracle's scalar loops (elementwise product in numpy: exact here)."""
+    k = golden["unit_tests"]["expr_2"]
+    t = -(np.array(k["mat1"]) * np.array(k["mat2"]))
+    oracle.lib().oracle_mul_scalar(4, oracle._p(t), k["half"])
+    q = np.array(k["mat3"])
+    oracle.lib().oracle_div_scalar(4, oracle._p(q), k["hundredth"])
+    oracle.lib().oracle_axpy(4, oracle._p(t), 1.0, oracle._p(q))
+    assert np.array_equal(t, np.array(k["result"]))
+
+
 def test_normalize_and_safe_divide(golden):
     k = golden["unit_tests"]["normalize"]
     m = np.array(k["mat"])
