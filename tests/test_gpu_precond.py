@@ -330,3 +330,42 @@ def test_cpp_adapter_every_solver_with_jacobi(kind, mode, side):
     assert got["converged"] and ref.converged
     assert abs(got["iterations"] - ref.iterations) <= max(2, int(0.1 * ref.iterations)), (got["iterations"], ref.iterations)
     assert abs(got["x_norm2"] - np.linalg.norm(ref.x)) <= 1e-5 * np.linalg.norm(ref.x)
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_random_matrices_every_solver_matches_oracle(env, seed):
+    """Randomised parity: diagonally dominant sparse matrices (symmetric for CG, non-symmetric otherwise) with
+    random patterns and values (fp64 records), every driver -- native device loops and statement-level ones --
+    against the oracle on the same CSR rows."""
+    import scipy.sparse as sp
+
+    api, mesh, oracle, ctx = env
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.integers(200, 1500))
+    nnz_row = int(rng.integers(2, 9))
+    rows = np.repeat(np.arange(n), nnz_row)
+    cols = (rows + rng.integers(1, n, size=rows.size)) % n
+    off = sp.coo_matrix((rng.uniform(-1.0, 1.0, rows.size), (rows, cols)), shape=(n, n)).tocsr()
+    off.sum_duplicates()
+    nonsym = off + sp.diags(np.abs(off).sum(axis=1).A1 * 1.5 + 1.0)
+    sym_off = (off + off.T) * 0.5
+    sym = sym_off + sp.diags(np.abs(sym_off).sum(axis=1).A1 * 1.5 + 1.0)
+    b_host = rng.standard_normal(n)
+    for kind, cls, a in (("cg", "CgSolver", sym), ("bicgstab", "BiCgStabSolver", nonsym), ("gmres", "GmresSolver", nonsym),
+                         ("cgs", "CgsSolver", nonsym), ("tfqmr", "TfqmrSolver", nonsym), ("tfqmr1", "Tfqmr1Solver", nonsym),
+                         ("bicgstabl", "BiCgStabLSolver", nonsym), ("idrs", "IdrsSolver", nonsym)):
+        a = a.tocsr()
+        mat = api.StencilMatrix.from_csr(ctx, a)
+        op = api.HipStencilOperator(mat, 1.0, 0.0)
+        b, x = api.DeviceVector.from_numpy(ctx, b_host), api.DeviceVector(ctx, n)
+        s = getattr(api, cls)()
+        api.rng_reset()
+        oracle.lib().oracle_rng_reset()
+        assert s.solve(x, b, op), kind
+        ref = oracle.solve(kind, oracle.CsrOperator(a), b_host, num_inner_iterations=s.num_inner_iterations
+                           if hasattr(s, "num_inner_iterations") else 50)
+        assert ref.converged
+        assert abs(s.iteration - ref.iterations) <= max(2, int(0.1 * ref.iterations)), (kind, s.iteration, ref.iterations)
+        assert np.linalg.norm(x.to_numpy() - ref.x) <= 1e-7 * np.linalg.norm(ref.x), kind
+        assert np.abs(a @ x.to_numpy() - b_host).max() <= 1e-4 * np.abs(b_host).max()
+        mat.close()
