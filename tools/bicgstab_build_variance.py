@@ -1,5 +1,11 @@
-import sys, os, json, time
-sys.path.insert(0, os.getcwd())
+"""BiCGStab, 256^3 Poisson, full solve on the two CPU builds of the oracle (strict / FMA contraction): how far
+the iteration count and the solution move with rounding alone (minutes of CPU time)."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from oracle import oracle
 from stormruler_amd import mesh

@@ -1,4 +1,8 @@
-import sys; sys.path.insert(0,'/root/repo')
+"""Device copy rate of the library's own copy kernel for 128 MiB .. 2 GiB vectors."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stormruler_amd import api
 ctx = api.Context(0)
 for logn in (24, 25, 26, 27, 28):
