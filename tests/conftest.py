@@ -16,7 +16,8 @@ def pytest_configure(config):
 def _native_pieces_are_built():
     """The built artefacts are git-ignored; rebuild them when a checkout arrives without them."""
     need = [os.path.join(ROOT, "stormruler_amd", "libstorm_hip.so"), os.path.join(ROOT, "oracle", "liboracle.so"),
-            os.path.join(ROOT, "oracle", "liboracle_fma.so"), os.path.join(ROOT, "tests", "cpp", "poisson_driver")]
+            os.path.join(ROOT, "oracle", "liboracle_fma.so"), os.path.join(ROOT, "tests", "cpp", "poisson_driver"),
+            os.path.join(ROOT, "tests", "c", "abi_poisson1d"), os.path.join(ROOT, "oracle", "liboracle_omp.so")]
     if not all(os.path.exists(p) for p in need):
         import __graft_entry__ as ge
 

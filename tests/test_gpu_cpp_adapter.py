@@ -48,3 +48,13 @@ def test_cpp_driver_reproduces_recorded_reference_case(golden):
         got = _run(32, "cg", mode)
         assert got["iterations"] == case["iterations"]
         assert abs(got["x_centre"] - case["x_centre"]) <= 1e-9 * case["x_centre"]
+
+
+def test_plain_c_host_reaches_the_1d_known_answer():
+    """tests/c/abi_poisson1d.c: the ABI from C99 (op_create_csr, vec_*, solve_cg with the reference's default
+    knobs) on the 1-D Poisson KAT of SURVEY 8c: x[31] = 528 in 32 CG iterations."""
+    exe = os.path.join(ROOT, "tests", "c", "abi_poisson1d")
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["iterations"] == 32 and out["converged"] == 1 and abs(out["x31"] - 528.0) < 1e-6
