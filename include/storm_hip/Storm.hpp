@@ -28,6 +28,7 @@
 
 #include <array>
 #include <cmath>
+#include <cstdio>
 #include <cstddef>
 #include <functional>
 #include <limits>
@@ -412,7 +413,23 @@ public:
 namespace detail {
 using native_entry = int (*)(const storm_hip_op*, double, double, const storm_hip_vec*, storm_hip_vec*,
                              const storm_hip_solver_params*, storm_hip_solver_result*, double*);
+inline std::function<void(const std::string&)>& log_sink() {
+  static std::function<void(const std::string&)> sink;  // empty: silent
+  return sink;
 }
+inline void log_solve(std::size_t iteration, real_t absolute_error, real_t relative_error) {
+  if (!log_sink()) return;
+  char line[128];
+  std::snprintf(line, sizeof line, "n_iter: %4zu, abs_err: %-12e, rel_err: %-12e", iteration, absolute_error,
+                relative_error);
+  log_sink()(line);
+}
+}  // namespace detail
+
+/// The reference logs one line per solve through spdlog (`STORM_INFO("n_iter: ..., abs_err: ..., rel_err: ...")`,
+/// Solvers/Solver.hpp:144-145).  This header has no logging dependency: install a sink to receive the same
+/// line (e.g. `Storm::set_log_sink([](const std::string& s) { spdlog::info(s); })`); none installed = silent.
+inline void set_log_sink(std::function<void(const std::string&)> sink) { detail::log_sink() = std::move(sink); }
 
 template<class InVector, class OutVector = InVector>
 class IterativeSolver : public Solver<InVector, OutVector> {
@@ -458,6 +475,7 @@ public:
         iteration = (std::size_t)r.iterations;
         absolute_error = r.absolute_error;
         relative_error = r.relative_error;
+        detail::log_solve(iteration, absolute_error, relative_error);
         return r.converged != 0;
       }
     }
@@ -477,6 +495,7 @@ public:
       converged |= (relative_error_tolerance > 0.0) && (relative_error < relative_error_tolerance);
     }
     finalize(x_vec, b_vec, any_op, pre_op.get());
+    detail::log_solve(iteration, absolute_error, relative_error);  // Solver.hpp:144-145
     return converged;
   }
 };

@@ -20,6 +20,7 @@ solver classes hand the whole solve to the device-resident entry points
 from __future__ import annotations
 
 import ctypes as C
+import logging
 import math
 import weakref
 from typing import Callable, List, Optional, Sequence
@@ -29,6 +30,8 @@ import numpy as np
 from . import _lib
 from ._lib import check, lib
 from .mesh import FaceGraph, face_coefficients
+
+_LOG = logging.getLogger("stormruler_amd.solvers")
 
 real_t = float
 
@@ -633,7 +636,13 @@ class IterativeSolver(Solver):
         self.absolute_error, self.relative_error = r.absolute_error, r.relative_error
         self.initial_error, self.num_applies = r.initial_error, r.num_applies
         self.history = None if hist is None else hist[: r.iterations + 1]
+        self._log()
         return bool(r.converged)
+
+    def _log(self) -> None:
+        """The reference's one line per solve (`STORM_INFO`, Solver.hpp:144-145) on the logger
+        ``stormruler_amd.solvers`` at INFO level."""
+        _LOG.info("n_iter: %4d, abs_err: %-12e, rel_err: %-12e", self.iteration, self.absolute_error, self.relative_error)
 
     def solve(self, x_vec, b_vec, any_op) -> bool:  # Solver.hpp:116-147
         if self._native and isinstance(any_op, HipStencilOperator) and self.pre_op is None:
@@ -659,6 +668,7 @@ class IterativeSolver(Solver):
             self.iteration += 1
         self.finalize(x_vec, b_vec, any_op, self.pre_op)
         self.history = np.array(hist)
+        self._log()
         return converged
 
 

@@ -66,6 +66,8 @@ static int run(int n, const std::string& mode, size_t restart) {
   DeviceVector b(ctx, mesh.n_cells), x(ctx, mesh.n_cells);
   fill_with(b, 1.0);
 
+  std::string logged;
+  set_log_sink([&](const std::string& line) { logged = line; });  // the reference's per-solve log line
   SolverT<DeviceVector> solver;
   if constexpr (std::is_base_of_v<InnerOuterIterativeSolver<DeviceVector>, SolverT<DeviceVector>>)
     solver.num_inner_iterations = restart;
@@ -88,6 +90,7 @@ static int run(int n, const std::string& mode, size_t restart) {
               "\"relative_error\": %.17g, \"x_centre\": %.17g, \"x_norm2\": %.17g, \"x0\": %.17g}\n",
               n, converged ? "true" : "false", solver.iteration, solver.absolute_error, solver.relative_error,
               xh[c], norm_2(x), xh[0]);
+  if (logged.rfind("n_iter:", 0) != 0) return 4;  // Solver.hpp:144-145
   // error conventions: conj_mul of a plain operator throws std::runtime_error (Operator.hpp:116-118)
   try {
     make_operator<DeviceVector>([](DeviceVector&, const DeviceVector&) {})->conj_mul(x, b);

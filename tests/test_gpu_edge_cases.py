@@ -222,3 +222,24 @@ def test_hipgraph_replay_option_gives_the_same_solve(cls):
         ctx.close()
     assert res[0][0] == res[1][0]
     assert np.array_equal(res[0][2], res[1][2])
+
+
+def test_solve_logs_the_reference_line(caplog):
+    """One INFO line per solve, the reference's `STORM_INFO("n_iter: ..., abs_err: ..., rel_err: ...")`
+    (Solver.hpp:144-145), on the logger `stormruler_amd.solvers` -- from the native loop and the statement path."""
+    import logging
+
+    from stormruler_amd import api, mesh
+
+    g = mesh.structured_box(10)
+    ctx = api.Context(0)
+    mat = api.StencilMatrix.from_face_graph(ctx, g)
+    b = api.DeviceVector.from_numpy(ctx, np.ones(g.n_cells))
+    with caplog.at_level(logging.INFO, logger="stormruler_amd.solvers"):
+        for op in (api.HipStencilOperator(mat, -1.0, 0.0), api.make_operator(lambda y, x: mat.apply(-1.0, 0.0, x, y))):
+            x = api.DeviceVector(ctx, g.n_cells)
+            s = api.CgSolver()
+            assert s.solve(x, b, op)
+    lines = [r.getMessage() for r in caplog.records]
+    assert len(lines) == 2 and all(ln.startswith("n_iter:") and "abs_err:" in ln and "rel_err:" in ln for ln in lines)
+    ctx.close()
