@@ -85,3 +85,29 @@ def test_product_code_never_touches_the_oracle():
                     if "liboracle" in t or "from oracle" in t or "import oracle" in t:
                         bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_solver_knobs_and_defaults_are_the_references():
+    """Runtime configuration of the reference = public data members of the solver objects:
+    same names, same defaults -- Solver.hpp:66-76,158-159, SolverBiCgStab.hpp:379-381, SolverIdrs.hpp:287-289,
+    SolverRichardson.hpp:45 -- in the Python mirror, and in the C ABI's `storm_hip_solver_params_default`."""
+    import ctypes as C
+
+    from stormruler_amd import _lib, api
+
+    for cls in (api.CgSolver, api.BiCgStabSolver, api.GmresSolver, api.FgmresSolver, api.CgsSolver, api.TfqmrSolver,
+                api.Tfqmr1Solver, api.RichardsonSolver, api.BiCgStabLSolver, api.IdrsSolver, api.JfnkSolver):
+        s = cls()
+        assert s.num_iterations == 2000
+        assert s.absolute_error_tolerance == 1.0e-6 and s.relative_error_tolerance == 1.0e-6
+        assert s.pre_side == api.PreconditionerSide.Right and s.pre_op is None
+        assert s.iteration == 0
+    assert api.GmresSolver().num_inner_iterations == 50 and api.FgmresSolver().num_inner_iterations == 50
+    assert api.BiCgStabLSolver().num_inner_iterations == 2
+    assert api.IdrsSolver().num_inner_iterations == 4
+    assert api.RichardsonSolver().relaxation_factor == 1.0e-4
+    p = _lib.SolverParams()
+    _lib.lib.storm_hip_solver_params_default(C.byref(p))
+    assert (p.num_iterations, p.absolute_error_tolerance, p.relative_error_tolerance, p.num_inner_iterations) == \
+        (2000, 1.0e-6, 1.0e-6, 50)
+    assert p.gram_schmidt == 0  # modified Gram-Schmidt: the reference's arithmetic
