@@ -105,6 +105,18 @@ int main(int argc, char** argv) {
     std::fprintf(stderr, "usage: %s <n> <solver> <native|lambda|jacobi|jacobi-left> [restart]\n", argv[0]);
     return 2;
   }
+  {  // knob names and defaults of the reference (Solver.hpp:66-76,158-159, SolverBiCgStab.hpp:379-381,
+     // SolverIdrs.hpp:287-289, SolverRichardson.hpp:45)
+    CgSolver<DeviceVector> cg;
+    GmresSolver<DeviceVector> gm;
+    BiCgStabLSolver<DeviceVector> bl;
+    IdrsSolver<DeviceVector> id;
+    RichardsonSolver<DeviceVector> ri;
+    if (cg.num_iterations != 2000 || cg.absolute_error_tolerance != 1.0e-6 || cg.relative_error_tolerance != 1.0e-6 ||
+        cg.pre_side != PreconditionerSide::Right || cg.pre_op != nullptr || gm.num_inner_iterations != 50 ||
+        bl.num_inner_iterations != 2 || id.num_inner_iterations != 4 || ri.relaxation_factor != 1.0e-4)
+      return 5;
+  }
   const int n = std::atoi(argv[1]);
   const std::string kind = argv[2];
   const std::string native = argv[3];
