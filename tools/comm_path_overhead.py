@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Cost of the multi-rank code path with the network taken out: one rank, RCCL communicator of size 1, a z-periodic
+256^3 box whose two halo planes are exchanged with the rank itself (pack kernel, grouped ncclSend/ncclRecv on the comm
+stream, interior / boundary split of the SpMV, reduction -> all-reduce -> step kernels) against the plain single-GPU
+path on the same box.  What remains at N > 1 beyond this is the latency of the real exchanges."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from stormruler_amd import api, mesh  # noqa: E402
+from test_gpu_comm import _periodic_z_local_graph  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+iters = 400
+
+
+def rate(ctx, mat, g):
+    b = api.DeviceVector(ctx, g.n_cells, g.n_halo)
+    api.fill_with(b, 1.0)
+    best = 0.0
+    for _ in range(3):
+        x = api.DeviceVector(ctx, g.n_cells, g.n_halo)
+        s = api.CgSolver()
+        s.num_iterations, s.absolute_error_tolerance, s.relative_error_tolerance = iters, 0.0, 0.0
+        ctx.sync()
+        t0 = time.perf_counter()
+        s.solve(x, b, api.HipStencilOperator(mat, -1.0, 0.05))
+        ctx.sync()
+        best = max(best, iters / (time.perf_counter() - t0))
+    return best
+
+
+out = {"n": n}
+ctx = api.Context(0)
+g0 = mesh.structured_box(n)
+m0 = api.StencilMatrix.from_face_graph(ctx, g0)
+out["plain_it_per_s"] = rate(ctx, m0, g0)
+m0.close()
+ctx.close()
+ctx = api.Context(0)
+ctx.comm_init(api.Context.comm_unique_id(), 1, 0)
+loc, send_idx = _periodic_z_local_graph(n, n, n)
+m1 = api.StencilMatrix.from_face_graph(ctx, loc)
+m1.set_halo([0], [0, loc.n_halo], send_idx, [0, loc.n_halo])
+st = m1.stats()
+out["comm_path_it_per_s"] = rate(ctx, m1, loc)
+out["interior_groups"], out["groups"], out["paired_rows"] = st["n_interior_slices"], st["n_slices"], st["paired_rows"]
+out["overhead_us_per_iteration"] = (1.0 / out["comm_path_it_per_s"] - 1.0 / out["plain_it_per_s"]) * 1e6
+print(json.dumps(out))
