@@ -57,7 +57,13 @@ def main() -> int:
                          "code path of this script on a one-GPU box -- the rates it prints mean nothing")
     ap.add_argument("--force-comm", action="store_true",
                     help="take the multi-rank code path (process group, RCCL communicator, all-reduces) even at N = 1")
+    ap.add_argument("--min-seconds", type=float, default=0.25,
+                    help="the K-step solve is repeated (each repeat bracketed by barrier + sync, max over ranks) until "
+                         "the timed repeats add up to this; ms_per_step is the median repeat")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus)
 
     import numpy as np
     import torch
@@ -129,7 +135,9 @@ def main() -> int:
         return s, x
 
     def spmv_roofline(operator, stats, iters):
-        """HIP-event pairs around every SpMV launch of one `iters`-iteration solve."""
+        """HIP-event pairs around every SpMV launch of one `iters`-iteration solve.  `achieved` / `frac` price the
+        bytes the operator's record format really streams (records + x + y); for fp64 records those ARE SURVEY.md
+        8d's algorithmic bytes.  The 8d figure over the same time is kept as `effective_vs_8d_GBs`."""
         ctx.set_option("profile_spmv", 1)
         run(iters, operator)
         launches, total_ms, min_ms = ctx.spmv_profile()
@@ -138,10 +146,10 @@ def main() -> int:
         ms = total_ms / max(iters + 1, 1)
         alg = 24 * N + 12 * stats["nnz_offdiag"]  # x + y + ext + (int32 col + f64 val) per entry
         fmt_bytes = stats["record_bytes"] + 16 * N  # the records this operator streams + x + y
-        return {"achieved": alg / (ms * 1e-3) / 1e9, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms, "min_launch_ms": min_ms,
-                "launches_timed": launches, "format_bytes_per_launch": fmt_bytes,
-                "frac_of_format_bytes": fmt_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        gbs = fmt_bytes / (ms * 1e-3) / 1e9
+        return {"achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "bytes_per_launch": fmt_bytes,
+                "algorithmic_bytes_8d": alg, "effective_vs_8d_GBs": alg / (ms * 1e-3) / 1e9,
+                "avg_launch_ms": ms, "min_launch_ms": min_ms, "launches_timed": launches}
 
     # Device spin-up (untimed, before the W warmup steps): the first process on an idle MI355X runs
     # ~20 % slow for its first several hundred milliseconds (clocks / memory power state); 10 ms of
@@ -155,14 +163,28 @@ def main() -> int:
     if W > 0:
         run(W)
     ctx.sync()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    s, x = run(K)
-    ctx.sync()
-    torch.cuda.synchronize()
-    dist.barrier()
-    elapsed = dist.allreduce_max(time.perf_counter() - t0)
+
+    def timed_solve():
+        """EXACTLY K steps between barrier + synchronize on both sides; max over ranks."""
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s_, x_ = run(K)
+        ctx.sync()
+        torch.cuda.synchronize()
+        dist.barrier()
+        return dist.allreduce_max(time.perf_counter() - t0), s_
+
+    # The driver's `--steps 20` is 6 ms of work: one interval would decide the headline.  The K-step solve is
+    # repeated until the timed repeats cover --min-seconds (same count on every rank: the elapsed times are
+    # already max-reduced) and the median repeat is reported; `steps` stays K.
+    repeats = []
+    while True:
+        e_, s = timed_solve()
+        repeats.append(e_)
+        if sum(repeats) >= args.min_seconds or len(repeats) >= 2000:
+            break
+    elapsed = float(np.median(repeats))
     final_residual = s.absolute_error
 
     # ---- roofline of the SpMV: HIP-event pairs around every launch --------------------------------
@@ -184,21 +206,41 @@ def main() -> int:
 
     # ---- the same problem through the fp64 records (what a mesh with all-distinct weights gets) ----
     general = None
-    if st["value_dictionary_size"] and world == 1 and not args.skip_general:
+    general_roof = None
+    if world == 1 and not args.skip_general:
         try:
-            ctx.set_option("spmv_dict", 0)
-            mat0 = api.StencilMatrix.from_face_graph(ctx, g)
-            ctx.set_option("spmv_dict", 3)
+            if st["value_dictionary_size"]:
+                ctx.set_option("spmv_dict", 0)
+                mat0 = api.StencilMatrix.from_face_graph(ctx, g)
+                ctx.set_option("spmv_dict", 3)
+            else:
+                mat0 = mat
             op0 = api.HipStencilOperator(mat0, alpha=-1.0, beta=0.0)
             run(max(W, 20), op0)
             ctx.sync()
-            t1 = time.perf_counter()
-            run(K, op0)
-            ctx.sync()
-            t1 = time.perf_counter() - t1
+            reps0 = []
+            while sum(reps0) < args.min_seconds and len(reps0) < 2000:
+                t1 = time.perf_counter()
+                run(K, op0)
+                ctx.sync()
+                reps0.append(time.perf_counter() - t1)
+            t1 = float(np.median(reps0))
+            r0 = spmv_roofline(op0, mat0.stats(), prof_iters)
             general = {"record_format": "fp64 weights + int32 columns", "cg_iter_per_s": K / t1,
-                       "ms_per_step": t1 / K * 1e3, "spmv": spmv_roofline(op0, mat0.stats(), prof_iters)}
-            mat0.close()
+                       "ms_per_step": t1 / K * 1e3, "repeats": len(reps0)}
+            gt = None
+            try:
+                tj = json.load(open(tfile))
+                gt = tj.get("general", {}).get("traffic_bytes_per_launch") if n == 256 else None
+            except Exception:
+                gt = None
+            general_roof = {"kernel": "spmv_sell_kernel (fp64 records: the format any mesh gets) + fused <p,Ap> partials",
+                            "bound": "hbm", "achieved": r0["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": r0["frac"], "traffic": gt, "bytes_per_launch": r0["bytes_per_launch"],
+                            "algorithmic_bytes_8d": r0["algorithmic_bytes_8d"], "avg_launch_ms": r0["avg_launch_ms"],
+                            "min_launch_ms": r0["min_launch_ms"], "launches_timed": r0["launches_timed"]}
+            if mat0 is not mat:
+                mat0.close()
         except Exception as e:
             general = {"error": repr(e)}
 
@@ -258,7 +300,8 @@ def main() -> int:
                 "partition": "single GPU" if world == 1 else
                              (f"z-slabs, {world} ranks, RCCL halo + all-reduce" if not args.shared_device else
                               f"DEBUG: {world} ranks sharing one device over the host-staged transport"),
-                "value_definition": "n_gpus x K / max-over-ranks wall time of a K-iteration solve (init residual included)",
+                "value_definition": "n_gpus x K / max-over-ranks wall time of a K-iteration solve (init residual included); "
+                                    "median over the repeats listed in `timing`",
             },
             "roofline": {
                 "kernel": ("spmv_pair_kernel" if st["paired_rows"] else
@@ -266,22 +309,27 @@ def main() -> int:
                           " (sliced-ELL gather SpMV + fused <p,Ap> partials)",
                 "bound": "hbm", "achieved": roof["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": roof["frac"], "traffic": traffic,
-                "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"],
+                "bytes_per_launch": roof["bytes_per_launch"], "record_format": fmt_name,
                 "avg_launch_ms": roof["avg_launch_ms"], "min_launch_ms": roof["min_launch_ms"],
                 "launches_timed": roof["launches_timed"], "measured_copy_GBs": copy_gbs,
-                "record_format": fmt_name, "format_bytes_per_launch": roof["format_bytes_per_launch"],
-                "frac_of_format_bytes": roof["frac_of_format_bytes"],
-                "note": "achieved = SURVEY 8d algorithmic bytes (fp64 weights, int32 columns) / launch time; "
-                        "the lossless byte-indexed records move format_bytes_per_launch instead, so frac can "
-                        "exceed 1 -- frac_of_format_bytes is the physical HBM fraction, general_mesh_path the "
-                        "same measurement on fp64 records",
+                "algorithmic_bytes_8d": roof["algorithmic_bytes_8d"],
+                "effective_vs_8d_GBs": roof["effective_vs_8d_GBs"],
+                "note": "achieved/frac = bytes this operator's record format streams per launch (records + x + y; "
+                        "`traffic` = the same by PMC) / launch time: a physical HBM fraction.  effective_vs_8d_GBs "
+                        "divides SURVEY 8d's fp64-weight + int32-column bytes by the same time and may exceed the "
+                        "peak for the lossless byte-indexed formats; roofline_general is the fp64-record kernel "
+                        "every mesh can use, where the two byte counts coincide",
             },
+            "roofline_general": general_roof,
             "general_mesh_path": general,
             "blas1": blas1,
             "cpu_baseline": cpu,
+            "timing": {"repeats": len(repeats), "timed_seconds_total": float(sum(repeats)),
+                       "ms_per_step_min": min(repeats) / K * 1e3, "ms_per_step_max": max(repeats) / K * 1e3,
+                       "ms_per_step_median": elapsed / K * 1e3},
             "cg": {"iterations_per_sec_global": K / elapsed,
-                   "algorithmic_bytes_per_iteration": roof["algorithmic_bytes_per_launch"] + 96 * N,
-                   "effective_GBs_reference_op_list": (roof["algorithmic_bytes_per_launch"] + 96 * N) * K / elapsed / 1e9,
+                   "algorithmic_bytes_per_iteration": roof["algorithmic_bytes_8d"] + 96 * N,
+                   "effective_GBs_reference_op_list": (roof["algorithmic_bytes_8d"] + 96 * N) * K / elapsed / 1e9,
                    "final_residual": final_residual},
             "op_stats": st,
             "device": ctx.info()["name"],
@@ -299,6 +347,32 @@ def main() -> int:
     except Exception:
         pass
     return 0
+
+
+def launch_ranks(n_ranks: int) -> int:
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as CHILD processes (one per GPU,
+    torch.distributed.run on 127.0.0.1) with this command line, relay their output (rank 0 prints the JSON
+    line) and return their exit code.  Nothing in this process has touched torch or HIP yet; no exec."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    sys.stderr.write(child.stderr[-8000:])
+    lines = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
+    for ln in child.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    return child.returncode
 
 
 def blas1_rates(api, ctx, N, reps=20):

@@ -1,0 +1,24 @@
+"""`python bench.py --gpus N` as the driver calls it (no launcher in front) must start its own ranks.
+
+On a box without a GPU every rank stops at "needs an MI355X" (rc 3) -- what this checks is that the ranks WERE
+started (child processes through torch.distributed.run on 127.0.0.1) and that their exit code is relayed, instead of
+the rc 2 "launch me under torchrun" refusal of round 1."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_starts_its_own_ranks():
+    import torch
+
+    if torch.cuda.is_available():
+        import pytest
+
+        pytest.skip("covered on the GPU by test_gpu_two_ranks.py::test_bench_script_multi_rank_path")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode not in (0, 2), (p.returncode, p.stderr[-2000:])
+    assert p.stderr.count("bench.py needs an MI355X") == 2, p.stderr[-3000:]  # both ranks ran main()

@@ -57,17 +57,18 @@ def test_bench_script_multi_rank_path(world):
     """bench.py's own N > 1 code path (partition, connect, the rank-uniform spin-up, barriers, max-over-ranks
     timing, rank-0 JSON) with the ranks sharing device 0 (`--shared-device`): it must terminate -- a collective
     that only some ranks reach hangs the 8-GPU run -- and print one JSON line on rank 0."""
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--shared-device", "--edge", "48", "--steps", "20",
-           "--warmup", "3", "--spinup-seconds", "0.2"]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"), cwd=ROOT)
+    # exactly as the driver calls it: no launcher in front -- bench.py starts its ranks itself (child processes)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--shared-device", "--edge", "48",
+           "--steps", "20", "--warmup", "3", "--spinup-seconds", "0.2", "--min-seconds", "0.05"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(env, OMP_NUM_THREADS="1"), cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + "\n" + p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == world and out["steps"] == 20 and out["value"] > 0 and out["scaling"] == "weak"
     assert out["roofline"]["launches_timed"] == 2 * (max(20, 20) + 1)  # interior + boundary launch per apply
+    assert 0.0 < out["roofline"]["frac"] <= 1.0 and out["timing"]["repeats"] >= 1
 
 
 @pytest.mark.parametrize("world", [3, 5])

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--traffic-json", default=None)
     ap.add_argument("--record-format", default=None)
     ap.add_argument("--algorithmic-bytes", type=float, default=None)
+    ap.add_argument("--format-bytes", type=float, default=None)
     args = ap.parse_args()
     acc = defaultdict(lambda: [0, 0.0])
     for d in args.dirs:
@@ -44,16 +45,32 @@ def main():
             n = sum(a for a, _ in sel)
             return sum(t for _, t in sel) / n if n else None
 
-        # the launches of a CG solve: the fused-dot instantiation <true, ...> of either SpMV kernel
-        is_spmv = lambda k: ("spmv_pair_kernel<true" in k) or ("spmv_dict_kernel<true" in k) or ("spmv_sell_kernel<true, true" in k)  # noqa: E731
-        fetch, write = avg("FETCH_SIZE", is_spmv), avg("WRITE_SIZE", is_spmv)
+        # the launches of a CG solve: the fused-dot instantiation <true, ...> of the SpMV kernels; the byte-indexed
+        # formats (headline operator) and the fp64 records (roofline_general) are reported separately
+        is_fmt = lambda k: ("spmv_pair_kernel<true" in k) or ("spmv_dict_kernel<true" in k)  # noqa: E731
+        is_sell = lambda k: "spmv_sell_kernel<true, true" in k  # noqa: E731
+        method = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950)"
+        out = {}
+        fetch, write = avg("FETCH_SIZE", is_fmt), avg("WRITE_SIZE", is_fmt)
+        if fetch is None or write is None:  # the operator did not qualify for a byte-indexed format
+            fetch, write = avg("FETCH_SIZE", is_sell), avg("WRITE_SIZE", is_sell)
         if fetch is not None and write is not None:
             traffic = (2.0 * fetch + write) * 1024.0
             out = {"traffic_bytes_per_launch": traffic, "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB": write,
-                   "record_format": args.record_format,
-                   "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950)"}
+                   "record_format": args.record_format, "method": method}
+            if args.format_bytes:
+                out["ratio_to_format_bytes"] = traffic / args.format_bytes
             if args.algorithmic_bytes:
                 out["ratio_to_algorithmic_bytes"] = traffic / args.algorithmic_bytes
+        fetch, write = avg("FETCH_SIZE", is_sell), avg("WRITE_SIZE", is_sell)
+        if fetch is not None and write is not None:
+            traffic = (2.0 * fetch + write) * 1024.0
+            out["general"] = {"traffic_bytes_per_launch": traffic, "FETCH_SIZE_KiB_raw": fetch,
+                              "WRITE_SIZE_KiB": write, "record_format": "fp64 weights + int32 columns",
+                              "method": method}
+            if args.algorithmic_bytes:
+                out["general"]["ratio_to_algorithmic_bytes"] = traffic / args.algorithmic_bytes
+        if out:
             with open(args.traffic_json, "w") as fh:
                 json.dump(out, fh, indent=1)
 

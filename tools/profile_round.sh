@@ -1,7 +1,9 @@
 #!/bin/bash
 # Produce the per-round profile artefacts on the GPU box (run through gpurun from the repo root):
-#   tools/profile_round.sh r01e
+#   tools/profile_round.sh r02a
 # writes gpurun_out/<tag>_{bench.json,bench_under_rocprof.json,kernel_stats.csv,pmc_summary.txt,spmv_hbm_traffic.json}
+# Every run includes the fp64-record repeat (roofline_general), so the kernel stats and the PMC passes cover
+# spmv_pair_kernel (headline operator) AND spmv_sell_kernel (the format any mesh gets).
 set -u
 TAG=${1:-round}
 OUT=$PWD/gpurun_out
@@ -9,21 +11,23 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 python3 bench.py 2>/dev/null | tail -1 > "$OUT/${TAG}_bench.json"
 rm -rf /tmp/prof_stats /tmp/prof_fetch /tmp/prof_write
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 bench.py --cpu-iters 0 --skip-general 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_under_rocprof.json"
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 bench.py --cpu-iters 0 --skip-blas1 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_under_rocprof.json"
 cp "$(find /tmp/prof_stats -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_kernel_stats.csv"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/prof_fetch -- python3 bench.py --cpu-iters 0 --skip-general --steps 20 --warmup 2 --spinup-seconds 0 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/prof_write -- python3 bench.py --cpu-iters 0 --skip-general --steps 20 --warmup 2 --spinup-seconds 0 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/prof_fetch -- python3 bench.py --cpu-iters 0 --skip-blas1 --steps 20 --warmup 2 --spinup-seconds 0 --min-seconds 0 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/prof_write -- python3 bench.py --cpu-iters 0 --skip-blas1 --steps 20 --warmup 2 --spinup-seconds 0 --min-seconds 0 > /dev/null 2>&1
 FMT=$(python3 -c "import json;print(json.load(open('$OUT/${TAG}_bench.json'))['roofline']['record_format'])")
-ALG=$(python3 -c "import json;print(json.load(open('$OUT/${TAG}_bench.json'))['roofline']['algorithmic_bytes_per_launch'])")
+ALG=$(python3 -c "import json;print(json.load(open('$OUT/${TAG}_bench.json'))['roofline']['algorithmic_bytes_8d'])")
+FBY=$(python3 -c "import json;print(json.load(open('$OUT/${TAG}_bench.json'))['roofline']['bytes_per_launch'])")
 python3 tools/pmc_summary.py /tmp/prof_fetch /tmp/prof_write --traffic-json "$OUT/${TAG}_spmv_hbm_traffic.json" \
-    --record-format "$FMT" --algorithmic-bytes "$ALG" > "$OUT/${TAG}_pmc_summary.txt"
+    --record-format "$FMT" --algorithmic-bytes "$ALG" --format-bytes "$FBY" > "$OUT/${TAG}_pmc_summary.txt"
 python3 -c "
 import json
 d = json.load(open('$OUT/${TAG}_bench.json'))
-print('CG it/s', d['value'], 'ms/step', d['ms_per_step'])
-print('roofline', {k: d['roofline'][k] for k in ('achieved', 'frac', 'avg_launch_ms', 'frac_of_format_bytes', 'record_format')})
+print('CG it/s', d['value'], 'ms/step', d['ms_per_step'], d['timing'])
+print('roofline', {k: d['roofline'][k] for k in ('achieved', 'frac', 'avg_launch_ms', 'effective_vs_8d_GBs', 'record_format')})
+print('roofline_general', d.get('roofline_general'))
 print('general', d.get('general_mesh_path'))
 print('cpu', d['cpu_baseline'] and d['cpu_baseline'].get('value'))
 "
-head -8 "$OUT/${TAG}_kernel_stats.csv" | cut -c1-160
+head -12 "$OUT/${TAG}_kernel_stats.csv" | cut -c1-160
 cat "$OUT/${TAG}_spmv_hbm_traffic.json"
