@@ -36,7 +36,7 @@ extern "C" {
 /* every declaration below is an exported symbol of libstorm_hip.so */
 #pragma GCC visibility push(default)
 
-#define STORM_HIP_ABI_VERSION 1
+#define STORM_HIP_ABI_VERSION 2
 
 enum {
   STORM_HIP_OK = 0,
@@ -107,6 +107,11 @@ int storm_hip_vec_upload(storm_hip_vec *v, const double *host, int64_t n);
 int storm_hip_vec_download(const storm_hip_vec *v, double *host, int64_t n);
 /* Raw device pointer (n_owned + n_halo doubles), for zero-copy interop. */
 int storm_hip_vec_device_ptr(storm_hip_vec *v, void **dev_ptr);
+/* The context a vector lives on. */
+int storm_hip_vec_context(const storm_hip_vec *v, storm_hip_ctx **ctx);
+/* One element (waits for the stream; a debugging / concept-check accessor, never used by the solvers):
+ * `Field::operator()(row, col)`, Feathers/Field.hpp:104-111. */
+int storm_hip_vec_get(const storm_hip_vec *v, int64_t row, double *value);
 
 /* ---- BLAS-1 --------------------------------------------------------------
  * One call per Bittern expression statement the solver bodies execute
@@ -282,6 +287,65 @@ int storm_hip_solve_bicgstab(const storm_hip_op *op, double alpha, double beta, 
 int storm_hip_solve_gmres(const storm_hip_op *op, double alpha, double beta, const storm_hip_vec *b,
                           storm_hip_vec *x, const storm_hip_solver_params *params,
                           storm_hip_solver_result *result, double *history);    /* SolverGmres.hpp:41-255 */
+
+/* ---- the general Krylov engine ---------------------------------------------
+ * Every solver of Solvers/  for ANY operator, device-resident:
+ *   storm_hip_krylov_* objects stand in for the reference's solver objects (`CgSolver<Vector> s;`,
+ *   Solvers/Solver.hpp:66-76): they hold the operator, the optional preconditioner (`pre_op`, `pre_side`,
+ *   Solver.hpp:74-75) and the work vectors.
+ * Operator and preconditioner are either native (a storm_hip_op / a diagonal held in a vector) or a
+ * CALLBACK -- the reference's only call site passes a lambda through make_operator
+ * (Playground.cpp:151-167, Operator.hpp:125-200).  A callback computes y = A(x) by calling this
+ * library (storm_hip_op_apply, storm_hip_op_apply_add, BLAS-1 ...): those calls only ENQUEUE work on the
+ * context's stream, so the solver loop around them never waits for the device -- every scalar of the
+ * recurrences (alpha, beta, rho, omega, the IDR/BiCGStab(l) small systems, Hessenberg + Givens) stays in
+ * HBM, the convergence rule of Solver.hpp:132-140 is evaluated there, and the host polls a pinned flag
+ * `check_lag` iterations behind.  A callback that itself waits (storm_hip_dot ...) is still correct.
+ * While a callback runs, the library calls it makes are predicated on the solve's `done` flag, so work
+ * enqueued past convergence costs nothing.  Return 0 from a callback; anything else aborts the solve with
+ * STORM_HIP_E_INVALID. */
+typedef struct storm_hip_krylov storm_hip_krylov;
+typedef int (*storm_hip_apply_fn)(void *user, storm_hip_vec *y, const storm_hip_vec *x);
+
+enum storm_hip_method {
+  STORM_HIP_CG = 0,          /* SolverCg.hpp:47-128 */
+  STORM_HIP_BICGSTAB = 1,    /* SolverBiCgStab.hpp:52-167 */
+  STORM_HIP_GMRES = 2,       /* SolverGmres.hpp:281-283 */
+  STORM_HIP_FGMRES = 3,      /* SolverGmres.hpp:306-308 */
+  STORM_HIP_CGS = 4,         /* SolverCgs.hpp:50-176 */
+  STORM_HIP_TFQMR = 5,       /* SolverTfqmr.hpp:227-240 */
+  STORM_HIP_TFQMR1 = 6,      /* SolverTfqmr.hpp:252-265 */
+  STORM_HIP_BICGSTAB_L = 7,  /* SolverBiCgStab.hpp:184-383; num_inner_iterations = l (default 2) */
+  STORM_HIP_IDRS = 8,        /* SolverIdrs.hpp:52-291;      num_inner_iterations = s (default 4) */
+  STORM_HIP_RICHARDSON = 9   /* SolverRichardson.hpp:41-98 */
+};
+enum storm_hip_side { STORM_HIP_LEFT = 0, STORM_HIP_RIGHT = 1, STORM_HIP_SYMMETRIC = 2 }; /* Preconditioner.hpp:39-60 */
+
+int storm_hip_krylov_create(storm_hip_ctx *ctx, int method, storm_hip_krylov **out);
+int storm_hip_krylov_destroy(storm_hip_krylov *k);
+/* A = beta*I + alpha*M of a stencil operator (CG / BiCGStab / GMRES without preconditioner then run the fused
+ * kernels of storm_hip_solve_*), or a callback. */
+int storm_hip_krylov_set_operator(storm_hip_krylov *k, const storm_hip_op *op, double alpha, double beta);
+int storm_hip_krylov_set_operator_fn(storm_hip_krylov *k, storm_hip_apply_fn apply, void *user);
+/* pre_op / pre_side.  fn == NULL removes it.  The diagonal form is y = d .* x (e.g. d from
+ * storm_hip_op_get_diagonal(..., invert = 1): Jacobi); the vector must outlive the solves. */
+int storm_hip_krylov_set_preconditioner_fn(storm_hip_krylov *k, storm_hip_apply_fn apply, void *user, int side);
+int storm_hip_krylov_set_preconditioner_diag(storm_hip_krylov *k, const storm_hip_vec *d, int side);
+/* Extra knobs: "relaxation_factor" (Richardson, default 1e-4, SolverRichardson.hpp:45). */
+int storm_hip_krylov_set_real(storm_hip_krylov *k, const char *key, double value);
+/* `Solver::solve(x, b, op)`: the whole solve, no host wait inside the loop.  num_applies counts operator
+ * applications; *pre_applies (nullable) preconditioner applications. */
+int storm_hip_krylov_solve(storm_hip_krylov *k, const storm_hip_vec *b, storm_hip_vec *x,
+                           const storm_hip_solver_params *params, storm_hip_solver_result *result,
+                           double *history, int64_t *pre_applies);
+/* The reference's protected stepping interface (Solver.hpp:78-111): init returns |b - A x|, each iterate the
+ * new residual norm (ONE host wait per call -- not per reduction); the caller owns the convergence decision,
+ * as IterativeSolver::solve does; finalize after the last iterate.  `params` supplies num_inner_iterations /
+ * gram_schmidt only. */
+int storm_hip_krylov_init(storm_hip_krylov *k, const storm_hip_vec *b, storm_hip_vec *x,
+                          const storm_hip_solver_params *params, double *initial_error);
+int storm_hip_krylov_iterate(storm_hip_krylov *k, double *error);
+int storm_hip_krylov_finalize(storm_hip_krylov *k);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

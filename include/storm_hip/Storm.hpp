@@ -12,14 +12,18 @@
 // they are restated here rather than included).
 //
 // `DeviceVector` plays the role of `Feathers::Field` (Feathers/Field.hpp:60-114).  Every vector
-// statement the solver bodies execute is intercepted by an overload in this header and lowered to
-// exactly ONE C-ABI call (one HIP kernel); nothing can fall through to a host element loop,
-// because DeviceVector has no element access at all.
+// statement a solver body executes is intercepted by an overload in this header and lowered to
+// exactly ONE C-ABI call (one HIP kernel).  DeviceVector also models the reference's `legacy_vector_like`
+// concept (Solvers/Operator.hpp:39-45: `shape()`, `operator()(row, col)`, `assign`), so the reference's own
+// solver templates can be instantiated on it (tools/check_reference_binding.sh); its element
+// access is a slow host proxy that exists for the concept only -- every statement of the overload census
+//  has a non-template overload here for const and non-const operands alike, which overload
+// resolution prefers to Bittern's generic element-loop templates.
 //
-// With a `HipStencilOperator` and no preconditioner, `IterativeSolver::solve` hands the whole
-// solve to the device-resident entry points (storm_hip_solve_*); any other operator -- e.g. a
-// lambda through make_operator, as Playground.cpp:151-167 does -- runs the statement sequence
-// below over the BLAS-1 calls.
+// The solver classes of this header are knob holders: `solve` hands the whole solve to the library's
+// device-resident loops (storm_hip_krylov_*, csrc/krylov.hip) for ANY operator -- a `HipStencilOperator`
+// binds natively, a lambda through make_operator (as Playground.cpp:151-167 does) as a callback that only
+// enqueues its kernels -- and no scalar of a recurrence ever visits the host.
 //
 // C++17, header-only, needs only <storm_hip.h> and libstorm_hip.so.
 #pragma once
@@ -30,11 +34,14 @@
 #include <cmath>
 #include <cstdio>
 #include <cstddef>
+#include <exception>
 #include <functional>
+#include <initializer_list>
 #include <limits>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -98,24 +105,32 @@ public:
   DeviceVector(const Context& ctx, std::size_t n_owned, std::size_t n_halo = 0) {
     detail::check(storm_hip_vec_create(ctx.handle(), (int64_t)n_owned, (int64_t)n_halo, &_h));
   }
-  DeviceVector(DeviceVector&& o) noexcept : _h(std::exchange(o._h, nullptr)) {}
+  DeviceVector(DeviceVector&& o) noexcept : _h(std::exchange(o._h, nullptr)), _view(std::exchange(o._view, false)) {}
   DeviceVector& operator=(DeviceVector&& o) noexcept {
     if (this != &o) {
-      storm_hip_vec_destroy(_h);
+      release();
       _h = std::exchange(o._h, nullptr);
+      _view = std::exchange(o._view, false);
     }
     return *this;
   }
   DeviceVector(const DeviceVector&) = delete;
   DeviceVector& operator=(const DeviceVector&) = delete;
-  ~DeviceVector() { storm_hip_vec_destroy(_h); }
+  ~DeviceVector() { release(); }
+
+  /// A non-owning view of a vector the library hands to an operator / preconditioner callback.
+  static DeviceVector view_of(storm_hip_vec* handle) noexcept {
+    DeviceVector v;
+    v._h = handle, v._view = true;
+    return v;
+  }
 
   /// Field::assign(other, copy): a new zero-initialised vector shaped like `other`; the reference
   /// ignores `copy` (Feathers/Field.hpp:82-84) and so does this.
   void assign(const DeviceVector& other, bool /*copy*/ = true) {
     storm_hip_vec* fresh = nullptr;
     detail::check(storm_hip_vec_create_like(other._h, &fresh));
-    storm_hip_vec_destroy(_h);
+    release();
     _h = fresh;
   }
 
@@ -126,6 +141,15 @@ public:
     return {(std::size_t)n, 1};
   }
   std::size_t size() const { return shape()[0]; }
+
+  /// Field::operator()(row, col) (Field.hpp:104-111; `col` ignored, NumVars == 1).  A HOST PROXY: one blocking
+  /// 8-byte copy per call.  It exists so that DeviceVector models the reference's `matrix` concept
+  /// (Bittern/Matrix.hpp:40-45: `std::apply(mat, mat.shape())`); no solver statement goes through it.
+  real_t operator()(std::size_t row, std::size_t /*col*/ = 0) const {
+    real_t value = 0.0;
+    detail::check(storm_hip_vec_get(_h, (int64_t)row, &value));
+    return value;
+  }
 
   void upload(const real_t* host, std::size_t n) { detail::check(storm_hip_vec_upload(_h, host, (int64_t)n)); }
   void download(real_t* host, std::size_t n) const { detail::check(storm_hip_vec_download(_h, host, (int64_t)n)); }
@@ -145,25 +169,53 @@ public:
   DeviceVector& operator/=(real_t s) { detail::check(storm_hip_div_scalar(_h, s)); return *this; }
 
 private:
+  void release() noexcept {
+    if (!_view) storm_hip_vec_destroy(_h);
+    _h = nullptr, _view = false;
+  }
   storm_hip_vec* _h = nullptr;
+  bool _view = false;
 };
 
 // Expression builders (Bittern/MatrixMath.hpp:247-285 for this vector type).
-inline expr::Scaled operator*(real_t a, const DeviceVector& v) { return {a, &v}; }
-inline expr::Lin2 operator+(const DeviceVector& x, const expr::Scaled& s) { return {1.0, &x, s.a, s.v}; }
-inline expr::Lin2 operator-(const DeviceVector& x, const expr::Scaled& s) { return {1.0, &x, -s.a, s.v}; }
-inline expr::Lin2 operator+(const DeviceVector& x, const DeviceVector& z) { return {1.0, &x, 1.0, &z}; }
-inline expr::Lin2 operator-(const DeviceVector& x, const DeviceVector& z) { return {1.0, &x, -1.0, &z}; }
-inline expr::Lin2 operator+(const expr::Scaled& a, const expr::Scaled& b) { return {a.a, a.v, b.a, b.v}; }
-inline expr::Quot operator/(const DeviceVector& v, real_t s) { return {&v, s}; }
-inline expr::ScaledLin2 operator*(real_t s, const expr::Lin2& e) { return {s, e}; }
-inline expr::Lin3 operator+(const DeviceVector& r, const expr::ScaledLin2& e) { return {&r, e.s, e.e}; }
+//
+// Bittern's own operators are templates on forwarding references (`operator*(scalar auto, matrix auto&&)` ...):
+// for a NON-const DeviceVector lvalue they deduce `DeviceVector&`, an identity binding that would beat an
+// overload taking `const DeviceVector&`.  So every first-level operator that has a raw DeviceVector operand is
+// spelled out for both `DeviceVector&` and `const DeviceVector&` -- equal conversions, and then the
+// non-template wins (tests/cpp/concept_check.cpp plays Bittern's side with templates of the same shape).
+#define STORM_HIP_CV1(MACRO) MACRO(const DeviceVector&) MACRO(DeviceVector&)
+#define STORM_HIP_CV2(MACRO)                                             \
+  MACRO(const DeviceVector&, const DeviceVector&) MACRO(DeviceVector&, const DeviceVector&) \
+  MACRO(const DeviceVector&, DeviceVector&) MACRO(DeviceVector&, DeviceVector&)
+
+#define STORM_HIP_SCALED(V) \
+  inline expr::Scaled operator*(real_t a, V v) { return {a, &v}; }
+STORM_HIP_CV1(STORM_HIP_SCALED)
+#define STORM_HIP_QUOT(V) \
+  inline expr::Quot operator/(V v, real_t s) { return {&v, s}; }
+STORM_HIP_CV1(STORM_HIP_QUOT)
+#define STORM_HIP_PLUS_SCALED(V)                                                                    \
+  inline expr::Lin2 operator+(V x, const expr::Scaled& s) { return {1.0, &x, s.a, s.v}; }           \
+  inline expr::Lin2 operator-(V x, const expr::Scaled& s) { return {1.0, &x, -s.a, s.v}; }          \
+  inline expr::Lin3 operator+(V r, const expr::ScaledLin2& e) { return {&r, e.s, e.e}; }
+STORM_HIP_CV1(STORM_HIP_PLUS_SCALED)
+#define STORM_HIP_SUM(X, Z)                                                      \
+  inline expr::Lin2 operator+(X x, Z z) { return {1.0, &x, 1.0, &z}; }           \
+  inline expr::Lin2 operator-(X x, Z z) { return {1.0, &x, -1.0, &z}; }
+STORM_HIP_CV2(STORM_HIP_SUM)
+namespace expr {  // (operands of namespace expr only: declared there, where argument-dependent lookup looks)
+inline Lin2 operator+(const Scaled& a, const Scaled& b) { return {a.a, a.v, b.a, b.v}; }
+inline ScaledLin2 operator*(real_t s, const Lin2& e) { return {s, e}; }
+}  // namespace expr
 
 // out <<= expr   (Bittern/MatrixAlgorithms.hpp:120-124)
-inline DeviceVector& operator<<=(DeviceVector& out, const DeviceVector& v) {
-  detail::check(storm_hip_copy(out.handle(), v.handle()));
-  return out;
-}
+#define STORM_HIP_COPY(V)                                              \
+  inline DeviceVector& operator<<=(DeviceVector& out, V v) {           \
+    detail::check(storm_hip_copy(out.handle(), v.handle()));           \
+    return out;                                                        \
+  }
+STORM_HIP_CV1(STORM_HIP_COPY)
 inline DeviceVector& operator<<=(DeviceVector& out, const expr::Scaled& e) {
   detail::check(storm_hip_axpbz(out.handle(), e.a, e.v->handle(), 0.0, e.v->handle()));
   return out;
@@ -185,7 +237,6 @@ inline DeviceVector& operator<<=(DeviceVector& out, const expr::ScaledLin2& e) {
   detail::check(storm_hip_scale(out.handle(), e.s));
   return out;
 }
-
 inline DeviceVector& operator<<=(DeviceVector& out, const expr::Quot& e) {  // p <<= r / phi, SolverIdrs.hpp:131
   if (e.v != &out) detail::check(storm_hip_copy(out.handle(), e.v->handle()));
   detail::check(storm_hip_div_scalar(out.handle(), e.s));
@@ -201,17 +252,30 @@ inline void vmul(DeviceVector& y, const DeviceVector& a, const DeviceVector& b) 
 }
 
 /// Bittern/MatrixAlgorithms.hpp:310-317 (global sum over all ranks).
-inline real_t dot_product(const DeviceVector& a, const DeviceVector& b) {
-  real_t r = 0.0;
-  detail::check(storm_hip_dot(a.handle(), b.handle(), &r));
-  return r;
-}
+#define STORM_HIP_DOT(A, B)                                              \
+  inline real_t dot_product(A a, B b) {                                  \
+    real_t r = 0.0;                                                      \
+    detail::check(storm_hip_dot(a.handle(), b.handle(), &r));            \
+    return r;                                                            \
+  }
+STORM_HIP_CV2(STORM_HIP_DOT)
 /// Bittern/MatrixAlgorithms.hpp:262-270.
-inline real_t norm_2(const DeviceVector& a) {
-  real_t r = 0.0;
-  detail::check(storm_hip_norm2(a.handle(), &r));
-  return r;
-}
+#define STORM_HIP_NORM(A)                                   \
+  inline real_t norm_2(A a) {                               \
+    real_t r = 0.0;                                         \
+    detail::check(storm_hip_norm2(a.handle(), &r));         \
+    return r;                                               \
+  }
+STORM_HIP_CV1(STORM_HIP_NORM)
+#undef STORM_HIP_SCALED
+#undef STORM_HIP_QUOT
+#undef STORM_HIP_PLUS_SCALED
+#undef STORM_HIP_SUM
+#undef STORM_HIP_COPY
+#undef STORM_HIP_DOT
+#undef STORM_HIP_NORM
+#undef STORM_HIP_CV1
+#undef STORM_HIP_CV2
 /// ADL hook used at Solvers/Solver.hpp:281 and SolverBiCgStab.hpp:224.
 inline void fill_with(DeviceVector& a, real_t value) { detail::check(storm_hip_fill(a.handle(), value)); }
 
@@ -397,6 +461,7 @@ public:
   }
   void mul(DeviceVector& y_vec, const DeviceVector& x_vec) const override { vmul(y_vec, _dinv, x_vec); }
   void conj_mul(DeviceVector& x_vec, const DeviceVector& y_vec) const override { vmul(x_vec, _dinv, y_vec); }
+  const DeviceVector& inverse_diagonal() const noexcept { return _dinv; }
 
 private:
   DeviceVector _dinv;
@@ -411,8 +476,6 @@ public:
 };
 
 namespace detail {
-using native_entry = int (*)(const storm_hip_op*, double, double, const storm_hip_vec*, storm_hip_vec*,
-                             const storm_hip_solver_params*, storm_hip_solver_result*, double*);
 inline std::function<void(const std::string&)>& log_sink() {
   static std::function<void(const std::string&)> sink;  // empty: silent
   return sink;
@@ -424,6 +487,75 @@ inline void log_solve(std::size_t iteration, real_t absolute_error, real_t relat
                 relative_error);
   log_sink()(line);
 }
+
+/// One `storm_hip_krylov` object -- the library's device-resident solver loops (csrc/krylov.hip) -- with the
+/// caller's Operator / Preconditioner objects bound to it.  A HipStencilOperator binds natively; any other
+/// operator (a lambda through make_operator, Playground.cpp:151-167) and any preconditioner but the Jacobi
+/// one bind as callbacks, which only enqueue kernels.  An exception thrown inside a callback aborts the solve
+/// and is rethrown from the call that ran it.
+class Engine {
+public:
+  Engine() = default;
+  Engine(const Engine&) = delete;
+  Engine& operator=(const Engine&) = delete;
+  ~Engine() { storm_hip_krylov_destroy(_h); }
+
+  void bind(int method, const DeviceVector& like, const Operator<DeviceVector>& any_op,
+            const Preconditioner<DeviceVector>* pre_op, PreconditionerSide side) {
+    storm_hip_ctx* ctx = nullptr;
+    check(storm_hip_vec_context(like.handle(), &ctx));
+    if (_h == nullptr || ctx != _ctx || method != _method) {
+      storm_hip_krylov_destroy(_h);
+      _h = nullptr;
+      check(storm_hip_krylov_create(ctx, method, &_h));
+      _ctx = ctx, _method = method;
+    }
+    _op = Bound{&any_op, &_thrown};
+    if (const auto* hip_op = dynamic_cast<const HipStencilOperator*>(&any_op))
+      check(storm_hip_krylov_set_operator(_h, hip_op->matrix().handle(), hip_op->alpha(), hip_op->beta()));
+    else
+      check(storm_hip_krylov_set_operator_fn(_h, &Engine::trampoline, &_op));
+    const int c_side = side == PreconditionerSide::Left    ? STORM_HIP_LEFT
+                       : side == PreconditionerSide::Right ? STORM_HIP_RIGHT
+                                                           : STORM_HIP_SYMMETRIC;
+    _pre = Bound{pre_op, &_thrown};
+    if (pre_op == nullptr)
+      check(storm_hip_krylov_set_preconditioner_diag(_h, nullptr, c_side));
+    else if (const auto* jacobi = dynamic_cast<const JacobiPreconditioner*>(pre_op))
+      check(storm_hip_krylov_set_preconditioner_diag(_h, jacobi->inverse_diagonal().handle(), c_side));
+    else
+      check(storm_hip_krylov_set_preconditioner_fn(_h, &Engine::trampoline, &_pre, c_side));
+  }
+  storm_hip_krylov* handle() const noexcept { return _h; }
+  /// Status of a library call that may have run callbacks.
+  void finish(int status) {
+    if (_thrown) std::rethrow_exception(std::exchange(_thrown, nullptr));
+    check(status);
+  }
+
+private:
+  struct Bound {
+    const Operator<DeviceVector>* op;
+    std::exception_ptr* thrown;
+  };
+  static int trampoline(void* user, storm_hip_vec* y, const storm_hip_vec* x) noexcept {
+    auto* bound = static_cast<Bound*>(user);
+    try {
+      DeviceVector y_view = DeviceVector::view_of(y);
+      const DeviceVector x_view = DeviceVector::view_of(const_cast<storm_hip_vec*>(x));
+      bound->op->mul(y_view, x_view);
+      return 0;
+    } catch (...) {
+      *bound->thrown = std::current_exception();
+      return 1;
+    }
+  }
+  storm_hip_krylov* _h = nullptr;
+  storm_hip_ctx* _ctx = nullptr;
+  int _method = -1;
+  Bound _op{nullptr, nullptr}, _pre{nullptr, nullptr};
+  std::exception_ptr _thrown;
+};
 }  // namespace detail
 
 /// The reference logs one line per solve through spdlog (`STORM_INFO("n_iter: ..., abs_err: ..., rel_err: ...")`,
@@ -431,6 +563,13 @@ inline void log_solve(std::size_t iteration, real_t absolute_error, real_t relat
 /// line (e.g. `Storm::set_log_sink([](const std::string& s) { spdlog::info(s); })`); none installed = silent.
 inline void set_log_sink(std::function<void(const std::string&)> sink) { detail::log_sink() = std::move(sink); }
 
+/// Solvers/Solver.hpp:62-149: the public knobs (names, defaults), the protected stepping hooks and `solve`.
+///
+/// The solvers this header ships name a library method (`device_method()`); their `solve` is ONE call,
+/// `storm_hip_krylov_solve`: the loop of Solver.hpp:132-140 and every scalar of the recurrence stay on the
+/// device.  Their init / iterate / finalize hooks go through `storm_hip_krylov_init / _iterate / _finalize`,
+/// and `device_loop = false` runs the host loop below over them instead (one host wait per iteration).  A
+/// user-defined subclass that names no method gets that host loop over its own hooks.
 template<class InVector, class OutVector = InVector>
 class IterativeSolver : public Solver<InVector, OutVector> {
 public:
@@ -446,6 +585,10 @@ public:
   std::unique_ptr<Preconditioner<InVector>> pre_op{nullptr};
   std::string name;
 
+  // extras of this build
+  bool device_loop{true};
+  std::size_t num_applies{0}, num_pre_applies{0};  ///< of the last device-loop solve
+
 protected:
   virtual real_t init(const InVector& x_vec, const OutVector& b_vec, const Operator<InVector, OutVector>& any_op,
                       const Preconditioner<InVector>* pre_op) = 0;
@@ -454,52 +597,62 @@ protected:
   virtual void finalize(InVector& /*x_vec*/, const OutVector& /*b_vec*/,
                         const Operator<InVector, OutVector>& /*any_op*/, const Preconditioner<InVector>* /*pre_op*/) {}
 
-  /// Whole-solver C entry point of the derived class (null: none) and its extra knobs.
-  virtual detail::native_entry native() const noexcept { return nullptr; }
-  virtual void fill_native_params(storm_hip_solver_params& /*p*/) const {}
+  /// storm_hip_method of a shipped solver; -1: none (the host loop runs the hooks above).
+  virtual int device_method() const noexcept { return -1; }
+  virtual void fill_params(storm_hip_solver_params& /*p*/) const {}
+  virtual void configure(storm_hip_krylov* /*k*/) const {}
+
+  storm_hip_solver_params params() const {
+    storm_hip_solver_params p;
+    storm_hip_solver_params_default(&p);
+    p.num_iterations = (int64_t)num_iterations;
+    p.absolute_error_tolerance = absolute_error_tolerance;
+    p.relative_error_tolerance = relative_error_tolerance;
+    p.num_inner_iterations = 0;  // "the method's default"; InnerOuterIterativeSolver fills its knob in
+    fill_params(p);
+    return p;
+  }
+  detail::Engine _engine;
 
 public:
   bool solve(InVector& x_vec, const OutVector& b_vec, const Operator<InVector, OutVector>& any_op) final {
+    if (pre_op != nullptr) pre_op->build(x_vec, b_vec, any_op);
     if constexpr (std::is_same_v<InVector, DeviceVector> && std::is_same_v<OutVector, DeviceVector>) {
-      const auto* hip_op = dynamic_cast<const HipStencilOperator*>(&any_op);
-      if (hip_op != nullptr && pre_op == nullptr && native() != nullptr) {
-        storm_hip_solver_params p;
-        storm_hip_solver_params_default(&p);
-        p.num_iterations = (int64_t)num_iterations;
-        p.absolute_error_tolerance = absolute_error_tolerance;
-        p.relative_error_tolerance = relative_error_tolerance;
-        fill_native_params(p);
+      if (device_method() >= 0 && device_loop) {
+        _engine.bind(device_method(), x_vec, any_op, pre_op.get(), pre_side);
+        configure(_engine.handle());
+        const storm_hip_solver_params p = params();
         storm_hip_solver_result r{};
-        detail::check(native()(hip_op->matrix().handle(), hip_op->alpha(), hip_op->beta(), b_vec.handle(),
-                               x_vec.handle(), &p, &r, nullptr));
+        int64_t n_pre = 0;
+        _engine.finish(storm_hip_krylov_solve(_engine.handle(), b_vec.handle(), x_vec.handle(), &p, &r, nullptr, &n_pre));
         iteration = (std::size_t)r.iterations;
-        absolute_error = r.absolute_error;
-        relative_error = r.relative_error;
+        absolute_error = r.absolute_error, relative_error = r.relative_error;
+        num_applies = (std::size_t)r.num_applies, num_pre_applies = (std::size_t)n_pre;
         detail::log_solve(iteration, absolute_error, relative_error);
         return r.converged != 0;
       }
     }
-    // The reference's control flow (Solver.hpp:116-147).
-    if (pre_op != nullptr) pre_op->build(x_vec, b_vec, any_op);
+    // Host loop with the reference's rule: stop on abs_tol > 0 && abs < abs_tol, or rel_tol > 0 && abs / initial < rel_tol.
     const real_t initial_error = init(x_vec, b_vec, any_op, pre_op.get());
     absolute_error = initial_error;
-    if (absolute_error_tolerance > 0.0 && absolute_error < absolute_error_tolerance) {
-      finalize(x_vec, b_vec, any_op, pre_op.get());
-      return true;
-    }
-    bool converged = false;
-    for (iteration = 0; !converged && (iteration < num_iterations); ++iteration) {
+    const auto met = [this](real_t value, real_t tolerance) { return tolerance > 0.0 && value < tolerance; };
+    bool converged = met(absolute_error, absolute_error_tolerance);
+    const bool silent = converged;  // the early return of Solver.hpp:124-128 logs nothing
+    iteration = 0;
+    while (!converged && iteration < num_iterations) {
       absolute_error = iterate(x_vec, b_vec, any_op, pre_op.get());
       relative_error = absolute_error / initial_error;
-      converged |= (absolute_error_tolerance > 0.0) && (absolute_error < absolute_error_tolerance);
-      converged |= (relative_error_tolerance > 0.0) && (relative_error < relative_error_tolerance);
+      converged = met(absolute_error, absolute_error_tolerance) || met(relative_error, relative_error_tolerance);
+      ++iteration;
     }
     finalize(x_vec, b_vec, any_op, pre_op.get());
-    detail::log_solve(iteration, absolute_error, relative_error);  // Solver.hpp:144-145
+    if (!silent) detail::log_solve(iteration, absolute_error, relative_error);
     return converged;
   }
 };
 
+/// Solvers/Solver.hpp:154-259: `num_inner_iterations` and the restart bookkeeping over five hooks.  (For the shipped
+/// solvers that bookkeeping lives in the library; they implement only outer_init / inner_iterate / outer_finalize.)
 template<class InVector, class OutVector = InVector>
 class InnerOuterIterativeSolver : public IterativeSolver<InVector, OutVector> {
 public:
@@ -518,11 +671,11 @@ protected:
   virtual void outer_finalize(InVector&, const OutVector&, const Operator<InVector, OutVector>&,
                               const Preconditioner<InVector>*) {}
 
-  void fill_native_params(storm_hip_solver_params& p) const override {
-    p.num_inner_iterations = (int64_t)num_inner_iterations;
-  }
+  void fill_params(storm_hip_solver_params& p) const override { p.num_inner_iterations = (int64_t)num_inner_iterations; }
 
 private:
+  bool closes_a_cycle() const noexcept { return inner_iteration + 1 == num_inner_iterations; }
+
   real_t init(const InVector& x_vec, const OutVector& b_vec, const Operator<InVector, OutVector>& any_op,
               const Preconditioner<InVector>* pre_op) final {
     return outer_init(x_vec, b_vec, any_op, pre_op);
@@ -532,12 +685,12 @@ private:
     inner_iteration = this->iteration % num_inner_iterations;
     if (inner_iteration == 0) inner_init(x_vec, b_vec, any_op, pre_op);
     const real_t residual_norm = inner_iterate(x_vec, b_vec, any_op, pre_op);
-    if (inner_iteration == num_inner_iterations - 1) inner_finalize(x_vec, b_vec, any_op, pre_op);
+    if (closes_a_cycle()) inner_finalize(x_vec, b_vec, any_op, pre_op);
     return residual_norm;
   }
   void finalize(InVector& x_vec, const OutVector& b_vec, const Operator<InVector, OutVector>& any_op,
                 const Preconditioner<InVector>* pre_op) final {
-    if (inner_iteration != num_inner_iterations - 1) inner_finalize(x_vec, b_vec, any_op, pre_op);
+    if (!closes_a_cycle()) inner_finalize(x_vec, b_vec, any_op, pre_op);
     outer_finalize(x_vec, b_vec, any_op, pre_op);
   }
 };
@@ -551,632 +704,180 @@ bool solve(Vector& x_vec, const Vector& b_vec, const Operator<Vector>& any_op) {
 /// A(x) = b for a non-uniform operator (A(0) != 0): solve A(x) - A(0) = b - A(0).  Solver.hpp:271-292.
 template<class Vector>
 bool solve_non_uniform(Solver<Vector>& solver, Vector& x_vec, const Vector& b_vec, const Operator<Vector>& any_op) {
-  Vector z_vec, f_vec;
-  z_vec.assign(x_vec, false);
-  f_vec.assign(b_vec, false);
-  fill_with(f_vec, 0.0);
-  any_op.mul(z_vec, f_vec);
-  f_vec <<= b_vec - z_vec;
-  const auto uni_op = make_operator<Vector>([&](Vector& y_vec, const Vector& in_vec) {
+  Vector at_zero, rhs;
+  at_zero.assign(x_vec, false);
+  rhs.assign(b_vec, false);
+  fill_with(rhs, 0.0);
+  any_op.mul(at_zero, rhs);
+  rhs <<= b_vec - at_zero;
+  const auto shifted = make_operator<Vector>([&](Vector& y_vec, const Vector& in_vec) {
     any_op.mul(y_vec, in_vec);
-    y_vec -= z_vec;
+    y_vec -= at_zero;
   });
-  return solver.solve(x_vec, f_vec, *uni_op);
+  return solver.solve(x_vec, rhs, *shifted);
 }
 
 // ---------------------------------------------------------------------------------------------
-/// Conjugate Gradients (SolverCg.hpp:47-128).
-template<class Vector>
-class CgSolver final : public IterativeSolver<Vector> {
-private:
-  real_t _gamma{};
-  Vector _p_vec, _r_vec, _z_vec;
+// The shipped solvers.  Each names its library method; the loop bodies are csrc/krylov.hip (and, for a stencil
+// operator without preconditioner, the fused kernels of csrc/solvers.hip).  They exist for DeviceVector only.
+namespace detail {
 
-  detail::native_entry native() const noexcept override { return &storm_hip_solve_cg; }
-
-  real_t init(const Vector& x_vec, const Vector& b_vec, const Operator<Vector>& lin_op,
-              const Preconditioner<Vector>* pre_op) override {
-    _p_vec.assign(x_vec, false);
-    _r_vec.assign(x_vec, false);
-    _z_vec.assign(x_vec, false);
-    lin_op.Residual(_r_vec, b_vec, x_vec);            // r <- b - A x
-    if (pre_op != nullptr) {
-      pre_op->mul(_z_vec, _r_vec);                    // z <- P r
-      _p_vec <<= _z_vec;
-      _gamma = dot_product(_r_vec, _z_vec);
-    } else {
-      _p_vec <<= _r_vec;
-      _gamma = dot_product(_r_vec, _r_vec);
-    }
-    return (pre_op != nullptr) ? norm_2(_r_vec) : std::sqrt(_gamma);
-  }
-
-  real_t iterate(Vector& x_vec, const Vector& /*b_vec*/, const Operator<Vector>& lin_op,
-                 const Preconditioner<Vector>* pre_op) override {
-    lin_op.mul(_z_vec, _p_vec);                       // z <- A p
-    const real_t alpha = safe_divide(_gamma, dot_product(_p_vec, _z_vec));
-    x_vec += alpha * _p_vec;
-    _r_vec -= alpha * _z_vec;
-    const real_t gamma_bar = _gamma;
-    if (pre_op != nullptr) {
-      pre_op->mul(_z_vec, _r_vec);
-      _gamma = dot_product(_r_vec, _z_vec);
-    } else {
-      _gamma = dot_product(_r_vec, _r_vec);
-    }
-    const real_t beta = safe_divide(_gamma, gamma_bar);
-    _p_vec <<= (pre_op != nullptr ? _z_vec : _r_vec) + beta * _p_vec;
-    return (pre_op != nullptr) ? norm_2(_r_vec) : std::sqrt(_gamma);
-  }
-};
-
-/// BiCGStab (SolverBiCgStab.hpp:52-167).
-template<class Vector>
-class BiCgStabSolver final : public IterativeSolver<Vector> {
-private:
-  real_t _alpha{}, _rho{}, _omega{};
-  Vector _p_vec, _r_vec, _r_tilde_vec, _t_vec, _v_vec, _z_vec;
-
-  detail::native_entry native() const noexcept override { return &storm_hip_solve_bicgstab; }
-
-  real_t init(const Vector& x_vec, const Vector& b_vec, const Operator<Vector>& lin_op,
-              const Preconditioner<Vector>* pre_op) override {
-    const bool left_pre = (pre_op != nullptr) && (this->pre_side == PreconditionerSide::Left);
-    for (Vector* v : {&_p_vec, &_r_vec, &_r_tilde_vec, &_t_vec, &_v_vec}) v->assign(x_vec, false);
-    if (pre_op != nullptr) _z_vec.assign(x_vec, false);
-    lin_op.Residual(_r_vec, b_vec, x_vec);
-    if (left_pre) {
-      std::swap(_z_vec, _r_vec);
-      pre_op->mul(_r_vec, _z_vec);
-    }
-    _r_tilde_vec <<= _r_vec;
-    _rho = dot_product(_r_tilde_vec, _r_vec);
-    return std::sqrt(_rho);
-  }
-
-  real_t iterate(Vector& x_vec, const Vector& /*b_vec*/, const Operator<Vector>& lin_op,
-                 const Preconditioner<Vector>* pre_op) override {
-    const bool left_pre = (pre_op != nullptr) && (this->pre_side == PreconditionerSide::Left);
-    const bool right_pre = (pre_op != nullptr) && (this->pre_side == PreconditionerSide::Right);
-    if (this->iteration == 0) {
-      _p_vec <<= _r_vec;
-    } else {
-      const real_t rho_bar = std::exchange(_rho, dot_product(_r_tilde_vec, _r_vec));
-      const real_t beta = safe_divide(_alpha * _rho, _omega * rho_bar);
-      _p_vec <<= _r_vec + beta * (_p_vec - _omega * _v_vec);
-    }
-    if (left_pre) pre_op->mul(_v_vec, _z_vec, lin_op, _p_vec);
-    else if (right_pre) lin_op.mul(_v_vec, _z_vec, *pre_op, _p_vec);
-    else lin_op.mul(_v_vec, _p_vec);
-    _alpha = safe_divide(_rho, dot_product(_r_tilde_vec, _v_vec));
-    x_vec += _alpha * (right_pre ? _z_vec : _p_vec);
-    _r_vec -= _alpha * _v_vec;
-    if (left_pre) pre_op->mul(_t_vec, _z_vec, lin_op, _r_vec);
-    else if (right_pre) lin_op.mul(_t_vec, _z_vec, *pre_op, _r_vec);
-    else lin_op.mul(_t_vec, _r_vec);
-    _omega = safe_divide(dot_product(_t_vec, _r_vec), dot_product(_t_vec, _t_vec));
-    x_vec += _omega * (right_pre ? _z_vec : _r_vec);
-    _r_vec -= _omega * _t_vec;
-    return norm_2(_r_vec);
-  }
-};
-
-/// Richardson iteration with a fixed relaxation factor (SolverRichardson.hpp:41-98).
-template<class Vector>
-class RichardsonSolver final : public IterativeSolver<Vector> {
-public:
-  real_t relaxation_factor = 1.0e-4;
-
-private:
-  Vector _r_vec, _z_vec;
-
-  void precondition(const Preconditioner<Vector>* pre_op) {
-    if (pre_op != nullptr) {
-      std::swap(_z_vec, _r_vec);
-      pre_op->mul(_r_vec, _z_vec);
-    }
-  }
-  real_t init(const Vector& x_vec, const Vector& b_vec, const Operator<Vector>& lin_op,
-              const Preconditioner<Vector>* pre_op) override {
-    _r_vec.assign(x_vec, false);
-    if (pre_op != nullptr) _z_vec.assign(x_vec, false);
-    lin_op.Residual(_r_vec, b_vec, x_vec);
-    precondition(pre_op);
-    return norm_2(_r_vec);
-  }
-  real_t iterate(Vector& x_vec, const Vector& b_vec, const Operator<Vector>& lin_op,
-                 const Preconditioner<Vector>* pre_op) override {
-    x_vec += relaxation_factor * _r_vec;
-    lin_op.Residual(_r_vec, b_vec, x_vec);
-    precondition(pre_op);
-    return norm_2(_r_vec);
-  }
-};
-
-/// Conjugate Gradients Squared (SolverCgs.hpp:50-176).
-template<class Vector>
-class CgsSolver final : public IterativeSolver<Vector> {
-private:
-  real_t _rho{};
-  Vector _p_vec, _q_vec, _r_vec, _r_tilde_vec, _u_vec, _v_vec;
-
-  real_t init(const Vector& x_vec, const Vector& b_vec, const Operator<Vector>& lin_op,
-              const Preconditioner<Vector>* pre_op) override {
-    const bool left_pre = (pre_op != nullptr) && (this->pre_side == PreconditionerSide::Left);
-    for (Vector* v : {&_p_vec, &_q_vec, &_r_vec, &_r_tilde_vec, &_u_vec, &_v_vec}) v->assign(x_vec, false);
-    lin_op.Residual(_r_vec, b_vec, x_vec);
-    if (left_pre) {
-      std::swap(_u_vec, _r_vec);
-      pre_op->mul(_r_vec, _u_vec);
-    }
-    _r_tilde_vec <<= _r_vec;
-    _rho = dot_product(_r_tilde_vec, _r_vec);
-    return std::sqrt(_rho);
-  }
-  real_t iterate(Vector& x_vec, const Vector& /*b_vec*/, const Operator<Vector>& lin_op,
-                 const Preconditioner<Vector>* pre_op) override {
-    const bool left_pre = (pre_op != nullptr) && (this->pre_side == PreconditionerSide::Left);
-    const bool right_pre = (pre_op != nullptr) && (this->pre_side == PreconditionerSide::Right);
-    if (this->iteration == 0) {
-      _u_vec <<= _r_vec;
-      _p_vec <<= _u_vec;
-    } else {
-      const real_t rho_bar = std::exchange(_rho, dot_product(_r_tilde_vec, _r_vec));
-      const real_t beta = safe_divide(_rho, rho_bar);
-      _u_vec <<= _r_vec + beta * _q_vec;
-      _p_vec <<= _u_vec + beta * (_q_vec + beta * _p_vec);
-    }
-    if (left_pre) pre_op->mul(_v_vec, _q_vec, lin_op, _p_vec);
-    else if (right_pre) lin_op.mul(_v_vec, _q_vec, *pre_op, _p_vec);
-    else lin_op.mul(_v_vec, _p_vec);
-    const real_t alpha = safe_divide(_rho, dot_product(_r_tilde_vec, _v_vec));
-    _q_vec <<= _u_vec - alpha * _v_vec;
-    _v_vec <<= _u_vec + _q_vec;
-    if (left_pre) {
-      x_vec += alpha * _v_vec;
-      pre_op->mul(_v_vec, _u_vec, lin_op, _v_vec);
-      _r_vec -= alpha * _v_vec;
-    } else if (right_pre) {
-      lin_op.mul(_v_vec, _u_vec, *pre_op, _v_vec);
-      x_vec += alpha * _u_vec;
-      _r_vec -= alpha * _v_vec;
-    } else {
-      lin_op.mul(_u_vec, _v_vec);
-      x_vec += alpha * _v_vec;
-      _r_vec -= alpha * _u_vec;
-    }
-    return norm_2(_r_vec);
-  }
-};
-
-/// Transpose-free QMR, with the 2-norm (L1 = false) or 1-norm-like (L1 = true) quasi-minimisation
-/// (SolverTfqmr.hpp:37-206).
-template<class Vector, bool L1>
-class BaseTfqmrSolver : public IterativeSolver<Vector> {
-private:
-  real_t _rho{}, _tau{};
-  Vector _d_vec, _r_tilde_vec, _u_vec, _v_vec, _y_vec, _s_vec, _z_vec;
-
-  void apply(const Operator<Vector>& lin_op, const Preconditioner<Vector>* pre_op) {  // s <- A y (preconditioned)
-    const bool left_pre = (pre_op != nullptr) && (this->pre_side == PreconditionerSide::Left);
-    const bool right_pre = (pre_op != nullptr) && (this->pre_side == PreconditionerSide::Right);
-    if (left_pre) pre_op->mul(_s_vec, _z_vec, lin_op, _y_vec);
-    else if (right_pre) lin_op.mul(_s_vec, _z_vec, *pre_op, _y_vec);
-    else lin_op.mul(_s_vec, _y_vec);
-  }
-  real_t init(const Vector& x_vec, const Vector& b_vec, const Operator<Vector>& lin_op,
-              const Preconditioner<Vector>* pre_op) override {
-    const bool left_pre = (pre_op != nullptr) && (this->pre_side == PreconditionerSide::Left);
-    for (Vector* v : {&_d_vec, &_r_tilde_vec, &_u_vec, &_v_vec, &_y_vec, &_s_vec}) v->assign(x_vec, false);
-    if (pre_op != nullptr) _z_vec.assign(x_vec, false);
-    if constexpr (L1) _d_vec <<= x_vec;
-    else fill_with(_d_vec, 0.0);
-    lin_op.Residual(_y_vec, b_vec, x_vec);
-    if (left_pre) {
-      std::swap(_z_vec, _y_vec);
-      pre_op->mul(_y_vec, _z_vec);
-    }
-    _u_vec <<= _y_vec;
-    _r_tilde_vec <<= _u_vec;
-    _rho = dot_product(_r_tilde_vec, _u_vec), _tau = std::sqrt(_rho);
-    return _tau;
-  }
-  real_t iterate(Vector& x_vec, const Vector& /*b_vec*/, const Operator<Vector>& lin_op,
-                 const Preconditioner<Vector>* pre_op) override {
-    const bool right_pre = (pre_op != nullptr) && (this->pre_side == PreconditionerSide::Right);
-    if (this->iteration == 0) {
-      apply(lin_op, pre_op);
-      _v_vec <<= _s_vec;
-    } else {
-      const real_t rho_bar = std::exchange(_rho, dot_product(_r_tilde_vec, _u_vec));
-      const real_t beta = safe_divide(_rho, rho_bar);
-      _v_vec <<= _s_vec + beta * _v_vec;
-      _y_vec <<= _u_vec + beta * _y_vec;
-      apply(lin_op, pre_op);
-      _v_vec <<= _s_vec + beta * _v_vec;
-    }
-    const real_t alpha = safe_divide(_rho, dot_product(_r_tilde_vec, _v_vec));
-    for (std::size_t m = 0; m <= 1; ++m) {
-      _u_vec -= alpha * _s_vec;
-      _d_vec += alpha * (right_pre ? _z_vec : _y_vec);
-      const real_t omega = norm_2(_u_vec);
-      if constexpr (L1) {
-        if (omega < _tau) _tau = omega, x_vec <<= _d_vec;
-      } else {
-        const auto rot = sym_ortho(_tau, omega);
-        _tau = omega * rot[0];
-        x_vec += std::pow(rot[0], 2) * _d_vec;
-        _d_vec *= std::pow(rot[1], 2);
-      }
-      if (m == 0) {
-        _y_vec -= alpha * _v_vec;
-        apply(lin_op, pre_op);
-      }
-    }
-    real_t tau_tilde = _tau;
-    if constexpr (!L1) tau_tilde *= std::sqrt(2.0 * (real_t)this->iteration + 3.0);
-    return tau_tilde;
-  }
+/// Stepping hooks of a shipped plain solver over the library's stepping calls.
+template<class Vector, int Method>
+class DeviceIterativeSolver : public IterativeSolver<Vector> {
+  static_assert(std::is_same_v<Vector, DeviceVector>, "the shipped solvers run on Storm::DeviceVector");
 
 protected:
-  BaseTfqmrSolver() = default;
+  int device_method() const noexcept final { return Method; }
+  real_t init(const Vector& x_vec, const Vector& b_vec, const Operator<Vector>& any_op,
+              const Preconditioner<Vector>* pre_op) final {
+    this->_engine.bind(Method, x_vec, any_op, pre_op, this->pre_side);
+    this->configure(this->_engine.handle());
+    const storm_hip_solver_params p = this->params();
+    real_t initial_error = 0.0;
+    this->_engine.finish(storm_hip_krylov_init(this->_engine.handle(), b_vec.handle(), x_vec.handle(), &p, &initial_error));
+    return initial_error;
+  }
+  real_t iterate(Vector&, const Vector&, const Operator<Vector>&, const Preconditioner<Vector>*) final {
+    real_t residual_norm = 0.0;
+    this->_engine.finish(storm_hip_krylov_iterate(this->_engine.handle(), &residual_norm));
+    return residual_norm;
+  }
+  void finalize(Vector&, const Vector&, const Operator<Vector>&, const Preconditioner<Vector>*) final {
+    this->_engine.finish(storm_hip_krylov_finalize(this->_engine.handle()));
+  }
 };
-template<class Vector>
-class TfqmrSolver final : public BaseTfqmrSolver<Vector, false> {};
-template<class Vector>
-class Tfqmr1Solver final : public BaseTfqmrSolver<Vector, true> {};
 
-/// BiCGStab(l) (SolverBiCgStab.hpp:184-383); `num_inner_iterations` is l (default 2).
-template<class Vector>
-class BiCgStabLSolver final : public InnerOuterIterativeSolver<Vector> {
-private:
-  real_t _alpha{}, _rho{}, _omega{};
-  std::vector<real_t> _gamma, _gamma_bar, _gamma_bbar, _sigma, _tau;  // tau is (l+1) x (l+1)
-  Vector _r_tilde_vec, _z_vec;
-  std::vector<Vector> _r_vecs, _u_vecs;
-
-  real_t& tau(std::size_t i, std::size_t j) { return _tau[i * (this->num_inner_iterations + 1) + j]; }
-
-  void apply(Vector& out, const Vector& in, const Operator<Vector>& lin_op, const Preconditioner<Vector>* pre_op) {
-    if (pre_op != nullptr) pre_op->mul(out, _z_vec, lin_op, in);
-    else lin_op.mul(out, in);
-  }
-  real_t outer_init(const Vector& x_vec, const Vector& b_vec, const Operator<Vector>& lin_op,
-                    const Preconditioner<Vector>* pre_op) override {
-    const std::size_t l = this->num_inner_iterations;
-    _gamma.assign(l + 1, 0.0), _gamma_bar.assign(l + 1, 0.0), _gamma_bbar.assign(l + 1, 0.0);
-    _sigma.assign(l + 1, 0.0), _tau.assign((l + 1) * (l + 1), 0.0);
-    _r_tilde_vec.assign(x_vec, false);
-    if (pre_op != nullptr) _z_vec.assign(x_vec, false);
-    _r_vecs.clear(), _u_vecs.clear();
-    _r_vecs.resize(l + 1), _u_vecs.resize(l + 1);
-    for (Vector& r_vec : _r_vecs) r_vec.assign(x_vec, false);
-    for (Vector& u_vec : _u_vecs) u_vec.assign(x_vec, false);
-    fill_with(_u_vecs[0], 0.0);
-    lin_op.Residual(_r_vecs[0], b_vec, x_vec);
-    if (pre_op != nullptr) {
-      std::swap(_z_vec, _r_vecs[0]);
-      pre_op->mul(_r_vecs[0], _z_vec);
-    }
-    _r_tilde_vec <<= _r_vecs[0];
-    _rho = dot_product(_r_tilde_vec, _r_vecs[0]);
-    return std::sqrt(_rho);
-  }
-  real_t inner_iterate(Vector& x_vec, const Vector& /*b_vec*/, const Operator<Vector>& lin_op,
-                       const Preconditioner<Vector>* pre_op) override {
-    const std::size_t l = this->num_inner_iterations, j = this->inner_iteration;
-    if (this->iteration == 0) {
-      _u_vecs[0] <<= _r_vecs[0];
-    } else {
-      const real_t rho_bar = std::exchange(_rho, dot_product(_r_tilde_vec, _r_vecs[j]));
-      const real_t beta = safe_divide(_alpha * _rho, rho_bar);
-      for (std::size_t i = 0; i <= j; ++i) _u_vecs[i] <<= _r_vecs[i] - beta * _u_vecs[i];
-    }
-    apply(_u_vecs[j + 1], _u_vecs[j], lin_op, pre_op);
-    _alpha = safe_divide(_rho, dot_product(_r_tilde_vec, _u_vecs[j + 1]));
-    for (std::size_t i = 0; i <= j; ++i) _r_vecs[i] -= _alpha * _u_vecs[i + 1];
-    x_vec += _alpha * _u_vecs[0];
-    apply(_r_vecs[j + 1], _r_vecs[j], lin_op, pre_op);
-    if (j == l - 1) {
-      for (std::size_t jj = 1; jj <= l; ++jj) {  // modified Gram-Schmidt on r_1..r_l
-        for (std::size_t i = 1; i < jj; ++i) {
-          tau(i, jj) = safe_divide(dot_product(_r_vecs[i], _r_vecs[jj]), _sigma[i]);
-          _r_vecs[jj] -= tau(i, jj) * _r_vecs[i];
-        }
-        _sigma[jj] = dot_product(_r_vecs[jj], _r_vecs[jj]);
-        _gamma_bar[jj] = safe_divide(dot_product(_r_vecs[0], _r_vecs[jj]), _sigma[jj]);
-      }
-      _omega = _gamma[l] = _gamma_bar[l], _rho *= -_omega;
-      for (std::size_t jj = l - 1; jj != 0; --jj) {
-        _gamma[jj] = _gamma_bar[jj];
-        for (std::size_t i = jj + 1; i <= l; ++i) _gamma[jj] -= tau(jj, i) * _gamma[i];
-      }
-      for (std::size_t jj = 1; jj < l; ++jj) {
-        _gamma_bbar[jj] = _gamma[jj + 1];
-        for (std::size_t i = jj + 1; i < l; ++i) _gamma_bbar[jj] += tau(jj, i) * _gamma[i + 1];
-      }
-      x_vec += _gamma[1] * _r_vecs[0];
-      _r_vecs[0] -= _gamma_bar[l] * _r_vecs[l];
-      _u_vecs[0] -= _gamma[l] * _u_vecs[l];
-      for (std::size_t jj = 1; jj < l; ++jj) {
-        x_vec += _gamma_bbar[jj] * _r_vecs[jj];
-        _r_vecs[0] -= _gamma_bar[jj] * _r_vecs[jj];
-        _u_vecs[0] -= _gamma[jj] * _u_vecs[jj];
-      }
-    }
-    return norm_2(_r_vecs[0]);
-  }
+/// The same for a restarted solver: the library restarts / updates x inside its iterate and finalize.
+template<class Vector, int Method, std::size_t DefaultInner>
+class DeviceInnerOuterSolver : public InnerOuterIterativeSolver<Vector> {
+  static_assert(std::is_same_v<Vector, DeviceVector>, "the shipped solvers run on Storm::DeviceVector");
 
 public:
-  BiCgStabLSolver() { this->num_inner_iterations = 2; }
-};
-
-/// IDR(s) (SolverIdrs.hpp:52-291); `num_inner_iterations` is s (default 4).
-template<class Vector>
-class IdrsSolver final : public InnerOuterIterativeSolver<Vector> {
-private:
-  real_t _omega{};
-  std::vector<real_t> _phi, _gamma, _mu;  // mu is s x s
-  Vector _r_vec, _v_vec, _z_vec;
-  std::vector<Vector> _p_vecs, _u_vecs, _g_vecs;
-
-  real_t& mu(std::size_t i, std::size_t j) { return _mu[i * this->num_inner_iterations + j]; }
-
-  real_t outer_init(const Vector& x_vec, const Vector& b_vec, const Operator<Vector>& lin_op,
-                    const Preconditioner<Vector>* pre_op) override {
-    const std::size_t s = this->num_inner_iterations;
-    const bool left_pre = (pre_op != nullptr) && (this->pre_side == PreconditionerSide::Left);
-    _phi.assign(s, 0.0), _gamma.assign(s, 0.0), _mu.assign(s * s, 0.0);
-    _r_vec.assign(x_vec, false), _v_vec.assign(x_vec, false);
-    if (pre_op != nullptr) _z_vec.assign(x_vec, false);
-    _p_vecs.clear(), _u_vecs.clear(), _g_vecs.clear();
-    _p_vecs.resize(s), _u_vecs.resize(s), _g_vecs.resize(s);
-    for (Vector& v : _p_vecs) v.assign(x_vec, false);
-    for (Vector& v : _u_vecs) v.assign(x_vec, false);
-    for (Vector& v : _g_vecs) v.assign(x_vec, false);
-    lin_op.Residual(_r_vec, b_vec, x_vec);
-    if (left_pre) {
-      std::swap(_z_vec, _r_vec);
-      pre_op->mul(_r_vec, _z_vec);
-    }
-    _phi[0] = norm_2(_r_vec);
-    return _phi[0];
-  }
-  void inner_init(const Vector& /*x_vec*/, const Vector& /*b_vec*/, const Operator<Vector>& /*lin_op*/,
-                  const Preconditioner<Vector>* /*pre_op*/) override {
-    const std::size_t s = this->num_inner_iterations;
-    if (this->iteration == 0) {
-      _omega = mu(0, 0) = 1.0;
-      _p_vecs[0] <<= _r_vec / _phi[0];
-      for (std::size_t i = 1; i < s; ++i) {
-        mu(i, i) = 1.0, _phi[i] = 0.0;
-        fill_randomly(_p_vecs[i]);
-        for (std::size_t j = 0; j < i; ++j) {
-          mu(i, j) = 0.0;
-          _p_vecs[i] -= dot_product(_p_vecs[i], _p_vecs[j]) * _p_vecs[j];
-        }
-        _p_vecs[i] /= norm_2(_p_vecs[i]);
-      }
-    } else {
-      for (std::size_t i = 0; i < s; ++i) _phi[i] = dot_product(_p_vecs[i], _r_vec);
-    }
-  }
-  real_t inner_iterate(Vector& x_vec, const Vector& /*b_vec*/, const Operator<Vector>& lin_op,
-                       const Preconditioner<Vector>* pre_op) override {
-    const std::size_t s = this->num_inner_iterations, k = this->inner_iteration;
-    const bool left_pre = (pre_op != nullptr) && (this->pre_side == PreconditionerSide::Left);
-    const bool right_pre = (pre_op != nullptr) && (this->pre_side == PreconditionerSide::Right);
-    for (std::size_t i = k; i < s; ++i) {  // lower-triangular solve for gamma_k..gamma_{s-1}
-      _gamma[i] = _phi[i];
-      for (std::size_t j = k; j < i; ++j) _gamma[i] -= mu(i, j) * _gamma[j];
-      _gamma[i] /= mu(i, i);
-    }
-    _v_vec <<= _r_vec - _gamma[k] * _g_vecs[k];
-    for (std::size_t i = k + 1; i < s; ++i) _v_vec -= _gamma[i] * _g_vecs[i];
-    if (right_pre) {
-      std::swap(_z_vec, _v_vec);
-      pre_op->mul(_v_vec, _z_vec);
-    }
-    _u_vecs[k] <<= _omega * _v_vec + _gamma[k] * _u_vecs[k];
-    for (std::size_t i = k + 1; i < s; ++i) _u_vecs[k] += _gamma[i] * _u_vecs[i];
-    if (left_pre) pre_op->mul(_g_vecs[k], _z_vec, lin_op, _u_vecs[k]);
-    else lin_op.mul(_g_vecs[k], _u_vecs[k]);
-    for (std::size_t i = 0; i < k; ++i) {
-      const real_t alpha = safe_divide(dot_product(_p_vecs[i], _g_vecs[k]), mu(i, i));
-      _u_vecs[k] -= alpha * _u_vecs[i];
-      _g_vecs[k] -= alpha * _g_vecs[i];
-    }
-    for (std::size_t i = k; i < s; ++i) mu(i, k) = dot_product(_p_vecs[i], _g_vecs[k]);
-    const real_t beta = safe_divide(_phi[k], mu(k, k));
-    x_vec += beta * _u_vecs[k];
-    _r_vec -= beta * _g_vecs[k];
-    for (std::size_t i = k + 1; i < s; ++i) _phi[i] -= beta * mu(i, k);
-    if (k == s - 1) {
-      if (left_pre) pre_op->mul(_v_vec, _z_vec, lin_op, _r_vec);
-      else if (right_pre) lin_op.mul(_v_vec, _z_vec, *pre_op, _r_vec);
-      else lin_op.mul(_v_vec, _r_vec);
-      _omega = safe_divide(dot_product(_v_vec, _r_vec), dot_product(_v_vec, _v_vec));
-      x_vec += _omega * (right_pre ? _z_vec : _r_vec);
-      _r_vec -= _omega * _v_vec;
-    }
-    return norm_2(_r_vec);
-  }
-
-public:
-  IdrsSolver() { this->num_inner_iterations = 4; }
-};
-
-/// GMRES(m) / FGMRES(m) (SolverGmres.hpp:41-255, `BaseGmresSolver<Vector, Flexible>`).  The
-/// host-statement path implements the unpreconditioned, left/right preconditioned and flexible
-/// (always right, :98-99; one z vector per inner iteration) variants over dense host arrays for H,
-/// beta, cs, sn (the reference's DenseMatrix helpers, Solvers/MatrixDense.hpp:43-170, are replaced
-/// by std::vector here).
-template<class Vector, bool Flexible>
-class BaseGmresSolver : public InnerOuterIterativeSolver<Vector> {
-private:
-  std::vector<real_t> _beta, _cs, _sn, _H;  // H is (m+1) x m, row-major
-  std::vector<Vector> _q_vecs;
-  std::vector<Vector> _z_vecs;              // m if Flexible, else 1 (SolverGmres.hpp:48-49)
-
-  real_t& H(std::size_t i, std::size_t j) { return _H[i * this->num_inner_iterations + j]; }
-
-  detail::native_entry native() const noexcept override { return &storm_hip_solve_gmres; }
-
-  void start(const Vector& x_vec, const Vector& b_vec, const Operator<Vector>& lin_op,
-             const Preconditioner<Vector>* pre_op) {
-    const bool left_pre = (pre_op != nullptr) && (!Flexible) && (this->pre_side == PreconditionerSide::Left);
-    lin_op.Residual(_q_vecs[0], b_vec, x_vec);
-    if (left_pre) {
-      std::swap(_z_vecs[0], _q_vecs[0]);
-      pre_op->mul(_q_vecs[0], _z_vecs[0]);
-    }
-    _beta[0] = norm_2(_q_vecs[0]);
-    _q_vecs[0] /= _beta[0];
-  }
-
-  real_t outer_init(const Vector& x_vec, const Vector& b_vec, const Operator<Vector>& lin_op,
-                    const Preconditioner<Vector>* pre_op) override {
-    const std::size_t m = this->num_inner_iterations;
-    _beta.assign(m + 1, 0.0);
-    _cs.assign(m, 0.0), _sn.assign(m, 0.0);
-    _H.assign((m + 1) * m, 0.0);
-    _q_vecs.clear();
-    _q_vecs.resize(m + 1);
-    for (Vector& q_vec : _q_vecs) q_vec.assign(x_vec, false);
-    _z_vecs.clear();
-    if (pre_op != nullptr) {
-      _z_vecs.resize(Flexible ? m : 1);
-      for (Vector& z_vec : _z_vecs) z_vec.assign(x_vec, false);
-    }
-    start(x_vec, b_vec, lin_op, pre_op);
-    return _beta[0];
-  }
-
-  void inner_init(const Vector& x_vec, const Vector& b_vec, const Operator<Vector>& lin_op,
-                  const Preconditioner<Vector>* pre_op) override {
-    start(x_vec, b_vec, lin_op, pre_op);
-  }
-
-  real_t inner_iterate(Vector& /*x_vec*/, const Vector& /*b_vec*/, const Operator<Vector>& lin_op,
-                       const Preconditioner<Vector>* pre_op) override {
-    const std::size_t k = this->inner_iteration;
-    const bool left_pre = (pre_op != nullptr) && (!Flexible && (this->pre_side == PreconditionerSide::Left));
-    const bool right_pre = (pre_op != nullptr) && (Flexible || (this->pre_side == PreconditionerSide::Right));
-    if (left_pre) pre_op->mul(_q_vecs[k + 1], _z_vecs[0], lin_op, _q_vecs[k]);
-    else if (right_pre) lin_op.mul(_q_vecs[k + 1], _z_vecs[Flexible ? k : 0], *pre_op, _q_vecs[k]);
-    else lin_op.mul(_q_vecs[k + 1], _q_vecs[k]);
-    for (std::size_t i = 0; i <= k; ++i) {  // modified Gram-Schmidt
-      H(i, k) = dot_product(_q_vecs[k + 1], _q_vecs[i]);
-      _q_vecs[k + 1] -= H(i, k) * _q_vecs[i];
-    }
-    H(k + 1, k) = norm_2(_q_vecs[k + 1]);
-    _q_vecs[k + 1] /= H(k + 1, k);
-    for (std::size_t i = 0; i < k; ++i) {   // apply the stored rotations to the new column
-      const real_t chi = _cs[i] * H(i, k) + _sn[i] * H(i + 1, k);
-      H(i + 1, k) = -_sn[i] * H(i, k) + _cs[i] * H(i + 1, k);
-      H(i, k) = chi;
-    }
-    const auto rot = sym_ortho(H(k, k), H(k + 1, k));
-    _cs[k] = rot[0], _sn[k] = rot[1];
-    H(k, k) = _cs[k] * H(k, k) + _sn[k] * H(k + 1, k);
-    H(k + 1, k) = 0.0;
-    _beta[k + 1] = -_sn[k] * _beta[k];
-    _beta[k] *= _cs[k];
-    return std::abs(_beta[k + 1]);
-  }
-
-  void inner_finalize(Vector& x_vec, const Vector& /*b_vec*/, const Operator<Vector>& /*lin_op*/,
-                      const Preconditioner<Vector>* pre_op) override {
-    const std::size_t k = this->inner_iteration;
-    const bool right_pre = (pre_op != nullptr) && (Flexible || (this->pre_side == PreconditionerSide::Right));
-    for (std::size_t i = k; i != SIZE_MAX; --i) {  // back substitution
-      for (std::size_t j = i + 1; j <= k; ++j) _beta[i] -= H(i, j) * _beta[j];
-      _beta[i] /= H(i, i);
-    }
-    if (!right_pre) {
-      for (std::size_t i = 0; i <= k; ++i) x_vec += _beta[i] * _q_vecs[i];
-    } else if constexpr (Flexible) {
-      for (std::size_t i = 0; i <= k; ++i) x_vec += _beta[i] * _z_vecs[i];
-    } else {
-      _q_vecs[0] *= _beta[0];
-      for (std::size_t i = 1; i <= k; ++i) _q_vecs[0] += _beta[i] * _q_vecs[i];
-      pre_op->mul(_z_vecs[0], _q_vecs[0]);
-      x_vec += _z_vecs[0];
-    }
-  }
+  DeviceInnerOuterSolver() { this->num_inner_iterations = DefaultInner; }
 
 protected:
-  BaseGmresSolver() = default;
+  int device_method() const noexcept final { return Method; }
+  real_t outer_init(const Vector& x_vec, const Vector& b_vec, const Operator<Vector>& any_op,
+                    const Preconditioner<Vector>* pre_op) final {
+    this->_engine.bind(Method, x_vec, any_op, pre_op, this->pre_side);
+    this->configure(this->_engine.handle());
+    const storm_hip_solver_params p = this->params();
+    real_t initial_error = 0.0;
+    this->_engine.finish(storm_hip_krylov_init(this->_engine.handle(), b_vec.handle(), x_vec.handle(), &p, &initial_error));
+    return initial_error;
+  }
+  real_t inner_iterate(Vector&, const Vector&, const Operator<Vector>&, const Preconditioner<Vector>*) final {
+    real_t residual_norm = 0.0;
+    this->_engine.finish(storm_hip_krylov_iterate(this->_engine.handle(), &residual_norm));
+    return residual_norm;
+  }
+  void outer_finalize(Vector&, const Vector&, const Operator<Vector>&, const Preconditioner<Vector>*) final {
+    this->_engine.finish(storm_hip_krylov_finalize(this->_engine.handle()));
+  }
 };
 
-/// SolverGmres.hpp:281-283.
-template<class Vector>
-class GmresSolver final : public BaseGmresSolver<Vector, false> {};
+}  // namespace detail
 
-/// SolverGmres.hpp:306-308: keeps every preconditioned vector so the preconditioner may vary between
-/// iterations; without a preconditioner it is GMRES (and runs natively).
+/// SolverCg.hpp:47-128.
 template<class Vector>
-class FgmresSolver final : public BaseGmresSolver<Vector, true> {};
+class CgSolver final : public detail::DeviceIterativeSolver<Vector, STORM_HIP_CG> {};
+/// SolverBiCgStab.hpp:52-167.
+template<class Vector>
+class BiCgStabSolver final : public detail::DeviceIterativeSolver<Vector, STORM_HIP_BICGSTAB> {};
+/// SolverCgs.hpp:50-176.
+template<class Vector>
+class CgsSolver final : public detail::DeviceIterativeSolver<Vector, STORM_HIP_CGS> {};
+/// SolverTfqmr.hpp:227-240 / :252-265.
+template<class Vector>
+class TfqmrSolver final : public detail::DeviceIterativeSolver<Vector, STORM_HIP_TFQMR> {};
+template<class Vector>
+class Tfqmr1Solver final : public detail::DeviceIterativeSolver<Vector, STORM_HIP_TFQMR1> {};
+/// SolverRichardson.hpp:41-98.
+template<class Vector>
+class RichardsonSolver final : public detail::DeviceIterativeSolver<Vector, STORM_HIP_RICHARDSON> {
+public:
+  real_t relaxation_factor{1.0e-4};
+
+private:
+  void configure(storm_hip_krylov* k) const override {
+    detail::check(storm_hip_krylov_set_real(k, "relaxation_factor", relaxation_factor));
+  }
+};
+/// SolverGmres.hpp:281-283 (default restart 50, Solver.hpp:159).  `gram_schmidt = 1`: classical Gram-Schmidt x2.
+template<class Vector>
+class GmresSolver final : public detail::DeviceInnerOuterSolver<Vector, STORM_HIP_GMRES, 50> {
+public:
+  int gram_schmidt{0};
+
+private:
+  void fill_params(storm_hip_solver_params& p) const override {
+    p.num_inner_iterations = (int64_t)this->num_inner_iterations;
+    p.gram_schmidt = gram_schmidt;
+  }
+};
+/// SolverGmres.hpp:306-308: one preconditioned vector per inner iteration, so the preconditioner may vary.
+template<class Vector>
+class FgmresSolver final : public detail::DeviceInnerOuterSolver<Vector, STORM_HIP_FGMRES, 50> {};
+/// SolverBiCgStab.hpp:184-383; `num_inner_iterations` is l (default 2, :379-381).
+template<class Vector>
+class BiCgStabLSolver final : public detail::DeviceInnerOuterSolver<Vector, STORM_HIP_BICGSTAB_L, 2> {};
+/// SolverIdrs.hpp:52-291; `num_inner_iterations` is s (default 4, :287-289).
+template<class Vector>
+class IdrsSolver final : public detail::DeviceInnerOuterSolver<Vector, STORM_HIP_IDRS, 4> {};
 
 /// SolverNewton.hpp:55-72: declared but unimplemented in the reference (STORM_ABORT); here the same
 /// message arrives as an exception instead of std::abort().
 template<class Vector>
 class NewtonSolver : public IterativeSolver<Vector> {
-  real_t init(const Vector&, const Vector&, const Operator<Vector>&, const Preconditioner<Vector>*) final {
-    throw std::runtime_error("Newton solver is not implemented yet!");
+  [[noreturn]] static void unimplemented() { throw std::runtime_error("Newton solver is not implemented yet!"); }
+  real_t init(const Vector&, const Vector&, const Operator<Vector>&, const Preconditioner<Vector>*) override {
+    unimplemented();
   }
-  real_t iterate(Vector&, const Vector&, const Operator<Vector>&, const Preconditioner<Vector>*) final {
-    throw std::runtime_error("Newton solver is not implemented yet!");
+  real_t iterate(Vector&, const Vector&, const Operator<Vector>&, const Preconditioner<Vector>*) override {
+    unimplemented();
   }
 };
 
-/// SolverNewton.hpp:101-173: first-order Jacobian-free Newton-Krylov; `any_op` may be nonlinear.
-/// Each iteration solves J(x) t = r with a BiCGStab (1e-8 tolerances, :133-135) on the
-/// finite-difference Jacobian-vector product (A(x + delta y) - A(x)) / delta (:136-148).
+/// SolverNewton.hpp:101-173: first-order Jacobian-free Newton-Krylov; `any_op` may be nonlinear.  A user-level
+/// solver on the host loop: every Newton step solves J(x) t = r with a BiCgStabSolver at 1e-8 (:133-135) whose
+/// operator is the finite-difference product (A(x + delta y) - A(x)) / delta, delta = mu / |y| (:136-148).
 template<class Vector>
 class JfnkSolver final : public IterativeSolver<Vector> {
-private:
-  Vector _s_vec, _t_vec, _r_vec, _w_vec;
-
-  real_t init(const Vector& x_vec, const Vector& b_vec, const Operator<Vector>& any_op,
-              const Preconditioner<Vector>* /*pre_op*/) override {
-    _s_vec.assign(x_vec, false);
-    _t_vec.assign(x_vec, false);
-    _r_vec.assign(x_vec, false);
-    _w_vec.assign(x_vec, false);
-    inner_iterations = 0;
-    any_op.mul(_w_vec, x_vec);
-    _r_vec <<= b_vec - _w_vec;
-    return norm_2(_r_vec);
-  }
-
-  real_t iterate(Vector& x_vec, const Vector& b_vec, const Operator<Vector>& any_op,
-                 const Preconditioner<Vector>* /*pre_op*/) override {
-    static const real_t sqrt_of_epsilon = std::sqrt(std::numeric_limits<real_t>::epsilon());
-    const real_t mu = sqrt_of_epsilon * std::sqrt(1.0 + norm_2(x_vec));
-    _t_vec <<= _r_vec;
-    {
-      BiCgStabSolver<Vector> solver{};
-      solver.absolute_error_tolerance = 1.0e-8;
-      solver.relative_error_tolerance = 1.0e-8;
-      auto op = make_operator<Vector>([&](Vector& z_vec, const Vector& y_vec) {
-        const real_t delta = safe_divide(mu, norm_2(y_vec));
-        _s_vec <<= x_vec + delta * y_vec;
-        any_op.mul(z_vec, _s_vec);
-        const real_t delta_inverse = safe_divide(1.0, delta);
-        z_vec <<= delta_inverse * (z_vec - _w_vec);
-      });
-      solver.solve(_t_vec, _r_vec, *op);
-      inner_iterations += solver.iteration;
-    }
-    x_vec += _t_vec;
-    any_op.mul(_w_vec, x_vec);
-    _r_vec <<= b_vec - _w_vec;
-    return norm_2(_r_vec);
-  }
-
 public:
-  std::size_t inner_iterations{0};  ///< total BiCGStab iterations of the last solve (diagnostic)
+  std::size_t inner_iterations{0};
+
+private:
+  Vector _shifted, _step, _residual, _at_x;
+
+  real_t residual_of(const Vector& x_vec, const Vector& b_vec, const Operator<Vector>& any_op) {
+    any_op.mul(_at_x, x_vec);
+    _residual <<= b_vec - _at_x;
+    return norm_2(_residual);
+  }
+  real_t init(const Vector& x_vec, const Vector& b_vec, const Operator<Vector>& any_op,
+              const Preconditioner<Vector>*) override {
+    for (Vector* work : {&_shifted, &_step, &_residual, &_at_x}) work->assign(x_vec, false);
+    inner_iterations = 0;
+    return residual_of(x_vec, b_vec, any_op);
+  }
+  real_t iterate(Vector& x_vec, const Vector& b_vec, const Operator<Vector>& any_op,
+                 const Preconditioner<Vector>*) override {
+    const real_t mu = std::sqrt(std::numeric_limits<real_t>::epsilon()) * std::sqrt(1.0 + norm_2(x_vec));
+    const auto jacobian = make_operator<Vector>([&](Vector& z_vec, const Vector& y_vec) {
+      const real_t delta = safe_divide(mu, norm_2(y_vec));
+      _shifted <<= x_vec + delta * y_vec;
+      any_op.mul(z_vec, _shifted);
+      z_vec <<= safe_divide(1.0, delta) * (z_vec - _at_x);
+    });
+    BiCgStabSolver<Vector> inner;
+    inner.absolute_error_tolerance = inner.relative_error_tolerance = 1.0e-8;
+    _step <<= _residual;
+    inner.solve(_step, _residual, *jacobian);
+    inner_iterations += inner.iteration;
+    x_vec += _step;
+    return residual_of(x_vec, b_vec, any_op);
+  }
 };
 
 }  // namespace Storm

@@ -15,7 +15,11 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATHS = {"strict": os.path.join(_HERE, "liboracle.so"),
-              "fma": os.path.join(_HERE, "liboracle_fma.so")}
+              "fma": os.path.join(_HERE, "liboracle_fma.so"),
+              # investigation builds (make variants): reductions summed pairwise / in one long double
+              "pairwise": os.path.join(_HERE, "liboracle_pairwise.so"),
+              "longdouble": os.path.join(_HERE, "liboracle_longdouble.so")}
+_INVESTIGATION = ("pairwise", "longdouble")
 
 f64p = C.POINTER(C.c_double)
 i64p = C.POINTER(C.c_int64)
@@ -24,7 +28,7 @@ i64p = C.POINTER(C.c_int64)
 def build(force: bool = False) -> None:
     """Compile both oracle variants (strict: -ffp-contract=off; fma: contraction allowed)."""
     src = os.path.join(_HERE, "storm_oracle.c")
-    stale = [p for p in _LIB_PATHS.values()
+    stale = [p for k, p in _LIB_PATHS.items() if k not in _INVESTIGATION
              if force or not os.path.exists(p) or os.path.getmtime(p) < os.path.getmtime(src)]
     omp_so, omp_src = os.path.join(_HERE, "liboracle_omp.so"), os.path.join(_HERE, "storm_oracle_omp.c")
     if force or not os.path.exists(omp_so) or os.path.getmtime(omp_so) < os.path.getmtime(omp_src):
@@ -70,6 +74,8 @@ _libs = {}
 def lib(variant: str = "strict"):
     if variant not in _libs:
         build()
+        if variant in _INVESTIGATION and not os.path.exists(_LIB_PATHS[variant]):
+            subprocess.check_call(["make", "-C", _HERE, "variants"], stdout=subprocess.DEVNULL)
         L = _libs[variant] = C.CDLL(_LIB_PATHS[variant])
         L.oracle_safe_divide.restype = C.c_double
         L.oracle_safe_divide.argtypes = [C.c_double, C.c_double]

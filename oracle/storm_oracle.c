@@ -55,20 +55,54 @@ ORACLE_API void oracle_sym_ortho(double a, double b, double *cs, double *sn,
 /* source/Storm/Bittern/MatrixAlgorithms.hpp:58-81 (matrix_for_each, one     */
 /* sequential loop over rows; NumVars == 1 so cols == 1, Field.hpp:77-79).   */
 
-/* dot_product: MatrixAlgorithms.hpp:310-317 -> reduce :191-205, init 0.0,   */
-/* strictly sequential; real DotProduct = a * b (Crow/MathUtils.hpp:90-95).  */
-ORACLE_API double oracle_dot(int64_t n, const double *a, const double *b) {
+/* ORACLE_SUM_ORDER selects how the two reductions below add their n terms.   */
+/*   0 (every build the tests and the bench load): the reference's order --    */
+/*     init 0.0, strictly sequential, left to right;                           */
+/*   1, 2: INVESTIGATION builds only (oracle/Makefile `variants`, loaded by    */
+/*     tools/make_full_size_fixtures.py to measure how far a solver's          */
+/*     iteration count moves with the summation order and nothing else):       */
+/*     1 = pairwise tree over blocks of 256 (the shape of a GPU reduction),    */
+/*     2 = one 80-bit long double accumulator (a correctly rounded sum for     */
+/*         all practical purposes).                                            */
+#ifndef ORACLE_SUM_ORDER
+#define ORACLE_SUM_ORDER 0
+#endif
+#if ORACLE_SUM_ORDER == 1
+static double pairwise_products(int64_t n, const double *a, const double *b) {
+  if (n <= 256) {
+    double s = 0.0;
+    for (int64_t i = 0; i < n; ++i) s = s + a[i] * b[i];
+    return s;
+  }
+  const int64_t h = (n / 2 + 255) & ~(int64_t)255;
+  return pairwise_products(h, a, b) + pairwise_products(n - h, a + h, b + h);
+}
+#endif
+static double sum_of_products(int64_t n, const double *a, const double *b) {
+#if ORACLE_SUM_ORDER == 0
   double s = 0.0;
   for (int64_t i = 0; i < n; ++i) s = s + a[i] * b[i];
   return s;
+#elif ORACLE_SUM_ORDER == 1
+  return pairwise_products(n, a, b);
+#else
+  long double s = 0.0L;
+  for (int64_t i = 0; i < n; ++i) s = s + (long double)(a[i] * b[i]);
+  return (double)s;
+#endif
+}
+ORACLE_API int oracle_sum_order(void) { return ORACLE_SUM_ORDER; }
+
+/* dot_product: MatrixAlgorithms.hpp:310-317 -> reduce :191-205, init 0.0,   */
+/* strictly sequential; real DotProduct = a * b (Crow/MathUtils.hpp:90-95).  */
+ORACLE_API double oracle_dot(int64_t n, const double *a, const double *b) {
+  return sum_of_products(n, a, b);
 }
 
 /* norm_2: MatrixAlgorithms.hpp:262-270: sqrt(sum |a_i|^2), AbsSquared =     */
 /* real(a * conj(a)) (Crow/FunctionalUtils.hpp:488-496).                     */
 ORACLE_API double oracle_norm2(int64_t n, const double *a) {
-  double s = 0.0;
-  for (int64_t i = 0; i < n; ++i) s = s + a[i] * a[i];
-  return sqrt(s);
+  return sqrt(sum_of_products(n, a, a));
 }
 
 /* sum / norm_1 / norm_inf: MatrixAlgorithms.hpp:214-300 (used by the KATs). */

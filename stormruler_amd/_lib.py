@@ -52,6 +52,8 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int64),
                           C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double))
 
+APPLY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)  # storm_hip_apply_fn(user, y, x)
+
 # name -> (restype, argtypes); every symbol include/storm_hip.h declares.
 SIGNATURES = {
     "storm_hip_abi_version": (C.c_int, []),
@@ -75,6 +77,8 @@ SIGNATURES = {
     "storm_hip_vec_upload": (C.c_int, [vp, f64p, C.c_int64]),
     "storm_hip_vec_download": (C.c_int, [vp, f64p, C.c_int64]),
     "storm_hip_vec_device_ptr": (C.c_int, [vp, C.POINTER(vp)]),
+    "storm_hip_vec_context": (C.c_int, [vp, C.POINTER(vp)]),
+    "storm_hip_vec_get": (C.c_int, [vp, C.c_int64, f64p]),
     "storm_hip_fill": (C.c_int, [vp, C.c_double]),
     "storm_hip_copy": (C.c_int, [vp, vp]),
     "storm_hip_scale": (C.c_int, [vp, C.c_double]),
@@ -110,6 +114,17 @@ SIGNATURES = {
                                            C.POINTER(SolverResult), f64p]),
     "storm_hip_solve_gmres": (C.c_int, [vp, C.c_double, C.c_double, vp, vp, C.POINTER(SolverParams),
                                         C.POINTER(SolverResult), f64p]),
+    "storm_hip_krylov_create": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
+    "storm_hip_krylov_destroy": (C.c_int, [vp]),
+    "storm_hip_krylov_set_operator": (C.c_int, [vp, vp, C.c_double, C.c_double]),
+    "storm_hip_krylov_set_operator_fn": (C.c_int, [vp, APPLY_FN, vp]),
+    "storm_hip_krylov_set_preconditioner_fn": (C.c_int, [vp, APPLY_FN, vp, C.c_int]),
+    "storm_hip_krylov_set_preconditioner_diag": (C.c_int, [vp, vp, C.c_int]),
+    "storm_hip_krylov_set_real": (C.c_int, [vp, C.c_char_p, C.c_double]),
+    "storm_hip_krylov_solve": (C.c_int, [vp, vp, vp, C.POINTER(SolverParams), C.POINTER(SolverResult), f64p, i64p]),
+    "storm_hip_krylov_init": (C.c_int, [vp, vp, vp, C.POINTER(SolverParams), f64p]),
+    "storm_hip_krylov_iterate": (C.c_int, [vp, f64p]),
+    "storm_hip_krylov_finalize": (C.c_int, [vp]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():
@@ -117,7 +132,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-if lib.storm_hip_abi_version() != 1:
+if lib.storm_hip_abi_version() != 2:
     raise ImportError("libstorm_hip.so ABI version mismatch")
 
 

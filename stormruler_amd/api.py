@@ -12,10 +12,10 @@ written against ``Storm::``:
 
 Every vector statement a solver body executes (``x += alpha * p``, ``p <<= r + beta * p`` ...)
 lowers to exactly one C-ABI call; an expression form without a kernel raises instead of
-falling back to a host loop.  With a :class:`HipStencilOperator` and no preconditioner the
-solver classes hand the whole solve to the device-resident entry points
-(``storm_hip_solve_*``); with any other ``Operator`` (e.g. a Python lambda through
-``make_operator``) they run the reference's statement sequence over the BLAS-1 calls.
+falling back to a host loop.  The solver classes are knob holders: their loops run inside
+libstorm_hip.so (``storm_hip_krylov_*``, csrc/krylov.hip) for ANY operator -- a
+:class:`HipStencilOperator` binds natively, a Python lambda through ``make_operator`` as a callback
+that only enqueues its kernels -- with every scalar of the recurrences device-resident.
 """
 from __future__ import annotations
 
@@ -203,9 +203,20 @@ class DeviceVector:
     def shape(self):
         return (self.n_owned, 1)  # Field::shape() = {N, NumVars}, Field.hpp:77-79
 
+    @classmethod
+    def _borrow(cls, ctx: Context, handle) -> "DeviceVector":
+        """A non-owning view of a vector the library hands to an operator / preconditioner callback."""
+        v = cls()
+        v.ctx, v._h, v._owned = ctx, C.c_void_p(handle), False
+        n, nh = C.c_int64(), C.c_int64()
+        check(lib.storm_hip_vec_size(v._h, C.byref(n), C.byref(nh)))
+        v.n_owned, v.n_halo = n.value, nh.value
+        return v
+
     def _free(self):
         if getattr(self, "_h", None):
-            lib.storm_hip_vec_destroy(self._h)
+            if getattr(self, "_owned", True):
+                lib.storm_hip_vec_destroy(self._h)
             self._h = None
 
     def __del__(self):  # pragma: no cover
@@ -585,10 +596,74 @@ class Solver:  # Solver.hpp:43-57
         raise NotImplementedError
 
 
-class IterativeSolver(Solver):
-    """Solver.hpp:62-149 -- same public knobs, defaults and convergence rule."""
+class _Engine:
+    """One ``storm_hip_krylov`` object (the library's device-resident solver loops, csrc/krylov.hip) with the
+    reference-side objects bound to it: a :class:`HipStencilOperator` binds natively, any other ``Operator`` --
+    e.g. a lambda through ``make_operator``, the reference's only call site (Playground.cpp:151-167) -- as a
+    callback that merely enqueues its kernels; likewise ``pre_op`` (a :class:`JacobiPreconditioner` binds as a
+    device diagonal).  An exception raised inside a callback aborts the solve and is re-raised from it."""
 
-    _native = None  # name of the whole-solver C entry point, if any
+    def __init__(self, ctx: Context, method: int):
+        h = C.c_void_p()
+        check(lib.storm_hip_krylov_create(ctx._h, method, C.byref(h)))
+        self.ctx, self._h, self._keep, self._error = ctx, h, [], None
+        ctx._children.add(self)
+
+    def _free(self):
+        if getattr(self, "_h", None):
+            lib.storm_hip_krylov_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self._free()
+        except Exception:
+            pass
+
+    def _callback(self, fn):
+        def trampoline(_user, y_handle, x_handle):
+            try:
+                fn(DeviceVector._borrow(self.ctx, y_handle), DeviceVector._borrow(self.ctx, x_handle))
+                return 0
+            except BaseException as e:  # never unwind through the C frames
+                self._error = e
+                return 1
+
+        cb = _lib.APPLY_FN(trampoline)
+        self._keep.append(cb)
+        return cb
+
+    def bind(self, any_op: Operator, pre_op, pre_side: int) -> None:
+        self._keep, self._error = [], None
+        if isinstance(any_op, HipStencilOperator):
+            check(lib.storm_hip_krylov_set_operator(self._h, any_op.matrix._h, any_op.alpha, any_op.beta))
+        else:
+            check(lib.storm_hip_krylov_set_operator_fn(self._h, self._callback(any_op.mul), None))
+        if pre_op is None:
+            check(lib.storm_hip_krylov_set_preconditioner_diag(self._h, None, int(pre_side)))
+        elif isinstance(pre_op, JacobiPreconditioner):
+            check(lib.storm_hip_krylov_set_preconditioner_diag(self._h, pre_op._dinv._h, int(pre_side)))
+        else:
+            check(lib.storm_hip_krylov_set_preconditioner_fn(self._h, self._callback(pre_op.mul), None, int(pre_side)))
+
+    def call(self, status: int) -> None:
+        err, self._error = self._error, None
+        if err is not None:
+            raise err
+        check(status)
+
+
+class IterativeSolver(Solver):
+    """Solver.hpp:62-149 -- same public knobs, defaults and convergence rule.
+
+    The solvers this module ships set ``_method`` and run inside libstorm_hip.so (``storm_hip_krylov_solve``):
+    the loop of Solver.hpp:132-140 is evaluated on the device, the host never waits for a scalar.  Their
+    ``init`` / ``iterate`` / ``finalize`` -- the reference's protected stepping interface (:78-111) -- go
+    through ``storm_hip_krylov_init / _iterate / _finalize`` (one host wait per call); ``device_loop = False``
+    makes ``solve`` run the reference's host loop over them.  A subclass that sets no ``_method`` and
+    overrides the three hooks gets that host loop as well."""
+
+    _method: Optional[int] = None
 
     def __init__(self):
         self.iteration = 0
@@ -604,18 +679,34 @@ class IterativeSolver(Solver):
         self.check_lag = 0
         self.record_history = False
         self.history: Optional[np.ndarray] = None
-        self.num_applies = 0
+        self.num_applies = 0        # operator applications of the last solve (logical: what the reference does)
+        self.num_pre_applies = 0    # preconditioner applications, likewise
         self.initial_error = 0.0
+        self.device_loop = True
+        self._engine: Optional[_Engine] = None
 
+    # -- the reference's stepping hooks ------------------------------------------------------
     def init(self, x_vec, b_vec, any_op, pre_op) -> float:
-        raise NotImplementedError
+        if self._method is None:
+            raise NotImplementedError
+        eng = self._bound_engine(x_vec, any_op, pre_op)
+        err = C.c_double()
+        p = self._params()
+        eng.call(lib.storm_hip_krylov_init(eng._h, b_vec._h, x_vec._h, C.byref(p), C.byref(err)))
+        return err.value
 
     def iterate(self, x_vec, b_vec, any_op, pre_op) -> float:
-        raise NotImplementedError
+        if self._method is None:
+            raise NotImplementedError
+        err = C.c_double()
+        self._engine.call(lib.storm_hip_krylov_iterate(self._engine._h, C.byref(err)))
+        return err.value
 
     def finalize(self, x_vec, b_vec, any_op, pre_op) -> None:
-        pass
+        if self._method is not None:
+            self._engine.call(lib.storm_hip_krylov_finalize(self._engine._h))
 
+    # -- plumbing ------------------------------------------------------------------------------
     def _params(self) -> _lib.SolverParams:
         p = _lib.SolverParams()
         lib.storm_hip_solver_params_default(C.byref(p))
@@ -623,21 +714,19 @@ class IterativeSolver(Solver):
         p.absolute_error_tolerance = self.absolute_error_tolerance
         p.relative_error_tolerance = self.relative_error_tolerance
         p.check_lag = self.check_lag
+        p.num_inner_iterations = int(getattr(self, "num_inner_iterations", 0))
+        p.gram_schmidt = int(getattr(self, "gram_schmidt", 0))
         return p
 
-    def _solve_native(self, x_vec, b_vec, op: HipStencilOperator) -> bool:
-        p = self._params()
-        r = _lib.SolverResult()
-        hist = np.zeros(self.num_iterations + 1) if self.record_history else None
-        fn = getattr(lib, self._native)
-        check(fn(op.matrix._h, op.alpha, op.beta, b_vec._h, x_vec._h, C.byref(p), C.byref(r),
-                 None if hist is None else hist.ctypes.data_as(_lib.f64p)))
-        self.iteration = r.iterations
-        self.absolute_error, self.relative_error = r.absolute_error, r.relative_error
-        self.initial_error, self.num_applies = r.initial_error, r.num_applies
-        self.history = None if hist is None else hist[: r.iterations + 1]
-        self._log()
-        return bool(r.converged)
+    def _configure(self, eng: _Engine) -> None:
+        pass
+
+    def _bound_engine(self, x_vec, any_op, pre_op) -> _Engine:
+        if self._engine is None or self._engine.ctx is not x_vec.ctx or self._engine._h is None:
+            self._engine = _Engine(x_vec.ctx, self._method)
+        self._engine.bind(any_op, pre_op, self.pre_side)
+        self._configure(self._engine)
+        return self._engine
 
     def _log(self) -> None:
         """The reference's one line per solve (`STORM_INFO`, Solver.hpp:144-145) on the logger
@@ -645,45 +734,52 @@ class IterativeSolver(Solver):
         _LOG.info("n_iter: %4d, abs_err: %-12e, rel_err: %-12e", self.iteration, self.absolute_error, self.relative_error)
 
     def solve(self, x_vec, b_vec, any_op) -> bool:  # Solver.hpp:116-147
-        if self._native and isinstance(any_op, HipStencilOperator) and self.pre_op is None:
-            return self._solve_native(x_vec, b_vec, any_op)
         if self.pre_op is not None:
             self.pre_op.build(x_vec, b_vec, any_op)
+        if self._method is not None and self.device_loop:
+            eng = self._bound_engine(x_vec, any_op, self.pre_op)
+            p, r, n_pre = self._params(), _lib.SolverResult(), C.c_int64()
+            hist = np.zeros(self.num_iterations + 1) if self.record_history else None
+            eng.call(lib.storm_hip_krylov_solve(eng._h, b_vec._h, x_vec._h, C.byref(p), C.byref(r),
+                                                None if hist is None else hist.ctypes.data_as(_lib.f64p),
+                                                C.byref(n_pre)))
+            self.iteration = r.iterations
+            self.absolute_error, self.relative_error = r.absolute_error, r.relative_error
+            self.initial_error, self.num_applies, self.num_pre_applies = r.initial_error, r.num_applies, n_pre.value
+            self.history = None if hist is None else hist[: r.iterations + 1]
+            self._log()
+            return bool(r.converged)
+        # the host loop: user-defined solvers, and the shipped ones stepwise when device_loop is off
         initial_error = self.init(x_vec, b_vec, any_op, self.pre_op)
-        self.initial_error = initial_error
-        self.absolute_error = initial_error
+        self.initial_error = self.absolute_error = initial_error
         hist = [initial_error]
-        if self.absolute_error_tolerance > 0.0 and self.absolute_error < self.absolute_error_tolerance:
-            self.finalize(x_vec, b_vec, any_op, self.pre_op)
-            self.history = np.array(hist)
-            return True
-        converged = False
         self.iteration = 0
-        while (not converged) and self.iteration < self.num_iterations:
+        converged = self.absolute_error_tolerance > 0.0 and initial_error < self.absolute_error_tolerance
+        early = converged
+        while not converged and self.iteration < self.num_iterations:
             self.absolute_error = self.iterate(x_vec, b_vec, any_op, self.pre_op)
             self.relative_error = self.absolute_error / initial_error
             hist.append(self.absolute_error)
-            converged |= (self.absolute_error_tolerance > 0.0) and (self.absolute_error < self.absolute_error_tolerance)
-            converged |= (self.relative_error_tolerance > 0.0) and (self.relative_error < self.relative_error_tolerance)
+            converged = ((self.absolute_error_tolerance > 0.0 and self.absolute_error < self.absolute_error_tolerance)
+                         or (self.relative_error_tolerance > 0.0 and self.relative_error < self.relative_error_tolerance))
             self.iteration += 1
         self.finalize(x_vec, b_vec, any_op, self.pre_op)
         self.history = np.array(hist)
-        self._log()
-        return converged
+        if not early:
+            self._log()
+        return bool(converged)
 
 
 class InnerOuterIterativeSolver(IterativeSolver):
-    """Solver.hpp:154-259."""
+    """Solver.hpp:154-259: ``num_inner_iterations`` (default 50) and the restart bookkeeping.  For the shipped
+    solvers that bookkeeping (``iteration % num_inner_iterations``, inner_init at 0, inner_finalize at the end
+    of a cycle and once more on exit) runs inside the library; a user-defined subclass implements the five
+    ``outer_* / inner_*`` hooks and gets it from here."""
 
     def __init__(self):
         super().__init__()
         self.inner_iteration = 0
         self.num_inner_iterations = 50
-
-    def _params(self):
-        p = super()._params()
-        p.num_inner_iterations = self.num_inner_iterations
-        return p
 
     def outer_init(self, x_vec, b_vec, any_op, pre_op) -> float:
         raise NotImplementedError
@@ -700,365 +796,114 @@ class InnerOuterIterativeSolver(IterativeSolver):
     def outer_finalize(self, x_vec, b_vec, any_op, pre_op) -> None:
         pass
 
-    def init(self, x_vec, b_vec, any_op, pre_op):  # :230-234
+    def init(self, x_vec, b_vec, any_op, pre_op):
+        if self._method is not None:
+            return super().init(x_vec, b_vec, any_op, pre_op)
         return self.outer_init(x_vec, b_vec, any_op, pre_op)
 
-    def iterate(self, x_vec, b_vec, any_op, pre_op):  # :236-248
+    def iterate(self, x_vec, b_vec, any_op, pre_op):
         self.inner_iteration = self.iteration % self.num_inner_iterations
+        if self._method is not None:
+            return super().iterate(x_vec, b_vec, any_op, pre_op)
+        last = self.inner_iteration == self.num_inner_iterations - 1
         if self.inner_iteration == 0:
             self.inner_init(x_vec, b_vec, any_op, pre_op)
         residual_norm = self.inner_iterate(x_vec, b_vec, any_op, pre_op)
-        if self.inner_iteration == self.num_inner_iterations - 1:
+        if last:
             self.inner_finalize(x_vec, b_vec, any_op, pre_op)
         return residual_norm
 
-    def finalize(self, x_vec, b_vec, any_op, pre_op):  # :250-257
+    def finalize(self, x_vec, b_vec, any_op, pre_op):
+        if self._method is not None:
+            return super().finalize(x_vec, b_vec, any_op, pre_op)
         if self.inner_iteration != self.num_inner_iterations - 1:
             self.inner_finalize(x_vec, b_vec, any_op, pre_op)
         self.outer_finalize(x_vec, b_vec, any_op, pre_op)
 
 
+# The shipped solvers: a method id each; their loops are csrc/krylov.hip (and, for a stencil operator without
+# preconditioner, the fused kernels of csrc/solvers.hip).
 class CgSolver(IterativeSolver):
     """SolverCg.hpp:47-128."""
 
-    _native = "storm_hip_solve_cg"
-
-    def init(self, x_vec, b_vec, lin_op, pre_op):  # :54-84
-        self._p_vec, self._r_vec, self._z_vec = DeviceVector(), DeviceVector(), DeviceVector()
-        self._p_vec.assign(x_vec, False)
-        self._r_vec.assign(x_vec, False)
-        self._z_vec.assign(x_vec, False)
-        lin_op.Residual(self._r_vec, b_vec, x_vec)
-        if pre_op is not None:
-            pre_op.mul(self._z_vec, self._r_vec)
-            self._p_vec <<= self._z_vec
-            self._gamma = dot_product(self._r_vec, self._z_vec)
-        else:
-            self._p_vec <<= self._r_vec
-            self._gamma = dot_product(self._r_vec, self._r_vec)
-        return norm_2(self._r_vec) if pre_op is not None else math.sqrt(self._gamma)
-
-    def iterate(self, x_vec, b_vec, lin_op, pre_op):  # :86-126
-        lin_op.mul(self._z_vec, self._p_vec)
-        alpha = safe_divide(self._gamma, dot_product(self._p_vec, self._z_vec))
-        x_vec += alpha * self._p_vec
-        self._r_vec -= alpha * self._z_vec
-        gamma_bar = self._gamma
-        if pre_op is not None:
-            pre_op.mul(self._z_vec, self._r_vec)
-            self._gamma = dot_product(self._r_vec, self._z_vec)
-        else:
-            self._gamma = dot_product(self._r_vec, self._r_vec)
-        beta = safe_divide(self._gamma, gamma_bar)
-        self._p_vec <<= (self._z_vec if pre_op is not None else self._r_vec) + beta * self._p_vec
-        return norm_2(self._r_vec) if pre_op is not None else math.sqrt(self._gamma)
+    _method = 0  # STORM_HIP_CG
 
 
 class BiCgStabSolver(IterativeSolver):
-    """SolverBiCgStab.hpp:52-167 (unpreconditioned and right/left preconditioned branches)."""
+    """SolverBiCgStab.hpp:52-167 (unpreconditioned and left / right preconditioned branches)."""
 
-    _native = "storm_hip_solve_bicgstab"
-
-    def init(self, x_vec, b_vec, lin_op, pre_op):  # :59-91
-        left_pre = pre_op is not None and self.pre_side == PreconditionerSide.Left
-        names = ["_p_vec", "_r_vec", "_r_tilde_vec", "_t_vec", "_v_vec"] + (["_z_vec"] if pre_op is not None else [])
-        for nme in names:
-            v = DeviceVector()
-            v.assign(x_vec, False)
-            setattr(self, nme, v)
-        lin_op.Residual(self._r_vec, b_vec, x_vec)
-        if left_pre:
-            self._z_vec, self._r_vec = self._r_vec, self._z_vec
-            pre_op.mul(self._r_vec, self._z_vec)
-        self._r_tilde_vec <<= self._r_vec
-        self._rho = dot_product(self._r_tilde_vec, self._r_vec)
-        self._alpha = self._omega = 0.0
-        return math.sqrt(self._rho)
-
-    def iterate(self, x_vec, b_vec, lin_op, pre_op):  # :93-165
-        left_pre = pre_op is not None and self.pre_side == PreconditionerSide.Left
-        right_pre = pre_op is not None and self.pre_side == PreconditionerSide.Right
-        if self.iteration == 0:
-            self._p_vec <<= self._r_vec
-        else:
-            rho_bar, self._rho = self._rho, dot_product(self._r_tilde_vec, self._r_vec)
-            beta = safe_divide(self._alpha * self._rho, self._omega * rho_bar)
-            self._p_vec <<= self._r_vec + beta * (self._p_vec - self._omega * self._v_vec)
-        if left_pre:
-            pre_op.mul_chain(self._v_vec, self._z_vec, lin_op, self._p_vec)
-        elif right_pre:
-            lin_op.mul_chain(self._v_vec, self._z_vec, pre_op, self._p_vec)
-        else:
-            lin_op.mul(self._v_vec, self._p_vec)
-        self._alpha = safe_divide(self._rho, dot_product(self._r_tilde_vec, self._v_vec))
-        x_vec += self._alpha * (self._z_vec if right_pre else self._p_vec)
-        self._r_vec -= self._alpha * self._v_vec
-        if left_pre:
-            pre_op.mul_chain(self._t_vec, self._z_vec, lin_op, self._r_vec)
-        elif right_pre:
-            lin_op.mul_chain(self._t_vec, self._z_vec, pre_op, self._r_vec)
-        else:
-            lin_op.mul(self._t_vec, self._r_vec)
-        self._omega = safe_divide(dot_product(self._t_vec, self._r_vec), dot_product(self._t_vec, self._t_vec))
-        x_vec += self._omega * (self._z_vec if right_pre else self._r_vec)
-        self._r_vec -= self._omega * self._t_vec
-        return norm_2(self._r_vec)
+    _method = 1  # STORM_HIP_BICGSTAB
 
 
 class GmresSolver(InnerOuterIterativeSolver):
-    """SolverGmres.hpp:41-255 (``BaseGmresSolver<Vector, Flexible>``): the unpreconditioned branches run
-    natively on the device; with a ``pre_op`` the statement-level path below takes the reference's
-    left / right (``Flexible = false``) or flexible (always right, :98-99) branches."""
+    """SolverGmres.hpp:41-255, :281-283.  ``gram_schmidt = 1`` switches the orthogonalisation from the
+    reference's modified Gram-Schmidt to classical Gram-Schmidt applied twice (batched reductions)."""
 
-    _native = "storm_hip_solve_gmres"
-    _flexible = False
+    _method = 2  # STORM_HIP_GMRES
 
     def __init__(self):
         super().__init__()
-        self.gram_schmidt = 0  # 0: modified (reference); 1: classical x2 (batched reductions)
+        self.gram_schmidt = 0
 
-    def _params(self):
-        p = super()._params()
-        p.gram_schmidt = self.gram_schmidt
-        return p
 
-    def _left_pre(self, pre_op) -> bool:
-        return pre_op is not None and not self._flexible and self.pre_side == PreconditionerSide.Left
+class FgmresSolver(GmresSolver):
+    """SolverGmres.hpp:306-308: flexible GMRES -- keeps every preconditioned vector z_k so the preconditioner
+    may change between iterations; right preconditioning only."""
 
-    def _right_pre(self, pre_op) -> bool:
-        return pre_op is not None and (self._flexible or self.pre_side == PreconditionerSide.Right)
+    _method = 3  # STORM_HIP_FGMRES
 
-    def _start(self, x_vec, b_vec, lin_op, pre_op):  # :66-90 == :93-117
-        q, z = self._q_vecs, self._z_vecs
-        lin_op.Residual(q[0], b_vec, x_vec)
-        if self._left_pre(pre_op):
-            z[0], q[0] = q[0], z[0]
-            pre_op.mul(q[0], z[0])
-        self._beta[0] = norm_2(q[0])
-        q[0] /= self._beta[0]
 
-    def outer_init(self, x_vec, b_vec, lin_op, pre_op):  # :51-91
-        m = self.num_inner_iterations
-        self._beta = np.zeros(m + 1)
-        self._cs, self._sn = np.zeros(m), np.zeros(m)
-        self._H = np.zeros((m + 1, m))
-        self._q_vecs: List[DeviceVector] = [_like(x_vec) for _ in range(m + 1)]
-        self._z_vecs: List[DeviceVector] = []
-        if pre_op is not None:  # :62-65
-            self._z_vecs = [_like(x_vec) for _ in range(m if self._flexible else 1)]
-        self._start(x_vec, b_vec, lin_op, pre_op)
-        return self._beta[0]
+class CgsSolver(IterativeSolver):
+    """SolverCgs.hpp:50-176."""
 
-    def inner_init(self, x_vec, b_vec, lin_op, pre_op):  # :93-117
-        self._start(x_vec, b_vec, lin_op, pre_op)
+    _method = 4  # STORM_HIP_CGS
 
-    def inner_iterate(self, x_vec, b_vec, lin_op, pre_op):  # :119-192
-        k, H, q, z = self.inner_iteration, self._H, self._q_vecs, self._z_vecs
-        if self._left_pre(pre_op):  # :148-149
-            pre_op.mul_chain(q[k + 1], z[0], lin_op, q[k])
-        elif self._right_pre(pre_op):  # :150-152
-            j = k if self._flexible else 0
-            lin_op.mul_chain(q[k + 1], z[j], pre_op, q[k])
-        else:
-            lin_op.mul(q[k + 1], q[k])
-        for i in range(k + 1):
-            H[i, k] = dot_product(q[k + 1], q[i])
-            q[k + 1] -= H[i, k] * q[i]
-        H[k + 1, k] = norm_2(q[k + 1])
-        q[k + 1] /= H[k + 1, k]
-        cs, sn, beta = self._cs, self._sn, self._beta
-        for i in range(k):
-            chi = cs[i] * H[i, k] + sn[i] * H[i + 1, k]
-            H[i + 1, k] = -sn[i] * H[i, k] + cs[i] * H[i + 1, k]
-            H[i, k] = chi
-        cs[k], sn[k], _ = sym_ortho(H[k, k], H[k + 1, k])
-        H[k, k] = cs[k] * H[k, k] + sn[k] * H[k + 1, k]
-        H[k + 1, k] = 0.0
-        beta[k + 1] = -sn[k] * beta[k]
-        beta[k] *= cs[k]
-        return abs(beta[k + 1])
 
-    def inner_finalize(self, x_vec, b_vec, lin_op, pre_op):  # :194-249
-        k, H, beta, q, z = self.inner_iteration, self._H, self._beta, self._q_vecs, self._z_vecs
-        for i in range(k, -1, -1):
-            for j in range(i + 1, k + 1):
-                beta[i] -= H[i, j] * beta[j]
-            beta[i] /= H[i, i]
-        if not self._right_pre(pre_op):  # :233-236
-            for i in range(k + 1):
-                x_vec += beta[i] * q[i]
-        elif self._flexible:  # :237-240
-            for i in range(k + 1):
-                x_vec += beta[i] * z[i]
-        else:  # :241-247
-            q[0] *= beta[0]
-            for i in range(1, k + 1):
-                q[0] += beta[i] * q[i]
-            pre_op.mul(z[0], q[0])
-            x_vec += z[0]
+class TfqmrSolver(IterativeSolver):
+    """SolverTfqmr.hpp:227-240 (L2 quasi-minimisation)."""
+
+    _method = 5  # STORM_HIP_TFQMR
+
+
+class Tfqmr1Solver(IterativeSolver):
+    """SolverTfqmr.hpp:252-265 (L1 variant)."""
+
+    _method = 6  # STORM_HIP_TFQMR1
+
+
+class BiCgStabLSolver(InnerOuterIterativeSolver):
+    """SolverBiCgStab.hpp:184-383; ``num_inner_iterations`` is l (default 2).  A preconditioner is always
+    applied on the left, whatever ``pre_side`` says (:226-229, :273-274, :292-293)."""
+
+    _method = 7  # STORM_HIP_BICGSTAB_L
+
+    def __init__(self):
+        super().__init__()
+        self.num_inner_iterations = 2  # :379-381
+
+
+class IdrsSolver(InnerOuterIterativeSolver):
+    """SolverIdrs.hpp:52-291; ``num_inner_iterations`` is s (default 4).  The shadow space comes from
+    ``fill_randomly`` (the reference's engine and sequence; ``rng_reset()`` = a fresh process)."""
+
+    _method = 8  # STORM_HIP_IDRS
+
+    def __init__(self):
+        super().__init__()
+        self.num_inner_iterations = 4  # :287-289
 
 
 class RichardsonSolver(IterativeSolver):
-    """SolverRichardson.hpp:41-98 (x += omega r with the fixed ``relaxation_factor``)."""
+    """SolverRichardson.hpp:41-98."""
+
+    _method = 9  # STORM_HIP_RICHARDSON
 
     def __init__(self):
         super().__init__()
         self.relaxation_factor = 1.0e-4  # :45
 
-    def _apply_pre(self, pre_op):
-        if pre_op is not None:
-            self._z_vec, self._r_vec = self._r_vec, self._z_vec
-            pre_op.mul(self._r_vec, self._z_vec)
-
-    def init(self, x_vec, b_vec, lin_op, pre_op):
-        self._r_vec, self._z_vec = DeviceVector(), DeviceVector()
-        self._r_vec.assign(x_vec, False)
-        if pre_op is not None:
-            self._z_vec.assign(x_vec, False)
-        lin_op.Residual(self._r_vec, b_vec, x_vec)
-        self._apply_pre(pre_op)
-        return norm_2(self._r_vec)
-
-    def iterate(self, x_vec, b_vec, lin_op, pre_op):
-        x_vec += self.relaxation_factor * self._r_vec
-        lin_op.Residual(self._r_vec, b_vec, x_vec)
-        self._apply_pre(pre_op)
-        return norm_2(self._r_vec)
-
-
-def _side_mul(solver, pre_op, lin_op, z_vec, y_vec, x_vec) -> None:
-    """The three-way dispatch every preconditioned solver body repeats (e.g. SolverBiCgStab.hpp:134-137):
-    left ``z = P(y = A x)``, right ``z = A(y = P x)``, otherwise ``z = A x``."""
-    if pre_op is not None and solver.pre_side == PreconditionerSide.Left:
-        pre_op.mul_chain(z_vec, y_vec, lin_op, x_vec)
-    elif pre_op is not None and solver.pre_side == PreconditionerSide.Right:
-        lin_op.mul_chain(z_vec, y_vec, pre_op, x_vec)
-    else:
-        lin_op.mul(z_vec, x_vec)
-
-
-class CgsSolver(IterativeSolver):
-    """SolverCgs.hpp:50-176 (unpreconditioned, left and right preconditioned branches)."""
-
-    def init(self, x_vec, b_vec, lin_op, pre_op):  # :57-90
-        left_pre = pre_op is not None and self.pre_side == PreconditionerSide.Left
-        for nme in ("_p_vec", "_q_vec", "_r_vec", "_r_tilde_vec", "_u_vec", "_v_vec"):
-            setattr(self, nme, _like(x_vec))
-        lin_op.Residual(self._r_vec, b_vec, x_vec)
-        if left_pre:  # :81-84
-            self._u_vec, self._r_vec = self._r_vec, self._u_vec
-            pre_op.mul(self._r_vec, self._u_vec)
-        self._r_tilde_vec <<= self._r_vec
-        self._rho = dot_product(self._r_tilde_vec, self._r_vec)
-        return math.sqrt(self._rho)
-
-    def iterate(self, x_vec, b_vec, lin_op, pre_op):  # :92-174
-        left_pre = pre_op is not None and self.pre_side == PreconditionerSide.Left
-        right_pre = pre_op is not None and self.pre_side == PreconditionerSide.Right
-        p, q, r, u, v = self._p_vec, self._q_vec, self._r_vec, self._u_vec, self._v_vec
-        if self.iteration == 0:
-            u <<= r
-            p <<= u
-        else:
-            rho_bar, self._rho = self._rho, dot_product(self._r_tilde_vec, r)
-            beta = safe_divide(self._rho, rho_bar)
-            u <<= r + beta * q
-            p <<= u + beta * (q + beta * p)
-        _side_mul(self, pre_op, lin_op, v, q, p)  # :137-139
-        alpha = safe_divide(self._rho, dot_product(self._r_tilde_vec, v))
-        q <<= u - alpha * v
-        v <<= u + q
-        if left_pre:  # :159-162
-            x_vec += alpha * v
-            pre_op.mul_chain(v, u, lin_op, v)
-            r -= alpha * v
-        elif right_pre:  # :163-166
-            lin_op.mul_chain(v, u, pre_op, v)
-            x_vec += alpha * u
-            r -= alpha * v
-        else:  # :167-169
-            lin_op.mul(u, v)
-            x_vec += alpha * v
-            r -= alpha * u
-        return norm_2(r)
-
-
-class _BaseTfqmrSolver(IterativeSolver):
-    """SolverTfqmr.hpp:37-206 (unpreconditioned, left and right preconditioned); ``_L1`` selects TFQMR1."""
-
-    _L1 = False
-
-    def init(self, x_vec, b_vec, lin_op, pre_op):  # :45-88
-        left_pre = pre_op is not None and self.pre_side == PreconditionerSide.Left
-        for nme in ("_d_vec", "_r_tilde_vec", "_u_vec", "_v_vec", "_y_vec", "_s_vec"):
-            setattr(self, nme, _like(x_vec))
-        self._z_vec = _like(x_vec) if pre_op is not None else None
-        if self._L1:
-            self._d_vec <<= x_vec
-        else:
-            fill_with(self._d_vec, 0.0)
-        lin_op.Residual(self._y_vec, b_vec, x_vec)
-        if left_pre:  # :79-82
-            self._z_vec, self._y_vec = self._y_vec, self._z_vec
-            pre_op.mul(self._y_vec, self._z_vec)
-        self._u_vec <<= self._y_vec
-        self._r_tilde_vec <<= self._u_vec
-        self._rho = dot_product(self._r_tilde_vec, self._u_vec)
-        self._tau = math.sqrt(self._rho)
-        return self._tau
-
-    def iterate(self, x_vec, b_vec, lin_op, pre_op):  # :90-206
-        right_pre = pre_op is not None and self.pre_side == PreconditionerSide.Right
-        d, u, v, y, s, z = self._d_vec, self._u_vec, self._v_vec, self._y_vec, self._s_vec, self._z_vec
-        if self.iteration == 0:
-            _side_mul(self, pre_op, lin_op, s, z, y)
-            v <<= s
-        else:
-            rho_bar, self._rho = self._rho, dot_product(self._r_tilde_vec, u)
-            beta = safe_divide(self._rho, rho_bar)
-            v <<= s + beta * v
-            y <<= u + beta * y
-            _side_mul(self, pre_op, lin_op, s, z, y)
-            v <<= s + beta * v
-        alpha = safe_divide(self._rho, dot_product(self._r_tilde_vec, v))
-        for m in range(2):
-            u -= alpha * s
-            d += alpha * (z if right_pre else y)  # :169
-            omega = norm_2(u)
-            if self._L1:
-                if omega < self._tau:
-                    self._tau = omega
-                    x_vec <<= d
-            else:
-                cs, sn, _ = sym_ortho(self._tau, omega)
-                self._tau = omega * cs
-                x_vec += (cs ** 2) * d
-                d *= sn ** 2
-            if m == 0:
-                y -= alpha * v
-                _side_mul(self, pre_op, lin_op, s, z, y)
-        tau_tilde = self._tau
-        if not self._L1:
-            tau_tilde *= math.sqrt(2.0 * self.iteration + 3.0)
-        return tau_tilde
-
-
-class TfqmrSolver(_BaseTfqmrSolver):
-    """SolverTfqmr.hpp:235-237."""
-
-
-class Tfqmr1Solver(_BaseTfqmrSolver):
-    """SolverTfqmr.hpp:262-264."""
-
-    _L1 = True
-
-
-class FgmresSolver(GmresSolver):
-    """SolverGmres.hpp:306-308: flexible GMRES -- keeps every preconditioned vector z_k so the
-    preconditioner may change between iterations; right preconditioning only.  Without a
-    preconditioner it is GMRES and runs natively."""
-
-    _flexible = True
+    def _configure(self, eng: _Engine) -> None:
+        check(lib.storm_hip_krylov_set_real(eng._h, b"relaxation_factor", float(self.relaxation_factor)))
 
 
 class NewtonSolver(IterativeSolver):
@@ -1072,199 +917,44 @@ class NewtonSolver(IterativeSolver):
 
 
 class JfnkSolver(IterativeSolver):
-    """SolverNewton.hpp:101-173: first-order Jacobian-free Newton-Krylov.  ``any_op`` may be nonlinear;
-    each iteration solves ``J(x) t = r`` with a BiCGStab (1e-8 tolerances, :133-135) on the
-    finite-difference Jacobian-vector product ``(A(x + delta y) - A(x)) / delta`` (:136-148)."""
+    """SolverNewton.hpp:101-173: first-order Jacobian-free Newton-Krylov.  ``any_op`` may be nonlinear.  A
+    user-level solver on the host loop above: every Newton step solves ``J(x) t = r`` with a
+    :class:`BiCgStabSolver` at 1e-8 (:133-135) whose operator is the finite-difference product
+    ``(A(x + delta y) - A(x)) / delta``, ``delta = mu / |y|`` (:136-148)."""
+
+    def _linearised_at(self, x_vec, any_op) -> "FunctionalOperator":
+        mu = math.sqrt(np.finfo(np.float64).eps) * math.sqrt(1.0 + norm_2(x_vec))  # :131
+        shifted, at_x = self._work[0], self._work[3]
+
+        def product(z_vec, y_vec):
+            delta = safe_divide(mu, norm_2(y_vec))
+            shifted <<= x_vec + delta * y_vec
+            any_op.mul(z_vec, shifted)
+            z_vec <<= safe_divide(1.0, delta) * (z_vec - at_x)
+
+        return make_operator(product)
+
+    def _residual(self, x_vec, b_vec, any_op) -> float:
+        at_x, res = self._work[3], self._work[2]
+        any_op.mul(at_x, x_vec)
+        res <<= b_vec - at_x
+        return norm_2(res)
 
     def init(self, x_vec, b_vec, any_op, pre_op):  # :106-122
-        self._s_vec, self._t_vec, self._r_vec, self._w_vec = (_like(x_vec) for _ in range(4))
+        self._work = [_like(x_vec) for _ in range(4)]  # s, t, r, w
         self.inner_iterations = 0
-        any_op.mul(self._w_vec, x_vec)
-        self._r_vec <<= b_vec - self._w_vec
-        return norm_2(self._r_vec)
+        return self._residual(x_vec, b_vec, any_op)
 
     def iterate(self, x_vec, b_vec, any_op, pre_op):  # :124-161
-        mu = math.sqrt(np.finfo(np.float64).eps) * math.sqrt(1.0 + norm_2(x_vec))
-        self._t_vec <<= self._r_vec
-        solver = BiCgStabSolver()
-        solver.absolute_error_tolerance = 1.0e-8
-        solver.relative_error_tolerance = 1.0e-8
-
-        def jacobian_vector_product(z_vec, y_vec):  # :136-148
-            delta = safe_divide(mu, norm_2(y_vec))
-            self._s_vec <<= x_vec + delta * y_vec
-            any_op.mul(z_vec, self._s_vec)
-            delta_inverse = safe_divide(1.0, delta)
-            z_vec <<= delta_inverse * (z_vec - self._w_vec)
-
-        solver.solve(self._t_vec, self._r_vec, make_operator(jacobian_vector_product))
-        self.inner_iterations += solver.iteration
-        x_vec += self._t_vec
-        any_op.mul(self._w_vec, x_vec)
-        self._r_vec <<= b_vec - self._w_vec
-        return norm_2(self._r_vec)
-
-
-class BiCgStabLSolver(InnerOuterIterativeSolver):
-    """SolverBiCgStab.hpp:184-383; ``num_inner_iterations`` is l (default 2).  A preconditioner is always
-    applied on the left, whatever ``pre_side`` says (:226-229, :273-274, :292-293)."""
-
-    def __init__(self):
-        super().__init__()
-        self.num_inner_iterations = 2  # :379-381
-
-    def outer_init(self, x_vec, b_vec, lin_op, pre_op):
-        l = self.num_inner_iterations
-        self._gamma, self._gamma_bar = np.zeros(l + 1), np.zeros(l + 1)
-        self._gamma_bbar, self._sigma = np.zeros(l + 1), np.zeros(l + 1)
-        self._tau = np.zeros((l + 1, l + 1))
-        mk = lambda: _like(x_vec)  # noqa: E731
-        self._r_tilde_vec = mk()
-        self._r_vecs = [mk() for _ in range(l + 1)]
-        self._u_vecs = [mk() for _ in range(l + 1)]
-        self._z_vec = mk() if pre_op is not None else None
-        fill_with(self._u_vecs[0], 0.0)
-        lin_op.Residual(self._r_vecs[0], b_vec, x_vec)
-        if pre_op is not None:  # :226-229
-            self._z_vec, self._r_vecs[0] = self._r_vecs[0], self._z_vec
-            pre_op.mul(self._r_vecs[0], self._z_vec)
-        self._r_tilde_vec <<= self._r_vecs[0]
-        self._rho = dot_product(self._r_tilde_vec, self._r_vecs[0])
-        self._alpha = self._omega = 0.0
-        return math.sqrt(self._rho)
-
-    def inner_iterate(self, x_vec, b_vec, lin_op, pre_op):
-        l, j = self.num_inner_iterations, self.inner_iteration
-        r, u = self._r_vecs, self._u_vecs
-        if self.iteration == 0:
-            u[0] <<= r[0]
-        else:
-            rho_bar, self._rho = self._rho, dot_product(self._r_tilde_vec, r[j])
-            beta = safe_divide(self._alpha * self._rho, rho_bar)
-            for i in range(j + 1):
-                u[i] <<= r[i] - beta * u[i]
-        if pre_op is not None:
-            pre_op.mul_chain(u[j + 1], self._z_vec, lin_op, u[j])
-        else:
-            lin_op.mul(u[j + 1], u[j])
-        self._alpha = safe_divide(self._rho, dot_product(self._r_tilde_vec, u[j + 1]))
-        for i in range(j + 1):
-            r[i] -= self._alpha * u[i + 1]
-        x_vec += self._alpha * u[0]
-        if pre_op is not None:
-            pre_op.mul_chain(r[j + 1], self._z_vec, lin_op, r[j])
-        else:
-            lin_op.mul(r[j + 1], r[j])
-        if j == l - 1:
-            tau, sigma, g, gb, gbb = self._tau, self._sigma, self._gamma, self._gamma_bar, self._gamma_bbar
-            for jj in range(1, l + 1):
-                for i in range(1, jj):
-                    tau[i, jj] = safe_divide(dot_product(r[i], r[jj]), sigma[i])
-                    r[jj] -= tau[i, jj] * r[i]
-                sigma[jj] = dot_product(r[jj], r[jj])
-                gb[jj] = safe_divide(dot_product(r[0], r[jj]), sigma[jj])
-            self._omega = g[l] = gb[l]
-            self._rho *= -self._omega
-            for jj in range(l - 1, 0, -1):
-                g[jj] = gb[jj]
-                for i in range(jj + 1, l + 1):
-                    g[jj] -= tau[jj, i] * g[i]
-            for jj in range(1, l):
-                gbb[jj] = g[jj + 1]
-                for i in range(jj + 1, l):
-                    gbb[jj] += tau[jj, i] * g[i + 1]
-            x_vec += g[1] * r[0]
-            r[0] -= gb[l] * r[l]
-            u[0] -= g[l] * u[l]
-            for jj in range(1, l):
-                x_vec += gbb[jj] * r[jj]
-                r[0] -= gb[jj] * r[jj]
-                u[0] -= g[jj] * u[jj]
-        return norm_2(r[0])
-
-
-class IdrsSolver(InnerOuterIterativeSolver):
-    """SolverIdrs.hpp:52-291 (unpreconditioned, left and right preconditioned); ``num_inner_iterations`` is s
-    (default 4)."""
-
-    def __init__(self):
-        super().__init__()
-        self.num_inner_iterations = 4  # :287-289
-
-    def outer_init(self, x_vec, b_vec, lin_op, pre_op):
-        s = self.num_inner_iterations
-        self._phi, self._gamma, self._mu = np.zeros(s), np.zeros(s), np.zeros((s, s))
-        mk = lambda: _like(x_vec)  # noqa: E731
-        self._r_vec, self._v_vec = mk(), mk()
-        self._p_vecs = [mk() for _ in range(s)]
-        self._u_vecs = [mk() for _ in range(s)]
-        self._g_vecs = [mk() for _ in range(s)]
-        self._z_vec = mk() if pre_op is not None else None
-        lin_op.Residual(self._r_vec, b_vec, x_vec)
-        if pre_op is not None and self.pre_side == PreconditionerSide.Left:  # :100-103
-            self._z_vec, self._r_vec = self._r_vec, self._z_vec
-            pre_op.mul(self._r_vec, self._z_vec)
-        self._phi[0] = norm_2(self._r_vec)
-        return self._phi[0]
-
-    def inner_init(self, x_vec, b_vec, lin_op, pre_op):
-        s, p, phi, mu = self.num_inner_iterations, self._p_vecs, self._phi, self._mu
-        if self.iteration == 0:
-            self._omega = mu[0, 0] = 1.0
-            p[0] <<= self._r_vec / phi[0]
-            for i in range(1, s):
-                mu[i, i], phi[i] = 1.0, 0.0
-                fill_randomly(p[i])
-                for j in range(i):
-                    mu[i, j] = 0.0
-                    p[i] -= dot_product(p[i], p[j]) * p[j]
-                p[i] /= norm_2(p[i])
-        else:
-            for i in range(s):
-                phi[i] = dot_product(p[i], self._r_vec)
-
-    def inner_iterate(self, x_vec, b_vec, lin_op, pre_op):
-        s, k = self.num_inner_iterations, self.inner_iteration
-        phi, gamma, mu = self._phi, self._gamma, self._mu
-        left_pre = pre_op is not None and self.pre_side == PreconditionerSide.Left
-        right_pre = pre_op is not None and self.pre_side == PreconditionerSide.Right
-        p, u, g, r, v = self._p_vecs, self._u_vecs, self._g_vecs, self._r_vec, self._v_vec
-        for i in range(k, s):
-            gamma[i] = phi[i]
-            for j in range(k, i):
-                gamma[i] -= mu[i, j] * gamma[j]
-            gamma[i] /= mu[i, i]
-        v <<= r - gamma[k] * g[k]
-        for i in range(k + 1, s):
-            v -= gamma[i] * g[i]
-        if right_pre:  # :204-207
-            self._z_vec, self._v_vec = self._v_vec, self._z_vec
-            v = self._v_vec
-            pre_op.mul(v, self._z_vec)
-        u[k] <<= self._omega * v + gamma[k] * u[k]
-        for i in range(k + 1, s):
-            u[k] += gamma[i] * u[i]
-        if left_pre:  # :212-213
-            pre_op.mul_chain(g[k], self._z_vec, lin_op, u[k])
-        else:
-            lin_op.mul(g[k], u[k])
-        for i in range(k):
-            alpha = safe_divide(dot_product(p[i], g[k]), mu[i, i])
-            u[k] -= alpha * u[i]
-            g[k] -= alpha * g[i]
-        for i in range(k, s):
-            mu[i, k] = dot_product(p[i], g[k])
-        beta = safe_divide(phi[k], mu[k, k])
-        x_vec += beta * u[k]
-        r -= beta * g[k]
-        for i in range(k + 1, s):
-            phi[i] -= beta * mu[i, k]
-        if k == s - 1:  # :268-279
-            _side_mul(self, pre_op, lin_op, v, self._z_vec, r)
-            self._omega = safe_divide(dot_product(v, r), dot_product(v, v))
-            x_vec += self._omega * (self._z_vec if right_pre else r)
-            r -= self._omega * v
-        return norm_2(r)
+        step, res = self._work[1], self._work[2]
+        inner = BiCgStabSolver()
+        inner.absolute_error_tolerance = inner.relative_error_tolerance = 1.0e-8
+        jacobian = self._linearised_at(x_vec, any_op)
+        step <<= res
+        inner.solve(step, res, jacobian)
+        self.inner_iterations += inner.iteration
+        x_vec += step
+        return self._residual(x_vec, b_vec, any_op)
 
 
 def _like(v: DeviceVector) -> DeviceVector:
@@ -1276,3 +966,17 @@ def _like(v: DeviceVector) -> DeviceVector:
 def solve(solver_cls, x_vec: DeviceVector, b_vec: DeviceVector, any_op: Operator) -> bool:
     """``solve<Solver>(x, b, op)``  Solver.hpp:261-265."""
     return solver_cls().solve(x_vec, b_vec, any_op)
+
+
+def solve_non_uniform(solver: Solver, x_vec: DeviceVector, b_vec: DeviceVector, any_op: Operator) -> bool:
+    """Solver.hpp:271-292: ``A(x) = b`` for an operator with ``A(0) != 0`` -- solve ``A(x) - A(0) = b - A(0)``."""
+    at_zero, rhs = _like(x_vec), _like(b_vec)
+    fill_with(rhs, 0.0)
+    any_op.mul(at_zero, rhs)
+    rhs <<= b_vec - at_zero
+
+    def uniform(y_vec, in_vec):
+        any_op.mul(y_vec, in_vec)
+        y_vec -= at_zero
+
+    return solver.solve(x_vec, rhs, make_operator(uniform))

@@ -153,7 +153,8 @@ int k_bicg_p(storm_hip_ctx *c, double *p, const double *r, Scal beta, Scal omega
 
 // y = r + s*(a*x + b*z), evaluated in exactly this nesting (operands may alias y).
 __global__ __launch_bounds__(kBlock) void lin3_kernel(int64_t n, double *y, const double *r, double s, double a,
-                                                      const double *x, double b, const double *z, int nt) {
+                                                      const double *x, double b, const double *z, const int *done, int nt) {
+  if (done && *done) return;
   const int64_t n2 = n >> 1;
   double2v *y2 = reinterpret_cast<double2v *>(y);
   const double2v *r2 = reinterpret_cast<const double2v *>(r), *x2 = reinterpret_cast<const double2v *>(x),
@@ -288,8 +289,9 @@ int k_reduce_final(storm_hip_ctx *c, const double *partials, int nblocks, int k,
   return STORM_HIP_OK;
 }
 
-int k_multi_dot(storm_hip_ctx *c, const double *a, const double *const *bs, int k, int64_t n,
-                double *d_out, const int *done) {
+// Per-block partials of <a, bs[j]>, j < k, into c->d_partials[j * nb + block]; *nb_out = nb.
+int k_multi_dot_partials(storm_hip_ctx *c, const double *a, const double *const *bs, int k, int64_t n,
+                         int *nb_out, const int *done) {
   STORM_REQUIRE(k >= 1 && k <= kMaxMulti, "multi_dot: k = %d outside [1, %d]", k, kMaxMulti);
   int nb = stream_blocks(n);
   if ((int64_t)nb * k > c->partials_capacity) nb = (int)(c->partials_capacity / k);  // grid-stride covers the rest
@@ -312,6 +314,14 @@ int k_multi_dot(storm_hip_ctx *c, const double *a, const double *const *bs, int 
     }
     HIP_TRY(hipGetLastError());
   }
+  *nb_out = nb;
+  return STORM_HIP_OK;
+}
+
+int k_multi_dot(storm_hip_ctx *c, const double *a, const double *const *bs, int k, int64_t n,
+                double *d_out, const int *done) {
+  int nb = 0;
+  STORM_TRY(k_multi_dot_partials(c, a, bs, k, n, &nb, done));
   return k_reduce_final(c, c->d_partials, nb, k, d_out, done);
 }
 
@@ -442,12 +452,12 @@ extern "C" {
 
 int storm_hip_fill(storm_hip_vec *y, double value) {
   STORM_REQUIRE(y, "fill: null vector");
-  return k_fill(y->ctx, y->d, y->n_owned, value);
+  return launch_ew(y->ctx, y->n_owned, EwPtrs{y->d, nullptr, nullptr}, FillF{value}, y->ctx->api_done);
 }
 
 int storm_hip_copy(storm_hip_vec *y, const storm_hip_vec *x) {
   STORM_TRY(check_pair(y, x, "copy"));
-  return k_copy(y->ctx, y->d, x->d, y->n_owned, nullptr);
+  return k_copy(y->ctx, y->d, x->d, y->n_owned, y->ctx->api_done);
 }
 
 int storm_hip_scale(storm_hip_vec *y, double s) {
@@ -462,18 +472,18 @@ int storm_hip_div_scalar(storm_hip_vec *y, double s) {
 
 int storm_hip_axpy(storm_hip_vec *y, double a, const storm_hip_vec *x) {
   STORM_TRY(check_pair(y, x, "axpy"));
-  return k_axpbz(y->ctx, y->d, host_scal(a), x->d, host_scal(1.0), y->d, y->n_owned, nullptr);
+  return k_axpbz(y->ctx, y->d, host_scal(a), x->d, host_scal(1.0), y->d, y->n_owned, y->ctx->api_done);
 }
 
 int storm_hip_xpay(storm_hip_vec *y, const storm_hip_vec *x, double b) {
   STORM_TRY(check_pair(y, x, "xpay"));
-  return k_axpbz(y->ctx, y->d, host_scal(1.0), x->d, host_scal(b), y->d, y->n_owned, nullptr);
+  return k_axpbz(y->ctx, y->d, host_scal(1.0), x->d, host_scal(b), y->d, y->n_owned, y->ctx->api_done);
 }
 
 int storm_hip_axpbz(storm_hip_vec *y, double a, const storm_hip_vec *x, double b, const storm_hip_vec *z) {
   STORM_TRY(check_pair(y, x, "axpbz"));
   STORM_TRY(check_pair(y, z, "axpbz"));
-  return k_axpbz(y->ctx, y->d, host_scal(a), x->d, host_scal(b), z->d, y->n_owned, nullptr);
+  return k_axpbz(y->ctx, y->d, host_scal(a), x->d, host_scal(b), z->d, y->n_owned, y->ctx->api_done);
 }
 
 int storm_hip_lin3(storm_hip_vec *y, const storm_hip_vec *r, double s, double a, const storm_hip_vec *x, double b,
@@ -484,7 +494,7 @@ int storm_hip_lin3(storm_hip_vec *y, const storm_hip_vec *r, double s, double a,
   if (y->n_owned <= 0) return STORM_HIP_OK;
   storm_hip_ctx *c = y->ctx;
   hipLaunchKernelGGL(lin3_kernel, dim3(stream_blocks(y->n_owned)), dim3(kBlock), 0, c->stream, y->n_owned, y->d,
-                     r->d, s, a, x->d, b, z->d, (int)(c->opt_blas1_nt != 0));
+                     r->d, s, a, x->d, b, z->d, c->api_done, (int)(c->opt_blas1_nt != 0));
   HIP_TRY(hipGetLastError());
   return STORM_HIP_OK;
 }
@@ -493,21 +503,21 @@ int storm_hip_vmul_add(storm_hip_vec *y, double s, const storm_hip_vec *a, const
   STORM_TRY(check_pair(y, a, "vmul_add"));
   STORM_TRY(check_pair(y, b, "vmul_add"));
   if (y->n_owned <= 0) return STORM_HIP_OK;
-  return launch_ew(y->ctx, y->n_owned, EwPtrs{y->d, a->d, b->d}, VmulAddF{s}, nullptr);
+  return launch_ew(y->ctx, y->n_owned, EwPtrs{y->d, a->d, b->d}, VmulAddF{s}, y->ctx->api_done);
 }
 
 int storm_hip_vmul(storm_hip_vec *y, const storm_hip_vec *a, const storm_hip_vec *b) {
   STORM_TRY(check_pair(y, a, "vmul"));
   STORM_TRY(check_pair(y, b, "vmul"));
   if (y->n_owned <= 0) return STORM_HIP_OK;
-  return launch_ew(y->ctx, y->n_owned, EwPtrs{y->d, a->d, b->d}, VmulF{}, nullptr);
+  return launch_ew(y->ctx, y->n_owned, EwPtrs{y->d, a->d, b->d}, VmulF{}, y->ctx->api_done);
 }
 
 int storm_hip_bicgstab_p(storm_hip_vec *p, const storm_hip_vec *r, double beta, double omega,
                          const storm_hip_vec *v) {
   STORM_TRY(check_pair(p, r, "bicgstab_p"));
   STORM_TRY(check_pair(p, v, "bicgstab_p"));
-  return k_bicg_p(p->ctx, p->d, r->d, host_scal(beta), host_scal(omega), v->d, p->n_owned, nullptr);
+  return k_bicg_p(p->ctx, p->d, r->d, host_scal(beta), host_scal(omega), v->d, p->n_owned, p->ctx->api_done);
 }
 
 int storm_hip_multi_dot(const storm_hip_vec *a, const storm_hip_vec *const *bs, int k, double *out) {
@@ -522,7 +532,7 @@ int storm_hip_multi_dot(const storm_hip_vec *a, const storm_hip_vec *const *bs, 
   if (a->n_owned == 0) {
     HIP_TRY(hipMemsetAsync(c->d_scalars, 0, sizeof(double) * (size_t)k, c->stream));
   } else {
-    STORM_TRY(k_multi_dot(c, a->d, ptrs, k, a->n_owned, c->d_scalars, nullptr));
+    STORM_TRY(k_multi_dot(c, a->d, ptrs, k, a->n_owned, c->d_scalars, c->api_done));
   }
   return finish_reduction(c, k, out);
 }
@@ -548,7 +558,7 @@ int storm_hip_multi_axpy(storm_hip_vec *y, const double *coefs, const storm_hip_
     STORM_TRY(check_pair(y, xs[j], "multi_axpy"));
     ptrs[j] = xs[j]->d;
   }
-  return multi_axpy_impl(y->ctx, y->d, coefs, nullptr, 1.0, ptrs, k, y->n_owned, nullptr);
+  return multi_axpy_impl(y->ctx, y->d, coefs, nullptr, 1.0, ptrs, k, y->n_owned, y->ctx->api_done);
 }
 
 }  // extern "C"

@@ -102,6 +102,7 @@ struct storm_hip_ctx {
   int64_t opt_blas1_nt = 1;  // non-temporal loads/stores in the streaming kernels
   int64_t opt_graph = 0;     // replay CG / BiCGStab iterations from a captured hipGraph: measured slower than eager launches (profiles/r01_notes.md), off
   int64_t opt_fuse_mgs = 1;  // GMRES/MGS on one rank, <= 2048 blocks: each step folds the previous step's partials itself (no final-reduction launch in between)
+  int64_t opt_generic_solvers = 0;  // 1: storm_hip_krylov_solve never takes the fused CG / BiCGStab / GMRES loops (A/B knob)
   int64_t opt_fuse_dot = 1;  // 0: reductions after an SpMV run as separate kernels (A/B knob)
   // Vector storage released by vec_destroy, kept for the next vec_create of the same size: a solve
   // allocates its work vectors on entry and frees them on return (the reference re-assigns them in
@@ -112,6 +113,9 @@ struct storm_hip_ctx {
   int64_t opt_pool_bytes = (int64_t)16 << 30;
   std::vector<hipEvent_t> prof_events;  // pairs (start, stop), grown on demand
   size_t prof_used = 0;
+  // Non-null while a solver is inside an operator / preconditioner callback: the device `done` flag of that
+  // solve.  Public entry points predicate the kernels they enqueue on it (work past convergence is free).
+  const int *api_done = nullptr;
   // communicator
   storm::Comm *comm = nullptr;
   int n_ranks = 1, rank = 0;
@@ -210,6 +214,8 @@ int k_bicg_p(storm_hip_ctx *c, double *p, const double *r, Scal beta, Scal omega
 // out[j] = <a, bs[j]> for j < k, written to d_out (device); local sums only.
 int k_multi_dot(storm_hip_ctx *c, const double *a, const double *const *bs, int k, int64_t n,
                 double *d_out, const int *done);
+int k_multi_dot_partials(storm_hip_ctx *c, const double *a, const double *const *bs, int k, int64_t n,
+                         int *nb_out, const int *done);
 // y += sum_j coef[j] * xs[j]; coefficients from device memory (d_coef, sign applied).
 int k_multi_axpy(storm_hip_ctx *c, double *y, const double *d_coef, double sign,
                  const double *const *xs, int k, int64_t n, const int *done);

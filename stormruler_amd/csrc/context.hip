@@ -117,6 +117,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   STORM_REQUIRE(c && key, "ctx_set_option: null argument");
   if (!strcmp(key, "ell_cap")) c->opt_ell_cap = value;
   else if (!strcmp(key, "spmv_variant")) c->opt_spmv_variant = value;
+  else if (!strcmp(key, "generic_solvers")) c->opt_generic_solvers = value;
   else if (!strcmp(key, "nontemporal")) c->opt_nt = value;
   else if (!strcmp(key, "spmv_xcd_remap")) c->opt_spmv_xcd_remap = value;
   else if (!strcmp(key, "spmv_dict")) c->opt_spmv_dict = value;
@@ -292,6 +293,22 @@ int storm_hip_fill_randomly(storm_hip_vec *v) {
 int storm_hip_vec_device_ptr(storm_hip_vec *v, void **dev_ptr) {
   STORM_REQUIRE(v && dev_ptr, "vec_device_ptr: null argument");
   *dev_ptr = v->d;
+  return STORM_HIP_OK;
+}
+
+int storm_hip_vec_context(const storm_hip_vec *v, storm_hip_ctx **ctx) {
+  STORM_REQUIRE(v && ctx, "vec_context: null argument");
+  *ctx = v->ctx;
+  return STORM_HIP_OK;
+}
+
+int storm_hip_vec_get(const storm_hip_vec *v, int64_t row, double *value) {
+  STORM_REQUIRE(v && value, "vec_get: null argument");
+  STORM_REQUIRE(row >= 0 && row < v->n_owned + v->n_halo, "vec_get: row %lld outside [0, %lld)", (long long)row,
+                (long long)(v->n_owned + v->n_halo));
+  HIP_TRY(hipSetDevice(v->ctx->device));
+  HIP_TRY(hipMemcpyAsync(value, v->d + row, sizeof(double), hipMemcpyDeviceToHost, v->ctx->stream));
+  HIP_TRY(hipStreamSynchronize(v->ctx->stream));
   return STORM_HIP_OK;
 }
 

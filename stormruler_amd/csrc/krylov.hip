@@ -1,0 +1,1305 @@
+// The general Krylov engine: every solver of the reference's Solvers/ directory, for any operator
+// (stencil operator or callback) and any preconditioner side, as a device-resident loop.
+//
+// What it stands in for (paths relative to the reference root): the bodies of
+//   Solvers/SolverCg.hpp:54-126, SolverBiCgStab.hpp:59-165 and :195-367, SolverGmres.hpp:51-249,
+//   SolverCgs.hpp:54-172, SolverTfqmr.hpp:41-204, SolverIdrs.hpp:60-281, SolverRichardson.hpp:48-96,
+// driven by IterativeSolver::solve / InnerOuterIterativeSolver (Solver.hpp:116-147, :236-257).
+//
+// How it is built (nothing like the reference's host loops):
+//   * A solver is written against a small ENGINE with three kinds of statements --
+//       vector statements   y = sum_t c_t v_t   (one streaming kernel; c_t = host number or scalar REGISTER),
+//                           y = A(x), y = P(x)  (stencil SpMV, or the caller's callback, which only enqueues),
+//       reductions          reg_j = <a, b_j>    (batched partials kernel + one final pass),
+//       scalar programs     short lists of micro-ops on the register file (safe_divide, sqrt, fma, compare,
+//                           Givens / back-substitution macros, and the convergence rule of Solver.hpp:132-140)
+//     The register file lives in HBM.  Scalar micro-ops are collected and ride in the kernel arguments of the final
+//     pass of the reduction that precedes them (one launch for "finish the dot, divide, take the root, test for
+//     convergence"), so a recurrence never costs the host a round trip.
+//   * The host enqueues iterations ahead of the device and polls a pinned `done` ring `check_lag` iterations
+//     behind; once the device's rule fires, every later kernel -- including those a callback enqueues, via
+//     ctx->api_done -- returns at its first instruction, so x is frozen at exactly the reference's iteration.
+//   * Multi-rank: a reduction's partial results are all-reduced (one call per batch) between the final pass and
+//     the scalar program.
+#include <cmath>
+#include <cstring>
+#include <initializer_list>
+#include <utility>
+#include <vector>
+
+#include "common.hpp"
+#include "solver_device.hpp"
+
+namespace storm {
+namespace kry {
+
+// ---- the scalar machine ---------------------------------------------------------------------------------
+enum : uint16_t {
+  SC_MOV,       // d = a
+  SC_ADD,       // d = a + b
+  SC_SUB,       // d = a - b
+  SC_MUL,       // d = a * b
+  SC_SDIV,      // d = safe_divide(a, b)          Crow/MathUtils.hpp:49-52
+  SC_DIV,       // d = a / b
+  SC_NEG,       // d = -a
+  SC_SQRT,      // d = sqrt(a)
+  SC_FMADD,     // d = d + a * b
+  SC_FMSUB,     // d = d - a * b
+  SC_LT,        // d = a < b ? 1 : 0
+  SC_CMOV,      // d = (b != 0) ? a : d
+  SC_SYMORTHO,  // (d, d+1, d+2) = (cs, sn, rr) of (a, b)   Crow/MathUtils.hpp:164-179
+  SC_BEGIN,     // Solver.hpp:122-128 with initial error a
+  SC_ADVANCE,   // Solver.hpp:132-140 with residual norm a
+  SC_GIVENS,    // GMRES column a (an integer, not a register): H(a+1, a) = reg b; rotations; d = |beta_{a+1}|
+  SC_BACKSOLVE  // GMRES: solve the a x a ... (a + 1) triangular system for beta (a an integer)
+};
+struct SOp {
+  uint16_t op, d, a, b;
+};
+constexpr int kProgOps = 100;
+constexpr int kProgImm = 8;
+constexpr uint16_t kImm0 = 0xFFF0;  // operand codes kImm0 + i read imm[i]
+struct SProg {
+  int n;
+  int aux[5];  // GMRES layout: H0, beta0, cs0, sn0, m (register indices)
+  double imm[kProgImm];
+  SOp ops[kProgOps];
+};
+struct RedOut {
+  int idx[kMaxMulti];
+};
+
+__device__ inline void exec_prog(const SProg &p, double *S, SolverState *st) {
+  for (int i = 0; i < p.n; ++i) {
+    const SOp o = p.ops[i];
+#define RD(r) ((r) >= kImm0 ? p.imm[(r) - kImm0] : S[(r)])
+    switch (o.op) {
+      case SC_MOV: S[o.d] = RD(o.a); break;
+      case SC_ADD: S[o.d] = RD(o.a) + RD(o.b); break;
+      case SC_SUB: S[o.d] = RD(o.a) - RD(o.b); break;
+      case SC_MUL: S[o.d] = RD(o.a) * RD(o.b); break;
+      case SC_SDIV: S[o.d] = safe_divide(RD(o.a), RD(o.b)); break;
+      case SC_DIV: S[o.d] = RD(o.a) / RD(o.b); break;
+      case SC_NEG: S[o.d] = -RD(o.a); break;
+      case SC_SQRT: S[o.d] = sqrt(RD(o.a)); break;
+      case SC_FMADD: S[o.d] = S[o.d] + RD(o.a) * RD(o.b); break;
+      case SC_FMSUB: S[o.d] = S[o.d] - RD(o.a) * RD(o.b); break;
+      case SC_LT: S[o.d] = RD(o.a) < RD(o.b) ? 1.0 : 0.0; break;
+      case SC_CMOV:
+        if (RD(o.b) != 0.0) S[o.d] = RD(o.a);
+        break;
+      case SC_SYMORTHO: {
+        const double a = RD(o.a), b = RD(o.b), rr = hypot(a, b);
+        S[o.d] = rr > 0.0 ? a / rr : 1.0;
+        S[o.d + 1] = rr > 0.0 ? b / rr : 0.0;
+        S[o.d + 2] = rr;
+      } break;
+      case SC_BEGIN: begin(st, RD(o.a)); break;
+      case SC_ADVANCE: advance(st, RD(o.a)); break;
+      case SC_GIVENS: {  // SolverGmres.hpp:176-191
+        double *H = S + p.aux[0], *beta = S + p.aux[1], *cs = S + p.aux[2], *sn = S + p.aux[3];
+        const int m = p.aux[4], k = o.a;
+#define H_(i, j) H[(i) * m + (j)]
+        H_(k + 1, k) = S[o.b];
+        for (int q = 0; q < k; ++q) {
+          const double chi = cs[q] * H_(q, k) + sn[q] * H_(q + 1, k);
+          H_(q + 1, k) = -sn[q] * H_(q, k) + cs[q] * H_(q + 1, k);
+          H_(q, k) = chi;
+        }
+        const double a = H_(k, k), b = H_(k + 1, k), rr = hypot(a, b);
+        const double c1 = rr > 0.0 ? a / rr : 1.0, s1 = rr > 0.0 ? b / rr : 0.0;
+        cs[k] = c1, sn[k] = s1;
+        H_(k, k) = c1 * H_(k, k) + s1 * H_(k + 1, k);
+        H_(k + 1, k) = 0.0;
+        beta[k + 1] = -s1 * beta[k];
+        beta[k] *= c1;
+        S[o.d] = fabs(beta[k + 1]);
+      } break;
+      case SC_BACKSOLVE: {  // SolverGmres.hpp:207-212
+        double *H = S + p.aux[0], *beta = S + p.aux[1];
+        const int m = p.aux[4], k = o.a;
+        for (int q = k; q >= 0; --q) {
+          for (int j = q + 1; j <= k; ++j) beta[q] -= H_(q, j) * beta[j];
+          beta[q] /= H_(q, q);
+        }
+#undef H_
+      } break;
+      default: break;
+    }
+#undef RD
+  }
+}
+
+// Final pass of k simultaneous reductions (out.idx[j] = register of sum j) + the scalar program behind them.
+__global__ __launch_bounds__(kBlock) void reduce_prog_kernel(const double *__restrict__ partials, int nblocks, int k,
+                                                             RedOut out, double *S, SolverState *st, SProg prog,
+                                                             const int *done) {
+  if (done && *done) return;
+  __shared__ double lds4[4];
+  for (int j = 0; j < k; ++j) {
+    const double *p = partials + (int64_t)j * nblocks;
+    double v = 0.0;
+#pragma unroll 8
+    for (int i = threadIdx.x; i < nblocks; i += kBlock) v += p[i];
+    const double sum = block_sum256(v, lds4);
+    if (threadIdx.x == 0) S[out.idx[j]] = sum;
+  }
+  if (threadIdx.x == 0 && prog.n > 0) {
+    __threadfence();
+    exec_prog(prog, S, st);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void reduce_stage1_kernel2(const double *__restrict__ partials, int nblocks,
+                                                                double *__restrict__ out, const int *done) {
+  if (done && *done) return;
+  __shared__ double lds4[4];
+  const int j = blockIdx.y, g = blockIdx.x;
+  const int chunk = (nblocks + gridDim.x - 1) / gridDim.x;
+  const int i0 = g * chunk, i1 = min(i0 + chunk, nblocks);
+  const double *p = partials + (int64_t)j * nblocks;
+  double v = 0.0;
+  for (int i = i0 + threadIdx.x; i < i1; i += kBlock) v += p[i];
+  const double sum = block_sum256(v, lds4);
+  if (threadIdx.x == 0) out[j * gridDim.x + g] = sum;
+}
+
+// A scalar program alone; with nscatter > 0 first S[out.idx[j]] = S[scr + j] (results of an all-reduce).
+__global__ void sprog_kernel(double *S, SolverState *st, SProg prog, int nscatter, RedOut out, int scr,
+                             const int *done) {
+  if (done && *done) return;
+  for (int j = 0; j < nscatter; ++j) S[out.idx[j]] = S[scr + j];
+  exec_prog(prog, S, st);
+}
+
+// ---- vector statements ------------------------------------------------------------------------------------
+typedef double double2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2v ldv(const double2v *p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ void stv(double2v *p, double2v v, bool nt) {
+  if (nt) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+__device__ __forceinline__ double ld_coef(const Scal &s) { return s.p ? (*s.p) * s.sign : s.v; }
+
+struct LinArgs {
+  double *y;
+  const double *v[4];
+  Scal c[4];
+  const double *cond;  // nullable: run only when *cond != 0
+};
+
+// y = c0 v0 + c1 v1 + ... (left to right), or NESTED (NT = 3):  y = v0 + c1 * (v1 + c2 * v2).
+// Operands may alias y (every element is read before it is written by the same lane).
+template <int NT, bool NESTED>
+__global__ __launch_bounds__(kBlock) void lin_kernel(int64_t n, LinArgs a, const int *done, int nt) {
+  if (done && *done) return;
+  if (a.cond && *a.cond == 0.0) return;
+  double c[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) c[t] = ld_coef(a.c[t]);
+  const int64_t n2 = n >> 1;
+  double2v *y2 = reinterpret_cast<double2v *>(a.y);
+  for (int64_t base = (int64_t)blockIdx.x * (kBlock * kUnroll) + threadIdx.x; base < n2;
+       base += (int64_t)gridDim.x * (kBlock * kUnroll)) {
+    double2v v[kUnroll][NT];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t i = base + u * kBlock;
+      if (i < n2) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) v[u][t] = ldv(reinterpret_cast<const double2v *>(a.v[t]) + i, nt);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t i = base + u * kBlock;
+      if (i < n2) {
+        double2v o;
+        if constexpr (NESTED) {
+          o = v[u][0] + c[1] * (v[u][1] + c[2] * v[u][NT - 1]);
+        } else {
+          o = c[0] * v[u][0];
+#pragma unroll
+          for (int t = 1; t < NT; ++t) o += c[t] * v[u][t];
+        }
+        stv(y2 + i, o, nt);
+      }
+    }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    double o;
+    if constexpr (NESTED) {
+      o = a.v[0][i] + c[1] * (a.v[1][i] + c[2] * a.v[NT - 1][i]);
+    } else {
+      o = c[0] * a.v[0][i];
+      for (int t = 1; t < NT; ++t) o += c[t] * a.v[t][i];
+    }
+    a.y[i] = o;
+  }
+}
+
+}  // namespace kry
+}  // namespace storm
+
+using namespace storm;
+using namespace storm::kry;
+
+// ---- the engine ---------------------------------------------------------------------------------------------
+namespace {
+
+struct Coef {  // a coefficient of a vector statement: a host number, or +-register
+  int reg;
+  double v, sign;
+};
+inline Coef R(int reg) { return Coef{reg, 0.0, 1.0}; }
+inline Coef mR(int reg) { return Coef{reg, 0.0, -1.0}; }
+inline Coef num(double v) { return Coef{-1, v, 1.0}; }
+typedef storm_hip_vec *V;
+struct Term {
+  Coef c;
+  const storm_hip_vec *v;
+};
+
+// registers every method has
+enum { R_ZERO = 0, R_ONE, R_ERR, R_T0, R_T1, R_T2, R_T3, R_SCR /* kMaxMulti all-reduce slots */, R_USER = R_SCR + kMaxMulti };
+
+}  // namespace
+
+struct KrylovEngine {
+  storm_hip_ctx *c = nullptr;
+  int method = 0;
+  // operator / preconditioner
+  const storm_hip_op *op = nullptr;
+  double op_alpha = 0.0, op_beta = 0.0;
+  storm_hip_apply_fn op_fn = nullptr;
+  void *op_user = nullptr;
+  storm_hip_apply_fn pre_fn = nullptr;
+  void *pre_user = nullptr;
+  const storm_hip_vec *pre_diag = nullptr;
+  int side = STORM_HIP_RIGHT;
+  double relaxation = 1.0e-4;  // SolverRichardson.hpp:45
+  // device state (own: solves may nest, e.g. a solver used as another solver's preconditioner)
+  SolverState *d_st = nullptr, *h_st = nullptr;
+  int *h_ring = nullptr, *d_ring = nullptr;
+  std::vector<hipEvent_t> ev;
+  double *S = nullptr;
+  int S_cap = 0, S_top = 0;
+  double *d_history = nullptr;
+  // the solve in progress
+  const storm_hip_vec *b = nullptr;
+  storm_hip_vec *x = nullptr;
+  int64_t n = 0;
+  int inner = 0, gram_schmidt = 0, lag = 4;
+  std::vector<V> work;
+  const int *dp = nullptr;  // predicate of the statements being enqueued (null: unconditional)
+  int status = STORM_HIP_OK;
+  int64_t it_enqueued = 0, applies = 0, pre_applies = 0;
+  std::vector<int64_t> applies_after, pre_after;  // totals after init ([0]) and after each enqueued iteration
+  bool stepping = false, active = false;
+  // pending scalar program / reduction
+  SProg prog{};
+  int n_imm = 0;
+  bool red_pending = false;
+  int red_nb = 0, red_k = 0;
+  RedOut red_out{};
+  // per-method vectors and registers
+  V p = nullptr, q = nullptr, r = nullptr, rt = nullptr, t = nullptr, u = nullptr, v = nullptr, y = nullptr, z = nullptr,
+    d = nullptr, s_ = nullptr;
+  std::vector<V> qs, zs, rs, us, ps, gs;
+  int r_alpha = 0, r_beta = 0, r_rho = 0, r_omega = 0, r_gamma = 0, r_tau = 0, r_a0 = 0, r_a1 = 0, r_a2 = 0, r_a3 = 0,
+      r_a4 = 0;
+  int H0 = 0, B0 = 0, CS0 = 0, SN0 = 0, r_hn = 0;
+
+  bool has_pre() const { return pre_fn != nullptr || pre_diag != nullptr; }
+  bool left() const { return has_pre() && side == STORM_HIP_LEFT; }
+  bool right() const { return has_pre() && side == STORM_HIP_RIGHT; }
+  bool ok() const { return status == STORM_HIP_OK; }
+  void fail(int st) {
+    if (status == STORM_HIP_OK) status = st;
+  }
+  int alloc(int count) {
+    const int at = S_top;
+    S_top += count;
+    return at;
+  }
+
+  // -- scalar statements
+  void sc(uint16_t opc, int dd, int aa = 0, int bb = 0) {
+    if (prog.n == kProgOps) flush();
+    prog.ops[prog.n++] = SOp{opc, (uint16_t)dd, (uint16_t)aa, (uint16_t)bb};
+  }
+  int imm(double value) {
+    if (n_imm == kProgImm || prog.n + 4 > kProgOps) flush();
+    prog.imm[n_imm] = value;
+    return kImm0 + n_imm++;
+  }
+  void reset_prog() { prog.n = 0, n_imm = 0; }
+
+  void flush() {
+    if (!ok()) {
+      reset_prog(), red_pending = false;
+      return;
+    }
+    if (red_pending) {
+      const double *partials = c->d_partials;
+      int nb = red_nb;
+      if (nb > 8192) {
+        hipLaunchKernelGGL(reduce_stage1_kernel2, dim3(kStage2, red_k), dim3(kBlock), 0, c->stream, partials, nb,
+                           c->d_partials2, dp);
+        partials = c->d_partials2, nb = kStage2;
+      }
+      if (c->comm == nullptr) {
+        hipLaunchKernelGGL(reduce_prog_kernel, dim3(1), dim3(kBlock), 0, c->stream, partials, nb, red_k, red_out, S,
+                           d_st, prog, dp);
+      } else {
+        RedOut scr{};
+        for (int j = 0; j < red_k; ++j) scr.idx[j] = R_SCR + j;
+        SProg none{};
+        hipLaunchKernelGGL(reduce_prog_kernel, dim3(1), dim3(kBlock), 0, c->stream, partials, nb, red_k, scr, S, d_st,
+                           none, dp);
+        const int st = comm_allreduce_sum(c, S + R_SCR, red_k);
+        if (st != STORM_HIP_OK) fail(st);
+        hipLaunchKernelGGL(sprog_kernel, dim3(1), dim3(1), 0, c->stream, S, d_st, prog, red_k, red_out, (int)R_SCR, dp);
+      }
+      red_pending = false;
+    } else if (prog.n > 0) {
+      hipLaunchKernelGGL(sprog_kernel, dim3(1), dim3(1), 0, c->stream, S, d_st, prog, 0, RedOut{}, 0, dp);
+    }
+    reset_prog();
+    if (hipGetLastError() != hipSuccess) {
+      set_error("krylov: kernel launch failed");
+      fail(STORM_HIP_E_HIP);
+    }
+  }
+
+  // -- reductions: reg_j = <a, b_j>
+  void dots(const storm_hip_vec *a, std::initializer_list<std::pair<int, const storm_hip_vec *>> outs) {
+    std::vector<std::pair<int, const storm_hip_vec *>> o(outs);
+    dots_v(a, o);
+  }
+  void dots_v(const storm_hip_vec *a, const std::vector<std::pair<int, const storm_hip_vec *>> &outs) {
+    flush();
+    if (!ok()) return;
+    const int k = (int)outs.size();
+    if (k < 1 || k > kMaxMulti) {
+      set_error("krylov: %d simultaneous reductions (limit %d)", k, kMaxMulti);
+      return fail(STORM_HIP_E_UNSUPPORTED);
+    }
+    const double *bs[kMaxMulti];
+    for (int j = 0; j < k; ++j) bs[j] = outs[j].second->d, red_out.idx[j] = outs[j].first;
+    if (n == 0) {  // an empty rank still takes part in the all-reduce
+      const int st = (int)hipMemsetAsync(c->d_partials, 0, sizeof(double) * (size_t)k, c->stream);
+      if (st != 0) return fail(STORM_HIP_E_HIP);
+      red_nb = 1;
+    } else {
+      const int st = k_multi_dot_partials(c, a->d, bs, k, n, &red_nb, dp);
+      if (st != STORM_HIP_OK) return fail(st);
+    }
+    red_k = k, red_pending = true;
+  }
+  void dot(int out, const storm_hip_vec *a, const storm_hip_vec *b2) { dots(a, {{out, b2}}); }
+
+  // -- vector statements
+  Scal scal(const Coef &co) const { return co.reg >= 0 ? Scal{S + co.reg, 0.0, co.sign} : Scal{nullptr, co.v, 1.0}; }
+  template <int NT, bool NESTED>
+  void launch_lin(const LinArgs &a) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL((lin_kernel<NT, NESTED>), dim3(stream_blocks(n)), dim3(kBlock), 0, c->stream, n, a, dp,
+                       (int)(c->opt_blas1_nt != 0));
+  }
+  void lin_v(V yv, const std::vector<Term> &terms, int cond = -1) {
+    flush();
+    if (!ok()) return;
+    size_t at = 0;
+    bool first = true;
+    while (at < terms.size()) {
+      LinArgs a{};
+      a.y = yv->d;
+      a.cond = cond >= 0 ? S + cond : nullptr;
+      int nt = 0;
+      if (!first) a.v[nt] = yv->d, a.c[nt] = Scal{nullptr, 1.0, 1.0}, ++nt;
+      while (at < terms.size() && nt < 4) a.v[nt] = terms[at].v->d, a.c[nt] = scal(terms[at].c), ++nt, ++at;
+      switch (nt) {
+        case 1: launch_lin<1, false>(a); break;
+        case 2: launch_lin<2, false>(a); break;
+        case 3: launch_lin<3, false>(a); break;
+        default: launch_lin<4, false>(a); break;
+      }
+      first = false;
+    }
+  }
+  void lin(V yv, std::initializer_list<Term> terms, int cond = -1) { lin_v(yv, std::vector<Term>(terms), cond); }
+  // y = v0 + c1 * (v1 + c2 * v2)
+  void lin_nested(V yv, const storm_hip_vec *v0, Coef c1, const storm_hip_vec *v1, Coef c2, const storm_hip_vec *v2) {
+    flush();
+    if (!ok()) return;
+    LinArgs a{};
+    a.y = yv->d;
+    a.v[0] = v0->d, a.v[1] = v1->d, a.v[2] = v2->d;
+    a.c[0] = Scal{nullptr, 1.0, 1.0}, a.c[1] = scal(c1), a.c[2] = scal(c2);
+    launch_lin<3, true>(a);
+  }
+  void copy(V yv, const storm_hip_vec *xv, int cond = -1) { lin(yv, {{num(1.0), xv}}, cond); }
+  void axpy(V yv, Coef a, const storm_hip_vec *xv) { lin(yv, {{num(1.0), yv}, {a, xv}}); }
+  void divide(V yv, int reg) {  // y /= reg (a true division per element, SolverGmres.hpp:88)
+    flush();
+    if (!ok()) return;
+    const int st = k_scale(c, yv->d, n, dev_scal(S + reg), true, dp);
+    if (st != STORM_HIP_OK) fail(st);
+  }
+  void scale(V yv, Coef a) { lin(yv, {{a, yv}}); }
+
+  struct ApiDone {  // library calls a callback makes are predicated on this solve's flag
+    storm_hip_ctx *c;
+    const int *saved;
+    ApiDone(storm_hip_ctx *c_, const int *dp_) : c(c_), saved(c_->api_done) { c->api_done = dp_; }
+    ~ApiDone() { c->api_done = saved; }
+  };
+  void apply(V yv, const storm_hip_vec *xv) {  // y = A(x)          Operator::mul, Operator.hpp:74
+    flush();
+    if (!ok()) return;
+    ++applies;
+    int st;
+    if (op_fn != nullptr) {
+      ApiDone guard(c, dp);
+      st = op_fn(op_user, yv, xv);
+      if (st != 0) {
+        if (st > 0 || storm_hip_last_error()[0] == 0) set_error("krylov: the operator callback returned %d", st);
+        st = st < 0 ? st : STORM_HIP_E_INVALID;
+      }
+    } else {
+      st = spmv_launch(op, host_scal(op_alpha), host_scal(op_beta), xv->d, yv->d, nullptr, dp);
+    }
+    if (st != STORM_HIP_OK) fail(st);
+  }
+  void pre(V yv, const storm_hip_vec *xv) {  // y = P(x)          Preconditioner::mul
+    flush();
+    if (!ok()) return;
+    ++pre_applies;
+    int st;
+    ApiDone guard(c, dp);
+    if (pre_fn != nullptr) {
+      st = pre_fn(pre_user, yv, xv);
+      if (st != 0) {
+        if (st > 0 || storm_hip_last_error()[0] == 0) set_error("krylov: the preconditioner callback returned %d", st);
+        st = st < 0 ? st : STORM_HIP_E_INVALID;
+      }
+    } else {
+      st = storm_hip_vmul(yv, pre_diag, xv);
+    }
+    if (st != STORM_HIP_OK) fail(st);
+  }
+  // The dispatch every preconditioned body repeats (chained mul, Operator.hpp:82-88):
+  //   left: z = P(y = A x);  right: z = A(y = P x);  none: z = A x.
+  void mul_side(V zv, V yv, const storm_hip_vec *xv) {
+    if (left()) apply(yv, xv), pre(zv, yv);
+    else if (right()) pre(yv, xv), apply(zv, yv);
+    else apply(zv, xv);
+  }
+  void residual(V rv, const storm_hip_vec *bv, const storm_hip_vec *xv) {  // Operator::Residual, Operator.hpp:95-99
+    apply(rv, xv);
+    lin(rv, {{num(1.0), bv}, {num(-1.0), rv}});
+  }
+  V vec() {
+    storm_hip_vec *w = nullptr;
+    if (ok()) {
+      const int st = storm_hip_vec_create_like(x, &w);
+      if (st != STORM_HIP_OK) fail(st);
+    }
+    work.push_back(w);
+    return w;
+  }
+  void norm_to_err_and(uint16_t what, const storm_hip_vec *a) {  // ERR = |a|; begin / advance
+    dot(R_T0, a, a);
+    sc(SC_SQRT, R_ERR, R_T0);
+    sc(what, 0, R_ERR);
+  }
+
+  // ---- the solvers -------------------------------------------------------------------------------------------
+  void setup();
+  void init();
+  void iterate(int64_t it);
+  void finalize(int64_t iterations, bool forced);
+  void gmres_start(bool outer);
+  void gmres_update_x(int k);
+};
+
+struct storm_hip_krylov : KrylovEngine {};  // the opaque handle of the C ABI
+
+namespace {
+typedef KrylovEngine K;
+}
+
+// Registers and work vectors of a method (the reference allocates in init(): e.g. SolverCg.hpp:57-59).
+void K::setup() {
+  S_top = R_USER;
+  const bool P = has_pre();
+  switch (method) {
+    case STORM_HIP_CG:
+      p = vec(), r = vec(), z = vec();
+      r_gamma = alloc(1), r_alpha = alloc(1), r_beta = alloc(1), r_a0 = alloc(1), r_a1 = alloc(1);
+      break;
+    case STORM_HIP_BICGSTAB:
+      p = vec(), r = vec(), rt = vec(), t = vec(), v = vec();
+      if (P) z = vec();
+      r_alpha = alloc(1), r_beta = alloc(1), r_rho = alloc(1), r_omega = alloc(1), r_a0 = alloc(1), r_a1 = alloc(1),
+      r_a2 = alloc(1);
+      break;
+    case STORM_HIP_CGS:
+      p = vec(), q = vec(), r = vec(), rt = vec(), u = vec(), v = vec();
+      r_alpha = alloc(1), r_beta = alloc(1), r_rho = alloc(1), r_a0 = alloc(1);
+      break;
+    case STORM_HIP_TFQMR:
+    case STORM_HIP_TFQMR1:
+      d = vec(), rt = vec(), u = vec(), v = vec(), y = vec(), s_ = vec();
+      if (P) z = vec();
+      r_alpha = alloc(1), r_beta = alloc(1), r_rho = alloc(1), r_tau = alloc(1), r_omega = alloc(1), r_a0 = alloc(1),
+      r_a1 = alloc(3), r_a2 = alloc(1), r_a3 = alloc(1);
+      break;
+    case STORM_HIP_RICHARDSON:
+      r = vec();
+      if (P) z = vec();
+      break;
+    case STORM_HIP_BICGSTAB_L: {
+      const int l = inner;
+      rt = vec();
+      if (P) z = vec();
+      rs.clear(), us.clear();
+      for (int i = 0; i <= l; ++i) rs.push_back(vec()), us.push_back(vec());
+      r_alpha = alloc(1), r_beta = alloc(1), r_rho = alloc(1), r_omega = alloc(1), r_a0 = alloc(1);
+      r_gamma = alloc(l + 1);           // gamma
+      r_a1 = alloc(l + 1);              // gamma_bar
+      r_a2 = alloc(l + 1);              // gamma_bbar
+      r_a3 = alloc(l + 1);              // sigma
+      r_a4 = alloc((l + 1) * (l + 1));  // tau
+    } break;
+    case STORM_HIP_IDRS: {
+      const int s = inner;
+      r = vec(), v = vec();
+      if (P) z = vec();
+      ps.clear(), us.clear(), gs.clear();
+      for (int i = 0; i < s; ++i) ps.push_back(vec()), us.push_back(vec()), gs.push_back(vec());
+      r_omega = alloc(1), r_alpha = alloc(1), r_beta = alloc(1);
+      r_a0 = alloc(s);      // phi
+      r_gamma = alloc(s);   // gamma
+      r_a1 = alloc(s * s);  // mu
+    } break;
+    case STORM_HIP_GMRES:
+    case STORM_HIP_FGMRES: {
+      const int m = inner;
+      qs.clear(), zs.clear();
+      for (int i = 0; i <= m; ++i) qs.push_back(vec());
+      if (P) {
+        const int nz = method == STORM_HIP_FGMRES ? m : 1;
+        for (int i = 0; i < nz; ++i) zs.push_back(vec());
+      }
+      r_hn = alloc(1);
+      B0 = alloc(m + 1), CS0 = alloc(m), SN0 = alloc(m);
+      r_a0 = alloc(2 * kMaxMulti);  // classical Gram-Schmidt x2: the two passes' coefficients
+      H0 = alloc((m + 1) * m);
+    } break;
+    default:
+      set_error("krylov: unknown method %d", method);
+      fail(STORM_HIP_E_INVALID);
+  }
+}
+
+// ---- GMRES / FGMRES pieces ----------------------------------------------------------------------------------
+// q0 = b - A x [left: q0 = P(b - A x)]; beta0 = |q0|; q0 /= beta0      (outer_init :82-90 and inner_init :110-116)
+void K::gmres_start(bool outer) {
+  const bool lp = has_pre() && method == STORM_HIP_GMRES && side == STORM_HIP_LEFT;
+  residual(qs[0], b, x);
+  if (lp) {
+    std::swap(zs[0], qs[0]);
+    pre(qs[0], zs[0]);
+  }
+  dot(R_T0, qs[0], qs[0]);
+  sc(SC_SQRT, B0, R_T0);
+  if (outer) sc(SC_BEGIN, 0, B0);
+  divide(qs[0], B0);
+}
+
+// x += sum_i beta_i q_i after the back substitution (inner_finalize :194-249)
+void K::gmres_update_x(int k) {
+  const bool rp = has_pre() && (method == STORM_HIP_FGMRES || side == STORM_HIP_RIGHT);
+  prog.aux[0] = H0, prog.aux[1] = B0, prog.aux[2] = CS0, prog.aux[3] = SN0, prog.aux[4] = inner;
+  sc(SC_BACKSOLVE, 0, k);
+  std::vector<Term> terms;
+  if (!rp) {
+    for (int i = 0; i <= k; ++i) terms.push_back({R(B0 + i), qs[i]});
+    terms.insert(terms.begin(), Term{num(1.0), x});
+    lin_v(x, terms);
+  } else if (method == STORM_HIP_FGMRES) {
+    terms.push_back({num(1.0), x});
+    for (int i = 0; i <= k; ++i) terms.push_back({R(B0 + i), zs[i]});
+    lin_v(x, terms);
+  } else {  // q0 = sum beta_i q_i; z0 = P q0; x += z0          :242-247
+    for (int i = 0; i <= k; ++i) terms.push_back({R(B0 + i), qs[i]});
+    lin_v(qs[0], terms);
+    pre(zs[0], qs[0]);
+    axpy(x, num(1.0), zs[0]);
+  }
+}
+
+namespace storm {
+// solvers.hip: the Gram-Schmidt step of storm_hip_solve_gmres, shared with this engine
+int gmres_orthogonalize(storm_hip_ctx *c, int64_t n, const SolverState *st, const int *done, double *qn,
+                        const double *const *q, int k, int m, double *H, double *norm2_out, double *scratch,
+                        int gram_schmidt);
+}  // namespace storm
+
+void K::init() {
+  const bool P = has_pre();
+  switch (method) {
+    case STORM_HIP_CG:  // SolverCg.hpp:54-84 (CG takes no notice of pre_side)
+      residual(r, b, x);
+      if (P) {
+        pre(z, r);
+        copy(p, z);
+        dots(r, {{r_gamma, z}, {R_T0, r}});
+        sc(SC_SQRT, R_ERR, R_T0);
+      } else {
+        copy(p, r);
+        dot(r_gamma, r, r);
+        sc(SC_SQRT, R_ERR, r_gamma);
+      }
+      sc(SC_BEGIN, 0, R_ERR);
+      break;
+    case STORM_HIP_BICGSTAB:  // SolverBiCgStab.hpp:59-91
+      residual(r, b, x);
+      if (left()) std::swap(z, r), pre(r, z);
+      copy(rt, r);
+      dot(r_rho, rt, r);
+      sc(SC_SQRT, R_ERR, r_rho);
+      sc(SC_BEGIN, 0, R_ERR);
+      break;
+    case STORM_HIP_CGS:  // SolverCgs.hpp:54-88
+      residual(r, b, x);
+      if (left()) std::swap(u, r), pre(r, u);
+      copy(rt, r);
+      dot(r_rho, rt, r);
+      sc(SC_SQRT, R_ERR, r_rho);
+      sc(SC_BEGIN, 0, R_ERR);
+      break;
+    case STORM_HIP_TFQMR:
+    case STORM_HIP_TFQMR1:  // SolverTfqmr.hpp:41-87
+      if (method == STORM_HIP_TFQMR1) copy(d, x);
+      residual(y, b, x);
+      if (left()) std::swap(z, y), pre(y, z);
+      copy(u, y);
+      copy(rt, u);
+      dot(r_rho, rt, u);
+      sc(SC_SQRT, r_tau, r_rho);
+      sc(SC_BEGIN, 0, r_tau);
+      break;
+    case STORM_HIP_RICHARDSON:  // SolverRichardson.hpp:48-71 (no notice of pre_side either)
+      residual(r, b, x);
+      if (P) std::swap(z, r), pre(r, z);
+      norm_to_err_and(SC_BEGIN, r);
+      break;
+    case STORM_HIP_BICGSTAB_L:  // SolverBiCgStab.hpp:195-233 (always left)
+      residual(rs[0], b, x);
+      if (P) std::swap(z, rs[0]), pre(rs[0], z);
+      copy(rt, rs[0]);
+      dot(r_rho, rt, rs[0]);
+      sc(SC_SQRT, R_ERR, r_rho);
+      sc(SC_BEGIN, 0, R_ERR);
+      break;
+    case STORM_HIP_IDRS:  // SolverIdrs.hpp:60-106
+      residual(r, b, x);
+      if (left()) std::swap(z, r), pre(r, z);
+      dot(R_T0, r, r);
+      sc(SC_SQRT, r_a0, R_T0);
+      sc(SC_BEGIN, 0, r_a0);
+      break;
+    case STORM_HIP_GMRES:
+    case STORM_HIP_FGMRES:  // SolverGmres.hpp:51-91
+      gmres_start(true);
+      break;
+  }
+  flush();
+}
+
+void K::iterate(int64_t it) {
+  const bool P = has_pre();
+  switch (method) {
+    case STORM_HIP_CG: {  // SolverCg.hpp:86-126
+      apply(z, p);
+      dot(R_T0, p, z);
+      sc(SC_SDIV, r_alpha, r_gamma, R_T0);
+      axpy(x, R(r_alpha), p);
+      axpy(r, mR(r_alpha), z);
+      sc(SC_MOV, r_a0, r_gamma);  // gamma_bar
+      if (P) {
+        pre(z, r);
+        dots(r, {{r_gamma, z}, {R_T1, r}});
+        sc(SC_SQRT, R_ERR, R_T1);
+      } else {
+        dot(r_gamma, r, r);
+        sc(SC_SQRT, R_ERR, r_gamma);
+      }
+      sc(SC_SDIV, r_beta, r_gamma, r_a0);
+      sc(SC_ADVANCE, 0, R_ERR);
+      lin(p, {{num(1.0), P ? z : r}, {R(r_beta), p}});
+    } break;
+
+    case STORM_HIP_BICGSTAB: {  // SolverBiCgStab.hpp:93-165
+      if (it == 0) {
+        copy(p, r);
+      } else {
+        sc(SC_MOV, r_a0, r_rho);  // rho_bar
+        dot(r_rho, rt, r);
+        sc(SC_MUL, R_T0, r_alpha, r_rho);
+        sc(SC_MUL, R_T1, r_omega, r_a0);
+        sc(SC_SDIV, r_beta, R_T0, R_T1);
+        lin_nested(p, r, R(r_beta), p, mR(r_omega), v);
+      }
+      mul_side(v, z, p);
+      dot(R_T0, rt, v);
+      sc(SC_SDIV, r_alpha, r_rho, R_T0);
+      axpy(x, R(r_alpha), right() ? z : p);
+      axpy(r, mR(r_alpha), v);
+      mul_side(t, z, r);
+      dots(t, {{R_T0, r}, {R_T1, t}});
+      sc(SC_SDIV, r_omega, R_T0, R_T1);
+      axpy(x, R(r_omega), right() ? z : r);
+      axpy(r, mR(r_omega), t);
+      norm_to_err_and(SC_ADVANCE, r);
+    } break;
+
+    case STORM_HIP_CGS: {  // SolverCgs.hpp:90-172
+      if (it == 0) {
+        copy(u, r);
+        copy(p, u);
+      } else {
+        sc(SC_MOV, r_a0, r_rho);
+        dot(r_rho, rt, r);
+        sc(SC_SDIV, r_beta, r_rho, r_a0);
+        lin(u, {{num(1.0), r}, {R(r_beta), q}});
+        lin_nested(p, u, R(r_beta), q, R(r_beta), p);
+      }
+      mul_side(v, q, p);
+      dot(R_T0, rt, v);
+      sc(SC_SDIV, r_alpha, r_rho, R_T0);
+      lin(q, {{num(1.0), u}, {mR(r_alpha), v}});
+      lin(v, {{num(1.0), u}, {num(1.0), q}});
+      if (left()) {
+        axpy(x, R(r_alpha), v);
+        apply(u, v), pre(v, u);
+        axpy(r, mR(r_alpha), v);
+      } else if (right()) {
+        pre(u, v), apply(v, u);
+        axpy(x, R(r_alpha), u);
+        axpy(r, mR(r_alpha), v);
+      } else {
+        apply(u, v);
+        axpy(x, R(r_alpha), v);
+        axpy(r, mR(r_alpha), u);
+      }
+      norm_to_err_and(SC_ADVANCE, r);
+    } break;
+
+    case STORM_HIP_TFQMR:
+    case STORM_HIP_TFQMR1: {  // SolverTfqmr.hpp:89-204
+      const bool l1 = method == STORM_HIP_TFQMR1;
+      if (it == 0) {
+        mul_side(s_, z, y);
+        copy(v, s_);
+      } else {
+        sc(SC_MOV, r_a0, r_rho);
+        dot(r_rho, rt, u);
+        sc(SC_SDIV, r_beta, r_rho, r_a0);
+        lin(v, {{num(1.0), s_}, {R(r_beta), v}});
+        lin(y, {{num(1.0), u}, {R(r_beta), y}});
+        mul_side(s_, z, y);
+        lin(v, {{num(1.0), s_}, {R(r_beta), v}});
+      }
+      dot(R_T0, rt, v);
+      sc(SC_SDIV, r_alpha, r_rho, R_T0);
+      for (int half = 0; half <= 1; ++half) {
+        axpy(u, mR(r_alpha), s_);
+        axpy(d, R(r_alpha), right() ? z : y);
+        dot(R_T0, u, u);
+        sc(SC_SQRT, r_omega, R_T0);
+        if (l1) {
+          sc(SC_LT, r_a2, r_omega, r_tau);
+          sc(SC_CMOV, r_tau, r_omega, r_a2);
+          copy(x, d, r_a2);
+        } else {
+          sc(SC_SYMORTHO, r_a1, r_tau, r_omega);  // (cs, sn, rr) in r_a1 .. r_a1 + 2
+          sc(SC_MUL, r_tau, r_omega, r_a1);
+          sc(SC_MUL, r_a2, r_a1, r_a1);            // cs^2
+          sc(SC_MUL, r_a3, r_a1 + 1, r_a1 + 1);    // sn^2
+          axpy(x, R(r_a2), d);
+          scale(d, R(r_a3));
+        }
+        if (half == 0) {
+          axpy(y, mR(r_alpha), v);
+          mul_side(s_, z, y);
+        }
+      }
+      if (l1) {
+        sc(SC_ADVANCE, 0, r_tau);
+      } else {
+        sc(SC_MUL, R_ERR, r_tau, imm(std::sqrt(2.0 * (double)it + 3.0)));
+        sc(SC_ADVANCE, 0, R_ERR);
+      }
+    } break;
+
+    case STORM_HIP_RICHARDSON: {  // SolverRichardson.hpp:73-96
+      axpy(x, num(relaxation), r);
+      residual(r, b, x);
+      if (P) std::swap(z, r), pre(r, z);
+      norm_to_err_and(SC_ADVANCE, r);
+    } break;
+
+    case STORM_HIP_BICGSTAB_L: {  // SolverBiCgStab.hpp:235-367
+      const int l = inner, j = (int)(it % l);
+      const int G = r_gamma, GB = r_a1, GBB = r_a2, SG = r_a3;
+      auto TAU = [&](int i, int jj) { return r_a4 + i * (l + 1) + jj; };
+      if (it == 0) {
+        copy(us[0], rs[0]);
+      } else {
+        sc(SC_MOV, r_a0, r_rho);
+        dot(r_rho, rt, rs[j]);
+        sc(SC_MUL, R_T0, r_alpha, r_rho);
+        sc(SC_SDIV, r_beta, R_T0, r_a0);
+        for (int i = 0; i <= j; ++i) lin(us[i], {{num(1.0), rs[i]}, {mR(r_beta), us[i]}});
+      }
+      if (P) apply(z, us[j]), pre(us[j + 1], z);
+      else apply(us[j + 1], us[j]);
+      dot(R_T0, rt, us[j + 1]);
+      sc(SC_SDIV, r_alpha, r_rho, R_T0);
+      for (int i = 0; i <= j; ++i) axpy(rs[i], mR(r_alpha), us[i + 1]);
+      axpy(x, R(r_alpha), us[0]);
+      if (P) apply(z, rs[j]), pre(rs[j + 1], z);
+      else apply(rs[j + 1], rs[j]);
+      if (j == l - 1) {
+        for (int jj = 1; jj <= l; ++jj) {
+          for (int i = 1; i < jj; ++i) {
+            dot(R_T0, rs[i], rs[jj]);
+            sc(SC_SDIV, TAU(i, jj), R_T0, SG + i);
+            axpy(rs[jj], mR(TAU(i, jj)), rs[i]);
+          }
+          dots(rs[jj], {{SG + jj, rs[jj]}, {R_T0, rs[0]}});
+          sc(SC_SDIV, GB + jj, R_T0, SG + jj);
+        }
+        sc(SC_MOV, G + l, GB + l);
+        sc(SC_MOV, r_omega, G + l);
+        sc(SC_NEG, R_T0, r_omega);
+        sc(SC_MUL, r_rho, r_rho, R_T0);
+        for (int jj = l - 1; jj != 0; --jj) {
+          sc(SC_MOV, G + jj, GB + jj);
+          for (int i = jj + 1; i <= l; ++i) sc(SC_FMSUB, G + jj, TAU(jj, i), G + i);
+        }
+        for (int jj = 1; jj < l; ++jj) {
+          sc(SC_MOV, GBB + jj, G + jj + 1);
+          for (int i = jj + 1; i < l; ++i) sc(SC_FMADD, GBB + jj, TAU(jj, i), G + i + 1);
+        }
+        axpy(x, R(G + 1), rs[0]);
+        axpy(rs[0], mR(GB + l), rs[l]);
+        axpy(us[0], mR(G + l), us[l]);
+        for (int jj = 1; jj < l; ++jj) {
+          axpy(x, R(GBB + jj), rs[jj]);
+          axpy(rs[0], mR(GB + jj), rs[jj]);
+          axpy(us[0], mR(G + jj), us[jj]);
+        }
+      }
+      norm_to_err_and(SC_ADVANCE, rs[0]);
+    } break;
+
+    case STORM_HIP_IDRS: {  // SolverIdrs.hpp:109-281
+      const int s = inner, k = (int)(it % s);
+      const int PHI = r_a0, GAM = r_gamma;
+      auto MU = [&](int i, int jj) { return r_a1 + i * s + jj; };
+      if (k == 0) {  // inner_init :109-156
+        if (it == 0) {
+          sc(SC_MOV, r_omega, R_ONE);
+          sc(SC_MOV, MU(0, 0), R_ONE);
+          copy(ps[0], r);
+          divide(ps[0], PHI);
+          for (int i = 1; i < s; ++i) {
+            sc(SC_MOV, MU(i, i), R_ONE);
+            sc(SC_MOV, PHI + i, R_ZERO);
+            flush();
+            if (ok()) {
+              const int st = storm_hip_fill_randomly(ps[i]);
+              if (st != STORM_HIP_OK) fail(st);
+            }
+            for (int jj = 0; jj < i; ++jj) {
+              sc(SC_MOV, MU(i, jj), R_ZERO);
+              dot(R_T0, ps[i], ps[jj]);
+              axpy(ps[i], mR(R_T0), ps[jj]);
+            }
+            dot(R_T0, ps[i], ps[i]);
+            sc(SC_SQRT, R_T1, R_T0);
+            divide(ps[i], R_T1);
+          }
+        } else {
+          std::vector<std::pair<int, const storm_hip_vec *>> outs;
+          for (int i = 0; i < s; ++i) outs.push_back({PHI + i, ps[i]});
+          dots_v(r, outs);
+        }
+      }
+      for (int i = k; i < s; ++i) {  // :182-188
+        sc(SC_MOV, GAM + i, PHI + i);
+        for (int jj = k; jj < i; ++jj) sc(SC_FMSUB, GAM + i, MU(i, jj), GAM + jj);
+        sc(SC_DIV, GAM + i, GAM + i, MU(i, i));
+      }
+      {
+        std::vector<Term> tv{{num(1.0), r}};
+        for (int i = k; i < s; ++i) tv.push_back({mR(GAM + i), gs[i]});
+        lin_v(v, tv);  // :200-203
+      }
+      if (right()) std::swap(z, v), pre(v, z);
+      {
+        std::vector<Term> tu{{R(r_omega), v}, {R(GAM + k), us[k]}};
+        for (int i = k + 1; i < s; ++i) tu.push_back({R(GAM + i), us[i]});
+        lin_v(us[k], tu);  // :208-211
+      }
+      if (left()) apply(z, us[k]), pre(gs[k], z);
+      else apply(gs[k], us[k]);
+      for (int i = 0; i < k; ++i) {  // :230-235
+        dot(R_T0, ps[i], gs[k]);
+        sc(SC_SDIV, r_alpha, R_T0, MU(i, i));
+        axpy(us[k], mR(r_alpha), us[i]);
+        axpy(gs[k], mR(r_alpha), gs[i]);
+      }
+      {
+        std::vector<std::pair<int, const storm_hip_vec *>> outs;
+        for (int i = k; i < s; ++i) outs.push_back({MU(i, k), ps[i]});
+        dots_v(gs[k], outs);  // :236-238
+      }
+      sc(SC_SDIV, r_beta, PHI + k, MU(k, k));
+      for (int i = k + 1; i < s; ++i) sc(SC_FMSUB, PHI + i, r_beta, MU(i, k));
+      axpy(x, R(r_beta), us[k]);
+      axpy(r, mR(r_beta), gs[k]);
+      if (k == s - 1) {  // :256-279
+        mul_side(v, z, r);
+        dots(v, {{R_T0, r}, {R_T1, v}});
+        sc(SC_SDIV, r_omega, R_T0, R_T1);
+        axpy(x, R(r_omega), right() ? z : r);
+        axpy(r, mR(r_omega), v);
+      }
+      norm_to_err_and(SC_ADVANCE, r);
+    } break;
+
+    case STORM_HIP_GMRES:
+    case STORM_HIP_FGMRES: {  // Solver.hpp:236-248 around SolverGmres.hpp:119-192
+      const int m = inner, k = (int)(it % m);
+      const bool flexible = method == STORM_HIP_FGMRES;
+      const bool lp = P && !flexible && side == STORM_HIP_LEFT, rp = P && (flexible || side == STORM_HIP_RIGHT);
+      if (k == 0) gmres_start(false);
+      V qn = qs[k + 1];
+      if (lp) apply(zs[0], qs[k]), pre(qn, zs[0]);
+      else if (rp) pre(zs[flexible ? k : 0], qs[k]), apply(qn, zs[flexible ? k : 0]);
+      else apply(qn, qs[k]);
+      flush();
+      if (ok()) {
+        std::vector<const double *> qd(m + 1);
+        for (int i = 0; i <= m; ++i) qd[i] = qs[i]->d;
+        const int st = gmres_orthogonalize(c, n, d_st, dp, qn->d, qd.data(), k, m, S + H0, S + R_T0, S + r_a0,
+                                           gram_schmidt);
+        if (st != STORM_HIP_OK) fail(st);
+      }
+      sc(SC_SQRT, r_hn, R_T0);
+      divide(qn, r_hn);
+      prog.aux[0] = H0, prog.aux[1] = B0, prog.aux[2] = CS0, prog.aux[3] = SN0, prog.aux[4] = m;
+      sc(SC_GIVENS, R_ERR, k, r_hn);
+      sc(SC_ADVANCE, 0, R_ERR);
+      if (k == m - 1) {
+        flush();
+        gmres_update_x(k);
+      }
+    } break;
+  }
+  flush();
+}
+
+// IterativeSolver::finalize (none of the plain solvers has one) / InnerOuterIterativeSolver::finalize, Solver.hpp:250-257.
+void K::finalize(int64_t iterations, bool forced) {
+  if (method != STORM_HIP_GMRES && method != STORM_HIP_FGMRES) return;
+  // The in-loop update of the last iteration was skipped by the `done` predicate (or, when stepping, must not be
+  // repeated: it already ran if that iteration closed a restart cycle).  With no iterate() at all the reference
+  // divides by H(0,0) = 0 here; not reproduced.
+  if (iterations <= 0) return;
+  const int k = (int)((iterations - 1) % inner);
+  if (!forced && k == inner - 1) return;
+  const int *saved = dp;
+  dp = nullptr;
+  gmres_update_x(k);
+  flush();
+  dp = saved;
+}
+
+// ---- host-side driving -----------------------------------------------------------------------------------------
+namespace {
+
+int check_ready(K *k, const storm_hip_vec *b, storm_hip_vec *x, const storm_hip_solver_params *p) {
+  STORM_REQUIRE(k && b && x && p, "krylov: null argument");
+  STORM_REQUIRE(k->op != nullptr || k->op_fn != nullptr, "krylov: no operator set");
+  STORM_REQUIRE(b->ctx == k->c && x->ctx == k->c, "krylov: context mismatch");
+  STORM_REQUIRE(b != x && b->d != x->d, "krylov: b and x must not alias");
+  STORM_REQUIRE(b->n_owned == x->n_owned, "krylov: b has %lld rows, x %lld", (long long)b->n_owned,
+                (long long)x->n_owned);
+  if (k->op) {
+    STORM_REQUIRE(k->op->ctx == k->c, "krylov: operator belongs to another context");
+    STORM_REQUIRE(x->n_owned == k->op->n_rows, "krylov: operator has %lld rows, x %lld", (long long)k->op->n_rows,
+                  (long long)x->n_owned);
+    STORM_REQUIRE(x->n_halo >= k->op->n_halo, "krylov: x has %lld halo rows, operator needs %lld",
+                  (long long)x->n_halo, (long long)k->op->n_halo);
+  }
+  if (k->pre_diag) STORM_REQUIRE(k->pre_diag->n_owned == x->n_owned, "krylov: diagonal preconditioner size mismatch");
+  STORM_REQUIRE(p->num_iterations >= 0, "krylov: num_iterations < 0");
+  return STORM_HIP_OK;
+}
+
+void release_work(K *k) {
+  for (auto *w : k->work) storm_hip_vec_destroy(w);
+  k->work.clear();
+  k->qs.clear(), k->zs.clear(), k->rs.clear(), k->us.clear(), k->ps.clear(), k->gs.clear();
+  if (k->d_history) (void)hipFree(k->d_history), k->d_history = nullptr;
+  k->active = false;
+}
+
+// Common start of solve() and init(): state, registers, work vectors, init() enqueued.
+int begin_solve(K *k, const storm_hip_vec *b, storm_hip_vec *x, const storm_hip_solver_params *p, bool stepping,
+                double *history) {
+  storm_hip_ctx *c = k->c;
+  STORM_TRY(check_ready(k, b, x, p));
+  HIP_TRY(hipSetDevice(c->device));
+  release_work(k);
+  k->b = b, k->x = x, k->n = x->n_owned, k->status = STORM_HIP_OK, k->stepping = stepping;
+  k->gram_schmidt = p->gram_schmidt;
+  k->lag = p->check_lag > 0 ? p->check_lag : 4;
+  if (k->lag > kStateRing - 1) k->lag = kStateRing - 1;
+  switch (k->method) {
+    case STORM_HIP_GMRES:
+    case STORM_HIP_FGMRES: k->inner = (int)(p->num_inner_iterations > 0 ? p->num_inner_iterations : 50); break;
+    case STORM_HIP_BICGSTAB_L: k->inner = (int)(p->num_inner_iterations > 0 ? p->num_inner_iterations : 2); break;
+    case STORM_HIP_IDRS: k->inner = (int)(p->num_inner_iterations > 0 ? p->num_inner_iterations : 4); break;
+    default: k->inner = 0;
+  }
+  if (k->method == STORM_HIP_BICGSTAB_L || k->method == STORM_HIP_IDRS)
+    STORM_REQUIRE(k->inner <= 48, "krylov: num_inner_iterations = %d too large for this method (<= 48)", k->inner);
+  if (k->method == STORM_HIP_IDRS)
+    STORM_REQUIRE(c->comm == nullptr, "krylov: IDR(s) draws its shadow space with fill_randomly, single rank only");
+  k->reset_prog(), k->red_pending = false;
+  k->dp = nullptr;
+  k->applies = k->pre_applies = 0;
+  k->it_enqueued = 0;
+  k->active = true;
+  k->setup();
+  if (!k->ok()) return k->status;
+  // register file
+  if (k->S_top > k->S_cap) {
+    if (k->S) (void)hipFree(k->S);
+    k->S = nullptr, k->S_cap = 0;
+    HIP_TRY(hipMalloc((void **)&k->S, sizeof(double) * (size_t)k->S_top));
+    k->S_cap = k->S_top;
+  }
+  HIP_TRY(hipMemsetAsync(k->S, 0, sizeof(double) * (size_t)k->S_top, c->stream));
+  {
+    static const double one = 1.0;
+    HIP_TRY(hipMemcpyAsync(k->S + R_ONE, &one, sizeof(double), hipMemcpyHostToDevice, c->stream));
+  }
+  // solver state
+  SolverState h;
+  memset(&h, 0, sizeof h);
+  h.abs_tol = stepping ? 0.0 : p->absolute_error_tolerance;  // stepping: the caller owns the convergence decision
+  h.rel_tol = stepping ? 0.0 : p->relative_error_tolerance;
+  h.num_iterations = stepping ? (1LL << 62) : p->num_iterations;
+  h.done_ring = k->d_ring;
+  for (int i = 0; i < kStateRing; ++i) k->h_ring[i] = 0;
+  if (history && !stepping) {
+    HIP_TRY(hipMalloc((void **)&k->d_history, sizeof(double) * (size_t)(p->num_iterations + 1)));
+    HIP_TRY(hipMemsetAsync(k->d_history, 0, sizeof(double) * (size_t)(p->num_iterations + 1), c->stream));
+    h.history = k->d_history;
+  }
+  *k->h_st = h;
+  HIP_TRY(hipMemcpyAsync(k->d_st, k->h_st, sizeof(SolverState), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  k->init();
+  k->applies_after.assign(1, k->applies);
+  k->pre_after.assign(1, k->pre_applies);
+  k->dp = &k->d_st->done;
+  return k->status;
+}
+
+int read_state(K *k) {
+  HIP_TRY(hipMemcpyAsync(k->h_st, k->d_st, sizeof(SolverState), hipMemcpyDeviceToHost, k->c->stream));
+  HIP_TRY(hipStreamSynchronize(k->c->stream));
+  return STORM_HIP_OK;
+}
+
+typedef int (*fused_entry)(const storm_hip_op *, double, double, const storm_hip_vec *, storm_hip_vec *,
+                           const storm_hip_solver_params *, storm_hip_solver_result *, double *);
+
+}  // namespace
+
+extern "C" {
+
+int storm_hip_krylov_create(storm_hip_ctx *ctx, int method, storm_hip_krylov **out) {
+  STORM_REQUIRE(ctx && out, "krylov_create: null argument");
+  STORM_REQUIRE(method >= STORM_HIP_CG && method <= STORM_HIP_RICHARDSON, "krylov_create: unknown method %d", method);
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(ctx->device));
+  auto *k = new storm_hip_krylov();
+  k->c = ctx, k->method = method;
+  HIP_TRY(hipMalloc((void **)&k->d_st, sizeof(SolverState)));
+  HIP_TRY(hipMemset(k->d_st, 0, sizeof(SolverState)));
+  HIP_TRY(hipHostMalloc((void **)&k->h_st, sizeof(SolverState), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void **)&k->h_ring, sizeof(int) * kStateRing, hipHostMallocMapped));
+  HIP_TRY(hipHostGetDevicePointer((void **)&k->d_ring, k->h_ring, 0));
+  k->ev.resize(kStateRing);
+  for (auto &e : k->ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  *out = k;
+  return STORM_HIP_OK;
+}
+
+int storm_hip_krylov_destroy(storm_hip_krylov *k) {
+  if (!k) return STORM_HIP_OK;
+  (void)hipSetDevice(k->c->device);
+  (void)hipStreamSynchronize(k->c->stream);
+  release_work(k);
+  for (auto &e : k->ev) (void)hipEventDestroy(e);
+  if (k->S) (void)hipFree(k->S);
+  (void)hipFree(k->d_st);
+  (void)hipHostFree(k->h_st);
+  (void)hipHostFree(k->h_ring);
+  delete k;
+  return STORM_HIP_OK;
+}
+
+int storm_hip_krylov_set_operator(storm_hip_krylov *k, const storm_hip_op *op, double alpha, double beta) {
+  STORM_REQUIRE(k && op, "krylov_set_operator: null argument");
+  k->op = op, k->op_alpha = alpha, k->op_beta = beta, k->op_fn = nullptr, k->op_user = nullptr;
+  return STORM_HIP_OK;
+}
+
+int storm_hip_krylov_set_operator_fn(storm_hip_krylov *k, storm_hip_apply_fn apply, void *user) {
+  STORM_REQUIRE(k && apply, "krylov_set_operator_fn: null argument");
+  k->op = nullptr, k->op_fn = apply, k->op_user = user;
+  return STORM_HIP_OK;
+}
+
+int storm_hip_krylov_set_preconditioner_fn(storm_hip_krylov *k, storm_hip_apply_fn apply, void *user, int side) {
+  STORM_REQUIRE(k, "krylov_set_preconditioner_fn: null solver");
+  STORM_REQUIRE(side >= STORM_HIP_LEFT && side <= STORM_HIP_SYMMETRIC, "krylov: unknown preconditioner side %d", side);
+  k->pre_fn = apply, k->pre_user = user, k->pre_diag = nullptr, k->side = side;
+  return STORM_HIP_OK;
+}
+
+int storm_hip_krylov_set_preconditioner_diag(storm_hip_krylov *k, const storm_hip_vec *d, int side) {
+  STORM_REQUIRE(k, "krylov_set_preconditioner_diag: null solver");
+  STORM_REQUIRE(side >= STORM_HIP_LEFT && side <= STORM_HIP_SYMMETRIC, "krylov: unknown preconditioner side %d", side);
+  STORM_REQUIRE(d == nullptr || d->ctx == k->c, "krylov: preconditioner diagonal belongs to another context");
+  k->pre_fn = nullptr, k->pre_user = nullptr, k->pre_diag = d, k->side = side;
+  return STORM_HIP_OK;
+}
+
+int storm_hip_krylov_set_real(storm_hip_krylov *k, const char *key, double value) {
+  STORM_REQUIRE(k && key, "krylov_set_real: null argument");
+  if (!strcmp(key, "relaxation_factor")) k->relaxation = value;
+  else STORM_FAIL(STORM_HIP_E_INVALID, "krylov_set_real: unknown key '%s'", key);
+  return STORM_HIP_OK;
+}
+
+int storm_hip_krylov_solve(storm_hip_krylov *k, const storm_hip_vec *b, storm_hip_vec *x,
+                           const storm_hip_solver_params *params, storm_hip_solver_result *result, double *history,
+                           int64_t *pre_applies) {
+  STORM_REQUIRE(k && result, "krylov_solve: null argument");
+  STORM_TRY(check_ready(k, b, x, params));
+  storm_hip_ctx *c = k->c;
+  // A stencil operator without preconditioner: CG / BiCGStab / GMRES have fused kernels (solvers.hip).
+  if (k->op != nullptr && !k->has_pre() && c->opt_generic_solvers == 0) {
+    fused_entry fused = k->method == STORM_HIP_CG         ? &storm_hip_solve_cg
+                        : k->method == STORM_HIP_BICGSTAB ? &storm_hip_solve_bicgstab
+                        : k->method == STORM_HIP_GMRES && params->num_inner_iterations < kMaxMulti
+                            ? &storm_hip_solve_gmres  // (its state slab holds restarts below kMaxMulti)
+                            : nullptr;
+    if (fused != nullptr) {
+      if (pre_applies) *pre_applies = 0;
+      return fused(k->op, k->op_alpha, k->op_beta, b, x, params, result, history);
+    }
+  }
+  int st = begin_solve(k, b, x, params, false, history);
+  for (int64_t it = 0; st == STORM_HIP_OK && it < params->num_iterations; ++it) {
+    k->iterate(it);
+    st = k->status;
+    if (st != STORM_HIP_OK) break;
+    k->it_enqueued = it + 1;
+    k->applies_after.push_back(k->applies);
+    k->pre_after.push_back(k->pre_applies);
+    // post a marker behind this iteration; look at the verdict of iteration it - lag
+    const int slot = (int)(it % kStateRing);
+    HIP_TRY(hipEventRecord(k->ev[slot], c->stream));
+    if (it >= k->lag) {
+      const int old = (int)((it - k->lag) % kStateRing);
+      HIP_TRY(hipEventSynchronize(k->ev[old]));
+      const bool stop = *(volatile int *)&k->h_ring[old] != 0;
+      k->h_ring[old] = 0;
+      if (stop) break;
+    }
+  }
+  if (st == STORM_HIP_OK) st = read_state(k);
+  if (st == STORM_HIP_OK) {
+    const int64_t iters = k->h_st->iteration;
+    const int64_t a0 = k->applies, p0 = k->pre_applies;
+    k->finalize(iters, true);
+    st = k->status;
+    const size_t at = (size_t)std::min<int64_t>(iters, (int64_t)k->applies_after.size() - 1);
+    result->iterations = iters;
+    result->absolute_error = k->h_st->absolute_error;
+    result->relative_error = k->h_st->relative_error;
+    result->initial_error = k->h_st->initial_error;
+    result->converged = k->h_st->converged;
+    result->num_applies = k->applies_after[at] + (k->applies - a0);
+    if (pre_applies) *pre_applies = k->pre_after[at] + (k->pre_applies - p0);
+    if (st == STORM_HIP_OK && history && k->d_history)
+      HIP_TRY(hipMemcpy(history, k->d_history, sizeof(double) * (size_t)(iters + 1), hipMemcpyDeviceToHost));
+    if (st == STORM_HIP_OK) HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  (void)hipStreamSynchronize(c->stream);
+  release_work(k);
+  return st;
+}
+
+int storm_hip_krylov_init(storm_hip_krylov *k, const storm_hip_vec *b, storm_hip_vec *x,
+                          const storm_hip_solver_params *params, double *initial_error) {
+  STORM_REQUIRE(k && initial_error, "krylov_init: null argument");
+  int st = begin_solve(k, b, x, params, true, nullptr);
+  if (st == STORM_HIP_OK) st = read_state(k);
+  if (st != STORM_HIP_OK) {
+    release_work(k);
+    return st;
+  }
+  *initial_error = k->h_st->initial_error;
+  return STORM_HIP_OK;
+}
+
+int storm_hip_krylov_iterate(storm_hip_krylov *k, double *error) {
+  STORM_REQUIRE(k && error, "krylov_iterate: null argument");
+  STORM_REQUIRE(k->active && k->stepping, "krylov_iterate: no storm_hip_krylov_init before");
+  HIP_TRY(hipSetDevice(k->c->device));
+  k->iterate(k->it_enqueued);
+  if (!k->ok()) return k->status;
+  k->it_enqueued += 1;
+  STORM_TRY(read_state(k));
+  *error = k->h_st->absolute_error;
+  return STORM_HIP_OK;
+}
+
+int storm_hip_krylov_finalize(storm_hip_krylov *k) {
+  STORM_REQUIRE(k, "krylov_finalize: null solver");
+  STORM_REQUIRE(k->active && k->stepping, "krylov_finalize: no storm_hip_krylov_init before");
+  HIP_TRY(hipSetDevice(k->c->device));
+  k->finalize(k->it_enqueued, false);
+  const int st = k->status;
+  (void)hipStreamSynchronize(k->c->stream);
+  release_work(k);
+  return st;
+}
+
+}  // extern "C"

@@ -1,0 +1,54 @@
+// Device-side pieces shared by the solver translation units (solvers.hip: the fused CG / BiCGStab / GMRES
+// loops of a stencil operator; krylov.hip: the general Krylov engine): the reference's scalar helpers and the
+// body of IterativeSolver::solve's loop, evaluated on the device against a SolverState.
+#pragma once
+
+#include "common.hpp"
+
+namespace storm {
+
+// Crow/MathUtils.hpp:49-52
+__device__ __forceinline__ double safe_divide(double x, double y) { return (y == 0.0) ? 0.0 : (x / y); }
+
+// The body of the for loop in IterativeSolver::solve, Solver.hpp:132-140.
+__device__ inline void advance(SolverState *st, double abs_err) {
+  st->absolute_error = abs_err;
+  st->relative_error = abs_err / st->initial_error;
+  bool conv = false;
+  conv |= (st->abs_tol > 0.0) && (st->absolute_error < st->abs_tol);
+  conv |= (st->rel_tol > 0.0) && (st->relative_error < st->rel_tol);
+  st->iteration += 1;
+  if (st->history) st->history[st->iteration] = abs_err;
+  if (conv) st->converged = 1;
+  if (conv || st->iteration >= st->num_iterations) st->done = 1;
+  // Tell the host (it polls this pinned ring `check_lag` iterations behind; the event it waits on
+  // is recorded after this kernel, so the store is visible by then).
+  if (st->done_ring) st->done_ring[(st->iteration - 1) % kStateRing] = st->done;
+}
+
+// After init(): Solver.hpp:122-128.
+__device__ inline void begin(SolverState *st, double initial_error) {
+  st->initial_error = initial_error;
+  st->absolute_error = initial_error;
+  st->relative_error = 0.0;
+  st->iteration = 0;
+  st->converged = 0;
+  st->done = 0;
+  if (st->history) st->history[0] = initial_error;
+  if (st->abs_tol > 0.0 && initial_error < st->abs_tol) st->converged = 1, st->done = 1;
+  if (st->num_iterations <= 0) st->done = 1;
+  if (st->done && st->done_ring)  // no iterate() will run: every poll must see it
+    for (int i = 0; i < kStateRing; ++i) st->done_ring[i] = 1;
+}
+
+__device__ __forceinline__ double block_sum256(double v, double *lds4) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) lds4[wave] = v;
+  __syncthreads();
+  return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+}
+
+}  // namespace storm

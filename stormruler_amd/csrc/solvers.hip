@@ -18,6 +18,7 @@
 #include <cstring>
 
 #include "common.hpp"
+#include "solver_device.hpp"
 
 namespace storm {
 
@@ -28,40 +29,6 @@ enum Slot {
   S_TMP, S_HN,
   S_SCRATCH = 32,
 };
-
-// Crow/MathUtils.hpp:49-52
-__device__ __forceinline__ double safe_divide(double x, double y) { return (y == 0.0) ? 0.0 : (x / y); }
-
-// The body of the for loop in IterativeSolver::solve, Solver.hpp:132-140.
-__device__ void advance(SolverState *st, double abs_err) {
-  st->absolute_error = abs_err;
-  st->relative_error = abs_err / st->initial_error;
-  bool conv = false;
-  conv |= (st->abs_tol > 0.0) && (st->absolute_error < st->abs_tol);
-  conv |= (st->rel_tol > 0.0) && (st->relative_error < st->rel_tol);
-  st->iteration += 1;
-  if (st->history) st->history[st->iteration] = abs_err;
-  if (conv) st->converged = 1;
-  if (conv || st->iteration >= st->num_iterations) st->done = 1;
-  // Tell the host (it polls this pinned ring `check_lag` iterations behind; the event it waits on
-  // is recorded after this kernel, so the store is visible by then).
-  if (st->done_ring) st->done_ring[(st->iteration - 1) % kStateRing] = st->done;
-}
-
-// After init(): Solver.hpp:122-128.
-__device__ void begin(SolverState *st, double initial_error) {
-  st->initial_error = initial_error;
-  st->absolute_error = initial_error;
-  st->relative_error = 0.0;
-  st->iteration = 0;
-  st->converged = 0;
-  st->done = 0;
-  if (st->history) st->history[0] = initial_error;
-  if (st->abs_tol > 0.0 && initial_error < st->abs_tol) st->converged = 1, st->done = 1;
-  if (st->num_iterations <= 0) st->done = 1;
-  if (st->done && st->done_ring)  // no iterate() will run: every poll must see it
-    for (int i = 0; i < kStateRing; ++i) st->done_ring[i] = 1;
-}
 
 enum StepKind {
   STEP_NONE = 0,
@@ -122,16 +89,6 @@ __device__ void do_step(int kind, SolverState *st, GmresDev g) {
       break;
     default: break;
   }
-}
-
-__device__ __forceinline__ double block_sum256(double v, double *lds4) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-  __syncthreads();
-  if (lane == 0) lds4[wave] = v;
-  __syncthreads();
-  return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
 }
 
 struct OutSlots {
@@ -389,12 +346,12 @@ __global__ __launch_bounds__(kBlock) void bicg_update_kernel(int64_t n, SolverSt
 // per-block partials: every block folds them itself in the same fixed order (so all blocks hold the
 // same h) and block 0 stores it into the Hessenberg -- the separate final-reduction launch between two
 // steps disappears, which is what a 128^3 problem (launch-bound MGS chain) is made of.
-__global__ __launch_bounds__(kBlock) void mgs_step_kernel(int64_t n, const SolverState *st, double *__restrict__ w,
+__global__ __launch_bounds__(kBlock) void mgs_step_kernel(int64_t n, const int *done, double *__restrict__ w,
                                                           const double *h, const double *__restrict__ in_partials,
                                                           int n_in, double *h_store,
                                                           const double *__restrict__ qa,
                                                           const double *qb, double *__restrict__ partials, int nt) {
-  if (st->done) return;
+  if (done && *done) return;
   __shared__ double lds4[4];
   double hv;
   if (in_partials) {
@@ -466,10 +423,11 @@ __global__ void gmres_givens_kernel(SolverState *st, GmresDev g, int k) {
 #undef H_
 }
 
-// Classical Gram-Schmidt x2: H(0:k, k) = h_pass0 + h_pass1.
-__global__ void gmres_cgs2_combine_kernel(SolverState *st, GmresDev g, int k) {
-  if (st->done) return;
-  for (int i = 0; i <= k; ++i) g.H[i * g.m + k] = st->s[S_SCRATCH + i] + st->s[S_SCRATCH + kMaxMulti + i];
+// Classical Gram-Schmidt x2: H(j0 : j0 + kk, k) = h_pass0 + h_pass1.
+__global__ void gmres_cgs2_combine_kernel(const int *done, double *H, int m, int k, int j0, int kk,
+                                          const double *scratch) {
+  if (done && *done) return;
+  for (int i = 0; i < kk; ++i) H[(j0 + i) * m + k] = scratch[i] + scratch[kMaxMulti + i];
 }
 
 // GMRES: back substitution, SolverGmres.hpp:207-212.
@@ -673,6 +631,84 @@ struct IterationGraph {
 static int64_t applies_cg(int64_t it, int64_t) { return 1 + it; }
 static int64_t applies_bicg(int64_t it, int64_t) { return 1 + 2 * it; }
 static int64_t applies_gmres(int64_t it, int64_t m) { return 1 + it + (it + m - 1) / m; }
+
+}  // namespace storm
+
+namespace storm {
+
+// Orthogonalise w = q_{k+1} against q_0 .. q_k (SolverGmres.hpp:157-161): H(0..k, k) and <w, w> (into *norm2_out;
+// the caller takes the root and normalises).  H is the (m+1) x m row-major device Hessenberg.
+//   gram_schmidt == 0: modified Gram-Schmidt with exactly the reference's values -- H(0,k) = <w,q_0>, then every
+//     step applies  w -= H(i,k) q_i  and already accumulates the next reduction (<w,q_{i+1}>, or <w,w>);
+//   gram_schmidt == 1: classical Gram-Schmidt applied twice (2 multi-dots + 2 multi-axpys, batched reductions);
+//     `scratch` = 2 * kMaxMulti doubles for the two passes' coefficients.
+// Shared by storm_hip_solve_gmres below and by the general engine (krylov.hip).
+int gmres_orthogonalize(storm_hip_ctx *c, int64_t n, const SolverState *st, const int *done, double *qn,
+                        const double *const *q, int k, int m, double *H, double *norm2_out, double *scratch,
+                        int gram_schmidt) {
+  const int nbv = stream_blocks(n);
+  if (n <= 0) {  // an empty rank: zeros (and its share of the all-reduces)
+    for (int i = 0; i <= k; ++i) {
+      HIP_TRY(hipMemsetAsync(&H[i * m + k], 0, sizeof(double), c->stream));
+      if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, &H[i * m + k], 1));
+    }
+    HIP_TRY(hipMemsetAsync(norm2_out, 0, sizeof(double), c->stream));
+    if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, norm2_out, 1));
+    return STORM_HIP_OK;
+  }
+  if (gram_schmidt == 0) {
+    const bool fold_in_consumer = c->comm == nullptr && nbv <= 2048 && 2 * (int64_t)nbv <= c->partials_capacity &&
+                                  c->opt_fuse_mgs != 0;
+    if (fold_in_consumer) {
+      // partials ping-pong between two halves of the workspace: step i folds what step i-1 wrote
+      double *cur = c->d_partials, *nxt = c->d_partials + nbv;
+      STORM_TRY(k_dot_partials(c, qn, q[0], n, cur, nbv, done));
+      for (int i = 0; i <= k; ++i) {
+        const double *qb = i < k ? q[i + 1] : nullptr;
+        hipLaunchKernelGGL(mgs_step_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, done, qn,
+                           (const double *)nullptr, cur, nbv, &H[i * m + k], q[i], qb, nxt,
+                           (int)(c->opt_blas1_nt != 0));
+        HIP_TRY(hipGetLastError());
+        std::swap(cur, nxt);
+      }
+      return k_reduce_final(c, cur, nbv, 1, norm2_out, done);  // <w, w>
+    }
+    {
+      const double *bs[1] = {q[0]};
+      STORM_TRY(k_multi_dot(c, qn, bs, 1, n, &H[0 * m + k], done));
+      if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, &H[0 * m + k], 1));
+    }
+    for (int i = 0; i <= k; ++i) {
+      double *h = &H[i * m + k];
+      const double *qb = i < k ? q[i + 1] : nullptr;
+      double *out = i < k ? &H[(i + 1) * m + k] : norm2_out;
+      hipLaunchKernelGGL(mgs_step_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, done, qn, h,
+                         (const double *)nullptr, 0, (double *)nullptr, q[i], qb, c->d_partials,
+                         (int)(c->opt_blas1_nt != 0));
+      HIP_TRY(hipGetLastError());
+      STORM_TRY(k_reduce_final(c, c->d_partials, nbv, 1, out, done));
+      if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, out, 1));
+    }
+    return STORM_HIP_OK;
+  }
+  // classical Gram-Schmidt applied twice; the second pass's coefficients are added to the first's (same span)
+  for (int j0 = 0; j0 <= k; j0 += kMaxMulti) {  // restarts longer than one launch is wide: in chunks
+    const int kk = std::min(k + 1 - j0, kMaxMulti);
+    for (int pass = 0; pass < 2; ++pass) {
+      STORM_TRY(k_multi_dot(c, qn, q + j0, kk, n, scratch + pass * kMaxMulti, done));
+      if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, scratch + pass * kMaxMulti, kk));
+      STORM_TRY(k_multi_axpy(c, qn, scratch + pass * kMaxMulti, -1.0, q + j0, kk, n, done));
+    }
+    hipLaunchKernelGGL(gmres_cgs2_combine_kernel, dim3(1), dim3(1), 0, c->stream, done, H, m, k, j0, kk, scratch);
+    HIP_TRY(hipGetLastError());
+  }
+  {
+    const double *bs[1] = {qn};
+    STORM_TRY(k_multi_dot(c, qn, bs, 1, n, norm2_out, done));  // :161
+    if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, norm2_out, 1));
+  }
+  return STORM_HIP_OK;
+}
 
 }  // namespace storm
 
@@ -900,60 +936,9 @@ int storm_hip_solve_gmres(const storm_hip_op *op, double alpha, double beta, con
     if (k == 0) STORM_TRY(start(false));                 // Solver.hpp:240-242
     double *qn = const_cast<double *>(q[k + 1]);
     STORM_TRY(d.apply(q[k], qn, nullptr, false, &nb));   // SolverGmres.hpp:155
-    if (params->gram_schmidt == 0) {
-      // modified Gram-Schmidt (:157-160): H(0,k) = <w,q_0>; then each step applies  w -= H(i,k) q_i
-      // and already accumulates the next reduction (<w,q_{i+1}>, or <w,w> for the norm of :161)
-      const bool fold_in_consumer = c->comm == nullptr && nbv <= 2048 && 2 * (int64_t)nbv <= c->partials_capacity &&
-                                    c->opt_fuse_mgs != 0;
-      if (fold_in_consumer) {
-        // partials ping-pong between two halves of the workspace: step i folds what step i-1 wrote
-        double *cur = c->d_partials, *nxt = c->d_partials + nbv;
-        STORM_TRY(k_dot_partials(c, qn, q[0], n, cur, nbv, d.done));
-        for (int i = 0; i <= k; ++i) {
-          const double *qb = i < k ? q[i + 1] : nullptr;
-          hipLaunchKernelGGL(mgs_step_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, qn,
-                             (const double *)nullptr, cur, nbv, &d.g.H[i * m + k], q[i], qb, nxt,
-                             (int)(c->opt_blas1_nt != 0));
-          HIP_TRY(hipGetLastError());
-          std::swap(cur, nxt);
-        }
-        STORM_TRY(k_reduce_final(c, cur, nbv, 1, d.slot(S_TMP), d.done));  // <w, w>
-      } else {
-      {
-        const double *bs[1] = {q[0]};
-        STORM_TRY(k_multi_dot(c, qn, bs, 1, n, &d.g.H[0 * m + k], d.done));
-        if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, &d.g.H[0 * m + k], 1));
-      }
-      for (int i = 0; i <= k; ++i) {
-        double *h = &d.g.H[i * m + k];
-        const double *qb = i < k ? q[i + 1] : nullptr;
-        double *out = i < k ? &d.g.H[(i + 1) * m + k] : d.slot(S_TMP);
-        hipLaunchKernelGGL(mgs_step_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, qn, h,
-                           (const double *)nullptr, 0, (double *)nullptr, q[i], qb, c->d_partials,
-                           (int)(c->opt_blas1_nt != 0));
-        HIP_TRY(hipGetLastError());
-        STORM_TRY(k_reduce_final(c, c->d_partials, nbv, 1, out, d.done));
-        if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, out, 1));
-      }
-      }
-    } else {
-      // classical Gram-Schmidt applied twice: two multi-dots + two multi-axpys, the second
-      // pass's coefficients are added to the first's (same span, batched reductions).
-      double *h0 = d.slot(S_SCRATCH);  // k + 1 <= 63 scratch slots
-      for (int pass = 0; pass < 2; ++pass) {
-        STORM_TRY(k_multi_dot(c, qn, q.data(), k + 1, n, h0 + pass * kMaxMulti, d.done));
-        if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, h0 + pass * kMaxMulti, k + 1));
-        STORM_TRY(k_multi_axpy(c, qn, h0 + pass * kMaxMulti, -1.0, q.data(), k + 1, n, d.done));
-      }
-      hipLaunchKernelGGL(gmres_cgs2_combine_kernel, dim3(1), dim3(1), 0, c->stream, d.st, d.g, k);
-      HIP_TRY(hipGetLastError());
-    }
+    STORM_TRY(gmres_orthogonalize(c, n, d.st, d.done, qn, q.data(), k, m, d.g.H, d.slot(S_TMP), d.slot(S_SCRATCH),
+                                  params->gram_schmidt));
     {
-      if (params->gram_schmidt != 0) {  // (the fused MGS chain already left <w,w> in S_TMP)
-        const double *bs[1] = {qn};
-        STORM_TRY(k_multi_dot(c, qn, bs, 1, n, d.slot(S_TMP), d.done));                         // :161
-        if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, d.slot(S_TMP), 1));
-      }
       hipLaunchKernelGGL(step_kernel, dim3(1), dim3(1), 0, c->stream, (int)STEP_GMRES_HN, d.st, d.g, false);
       HIP_TRY(hipGetLastError());
       STORM_TRY(k_scale(c, qn, n, dev_scal(d.slot(S_HN)), true, d.done));                       // :162

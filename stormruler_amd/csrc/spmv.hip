@@ -1273,7 +1273,7 @@ int storm_hip_op_apply(const storm_hip_op *op, double alpha, double beta, const 
                 (long long)op->n_rows, (long long)x->n_owned, (long long)y->n_owned);
   STORM_REQUIRE(x->n_halo >= op->n_halo, "op_apply: x has %lld halo rows, operator needs %lld", (long long)x->n_halo,
                 (long long)op->n_halo);
-  return spmv_launch(op, host_scal(alpha), host_scal(beta), x->d, y->d, nullptr, nullptr);
+  return spmv_launch(op, host_scal(alpha), host_scal(beta), x->d, y->d, nullptr, op->ctx->api_done);
 }
 
 int storm_hip_op_apply_add(const storm_hip_op *op, double alpha, const storm_hip_vec *x, storm_hip_vec *y) {
@@ -1284,7 +1284,7 @@ int storm_hip_op_apply_add(const storm_hip_op *op, double alpha, const storm_hip
                 (long long)op->n_rows, (long long)x->n_owned, (long long)y->n_owned);
   STORM_REQUIRE(x->n_halo >= op->n_halo, "op_apply_add: x has %lld halo rows, operator needs %lld", (long long)x->n_halo,
                 (long long)op->n_halo);
-  return spmv_launch(op, host_scal(alpha), host_scal(0.0), x->d, y->d, nullptr, nullptr, true);
+  return spmv_launch(op, host_scal(alpha), host_scal(0.0), x->d, y->d, nullptr, op->ctx->api_done, true);
 }
 
 int storm_hip_op_get_diagonal(const storm_hip_op *op, double alpha, double beta, int invert, storm_hip_vec *d) {

@@ -1,0 +1,144 @@
+"""Full-size, full-solve parity at the BASELINE sizes against the oracle's committed fixtures
+(tests/golden/full_size_*.json, written by tools/make_full_size_fixtures.py from oracle/liboracle.so):
+
+    configs[1]  CG,        7-point Poisson 256^3            526 iterations
+    configs[2]  BiCGStab,  the same 256^3 block per GPU     355 iterations (reference summation order)
+    configs[3]  GMRES(30), convection-diffusion 128^3       376 iterations
+
+Every case runs twice on the device: through the fused loops of csrc/solvers.hip (what a stencil operator gets)
+and through the general engine of csrc/krylov.hip (`generic_solvers = 1`: what a callback operator gets).
+
+CG and GMRES reproduce the fixtures: same iteration count, residual histories and solution samples to 1e-8.
+
+BiCGStab at 256^3 cannot, and the fixture says why: the SAME oracle source with ONLY the order in which its
+dot products add their 16.7 M terms changed (pairwise tree / one long double) or with FMA contraction allowed gives
+350 / 352 / 355 / 361 iterations, and every one of those variants leaves the reference-order history by 1e-8 at
+iteration 10, by 1e-6 at 18, by 1e-3 at 28 and by 10 % before iteration 45 (`summation_order_study`): the recurrence
+amplifies rounding by ~10^2 every 8 iterations, after ~40 iterations no two roundings share a digit and the stopping
+iteration (the residual hovers around the tolerance for the last ~30 iterations) is a draw.  A GPU reduction is a
+tree sum, i.e. one more such variant.  What is asserted for it is therefore what the CPU variants satisfy among
+themselves:
+  * the residual history equals the reference-order one to 1e-6 for the first 12 iterations and to 1e-3 for the
+    first 20 (the variants: 18 and 28),
+  * the solve converges, the TRUE residual |b - A x| / |b| of the returned x is below 1.5e-6,
+  * the solution agrees with the reference-order one to 1e-6 relative at every sampled cell and in norm (two solves
+    that stop at relative residual 1e-6; the CPU variants differ by 6e-8 in norm),
+  * the iteration count is within 10 % of 355 (CPU variants: -1.4 % .. +1.7 %; the device loops land at +5 .. 7 %).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NU, VEL = 1e-2, (1.0, 0.5, 0.25)
+
+
+def _fixture(case):
+    with open(os.path.join(ROOT, "tests", "golden", f"full_size_{case}.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def env():
+    from stormruler_amd import api, mesh
+
+    ctx = api.Context(0)
+    yield api, mesh, ctx
+    ctx.close()
+
+
+@pytest.fixture(scope="module")
+def poisson256(env):
+    api, mesh, ctx = env
+    g = mesh.structured_box(256)
+    mat = api.StencilMatrix.from_face_graph(ctx, g)
+    yield g, mat
+    mat.close()
+
+
+def _solve(api, ctx, solver, op, n_cells, generic):
+    b, x = api.DeviceVector(ctx, n_cells), api.DeviceVector(ctx, n_cells)
+    api.fill_with(b, 1.0)
+    solver.record_history = True
+    ctx.set_option("generic_solvers", int(generic))
+    try:
+        ok = solver.solve(x, b, op)
+    finally:
+        ctx.set_option("generic_solvers", 0)
+    r = api.DeviceVector(ctx, n_cells)
+    op.Residual(r, b, x)
+    true_rel = api.norm_2(r) / api.norm_2(b)
+    return ok, x.to_numpy(), true_rel
+
+
+def _compare_exactly(fx, solver, ok, x, true_rel, hist_tol, x_tol):
+    assert ok and fx["converged"]
+    assert solver.iteration == fx["iterations"], (solver.iteration, fx["iterations"])
+    assert solver.num_applies == fx["num_applies"]
+    ref_h = np.array(fx["history"])
+    assert len(solver.history) == len(ref_h)
+    assert np.max(np.abs(solver.history - ref_h) / ref_h) <= hist_tol
+    idx, ref_x = np.array(fx["sample_cells"]), np.array(fx["x_samples"])
+    assert np.max(np.abs(x[idx] - ref_x) / np.abs(ref_x)) <= x_tol
+    assert abs(np.sqrt(np.sum(x * x)) - fx["x_norm2"]) <= x_tol * fx["x_norm2"]
+    assert abs(solver.relative_error - fx["relative_error"]) <= 1e-6 * fx["relative_error"] + hist_tol
+    assert true_rel <= 1.5e-6
+
+
+@pytest.mark.parametrize("generic", [False, True], ids=["fused", "engine"])
+def test_cg_256_matches_the_oracle_fixture(env, poisson256, generic):
+    api, mesh, ctx = env
+    g, mat = poisson256
+    fx = _fixture("cg256")
+    s = api.CgSolver()
+    ok, x, true_rel = _solve(api, ctx, s, api.HipStencilOperator(mat, -1.0, 0.0), g.n_cells, generic)
+    _compare_exactly(fx, s, ok, x, true_rel, hist_tol=1e-8, x_tol=1e-8)
+
+
+@pytest.mark.parametrize("generic", [False, True], ids=["fused", "engine"])
+def test_gmres30_convdiff_128_matches_the_oracle_fixture(env, generic):
+    api, mesh, ctx = env
+    fx = _fixture("gmres128cd")
+    g = mesh.structured_box(128)
+    wi, wo, de = mesh.convection_diffusion_weights(g, NU, VEL)
+    mat = api.StencilMatrix.from_face_weights(ctx, g.n_cells, g.n_halo, g.inner, g.outer, wi, wo, de)
+    s = api.GmresSolver()
+    s.num_inner_iterations = 30
+    ok, x, true_rel = _solve(api, ctx, s, api.HipStencilOperator(mat, 1.0, 0.0), g.n_cells, generic)
+    _compare_exactly(fx, s, ok, x, true_rel, hist_tol=1e-8, x_tol=1e-8)
+    mat.close()
+
+
+def test_the_fixture_itself_shows_bicgstab_256_is_a_draw():
+    """CPU-side facts the BiCGStab bound rests on (no GPU involved; kept with the test that uses them)."""
+    fx = _fixture("bicgstab256")
+    study = fx["summation_order_study"]
+    counts = {v: o["iterations"] for v, o in study.items()}
+    assert fx["iterations"] == 355 and counts == {"fma": 350, "pairwise": 361, "longdouble": 352}
+    for o in study.values():
+        first = o["first_iteration_where_history_leaves_strict_by"]
+        assert first["1e-08"] <= 12 and first["1e-06"] <= 20 and first["0.001"] <= 30 and first["0.1"] <= 45
+        assert abs(o["x_norm2"] - fx["x_norm2"]) <= 1e-7 * fx["x_norm2"]
+
+
+@pytest.mark.parametrize("generic", [False, True], ids=["fused", "engine"])
+def test_bicgstab_256_within_the_bound_summation_order_allows(env, poisson256, generic):
+    api, mesh, ctx = env
+    g, mat = poisson256
+    fx = _fixture("bicgstab256")
+    s = api.BiCgStabSolver()
+    ok, x, true_rel = _solve(api, ctx, s, api.HipStencilOperator(mat, -1.0, 0.0), g.n_cells, generic)
+    assert ok and s.relative_error < 1e-6 and true_rel <= 1.5e-6
+    ref_h = np.array(fx["history"])
+    rel = np.abs(s.history[:21] - ref_h[:21]) / ref_h[:21]
+    assert np.max(rel[:13]) <= 1e-6, rel[:13]
+    assert np.max(rel) <= 1e-3, rel
+    assert abs(s.iteration - fx["iterations"]) <= 0.10 * fx["iterations"], (s.iteration, fx["iterations"])
+    assert s.num_applies == 1 + 2 * s.iteration
+    idx, ref_x = np.array(fx["sample_cells"]), np.array(fx["x_samples"])
+    assert np.max(np.abs(x[idx] - ref_x) / np.abs(ref_x)) <= 1e-6
+    assert abs(np.sqrt(np.sum(x * x)) - fx["x_norm2"]) <= 1e-6 * fx["x_norm2"]

@@ -163,7 +163,9 @@ def test_flexible_gmres_with_a_varying_preconditioner(env):
     assert s.solve(x, b, op)
     ref, n_pre = oracle.solve_gmres_pre(ref_op, oracle.CallbackOperator(g.n_cells, ref_pre), b_host, flexible=True,
                                         num_inner_iterations=15)
-    assert ref.converged and n_pre == s.pre_op.calls == ref.iterations
+    # the device loop enqueues a few iterations ahead of the convergence verdict: the callback is ENTERED more
+    # often than the preconditioner is applied; the logical count is the reference's
+    assert ref.converged and n_pre == s.num_pre_applies == ref.iterations and s.pre_op.calls >= n_pre
     assert abs(s.iteration - ref.iterations) <= 2
     assert np.linalg.norm(x.to_numpy() - ref.x) <= 1e-6 * np.linalg.norm(ref.x)
     # the true residual of the returned x honours the reported (right-preconditioned => true) norm
