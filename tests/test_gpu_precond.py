@@ -303,6 +303,7 @@ def test_every_solver_with_jacobi_matches_oracle(env, kind, cls, side):
     s.pre_side = api.PreconditionerSide.Left if side == "left" else api.PreconditionerSide.Right
     api.rng_reset()
     oracle.lib().oracle_rng_reset()
+    s.record_history = True
     assert s.solve(x, b, op)
     ref = oracle.solve(kind, ref_op, b_host, pre=oracle.DiagOperator(dinv), side=side, **kw)
     assert ref.converged

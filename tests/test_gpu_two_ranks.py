@@ -71,7 +71,7 @@ def test_bench_script_multi_rank_path(world):
     assert 0.0 < out["roofline"]["frac"] <= 1.0 and out["timing"]["repeats"] >= 1
 
 
-@pytest.mark.parametrize("world", [3, 5])
+@pytest.mark.parametrize("world", [3, 4])  # (a GPU box admits 6 processes on its card: 4 ranks + this one + slack)
 def test_unstructured_partition_reproduces_the_recorded_reference_run(world, tmp_path):
     """General meshes: RCB parts of the reference's Triangle mesh, general halo plans."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",

@@ -59,6 +59,7 @@ def test_hip_statement_path_matches_oracle(kind):
         s.num_iterations = kw["num_iterations"] = 300
         s.relative_error_tolerance = kw["rel_tol"] = 1e-2
     b, x = api.DeviceVector.from_numpy(ctx, b_host), api.DeviceVector(ctx, g.n_cells)
+    s.record_history = True
     ok = s.solve(x, b, op)
     ref = oracle.solve(kind, oracle.StencilOperator(g, -1.0, 0.0), b_host, **kw)
     assert ok == ref.converged
@@ -148,6 +149,7 @@ def test_hip_bicgstabl_idrs_match_oracle(kind, m):
     b, x = api.DeviceVector.from_numpy(ctx, b_host), api.DeviceVector(ctx, g.n_cells)
     api.rng_reset()
     oracle.rng_reset()
+    s.record_history = True
     ok = s.solve(x, b, op)
     ref = oracle.solve(kind, oracle.StencilOperator(g, -1.0, 0.0), b_host, num_inner_iterations=m)
     assert ok and ref.converged
