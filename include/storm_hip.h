@@ -221,7 +221,13 @@ int storm_hip_op_set_halo(storm_hip_op *op, int n_nbrs, const int32_t *nbr_rank,
                           const int64_t *recv_ptr);
 
 /* `Operator::mul(y, x)`  Solvers/Operator.hpp:74:  y = beta*x + alpha*M(x).
- * Exchanges x's halo first when a halo plan is set.  x and y must not alias. */
+ * Exchanges x's halo first when a halo plan is set.  x and y must not alias.
+ * PRECONDITION: x is finite.  An Inf / NaN in x reaches the rows the reference's face loop lets it reach, and --
+ * in the paired record format (spmv_dict = 3: two rows share their gathers; a row without a neighbour in a
+ * shared slot multiplies the gathered value by weight 0) -- additionally rows whose index is one stencil
+ * offset away from it without being its neighbour; rows stored in the CSR tail form a_ii x_i as
+ * rowsum x_i - sum_j a_ij x_i, which is NaN instead of Inf for x_i = Inf.  Nothing else differs
+ * (tests/test_gpu_edge_cases.py pins this). */
 int storm_hip_op_apply(const storm_hip_op *op, double alpha, double beta, const storm_hip_vec *x,
                        storm_hip_vec *y);
 

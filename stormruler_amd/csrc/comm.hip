@@ -8,6 +8,7 @@
 #include <rccl/rccl.h>
 
 #include <cstring>
+#include <vector>
 
 #include "common.hpp"
 
@@ -128,6 +129,47 @@ int comm_halo_exchange_end(const storm_hip_op *op) {
   return STORM_HIP_OK;
 }
 
+// A plan whose send count towards a neighbour differs from what that neighbour expects to receive hangs the first
+// exchange inside RCCL.  Once, when the plan is set: every rank tells each neighbour how many rows it will send,
+// and compares what it is told with its own receive counts.  (Same transport as the halo itself.)
+int halo_plan_cross_check(const storm_hip_op *op) {
+  storm_hip_ctx *c = op->ctx;
+  const HaloPlan &h = op->halo;
+  if (h.n_nbrs == 0 || c->comm == nullptr) return STORM_HIP_OK;
+  std::vector<double> mine((size_t)h.n_nbrs), theirs((size_t)h.n_nbrs, -1.0);
+  for (int q = 0; q < h.n_nbrs; ++q) mine[(size_t)q] = (double)(h.send_ptr[q + 1] - h.send_ptr[q]);
+  if (c->comm->host_exchange) {
+    std::vector<int64_t> one((size_t)h.n_nbrs + 1);
+    for (int q = 0; q <= h.n_nbrs; ++q) one[(size_t)q] = q;
+    const int rc = c->comm->host_exchange(c->comm->host_user, h.n_nbrs, h.nbr_rank.data(), one.data(), mine.data(),
+                                          one.data(), theirs.data());
+    if (rc != 0) STORM_FAIL(STORM_HIP_E_COMM, "host halo-exchange callback returned %d", rc);
+  } else {
+    double *d_buf = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_buf, sizeof(double) * 2 * (size_t)h.n_nbrs));
+    HIP_TRY(hipMemcpyAsync(d_buf, mine.data(), sizeof(double) * (size_t)h.n_nbrs, hipMemcpyHostToDevice, c->comm_stream));
+    ncclResult_t r = ncclGroupStart();
+    for (int q = 0; q < h.n_nbrs && r == ncclSuccess; ++q) {
+      r = ncclSend(d_buf + q, 1, ncclDouble, h.nbr_rank[q], c->comm->halo, c->comm_stream);
+      if (r == ncclSuccess) r = ncclRecv(d_buf + h.n_nbrs + q, 1, ncclDouble, h.nbr_rank[q], c->comm->halo, c->comm_stream);
+    }
+    if (r == ncclSuccess) r = ncclGroupEnd();
+    hipError_t e = hipMemcpyAsync(theirs.data(), d_buf + h.n_nbrs, sizeof(double) * (size_t)h.n_nbrs,
+                                  hipMemcpyDeviceToHost, c->comm_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->comm_stream);
+    (void)hipFree(d_buf);
+    if (r != ncclSuccess) STORM_FAIL(STORM_HIP_E_COMM, "halo plan cross-check: %s", ncclGetErrorString(r));
+    HIP_TRY(e);
+  }
+  for (int q = 0; q < h.n_nbrs; ++q) {
+    const int64_t expect = h.recv_ptr[q + 1] - h.recv_ptr[q];
+    STORM_REQUIRE((int64_t)theirs[(size_t)q] == expect,
+                  "op_set_halo: rank %d will send %lld rows to rank %d, whose plan receives %lld from it",
+                  h.nbr_rank[q], (long long)theirs[(size_t)q], c->rank, (long long)expect);
+  }
+  return STORM_HIP_OK;
+}
+
 void comm_destroy(storm_hip_ctx *c) {
   if (!c->comm) return;
   if (c->comm->red && c->comm->red != c->comm->halo) (void)ncclCommDestroy(c->comm->red);
@@ -170,9 +212,29 @@ int storm_hip_ctx_comm_init(storm_hip_ctx *c, const void *id128, int n_ranks, in
     c->n_ranks = 1, c->rank = 0;
     STORM_FAIL(STORM_HIP_E_COMM, "ncclCommInitRank failed: %s", ncclGetErrorString(r));
   }
-  // Second communicator for the reductions; fall back to sharing one if the split is refused.
+  // Second communicator for the reductions; fall back to sharing one if the split is refused.  The decision
+  // must be the SAME on every rank (a rank that all-reduces on `halo` while the others use `red` hangs the first
+  // dot product), so the ranks agree on it: min over ranks of "my split worked", on the communicator all have.
   r = ncclCommSplit(cm->halo, 0, rank, &cm->red, nullptr);
-  if (r != ncclSuccess || cm->red == nullptr) cm->red = cm->halo;
+  int split_ok = (r == ncclSuccess && cm->red != nullptr) ? 1 : 0;
+  {
+    int *d_flag = reinterpret_cast<int *>(c->d_scalars);
+    bool agreed = hipMemcpyAsync(d_flag, &split_ok, sizeof(int), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+                  ncclAllReduce(d_flag, d_flag, 1, ncclInt, ncclMin, cm->halo, c->stream) == ncclSuccess &&
+                  hipMemcpyAsync(&split_ok, d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+                  hipStreamSynchronize(c->stream) == hipSuccess;
+    if (!agreed) {
+      if (cm->red && cm->red != cm->halo) (void)ncclCommDestroy(cm->red);
+      (void)ncclCommDestroy(cm->halo);
+      delete cm;
+      c->n_ranks = 1, c->rank = 0;
+      STORM_FAIL(STORM_HIP_E_COMM, "comm_init: the ranks could not agree on the reduction communicator");
+    }
+  }
+  if (!split_ok) {
+    if (cm->red && cm->red != cm->halo) (void)ncclCommDestroy(cm->red);
+    cm->red = cm->halo;
+  }
   c->comm = cm;
   return STORM_HIP_OK;
 }
@@ -230,6 +292,7 @@ int storm_hip_op_set_halo(storm_hip_op *op, int n_nbrs, const int32_t *nbr_rank,
   h.nbr_rank.assign(nbr_rank, nbr_rank + n_nbrs);
   h.send_ptr.assign(send_ptr, send_ptr + n_nbrs + 1);
   h.recv_ptr.assign(recv_ptr, recv_ptr + n_nbrs + 1);
+  STORM_TRY(halo_plan_cross_check(op));
   return op_upload_slice_lists(op);
 }
 

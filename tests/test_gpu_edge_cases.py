@@ -243,3 +243,92 @@ def test_solve_logs_the_reference_line(caplog):
     lines = [r.getMessage() for r in caplog.records]
     assert len(lines) == 2 and all(ln.startswith("n_iter:") and "abs_err:" in ln and "rel_err:" in ln for ln in lines)
     ctx.close()
+
+
+# ---- documented deviations, pinned (DESIGN.md "Deviations") -----------------------------------------------------
+
+def test_non_finite_input_reaches_at_most_the_stencil_offsets_in_paired_records(env):
+    """Precondition of the paired record format (storm_hip.h, storm_hip_op_apply): x is finite.  With fp64 records an
+    Inf in x reaches exactly the rows the reference's face loop lets it reach; in format 3 (two rows share their
+    16-byte gathers; a row without a neighbour in a merged slot multiplies the gathered value by weight 0) it also
+    turns rows whose row index is one stencil OFFSET away from the Inf -- but no true neighbour of it: the cells on
+    the other side of a box face -- into NaN.  Nothing further away is touched."""
+    api, mesh, oracle, ctx = env
+    n = 12
+    g = mesh.structured_box(n)
+    k = (5 * n + 7) * n + 0  # a cell on the x = 0 face: row k - 1 is the LAST cell of the previous grid line
+    x_host = np.sin(0.37 * np.arange(g.n_cells))
+    x_host[k] = np.inf
+    with np.errstate(invalid="ignore"):
+        ref_bad = ~np.isfinite(oracle.StencilOperator(g, -1.0, 0.0).apply(x_host))
+    assert ref_bad.sum() == 6  # the cell and its 5 true neighbours (its sixth face is a wall)
+    bad = {}
+    for fmt in (0, 3):
+        ctx.set_option("spmv_dict", fmt)
+        mat = api.StencilMatrix.from_face_graph(ctx, g)
+        ctx.set_option("spmv_dict", 3)
+        assert bool(mat.stats()["paired_rows"]) == (fmt == 3)
+        x, y = api.DeviceVector.from_numpy(ctx, x_host), api.DeviceVector(ctx, g.n_cells)
+        mat.apply(-1.0, 0.0, x, y)
+        bad[fmt] = ~np.isfinite(y.to_numpy())
+        mat.close()
+    assert np.array_equal(bad[0], ref_bad)                      # fp64 records: the reference's propagation
+    assert np.all(bad[3][ref_bad])                              # paired records: a superset ...
+    extra = set(np.flatnonzero(bad[3] & ~ref_bad))
+    allowed = {k - o for o in (1, -1, n, -n, n * n, -n * n)}    # ... within one stencil offset of the Inf
+    assert extra and extra <= allowed, (extra, allowed)
+
+
+@pytest.mark.parametrize("generic", [0, 1])
+@pytest.mark.parametrize("how", ["abs_tol_above_initial_error", "num_iterations_zero"])
+def test_gmres_without_a_single_iteration_leaves_x_alone(env, generic, how):
+    """Deviation from SolverGmres.hpp:194-249: when NO iterate() ran (the initial residual already meets the
+    absolute tolerance, Solver.hpp:124-128, or num_iterations = 0) the reference's finalize still back-substitutes
+    and divides by H(0,0) = 0 -- its x comes back non-finite (the oracle reproduces that).  This build skips that
+    finalize: x is returned bit for bit as it came in, on the fused loop and on the engine."""
+    api, mesh, oracle, ctx = env
+    g = mesh.structured_box(8)
+    mat = api.StencilMatrix.from_face_graph(ctx, g)
+    op = api.HipStencilOperator(mat, -1.0, 0.0)
+    b_host, x0 = np.ones(g.n_cells), np.cos(0.1 * np.arange(g.n_cells))
+    kw = {"abs_tol": 1e9} if how == "abs_tol_above_initial_error" else {"num_iterations": 0}
+    with np.errstate(all="ignore"):
+        ref = oracle.solve("gmres", oracle.StencilOperator(g, -1.0, 0.0), b_host, x0=x0, **kw)
+    assert ref.iterations == 0 and not np.all(np.isfinite(ref.x))   # the reference's own behaviour
+    s = api.GmresSolver()
+    if "abs_tol" in kw:
+        s.absolute_error_tolerance = 1e9
+    else:
+        s.num_iterations = 0
+    b, x = api.DeviceVector.from_numpy(ctx, b_host), api.DeviceVector.from_numpy(ctx, x0)
+    ctx.set_option("generic_solvers", generic)
+    try:
+        converged = s.solve(x, b, op)
+    finally:
+        ctx.set_option("generic_solvers", 0)
+    assert s.iteration == 0 and converged == ("abs_tol" in kw) and converged == ref.converged
+    assert abs(s.absolute_error - ref.initial_error) <= 1e-12 * ref.initial_error
+    assert np.array_equal(x.to_numpy(), x0)
+    mat.close()
+
+
+@pytest.mark.parametrize("m", [64, 70])
+def test_gmres_restart_of_64_and_more(env, m):
+    """The reference takes any restart length (Solver.hpp:159); the fused loop's state slab holds restarts below 64,
+    longer ones run on the general engine -- same answers (GMRES(100) used to be refused)."""
+    api, mesh, oracle, ctx = env
+    g = mesh.structured_box(32)
+    mat = api.StencilMatrix.from_face_graph(ctx, g)
+    b_host = np.ones(g.n_cells)
+    ref = oracle.solve("gmres", oracle.StencilOperator(g, -1.0, 0.0), b_host, num_inner_iterations=m, rel_tol=1e-10,
+                       abs_tol=0.0)
+    for gram_schmidt in (0, 1):
+        s = api.GmresSolver()
+        s.num_inner_iterations, s.gram_schmidt = m, gram_schmidt
+        s.relative_error_tolerance, s.absolute_error_tolerance = 1e-10, 0.0
+        b, x = api.DeviceVector.from_numpy(ctx, b_host), api.DeviceVector(ctx, g.n_cells)
+        assert s.solve(x, b, api.HipStencilOperator(mat, -1.0, 0.0)) and ref.converged
+        assert ref.iterations > m  # at least one restart happened
+        assert abs(s.iteration - ref.iterations) <= max(2, int(0.05 * ref.iterations))
+        assert np.linalg.norm(x.to_numpy() - ref.x) <= 1e-7 * np.linalg.norm(ref.x)
+    mat.close()
