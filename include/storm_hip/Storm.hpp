@@ -57,6 +57,7 @@ inline void check(int status) {
 }
 }  // namespace detail
 
+#ifndef STORM_HIP_NO_SOLVERS  // (defined: the reference's own Crow / Solvers headers supply what this block restates)
 /// y == 0 ? 0 : x / y                                         (Crow/MathUtils.hpp:49-52)
 inline real_t safe_divide(real_t x, real_t y) noexcept { return (y == 0.0) ? 0.0 : (x / y); }
 
@@ -67,6 +68,7 @@ inline std::array<real_t, 3> sym_ortho(real_t a, real_t b) noexcept {
   return {1.0, 0.0, rr};
 }
 
+#endif  // STORM_HIP_NO_SOLVERS
 // ---------------------------------------------------------------------------------------------
 /// One GPU and its streams / workspaces.  One per process (rank).
 class Context {
@@ -280,6 +282,7 @@ STORM_HIP_CV1(STORM_HIP_NORM)
 inline void fill_with(DeviceVector& a, real_t value) { detail::check(storm_hip_fill(a.handle(), value)); }
 
 // ---------------------------------------------------------------------------------------------
+#ifndef STORM_HIP_NO_SOLVERS
 /// Abstract operator y <- A(x).
 template<class InVector, class OutVector = InVector>
 class Operator {
@@ -349,6 +352,8 @@ template<class Vector, class MatVec>
 auto make_symmetric_operator(MatVec&& mat_vec) {
   return std::make_unique<FunctionalOperator<Vector>>(mat_vec, std::forward<MatVec>(mat_vec));
 }
+
+#endif  // STORM_HIP_NO_SOLVERS
 
 // ---------------------------------------------------------------------------------------------
 /// The face-graph operator M in HBM (sliced-ELL records + CSR tail); owns the handle.
@@ -431,6 +436,7 @@ private:
 };
 
 // ---------------------------------------------------------------------------------------------
+#ifndef STORM_HIP_NO_SOLVERS
 enum class PreconditionerSide { Left, Right, Symmetric };
 
 template<class Vector>
@@ -445,6 +451,8 @@ class IdentityPreconditioner final : public Preconditioner<Vector> {
   void mul(Vector& y_vec, const Vector& x_vec) const override { y_vec <<= x_vec; }
   void conj_mul(Vector& x_vec, const Vector& y_vec) const override { x_vec <<= y_vec; }
 };
+
+#endif  // STORM_HIP_NO_SOLVERS
 
 /// Diagonal preconditioner P = diag(A)^-1 of a HipStencilOperator, entirely on the device: the
 /// build's own addition behind the reference's pre_op hook (Solver.hpp:74-75).  `build`
@@ -467,6 +475,7 @@ private:
   DeviceVector _dinv;
 };
 
+#ifndef STORM_HIP_NO_SOLVERS
 // ---------------------------------------------------------------------------------------------
 template<class InVector, class OutVector = InVector>
 class Solver {
@@ -879,5 +888,7 @@ private:
     return residual_of(x_vec, b_vec, any_op);
   }
 };
+
+#endif  // STORM_HIP_NO_SOLVERS
 
 }  // namespace Storm
