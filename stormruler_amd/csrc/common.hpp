@@ -94,7 +94,7 @@ struct storm_hip_ctx {
   // options
   int64_t opt_ell_cap = 0;
   int64_t opt_spmv_variant = 0;      // 0 gathers from global (default), 1 + LDS x window
-  int64_t opt_spmv_dict = 3;         // dictionary records whenever an operator qualifies (lossless): 3 + paired rows, 2 values + column offsets, 1 values only, 0 never
+  int64_t opt_spmv_dict = 4;         // dictionary records whenever an operator qualifies (lossless): 3 + paired rows, 2 values + column offsets, 1 values only, 0 never
   int64_t opt_spmv_spw = 0;          // slices per wave of the dictionary kernel: 1, 2 or 4 (0 = default)
   int64_t opt_spmv_xcd_remap = 8;    // 0 off; 1 one contiguous run per XCD (slower); G > 1: runs of G tiles per XCD
   int64_t opt_nt = 1;
@@ -156,7 +156,9 @@ struct storm_hip_op {
   int dict_size = 0;               // > 0: records are [idx 64 u64][col W*64 i32]
   int *d_offs = nullptr;           // format 2: the 256-entry column-offset table
   int offs_size = 0;               // > 0: records are 64 x 16-byte words (values + offsets as byte indices)
-  int pair = 0;                    // 1: format 3 -- 128-row groups of paired rows, n_slices counts those groups
+  int pair = 0;                    // 1: format 3 -- 128-row groups of paired rows, n_slices counts those groups; 2: format 4 (common offset order)
+  int canon_k = 0, canon_m1 = -1;  // format 4: number of common offsets, slot of offset -1 (+1 follows)
+  int canon_off[7] = {0, 0, 0, 0, 0, 0, 0};
   int64_t pack_bytes = 0;
   int64_t spw = 1;                 // slices per wavefront of the uniform-width dictionary kernel
   // tail

@@ -572,6 +572,118 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(SellArgs A, Scal alph
   }
 }
 
+
+// Format 4 ("canonical" paired rows): a format-3 operator whose rows all list their neighbours in ONE common
+// order of at most 7 offsets col - row (a structured box in its natural ordering: -nx*ny, -nx, -1, +1, +nx, +nx*ny).
+// The offsets are kernel arguments (SGPRs) instead of per-lane bytes, so a 128-row group is 64 x (weights of row
+// 2p : u64, of row 2p+1 : u64) = 8 B/row, and slot k means the same neighbour in every lane:
+//   * the slots of offsets -1 and +1 (template M1, M1 + 1) need no load at all -- x[2p-1] is the left lane's
+//     xi.y, x[2p+2] the right lane's xi.x (two DPP moves each); only lanes 0 and 63 load their outer neighbour,
+//     one 8-byte load instruction with two active lanes;
+//   * a row that lacks a neighbour carries weight 0 in that slot and gathers from a CLAMPED address (the value
+//     is multiplied by 0; x finite is the precondition of storm_hip_op_apply).
+// 8 + 8 + 8 = 24 B/row and 8 vector-memory instructions per row pair (format 3: 28 B/row and 10).  The sums run
+// over the slots in the common order = every row's own face order, with exactly the bit patterns of the other
+// formats: results are bit-identical (tests/test_gpu_formats.py).
+constexpr int kCanonRecBytes = 2 * kWave * 8;
+struct CanonArgs {
+  int off[7];
+  int max_gather;  // largest guard-relative index a 16-byte gather may start at
+};
+template <int CTRL>
+__device__ __forceinline__ double dpp_shift(double v) {  // lanes without a source get 0
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <bool DOT, int K, int M1>
+__global__ __launch_bounds__(kBlock) void spmv_canon_kernel(SellArgs A, CanonArgs C, Scal alpha_s, Scal beta_s,
+                                                            const double *__restrict__ x, double *__restrict__ y,
+                                                            const int *__restrict__ slice_list,
+                                                            int64_t n_launch_slices, DotArgs dot, const int *done) {
+  const int done_flag = done ? *done : 0;
+  __shared__ double dict_sh[32];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int bidx = (int)blockIdx.x;
+  const int lb = A.xcd_group > 1 ? xcd_remap_grouped(bidx, gridDim.x, A.xcd_group)
+                                 : (A.xcd_group == 1 ? xcd_remap(bidx, gridDim.x) : bidx);
+  const int64_t sl = (int64_t)lb * (kBlock / kWave) + wave;
+  const bool active = sl < n_launch_slices;  // wave-uniform
+  const uint32_t slice = (uint32_t)(slice_list ? slice_list[active ? sl : 0] : (active ? sl : 0));
+  const double alpha = ld_scal2(alpha_s), beta = ld_scal2(beta_s);
+  const uint32_t last_row = (uint32_t)(A.n_rows - 1);
+  const bool w_is_x = DOT && dot.w == x;
+  const bool w_load = DOT && dot.w != nullptr && !w_is_x;
+  const char *xb = reinterpret_cast<const char *>(x);
+  const char *xg_base = xb - (size_t)kVecGuard * 8;  // start of the zero guard in front of x
+  char *yb = reinterpret_cast<char *>(y);
+
+  const uint32_t r0 = slice * (2 * kWave) + 2 * lane;  // row A; row B = r0 + 1
+  const bool valid_a = active && r0 <= last_row, valid_b = active && r0 + 1 <= last_row;
+  const uint32_t rc = r0 <= last_row ? r0 : (last_row & ~1u);  // pairs past the end re-read the last pair
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  const u64x2 vw = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(A.pack + (size_t)slice * kCanonRecBytes) + lane);
+  const double2v xi = *reinterpret_cast<const double2v *>(xb + (size_t)(rc << 3));
+  double2v yo = {0.0, 0.0}, wi = {0.0, 0.0};
+  if (A.accumulate) yo = *reinterpret_cast<const double2v *>(yb + (size_t)(rc << 3));
+  if (w_load) wi = *reinterpret_cast<const double2v *>(reinterpret_cast<const char *>(dot.w) + (size_t)(rc << 3));
+  if (lane < 32) dict_sh[lane] = A.dict[lane];  // one copy per block, every wave stores the same words: no barrier
+  double2v xg[K];
+  if (M1 >= 0) {
+    // x[rc - 1] and x[rc + 2]: the neighbouring lanes' own rows; the wave's two outer ones are loaded
+    const bool edge = lane == 0 || lane == kWave - 1;
+    double e = 0.0;
+    if (edge) e = *reinterpret_cast<const double *>(xg_base + (size_t)((rc + (uint32_t)(kVecGuard + (lane == 0 ? -1 : 2))) << 3));
+    const double left = dpp_shift<0x138>(xi.y);   // wave_shr:1 -- lane i receives lane i - 1
+    const double right = dpp_shift<0x130>(xi.x);  // wave_shl:1 -- lane i receives lane i + 1
+    xg[M1 >= 0 ? M1 : 0].x = lane == 0 ? e : left;
+    xg[M1 >= 0 ? M1 : 0].y = xi.x;
+    xg[M1 >= 0 ? M1 + 1 : 0].x = xi.y;
+    xg[M1 >= 0 ? M1 + 1 : 0].y = lane == kWave - 1 ? e : right;
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (M1 >= 0 && (k == M1 || k == M1 + 1)) continue;
+    int t = (int)rc + C.off[k] + kVecGuard;  // guard-relative, clamped: an absent neighbour may point anywhere
+    t = t < 0 ? 0 : t;
+    t = t > C.max_gather ? C.max_gather : t;
+    xg[k] = *reinterpret_cast<const double2v *>(xg_base + ((size_t)(uint32_t)t << 3));
+  }
+  __builtin_amdgcn_wave_barrier();  // this wave's copy of the table is complete (same-wave LDS order)
+  double acc_a = 0.0, acc_b = 0.0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const unsigned ba = (unsigned)(vw.x >> (8 * (k + 1))) & 0xffu, bb = (unsigned)(vw.y >> (8 * (k + 1))) & 0xffu;
+    acc_a += *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + ba) * (xg[k].x - xi.x);
+    acc_b += *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + bb) * (xg[k].y - xi.y);
+  }
+  const double ext_a = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + ((unsigned)vw.x & 0xffu));
+  const double ext_b = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + ((unsigned)vw.y & 0xffu));
+  double2v yi;
+  yi.x = (A.accumulate ? yo.x : beta * xi.x) + alpha * (acc_a + ext_a * xi.x);
+  yi.y = (A.accumulate ? yo.y : beta * xi.y) + alpha * (acc_b + ext_b * xi.y);
+  if (!done_flag) {
+    if (valid_b) __builtin_nontemporal_store(yi, reinterpret_cast<double2v *>(yb + (size_t)(rc << 3)));
+    else if (valid_a) y[rc] = yi.x;  // the odd last row
+  }
+  if (done_flag) return;
+  if (DOT) {
+    yi.x = valid_a ? yi.x : 0.0;
+    yi.y = valid_b ? yi.y : 0.0;
+    double a = dot.w ? (w_is_x ? xi.x : wi.x) * yi.x + (w_is_x ? xi.y : wi.y) * yi.y : 0.0;
+    double b = yi.x * yi.x + yi.y * yi.y;
+    a = wave_sum_to_lane63(a);
+    if (dot.yy) b = wave_sum_to_lane63(b);
+    if (lane == kWave - 1) {
+      const int slot = dot.block_offset + (int)blockIdx.x * (kBlock / kWave) + wave;
+      dot.partials[slot] = a;
+      if (dot.yy) dot.partials[dot.nblocks_total + slot] = b;
+    }
+  }
+}
+
 // CSR tail: one wavefront per overflowing row; the lanes' partial products are folded
 // with __shfl_down and lane 0 adds the row's remainder to y.
 __global__ __launch_bounds__(kBlock) void spmv_tail_kernel(int64_t n_tail, const int *__restrict__ tail_row,
@@ -634,6 +746,19 @@ static void launch_pair(const storm_hip_op *op, int nb, Scal alpha, Scal beta, c
   SellArgs A{op->d_pack, op->d_slice_off, op->n_rows, op->uniform_width, group, op->d_dict, op->dict_size,
              op->d_offs, op->offs_size, (int)accumulate};
   hipStream_t st = op->ctx->stream;
+  if (op->pair == 2) {  // format 4: the common offsets travel as kernel arguments
+    CanonArgs C;
+    for (int k = 0; k < 7; ++k) C.off[k] = op->canon_off[k];
+    C.max_gather = (int)(op->n_rows + op->n_halo) + kVecGuard + 2;
+#define CANON_GO(K_, M1_)                                                                                          \
+  hipExtLaunchKernelGGL((spmv_canon_kernel<DOT, K_, M1_>), dim3(nb), dim3(kBlock), 0, st, ev0, ev1, 0, A, C, alpha, \
+                        beta, x, y, slice_list, n_launch, dot, done)
+    if (op->canon_k == 6) CANON_GO(6, 2);
+    else if (op->canon_k == 4) CANON_GO(4, 1);
+    else CANON_GO(2, 0);
+#undef CANON_GO
+    return;
+  }
 #define PAIR_GO(W_)                                                                                              \
   hipExtLaunchKernelGGL((spmv_pair_kernel<DOT, W_>), dim3(nb), dim3(kBlock), 0, st, ev0, ev1, 0, A, alpha, beta, \
                         x, y, slice_list, n_launch, dot, done)
@@ -790,8 +915,8 @@ __global__ __launch_bounds__(kBlock) void diag_sell_kernel(const char *__restric
   const int64_t s = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
   const int64_t r = s * kWave + lane;
   if (r >= n_rows) return;
-  if (fmt2 == 3) {  // paired rows: 128-row groups, weights of row r in word (r % 128), bytes pre-scaled by 8
-    const uint64_t iw = reinterpret_cast<const uint64_t *>(pack + (r >> 7) * kPairRecBytes)[r & 127];
+  if (fmt2 == 3 || fmt2 == 4) {  // paired rows: 128-row groups, weights of row r in word (r % 128), bytes pre-scaled by 8
+    const uint64_t iw = reinterpret_cast<const uint64_t *>(pack + (r >> 7) * (fmt2 == 4 ? kCanonRecBytes : kPairRecBytes))[r & 127];
     double sum = 0.0;
     for (int k = 0; k < 7; ++k) sum += dict[((unsigned)(iw >> (8 * (k + 1))) & 0xffu) >> 3];
     d[r] = beta + alpha * (dict[((unsigned)iw & 0xffu) >> 3] - sum);
@@ -978,14 +1103,85 @@ static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vect
     }
     pr = pr && pair_width > 0;
   }
+  // ... and whether all rows list their neighbours in one common order of offsets (format 4, see spmv_canon_kernel)
+  int64_t canon[16];
+  int canon_len = 0, canon_m1 = -1;
+  bool cn = pr && c->opt_spmv_dict >= 4 && n_halo == 0;
+  if (cn) {
+    // the distinct offsets and who precedes whom in some row; a common order = a linear extension of that relation
+    int64_t dist[8];
+    int nd = 0;
+    bool before[8][8] = {};
+    for (int64_t r = 0; cn && r < n; ++r) {
+      int idx[8], no = 0;
+      for (int64_t k = row_ptr[r]; cn && k < row_ptr[r + 1]; ++k) {
+        const int64_t o = (int64_t)col[(size_t)k] - r;
+        int q = 0;
+        while (q < nd && dist[q] != o) ++q;
+        if (q == nd) {
+          if (nd == 7) { cn = false; break; }
+          dist[nd++] = o;
+        }
+        idx[no++] = q;
+      }
+      for (int i = 0; cn && i < no; ++i)
+        for (int j = i + 1; j < no; ++j) {
+          if (idx[i] == idx[j]) cn = false;  // the same offset twice in one row
+          before[idx[i]][idx[j]] = true;
+        }
+    }
+    bool placed[8] = {};
+    while (cn && canon_len < nd) {  // Kahn's algorithm; ties go to the smaller offset
+      int pick = -1;
+      for (int q = 0; q < nd; ++q) {
+        if (placed[q]) continue;
+        bool free_ = true;
+        for (int q2 = 0; q2 < nd; ++q2) free_ = free_ && !(before[q2][q] && !placed[q2]);
+        if (free_ && (pick < 0 || dist[q] < dist[pick])) pick = q;
+      }
+      if (pick < 0) { cn = false; break; }  // a cycle: rows disagree about the order
+      placed[pick] = true;
+      canon[canon_len++] = dist[pick];
+    }
+    for (int q = 0; cn && q + 1 < canon_len; ++q)
+      if (canon[q] == -1 && canon[q + 1] == 1) canon_m1 = q;
+    cn = cn && ((canon_len == 6 && canon_m1 == 2) || (canon_len == 4 && canon_m1 == 1) || (canon_len == 2 && canon_m1 == 0));
+    for (int q = 0; cn && q < canon_len; ++q) cn = canon[q] > -(int64_t)INT32_MAX / 2 && canon[q] < (int64_t)INT32_MAX / 2;
+  }
+  if (cn) {
+    pair_pack.assign((size_t)n_groups * kCanonRecBytes, 0);
+    const uint64_t zero_v = (uint64_t)vd.index(0.0) << 3;
+    for (int64_t p = 0; 2 * p < n_groups * 2 * kWave; ++p) {
+      uint64_t w2[2];
+      for (int half = 0; half < 2; ++half) {
+        const int64_t r = 2 * p + half;
+        uint64_t w = r < n ? ((uint64_t)vd.index(ext[(size_t)r]) << 3) : zero_v;
+        for (int k = 0; k < 7; ++k) w |= zero_v << (8 * (k + 1));
+        if (r < n) {
+          int q = 0;
+          for (int64_t k = row_ptr[r]; k < row_ptr[r + 1]; ++k) {
+            while (canon[q] != (int64_t)col[(size_t)k] - r) ++q;  // a subsequence of the common order
+            w &= ~(0xffull << (8 * (q + 1)));
+            w |= ((uint64_t)vd.index(val[(size_t)k]) << 3) << (8 * (q + 1));
+          }
+        }
+        w2[half] = w;
+      }
+      uint64_t *rec = reinterpret_cast<uint64_t *>(pair_pack.data() + (p / kWave) * kCanonRecBytes);
+      rec[2 * (p % kWave)] = w2[0], rec[2 * (p % kWave) + 1] = w2[1];
+    }
+    op->canon_k = canon_len, op->canon_m1 = canon_m1;
+    for (int k = 0; k < 7; ++k) op->canon_off[k] = k < canon_len ? (int)canon[k] : 0;
+  }
   if (pr) {
-    // format 3 it is: a "slice" of this operator is a 128-row group
-    op->pair = 1;
+    // format 3 (or 4) it is: a "slice" of this operator is a 128-row group
+    op->pair = cn ? 2 : 1;
+    if (cn) pair_width = canon_len;
     op->n_slices = n_groups;
     op->uniform_width = pair_width;
     op->ell_slots = n_groups * 2 * kWave * pair_width;
     std::vector<int64_t> goff((size_t)n_groups + 1);
-    for (int64_t s = 0; s <= n_groups; ++s) goff[(size_t)s] = s * kPairRecBytes;
+    for (int64_t s = 0; s <= n_groups; ++s) goff[(size_t)s] = s * (cn ? kCanonRecBytes : kPairRecBytes);
     for (int64_t s = 0; s < n_groups; ++s) {
       bool touches_halo = false;
       const int64_t r1 = std::min<int64_t>(n, (s + 1) * 2 * kWave);
@@ -1298,7 +1494,7 @@ int storm_hip_op_get_diagonal(const storm_hip_op *op, double alpha, double beta,
   const int64_t n64 = (op->n_rows + kWave - 1) / kWave;  // the kernel walks 64-row groups whatever the format
   const int nb = (int)((n64 + (kBlock / kWave) - 1) / (kBlock / kWave));
   hipLaunchKernelGGL(diag_sell_kernel, dim3(nb), dim3(kBlock), 0, c->stream, op->d_pack, op->d_slice_off, op->n_rows,
-                     op->d_dict, op->pair ? 3 : (int)(op->offs_size > 0), alpha, beta, d->d);
+                     op->d_dict, op->pair == 2 ? 4 : op->pair ? 3 : (int)(op->offs_size > 0), alpha, beta, d->d);
   if (op->tail_rows > 0)
     hipLaunchKernelGGL(diag_tail_kernel, dim3((int)((op->tail_rows + 255) / 256)), dim3(256), 0, c->stream,
                        op->tail_rows, op->d_tail_row, op->d_tail_ptr, op->d_tail_val, alpha, d->d);

@@ -43,7 +43,7 @@ def main():
     for fmt in (0, 2, 3):
         ctx.set_option("spmv_dict", fmt)
         mat = api.StencilMatrix.from_face_graph(ctx, loc)
-        ctx.set_option("spmv_dict", 3)
+        ctx.set_option("spmv_dict", 4)
         st = mat.stats()
         assert (st["offset_dictionary_size"] > 0) == (fmt >= 2), st
         assert (fmt == 3 or not st["paired_rows"]) and (st["paired_rows"] or fmt != 3 or nx % 2 == 1), st

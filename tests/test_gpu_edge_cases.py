@@ -266,7 +266,7 @@ def test_non_finite_input_reaches_at_most_the_stencil_offsets_in_paired_records(
     for fmt in (0, 3):
         ctx.set_option("spmv_dict", fmt)
         mat = api.StencilMatrix.from_face_graph(ctx, g)
-        ctx.set_option("spmv_dict", 3)
+        ctx.set_option("spmv_dict", 4)
         assert bool(mat.stats()["paired_rows"]) == (fmt == 3)
         x, y = api.DeviceVector.from_numpy(ctx, x_host), api.DeviceVector(ctx, g.n_cells)
         mat.apply(-1.0, 0.0, x, y)

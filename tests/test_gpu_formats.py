@@ -1,5 +1,6 @@
 """The record formats of the SpMV (fp64 weights + int32 columns; byte-indexed weights; byte-indexed weights and
-column offsets; the same with two rows per lane sharing their gathers) are lossless re-encodings: every format must give bit-identical results, the
+column offsets; the same with two rows per lane sharing their gathers; the same with one common offset order for
+the whole operator and the +-1 neighbours taken from the adjacent lanes) are lossless re-encodings: every format must give bit-identical results, the
 library must pick them only when the operator qualifies, and every code path around the kernel (fused dot
 products, slice lists of a partitioned operator, CSR tail, diagonal extraction, ragged last slice, non-uniform
 widths) must hold for each of them."""
@@ -8,7 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-FORMATS = [(0, 1), (1, 1), (1, 2), (2, 1), (2, 2), (2, 4), (3, 0)]  # (spmv_dict, spmv_spw)
+FORMATS = [(0, 1), (1, 1), (1, 2), (2, 1), (2, 2), (2, 4), (3, 0), (4, 0)]  # (spmv_dict, spmv_spw)
 
 
 @pytest.fixture(scope="module")
@@ -19,7 +20,7 @@ def env():
     ctx = api.Context(0)
     ctx.comm_init(api.Context.comm_unique_id(), 1, 0)  # lets the self-halo (periodic) case run
     yield api, mesh, oracle, ctx
-    ctx.set_option("spmv_dict", 3)
+    ctx.set_option("spmv_dict", 4)
     ctx.set_option("spmv_spw", 0)
     ctx.close()
 
@@ -28,7 +29,7 @@ def _build(ctx, fmt, make):
     ctx.set_option("spmv_dict", fmt[0])
     ctx.set_option("spmv_spw", fmt[1])
     m = make()
-    ctx.set_option("spmv_dict", 3)
+    ctx.set_option("spmv_dict", 4)
     ctx.set_option("spmv_spw", 0)
     return m
 
@@ -59,7 +60,12 @@ def test_box_all_formats_bitwise_equal_and_match_oracle(env, shape):
             # if the merged neighbour lists still fit 7 slots -- otherwise format 2 is kept
             assert st["paired_rows"] or shape[0] % 2 == 1, st
             if st["paired_rows"]:
+                assert st["paired_rows"] == 1
                 assert st["record_bytes"] == 1536 * st["n_slices"] and st["n_slices"] == (g.n_cells + 127) // 128
+        if fmt[0] == 4 and st["paired_rows"]:
+            # every box in natural ordering lists its neighbours in one common order: the canonical records
+            # (no per-lane offsets: 8 B/row) are taken whenever the rows pair up at all
+            assert st["paired_rows"] == 2 and st["record_bytes"] == 1024 * st["n_slices"], st
         ys[fmt] = _apply(api, ctx, mat, x)
         # the diagonal read back from every format is the same
         d = api.DeviceVector(ctx, g.n_cells)

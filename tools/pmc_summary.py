@@ -47,7 +47,7 @@ def main():
 
         # the launches of a CG solve: the fused-dot instantiation <true, ...> of the SpMV kernels; the byte-indexed
         # formats (headline operator) and the fp64 records (roofline_general) are reported separately
-        is_fmt = lambda k: ("spmv_pair_kernel<true" in k) or ("spmv_dict_kernel<true" in k)  # noqa: E731
+        is_fmt = lambda k: ("spmv_canon_kernel<true" in k) or ("spmv_pair_kernel<true" in k) or ("spmv_dict_kernel<true" in k)  # noqa: E731
         is_sell = lambda k: "spmv_sell_kernel<true, true" in k  # noqa: E731
         method = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950)"
         out = {}
