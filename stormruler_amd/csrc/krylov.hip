@@ -188,6 +188,10 @@ struct LinArgs {
   const double *cond;  // nullable: run only when *cond != 0
 };
 
+// 16-byte accesses per stream and thread in flight: 4 for up to three streams, fewer beyond (measured,
+// tools/cg_kernels_bench.hip: a 5-stream kernel runs 5 % faster with 1 than with 4, and collapses with 8).
+__host__ __device__ constexpr int lin_unroll(int nt) { return nt <= 2 ? 4 : (nt == 3 ? 2 : 1); }
+
 // y = c0 v0 + c1 v1 + ... (left to right), or NESTED (NT = 3):  y = v0 + c1 * (v1 + c2 * v2).
 // Operands may alias y (every element is read before it is written by the same lane).
 template <int NT, bool NESTED>
@@ -199,11 +203,12 @@ __global__ __launch_bounds__(kBlock) void lin_kernel(int64_t n, LinArgs a, const
   for (int t = 0; t < NT; ++t) c[t] = ld_coef(a.c[t]);
   const int64_t n2 = n >> 1;
   double2v *y2 = reinterpret_cast<double2v *>(a.y);
-  for (int64_t base = (int64_t)blockIdx.x * (kBlock * kUnroll) + threadIdx.x; base < n2;
-       base += (int64_t)gridDim.x * (kBlock * kUnroll)) {
-    double2v v[kUnroll][NT];
+  constexpr int U = lin_unroll(NT);
+  for (int64_t base = (int64_t)blockIdx.x * (kBlock * U) + threadIdx.x; base < n2;
+       base += (int64_t)gridDim.x * (kBlock * U)) {
+    double2v v[U][NT];
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int64_t i = base + u * kBlock;
       if (i < n2) {
 #pragma unroll
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(kBlock) void lin_kernel(int64_t n, LinArgs a, const
       }
     }
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int64_t i = base + u * kBlock;
       if (i < n2) {
         double2v o;
@@ -405,7 +410,9 @@ struct KrylovEngine {
   template <int NT, bool NESTED>
   void launch_lin(const LinArgs &a) {
     if (n <= 0) return;
-    hipLaunchKernelGGL((lin_kernel<NT, NESTED>), dim3(stream_blocks(n)), dim3(kBlock), 0, c->stream, n, a, dp,
+    const int64_t per_block = (int64_t)kBlock * lin_unroll(NT) * 2;
+    const int64_t nb = std::min<int64_t>(65536, std::max<int64_t>(1, (n + per_block - 1) / per_block));
+    hipLaunchKernelGGL((lin_kernel<NT, NESTED>), dim3((int)nb), dim3(kBlock), 0, c->stream, n, a, dp,
                        (int)(c->opt_blas1_nt != 0));
   }
   void lin_v(V yv, const std::vector<Term> &terms, int cond = -1) {

@@ -233,6 +233,10 @@ __global__ __launch_bounds__(kBlock) void cg_r_kernel(int64_t n, SolverState *st
   if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
+// Five streams (3 loads, 2 stores): measured best with ONE 16-byte access per stream and thread in flight
+// (tools/cg_kernels_bench.hip at 256^3: U = 1 105.6 us, U = 2 108.2, U = 4 111.4 -- and U = 8 615 us: a wave that
+// holds too many loads in flight stalls the memory pipeline), unlike the 2- and 3-stream kernels (U = 4).
+constexpr int kUnrollXp = 1;
 __global__ __launch_bounds__(kBlock) void cg_xp_kernel(int64_t n, const SolverState *st, long long my_iteration,
                                                        double *__restrict__ x, double *__restrict__ p,
                                                        const double *__restrict__ r, int nt) {
@@ -242,10 +246,11 @@ __global__ __launch_bounds__(kBlock) void cg_xp_kernel(int64_t n, const SolverSt
   const int64_t n2 = n >> 1;
   double2v *x2 = reinterpret_cast<double2v *>(x), *p2 = reinterpret_cast<double2v *>(p);
   const double2v *r2 = reinterpret_cast<const double2v *>(r);
-  STORM_STREAM_FOR(base, n2) {
-    double2v vx[kUnroll], vp[kUnroll], vr[kUnroll];
+  for (int64_t base = (int64_t)blockIdx.x * (kBlock * kUnrollXp) + threadIdx.x; base < n2;
+       base += (int64_t)gridDim.x * (kBlock * kUnrollXp)) {
+    double2v vx[kUnrollXp], vp[kUnrollXp], vr[kUnrollXp];
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
+    for (int u = 0; u < kUnrollXp; ++u) {
       const int64_t i = base + u * kBlock;
       if (i < n2) {
         vx[u] = ldv(x2 + i, nt), vp[u] = ldv(p2 + i, nt);
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(kBlock) void cg_xp_kernel(int64_t n, const SolverSt
       }
     }
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
+    for (int u = 0; u < kUnrollXp; ++u) {
       const int64_t i = base + u * kBlock;
       if (i < n2) {
         vx[u] += alpha * vp[u];
@@ -267,6 +272,10 @@ __global__ __launch_bounds__(kBlock) void cg_xp_kernel(int64_t n, const SolverSt
     x[i] += alpha * p[i];
     if (update_p) p[i] = r[i] + beta * p[i];
   }
+}
+static inline int xp_blocks(int64_t n) {
+  int64_t b = ((n >> 1) + kBlock * kUnrollXp - 1) / (kBlock * kUnrollXp);
+  return (int)(b < 1 ? 1 : (b > 131072 ? 131072 : b));
 }
 
 // The two half-steps of a BiCGStab iteration (SolverBiCgStab.hpp:140-141 and :161-164).
@@ -288,10 +297,12 @@ __global__ __launch_bounds__(kBlock) void bicg_update_kernel(int64_t n, SolverSt
   double2v *x2 = reinterpret_cast<double2v *>(x), *r2 = reinterpret_cast<double2v *>(r);
   const double2v *p2 = reinterpret_cast<const double2v *>(p), *w2 = reinterpret_cast<const double2v *>(w);
   const double2v *rt2 = reinterpret_cast<const double2v *>(rt);
-  STORM_STREAM_FOR(base, n2) {
-    double2v vx[kUnroll], vr[kUnroll], vw[kUnroll], vp[kUnroll], vt[kUnroll];
+  constexpr int U = SECOND ? 1 : kUnroll;  // 7 streams: one access per stream in flight (see cg_xp_kernel)
+  for (int64_t base = (int64_t)blockIdx.x * (kBlock * U) + threadIdx.x; base < n2;
+       base += (int64_t)gridDim.x * (kBlock * U)) {
+    double2v vx[U], vr[U], vw[U], vp[U], vt[U];
 #pragma unroll
-    for (int q = 0; q < kUnroll; ++q) {
+    for (int q = 0; q < U; ++q) {
       const int64_t i = base + q * kBlock;
       if (i < n2) {
         vr[q] = ldv(r2 + i, nt), vw[q] = ldv(w2 + i, nt);
@@ -299,7 +310,7 @@ __global__ __launch_bounds__(kBlock) void bicg_update_kernel(int64_t n, SolverSt
       }
     }
 #pragma unroll
-    for (int q = 0; q < kUnroll; ++q) {
+    for (int q = 0; q < U; ++q) {
       const int64_t i = base + q * kBlock;
       if (i < n2) {
         if (!SECOND) {
@@ -772,7 +783,7 @@ int storm_hip_solve_cg(const storm_hip_op *op, double alpha, double beta, const 
       STORM_TRY(d.finish(nbv, 1, slots, STEP_CG_RR));
     }
     // x += alpha p; p = r + beta p                    SolverCg.hpp:98,123
-    hipLaunchKernelGGL(cg_xp_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, (long long)(cur_it + 1), x->d,
+    hipLaunchKernelGGL(cg_xp_kernel, dim3(xp_blocks(n)), dim3(kBlock), 0, c->stream, n, d.st, (long long)(cur_it + 1), x->d,
                        p, r, (int)(c->opt_blas1_nt != 0));
     HIP_TRY(hipGetLastError());
     return STORM_HIP_OK;
@@ -800,6 +811,7 @@ int storm_hip_solve_bicgstab(const storm_hip_op *op, double alpha, double beta, 
   STORM_TRY(pool.make(x, 5));
   double *p = pool.v[0]->d, *r = pool.v[1]->d, *rt = pool.v[2]->d, *t = pool.v[3]->d, *v = pool.v[4]->d;
   const int nbv = vec_blocks(c, n);
+  const int nbv2 = nbv;  // second half-step: one access per stream in flight, four trips per thread
   int nb = 0;
 
   // init: r = b - A x; rt = r; rho = <rt,r>           SolverBiCgStab.hpp:82-90
@@ -842,12 +854,12 @@ int storm_hip_solve_bicgstab(const storm_hip_op *op, double alpha, double beta, 
       STORM_TRY(d.finish(nb, 2, slots, STEP_BICG_OMEGA));
     }
     // x = (x + alpha p) + omega r; r -= omega t; |r|, <rt,r>    :140, :161-164 (+ :116 of the next iteration)
-    hipLaunchKernelGGL(bicg_update_kernel<true>, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, x->d, r,
+    hipLaunchKernelGGL(bicg_update_kernel<true>, dim3(nbv2), dim3(kBlock), 0, c->stream, n, d.st, x->d, r,
                        p, t, rt, c->d_partials, (int)(c->opt_blas1_nt != 0));
     HIP_TRY(hipGetLastError());
     {
       const int slots[2] = {S_RR, S_RHO_NEW};
-      STORM_TRY(d.finish(nbv, 2, slots, STEP_BICG_END));
+      STORM_TRY(d.finish(nbv2, 2, slots, STEP_BICG_END));
     }
     return STORM_HIP_OK;
   };

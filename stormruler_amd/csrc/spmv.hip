@@ -624,32 +624,37 @@ __global__ __launch_bounds__(kBlock) void spmv_canon_kernel(SellArgs A, CanonArg
   const bool valid_a = active && r0 <= last_row, valid_b = active && r0 + 1 <= last_row;
   const uint32_t rc = r0 <= last_row ? r0 : (last_row & ~1u);  // pairs past the end re-read the last pair
   typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  // Issue order matters (loads return in order; a wait for one load waits for every earlier one): the value table
+  // first -- its LDS copy is needed before anything else can be consumed -- then the record, the own rows, all
+  // gathers and the two outer neighbours back to back; nothing is consumed before the last load is in flight.
+  const double dict_word = A.dict[lane & 31];
   const u64x2 vw = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(A.pack + (size_t)slice * kCanonRecBytes) + lane);
   const double2v xi = *reinterpret_cast<const double2v *>(xb + (size_t)(rc << 3));
   double2v yo = {0.0, 0.0}, wi = {0.0, 0.0};
   if (A.accumulate) yo = *reinterpret_cast<const double2v *>(yb + (size_t)(rc << 3));
   if (w_load) wi = *reinterpret_cast<const double2v *>(reinterpret_cast<const char *>(dot.w) + (size_t)(rc << 3));
-  if (lane < 32) dict_sh[lane] = A.dict[lane];  // one copy per block, every wave stores the same words: no barrier
   double2v xg[K];
-  if (M1 >= 0) {
-    // x[rc - 1] and x[rc + 2]: the neighbouring lanes' own rows; the wave's two outer ones are loaded
-    const bool edge = lane == 0 || lane == kWave - 1;
-    double e = 0.0;
-    if (edge) e = *reinterpret_cast<const double *>(xg_base + (size_t)((rc + (uint32_t)(kVecGuard + (lane == 0 ? -1 : 2))) << 3));
-    const double left = dpp_shift<0x138>(xi.y);   // wave_shr:1 -- lane i receives lane i - 1
-    const double right = dpp_shift<0x130>(xi.x);  // wave_shl:1 -- lane i receives lane i + 1
-    xg[M1 >= 0 ? M1 : 0].x = lane == 0 ? e : left;
-    xg[M1 >= 0 ? M1 : 0].y = xi.x;
-    xg[M1 >= 0 ? M1 + 1 : 0].x = xi.y;
-    xg[M1 >= 0 ? M1 + 1 : 0].y = lane == kWave - 1 ? e : right;
-  }
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     if (M1 >= 0 && (k == M1 || k == M1 + 1)) continue;
     int t = (int)rc + C.off[k] + kVecGuard;  // guard-relative, clamped: an absent neighbour may point anywhere
     t = t < 0 ? 0 : t;
     t = t > C.max_gather ? C.max_gather : t;
-    xg[k] = *reinterpret_cast<const double2v *>(xg_base + ((size_t)(uint32_t)t << 3));
+    // (32-bit byte offset from a uniform base: n_rows + n_halo < 2^28 is a condition of the paired formats)
+    xg[k] = *reinterpret_cast<const double2v *>(xg_base + (size_t)((uint32_t)t << 3));
+  }
+  double e = 0.0;
+  if (M1 >= 0 && (lane == 0 || lane == kWave - 1))  // x[rc - 1] of lane 0, x[rc + 2] of lane 63
+    e = *reinterpret_cast<const double *>(xg_base + (size_t)((rc + (uint32_t)(kVecGuard + (lane == 0 ? -1 : 2))) << 3));
+  if (lane < 32) dict_sh[lane] = dict_word;  // one copy per block, every wave stores the same words: no barrier
+  if (M1 >= 0) {
+    // x[rc - 1] and x[rc + 2] are the neighbouring lanes' own rows
+    const double left = dpp_shift<0x138>(xi.y);   // wave_shr:1 -- lane i receives lane i - 1
+    const double right = dpp_shift<0x130>(xi.x);  // wave_shl:1 -- lane i receives lane i + 1
+    xg[M1 >= 0 ? M1 : 0].x = lane == 0 ? e : left;
+    xg[M1 >= 0 ? M1 : 0].y = xi.x;
+    xg[M1 >= 0 ? M1 + 1 : 0].x = xi.y;
+    xg[M1 >= 0 ? M1 + 1 : 0].y = lane == kWave - 1 ? e : right;
   }
   __builtin_amdgcn_wave_barrier();  // this wave's copy of the table is complete (same-wave LDS order)
   double acc_a = 0.0, acc_b = 0.0;
