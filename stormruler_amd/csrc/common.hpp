@@ -85,6 +85,7 @@ struct storm_hip_ctx {
   int64_t partials_capacity = 0;
   double *d_partials2 = nullptr;      // [kMaxMulti * kStage2] second-stage partials
   double *d_scalars = nullptr;        // [kMaxMulti] results of host-visible reductions
+  unsigned *d_barrier = nullptr;      // words of the latency path's grid barrier (one cache line each)
   double *h_scalars = nullptr;        // pinned mirror
   storm::SolverState *d_state = nullptr;
   storm::SolverState *h_state = nullptr;  // pinned staging copy of the state
@@ -102,6 +103,8 @@ struct storm_hip_ctx {
   int64_t opt_blas1_nt = 1;  // non-temporal loads/stores in the streaming kernels
   int64_t opt_graph = 0;     // replay CG / BiCGStab iterations from a captured hipGraph: measured slower than eager launches (profiles/r01_notes.md), off
   int64_t opt_fuse_mgs = 1;  // GMRES/MGS on one rank, <= 2048 blocks: each step folds the previous step's partials itself (no final-reduction launch in between)
+  int64_t opt_latency_path = 1;         // small operators: CG as one cooperative persistent kernel (latency.hip)
+  int64_t opt_latency_rows = 1 << 19;   // ... up to this many rows (a compact copy of the operator is kept for it)
   int64_t opt_generic_solvers = 0;  // 1: storm_hip_krylov_solve never takes the fused CG / BiCGStab / GMRES loops (A/B knob)
   int64_t opt_fuse_dot = 1;  // 0: reductions after an SpMV run as separate kernels (A/B knob)
   // Vector storage released by vec_destroy, kept for the next vec_create of the same size: a solve
@@ -173,6 +176,10 @@ struct storm_hip_op {
   int *d_interior = nullptr, *d_boundary = nullptr;
   int64_t n_interior = 0, n_boundary = 0;
   int64_t device_bytes = 0;
+  // compact fp64 copy for the latency path (latency.hip); null when the operator does not qualify
+  char *d_lat_pack = nullptr;
+  int64_t *d_lat_off = nullptr;
+  int64_t lat_bytes = 0;
   storm::HaloPlan halo;
 };
 
@@ -240,6 +247,13 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
                 const SpmvDot *dot, const int *done, bool accumulate = false);
 int spmv_grid_blocks(const storm_hip_op *op);
 int op_upload_slice_lists(storm_hip_op *op);
+
+// latency.hip
+int op_make_latency_copy(storm_hip_op *op, int64_t n, int64_t n_halo, const std::vector<int64_t> &row_ptr,
+                         const std::vector<int> &col, const std::vector<double> &val, const std::vector<double> &ext);
+bool cg_latency_eligible(const storm_hip_op *op);
+int cg_latency_solve(const storm_hip_op *op, double alpha, double beta, const double *b, double *x, double *p,
+                     double *r, SolverState *d_state);
 
 // comm.hip
 int comm_allreduce_sum(storm_hip_ctx *c, double *d_buf, int count);  // in place, on ctx->stream

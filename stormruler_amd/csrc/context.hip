@@ -58,6 +58,8 @@ int storm_hip_ctx_create(int device_id, storm_hip_ctx **out) {
   HIP_TRY(hipMalloc(&c->d_partials2, sizeof(double) * kMaxMulti * kStage2));
   HIP_TRY(hipMalloc(&c->d_scalars, sizeof(double) * kMaxMulti));
   HIP_TRY(hipHostMalloc((void **)&c->h_scalars, sizeof(double) * kMaxMulti, hipHostMallocDefault));
+  HIP_TRY(hipMalloc((void **)&c->d_barrier, 10 * 32 * sizeof(unsigned)));  // latency.hip: 8 group counters, root, generation
+  HIP_TRY(hipMemset(c->d_barrier, 0, 10 * 32 * sizeof(unsigned)));
   HIP_TRY(hipMalloc((void **)&c->d_state, sizeof(SolverState)));
   HIP_TRY(hipMemset(c->d_state, 0, sizeof(SolverState)));
   HIP_TRY(hipHostMalloc((void **)&c->h_state, sizeof(SolverState), hipHostMallocDefault));
@@ -80,6 +82,7 @@ int storm_hip_ctx_destroy(storm_hip_ctx *c) {
   (void)hipFree(c->d_partials);
   (void)hipFree(c->d_partials2);
   (void)hipFree(c->d_scalars);
+  (void)hipFree(c->d_barrier);
   (void)hipHostFree(c->h_scalars);
   (void)hipFree(c->d_state);
   (void)hipHostFree(c->h_state);
@@ -118,6 +121,8 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   if (!strcmp(key, "ell_cap")) c->opt_ell_cap = value;
   else if (!strcmp(key, "spmv_variant")) c->opt_spmv_variant = value;
   else if (!strcmp(key, "generic_solvers")) c->opt_generic_solvers = value;
+  else if (!strcmp(key, "latency_path")) c->opt_latency_path = value;
+  else if (!strcmp(key, "latency_rows")) c->opt_latency_rows = value;
   else if (!strcmp(key, "nontemporal")) c->opt_nt = value;
   else if (!strcmp(key, "spmv_xcd_remap")) c->opt_spmv_xcd_remap = value;
   else if (!strcmp(key, "spmv_dict")) c->opt_spmv_dict = value;

@@ -1,0 +1,331 @@
+// The latency path: CG for SMALL operators as ONE cooperative, persistent kernel per solve.
+//
+// The reference's own meshes have 6 000 .. 80 000 cells (tests/_data/mesh), BASELINE config 1 has 64^3 = 262 144:
+// vectors of 50 KB .. 2 MB.  The throughput path (solvers.hip) spends such an iteration on launch latency -- 7 kernels
+// of a few microseconds each.  Here a solve is one launch (SolverCg.hpp:54-126 inside Solver.hpp:116-147):
+//
+//   * every wavefront owns a fixed set of 64-row slices for the whole solve and keeps x, r, p, z of its rows in
+//     REGISTERS; what other wavefronts need for their gathers is published once per iteration -- the rows of the
+//     new r and of the CURRENT p -- and a gathering wave forms the neighbour's next direction itself,
+//     p'[c] = r[c] + beta p[c], with the same expression (hence the same bits) as the owner does in registers.
+//     That removes the third synchronisation point of a CG iteration ("p complete"): TWO grid barriers per
+//     iteration remain, one behind each reduction;
+//   * the operator is read from a compact fp64 sliced-ELL copy made when the operator was built
+//     ([ext 64 f64][col W x 64 i32][val W x 64 f64] per slice, slot-major; small: it stays in L2 / Infinity Cache);
+//   * the two reductions (<p, Ap>, <r, r>) are per-block partials that EVERY block folds itself in the same fixed
+//     order after the barrier, so all blocks hold bit-identical alpha, beta and the same convergence verdict: the
+//     exit condition is uniform.
+//   * rows are summed slot by slot exactly as the throughput kernels do (same expression, same contraction): the
+//     SpMV values are bit-identical; dot products group their terms differently (rounding-level differences).
+//
+// Taken by storm_hip_solve_cg when the operator has a latency copy (n_rows <= option `latency_rows`, no halo, no
+// CSR tail), the context has no communicator, and option `latency_path` != 0.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.hpp"
+#include "solver_device.hpp"
+
+namespace storm {
+
+constexpr int kLatSlices = 8;  // slices a wavefront may own (registers: 4 doubles per slice and lane)
+constexpr int kLatBlock = 1024;  // one block per CU: the grid barrier costs per ARRIVING BLOCK (serialised atomics)
+constexpr int kLatWaves = kLatBlock / kWave;
+constexpr int kLatGroups = 8;    // arrival counters (one per XCD-sized group of blocks), each on its own cache line
+constexpr int kLatLine = 32;     // unsigned words per 128-byte line
+
+struct LatArgs {
+  const char *pack;          // compact records
+  const int64_t *rec_off;    // [n_slices + 1] byte offsets
+  int64_t n_rows, n_slices;
+  double alpha, beta;        // A = beta I + alpha M
+  const double *b;
+  double *x;
+  double *p, *r;             // published rows of the current direction and the new residual (see the header)
+  double *partials;          // [2 * gridDim.x]
+  SolverState *st;
+  unsigned *barrier;         // {arrival count, generation}
+};
+
+// Data that crosses wavefronts inside the kernel -- the rows of p, the reduction partials, the barrier words -- is
+// written and read with RELAXED AGENT-SCOPE ATOMIC accesses: single stores / loads that are coherent across the
+// XCDs' private L2s (write-through, miss-through).  Whole-cache release / acquire fences (L2 write-back and
+// invalidate, which an agent-scope fence means on this chip) are never issued: they cost ~100 us per barrier when
+// 4 096 wavefronts execute them, and would evict the operator records, which are read-only and may stay cached.
+__device__ __forceinline__ void co_store(double *p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double co_load(const double *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Grid barrier for a co-resident (cooperative) grid.  Same-address agent-scope atomics serialise at ~35 ns each
+// (measured: 1 024 arriving blocks = 37 us per barrier), so arrivals are counted in two levels: kLatGroups counters on
+// separate cache lines (block b -> group b % 8, the XCD it runs on), whose last arriver reports to one root counter;
+// the last of those moves the generation word everybody polls.  256 blocks: 32 + 8 serial atomics instead of 256.
+// A wave's coherent stores are complete once its own memory counter has drained (workgroup-scope release =
+// s_waitcnt), which every wave does before its block arrives.
+//   bar[g * kLatLine], g < 8: group counters;  bar[8 * kLatLine]: root counter;  bar[9 * kLatLine]: generation.
+__device__ __forceinline__ void lat_grid_barrier(unsigned *bar, unsigned n_blocks) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned *gen_word = bar + 9 * kLatLine, *root = bar + 8 * kLatLine;
+    const unsigned gen = __hip_atomic_load(gen_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned group = blockIdx.x % kLatGroups;
+    const unsigned n_groups = n_blocks < kLatGroups ? n_blocks : kLatGroups;
+    const unsigned in_group = (n_blocks - group + kLatGroups - 1) / kLatGroups;
+    unsigned *mine = bar + group * kLatLine;
+    bool released = false;
+    if (__hip_atomic_fetch_add(mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_group - 1) {
+      __hip_atomic_store(mine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__hip_atomic_fetch_add(root, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_groups - 1) {
+        __hip_atomic_store(root, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // every reset is out before the generation moves
+        __hip_atomic_fetch_add(gen_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        released = true;
+      }
+    }
+    if (!released)
+      while (__hip_atomic_load(gen_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(1);
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ double lat_wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+
+// Every block: sum of `count` partials in one fixed order (so all blocks hold the same bits).
+__device__ __forceinline__ double lat_block_sum(double v, double *lds) {  // the same bits in every thread
+  v = lat_wave_sum(v);
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) lds[wave] = v;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int w = 0; w < kLatWaves; ++w) t += lds[w];
+  return t;
+}
+__device__ __forceinline__ double lat_fold(const double *partials, int count, double *lds) {
+  double v = 0.0;
+  for (int i = threadIdx.x; i < count; i += kLatBlock) v += co_load(partials + i);
+  return lat_block_sum(v, lds);
+}
+
+__device__ __forceinline__ void lat_block_partial(double v, double *out, double *lds) {
+  const double t = lat_block_sum(v, lds);
+  if (threadIdx.x == 0) co_store(out, t);
+}
+
+// (M v)_row for one row of slice s: sum_k w_k (v[col_k] - v_i) + ext v_i, slots in order.
+// Neighbour value of the vector an SpMV is applied to: plain x (init), or the direction p' = r + beta p formed
+// from the published rows.
+struct LatPlain {
+  const double *v;
+  __device__ __forceinline__ double operator()(int c) const { return v[c]; }
+};
+struct LatDirection {
+  const double *r, *p;
+  double beta;
+  __device__ __forceinline__ double operator()(int c) const { return co_load(r + c) + beta * co_load(p + c); }
+};
+
+// (M v)_row for one row of slice s: sum_k w_k (v[col_k] - v_i) + ext v_i, slots in order.
+template <class Get>
+__device__ __forceinline__ double lat_row(const LatArgs &a, int64_t s, int lane, const Get &get, double vi) {
+  const int64_t o0 = a.rec_off[s];
+  const int width = (int)((a.rec_off[s + 1] - o0 - kWave * 8) / (kWave * 12));
+  const char *rec = a.pack + o0;
+  const double ext = reinterpret_cast<const double *>(rec)[lane];
+  const int *col = reinterpret_cast<const int *>(rec + kWave * 8) + lane;
+  const double *val = reinterpret_cast<const double *>(rec + kWave * 8 + (int64_t)width * (kWave * 4)) + lane;
+  double acc = 0.0;
+  int k = 0;
+  for (; k + 4 <= width; k += 4) {  // four neighbours in flight
+    const int c0 = col[k * kWave], c1 = col[(k + 1) * kWave], c2 = col[(k + 2) * kWave], c3 = col[(k + 3) * kWave];
+    const double w0 = val[k * kWave], w1 = val[(k + 1) * kWave], w2 = val[(k + 2) * kWave], w3 = val[(k + 3) * kWave];
+    const double g0 = get(c0), g1 = get(c1), g2 = get(c2), g3 = get(c3);
+    acc += w0 * (g0 - vi);
+    acc += w1 * (g1 - vi);
+    acc += w2 * (g2 - vi);
+    acc += w3 * (g3 - vi);
+  }
+  for (; k < width; ++k) acc += val[k * kWave] * (get(col[k * kWave]) - vi);
+  return a.beta * vi + a.alpha * (acc + ext * vi);
+}
+
+template <int S>
+__global__ __launch_bounds__(kLatBlock) void cg_latency_kernel(LatArgs a) {
+  __shared__ double lds4[kLatWaves];
+  SolverState *st = a.st;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t wave_id = (int64_t)blockIdx.x * kLatWaves + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * kLatWaves;
+  double *part0 = a.partials, *part1 = a.partials + gridDim.x;
+  double x[S], r[S], p[S], z[S];
+
+  // ---- init: r = b - A x; p = r; gamma = <r, r>                                   SolverCg.hpp:54-84
+  // (a.p arrives zero-filled -- a fresh work vector -- so the first direction r + 0 * p is r)
+  double acc = 0.0;
+#pragma unroll
+  for (int q = 0; q < S; ++q) {
+    const int64_t s = wave_id + q * n_waves, row = s * kWave + lane;
+    const bool valid = s < a.n_slices && row < a.n_rows;
+    x[q] = valid ? a.x[row] : 0.0;
+    r[q] = p[q] = z[q] = 0.0;
+    if (s < a.n_slices) {
+      const double ax = lat_row(a, s, lane, LatPlain{a.x}, x[q]);  // x is not written before the kernel's end
+      r[q] = valid ? a.b[row] - ax : 0.0;
+      p[q] = r[q];
+      if (valid) co_store(a.r + row, r[q]);
+      acc += r[q] * r[q];
+    }
+  }
+  lat_block_partial(acc, part1 + blockIdx.x, lds4);
+  lat_grid_barrier(a.barrier, gridDim.x);
+  double gamma = lat_fold(part1, gridDim.x, lds4);
+  const double initial_error = sqrt(gamma);
+  const double abs_tol = st->abs_tol, rel_tol = st->rel_tol;
+  const long long num_iterations = st->num_iterations;
+  double *history = st->history;
+  bool converged = abs_tol > 0.0 && initial_error < abs_tol;  // Solver.hpp:124-128
+  double abs_err = initial_error, rel_err = 0.0, beta = 0.0;
+  long long it = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && history) history[0] = initial_error;
+
+  // ---- iterations                                                                 SolverCg.hpp:86-126
+  // entering: registers hold x, r and the direction p of the own rows; memory holds r and the PREVIOUS direction,
+  // from which a neighbour's current direction is r[c] + beta p_prev[c]
+  while (!converged && it < num_iterations) {
+    acc = 0.0;
+    const LatDirection dir{a.r, a.p, beta};
+#pragma unroll
+    for (int q = 0; q < S; ++q) {
+      const int64_t s = wave_id + q * n_waves;
+      if (s < a.n_slices) {
+        z[q] = lat_row(a, s, lane, dir, p[q]);
+        z[q] = (s * kWave + lane < a.n_rows) ? z[q] : 0.0;
+        acc += p[q] * z[q];
+      }
+    }
+    lat_block_partial(acc, part0 + blockIdx.x, lds4);
+    lat_grid_barrier(a.barrier, gridDim.x);  // every gather is done, every <p, z> partial is out
+    const double alpha = safe_divide(gamma, lat_fold(part0, gridDim.x, lds4));
+    acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < S; ++q) {
+      const int64_t s = wave_id + q * n_waves, row = s * kWave + lane;
+      x[q] += alpha * p[q];
+      r[q] -= alpha * z[q];
+      acc += r[q] * r[q];
+      if (s < a.n_slices && row < a.n_rows) co_store(a.r + row, r[q]), co_store(a.p + row, p[q]);
+    }
+    lat_block_partial(acc, part1 + blockIdx.x, lds4);
+    lat_grid_barrier(a.barrier, gridDim.x);  // the new r, the current p and every <r, r> partial are out
+    const double gamma_bar = gamma;
+    gamma = lat_fold(part1, gridDim.x, lds4);
+    beta = safe_divide(gamma, gamma_bar);
+    abs_err = sqrt(gamma);
+    rel_err = abs_err / initial_error;
+    converged = (abs_tol > 0.0 && abs_err < abs_tol) || (rel_tol > 0.0 && rel_err < rel_tol);  // Solver.hpp:132-140
+    ++it;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && history) history[it] = abs_err;
+#pragma unroll
+    for (int q = 0; q < S; ++q) p[q] = r[q] + beta * p[q];
+  }
+#pragma unroll
+  for (int q = 0; q < S; ++q) {
+    const int64_t s = wave_id + q * n_waves, row = s * kWave + lane;
+    if (s < a.n_slices && row < a.n_rows) a.x[row] = x[q];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->initial_error = initial_error;
+    st->absolute_error = abs_err;
+    st->relative_error = rel_err;
+    st->iteration = it;
+    st->converged = converged ? 1 : 0;
+    st->done = 1;
+  }
+}
+
+// Compact fp64 copy of an operator for the latency path (called by build_op); absent when the operator is too
+// large, partitioned, or has rows longer than its ELL cap.
+int op_make_latency_copy(storm_hip_op *op, int64_t n, int64_t n_halo, const std::vector<int64_t> &row_ptr,
+                         const std::vector<int> &col, const std::vector<double> &val, const std::vector<double> &ext) {
+  storm_hip_ctx *c = op->ctx;
+  if (c->opt_latency_path == 0 || n_halo != 0 || n <= 0 || n > c->opt_latency_rows) return STORM_HIP_OK;
+  const int64_t n_slices = (n + kWave - 1) / kWave;
+  std::vector<int64_t> off((size_t)n_slices + 1, 0);
+  for (int64_t s = 0; s < n_slices; ++s) {
+    int64_t w = 0;
+    for (int64_t r = s * kWave; r < std::min(n, (s + 1) * kWave); ++r) w = std::max(w, row_ptr[r + 1] - row_ptr[r]);
+    if (w > 64) return STORM_HIP_OK;  // a very long row: the throughput path's CSR tail handles those
+    off[(size_t)s + 1] = off[(size_t)s] + kWave * 8 + w * (kWave * 12);
+  }
+  std::vector<char> pack((size_t)off[(size_t)n_slices], 0);
+  for (int64_t s = 0; s < n_slices; ++s) {
+    const int width = (int)((off[(size_t)s + 1] - off[(size_t)s] - kWave * 8) / (kWave * 12));
+    char *rec = pack.data() + off[(size_t)s];
+    double *e_ = reinterpret_cast<double *>(rec);
+    int *c_ = reinterpret_cast<int *>(rec + kWave * 8);
+    double *v_ = reinterpret_cast<double *>(rec + kWave * 8 + (int64_t)width * (kWave * 4));
+    for (int l = 0; l < kWave; ++l) {
+      const int64_t r = s * kWave + l;
+      e_[l] = r < n ? ext[(size_t)r] : 0.0;
+      const int64_t b0 = r < n ? row_ptr[r] : 0, e0 = r < n ? row_ptr[r + 1] : 0;
+      for (int k = 0; k < width; ++k) {
+        const bool real = b0 + k < e0;
+        c_[k * kWave + l] = real ? col[(size_t)(b0 + k)] : (int)(r < n ? r : n - 1);
+        v_[k * kWave + l] = real ? val[(size_t)(b0 + k)] : 0.0;
+      }
+    }
+  }
+  HIP_TRY(hipMalloc((void **)&op->d_lat_pack, pack.size() ? pack.size() : 1));
+  HIP_TRY(hipMalloc((void **)&op->d_lat_off, sizeof(int64_t) * off.size()));
+  HIP_TRY(hipMemcpy(op->d_lat_pack, pack.data(), pack.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(op->d_lat_off, off.data(), sizeof(int64_t) * off.size(), hipMemcpyHostToDevice));
+  op->lat_bytes = (int64_t)pack.size();
+  return STORM_HIP_OK;
+}
+
+bool cg_latency_eligible(const storm_hip_op *op) {
+  const storm_hip_ctx *c = op->ctx;
+  return c->opt_latency_path != 0 && c->comm == nullptr && op->d_lat_pack != nullptr && c->opt_profile_spmv == 0;
+}
+
+// The whole solve; fills the SolverState on the device (the caller reads it back).
+int cg_latency_solve(const storm_hip_op *op, double alpha, double beta, const double *b, double *x, double *p,
+                     double *r, SolverState *d_state) {
+  storm_hip_ctx *c = op->ctx;
+  const int64_t n_slices = (op->n_rows + kWave - 1) / kWave;
+  // A co-resident grid (cooperative launch): one 1024-thread block per CU at most, at least one slice per
+  // wavefront.  The smallest register variant that covers all slices with that grid is taken.
+  const void *variants[4] = {(const void *)cg_latency_kernel<1>, (const void *)cg_latency_kernel<2>,
+                             (const void *)cg_latency_kernel<4>, (const void *)cg_latency_kernel<8>};
+  const int capacity[4] = {1, 2, 4, 8};
+  const void *fn = nullptr;
+  int64_t blocks = 0;
+  for (int v = 0; v < 4 && fn == nullptr; ++v) {
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, variants[v], kLatBlock, 0));
+    if (per_cu < 1) continue;
+    blocks = std::max<int64_t>(1, std::min<int64_t>((int64_t)c->num_cus, (n_slices + kLatWaves - 1) / kLatWaves));
+    const int64_t waves = blocks * kLatWaves;
+    if ((n_slices + waves - 1) / waves <= capacity[v]) fn = variants[v];
+  }
+  STORM_REQUIRE(fn != nullptr, "latency path: %lld rows do not fit %d slices per wavefront", (long long)op->n_rows,
+                kLatSlices);
+  STORM_REQUIRE(2 * blocks <= c->partials_capacity, "latency path: partials workspace too small");
+  LatArgs a{op->d_lat_pack, op->d_lat_off, op->n_rows, n_slices, alpha, beta, b, x, p, r, c->d_partials, d_state, c->d_barrier};
+  void *args[] = {&a};
+  HIP_TRY(hipLaunchCooperativeKernel(fn, dim3((unsigned)blocks), dim3(kLatBlock), args, 0, c->stream));
+  return STORM_HIP_OK;
+}
+
+}  // namespace storm

@@ -747,6 +747,11 @@ int storm_hip_solve_cg(const storm_hip_op *op, double alpha, double beta, const 
   Driver d{c, op, alpha, beta, n, c->d_state, &c->d_state->done};
   STORM_TRY(prepare_state(d, params, history));
   VecPool pool;
+  if (cg_latency_eligible(op)) {  // a small operator: the whole solve as one cooperative kernel (latency.hip)
+    STORM_TRY(pool.make(x, 2));  // zero-filled: the kernel relies on that for the first direction
+    STORM_TRY(cg_latency_solve(op, alpha, beta, b->d, x->d, pool.v[0]->d, pool.v[1]->d, c->d_state));
+    return collect(d, result, history, applies_cg, 0);
+  }
   STORM_TRY(pool.make(x, 3));
   double *p = pool.v[0]->d, *r = pool.v[1]->d, *z = pool.v[2]->d;
   const int nbv = vec_blocks(c, n);

@@ -1040,6 +1040,13 @@ static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vect
   int64_t max_len = 0;
   for (int64_t i = 0; i < n; ++i) max_len = std::max(max_len, row_ptr[i + 1] - row_ptr[i]);
   op->max_row_len = max_len;
+  {
+    const int st_lat = op_make_latency_copy(op, n, n_halo, row_ptr, col, val, ext);
+    if (st_lat != STORM_HIP_OK) {
+      storm_hip_op_destroy(op);
+      return st_lat;
+    }
+  }
   int64_t cap = c->opt_ell_cap;
   if (cap <= 0) {
     const double mean = n > 0 ? (double)op->nnz / (double)n : 0.0;
@@ -1542,6 +1549,8 @@ int storm_hip_op_destroy(storm_hip_op *op) {
   (void)hipFree(op->d_tail_ptr);
   (void)hipFree(op->d_tail_col);
   (void)hipFree(op->d_tail_val);
+  (void)hipFree(op->d_lat_pack);
+  (void)hipFree(op->d_lat_off);
   (void)hipFree(op->halo.d_send_idx);
   (void)hipFree(op->halo.d_sendbuf);
   delete op;
