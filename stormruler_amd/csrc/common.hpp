@@ -85,7 +85,7 @@ struct storm_hip_ctx {
   int64_t partials_capacity = 0;
   double *d_partials2 = nullptr;      // [kMaxMulti * kStage2] second-stage partials
   double *d_scalars = nullptr;        // [kMaxMulti] results of host-visible reductions
-  unsigned *d_barrier = nullptr;      // words of the latency path's grid barrier (one cache line each)
+  char *d_lat_slots = nullptr;        // latency path: one 256-byte all-reduce slot per block (256 blocks)
   double *h_scalars = nullptr;        // pinned mirror
   storm::SolverState *d_state = nullptr;
   storm::SolverState *h_state = nullptr;  // pinned staging copy of the state

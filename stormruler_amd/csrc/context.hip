@@ -58,8 +58,8 @@ int storm_hip_ctx_create(int device_id, storm_hip_ctx **out) {
   HIP_TRY(hipMalloc(&c->d_partials2, sizeof(double) * kMaxMulti * kStage2));
   HIP_TRY(hipMalloc(&c->d_scalars, sizeof(double) * kMaxMulti));
   HIP_TRY(hipHostMalloc((void **)&c->h_scalars, sizeof(double) * kMaxMulti, hipHostMallocDefault));
-  HIP_TRY(hipMalloc((void **)&c->d_barrier, 10 * 32 * sizeof(unsigned)));  // latency.hip: 8 group counters, root, generation
-  HIP_TRY(hipMemset(c->d_barrier, 0, 10 * 32 * sizeof(unsigned)));
+  HIP_TRY(hipMalloc((void **)&c->d_lat_slots, 256 * 256));  // latency.hip: all-reduce slots
+  HIP_TRY(hipMemset(c->d_lat_slots, 0, 256 * 256));
   HIP_TRY(hipMalloc((void **)&c->d_state, sizeof(SolverState)));
   HIP_TRY(hipMemset(c->d_state, 0, sizeof(SolverState)));
   HIP_TRY(hipHostMalloc((void **)&c->h_state, sizeof(SolverState), hipHostMallocDefault));
@@ -82,7 +82,7 @@ int storm_hip_ctx_destroy(storm_hip_ctx *c) {
   (void)hipFree(c->d_partials);
   (void)hipFree(c->d_partials2);
   (void)hipFree(c->d_scalars);
-  (void)hipFree(c->d_barrier);
+  (void)hipFree(c->d_lat_slots);
   (void)hipHostFree(c->h_scalars);
   (void)hipFree(c->d_state);
   (void)hipHostFree(c->h_state);

@@ -12,9 +12,13 @@
 //     iteration remain, one behind each reduction;
 //   * the operator is read from a compact fp64 sliced-ELL copy made when the operator was built
 //     ([ext 64 f64][col W x 64 i32][val W x 64 f64] per slice, slot-major; small: it stays in L2 / Infinity Cache);
-//   * the two reductions (<p, Ap>, <r, r>) are per-block partials that EVERY block folds itself in the same fixed
-//     order after the barrier, so all blocks hold bit-identical alpha, beta and the same convergence verdict: the
-//     exit condition is uniform.
+//   * a reduction IS the barrier: every block publishes (partial, sequence number) in its own slot -- the value,
+//     then, once that store is acknowledged, the tag -- and every block polls all slots with single 16-byte
+//     coherent loads until each carries the current sequence number, then folds the values in slot order.  All
+//     blocks hold bit-identical alpha, beta and the same convergence verdict (the exit condition is uniform), and
+//     a synchronisation point costs about 2.5 memory round trips instead of the 6 of "partials, counter barrier,
+//     read partials" (an iteration is a chain of ~0.8 us round trips; nothing else matters at this size);
+//   * the records of a wave's slices are loaded into registers once (<= 8 slots per row, <= 2 slices per wave).
 //   * rows are summed slot by slot exactly as the throughput kernels do (same expression, same contraction): the
 //     SpMV values are bit-identical; dot products group their terms differently (rounding-level differences).
 //
@@ -31,10 +35,8 @@
 namespace storm {
 
 constexpr int kLatSlices = 8;  // slices a wavefront may own (registers: 4 doubles per slice and lane)
-constexpr int kLatBlock = 1024;  // one block per CU: the grid barrier costs per ARRIVING BLOCK (serialised atomics)
+constexpr int kLatBlock = 1024;  // one block per CU: a synchronisation point costs per participating BLOCK
 constexpr int kLatWaves = kLatBlock / kWave;
-constexpr int kLatGroups = 8;    // arrival counters (one per XCD-sized group of blocks), each on its own cache line
-constexpr int kLatLine = 32;     // unsigned words per 128-byte line
 
 struct LatArgs {
   const char *pack;          // compact records
@@ -44,12 +46,11 @@ struct LatArgs {
   const double *b;
   double *x;
   double *p, *r;             // published rows of the current direction and the new residual (see the header)
-  double *partials;          // [2 * gridDim.x]
+  char *slots;               // all-reduce slots, kLatSlotStride bytes per block, zeroed before the launch
   SolverState *st;
-  unsigned *barrier;         // {arrival count, generation}
 };
 
-// Data that crosses wavefronts inside the kernel -- the rows of p, the reduction partials, the barrier words -- is
+// Data that crosses wavefronts inside the kernel -- the published rows of r and p, the all-reduce slots -- is
 // written and read with RELAXED AGENT-SCOPE ATOMIC accesses: single stores / loads that are coherent across the
 // XCDs' private L2s (write-through, miss-through).  Whole-cache release / acquire fences (L2 write-back and
 // invalidate, which an agent-scope fence means on this chip) are never issued: they cost ~100 us per barrier when
@@ -61,46 +62,24 @@ __device__ __forceinline__ double co_load(const double *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Grid barrier for a co-resident (cooperative) grid.  Same-address agent-scope atomics serialise at ~35 ns each
-// (measured: 1 024 arriving blocks = 37 us per barrier), so arrivals are counted in two levels: kLatGroups counters on
-// separate cache lines (block b -> group b % 8, the XCD it runs on), whose last arriver reports to one root counter;
-// the last of those moves the generation word everybody polls.  256 blocks: 32 + 8 serial atomics instead of 256.
-// A wave's coherent stores are complete once its own memory counter has drained (workgroup-scope release =
-// s_waitcnt), which every wave does before its block arrives.
-//   bar[g * kLatLine], g < 8: group counters;  bar[8 * kLatLine]: root counter;  bar[9 * kLatLine]: generation.
-__device__ __forceinline__ void lat_grid_barrier(unsigned *bar, unsigned n_blocks) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned *gen_word = bar + 9 * kLatLine, *root = bar + 8 * kLatLine;
-    const unsigned gen = __hip_atomic_load(gen_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned group = blockIdx.x % kLatGroups;
-    const unsigned n_groups = n_blocks < kLatGroups ? n_blocks : kLatGroups;
-    const unsigned in_group = (n_blocks - group + kLatGroups - 1) / kLatGroups;
-    unsigned *mine = bar + group * kLatLine;
-    bool released = false;
-    if (__hip_atomic_fetch_add(mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_group - 1) {
-      __hip_atomic_store(mine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (__hip_atomic_fetch_add(root, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_groups - 1) {
-        __hip_atomic_store(root, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // every reset is out before the generation moves
-        __hip_atomic_fetch_add(gen_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        released = true;
-      }
-    }
-    if (!released)
-      while (__hip_atomic_load(gen_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(1);
-  }
-  __syncthreads();
+// All-reduce across a co-resident (cooperative) grid, which is also its barrier.  Slot of block b: 16 bytes
+// {value, tag} at slots + b * kLatSlotStride (256 bytes apart, so the polling load of all blocks spreads over the
+// memory channels).  Writer: value; wait for the acknowledgement (which also covers every coherent store the
+// block's waves issued before: each wave drains its own counter ahead of the block-wide barrier); tag.  Reader: ONE
+// aligned 16-byte coherent load per try -- a load that sees the new tag sees the value stored before it.
+constexpr int kLatSlotStride = 256;
+__device__ __forceinline__ void co_load_slot(const char *slot, double *value, unsigned long long *tag) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 w;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(slot) : "memory");
+  *value = __hiloint2double((int)w.y, (int)w.x);
+  *tag = ((unsigned long long)w.w << 32) | w.z;
 }
-
 __device__ __forceinline__ double lat_wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
   return v;
 }
-
-// Every block: sum of `count` partials in one fixed order (so all blocks hold the same bits).
 __device__ __forceinline__ double lat_block_sum(double v, double *lds) {  // the same bits in every thread
   v = lat_wave_sum(v);
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
@@ -112,18 +91,29 @@ __device__ __forceinline__ double lat_block_sum(double v, double *lds) {  // the
   for (int w = 0; w < kLatWaves; ++w) t += lds[w];
   return t;
 }
-__device__ __forceinline__ double lat_fold(const double *partials, int count, double *lds) {
+// Sum over all blocks of `mine` (a per-thread partial), identical bits in every thread of every block.
+__device__ __forceinline__ double lat_allreduce(double mine, char *slots, unsigned long long seq, double *lds) {
+  const double block_value = lat_block_sum(mine, lds);
+  char *my_slot = slots + (size_t)blockIdx.x * kLatSlotStride;
+  if (threadIdx.x == 0) co_store(reinterpret_cast<double *>(my_slot), block_value);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's coherent stores are acknowledged ...
+  __syncthreads();                                         // ... and so are every other wave's of this block
+  if (threadIdx.x == 0)
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(my_slot + 8), seq, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
   double v = 0.0;
-  for (int i = threadIdx.x; i < count; i += kLatBlock) v += co_load(partials + i);
-  return lat_block_sum(v, lds);
+  if (threadIdx.x < gridDim.x) {  // gridDim.x <= 256 <= blockDim.x: thread t watches block t
+    unsigned long long tag;
+    const char *slot = slots + (size_t)threadIdx.x * kLatSlotStride;
+    for (;;) {
+      co_load_slot(slot, &v, &tag);
+      if (tag == seq) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  return lat_block_sum(v, lds);  // slot order: lanes, then waves -- the same tree in every block
 }
 
-__device__ __forceinline__ void lat_block_partial(double v, double *out, double *lds) {
-  const double t = lat_block_sum(v, lds);
-  if (threadIdx.x == 0) co_store(out, t);
-}
-
-// (M v)_row for one row of slice s: sum_k w_k (v[col_k] - v_i) + ext v_i, slots in order.
 // Neighbour value of the vector an SpMV is applied to: plain x (init), or the direction p' = r + beta p formed
 // from the published rows.
 struct LatPlain {
@@ -134,6 +124,14 @@ struct LatDirection {
   const double *r, *p;
   double beta;
   __device__ __forceinline__ double operator()(int c) const { return co_load(r + c) + beta * co_load(p + c); }
+};
+
+constexpr int kLatCacheWidth = 8;  // slots per row held in registers
+template <int S, bool CACHED>
+struct LatRecords {  // the records of a wave's slices: in registers (CACHED) or re-read from memory every time
+  int col[CACHED ? S : 1][CACHED ? kLatCacheWidth : 1];
+  double val[CACHED ? S : 1][CACHED ? kLatCacheWidth : 1];
+  double ext[CACHED ? S : 1];
 };
 
 // (M v)_row for one row of slice s: sum_k w_k (v[col_k] - v_i) + ext v_i, slots in order.
@@ -159,16 +157,53 @@ __device__ __forceinline__ double lat_row(const LatArgs &a, int64_t s, int lane,
   for (; k < width; ++k) acc += val[k * kWave] * (get(col[k * kWave]) - vi);
   return a.beta * vi + a.alpha * (acc + ext * vi);
 }
+// The same from registers: kLatCacheWidth slots, the ones past the row's width carry weight 0 and the row's own
+// column (a term 0 * (v_i - v_i) leaves the sum as it is).
+template <int S, class Get>
+__device__ __forceinline__ double lat_row_cached(const LatArgs &a, const LatRecords<S, true> &rec, int q, const Get &get,
+                                                 double vi) {
+  double g[kLatCacheWidth];
+#pragma unroll
+  for (int k = 0; k < kLatCacheWidth; ++k) g[k] = get(rec.col[q][k]);
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < kLatCacheWidth; ++k) acc += rec.val[q][k] * (g[k] - vi);
+  return a.beta * vi + a.alpha * (acc + rec.ext[q] * vi);
+}
 
-template <int S>
+template <int S, bool CACHED>
 __global__ __launch_bounds__(kLatBlock) void cg_latency_kernel(LatArgs a) {
-  __shared__ double lds4[kLatWaves];
+  __shared__ double lds[kLatWaves];
   SolverState *st = a.st;
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t wave_id = (int64_t)blockIdx.x * kLatWaves + (threadIdx.x >> 6);
   const int64_t n_waves = (int64_t)gridDim.x * kLatWaves;
-  double *part0 = a.partials, *part1 = a.partials + gridDim.x;
+  unsigned long long seq = 0;
   double x[S], r[S], p[S], z[S];
+  LatRecords<S, CACHED> rec;
+  if (CACHED) {
+#pragma unroll
+    for (int q = 0; q < S; ++q) {
+      const int64_t s = wave_id + q * n_waves, row = s * kWave + lane;
+      const bool live = s < a.n_slices;
+      const int64_t o0 = live ? a.rec_off[s] : 0;
+      const int width = live ? (int)((a.rec_off[s + 1] - o0 - kWave * 8) / (kWave * 12)) : 0;
+      const char *base = a.pack + o0;
+      rec.ext[q] = live ? reinterpret_cast<const double *>(base)[lane] : 0.0;
+#pragma unroll
+      for (int k = 0; k < kLatCacheWidth; ++k) {
+        const bool has = k < width;
+        rec.col[q][k] = has ? (reinterpret_cast<const int *>(base + kWave * 8) + lane)[k * kWave]
+                            : (int)(row < a.n_rows ? row : a.n_rows - 1);
+        rec.val[q][k] = has ? (reinterpret_cast<const double *>(base + kWave * 8 + (int64_t)width * (kWave * 4)) + lane)[k * kWave]
+                            : 0.0;
+      }
+    }
+  }
+  auto apply_row = [&](int q, int64_t s, const auto &get, double vi) -> double {
+    if constexpr (CACHED) return lat_row_cached<S>(a, rec, q, get, vi);
+    else return lat_row(a, s, lane, get, vi);
+  };
 
   // ---- init: r = b - A x; p = r; gamma = <r, r>                                   SolverCg.hpp:54-84
   // (a.p arrives zero-filled -- a fresh work vector -- so the first direction r + 0 * p is r)
@@ -180,16 +215,14 @@ __global__ __launch_bounds__(kLatBlock) void cg_latency_kernel(LatArgs a) {
     x[q] = valid ? a.x[row] : 0.0;
     r[q] = p[q] = z[q] = 0.0;
     if (s < a.n_slices) {
-      const double ax = lat_row(a, s, lane, LatPlain{a.x}, x[q]);  // x is not written before the kernel's end
+      const double ax = apply_row(q, s, LatPlain{a.x}, x[q]);  // x is not written before the kernel's end
       r[q] = valid ? a.b[row] - ax : 0.0;
       p[q] = r[q];
       if (valid) co_store(a.r + row, r[q]);
       acc += r[q] * r[q];
     }
   }
-  lat_block_partial(acc, part1 + blockIdx.x, lds4);
-  lat_grid_barrier(a.barrier, gridDim.x);
-  double gamma = lat_fold(part1, gridDim.x, lds4);
+  double gamma = lat_allreduce(acc, a.slots, ++seq, lds);
   const double initial_error = sqrt(gamma);
   const double abs_tol = st->abs_tol, rel_tol = st->rel_tol;
   const long long num_iterations = st->num_iterations;
@@ -209,14 +242,13 @@ __global__ __launch_bounds__(kLatBlock) void cg_latency_kernel(LatArgs a) {
     for (int q = 0; q < S; ++q) {
       const int64_t s = wave_id + q * n_waves;
       if (s < a.n_slices) {
-        z[q] = lat_row(a, s, lane, dir, p[q]);
+        z[q] = apply_row(q, s, dir, p[q]);
         z[q] = (s * kWave + lane < a.n_rows) ? z[q] : 0.0;
         acc += p[q] * z[q];
       }
     }
-    lat_block_partial(acc, part0 + blockIdx.x, lds4);
-    lat_grid_barrier(a.barrier, gridDim.x);  // every gather is done, every <p, z> partial is out
-    const double alpha = safe_divide(gamma, lat_fold(part0, gridDim.x, lds4));
+    // every gather of this iteration is done once all blocks have published their <p, z> partial
+    const double alpha = safe_divide(gamma, lat_allreduce(acc, a.slots, ++seq, lds));
     acc = 0.0;
 #pragma unroll
     for (int q = 0; q < S; ++q) {
@@ -226,10 +258,9 @@ __global__ __launch_bounds__(kLatBlock) void cg_latency_kernel(LatArgs a) {
       acc += r[q] * r[q];
       if (s < a.n_slices && row < a.n_rows) co_store(a.r + row, r[q]), co_store(a.p + row, p[q]);
     }
-    lat_block_partial(acc, part1 + blockIdx.x, lds4);
-    lat_grid_barrier(a.barrier, gridDim.x);  // the new r, the current p and every <r, r> partial are out
+    // the new r and the current p are out (acknowledged before a block's tag is stored) with the <r, r> partials
     const double gamma_bar = gamma;
-    gamma = lat_fold(part1, gridDim.x, lds4);
+    gamma = lat_allreduce(acc, a.slots, ++seq, lds);
     beta = safe_divide(gamma, gamma_bar);
     abs_err = sqrt(gamma);
     rel_err = abs_err / initial_error;
@@ -304,10 +335,13 @@ int cg_latency_solve(const storm_hip_op *op, double alpha, double beta, const do
                      double *r, SolverState *d_state) {
   storm_hip_ctx *c = op->ctx;
   const int64_t n_slices = (op->n_rows + kWave - 1) / kWave;
-  // A co-resident grid (cooperative launch): one 1024-thread block per CU at most, at least one slice per
-  // wavefront.  The smallest register variant that covers all slices with that grid is taken.
-  const void *variants[4] = {(const void *)cg_latency_kernel<1>, (const void *)cg_latency_kernel<2>,
-                             (const void *)cg_latency_kernel<4>, (const void *)cg_latency_kernel<8>};
+  // A co-resident grid (cooperative launch): one 1024-thread block per CU at most (<= 256 blocks: one polling
+  // thread per block), at least one slice per wavefront; the smallest register variant that covers all slices.
+  // registers can hold the records of a wave's slices when rows have <= kLatCacheWidth slots and S <= 2
+  const bool cached = op->max_row_len <= kLatCacheWidth;
+  const void *variants[4] = {cached ? (const void *)cg_latency_kernel<1, true> : (const void *)cg_latency_kernel<1, false>,
+                             cached ? (const void *)cg_latency_kernel<2, true> : (const void *)cg_latency_kernel<2, false>,
+                             (const void *)cg_latency_kernel<4, false>, (const void *)cg_latency_kernel<8, false>};
   const int capacity[4] = {1, 2, 4, 8};
   const void *fn = nullptr;
   int64_t blocks = 0;
@@ -315,14 +349,14 @@ int cg_latency_solve(const storm_hip_op *op, double alpha, double beta, const do
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, variants[v], kLatBlock, 0));
     if (per_cu < 1) continue;
-    blocks = std::max<int64_t>(1, std::min<int64_t>((int64_t)c->num_cus, (n_slices + kLatWaves - 1) / kLatWaves));
+    blocks = std::max<int64_t>(1, std::min<int64_t>(std::min(c->num_cus, 256), (n_slices + kLatWaves - 1) / kLatWaves));
     const int64_t waves = blocks * kLatWaves;
     if ((n_slices + waves - 1) / waves <= capacity[v]) fn = variants[v];
   }
   STORM_REQUIRE(fn != nullptr, "latency path: %lld rows do not fit %d slices per wavefront", (long long)op->n_rows,
                 kLatSlices);
-  STORM_REQUIRE(2 * blocks <= c->partials_capacity, "latency path: partials workspace too small");
-  LatArgs a{op->d_lat_pack, op->d_lat_off, op->n_rows, n_slices, alpha, beta, b, x, p, r, c->d_partials, d_state, c->d_barrier};
+  HIP_TRY(hipMemsetAsync(c->d_lat_slots, 0, (size_t)256 * kLatSlotStride, c->stream));  // tags restart at 1
+  LatArgs a{op->d_lat_pack, op->d_lat_off, op->n_rows, n_slices, alpha, beta, b, x, p, r, c->d_lat_slots, d_state};
   void *args[] = {&a};
   HIP_TRY(hipLaunchCooperativeKernel(fn, dim3((unsigned)blocks), dim3(kLatBlock), args, 0, c->stream));
   return STORM_HIP_OK;

@@ -1,0 +1,133 @@
+"""The latency path (csrc/latency.hip): CG for small operators as one cooperative persistent kernel -- vectors in
+registers, two all-reduce synchronisation points per iteration.  It must be indistinguishable from the throughput
+path (csrc/solvers.hip) except for rounding-level differences of the dot products: same convergence rule and
+counters (Solver.hpp:116-147), same iteration counts (+-1), same solutions, against the oracle too; for every
+register variant (1 / 2 / 4 / 8 slices per wavefront, records cached in registers or re-read), ragged last slices,
+rows longer than the register cache, early exits and zero iterations."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    from oracle import oracle
+    from stormruler_amd import api, mesh
+
+    ctx = api.Context(0)
+    yield api, mesh, oracle, ctx
+    ctx.set_option("latency_path", 1)
+    ctx.set_option("latency_rows", 1 << 19)
+    ctx.close()
+
+
+def _cg(api, ctx, op, b_host, latency, **knobs):
+    ctx.set_option("latency_path", int(latency))
+    s = api.CgSolver()
+    s.record_history = True
+    for k, v in knobs.items():
+        setattr(s, k, v)
+    b, x = api.DeviceVector.from_numpy(ctx, b_host), api.DeviceVector(ctx, b_host.size)
+    ok = s.solve(x, b, op)
+    ctx.set_option("latency_path", 1)
+    return ok, s, x.to_numpy()
+
+
+# rows: 64^3 fills 256 blocks x 16 waves with one slice each; the larger boxes need 2 / 4 / 8 slices per wavefront
+@pytest.mark.parametrize("shape", [(5, 3, 2), (9, 7, 1), (24, 24, 24), (64, 64, 64), (80, 80, 80), (100, 100, 100),
+                                   (128, 128, 100)])
+def test_box_matches_throughput_path_and_oracle(env, shape):
+    api, mesh, oracle, ctx = env
+    g = mesh.structured_box(*shape)
+    ctx.set_option("latency_rows", 1 << 21)
+    mat = api.StencilMatrix.from_face_graph(ctx, g)
+    ctx.set_option("latency_rows", 1 << 19)
+    op = api.HipStencilOperator(mat, -1.0, 0.0)
+    b_host = 1.0 + 0.25 * np.sin(0.01 * np.arange(g.n_cells))
+    ok_l, s_l, x_l = _cg(api, ctx, op, b_host, True)
+    ok_t, s_t, x_t = _cg(api, ctx, op, b_host, False)
+    assert ok_l and ok_t
+    assert abs(s_l.iteration - s_t.iteration) <= 1 and s_l.num_applies == s_l.iteration + 1
+    m = min(len(s_l.history), len(s_t.history))
+    assert np.allclose(s_l.history[:m], s_t.history[:m], rtol=1e-9)
+    assert np.linalg.norm(x_l - x_t) <= 1e-9 * np.linalg.norm(x_t)
+    if g.n_cells <= 64 ** 3:
+        ref = oracle.solve("cg", oracle.StencilOperator(g, -1.0, 0.0), b_host)
+        assert abs(s_l.iteration - ref.iterations) <= max(2, int(0.02 * ref.iterations))
+        assert np.linalg.norm(x_l - ref.x) <= 1e-8 * np.linalg.norm(ref.x)
+    mat.close()
+
+
+def test_the_reference_mesh_runs_on_the_latency_path(env):
+    """step.1 (79 672 cells, 3 neighbours per row) -- the reference's own mesh, the recorded run of BASELINE.md 2."""
+    import os
+
+    api, mesh, oracle, ctx = env
+    from stormruler_amd import io_triangle
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = io_triangle.read_triangle(os.path.join(root, "tests", "golden", "mesh", "step.1."))
+    g = mesh.FaceGraph(g.n_cells, 2, g.inner, g.outer, g.area, g.center, g.volume, b_center=np.zeros((0, 2)))
+    mat = api.StencilMatrix.from_face_graph(ctx, g)
+    b_host = np.sin(3 * g.center[:, 0]) * np.cos(7 * g.center[:, 1])
+    ok, s, x = _cg(api, ctx, api.HipStencilOperator(mat, -1.0e-2, 1.0), b_host, True)
+    assert ok and abs(s.iteration - 621) <= 12
+    assert abs(np.linalg.norm(x) - 108.293490873643) <= 1e-7 * 108.293490873643
+    mat.close()
+
+
+def test_rows_longer_than_the_register_cache_and_ragged_sizes(env):
+    api, mesh, oracle, ctx = env
+    rng = np.random.default_rng(5)
+    for n, per_row in ((1, 0), (63, 2), (65, 3), (1000, 12), (4099, 20)):
+        if per_row:
+            rows = np.repeat(np.arange(n), per_row)
+            cols = rng.integers(0, n, rows.size)
+            a = sp.coo_matrix((rng.random(rows.size) * 0.1, (rows, cols)), shape=(n, n)).tocsr()
+            a = a + a.T
+            a.setdiag(0.0)
+            a.eliminate_zeros()
+            a = (sp.diags(np.asarray(abs(a).sum(axis=1)).ravel() + 1.0) - a).tocsr()  # SPD, diagonally dominant
+        else:
+            a = sp.csr_matrix(np.array([[2.0]]))
+        mat = api.StencilMatrix.from_csr(ctx, a)
+        assert mat.stats()["tail_rows"] == 0
+        b_host = rng.random(n) + 0.5
+        op = api.HipStencilOperator(mat, 1.0, 0.0)
+        ok_l, s_l, x_l = _cg(api, ctx, op, b_host, True, relative_error_tolerance=1e-10, absolute_error_tolerance=0.0)
+        ok_t, s_t, x_t = _cg(api, ctx, op, b_host, False, relative_error_tolerance=1e-10, absolute_error_tolerance=0.0)
+        assert ok_l and ok_t and abs(s_l.iteration - s_t.iteration) <= 1
+        assert np.linalg.norm(a @ x_l - b_host) <= 1e-8 * np.linalg.norm(b_host)
+        assert np.linalg.norm(x_l - x_t) <= 1e-9 * np.linalg.norm(x_t)
+        mat.close()
+
+
+def test_convergence_rule_edges_on_the_latency_path(env):
+    api, mesh, oracle, ctx = env
+    g = mesh.structured_box(10)
+    mat = api.StencilMatrix.from_face_graph(ctx, g)
+    op = api.HipStencilOperator(mat, -1.0, 0.0)
+    b_host = np.ones(g.n_cells)
+    # tolerances off: exactly num_iterations iterate() calls, converged == False
+    ok, s, _ = _cg(api, ctx, op, b_host, True, num_iterations=17, relative_error_tolerance=0.0,
+                   absolute_error_tolerance=0.0)
+    assert not ok and s.iteration == 17 and len(s.history) == 18
+    # the initial residual already meets the absolute tolerance: no iteration, converged (Solver.hpp:124-128)
+    ok, s, x = _cg(api, ctx, op, b_host, True, absolute_error_tolerance=1e9)
+    assert ok and s.iteration == 0 and not x.any()
+    # num_iterations = 0
+    ok, s, x = _cg(api, ctx, op, b_host, True, num_iterations=0)
+    assert not ok and s.iteration == 0 and not x.any()
+    # zero right-hand side: safe_divide keeps everything finite (Crow/MathUtils.hpp:49-52)
+    ok, s, x = _cg(api, ctx, op, np.zeros(g.n_cells), True)
+    assert np.all(np.isfinite(x)) and not x.any()
+    # a warm start is honoured
+    ref = oracle.solve("cg", oracle.StencilOperator(g, -1.0, 0.0), b_host)
+    ctx.set_option("latency_path", 1)
+    sv = api.CgSolver()
+    b, xw = api.DeviceVector.from_numpy(ctx, b_host), api.DeviceVector.from_numpy(ctx, ref.x)
+    sv.solve(xw, b, op)
+    assert sv.initial_error <= 2e-6 * np.linalg.norm(b_host)  # started from the solution, not from zero
+    mat.close()
