@@ -55,6 +55,10 @@ def main() -> int:
     ap.add_argument("--shared-device", action="store_true",
                     help="debug: all ranks on device 0 over the host-staged transport (gloo); exercises the N > 1 "
                          "code path of this script on a one-GPU box -- the rates it prints mean nothing")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "ipc"],
+                    help="N > 1: RCCL (halo send/recv + all-reduce; the default) or the library's peer-window transport "
+                         "(hipIpc-mapped device memory, direct stores over xGMI, one-shot rank-ordered all-reduce fused "
+                         "into the reductions' final pass; verified with 2-4 ranks on one GPU, not yet across GPUs)")
     ap.add_argument("--force-comm", action="store_true",
                     help="take the multi-rank code path (process group, RCCL communicator, all-reduces) even at N = 1")
     ap.add_argument("--min-seconds", type=float, default=0.25,
@@ -108,7 +112,9 @@ def main() -> int:
     for kv in args.opt:
         k_, v_ = kv.split("=")
         ctx.set_option(k_, int(v_))
-    if args.shared_device and world > 1:
+    if args.transport == "ipc" and world > 1:
+        dist.connect_ipc(ctx)
+    elif args.shared_device and world > 1:
         dist.connect_host_staged(ctx)
     elif args.force_comm and world == 1:
         ctx.comm_init(api.Context.comm_unique_id(), 1, 0)
@@ -299,7 +305,8 @@ def main() -> int:
                             f"no preconditioner, b=1, x0=0 [BASELINE.json configs[1]]",
                 "cells_per_gpu": N, "interior_faces_per_gpu": g.n_faces, "ordering": args.ordering,
                 "partition": "single GPU" if world == 1 else
-                             (f"z-slabs, {world} ranks, RCCL halo + all-reduce" if not args.shared_device else
+                             (f"z-slabs, {world} ranks, peer-window halo + all-reduce" if args.transport == "ipc" else
+                              f"z-slabs, {world} ranks, RCCL halo + all-reduce" if not args.shared_device else
                               f"DEBUG: {world} ranks sharing one device over the host-staged transport"),
                 "value_definition": "n_gpus x K / max-over-ranks wall time of a K-iteration solve (init residual included); "
                                     "median over the repeats listed in `timing`",
@@ -340,6 +347,8 @@ def main() -> int:
     dist.barrier()
     try:  # leave no dangling process group / communicator behind
         mat.close()
+        ctx.sync()
+        dist.barrier()  # nobody frees a peer window another rank's kernels may still write to
         ctx.close()
         import torch.distributed as td
 

@@ -95,6 +95,20 @@ typedef int (*storm_hip_exchange_fn)(void *user, int n_nbrs, const int32_t *nbr_
 int storm_hip_ctx_comm_init_host(storm_hip_ctx *ctx, int n_ranks, int rank, storm_hip_allreduce_fn allreduce,
                                  storm_hip_exchange_fn exchange, void *user);
 
+/* Peer-window transport: every rank owns a window of device memory that all ranks map through HIP IPC; halo planes
+ * and reduction scalars are written straight into the RECEIVER's window by the sender's kernels (over xGMI between
+ * GPUs) and picked up by polling -- a one-shot all-reduce of up to 64 doubles summed in rank order (the same bits
+ * on every rank; SURVEY.md 8e "Determinism") and direct halo writes with flag + acknowledgement, in place of
+ * RCCL's latency-bound small collectives.  Also works between processes that share ONE device.
+ *   1. every rank: storm_hip_ctx_comm_ipc_export(ctx, n_ranks, rank, window_bytes (0 = 16 MiB), handle64)
+ *   2. the host program all-gathers the 64-byte handles (rank order)
+ *   3. every rank: storm_hip_ctx_comm_init_ipc(ctx, handles)
+ * A (sender, receiver) pair may move up to (window_bytes / (2 n_ranks)) bytes per exchange.  Waits are bounded (5 s);
+ * a timeout surfaces as STORM_HIP_E_COMM from the next call.  Needs HSA_ENABLE_IPC_MODE_LEGACY=0 on hosts whose
+ * driver only supports dmabuf IPC.  Nothing in the reference corresponds to it (single process). */
+int storm_hip_ctx_comm_ipc_export(storm_hip_ctx *ctx, int n_ranks, int rank, int64_t window_bytes, void *handle64);
+int storm_hip_ctx_comm_init_ipc(storm_hip_ctx *ctx, const void *handles);
+
 /* ---- vectors -------------------------------------------------------------
  * `Feathers::Field` as the solver `Vector` (Feathers/Field.hpp:60-114):
  * contiguous doubles, one per cell.  create == `assign(other, false)`, which

@@ -70,6 +70,8 @@ SIGNATURES = {
     "storm_hip_ctx_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int]),
     "storm_hip_ctx_comm_init_host": (C.c_int, [vp, C.c_int, C.c_int, ALLREDUCE_FN, EXCHANGE_FN, vp]),
     "storm_hip_ctx_comm_size": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "storm_hip_ctx_comm_ipc_export": (C.c_int, [vp, C.c_int, C.c_int, C.c_int64, vp]),
+    "storm_hip_ctx_comm_init_ipc": (C.c_int, [vp, vp]),
     "storm_hip_vec_create": (C.c_int, [vp, C.c_int64, C.c_int64, C.POINTER(vp)]),
     "storm_hip_vec_create_like": (C.c_int, [vp, C.POINTER(vp)]),
     "storm_hip_vec_destroy": (C.c_int, [vp]),

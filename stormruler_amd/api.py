@@ -100,6 +100,18 @@ class Context:
         check(lib.storm_hip_ctx_comm_init(self._h, buf, n_ranks, rank))
         self.n_ranks, self.rank = n_ranks, rank
 
+    def comm_ipc_export(self, n_ranks: int, rank: int, window_bytes: int = 0) -> bytes:
+        """Allocate this rank's peer window (``storm_hip_ctx_comm_ipc_export``); returns its 64-byte IPC handle."""
+        buf = C.create_string_buffer(64)
+        check(lib.storm_hip_ctx_comm_ipc_export(self._h, n_ranks, rank, int(window_bytes), buf))
+        self.n_ranks, self.rank = n_ranks, rank
+        return buf.raw
+
+    def comm_init_ipc(self, handles: bytes):
+        """Map every rank's window (``handles`` = the n_ranks exported handles, rank order)."""
+        assert len(handles) == 64 * self.n_ranks
+        check(lib.storm_hip_ctx_comm_init_ipc(self._h, C.create_string_buffer(handles, len(handles))))
+
     def comm_init_host(self, n_ranks: int, rank: int, allreduce, exchange):
         """Host-staged transport (``storm_hip_ctx_comm_init_host``): ``allreduce(buf)`` sums a float64 array over
         the ranks in place; ``exchange(nbr_rank, sends, recvs)`` delivers ``sends[q]`` to rank ``nbr_rank[q]``

@@ -260,5 +260,8 @@ int comm_allreduce_sum(storm_hip_ctx *c, double *d_buf, int count);  // in place
 int comm_halo_exchange_begin(const storm_hip_op *op, double *x);      // pack + send/recv on comm stream
 int comm_halo_exchange_end(const storm_hip_op *op);                   // compute stream waits
 void comm_destroy(storm_hip_ctx *c);
+int comm_check_error(storm_hip_ctx *c);  // a bounded wait of the peer-window transport gave up
+struct IpcDev;                            // ipc_device.hpp
+bool comm_ipc_next(storm_hip_ctx *c, IpcDev *w, unsigned long long *epoch);
 
 }  // namespace storm

@@ -101,7 +101,7 @@ int storm_hip_ctx_sync(storm_hip_ctx *c) {
   STORM_REQUIRE(c, "ctx_sync: null context");
   HIP_TRY(hipStreamSynchronize(c->comm_stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  return STORM_HIP_OK;
+  return comm_check_error(c);
 }
 
 int storm_hip_ctx_info(storm_hip_ctx *c, char *name, int name_len, int *num_cus,

@@ -29,6 +29,7 @@
 
 #include "common.hpp"
 #include "solver_device.hpp"
+#include "ipc_device.hpp"
 
 namespace storm {
 namespace kry {
@@ -130,20 +131,29 @@ __device__ inline void exec_prog(const SProg &p, double *S, SolverState *st) {
   }
 }
 
-// Final pass of k simultaneous reductions (out.idx[j] = register of sum j) + the scalar program behind them.
+// Final pass of k simultaneous reductions (out.idx[j] = register of sum j) + the scalar program behind them.  On the
+// peer-window transport (use_ipc) the block also exchanges its sums with the other ranks in between: one launch.
 __global__ __launch_bounds__(kBlock) void reduce_prog_kernel(const double *__restrict__ partials, int nblocks, int k,
                                                              RedOut out, double *S, SolverState *st, SProg prog,
-                                                             const int *done) {
-  if (done && *done) return;
+                                                             const int *done, IpcDev w, unsigned long long epoch,
+                                                             int use_ipc) {
+  const bool skip = done && *done;  // (the all-reduce still runs: epochs advance in step on every rank)
+  if (skip && !use_ipc) return;
   __shared__ double lds4[4];
+  __shared__ double vals[kMaxMulti];
   for (int j = 0; j < k; ++j) {
     const double *p = partials + (int64_t)j * nblocks;
     double v = 0.0;
 #pragma unroll 8
     for (int i = threadIdx.x; i < nblocks; i += kBlock) v += p[i];
     const double sum = block_sum256(v, lds4);
-    if (threadIdx.x == 0) S[out.idx[j]] = sum;
+    if (threadIdx.x == 0) vals[j] = sum;
   }
+  if (use_ipc) ipc_allreduce_block(w, vals, k, epoch);
+  else __syncthreads();
+  if (skip) return;
+  if ((int)threadIdx.x < k) S[out.idx[threadIdx.x]] = vals[threadIdx.x];
+  __syncthreads();
   if (threadIdx.x == 0 && prog.n > 0) {
     __threadfence();
     exec_prog(prog, S, st);
@@ -354,15 +364,18 @@ struct KrylovEngine {
                            c->d_partials2, dp);
         partials = c->d_partials2, nb = kStage2;
       }
-      if (c->comm == nullptr) {
+      IpcDev w{};
+      unsigned long long epoch = 0;
+      const bool ipc = c->comm != nullptr && comm_ipc_next(c, &w, &epoch);
+      if (c->comm == nullptr || ipc) {
         hipLaunchKernelGGL(reduce_prog_kernel, dim3(1), dim3(kBlock), 0, c->stream, partials, nb, red_k, red_out, S,
-                           d_st, prog, dp);
+                           d_st, prog, dp, w, epoch, (int)ipc);
       } else {
         RedOut scr{};
         for (int j = 0; j < red_k; ++j) scr.idx[j] = R_SCR + j;
         SProg none{};
         hipLaunchKernelGGL(reduce_prog_kernel, dim3(1), dim3(kBlock), 0, c->stream, partials, nb, red_k, scr, S, d_st,
-                           none, dp);
+                           none, dp, w, epoch, 0);
         const int st = comm_allreduce_sum(c, S + R_SCR, red_k);
         if (st != STORM_HIP_OK) fail(st);
         hipLaunchKernelGGL(sprog_kernel, dim3(1), dim3(1), 0, c->stream, S, d_st, prog, red_k, red_out, (int)R_SCR, dp);

@@ -19,6 +19,7 @@
 
 #include "common.hpp"
 #include "solver_device.hpp"
+#include "ipc_device.hpp"
 
 namespace storm {
 
@@ -95,20 +96,30 @@ struct OutSlots {
   double *p[4];
 };
 
-// Final pass of up to 4 simultaneous reductions + (single rank) the scalar step.
+// Final pass of up to 4 simultaneous reductions + the scalar step.  On one rank, and on the peer-window transport
+// (use_ipc: the block exchanges its sums with the other ranks itself, ipc_device.hpp), that is ONE launch.
 __global__ __launch_bounds__(kBlock) void reduce_step_kernel(const double *__restrict__ partials, int nblocks,
                                                              int k, OutSlots out, int step, SolverState *st,
-                                                             GmresDev g, bool force) {
-  if (!force && st->done) return;
+                                                             GmresDev g, bool force, IpcDev w,
+                                                             unsigned long long epoch, int use_ipc) {
+  // (the transport's all-reduce runs even when the solve is done: epochs advance in step on every rank)
+  const bool skip = !force && st->done;
+  if (skip && !use_ipc) return;
   __shared__ double lds4[4];
+  __shared__ double vals[4];
   for (int j = 0; j < k; ++j) {
     const double *p = partials + (int64_t)j * nblocks;
     double v = 0.0;
 #pragma unroll 8
     for (int i = threadIdx.x; i < nblocks; i += kBlock) v += p[i];
     const double sum = block_sum256(v, lds4);
-    if (threadIdx.x == 0) *out.p[j] = sum;
+    if (threadIdx.x == 0) vals[j] = sum;
   }
+  if (use_ipc) ipc_allreduce_block(w, vals, k, epoch);
+  else __syncthreads();
+  if (skip) return;
+  if ((int)threadIdx.x < k) *out.p[threadIdx.x] = vals[threadIdx.x];
+  __syncthreads();
   if (step != STEP_NONE && threadIdx.x == 0) do_step(step, st, g);
 }
 
@@ -485,14 +496,17 @@ struct Driver {
       partials = c->d_partials2;
       nblocks = kStage2;
     }
-    if (c->comm == nullptr) {
+    IpcDev w{};
+    unsigned long long epoch = 0;
+    const bool ipc = c->comm != nullptr && comm_ipc_next(c, &w, &epoch);
+    if (c->comm == nullptr || ipc) {
       hipLaunchKernelGGL(reduce_step_kernel, dim3(1), dim3(kBlock), 0, c->stream, partials, nblocks, k,
-                         out, step, st, g, force);
+                         out, step, st, g, force, w, epoch, (int)ipc);
       HIP_TRY(hipGetLastError());
       return STORM_HIP_OK;
     }
     hipLaunchKernelGGL(reduce_step_kernel, dim3(1), dim3(kBlock), 0, c->stream, partials, nblocks, k, out,
-                       (int)STEP_NONE, st, g, force);
+                       (int)STEP_NONE, st, g, force, w, epoch, 0);
     HIP_TRY(hipGetLastError());
     if (contiguous) {
       STORM_TRY(comm_allreduce_sum(c, contiguous, k));

@@ -93,6 +93,23 @@ def connect_host_staged(ctx) -> None:
     ctx.comm_init_host(world, rank, allreduce, exchange)
 
 
+def connect_ipc(ctx, window_bytes: int = 0) -> None:
+    """Give ``ctx`` the peer-window transport (``storm_hip_ctx_comm_ipc_export`` / ``_init_ipc``): every rank's window
+    handle is all-gathered over the default torch.distributed group (any backend), then mapped.  Halo planes and
+    reduction scalars then move by direct stores into the receiver's window -- between GPUs over xGMI, or between
+    processes that share one device (tests/test_gpu_two_ranks.py)."""
+    import torch
+    import torch.distributed as td
+
+    rank, world = td.get_rank(), td.get_world_size()
+    mine = ctx.comm_ipc_export(world, rank, window_bytes)
+    dev = torch.device("cuda", torch.cuda.current_device()) if td.get_backend() == "nccl" else torch.device("cpu")
+    parts = [torch.zeros(64, dtype=torch.uint8, device=dev) for _ in range(world)]
+    td.all_gather(parts, torch.tensor(list(mine), dtype=torch.uint8, device=dev))
+    ctx.comm_init_ipc(b"".join(bytes(p.cpu().numpy().tobytes()) for p in parts))
+    td.barrier()
+
+
 def allreduce_max(value: float) -> float:
     import torch
     import torch.distributed as td

@@ -1,7 +1,8 @@
 """Worker of tests/test_gpu_two_ranks.py: one rank of a W-rank run whose ranks all share device 0.
 
 Launched by torch.distributed.run with the gloo backend.  Every rank builds its z-slab of an nx*ny*(nzl*W) box
-on the GPU, connects the library's HOST-STAGED transport (halo planes and reduction scalars travel through gloo)
+on the GPU, connects the library's HOST-STAGED transport (halo planes and reduction scalars travel through gloo) or,
+with STORM_TRANSPORT=ipc, its PEER-WINDOW transport (hipIpc-mapped device memory, direct stores, polled flags),
 and checks the partitioned device path -- SpMV with interior/boundary split, fused dots, CG / BiCGStab / GMRES
 device loops with their all-reduces -- against the CPU oracle on the UNPARTITIONED global mesh.  Everything the
 8-GPU run does except the RCCL calls themselves (those: tests/test_gpu_comm.py)."""
@@ -25,7 +26,10 @@ def main():
     dist.init_process_group("gloo")
     rank, world = td.get_rank(), td.get_world_size()
     ctx = api.Context(0)
-    dist.connect_host_staged(ctx)
+    if os.environ.get("STORM_TRANSPORT", "host") == "ipc":
+        dist.connect_ipc(ctx)  # peer windows: direct stores into the receiver's memory, polled flags
+    else:
+        dist.connect_host_staged(ctx)
     assert (ctx.n_ranks, ctx.rank) == (world, rank)
 
     loc, plan = partition.slab_partition(nx, ny, nzl, world, rank)
@@ -96,6 +100,8 @@ def main():
         assert abs(s.iteration - ref.iterations) <= max(2, int(0.1 * ref.iterations))
         assert np.linalg.norm(x.to_numpy() - ref.x[gid]) <= 1e-6 * np.linalg.norm(ref.x[gid])
         mat.close()
+    ctx.sync()
+    td.barrier()  # nobody unmaps / frees a peer window another rank's kernels may still write to
     ctx.close()
     td.barrier()
     with open(os.path.join(os.environ["STORM_REPORT_DIR"], f"rank{rank}.json"), "w") as f:

@@ -24,12 +24,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
+@pytest.mark.parametrize("transport", ["host", "ipc"])
 @pytest.mark.parametrize("world,dims", [(2, (16, 12, 8)), (3, (20, 8, 5)), (4, (12, 12, 4))])
-def test_partitioned_device_path_matches_the_global_oracle(world, dims, tmp_path):
+def test_partitioned_device_path_matches_the_global_oracle(world, dims, transport, tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "multi_rank_worker.py"), *map(str, dims)]
-    env = dict(os.environ, OMP_NUM_THREADS="1", STORM_REPORT_DIR=str(tmp_path))
+    env = dict(os.environ, OMP_NUM_THREADS="1", STORM_REPORT_DIR=str(tmp_path), STORM_TRANSPORT=transport,
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-3000:]
     reports = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(world)]
@@ -52,16 +54,17 @@ def test_cavity_on_four_ranks(tmp_path):
     assert all(r["steps"][k][0] == reports[0]["steps"][k][0] for r in reports for k in range(4))
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_bench_script_multi_rank_path(world):
+@pytest.mark.parametrize("world,transport", [(2, "rccl"), (3, "rccl"), (3, "ipc")])
+def test_bench_script_multi_rank_path(world, transport):
     """bench.py's own N > 1 code path (partition, connect, the rank-uniform spin-up, barriers, max-over-ranks
     timing, rank-0 JSON) with the ranks sharing device 0 (`--shared-device`): it must terminate -- a collective
     that only some ranks reach hangs the 8-GPU run -- and print one JSON line on rank 0."""
     # exactly as the driver calls it: no launcher in front -- bench.py starts its ranks itself (child processes)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--shared-device", "--edge", "48",
-           "--steps", "20", "--warmup", "3", "--spinup-seconds", "0.2", "--min-seconds", "0.05"]
+           "--steps", "20", "--warmup", "3", "--spinup-seconds", "0.2", "--min-seconds", "0.05", "--transport", transport]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(env, OMP_NUM_THREADS="1"), cwd=ROOT)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300,
+                       env=dict(env, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + "\n" + p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1

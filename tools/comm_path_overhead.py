@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Cost of the multi-rank code path with the network taken out: one rank, RCCL communicator of size 1, a z-periodic
+"""Cost of the multi-rank code path with the network taken out: one rank, a communicator of size 1 (RCCL, then the
+peer-window transport), a z-periodic
 256^3 box whose two halo planes are exchanged with the rank itself (pack kernel, grouped ncclSend/ncclRecv on the comm
 stream, interior / boundary split of the SpMV, reduction -> all-reduce -> step kernels) against the plain single-GPU
 path on the same box.  What remains at N > 1 beyond this is the latency of the real exchanges."""
@@ -17,7 +18,8 @@ from stormruler_amd import api, mesh  # noqa: E402
 from test_gpu_comm import _periodic_z_local_graph  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-iters = 400
+only = sys.argv[2] if len(sys.argv) > 2 else ""  # "ipc" / "rccl": that transport alone, few iterations (for a kernel trace)
+iters = 60 if only else 400
 
 
 def rate(ctx, mat, g):
@@ -39,17 +41,26 @@ def rate(ctx, mat, g):
 out = {"n": n}
 ctx = api.Context(0)
 g0 = mesh.structured_box(n)
-m0 = api.StencilMatrix.from_face_graph(ctx, g0)
-out["plain_it_per_s"] = rate(ctx, m0, g0)
-m0.close()
+for fmt in (() if only else (4, 3)):  # the halo operator below cannot take format 4 (two extra offsets): compare like with like
+    ctx.set_option("spmv_dict", fmt)
+    m0 = api.StencilMatrix.from_face_graph(ctx, g0)
+    out[f"plain_fmt{fmt}_it_per_s"] = rate(ctx, m0, g0)
+    m0.close()
 ctx.close()
-ctx = api.Context(0)
-ctx.comm_init(api.Context.comm_unique_id(), 1, 0)
 loc, send_idx = _periodic_z_local_graph(n, n, n)
-m1 = api.StencilMatrix.from_face_graph(ctx, loc)
-m1.set_halo([0], [0, loc.n_halo], send_idx, [0, loc.n_halo])
-st = m1.stats()
-out["comm_path_it_per_s"] = rate(ctx, m1, loc)
-out["interior_groups"], out["groups"], out["paired_rows"] = st["n_interior_slices"], st["n_slices"], st["paired_rows"]
-out["overhead_us_per_iteration"] = (1.0 / out["comm_path_it_per_s"] - 1.0 / out["plain_it_per_s"]) * 1e6
+for transport in ((only,) if only else ("rccl", "ipc")):
+    ctx = api.Context(0)
+    if transport == "rccl":
+        ctx.comm_init(api.Context.comm_unique_id(), 1, 0)
+    else:  # peer windows: the single rank maps its own window
+        ctx.comm_init_ipc(ctx.comm_ipc_export(1, 0))
+    m1 = api.StencilMatrix.from_face_graph(ctx, loc)
+    m1.set_halo([0], [0, loc.n_halo], send_idx, [0, loc.n_halo])
+    st = m1.stats()
+    out[f"{transport}_it_per_s"] = rate(ctx, m1, loc)
+    out["interior_groups"], out["groups"], out["paired_rows"] = st["n_interior_slices"], st["n_slices"], st["paired_rows"]
+    if not only:
+        out[f"{transport}_overhead_us_per_iteration"] = (1.0 / out[f"{transport}_it_per_s"] - 1.0 / out["plain_fmt3_it_per_s"]) * 1e6
+    m1.close()
+    ctx.close()
 print(json.dumps(out))
