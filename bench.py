@@ -375,7 +375,7 @@ def launch_ranks(n_ranks: int) -> int:
     env.setdefault("OMP_NUM_THREADS", "1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    sys.stderr.write(child.stderr[-8000:])
+    sys.stderr.write(child.stderr)
     lines = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
     for ln in child.stdout.splitlines():
         if not ln.startswith("{"):

@@ -12,6 +12,26 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _gpu_present() -> bool:
+    try:
+        import torch
+
+        return bool(torch.cuda.is_available())
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    """Plain `pytest` on a box without a GPU: gpu-marked tests are SKIPPED (with the reason), not failed at
+    Context(0).  (The product itself still refuses loudly: tests/test_abi_symbols.py checks that.)"""
+    if _gpu_present():
+        return
+    skip = pytest.mark.skip(reason="needs an MI355X: no HIP device in this process")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _native_pieces_are_built():
     """The built artefacts are git-ignored; rebuild them when a checkout arrives without them."""
