@@ -345,9 +345,10 @@ int cg_latency_solve(const storm_hip_op *op, double alpha, double beta, const do
   const int capacity[4] = {1, 2, 4, 8};
   const void *fn = nullptr;
   int64_t blocks = 0;
+  static int resident[2][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}};  // blocks per CU of each variant, asked once
   for (int v = 0; v < 4 && fn == nullptr; ++v) {
-    int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, variants[v], kLatBlock, 0));
+    int &per_cu = resident[cached ? 1 : 0][v];
+    if (per_cu < 0) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, variants[v], kLatBlock, 0));
     if (per_cu < 1) continue;
     blocks = std::max<int64_t>(1, std::min<int64_t>(std::min(c->num_cus, 256), (n_slices + kLatWaves - 1) / kLatWaves));
     const int64_t waves = blocks * kLatWaves;
