@@ -254,6 +254,68 @@ __global__ __launch_bounds__(kBlock) void lin_kernel(int64_t n, LinArgs a, const
   }
 }
 
+
+// The same statement with reductions of its RESULT folded in: per-block partials of <y, y> (dot_yy) and / or
+// <y, w> into partials[j * gridDim.x + block] -- "r -= alpha z; gamma = <r, r>" is one pass over r, not two.
+template <int NT>
+__global__ __launch_bounds__(kBlock) void lin_dot_kernel(int64_t n, LinArgs a, const double *w, int dot_yy,
+                                                         double *__restrict__ partials, const int *done, int nt) {
+  if (done && *done) return;
+  __shared__ double lds4[4];
+  double c[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) c[t] = ld_coef(a.c[t]);
+  const int64_t n2 = n >> 1;
+  double2v *y2 = reinterpret_cast<double2v *>(a.y);
+  const double2v *w2 = reinterpret_cast<const double2v *>(w);
+  constexpr int U = lin_unroll(NT + 1);
+  double acc_yy = 0.0, acc_yw = 0.0;
+  for (int64_t base = (int64_t)blockIdx.x * (kBlock * U) + threadIdx.x; base < n2;
+       base += (int64_t)gridDim.x * (kBlock * U)) {
+    double2v v[U][NT], vw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = base + u * kBlock;
+      if (i < n2) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) v[u][t] = ldv(reinterpret_cast<const double2v *>(a.v[t]) + i, nt);
+        if (w) vw[u] = ldv(w2 + i, nt);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = base + u * kBlock;
+      if (i < n2) {
+        double2v o = c[0] * v[u][0];
+#pragma unroll
+        for (int t = 1; t < NT; ++t) o += c[t] * v[u][t];
+        stv(y2 + i, o, nt);
+        acc_yy += o.x * o.x;
+        acc_yy += o.y * o.y;
+        if (w) acc_yw += o.x * vw[u].x, acc_yw += o.y * vw[u].y;
+      }
+    }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    double o = c[0] * a.v[0][i];
+    for (int t = 1; t < NT; ++t) o += c[t] * a.v[t][i];
+    a.y[i] = o;
+    acc_yy += o * o;
+    if (w) acc_yw += o * w[i];
+  }
+  int j = 0;
+  if (dot_yy) {
+    const double sum = block_sum256(acc_yy, lds4);
+    if (threadIdx.x == 0) partials[(int64_t)j * gridDim.x + blockIdx.x] = sum;
+    ++j;
+  }
+  if (w) {
+    const double sum = block_sum256(acc_yw, lds4);
+    if (threadIdx.x == 0) partials[(int64_t)j * gridDim.x + blockIdx.x] = sum;
+  }
+}
+
 }  // namespace kry
 }  // namespace storm
 
@@ -469,6 +531,71 @@ struct KrylovEngine {
     if (st != STORM_HIP_OK) fail(st);
   }
   void scale(V yv, Coef a) { lin(yv, {{a, yv}}); }
+
+  // y = sum_t c_t v_t  AND  reg_yy = <y, y>, reg_yw = <y, w> of the new y (register < 0: not wanted), one pass.
+  void lin_dots(V yv, std::initializer_list<Term> terms_il, int reg_yy, int reg_yw = -1, const storm_hip_vec *wv = nullptr) {
+    std::vector<Term> terms(terms_il);
+    if (terms.size() > 3 || n <= 0 || (wv != nullptr && wv == yv)) {  // not this kernel's shape: two statements
+      lin_v(yv, terms);
+      std::vector<std::pair<int, const storm_hip_vec *>> outs;
+      if (reg_yy >= 0) outs.push_back({reg_yy, yv});
+      if (reg_yw >= 0) outs.push_back({reg_yw, wv});
+      dots_v(yv, outs);
+      return;
+    }
+    flush();
+    if (!ok()) return;
+    LinArgs a{};
+    a.y = yv->d;
+    const int nt = (int)terms.size();
+    for (int t = 0; t < nt; ++t) a.v[t] = terms[(size_t)t].v->d, a.c[t] = scal(terms[(size_t)t].c);
+    const int64_t per_block = (int64_t)kBlock * lin_unroll(nt + 1) * 2;
+    int64_t nb = std::max<int64_t>(1, (n + per_block - 1) / per_block);
+    nb = std::min<int64_t>(nb, std::min<int64_t>(32768, c->partials_capacity / 2));
+    const double *wd = (reg_yw >= 0 && wv != nullptr) ? wv->d : nullptr;
+    const int nti = (int)(c->opt_blas1_nt != 0);
+    switch (nt) {
+      case 1: hipLaunchKernelGGL((lin_dot_kernel<1>), dim3((int)nb), dim3(kBlock), 0, c->stream, n, a, wd, (int)(reg_yy >= 0), c->d_partials, dp, nti); break;
+      case 2: hipLaunchKernelGGL((lin_dot_kernel<2>), dim3((int)nb), dim3(kBlock), 0, c->stream, n, a, wd, (int)(reg_yy >= 0), c->d_partials, dp, nti); break;
+      default: hipLaunchKernelGGL((lin_dot_kernel<3>), dim3((int)nb), dim3(kBlock), 0, c->stream, n, a, wd, (int)(reg_yy >= 0), c->d_partials, dp, nti); break;
+    }
+    red_k = 0;
+    if (reg_yy >= 0) red_out.idx[red_k++] = reg_yy;
+    if (wd != nullptr) red_out.idx[red_k++] = reg_yw;
+    red_nb = (int)nb, red_pending = red_k > 0;
+  }
+  // y = A(x)  AND  reg_wy = <w, y>, reg_yy = <y, y> (register < 0: not wanted): the stencil SpMV's fused epilogue
+  // when the operator is native and has no CSR tail, separate reductions otherwise.
+  void apply_dots(V yv, const storm_hip_vec *xv, int reg_wy, const storm_hip_vec *wv, int reg_yy = -1) {
+    const bool fusable = op_fn == nullptr && op != nullptr && op->tail_rows == 0 && c->opt_fuse_dot != 0 && n > 0 &&
+                         reg_wy >= 0;
+    if (!fusable) {
+      apply(yv, xv);
+      std::vector<std::pair<int, const storm_hip_vec *>> outs;
+      if (reg_wy >= 0) outs.push_back({reg_wy, wv});
+      if (reg_yy >= 0) outs.push_back({reg_yy, yv});
+      dots_v(yv, outs);
+      return;
+    }
+    flush();
+    if (!ok()) return;
+    ++applies;
+    int nblocks = 0;
+    SpmvDot sd;
+    sd.w = wv->d, sd.yy = reg_yy >= 0, sd.partials = c->d_partials, sd.nblocks_out = &nblocks;
+    const int st = spmv_launch(op, host_scal(op_alpha), host_scal(op_beta), xv->d, yv->d, &sd, dp);
+    if (st != STORM_HIP_OK) return fail(st);
+    if (nblocks <= 0) {  // the launch did not fuse after all
+      std::vector<std::pair<int, const storm_hip_vec *>> outs{{reg_wy, wv}};
+      if (reg_yy >= 0) outs.push_back({reg_yy, yv});
+      dots_v(yv, outs);
+      return;
+    }
+    red_k = 0;
+    red_out.idx[red_k++] = reg_wy;
+    if (reg_yy >= 0) red_out.idx[red_k++] = reg_yy;
+    red_nb = nblocks, red_pending = true;
+  }
 
   struct ApiDone {  // library calls a callback makes are predicated on this solve's flag
     storm_hip_ctx *c;
@@ -745,18 +872,17 @@ void K::iterate(int64_t it) {
   const bool P = has_pre();
   switch (method) {
     case STORM_HIP_CG: {  // SolverCg.hpp:86-126
-      apply(z, p);
-      dot(R_T0, p, z);
+      apply_dots(z, p, R_T0, p);
       sc(SC_SDIV, r_alpha, r_gamma, R_T0);
-      axpy(x, R(r_alpha), p);
-      axpy(r, mR(r_alpha), z);
       sc(SC_MOV, r_a0, r_gamma);  // gamma_bar
+      axpy(x, R(r_alpha), p);
       if (P) {
+        axpy(r, mR(r_alpha), z);
         pre(z, r);
         dots(r, {{r_gamma, z}, {R_T1, r}});
         sc(SC_SQRT, R_ERR, R_T1);
       } else {
-        dot(r_gamma, r, r);
+        lin_dots(r, {{num(1.0), r}, {mR(r_alpha), z}}, r_gamma);
         sc(SC_SQRT, R_ERR, r_gamma);
       }
       sc(SC_SDIV, r_beta, r_gamma, r_a0);
@@ -775,17 +901,28 @@ void K::iterate(int64_t it) {
         sc(SC_SDIV, r_beta, R_T0, R_T1);
         lin_nested(p, r, R(r_beta), p, mR(r_omega), v);
       }
-      mul_side(v, z, p);
-      dot(R_T0, rt, v);
+      if (left()) {
+        mul_side(v, z, p);
+        dot(R_T0, rt, v);
+      } else {  // the operator is applied last: its reduction rides in the SpMV
+        if (right()) pre(z, p);
+        apply_dots(v, right() ? z : p, R_T0, rt);
+      }
       sc(SC_SDIV, r_alpha, r_rho, R_T0);
       axpy(x, R(r_alpha), right() ? z : p);
       axpy(r, mR(r_alpha), v);
-      mul_side(t, z, r);
-      dots(t, {{R_T0, r}, {R_T1, t}});
+      if (left()) {
+        mul_side(t, z, r);
+        dots(t, {{R_T0, r}, {R_T1, t}});
+      } else {
+        if (right()) pre(z, r);
+        apply_dots(t, right() ? z : r, R_T0, r, R_T1);
+      }
       sc(SC_SDIV, r_omega, R_T0, R_T1);
       axpy(x, R(r_omega), right() ? z : r);
-      axpy(r, mR(r_omega), t);
-      norm_to_err_and(SC_ADVANCE, r);
+      lin_dots(r, {{num(1.0), r}, {mR(r_omega), t}}, R_T0);
+      sc(SC_SQRT, R_ERR, R_T0);
+      sc(SC_ADVANCE, 0, R_ERR);
     } break;
 
     case STORM_HIP_CGS: {  // SolverCgs.hpp:90-172
@@ -804,20 +941,21 @@ void K::iterate(int64_t it) {
       sc(SC_SDIV, r_alpha, r_rho, R_T0);
       lin(q, {{num(1.0), u}, {mR(r_alpha), v}});
       lin(v, {{num(1.0), u}, {num(1.0), q}});
+      const storm_hip_vec *step = v;  // what r loses alpha times of
       if (left()) {
         axpy(x, R(r_alpha), v);
         apply(u, v), pre(v, u);
-        axpy(r, mR(r_alpha), v);
       } else if (right()) {
         pre(u, v), apply(v, u);
         axpy(x, R(r_alpha), u);
-        axpy(r, mR(r_alpha), v);
       } else {
         apply(u, v);
         axpy(x, R(r_alpha), v);
-        axpy(r, mR(r_alpha), u);
+        step = u;
       }
-      norm_to_err_and(SC_ADVANCE, r);
+      lin_dots(r, {{num(1.0), r}, {mR(r_alpha), step}}, R_T0);
+      sc(SC_SQRT, R_ERR, R_T0);
+      sc(SC_ADVANCE, 0, R_ERR);
     } break;
 
     case STORM_HIP_TFQMR:
@@ -838,9 +976,8 @@ void K::iterate(int64_t it) {
       dot(R_T0, rt, v);
       sc(SC_SDIV, r_alpha, r_rho, R_T0);
       for (int half = 0; half <= 1; ++half) {
-        axpy(u, mR(r_alpha), s_);
         axpy(d, R(r_alpha), right() ? z : y);
-        dot(R_T0, u, u);
+        lin_dots(u, {{num(1.0), u}, {mR(r_alpha), s_}}, R_T0);
         sc(SC_SQRT, r_omega, R_T0);
         if (l1) {
           sc(SC_LT, r_a2, r_omega, r_tau);
