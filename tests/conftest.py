@@ -37,7 +37,8 @@ def _native_pieces_are_built():
     """The built artefacts are git-ignored; rebuild them when a checkout arrives without them."""
     need = [os.path.join(ROOT, "stormruler_amd", "libstorm_hip.so"), os.path.join(ROOT, "oracle", "liboracle.so"),
             os.path.join(ROOT, "oracle", "liboracle_fma.so"), os.path.join(ROOT, "tests", "cpp", "poisson_driver"),
-            os.path.join(ROOT, "tests", "c", "abi_poisson1d"), os.path.join(ROOT, "oracle", "liboracle_omp.so")]
+            os.path.join(ROOT, "tests", "c", "abi_poisson1d"), os.path.join(ROOT, "tests", "c", "abi_krylov_callback"),
+            os.path.join(ROOT, "oracle", "liboracle_omp.so")]
     if not all(os.path.exists(p) for p in need):
         import __graft_entry__ as ge
 

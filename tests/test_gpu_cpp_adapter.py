@@ -58,3 +58,15 @@ def test_plain_c_host_reaches_the_1d_known_answer():
     assert p.returncode == 0, p.stdout + p.stderr
     out = json.loads(p.stdout.strip().splitlines()[-1])
     assert out["iterations"] == 32 and out["converged"] == 1 and abs(out["x31"] - 528.0) < 1e-6
+
+
+def test_plain_c_host_drives_every_engine_method_through_a_callback_operator():
+    """tests/c/abi_krylov_callback.c: storm_hip_krylov_* from C99 with a callback operator (what the reference's call
+    site hands a solver: a lambda) -- every method x {no preconditioner, diagonal left, diagonal right} on the 1-D known
+    answer, the stepping interface, and a failing callback."""
+    exe = os.path.join(ROOT, "tests", "c", "abi_krylov_callback")
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 9 * 3 + 3 and all(ln["ok"] for ln in lines), p.stdout + p.stderr
+    unpre = {ln["method"]: ln["iterations"] for ln in lines if ln.get("side") == -1}
+    assert unpre["cg"] == unpre["cgs"] == unpre["tfqmr1"] == unpre["gmres"] == 32  # SURVEY 8c: the reference's counts
