@@ -54,6 +54,20 @@ def test_cavity_on_four_ranks(tmp_path):
     assert all(r["steps"][k][0] == reports[0]["steps"][k][0] for r in reports for k in range(4))
 
 
+def test_peer_window_waits_are_bounded(tmp_path):
+    """A rank that never joins a reduction must not hang the others: the waiting kernel gives up after 5 s and the next
+    library call returns STORM_HIP_E_COMM (-4)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "multi_rank_timeout_worker.py")]
+    env = dict(os.environ, OMP_NUM_THREADS="1", STORM_REPORT_DIR=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-3000:]
+    r0 = json.load(open(tmp_path / "rank0.json"))
+    assert r0["outcome"] == "error" and r0["status"] == -4 and "timed out" in r0["what"], r0
+    assert 4.0 <= r0["seconds"] <= 9.0, r0
+
+
 @pytest.mark.parametrize("world,transport", [(2, "rccl"), (3, "rccl"), (3, "ipc")])
 def test_bench_script_multi_rank_path(world, transport):
     """bench.py's own N > 1 code path (partition, connect, the rank-uniform spin-up, barriers, max-over-ranks
