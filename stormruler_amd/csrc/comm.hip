@@ -37,6 +37,8 @@ struct Comm {
   int64_t win_bytes = 0, seg_bytes = 0;
   unsigned long long ar_epoch = 0, halo_epoch = 0;
   int *d_error = nullptr, *h_error = nullptr;  // set by a kernel whose wait timed out
+  double *pending_x = nullptr;          // single-stream mode: the receive half runs in comm_halo_exchange_end
+  unsigned long long pending_epoch = 0;
 };
 
 static int host_stage(storm_hip_ctx *c, int64_t len) {
@@ -211,6 +213,25 @@ __global__ __launch_bounds__(kBlock) void halo_pack_kernel(int64_t n, const int 
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) buf[i] = x[idx[i]];
 }
 
+static int ipc_halo_receive(const storm_hip_op *op, double *x, unsigned long long epoch, hipStream_t hs) {
+  storm_hip_ctx *c = op->ctx;
+  const HaloPlan &h = op->halo;
+  const IpcDev w = ipc_dev(c);
+  IpcPeers peers;
+  std::vector<int64_t> send_off, recv_off;
+  ipc_plan_offsets(h, &peers, &send_off, &recv_off);
+  for (int q = 0; q < h.n_nbrs; ++q) {
+    const int64_t nr = h.recv_ptr[q + 1] - h.recv_ptr[q];
+    if (nr <= 0) continue;
+    const int nb = (int)std::min<int64_t>(512, (nr + kBlock * 2 - 1) / (kBlock * 2));
+    hipLaunchKernelGGL(ipc_halo_recv_kernel, dim3(nb), dim3(kBlock), 0, hs, w, h.nbr_rank[q], nr, recv_off[(size_t)q],
+                       x + op->n_rows + h.recv_ptr[q], epoch);
+  }
+  hipLaunchKernelGGL(ipc_halo_ack_kernel, dim3(1), dim3(kWave), 0, hs, w, peers, epoch);
+  HIP_TRY(hipGetLastError());
+  return STORM_HIP_OK;
+}
+
 int comm_halo_exchange_begin(const storm_hip_op *op, double *x) {
   storm_hip_ctx *c = op->ctx;
   const HaloPlan &h = op->halo;
@@ -245,25 +266,29 @@ int comm_halo_exchange_begin(const storm_hip_op *op, double *x) {
     IpcPeers peers;
     std::vector<int64_t> send_off, recv_off;
     ipc_plan_offsets(h, &peers, &send_off, &recv_off);
-    HIP_TRY(hipEventRecord(c->ev_x_ready, c->stream));  // x must be complete before it is packed
-    HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_x_ready, 0));
+    // Two streams (default): the exchange runs on the comm stream beside the interior rows, ordered by events.  One
+    // stream (option ipc_streams = 1): send + flag ahead of the interior launch, receive + acknowledge behind it on
+    // the compute stream -- no cross-stream events; the sends are then not hidden behind the interior rows.
+    const bool one_stream = c->opt_ipc_streams == 1;
+    hipStream_t hs = one_stream ? c->stream : c->comm_stream;
+    if (!one_stream) {
+      HIP_TRY(hipEventRecord(c->ev_x_ready, c->stream));  // x must be complete before it is packed
+      HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_x_ready, 0));
+    }
     for (int q = 0; q < h.n_nbrs; ++q) {
       const int64_t ns = h.send_ptr[q + 1] - h.send_ptr[q];
       if (ns <= 0) continue;
       const int nb = (int)std::min<int64_t>(512, (ns + kBlock * 2 - 1) / (kBlock * 2));
-      hipLaunchKernelGGL(ipc_halo_send_kernel, dim3(nb), dim3(kBlock), 0, c->comm_stream, w, h.nbr_rank[q], ns,
+      hipLaunchKernelGGL(ipc_halo_send_kernel, dim3(nb), dim3(kBlock), 0, hs, w, h.nbr_rank[q], ns,
                          send_off[(size_t)q], h.d_send_idx + h.send_ptr[q], (const double *)x, epoch);
     }
-    hipLaunchKernelGGL(ipc_halo_flag_kernel, dim3(1), dim3(kWave), 0, c->comm_stream, w, peers, epoch);
-    for (int q = 0; q < h.n_nbrs; ++q) {
-      const int64_t nr = h.recv_ptr[q + 1] - h.recv_ptr[q];
-      if (nr <= 0) continue;
-      const int nb = (int)std::min<int64_t>(512, (nr + kBlock * 2 - 1) / (kBlock * 2));
-      hipLaunchKernelGGL(ipc_halo_recv_kernel, dim3(nb), dim3(kBlock), 0, c->comm_stream, w, h.nbr_rank[q], nr,
-                         recv_off[(size_t)q], x + op->n_rows + h.recv_ptr[q], epoch);
-    }
-    hipLaunchKernelGGL(ipc_halo_ack_kernel, dim3(1), dim3(kWave), 0, c->comm_stream, w, peers, epoch);
+    hipLaunchKernelGGL(ipc_halo_flag_kernel, dim3(1), dim3(kWave), 0, hs, w, peers, epoch);
     HIP_TRY(hipGetLastError());
+    if (one_stream) {
+      cm->pending_x = x, cm->pending_epoch = epoch;
+      return STORM_HIP_OK;
+    }
+    STORM_TRY(ipc_halo_receive(op, x, epoch, hs));
     HIP_TRY(hipEventRecord(c->ev_halo_done, c->comm_stream));
     return STORM_HIP_OK;
   }
@@ -296,6 +321,11 @@ int comm_halo_exchange_begin(const storm_hip_op *op, double *x) {
 int comm_halo_exchange_end(const storm_hip_op *op) {
   storm_hip_ctx *c = op->ctx;
   if (op->halo.n_nbrs == 0 || c->comm == nullptr || c->comm->host_exchange) return STORM_HIP_OK;
+  if (c->comm->ipc && c->comm->pending_x != nullptr) {  // single-stream mode: the receive half, behind the interior rows
+    double *x = c->comm->pending_x;
+    c->comm->pending_x = nullptr;
+    return ipc_halo_receive(op, x, c->comm->pending_epoch, c->stream);
+  }
   HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_halo_done, 0));
   return STORM_HIP_OK;
 }

@@ -105,6 +105,7 @@ struct storm_hip_ctx {
   int64_t opt_fuse_mgs = 1;  // GMRES/MGS on one rank, <= 2048 blocks: each step folds the previous step's partials itself (no final-reduction launch in between)
   int64_t opt_latency_path = 1;         // small operators: CG as one cooperative persistent kernel (latency.hip)
   int64_t opt_latency_rows = 1 << 19;   // ... up to this many rows (a compact copy of the operator is kept for it)
+  int64_t opt_ipc_streams = 2;          // peer-window halo exchange: 2 = on the comm stream beside the interior rows, 1 = on the compute stream around them
   int64_t opt_generic_solvers = 0;  // 1: storm_hip_krylov_solve never takes the fused CG / BiCGStab / GMRES loops (A/B knob)
   int64_t opt_fuse_dot = 1;  // 0: reductions after an SpMV run as separate kernels (A/B knob)
   // Vector storage released by vec_destroy, kept for the next vec_create of the same size: a solve

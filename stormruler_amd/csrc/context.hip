@@ -121,6 +121,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   if (!strcmp(key, "ell_cap")) c->opt_ell_cap = value;
   else if (!strcmp(key, "spmv_variant")) c->opt_spmv_variant = value;
   else if (!strcmp(key, "generic_solvers")) c->opt_generic_solvers = value;
+  else if (!strcmp(key, "ipc_streams")) c->opt_ipc_streams = value;
   else if (!strcmp(key, "latency_path")) c->opt_latency_path = value;
   else if (!strcmp(key, "latency_rows")) c->opt_latency_rows = value;
   else if (!strcmp(key, "nontemporal")) c->opt_nt = value;

@@ -48,8 +48,10 @@ for fmt in (() if only else (4, 3)):  # the halo operator below cannot take form
     m0.close()
 ctx.close()
 loc, send_idx = _periodic_z_local_graph(n, n, n)
-for transport in ((only,) if only else ("rccl", "ipc")):
+for transport in ((only,) if only else ("rccl", "ipc", "ipc1")):
     ctx = api.Context(0)
+    if transport == "ipc1":  # peer windows, halo kernels on the compute stream (no cross-stream events)
+        ctx.set_option("ipc_streams", 1)
     if transport == "rccl":
         ctx.comm_init(api.Context.comm_unique_id(), 1, 0)
     else:  # peer windows: the single rank maps its own window
