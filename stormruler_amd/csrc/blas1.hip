@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kBlock) void multi_dot_kernel(int64_t n, const doub
   for (int j = 0; j < KB; ++j) acc[j] = 0.0;
   const int64_t n2 = n >> 1;
   const double2v *__restrict__ a2 = reinterpret_cast<const double2v *>(a);
-  constexpr int U = KB <= 2 ? kUnroll : 2;  // keep the in-flight registers bounded for wide KB
+  constexpr int U = KB <= 2 ? kUnroll : (KB <= 4 ? 2 : 1);  // many streams: few accesses per stream in flight (tools/cg_kernels_bench.hip)
   for (int64_t base = (int64_t)blockIdx.x * (kBlock * kUnroll) + threadIdx.x; base < n2;
        base += (int64_t)gridDim.x * (kBlock * kUnroll)) {
 #pragma unroll
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(kBlock) void multi_axpy_kernel(int64_t n, double *_
   for (int j = 0; j < KB; ++j) cf[j] = a.dc ? a.dc[j] * a.sign : a.c[j];
   const int64_t n2 = n >> 1;
   double2v *__restrict__ y2 = reinterpret_cast<double2v *>(y);
-  constexpr int U = KB <= 2 ? kUnroll : 2;
+  constexpr int U = KB <= 2 ? kUnroll : (KB <= 4 ? 2 : 1);
   for (int64_t base = (int64_t)blockIdx.x * (kBlock * kUnroll) + threadIdx.x; base < n2;
        base += (int64_t)gridDim.x * (kBlock * kUnroll)) {
 #pragma unroll

@@ -99,6 +99,7 @@ struct storm_hip_ctx {
   int64_t opt_spmv_spw = 0;          // slices per wave of the dictionary kernel: 1, 2 or 4 (0 = default)
   int64_t opt_spmv_xcd_remap = 8;    // 0 off; 1 one contiguous run per XCD (slower); G > 1: runs of G tiles per XCD
   int64_t opt_nt = 1;
+  int64_t opt_spmv_nt_y = 1;         // format-4 kernel: store y non-temporally (A/B knob)
   int64_t opt_profile_spmv = 0;
   int64_t opt_blas1_nt = 1;  // non-temporal loads/stores in the streaming kernels
   int64_t opt_graph = 0;     // replay CG / BiCGStab iterations from a captured hipGraph: measured slower than eager launches (profiles/r01_notes.md), off

@@ -76,6 +76,7 @@ struct SellArgs {
   const int *__restrict__ offs;           // format 2: the column-offset dictionary
   int offs_size;
   int accumulate;                         // y += alpha*M(x) (stormDivGrad's own form) instead of y = beta*x + alpha*M(x)
+  int nt_y = 1;                           // y stored non-temporally (0: it may stay in the Infinity Cache for the consumer)
 };
 
 constexpr int kDictSize = 256;
@@ -670,7 +671,7 @@ __global__ __launch_bounds__(kBlock) void spmv_canon_kernel(SellArgs A, CanonArg
   yi.x = (A.accumulate ? yo.x : beta * xi.x) + alpha * (acc_a + ext_a * xi.x);
   yi.y = (A.accumulate ? yo.y : beta * xi.y) + alpha * (acc_b + ext_b * xi.y);
   if (!done_flag) {
-    if (valid_b) __builtin_nontemporal_store(yi, reinterpret_cast<double2v *>(yb + (size_t)(rc << 3)));
+    if (valid_b) { if (A.nt_y) __builtin_nontemporal_store(yi, reinterpret_cast<double2v *>(yb + (size_t)(rc << 3))); else *reinterpret_cast<double2v *>(yb + (size_t)(rc << 3)) = yi; }
     else if (valid_a) y[rc] = yi.x;  // the odd last row
   }
   if (done_flag) return;
@@ -750,6 +751,7 @@ static void launch_pair(const storm_hip_op *op, int nb, Scal alpha, Scal beta, c
   const int group = slice_list ? 0 : (int)op->ctx->opt_spmv_xcd_remap;
   SellArgs A{op->d_pack, op->d_slice_off, op->n_rows, op->uniform_width, group, op->d_dict, op->dict_size,
              op->d_offs, op->offs_size, (int)accumulate};
+  A.nt_y = (int)(op->ctx->opt_spmv_nt_y != 0);
   hipStream_t st = op->ctx->stream;
   if (op->pair == 2) {  // format 4: the common offsets travel as kernel arguments
     CanonArgs C;
