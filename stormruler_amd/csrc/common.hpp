@@ -85,7 +85,8 @@ struct storm_hip_ctx {
   int64_t partials_capacity = 0;
   double *d_partials2 = nullptr;      // [kMaxMulti * kStage2] second-stage partials
   double *d_scalars = nullptr;        // [kMaxMulti] results of host-visible reductions
-  char *d_lat_slots = nullptr;        // latency path: one 256-byte all-reduce slot per block (256 blocks)
+  unsigned long long lat_seq = 0;     // running sequence number of the cooperative Gram-Schmidt chains' all-reduces
+  char *d_lat_slots = nullptr;        // latency path: two 256-byte all-reduce slots per block (256 blocks)
   double *h_scalars = nullptr;        // pinned mirror
   storm::SolverState *d_state = nullptr;
   storm::SolverState *h_state = nullptr;  // pinned staging copy of the state
@@ -104,6 +105,7 @@ struct storm_hip_ctx {
   int64_t opt_blas1_nt = 1;  // non-temporal loads/stores in the streaming kernels
   int64_t opt_graph = 0;     // replay CG / BiCGStab iterations from a captured hipGraph: measured slower than eager launches (profiles/r01_notes.md), off
   int64_t opt_fuse_mgs = 1;  // GMRES/MGS on one rank, <= 2048 blocks: each step folds the previous step's partials itself (no final-reduction launch in between)
+  int64_t opt_coop_mgs = 1;             // GMRES: the Gram-Schmidt chain of an Arnoldi step as one cooperative kernel (latency.hip)
   int64_t opt_latency_path = 1;         // small operators: CG as one cooperative persistent kernel (latency.hip)
   int64_t opt_latency_rows = 1 << 19;   // ... up to this many rows (a compact copy of the operator is kept for it)
   int64_t opt_ipc_streams = 2;          // peer-window halo exchange: 2 = on the comm stream beside the interior rows, 1 = on the compute stream around them
@@ -254,6 +256,8 @@ int op_upload_slice_lists(storm_hip_op *op);
 int op_make_latency_copy(storm_hip_op *op, int64_t n, int64_t n_halo, const std::vector<int64_t> &row_ptr,
                          const std::vector<int> &col, const std::vector<double> &val, const std::vector<double> &ext);
 bool cg_latency_eligible(const storm_hip_op *op);
+int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w, const double *const *q, int k, int m,
+                         double *H, double *norm2_out, bool normalise, bool *taken);
 int cg_latency_solve(const storm_hip_op *op, double alpha, double beta, const double *b, double *x, double *p,
                      double *r, SolverState *d_state);
 

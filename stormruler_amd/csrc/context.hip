@@ -58,8 +58,8 @@ int storm_hip_ctx_create(int device_id, storm_hip_ctx **out) {
   HIP_TRY(hipMalloc(&c->d_partials2, sizeof(double) * kMaxMulti * kStage2));
   HIP_TRY(hipMalloc(&c->d_scalars, sizeof(double) * kMaxMulti));
   HIP_TRY(hipHostMalloc((void **)&c->h_scalars, sizeof(double) * kMaxMulti, hipHostMallocDefault));
-  HIP_TRY(hipMalloc((void **)&c->d_lat_slots, 256 * 256));  // latency.hip: all-reduce slots
-  HIP_TRY(hipMemset(c->d_lat_slots, 0, 256 * 256));
+  HIP_TRY(hipMalloc((void **)&c->d_lat_slots, 2 * 256 * 256));  // latency.hip: all-reduce slots (two per block)
+  HIP_TRY(hipMemset(c->d_lat_slots, 0, 2 * 256 * 256));
   HIP_TRY(hipMalloc((void **)&c->d_state, sizeof(SolverState)));
   HIP_TRY(hipMemset(c->d_state, 0, sizeof(SolverState)));
   HIP_TRY(hipHostMalloc((void **)&c->h_state, sizeof(SolverState), hipHostMallocDefault));
@@ -123,6 +123,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "generic_solvers")) c->opt_generic_solvers = value;
   else if (!strcmp(key, "ipc_streams")) c->opt_ipc_streams = value;
   else if (!strcmp(key, "latency_path")) c->opt_latency_path = value;
+  else if (!strcmp(key, "coop_mgs")) c->opt_coop_mgs = value;
   else if (!strcmp(key, "latency_rows")) c->opt_latency_rows = value;
   else if (!strcmp(key, "nontemporal")) c->opt_nt = value;
   else if (!strcmp(key, "spmv_nt_y")) c->opt_spmv_nt_y = value;

@@ -793,7 +793,7 @@ namespace storm {
 // solvers.hip: the Gram-Schmidt step of storm_hip_solve_gmres, shared with this engine
 int gmres_orthogonalize(storm_hip_ctx *c, int64_t n, const SolverState *st, const int *done, double *qn,
                         const double *const *q, int k, int m, double *H, double *norm2_out, double *scratch,
-                        int gram_schmidt);
+                        int gram_schmidt, bool *normalised);
 }  // namespace storm
 
 void K::init() {
@@ -1153,15 +1153,16 @@ void K::iterate(int64_t it) {
       else if (rp) pre(zs[flexible ? k : 0], qs[k]), apply(qn, zs[flexible ? k : 0]);
       else apply(qn, qs[k]);
       flush();
+      bool normalised = false;
       if (ok()) {
         std::vector<const double *> qd(m + 1);
         for (int i = 0; i <= m; ++i) qd[i] = qs[i]->d;
         const int st = gmres_orthogonalize(c, n, d_st, dp, qn->d, qd.data(), k, m, S + H0, S + R_T0, S + r_a0,
-                                           gram_schmidt);
+                                           gram_schmidt, &normalised);
         if (st != STORM_HIP_OK) fail(st);
       }
       sc(SC_SQRT, r_hn, R_T0);
-      divide(qn, r_hn);
+      if (!normalised) divide(qn, r_hn);
       prog.aux[0] = H0, prog.aux[1] = B0, prog.aux[2] = CS0, prog.aux[3] = SN0, prog.aux[4] = m;
       sc(SC_GIVENS, R_ERR, k, r_hn);
       sc(SC_ADVANCE, 0, R_ERR);

@@ -62,9 +62,12 @@ __device__ __forceinline__ double co_load(const double *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// All-reduce across a co-resident (cooperative) grid, which is also its barrier.  Slot of block b: 16 bytes
-// {value, tag} at slots + b * kLatSlotStride (256 bytes apart, so the polling load of all blocks spreads over the
-// memory channels).  Writer: value; wait for the acknowledgement (which also covers every coherent store the
+// All-reduce across a co-resident (cooperative) grid, which is also its barrier.  Slot (b, parity) of block b: 16
+// bytes {value, tag} at slots + (2 b + (seq & 1)) * kLatSlotStride (256 bytes apart, so the polling load of all
+// blocks spreads over the memory channels).  TWO slots per block, used alternately: a block that has passed
+// all-reduce `seq` may publish `seq + 1` while a slower block is still polling for `seq` -- into the other slot; it
+// can only overwrite slot (seq & 1) with `seq + 2` after passing `seq + 1`, which needed the slow block's `seq + 1`
+// tag, which that block stores after it has finished reading `seq`.  Writer: value; wait for the acknowledgement (which also covers every coherent store the
 // block's waves issued before: each wave drains its own counter ahead of the block-wide barrier); tag.  Reader: ONE
 // aligned 16-byte coherent load per try -- a load that sees the new tag sees the value stored before it.
 constexpr int kLatSlotStride = 256;
@@ -94,7 +97,7 @@ __device__ __forceinline__ double lat_block_sum(double v, double *lds) {  // the
 // Sum over all blocks of `mine` (a per-thread partial), identical bits in every thread of every block.
 __device__ __forceinline__ double lat_allreduce(double mine, char *slots, unsigned long long seq, double *lds) {
   const double block_value = lat_block_sum(mine, lds);
-  char *my_slot = slots + (size_t)blockIdx.x * kLatSlotStride;
+  char *my_slot = slots + ((size_t)blockIdx.x * 2 + (seq & 1)) * kLatSlotStride;
   if (threadIdx.x == 0) co_store(reinterpret_cast<double *>(my_slot), block_value);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's coherent stores are acknowledged ...
   __syncthreads();                                         // ... and so are every other wave's of this block
@@ -104,7 +107,7 @@ __device__ __forceinline__ double lat_allreduce(double mine, char *slots, unsign
   double v = 0.0;
   if (threadIdx.x < gridDim.x) {  // gridDim.x <= 256 <= blockDim.x: thread t watches block t
     unsigned long long tag;
-    const char *slot = slots + (size_t)threadIdx.x * kLatSlotStride;
+    const char *slot = slots + ((size_t)threadIdx.x * 2 + (seq & 1)) * kLatSlotStride;
     for (;;) {
       co_load_slot(slot, &v, &tag);
       if (tag == seq) break;
@@ -285,6 +288,103 @@ __global__ __launch_bounds__(kLatBlock) void cg_latency_kernel(LatArgs a) {
   }
 }
 
+// ---- modified Gram-Schmidt as ONE cooperative kernel -------------------------------------------------------------
+// GMRES's Arnoldi step orthogonalises w = A q_k against q_0 .. q_k one after the other (SolverGmres.hpp:157-161); each
+// step needs a global reduction before the next may start.  The throughput path runs a kernel per step that reads w,
+// q_i and q_{i+1} and writes w (32 B/row/step, 13 us at 128^3: launch + HBM).  Here every wavefront keeps ITS rows of w
+// in registers for the whole chain, streams the rows of q_i through once (prefetching q_{i+1} while the all-reduce of
+// step i is in flight), and the k + 2 reductions are the tagged-slot all-reduces of the latency path: 8 B/row/step and
+// ~3 us per step.  Same values in the same order (h_i = <w, q_i> with the updated w; w -= h_i q_i), the reduction
+// trees differ in rounding only.  Finishes with h_{k+1,k}^2 = <w, w> and (optionally) q_{k+1} = w / sqrt of it.
+constexpr int kMgsMaxVectors = 64;
+struct MgsArgs {
+  const double *q[kMgsMaxVectors];
+  double *w;          // in: A q_k; out: q_{k+1} (normalised when `normalise`)
+  double *H;          // column k of the (m + 1) x m row-major Hessenberg: H[i * m + k]
+  double *norm2_out;  // <w, w> after the chain
+  int64_t n_rows, n_slices;
+  int k, m, normalise;
+  unsigned long long seq_base;  // tags of this launch: seq_base + 1 .. seq_base + k + 2 (bit 63 set: never a CG tag)
+  char *slots;
+  const int *done;
+};
+template <int S>
+__global__ __launch_bounds__(kLatBlock) void mgs_chain_kernel(MgsArgs a) {
+  if (a.done && *a.done) return;  // (uniform: every block reads the same flag before any of them synchronises)
+  __shared__ double lds[kLatWaves];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t wave_id = (int64_t)blockIdx.x * kLatWaves + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * kLatWaves;
+  unsigned long long seq = a.seq_base;
+  double w[S], qc[S], qn[S];
+  int64_t row[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int64_t sl = wave_id + s * n_waves;
+    row[s] = (sl < a.n_slices && sl * kWave + lane < a.n_rows) ? sl * kWave + lane : -1;
+    w[s] = row[s] >= 0 ? a.w[row[s]] : 0.0;
+    qc[s] = row[s] >= 0 ? a.q[0][row[s]] : 0.0;
+    qn[s] = 0.0;
+  }
+  for (int i = 0; i <= a.k; ++i) {
+    double acc = 0.0;
+#pragma unroll
+    for (int s = 0; s < S; ++s) acc += w[s] * qc[s];
+    if (i < a.k) {  // the next basis vector travels while the reduction is in flight
+#pragma unroll
+      for (int s = 0; s < S; ++s) qn[s] = row[s] >= 0 ? a.q[i + 1][row[s]] : 0.0;
+    }
+    const double h = lat_allreduce(acc, a.slots, ++seq, lds);
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.H[(int64_t)i * a.m + a.k] = h;
+#pragma unroll
+    for (int s = 0; s < S; ++s) w[s] -= h * qc[s], qc[s] = qn[s];
+  }
+  double acc = 0.0;
+#pragma unroll
+  for (int s = 0; s < S; ++s) acc += w[s] * w[s];
+  const double norm2 = lat_allreduce(acc, a.slots, ++seq, lds);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *a.norm2_out = norm2;
+  const double hn = sqrt(norm2);
+#pragma unroll
+  for (int s = 0; s < S; ++s)
+    if (row[s] >= 0) a.w[row[s]] = a.normalise ? w[s] / hn : w[s];
+}
+
+// Returns STORM_HIP_OK with *taken = false when the chain does not qualify (too many rows / vectors, a communicator).
+int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w, const double *const *q, int k, int m,
+                         double *H, double *norm2_out, bool normalise, bool *taken) {
+  *taken = false;
+  if (c->opt_coop_mgs == 0 || c->comm != nullptr || n <= 0 || k + 1 > kMgsMaxVectors || c->opt_profile_spmv != 0)
+    return STORM_HIP_OK;
+  const int64_t n_slices = (n + kWave - 1) / kWave;
+  const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(std::min(c->num_cus, 256), (n_slices + kLatWaves - 1) / kLatWaves));
+  const int64_t waves = blocks * kLatWaves;
+  const int64_t need = (n_slices + waves - 1) / waves;
+  const void *fn = need <= 1    ? (const void *)mgs_chain_kernel<1>
+                   : need <= 2  ? (const void *)mgs_chain_kernel<2>
+                   : need <= 4  ? (const void *)mgs_chain_kernel<4>
+                   : need <= 8  ? (const void *)mgs_chain_kernel<8>
+                   : need <= 16 ? (const void *)mgs_chain_kernel<16>
+                                : nullptr;
+  if (fn == nullptr) return STORM_HIP_OK;  // more than 16 slices per wavefront: registers cannot hold w
+  static int resident[5] = {-1, -1, -1, -1, -1};
+  const int vi = need <= 1 ? 0 : need <= 2 ? 1 : need <= 4 ? 2 : need <= 8 ? 3 : 4;
+  if (resident[vi] < 0) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident[vi], fn, kLatBlock, 0));
+  if (resident[vi] < 1) return STORM_HIP_OK;
+  MgsArgs a;
+  for (int i = 0; i <= k; ++i) a.q[i] = q[i];
+  for (int i = k + 1; i < kMgsMaxVectors; ++i) a.q[i] = q[0];
+  a.w = w, a.H = H, a.norm2_out = norm2_out, a.n_rows = n, a.n_slices = n_slices, a.k = k, a.m = m;
+  a.normalise = normalise ? 1 : 0;
+  a.seq_base = (1ull << 63) | c->lat_seq;
+  c->lat_seq += (unsigned long long)k + 2;
+  a.slots = c->d_lat_slots, a.done = done;
+  void *args[] = {&a};
+  HIP_TRY(hipLaunchCooperativeKernel(fn, dim3((unsigned)blocks), dim3(kLatBlock), args, 0, c->stream));
+  *taken = true;
+  return STORM_HIP_OK;
+}
+
 // Compact fp64 copy of an operator for the latency path (called by build_op); absent when the operator is too
 // large, partitioned, or has rows longer than its ELL cap.
 int op_make_latency_copy(storm_hip_op *op, int64_t n, int64_t n_halo, const std::vector<int64_t> &row_ptr,
@@ -356,7 +456,7 @@ int cg_latency_solve(const storm_hip_op *op, double alpha, double beta, const do
   }
   STORM_REQUIRE(fn != nullptr, "latency path: %lld rows do not fit %d slices per wavefront", (long long)op->n_rows,
                 kLatSlices);
-  HIP_TRY(hipMemsetAsync(c->d_lat_slots, 0, (size_t)256 * kLatSlotStride, c->stream));  // tags restart at 1
+  HIP_TRY(hipMemsetAsync(c->d_lat_slots, 0, (size_t)2 * 256 * kLatSlotStride, c->stream));  // tags restart at 1
   LatArgs a{op->d_lat_pack, op->d_lat_off, op->n_rows, n_slices, alpha, beta, b, x, p, r, c->d_lat_slots, d_state};
   void *args[] = {&a};
   HIP_TRY(hipLaunchCooperativeKernel(fn, dim3((unsigned)blocks), dim3(kLatBlock), args, 0, c->stream));

@@ -668,9 +668,19 @@ namespace storm {
 //   gram_schmidt == 1: classical Gram-Schmidt applied twice (2 multi-dots + 2 multi-axpys, batched reductions);
 //     `scratch` = 2 * kMaxMulti doubles for the two passes' coefficients.
 // Shared by storm_hip_solve_gmres below and by the general engine (krylov.hip).
+// *normalised (nullable) = true when qn has already been divided by its norm (the cooperative chain does that).
 int gmres_orthogonalize(storm_hip_ctx *c, int64_t n, const SolverState *st, const int *done, double *qn,
                         const double *const *q, int k, int m, double *H, double *norm2_out, double *scratch,
-                        int gram_schmidt) {
+                        int gram_schmidt, bool *normalised) {
+  if (normalised) *normalised = false;
+  if (gram_schmidt == 0 && n > 0) {  // small enough for registers: the whole chain as one cooperative kernel
+    bool taken = false;
+    STORM_TRY(gmres_mgs_chain_coop(c, n, done, qn, q, k, m, H, norm2_out, normalised != nullptr, &taken));
+    if (taken) {
+      if (normalised) *normalised = true;
+      return STORM_HIP_OK;
+    }
+  }
   const int nbv = stream_blocks(n);
   if (n <= 0) {  // an empty rank: zeros (and its share of the all-reduces)
     for (int i = 0; i <= k; ++i) {
@@ -967,12 +977,13 @@ int storm_hip_solve_gmres(const storm_hip_op *op, double alpha, double beta, con
     if (k == 0) STORM_TRY(start(false));                 // Solver.hpp:240-242
     double *qn = const_cast<double *>(q[k + 1]);
     STORM_TRY(d.apply(q[k], qn, nullptr, false, &nb));   // SolverGmres.hpp:155
+    bool normalised = false;
     STORM_TRY(gmres_orthogonalize(c, n, d.st, d.done, qn, q.data(), k, m, d.g.H, d.slot(S_TMP), d.slot(S_SCRATCH),
-                                  params->gram_schmidt));
+                                  params->gram_schmidt, &normalised));
     {
       hipLaunchKernelGGL(step_kernel, dim3(1), dim3(1), 0, c->stream, (int)STEP_GMRES_HN, d.st, d.g, false);
       HIP_TRY(hipGetLastError());
-      STORM_TRY(k_scale(c, qn, n, dev_scal(d.slot(S_HN)), true, d.done));                       // :162
+      if (!normalised) STORM_TRY(k_scale(c, qn, n, dev_scal(d.slot(S_HN)), true, d.done));      // :162
     }
     hipLaunchKernelGGL(gmres_givens_kernel, dim3(1), dim3(1), 0, c->stream, d.st, d.g, k);    // :176-191
     HIP_TRY(hipGetLastError());
