@@ -354,7 +354,11 @@ __global__ __launch_bounds__(kLatBlock) void mgs_chain_kernel(MgsArgs a) {
 int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w, const double *const *q, int k, int m,
                          double *H, double *norm2_out, bool normalise, bool *taken) {
   *taken = false;
-  if (c->opt_coop_mgs == 0 || c->comm != nullptr || n <= 0 || k + 1 > kMgsMaxVectors || c->opt_profile_spmv != 0)
+  // (a step of the chain costs one all-reduce, ~5 us, whatever the size; the kernel-per-step path costs a launch,
+  //  ~3.5 us, or 32 B/row of HBM traffic, whichever is more: the chain pays from ~0.5 M rows -- measured: step.1,
+  //  80 k rows, 12 500 it/s per-step vs 10 600 chained; 128^3 4 030 vs 6 340)
+  if (c->opt_coop_mgs == 0 || c->comm != nullptr || n < c->opt_coop_mgs_min_rows || k + 1 > kMgsMaxVectors ||
+      c->opt_profile_spmv != 0)
     return STORM_HIP_OK;
   const int64_t n_slices = (n + kWave - 1) / kWave;
   const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(std::min(c->num_cus, 256), (n_slices + kLatWaves - 1) / kLatWaves));

@@ -131,3 +131,44 @@ def test_convergence_rule_edges_on_the_latency_path(env):
     sv.solve(xw, b, op)
     assert sv.initial_error <= 2e-6 * np.linalg.norm(b_host)  # started from the solution, not from zero
     mat.close()
+
+
+@pytest.mark.parametrize("shape,m", [((7, 5, 3), 5), ((24, 24, 24), 30), ((64, 64, 64), 20), ((96, 96, 96), 30),
+                                     ((128, 128, 130), 12)])
+def test_cooperative_gram_schmidt_chain_matches_the_kernel_per_step_path(env, shape, m):
+    """GMRES's Arnoldi orthogonalisation as one cooperative kernel (w in registers; 1 / 2 / 4 / 8 / 16 slices per
+    wavefront here) against the kernel-per-basis-vector path and the oracle: same values in the same order, the
+    reduction trees differ in rounding only."""
+    api, mesh, oracle, ctx = env
+    g = mesh.structured_box(*shape)
+    wi, wo, de = mesh.convection_diffusion_weights(g, 1e-2, (1.0, 0.5, 0.25))
+    mat = api.StencilMatrix.from_face_weights(ctx, g.n_cells, g.n_halo, g.inner, g.outer, wi, wo, de)
+    op = api.HipStencilOperator(mat, 1.0, 0.0)
+    b_host = 1.0 + 0.25 * np.cos(0.02 * np.arange(g.n_cells))
+    runs = {}
+    for coop in (1, 0):
+        for generic in (0, 1):  # the fused loop and the engine share the chain
+            ctx.set_option("coop_mgs", coop)
+            ctx.set_option("coop_mgs_min_rows", 0)
+            ctx.set_option("generic_solvers", generic)
+            s = api.GmresSolver()
+            s.num_inner_iterations, s.record_history = m, True
+            b, x = api.DeviceVector.from_numpy(ctx, b_host), api.DeviceVector(ctx, g.n_cells)
+            ok = s.solve(x, b, op)
+            runs[(coop, generic)] = (ok, s.iteration, s.history.copy(), x.to_numpy())
+    ctx.set_option("coop_mgs", 1)
+    ctx.set_option("coop_mgs_min_rows", 400000)
+    ctx.set_option("generic_solvers", 0)
+    ok0, it0, h0, x0 = runs[(0, 0)]
+    assert ok0
+    for key, (ok, it, h, x) in runs.items():
+        assert ok and abs(it - it0) <= 1, (key, it, it0)
+        k = min(len(h), len(h0))
+        assert np.allclose(h[:k], h0[:k], rtol=1e-8), key
+        assert np.linalg.norm(x - x0) <= 1e-8 * np.linalg.norm(x0), key
+    if g.n_cells <= 64 ** 3:
+        ref = oracle.solve("gmres", oracle.StencilOperator(g, -1e-2, 0.0, conv=1.0, vel=(1.0, 0.5, 0.25)), b_host,
+                           num_inner_iterations=m)
+        assert abs(runs[(1, 0)][1] - ref.iterations) <= max(2, int(0.05 * ref.iterations))
+        assert np.linalg.norm(runs[(1, 0)][3] - ref.x) <= 1e-7 * np.linalg.norm(ref.x)
+    mat.close()
