@@ -332,3 +332,26 @@ def test_gmres_restart_of_64_and_more(env, m):
         assert abs(s.iteration - ref.iterations) <= max(2, int(0.05 * ref.iterations))
         assert np.linalg.norm(x.to_numpy() - ref.x) <= 1e-7 * np.linalg.norm(ref.x)
     mat.close()
+
+
+def test_solve_non_uniform_shifts_an_affine_operator(env):
+    """Solver.hpp:271-292: A(x) = M x + c has A(0) != 0; solve_non_uniform solves A(x) - A(0) = b - A(0) with the
+    solver it is given (the shifted operator is a lambda: it runs on the engine)."""
+    api, mesh, oracle, ctx = env
+    g = mesh.structured_box(11, 9, 7)
+    mat = api.StencilMatrix.from_face_graph(ctx, g)
+    c_host = 0.3 * np.cos(0.2 * np.arange(g.n_cells))
+    b_host = np.ones(g.n_cells)
+    cv = api.DeviceVector.from_numpy(ctx, c_host)
+
+    def affine(y, x):
+        mat.apply(-1.0, 0.0, x, y)
+        y += cv
+
+    b, x = api.DeviceVector.from_numpy(ctx, b_host), api.DeviceVector(ctx, g.n_cells)
+    s = api.BiCgStabSolver()
+    s.relative_error_tolerance, s.absolute_error_tolerance = 1e-10, 0.0
+    assert api.solve_non_uniform(s, x, b, api.make_operator(affine))
+    ref = oracle.solve("bicgstab", oracle.StencilOperator(g, -1.0, 0.0), b_host - c_host, rel_tol=1e-10, abs_tol=0.0)
+    assert np.linalg.norm(x.to_numpy() - ref.x) <= 1e-8 * np.linalg.norm(ref.x)
+    mat.close()
