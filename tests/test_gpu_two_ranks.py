@@ -101,3 +101,31 @@ def test_unstructured_partition_reproduces_the_recorded_reference_run(world, tmp
     assert sum(r["n_local"] for r in reports) == 6252
     assert len({r["iterations"] for r in reports}) == 1
     assert max(len(r["nbrs"]) for r in reports) >= 2  # not a chain of slabs
+
+
+def test_bench_line_contract_at_one_gpu():
+    """`python bench.py` (N = 1) on a small edge: ONE JSON line carrying the contract's fields -- `roofline` with a
+    physical fraction <= 1 that follows from its own bytes and time, `roofline_general`, `cpu_baseline`, `timing`."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--edge", "96", "--steps", "20", "--warmup", "3",
+           "--spinup-seconds", "0.2", "--min-seconds", "0.05", "--cpu-iters", "3"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(env, OMP_NUM_THREADS="1"), cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + "\n" + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["steps"] == 20 and out["dtype"] == "f64" and out["vs_baseline"] is None
+    assert "workload" in out["config"] and "model" not in out["config"]
+    for name in ("roofline", "roofline_general"):
+        r = out[name]
+        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+        assert 0.0 < r["frac"] <= 1.0
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-12
+        assert abs(r["achieved"] - r["bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
+    assert out["roofline_general"]["bytes_per_launch"] >= out["roofline_general"]["algorithmic_bytes_8d"]
+    cpu = out["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0 and cpu["gpu_vs_cpu_residual_rel_diff"] <= 1e-9
+    assert out["timing"]["repeats"] >= 1 and out["value"] > 10 * cpu["value"]
