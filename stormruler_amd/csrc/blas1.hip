@@ -276,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void reduce_stage1_plain_kernel(const doubl
 
 int k_reduce_final(storm_hip_ctx *c, const double *partials, int nblocks, int k, double *d_out,
                    const int *done) {
-  if (nblocks > 8192) {
+  if (nblocks > kSinglePassPartials) {
     hipLaunchKernelGGL(reduce_stage1_plain_kernel, dim3(kStage2, k), dim3(kBlock), 0, c->stream, partials,
                        nblocks, c->d_partials2, done);
     HIP_TRY(hipGetLastError());

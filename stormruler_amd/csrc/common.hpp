@@ -49,6 +49,10 @@ constexpr int kMaxMulti = 64;        // widest multi-dot / multi-axpy in one lau
 constexpr int kSlab = 256;           // doubles in the device scalar slab
 constexpr int kStateRing = 64;       // iterations the host may run ahead of the device's verdict
 constexpr int kStage2 = 128;         // blocks of the first pass of a two-pass final reduction
+// Up to this many per-block partials one block folds them in a single launch (32 loads per thread at the limit);
+// beyond, a first pass of kStage2 blocks (raising the limit to 32 768 gave no measurable gain at 128^3: the longer
+// single-block fold costs what the second launch did).
+constexpr int kSinglePassPartials = 8192;
 
 // Device-resident solver state: every scalar a Krylov loop carries, so no
 // alpha/beta/omega/Givens value ever visits the host (SURVEY.md section 7

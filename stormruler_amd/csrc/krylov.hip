@@ -421,7 +421,7 @@ struct KrylovEngine {
     if (red_pending) {
       const double *partials = c->d_partials;
       int nb = red_nb;
-      if (nb > 8192) {
+      if (nb > kSinglePassPartials) {
         hipLaunchKernelGGL(reduce_stage1_kernel2, dim3(kStage2, red_k), dim3(kBlock), 0, c->stream, partials, nb,
                            c->d_partials2, dp);
         partials = c->d_partials2, nb = kStage2;

@@ -489,7 +489,7 @@ struct Driver {
   }
   int finish_ptrs(int nblocks, int k, OutSlots out, double *contiguous, int step, bool force = false) {
     const double *partials = c->d_partials;
-    if (nblocks > 8192) {
+    if (nblocks > kSinglePassPartials) {
       hipLaunchKernelGGL(reduce_stage1_kernel, dim3(kStage2, k), dim3(kBlock), 0, c->stream, c->d_partials,
                          nblocks, c->d_partials2, st, force);
       HIP_TRY(hipGetLastError());
