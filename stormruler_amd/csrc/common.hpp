@@ -261,6 +261,7 @@ int op_upload_slice_lists(storm_hip_op *op);
 int op_make_latency_copy(storm_hip_op *op, int64_t n, int64_t n_halo, const std::vector<int64_t> &row_ptr,
                          const std::vector<int> &col, const std::vector<double> &val, const std::vector<double> &ext);
 bool cg_latency_eligible(const storm_hip_op *op);
+int lat_check_gave_up(storm_hip_ctx *c);
 int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w, const double *const *q, int k, int m,
                          double *H, double *norm2_out, bool normalise, bool *taken);
 int cg_latency_solve(const storm_hip_op *op, double alpha, double beta, const double *b, double *x, double *p,

@@ -1402,6 +1402,7 @@ int storm_hip_krylov_solve(storm_hip_krylov *k, const storm_hip_vec *b, storm_hi
     }
   }
   if (st == STORM_HIP_OK) st = read_state(k);
+  if (st == STORM_HIP_OK) st = lat_check_gave_up(c);
   if (st == STORM_HIP_OK) {
     const int64_t iters = k->h_st->iteration;
     const int64_t a0 = k->applies, p0 = k->pre_applies;

@@ -71,6 +71,7 @@ __device__ __forceinline__ double co_load(const double *p) {
 // block's waves issued before: each wave drains its own counter ahead of the block-wide barrier); tag.  Reader: ONE
 // aligned 16-byte coherent load per try -- a load that sees the new tag sees the value stored before it.
 constexpr int kLatSlotStride = 256;
+constexpr long long kLatTimeoutTicks = 1000000000LL;  // 10 s of the 100 MHz real-time counter
 __device__ __forceinline__ void co_load_slot(const char *slot, double *value, unsigned long long *tag) {
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   u32x4 w;
@@ -108,10 +109,21 @@ __device__ __forceinline__ double lat_allreduce(double mine, char *slots, unsign
   if (threadIdx.x < gridDim.x) {  // gridDim.x <= 256 <= blockDim.x: thread t watches block t
     unsigned long long tag;
     const char *slot = slots + ((size_t)threadIdx.x * 2 + (seq & 1)) * kLatSlotStride;
-    for (;;) {
+    // Every wait is bounded: the grid is launched cooperatively (all blocks resident), but should a block never
+    // arrive -- the device shared with another process's cooperative kernel, say -- the others give up after
+    // kLatTimeoutTicks instead of spinning forever, raise the flag behind the slots and fall through every later
+    // wait at once; the host turns the flag into an error.
+    int *gave_up = reinterpret_cast<int *>(slots + (size_t)2 * 256 * kLatSlotStride);
+    const long long t0 = wall_clock64();
+    for (int spins = 0;; ++spins) {
       co_load_slot(slot, &v, &tag);
       if (tag == seq) break;
       __builtin_amdgcn_s_sleep(1);
+      if ((spins & 1023) == 1023 &&
+          (wall_clock64() - t0 > kLatTimeoutTicks || __hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        __hip_atomic_store(gave_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
     }
   }
   return lat_block_sum(v, lds);  // slot order: lanes, then waves -- the same tree in every block
@@ -429,6 +441,19 @@ int op_make_latency_copy(storm_hip_op *op, int64_t n, int64_t n_halo, const std:
   return STORM_HIP_OK;
 }
 
+// After a cooperative kernel has completed: did one of its waits give up?
+int lat_check_gave_up(storm_hip_ctx *c) {
+  int flag = 0;
+  HIP_TRY(hipMemcpyAsync(&flag, c->d_lat_slots + (size_t)2 * 256 * kLatSlotStride, sizeof flag, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (flag != 0) {
+    (void)hipMemsetAsync(c->d_lat_slots + (size_t)2 * 256 * kLatSlotStride, 0, sizeof flag, c->stream);
+    STORM_FAIL(STORM_HIP_E_HIP, "cooperative kernel: a block waited 10 s for the others (is the device shared with another "
+                                "process's cooperative kernel?)");
+  }
+  return STORM_HIP_OK;
+}
+
 bool cg_latency_eligible(const storm_hip_op *op) {
   const storm_hip_ctx *c = op->ctx;
   return c->opt_latency_path != 0 && c->comm == nullptr && op->d_lat_pack != nullptr && c->opt_profile_spmv == 0;
@@ -460,7 +485,7 @@ int cg_latency_solve(const storm_hip_op *op, double alpha, double beta, const do
   }
   STORM_REQUIRE(fn != nullptr, "latency path: %lld rows do not fit %d slices per wavefront", (long long)op->n_rows,
                 kLatSlices);
-  HIP_TRY(hipMemsetAsync(c->d_lat_slots, 0, (size_t)2 * 256 * kLatSlotStride, c->stream));  // tags restart at 1
+  HIP_TRY(hipMemsetAsync(c->d_lat_slots, 0, (size_t)2 * 256 * kLatSlotStride + 256, c->stream));  // tags restart at 1; flag down
   LatArgs a{op->d_lat_pack, op->d_lat_off, op->n_rows, n_slices, alpha, beta, b, x, p, r, c->d_lat_slots, d_state};
   void *args[] = {&a};
   HIP_TRY(hipLaunchCooperativeKernel(fn, dim3((unsigned)blocks), dim3(kLatBlock), args, 0, c->stream));

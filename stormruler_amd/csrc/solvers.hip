@@ -579,6 +579,7 @@ static int collect(Driver &d, storm_hip_solver_result *res, double *history, int
   storm_hip_ctx *c = d.c;
   HIP_TRY(hipMemcpyAsync(&c->h_state[0], c->d_state, sizeof(SolverState), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  STORM_TRY(lat_check_gave_up(c));  // (a cooperative kernel of this solve -- CG's, a Gram-Schmidt chain -- timed out)
   const SolverState &h = c->h_state[0];
   res->iterations = h.iteration;
   res->absolute_error = h.absolute_error;
