@@ -115,6 +115,7 @@ struct storm_hip_ctx {
   int64_t opt_latency_rows = 1 << 19;   // ... up to this many rows (a compact copy of the operator is kept for it)
   int64_t opt_ipc_streams = 2;          // peer-window halo exchange: 2 = on the comm stream beside the interior rows, 1 = on the compute stream around them
   int64_t opt_generic_solvers = 0;  // 1: storm_hip_krylov_solve never takes the fused CG / BiCGStab / GMRES loops (A/B knob)
+  int64_t opt_fold_pz = 1;   // CG, one rank, > 8192 SpMV partials: cg_r_kernel folds the first-pass partials of <p,z> itself (one launch fewer)
   int64_t opt_fuse_dot = 1;  // 0: reductions after an SpMV run as separate kernels (A/B knob)
   // Vector storage released by vec_destroy, kept for the next vec_create of the same size: a solve
   // allocates its work vectors on entry and frees them on return (the reference re-assigns them in

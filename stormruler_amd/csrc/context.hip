@@ -141,6 +141,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "spmv_spw")) c->opt_spmv_spw = value;
   else if (!strcmp(key, "profile_spmv")) c->opt_profile_spmv = value;
   else if (!strcmp(key, "fuse_dot")) c->opt_fuse_dot = value;
+  else if (!strcmp(key, "fold_pz")) c->opt_fold_pz = value;
   else if (!strcmp(key, "fuse_mgs")) c->opt_fuse_mgs = value;
   else if (!strcmp(key, "graph")) c->opt_graph = value;
   else if (!strcmp(key, "blas1_nt")) c->opt_blas1_nt = value;

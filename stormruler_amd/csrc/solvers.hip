@@ -206,12 +206,24 @@ __global__ __launch_bounds__(kBlock) void init_residual_kernel(int64_t n, double
 // is read anyway: same values, 64N instead of 72N bytes per iteration.  cg_xp must apply the x
 // update of the iteration in which the solver converged (p no longer matters then), so it is
 // keyed on the iteration counter, not on `done`.
+// With pz_partials != null the kernel folds the (first-pass) partials of <p,z> itself -- every block the same
+// n_pz values in the same order, hence the same alpha -- and the separate final-pass launch disappears.
 __global__ __launch_bounds__(kBlock) void cg_r_kernel(int64_t n, SolverState *st, double *__restrict__ r,
                                                       const double *__restrict__ z,
-                                                      double *__restrict__ partials, int nt) {
+                                                      double *__restrict__ partials, int nt,
+                                                      const double *__restrict__ pz_partials, int n_pz) {
   if (st->done) return;
   __shared__ double lds4[4];
-  const double alpha = safe_divide(st->s[S_GAMMA], st->s[S_PZ]);
+  double pz;
+  if (pz_partials) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n_pz; i += kBlock) v += pz_partials[i];
+    pz = block_sum256(v, lds4);
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->s[S_PZ] = pz;
+  } else {
+    pz = st->s[S_PZ];
+  }
+  const double alpha = safe_divide(st->s[S_GAMMA], pz);
   if (blockIdx.x == 0 && threadIdx.x == 0) st->s[S_ALPHA] = alpha;  // for cg_xp_kernel of this iteration
   double acc = 0.0;
   const int64_t n2 = n >> 1;
@@ -796,17 +808,24 @@ int storm_hip_solve_cg(const storm_hip_op *op, double alpha, double beta, const 
   auto enqueue_iteration = [&]() -> int {
     // z = A p, <p,z>                                  SolverCg.hpp:96-97
     STORM_TRY(d.apply(p, z, p, false, &nb));
+    const double *pz_partials = nullptr;
     if (nb == 0) {  // operator has a CSR tail: separate dot
       const double *bs[1] = {z};
       STORM_TRY(k_multi_dot(c, p, bs, 1, n, d.slot(S_PZ), d.done));
       if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, d.slot(S_PZ), 1));
+    } else if (c->comm == nullptr && nb > kSinglePassPartials && c->opt_fold_pz != 0) {
+      // many partials, one rank: the first pass here, the fold of its kStage2 results inside cg_r_kernel
+      hipLaunchKernelGGL(reduce_stage1_kernel, dim3(kStage2, 1), dim3(kBlock), 0, c->stream, c->d_partials, nb,
+                         c->d_partials2, d.st, false);
+      HIP_TRY(hipGetLastError());
+      pz_partials = c->d_partials2;
     } else {
       const int slots[1] = {S_PZ};
       STORM_TRY(d.finish(nb, 1, slots, STEP_NONE));
     }
     // r -= alpha z; gamma = <r,r>                     SolverCg.hpp:97,99,115
     hipLaunchKernelGGL(cg_r_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, r, z, c->d_partials,
-                       (int)(c->opt_blas1_nt != 0));
+                       (int)(c->opt_blas1_nt != 0), pz_partials, (int)kStage2);
     HIP_TRY(hipGetLastError());
     {
       const int slots[1] = {S_GAMMA_NEW};
