@@ -2,7 +2,7 @@
 // (source_apps/playground/Playground.cpp:151-167): build the mesh quantities, wrap the stencil in
 // an operator, call solve<XSolver>(x, b, op).  Compiled against include/storm_hip/Storm.hpp only.
 //
-//   poisson_driver <n> <cg|bicgstab|gmres|fgmres|jfnk|...> <native|lambda|jacobi|jacobi-left> [restart]
+//   poisson_driver <n> <cg|bicgstab|gmres|fgmres|jfnk|...|user-steepest-descent> <native|lambda|jacobi|jacobi-left|stepping> [restart]
 //
 // prints one JSON line.  "lambda" passes the operator through make_operator (forcing the
 // statement-by-statement solver templates over the BLAS-1 ABI); "native" passes a
@@ -56,6 +56,28 @@ static BoxMesh make_box(int n) {
   return m;
 }
 
+// A solver a USER of the interface writes: derive from IterativeSolver, implement the protected hooks with the vector
+// statements of the overload census, and `solve` (final in the base, Solver.hpp:116-147) runs the reference's host loop
+// over them.  Steepest descent: r = b - A x; alpha = <r,r> / <r,A r>; x += alpha r.
+template<class Vector>
+class SteepestDescentSolver final : public IterativeSolver<Vector> {
+  Vector _r_vec, _z_vec;
+  real_t init(const Vector& x_vec, const Vector& b_vec, const Operator<Vector>& any_op,
+              const Preconditioner<Vector>*) override {
+    _r_vec.assign(x_vec, false);
+    _z_vec.assign(x_vec, false);
+    any_op.Residual(_r_vec, b_vec, x_vec);
+    return norm_2(_r_vec);
+  }
+  real_t iterate(Vector& x_vec, const Vector&, const Operator<Vector>& any_op, const Preconditioner<Vector>*) override {
+    any_op.mul(_z_vec, _r_vec);
+    const real_t alpha = safe_divide(dot_product(_r_vec, _r_vec), dot_product(_r_vec, _z_vec));
+    x_vec += alpha * _r_vec;
+    _r_vec -= alpha * _z_vec;
+    return norm_2(_r_vec);
+  }
+};
+
 template<template<class> class SolverT>
 static int run(int n, const std::string& mode, size_t restart) {
   const bool native = mode != "lambda";
@@ -71,6 +93,7 @@ static int run(int n, const std::string& mode, size_t restart) {
   SolverT<DeviceVector> solver;
   if constexpr (std::is_base_of_v<InnerOuterIterativeSolver<DeviceVector>, SolverT<DeviceVector>>)
     solver.num_inner_iterations = restart;
+  if (mode == "stepping") solver.device_loop = false;  // the host loop over init / iterate / finalize
   if (mode == "jacobi" || mode == "jacobi-left") {
     solver.pre_op = std::make_unique<JacobiPreconditioner>();
     solver.pre_side = mode == "jacobi" ? PreconditionerSide::Right : PreconditionerSide::Left;
@@ -132,6 +155,7 @@ int main(int argc, char** argv) {
     if (kind == "cgs") return run<CgsSolver>(n, native, restart);
     if (kind == "tfqmr") return run<TfqmrSolver>(n, native, restart);
     if (kind == "tfqmr1") return run<Tfqmr1Solver>(n, native, restart);
+    if (kind == "user-steepest-descent") return run<SteepestDescentSolver>(n, native, restart);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "error: %s\n", e.what());
     return 1;

@@ -70,3 +70,35 @@ def test_plain_c_host_drives_every_engine_method_through_a_callback_operator():
     assert p.returncode == 0 and len(lines) == 9 * 3 + 3 and all(ln["ok"] for ln in lines), p.stdout + p.stderr
     unpre = {ln["method"]: ln["iterations"] for ln in lines if ln.get("side") == -1}
     assert unpre["cg"] == unpre["cgs"] == unpre["tfqmr1"] == unpre["gmres"] == 32  # the reference's counts
+
+
+@pytest.mark.parametrize("kind", ["cg", "bicgstab", "gmres", "idrs"])
+def test_cpp_host_loop_over_the_stepping_hooks_matches_the_device_loop(kind):
+    """`solver.device_loop = false`: IterativeSolver::solve runs the reference's host loop (Solver.hpp:116-147) over
+    init / iterate / finalize, which the shipped solvers implement with storm_hip_krylov_init / _iterate / _finalize."""
+    outs = {}
+    for mode in ("native", "stepping"):
+        p = subprocess.run([DRIVER, "16", kind, mode, "20"], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        outs[mode] = json.loads(p.stdout.strip().splitlines()[-1])
+    a, b = outs["native"], outs["stepping"]
+    assert a["converged"] and b["converged"] and abs(a["iterations"] - b["iterations"]) <= 1
+    assert abs(a["x_norm2"] - b["x_norm2"]) <= 1e-8 * a["x_norm2"]
+
+
+def test_cpp_user_defined_solver_runs_on_the_interface():
+    """A solver written by a USER of the interface (tests/cpp/poisson_driver.cpp: SteepestDescentSolver derives from
+    IterativeSolver and implements init / iterate with the overloaded vector statements): the base class's final
+    `solve` drives it with the reference's convergence rule."""
+    p = subprocess.run([DRIVER, "8", "user-steepest-descent", "native"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    import numpy as np
+
+    from oracle import oracle
+    from stormruler_amd import mesh
+
+    g = mesh.structured_box(8)
+    ref = oracle.solve("cg", oracle.StencilOperator(g, -1.0, 0.0), np.ones(g.n_cells), rel_tol=1e-12, abs_tol=0.0)
+    assert out["converged"] and out["iterations"] > 20  # steepest descent needs many more steps than CG
+    assert abs(out["x_norm2"] - np.linalg.norm(ref.x)) <= 1e-4 * np.linalg.norm(ref.x)
