@@ -63,51 +63,56 @@ __device__ __forceinline__ double co_load(const double *p) {
 }
 
 // All-reduce across a co-resident (cooperative) grid, which is also its barrier.  Slot (b, parity) of block b: 16
-// bytes {value, tag} at slots + (2 b + (seq & 1)) * kLatSlotStride (256 bytes apart, so the polling load of all
-// blocks spreads over the memory channels).  TWO slots per block, used alternately: a block that has passed
-// all-reduce `seq` may publish `seq + 1` while a slower block is still polling for `seq` -- into the other slot; it
-// can only overwrite slot (seq & 1) with `seq + 2` after passing `seq + 1`, which needed the slow block's `seq + 1`
-// tag, which that block stores after it has finished reading `seq`.  Writer: value; wait for the acknowledgement (which also covers every coherent store the
-// block's waves issued before: each wave drains its own counter ahead of the block-wide barrier); tag.  Reader: ONE
-// aligned 16-byte coherent load per try -- a load that sees the new tag sees the value stored before it.
+// bytes at slots + (2 b + (seq & 1)) * kLatSlotStride (256 bytes apart, so the polling load of all blocks spreads
+// over the memory channels), holding the block's value in two self-validating 8-byte words
+//     { low half of the double, tag }   { high half, tag }        (tag = low 32 bits of the sequence number)
+// Each word is ONE 8-byte store -- atomic -- so the writer needs no ordering between them and no acknowledgement:
+// two stores, fire and forget; a reader's 16-byte load is good when BOTH tags are the current one.  (The scheme of
+// collective libraries' low-latency protocols.)  A synchronisation point costs: stores in flight, one polled load.
+// TWO slots per block, used alternately: a block that has passed all-reduce `seq` may publish `seq + 1` while a
+// slower block is still polling for `seq` -- into the other slot; it can only overwrite slot (seq & 1) with `seq + 2`
+// after passing `seq + 1`, which needed the slow block's `seq + 1` words, which that block stores after it has
+// finished reading `seq`.
 constexpr int kLatSlotStride = 256;
 constexpr long long kLatTimeoutTicks = 1000000000LL;  // 10 s of the 100 MHz real-time counter
-__device__ __forceinline__ void co_load_slot(const char *slot, double *value, unsigned long long *tag) {
+__device__ __forceinline__ bool co_load_slot(const char *slot, unsigned tag, double *value) {
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   u32x4 w;
   asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(slot) : "memory");
-  *value = __hiloint2double((int)w.y, (int)w.x);
-  *tag = ((unsigned long long)w.w << 32) | w.z;
+  *value = __hiloint2double((int)w.z, (int)w.x);
+  return w.y == tag && w.w == tag;
+}
+__device__ __forceinline__ void co_store_slot(char *slot, unsigned tag, double value) {
+  const unsigned long long lo = ((unsigned long long)tag << 32) | (unsigned)__double2loint(value);
+  const unsigned long long hi = ((unsigned long long)tag << 32) | (unsigned)__double2hiint(value);
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(slot), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(slot) + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ double lat_wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
   return v;
 }
-__device__ __forceinline__ double lat_block_sum(double v, double *lds) {  // the same bits in every thread
-  v = lat_wave_sum(v);
+// Sum over all blocks of `mine` (a per-thread partial), identical bits in every thread of every block.
+// `publishes`: the block's waves have issued coherent stores (rows of r, p) that other blocks read once they are past
+// this point -- every wave then drains its own store counter before the block's words go out.
+__device__ __forceinline__ double lat_allreduce(double mine, char *slots, unsigned long long seq, double *lds,
+                                                bool publishes = true) {
+  const unsigned tag = (unsigned)seq;
+  double v = lat_wave_sum(mine);
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-  __syncthreads();
+  if (publishes) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's rows are acknowledged
+  __syncthreads();  // (lds may still be read by the previous call)
   if (lane == 0) lds[wave] = v;
   __syncthreads();
-  double t = 0.0;
+  if (threadIdx.x == 0) {
+    double t = 0.0;
 #pragma unroll
-  for (int w = 0; w < kLatWaves; ++w) t += lds[w];
-  return t;
-}
-// Sum over all blocks of `mine` (a per-thread partial), identical bits in every thread of every block.
-__device__ __forceinline__ double lat_allreduce(double mine, char *slots, unsigned long long seq, double *lds) {
-  const double block_value = lat_block_sum(mine, lds);
-  char *my_slot = slots + ((size_t)blockIdx.x * 2 + (seq & 1)) * kLatSlotStride;
-  if (threadIdx.x == 0) co_store(reinterpret_cast<double *>(my_slot), block_value);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's coherent stores are acknowledged ...
-  __syncthreads();                                         // ... and so are every other wave's of this block
-  if (threadIdx.x == 0)
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(my_slot + 8), seq, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-  double v = 0.0;
+    for (int w = 0; w < kLatWaves; ++w) t += lds[w];
+    co_store_slot(slots + ((size_t)blockIdx.x * 2 + (seq & 1)) * kLatSlotStride, tag, t);
+  }
+  v = 0.0;
   if (threadIdx.x < gridDim.x) {  // gridDim.x <= 256 <= blockDim.x: thread t watches block t
-    unsigned long long tag;
     const char *slot = slots + ((size_t)threadIdx.x * 2 + (seq & 1)) * kLatSlotStride;
     // Every wait is bounded: the grid is launched cooperatively (all blocks resident), but should a block never
     // arrive -- the device shared with another process's cooperative kernel, say -- the others give up after
@@ -116,8 +121,7 @@ __device__ __forceinline__ double lat_allreduce(double mine, char *slots, unsign
     int *gave_up = reinterpret_cast<int *>(slots + (size_t)2 * 256 * kLatSlotStride);
     const long long t0 = wall_clock64();
     for (int spins = 0;; ++spins) {
-      co_load_slot(slot, &v, &tag);
-      if (tag == seq) break;
+      if (co_load_slot(slot, tag, &v)) break;
       __builtin_amdgcn_s_sleep(1);
       if ((spins & 1023) == 1023 &&
           (wall_clock64() - t0 > kLatTimeoutTicks || __hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
@@ -126,7 +130,12 @@ __device__ __forceinline__ double lat_allreduce(double mine, char *slots, unsign
       }
     }
   }
-  return lat_block_sum(v, lds);  // slot order: lanes, then waves -- the same tree in every block
+  // slot order: lanes, then the (up to four) polling waves -- the same tree in every block
+  v = lat_wave_sum(v);
+  __syncthreads();
+  if (lane == 0 && wave < 4) lds[wave] = v;
+  __syncthreads();
+  return (lds[0] + lds[1]) + (lds[2] + lds[3]);
 }
 
 // Neighbour value of the vector an SpMV is applied to: plain x (init), or the direction p' = r + beta p formed
@@ -316,7 +325,7 @@ struct MgsArgs {
   double *norm2_out;  // <w, w> after the chain
   int64_t n_rows, n_slices;
   int k, m, normalise;
-  unsigned long long seq_base;  // tags of this launch: seq_base + 1 .. seq_base + k + 2 (bit 63 set: never a CG tag)
+  unsigned long long seq_base;  // tags of this launch: seq_base + 1 .. seq_base + k + 2 (bit 31 set: never a CG tag)
   char *slots;
   const int *done;
 };
@@ -346,7 +355,7 @@ __global__ __launch_bounds__(kLatBlock) void mgs_chain_kernel(MgsArgs a) {
 #pragma unroll
       for (int s = 0; s < S; ++s) qn[s] = row[s] >= 0 ? a.q[i + 1][row[s]] : 0.0;
     }
-    const double h = lat_allreduce(acc, a.slots, ++seq, lds);
+    const double h = lat_allreduce(acc, a.slots, ++seq, lds, false);
     if (blockIdx.x == 0 && threadIdx.x == 0) a.H[(int64_t)i * a.m + a.k] = h;
 #pragma unroll
     for (int s = 0; s < S; ++s) w[s] -= h * qc[s], qc[s] = qn[s];
@@ -354,7 +363,7 @@ __global__ __launch_bounds__(kLatBlock) void mgs_chain_kernel(MgsArgs a) {
   double acc = 0.0;
 #pragma unroll
   for (int s = 0; s < S; ++s) acc += w[s] * w[s];
-  const double norm2 = lat_allreduce(acc, a.slots, ++seq, lds);
+  const double norm2 = lat_allreduce(acc, a.slots, ++seq, lds, false);
   if (blockIdx.x == 0 && threadIdx.x == 0) *a.norm2_out = norm2;
   const double hn = sqrt(norm2);
 #pragma unroll
@@ -392,7 +401,7 @@ int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w
   for (int i = k + 1; i < kMgsMaxVectors; ++i) a.q[i] = q[0];
   a.w = w, a.H = H, a.norm2_out = norm2_out, a.n_rows = n, a.n_slices = n_slices, a.k = k, a.m = m;
   a.normalise = normalise ? 1 : 0;
-  a.seq_base = (1ull << 63) | c->lat_seq;
+  a.seq_base = (1ull << 31) | (c->lat_seq & 0x7fffffffull);  // bit 31: never the tag of a CG solve (those count from 1)
   c->lat_seq += (unsigned long long)k + 2;
   a.slots = c->d_lat_slots, a.done = done;
   void *args[] = {&a};
