@@ -62,8 +62,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--meshes", default="box256,step1,box64")
     ap.add_argument("--solvers", default=",".join(SOLVERS))
+    ap.add_argument("--opt", action="append", default=[], help="library option key=value (repeatable)")
     a = ap.parse_args()
     ctx = api.Context(0)
+    for kv in a.opt:
+        key, value = kv.split("=")
+        ctx.set_option(key, int(value))
     for name in a.meshes.split(","):
         if name.startswith("box"):
             n = int(name[3:])
