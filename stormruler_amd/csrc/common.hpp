@@ -112,6 +112,7 @@ struct storm_hip_ctx {
   int64_t opt_coop_mgs_min_rows = 400000;  // ... from this many rows on (below, a launch per step is cheaper than an all-reduce per step)
   int64_t opt_coop_mgs = 1;             // GMRES: the Gram-Schmidt chain of an Arnoldi step as one cooperative kernel (latency.hip)
   int64_t opt_latency_path = 1;         // small operators: CG as one cooperative persistent kernel (latency.hip)
+  int opt_latency_cache = 1;            // ... with the wave's operator records held in registers where they fit
   int64_t opt_latency_rows = 1 << 19;   // ... up to this many rows (a compact copy of the operator is kept for it)
   int64_t opt_ipc_streams = 2;          // peer-window halo exchange: 2 = on the comm stream beside the interior rows, 1 = on the compute stream around them
   int64_t opt_generic_solvers = 0;  // 1: storm_hip_krylov_solve never takes the fused CG / BiCGStab / GMRES loops (A/B knob)
@@ -267,6 +268,8 @@ int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w
                          double *H, double *norm2_out, bool normalise, bool *taken);
 int cg_latency_solve(const storm_hip_op *op, double alpha, double beta, const double *b, double *x, double *p,
                      double *r, SolverState *d_state);
+int bicgstab_latency_solve(const storm_hip_op *op, double alpha, double beta, const double *b, double *x,
+                           double *const work[4], SolverState *d_state);
 
 // comm.hip
 int comm_allreduce_sum(storm_hip_ctx *c, double *d_buf, int count);  // in place, on ctx->stream

@@ -1,4 +1,4 @@
-// The latency path: CG for SMALL operators as ONE cooperative, persistent kernel per solve.
+// The latency path: CG and BiCGStab for SMALL operators as ONE cooperative, persistent kernel per solve.
 //
 // The reference's own meshes have 6 000 .. 80 000 cells (tests/_data/mesh), BASELINE config 1 has 64^3 = 262 144:
 // vectors of 50 KB .. 2 MB.  The throughput path (solvers.hip) spends such an iteration on launch latency -- 7 kernels
@@ -22,7 +22,7 @@
 //   * rows are summed slot by slot exactly as the throughput kernels do (same expression, same contraction): the
 //     SpMV values are bit-identical; dot products group their terms differently (rounding-level differences).
 //
-// Taken by storm_hip_solve_cg when the operator has a latency copy (n_rows <= option `latency_rows`, no halo, no
+// Taken by storm_hip_solve_cg / storm_hip_solve_bicgstab when the operator has a latency copy (n_rows <= option `latency_rows`, no halo, no
 // CSR tail), the context has no communicator, and option `latency_path` != 0.
 #include <algorithm>
 #include <cmath>
@@ -46,6 +46,7 @@ struct LatArgs {
   const double *b;
   double *x;
   double *p, *r;             // published rows of the current direction and the new residual (see the header)
+  double *v0, *v1;           // BiCGStab: published rows of v = A p of even / odd iterations
   char *slots;               // all-reduce slots, kLatSlotStride bytes per block, zeroed before the launch
   SolverState *st;
 };
@@ -138,6 +139,57 @@ __device__ __forceinline__ double lat_allreduce(double mine, char *slots, unsign
   return (lds[0] + lds[1]) + (lds[2] + lds[3]);
 }
 
+// The same for TWO sums at once (BiCGStab's <t, s>, <t, t> and <r, r>, <rt, r>): the slot carries four words.
+__device__ __forceinline__ bool co_load_slot2(const char *slot, unsigned tag, double *v0, double *v1) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 w0, w1;
+  asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(w0), "=&v"(w1)
+               : "v"(slot)
+               : "memory");
+  *v0 = __hiloint2double((int)w0.z, (int)w0.x);
+  *v1 = __hiloint2double((int)w1.z, (int)w1.x);
+  return w0.y == tag && w0.w == tag && w1.y == tag && w1.w == tag;
+}
+__device__ __forceinline__ void lat_allreduce2(double &s0, double &s1, char *slots, unsigned long long seq, double *lds,
+                                               bool publishes = true) {
+  const unsigned tag = (unsigned)seq;
+  double v0 = lat_wave_sum(s0), v1 = lat_wave_sum(s1);
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  if (publishes) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (lane == 0) lds[wave] = v0, lds[kLatWaves + wave] = v1;
+  __syncthreads();
+  if (threadIdx.x < 2) {  // thread 0 folds and stores the first sum, thread 1 the second
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < kLatWaves; ++w) t += lds[threadIdx.x * kLatWaves + w];
+    co_store_slot(slots + ((size_t)blockIdx.x * 2 + (seq & 1)) * kLatSlotStride + 16 * threadIdx.x, tag, t);
+  }
+  v0 = v1 = 0.0;
+  if (threadIdx.x < gridDim.x) {
+    const char *slot = slots + ((size_t)threadIdx.x * 2 + (seq & 1)) * kLatSlotStride;
+    int *gave_up = reinterpret_cast<int *>(slots + (size_t)2 * 256 * kLatSlotStride);
+    const long long t0 = wall_clock64();
+    for (int spins = 0;; ++spins) {
+      if (co_load_slot2(slot, tag, &v0, &v1)) break;
+      __builtin_amdgcn_s_sleep(1);
+      if ((spins & 1023) == 1023 &&
+          (wall_clock64() - t0 > kLatTimeoutTicks || __hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        __hip_atomic_store(gave_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v0 = v1 = 0.0;
+        break;
+      }
+    }
+  }
+  v0 = lat_wave_sum(v0), v1 = lat_wave_sum(v1);
+  __syncthreads();
+  if (lane == 0 && wave < 4) lds[wave] = v0, lds[kLatWaves + wave] = v1;
+  __syncthreads();
+  s0 = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+  s1 = (lds[kLatWaves] + lds[kLatWaves + 1]) + (lds[kLatWaves + 2] + lds[kLatWaves + 3]);
+}
+
 // Neighbour value of the vector an SpMV is applied to: plain x (init), or the direction p' = r + beta p formed
 // from the published rows.
 struct LatPlain {
@@ -150,12 +202,12 @@ struct LatDirection {
   __device__ __forceinline__ double operator()(int c) const { return co_load(r + c) + beta * co_load(p + c); }
 };
 
-constexpr int kLatCacheWidth = 8;  // slots per row held in registers
-template <int S, bool CACHED>
-struct LatRecords {  // the records of a wave's slices: in registers (CACHED) or re-read from memory every time
-  int col[CACHED ? S : 1][CACHED ? kLatCacheWidth : 1];
-  double val[CACHED ? S : 1][CACHED ? kLatCacheWidth : 1];
-  double ext[CACHED ? S : 1];
+constexpr int kLatCacheWidth = 8;  // slots per row held in registers, at most
+template <int S, int W>
+struct LatRecords {  // the records of a wave's slices: W slots per row in registers, or (W == 0) re-read every time
+  int col[W ? S : 1][W ? W : 1];
+  double val[W ? S : 1][W ? W : 1];
+  double ext[W ? S : 1];
 };
 
 // (M v)_row for one row of slice s: sum_k w_k (v[col_k] - v_i) + ext v_i, slots in order.
@@ -181,31 +233,29 @@ __device__ __forceinline__ double lat_row(const LatArgs &a, int64_t s, int lane,
   for (; k < width; ++k) acc += val[k * kWave] * (get(col[k * kWave]) - vi);
   return a.beta * vi + a.alpha * (acc + ext * vi);
 }
-// The same from registers: kLatCacheWidth slots, the ones past the row's width carry weight 0 and the row's own
+// The same from registers: W slots (4: triangle / quadrilateral meshes; 8), the ones past the row's width carry weight 0 and the row's own
 // column (a term 0 * (v_i - v_i) leaves the sum as it is).
-template <int S, class Get>
-__device__ __forceinline__ double lat_row_cached(const LatArgs &a, const LatRecords<S, true> &rec, int q, const Get &get,
+// (CHUNK neighbours in flight at a time: a neighbour costs one load with LatPlain, up to three with BiCGStab's.)
+template <int S, int W, int CHUNK = W, class Get>
+__device__ __forceinline__ double lat_row_cached(const LatArgs &a, const LatRecords<S, W> &rec, int q, const Get &get,
                                                  double vi) {
-  double g[kLatCacheWidth];
-#pragma unroll
-  for (int k = 0; k < kLatCacheWidth; ++k) g[k] = get(rec.col[q][k]);
   double acc = 0.0;
 #pragma unroll
-  for (int k = 0; k < kLatCacheWidth; ++k) acc += rec.val[q][k] * (g[k] - vi);
+  for (int k0 = 0; k0 < W; k0 += CHUNK) {
+    double g[CHUNK];
+#pragma unroll
+    for (int k = 0; k < CHUNK; ++k) g[k] = get(rec.col[q][k0 + k]);
+#pragma unroll
+    for (int k = 0; k < CHUNK; ++k) acc += rec.val[q][k0 + k] * (g[k] - vi);
+  }
   return a.beta * vi + a.alpha * (acc + rec.ext[q] * vi);
 }
 
-template <int S, bool CACHED>
-__global__ __launch_bounds__(kLatBlock) void cg_latency_kernel(LatArgs a) {
-  __shared__ double lds[kLatWaves];
-  SolverState *st = a.st;
-  const int lane = threadIdx.x & (kWave - 1);
-  const int64_t wave_id = (int64_t)blockIdx.x * kLatWaves + (threadIdx.x >> 6);
-  const int64_t n_waves = (int64_t)gridDim.x * kLatWaves;
-  unsigned long long seq = 0;
-  double x[S], r[S], p[S], z[S];
-  LatRecords<S, CACHED> rec;
-  if (CACHED) {
+// The records of a wave's slices into registers (W > 0 variants).
+template <int S, int W>
+__device__ __forceinline__ void lat_load_records(const LatArgs &a, int64_t wave_id, int64_t n_waves, int lane,
+                                                 LatRecords<S, W> &rec) {
+  if (W > 0) {
 #pragma unroll
     for (int q = 0; q < S; ++q) {
       const int64_t s = wave_id + q * n_waves, row = s * kWave + lane;
@@ -215,7 +265,7 @@ __global__ __launch_bounds__(kLatBlock) void cg_latency_kernel(LatArgs a) {
       const char *base = a.pack + o0;
       rec.ext[q] = live ? reinterpret_cast<const double *>(base)[lane] : 0.0;
 #pragma unroll
-      for (int k = 0; k < kLatCacheWidth; ++k) {
+      for (int k = 0; k < W; ++k) {
         const bool has = k < width;
         rec.col[q][k] = has ? (reinterpret_cast<const int *>(base + kWave * 8) + lane)[k * kWave]
                             : (int)(row < a.n_rows ? row : a.n_rows - 1);
@@ -224,8 +274,21 @@ __global__ __launch_bounds__(kLatBlock) void cg_latency_kernel(LatArgs a) {
       }
     }
   }
+}
+
+template <int S, int W>
+__global__ __launch_bounds__(kLatBlock) void cg_latency_kernel(LatArgs a) {
+  __shared__ double lds[kLatWaves];
+  SolverState *st = a.st;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t wave_id = (int64_t)blockIdx.x * kLatWaves + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * kLatWaves;
+  unsigned long long seq = 0;
+  double x[S], r[S], p[S], z[S];
+  LatRecords<S, W> rec;
+  lat_load_records<S, W>(a, wave_id, n_waves, lane, rec);
   auto apply_row = [&](int q, int64_t s, const auto &get, double vi) -> double {
-    if constexpr (CACHED) return lat_row_cached<S>(a, rec, q, get, vi);
+    if constexpr (W > 0) return lat_row_cached<S, W>(a, rec, q, get, vi);
     else return lat_row(a, s, lane, get, vi);
   };
 
@@ -293,6 +356,151 @@ __global__ __launch_bounds__(kLatBlock) void cg_latency_kernel(LatArgs a) {
     if (blockIdx.x == 0 && threadIdx.x == 0 && history) history[it] = abs_err;
 #pragma unroll
     for (int q = 0; q < S; ++q) p[q] = r[q] + beta * p[q];
+  }
+#pragma unroll
+  for (int q = 0; q < S; ++q) {
+    const int64_t s = wave_id + q * n_waves, row = s * kWave + lane;
+    if (s < a.n_slices && row < a.n_rows) a.x[row] = x[q];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->initial_error = initial_error;
+    st->absolute_error = abs_err;
+    st->relative_error = rel_err;
+    st->iteration = it;
+    st->converged = converged ? 1 : 0;
+    st->done = 1;
+  }
+}
+
+// ---- BiCGStab on the latency path ---------------------------------------------------------------------------------
+// SolverBiCgStab.hpp:60-167 inside Solver.hpp:116-147, THREE synchronisation points per iteration (the throughput path
+// spends 13 launches on it).  Registers hold x, r, p, v, rt of the own rows.  What a neighbour needs is published as
+// rows of r (the residual at the iteration's end), p, and v (two buffers, alternating by iteration); a gathering wave
+// forms the vector the operator is applied to itself, by the expression the owner uses:
+//   A p':  p'[c] = r[c] + beta (p[c] - omega v[c])            from r, p, v as of the END of the previous iteration
+//   A s :  s[c]  = r[c] - alpha v'[c]                         from the same r and THIS iteration's v (other buffer)
+// so neither "p complete" nor "s complete" is a barrier of its own: the all-reduces of <rt, v>, (<t, s>, <t, t>) and
+// (<r, r>, <rt, r>) are the only ones.  A buffer is overwritten only after an all-reduce that every block enters
+// after its last gather from it (r, p: behind the omega all-reduce; v of parity k: written in iteration k + 2, read
+// last in iteration k + 1 before its first all-reduce).
+__device__ __forceinline__ double bicg_direction(double r, double p, double v, double beta, double omega) {
+  return __builtin_fma(beta, __builtin_fma(-omega, v, p), r);  // r + beta (p - omega v)      SolverBiCgStab.hpp:119
+}
+__device__ __forceinline__ double bicg_half_residual(double r, double v, double alpha) {
+  return __builtin_fma(-alpha, v, r);  // r - alpha v                                         SolverBiCgStab.hpp:141
+}
+struct LatBicgDirection {
+  const double *r, *p, *v;
+  double beta, omega;
+  __device__ __forceinline__ double operator()(int c) const {
+    return bicg_direction(co_load(r + c), co_load(p + c), co_load(v + c), beta, omega);
+  }
+};
+struct LatBicgHalf {
+  const double *r, *v;
+  double alpha;
+  __device__ __forceinline__ double operator()(int c) const { return bicg_half_residual(co_load(r + c), co_load(v + c), alpha); }
+};
+
+template <int S, int W>
+__global__ __launch_bounds__(kLatBlock) void bicgstab_latency_kernel(LatArgs a) {
+  __shared__ double lds[2 * kLatWaves];
+  SolverState *st = a.st;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t wave_id = (int64_t)blockIdx.x * kLatWaves + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * kLatWaves;
+  unsigned long long seq = 0;
+  double x[S], r[S], p[S], v[S], rt[S];
+  LatRecords<S, W> rec;
+  lat_load_records<S, W>(a, wave_id, n_waves, lane, rec);
+  auto apply_row = [&](int q, int64_t s, const auto &get, double vi) -> double {
+    if constexpr (W > 0) return lat_row_cached<S, W, 4>(a, rec, q, get, vi);
+    else return lat_row(a, s, lane, get, vi);
+  };
+
+  // ---- init: r = b - A x; rt = r; rho = <rt, r>                                   SolverBiCgStab.hpp:82-90
+  // (a.p, a.v0, a.v1 arrive zero-filled: the first direction r + 0 * (p - 0 * v) is r, :114)
+  double acc = 0.0;
+#pragma unroll
+  for (int q = 0; q < S; ++q) {
+    const int64_t s = wave_id + q * n_waves, row = s * kWave + lane;
+    const bool valid = s < a.n_slices && row < a.n_rows;
+    x[q] = valid ? a.x[row] : 0.0;
+    r[q] = p[q] = v[q] = rt[q] = 0.0;
+    if (s < a.n_slices) {
+      const double ax = apply_row(q, s, LatPlain{a.x}, x[q]);
+      r[q] = valid ? a.b[row] - ax : 0.0;
+      rt[q] = r[q];
+      if (valid) co_store(a.r + row, r[q]);
+      acc += rt[q] * r[q];
+    }
+  }
+  double rho = lat_allreduce(acc, a.slots, ++seq, lds);
+  const double initial_error = sqrt(rho);
+  const double abs_tol = st->abs_tol, rel_tol = st->rel_tol;
+  const long long num_iterations = st->num_iterations;
+  double *history = st->history;
+  bool converged = abs_tol > 0.0 && initial_error < abs_tol;  // Solver.hpp:124-128
+  double abs_err = initial_error, rel_err = 0.0, alpha = 0.0, beta = 0.0, omega = 0.0;
+  long long it = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && history) history[0] = initial_error;
+
+  while (!converged && it < num_iterations) {
+    double *v_prev = (it & 1) ? a.v0 : a.v1, *v_cur = (it & 1) ? a.v1 : a.v0;
+    // p = r + beta (p - omega v) (own rows, registers); v = A p; <rt, v>              :114-119, :137-139
+    acc = 0.0;
+    const LatBicgDirection dir{a.r, a.p, v_prev, beta, omega};
+#pragma unroll
+    for (int q = 0; q < S; ++q) {
+      const int64_t s = wave_id + q * n_waves, row = s * kWave + lane;
+      p[q] = bicg_direction(r[q], p[q], v[q], beta, omega);
+      if (s < a.n_slices) {
+        v[q] = apply_row(q, s, dir, p[q]);
+        v[q] = (row < a.n_rows) ? v[q] : 0.0;
+        if (row < a.n_rows) co_store(v_cur + row, v[q]);
+        acc += rt[q] * v[q];
+      }
+    }
+    alpha = safe_divide(rho, lat_allreduce(acc, a.slots, ++seq, lds));
+    // s = r - alpha v (kept in r); t = A s; omega = <t, s> / <t, t>                   :140-141, :158-160
+    double t[S];
+    double acc_ts = 0.0, acc_tt = 0.0;
+    const LatBicgHalf half{a.r, v_cur, alpha};
+#pragma unroll
+    for (int q = 0; q < S; ++q) {
+      const int64_t s = wave_id + q * n_waves, row = s * kWave + lane;
+      r[q] = bicg_half_residual(r[q], v[q], alpha);
+      t[q] = 0.0;
+      if (s < a.n_slices) {
+        t[q] = apply_row(q, s, half, r[q]);
+        t[q] = (row < a.n_rows) ? t[q] : 0.0;
+        acc_ts += t[q] * r[q];
+        acc_tt += t[q] * t[q];
+      }
+    }
+    lat_allreduce2(acc_ts, acc_tt, a.slots, ++seq, lds, false);  // nothing published since the last one
+    omega = safe_divide(acc_ts, acc_tt);
+    // x += alpha p + omega s; r = s - omega t; |r|, <rt, r>                           :140, :161-164, :116
+    double acc_rr = 0.0, acc_rho = 0.0;
+#pragma unroll
+    for (int q = 0; q < S; ++q) {
+      const int64_t s = wave_id + q * n_waves, row = s * kWave + lane;
+      x[q] += alpha * p[q];
+      x[q] += omega * r[q];
+      r[q] -= omega * t[q];
+      acc_rr += r[q] * r[q];
+      acc_rho += rt[q] * r[q];
+      if (s < a.n_slices && row < a.n_rows) co_store(a.r + row, r[q]), co_store(a.p + row, p[q]);
+    }
+    lat_allreduce2(acc_rr, acc_rho, a.slots, ++seq, lds);
+    const double rho_bar = rho;
+    rho = acc_rho;
+    beta = safe_divide(alpha * rho, omega * rho_bar);  // :116-118, for the next iteration
+    abs_err = sqrt(acc_rr);
+    rel_err = abs_err / initial_error;
+    converged = (abs_tol > 0.0 && abs_err < abs_tol) || (rel_tol > 0.0 && rel_err < rel_tol);  // Solver.hpp:132-140
+    ++it;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && history) history[it] = abs_err;
   }
 #pragma unroll
   for (int q = 0; q < S; ++q) {
@@ -468,26 +676,37 @@ bool cg_latency_eligible(const storm_hip_op *op) {
   return c->opt_latency_path != 0 && c->comm == nullptr && op->d_lat_pack != nullptr && c->opt_profile_spmv == 0;
 }
 
-// The whole solve; fills the SolverState on the device (the caller reads it back).
-int cg_latency_solve(const storm_hip_op *op, double alpha, double beta, const double *b, double *x, double *p,
-                     double *r, SolverState *d_state) {
+// The whole solve; fills the SolverState on the device (the caller reads it back).  `bicgstab`: which of the two
+// kernels; work vectors p, r (CG) and p, r, v0, v1 (BiCGStab) arrive zero-filled.
+static int latency_solve(bool bicgstab, const storm_hip_op *op, LatArgs a) {
   storm_hip_ctx *c = op->ctx;
   const int64_t n_slices = (op->n_rows + kWave - 1) / kWave;
   // A co-resident grid (cooperative launch): one 1024-thread block per CU at most (<= 256 blocks: one polling
   // thread per block), at least one slice per wavefront; the smallest register variant that covers all slices.
   // registers can hold the records of a wave's slices when rows have <= kLatCacheWidth slots and S <= 2
-  const bool cached = op->max_row_len <= kLatCacheWidth;
-  const void *variants[4] = {cached ? (const void *)cg_latency_kernel<1, true> : (const void *)cg_latency_kernel<1, false>,
-                             cached ? (const void *)cg_latency_kernel<2, true> : (const void *)cg_latency_kernel<2, false>,
-                             (const void *)cg_latency_kernel<4, false>, (const void *)cg_latency_kernel<8, false>};
+  const int w = c->opt_latency_cache == 0 ? 0 : op->max_row_len <= 4 ? 4 : op->max_row_len <= kLatCacheWidth ? 8 : 0;
+  auto pick = [w](const void *w0, const void *w4, const void *w8) { return w == 4 ? w4 : w == 8 ? w8 : w0; };
+  const void *cg[4] = {
+      pick((const void *)cg_latency_kernel<1, 0>, (const void *)cg_latency_kernel<1, 4>, (const void *)cg_latency_kernel<1, 8>),
+      pick((const void *)cg_latency_kernel<2, 0>, (const void *)cg_latency_kernel<2, 4>, (const void *)cg_latency_kernel<2, 8>),
+      (const void *)cg_latency_kernel<4, 0>, (const void *)cg_latency_kernel<8, 0>};
+  const void *bi[4] = {  // (two slices of records AND five vectors do not fit the registers)
+      pick((const void *)bicgstab_latency_kernel<1, 0>, (const void *)bicgstab_latency_kernel<1, 4>,
+           (const void *)bicgstab_latency_kernel<1, 8>),
+      (const void *)bicgstab_latency_kernel<2, 0>, (const void *)bicgstab_latency_kernel<4, 0>, (const void *)bicgstab_latency_kernel<8, 0>};
+  const void *const *variants = bicgstab ? bi : cg;
   const int capacity[4] = {1, 2, 4, 8};
   const void *fn = nullptr;
   int64_t blocks = 0;
-  static int resident[2][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}};  // blocks per CU of each variant, asked once
+  static int resident[2][3][4];  // blocks per CU of each variant + 1, asked once (0: not yet)
   for (int v = 0; v < 4 && fn == nullptr; ++v) {
-    int &per_cu = resident[cached ? 1 : 0][v];
-    if (per_cu < 0) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, variants[v], kLatBlock, 0));
-    if (per_cu < 1) continue;
+    int &asked = resident[bicgstab ? 1 : 0][w == 0 ? 0 : w == 4 ? 1 : 2][v];
+    if (asked == 0) {
+      int per_cu = 0;
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, variants[v], kLatBlock, 0));
+      asked = per_cu + 1;
+    }
+    if (asked < 2) continue;
     blocks = std::max<int64_t>(1, std::min<int64_t>(std::min(c->num_cus, 256), (n_slices + kLatWaves - 1) / kLatWaves));
     const int64_t waves = blocks * kLatWaves;
     if ((n_slices + waves - 1) / waves <= capacity[v]) fn = variants[v];
@@ -495,10 +714,24 @@ int cg_latency_solve(const storm_hip_op *op, double alpha, double beta, const do
   STORM_REQUIRE(fn != nullptr, "latency path: %lld rows do not fit %d slices per wavefront", (long long)op->n_rows,
                 kLatSlices);
   HIP_TRY(hipMemsetAsync(c->d_lat_slots, 0, (size_t)2 * 256 * kLatSlotStride + 256, c->stream));  // tags restart at 1; flag down
-  LatArgs a{op->d_lat_pack, op->d_lat_off, op->n_rows, n_slices, alpha, beta, b, x, p, r, c->d_lat_slots, d_state};
+  a.pack = op->d_lat_pack, a.rec_off = op->d_lat_off, a.n_rows = op->n_rows, a.n_slices = n_slices, a.slots = c->d_lat_slots;
   void *args[] = {&a};
   HIP_TRY(hipLaunchCooperativeKernel(fn, dim3((unsigned)blocks), dim3(kLatBlock), args, 0, c->stream));
   return STORM_HIP_OK;
+}
+
+int cg_latency_solve(const storm_hip_op *op, double alpha, double beta, const double *b, double *x, double *p,
+                     double *r, SolverState *d_state) {
+  LatArgs a{};
+  a.alpha = alpha, a.beta = beta, a.b = b, a.x = x, a.p = p, a.r = r, a.st = d_state;
+  return latency_solve(false, op, a);
+}
+
+int bicgstab_latency_solve(const storm_hip_op *op, double alpha, double beta, const double *b, double *x,
+                           double *const work[4], SolverState *d_state) {
+  LatArgs a{};
+  a.alpha = alpha, a.beta = beta, a.b = b, a.x = x, a.p = work[0], a.r = work[1], a.v0 = work[2], a.v1 = work[3], a.st = d_state;
+  return latency_solve(true, op, a);
 }
 
 }  // namespace storm

@@ -857,6 +857,12 @@ int storm_hip_solve_bicgstab(const storm_hip_op *op, double alpha, double beta, 
   Driver d{c, op, alpha, beta, n, c->d_state, &c->d_state->done};
   STORM_TRY(prepare_state(d, params, history));
   VecPool pool;
+  if (cg_latency_eligible(op)) {  // a small operator: the whole solve as one cooperative kernel (latency.hip)
+    STORM_TRY(pool.make(x, 4));  // zero-filled: the kernel relies on that for the first direction
+    double *const work[4] = {pool.v[0]->d, pool.v[1]->d, pool.v[2]->d, pool.v[3]->d};
+    STORM_TRY(bicgstab_latency_solve(op, alpha, beta, b->d, x->d, work, c->d_state));
+    return collect(d, result, history, applies_bicg, 0);
+  }
   STORM_TRY(pool.make(x, 5));
   double *p = pool.v[0]->d, *r = pool.v[1]->d, *rt = pool.v[2]->d, *t = pool.v[3]->d, *v = pool.v[4]->d;
   const int nbv = vec_blocks(c, n);

@@ -1,6 +1,6 @@
-"""The latency path (csrc/latency.hip): CG for small operators as one cooperative persistent kernel -- vectors in
-registers, two all-reduce synchronisation points per iteration.  It must be indistinguishable from the throughput
-path (csrc/solvers.hip) except for rounding-level differences of the dot products: same convergence rule and
+"""The latency path (csrc/latency.hip): CG and BiCGStab for small operators as one cooperative persistent kernel --
+vectors in registers, two (CG) / three (BiCGStab) all-reduce synchronisation points per iteration.  It must be
+indistinguishable from the throughput path (csrc/solvers.hip) except for rounding-level differences of the dot products: same convergence rule and
 counters (Solver.hpp:116-147), same iteration counts (+-1), same solutions, against the oracle too; for every
 register variant (1 / 2 / 4 / 8 slices per wavefront, records cached in registers or re-read), ragged last slices,
 rows longer than the register cache, early exits and zero iterations."""
@@ -57,6 +57,84 @@ def test_box_matches_throughput_path_and_oracle(env, shape):
         ref = oracle.solve("cg", oracle.StencilOperator(g, -1.0, 0.0), b_host)
         assert abs(s_l.iteration - ref.iterations) <= max(2, int(0.02 * ref.iterations))
         assert np.linalg.norm(x_l - ref.x) <= 1e-8 * np.linalg.norm(ref.x)
+    mat.close()
+
+
+def _bicgstab(api, ctx, op, b_host, latency, cache=1, **knobs):
+    ctx.set_option("latency_path", int(latency))
+    ctx.set_option("latency_cache", cache)
+    s = api.BiCgStabSolver()
+    s.record_history = True
+    for k, v in knobs.items():
+        setattr(s, k, v)
+    b, x = api.DeviceVector.from_numpy(ctx, b_host), api.DeviceVector(ctx, b_host.size)
+    ok = s.solve(x, b, op)
+    ctx.set_option("latency_path", 1)
+    ctx.set_option("latency_cache", 1)
+    return ok, s, x.to_numpy()
+
+
+@pytest.mark.parametrize("shape", [(5, 3, 2), (9, 7, 1), (24, 24, 24), (64, 64, 64), (80, 80, 80), (100, 100, 100),
+                                   (128, 128, 100)])
+def test_bicgstab_box_matches_throughput_path_and_oracle(env, shape):
+    """SolverBiCgStab.hpp:60-167 as one cooperative kernel, on a NON-symmetric operator (convection-diffusion): the
+    neighbours' p and s are formed by the gathering wave from published rows; every register variant."""
+    api, mesh, oracle, ctx = env
+    g = mesh.structured_box(*shape)
+    wi, wo, de = mesh.convection_diffusion_weights(g, 1e-2, (1.0, 0.5, 0.25))
+    ctx.set_option("latency_rows", 1 << 21)
+    mat = api.StencilMatrix.from_face_weights(ctx, g.n_cells, g.n_halo, g.inner, g.outer, wi, wo, de)
+    ctx.set_option("latency_rows", 1 << 19)
+    op = api.HipStencilOperator(mat, 1.0, 0.0)
+    b_host = 1.0 + 0.25 * np.sin(0.01 * np.arange(g.n_cells))
+    ok_t, s_t, x_t = _bicgstab(api, ctx, op, b_host, False)
+    assert ok_t
+    for cache in (1, 0):
+        ok_l, s_l, x_l = _bicgstab(api, ctx, op, b_host, True, cache)
+        assert ok_l and s_l.num_applies == 2 * s_l.iteration + 1
+        assert abs(s_l.iteration - s_t.iteration) <= max(1, int(0.05 * s_t.iteration)), (s_l.iteration, s_t.iteration)
+        m = min(len(s_l.history), len(s_t.history), 6)
+        assert np.allclose(s_l.history[:m], s_t.history[:m], rtol=1e-8)
+        assert np.linalg.norm(x_l - x_t) <= 1e-6 * np.linalg.norm(x_t)
+    if g.n_cells <= 64 ** 3:
+        ref = oracle.solve("bicgstab", oracle.StencilOperator(g, -1e-2, 0.0, conv=1.0, vel=(1.0, 0.5, 0.25)), b_host)
+        assert abs(s_l.iteration - ref.iterations) <= max(2, int(0.05 * ref.iterations))
+        assert np.linalg.norm(x_l - ref.x) <= 1e-6 * np.linalg.norm(ref.x)
+    mat.close()
+
+
+def test_bicgstab_convergence_rule_edges_on_the_latency_path(env):
+    api, mesh, oracle, ctx = env
+    g = mesh.structured_box(10)
+    mat = api.StencilMatrix.from_face_graph(ctx, g)
+    op = api.HipStencilOperator(mat, -1.0, 0.0)
+    b_host = np.ones(g.n_cells)
+    ok, s, _ = _bicgstab(api, ctx, op, b_host, True, num_iterations=9, relative_error_tolerance=0.0,
+                         absolute_error_tolerance=0.0)
+    assert not ok and s.iteration == 9 and len(s.history) == 10
+    ok, s, x = _bicgstab(api, ctx, op, b_host, True, absolute_error_tolerance=1e9)
+    assert ok and s.iteration == 0 and not x.any()
+    ok, s, x = _bicgstab(api, ctx, op, b_host, True, num_iterations=0)
+    assert not ok and s.iteration == 0 and not x.any()
+    ok, s, x = _bicgstab(api, ctx, op, np.zeros(g.n_cells), True)
+    assert np.all(np.isfinite(x)) and not x.any()
+    # a one-row operator and rows longer than the register cache
+    rng = np.random.default_rng(11)
+    for n, per_row in ((1, 0), (65, 3), (4099, 20)):
+        if per_row:
+            rows = np.repeat(np.arange(n), per_row)
+            a = sp.coo_matrix((rng.random(rows.size) * 0.1, (rows, rng.integers(0, n, rows.size))), shape=(n, n)).tocsr()
+            a.setdiag(0.0)
+            a.eliminate_zeros()
+            a = (sp.diags(np.asarray(abs(a).sum(axis=1)).ravel() + 1.0) - a).tocsr()  # non-symmetric, dominant
+        else:
+            a = sp.csr_matrix(np.array([[2.0]]))
+        m2 = api.StencilMatrix.from_csr(ctx, a)
+        bh = rng.random(n) + 0.5
+        ok, s, x = _bicgstab(api, ctx, api.HipStencilOperator(m2, 1.0, 0.0), bh, True, relative_error_tolerance=1e-10,
+                             absolute_error_tolerance=0.0)
+        assert ok and np.linalg.norm(a @ x - bh) <= 1e-8 * np.linalg.norm(bh)
+        m2.close()
     mat.close()
 
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""CG microseconds per iteration, latency path (csrc/latency.hip) against throughput path (csrc/solvers.hip), over
+"""CG and BiCGStab microseconds per iteration, latency path (csrc/latency.hip) against throughput path (csrc/solvers.hip), over
 problem sizes -- where does the cooperative persistent kernel stop paying?  One JSON line per size."""
 import json
 import os
@@ -14,11 +14,11 @@ from stormruler_amd import api, io_triangle, mesh  # noqa: E402
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def rate(ctx, op, b, n, latency, iters=400):
+def rate(ctx, op, b, n, latency, iters=400, cls=None):
     ctx.set_option("latency_path", int(latency))
     best = None
     for _ in range(3):
-        s = api.CgSolver()
+        s = (cls or api.CgSolver)()
         s.num_iterations, s.absolute_error_tolerance, s.relative_error_tolerance = iters, 0.0, 0.0
         x = api.DeviceVector(ctx, n)
         ctx.sync()
@@ -47,10 +47,15 @@ def main():
         op = api.HipStencilOperator(mat, alpha, beta)
         b = api.DeviceVector(ctx, g.n_cells)
         api.fill_with(b, 1.0)
-        lat, thr = rate(ctx, op, b, g.n_cells, True), rate(ctx, op, b, g.n_cells, False)
-        print(json.dumps({"mesh": kind if shape is None else "x".join(map(str, shape)), "rows": g.n_cells,
-                          "latency_path_us_per_iteration": lat, "throughput_path_us_per_iteration": thr,
-                          "ratio": thr / lat}), flush=True)
+        for name, cls in (("cg", api.CgSolver), ("bicgstab", api.BiCgStabSolver)):
+            lat, thr = rate(ctx, op, b, g.n_cells, True, cls=cls), rate(ctx, op, b, g.n_cells, False, cls=cls)
+            line = {"solver": name, "mesh": kind if shape is None else "x".join(map(str, shape)), "rows": g.n_cells,
+                    "latency_path_us_per_iteration": lat, "throughput_path_us_per_iteration": thr, "ratio": thr / lat}
+            if name == "bicgstab":
+                ctx.set_option("latency_cache", 0)
+                line["latency_path_records_not_cached_us"] = rate(ctx, op, b, g.n_cells, True, cls=cls)
+                ctx.set_option("latency_cache", 1)
+            print(json.dumps(line), flush=True)
         mat.close()
 
 

@@ -1,6 +1,6 @@
 """Soak test (not in the suite): thousands of back-to-back solves must all converge with ONE iteration count per
 (solver, path) -- the reductions are run-to-run reproducible -- and leave no memory behind:
-  * 64^3: CG on the latency path (one cooperative persistent kernel per solve: 1 500 launches of a grid that
+  * 64^3: CG and BiCGStab on the latency path (one cooperative persistent kernel per solve: 1 500 launches each of a grid that
     synchronises through memory -- a lost wake-up would hang here), CG / BiCGStab / GMRES on the throughput path,
     CG with a lambda operator and IDR(4) on the engine;
   * the reference's Triangle mesh step.1 on the latency path;
@@ -26,7 +26,8 @@ b = api.DeviceVector.from_numpy(ctx, np.ones(g.n_cells))
 its = set()
 t = time.time()
 free0 = torch.cuda.mem_get_info()[0]
-cases = [("cg/latency", api.CgSolver, op, 1), ("cg/throughput", api.CgSolver, op, 0), ("bicgstab", api.BiCgStabSolver, op, 0),
+cases = [("cg/latency", api.CgSolver, op, 1), ("cg/throughput", api.CgSolver, op, 0),
+         ("bicgstab/latency", api.BiCgStabSolver, op, 1), ("bicgstab/throughput", api.BiCgStabSolver, op, 0),
          ("gmres", api.GmresSolver, op, 0), ("cg/engine-lambda", api.CgSolver, lam, 0), ("idrs/engine", api.IdrsSolver, op, 0)]
 n_rounds = 1500
 for k in range(n_rounds):
