@@ -77,6 +77,7 @@ struct SellArgs {
   int offs_size;
   int accumulate;                         // y += alpha*M(x) (stormDivGrad's own form) instead of y = beta*x + alpha*M(x)
   int nt_y = 1;                           // y stored non-temporally (0: it may stay in the Infinity Cache for the consumer)
+  int rec_by_pos = 0;                     // paired records stored in slice-LIST order (the boundary groups of a mixed operator)
 };
 
 constexpr int kDictSize = 256;
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(SellArgs A, Scal alph
   const uint32_t r0 = slice * (2 * kWave) + 2 * lane;  // row A; row B = r0 + 1
   const bool valid_a = active && r0 <= last_row, valid_b = active && r0 + 1 <= last_row;
   const uint32_t rc = r0 <= last_row ? r0 : (last_row & ~1u);  // pairs past the end re-read the last pair
-  const char *rec = A.pack + (size_t)slice * kPairRecBytes;
+  const char *rec = A.pack + (size_t)(A.rec_by_pos ? (uint32_t)(active ? sl : 0) : slice) * kPairRecBytes;
   typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
   const u64x2 vw = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(rec) + lane);
   const uint64_t jw = __builtin_nontemporal_load(reinterpret_cast<const uint64_t *>(rec + 2 * kWave * 8) + lane);
@@ -748,12 +749,19 @@ template <bool DOT>
 static void launch_pair(const storm_hip_op *op, int nb, Scal alpha, Scal beta, const double *x, double *y,
                         const int *slice_list, int64_t n_launch, DotArgs dot, const int *done, hipEvent_t ev0,
                         hipEvent_t ev1, bool accumulate) {
-  const int group = slice_list ? 0 : (int)op->ctx->opt_spmv_xcd_remap;
+  // the interior list of a partitioned operator is consecutive but for a few gaps: the XCD grouping still pays there
+  const int group = (slice_list == nullptr || slice_list == op->d_interior) ? (int)op->ctx->opt_spmv_xcd_remap : 0;
   SellArgs A{op->d_pack, op->d_slice_off, op->n_rows, op->uniform_width, group, op->d_dict, op->dict_size,
              op->d_offs, op->offs_size, (int)accumulate};
   A.nt_y = (int)(op->ctx->opt_spmv_nt_y != 0);
   hipStream_t st = op->ctx->stream;
-  if (op->pair == 2) {  // format 4: the common offsets travel as kernel arguments
+  int width = op->uniform_width;
+  const bool boundary_of_mixed = op->d_bnd_pack != nullptr && slice_list != nullptr && slice_list == op->d_boundary;
+  if (boundary_of_mixed) {  // the groups that read halo columns: format-3 records of their own, in list order
+    A.pack = op->d_bnd_pack, A.rec_by_pos = 1;
+    width = op->bnd_width;
+  }
+  if (op->pair == 2 && !boundary_of_mixed) {  // format 4: the common offsets travel as kernel arguments
     CanonArgs C;
     for (int k = 0; k < 7; ++k) C.off[k] = op->canon_off[k];
     C.max_gather = (int)(op->n_rows + op->n_halo) + kVecGuard + 2;
@@ -769,7 +777,7 @@ static void launch_pair(const storm_hip_op *op, int nb, Scal alpha, Scal beta, c
 #define PAIR_GO(W_)                                                                                              \
   hipExtLaunchKernelGGL((spmv_pair_kernel<DOT, W_>), dim3(nb), dim3(kBlock), 0, st, ev0, ev1, 0, A, alpha, beta, \
                         x, y, slice_list, n_launch, dot, done)
-  switch (op->uniform_width) {
+  switch (width) {
     case 1: PAIR_GO(1); break;
     case 2: PAIR_GO(2); break;
     case 3: PAIR_GO(3); break;
@@ -879,7 +887,9 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
   const bool fuse_dot = sd != nullptr && op->tail_rows == 0;
   STORM_REQUIRE(op->halo.n_nbrs == 0 || c->comm != nullptr,
                 "operator has a halo plan but the context has no communicator (call storm_hip_ctx_comm_init)");
-  const bool split = op->halo.n_nbrs > 0;
+  // (a mixed operator -- format 4 inside, format 3 where rows read halo columns -- always runs as its two lists)
+  const bool exchange = op->halo.n_nbrs > 0;
+  const bool split = exchange || op->d_bnd_pack != nullptr;
   DotArgs dot{nullptr, nullptr, 0, 0, 0};
   const int nb_int = split ? blocks_for(op, op->n_interior) : spmv_grid_blocks(op);
   const int nb_bnd = split ? blocks_for(op, op->n_boundary) : 0;
@@ -895,9 +905,9 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
     STORM_TRY(launch_range(op, alpha, beta, x, y, nullptr, op->n_slices, dot, fuse_dot, done, accumulate));
   } else {
     // interior rows overlap the halo exchange running on the comm stream
-    STORM_TRY(comm_halo_exchange_begin(op, const_cast<double *>(x)));
+    if (exchange) STORM_TRY(comm_halo_exchange_begin(op, const_cast<double *>(x)));
     STORM_TRY(launch_range(op, alpha, beta, x, y, op->d_interior, op->n_interior, dot, fuse_dot, done, accumulate));
-    STORM_TRY(comm_halo_exchange_end(op));
+    if (exchange) STORM_TRY(comm_halo_exchange_end(op));
     dot.block_offset = 4 * nb_int;
     STORM_TRY(launch_range(op, alpha, beta, x, y, op->d_boundary, op->n_boundary, dot, fuse_dot, done, accumulate));
   }
@@ -1117,16 +1127,34 @@ static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vect
     }
     pr = pr && pair_width > 0;
   }
-  // ... and whether all rows list their neighbours in one common order of offsets (format 4, see spmv_canon_kernel)
+  // groups with a row that reads a halo column (they run behind the halo exchange)
+  std::vector<char> grp_bnd;
+  int64_t n_bnd_groups = 0;
+  if (pr) {
+    grp_bnd.assign((size_t)n_groups, 0);
+    for (int64_t g = 0; n_halo > 0 && g < n_groups; ++g) {
+      const int64_t r1 = std::min<int64_t>(n, (g + 1) * 2 * kWave);
+      for (int64_t k = row_ptr[g * 2 * kWave]; k < row_ptr[r1] && !grp_bnd[(size_t)g]; ++k) grp_bnd[(size_t)g] = col[(size_t)k] >= n;
+      n_bnd_groups += grp_bnd[(size_t)g];
+    }
+  }
+  // ... and whether all rows list their neighbours in one common order of offsets (format 4, see spmv_canon_kernel).
+  // A partitioned operator is MIXED: the common order is asked of the groups that read no halo column (a rank's
+  // slab of a structured box but for its outer planes), the others keep their format-3 records.
   int64_t canon[16];
   int canon_len = 0, canon_m1 = -1;
-  bool cn = pr && c->opt_spmv_dict >= 4 && n_halo == 0;
+  bool cn = pr && c->opt_spmv_dict >= 4 && 2 * n_bnd_groups <= n_groups && (n_bnd_groups == 0 || c->opt_spmv_mixed != 0);
+  std::vector<char> bnd_pack;
   if (cn) {
     // the distinct offsets and who precedes whom in some row; a common order = a linear extension of that relation
     int64_t dist[8];
     int nd = 0;
     bool before[8][8] = {};
     for (int64_t r = 0; cn && r < n; ++r) {
+      if (grp_bnd[(size_t)(r / (2 * kWave))]) {
+        r = (r / (2 * kWave) + 1) * (2 * kWave) - 1;
+        continue;
+      }
       int idx[8], no = 0;
       for (int64_t k = row_ptr[r]; cn && k < row_ptr[r + 1]; ++k) {
         const int64_t o = (int64_t)col[(size_t)k] - r;
@@ -1163,6 +1191,9 @@ static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vect
     for (int q = 0; cn && q < canon_len; ++q) cn = canon[q] > -(int64_t)INT32_MAX / 2 && canon[q] < (int64_t)INT32_MAX / 2;
   }
   if (cn) {
+    for (int64_t g = 0; g < n_groups; ++g)  // the format-3 records of the boundary groups, in list order
+      if (grp_bnd[(size_t)g])
+        bnd_pack.insert(bnd_pack.end(), pair_pack.begin() + (size_t)g * kPairRecBytes, pair_pack.begin() + (size_t)(g + 1) * kPairRecBytes);
     pair_pack.assign((size_t)n_groups * kCanonRecBytes, 0);
     const uint64_t zero_v = (uint64_t)vd.index(0.0) << 3;
     for (int64_t p = 0; 2 * p < n_groups * 2 * kWave; ++p) {
@@ -1173,8 +1204,10 @@ static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vect
         for (int k = 0; k < 7; ++k) w |= zero_v << (8 * (k + 1));
         if (r < n) {
           int q = 0;
-          for (int64_t k = row_ptr[r]; k < row_ptr[r + 1]; ++k) {
-            while (canon[q] != (int64_t)col[(size_t)k] - r) ++q;  // a subsequence of the common order
+          const bool by_entry = grp_bnd[(size_t)(r / (2 * kWave))] != 0;  // never applied from here: the weights
+          for (int64_t k = row_ptr[r]; k < row_ptr[r + 1]; ++k) {         // only serve diag_sell_kernel
+            if (by_entry) q = (int)(k - row_ptr[r]);
+            else while (canon[q] != (int64_t)col[(size_t)k] - r) ++q;  // a subsequence of the common order
             w &= ~(0xffull << (8 * (q + 1)));
             w |= ((uint64_t)vd.index(val[(size_t)k]) << 3) << (8 * (q + 1));
           }
@@ -1190,19 +1223,14 @@ static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vect
   if (pr) {
     // format 3 (or 4) it is: a "slice" of this operator is a 128-row group
     op->pair = cn ? 2 : 1;
+    op->bnd_width = pair_width;
     if (cn) pair_width = canon_len;
     op->n_slices = n_groups;
     op->uniform_width = pair_width;
     op->ell_slots = n_groups * 2 * kWave * pair_width;
     std::vector<int64_t> goff((size_t)n_groups + 1);
     for (int64_t s = 0; s <= n_groups; ++s) goff[(size_t)s] = s * (cn ? kCanonRecBytes : kPairRecBytes);
-    for (int64_t s = 0; s < n_groups; ++s) {
-      bool touches_halo = false;
-      const int64_t r1 = std::min<int64_t>(n, (s + 1) * 2 * kWave);
-      for (int64_t r = s * 2 * kWave; r < r1 && !touches_halo; ++r)
-        for (int64_t k = row_ptr[r]; k < row_ptr[r + 1]; ++k) touches_halo |= col[(size_t)k] >= n;
-      (touches_halo ? op->h_boundary : op->h_interior).push_back((int)s);
-    }
+    for (int64_t s = 0; s < n_groups; ++s) (grp_bnd[(size_t)s] ? op->h_boundary : op->h_interior).push_back((int)s);
     op->n_interior_slices = (int64_t)op->h_interior.size();
     int st3 = STORM_HIP_OK;
     int64_t bytes3 = 0;
@@ -1212,7 +1240,7 @@ static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vect
     for (size_t k = 0; k < od.values.size(); ++k) otab[k] = (int)(int64_t)od.values[k];
     op->dict_size = (int)vd.values.size();
     op->offs_size = (int)od.values.size();
-    op->pack_bytes = (int64_t)pair_pack.size();
+    op->pack_bytes = (int64_t)pair_pack.size() + (int64_t)bnd_pack.size();
     op->spw = 1;
     std::vector<int> no_i;
     std::vector<int64_t> one_zero(1, 0);
@@ -1224,7 +1252,11 @@ static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vect
       storm_hip_op_destroy(op);
       return st3;
     }
-    op->device_bytes = bytes3;
+    if (!bnd_pack.empty() && ((st3 = upload(&op->d_bnd_pack, bnd_pack, &bytes3)) || (st3 = op_upload_slice_lists(op)))) {
+      storm_hip_op_destroy(op);
+      return st3;
+    }
+    op->device_bytes += bytes3;
     const int64_t need3 = 8 * ((n_slices + 3) / 4) + 16 + 2 * kMaxMulti;
     if (need3 > c->partials_capacity) {
       HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1545,6 +1577,7 @@ int storm_hip_op_destroy(storm_hip_op *op) {
   (void)hipFree(op->d_boundary);
   (void)hipFree(op->d_slice_off);
   (void)hipFree(op->d_pack);
+  (void)hipFree(op->d_bnd_pack);
   (void)hipFree(op->d_dict);
   (void)hipFree(op->d_offs);
   (void)hipFree(op->d_tail_row);

@@ -226,6 +226,66 @@ def test_partitioned_operator_with_every_format(env, fmt):
     mat.close()
 
 
+@pytest.mark.parametrize("shape,expect_mixed", [((20, 12, 9), True), ((32, 16, 40), True), ((64, 64, 6), True),
+                                                ((64, 64, 3), False), ((33, 7, 12), True)])
+def test_mixed_records_of_a_partitioned_box(env, shape, expect_mixed):
+    """A rank's slab: the groups of rows that read no halo column share one offset order (format 4), the outer
+    planes keep format-3 records of their own (in boundary-list order).  Bitwise the same y as the all-format-3
+    operator, the oracle's values, the same diagonal; with and without fused dots; `apply_add`."""
+    from test_gpu_comm import _periodic_z_local_graph
+
+    api, mesh, oracle, ctx = env
+    loc, send_idx = _periodic_z_local_graph(*shape)
+    mixed = api.StencilMatrix.from_face_graph(ctx, loc)
+    ctx.set_option("spmv_mixed", 0)
+    plain = api.StencilMatrix.from_face_graph(ctx, loc)
+    ctx.set_option("spmv_mixed", 1)
+    sm, sp_ = mixed.stats(), plain.stats()
+    assert sp_["paired_rows"] in (0, 1)
+    if sp_["paired_rows"] == 0:  # an odd nx whose merged neighbour lists do not fit: nothing to mix
+        assert sm["paired_rows"] == 0
+        return
+    assert sm["paired_rows"] == (2 if expect_mixed else 1)
+    assert 0 < sm["n_interior_slices"] < sm["n_slices"]
+    if expect_mixed:
+        n_bnd = sm["n_slices"] - sm["n_interior_slices"]
+        assert sm["record_bytes"] == 1024 * sm["n_slices"] + 1536 * n_bnd
+    x = np.sin(0.37 * np.arange(loc.n_cells)) + 1e-3 * np.arange(loc.n_cells)
+    ys = []
+    for mat in (mixed, plain):
+        mat.set_halo([0], [0, loc.n_halo], send_idx, [0, loc.n_halo])
+        ys.append(_apply(api, ctx, mat, x, n_halo=loc.n_halo, alpha=-1.0, beta=0.05))
+    assert np.array_equal(ys[0], ys[1])
+    xf = np.concatenate([x, x[send_idx]])
+    y_ref = oracle.StencilOperator(loc, -1.0, 0.05).apply(xf)[: loc.n_cells]
+    assert np.abs(ys[0] - y_ref).max() <= 1e-13 * np.abs(y_ref).max()
+    ds = []
+    for mat in (mixed, plain):
+        d = api.DeviceVector(ctx, loc.n_cells, loc.n_halo)
+        mat.diagonal(-1.0, 0.05, d)
+        ds.append(d.to_numpy())
+    assert np.array_equal(ds[0], ds[1]) and np.all(ds[0] > 0)
+    # the fused-dot path (CG) and the accumulate form
+    its = []
+    for mat in (mixed, plain):
+        b = api.DeviceVector(ctx, loc.n_cells, loc.n_halo)
+        api.fill_with(b, 1.0)
+        xs = api.DeviceVector(ctx, loc.n_cells, loc.n_halo)
+        s = api.CgSolver()
+        assert s.solve(xs, b, api.HipStencilOperator(mat, -1.0, 0.05))
+        its.append((s.iteration, xs.to_numpy()))
+    assert its[0][0] == its[1][0] and np.array_equal(its[0][1], its[1][1])
+    us = []
+    for mat in (mixed, plain):
+        cv = api.DeviceVector.from_numpy(ctx, x, n_halo=loc.n_halo)
+        uv = api.DeviceVector.from_numpy(ctx, np.cos(0.11 * np.arange(loc.n_cells)), n_halo=loc.n_halo)
+        api.stormDivGrad(mat, uv, -1.0e-3, cv)
+        us.append(uv.to_numpy())
+    assert np.array_equal(us[0], us[1])
+    mixed.close()
+    plain.close()
+
+
 @pytest.mark.parametrize("fmt", [(0, 1), (1, 2), (2, 2), (3, 0)])
 @pytest.mark.parametrize("mesh_kind", ["box", "triangle", "periodic"])
 def test_stormDivGrad_accumulate_form(env, fmt, mesh_kind):

@@ -41,28 +41,34 @@ def rate(ctx, mat, g):
 out = {"n": n}
 ctx = api.Context(0)
 g0 = mesh.structured_box(n)
-for fmt in (() if only else (4, 3)):  # the halo operator below cannot take format 4 (two extra offsets): compare like with like
+for fmt in (() if only else (4, 3)):
     ctx.set_option("spmv_dict", fmt)
     m0 = api.StencilMatrix.from_face_graph(ctx, g0)
     out[f"plain_fmt{fmt}_it_per_s"] = rate(ctx, m0, g0)
     m0.close()
 ctx.close()
 loc, send_idx = _periodic_z_local_graph(n, n, n)
+# the halo operator: MIXED records by default (format 4 where rows read no halo column, format 3 in the outer
+# planes) -- compared with the plain format-4 operator; spmv_mixed = 0 (format 3 throughout) with plain format 3
 for transport in ((only,) if only else ("rccl", "ipc", "ipc1")):
-    ctx = api.Context(0)
-    if transport == "ipc1":  # peer windows, halo kernels on the compute stream (no cross-stream events)
-        ctx.set_option("ipc_streams", 1)
-    if transport == "rccl":
-        ctx.comm_init(api.Context.comm_unique_id(), 1, 0)
-    else:  # peer windows: the single rank maps its own window
-        ctx.comm_init_ipc(ctx.comm_ipc_export(1, 0))
-    m1 = api.StencilMatrix.from_face_graph(ctx, loc)
-    m1.set_halo([0], [0, loc.n_halo], send_idx, [0, loc.n_halo])
-    st = m1.stats()
-    out[f"{transport}_it_per_s"] = rate(ctx, m1, loc)
-    out["interior_groups"], out["groups"], out["paired_rows"] = st["n_interior_slices"], st["n_slices"], st["paired_rows"]
-    if not only:
-        out[f"{transport}_overhead_us_per_iteration"] = (1.0 / out[f"{transport}_it_per_s"] - 1.0 / out["plain_fmt3_it_per_s"]) * 1e6
-    m1.close()
-    ctx.close()
+    for mixed in ((1,) if only else (1, 0)):
+        ctx = api.Context(0)
+        ctx.set_option("spmv_mixed", mixed)
+        if transport == "ipc1":  # peer windows, halo kernels on the compute stream (no cross-stream events)
+            ctx.set_option("ipc_streams", 1)
+        if transport == "rccl":
+            ctx.comm_init(api.Context.comm_unique_id(), 1, 0)
+        else:  # peer windows: the single rank maps its own window
+            ctx.comm_init_ipc(ctx.comm_ipc_export(1, 0))
+        m1 = api.StencilMatrix.from_face_graph(ctx, loc)
+        m1.set_halo([0], [0, loc.n_halo], send_idx, [0, loc.n_halo])
+        st = m1.stats()
+        key = f"{transport}_{'mixed' if mixed else 'fmt3'}"
+        out[f"{key}_it_per_s"] = rate(ctx, m1, loc)
+        out["interior_groups"], out["groups"], out[f"{key}_paired_rows"] = st["n_interior_slices"], st["n_slices"], st["paired_rows"]
+        if not only:
+            base = out["plain_fmt4_it_per_s" if mixed else "plain_fmt3_it_per_s"]
+            out[f"{key}_overhead_us_per_iteration"] = (1.0 / out[f"{key}_it_per_s"] - 1.0 / base) * 1e6
+        m1.close()
+        ctx.close()
 print(json.dumps(out))
