@@ -8,13 +8,12 @@
 // pass over the per-block partials (two passes when there are more than 4096 of them).  The
 // summation tree depends only on n, so results are bitwise reproducible run to run.
 #include "common.hpp"
+#include "blas1_device.hpp"
 
 namespace storm {
 
-typedef double double2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ double ld_scal(const Scal &s) { return s.p ? (*s.p) * s.sign : s.v; }
-__device__ __forceinline__ double2v ld2(const double2v *p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
 __device__ __forceinline__ void st2(double2v *p, double2v v, bool nt) {
   if (nt) __builtin_nontemporal_store(v, p);
   else *p = v;
@@ -189,11 +188,6 @@ __device__ __forceinline__ double block_sum(double v, double *lds4) {
   return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
 }
 
-constexpr int kDotChunk = 8;
-struct DotPtrs {
-  const double *b[kDotChunk];
-};
-
 template <int KB>
 __global__ __launch_bounds__(kBlock) void multi_dot_kernel(int64_t n, const double *__restrict__ a,
                                                            DotPtrs bs, double *__restrict__ partials,
@@ -203,40 +197,7 @@ __global__ __launch_bounds__(kBlock) void multi_dot_kernel(int64_t n, const doub
   double acc[KB];
 #pragma unroll
   for (int j = 0; j < KB; ++j) acc[j] = 0.0;
-  const int64_t n2 = n >> 1;
-  const double2v *__restrict__ a2 = reinterpret_cast<const double2v *>(a);
-  constexpr int U = KB <= 2 ? kUnroll : (KB <= 4 ? 2 : 1);  // many streams: few accesses per stream in flight (tools/cg_kernels_bench.hip)
-  for (int64_t base = (int64_t)blockIdx.x * (kBlock * kUnroll) + threadIdx.x; base < n2;
-       base += (int64_t)gridDim.x * (kBlock * kUnroll)) {
-#pragma unroll
-    for (int u0 = 0; u0 < kUnroll; u0 += U) {
-      double2v va[U], vb[U][KB];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int64_t i = base + (u0 + u) * kBlock;
-        if (i < n2) {
-          va[u] = ld2(a2 + i, nt);
-#pragma unroll
-          for (int j = 0; j < KB; ++j) vb[u][j] = ld2(reinterpret_cast<const double2v *>(bs.b[j]) + i, nt);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int64_t i = base + (u0 + u) * kBlock;
-        if (i < n2) {
-#pragma unroll
-          for (int j = 0; j < KB; ++j) {
-            acc[j] += va[u].x * vb[u][j].x;
-            acc[j] += va[u].y * vb[u][j].y;
-          }
-        }
-      }
-    }
-  }
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-#pragma unroll
-    for (int j = 0; j < KB; ++j) acc[j] += a[n - 1] * bs.b[j][n - 1];
-  }
+  multi_dot_accumulate<KB>(n, a, bs, nt, acc);
 #pragma unroll
   for (int j = 0; j < KB; ++j) {
     const double s = block_sum(acc[j], lds4);

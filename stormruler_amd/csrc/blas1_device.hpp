@@ -1,0 +1,56 @@
+// Shared by blas1.hip and krylov.hip: the accumulation loop of the multi-dot kernels (ONE definition, so that the
+// partial sums -- and with them every reduction's bits -- do not depend on which kernel ran the loop).
+#pragma once
+#include "common.hpp"
+
+namespace storm {
+
+typedef double double2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2v ld2(const double2v *p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
+
+constexpr int kDotChunk = 8;
+struct DotPtrs {
+  const double *b[kDotChunk];
+};
+
+// acc[j] += this thread's share of <a, bs.b[j]>, j < KB.
+template <int KB>
+__device__ __forceinline__ void multi_dot_accumulate(int64_t n, const double *__restrict__ a, const DotPtrs &bs, int nt,
+                                                     double (&acc)[KB]) {
+  const int64_t n2 = n >> 1;
+  const double2v *__restrict__ a2 = reinterpret_cast<const double2v *>(a);
+  constexpr int U = KB <= 2 ? kUnroll : (KB <= 4 ? 2 : 1);  // many streams: few accesses per stream in flight (tools/cg_kernels_bench.hip)
+  for (int64_t base = (int64_t)blockIdx.x * (kBlock * kUnroll) + threadIdx.x; base < n2;
+       base += (int64_t)gridDim.x * (kBlock * kUnroll)) {
+#pragma unroll
+    for (int u0 = 0; u0 < kUnroll; u0 += U) {
+      double2v va[U], vb[U][KB];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = base + (u0 + u) * kBlock;
+        if (i < n2) {
+          va[u] = ld2(a2 + i, nt);
+#pragma unroll
+          for (int j = 0; j < KB; ++j) vb[u][j] = ld2(reinterpret_cast<const double2v *>(bs.b[j]) + i, nt);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = base + (u0 + u) * kBlock;
+        if (i < n2) {
+#pragma unroll
+          for (int j = 0; j < KB; ++j) {
+            acc[j] += va[u].x * vb[u][j].x;
+            acc[j] += va[u].y * vb[u][j].y;
+          }
+        }
+      }
+    }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < KB; ++j) acc[j] += a[n - 1] * bs.b[j][n - 1];
+  }
+}
+
+}  // namespace storm

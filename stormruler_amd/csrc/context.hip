@@ -60,6 +60,8 @@ int storm_hip_ctx_create(int device_id, storm_hip_ctx **out) {
   HIP_TRY(hipHostMalloc((void **)&c->h_scalars, sizeof(double) * kMaxMulti, hipHostMallocDefault));
   HIP_TRY(hipMalloc((void **)&c->d_lat_slots, 2 * 256 * 256 + 256));  // latency.hip: all-reduce slots (two per block) + the gave-up flag
   HIP_TRY(hipMemset(c->d_lat_slots, 0, 2 * 256 * 256 + 256));
+  HIP_TRY(hipMalloc((void **)&c->d_fin_counter, 256));  // krylov.hip: ticket counter of the one-launch reductions
+  HIP_TRY(hipMemset(c->d_fin_counter, 0, 256));
   HIP_TRY(hipMalloc((void **)&c->d_state, sizeof(SolverState)));
   HIP_TRY(hipMemset(c->d_state, 0, sizeof(SolverState)));
   HIP_TRY(hipHostMalloc((void **)&c->h_state, sizeof(SolverState), hipHostMallocDefault));
@@ -83,6 +85,7 @@ int storm_hip_ctx_destroy(storm_hip_ctx *c) {
   (void)hipFree(c->d_partials2);
   (void)hipFree(c->d_scalars);
   (void)hipFree(c->d_lat_slots);
+  (void)hipFree(c->d_fin_counter);
   (void)hipHostFree(c->h_scalars);
   (void)hipFree(c->d_state);
   (void)hipHostFree(c->h_state);
@@ -126,6 +129,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "coop_mgs")) c->opt_coop_mgs = value;
   else if (!strcmp(key, "coop_mgs_min_rows")) c->opt_coop_mgs_min_rows = value;
   else if (!strcmp(key, "spmv_mixed")) c->opt_spmv_mixed = value;
+  else if (!strcmp(key, "fused_reduce")) c->opt_fused_reduce = (int)value;
   else if (!strcmp(key, "latency_rows")) c->opt_latency_rows = value;
   else if (!strcmp(key, "latency_cache")) c->opt_latency_cache = (int)value;
   else if (!strcmp(key, "nontemporal")) c->opt_nt = value;

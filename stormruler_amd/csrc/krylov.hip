@@ -30,6 +30,7 @@
 #include "common.hpp"
 #include "solver_device.hpp"
 #include "ipc_device.hpp"
+#include "blas1_device.hpp"
 
 namespace storm {
 namespace kry {
@@ -182,6 +183,69 @@ __global__ void sprog_kernel(double *S, SolverState *st, SProg prog, int nscatte
   exec_prog(prog, S, st);
 }
 
+// ---- reductions in ONE launch (small operators) ---------------------------------------------------------------
+// A reduction is "partials kernel, then a one-block final pass that also runs the scalar program": two launches, and
+// on the reference's own mesh sizes an iteration is nothing but launches (~4 us each, dependent).  When the partials
+// kernel has few blocks the LAST block to finish does the final pass itself: every block publishes its partial sums
+// with coherent (write-through) stores, waits for their acknowledgement, and takes a ticket from a counter; the block
+// that draws the last ticket reads all partials back with coherent loads, folds them in the order of
+// reduce_prog_kernel (thread t takes blocks t, t + 256, ...; block_sum256) -- the same bits whichever path ran --
+// writes the registers, runs the scalar program and re-arms the counter.  No cache-wide fence anywhere (an
+// agent-scope release would write back the whole L2, see latency.hip).
+struct FinalPass {
+  int *counter;  // zero between launches
+  int k;
+  RedOut out;
+  double *S;
+  SolverState *st;
+  SProg prog;
+};
+constexpr int kFinalPassMaxBlocks = 256;
+
+// `mine[j]` (valid in thread 0): this block's partial of sum j.  Returns after the final pass in the last block.
+template <int KMAX>
+__device__ __forceinline__ void publish_and_finish(double *partials, const double (&mine)[KMAX], const FinalPass &f) {
+  __shared__ int is_last;
+  __shared__ double lds4f[4];
+  const int nb = (int)gridDim.x;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j)
+      if (j < f.k) __hip_atomic_store(partials + (int64_t)j * nb + blockIdx.x, mine[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the stores above are acknowledged (no cache write-back)
+    const int ticket = __hip_atomic_fetch_add(f.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = ticket == nb - 1;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  for (int j = 0; j < f.k; ++j) {
+    const double *p = partials + (int64_t)j * nb;
+    double v = 0.0;
+    for (int i = threadIdx.x; i < nb; i += kBlock) v += __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double sum = block_sum256(v, lds4f);
+    if (threadIdx.x == 0) f.S[f.out.idx[j]] = sum;
+  }
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(f.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (f.prog.n > 0) exec_prog(f.prog, f.S, f.st);
+  }
+}
+
+template <int KB>
+__global__ __launch_bounds__(kBlock) void dots_prog_kernel(int64_t n, const double *__restrict__ a, DotPtrs bs,
+                                                           double *partials, const int *done, int nt, FinalPass f) {
+  if (done && *done) return;
+  __shared__ double lds4[4];
+  double acc[KB];
+#pragma unroll
+  for (int j = 0; j < KB; ++j) acc[j] = 0.0;
+  multi_dot_accumulate<KB>(n, a, bs, nt, acc);
+  double mine[KB];
+#pragma unroll
+  for (int j = 0; j < KB; ++j) mine[j] = block_sum256(acc[j], lds4);
+  publish_and_finish<KB>(partials, mine, f);
+}
+
 // ---- vector statements ------------------------------------------------------------------------------------
 typedef double double2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double2v ldv(const double2v *p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
@@ -258,10 +322,8 @@ __global__ __launch_bounds__(kBlock) void lin_kernel(int64_t n, LinArgs a, const
 // The same statement with reductions of its RESULT folded in: per-block partials of <y, y> (dot_yy) and / or
 // <y, w> into partials[j * gridDim.x + block] -- "r -= alpha z; gamma = <r, r>" is one pass over r, not two.
 template <int NT>
-__global__ __launch_bounds__(kBlock) void lin_dot_kernel(int64_t n, LinArgs a, const double *w, int dot_yy,
-                                                         double *__restrict__ partials, const int *done, int nt) {
-  if (done && *done) return;
-  __shared__ double lds4[4];
+__device__ __forceinline__ void lin_dot_body(int64_t n, const LinArgs &a, const double *w, int nt, double &acc_yy,
+                                             double &acc_yw) {
   double c[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) c[t] = ld_coef(a.c[t]);
@@ -269,7 +331,6 @@ __global__ __launch_bounds__(kBlock) void lin_dot_kernel(int64_t n, LinArgs a, c
   double2v *y2 = reinterpret_cast<double2v *>(a.y);
   const double2v *w2 = reinterpret_cast<const double2v *>(w);
   constexpr int U = lin_unroll(NT + 1);
-  double acc_yy = 0.0, acc_yw = 0.0;
   for (int64_t base = (int64_t)blockIdx.x * (kBlock * U) + threadIdx.x; base < n2;
        base += (int64_t)gridDim.x * (kBlock * U)) {
     double2v v[U][NT], vw[U];
@@ -304,6 +365,15 @@ __global__ __launch_bounds__(kBlock) void lin_dot_kernel(int64_t n, LinArgs a, c
     acc_yy += o * o;
     if (w) acc_yw += o * w[i];
   }
+}
+
+template <int NT>
+__global__ __launch_bounds__(kBlock) void lin_dot_kernel(int64_t n, LinArgs a, const double *w, int dot_yy,
+                                                         double *__restrict__ partials, const int *done, int nt) {
+  if (done && *done) return;
+  __shared__ double lds4[4];
+  double acc_yy = 0.0, acc_yw = 0.0;
+  lin_dot_body<NT>(n, a, w, nt, acc_yy, acc_yw);
   int j = 0;
   if (dot_yy) {
     const double sum = block_sum256(acc_yy, lds4);
@@ -314,6 +384,21 @@ __global__ __launch_bounds__(kBlock) void lin_dot_kernel(int64_t n, LinArgs a, c
     const double sum = block_sum256(acc_yw, lds4);
     if (threadIdx.x == 0) partials[(int64_t)j * gridDim.x + blockIdx.x] = sum;
   }
+}
+
+// ... and with the final pass in the last block (see publish_and_finish).
+template <int NT>
+__global__ __launch_bounds__(kBlock) void lin_dot_prog_kernel(int64_t n, LinArgs a, const double *w, int dot_yy,
+                                                              double *partials, const int *done, int nt, FinalPass f) {
+  if (done && *done) return;
+  __shared__ double lds4[4];
+  double acc_yy = 0.0, acc_yw = 0.0;
+  lin_dot_body<NT>(n, a, w, nt, acc_yy, acc_yw);
+  double mine[2] = {0.0, 0.0};
+  int j = 0;
+  if (dot_yy) mine[j++] = block_sum256(acc_yy, lds4);
+  if (w) mine[j] = block_sum256(acc_yw, lds4);
+  publish_and_finish<2>(partials, mine, f);
 }
 
 }  // namespace kry
@@ -380,6 +465,12 @@ struct KrylovEngine {
   bool red_pending = false;
   int red_nb = 0, red_k = 0;
   RedOut red_out{};
+  // a reduction whose partials kernel is launched at flush(), with the final pass and the scalar program inside
+  enum { PEND_NONE, PEND_DOTS, PEND_LIN_DOT } pend = PEND_NONE;
+  const double *pend_a = nullptr, *pend_w = nullptr;
+  DotPtrs pend_bs{};
+  LinArgs pend_lin{};
+  int pend_nt = 0, pend_yy = 0;
   // per-method vectors and registers
   V p = nullptr, q = nullptr, r = nullptr, rt = nullptr, t = nullptr, u = nullptr, v = nullptr, y = nullptr, z = nullptr,
     d = nullptr, s_ = nullptr;
@@ -418,7 +509,34 @@ struct KrylovEngine {
       reset_prog(), red_pending = false;
       return;
     }
-    if (red_pending) {
+    if (red_pending && pend != PEND_NONE) {
+      const FinalPass f{c->d_fin_counter, red_k, red_out, S, d_st, prog};
+      const int nti = (int)(c->opt_blas1_nt != 0);
+      const dim3 g(red_nb), b(kBlock);
+      if (pend == PEND_DOTS) {
+#define DOTS_GO(K_) hipLaunchKernelGGL(dots_prog_kernel<K_>, g, b, 0, c->stream, n, pend_a, pend_bs, c->d_partials, dp, nti, f)
+        switch (red_k) {
+          case 1: DOTS_GO(1); break;
+          case 2: DOTS_GO(2); break;
+          case 3: DOTS_GO(3); break;
+          case 4: DOTS_GO(4); break;
+          case 5: DOTS_GO(5); break;
+          case 6: DOTS_GO(6); break;
+          case 7: DOTS_GO(7); break;
+          default: DOTS_GO(8); break;
+        }
+#undef DOTS_GO
+      } else {
+#define LIN_GO(NT_) hipLaunchKernelGGL(lin_dot_prog_kernel<NT_>, g, b, 0, c->stream, n, pend_lin, pend_w, pend_yy, c->d_partials, dp, nti, f)
+        switch (pend_nt) {
+          case 1: LIN_GO(1); break;
+          case 2: LIN_GO(2); break;
+          default: LIN_GO(3); break;
+        }
+#undef LIN_GO
+      }
+      pend = PEND_NONE, red_pending = false;
+    } else if (red_pending) {
       const double *partials = c->d_partials;
       int nb = red_nb;
       if (nb > kSinglePassPartials) {
@@ -458,6 +576,7 @@ struct KrylovEngine {
     std::vector<std::pair<int, const storm_hip_vec *>> o(outs);
     dots_v(a, o);
   }
+  bool one_launch(int k) const { return c->comm == nullptr && c->opt_fused_reduce != 0 && n > 0 && k <= kDotChunk; }
   void dots_v(const storm_hip_vec *a, const std::vector<std::pair<int, const storm_hip_vec *>> &outs) {
     flush();
     if (!ok()) return;
@@ -468,6 +587,16 @@ struct KrylovEngine {
     }
     const double *bs[kMaxMulti];
     for (int j = 0; j < k; ++j) bs[j] = outs[j].second->d, red_out.idx[j] = outs[j].first;
+    if (one_launch(k)) {  // small: the partials kernel goes out at flush(), with the final pass in its last block
+      int nb = stream_blocks(n);
+      if ((int64_t)nb * k > c->partials_capacity) nb = (int)(c->partials_capacity / k);
+      if (nb <= kFinalPassMaxBlocks) {
+        pend = PEND_DOTS, pend_a = a->d;
+        for (int j = 0; j < kDotChunk; ++j) pend_bs.b[j] = bs[j < k ? j : 0];
+        red_nb = nb, red_k = k, red_pending = true;
+        return;
+      }
+    }
     if (n == 0) {  // an empty rank still takes part in the all-reduce
       const int st = (int)hipMemsetAsync(c->d_partials, 0, sizeof(double) * (size_t)k, c->stream);
       if (st != 0) return fail(STORM_HIP_E_HIP);
@@ -554,6 +683,14 @@ struct KrylovEngine {
     nb = std::min<int64_t>(nb, std::min<int64_t>(32768, c->partials_capacity / 2));
     const double *wd = (reg_yw >= 0 && wv != nullptr) ? wv->d : nullptr;
     const int nti = (int)(c->opt_blas1_nt != 0);
+    if (one_launch(2) && nb <= kFinalPassMaxBlocks && (reg_yy >= 0 || wd != nullptr)) {
+      pend = PEND_LIN_DOT, pend_lin = a, pend_nt = nt, pend_w = wd, pend_yy = (int)(reg_yy >= 0);
+      red_k = 0;
+      if (reg_yy >= 0) red_out.idx[red_k++] = reg_yy;
+      if (wd != nullptr) red_out.idx[red_k++] = reg_yw;
+      red_nb = (int)nb, red_pending = true;
+      return;
+    }
     switch (nt) {
       case 1: hipLaunchKernelGGL((lin_dot_kernel<1>), dim3((int)nb), dim3(kBlock), 0, c->stream, n, a, wd, (int)(reg_yy >= 0), c->d_partials, dp, nti); break;
       case 2: hipLaunchKernelGGL((lin_dot_kernel<2>), dim3((int)nb), dim3(kBlock), 0, c->stream, n, a, wd, (int)(reg_yy >= 0), c->d_partials, dp, nti); break;

@@ -355,3 +355,48 @@ def test_solve_non_uniform_shifts_an_affine_operator(env):
     ref = oracle.solve("bicgstab", oracle.StencilOperator(g, -1.0, 0.0), b_host - c_host, rel_tol=1e-10, abs_tol=0.0)
     assert np.linalg.norm(x.to_numpy() - ref.x) <= 1e-8 * np.linalg.norm(ref.x)
     mat.close()
+
+
+@pytest.mark.parametrize("kind", ["cg", "bicgstab", "cgs", "tfqmr", "idrs", "bicgstabl"])
+@pytest.mark.parametrize("shape", [(9, 7, 5), (40, 40, 40), (64, 64, 64)])
+def test_one_launch_reductions_give_the_same_bits(kind, shape):
+    """Engine reductions of small operators finish in the partials kernel's LAST block (option `fused_reduce`,
+    csrc/krylov.hip publish_and_finish): same folding order as the two-launch final pass, so the residual history
+    and x must be IDENTICAL, with a lambda operator and with a diagonal preconditioner."""
+    from stormruler_amd import api, mesh
+
+    ctx = api.Context(0)
+    g = mesh.structured_box(*shape)
+    wi, wo, de = mesh.convection_diffusion_weights(g, 1e-2, (1.0, 0.5, 0.25))
+    mat = api.StencilMatrix.from_face_weights(ctx, g.n_cells, g.n_halo, g.inner, g.outer, wi, wo, de)
+    cls = {"cg": api.CgSolver, "bicgstab": api.BiCgStabSolver, "cgs": api.CgsSolver, "tfqmr": api.TfqmrSolver,
+           "idrs": api.IdrsSolver, "bicgstabl": api.BiCgStabLSolver}[kind]
+    if kind == "cg":  # needs a symmetric operator
+        mat.close()
+        mat = api.StencilMatrix.from_face_graph(ctx, g)
+    b = api.DeviceVector.from_numpy(ctx, 1.0 + 0.25 * np.sin(0.01 * np.arange(g.n_cells)))
+    alpha = -1.0 if kind == "cg" else 1.0
+    lam = api.make_operator(lambda y, x: mat.apply(alpha, 0.0, x, y))
+    runs = {}
+    for fused in (1, 0):
+        ctx.set_option("fused_reduce", fused)
+        for pre in (None, api.JacobiPreconditioner):
+            api.rng_reset()
+            s = cls()
+            s.record_history, s.num_iterations = True, 60
+            if pre is not None and kind != "cg":
+                s.pre_op = pre()
+                op = api.HipStencilOperator(mat, alpha, 0.0)
+                ctx.set_option("generic_solvers", 1)
+            else:
+                op = lam
+            x = api.DeviceVector(ctx, g.n_cells)
+            s.solve(x, b, op)
+            ctx.set_option("generic_solvers", 0)
+            runs[(fused, pre is not None)] = (s.iteration, np.array(s.history), x.to_numpy())
+    ctx.set_option("fused_reduce", 1)
+    for with_pre in (False, True):
+        a, c = runs[(1, with_pre)], runs[(0, with_pre)]
+        assert a[0] == c[0] and np.array_equal(a[1], c[1]) and np.array_equal(a[2], c[2]), (kind, with_pre)
+    mat.close()
+    ctx.close()
