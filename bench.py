@@ -196,7 +196,9 @@ def main() -> int:
     # ---- roofline of the SpMV: HIP-event pairs around every launch --------------------------------
     prof_iters = max(K, 20)
     roof = spmv_roofline(op, st, prof_iters)
-    fmt_name = ("canonical paired rows: byte-indexed weights, one common offset order (8 B/row)" if st["paired_rows"] == 2 else
+    fmt_name = ("typed canonical paired rows: one byte per row into a table of weight words, one common offset order (1 B/row)"
+                if st["paired_rows"] == 3 else
+                "canonical paired rows: byte-indexed weights, one common offset order (8 B/row)" if st["paired_rows"] == 2 else
                 "paired rows: byte-indexed weights + shared column offsets (12 B/row)" if st["paired_rows"] else
                 "byte-indexed weights + column offsets (16 B/row)" if st["offset_dictionary_size"] else
                 "byte-indexed weights (8 B/row + int32 columns)" if st["value_dictionary_size"] else
@@ -318,7 +320,7 @@ def main() -> int:
                                     "median over the repeats listed in `timing`",
             },
             "roofline": {
-                "kernel": ("spmv_canon_kernel" if st["paired_rows"] == 2 else "spmv_pair_kernel" if st["paired_rows"] else
+                "kernel": ("spmv_canon_kernel" if st["paired_rows"] >= 2 else "spmv_pair_kernel" if st["paired_rows"] else
                            "spmv_dict_kernel" if st["value_dictionary_size"] else "spmv_sell_kernel") +
                           " (sliced-ELL gather SpMV + fused <p,Ap> partials)",
                 "bound": "hbm", "achieved": roof["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

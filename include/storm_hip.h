@@ -225,6 +225,8 @@ int storm_hip_op_create_csr(storm_hip_ctx *ctx, int64_t n_rows, int64_t n_halo,
  *              and the tables are small (<= 32 values, <= 64 offsets); 4 (default) additionally drops the
  *              per-lane offsets when every row lists its neighbours in one common order of offsets (a
  *              structured box in natural ordering) and takes the +-1 neighbours from the adjacent lanes;
+ *              5 (opt-in) additionally stores ONE byte per row when the rows' weight words take at most 32
+ *              distinct values (a box with spacings exact in binary);
  *              0 always stores fp64 weights and int32 columns. */
 int storm_hip_ctx_set_option(storm_hip_ctx *ctx, const char *key, int64_t value);
 
@@ -267,7 +269,7 @@ typedef struct storm_hip_op_stats {
   int64_t record_bytes;                 /* bytes of slice records one apply streams */
   int64_t value_dictionary_size;        /* > 0: weights stored as byte indices into this many distinct values */
   int64_t offset_dictionary_size;       /* > 0: columns stored as byte indices into this many distinct col - row */
-  int64_t paired_rows;                  /* 1: two consecutive rows per lane share their 16-byte gathers; n_slices then counts 128-row groups; 2: the same with one common offset order (format 4) */
+  int64_t paired_rows;                  /* 1: two consecutive rows per lane share their 16-byte gathers; n_slices then counts 128-row groups; 2: the same with one common offset order (format 4); 3: format 5 (one byte per row) */
 } storm_hip_op_stats;
 int storm_hip_op_get_stats(const storm_hip_op *op, storm_hip_op_stats *stats);
 int storm_hip_op_destroy(storm_hip_op *op);

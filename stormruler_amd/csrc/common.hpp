@@ -105,6 +105,7 @@ struct storm_hip_ctx {
   int64_t opt_spmv_spw = 0;          // slices per wave of the dictionary kernel: 1, 2 or 4 (0 = default)
   int64_t opt_spmv_xcd_remap = 8;    // 0 off; 1 one contiguous run per XCD (slower); G > 1: runs of G tiles per XCD
   int64_t opt_nt = 1;
+  int64_t opt_spmv_canon_groups = 2; // format-4 / 5 kernel: 128-row groups per wavefront (1 or 2)
   int64_t opt_spmv_mixed = 1;        // partitioned operators: format 4 for the groups that read no halo column, format 3 for the rest
   int64_t opt_spmv_nt_y = 1;         // format-4 kernel: store y non-temporally (A/B knob)
   int64_t opt_profile_spmv = 0;
@@ -173,7 +174,8 @@ struct storm_hip_op {
   int dict_size = 0;               // > 0: records are [idx 64 u64][col W*64 i32]
   int *d_offs = nullptr;           // format 2: the 256-entry column-offset table
   int offs_size = 0;               // > 0: records are 64 x 16-byte words (values + offsets as byte indices)
-  int pair = 0;                    // 1: format 3 -- 128-row groups of paired rows, n_slices counts those groups; 2: format 4 (common offset order)
+  int pair = 0;                    // 1: format 3 -- 128-row groups of paired rows, n_slices counts those groups; 2: format 4 (common offset order); 3: format 5 (+ one byte per row)
+  unsigned long long *d_types = nullptr;  // format 5: the distinct weight words (kMaxRowTypes entries)
   char *d_bnd_pack = nullptr;      // mixed operator: format-3 records of the boundary groups, in d_boundary order
   int bnd_width = 0;               // ... and their merged width
   int canon_k = 0, canon_m1 = -1;  // format 4: number of common offsets, slot of offset -1 (+1 follows)

@@ -78,6 +78,7 @@ struct SellArgs {
   int accumulate;                         // y += alpha*M(x) (stormDivGrad's own form) instead of y = beta*x + alpha*M(x)
   int nt_y = 1;                           // y stored non-temporally (0: it may stay in the Infinity Cache for the consumer)
   int rec_by_pos = 0;                     // paired records stored in slice-LIST order (the boundary groups of a mixed operator)
+  const unsigned long long *types = nullptr;  // format 5: the (<= 32) distinct weight words of the operator's rows
 };
 
 constexpr int kDictSize = 256;
@@ -599,21 +600,27 @@ __device__ __forceinline__ double dpp_shift(double v) {  // lanes without a sour
   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
-template <bool DOT, int K, int M1>
+// TYPED (format 5): the rows' 8-byte weight words take at most 32 distinct values (a box with uniform spacing: the 27
+// combinations of "which walls does the cell touch") -- a row stores ONE byte, the index of its word in a table held
+// in LDS beside the value table: 1 + 8 + 8 = 17 B/row.
+constexpr int kTypedRecBytes = 2 * kWave;
+constexpr int kMaxRowTypes = 32;
+// G: consecutive 128-row groups per wavefront (1 or 2).  With two, every load of both groups is in flight before the
+// first use, the prologue (tile mapping, tables) and the fused-dot's wave reduction are paid once per 256 rows.
+template <bool DOT, int K, int M1, bool TYPED, int G>
 __global__ __launch_bounds__(kBlock) void spmv_canon_kernel(SellArgs A, CanonArgs C, Scal alpha_s, Scal beta_s,
                                                             const double *__restrict__ x, double *__restrict__ y,
                                                             const int *__restrict__ slice_list,
                                                             int64_t n_launch_slices, DotArgs dot, const int *done) {
   const int done_flag = done ? *done : 0;
   __shared__ double dict_sh[32];
+  __shared__ unsigned long long types_sh[TYPED ? kMaxRowTypes : 1];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bidx = (int)blockIdx.x;
   const int lb = A.xcd_group > 1 ? xcd_remap_grouped(bidx, gridDim.x, A.xcd_group)
                                  : (A.xcd_group == 1 ? xcd_remap(bidx, gridDim.x) : bidx);
-  const int64_t sl = (int64_t)lb * (kBlock / kWave) + wave;
-  const bool active = sl < n_launch_slices;  // wave-uniform
-  const uint32_t slice = (uint32_t)(slice_list ? slice_list[active ? sl : 0] : (active ? sl : 0));
+  const int64_t sl0 = ((int64_t)lb * (kBlock / kWave) + wave) * G;
   const double alpha = ld_scal2(alpha_s), beta = ld_scal2(beta_s);
   const uint32_t last_row = (uint32_t)(A.n_rows - 1);
   const bool w_is_x = DOT && dot.w == x;
@@ -621,72 +628,104 @@ __global__ __launch_bounds__(kBlock) void spmv_canon_kernel(SellArgs A, CanonArg
   const char *xb = reinterpret_cast<const char *>(x);
   const char *xg_base = xb - (size_t)kVecGuard * 8;  // start of the zero guard in front of x
   char *yb = reinterpret_cast<char *>(y);
-
-  const uint32_t r0 = slice * (2 * kWave) + 2 * lane;  // row A; row B = r0 + 1
-  const bool valid_a = active && r0 <= last_row, valid_b = active && r0 + 1 <= last_row;
-  const uint32_t rc = r0 <= last_row ? r0 : (last_row & ~1u);  // pairs past the end re-read the last pair
   typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-  // Issue order matters (loads return in order; a wait for one load waits for every earlier one): the value table
-  // first -- its LDS copy is needed before anything else can be consumed -- then the record, the own rows, all
-  // gathers and the two outer neighbours back to back; nothing is consumed before the last load is in flight.
+
+  // Issue order matters (loads return in order; a wait for one load waits for every earlier one): the tables first
+  // -- their LDS copies are needed before anything else can be consumed -- then per group the record, the own rows,
+  // all gathers and the two outer neighbours back to back; nothing is consumed before the last load is in flight.
   const double dict_word = A.dict[lane & 31];
-  const u64x2 vw = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(A.pack + (size_t)slice * kCanonRecBytes) + lane);
-  const double2v xi = *reinterpret_cast<const double2v *>(xb + (size_t)(rc << 3));
-  double2v yo = {0.0, 0.0}, wi = {0.0, 0.0};
-  if (A.accumulate) yo = *reinterpret_cast<const double2v *>(yb + (size_t)(rc << 3));
-  if (w_load) wi = *reinterpret_cast<const double2v *>(reinterpret_cast<const char *>(dot.w) + (size_t)(rc << 3));
-  double2v xg[K];
+  unsigned long long type_word = 0ull;
+  if (TYPED) type_word = A.types[lane & (kMaxRowTypes - 1)];
+  bool valid_a[G], valid_b[G];
+  uint32_t rc[G];
+  u64x2 vw[G];
+  unsigned type_pair[G];  // (type of row A) | (type of row B) << 8, both pre-scaled by 8
+  double2v xi[G], yo[G], wi[G], xg[G][K];
+  double e[G];
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    if (M1 >= 0 && (k == M1 || k == M1 + 1)) continue;
-    int t = (int)rc + C.off[k] + kVecGuard;  // guard-relative, clamped: an absent neighbour may point anywhere
-    t = t < 0 ? 0 : t;
-    t = t > C.max_gather ? C.max_gather : t;
-    // (32-bit byte offset from a uniform base: n_rows + n_halo < 2^28 is a condition of the paired formats)
-    xg[k] = *reinterpret_cast<const double2v *>(xg_base + (size_t)((uint32_t)t << 3));
+  for (int g = 0; g < G; ++g) {
+    const bool active = sl0 + g < n_launch_slices;  // wave-uniform
+    const uint32_t slice = (uint32_t)(slice_list ? slice_list[active ? sl0 + g : 0] : (active ? sl0 + g : 0));
+    const uint32_t r0 = slice * (2 * kWave) + 2 * lane;  // row A; row B = r0 + 1
+    valid_a[g] = active && r0 <= last_row, valid_b[g] = active && r0 + 1 <= last_row;
+    rc[g] = r0 <= last_row ? r0 : (last_row & ~1u);  // pairs past the end re-read the last pair
+    vw[g] = u64x2{0ull, 0ull};
+    type_pair[g] = 0u;
+    if (TYPED)
+      type_pair[g] = __builtin_nontemporal_load(reinterpret_cast<const unsigned short *>(A.pack + (size_t)slice * kTypedRecBytes) + lane);
+    else
+      vw[g] = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(A.pack + (size_t)slice * kCanonRecBytes) + lane);
+    xi[g] = *reinterpret_cast<const double2v *>(xb + (size_t)(rc[g] << 3));
+    yo[g] = double2v{0.0, 0.0}, wi[g] = double2v{0.0, 0.0};
+    if (A.accumulate) yo[g] = *reinterpret_cast<const double2v *>(yb + (size_t)(rc[g] << 3));
+    if (w_load) wi[g] = *reinterpret_cast<const double2v *>(reinterpret_cast<const char *>(dot.w) + (size_t)(rc[g] << 3));
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (M1 >= 0 && (k == M1 || k == M1 + 1)) continue;
+      int t = (int)rc[g] + C.off[k] + kVecGuard;  // guard-relative, clamped: an absent neighbour may point anywhere
+      t = t < 0 ? 0 : t;
+      t = t > C.max_gather ? C.max_gather : t;
+      // (32-bit byte offset from a uniform base: n_rows + n_halo < 2^28 is a condition of the paired formats)
+      xg[g][k] = *reinterpret_cast<const double2v *>(xg_base + (size_t)((uint32_t)t << 3));
+    }
+    e[g] = 0.0;
+    if (M1 >= 0 && (lane == 0 || lane == kWave - 1))  // x[rc - 1] of lane 0, x[rc + 2] of lane 63
+      e[g] = *reinterpret_cast<const double *>(xg_base + (size_t)((rc[g] + (uint32_t)(kVecGuard + (lane == 0 ? -1 : 2))) << 3));
   }
-  double e = 0.0;
-  if (M1 >= 0 && (lane == 0 || lane == kWave - 1))  // x[rc - 1] of lane 0, x[rc + 2] of lane 63
-    e = *reinterpret_cast<const double *>(xg_base + (size_t)((rc + (uint32_t)(kVecGuard + (lane == 0 ? -1 : 2))) << 3));
   if (lane < 32) dict_sh[lane] = dict_word;  // one copy per block, every wave stores the same words: no barrier
-  if (M1 >= 0) {
-    // x[rc - 1] and x[rc + 2] are the neighbouring lanes' own rows
-    const double left = dpp_shift<0x138>(xi.y);   // wave_shr:1 -- lane i receives lane i - 1
-    const double right = dpp_shift<0x130>(xi.x);  // wave_shl:1 -- lane i receives lane i + 1
-    xg[M1 >= 0 ? M1 : 0].x = lane == 0 ? e : left;
-    xg[M1 >= 0 ? M1 : 0].y = xi.x;
-    xg[M1 >= 0 ? M1 + 1 : 0].x = xi.y;
-    xg[M1 >= 0 ? M1 + 1 : 0].y = lane == kWave - 1 ? e : right;
-  }
-  __builtin_amdgcn_wave_barrier();  // this wave's copy of the table is complete (same-wave LDS order)
-  double acc_a = 0.0, acc_b = 0.0;
+  if (TYPED && lane < kMaxRowTypes) types_sh[lane] = type_word;
+  __builtin_amdgcn_wave_barrier();  // this wave's copy of the tables is complete (same-wave LDS order)
+  double dot_a = 0.0, dot_b = 0.0;
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const unsigned ba = (unsigned)(vw.x >> (8 * (k + 1))) & 0xffu, bb = (unsigned)(vw.y >> (8 * (k + 1))) & 0xffu;
-    acc_a += *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + ba) * (xg[k].x - xi.x);
-    acc_b += *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + bb) * (xg[k].y - xi.y);
-  }
-  const double ext_a = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + ((unsigned)vw.x & 0xffu));
-  const double ext_b = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + ((unsigned)vw.y & 0xffu));
-  double2v yi;
-  yi.x = (A.accumulate ? yo.x : beta * xi.x) + alpha * (acc_a + ext_a * xi.x);
-  yi.y = (A.accumulate ? yo.y : beta * xi.y) + alpha * (acc_b + ext_b * xi.y);
-  if (!done_flag) {
-    if (valid_b) { if (A.nt_y) __builtin_nontemporal_store(yi, reinterpret_cast<double2v *>(yb + (size_t)(rc << 3))); else *reinterpret_cast<double2v *>(yb + (size_t)(rc << 3)) = yi; }
-    else if (valid_a) y[rc] = yi.x;  // the odd last row
+  for (int g = 0; g < G; ++g) {
+    if (M1 >= 0) {
+      // x[rc - 1] and x[rc + 2] are the neighbouring lanes' own rows
+      const double left = dpp_shift<0x138>(xi[g].y);   // wave_shr:1 -- lane i receives lane i - 1
+      const double right = dpp_shift<0x130>(xi[g].x);  // wave_shl:1 -- lane i receives lane i + 1
+      xg[g][M1 >= 0 ? M1 : 0].x = lane == 0 ? e[g] : left;
+      xg[g][M1 >= 0 ? M1 : 0].y = xi[g].x;
+      xg[g][M1 >= 0 ? M1 + 1 : 0].x = xi[g].y;
+      xg[g][M1 >= 0 ? M1 + 1 : 0].y = lane == kWave - 1 ? e[g] : right;
+    }
+    if (TYPED) {
+      vw[g].x = *reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(types_sh) + (type_pair[g] & 0xffu));
+      vw[g].y = *reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(types_sh) + (type_pair[g] >> 8));
+    }
+    double acc_a = 0.0, acc_b = 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const unsigned ba = (unsigned)(vw[g].x >> (8 * (k + 1))) & 0xffu, bb = (unsigned)(vw[g].y >> (8 * (k + 1))) & 0xffu;
+      acc_a += *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + ba) * (xg[g][k].x - xi[g].x);
+      acc_b += *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + bb) * (xg[g][k].y - xi[g].y);
+    }
+    const double ext_a = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + ((unsigned)vw[g].x & 0xffu));
+    const double ext_b = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + ((unsigned)vw[g].y & 0xffu));
+    double2v yi;
+    yi.x = (A.accumulate ? yo[g].x : beta * xi[g].x) + alpha * (acc_a + ext_a * xi[g].x);
+    yi.y = (A.accumulate ? yo[g].y : beta * xi[g].y) + alpha * (acc_b + ext_b * xi[g].y);
+    if (!done_flag) {
+      double2v *yp = reinterpret_cast<double2v *>(yb + (size_t)(rc[g] << 3));
+      if (valid_b[g]) { if (A.nt_y) __builtin_nontemporal_store(yi, yp); else *yp = yi; }
+      else if (valid_a[g]) y[rc[g]] = yi.x;  // the odd last row
+    }
+    if (DOT) {
+      yi.x = valid_a[g] ? yi.x : 0.0;
+      yi.y = valid_b[g] ? yi.y : 0.0;
+      // (group by group, rows in order: with G == 1 exactly the sums of the one-group kernel)
+      const double a = dot.w ? (w_is_x ? xi[g].x : wi[g].x) * yi.x + (w_is_x ? xi[g].y : wi[g].y) * yi.y : 0.0;
+      const double b = yi.x * yi.x + yi.y * yi.y;
+      dot_a = g == 0 ? a : dot_a + a;
+      dot_b = g == 0 ? b : dot_b + b;
+    }
   }
   if (done_flag) return;
   if (DOT) {
-    yi.x = valid_a ? yi.x : 0.0;
-    yi.y = valid_b ? yi.y : 0.0;
-    double a = dot.w ? (w_is_x ? xi.x : wi.x) * yi.x + (w_is_x ? xi.y : wi.y) * yi.y : 0.0;
-    double b = yi.x * yi.x + yi.y * yi.y;
-    a = wave_sum_to_lane63(a);
-    if (dot.yy) b = wave_sum_to_lane63(b);
+    dot_a = wave_sum_to_lane63(dot_a);
+    if (dot.yy) dot_b = wave_sum_to_lane63(dot_b);
     if (lane == kWave - 1) {
       const int slot = dot.block_offset + (int)blockIdx.x * (kBlock / kWave) + wave;
-      dot.partials[slot] = a;
-      if (dot.yy) dot.partials[dot.nblocks_total + slot] = b;
+      dot.partials[slot] = dot_a;
+      if (dot.yy) dot.partials[dot.nblocks_total + slot] = dot_b;
     }
   }
 }
@@ -739,6 +778,8 @@ static void launch_sell(const storm_hip_op *op, int nb, Scal alpha, Scal beta, c
   }
 }
 
+// 128-row groups per wave of the format-4 / 5 kernel.
+static inline int canon_groups(const storm_hip_op *op) { return op->ctx->opt_spmv_canon_groups == 2 ? 2 : 1; }
 // Slices per wave: SPW for the uniform-width value-dictionary kernel, 1 otherwise.
 static inline int op_spw(const storm_hip_op *op) {
   if (op->pair) return 1;  // a "slice" of a format-3 operator is a 128-row group, one per wave
@@ -761,17 +802,30 @@ static void launch_pair(const storm_hip_op *op, int nb, Scal alpha, Scal beta, c
     A.pack = op->d_bnd_pack, A.rec_by_pos = 1;
     width = op->bnd_width;
   }
-  if (op->pair == 2 && !boundary_of_mixed) {  // format 4: the common offsets travel as kernel arguments
+  if (op->pair >= 2 && !boundary_of_mixed) {  // formats 4, 5: the common offsets travel as kernel arguments
     CanonArgs C;
     for (int k = 0; k < 7; ++k) C.off[k] = op->canon_off[k];
     C.max_gather = (int)(op->n_rows + op->n_halo) + kVecGuard + 2;
-#define CANON_GO(K_, M1_)                                                                                          \
-  hipExtLaunchKernelGGL((spmv_canon_kernel<DOT, K_, M1_>), dim3(nb), dim3(kBlock), 0, st, ev0, ev1, 0, A, C, alpha, \
+    A.types = op->d_types;
+#define CANON_GO2(K_, M1_, T_, G_)                                                                                       \
+  hipExtLaunchKernelGGL((spmv_canon_kernel<DOT, K_, M1_, T_, G_>), dim3(nb), dim3(kBlock), 0, st, ev0, ev1, 0, A, C, alpha, \
                         beta, x, y, slice_list, n_launch, dot, done)
+#define CANON_GO(K_, M1_)                                      \
+  do {                                                         \
+    const bool two = canon_groups(op) == 2;                    \
+    if (op->pair == 3) {                                       \
+      if (two) CANON_GO2(K_, M1_, true, 2);                    \
+      else CANON_GO2(K_, M1_, true, 1);                        \
+    } else {                                                   \
+      if (two) CANON_GO2(K_, M1_, false, 2);                   \
+      else CANON_GO2(K_, M1_, false, 1);                       \
+    }                                                          \
+  } while (0)
     if (op->canon_k == 6) CANON_GO(6, 2);
     else if (op->canon_k == 4) CANON_GO(4, 1);
     else CANON_GO(2, 0);
 #undef CANON_GO
+#undef CANON_GO2
     return;
   }
 #define PAIR_GO(W_)                                                                                              \
@@ -788,8 +842,8 @@ static void launch_pair(const storm_hip_op *op, int nb, Scal alpha, Scal beta, c
   }
 #undef PAIR_GO
 }
-static inline int blocks_for(const storm_hip_op *op, int64_t n_launch_slices) {
-  const int64_t per_block = (kBlock / kWave) * op_spw(op);
+static inline int blocks_for(const storm_hip_op *op, int64_t n_launch_slices, bool boundary_of_mixed = false) {
+  const int64_t per_block = (kBlock / kWave) * ((op->pair >= 2 && !boundary_of_mixed) ? canon_groups(op) : op_spw(op));
   return (int)((n_launch_slices + per_block - 1) / per_block);
 }
 
@@ -840,7 +894,7 @@ static int launch_range(const storm_hip_op *op, Scal alpha, Scal beta, const dou
     // stamped at the kernel's begin and end, the quantity rocprofv3's kernel trace reports
     ev0 = c->prof_events[c->prof_used], ev1 = c->prof_events[c->prof_used + 1];
   }
-  const int nb = blocks_for(op, n_launch);
+  const int nb = blocks_for(op, n_launch, op->d_bnd_pack != nullptr && slice_list != nullptr && slice_list == op->d_boundary);
   const bool nt = c->opt_nt != 0;
   if (op->pair) {
     if (want_dot) launch_pair<true>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1, accumulate);
@@ -892,7 +946,7 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
   const bool split = exchange || op->d_bnd_pack != nullptr;
   DotArgs dot{nullptr, nullptr, 0, 0, 0};
   const int nb_int = split ? blocks_for(op, op->n_interior) : spmv_grid_blocks(op);
-  const int nb_bnd = split ? blocks_for(op, op->n_boundary) : 0;
+  const int nb_bnd = split ? blocks_for(op, op->n_boundary, op->d_bnd_pack != nullptr) : 0;
   const int nb_total = nb_int + nb_bnd;
   if (fuse_dot) {
     STORM_REQUIRE(8 * (int64_t)nb_total <= c->partials_capacity,
@@ -927,13 +981,15 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
 __global__ __launch_bounds__(kBlock) void diag_sell_kernel(const char *__restrict__ pack,
                                                            const int64_t *__restrict__ slice_off, int64_t n_rows,
                                                            const double *__restrict__ dict, int fmt2, double alpha,
-                                                           double beta, double *__restrict__ d) {
+                                                           double beta, double *__restrict__ d,
+                                                           const unsigned long long *__restrict__ types) {
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t s = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
   const int64_t r = s * kWave + lane;
   if (r >= n_rows) return;
-  if (fmt2 == 3 || fmt2 == 4) {  // paired rows: 128-row groups, weights of row r in word (r % 128), bytes pre-scaled by 8
-    const uint64_t iw = reinterpret_cast<const uint64_t *>(pack + (r >> 7) * (fmt2 == 4 ? kCanonRecBytes : kPairRecBytes))[r & 127];
+  if (fmt2 >= 3) {  // paired rows: 128-row groups, weights of row r in word (r % 128), bytes pre-scaled by 8
+    const uint64_t iw = fmt2 == 5 ? types[reinterpret_cast<const unsigned char *>(pack)[r] >> 3]
+                                  : reinterpret_cast<const uint64_t *>(pack + (r >> 7) * (fmt2 == 4 ? kCanonRecBytes : kPairRecBytes))[r & 127];
     double sum = 0.0;
     for (int k = 0; k < 7; ++k) sum += dict[((unsigned)(iw >> (8 * (k + 1))) & 0xffu) >> 3];
     d[r] = beta + alpha * (dict[((unsigned)iw & 0xffu) >> 3] - sum);
@@ -1145,6 +1201,7 @@ static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vect
   int canon_len = 0, canon_m1 = -1;
   bool cn = pr && c->opt_spmv_dict >= 4 && 2 * n_bnd_groups <= n_groups && (n_bnd_groups == 0 || c->opt_spmv_mixed != 0);
   std::vector<char> bnd_pack;
+  std::vector<unsigned long long> row_types;  // format 5
   if (cn) {
     // the distinct offsets and who precedes whom in some row; a common order = a linear extension of that relation
     int64_t dist[8];
@@ -1219,17 +1276,44 @@ static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vect
     }
     op->canon_k = canon_len, op->canon_m1 = canon_m1;
     for (int k = 0; k < 7; ++k) op->canon_off[k] = k < canon_len ? (int)canon[k] : 0;
+    // ... and whether the rows' weight words take few distinct values (format 5): one byte per row
+    if (c->opt_spmv_dict >= 5) {
+      const uint64_t *words = reinterpret_cast<const uint64_t *>(pair_pack.data());
+      const int64_t n_words = n_groups * 2 * kWave;
+      std::vector<unsigned char> typed((size_t)n_words);
+      bool ty = true;
+      uint64_t last = ~0ull;
+      int last_idx = -1;
+      for (int64_t r = 0; ty && r < n_words; ++r) {
+        const uint64_t w = words[r];
+        int idx = (w == last) ? last_idx : -1;
+        for (int t = 0; idx < 0 && t < (int)row_types.size(); ++t) idx = row_types[(size_t)t] == w ? t : -1;
+        if (idx < 0) {
+          if ((int)row_types.size() == kMaxRowTypes) ty = false;
+          else idx = (int)row_types.size(), row_types.push_back(w);
+        }
+        last = w, last_idx = idx;
+        typed[(size_t)r] = (unsigned char)(idx << 3);
+      }
+      if (ty) {
+        pair_pack.assign(reinterpret_cast<const char *>(typed.data()), reinterpret_cast<const char *>(typed.data()) + typed.size());
+        row_types.resize(kMaxRowTypes, 0ull);
+      } else {
+        row_types.clear();
+      }
+    }
   }
   if (pr) {
     // format 3 (or 4) it is: a "slice" of this operator is a 128-row group
-    op->pair = cn ? 2 : 1;
+    op->pair = cn ? (row_types.empty() ? 2 : 3) : 1;
     op->bnd_width = pair_width;
     if (cn) pair_width = canon_len;
     op->n_slices = n_groups;
     op->uniform_width = pair_width;
     op->ell_slots = n_groups * 2 * kWave * pair_width;
     std::vector<int64_t> goff((size_t)n_groups + 1);
-    for (int64_t s = 0; s <= n_groups; ++s) goff[(size_t)s] = s * (cn ? kCanonRecBytes : kPairRecBytes);
+    for (int64_t s = 0; s <= n_groups; ++s)
+      goff[(size_t)s] = s * (cn ? (row_types.empty() ? kCanonRecBytes : kTypedRecBytes) : kPairRecBytes);
     for (int64_t s = 0; s < n_groups; ++s) (grp_bnd[(size_t)s] ? op->h_boundary : op->h_interior).push_back((int)s);
     op->n_interior_slices = (int64_t)op->h_interior.size();
     int st3 = STORM_HIP_OK;
@@ -1249,6 +1333,10 @@ static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vect
         (st3 = upload(&op->d_slice_off, goff, &bytes3)) || (st3 = upload(&op->d_pack, pair_pack, &bytes3)) ||
         (st3 = upload(&op->d_tail_row, no_i, &bytes3)) || (st3 = upload(&op->d_tail_ptr, one_zero, &bytes3)) ||
         (st3 = upload(&op->d_tail_col, no_i, &bytes3)) || (st3 = upload(&op->d_tail_val, no_d, &bytes3))) {
+      storm_hip_op_destroy(op);
+      return st3;
+    }
+    if (!row_types.empty() && (st3 = upload(&op->d_types, row_types, &bytes3))) {
       storm_hip_op_destroy(op);
       return st3;
     }
@@ -1540,7 +1628,8 @@ int storm_hip_op_get_diagonal(const storm_hip_op *op, double alpha, double beta,
   const int64_t n64 = (op->n_rows + kWave - 1) / kWave;  // the kernel walks 64-row groups whatever the format
   const int nb = (int)((n64 + (kBlock / kWave) - 1) / (kBlock / kWave));
   hipLaunchKernelGGL(diag_sell_kernel, dim3(nb), dim3(kBlock), 0, c->stream, op->d_pack, op->d_slice_off, op->n_rows,
-                     op->d_dict, op->pair == 2 ? 4 : op->pair ? 3 : (int)(op->offs_size > 0), alpha, beta, d->d);
+                     op->d_dict, op->pair >= 2 ? op->pair + 2 : op->pair ? 3 : (int)(op->offs_size > 0), alpha, beta, d->d,
+                     op->d_types);
   if (op->tail_rows > 0)
     hipLaunchKernelGGL(diag_tail_kernel, dim3((int)((op->tail_rows + 255) / 256)), dim3(256), 0, c->stream,
                        op->tail_rows, op->d_tail_row, op->d_tail_ptr, op->d_tail_val, alpha, d->d);
@@ -1578,6 +1667,7 @@ int storm_hip_op_destroy(storm_hip_op *op) {
   (void)hipFree(op->d_slice_off);
   (void)hipFree(op->d_pack);
   (void)hipFree(op->d_bnd_pack);
+  (void)hipFree(op->d_types);
   (void)hipFree(op->d_dict);
   (void)hipFree(op->d_offs);
   (void)hipFree(op->d_tail_row);

@@ -9,7 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-FORMATS = [(0, 1), (1, 1), (1, 2), (2, 1), (2, 2), (2, 4), (3, 0), (4, 0)]  # (spmv_dict, spmv_spw)
+FORMATS = [(0, 1), (1, 1), (1, 2), (2, 1), (2, 2), (2, 4), (3, 0), (4, 0), (5, 0)]  # (spmv_dict, spmv_spw)
 
 
 @pytest.fixture(scope="module")
@@ -66,6 +66,12 @@ def test_box_all_formats_bitwise_equal_and_match_oracle(env, shape):
             # every box in natural ordering lists its neighbours in one common order: the canonical records
             # (no per-lane offsets: 8 B/row) are taken whenever the rows pair up at all
             assert st["paired_rows"] == 2 and st["record_bytes"] == 1024 * st["n_slices"], st
+        if fmt[0] == 5 and st["paired_rows"]:
+            # ... and when the rows' weight words take at most 32 distinct values (27 kinds of cells in a box whose
+            # spacings are exact in binary; rounding of the centre distances makes more otherwise): one byte per row
+            assert st["paired_rows"] in (2, 3) and st["record_bytes"] == (128 if st["paired_rows"] == 3 else 1024) * st["n_slices"], st
+            if shape in ((64, 2, 2), (16, 10, 6)):
+                assert st["paired_rows"] == 3 or shape == (16, 10, 6)
         ys[fmt] = _apply(api, ctx, mat, x)
         # the diagonal read back from every format is the same
         d = api.DeviceVector(ctx, g.n_cells)
@@ -274,7 +280,8 @@ def test_mixed_records_of_a_partitioned_box(env, shape, expect_mixed):
         s = api.CgSolver()
         assert s.solve(xs, b, api.HipStencilOperator(mat, -1.0, 0.05))
         its.append((s.iteration, xs.to_numpy()))
-    assert its[0][0] == its[1][0] and np.array_equal(its[0][1], its[1][1])
+    # (the format-4 kernel folds two groups' fused-dot terms per wavefront: <p, Ap> differs in rounding, y does not)
+    assert its[0][0] == its[1][0] and np.allclose(its[0][1], its[1][1], rtol=1e-11, atol=0.0)
     us = []
     for mat in (mixed, plain):
         cv = api.DeviceVector.from_numpy(ctx, x, n_halo=loc.n_halo)
