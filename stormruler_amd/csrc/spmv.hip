@@ -592,6 +592,8 @@ constexpr int kCanonRecBytes = 2 * kWave * 8;
 struct CanonArgs {
   int off[7];
   int max_gather;  // largest guard-relative index a 16-byte gather may start at
+  int xcd_shift;   // >= 0: the XCD grouping with runs of 2^xcd_shift tiles, by shifts (no integer division per block)
+  int xcd_full;    // ... applied to blocks below this index (a multiple of 8 * 2^xcd_shift), identity beyond
 };
 template <int CTRL>
 __device__ __forceinline__ double dpp_shift(double v) {  // lanes without a source get 0
@@ -618,8 +620,17 @@ __global__ __launch_bounds__(kBlock) void spmv_canon_kernel(SellArgs A, CanonArg
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bidx = (int)blockIdx.x;
-  const int lb = A.xcd_group > 1 ? xcd_remap_grouped(bidx, gridDim.x, A.xcd_group)
-                                 : (A.xcd_group == 1 ? xcd_remap(bidx, gridDim.x) : bidx);
+  int lb = bidx;
+  if (C.xcd_shift >= 0) {  // xcd_remap_grouped for a power-of-two run length
+    if (bidx < C.xcd_full) {
+      const int xcd = bidx & (kNumXcd - 1), j = bidx >> 3;
+      lb = ((((j >> C.xcd_shift) << 3) + xcd) << C.xcd_shift) + (j & ((1 << C.xcd_shift) - 1));
+    }
+  } else if (A.xcd_group > 1) {
+    lb = xcd_remap_grouped(bidx, gridDim.x, A.xcd_group);
+  } else if (A.xcd_group == 1) {
+    lb = xcd_remap(bidx, gridDim.x);
+  }
   const int64_t sl0 = ((int64_t)lb * (kBlock / kWave) + wave) * G;
   const double alpha = ld_scal2(alpha_s), beta = ld_scal2(beta_s);
   const uint32_t last_row = (uint32_t)(A.n_rows - 1);
@@ -806,6 +817,12 @@ static void launch_pair(const storm_hip_op *op, int nb, Scal alpha, Scal beta, c
     CanonArgs C;
     for (int k = 0; k < 7; ++k) C.off[k] = op->canon_off[k];
     C.max_gather = (int)(op->n_rows + op->n_halo) + kVecGuard + 2;
+    C.xcd_shift = -1, C.xcd_full = 0;
+    if (group > 1 && (group & (group - 1)) == 0) {
+      while ((1 << (C.xcd_shift + 1)) <= group) ++C.xcd_shift;
+      const int span = kNumXcd * group;
+      C.xcd_full = (nb / span) * span;
+    }
     A.types = op->d_types;
 #define CANON_GO2(K_, M1_, T_, G_)                                                                                       \
   hipExtLaunchKernelGGL((spmv_canon_kernel<DOT, K_, M1_, T_, G_>), dim3(nb), dim3(kBlock), 0, st, ev0, ev1, 0, A, C, alpha, \
