@@ -26,14 +26,15 @@ struct EwPtrs {
 };
 
 template <class F>
-__global__ __launch_bounds__(kBlock) void ew_kernel(int64_t n, EwPtrs p, F f, const int *done, int nt) {
+__global__ __launch_bounds__(kBlock) void ew_kernel(int64_t n, EwPtrs p, F f, const int *done, int nt, int reverse) {
   if (done && *done) return;
+  const unsigned bx = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;  // a solver's sweep-direction scheme
   f.prepare();
   const int64_t n2 = n >> 1;
   double2v *__restrict__ y2 = reinterpret_cast<double2v *>(p.y);
   const double2v *__restrict__ a2 = reinterpret_cast<const double2v *>(p.x0);
   const double2v *__restrict__ b2 = reinterpret_cast<const double2v *>(p.x1);
-  for (int64_t base = (int64_t)blockIdx.x * (kBlock * kUnroll) + threadIdx.x; base < n2;
+  for (int64_t base = (int64_t)bx * (kBlock * kUnroll) + threadIdx.x; base < n2;
        base += (int64_t)gridDim.x * (kBlock * kUnroll)) {
     double2v vy[kUnroll], va[kUnroll], vb[kUnroll];
 #pragma unroll
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(int64_t n, EwPtrs p, F f, co
       }
     }
   }
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+  if ((n & 1) && bx == 0 && threadIdx.x == 0) {
     const int64_t i = n - 1;
     const double vy = F::reads_y ? p.y[i] : 0.0;
     const double va = F::nin > 0 ? p.x0[i] : 0.0;
@@ -127,7 +128,7 @@ template <class F>
 static int launch_ew(storm_hip_ctx *c, int64_t n, EwPtrs p, F f, const int *done) {
   if (n <= 0) return STORM_HIP_OK;
   hipLaunchKernelGGL(ew_kernel<F>, dim3(stream_blocks(n)), dim3(kBlock), 0, c->stream, n, p, f, done,
-                     (int)(c->opt_blas1_nt != 0));
+                     (int)(c->opt_blas1_nt != 0), c->stream_reverse);
   HIP_TRY(hipGetLastError());
   return STORM_HIP_OK;
 }
@@ -198,10 +199,11 @@ __global__ __launch_bounds__(kBlock) void multi_dot_kernel(int64_t n, const doub
 #pragma unroll
   for (int j = 0; j < KB; ++j) acc[j] = 0.0;
   multi_dot_accumulate<KB>(n, a, bs, nt, acc);
+  const unsigned bx = (nt & 2) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
 #pragma unroll
   for (int j = 0; j < KB; ++j) {
     const double s = block_sum(acc[j], lds4);
-    if (threadIdx.x == 0) partials[(int64_t)j * gridDim.x + blockIdx.x] = s;
+    if (threadIdx.x == 0) partials[(int64_t)j * gridDim.x + bx] = s;
   }
 }
 
@@ -256,7 +258,7 @@ int k_multi_dot_partials(storm_hip_ctx *c, const double *a, const double *const 
   STORM_REQUIRE(k >= 1 && k <= kMaxMulti, "multi_dot: k = %d outside [1, %d]", k, kMaxMulti);
   int nb = stream_blocks(n);
   if ((int64_t)nb * k > c->partials_capacity) nb = (int)(c->partials_capacity / k);  // grid-stride covers the rest
-  const int nt = (int)(c->opt_blas1_nt != 0);
+  const int nt = (int)(c->opt_blas1_nt != 0) | (c->stream_reverse << 1);
   for (int j0 = 0; j0 < k; j0 += kDotChunk) {
     const int kb = (k - j0) < kDotChunk ? (k - j0) : kDotChunk;
     DotPtrs ptrs;

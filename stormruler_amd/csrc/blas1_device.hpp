@@ -17,10 +17,13 @@ struct DotPtrs {
 template <int KB>
 __device__ __forceinline__ void multi_dot_accumulate(int64_t n, const double *__restrict__ a, const DotPtrs &bs, int nt,
                                                      double (&acc)[KB]) {
+  // nt: bit 0 = non-temporal loads, bit 1 = blocks dealt out from the far end (a block keeps its rows)
+  const unsigned bx = (nt & 2) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+  nt &= 1;
   const int64_t n2 = n >> 1;
   const double2v *__restrict__ a2 = reinterpret_cast<const double2v *>(a);
   constexpr int U = KB <= 2 ? kUnroll : (KB <= 4 ? 2 : 1);  // many streams: few accesses per stream in flight (tools/cg_kernels_bench.hip)
-  for (int64_t base = (int64_t)blockIdx.x * (kBlock * kUnroll) + threadIdx.x; base < n2;
+  for (int64_t base = (int64_t)bx * (kBlock * kUnroll) + threadIdx.x; base < n2;
        base += (int64_t)gridDim.x * (kBlock * kUnroll)) {
 #pragma unroll
     for (int u0 = 0; u0 < kUnroll; u0 += U) {
@@ -47,7 +50,7 @@ __device__ __forceinline__ void multi_dot_accumulate(int64_t n, const double *__
       }
     }
   }
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+  if ((n & 1) && bx == 0 && threadIdx.x == 0) {
 #pragma unroll
     for (int j = 0; j < KB; ++j) acc[j] += a[n - 1] * bs.b[j][n - 1];
   }

@@ -105,6 +105,9 @@ struct storm_hip_ctx {
   int64_t opt_spmv_spw = 0;          // slices per wave of the dictionary kernel: 1, 2 or 4 (0 = default)
   int64_t opt_spmv_xcd_remap = 8;    // 0 off; 1 one contiguous run per XCD (slower); G > 1: runs of G tiles per XCD
   int64_t opt_nt = 1;
+  int64_t opt_sweep_alternate = 1;   // fused CG: consecutive kernels sweep the rows in opposite directions (2: and without non-temporal hints)
+  int stream_reverse = 0;            // ... and the same for the next elementwise kernel
+  int spmv_reverse = 0;              // set around a format-4 SpMV launch by the solver: deal the tiles out from the far end
   int64_t opt_spmv_canon_groups = 2; // format-4 / 5 kernel: 128-row groups per wavefront (1 or 2)
   int64_t opt_spmv_mixed = 1;        // partitioned operators: format 4 for the groups that read no halo column, format 3 for the rest
   int64_t opt_spmv_nt_y = 1;         // format-4 kernel: store y non-temporally (A/B knob)

@@ -183,6 +183,10 @@ __global__ void sprog_kernel(double *S, SolverState *st, SProg prog, int nscatte
   exec_prog(prog, S, st);
 }
 
+// The `nt` argument of the streaming kernels carries two flags: bit 0 = non-temporal accesses, bit 1 = deal the
+// blocks out from the far end of the rows (the engine's sweep-direction scheme; a block keeps its rows and slots).
+__device__ __forceinline__ unsigned sweep_block(int flags) { return (flags & 2) ? gridDim.x - 1 - blockIdx.x : blockIdx.x; }
+
 // ---- reductions in ONE launch (small operators) ---------------------------------------------------------------
 // A reduction is "partials kernel, then a one-block final pass that also runs the scalar program": two launches, and
 // on the reference's own mesh sizes an iteration is nothing but launches (~4 us each, dependent).  When the partials
@@ -204,14 +208,15 @@ constexpr int kFinalPassMaxBlocks = 256;
 
 // `mine[j]` (valid in thread 0): this block's partial of sum j.  Returns after the final pass in the last block.
 template <int KMAX>
-__device__ __forceinline__ void publish_and_finish(double *partials, const double (&mine)[KMAX], const FinalPass &f) {
+__device__ __forceinline__ void publish_and_finish(double *partials, const double (&mine)[KMAX], const FinalPass &f,
+                                                   unsigned slot) {
   __shared__ int is_last;
   __shared__ double lds4f[4];
   const int nb = (int)gridDim.x;
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int j = 0; j < KMAX; ++j)
-      if (j < f.k) __hip_atomic_store(partials + (int64_t)j * nb + blockIdx.x, mine[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (j < f.k) __hip_atomic_store(partials + (int64_t)j * nb + slot, mine[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the stores above are acknowledged (no cache write-back)
     const int ticket = __hip_atomic_fetch_add(f.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     is_last = ticket == nb - 1;
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(kBlock) void dots_prog_kernel(int64_t n, const doub
   double mine[KB];
 #pragma unroll
   for (int j = 0; j < KB; ++j) mine[j] = block_sum256(acc[j], lds4);
-  publish_and_finish<KB>(partials, mine, f);
+  publish_and_finish<KB>(partials, mine, f, sweep_block(nt));
 }
 
 // ---- vector statements ------------------------------------------------------------------------------------
@@ -272,13 +277,15 @@ template <int NT, bool NESTED>
 __global__ __launch_bounds__(kBlock) void lin_kernel(int64_t n, LinArgs a, const int *done, int nt) {
   if (done && *done) return;
   if (a.cond && *a.cond == 0.0) return;
+  const unsigned bx = sweep_block(nt);
+  nt &= 1;
   double c[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) c[t] = ld_coef(a.c[t]);
   const int64_t n2 = n >> 1;
   double2v *y2 = reinterpret_cast<double2v *>(a.y);
   constexpr int U = lin_unroll(NT);
-  for (int64_t base = (int64_t)blockIdx.x * (kBlock * U) + threadIdx.x; base < n2;
+  for (int64_t base = (int64_t)bx * (kBlock * U) + threadIdx.x; base < n2;
        base += (int64_t)gridDim.x * (kBlock * U)) {
     double2v v[U][NT];
 #pragma unroll
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(kBlock) void lin_kernel(int64_t n, LinArgs a, const
       }
     }
   }
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+  if ((n & 1) && bx == 0 && threadIdx.x == 0) {
     const int64_t i = n - 1;
     double o;
     if constexpr (NESTED) {
@@ -324,6 +331,8 @@ __global__ __launch_bounds__(kBlock) void lin_kernel(int64_t n, LinArgs a, const
 template <int NT>
 __device__ __forceinline__ void lin_dot_body(int64_t n, const LinArgs &a, const double *w, int nt, double &acc_yy,
                                              double &acc_yw) {
+  const unsigned bx = sweep_block(nt);
+  nt &= 1;
   double c[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) c[t] = ld_coef(a.c[t]);
@@ -331,7 +340,7 @@ __device__ __forceinline__ void lin_dot_body(int64_t n, const LinArgs &a, const 
   double2v *y2 = reinterpret_cast<double2v *>(a.y);
   const double2v *w2 = reinterpret_cast<const double2v *>(w);
   constexpr int U = lin_unroll(NT + 1);
-  for (int64_t base = (int64_t)blockIdx.x * (kBlock * U) + threadIdx.x; base < n2;
+  for (int64_t base = (int64_t)bx * (kBlock * U) + threadIdx.x; base < n2;
        base += (int64_t)gridDim.x * (kBlock * U)) {
     double2v v[U][NT], vw[U];
 #pragma unroll
@@ -357,7 +366,7 @@ __device__ __forceinline__ void lin_dot_body(int64_t n, const LinArgs &a, const 
       }
     }
   }
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+  if ((n & 1) && bx == 0 && threadIdx.x == 0) {
     const int64_t i = n - 1;
     double o = c[0] * a.v[0][i];
     for (int t = 1; t < NT; ++t) o += c[t] * a.v[t][i];
@@ -377,12 +386,12 @@ __global__ __launch_bounds__(kBlock) void lin_dot_kernel(int64_t n, LinArgs a, c
   int j = 0;
   if (dot_yy) {
     const double sum = block_sum256(acc_yy, lds4);
-    if (threadIdx.x == 0) partials[(int64_t)j * gridDim.x + blockIdx.x] = sum;
+    if (threadIdx.x == 0) partials[(int64_t)j * gridDim.x + sweep_block(nt)] = sum;
     ++j;
   }
   if (w) {
     const double sum = block_sum256(acc_yw, lds4);
-    if (threadIdx.x == 0) partials[(int64_t)j * gridDim.x + blockIdx.x] = sum;
+    if (threadIdx.x == 0) partials[(int64_t)j * gridDim.x + sweep_block(nt)] = sum;
   }
 }
 
@@ -398,7 +407,7 @@ __global__ __launch_bounds__(kBlock) void lin_dot_prog_kernel(int64_t n, LinArgs
   int j = 0;
   if (dot_yy) mine[j++] = block_sum256(acc_yy, lds4);
   if (w) mine[j] = block_sum256(acc_yw, lds4);
-  publish_and_finish<2>(partials, mine, f);
+  publish_and_finish<2>(partials, mine, f, sweep_block(nt));
 }
 
 }  // namespace kry
@@ -470,7 +479,12 @@ struct KrylovEngine {
   const double *pend_a = nullptr, *pend_w = nullptr;
   DotPtrs pend_bs{};
   LinArgs pend_lin{};
-  int pend_nt = 0, pend_yy = 0;
+  int pend_nt = 0, pend_yy = 0, pend_flags = 0;
+  // Sweep directions (see storm_hip_solve_cg): every streaming statement deals its blocks out from the end of the
+  // rows where the previous one stopped -- what the Infinity Cache still holds.  Same rows and slots per block.
+  int sweep_dir = 1;
+  int flip() { return (c->opt_sweep_alternate != 0 && c->comm == nullptr) ? (sweep_dir ^= 1) : 0; }
+  int stream_flags() { return (int)(c->opt_blas1_nt != 0) | (flip() << 1); }
   // per-method vectors and registers
   V p = nullptr, q = nullptr, r = nullptr, rt = nullptr, t = nullptr, u = nullptr, v = nullptr, y = nullptr, z = nullptr,
     d = nullptr, s_ = nullptr;
@@ -511,7 +525,7 @@ struct KrylovEngine {
     }
     if (red_pending && pend != PEND_NONE) {
       const FinalPass f{c->d_fin_counter, red_k, red_out, S, d_st, prog};
-      const int nti = (int)(c->opt_blas1_nt != 0);
+      const int nti = pend_flags;
       const dim3 g(red_nb), b(kBlock);
       if (pend == PEND_DOTS) {
 #define DOTS_GO(K_) hipLaunchKernelGGL(dots_prog_kernel<K_>, g, b, 0, c->stream, n, pend_a, pend_bs, c->d_partials, dp, nti, f)
@@ -591,7 +605,7 @@ struct KrylovEngine {
       int nb = stream_blocks(n);
       if ((int64_t)nb * k > c->partials_capacity) nb = (int)(c->partials_capacity / k);
       if (nb <= kFinalPassMaxBlocks) {
-        pend = PEND_DOTS, pend_a = a->d;
+        pend = PEND_DOTS, pend_a = a->d, pend_flags = stream_flags();
         for (int j = 0; j < kDotChunk; ++j) pend_bs.b[j] = bs[j < k ? j : 0];
         red_nb = nb, red_k = k, red_pending = true;
         return;
@@ -602,7 +616,9 @@ struct KrylovEngine {
       if (st != 0) return fail(STORM_HIP_E_HIP);
       red_nb = 1;
     } else {
+      c->stream_reverse = flip();
       const int st = k_multi_dot_partials(c, a->d, bs, k, n, &red_nb, dp);
+      c->stream_reverse = 0;
       if (st != STORM_HIP_OK) return fail(st);
     }
     red_k = k, red_pending = true;
@@ -616,8 +632,7 @@ struct KrylovEngine {
     if (n <= 0) return;
     const int64_t per_block = (int64_t)kBlock * lin_unroll(NT) * 2;
     const int64_t nb = std::min<int64_t>(65536, std::max<int64_t>(1, (n + per_block - 1) / per_block));
-    hipLaunchKernelGGL((lin_kernel<NT, NESTED>), dim3((int)nb), dim3(kBlock), 0, c->stream, n, a, dp,
-                       (int)(c->opt_blas1_nt != 0));
+    hipLaunchKernelGGL((lin_kernel<NT, NESTED>), dim3((int)nb), dim3(kBlock), 0, c->stream, n, a, dp, stream_flags());
   }
   void lin_v(V yv, const std::vector<Term> &terms, int cond = -1) {
     flush();
@@ -656,7 +671,9 @@ struct KrylovEngine {
   void divide(V yv, int reg) {  // y /= reg (a true division per element, SolverGmres.hpp:88)
     flush();
     if (!ok()) return;
+    c->stream_reverse = flip();
     const int st = k_scale(c, yv->d, n, dev_scal(S + reg), true, dp);
+    c->stream_reverse = 0;
     if (st != STORM_HIP_OK) fail(st);
   }
   void scale(V yv, Coef a) { lin(yv, {{a, yv}}); }
@@ -682,9 +699,9 @@ struct KrylovEngine {
     int64_t nb = std::max<int64_t>(1, (n + per_block - 1) / per_block);
     nb = std::min<int64_t>(nb, std::min<int64_t>(32768, c->partials_capacity / 2));
     const double *wd = (reg_yw >= 0 && wv != nullptr) ? wv->d : nullptr;
-    const int nti = (int)(c->opt_blas1_nt != 0);
+    const int nti = stream_flags();
     if (one_launch(2) && nb <= kFinalPassMaxBlocks && (reg_yy >= 0 || wd != nullptr)) {
-      pend = PEND_LIN_DOT, pend_lin = a, pend_nt = nt, pend_w = wd, pend_yy = (int)(reg_yy >= 0);
+      pend = PEND_LIN_DOT, pend_lin = a, pend_nt = nt, pend_w = wd, pend_yy = (int)(reg_yy >= 0), pend_flags = nti;
       red_k = 0;
       if (reg_yy >= 0) red_out.idx[red_k++] = reg_yy;
       if (wd != nullptr) red_out.idx[red_k++] = reg_yw;
@@ -720,7 +737,9 @@ struct KrylovEngine {
     int nblocks = 0;
     SpmvDot sd;
     sd.w = wv->d, sd.yy = reg_yy >= 0, sd.partials = c->d_partials, sd.nblocks_out = &nblocks;
+    c->spmv_reverse = flip();
     const int st = spmv_launch(op, host_scal(op_alpha), host_scal(op_beta), xv->d, yv->d, &sd, dp);
+    c->spmv_reverse = 0;
     if (st != STORM_HIP_OK) return fail(st);
     if (nblocks <= 0) {  // the launch did not fuse after all
       std::vector<std::pair<int, const storm_hip_vec *>> outs{{reg_wy, wv}};
@@ -753,7 +772,9 @@ struct KrylovEngine {
         st = st < 0 ? st : STORM_HIP_E_INVALID;
       }
     } else {
+      c->spmv_reverse = flip();
       st = spmv_launch(op, host_scal(op_alpha), host_scal(op_beta), xv->d, yv->d, nullptr, dp);
+      c->spmv_reverse = 0;
     }
     if (st != STORM_HIP_OK) fail(st);
   }
@@ -770,7 +791,9 @@ struct KrylovEngine {
         st = st < 0 ? st : STORM_HIP_E_INVALID;
       }
     } else {
+      c->stream_reverse = flip();
       st = storm_hip_vmul(yv, pre_diag, xv);
+      c->stream_reverse = 0;
     }
     if (st != STORM_HIP_OK) fail(st);
   }

@@ -211,9 +211,12 @@ __global__ __launch_bounds__(kBlock) void init_residual_kernel(int64_t n, double
 __global__ __launch_bounds__(kBlock) void cg_r_kernel(int64_t n, SolverState *st, double *__restrict__ r,
                                                       const double *__restrict__ z,
                                                       double *__restrict__ partials, int nt,
-                                                      const double *__restrict__ pz_partials, int n_pz) {
+                                                      const double *__restrict__ pz_partials, int n_pz, int reverse) {
   if (st->done) return;
   __shared__ double lds4[4];
+  // `reverse`: the blocks sweep the rows from the far end (see the sweep-direction note in storm_hip_solve_cg);
+  // block bx still owns the same rows and the same partial, whichever way the grid is dealt out
+  const unsigned bx = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
   double pz;
   if (pz_partials) {
     double v = 0.0;
@@ -229,7 +232,8 @@ __global__ __launch_bounds__(kBlock) void cg_r_kernel(int64_t n, SolverState *st
   const int64_t n2 = n >> 1;
   double2v *r2 = reinterpret_cast<double2v *>(r);
   const double2v *z2 = reinterpret_cast<const double2v *>(z);
-  STORM_STREAM_FOR(base, n2) {
+  for (int64_t base = (int64_t)bx * (kBlock * kUnroll) + threadIdx.x; base < n2;
+       base += (int64_t)gridDim.x * (kBlock * kUnroll)) {
     double2v vr[kUnroll], vz[kUnroll];
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
@@ -247,13 +251,13 @@ __global__ __launch_bounds__(kBlock) void cg_r_kernel(int64_t n, SolverState *st
       }
     }
   }
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+  if ((n & 1) && bx == 0 && threadIdx.x == 0) {
     const double vr = r[n - 1] - alpha * z[n - 1];
     r[n - 1] = vr;
     acc += vr * vr;
   }
   const double s = block_sum256(acc, lds4);
-  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+  if (threadIdx.x == 0) partials[bx] = s;
 }
 
 // Five streams (3 loads, 2 stores): measured best with ONE 16-byte access per stream and thread in flight
@@ -262,14 +266,15 @@ __global__ __launch_bounds__(kBlock) void cg_r_kernel(int64_t n, SolverState *st
 constexpr int kUnrollXp = 1;
 __global__ __launch_bounds__(kBlock) void cg_xp_kernel(int64_t n, const SolverState *st, long long my_iteration,
                                                        double *__restrict__ x, double *__restrict__ p,
-                                                       const double *__restrict__ r, int nt) {
+                                                       const double *__restrict__ r, int nt, int reverse) {
   if (st->iteration < my_iteration) return;  // enqueued past convergence: this iteration never ran
+  const unsigned bx = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
   const bool update_p = !st->done;
   const double alpha = st->s[S_ALPHA], beta = st->s[S_BETA];
   const int64_t n2 = n >> 1;
   double2v *x2 = reinterpret_cast<double2v *>(x), *p2 = reinterpret_cast<double2v *>(p);
   const double2v *r2 = reinterpret_cast<const double2v *>(r);
-  for (int64_t base = (int64_t)blockIdx.x * (kBlock * kUnrollXp) + threadIdx.x; base < n2;
+  for (int64_t base = (int64_t)bx * (kBlock * kUnrollXp) + threadIdx.x; base < n2;
        base += (int64_t)gridDim.x * (kBlock * kUnrollXp)) {
     double2v vx[kUnrollXp], vp[kUnrollXp], vr[kUnrollXp];
 #pragma unroll
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(kBlock) void cg_xp_kernel(int64_t n, const SolverSt
       }
     }
   }
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+  if ((n & 1) && bx == 0 && threadIdx.x == 0) {
     const int64_t i = n - 1;
     x[i] += alpha * p[i];
     if (update_p) p[i] = r[i] + beta * p[i];
@@ -311,8 +316,9 @@ __global__ __launch_bounds__(kBlock) void bicg_update_kernel(int64_t n, SolverSt
                                                              double *__restrict__ r, const double *__restrict__ p,
                                                              const double *__restrict__ w,
                                                              const double *__restrict__ rt,
-                                                             double *__restrict__ partials, int nt) {
+                                                             double *__restrict__ partials, int nt, int reverse) {
   if (st->done) return;
+  const unsigned bx = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;  // the same rows and slots, dealt out from the far end
   __shared__ double lds4[4];
   const double alpha = st->s[S_ALPHA], omega = st->s[S_OMEGA];
   double acc_rr = 0.0, acc_rho = 0.0;
@@ -321,7 +327,7 @@ __global__ __launch_bounds__(kBlock) void bicg_update_kernel(int64_t n, SolverSt
   const double2v *p2 = reinterpret_cast<const double2v *>(p), *w2 = reinterpret_cast<const double2v *>(w);
   const double2v *rt2 = reinterpret_cast<const double2v *>(rt);
   constexpr int U = SECOND ? 1 : kUnroll;  // 7 streams: one access per stream in flight (see cg_xp_kernel)
-  for (int64_t base = (int64_t)blockIdx.x * (kBlock * U) + threadIdx.x; base < n2;
+  for (int64_t base = (int64_t)bx * (kBlock * U) + threadIdx.x; base < n2;
        base += (int64_t)gridDim.x * (kBlock * U)) {
     double2v vx[U], vr[U], vw[U], vp[U], vt[U];
 #pragma unroll
@@ -353,7 +359,7 @@ __global__ __launch_bounds__(kBlock) void bicg_update_kernel(int64_t n, SolverSt
       }
     }
   }
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+  if ((n & 1) && bx == 0 && threadIdx.x == 0) {
     const int64_t i = n - 1;
     if (!SECOND) {
       r[i] -= alpha * w[i];
@@ -369,7 +375,7 @@ __global__ __launch_bounds__(kBlock) void bicg_update_kernel(int64_t n, SolverSt
   if (SECOND) {
     const double s0 = block_sum256(acc_rr, lds4);
     const double s1 = block_sum256(acc_rho, lds4);
-    if (threadIdx.x == 0) partials[blockIdx.x] = s0, partials[gridDim.x + blockIdx.x] = s1;
+    if (threadIdx.x == 0) partials[bx] = s0, partials[gridDim.x + bx] = s1;
   }
 }
 
@@ -805,9 +811,19 @@ int storm_hip_solve_cg(const storm_hip_op *op, double alpha, double beta, const 
   }
   // One iteration's launches (the scalars live in the slab; only the iteration index varies).
   int64_t cur_it = 0;
+  // Sweep directions.  The 256 MB Infinity Cache still holds the END of what the previous kernel streamed (a read
+  // served from it runs ~18 % faster than from HBM, tools/mall_probe.hip), so every kernel starts where its
+  // predecessor stopped: iteration k even -- SpMV forward, cg_r backward, cg_xp forward; k odd -- the mirror image.
+  // Blocks keep their rows and their partial slots: the same bits either way.
+  const bool sweep = c->opt_sweep_alternate != 0 && c->comm == nullptr;
+  const int nt_stream = (int)(c->opt_blas1_nt != 0 && !(sweep && c->opt_sweep_alternate == 2));
   auto enqueue_iteration = [&]() -> int {
+    const int q = sweep ? (int)(cur_it & 1) : 0;
     // z = A p, <p,z>                                  SolverCg.hpp:96-97
-    STORM_TRY(d.apply(p, z, p, false, &nb));
+    c->spmv_reverse = q;
+    const int st_apply = d.apply(p, z, p, false, &nb);
+    c->spmv_reverse = 0;
+    STORM_TRY(st_apply);
     const double *pz_partials = nullptr;
     if (nb == 0) {  // operator has a CSR tail: separate dot
       const double *bs[1] = {z};
@@ -825,7 +841,7 @@ int storm_hip_solve_cg(const storm_hip_op *op, double alpha, double beta, const 
     }
     // r -= alpha z; gamma = <r,r>                     SolverCg.hpp:97,99,115
     hipLaunchKernelGGL(cg_r_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, r, z, c->d_partials,
-                       (int)(c->opt_blas1_nt != 0), pz_partials, (int)kStage2);
+                       nt_stream, pz_partials, (int)kStage2, sweep ? 1 - q : 0);
     HIP_TRY(hipGetLastError());
     {
       const int slots[1] = {S_GAMMA_NEW};
@@ -833,7 +849,7 @@ int storm_hip_solve_cg(const storm_hip_op *op, double alpha, double beta, const 
     }
     // x += alpha p; p = r + beta p                    SolverCg.hpp:98,123
     hipLaunchKernelGGL(cg_xp_kernel, dim3(xp_blocks(n)), dim3(kBlock), 0, c->stream, n, d.st, (long long)(cur_it + 1), x->d,
-                       p, r, (int)(c->opt_blas1_nt != 0));
+                       p, r, nt_stream, q);
     HIP_TRY(hipGetLastError());
     return STORM_HIP_OK;
   };
@@ -878,10 +894,21 @@ int storm_hip_solve_bicgstab(const storm_hip_op *op, double alpha, double beta, 
     const int slots[1] = {S_RHO};
     STORM_TRY(d.finish(nbv, 1, slots, STEP_BICG_INIT, true));
   }
+  // Sweep directions as in storm_hip_solve_cg: every streaming kernel starts at the end of the rows where its
+  // predecessor stopped (what the Infinity Cache still holds); blocks keep their rows and partial slots.
+  const bool sweep = c->opt_sweep_alternate != 0 && c->comm == nullptr && c->opt_graph == 0;
+  int dir = 1;
+  auto flip = [&]() -> int { return sweep ? (dir ^= 1) : 0; };
+  auto apply_dir = [&](const double *xin, double *yout, const double *w, bool yy) -> int {
+    c->spmv_reverse = flip();
+    const int st_apply = d.apply(xin, yout, w, yy, &nb);
+    c->spmv_reverse = 0;
+    return st_apply;
+  };
   // Everything of an iteration after the p update (iteration-invariant arguments).
   auto enqueue_rest = [&]() -> int {
     // v = A p; alpha = rho / <rt,v>                   :137-139
-    STORM_TRY(d.apply(p, v, rt, false, &nb));
+    STORM_TRY(apply_dir(p, v, rt, false));
     if (nb == 0) {
       const double *bs[1] = {v};
       STORM_TRY(k_multi_dot(c, rt, bs, 1, n, d.slot(S_RTV), d.done));
@@ -894,10 +921,10 @@ int storm_hip_solve_bicgstab(const storm_hip_op *op, double alpha, double beta, 
     }
     // r -= alpha v   (x += alpha p is applied in the second half-step)      :140-141
     hipLaunchKernelGGL(bicg_update_kernel<false>, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, x->d, r, p, v,
-                       rt, c->d_partials, (int)(c->opt_blas1_nt != 0));
+                       rt, c->d_partials, (int)(c->opt_blas1_nt != 0), flip());
     HIP_TRY(hipGetLastError());
     // t = A r; omega = <t,r> / <t,t>                  :158-160
-    STORM_TRY(d.apply(r, t, r, true, &nb));
+    STORM_TRY(apply_dir(r, t, r, true));
     if (nb == 0) {
       const double *bs[2] = {r, t};
       STORM_TRY(k_multi_dot(c, t, bs, 2, n, d.slot(S_TR), d.done));
@@ -910,7 +937,7 @@ int storm_hip_solve_bicgstab(const storm_hip_op *op, double alpha, double beta, 
     }
     // x = (x + alpha p) + omega r; r -= omega t; |r|, <rt,r>    :140, :161-164 (+ :116 of the next iteration)
     hipLaunchKernelGGL(bicg_update_kernel<true>, dim3(nbv2), dim3(kBlock), 0, c->stream, n, d.st, x->d, r,
-                       p, t, rt, c->d_partials, (int)(c->opt_blas1_nt != 0));
+                       p, t, rt, c->d_partials, (int)(c->opt_blas1_nt != 0), flip());
     HIP_TRY(hipGetLastError());
     {
       const int slots[2] = {S_RR, S_RHO_NEW};
@@ -920,7 +947,10 @@ int storm_hip_solve_bicgstab(const storm_hip_op *op, double alpha, double beta, 
   };
   auto enqueue_iteration = [&]() -> int {  // iterations >= 1
     // rho, beta were formed by STEP_BICG_END of the previous iteration (same r): :116-119
-    STORM_TRY(k_bicg_p(c, p, r, dev_scal(d.slot(S_BETA)), dev_scal(d.slot(S_OMEGA)), v, n, d.done));
+    c->stream_reverse = flip();
+    const int st_p = k_bicg_p(c, p, r, dev_scal(d.slot(S_BETA)), dev_scal(d.slot(S_OMEGA)), v, n, d.done);
+    c->stream_reverse = 0;
+    STORM_TRY(st_p);
     return enqueue_rest();
   };
   IterationGraph graph;

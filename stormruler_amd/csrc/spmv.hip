@@ -592,6 +592,7 @@ constexpr int kCanonRecBytes = 2 * kWave * 8;
 struct CanonArgs {
   int off[7];
   int max_gather;  // largest guard-relative index a 16-byte gather may start at
+  int reverse;     // deal the tiles out from the far end (the solver's sweep-direction scheme; same tile per block index)
   int xcd_shift;   // >= 0: the XCD grouping with runs of 2^xcd_shift tiles, by shifts (no integer division per block)
   int xcd_full;    // ... applied to blocks below this index (a multiple of 8 * 2^xcd_shift), identity beyond
 };
@@ -619,7 +620,7 @@ __global__ __launch_bounds__(kBlock) void spmv_canon_kernel(SellArgs A, CanonArg
   __shared__ unsigned long long types_sh[TYPED ? kMaxRowTypes : 1];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int bidx = (int)blockIdx.x;
+  const int bidx = C.reverse ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
   int lb = bidx;
   if (C.xcd_shift >= 0) {  // xcd_remap_grouped for a power-of-two run length
     if (bidx < C.xcd_full) {
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(kBlock) void spmv_canon_kernel(SellArgs A, CanonArg
     dot_a = wave_sum_to_lane63(dot_a);
     if (dot.yy) dot_b = wave_sum_to_lane63(dot_b);
     if (lane == kWave - 1) {
-      const int slot = dot.block_offset + (int)blockIdx.x * (kBlock / kWave) + wave;
+      const int slot = dot.block_offset + bidx * (kBlock / kWave) + wave;
       dot.partials[slot] = dot_a;
       if (dot.yy) dot.partials[dot.nblocks_total + slot] = dot_b;
     }
@@ -817,6 +818,7 @@ static void launch_pair(const storm_hip_op *op, int nb, Scal alpha, Scal beta, c
     CanonArgs C;
     for (int k = 0; k < 7; ++k) C.off[k] = op->canon_off[k];
     C.max_gather = (int)(op->n_rows + op->n_halo) + kVecGuard + 2;
+    C.reverse = op->ctx->spmv_reverse;
     C.xcd_shift = -1, C.xcd_full = 0;
     if (group > 1 && (group & (group - 1)) == 0) {
       while ((1 << (C.xcd_shift + 1)) <= group) ++C.xcd_shift;
