@@ -227,7 +227,21 @@ int storm_hip_op_create_csr(storm_hip_ctx *ctx, int64_t n_rows, int64_t n_halo,
  *              structured box in natural ordering) and takes the +-1 neighbours from the adjacent lanes;
  *              5 (opt-in) additionally stores ONE byte per row when the rows' weight words take at most 32
  *              distinct values (a box with spacings exact in binary);
- *              0 always stores fp64 weights and int32 columns. */
+ *              0 always stores fp64 weights and int32 columns.
+ *   spmv_mixed (1): a partitioned operator keeps format 4 for the row groups that read no halo column and
+ *              format-3 records for the others; 0: format 3 throughout.
+ * Run-time switches (A/B knobs; the defaults are the measured best):
+ *   latency_path (1), latency_rows (2^19), latency_cache (1): CG / BiCGStab of a small halo-free operator as ONE
+ *              cooperative kernel per solve; the size limit (latency_rows is read when the operator is built); the
+ *              operator records in registers;
+ *   coop_mgs (1), coop_mgs_min_rows (400 000): GMRES's Gram-Schmidt chain as one cooperative kernel per Arnoldi step;
+ *   fused_reduce (1): engine reductions of at most 256 partial blocks finish in the partials kernel's last block;
+ *   sweep_alternate (1): consecutive streaming kernels of a solve sweep the rows from opposite ends (Infinity Cache);
+ *   spmv_canon_groups (2): 128-row groups per wavefront of the format-4 / 5 kernel;
+ *   generic_solvers (0): 1 sends storm_hip_krylov_solve through the engine even where a fused loop exists;
+ *   fuse_dot, fold_pz, fuse_mgs (1): the fused-reduction variants of the fused loops;
+ *   ipc_streams (2): peer-window halo kernels on the comm stream (2) or on the compute stream (1);
+ *   spmv_xcd_remap (8), spmv_nt_y (1), nontemporal (1), blas1_nt (1), spmv_spw, spmv_variant, graph (0), profile_spmv (0). */
 int storm_hip_ctx_set_option(storm_hip_ctx *ctx, const char *key, int64_t value);
 
 /* Halo plan of a row-partitioned operator.  For neighbour q
