@@ -90,6 +90,7 @@ struct storm_hip_ctx {
   double *d_partials2 = nullptr;      // [kMaxMulti * kStage2] second-stage partials
   double *d_scalars = nullptr;        // [kMaxMulti] results of host-visible reductions
   unsigned long long lat_seq = 0;     // running sequence number of the cooperative Gram-Schmidt chains' all-reduces
+  int *d_tickets = nullptr;           // ticket_device.hpp: self-re-arming counters of the in-kernel reductions
   int *d_fin_counter = nullptr;       // engine: ticket counter of reductions that finish in their last block
   char *d_lat_slots = nullptr;        // latency path: two 256-byte all-reduce slots per block (256 blocks)
   double *h_scalars = nullptr;        // pinned mirror
@@ -118,6 +119,7 @@ struct storm_hip_ctx {
   int64_t opt_coop_mgs_min_rows = 400000;  // ... from this many rows on (below, a launch per step is cheaper than an all-reduce per step)
   int64_t opt_coop_mgs = 1;             // GMRES: the Gram-Schmidt chain of an Arnoldi step as one cooperative kernel (latency.hip)
   int64_t opt_latency_path = 1;         // small operators: CG as one cooperative persistent kernel (latency.hip)
+  int opt_ticket_reduce = 1;            // fused CG / BiCGStab: reductions finish inside the kernels that produce their partials
   int opt_fused_reduce = 1;             // engine: reductions of small operators as ONE launch (the last block runs the final pass)
   int opt_latency_cache = 1;            // ... with the wave's operator records held in registers where they fit
   int64_t opt_latency_rows = 1 << 19;   // ... up to this many rows (a compact copy of the operator is kept for it)
@@ -263,6 +265,11 @@ struct SpmvDot {
   bool yy = false;             // also partial of <y, y>
   double *partials = nullptr;  // [2 * nblocks] layout: [<w,y> blocks..., <y,y> blocks...]
   int *nblocks_out = nullptr;  // host out: number of partial blocks written
+  // Finish the reduction(s) inside the SpMV kernel (ticket_device.hpp): the sums go to out[0] (<w,y>) and out[1]
+  // (<y,y>), no final-pass launch follows.  Honoured by the format-4 / 5 kernel in an unsplit launch;
+  // *ticketed_out tells whether it was.
+  double *out[2] = {nullptr, nullptr};
+  int *ticketed_out = nullptr;
 };
 int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, double *y,
                 const SpmvDot *dot, const int *done, bool accumulate = false);

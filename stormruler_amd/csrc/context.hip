@@ -60,6 +60,8 @@ int storm_hip_ctx_create(int device_id, storm_hip_ctx **out) {
   HIP_TRY(hipHostMalloc((void **)&c->h_scalars, sizeof(double) * kMaxMulti, hipHostMallocDefault));
   HIP_TRY(hipMalloc((void **)&c->d_lat_slots, 2 * 256 * 256 + 256));  // latency.hip: all-reduce slots (two per block) + the gave-up flag
   HIP_TRY(hipMemset(c->d_lat_slots, 0, 2 * 256 * 256 + 256));
+  HIP_TRY(hipMalloc((void **)&c->d_tickets, sizeof(int) * (1 + 2048) * 16));  // ticket_device.hpp: kTicketMaxGroups, kTicketStride
+  HIP_TRY(hipMemset(c->d_tickets, 0, sizeof(int) * (1 + 2048) * 16));
   HIP_TRY(hipMalloc((void **)&c->d_fin_counter, 256));  // krylov.hip: ticket counter of the one-launch reductions
   HIP_TRY(hipMemset(c->d_fin_counter, 0, 256));
   HIP_TRY(hipMalloc((void **)&c->d_state, sizeof(SolverState)));
@@ -86,6 +88,7 @@ int storm_hip_ctx_destroy(storm_hip_ctx *c) {
   (void)hipFree(c->d_scalars);
   (void)hipFree(c->d_lat_slots);
   (void)hipFree(c->d_fin_counter);
+  (void)hipFree(c->d_tickets);
   (void)hipHostFree(c->h_scalars);
   (void)hipFree(c->d_state);
   (void)hipHostFree(c->h_state);
@@ -132,6 +135,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "sweep_alternate")) c->opt_sweep_alternate = value;
   else if (!strcmp(key, "spmv_canon_groups")) c->opt_spmv_canon_groups = value;
   else if (!strcmp(key, "fused_reduce")) c->opt_fused_reduce = (int)value;
+  else if (!strcmp(key, "ticket_reduce")) c->opt_ticket_reduce = (int)value;
   else if (!strcmp(key, "latency_rows")) c->opt_latency_rows = value;
   else if (!strcmp(key, "latency_cache")) c->opt_latency_cache = (int)value;
   else if (!strcmp(key, "nontemporal")) c->opt_nt = value;

@@ -31,6 +31,7 @@
 #include "solver_device.hpp"
 #include "ipc_device.hpp"
 #include "blas1_device.hpp"
+#include "ticket_device.hpp"
 
 namespace storm {
 namespace kry {
@@ -191,7 +192,7 @@ __device__ __forceinline__ unsigned sweep_block(int flags) { return (flags & 2) 
 // A reduction is "partials kernel, then a one-block final pass that also runs the scalar program": two launches, and
 // on the reference's own mesh sizes an iteration is nothing but launches (~4 us each, dependent).  When the partials
 // kernel has few blocks the LAST block to finish does the final pass itself: every block publishes its partial sums
-// with coherent (write-through) stores, waits for their acknowledgement, and takes a ticket from a counter; the block
+// with atomic exchanges (at the point of coherence once they return), and takes a ticket from a counter; the block
 // that draws the last ticket reads all partials back with coherent loads, folds them in the order of
 // reduce_prog_kernel (thread t takes blocks t, t + 256, ...; block_sum256) -- the same bits whichever path ran --
 // writes the registers, runs the scalar program and re-arms the counter.  No cache-wide fence anywhere (an
@@ -216,8 +217,7 @@ __device__ __forceinline__ void publish_and_finish(double *partials, const doubl
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int j = 0; j < KMAX; ++j)
-      if (j < f.k) __hip_atomic_store(partials + (int64_t)j * nb + slot, mine[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the stores above are acknowledged (no cache write-back)
+      if (j < f.k) ticket_publish(partials + (int64_t)j * nb + slot, mine[j]);  // at the point of coherence on return
     const int ticket = __hip_atomic_fetch_add(f.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     is_last = ticket == nb - 1;
   }

@@ -19,6 +19,7 @@
 
 #include "common.hpp"
 #include "solver_device.hpp"
+#include "ticket_device.hpp"
 #include "ipc_device.hpp"
 
 namespace storm {
@@ -211,7 +212,8 @@ __global__ __launch_bounds__(kBlock) void init_residual_kernel(int64_t n, double
 __global__ __launch_bounds__(kBlock) void cg_r_kernel(int64_t n, SolverState *st, double *__restrict__ r,
                                                       const double *__restrict__ z,
                                                       double *__restrict__ partials, int nt,
-                                                      const double *__restrict__ pz_partials, int n_pz, int reverse) {
+                                                      const double *__restrict__ pz_partials, int n_pz, int reverse,
+                                                      TicketArgs tickets) {
   if (st->done) return;
   __shared__ double lds4[4];
   // `reverse`: the blocks sweep the rows from the far end (see the sweep-direction note in storm_hip_solve_cg);
@@ -257,7 +259,19 @@ __global__ __launch_bounds__(kBlock) void cg_r_kernel(int64_t n, SolverState *st
     acc += vr * vr;
   }
   const double s = block_sum256(acc, lds4);
-  if (threadIdx.x == 0) partials[bx] = s;
+  if (tickets.cnt == nullptr) {
+    if (threadIdx.x == 0) partials[bx] = s;
+    return;
+  }
+  // <r, r> finishes here (ticket_device.hpp); the last block runs the scalar step of SolverCg.hpp:110-125 and the
+  // convergence rule: no final-pass launch
+  if (threadIdx.x >= kWave) return;
+  const double mine[1] = {s};
+  double total[1];
+  if (ticket_reduce_wave0<1>(tickets, mine, 1, bx, gridDim.x, total) && threadIdx.x == 0) {
+    st->s[S_GAMMA_NEW] = total[0];
+    do_step(STEP_CG_RR, st, GmresDev{});
+  }
 }
 
 // Five streams (3 loads, 2 stores): measured best with ONE 16-byte access per stream and thread in flight
@@ -316,11 +330,23 @@ __global__ __launch_bounds__(kBlock) void bicg_update_kernel(int64_t n, SolverSt
                                                              double *__restrict__ r, const double *__restrict__ p,
                                                              const double *__restrict__ w,
                                                              const double *__restrict__ rt,
-                                                             double *__restrict__ partials, int nt, int reverse) {
+                                                             double *__restrict__ partials, int nt, int reverse,
+                                                             TicketArgs tickets) {
   if (st->done) return;
   const unsigned bx = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;  // the same rows and slots, dealt out from the far end
   __shared__ double lds4[4];
-  const double alpha = st->s[S_ALPHA], omega = st->s[S_OMEGA];
+  // With tickets the SpMV before this kernel left the finished sums in the slab and no step kernel ran: every
+  // block forms alpha (first half-step, :139) / omega (second, :159-160) itself, block 0 keeps it for later readers.
+  double alpha = st->s[S_ALPHA], omega = st->s[S_OMEGA];
+  if (tickets.cnt != nullptr) {
+    if (!SECOND) {
+      alpha = safe_divide(st->s[S_RHO], st->s[S_RTV]);
+      if (blockIdx.x == 0 && threadIdx.x == 0) st->s[S_ALPHA] = alpha;
+    } else {
+      omega = safe_divide(st->s[S_TR], st->s[S_TT]);
+      if (blockIdx.x == 0 && threadIdx.x == 0) st->s[S_OMEGA] = omega;
+    }
+  }
   double acc_rr = 0.0, acc_rho = 0.0;
   const int64_t n2 = n >> 1;
   double2v *x2 = reinterpret_cast<double2v *>(x), *r2 = reinterpret_cast<double2v *>(r);
@@ -375,7 +401,18 @@ __global__ __launch_bounds__(kBlock) void bicg_update_kernel(int64_t n, SolverSt
   if (SECOND) {
     const double s0 = block_sum256(acc_rr, lds4);
     const double s1 = block_sum256(acc_rho, lds4);
-    if (threadIdx.x == 0) partials[bx] = s0, partials[gridDim.x + bx] = s1;
+    if (tickets.cnt == nullptr) {
+      if (threadIdx.x == 0) partials[bx] = s0, partials[gridDim.x + bx] = s1;
+      return;
+    }
+    if (threadIdx.x >= kWave) return;
+    const double mine[2] = {s0, s1};
+    double total[2];
+    if (ticket_reduce_wave0<2>(tickets, mine, 2, bx, gridDim.x, total) && threadIdx.x == 0) {
+      st->s[S_RR] = total[0], st->s[S_RHO_NEW] = total[1];
+      st->s[S_OMEGA] = omega;  // (block 0's store of the same value need not be visible to this block yet)
+      do_step(STEP_BICG_END, st, GmresDev{});  // :164, :116-118 and the convergence rule
+    }
   }
 }
 
@@ -539,12 +576,19 @@ struct Driver {
   }
 
   // y = A x, optionally with fused <w, y> / <y, y> partials.  Returns nblocks of partials (0 = not fused).
-  int apply(const double *x, double *y, const double *dot_w, bool dot_yy, int *nblocks, bool predicated = true) {
+  // out0 / out1 (slab slots; -1: none): where an in-kernel (ticketed) reduction may leave <w,y> / <y,y>;
+  // *ticketed tells whether it did -- then there are no partials to finish (*nblocks is still their count).
+  int apply(const double *x, double *y, const double *dot_w, bool dot_yy, int *nblocks, bool predicated = true,
+            int out0 = -1, int out1 = -1, int *ticketed = nullptr) {
     SpmvDot sd;
     sd.w = dot_w;
     sd.yy = dot_yy;
     sd.partials = c->d_partials;
     sd.nblocks_out = nblocks;
+    if (out0 >= 0) sd.out[0] = slot(out0);
+    if (out1 >= 0) sd.out[1] = slot(out1);
+    sd.ticketed_out = ticketed;
+    if (ticketed) *ticketed = 0;
     const bool want = (dot_w != nullptr || dot_yy) && c->opt_fuse_dot != 0;
     if (!want && nblocks) *nblocks = 0;
     return spmv_launch(op, host_scal(alpha), host_scal(beta), x, y, want ? &sd : nullptr,
@@ -817,15 +861,20 @@ int storm_hip_solve_cg(const storm_hip_op *op, double alpha, double beta, const 
   // Blocks keep their rows and their partial slots: the same bits either way.
   const bool sweep = c->opt_sweep_alternate != 0 && c->comm == nullptr;
   const int nt_stream = (int)(c->opt_blas1_nt != 0 && !(sweep && c->opt_sweep_alternate == 2));
+  // Reductions that finish inside the kernels producing their partials (ticket_device.hpp), one rank: an iteration
+  // is then three launches -- SpMV (+ <p,z>), cg_r (+ <r,r>, beta, the convergence rule), cg_xp.
+  const bool tick = c->opt_ticket_reduce != 0 && c->comm == nullptr && nbv <= kTicketGroup * kTicketMaxGroups;
   auto enqueue_iteration = [&]() -> int {
     const int q = sweep ? (int)(cur_it & 1) : 0;
     // z = A p, <p,z>                                  SolverCg.hpp:96-97
     c->spmv_reverse = q;
-    const int st_apply = d.apply(p, z, p, false, &nb);
+    int pz_done = 0;  // <p,z> finished inside the SpMV kernel (tickets): cg_r reads it from the slab
+    const int st_apply = d.apply(p, z, p, false, &nb, true, tick ? (int)S_PZ : -1, -1, &pz_done);
     c->spmv_reverse = 0;
     STORM_TRY(st_apply);
     const double *pz_partials = nullptr;
-    if (nb == 0) {  // operator has a CSR tail: separate dot
+    if (pz_done) {
+    } else if (nb == 0) {  // operator has a CSR tail: separate dot
       const double *bs[1] = {z};
       STORM_TRY(k_multi_dot(c, p, bs, 1, n, d.slot(S_PZ), d.done));
       if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, d.slot(S_PZ), 1));
@@ -841,9 +890,10 @@ int storm_hip_solve_cg(const storm_hip_op *op, double alpha, double beta, const 
     }
     // r -= alpha z; gamma = <r,r>                     SolverCg.hpp:97,99,115
     hipLaunchKernelGGL(cg_r_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, r, z, c->d_partials,
-                       nt_stream, pz_partials, (int)kStage2, sweep ? 1 - q : 0);
+                       nt_stream, pz_partials, (int)kStage2, sweep ? 1 - q : 0,
+                       tick ? TicketArgs{c->d_tickets, c->d_partials, c->d_partials2} : TicketArgs{nullptr, nullptr, nullptr});
     HIP_TRY(hipGetLastError());
-    {
+    if (!tick) {
       const int slots[1] = {S_GAMMA_NEW};
       STORM_TRY(d.finish(nbv, 1, slots, STEP_CG_RR));
     }
@@ -899,17 +949,23 @@ int storm_hip_solve_bicgstab(const storm_hip_op *op, double alpha, double beta, 
   const bool sweep = c->opt_sweep_alternate != 0 && c->comm == nullptr && c->opt_graph == 0;
   int dir = 1;
   auto flip = [&]() -> int { return sweep ? (dir ^= 1) : 0; };
-  auto apply_dir = [&](const double *xin, double *yout, const double *w, bool yy) -> int {
+  // ... and reductions finished in-kernel (see storm_hip_solve_cg): five launches per iteration instead of eleven.
+  const bool tick = c->opt_ticket_reduce != 0 && c->comm == nullptr && nbv <= kTicketGroup * kTicketMaxGroups;
+  const TicketArgs no_tickets{nullptr, nullptr, nullptr}, tickets{c->d_tickets, c->d_partials, c->d_partials2};
+  int ticketed = 0;
+  auto apply_dir = [&](const double *xin, double *yout, const double *w, bool yy, int out0, int out1) -> int {
     c->spmv_reverse = flip();
-    const int st_apply = d.apply(xin, yout, w, yy, &nb);
+    const int st_apply = d.apply(xin, yout, w, yy, &nb, true, tick ? out0 : -1, tick ? out1 : -1, &ticketed);
     c->spmv_reverse = 0;
     return st_apply;
   };
   // Everything of an iteration after the p update (iteration-invariant arguments).
   auto enqueue_rest = [&]() -> int {
     // v = A p; alpha = rho / <rt,v>                   :137-139
-    STORM_TRY(apply_dir(p, v, rt, false));
-    if (nb == 0) {
+    STORM_TRY(apply_dir(p, v, rt, false, (int)S_RTV, -1));
+    const bool alpha_in_kernel = ticketed != 0;  // <rt,v> is in the slab; bicg_update forms alpha itself
+    if (alpha_in_kernel) {
+    } else if (nb == 0) {
       const double *bs[1] = {v};
       STORM_TRY(k_multi_dot(c, rt, bs, 1, n, d.slot(S_RTV), d.done));
       if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, d.slot(S_RTV), 1));
@@ -921,11 +977,13 @@ int storm_hip_solve_bicgstab(const storm_hip_op *op, double alpha, double beta, 
     }
     // r -= alpha v   (x += alpha p is applied in the second half-step)      :140-141
     hipLaunchKernelGGL(bicg_update_kernel<false>, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, x->d, r, p, v,
-                       rt, c->d_partials, (int)(c->opt_blas1_nt != 0), flip());
+                       rt, c->d_partials, (int)(c->opt_blas1_nt != 0), flip(), alpha_in_kernel ? tickets : no_tickets);
     HIP_TRY(hipGetLastError());
     // t = A r; omega = <t,r> / <t,t>                  :158-160
-    STORM_TRY(apply_dir(r, t, r, true));
-    if (nb == 0) {
+    STORM_TRY(apply_dir(r, t, r, true, (int)S_TR, (int)S_TT));
+    const bool omega_in_kernel = ticketed != 0;
+    if (omega_in_kernel) {
+    } else if (nb == 0) {
       const double *bs[2] = {r, t};
       STORM_TRY(k_multi_dot(c, t, bs, 2, n, d.slot(S_TR), d.done));
       if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, d.slot(S_TR), 2));
@@ -937,9 +995,9 @@ int storm_hip_solve_bicgstab(const storm_hip_op *op, double alpha, double beta, 
     }
     // x = (x + alpha p) + omega r; r -= omega t; |r|, <rt,r>    :140, :161-164 (+ :116 of the next iteration)
     hipLaunchKernelGGL(bicg_update_kernel<true>, dim3(nbv2), dim3(kBlock), 0, c->stream, n, d.st, x->d, r,
-                       p, t, rt, c->d_partials, (int)(c->opt_blas1_nt != 0), flip());
+                       p, t, rt, c->d_partials, (int)(c->opt_blas1_nt != 0), flip(), omega_in_kernel ? tickets : no_tickets);
     HIP_TRY(hipGetLastError());
-    {
+    if (!omega_in_kernel) {
       const int slots[2] = {S_RR, S_RHO_NEW};
       STORM_TRY(d.finish(nbv2, 2, slots, STEP_BICG_END));
     }

@@ -54,6 +54,7 @@
 #include <hip/hip_ext.h>
 
 #include "common.hpp"
+#include "ticket_device.hpp"
 
 namespace storm {
 
@@ -91,6 +92,11 @@ struct DotArgs {
   int yy;
   int nblocks_total;  // stride between the two partial arrays
   int block_offset;   // where this launch's blocks start
+  // tickets != null (format-4 / 5 kernel, unsplit launch): the reduction finishes in the kernel (ticket_device.hpp);
+  // `partials` then holds one partial per BLOCK, part2 the groups' sums, and the totals go to out0 / out1
+  int *tickets = nullptr;
+  double *part2 = nullptr;
+  double *out0 = nullptr, *out1 = nullptr;
 };
 
 // Blocks are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8), each with a private
@@ -734,10 +740,25 @@ __global__ __launch_bounds__(kBlock) void spmv_canon_kernel(SellArgs A, CanonArg
   if (DOT) {
     dot_a = wave_sum_to_lane63(dot_a);
     if (dot.yy) dot_b = wave_sum_to_lane63(dot_b);
-    if (lane == kWave - 1) {
-      const int slot = dot.block_offset + bidx * (kBlock / kWave) + wave;
-      dot.partials[slot] = dot_a;
-      if (dot.yy) dot.partials[dot.nblocks_total + slot] = dot_b;
+    if (dot.tickets == nullptr) {
+      if (lane == kWave - 1) {
+        const int slot = dot.block_offset + bidx * (kBlock / kWave) + wave;
+        dot.partials[slot] = dot_a;
+        if (dot.yy) dot.partials[dot.nblocks_total + slot] = dot_b;
+      }
+    } else {  // the reduction finishes here: block partial, then two levels of tickets
+      __shared__ double wave_part[2 * (kBlock / kWave)];
+      if (lane == kWave - 1) wave_part[wave] = dot_a, wave_part[kBlock / kWave + wave] = dot.yy ? dot_b : 0.0;
+      __syncthreads();
+      if (wave != 0) return;
+      const double mine[2] = {(wave_part[0] + wave_part[1]) + (wave_part[2] + wave_part[3]),
+                              (wave_part[4] + wave_part[5]) + (wave_part[6] + wave_part[7])};
+      double total[2];
+      const TicketArgs t{dot.tickets, dot.partials, dot.part2};
+      if (ticket_reduce_wave0<2>(t, mine, dot.yy ? 2 : 1, (unsigned)bidx, gridDim.x, total) && lane == 0) {
+        *dot.out0 = total[0];
+        if (dot.yy) *dot.out1 = total[1];
+      }
     }
   }
 }
@@ -973,6 +994,14 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
     dot = DotArgs{sd->w, sd->partials, sd->yy ? 1 : 0, 4 * nb_total, 0};  // one partial per wave
   }
   if (sd && sd->nblocks_out) *sd->nblocks_out = fuse_dot ? 4 * nb_total : 0;
+  if (sd && sd->ticketed_out) *sd->ticketed_out = 0;
+  if (fuse_dot && !split && op->pair >= 2 && sd->out[0] != nullptr && c->opt_ticket_reduce != 0 && c->comm == nullptr &&
+      c->opt_profile_spmv == 0 && nb_total <= kTicketGroup * kTicketMaxGroups && 2 * nb_total <= c->partials_capacity &&
+      (!sd->yy || sd->out[1] != nullptr)) {
+    dot.tickets = c->d_tickets, dot.part2 = c->d_partials2, dot.out0 = sd->out[0], dot.out1 = sd->out[1];
+    dot.nblocks_total = nb_total;
+    if (sd->ticketed_out) *sd->ticketed_out = 1;
+  }
 
   if (!split) {
     STORM_TRY(launch_range(op, alpha, beta, x, y, nullptr, op->n_slices, dot, fuse_dot, done, accumulate));

@@ -1,0 +1,102 @@
+// A reduction that finishes inside the kernel that produced its partial sums, for ANY grid size: two levels of
+// tickets.  Blocks form groups of kTicketGroup; the last block of a group to arrive folds the group's partials, the
+// last group-folder to arrive folds the groups' sums and owns the result -- it can run the scalar step of the
+// solver right there, and the launch of a separate final-pass kernel (~4-5 us, dependent) disappears.
+//
+// Protocol (no cache-wide fence anywhere -- an agent-scope release writes back the whole L2 on this chip):
+//   * a partial sum is published by lane 0 with an atomic EXCHANGE whose returned value it waits for: a returning
+//     read-modify-write has been performed at the point of coherence (a plain write-through store is acknowledged
+//     by the XCD's L2 before the data has left it -- under load a reader on another XCD could still miss it: seen
+//     as a rare wrong sum at 256^3); only then it draws its ticket with a relaxed agent-scope atomic add; whoever
+//     draws the last ticket therefore finds every partial at the coherence point and reads it with coherent loads;
+//   * counters re-arm themselves (the drawer of the last ticket stores 0), so a buffer zeroed once serves forever;
+//   * only wave 0 of a block takes part (the other waves retire as soon as the block's partial is formed);
+//   * fixed folding order (lane i takes entry i, i + 64, ...; xor-shuffle tree): run-to-run reproducible.
+#pragma once
+#include "common.hpp"
+
+namespace storm {
+
+constexpr int kTicketGroup = 64;
+constexpr int kTicketStride = 16;          // ints between counters (one 64-byte line each)
+constexpr int kTicketMaxGroups = 2048;     // 131 072 blocks
+
+struct TicketArgs {
+  int *cnt;       // [1 + kTicketMaxGroups] counters, kTicketStride apart; null = tickets off
+  double *part1;  // [K][n_blocks] block partials
+  double *part2;  // [K][n_groups] group partials
+};
+
+// Store `v` so that it is at the point of coherence when the function returns.
+__device__ __forceinline__ void ticket_publish(double *p, double v) {
+#ifdef STORM_TICKET_STORE_EXPERIMENT  // (what the first version did; kept to reproduce the failure)
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  return;
+#endif
+  const unsigned long long old = __hip_atomic_exchange(reinterpret_cast<unsigned long long *>(p),
+                                                       (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+  // the exchange must RETURN (a returning read-modify-write has been performed at the point of coherence) before
+  // anything later is issued: the empty statement consumes its result and is a compiler barrier for memory
+  asm volatile("" : : "v"(old) : "memory");
+}
+__device__ __forceinline__ double ticket_wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+
+// Wave 0 of every block calls this (all 64 lanes) with the block's partials `mine[0 .. k)` (k <= KMAX).
+// Returns true in wave 0 of exactly one block, the last to arrive, with total[j] valid in all lanes.
+template <int KMAX>
+__device__ __forceinline__ bool ticket_reduce_wave0(const TicketArgs &t, const double (&mine)[KMAX], int k, unsigned bx,
+                                                    unsigned nb, double (&total)[KMAX]) {
+  const unsigned lane = threadIdx.x & (kWave - 1);
+  const unsigned g = bx / kTicketGroup, ng = (nb + kTicketGroup - 1) / kTicketGroup;
+  const unsigned gsize = (nb - g * kTicketGroup) < (unsigned)kTicketGroup ? (nb - g * kTicketGroup) : (unsigned)kTicketGroup;
+  int go = 0;
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j)
+      if (j < k) ticket_publish(t.part1 + (size_t)j * nb + bx, mine[j]);
+    int *c = t.cnt + (size_t)(1 + g) * kTicketStride;
+    if (__hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gsize - 1) {
+      __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      go = 1;
+    }
+  }
+  go = __shfl(go, 0, kWave);
+  if (!go) return false;
+  double gp[KMAX];
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) {
+    double v = 0.0;
+    if (j < k && lane < gsize)
+      v = __hip_atomic_load(t.part1 + (size_t)j * nb + (size_t)g * kTicketGroup + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    gp[j] = ticket_wave_sum(v);
+  }
+  go = 0;
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j)
+      if (j < k) ticket_publish(t.part2 + (size_t)j * ng + g, gp[j]);
+    if (__hip_atomic_fetch_add(t.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)ng - 1) {
+      __hip_atomic_store(t.cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      go = 1;
+    }
+  }
+  go = __shfl(go, 0, kWave);
+  if (!go) return false;
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) {
+    double v = 0.0;
+    if (j < k)
+      for (unsigned i = lane; i < ng; i += kWave)
+        v += __hip_atomic_load(t.part2 + (size_t)j * ng + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    total[j] = ticket_wave_sum(v);
+  }
+  return true;
+}
+
+}  // namespace storm

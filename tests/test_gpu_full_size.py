@@ -144,3 +144,30 @@ def test_bicgstab_256_within_the_bound_summation_order_allows(env, poisson256, g
     idx, ref_x = np.array(fx["sample_cells"]), np.array(fx["x_samples"])
     assert np.max(np.abs(x[idx] - ref_x) / np.abs(ref_x)) <= 1e-6
     assert abs(np.sqrt(np.sum(x * x)) - fx["x_norm2"]) <= 1e-6 * fx["x_norm2"]
+
+
+@pytest.mark.parametrize("kind", ["cg", "bicgstab"])
+def test_in_kernel_reductions_are_reproducible_at_full_size(env, poisson256, kind):
+    """The fused loops finish their reductions inside the kernels that produce the partial sums (two levels of
+    tickets over up to 16 384 blocks, csrc/ticket_device.hpp).  A partial that a block published but the folding
+    block did not yet see would show as a rare wrong sum: 1 500 iterations with the tolerances off, twice -- the
+    residual histories (4 500 .. 7 500 ticketed reductions each) must agree BITWISE, and with the two-launch path
+    (`ticket_reduce = 0`: other folding order) to rounding."""
+    api, mesh, ctx = env
+    g, mat = poisson256
+    op = api.HipStencilOperator(mat, -1.0, 0.0)
+    b = api.DeviceVector(ctx, g.n_cells)
+    api.fill_with(b, 1.0)
+    runs = []
+    for ticket in (1, 1, 0):
+        ctx.set_option("ticket_reduce", ticket)
+        s = api.CgSolver() if kind == "cg" else api.BiCgStabSolver()
+        s.record_history, s.num_iterations = True, 1500 if kind == "cg" else 60
+        s.absolute_error_tolerance = s.relative_error_tolerance = 0.0
+        x = api.DeviceVector(ctx, g.n_cells)
+        s.solve(x, b, op)
+        runs.append(np.array(s.history))
+    ctx.set_option("ticket_reduce", 1)
+    assert np.array_equal(runs[0], runs[1])
+    k = 400 if kind == "cg" else 12  # (beyond, rounding differences have grown: see the module docstring)
+    assert np.allclose(runs[0][:k], runs[2][:k], rtol=1e-6 if kind == "cg" else 1e-5)

@@ -250,3 +250,27 @@ def test_cooperative_gram_schmidt_chain_matches_the_kernel_per_step_path(env, sh
         assert abs(runs[(1, 0)][1] - ref.iterations) <= max(2, int(0.05 * ref.iterations))
         assert np.linalg.norm(runs[(1, 0)][3] - ref.x) <= 1e-7 * np.linalg.norm(ref.x)
     mat.close()
+
+
+@pytest.mark.parametrize("kind", ["cg", "bicgstab"])
+@pytest.mark.parametrize("shape", [(64, 64, 64), (80, 80, 80), (100, 100, 64)])
+def test_latency_path_is_bitwise_reproducible(env, kind, shape):
+    """Rows published by one block are gathered by others behind an all-reduce only: a row that a gathering wave
+    saw too early would show as a run-to-run difference.  2 000 iterations (4 000 .. 6 000 synchronisation points,
+    every block's rows republished each time) with the tolerances off, three times: bitwise equal histories."""
+    api, mesh, oracle, ctx = env
+    g = mesh.structured_box(*shape)
+    ctx.set_option("latency_rows", 1 << 21)
+    mat = api.StencilMatrix.from_face_graph(ctx, g)
+    ctx.set_option("latency_rows", 1 << 19)
+    op = api.HipStencilOperator(mat, -1.0, 0.0)
+    b_host = 1.0 + 0.25 * np.sin(0.01 * np.arange(g.n_cells))
+    runs = []
+    for _ in range(3):
+        f = _cg if kind == "cg" else _bicgstab
+        ok, s, x = f(api, ctx, op, b_host, True, num_iterations=2000 if kind == "cg" else 120,
+                     relative_error_tolerance=0.0, absolute_error_tolerance=0.0)
+        runs.append((np.array(s.history), x))
+    for h, x in runs[1:]:
+        assert np.array_equal(h, runs[0][0]) and np.array_equal(x, runs[0][1])
+    mat.close()
