@@ -91,7 +91,6 @@ struct storm_hip_ctx {
   double *d_scalars = nullptr;        // [kMaxMulti] results of host-visible reductions
   unsigned long long lat_seq = 0;     // running sequence number of the cooperative Gram-Schmidt chains' all-reduces
   int *d_tickets = nullptr;           // ticket_device.hpp: self-re-arming counters of the in-kernel reductions
-  int *d_fin_counter = nullptr;       // engine: ticket counter of reductions that finish in their last block
   char *d_lat_slots = nullptr;        // latency path: two 256-byte all-reduce slots per block (256 blocks)
   double *h_scalars = nullptr;        // pinned mirror
   storm::SolverState *d_state = nullptr;
@@ -120,7 +119,7 @@ struct storm_hip_ctx {
   int64_t opt_coop_mgs = 1;             // GMRES: the Gram-Schmidt chain of an Arnoldi step as one cooperative kernel (latency.hip)
   int64_t opt_latency_path = 1;         // small operators: CG as one cooperative persistent kernel (latency.hip)
   int opt_ticket_reduce = 1;            // fused CG / BiCGStab: reductions finish inside the kernels that produce their partials
-  int opt_fused_reduce = 1;             // engine: reductions of small operators as ONE launch (the last block runs the final pass)
+  int opt_fused_reduce = 1;             // engine: a reduction is ONE launch (its last block folds the partials and runs the scalar program)
   int opt_latency_cache = 1;            // ... with the wave's operator records held in registers where they fit
   int64_t opt_latency_rows = 1 << 19;   // ... up to this many rows (a compact copy of the operator is kept for it)
   int64_t opt_ipc_streams = 2;          // peer-window halo exchange: 2 = on the comm stream beside the interior rows, 1 = on the compute stream around them

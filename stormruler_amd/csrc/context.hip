@@ -62,8 +62,6 @@ int storm_hip_ctx_create(int device_id, storm_hip_ctx **out) {
   HIP_TRY(hipMemset(c->d_lat_slots, 0, 2 * 256 * 256 + 256));
   HIP_TRY(hipMalloc((void **)&c->d_tickets, sizeof(int) * (1 + 2048) * 16));  // ticket_device.hpp: kTicketMaxGroups, kTicketStride
   HIP_TRY(hipMemset(c->d_tickets, 0, sizeof(int) * (1 + 2048) * 16));
-  HIP_TRY(hipMalloc((void **)&c->d_fin_counter, 256));  // krylov.hip: ticket counter of the one-launch reductions
-  HIP_TRY(hipMemset(c->d_fin_counter, 0, 256));
   HIP_TRY(hipMalloc((void **)&c->d_state, sizeof(SolverState)));
   HIP_TRY(hipMemset(c->d_state, 0, sizeof(SolverState)));
   HIP_TRY(hipHostMalloc((void **)&c->h_state, sizeof(SolverState), hipHostMallocDefault));
@@ -87,7 +85,6 @@ int storm_hip_ctx_destroy(storm_hip_ctx *c) {
   (void)hipFree(c->d_partials2);
   (void)hipFree(c->d_scalars);
   (void)hipFree(c->d_lat_slots);
-  (void)hipFree(c->d_fin_counter);
   (void)hipFree(c->d_tickets);
   (void)hipHostFree(c->h_scalars);
   (void)hipFree(c->d_state);

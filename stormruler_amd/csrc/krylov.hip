@@ -188,50 +188,33 @@ __global__ void sprog_kernel(double *S, SolverState *st, SProg prog, int nscatte
 // blocks out from the far end of the rows (the engine's sweep-direction scheme; a block keeps its rows and slots).
 __device__ __forceinline__ unsigned sweep_block(int flags) { return (flags & 2) ? gridDim.x - 1 - blockIdx.x : blockIdx.x; }
 
-// ---- reductions in ONE launch (small operators) ---------------------------------------------------------------
+// ---- reductions in ONE launch -----------------------------------------------------------------------------------
 // A reduction is "partials kernel, then a one-block final pass that also runs the scalar program": two launches, and
-// on the reference's own mesh sizes an iteration is nothing but launches (~4 us each, dependent).  When the partials
-// kernel has few blocks the LAST block to finish does the final pass itself: every block publishes its partial sums
-// with atomic exchanges (at the point of coherence once they return), and takes a ticket from a counter; the block
-// that draws the last ticket reads all partials back with coherent loads, folds them in the order of
-// reduce_prog_kernel (thread t takes blocks t, t + 256, ...; block_sum256) -- the same bits whichever path ran --
-// writes the registers, runs the scalar program and re-arms the counter.  No cache-wide fence anywhere (an
-// agent-scope release would write back the whole L2, see latency.hip).
+// on the reference's own mesh sizes an iteration is nothing but launches (~4 us each, dependent).  Here the partials
+// kernel finishes the job itself (ticket_device.hpp: two levels of tickets, partials published by awaited atomic
+// exchange, fixed folding order): the block that draws the last ticket holds the sums, writes the registers and
+// runs the scalar program.  The engine holds the partials kernel back until the program behind it is complete.
 struct FinalPass {
-  int *counter;  // zero between launches
+  int *tickets;   // ticket_device.hpp counters (self re-arming)
+  double *part2;  // [k][groups] group sums
   int k;
   RedOut out;
   double *S;
   SolverState *st;
   SProg prog;
 };
-constexpr int kFinalPassMaxBlocks = 256;
 
-// `mine[j]` (valid in thread 0): this block's partial of sum j.  Returns after the final pass in the last block.
+// `mine[j]`: this block's partial of sum j (the same value in every thread).
 template <int KMAX>
 __device__ __forceinline__ void publish_and_finish(double *partials, const double (&mine)[KMAX], const FinalPass &f,
                                                    unsigned slot) {
-  __shared__ int is_last;
-  __shared__ double lds4f[4];
-  const int nb = (int)gridDim.x;
-  if (threadIdx.x == 0) {
+  if (threadIdx.x >= kWave) return;
+  double total[KMAX];
+  const TicketArgs t{f.tickets, partials, f.part2};
+  if (ticket_reduce_wave0<KMAX>(t, mine, f.k, slot, gridDim.x, total) && threadIdx.x == 0) {
 #pragma unroll
     for (int j = 0; j < KMAX; ++j)
-      if (j < f.k) ticket_publish(partials + (int64_t)j * nb + slot, mine[j]);  // at the point of coherence on return
-    const int ticket = __hip_atomic_fetch_add(f.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = ticket == nb - 1;
-  }
-  __syncthreads();
-  if (!is_last) return;
-  for (int j = 0; j < f.k; ++j) {
-    const double *p = partials + (int64_t)j * nb;
-    double v = 0.0;
-    for (int i = threadIdx.x; i < nb; i += kBlock) v += __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const double sum = block_sum256(v, lds4f);
-    if (threadIdx.x == 0) f.S[f.out.idx[j]] = sum;
-  }
-  if (threadIdx.x == 0) {
-    __hip_atomic_store(f.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (j < f.k) f.S[f.out.idx[j]] = total[j];
     if (f.prog.n > 0) exec_prog(f.prog, f.S, f.st);
   }
 }
@@ -524,7 +507,7 @@ struct KrylovEngine {
       return;
     }
     if (red_pending && pend != PEND_NONE) {
-      const FinalPass f{c->d_fin_counter, red_k, red_out, S, d_st, prog};
+      const FinalPass f{c->d_tickets, c->d_partials2, red_k, red_out, S, d_st, prog};
       const int nti = pend_flags;
       const dim3 g(red_nb), b(kBlock);
       if (pend == PEND_DOTS) {
@@ -604,7 +587,7 @@ struct KrylovEngine {
     if (one_launch(k)) {  // small: the partials kernel goes out at flush(), with the final pass in its last block
       int nb = stream_blocks(n);
       if ((int64_t)nb * k > c->partials_capacity) nb = (int)(c->partials_capacity / k);
-      if (nb <= kFinalPassMaxBlocks) {
+      if ((int64_t)k * ((nb + kTicketGroup - 1) / kTicketGroup) <= (int64_t)kMaxMulti * kStage2) {
         pend = PEND_DOTS, pend_a = a->d, pend_flags = stream_flags();
         for (int j = 0; j < kDotChunk; ++j) pend_bs.b[j] = bs[j < k ? j : 0];
         red_nb = nb, red_k = k, red_pending = true;
@@ -700,7 +683,7 @@ struct KrylovEngine {
     nb = std::min<int64_t>(nb, std::min<int64_t>(32768, c->partials_capacity / 2));
     const double *wd = (reg_yw >= 0 && wv != nullptr) ? wv->d : nullptr;
     const int nti = stream_flags();
-    if (one_launch(2) && nb <= kFinalPassMaxBlocks && (reg_yy >= 0 || wd != nullptr)) {
+    if (one_launch(2) && (reg_yy >= 0 || wd != nullptr)) {
       pend = PEND_LIN_DOT, pend_lin = a, pend_nt = nt, pend_w = wd, pend_yy = (int)(reg_yy >= 0), pend_flags = nti;
       red_k = 0;
       if (reg_yy >= 0) red_out.idx[red_k++] = reg_yy;
