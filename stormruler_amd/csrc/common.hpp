@@ -90,6 +90,7 @@ struct storm_hip_ctx {
   double *d_partials2 = nullptr;      // [kMaxMulti * kStage2] second-stage partials
   double *d_scalars = nullptr;        // [kMaxMulti] results of host-visible reductions
   unsigned long long lat_seq = 0;     // running sequence number of the cooperative Gram-Schmidt chains' all-reduces
+  double *d_ticket_sums = nullptr;    // ... and the groups' sums (a buffer of their own: d_partials2 may hold a first pass a kernel is still reading)
   int *d_tickets = nullptr;           // ticket_device.hpp: self-re-arming counters of the in-kernel reductions
   char *d_lat_slots = nullptr;        // latency path: two 256-byte all-reduce slots per block (256 blocks)
   double *h_scalars = nullptr;        // pinned mirror

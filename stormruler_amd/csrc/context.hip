@@ -60,6 +60,7 @@ int storm_hip_ctx_create(int device_id, storm_hip_ctx **out) {
   HIP_TRY(hipHostMalloc((void **)&c->h_scalars, sizeof(double) * kMaxMulti, hipHostMallocDefault));
   HIP_TRY(hipMalloc((void **)&c->d_lat_slots, 2 * 256 * 256 + 256));  // latency.hip: all-reduce slots (two per block) + the gave-up flag
   HIP_TRY(hipMemset(c->d_lat_slots, 0, 2 * 256 * 256 + 256));
+  HIP_TRY(hipMalloc((void **)&c->d_ticket_sums, sizeof(double) * 8 * 2048));  // [k <= 8][kTicketMaxGroups] group sums
   HIP_TRY(hipMalloc((void **)&c->d_tickets, sizeof(int) * (1 + 2048) * 16));  // ticket_device.hpp: kTicketMaxGroups, kTicketStride
   HIP_TRY(hipMemset(c->d_tickets, 0, sizeof(int) * (1 + 2048) * 16));
   HIP_TRY(hipMalloc((void **)&c->d_state, sizeof(SolverState)));
@@ -86,6 +87,7 @@ int storm_hip_ctx_destroy(storm_hip_ctx *c) {
   (void)hipFree(c->d_scalars);
   (void)hipFree(c->d_lat_slots);
   (void)hipFree(c->d_tickets);
+  (void)hipFree(c->d_ticket_sums);
   (void)hipHostFree(c->h_scalars);
   (void)hipFree(c->d_state);
   (void)hipHostFree(c->h_state);

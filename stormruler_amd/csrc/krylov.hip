@@ -507,7 +507,7 @@ struct KrylovEngine {
       return;
     }
     if (red_pending && pend != PEND_NONE) {
-      const FinalPass f{c->d_tickets, c->d_partials2, red_k, red_out, S, d_st, prog};
+      const FinalPass f{c->d_tickets, c->d_ticket_sums, red_k, red_out, S, d_st, prog};
       const int nti = pend_flags;
       const dim3 g(red_nb), b(kBlock);
       if (pend == PEND_DOTS) {
@@ -587,7 +587,7 @@ struct KrylovEngine {
     if (one_launch(k)) {  // small: the partials kernel goes out at flush(), with the final pass in its last block
       int nb = stream_blocks(n);
       if ((int64_t)nb * k > c->partials_capacity) nb = (int)(c->partials_capacity / k);
-      if ((int64_t)k * ((nb + kTicketGroup - 1) / kTicketGroup) <= (int64_t)kMaxMulti * kStage2) {
+      if ((int64_t)k * ((nb + kTicketGroup - 1) / kTicketGroup) <= (int64_t)8 * kTicketMaxGroups) {
         pend = PEND_DOTS, pend_a = a->d, pend_flags = stream_flags();
         for (int j = 0; j < kDotChunk; ++j) pend_bs.b[j] = bs[j < k ? j : 0];
         red_nb = nb, red_k = k, red_pending = true;

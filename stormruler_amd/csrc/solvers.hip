@@ -864,12 +864,15 @@ int storm_hip_solve_cg(const storm_hip_op *op, double alpha, double beta, const 
   // Reductions that finish inside the kernels producing their partials (ticket_device.hpp), one rank: an iteration
   // is then three launches -- SpMV (+ <p,z>), cg_r (+ <r,r>, beta, the convergence rule), cg_xp.
   const bool tick = c->opt_ticket_reduce != 0 && c->comm == nullptr && nbv <= kTicketGroup * kTicketMaxGroups;
+  // (<p,z> inside the SpMV only where it replaces a whole final-pass launch: with more per-wave partials than one
+  // pass folds, the first pass + the fold inside cg_r cost what the ticket tail would add to the SpMV)
+  const bool tick_spmv = tick && (4 * (int64_t)spmv_grid_blocks(op) <= kSinglePassPartials || c->opt_fold_pz == 0);
   auto enqueue_iteration = [&]() -> int {
     const int q = sweep ? (int)(cur_it & 1) : 0;
     // z = A p, <p,z>                                  SolverCg.hpp:96-97
     c->spmv_reverse = q;
     int pz_done = 0;  // <p,z> finished inside the SpMV kernel (tickets): cg_r reads it from the slab
-    const int st_apply = d.apply(p, z, p, false, &nb, true, tick ? (int)S_PZ : -1, -1, &pz_done);
+    const int st_apply = d.apply(p, z, p, false, &nb, true, tick_spmv ? (int)S_PZ : -1, -1, &pz_done);
     c->spmv_reverse = 0;
     STORM_TRY(st_apply);
     const double *pz_partials = nullptr;
@@ -891,7 +894,7 @@ int storm_hip_solve_cg(const storm_hip_op *op, double alpha, double beta, const 
     // r -= alpha z; gamma = <r,r>                     SolverCg.hpp:97,99,115
     hipLaunchKernelGGL(cg_r_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, r, z, c->d_partials,
                        nt_stream, pz_partials, (int)kStage2, sweep ? 1 - q : 0,
-                       tick ? TicketArgs{c->d_tickets, c->d_partials, c->d_partials2} : TicketArgs{nullptr, nullptr, nullptr});
+                       tick ? TicketArgs{c->d_tickets, c->d_partials, c->d_ticket_sums} : TicketArgs{nullptr, nullptr, nullptr});
     HIP_TRY(hipGetLastError());
     if (!tick) {
       const int slots[1] = {S_GAMMA_NEW};
@@ -951,7 +954,7 @@ int storm_hip_solve_bicgstab(const storm_hip_op *op, double alpha, double beta, 
   auto flip = [&]() -> int { return sweep ? (dir ^= 1) : 0; };
   // ... and reductions finished in-kernel (see storm_hip_solve_cg): five launches per iteration instead of eleven.
   const bool tick = c->opt_ticket_reduce != 0 && c->comm == nullptr && nbv <= kTicketGroup * kTicketMaxGroups;
-  const TicketArgs no_tickets{nullptr, nullptr, nullptr}, tickets{c->d_tickets, c->d_partials, c->d_partials2};
+  const TicketArgs no_tickets{nullptr, nullptr, nullptr}, tickets{c->d_tickets, c->d_partials, c->d_ticket_sums};
   int ticketed = 0;
   auto apply_dir = [&](const double *xin, double *yout, const double *w, bool yy, int out0, int out1) -> int {
     c->spmv_reverse = flip();

@@ -996,9 +996,9 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
   if (sd && sd->nblocks_out) *sd->nblocks_out = fuse_dot ? 4 * nb_total : 0;
   if (sd && sd->ticketed_out) *sd->ticketed_out = 0;
   if (fuse_dot && !split && op->pair >= 2 && sd->out[0] != nullptr && c->opt_ticket_reduce != 0 && c->comm == nullptr &&
-      c->opt_profile_spmv == 0 && nb_total <= kTicketGroup * kTicketMaxGroups && 2 * nb_total <= c->partials_capacity &&
+      nb_total <= kTicketGroup * kTicketMaxGroups && 2 * nb_total <= c->partials_capacity &&
       (!sd->yy || sd->out[1] != nullptr)) {
-    dot.tickets = c->d_tickets, dot.part2 = c->d_partials2, dot.out0 = sd->out[0], dot.out1 = sd->out[1];
+    dot.tickets = c->d_tickets, dot.part2 = c->d_ticket_sums, dot.out0 = sd->out[0], dot.out1 = sd->out[1];
     dot.nblocks_total = nb_total;
     if (sd->ticketed_out) *sd->ticketed_out = 1;
   }
