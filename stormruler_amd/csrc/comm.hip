@@ -61,7 +61,7 @@ static int host_stage(storm_hip_ctx *c, int64_t len) {
 
 // ---- peer-window transport ---------------------------------------------------------------------------------
 // Window of rank r (all offsets multiples of 256 bytes; P = n_ranks, "parity" = epoch & 1 double-buffers everything):
-//   [all-reduce slots ]  2 x P x kIpcArSlot      slot (parity, s): the 64 doubles rank s contributed + their tag
+//   [all-reduce slots ]  2 x P x kIpcArSlot      slot (parity, s): the 64 values rank s contributed, each as two tagged 8-byte words
 //   [halo flags       ]  2 x P x 64              flag (parity, s): epoch of the plane rank s has finished writing
 //   [halo acks        ]  P x 64                  ack (d): last epoch rank d has consumed of what THIS rank sent it
 //   [halo data        ]  2 x P x seg_bytes       data (parity, s): the rows rank s sends here
