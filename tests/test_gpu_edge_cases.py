@@ -403,3 +403,42 @@ def test_one_launch_reductions_give_the_same_bits(kind, shape):
         assert abs(a[0] - c[0]) <= 2 and np.allclose(a[1][:k], c[1][:k], rtol=1e-9), (kind, with_pre)
     mat.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("n_rows", [300, 2048 * 2 - 10, 2048 * 63 + 5, 2048 * 64, 2048 * 64 + 1, 2048 * 65 + 7, 2048 * 129 - 3])
+def test_ticket_groups_at_their_edges(n_rows):
+    """In-kernel reductions (csrc/ticket_device.hpp) with block counts around the group size of 64: one block, one
+    partial group, exactly one / two groups, a last group of one block.  Fused CG and BiCGStab (latency path off)
+    against the two-launch final pass: same iteration counts, solutions to rounding; the ticket path twice, bitwise."""
+    from stormruler_amd import api
+
+    ctx = api.Context(0)
+    ctx.set_option("latency_path", 0)
+    # a 1-D chain with a few long-range couplings, diagonally dominant (CG needs symmetry: built symmetric)
+    rng = np.random.default_rng(n_rows)
+    i = np.arange(n_rows - 1)
+    a = sp.coo_matrix((np.full(n_rows - 1, 0.45), (i, i + 1)), shape=(n_rows, n_rows))
+    j = rng.integers(0, n_rows - 7, n_rows // 3)
+    a = a + sp.coo_matrix((np.full(j.size, 0.05), (j, j + 7)), shape=(n_rows, n_rows))
+    a = (a + a.T).tocsr()
+    a.sum_duplicates()
+    m = (sp.diags(np.asarray(a.sum(axis=1)).ravel() + 0.2) - a).tocsr()
+    mat = api.StencilMatrix.from_csr(ctx, m)
+    b_host = 1.0 + 0.5 * np.sin(0.003 * np.arange(n_rows))
+    for cls in (api.CgSolver, api.BiCgStabSolver):
+        runs = []
+        for ticket in (1, 1, 0):
+            ctx.set_option("ticket_reduce", ticket)
+            s = cls()
+            s.record_history = True
+            s.relative_error_tolerance, s.absolute_error_tolerance = 1e-10, 0.0
+            b, x = api.DeviceVector.from_numpy(ctx, b_host), api.DeviceVector(ctx, n_rows)
+            assert s.solve(x, b, api.HipStencilOperator(mat, 1.0, 0.0))
+            runs.append((s.iteration, np.array(s.history), x.to_numpy()))
+        ctx.set_option("ticket_reduce", 1)
+        assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
+        assert abs(runs[0][0] - runs[2][0]) <= 1
+        assert np.linalg.norm(runs[0][2] - runs[2][2]) <= 1e-9 * np.linalg.norm(runs[2][2])
+        assert np.linalg.norm(m @ runs[0][2] - b_host) <= 1e-8 * np.linalg.norm(b_host)
+    mat.close()
+    ctx.close()
