@@ -9,6 +9,7 @@
 // summation tree depends only on n, so results are bitwise reproducible run to run.
 #include "common.hpp"
 #include "blas1_device.hpp"
+#include "ticket_device.hpp"
 
 namespace storm {
 
@@ -207,6 +208,28 @@ __global__ __launch_bounds__(kBlock) void multi_dot_kernel(int64_t n, const doub
   }
 }
 
+// The same with the reduction finished in the kernel (ticket_device.hpp): out[j] = <a, bs.b[j]>, one launch.
+template <int KB>
+__global__ __launch_bounds__(kBlock) void multi_dot_ticket_kernel(int64_t n, const double *__restrict__ a, DotPtrs bs,
+                                                                  TicketArgs tickets, double *__restrict__ out,
+                                                                  const int *done, int nt) {
+  if (done && *done) return;
+  __shared__ double lds4[4];
+  double acc[KB];
+#pragma unroll
+  for (int j = 0; j < KB; ++j) acc[j] = 0.0;
+  multi_dot_accumulate<KB>(n, a, bs, nt, acc);
+  double mine[KB], total[KB];
+#pragma unroll
+  for (int j = 0; j < KB; ++j) mine[j] = block_sum(acc[j], lds4);
+  if (threadIdx.x >= kWave) return;
+  const unsigned bx = (nt & 2) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+  if (ticket_reduce_wave0<KB>(tickets, mine, KB, bx, gridDim.x, total) && threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < KB; ++j) out[j] = total[j];
+  }
+}
+
 // out[j] = sum_b partials[j * nblocks + b]; one block per j, fixed order.
 __global__ __launch_bounds__(kBlock) void reduce_final_kernel(const double *__restrict__ partials,
                                                               int nblocks, double *__restrict__ out,
@@ -283,6 +306,29 @@ int k_multi_dot_partials(storm_hip_ctx *c, const double *a, const double *const 
 
 int k_multi_dot(storm_hip_ctx *c, const double *a, const double *const *bs, int k, int64_t n,
                 double *d_out, const int *done) {
+  if (c->opt_ticket_reduce != 0 && k <= kDotChunk && n > 0) {  // one launch: partials, tickets, the sums
+    int nbt = stream_blocks(n);
+    if ((int64_t)nbt * k > c->partials_capacity) nbt = (int)(c->partials_capacity / k);
+    const int nt = (int)(c->opt_blas1_nt != 0) | (c->stream_reverse << 1);
+    DotPtrs ptrs;
+    for (int j = 0; j < kDotChunk; ++j) ptrs.b[j] = bs[j < k ? j : 0];
+    const TicketArgs t{c->d_tickets, c->d_partials, c->d_ticket_sums};
+    const dim3 g(nbt), b(kBlock);
+#define TD_GO(K_) hipLaunchKernelGGL(multi_dot_ticket_kernel<K_>, g, b, 0, c->stream, n, a, ptrs, t, d_out, done, nt)
+    switch (k) {
+      case 1: TD_GO(1); break;
+      case 2: TD_GO(2); break;
+      case 3: TD_GO(3); break;
+      case 4: TD_GO(4); break;
+      case 5: TD_GO(5); break;
+      case 6: TD_GO(6); break;
+      case 7: TD_GO(7); break;
+      default: TD_GO(8); break;
+    }
+#undef TD_GO
+    HIP_TRY(hipGetLastError());
+    return STORM_HIP_OK;
+  }
   int nb = 0;
   STORM_TRY(k_multi_dot_partials(c, a, bs, k, n, &nb, done));
   return k_reduce_final(c, c->d_partials, nb, k, d_out, done);

@@ -27,19 +27,29 @@ struct TicketArgs {
   double *part2;  // [K][n_groups] group partials
 };
 
-// Store `v` so that it is at the point of coherence when the function returns.
-__device__ __forceinline__ void ticket_publish(double *p, double v) {
+// Store v[0 .. k) to p[j * stride] so that they are at the point of coherence when the function returns: atomic
+// EXCHANGES, all issued back to back, whose returned values are then consumed -- a returning read-modify-write has
+// been performed at the point of coherence; the empty statement that consumes them is also a compiler barrier for
+// memory, so nothing later is issued before they are back.
+template <int KMAX>
+__device__ __forceinline__ void ticket_publish(double *p, size_t stride, const double (&v)[KMAX], int k) {
+  unsigned long long seen = 0ull;
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) {
+    if (j < k) {
 #ifdef STORM_TICKET_STORE_EXPERIMENT  // (what the first version did; kept to reproduce the failure)
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  return;
+      __hip_atomic_store(p + (size_t)j * stride, v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+      seen ^= __hip_atomic_exchange(reinterpret_cast<unsigned long long *>(p + (size_t)j * stride),
+                                    (unsigned long long)__double_as_longlong(v[j]), __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT);
 #endif
-  const unsigned long long old = __hip_atomic_exchange(reinterpret_cast<unsigned long long *>(p),
-                                                       (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT);
-  // the exchange must RETURN (a returning read-modify-write has been performed at the point of coherence) before
-  // anything later is issued: the empty statement consumes its result and is a compiler barrier for memory
-  asm volatile("" : : "v"(old) : "memory");
+    }
+  }
+#ifdef STORM_TICKET_STORE_EXPERIMENT
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#endif
+  asm volatile("" : : "v"(seen) : "memory");
 }
 __device__ __forceinline__ double ticket_wave_sum(double v) {
 #pragma unroll
@@ -57,9 +67,7 @@ __device__ __forceinline__ bool ticket_reduce_wave0(const TicketArgs &t, const d
   const unsigned gsize = (nb - g * kTicketGroup) < (unsigned)kTicketGroup ? (nb - g * kTicketGroup) : (unsigned)kTicketGroup;
   int go = 0;
   if (lane == 0) {
-#pragma unroll
-    for (int j = 0; j < KMAX; ++j)
-      if (j < k) ticket_publish(t.part1 + (size_t)j * nb + bx, mine[j]);
+    ticket_publish<KMAX>(t.part1 + bx, nb, mine, k);
     int *c = t.cnt + (size_t)(1 + g) * kTicketStride;
     if (__hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gsize - 1) {
       __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -78,9 +86,7 @@ __device__ __forceinline__ bool ticket_reduce_wave0(const TicketArgs &t, const d
   }
   go = 0;
   if (lane == 0) {
-#pragma unroll
-    for (int j = 0; j < KMAX; ++j)
-      if (j < k) ticket_publish(t.part2 + (size_t)j * ng + g, gp[j]);
+    ticket_publish<KMAX>(t.part2 + g, ng, gp, k);
     if (__hip_atomic_fetch_add(t.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)ng - 1) {
       __hip_atomic_store(t.cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       go = 1;
