@@ -119,6 +119,7 @@ struct storm_hip_ctx {
   int64_t opt_coop_mgs_min_rows = 400000;  // ... from this many rows on (below, a launch per step is cheaper than an all-reduce per step)
   int64_t opt_coop_mgs = 1;             // GMRES: the Gram-Schmidt chain of an Arnoldi step as one cooperative kernel (latency.hip)
   int64_t opt_latency_path = 1;         // small operators: CG as one cooperative persistent kernel (latency.hip)
+  int opt_lin_fuse = 1;                 // engine: two consecutive vector statements go out as one pass
   int opt_ticket_reduce = 1;            // fused CG / BiCGStab: reductions finish inside the kernels that produce their partials
   int opt_fused_reduce = 1;             // engine: a reduction is ONE launch (its last block folds the partials and runs the scalar program)
   int opt_latency_cache = 1;            // ... with the wave's operator records held in registers where they fit

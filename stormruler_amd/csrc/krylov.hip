@@ -184,6 +184,13 @@ __global__ void sprog_kernel(double *S, SolverState *st, SProg prog, int nscatte
   exec_prog(prog, S, st);
 }
 
+// o + c * v with ONE rounding per component, spelled out: the same statement must give the same bits whichever
+// kernel evaluates it (alone, paired with its successor, with a reduction folded in).
+__device__ __forceinline__ double2v fma2(double c, double2v v, double2v o) {
+  double2v r;
+  r.x = __builtin_fma(c, v.x, o.x), r.y = __builtin_fma(c, v.y, o.y);
+  return r;
+}
 // The `nt` argument of the streaming kernels carries two flags: bit 0 = non-temporal accesses, bit 1 = deal the
 // blocks out from the far end of the rows (the engine's sweep-direction scheme; a block keeps its rows and slots).
 __device__ __forceinline__ unsigned sweep_block(int flags) { return (flags & 2) ? gridDim.x - 1 - blockIdx.x : blockIdx.x; }
@@ -256,9 +263,13 @@ __host__ __device__ constexpr int lin_unroll(int nt) { return nt <= 2 ? 4 : (nt 
 
 // y = c0 v0 + c1 v1 + ... (left to right), or NESTED (NT = 3):  y = v0 + c1 * (v1 + c2 * v2).
 // Operands may alias y (every element is read before it is written by the same lane).
+// `gate` (nullable): the statement was issued BEFORE the convergence rule of iteration gate_val - 1 but runs behind
+// it (the engine held it back): it must execute iff that rule was evaluated at all -- the iteration counter has reached
+// gate_val -- even when the rule then declared the solve done (the x update of the converging iteration).
 template <int NT, bool NESTED>
-__global__ __launch_bounds__(kBlock) void lin_kernel(int64_t n, LinArgs a, const int *done, int nt) {
-  if (done && *done) return;
+__global__ __launch_bounds__(kBlock) void lin_kernel(int64_t n, LinArgs a, const int *done, int nt,
+                                                     const long long *gate, long long gate_val) {
+  if (gate ? (*gate < gate_val) : (done && *done)) return;
   if (a.cond && *a.cond == 0.0) return;
   const unsigned bx = sweep_block(nt);
   nt &= 1;
@@ -289,7 +300,7 @@ __global__ __launch_bounds__(kBlock) void lin_kernel(int64_t n, LinArgs a, const
         } else {
           o = c[0] * v[u][0];
 #pragma unroll
-          for (int t = 1; t < NT; ++t) o += c[t] * v[u][t];
+          for (int t = 1; t < NT; ++t) o = fma2(c[t], v[u][t], o);
         }
         stv(y2 + i, o, nt);
       }
@@ -302,12 +313,62 @@ __global__ __launch_bounds__(kBlock) void lin_kernel(int64_t n, LinArgs a, const
       o = a.v[0][i] + c[1] * (a.v[1][i] + c[2] * a.v[NT - 1][i]);
     } else {
       o = c[0] * a.v[0][i];
-      for (int t = 1; t < NT; ++t) o += c[t] * a.v[t][i];
+      for (int t = 1; t < NT; ++t) o = __builtin_fma(c[t], a.v[t][i], o);
     }
     a.y[i] = o;
   }
 }
 
+
+// TWO consecutive vector statements in one pass, executed per element in program order (both are elementwise, so
+// that is exactly their sequential meaning): y1 = sum c1_t v1_t;  y2 = sum c2_t v2_t, where an operand of the second
+// that IS y1 takes the new value.  Every operand is loaded before anything is stored, so the second statement may
+// overwrite an operand of the first ("x += alpha p;  p = r + beta p" -- p is read once: 40 instead of 48 bytes per
+// row, one launch instead of two).
+template <int NT1, int NT2>
+__global__ __launch_bounds__(kBlock) void lin2_kernel(int64_t n, LinArgs a1, LinArgs a2, const int *done, int nt,
+                                                      const long long *gate, long long gate_val) {
+  const bool run2 = !(done && *done);
+  const bool run1 = gate ? (*gate >= gate_val) : run2;  // (see lin_kernel; run2 implies run1)
+  if (!run1) return;
+  const unsigned bx = sweep_block(nt);
+  nt &= 1;
+  double c1[NT1], c2[NT2];
+  bool from1[NT2];
+#pragma unroll
+  for (int t = 0; t < NT1; ++t) c1[t] = ld_coef(a1.c[t]);
+#pragma unroll
+  for (int t = 0; t < NT2; ++t) c2[t] = ld_coef(a2.c[t]), from1[t] = a2.v[t] == a1.y;
+  const int64_t n2 = n >> 1;
+  double2v *y1 = reinterpret_cast<double2v *>(a1.y), *y2 = reinterpret_cast<double2v *>(a2.y);
+  for (int64_t i = (int64_t)bx * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
+    double2v v1[NT1], v2[NT2];
+#pragma unroll
+    for (int t = 0; t < NT1; ++t) v1[t] = ldv(reinterpret_cast<const double2v *>(a1.v[t]) + i, nt);
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) v2[t] = ldv(reinterpret_cast<const double2v *>(a2.v[t]) + i, nt);
+    double2v o1 = c1[0] * v1[0];
+#pragma unroll
+    for (int t = 1; t < NT1; ++t) o1 = fma2(c1[t], v1[t], o1);
+    double2v o2 = c2[0] * (from1[0] ? o1 : v2[0]);
+#pragma unroll
+    for (int t = 1; t < NT2; ++t) o2 = fma2(c2[t], from1[t] ? o1 : v2[t], o2);
+    stv(y1 + i, o1, nt);
+    if (run2) stv(y2 + i, o2, nt);
+  }
+  if ((n & 1) && bx == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    double w1[NT1], w2[NT2];
+    for (int t = 0; t < NT1; ++t) w1[t] = a1.v[t][i];
+    for (int t = 0; t < NT2; ++t) w2[t] = a2.v[t][i];
+    double o1 = c1[0] * w1[0];
+    for (int t = 1; t < NT1; ++t) o1 = __builtin_fma(c1[t], w1[t], o1);
+    double o2 = c2[0] * (from1[0] ? o1 : w2[0]);
+    for (int t = 1; t < NT2; ++t) o2 = __builtin_fma(c2[t], from1[t] ? o1 : w2[t], o2);
+    a1.y[i] = o1;
+    if (run2) a2.y[i] = o2;
+  }
+}
 
 // The same statement with reductions of its RESULT folded in: per-block partials of <y, y> (dot_yy) and / or
 // <y, w> into partials[j * gridDim.x + block] -- "r -= alpha z; gamma = <r, r>" is one pass over r, not two.
@@ -341,7 +402,7 @@ __device__ __forceinline__ void lin_dot_body(int64_t n, const LinArgs &a, const 
       if (i < n2) {
         double2v o = c[0] * v[u][0];
 #pragma unroll
-        for (int t = 1; t < NT; ++t) o += c[t] * v[u][t];
+        for (int t = 1; t < NT; ++t) o = fma2(c[t], v[u][t], o);
         stv(y2 + i, o, nt);
         acc_yy += o.x * o.x;
         acc_yy += o.y * o.y;
@@ -352,7 +413,7 @@ __device__ __forceinline__ void lin_dot_body(int64_t n, const LinArgs &a, const 
   if ((n & 1) && bx == 0 && threadIdx.x == 0) {
     const int64_t i = n - 1;
     double o = c[0] * a.v[0][i];
-    for (int t = 1; t < NT; ++t) o += c[t] * a.v[t][i];
+    for (int t = 1; t < NT; ++t) o = __builtin_fma(c[t], a.v[t][i], o);
     a.y[i] = o;
     acc_yy += o * o;
     if (w) acc_yw += o * w[i];
@@ -463,6 +524,16 @@ struct KrylovEngine {
   DotPtrs pend_bs{};
   LinArgs pend_lin{};
   int pend_nt = 0, pend_yy = 0, pend_flags = 0;
+  // A vector statement held back (at most one): if the next statement is one too, both go out as ONE pass
+  // (lin2_kernel); it may also be overtaken by a reduction that shares no vector with it.  It is older than any
+  // pending reduction / scalar program, so launching it first is always right; holding it back past a program is
+  // right when the program writes none of the registers its coefficients read.
+  bool q_has = false;
+  LinArgs q_lin{};
+  int q_nt = 0;
+  int q_regs[3] = {-1, -1, -1};
+  long long q_gate = -1;  // >= 0: held back past the convergence rule of iteration q_gate - 1 (see lin_kernel)
+  int64_t cur_it = 0;     // the iteration iterate() is enqueuing
   // Sweep directions (see storm_hip_solve_cg): every streaming statement deals its blocks out from the end of the
   // rows where the previous one stopped -- what the Infinity Cache still holds.  Same rows and slots per block.
   int sweep_dir = 1;
@@ -501,9 +572,50 @@ struct KrylovEngine {
   }
   void reset_prog() { prog.n = 0, n_imm = 0; }
 
-  void flush() {
+  // May the held-back statement stay behind the scalar program about to go out?  0: no; 1: yes; 2: yes, and the
+  // program holds this iteration's convergence rule (the statement is then gated on the iteration counter).
+  int prog_lets_queued_wait() const {
+    int verdict = 1;
+    for (int i = 0; i < prog.n; ++i) {
+      const SOp &o = prog.ops[i];
+      if (o.op == SC_GIVENS || o.op == SC_BACKSOLVE || o.op == SC_BEGIN) return 0;  // (macros over register ranges; init)
+      if (o.op == SC_ADVANCE) {
+        verdict = 2;
+        continue;
+      }
+      const int span = o.op == SC_SYMORTHO ? 3 : 1;
+      for (int t = 0; t < 3; ++t)
+        if (q_regs[t] >= (int)o.d && q_regs[t] < (int)o.d + span) return 0;
+    }
+    return verdict;
+  }
+  void settle() {  // the held-back statement goes out alone
+    if (!q_has) return;
+    q_has = false;
+    if (!ok()) return;
+    switch (q_nt) {
+      case 1: launch_lin<1, false>(q_lin, q_gate); break;
+      case 2: launch_lin<2, false>(q_lin, q_gate); break;
+      default: launch_lin<3, false>(q_lin, q_gate); break;
+    }
+    q_gate = -1;
+  }
+  bool queued_touches(const double *ptr, bool written) const {  // would a statement on `ptr` conflict with it?
+    if (!q_has || ptr == nullptr) return false;
+    if (ptr == q_lin.y) return true;
+    if (written)
+      for (int t = 0; t < q_nt; ++t)
+        if (ptr == q_lin.v[t]) return true;
+    return false;
+  }
+  void flush(bool keep_queued = false) {
+    if (q_has) {
+      const int wait = (keep_queued && ok()) ? prog_lets_queued_wait() : 0;
+      if (wait == 0) settle();
+      else if (wait == 2) q_gate = (long long)cur_it + 1;
+    }
     if (!ok()) {
-      reset_prog(), red_pending = false;
+      reset_prog(), red_pending = false, q_has = false;
       return;
     }
     if (red_pending && pend != PEND_NONE) {
@@ -575,7 +687,9 @@ struct KrylovEngine {
   }
   bool one_launch(int k) const { return c->comm == nullptr && c->opt_fused_reduce != 0 && n > 0 && k <= kDotChunk; }
   void dots_v(const storm_hip_vec *a, const std::vector<std::pair<int, const storm_hip_vec *>> &outs) {
-    flush();
+    bool overtake = !queued_touches(a->d, false);  // a pure read: conflicts only with the held-back statement's target
+    for (const auto &o : outs) overtake = overtake && !queued_touches(o.second->d, false);
+    flush(overtake);
     if (!ok()) return;
     const int k = (int)outs.size();
     if (k < 1 || k > kMaxMulti) {
@@ -611,13 +725,48 @@ struct KrylovEngine {
   // -- vector statements
   Scal scal(const Coef &co) const { return co.reg >= 0 ? Scal{S + co.reg, 0.0, co.sign} : Scal{nullptr, co.v, 1.0}; }
   template <int NT, bool NESTED>
-  void launch_lin(const LinArgs &a) {
+  void launch_lin(const LinArgs &a, long long gate = -1) {
     if (n <= 0) return;
     const int64_t per_block = (int64_t)kBlock * lin_unroll(NT) * 2;
     const int64_t nb = std::min<int64_t>(65536, std::max<int64_t>(1, (n + per_block - 1) / per_block));
-    hipLaunchKernelGGL((lin_kernel<NT, NESTED>), dim3((int)nb), dim3(kBlock), 0, c->stream, n, a, dp, stream_flags());
+    hipLaunchKernelGGL((lin_kernel<NT, NESTED>), dim3((int)nb), dim3(kBlock), 0, c->stream, n, a, dp, stream_flags(),
+                       gate >= 0 ? &d_st->iteration : nullptr, gate);
+  }
+  template <int NT1>
+  void launch_lin2(const LinArgs &a1, const LinArgs &a2, int nt2) {
+    const int64_t nb = std::min<int64_t>(131072, std::max<int64_t>(1, ((n >> 1) + kBlock - 1) / kBlock));
+    const int fl = stream_flags();
+    const long long *gp = q_gate >= 0 ? &d_st->iteration : nullptr;
+    const long long gv = q_gate;
+    switch (nt2) {
+      case 1: hipLaunchKernelGGL((lin2_kernel<NT1, 1>), dim3((int)nb), dim3(kBlock), 0, c->stream, n, a1, a2, dp, fl, gp, gv); break;
+      case 2: hipLaunchKernelGGL((lin2_kernel<NT1, 2>), dim3((int)nb), dim3(kBlock), 0, c->stream, n, a1, a2, dp, fl, gp, gv); break;
+      default: hipLaunchKernelGGL((lin2_kernel<NT1, 3>), dim3((int)nb), dim3(kBlock), 0, c->stream, n, a1, a2, dp, fl, gp, gv); break;
+    }
+    q_gate = -1;
   }
   void lin_v(V yv, const std::vector<Term> &terms, int cond = -1) {
+    if (c->opt_lin_fuse != 0 && cond < 0 && terms.size() >= 1 && terms.size() <= 3 && n > 1) {
+      flush(true);
+      if (!ok()) return;
+      LinArgs a{};
+      a.y = yv->d;
+      const int nt = (int)terms.size();
+      int regs[3] = {-1, -1, -1};
+      for (int t = 0; t < nt; ++t) a.v[t] = terms[(size_t)t].v->d, a.c[t] = scal(terms[(size_t)t].c), regs[t] = terms[(size_t)t].c.reg;
+      if (q_has) {  // the held-back statement and this one: one pass
+        q_has = false;
+        switch (q_nt) {
+          case 1: launch_lin2<1>(q_lin, a, nt); break;
+          case 2: launch_lin2<2>(q_lin, a, nt); break;
+          default: launch_lin2<3>(q_lin, a, nt); break;
+        }
+      } else {
+        q_has = true, q_lin = a, q_nt = nt;
+        for (int t = 0; t < 3; ++t) q_regs[t] = regs[t];
+      }
+      return;
+    }
     flush();
     if (!ok()) return;
     size_t at = 0;
@@ -672,7 +821,11 @@ struct KrylovEngine {
       dots_v(yv, outs);
       return;
     }
-    flush();
+    {
+      bool overtake = !queued_touches(yv->d, true) && !(wv != nullptr && queued_touches(wv->d, false));
+      for (const Term &t : terms) overtake = overtake && !queued_touches(t.v->d, false);
+      flush(overtake);
+    }
     if (!ok()) return;
     LinArgs a{};
     a.y = yv->d;
@@ -1012,6 +1165,7 @@ void K::init() {
 }
 
 void K::iterate(int64_t it) {
+  cur_it = it;
   const bool P = has_pre();
   switch (method) {
     case STORM_HIP_CG: {  // SolverCg.hpp:86-126

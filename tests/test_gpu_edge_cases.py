@@ -442,3 +442,52 @@ def test_ticket_groups_at_their_edges(n_rows):
         assert np.linalg.norm(m @ runs[0][2] - b_host) <= 1e-8 * np.linalg.norm(b_host)
     mat.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("kind", ["cg", "bicgstab", "cgs", "tfqmr", "tfqmr1", "idrs", "bicgstabl", "gmres", "fgmres"])
+def test_paired_vector_statements_give_the_same_bits(kind):
+    """The engine holds one vector statement back and sends two consecutive ones out as ONE pass (`lin_fuse`,
+    csrc/krylov.hip lin2_kernel), or lets an independent reduction overtake it.  Elementwise statements executed per
+    element in program order are the same arithmetic: histories and x IDENTICAL with the option off; lambda operator,
+    Jacobi preconditioner on either side."""
+    from stormruler_amd import api, mesh
+
+    ctx = api.Context(0)
+    g = mesh.structured_box(23, 17, 11)
+    wi, wo, de = mesh.convection_diffusion_weights(g, 1e-2, (1.0, 0.5, 0.25))
+    mat = api.StencilMatrix.from_face_weights(ctx, g.n_cells, g.n_halo, g.inner, g.outer, wi, wo, de)
+    cls = {"cg": api.CgSolver, "bicgstab": api.BiCgStabSolver, "cgs": api.CgsSolver, "tfqmr": api.TfqmrSolver,
+           "tfqmr1": api.Tfqmr1Solver, "idrs": api.IdrsSolver, "bicgstabl": api.BiCgStabLSolver,
+           "gmres": api.GmresSolver, "fgmres": api.FgmresSolver}[kind]
+    if kind == "cg":
+        mat.close()
+        mat = api.StencilMatrix.from_face_graph(ctx, g)
+    alpha = -1.0 if kind == "cg" else 1.0
+    b = api.DeviceVector.from_numpy(ctx, 1.0 + 0.25 * np.sin(0.01 * np.arange(g.n_cells)))
+    lam = api.make_operator(lambda y, x: mat.apply(alpha, 0.0, x, y))
+    runs = {}
+    for fuse in (1, 0):
+        ctx.set_option("lin_fuse", fuse)
+        for variant in ("lambda", "jacobi-right", "jacobi-left"):
+            if kind == "cg" and variant != "lambda":
+                continue
+            api.rng_reset()
+            s = cls()
+            s.record_history, s.num_iterations = True, 80
+            op = lam
+            if variant != "lambda":
+                s.pre_op = api.JacobiPreconditioner()
+                s.pre_side = api.PreconditionerSide.Right if variant.endswith("right") else api.PreconditionerSide.Left
+                op = api.HipStencilOperator(mat, alpha, 0.0)
+                ctx.set_option("generic_solvers", 1)
+            x = api.DeviceVector(ctx, g.n_cells)
+            s.solve(x, b, op)
+            ctx.set_option("generic_solvers", 0)
+            runs[(fuse, variant)] = (s.iteration, np.array(s.history), x.to_numpy())
+    ctx.set_option("lin_fuse", 1)
+    for (fuse, variant), r in runs.items():
+        if fuse == 1:
+            o = runs[(0, variant)]
+            assert r[0] == o[0] and np.array_equal(r[1], o[1]) and np.array_equal(r[2], o[2]), (kind, variant)
+    mat.close()
+    ctx.close()
