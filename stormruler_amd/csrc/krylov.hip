@@ -991,14 +991,14 @@ void K::setup() {
       break;
     case STORM_HIP_CGS:
       p = vec(), q = vec(), r = vec(), rt = vec(), u = vec(), v = vec();
-      r_alpha = alloc(1), r_beta = alloc(1), r_rho = alloc(1), r_a0 = alloc(1);
+      r_alpha = alloc(1), r_beta = alloc(1), r_rho = alloc(1), r_a0 = alloc(1), r_a1 = alloc(1);
       break;
     case STORM_HIP_TFQMR:
     case STORM_HIP_TFQMR1:
       d = vec(), rt = vec(), u = vec(), v = vec(), y = vec(), s_ = vec();
       if (P) z = vec();
       r_alpha = alloc(1), r_beta = alloc(1), r_rho = alloc(1), r_tau = alloc(1), r_omega = alloc(1), r_a0 = alloc(1),
-      r_a1 = alloc(3), r_a2 = alloc(1), r_a3 = alloc(1);
+      r_a1 = alloc(3), r_a2 = alloc(1), r_a3 = alloc(1), r_a4 = alloc(1);
       break;
     case STORM_HIP_RICHARDSON:
       r = vec();
@@ -1192,7 +1192,7 @@ void K::iterate(int64_t it) {
         copy(p, r);
       } else {
         sc(SC_MOV, r_a0, r_rho);  // rho_bar
-        dot(r_rho, rt, r);
+        sc(SC_MOV, r_rho, r_a1);  // <rt, r> (:116): the same r, formed in the pass that produced it (below)
         sc(SC_MUL, R_T0, r_alpha, r_rho);
         sc(SC_MUL, R_T1, r_omega, r_a0);
         sc(SC_SDIV, r_beta, R_T0, R_T1);
@@ -1217,7 +1217,7 @@ void K::iterate(int64_t it) {
       }
       sc(SC_SDIV, r_omega, R_T0, R_T1);
       axpy(x, R(r_omega), right() ? z : r);
-      lin_dots(r, {{num(1.0), r}, {mR(r_omega), t}}, R_T0);
+      lin_dots(r, {{num(1.0), r}, {mR(r_omega), t}}, R_T0, r_a1, rt);  // |r|^2 and the next iteration's <rt, r>
       sc(SC_SQRT, R_ERR, R_T0);
       sc(SC_ADVANCE, 0, R_ERR);
     } break;
@@ -1228,7 +1228,7 @@ void K::iterate(int64_t it) {
         copy(p, u);
       } else {
         sc(SC_MOV, r_a0, r_rho);
-        dot(r_rho, rt, r);
+        sc(SC_MOV, r_rho, r_a1);  // <rt, r> (SolverCgs.hpp:116): formed in the pass that produced this r (below)
         sc(SC_SDIV, r_beta, r_rho, r_a0);
         lin(u, {{num(1.0), r}, {R(r_beta), q}});
         lin_nested(p, u, R(r_beta), q, R(r_beta), p);
@@ -1250,7 +1250,7 @@ void K::iterate(int64_t it) {
         axpy(x, R(r_alpha), v);
         step = u;
       }
-      lin_dots(r, {{num(1.0), r}, {mR(r_alpha), step}}, R_T0);
+      lin_dots(r, {{num(1.0), r}, {mR(r_alpha), step}}, R_T0, r_a1, rt);  // |r|^2 and the next iteration's <rt, r>
       sc(SC_SQRT, R_ERR, R_T0);
       sc(SC_ADVANCE, 0, R_ERR);
     } break;
@@ -1263,7 +1263,7 @@ void K::iterate(int64_t it) {
         copy(v, s_);
       } else {
         sc(SC_MOV, r_a0, r_rho);
-        dot(r_rho, rt, u);
+        sc(SC_MOV, r_rho, r_a4);  // <rt, u>: formed in the pass that produced this u (second half-step below)
         sc(SC_SDIV, r_beta, r_rho, r_a0);
         lin(v, {{num(1.0), s_}, {R(r_beta), v}});
         lin(y, {{num(1.0), u}, {R(r_beta), y}});
@@ -1274,7 +1274,8 @@ void K::iterate(int64_t it) {
       sc(SC_SDIV, r_alpha, r_rho, R_T0);
       for (int half = 0; half <= 1; ++half) {
         axpy(d, R(r_alpha), right() ? z : y);
-        lin_dots(u, {{num(1.0), u}, {mR(r_alpha), s_}}, R_T0);
+        if (half == 1) lin_dots(u, {{num(1.0), u}, {mR(r_alpha), s_}}, R_T0, r_a4, rt);  // + the next <rt, u>
+        else lin_dots(u, {{num(1.0), u}, {mR(r_alpha), s_}}, R_T0);
         sc(SC_SQRT, r_omega, R_T0);
         if (l1) {
           sc(SC_LT, r_a2, r_omega, r_tau);
