@@ -1191,12 +1191,7 @@ void K::iterate(int64_t it) {
       if (it == 0) {
         copy(p, r);
       } else {
-        sc(SC_MOV, r_a0, r_rho);  // rho_bar
-        sc(SC_MOV, r_rho, r_a1);  // <rt, r> (:116): the same r, formed in the pass that produced it (below)
-        sc(SC_MUL, R_T0, r_alpha, r_rho);
-        sc(SC_MUL, R_T1, r_omega, r_a0);
-        sc(SC_SDIV, r_beta, R_T0, R_T1);
-        lin_nested(p, r, R(r_beta), p, mR(r_omega), v);
+        lin_nested(p, r, R(r_beta), p, mR(r_omega), v);  // (rho, beta: formed at the end of the previous iteration)
       }
       if (left()) {
         mul_side(v, z, p);
@@ -1220,6 +1215,13 @@ void K::iterate(int64_t it) {
       lin_dots(r, {{num(1.0), r}, {mR(r_omega), t}}, R_T0, r_a1, rt);  // |r|^2 and the next iteration's <rt, r>
       sc(SC_SQRT, R_ERR, R_T0);
       sc(SC_ADVANCE, 0, R_ERR);
+      // :116-118 of the NEXT iteration (the same r): rho_bar = rho; rho = <rt, r>; beta = (alpha rho) / (omega rho_bar)
+      // -- in this pass's scalar program instead of a launch of their own at the start of the next iteration
+      sc(SC_MOV, r_a0, r_rho);
+      sc(SC_MOV, r_rho, r_a1);
+      sc(SC_MUL, R_T0, r_alpha, r_rho);
+      sc(SC_MUL, R_T1, r_omega, r_a0);
+      sc(SC_SDIV, r_beta, R_T0, R_T1);
     } break;
 
     case STORM_HIP_CGS: {  // SolverCgs.hpp:90-172
@@ -1227,10 +1229,7 @@ void K::iterate(int64_t it) {
         copy(u, r);
         copy(p, u);
       } else {
-        sc(SC_MOV, r_a0, r_rho);
-        sc(SC_MOV, r_rho, r_a1);  // <rt, r> (SolverCgs.hpp:116): formed in the pass that produced this r (below)
-        sc(SC_SDIV, r_beta, r_rho, r_a0);
-        lin(u, {{num(1.0), r}, {R(r_beta), q}});
+        lin(u, {{num(1.0), r}, {R(r_beta), q}});  // (rho, beta: formed at the end of the previous iteration)
         lin_nested(p, u, R(r_beta), q, R(r_beta), p);
       }
       mul_side(v, q, p);
@@ -1253,6 +1252,9 @@ void K::iterate(int64_t it) {
       lin_dots(r, {{num(1.0), r}, {mR(r_alpha), step}}, R_T0, r_a1, rt);  // |r|^2 and the next iteration's <rt, r>
       sc(SC_SQRT, R_ERR, R_T0);
       sc(SC_ADVANCE, 0, R_ERR);
+      sc(SC_MOV, r_a0, r_rho);  // SolverCgs.hpp:116-118 of the next iteration, in this pass's scalar program
+      sc(SC_MOV, r_rho, r_a1);
+      sc(SC_SDIV, r_beta, r_rho, r_a0);
     } break;
 
     case STORM_HIP_TFQMR:
