@@ -454,6 +454,79 @@ __global__ __launch_bounds__(kBlock) void lin_dot_prog_kernel(int64_t n, LinArgs
   publish_and_finish<2>(partials, mine, f, sweep_block(nt));
 }
 
+// A held-back vector statement, the statement that follows it, and the reductions of THAT statement's result, in
+// one pass (lin2_kernel + lin_dot_prog_kernel): BiCGStab's "x += alpha p + omega s;  r = s - omega t;  |r|^2, <rt, r>"
+// reads x, p, r, t, rt and writes x, r once -- the hand-fused loop's second half-step.
+template <int NT1, int NT2>
+__global__ __launch_bounds__(kBlock) void lin2_dot_prog_kernel(int64_t n, LinArgs a1, LinArgs a2, const double *w,
+                                                               int dot_yy, double *partials, const int *done, int nt,
+                                                               FinalPass f) {
+  if (done && *done) return;
+  __shared__ double lds4[4];
+  const unsigned bx = sweep_block(nt);
+  const bool ntl = nt & 1;
+  double c1[NT1], c2[NT2];
+  bool from1[NT2];
+#pragma unroll
+  for (int t = 0; t < NT1; ++t) c1[t] = ld_coef(a1.c[t]);
+#pragma unroll
+  for (int t = 0; t < NT2; ++t) c2[t] = ld_coef(a2.c[t]), from1[t] = a2.v[t] == a1.y;
+  const bool w_from1 = w == a1.y;
+  const int64_t n2 = n >> 1;
+  double2v *y1 = reinterpret_cast<double2v *>(a1.y), *y2 = reinterpret_cast<double2v *>(a2.y);
+  const double2v *w2 = reinterpret_cast<const double2v *>(w);
+  double acc_yy = 0.0, acc_yw = 0.0;
+  // (the rows of a block and the order of a thread's terms are those of lin_dot_body for the second statement: the
+  //  partial sums -- and the reduction's bits -- do not depend on whether a held-back statement rode along)
+  constexpr int U = lin_unroll(NT2 + 1);
+  for (int64_t base = (int64_t)bx * (kBlock * U) + threadIdx.x; base < n2; base += (int64_t)gridDim.x * (kBlock * U)) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = base + u * kBlock;
+      if (i < n2) {
+        double2v v1[NT1], v2[NT2], vw = {0.0, 0.0};
+#pragma unroll
+        for (int t = 0; t < NT1; ++t) v1[t] = ldv(reinterpret_cast<const double2v *>(a1.v[t]) + i, ntl);
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) v2[t] = ldv(reinterpret_cast<const double2v *>(a2.v[t]) + i, ntl);
+        if (w) vw = ldv(w2 + i, ntl);
+        double2v o1 = c1[0] * v1[0];
+#pragma unroll
+        for (int t = 1; t < NT1; ++t) o1 = fma2(c1[t], v1[t], o1);
+        double2v o2 = c2[0] * (from1[0] ? o1 : v2[0]);
+#pragma unroll
+        for (int t = 1; t < NT2; ++t) o2 = fma2(c2[t], from1[t] ? o1 : v2[t], o2);
+        stv(y1 + i, o1, ntl);
+        stv(y2 + i, o2, ntl);
+        if (w_from1) vw = o1;
+        acc_yy += o2.x * o2.x;
+        acc_yy += o2.y * o2.y;
+        if (w) acc_yw += o2.x * vw.x, acc_yw += o2.y * vw.y;
+      }
+    }
+  }
+  if ((n & 1) && bx == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    double w1[NT1], w2v[NT2];
+    for (int t = 0; t < NT1; ++t) w1[t] = a1.v[t][i];
+    for (int t = 0; t < NT2; ++t) w2v[t] = a2.v[t][i];
+    const double wl = w ? w[i] : 0.0;
+    double o1 = c1[0] * w1[0];
+    for (int t = 1; t < NT1; ++t) o1 = __builtin_fma(c1[t], w1[t], o1);
+    double o2 = c2[0] * (from1[0] ? o1 : w2v[0]);
+    for (int t = 1; t < NT2; ++t) o2 = __builtin_fma(c2[t], from1[t] ? o1 : w2v[t], o2);
+    a1.y[i] = o1;
+    a2.y[i] = o2;
+    acc_yy += o2 * o2;
+    if (w) acc_yw += o2 * (w_from1 ? o1 : wl);
+  }
+  double mine[2] = {0.0, 0.0};
+  int j = 0;
+  if (dot_yy) mine[j++] = block_sum256(acc_yy, lds4);
+  if (w) mine[j] = block_sum256(acc_yw, lds4);
+  publish_and_finish<2>(partials, mine, f, bx);
+}
+
 }  // namespace kry
 }  // namespace storm
 
@@ -519,10 +592,11 @@ struct KrylovEngine {
   int red_nb = 0, red_k = 0;
   RedOut red_out{};
   // a reduction whose partials kernel is launched at flush(), with the final pass and the scalar program inside
-  enum { PEND_NONE, PEND_DOTS, PEND_LIN_DOT } pend = PEND_NONE;
+  enum { PEND_NONE, PEND_DOTS, PEND_LIN_DOT, PEND_LIN2_DOT } pend = PEND_NONE;
   const double *pend_a = nullptr, *pend_w = nullptr;
   DotPtrs pend_bs{};
-  LinArgs pend_lin{};
+  LinArgs pend_lin{}, pend_lin0{};  // (pend_lin0: the held-back statement of PEND_LIN2_DOT)
+  int pend_nt0 = 0;
   int pend_nt = 0, pend_yy = 0, pend_flags = 0;
   // A vector statement held back (at most one): if the next statement is one too, both go out as ONE pass
   // (lin2_kernel); it may also be overtaken by a reduction that shares no vector with it.  It is older than any
@@ -635,7 +709,7 @@ struct KrylovEngine {
           default: DOTS_GO(8); break;
         }
 #undef DOTS_GO
-      } else {
+      } else if (pend == PEND_LIN_DOT) {
 #define LIN_GO(NT_) hipLaunchKernelGGL(lin_dot_prog_kernel<NT_>, g, b, 0, c->stream, n, pend_lin, pend_w, pend_yy, c->d_partials, dp, nti, f)
         switch (pend_nt) {
           case 1: LIN_GO(1); break;
@@ -643,6 +717,20 @@ struct KrylovEngine {
           default: LIN_GO(3); break;
         }
 #undef LIN_GO
+      } else {
+#define LIN2_GO(A_, B_) hipLaunchKernelGGL((lin2_dot_prog_kernel<A_, B_>), g, b, 0, c->stream, n, pend_lin0, pend_lin, pend_w, pend_yy, c->d_partials, dp, nti, f)
+        switch (pend_nt0 * 4 + pend_nt) {
+          case 5: LIN2_GO(1, 1); break;
+          case 6: LIN2_GO(1, 2); break;
+          case 7: LIN2_GO(1, 3); break;
+          case 9: LIN2_GO(2, 1); break;
+          case 10: LIN2_GO(2, 2); break;
+          case 11: LIN2_GO(2, 3); break;
+          case 13: LIN2_GO(3, 1); break;
+          case 14: LIN2_GO(3, 2); break;
+          default: LIN2_GO(3, 3); break;
+        }
+#undef LIN2_GO
       }
       pend = PEND_NONE, red_pending = false;
     } else if (red_pending) {
@@ -821,10 +909,19 @@ struct KrylovEngine {
       dots_v(yv, outs);
       return;
     }
+    bool with_held = false;  // the held-back statement goes into THIS pass (it conflicts, so it cannot wait)
     {
       bool overtake = !queued_touches(yv->d, true) && !(wv != nullptr && queued_touches(wv->d, false));
       for (const Term &t : terms) overtake = overtake && !queued_touches(t.v->d, false);
-      flush(overtake);
+      with_held = q_has && !overtake && q_gate < 0 && c->opt_lin_fuse != 0 && one_launch(2) && n > 1 &&
+                  (reg_yy >= 0 || (reg_yw >= 0 && wv != nullptr));
+      if (with_held) {
+        flush(true);                         // (may still settle it: a scalar program in the way)
+        with_held = q_has && q_gate < 0;
+        if (q_has && !with_held) settle();
+      } else {
+        flush(overtake);
+      }
     }
     if (!ok()) return;
     LinArgs a{};
@@ -836,6 +933,16 @@ struct KrylovEngine {
     nb = std::min<int64_t>(nb, std::min<int64_t>(32768, c->partials_capacity / 2));
     const double *wd = (reg_yw >= 0 && wv != nullptr) ? wv->d : nullptr;
     const int nti = stream_flags();
+    if (with_held) {
+      const int64_t nb2 = nb;  // the grid of the statement alone (same rows per block, same partial sums)
+      pend = PEND_LIN2_DOT, pend_lin0 = q_lin, pend_nt0 = q_nt, q_has = false;
+      pend_lin = a, pend_nt = nt, pend_w = wd, pend_yy = (int)(reg_yy >= 0), pend_flags = nti;
+      red_k = 0;
+      if (reg_yy >= 0) red_out.idx[red_k++] = reg_yy;
+      if (wd != nullptr) red_out.idx[red_k++] = reg_yw;
+      red_nb = (int)nb2, red_pending = true;
+      return;
+    }
     if (one_launch(2) && (reg_yy >= 0 || wd != nullptr)) {
       pend = PEND_LIN_DOT, pend_lin = a, pend_nt = nt, pend_w = wd, pend_yy = (int)(reg_yy >= 0), pend_flags = nti;
       red_k = 0;
@@ -1201,7 +1308,9 @@ void K::iterate(int64_t it) {
         apply_dots(v, right() ? z : p, R_T0, rt);
       }
       sc(SC_SDIV, r_alpha, r_rho, R_T0);
-      axpy(x, R(r_alpha), right() ? z : p);
+      // (:140, :161: without a preconditioner p and s = r are still there when omega is known, and
+      //  x = (x + alpha p) + omega s goes out as ONE statement below -- the same two roundings per element)
+      if (P) axpy(x, R(r_alpha), right() ? z : p);
       axpy(r, mR(r_alpha), v);
       if (left()) {
         mul_side(t, z, r);
@@ -1211,7 +1320,8 @@ void K::iterate(int64_t it) {
         apply_dots(t, right() ? z : r, R_T0, r, R_T1);
       }
       sc(SC_SDIV, r_omega, R_T0, R_T1);
-      axpy(x, R(r_omega), right() ? z : r);
+      if (P) axpy(x, R(r_omega), right() ? z : r);
+      else lin(x, {{num(1.0), x}, {R(r_alpha), p}, {R(r_omega), r}});
       lin_dots(r, {{num(1.0), r}, {mR(r_omega), t}}, R_T0, r_a1, rt);  // |r|^2 and the next iteration's <rt, r>
       sc(SC_SQRT, R_ERR, R_T0);
       sc(SC_ADVANCE, 0, R_ERR);
