@@ -328,9 +328,11 @@ __global__ __launch_bounds__(kBlock) void lin_kernel(int64_t n, LinArgs a, const
 template <int NT1, int NT2>
 __global__ __launch_bounds__(kBlock) void lin2_kernel(int64_t n, LinArgs a1, LinArgs a2, const int *done, int nt,
                                                       const long long *gate, long long gate_val) {
-  const bool run2 = !(done && *done);
-  const bool run1 = gate ? (*gate >= gate_val) : run2;  // (see lin_kernel; run2 implies run1)
-  if (!run1) return;
+  bool run2 = !(done && *done);
+  bool run1 = gate ? (*gate >= gate_val) : run2;  // (see lin_kernel; run2 implies run1)
+  if (a1.cond && *a1.cond == 0.0) run1 = false;   // a conditional statement (TFQMR1's `if (omega < tau) x = d`)
+  if (a2.cond && *a2.cond == 0.0) run2 = false;
+  if (!run1 && !run2) return;
   const unsigned bx = sweep_block(nt);
   nt &= 1;
   double c1[NT1], c2[NT2];
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(kBlock) void lin2_kernel(int64_t n, LinArgs a1, Lin
 #pragma unroll
   for (int t = 0; t < NT1; ++t) c1[t] = ld_coef(a1.c[t]);
 #pragma unroll
-  for (int t = 0; t < NT2; ++t) c2[t] = ld_coef(a2.c[t]), from1[t] = a2.v[t] == a1.y;
+  for (int t = 0; t < NT2; ++t) c2[t] = ld_coef(a2.c[t]), from1[t] = run1 && a2.v[t] == a1.y;
   const int64_t n2 = n >> 1;
   double2v *y1 = reinterpret_cast<double2v *>(a1.y), *y2 = reinterpret_cast<double2v *>(a2.y);
   for (int64_t i = (int64_t)bx * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(kBlock) void lin2_kernel(int64_t n, LinArgs a1, Lin
     double2v o2 = c2[0] * (from1[0] ? o1 : v2[0]);
 #pragma unroll
     for (int t = 1; t < NT2; ++t) o2 = fma2(c2[t], from1[t] ? o1 : v2[t], o2);
-    stv(y1 + i, o1, nt);
+    if (run1) stv(y1 + i, o1, nt);
     if (run2) stv(y2 + i, o2, nt);
   }
   if ((n & 1) && bx == 0 && threadIdx.x == 0) {
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(kBlock) void lin2_kernel(int64_t n, LinArgs a1, Lin
     for (int t = 1; t < NT1; ++t) o1 = __builtin_fma(c1[t], w1[t], o1);
     double o2 = c2[0] * (from1[0] ? o1 : w2[0]);
     for (int t = 1; t < NT2; ++t) o2 = __builtin_fma(c2[t], from1[t] ? o1 : w2[t], o2);
-    a1.y[i] = o1;
+    if (run1) a1.y[i] = o1;
     if (run2) a2.y[i] = o2;
   }
 }
@@ -605,7 +607,7 @@ struct KrylovEngine {
   bool q_has = false;
   LinArgs q_lin{};
   int q_nt = 0;
-  int q_regs[3] = {-1, -1, -1};
+  int q_regs[4] = {-1, -1, -1, -1};  // registers its coefficients (and its condition) read
   long long q_gate = -1;  // >= 0: held back past the convergence rule of iteration q_gate - 1 (see lin_kernel)
   int64_t cur_it = 0;     // the iteration iterate() is enqueuing
   // Sweep directions (see storm_hip_solve_cg): every streaming statement deals its blocks out from the end of the
@@ -658,7 +660,7 @@ struct KrylovEngine {
         continue;
       }
       const int span = o.op == SC_SYMORTHO ? 3 : 1;
-      for (int t = 0; t < 3; ++t)
+      for (int t = 0; t < 4; ++t)
         if (q_regs[t] >= (int)o.d && q_regs[t] < (int)o.d + span) return 0;
     }
     return verdict;
@@ -834,13 +836,14 @@ struct KrylovEngine {
     q_gate = -1;
   }
   void lin_v(V yv, const std::vector<Term> &terms, int cond = -1) {
-    if (c->opt_lin_fuse != 0 && cond < 0 && terms.size() >= 1 && terms.size() <= 3 && n > 1) {
+    if (c->opt_lin_fuse != 0 && terms.size() >= 1 && terms.size() <= 3 && n > 1) {
       flush(true);
       if (!ok()) return;
       LinArgs a{};
       a.y = yv->d;
+      a.cond = cond >= 0 ? S + cond : nullptr;
       const int nt = (int)terms.size();
-      int regs[3] = {-1, -1, -1};
+      int regs[4] = {-1, -1, -1, cond};
       for (int t = 0; t < nt; ++t) a.v[t] = terms[(size_t)t].v->d, a.c[t] = scal(terms[(size_t)t].c), regs[t] = terms[(size_t)t].c.reg;
       if (q_has) {  // the held-back statement and this one: one pass
         q_has = false;
@@ -851,7 +854,7 @@ struct KrylovEngine {
         }
       } else {
         q_has = true, q_lin = a, q_nt = nt;
-        for (int t = 0; t < 3; ++t) q_regs[t] = regs[t];
+        for (int t = 0; t < 4; ++t) q_regs[t] = regs[t];
       }
       return;
     }
@@ -913,7 +916,7 @@ struct KrylovEngine {
     {
       bool overtake = !queued_touches(yv->d, true) && !(wv != nullptr && queued_touches(wv->d, false));
       for (const Term &t : terms) overtake = overtake && !queued_touches(t.v->d, false);
-      with_held = q_has && !overtake && q_gate < 0 && c->opt_lin_fuse != 0 && one_launch(2) && n > 1 &&
+      with_held = q_has && !overtake && q_gate < 0 && q_lin.cond == nullptr && c->opt_lin_fuse != 0 && one_launch(2) && n > 1 &&
                   (reg_yy >= 0 || (reg_yw >= 0 && wv != nullptr));
       if (with_held) {
         flush(true);                         // (may still settle it: a scalar program in the way)
