@@ -12,9 +12,10 @@
 //     iteration remain, one behind each reduction;
 //   * the operator is read from a compact fp64 sliced-ELL copy made when the operator was built
 //     ([ext 64 f64][col W x 64 i32][val W x 64 f64] per slice, slot-major; small: it stays in L2 / Infinity Cache);
-//   * a reduction IS the barrier: every block publishes (partial, sequence number) in its own slot -- the value,
-//     then, once that store is acknowledged, the tag -- and every block polls all slots with single 16-byte
-//     coherent loads until each carries the current sequence number, then folds the values in slot order.  All
+//   * a reduction IS the barrier: every block publishes its partial in its own slot as two self-validating 8-byte
+//     words { half of the value, sequence number } (fire and forget: no ordering to rely on), and every block polls
+//     all slots with single 16-byte coherent loads until both words of each carry the current sequence number, then
+//     folds the values in slot order.  All
 //     blocks hold bit-identical alpha, beta and the same convergence verdict (the exit condition is uniform), and
 //     a synchronisation point costs about 2.5 memory round trips instead of the 6 of "partials, counter barrier,
 //     read partials" (an iteration is a chain of ~0.8 us round trips; nothing else matters at this size);
