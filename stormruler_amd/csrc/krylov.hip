@@ -613,7 +613,7 @@ struct KrylovEngine {
   // Sweep directions (see storm_hip_solve_cg): every streaming statement deals its blocks out from the end of the
   // rows where the previous one stopped -- what the Infinity Cache still holds.  Same rows and slots per block.
   int sweep_dir = 1;
-  int flip() { return (c->opt_sweep_alternate != 0 && c->comm == nullptr) ? (sweep_dir ^= 1) : 0; }
+  int flip() { return (c->opt_sweep_alternate != 0) ? (sweep_dir ^= 1) : 0; }
   int stream_flags() { return (int)(c->opt_blas1_nt != 0) | (flip() << 1); }
   // per-method vectors and registers
   V p = nullptr, q = nullptr, r = nullptr, rt = nullptr, t = nullptr, u = nullptr, v = nullptr, y = nullptr, z = nullptr,

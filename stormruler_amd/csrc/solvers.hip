@@ -859,7 +859,7 @@ int storm_hip_solve_cg(const storm_hip_op *op, double alpha, double beta, const 
   // served from it runs ~18 % faster than from HBM, tools/mall_probe.hip), so every kernel starts where its
   // predecessor stopped: iteration k even -- SpMV forward, cg_r backward, cg_xp forward; k odd -- the mirror image.
   // Blocks keep their rows and their partial slots: the same bits either way.
-  const bool sweep = c->opt_sweep_alternate != 0 && c->comm == nullptr;
+  const bool sweep = c->opt_sweep_alternate != 0;  // (per rank: with a communicator too)
   const int nt_stream = (int)(c->opt_blas1_nt != 0 && !(sweep && c->opt_sweep_alternate == 2));
   // Reductions that finish inside the kernels producing their partials (ticket_device.hpp), one rank: an iteration
   // is then three launches -- SpMV (+ <p,z>), cg_r (+ <r,r>, beta, the convergence rule), cg_xp.
@@ -949,7 +949,7 @@ int storm_hip_solve_bicgstab(const storm_hip_op *op, double alpha, double beta, 
   }
   // Sweep directions as in storm_hip_solve_cg: every streaming kernel starts at the end of the rows where its
   // predecessor stopped (what the Infinity Cache still holds); blocks keep their rows and partial slots.
-  const bool sweep = c->opt_sweep_alternate != 0 && c->comm == nullptr && c->opt_graph == 0;
+  const bool sweep = c->opt_sweep_alternate != 0 && c->opt_graph == 0;
   int dir = 1;
   auto flip = [&]() -> int { return sweep ? (dir ^= 1) : 0; };
   // ... and reductions finished in-kernel (see storm_hip_solve_cg): five launches per iteration instead of eleven.
