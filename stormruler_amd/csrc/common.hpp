@@ -110,6 +110,7 @@ struct storm_hip_ctx {
   int stream_reverse = 0;            // ... and the same for the next elementwise kernel
   int spmv_reverse = 0;              // set around a format-4 SpMV launch by the solver: deal the tiles out from the far end
   int64_t opt_spmv_canon_groups = 2; // format-4 / 5 kernel: 128-row groups per wavefront (1 or 2)
+  int64_t opt_coop_mgs_pairs = 1;    // cooperative Gram-Schmidt chain: two steps per synchronisation point
   int64_t opt_spmv_mixed = 1;        // partitioned operators: format 4 for the groups that read no halo column, format 3 for the rest
   int64_t opt_spmv_nt_y = 1;         // format-4 kernel: store y non-temporally (A/B knob)
   int64_t opt_profile_spmv = 0;
@@ -282,8 +283,14 @@ int op_make_latency_copy(storm_hip_op *op, int64_t n, int64_t n_halo, const std:
                          const std::vector<int> &col, const std::vector<double> &val, const std::vector<double> &ext);
 bool cg_latency_eligible(const storm_hip_op *op);
 int lat_check_gave_up(storm_hip_ctx *c);
+// What the cooperative chain needs to finish an Arnoldi step itself (fused GMRES loop): the state, the Hessenberg and
+// rotation arrays, and where sqrt(<w,w>) goes.
+struct MgsGivens {
+  SolverState *st;
+  double *H, *beta, *cs, *sn, *hn_slot;
+};
 int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w, const double *const *q, int k, int m,
-                         double *H, double *norm2_out, bool normalise, bool *taken);
+                         double *H, double *norm2_out, bool normalise, bool *taken, const MgsGivens *givens = nullptr);
 int cg_latency_solve(const storm_hip_op *op, double alpha, double beta, const double *b, double *x, double *p,
                      double *r, SolverState *d_state);
 int bicgstab_latency_solve(const storm_hip_op *op, double alpha, double beta, const double *b, double *x,

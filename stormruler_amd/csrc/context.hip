@@ -130,6 +130,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "latency_path")) c->opt_latency_path = value;
   else if (!strcmp(key, "coop_mgs")) c->opt_coop_mgs = value;
   else if (!strcmp(key, "coop_mgs_min_rows")) c->opt_coop_mgs_min_rows = value;
+  else if (!strcmp(key, "coop_mgs_pairs")) c->opt_coop_mgs_pairs = value;
   else if (!strcmp(key, "spmv_mixed")) c->opt_spmv_mixed = value;
   else if (!strcmp(key, "sweep_alternate")) c->opt_sweep_alternate = value;
   else if (!strcmp(key, "spmv_canon_groups")) c->opt_spmv_canon_groups = value;

@@ -1199,7 +1199,8 @@ namespace storm {
 // solvers.hip: the Gram-Schmidt step of storm_hip_solve_gmres, shared with this engine
 int gmres_orthogonalize(storm_hip_ctx *c, int64_t n, const SolverState *st, const int *done, double *qn,
                         const double *const *q, int k, int m, double *H, double *norm2_out, double *scratch,
-                        int gram_schmidt, bool *normalised);
+                        int gram_schmidt, bool *normalised, const MgsGivens *givens = nullptr,
+                        bool *givens_done = nullptr);
 }  // namespace storm
 
 void K::init() {

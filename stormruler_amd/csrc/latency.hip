@@ -191,6 +191,50 @@ __device__ __forceinline__ void lat_allreduce2(double &s0, double &s1, char *slo
   s1 = (lds[kLatWaves] + lds[kLatWaves + 1]) + (lds[kLatWaves + 2] + lds[kLatWaves + 3]);
 }
 
+// ... and THREE (the paired Gram-Schmidt step: <w, q_i>, <w, q_i+1>, <q_i, q_i+1>): six words, 48 bytes of the slot.
+__device__ __forceinline__ void lat_allreduce3(double &s0, double &s1, double &s2, char *slots, unsigned long long seq,
+                                               double *lds /* [3 * kLatWaves] */) {
+  const unsigned tag = (unsigned)seq;
+  double v0 = lat_wave_sum(s0), v1 = lat_wave_sum(s1), v2 = lat_wave_sum(s2);
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) lds[wave] = v0, lds[kLatWaves + wave] = v1, lds[2 * kLatWaves + wave] = v2;
+  __syncthreads();
+  if (threadIdx.x < 3) {  // thread j folds and stores sum j
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < kLatWaves; ++w) t += lds[threadIdx.x * kLatWaves + w];
+    co_store_slot(slots + ((size_t)blockIdx.x * 2 + (seq & 1)) * kLatSlotStride + 16 * threadIdx.x, tag, t);
+  }
+  v0 = v1 = v2 = 0.0;
+  if (threadIdx.x < gridDim.x) {
+    const char *slot = slots + ((size_t)threadIdx.x * 2 + (seq & 1)) * kLatSlotStride;
+    int *gave_up = reinterpret_cast<int *>(slots + (size_t)2 * 256 * kLatSlotStride);
+    const long long t0 = wall_clock64();
+    for (int spins = 0;; ++spins) {
+      double x2 = 0.0;
+      const bool ok01 = co_load_slot2(slot, tag, &v0, &v1);
+      const bool ok2 = co_load_slot(slot + 32, tag, &x2);
+      v2 = x2;
+      if (ok01 && ok2) break;
+      __builtin_amdgcn_s_sleep(1);
+      if ((spins & 1023) == 1023 &&
+          (wall_clock64() - t0 > kLatTimeoutTicks || __hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        __hip_atomic_store(gave_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v0 = v1 = v2 = 0.0;
+        break;
+      }
+    }
+  }
+  v0 = lat_wave_sum(v0), v1 = lat_wave_sum(v1), v2 = lat_wave_sum(v2);
+  __syncthreads();
+  if (lane == 0 && wave < 4) lds[wave] = v0, lds[kLatWaves + wave] = v1, lds[2 * kLatWaves + wave] = v2;
+  __syncthreads();
+  s0 = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+  s1 = (lds[kLatWaves] + lds[kLatWaves + 1]) + (lds[kLatWaves + 2] + lds[kLatWaves + 3]);
+  s2 = (lds[2 * kLatWaves] + lds[2 * kLatWaves + 1]) + (lds[2 * kLatWaves + 2] + lds[2 * kLatWaves + 3]);
+}
+
 // Neighbour value of the vector an SpMV is applied to: plain x (init), or the direction p' = r + beta p formed
 // from the published rows.
 struct LatPlain {
@@ -534,14 +578,21 @@ struct MgsArgs {
   double *norm2_out;  // <w, w> after the chain
   int64_t n_rows, n_slices;
   int k, m, normalise;
+  int pairs;          // two Gram-Schmidt steps per synchronisation point (see the kernel)
   unsigned long long seq_base;  // tags of this launch: seq_base + 1 .. seq_base + k + 2 (bit 31 set: never a CG tag)
   char *slots;
   const int *done;
+  MgsGivens givens;  // st == nullptr: the caller applies the rotations
 };
 template <int S>
 __global__ __launch_bounds__(kLatBlock) void mgs_chain_kernel(MgsArgs a) {
   if (a.done && *a.done) return;  // (uniform: every block reads the same flag before any of them synchronises)
-  __shared__ double lds[kLatWaves];
+  __shared__ double lds[3 * kLatWaves];
+  // block 0 keeps column k of the Hessenberg and the earlier rotations in LDS: the Givens recurrence at the end is a
+  // chain of k dependent steps -- ~1.5 us from LDS, ~9 us through memory
+  __shared__ double hcol[kMgsMaxVectors + 1], cs_sh[kMgsMaxVectors], sn_sh[kMgsMaxVectors];
+  const bool rotate = a.givens.st != nullptr && blockIdx.x == 0;
+  if (rotate && (int)threadIdx.x < a.k) cs_sh[threadIdx.x] = a.givens.cs[threadIdx.x], sn_sh[threadIdx.x] = a.givens.sn[threadIdx.x];
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t wave_id = (int64_t)blockIdx.x * kLatWaves + (threadIdx.x >> 6);
   const int64_t n_waves = (int64_t)gridDim.x * kLatWaves;
@@ -556,7 +607,38 @@ __global__ __launch_bounds__(kLatBlock) void mgs_chain_kernel(MgsArgs a) {
     qc[s] = row[s] >= 0 ? a.q[0][row[s]] : 0.0;
     qn[s] = 0.0;
   }
-  for (int i = 0; i <= a.k; ++i) {
+  int i0 = 0;
+  if (a.pairs) {
+    // Two steps per synchronisation point.  The reference's h_{i+1} = <w - h_i q_i, q_{i+1}> is, by bilinearity,
+    // <w, q_{i+1}> - h_i <q_i, q_{i+1}>: the three dot products of the right-hand side need only the w BEFORE step i,
+    // so they share one all-reduce (the same algorithm; the roundings of the dot products group differently, as
+    // with any other summation order).  q_{i+2} travels while the reduction is in flight.
+    double qd[S];
+    for (; i0 + 1 <= a.k; i0 += 2) {
+#pragma unroll
+      for (int s = 0; s < S; ++s) qn[s] = row[s] >= 0 ? a.q[i0 + 1][row[s]] : 0.0;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int s = 0; s < S; ++s) s0 += w[s] * qc[s], s1 += w[s] * qn[s], s2 += qc[s] * qn[s];
+      if (i0 + 2 <= a.k) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) qd[s] = row[s] >= 0 ? a.q[i0 + 2][row[s]] : 0.0;
+      }
+      lat_allreduce3(s0, s1, s2, a.slots, ++seq, lds);
+      const double h0 = s0, h1 = s1 - h0 * s2;
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (rotate) hcol[i0] = h0, hcol[i0 + 1] = h1;
+        else a.H[(int64_t)i0 * a.m + a.k] = h0, a.H[(int64_t)(i0 + 1) * a.m + a.k] = h1;
+      }
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        w[s] -= h0 * qc[s];
+        w[s] -= h1 * qn[s];
+        qc[s] = qd[s];
+      }
+    }
+  }
+  for (int i = i0; i <= a.k; ++i) {
     double acc = 0.0;
 #pragma unroll
     for (int s = 0; s < S; ++s) acc += w[s] * qc[s];
@@ -565,7 +647,10 @@ __global__ __launch_bounds__(kLatBlock) void mgs_chain_kernel(MgsArgs a) {
       for (int s = 0; s < S; ++s) qn[s] = row[s] >= 0 ? a.q[i + 1][row[s]] : 0.0;
     }
     const double h = lat_allreduce(acc, a.slots, ++seq, lds, false);
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.H[(int64_t)i * a.m + a.k] = h;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      if (rotate) hcol[i] = h;  // (written back rotated, below)
+      else a.H[(int64_t)i * a.m + a.k] = h;
+    }
 #pragma unroll
     for (int s = 0; s < S; ++s) w[s] -= h * qc[s], qc[s] = qn[s];
   }
@@ -578,11 +663,37 @@ __global__ __launch_bounds__(kLatBlock) void mgs_chain_kernel(MgsArgs a) {
 #pragma unroll
   for (int s = 0; s < S; ++s)
     if (row[s] >= 0) a.w[row[s]] = a.normalise ? w[s] / hn : w[s];
+  // SolverGmres.hpp:161, :176-191 and Solver.hpp:132-140 by the thread that holds column k of the Hessenberg (the
+  // arithmetic of gmres_givens_update, solver_device.hpp, on the LDS copies; cs_sh / sn_sh were filled before the
+  // block's first barrier)
+  if (rotate && threadIdx.x == 0) {
+    const int k = a.k, m = a.m;
+    *a.givens.hn_slot = hn;
+    hcol[k + 1] = hn;
+    for (int i = 0; i < k; ++i) {
+      const double chi = cs_sh[i] * hcol[i] + sn_sh[i] * hcol[i + 1];
+      hcol[i + 1] = -sn_sh[i] * hcol[i] + cs_sh[i] * hcol[i + 1];
+      hcol[i] = chi;
+    }
+    const double ha = hcol[k], hb = hcol[k + 1];
+    const double rr = hypot(ha, hb);
+    double cs, sn;
+    if (rr > 0.0) cs = ha / rr, sn = hb / rr;
+    else cs = 1.0, sn = 0.0;
+    a.givens.cs[k] = cs, a.givens.sn[k] = sn;
+    hcol[k] = cs * ha + sn * hb;
+    hcol[k + 1] = 0.0;
+    for (int i = 0; i <= k + 1; ++i) a.givens.H[(int64_t)i * m + k] = hcol[i];
+    const double bk = a.givens.beta[k];
+    a.givens.beta[k + 1] = -sn * bk;
+    a.givens.beta[k] = bk * cs;
+    advance(a.givens.st, fabs(-sn * bk));
+  }
 }
 
 // Returns STORM_HIP_OK with *taken = false when the chain does not qualify (too many rows / vectors, a communicator).
 int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w, const double *const *q, int k, int m,
-                         double *H, double *norm2_out, bool normalise, bool *taken) {
+                         double *H, double *norm2_out, bool normalise, bool *taken, const MgsGivens *givens) {
   *taken = false;
   // (a step of the chain costs one all-reduce, ~5 us, whatever the size; the kernel-per-step path costs a launch,
   //  ~3.5 us, or 32 B/row of HBM traffic, whichever is more: the chain pays from ~0.5 M rows -- measured: step.1,
@@ -610,9 +721,12 @@ int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w
   for (int i = k + 1; i < kMgsMaxVectors; ++i) a.q[i] = q[0];
   a.w = w, a.H = H, a.norm2_out = norm2_out, a.n_rows = n, a.n_slices = n_slices, a.k = k, a.m = m;
   a.normalise = normalise ? 1 : 0;
+  a.pairs = (c->opt_coop_mgs_pairs != 0 && need <= 8) ? 1 : 0;  // (16 slices per wave + a third basis vector: spills)
   a.seq_base = (1ull << 31) | (c->lat_seq & 0x7fffffffull);  // bit 31: never the tag of a CG solve (those count from 1)
   c->lat_seq += (unsigned long long)k + 2;
   a.slots = c->d_lat_slots, a.done = done;
+  a.givens = (givens != nullptr && normalise && c->opt_coop_mgs != 2) ? *givens  // (coop_mgs = 2: A/B, rotations by the caller)
+                                                                        : MgsGivens{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   void *args[] = {&a};
   HIP_TRY(hipLaunchCooperativeKernel(fn, dim3((unsigned)blocks), dim3(kLatBlock), args, 0, c->stream));
   *taken = true;

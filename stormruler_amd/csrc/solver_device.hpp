@@ -41,6 +41,35 @@ __device__ inline void begin(SolverState *st, double initial_error) {
     for (int i = 0; i < kStateRing; ++i) st->done_ring[i] = 1;
 }
 
+// The device-side state of a GMRES cycle and the Givens update of Hessenberg column k with the beta recurrence
+// (SolverGmres.hpp:176-191; sym_ortho: Crow/MathUtils.hpp:164-179), followed by the convergence rule.  One thread.
+struct GmresDev {
+  double *H, *beta, *cs, *sn;  // device arrays: (m+1) x m row-major, m+1, m, m
+  int m;
+};
+__device__ inline void gmres_givens_update(SolverState *st, GmresDev g, int k, double hn) {
+  const int m = g.m;
+#define H_(i, j) g.H[(i) * m + (j)]
+  H_(k + 1, k) = hn;
+  for (int i = 0; i < k; ++i) {
+    const double chi = g.cs[i] * H_(i, k) + g.sn[i] * H_(i + 1, k);
+    H_(i + 1, k) = -g.sn[i] * H_(i, k) + g.cs[i] * H_(i + 1, k);
+    H_(i, k) = chi;
+  }
+  const double a = H_(k, k), b = H_(k + 1, k);
+  const double rr = hypot(a, b);
+  double cs, sn;
+  if (rr > 0.0) cs = a / rr, sn = b / rr;
+  else cs = 1.0, sn = 0.0;
+  g.cs[k] = cs, g.sn[k] = sn;
+  H_(k, k) = cs * H_(k, k) + sn * H_(k + 1, k);
+  H_(k + 1, k) = 0.0;
+  g.beta[k + 1] = -sn * g.beta[k];
+  g.beta[k] *= cs;
+  advance(st, fabs(g.beta[k + 1]));
+#undef H_
+}
+
 __device__ __forceinline__ double block_sum256(double v, double *lds4) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);

@@ -45,11 +45,6 @@ enum StepKind {
   STEP_GMRES_HN,          // hn = sqrt(tmp)
 };
 
-struct GmresDev {
-  double *H, *beta, *cs, *sn;  // device arrays: (m+1) x m row-major, m+1, m, m
-  int m;
-};
-
 __device__ void do_step(int kind, SolverState *st, GmresDev g) {
   double *s = st->s;
   switch (kind) {
@@ -477,27 +472,7 @@ __global__ __launch_bounds__(kBlock) void mgs_step_kernel(int64_t n, const int *
 // GMRES: Givens update of column k and the beta recurrence, SolverGmres.hpp:176-191.
 __global__ void gmres_givens_kernel(SolverState *st, GmresDev g, int k) {
   if (st->done) return;
-  const int m = g.m;
-#define H_(i, j) g.H[(i) * m + (j)]
-  H_(k + 1, k) = st->s[S_HN];
-  for (int i = 0; i < k; ++i) {
-    const double chi = g.cs[i] * H_(i, k) + g.sn[i] * H_(i + 1, k);
-    H_(i + 1, k) = -g.sn[i] * H_(i, k) + g.cs[i] * H_(i + 1, k);
-    H_(i, k) = chi;
-  }
-  // sym_ortho, Crow/MathUtils.hpp:164-179
-  const double a = H_(k, k), b = H_(k + 1, k);
-  const double rr = hypot(a, b);
-  double cs, sn;
-  if (rr > 0.0) cs = a / rr, sn = b / rr;
-  else cs = 1.0, sn = 0.0;
-  g.cs[k] = cs, g.sn[k] = sn;
-  H_(k, k) = cs * H_(k, k) + sn * H_(k + 1, k);
-  H_(k + 1, k) = 0.0;
-  g.beta[k + 1] = -sn * g.beta[k];
-  g.beta[k] *= cs;
-  advance(st, fabs(g.beta[k + 1]));
-#undef H_
+  gmres_givens_update(st, g, k, st->s[S_HN]);
 }
 
 // Classical Gram-Schmidt x2: H(j0 : j0 + kk, k) = h_pass0 + h_pass1.
@@ -734,11 +709,13 @@ namespace storm {
 // *normalised (nullable) = true when qn has already been divided by its norm (the cooperative chain does that).
 int gmres_orthogonalize(storm_hip_ctx *c, int64_t n, const SolverState *st, const int *done, double *qn,
                         const double *const *q, int k, int m, double *H, double *norm2_out, double *scratch,
-                        int gram_schmidt, bool *normalised) {
+                        int gram_schmidt, bool *normalised, const MgsGivens *givens, bool *givens_done) {
   if (normalised) *normalised = false;
+  if (givens_done) *givens_done = false;
   if (gram_schmidt == 0 && n > 0) {  // small enough for registers: the whole chain as one cooperative kernel
     bool taken = false;
-    STORM_TRY(gmres_mgs_chain_coop(c, n, done, qn, q, k, m, H, norm2_out, normalised != nullptr, &taken));
+    STORM_TRY(gmres_mgs_chain_coop(c, n, done, qn, q, k, m, H, norm2_out, normalised != nullptr, &taken, givens));
+    if (taken && givens != nullptr && givens_done && c->opt_coop_mgs != 2) *givens_done = true;
     if (taken) {
       if (normalised) *normalised = true;
       return STORM_HIP_OK;
@@ -1094,16 +1071,19 @@ int storm_hip_solve_gmres(const storm_hip_op *op, double alpha, double beta, con
     if (k == 0) STORM_TRY(start(false));                 // Solver.hpp:240-242
     double *qn = const_cast<double *>(q[k + 1]);
     STORM_TRY(d.apply(q[k], qn, nullptr, false, &nb));   // SolverGmres.hpp:155
-    bool normalised = false;
+    bool normalised = false, givens_done = false;
+    // (the cooperative Gram-Schmidt chain, when it runs, also takes the root, normalises, applies the Givens
+    //  rotations and the convergence rule in its last instructions: an inner iteration is then two launches)
+    const MgsGivens givens{d.st, d.g.H, d.g.beta, d.g.cs, d.g.sn, d.slot(S_HN)};
     STORM_TRY(gmres_orthogonalize(c, n, d.st, d.done, qn, q.data(), k, m, d.g.H, d.slot(S_TMP), d.slot(S_SCRATCH),
-                                  params->gram_schmidt, &normalised));
-    {
+                                  params->gram_schmidt, &normalised, &givens, &givens_done));
+    if (!givens_done) {
       hipLaunchKernelGGL(step_kernel, dim3(1), dim3(1), 0, c->stream, (int)STEP_GMRES_HN, d.st, d.g, false);
       HIP_TRY(hipGetLastError());
       if (!normalised) STORM_TRY(k_scale(c, qn, n, dev_scal(d.slot(S_HN)), true, d.done));      // :162
+      hipLaunchKernelGGL(gmres_givens_kernel, dim3(1), dim3(1), 0, c->stream, d.st, d.g, k);    // :176-191
+      HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(gmres_givens_kernel, dim3(1), dim3(1), 0, c->stream, d.st, d.g, k);    // :176-191
-    HIP_TRY(hipGetLastError());
     if (k == m - 1) STORM_TRY(finalize(k, false));       // Solver.hpp:244-246
     bool stop = false;
     STORM_TRY(post_and_poll(d, it, &stop));
