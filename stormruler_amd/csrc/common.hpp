@@ -117,7 +117,7 @@ struct storm_hip_ctx {
   int64_t opt_blas1_nt = 1;  // non-temporal loads/stores in the streaming kernels
   int64_t opt_graph = 0;     // replay CG / BiCGStab iterations from a captured hipGraph: measured slower than eager launches (profiles/r01_notes.md), off
   int64_t opt_fuse_mgs = 1;  // GMRES/MGS on one rank, <= 2048 blocks: each step folds the previous step's partials itself (no final-reduction launch in between)
-  int64_t opt_coop_mgs_min_rows = 400000;  // ... from this many rows on (below, a launch per step is cheaper than an all-reduce per step)
+  int64_t opt_coop_mgs_min_rows = 0;  // ... from this many rows on (0: always; with two steps per synchronisation point the chain is no slower than a launch per step even on small meshes)
   int64_t opt_coop_mgs = 1;             // GMRES: the Gram-Schmidt chain of an Arnoldi step as one cooperative kernel (latency.hip)
   int64_t opt_latency_path = 1;         // small operators: CG as one cooperative persistent kernel (latency.hip)
   int opt_lin_fuse = 1;                 // engine: two consecutive vector statements go out as one pass

@@ -695,9 +695,9 @@ __global__ __launch_bounds__(kLatBlock) void mgs_chain_kernel(MgsArgs a) {
 int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w, const double *const *q, int k, int m,
                          double *H, double *norm2_out, bool normalise, bool *taken, const MgsGivens *givens) {
   *taken = false;
-  // (a step of the chain costs one all-reduce, ~5 us, whatever the size; the kernel-per-step path costs a launch,
-  //  ~3.5 us, or 32 B/row of HBM traffic, whichever is more: the chain pays from ~0.5 M rows -- measured: step.1,
-  //  80 k rows, 12 500 it/s per-step vs 10 600 chained; 128^3 4 030 vs 6 340)
+  // (a step of the chain costs half an all-reduce, ~2.5 us, whatever the size; the kernel-per-step path costs a launch,
+  //  ~3.5 us, or 32 B/row of HBM traffic, whichever is more -- measured, us per inner iteration, per-step vs chained:
+  //  step.1 83..106 vs 74.5, 32^3 84..109 vs 72, 64^3 91..106 vs 93, 128^3 248 vs 147)
   if (c->opt_coop_mgs == 0 || c->comm != nullptr || n < c->opt_coop_mgs_min_rows || k + 1 > kMgsMaxVectors ||
       c->opt_profile_spmv != 0)
     return STORM_HIP_OK;

@@ -235,7 +235,7 @@ def test_cooperative_gram_schmidt_chain_matches_the_kernel_per_step_path(env, sh
             ok = s.solve(x, b, op)
             runs[(coop, generic)] = (ok, s.iteration, s.history.copy(), x.to_numpy())
     ctx.set_option("coop_mgs", 1)
-    ctx.set_option("coop_mgs_min_rows", 400000)
+    ctx.set_option("coop_mgs_min_rows", 0)
     ctx.set_option("generic_solvers", 0)
     ok0, it0, h0, x0 = runs[(0, 0)]
     assert ok0
