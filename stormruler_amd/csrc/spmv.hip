@@ -710,12 +710,18 @@ __global__ __launch_bounds__(kBlock) void spmv_canon_kernel(SellArgs A, CanonArg
       vw[g].y = *reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(types_sh) + (type_pair[g] >> 8));
     }
     double acc_a = 0.0, acc_b = 0.0;
+#ifdef STORM_CANON_EXPERIMENT  // (measurement only: the kernel's memory floor -- no table lookups, one add per neighbour)
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc_a += xg[g][k].x, acc_b += xg[g][k].y;
+    acc_a += __longlong_as_double((long long)vw[g].x), acc_b += __longlong_as_double((long long)vw[g].y);
+#else
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const unsigned ba = (unsigned)(vw[g].x >> (8 * (k + 1))) & 0xffu, bb = (unsigned)(vw[g].y >> (8 * (k + 1))) & 0xffu;
       acc_a += *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + ba) * (xg[g][k].x - xi[g].x);
       acc_b += *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + bb) * (xg[g][k].y - xi[g].y);
     }
+#endif
     const double ext_a = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + ((unsigned)vw[g].x & 0xffu));
     const double ext_b = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + ((unsigned)vw[g].y & 0xffu));
     double2v yi;
