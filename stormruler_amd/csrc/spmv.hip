@@ -684,7 +684,11 @@ __global__ __launch_bounds__(kBlock) void spmv_canon_kernel(SellArgs A, CanonArg
       t = t < 0 ? 0 : t;
       t = t > C.max_gather ? C.max_gather : t;
       // (32-bit byte offset from a uniform base: n_rows + n_halo < 2^28 is a condition of the paired formats)
+#if defined(STORM_CANON_EXPERIMENT) && STORM_CANON_EXPERIMENT >= 2  // (measurement only: no gathers either)
+      xg[g][k] = xi[g] + (double)t;
+#else
       xg[g][k] = *reinterpret_cast<const double2v *>(xg_base + (size_t)((uint32_t)t << 3));
+#endif
     }
     e[g] = 0.0;
     if (M1 >= 0 && (lane == 0 || lane == kWave - 1))  // x[rc - 1] of lane 0, x[rc + 2] of lane 63
