@@ -456,6 +456,51 @@ __global__ __launch_bounds__(kBlock) void lin_dot_prog_kernel(int64_t n, LinArgs
   publish_and_finish<2>(partials, mine, f, sweep_block(nt));
 }
 
+// A diagonal preconditioner and the reductions behind it in one pass: z = d .* r, <r, z>, <r, r> (preconditioned CG,
+// SolverCg.hpp:100-115).  Rows per block and order of a thread's terms are those of multi_dot_accumulate<2>
+// (blas1_device.hpp), so the sums carry the bits of the separate vmul + multi-dot.
+__global__ __launch_bounds__(kBlock) void vmul_dots_prog_kernel(int64_t n, double *__restrict__ z,
+                                                                const double *__restrict__ d,
+                                                                const double *__restrict__ r, double *partials,
+                                                                const int *done, int nt, FinalPass f) {
+  if (done && *done) return;
+  __shared__ double lds4[4];
+  const unsigned bx = sweep_block(nt);
+  const bool ntl = nt & 1;
+  const int64_t n2 = n >> 1;
+  double2v *z2 = reinterpret_cast<double2v *>(z);
+  const double2v *d2 = reinterpret_cast<const double2v *>(d), *r2 = reinterpret_cast<const double2v *>(r);
+  double acc_rz = 0.0, acc_rr = 0.0;
+  for (int64_t base = (int64_t)bx * (kBlock * kUnroll) + threadIdx.x; base < n2; base += (int64_t)gridDim.x * (kBlock * kUnroll)) {
+    double2v vd[kUnroll], vr[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t i = base + u * kBlock;
+      if (i < n2) vd[u] = ldv(d2 + i, ntl), vr[u] = ldv(r2 + i, ntl);
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t i = base + u * kBlock;
+      if (i < n2) {
+        const double2v vz = vd[u] * vr[u];
+        stv(z2 + i, vz, ntl);
+        acc_rz += vr[u].x * vz.x;
+        acc_rz += vr[u].y * vz.y;
+        acc_rr += vr[u].x * vr[u].x;
+        acc_rr += vr[u].y * vr[u].y;
+      }
+    }
+  }
+  if ((n & 1) && bx == 0 && threadIdx.x == 0) {
+    const double vz = d[n - 1] * r[n - 1];
+    z[n - 1] = vz;
+    acc_rz += r[n - 1] * vz;
+    acc_rr += r[n - 1] * r[n - 1];
+  }
+  const double mine[2] = {block_sum256(acc_rz, lds4), block_sum256(acc_rr, lds4)};
+  publish_and_finish<2>(partials, mine, f, bx);
+}
+
 // A held-back vector statement, the statement that follows it, and the reductions of THAT statement's result, in
 // one pass (lin2_kernel + lin_dot_prog_kernel): BiCGStab's "x += alpha p + omega s;  r = s - omega t;  |r|^2, <rt, r>"
 // reads x, p, r, t, rt and writes x, r once -- the hand-fused loop's second half-step.
@@ -594,7 +639,9 @@ struct KrylovEngine {
   int red_nb = 0, red_k = 0;
   RedOut red_out{};
   // a reduction whose partials kernel is launched at flush(), with the final pass and the scalar program inside
-  enum { PEND_NONE, PEND_DOTS, PEND_LIN_DOT, PEND_LIN2_DOT } pend = PEND_NONE;
+  enum { PEND_NONE, PEND_DOTS, PEND_LIN_DOT, PEND_LIN2_DOT, PEND_VMUL_DOTS } pend = PEND_NONE;
+  double *pend_z = nullptr;
+  const double *pend_d = nullptr, *pend_r = nullptr;
   const double *pend_a = nullptr, *pend_w = nullptr;
   DotPtrs pend_bs{};
   LinArgs pend_lin{}, pend_lin0{};  // (pend_lin0: the held-back statement of PEND_LIN2_DOT)
@@ -711,6 +758,8 @@ struct KrylovEngine {
           default: DOTS_GO(8); break;
         }
 #undef DOTS_GO
+      } else if (pend == PEND_VMUL_DOTS) {
+        hipLaunchKernelGGL(vmul_dots_prog_kernel, g, b, 0, c->stream, n, pend_z, pend_d, pend_r, c->d_partials, dp, nti, f);
       } else if (pend == PEND_LIN_DOT) {
 #define LIN_GO(NT_) hipLaunchKernelGGL(lin_dot_prog_kernel<NT_>, g, b, 0, c->stream, n, pend_lin, pend_w, pend_yy, c->d_partials, dp, nti, f)
         switch (pend_nt) {
@@ -1043,6 +1092,22 @@ struct KrylovEngine {
     }
     if (st != STORM_HIP_OK) fail(st);
   }
+  // z = P(r) AND reg_rz = <r, z>, reg_rr = <r, r>: one pass when the preconditioner is the library's diagonal one.
+  void pre_dots(V zv, const storm_hip_vec *rv, int reg_rz, int reg_rr) {
+    if (pre_diag == nullptr || c->opt_lin_fuse == 0 || !one_launch(2) || zv == rv) {
+      pre(zv, rv);
+      dots(rv, {{reg_rz, zv}, {reg_rr, rv}});
+      return;
+    }
+    flush();
+    if (!ok()) return;
+    ++pre_applies;
+    int nb = stream_blocks(n);
+    if ((int64_t)nb * 2 > c->partials_capacity) nb = (int)(c->partials_capacity / 2);
+    pend = PEND_VMUL_DOTS, pend_z = zv->d, pend_d = pre_diag->d, pend_r = rv->d, pend_flags = stream_flags();
+    red_k = 2, red_out.idx[0] = reg_rz, red_out.idx[1] = reg_rr;
+    red_nb = nb, red_pending = true;
+  }
   // The dispatch every preconditioned body repeats (chained mul, Operator.hpp:82-88):
   //   left: z = P(y = A x);  right: z = A(y = P x);  none: z = A x.
   void mul_side(V zv, V yv, const storm_hip_vec *xv) {
@@ -1286,8 +1351,7 @@ void K::iterate(int64_t it) {
       axpy(x, R(r_alpha), p);
       if (P) {
         axpy(r, mR(r_alpha), z);
-        pre(z, r);
-        dots(r, {{r_gamma, z}, {R_T1, r}});
+        pre_dots(z, r, r_gamma, R_T1);
         sc(SC_SQRT, R_ERR, R_T1);
       } else {
         lin_dots(r, {{num(1.0), r}, {mR(r_alpha), z}}, r_gamma);

@@ -469,8 +469,8 @@ def test_paired_vector_statements_give_the_same_bits(kind):
     for fuse in (1, 0):
         ctx.set_option("lin_fuse", fuse)
         for variant in ("lambda", "jacobi-right", "jacobi-left"):
-            if kind == "cg" and variant != "lambda":
-                continue
+            if kind == "cg" and variant == "jacobi-left":
+                continue  # (CG takes its preconditioner one way only)
             api.rng_reset()
             s = cls()
             s.record_history, s.num_iterations = True, 80
