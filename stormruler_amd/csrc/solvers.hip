@@ -475,6 +475,68 @@ __global__ void gmres_givens_kernel(SolverState *st, GmresDev g, int k) {
   gmres_givens_update(st, g, k, st->s[S_HN]);
 }
 
+// TWO modified-Gram-Schmidt steps per pass, the reductions finished in the kernel (ticket_device.hpp):
+//   w -= ha qa;  w -= hb qb;                       (ha, hb from the Hessenberg; qa == nullptr: nothing to subtract,
+//                                                   qb == nullptr: one vector)
+//   then, of the updated w:  a = <w, qc>, b = <w, qd>, c = <qc, qd>   ->   *out_c = a,  *out_d = b - a c
+//   (the reference's h = <w - a qc, qd>, by bilinearity -- see mgs_chain_kernel, latency.hip);
+//   qd == nullptr: *out_c = <w, qc>;  qc == nullptr: *out_c = <w, w> (SolverGmres.hpp:161).
+// 24 B/row/step and half a launch per step instead of 32 B/row/step and two launches (mgs_step_kernel + final pass).
+__global__ __launch_bounds__(kBlock) void mgs_pair_kernel(int64_t n, const int *done, double *__restrict__ w,
+                                                          const double *ha, const double *hb,
+                                                          const double *__restrict__ qa, const double *__restrict__ qb,
+                                                          const double *__restrict__ qc, const double *__restrict__ qd,
+                                                          double *out_c, double *out_d, TicketArgs tickets, int nt) {
+  if (done && *done) return;
+  __shared__ double lds4[4];
+  const double va = qa ? *ha : 0.0, vb = qb ? *hb : 0.0;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  const int64_t n2 = n >> 1;
+  double2v *w2 = reinterpret_cast<double2v *>(w);
+  const double2v *a2 = reinterpret_cast<const double2v *>(qa), *b2 = reinterpret_cast<const double2v *>(qb);
+  const double2v *c2 = reinterpret_cast<const double2v *>(qc), *d2 = reinterpret_cast<const double2v *>(qd);
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
+    double2v vw = ldv(w2 + i, nt), xa = {0.0, 0.0}, xb = {0.0, 0.0}, xc = {0.0, 0.0}, xd = {0.0, 0.0};
+    if (qa) xa = ldv(a2 + i, nt);
+    if (qb) xb = ldv(b2 + i, nt);
+    if (qc) xc = ldv(c2 + i, nt);
+    if (qd) xd = ldv(d2 + i, nt);
+    if (qa) {
+      vw -= va * xa;
+      if (qb) vw -= vb * xb;
+      stv(w2 + i, vw, nt);
+    }
+    if (qc) {
+      s0 += vw.x * xc.x, s0 += vw.y * xc.y;
+      if (qd) s1 += vw.x * xd.x, s1 += vw.y * xd.y, s2 += xc.x * xd.x, s2 += xc.y * xd.y;
+    } else {
+      s0 += vw.x * vw.x, s0 += vw.y * vw.y;
+    }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    double vw = w[i];
+    if (qa) {
+      vw -= va * qa[i];
+      if (qb) vw -= vb * qb[i];
+      w[i] = vw;
+    }
+    if (qc) {
+      s0 += vw * qc[i];
+      if (qd) s1 += vw * qd[i], s2 += qc[i] * qd[i];
+    } else {
+      s0 += vw * vw;
+    }
+  }
+  const double mine[3] = {block_sum256(s0, lds4), block_sum256(s1, lds4), block_sum256(s2, lds4)};
+  if (threadIdx.x >= kWave) return;
+  double total[3];
+  if (ticket_reduce_wave0<3>(tickets, mine, qd ? 3 : 1, blockIdx.x, gridDim.x, total) && threadIdx.x == 0) {
+    *out_c = total[0];
+    if (qd) *out_d = total[1] - total[0] * total[2];
+  }
+}
+
 // Classical Gram-Schmidt x2: H(j0 : j0 + kk, k) = h_pass0 + h_pass1.
 __global__ void gmres_cgs2_combine_kernel(const int *done, double *H, int m, int k, int j0, int kk,
                                           const double *scratch) {
@@ -729,6 +791,26 @@ int gmres_orthogonalize(storm_hip_ctx *c, int64_t n, const SolverState *st, cons
     }
     HIP_TRY(hipMemsetAsync(norm2_out, 0, sizeof(double), c->stream));
     if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, norm2_out, 1));
+    return STORM_HIP_OK;
+  }
+  if (gram_schmidt == 0 && c->comm == nullptr && c->opt_ticket_reduce != 0 && c->opt_coop_mgs_pairs != 0) {
+    // two steps per pass (mgs_pair_kernel): ceil((k + 1) / 2) + 1 launches for the k + 1 basis vectors
+    const int nbp = (int)std::min<int64_t>(std::max<int64_t>(1, ((n >> 1) + kBlock - 1) / kBlock),
+                                           std::min<int64_t>(32768, c->partials_capacity / 3));
+    const TicketArgs t{c->d_tickets, c->d_partials, c->d_ticket_sums};
+    const int nti = (int)(c->opt_blas1_nt != 0);
+    auto h_of = [&](int i) { return &H[(int64_t)i * m + k]; };
+    auto launch = [&](int sub, int nsub, int nxt) {  // subtract q[sub .. sub + nsub), then the dots of q[nxt], q[nxt + 1]
+      const int nnext = std::min(2, k + 1 - nxt);    // 2: a pair; 1: one vector; 0: the norm
+      hipLaunchKernelGGL(mgs_pair_kernel, dim3(nbp), dim3(kBlock), 0, c->stream, n, done, qn,
+                         nsub >= 1 ? h_of(sub) : nullptr, nsub >= 2 ? h_of(sub + 1) : nullptr,
+                         nsub >= 1 ? q[sub] : nullptr, nsub >= 2 ? q[sub + 1] : nullptr,
+                         nnext >= 1 ? q[nxt] : nullptr, nnext >= 2 ? q[nxt + 1] : nullptr,
+                         nnext >= 1 ? h_of(nxt) : norm2_out, nnext >= 2 ? h_of(nxt + 1) : (double *)nullptr, t, nti);
+    };
+    launch(0, 0, 0);
+    for (int i = 0; i <= k; i += 2) launch(i, std::min(2, k + 1 - i), i + 2);
+    HIP_TRY(hipGetLastError());
     return STORM_HIP_OK;
   }
   if (gram_schmidt == 0) {
