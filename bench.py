@@ -6,20 +6,32 @@
 A "step" is one CG iteration (one pass of the hot path: stencil SpMV + the BLAS-1 ops of
 SolverCg.hpp:96-123) on the per-GPU 256^3 7-point Poisson block of BASELINE.json configs[1]
 (synthetic structured-as-unstructured face graph, b = 1, x0 = 0, fp64, tolerances disabled so
-exactly K iterations run).  For N > 1 (launched by torch.distributed.run, one rank per GPU)
-the global mesh is 256 x 256 x (256 N) row-partitioned in z-slabs (weak scaling): halo planes
-and dot-product all-reduces go over RCCL inside libstorm_hip.so.
+exactly K iterations run).  For N > 1 (one rank per GPU) the global mesh is 256 x 256 x (256 N)
+row-partitioned in z-slabs (weak scaling): halo planes and dot-product all-reduces move inside
+libstorm_hip.so (RCCL, or the library's peer-window transport).
 
-Prints ONE JSON line on rank 0.  `value` = 256^3-block CG iterations per second summed over the
-GPUs (N x the global iteration rate; at N = 1 plain CG it/s).  `roofline` prices the SpMV
-(sliced-ELL gather kernel with the fused <p, Ap> epilogue) from HIP-event pairs recorded around
-every launch on the library's compute stream during a second, identical solve.  `achieved` is
-SURVEY.md 8d's ALGORITHMIC bytes (fp64 weights + int32 columns) over the launch time; the library
-stores this operator -- few distinct weights and column offsets -- in a lossless byte-indexed
-record format that moves a third of those bytes (`format_bytes_per_launch`, `frac_of_format_bytes`),
-so `achieved` can exceed the HBM peak.  `general_mesh_path` repeats the measurement with that
-format switched off (fp64 records: what a mesh with all-distinct weights gets).  `cpu_baseline`
-times the CPU oracle (single thread, the reference is single-threaded) on a bounded sample.
+Prints ONE JSON line on rank 0.
+  value             256^3-block CG iterations per second summed over the GPUs (at N = 1 plain CG it/s) on the record
+                    format the operator qualifies for (the natural-order box: byte-indexed canonical rows);
+  value_general     the same solve on fp64 records, the format ANY mesh gets (Triangle, graded, renumbered);
+  roofline          the SpMV kernel of the headline run from HIP-event pairs around every launch on the library's
+                    compute stream during a second, identical solve.  `achieved` / `frac` price the bytes the
+                    operator's record format REALLY streams per launch (records + x + y: a physical HBM fraction
+                    <= 1).  `traffic` = HBM bytes per launch by PMC (FETCH_SIZE doubled + WRITE_SIZE, separate
+                    rocprofv3 passes of a child process started by THIS run); when that measurement is unavailable
+                    `traffic` is null and `traffic_from_profile` quotes the committed profile with its file hash.
+                    SURVEY.md 8d's fp64-weight + int32-column bytes over the same time are `effective_vs_8d_GBs`
+                    (may exceed the peak: the byte-indexed formats do not move those bytes -- not a bandwidth);
+  roofline_general  the same for the fp64-record kernel, where streamed bytes == 8d's algorithmic bytes;
+  roofline_permuted_rcm  SURVEY.md 8d's unstructured stress variant: cells renumbered by the seeded permutation,
+                    then reverse Cuthill-McKee; whatever record format that operator gets;
+  cpu_baseline      the CPU oracle (single thread, the reference is single-threaded) on a bounded sample.
+
+N > 1: every rank process is a SUPERVISOR that never touches the GPU; it starts the measuring rank as a child with
+a wall-clock budget.  The child runs a bounded pre-flight (one halo exchange + one all-reduce on a tiny slab stack,
+checked numerically) before the 256^3 setup.  If any rank's child fails or exceeds the budget, all children are
+killed and a FRESH set starts on the next transport of the chain (rccl -> ipc -> host-staged); the line records
+`transport` and `transport_fallback`.
 """
 from __future__ import annotations
 
@@ -53,21 +65,47 @@ def main() -> int:
     ap.add_argument("--skip-general", action="store_true", help="skip the fp64-record repeat of the measurement")
     ap.add_argument("--skip-blas1", action="store_true", help="skip the per-kernel BLAS-1 rates")
     ap.add_argument("--shared-device", action="store_true",
-                    help="debug: all ranks on device 0 over the host-staged transport (gloo); exercises the N > 1 "
-                         "code path of this script on a one-GPU box -- the rates it prints mean nothing")
-    ap.add_argument("--transport", default="rccl", choices=["rccl", "ipc"],
-                    help="N > 1: RCCL (halo send/recv + all-reduce; the default) or the library's peer-window transport "
-                         "(hipIpc-mapped device memory, direct stores over xGMI, one-shot rank-ordered all-reduce fused "
-                         "into the reductions' final pass; verified with 2-4 ranks on one GPU, not yet across GPUs)")
+                    help="debug: all ranks on device 0 (transport chain ipc,host); exercises the N > 1 code path of this "
+                         "script on a one-GPU box -- the rates it prints mean nothing")
+    ap.add_argument("--transport", default=None,
+                    help="N > 1: comma-separated chain tried in order, each attempt with FRESH rank processes: rccl (halo "
+                         "send/recv + all-reduce), ipc (the library's peer-window transport: hipIpc-mapped device memory, "
+                         "direct stores over xGMI, rank-ordered all-reduce fused into the reductions' final pass), host "
+                         "(halo planes and scalars staged through host memory over gloo).  Default rccl,ipc,host "
+                         "(--shared-device: ipc,host)")
+    ap.add_argument("--attempt-seconds", default="240,150,150",
+                    help="wall-clock budget of the 1st, 2nd, 3rd transport attempt (N > 1)")
+    ap.add_argument("--inject-fail", default="", help="test hook: TRANSPORT=hang|exit|wrong[:RANK] makes that attempt fail")
     ap.add_argument("--force-comm", action="store_true",
                     help="take the multi-rank code path (process group, RCCL communicator, all-reduces) even at N = 1")
     ap.add_argument("--min-seconds", type=float, default=0.25,
                     help="the K-step solve is repeated (each repeat bracketed by barrier + sync, max over ranks) until "
                          "the timed repeats add up to this; ms_per_step is the median repeat")
+    ap.add_argument("--traffic", default="measure", choices=["measure", "profile", "off"],
+                    help="roofline.traffic: measure = two rocprofv3 --pmc passes of a child process in this run (N = 1, "
+                         "edge 256); profile = quote profiles/spmv_hbm_traffic.json as traffic_from_profile only")
+    ap.add_argument("--skip-permuted", action="store_true", help="skip the permuted + RCM stress variant (SURVEY.md 8d)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    chain = [t for t in (args.transport or ("ipc,host" if args.shared_device else "rccl,ipc,host")).split(",") if t]
+    for t in chain:
+        if t not in ("rccl", "ipc", "host"):
+            ap.error(f"unknown transport {t!r}")
 
+    if args.pmc_child:
+        return pmc_child(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        return launch_ranks(args.gpus)
+        return launch_ranks(args.gpus, args)
+    if args.gpus > 1 and os.environ.get("STORM_BENCH_WORKER") != "1":
+        return supervise(args, chain)
+    transport = os.environ.get("STORM_BENCH_TRANSPORT", chain[0])
+    if os.environ.get("STORM_BENCH_WORKER") == "1":
+        # a rank that hangs inside a C call (RCCL bootstrap, a stream wait) never returns to the interpreter: the
+        # default action of SIGALRM ends the process whatever it is doing; cancelled once the pre-flight has passed
+        import signal
+
+        signal.signal(signal.SIGALRM, signal.SIG_DFL)
+        signal.alarm(int(os.environ.get("STORM_BENCH_PREFLIGHT_SECONDS", "120")))
 
     import numpy as np
     import torch
@@ -90,7 +128,41 @@ def main() -> int:
     if world > 1 or args.force_comm:
         os.environ.setdefault("RANK", "0"), os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"), os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("gloo" if args.shared_device else "nccl")
+        # torch.distributed only bootstraps (ids, window handles, barriers, the max of timings): gloo whenever the data
+        # path itself is not RCCL, so that a rank pair RCCL cannot serve still has a control plane
+        dist.init_process_group("nccl" if (transport == "rccl" and not args.shared_device) else "gloo")
+
+    def connect(ctx_):
+        if world == 1:
+            if args.force_comm:
+                ctx_.comm_init(api.Context.comm_unique_id(), 1, 0)
+            else:
+                dist.connect(ctx_)
+        elif transport == "ipc":
+            dist.connect_ipc(ctx_)
+        elif transport == "host":
+            dist.connect_host_staged(ctx_)
+        else:
+            dist.connect(ctx_)
+
+    preflight = None
+    if world > 1:
+        inject = dict(kv.split("=") for kv in args.inject_fail.split(",") if "=" in kv).get(transport, "")
+        kind, _, who = inject.partition(":")
+        hit = bool(kind) and (who == "" or int(who) == rank)
+        if hit and kind == "exit":
+            print(f"bench.py: injected failure on rank {rank} ({transport})", file=sys.stderr)
+            os._exit(41)
+        if hit and kind == "hang":
+            import signal as _sig
+
+            _sig.alarm(0)
+            time.sleep(3600)
+        preflight = run_preflight(api, dist, mesh, partition, connect, local_rank, world, rank, wrong=hit and kind == "wrong")
+    if os.environ.get("STORM_BENCH_WORKER") == "1":
+        import signal
+
+        signal.alarm(0)
 
     n, K, W = args.n, args.steps, args.warmup
     t_setup = time.time()
@@ -99,6 +171,7 @@ def main() -> int:
         plan = None
     else:
         g, plan = partition.slab_partition(n, n, n, world, rank)
+    setup_breakdown = {"mesh_python": time.time() - t_setup}
     perm = None
     if args.ordering == "tile" and world == 1:
         perm = mesh.tile_ordering(n, n, n, 16, 16)
@@ -112,15 +185,10 @@ def main() -> int:
     for kv in args.opt:
         k_, v_ = kv.split("=")
         ctx.set_option(k_, int(v_))
-    if args.transport == "ipc" and world > 1:
-        dist.connect_ipc(ctx)
-    elif args.shared_device and world > 1:
-        dist.connect_host_staged(ctx)
-    elif args.force_comm and world == 1:
-        ctx.comm_init(api.Context.comm_unique_id(), 1, 0)
-    else:
-        dist.connect(ctx)
+    connect(ctx)
+    t_op = time.time()
     mat = api.StencilMatrix.from_face_graph(ctx, g)
+    setup_breakdown["operator_build"] = time.time() - t_op
     if plan is not None and plan.n_nbrs:
         mat.set_halo(plan.nbr_rank, plan.send_ptr, plan.send_idx, plan.recv_ptr)
     st = mat.stats()
@@ -178,8 +246,9 @@ def main() -> int:
         s_, x_ = run(K)
         ctx.sync()
         torch.cuda.synchronize()
+        local = time.perf_counter() - t0  # this rank's K steps are complete (every step holds two all-reduces)
         dist.barrier()
-        return dist.allreduce_max(time.perf_counter() - t0), s_
+        return dist.allreduce_max(local), s_
 
     # The driver's `--steps 20` is 6 ms of work: one interval would decide the headline.  The K-step solve is
     # repeated until the timed repeats cover --min-seconds (same count on every rank: the elapsed times are
@@ -196,22 +265,27 @@ def main() -> int:
     # ---- roofline of the SpMV: HIP-event pairs around every launch --------------------------------
     prof_iters = max(K, 20)
     roof = spmv_roofline(op, st, prof_iters)
-    fmt_name = ("typed canonical paired rows: one byte per row into a table of weight words, one common offset order (1 B/row)"
-                if st["paired_rows"] == 3 else
-                "canonical paired rows: byte-indexed weights, one common offset order (8 B/row)" if st["paired_rows"] == 2 else
-                "paired rows: byte-indexed weights + shared column offsets (12 B/row)" if st["paired_rows"] else
-                "byte-indexed weights + column offsets (16 B/row)" if st["offset_dictionary_size"] else
-                "byte-indexed weights (8 B/row + int32 columns)" if st["value_dictionary_size"] else
-                "fp64 weights + int32 columns")
-    traffic = None
+    fmt_name = record_format_name(st)
+    # HBM bytes per launch by PMC: measured by a child of THIS run (two rocprofv3 --pmc passes over a short solve of
+    # the same operator), else quoted from the committed profile -- under its own name, with the file's hash
     tfile = os.path.join(ROOT, "profiles", "spmv_hbm_traffic.json")
-    if os.path.exists(tfile) and n == 256 and world == 1:
+    traffic, traffic_general, traffic_note = None, None, None
+    if args.traffic == "measure" and n == 256 and world == 1 and rank == 0:
+        ctx.sync()
+        traffic, traffic_general, traffic_note = measure_traffic(args)
+    traffic_from_profile = None
+    if args.traffic != "off" and os.path.exists(tfile) and n == 256 and world == 1:
         try:
-            tj = json.load(open(tfile))
-            if tj.get("record_format") == fmt_name:
-                traffic = tj.get("traffic_bytes_per_launch")
+            import hashlib
+
+            raw = open(tfile, "rb").read()
+            tj = json.loads(raw)
+            traffic_from_profile = {"file": "profiles/spmv_hbm_traffic.json", "sha256": hashlib.sha256(raw).hexdigest(),
+                                    "bytes_per_launch": tj.get("traffic_bytes_per_launch") if tj.get("record_format") == fmt_name else None,
+                                    "general_bytes_per_launch": tj.get("general", {}).get("traffic_bytes_per_launch"),
+                                    "note": "from a committed rocprofv3 --pmc profile of an earlier run, NOT measured in this run"}
         except Exception:
-            traffic = None
+            traffic_from_profile = None
 
     # ---- the same problem through the fp64 records (what a mesh with all-distinct weights gets) ----
     general = None
@@ -237,12 +311,7 @@ def main() -> int:
             r0 = spmv_roofline(op0, mat0.stats(), prof_iters)
             general = {"record_format": "fp64 weights + int32 columns", "cg_iter_per_s": K / t1,
                        "ms_per_step": t1 / K * 1e3, "repeats": len(reps0)}
-            gt = None
-            try:
-                tj = json.load(open(tfile))
-                gt = tj.get("general", {}).get("traffic_bytes_per_launch") if n == 256 else None
-            except Exception:
-                gt = None
+            gt = traffic_general
             general_roof = {"kernel": "spmv_sell_kernel (fp64 records: the format any mesh gets) + fused <p,Ap> partials",
                             "bound": "hbm", "achieved": r0["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": r0["frac"], "traffic": gt, "bytes_per_launch": r0["bytes_per_launch"],
@@ -252,6 +321,45 @@ def main() -> int:
                 mat0.close()
         except Exception as e:
             general = {"error": repr(e)}
+
+    # ---- SURVEY.md 8d's unstructured stress variant: seeded permutation -> RCM, whatever format that gets ----
+    permuted = None
+    if world == 1 and not args.skip_permuted and not args.skip_general:
+        try:
+            tp = time.time()
+            g0 = g if perm is None else mesh.structured_box(n)
+            gs = mesh.permute_cells(g0, mesh.random_permutation(N))
+            gr = mesh.permute_cells(gs, mesh.rcm_ordering(gs))
+            del gs
+            matp = api.StencilMatrix.from_face_graph(ctx, gr)
+            stp = matp.stats()
+            opp = api.HipStencilOperator(matp, alpha=-1.0, beta=0.0)
+            tp = time.time() - tp
+            run(max(W, 20), opp)
+            ctx.sync()
+            repsp = []
+            while sum(repsp) < args.min_seconds and len(repsp) < 2000:
+                t1 = time.perf_counter()
+                sp_, _ = run(K, opp)
+                ctx.sync()
+                repsp.append(time.perf_counter() - t1)
+            t1 = float(np.median(repsp))
+            rp = spmv_roofline(opp, stp, prof_iters)
+            band = np.abs(np.asarray(gr.inner) - np.asarray(gr.outer))
+            permuted = {"kernel": kernel_name(stp), "record_format": record_format_name(stp), "bound": "hbm",
+                        "achieved": rp["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rp["frac"], "traffic": None,
+                        "bytes_per_launch": rp["bytes_per_launch"], "algorithmic_bytes_8d": rp["algorithmic_bytes_8d"],
+                        "effective_vs_8d_GBs": rp["effective_vs_8d_GBs"], "avg_launch_ms": rp["avg_launch_ms"],
+                        "min_launch_ms": rp["min_launch_ms"], "launches_timed": rp["launches_timed"],
+                        "cg_iter_per_s": K / t1, "ms_per_step": t1 / K * 1e3,
+                        "final_residual_rel_diff_vs_natural_order": abs(sp_.absolute_error - final_residual) / final_residual,
+                        "ordering": "numpy.random.default_rng(12345).permutation(N), then reverse Cuthill-McKee "
+                                    "(stormruler_amd.mesh.rcm_ordering)",
+                        "max_column_distance": int(band.max()), "host_seconds_permute_rcm_build": tp}
+            matp.close()
+            del gr, band
+        except Exception as e:
+            permuted = {"error": repr(e)}
 
     # a measured device-copy ceiling in the same run (achievable HBM rate, for context)
     # (two 1 GiB buffers: far beyond the 256 MiB Infinity Cache, so this is an HBM number)
@@ -313,18 +421,19 @@ def main() -> int:
                             f"no preconditioner, b=1, x0=0 [BASELINE.json configs[1]]",
                 "cells_per_gpu": N, "interior_faces_per_gpu": g.n_faces, "ordering": args.ordering,
                 "partition": "single GPU" if world == 1 else
-                             (f"z-slabs, {world} ranks, peer-window halo + all-reduce" if args.transport == "ipc" else
-                              f"z-slabs, {world} ranks, RCCL halo + all-reduce" if not args.shared_device else
-                              f"DEBUG: {world} ranks sharing one device over the host-staged transport"),
-                "value_definition": "n_gpus x K / max-over-ranks wall time of a K-iteration solve (init residual included); "
-                                    "median over the repeats listed in `timing`",
+                             (("DEBUG, ranks share ONE device: " if args.shared_device else "") + f"z-slabs, {world} ranks, " +
+                              {"ipc": "peer-window halo + all-reduce (hipIpc-mapped windows, direct stores over xGMI)",
+                               "rccl": "RCCL halo send/recv + all-reduce over xGMI",
+                               "host": "halo planes and scalars staged through host memory (gloo)"}[transport]),
+                "value_definition": "n_gpus x K / max-over-ranks wall time of a K-iteration solve (init residual included; "
+                                    "barrier + synchronize, clock, K steps, synchronize, clock, barrier); median over the "
+                                    "repeats listed in `timing`",
             },
             "roofline": {
-                "kernel": ("spmv_canon_kernel" if st["paired_rows"] >= 2 else "spmv_pair_kernel" if st["paired_rows"] else
-                           "spmv_dict_kernel" if st["value_dictionary_size"] else "spmv_sell_kernel") +
-                          " (sliced-ELL gather SpMV + fused <p,Ap> partials)",
+                "kernel": kernel_name(st) + " (sliced-ELL gather SpMV + fused <p,Ap> partials)",
                 "bound": "hbm", "achieved": roof["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": roof["frac"], "traffic": traffic,
+                "frac": roof["frac"], "traffic": traffic, "traffic_method": traffic_note,
+                "traffic_from_profile": traffic_from_profile,
                 "bytes_per_launch": roof["bytes_per_launch"], "record_format": fmt_name,
                 "avg_launch_ms": roof["avg_launch_ms"], "min_launch_ms": roof["min_launch_ms"],
                 "launches_timed": roof["launches_timed"], "measured_copy_GBs": copy_gbs,
@@ -339,6 +448,8 @@ def main() -> int:
                         "every mesh can use, where the two byte counts coincide",
             },
             "roofline_general": general_roof,
+            "roofline_permuted_rcm": permuted,
+            "value_general": general.get("cg_iter_per_s") if isinstance(general, dict) else None,
             "general_mesh_path": general,
             "blas1": blas1,
             "cpu_baseline": cpu,
@@ -347,12 +458,18 @@ def main() -> int:
                        "ms_per_step_median": elapsed / K * 1e3},
             "cg": {"iterations_per_sec_global": K / elapsed,
                    "algorithmic_bytes_per_iteration": roof["algorithmic_bytes_8d"] + 96 * N,
-                   "effective_GBs_reference_op_list": (roof["algorithmic_bytes_8d"] + 96 * N) * K / elapsed / 1e9,
+                   "reference_op_list_bytes_over_time_GBs_NOT_A_BANDWIDTH": (roof["algorithmic_bytes_8d"] + 96 * N) * K / elapsed / 1e9,
+                   "bytes_really_moved_per_iteration": roof["bytes_per_launch"] + 64 * N,
+                   "achieved_GBs_bytes_really_moved": (roof["bytes_per_launch"] + 64 * N) * K / elapsed / 1e9,
                    "final_residual": final_residual},
             "op_stats": st,
             "device": ctx.info()["name"],
             "setup_seconds": t_setup,
+            "setup_breakdown_seconds": setup_breakdown,
         }
+        if world > 1:
+            out["transport"] = transport
+            out["preflight"] = preflight
         print(json.dumps(out), flush=True)
     dist.barrier()
     try:  # leave no dangling process group / communicator behind
@@ -369,10 +486,161 @@ def main() -> int:
     return 0
 
 
-def launch_ranks(n_ranks: int) -> int:
-    """`python bench.py --gpus N` outside a launcher: start the N ranks as CHILD processes (one per GPU,
+def record_format_name(st) -> str:
+    return ("typed canonical paired rows: one byte per row into a table of weight words, one common offset order (1 B/row)"
+            if st["paired_rows"] == 3 else
+            "canonical paired rows: byte-indexed weights, one common offset order (8 B/row)" if st["paired_rows"] == 2 else
+            "paired rows: byte-indexed weights + shared column offsets (12 B/row)" if st["paired_rows"] else
+            "byte-indexed weights + column offsets (16 B/row)" if st["offset_dictionary_size"] else
+            "byte-indexed weights (8 B/row + int32 columns)" if st["value_dictionary_size"] else
+            "fp64 weights + int32 columns")
+
+
+def kernel_name(st) -> str:
+    return ("spmv_canon_kernel" if st["paired_rows"] >= 2 else "spmv_pair_kernel" if st["paired_rows"] else
+            "spmv_dict_kernel" if st["value_dictionary_size"] and st.get("uniform_width", 1) else
+            "spmv_sell_kernel")
+
+
+def run_preflight(api, dist, mesh, partition, connect, local_rank, world, rank, wrong=False):
+    """Bounded pre-flight of a transport, before the 256^3 setup: a 16 x 16 x (8 world) slab stack, ONE halo-exchanged
+    SpMV and ONE all-reduce, both checked numerically.  x = the global z index of a cell: rows away from the walls
+    must give exactly 0 (every difference x_nb - x_i is +-1 or 0 and the weights cancel in pairs), which fails at the
+    slab interfaces iff a halo plane is stale or misplaced; <1, 1> must be the global cell count exactly."""
+    import numpy as np
+
+    t0 = time.perf_counter()
+    nx = ny = 16
+    nzl = 8
+    g, plan = partition.slab_partition(nx, ny, nzl, world, rank)
+    ctx = api.Context(local_rank)
+    connect(ctx)
+    mat = api.StencilMatrix.from_face_graph(ctx, g)
+    if plan.n_nbrs:
+        mat.set_halo(plan.nbr_rank, plan.send_ptr, plan.send_idx, plan.recv_ptr)
+    op = api.HipStencilOperator(mat, alpha=1.0, beta=0.0)
+    gid = np.asarray(g.global_id[:g.n_cells], dtype=np.int64)
+    kz = (gid // (nx * ny)).astype(np.float64)
+    x = api.DeviceVector(ctx, g.n_cells, g.n_halo)
+    x.upload(kz + (1.0 if wrong else 0.0) * (rank == 1))
+    y = api.DeviceVector(ctx, g.n_cells, g.n_halo)
+    op.mul(y, x)
+    yv = y.to_numpy()
+    i, j = gid % nx, (gid // nx) % ny
+    kg = gid // (nx * ny)
+    inner = (i > 0) & (i < nx - 1) & (j > 0) & (j < ny - 1) & (kg > 0) & (kg < nzl * world - 1)
+    bad = int(np.count_nonzero(yv[inner] != 0.0))
+    ones = api.DeviceVector(ctx, g.n_cells, g.n_halo)
+    api.fill_with(ones, 1.0)
+    total = api.dot_product(ones, ones)
+    ctx.sync()
+    ok = bad == 0 and total == float(nx * ny * nzl * world)
+    worst = dist.allreduce_max(0.0 if ok else 1.0)
+    mat.close()
+    dist.barrier()
+    ctx.close()
+    res = {"ok": worst == 0.0, "halo_rows_wrong_on_this_rank": bad, "allreduce_sum": total,
+           "expected_sum": float(nx * ny * nzl * world), "seconds": time.perf_counter() - t0}
+    if worst != 0.0:
+        print(f"bench.py: pre-flight FAILED on rank {rank}: {res}", file=sys.stderr, flush=True)
+        os._exit(42)
+    return res
+
+
+def supervise(args, chain) -> int:
+    """One rank of an N > 1 run as torch.distributed.run (the driver's, or launch_ranks' below) starts it.  This process
+    never touches the GPU: it starts the measuring rank as a CHILD per transport attempt, watches it against a
+    wall-clock budget together with the other ranks' supervisors (gloo, once a second), and on any failure kills the
+    children and starts a fresh set on the next transport.  Rank 0 relays the JSON line, adding what happened."""
+    import signal
+    import socket
+    import subprocess
+
+    import torch
+    import torch.distributed as td
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    budgets = [float(v) for v in args.attempt_seconds.split(",")]
+    fallbacks, line = [], None
+    for attempt, transport in enumerate(chain):
+        budget = budgets[min(attempt, len(budgets) - 1)]
+        port = torch.zeros(1, dtype=torch.int64)
+        if rank == 0:
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                port[0] = sock.getsockname()[1]
+        td.broadcast(port, src=0)
+        env = dict(os.environ, STORM_BENCH_WORKER="1", STORM_BENCH_TRANSPORT=transport, MASTER_PORT=str(int(port[0])),
+                   STORM_BENCH_PREFLIGHT_SECONDS=str(int(min(120, budget))))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE"):  # the child makes its own rendezvous on `port`
+            env.pop(k, None)
+        out_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"storm_bench_{os.getpid()}_{attempt}.out")
+        with open(out_path, "w") as fo:
+            child = subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env, stdout=fo,
+                                     stderr=None, start_new_session=True)
+        t0 = time.perf_counter()
+        reason = None
+        while True:
+            rc = child.poll()
+            mine = torch.tensor([1.0 if rc == 0 else 0.0, 1.0 if (rc is not None and rc != 0) else 0.0,
+                                 1.0 if (rank == 0 and time.perf_counter() - t0 > budget) else 0.0], dtype=torch.float64)
+            td.all_reduce(mine)  # sums: ranks done ok, ranks failed, rank 0's clock says "over budget"
+            if mine[1] > 0:
+                reason = f"a rank's process failed (this rank's exit code: {rc})"
+                break
+            if mine[2] > 0:
+                reason = f"no result within the budget of {budget:.0f} s"
+                break
+            if mine[0] == world:
+                break
+            time.sleep(1.0)
+        if reason is None:
+            text = open(out_path).read()
+            lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+            line = lines[-1] if lines else None
+            ok = torch.tensor([1.0 if (rank != 0 or line is not None) else 0.0], dtype=torch.float64)
+            td.all_reduce(ok, op=td.ReduceOp.MIN)
+            if ok[0] == 0:
+                reason = "rank 0 printed no result line"
+        try:
+            os.remove(out_path)
+        except OSError:
+            pass
+        if reason is None:
+            break
+        if child.poll() is None:  # end exactly the process group this supervisor started
+            try:
+                os.killpg(child.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+        child.wait()
+        fallbacks.append({"transport": transport, "reason": reason, "seconds": time.perf_counter() - t0})
+        if rank == 0:
+            print(f"bench.py: transport {transport}: {reason}; " +
+                  (f"starting fresh ranks on {chain[attempt + 1]}" if attempt + 1 < len(chain) else "no transport left"),
+                  file=sys.stderr, flush=True)
+        line = None
+        td.barrier()
+    status = 0 if line is not None or rank != 0 else 1
+    if rank == 0 and line is not None:
+        out = json.loads(line)
+        out["transport_fallback"] = fallbacks
+        print(json.dumps(out), flush=True)
+    flag = torch.tensor([float(status)], dtype=torch.float64)
+    td.all_reduce(flag, op=td.ReduceOp.MAX)
+    td.destroy_process_group()
+    return int(flag[0])
+
+
+def launch_ranks(n_ranks: int, args) -> int:
+    """`python bench.py --gpus N` outside a launcher: start the N rank supervisors as CHILD processes (one per GPU,
     torch.distributed.run on 127.0.0.1) with this command line, relay their output (rank 0 prints the JSON
-    line) and return their exit code.  Nothing in this process has touched torch or HIP yet; no exec."""
+    line) and return their exit code.  Nothing in this process has touched torch or HIP; no exec.  Bounded: the
+    launcher and everything below it is ended when the attempts' budgets (plus slack) are spent."""
+    import signal
     import socket
     import subprocess
 
@@ -384,15 +652,105 @@ def launch_ranks(n_ranks: int) -> int:
     env = dict(os.environ)
     env.setdefault("OMP_NUM_THREADS", "1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    sys.stderr.write(child.stderr)
-    lines = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
-    for ln in child.stdout.splitlines():
+    n_chain = len((args.transport or ("ipc,host" if args.shared_device else "rccl,ipc,host")).split(","))
+    budgets = [float(v) for v in args.attempt_seconds.split(",")]
+    total = sum(budgets[min(i, len(budgets) - 1)] for i in range(n_chain)) + 120.0
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        stdout, stderr = child.communicate(timeout=total)
+    except subprocess.TimeoutExpired:
+        os.killpg(child.pid, signal.SIGKILL)
+        stdout, stderr = child.communicate()
+        stderr += f"\nbench.py: no result within {total:.0f} s; the rank processes were ended\n"
+    sys.stderr.write(stderr)
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    for ln in stdout.splitlines():
         if not ln.startswith("{"):
             print(ln, file=sys.stderr)
     if lines:
         print(lines[-1], flush=True)
-    return child.returncode
+    return child.returncode if child.returncode is not None else 1
+
+
+def pmc_child(args) -> int:
+    """The process rocprofv3 wraps for `roofline.traffic`: the headline operator and its fp64-record twin, a short CG
+    solve each (SpMV launches with the fused-dot epilogue, like the timed region's)."""
+    from stormruler_amd import api, mesh
+
+    g = mesh.structured_box(args.n)
+    ctx = api.Context(0)
+    for kv in args.opt:
+        k_, v_ = kv.split("=")
+        ctx.set_option(k_, int(v_))
+    b = api.DeviceVector(ctx, g.n_cells)
+    api.fill_with(b, 1.0)
+    for dict_level in (None, 0):
+        if dict_level is not None:
+            ctx.set_option("spmv_dict", dict_level)
+        mat = api.StencilMatrix.from_face_graph(ctx, g)
+        s = api.CgSolver()
+        s.num_iterations, s.absolute_error_tolerance, s.relative_error_tolerance = 12, 0.0, 0.0
+        s.solve(api.DeviceVector(ctx, g.n_cells), b, api.HipStencilOperator(mat, -1.0, 0.0))
+        ctx.sync()
+        mat.close()
+    ctx.close()
+    return 0
+
+
+def measure_traffic(args):
+    """HBM bytes per SpMV launch by PMC, as /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE
+    in SEPARATE rocprofv3 passes (--pmc with --kernel-trace only), FETCH_SIZE doubled (on gfx950 it reports exactly half the
+    bytes of a wide coalesced streaming read: 128-byte requests tallied at 64 B), both in KiB.  Returns (headline kernel, fp64-record kernel,
+    method note); (None, None, reason) when the profiler is unavailable -- never raises."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, None, "rocprofv3 not found"
+    sums = {}
+    tmp = tempfile.mkdtemp(prefix="storm_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--edge", str(args.n),
+                   *[f"--opt={kv}" for kv in args.opt]]
+            env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+            env["TMPDIR"] = "/tmp"
+            p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=240)
+            if p.returncode != 0:
+                return None, None, f"rocprofv3 --pmc {counter} exited with {p.returncode}: {p.stderr[-300:]}"
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f, newline="") as fh:
+                    for row in csv.DictReader(fh):
+                        if row["Counter_Name"] != counter:
+                            continue
+                        k = row["Kernel_Name"]
+                        kind = ("fmt" if ("spmv_canon_kernel<true" in k or "spmv_pair_kernel<true" in k or "spmv_dict_kernel<true" in k)
+                                else "sell" if "spmv_sell_kernel<true, true" in k else None)
+                        if kind:
+                            a = sums.setdefault((counter, kind), [0, 0.0])
+                            a[0] += 1
+                            a[1] += float(row["Counter_Value"])
+
+        def per_launch(kind):
+            f, w = sums.get(("FETCH_SIZE", kind)), sums.get(("WRITE_SIZE", kind))
+            if not f or not w:
+                return None
+            return (2.0 * f[1] / f[0] + w[1] / w[0]) * 1024.0
+
+        note = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over a child process "
+                f"(12-iteration CG, {sums.get(('FETCH_SIZE', 'fmt'), [0])[0]} launches averaged); FETCH_SIZE doubled (gfx950), KiB")
+        fmt, sell = per_launch("fmt"), per_launch("sell")
+        return (fmt if fmt is not None else sell), sell, note
+    except Exception as e:  # the measurement must never cost the headline line
+        return None, None, f"traffic measurement failed: {e!r}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def blas1_rates(api, ctx, N, reps=20):

@@ -18,8 +18,9 @@ _LIB_PATHS = {"strict": os.path.join(_HERE, "liboracle.so"),
               "fma": os.path.join(_HERE, "liboracle_fma.so"),
               # investigation builds (make variants): reductions summed pairwise / in one long double
               "pairwise": os.path.join(_HERE, "liboracle_pairwise.so"),
-              "longdouble": os.path.join(_HERE, "liboracle_longdouble.so")}
-_INVESTIGATION = ("pairwise", "longdouble")
+              "longdouble": os.path.join(_HERE, "liboracle_longdouble.so"),
+              "devlike": os.path.join(_HERE, "liboracle_devlike.so")}
+_INVESTIGATION = ("pairwise", "longdouble", "devlike")
 
 f64p = C.POINTER(C.c_double)
 i64p = C.POINTER(C.c_int64)
@@ -101,6 +102,7 @@ def lib(variant: str = "strict"):
         L.oracle_convection.argtypes = [C.POINTER(_Mesh), f64p, C.c_double, f64p, f64p]
         L.oracle_stencil_apply.argtypes = [C.c_void_p, f64p, f64p]
         L.oracle_csr_apply.argtypes = [C.c_void_p, f64p, f64p]
+        L.oracle_gather_apply.argtypes = [C.c_void_p, f64p, f64p]
         for name in ("oracle_solve_cg", "oracle_solve_bicgstab", "oracle_solve_gmres", "oracle_solve_richardson",
                      "oracle_solve_cgs", "oracle_solve_tfqmr", "oracle_solve_tfqmr1", "oracle_solve_bicgstabl",
                      "oracle_solve_idrs"):
@@ -269,6 +271,55 @@ class CsrOperator:
         x = f64(x)
         y = np.empty_like(x)
         lib().oracle_csr_apply(self.ctx, _p(y), _p(x))
+        return y
+
+
+class _GatherOp(C.Structure):
+    _fields_ = [("n", C.c_int64), ("width", C.c_int32), ("col", i64p), ("w", f64p), ("ext", f64p),
+                ("alpha", C.c_double), ("beta", C.c_double), ("seed", C.c_uint64), ("applies", C.c_uint64)]
+
+
+class GatherOperator:
+    """INVESTIGATION only (tools/bicgstab_draw_study.py): the face-graph operator in the HIP kernels' arithmetic
+    form -- pre-divided weights, rows gathered in face order, difference form, FMAs -- with an optional seeded
+    perturbation of every apply by at most one unit in the last place (``oracle_gather_apply``)."""
+
+    def __init__(self, g, alpha: float, beta: float, seed: int = 0, variant: str = "strict"):
+        from stormruler_amd import mesh as _mesh
+
+        coef, b_coef = _mesh.face_coefficients(g)
+        n = g.n_cells
+        inner, outer = np.asarray(g.inner, np.int64), np.asarray(g.outer, np.int64)
+        wi, wo = coef / g.volume[inner], coef / g.volume[outer]  # storm_hip_op_create_from_faces
+        # rows in face order: entry 2f = (inner -> outer), 2f + 1 = (outer -> inner); a stable sort by row keeps it
+        rows = np.empty(2 * g.n_faces, np.int64)
+        rows[0::2], rows[1::2] = inner, outer
+        cols = np.empty_like(rows)
+        cols[0::2], cols[1::2] = outer, inner
+        vals = np.empty(2 * g.n_faces)
+        vals[0::2], vals[1::2] = wi, wo
+        order = np.argsort(rows, kind="stable")
+        rows, cols, vals = rows[order], cols[order], vals[order]
+        cnt = np.bincount(rows, minlength=n)
+        width = int(cnt.max()) if n else 0
+        start = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+        slot = np.arange(rows.size) - start[rows]
+        self.col = np.full((n, width), -1, np.int64)
+        self.w = np.zeros((n, width))
+        self.col[rows, slot], self.w[rows, slot] = cols, vals
+        ext = np.zeros(n)
+        if g.n_bfaces:
+            np.subtract.at(ext, np.asarray(g.b_cell, np.int64), b_coef / g.volume[np.asarray(g.b_cell, np.int64)])
+        self.ext = ext
+        self.n, self.variant = n, variant
+        self.c = _GatherOp(n, width, _pi(self.col.reshape(-1)), _p(self.w.reshape(-1)), _p(self.ext), alpha, beta, seed, 0)
+        self.fn = C.cast(lib(variant).oracle_gather_apply, C.c_void_p)
+        self.ctx = C.cast(C.pointer(self.c), C.c_void_p)
+
+    def apply(self, x: np.ndarray) -> np.ndarray:
+        x = f64(x)
+        y = np.empty_like(x)
+        lib(self.variant).oracle_gather_apply(self.ctx, _p(y), _p(x))
         return y
 
 

@@ -313,6 +313,60 @@ ORACLE_API void oracle_csr_apply(void *ctx, double *y, const double *x) {
   }
 }
 
+/*
+ * INVESTIGATION operator (tools/bicgstab_draw_study.py only; never loaded by a
+ * parity check): the SAME operator in the arithmetic form the HIP kernels use
+ * (stormruler_amd/csrc/spmv.hip) -- weights divided once at build time,
+ * gather by rows in face order, difference form, the products contracted
+ * into FMAs as hipcc does:
+ *     acc = fma(w_ik, x[col_ik] - x_i, acc)           slot by slot
+ *     y_i = fma(alpha, fma(ext_i, x_i, acc), beta * x_i)
+ * plus an optional seeded perturbation of the result by at most one unit in the
+ * last place (seed != 0: each y_i moves to its upper / lower neighbour with
+ * probability 1/4 each), which is the size of the difference between any two
+ * correctly rounded evaluation orders of the same row.
+ * Used to measure how far BiCGStab's iteration count at 256^3 moves when
+ * nothing but last-place roundings of the apply change.
+ */
+typedef struct oracle_gather_op {
+  int64_t n;
+  int32_t width;        /* slots per row; col < 0 marks an absent slot       */
+  const int64_t *col;   /* [n * width] */
+  const double *w;      /* [n * width] */
+  const double *ext;    /* [n] */
+  double alpha, beta;
+  uint64_t seed;        /* 0: no perturbation */
+  uint64_t applies;     /* counts applies (decorrelates the perturbations)   */
+} oracle_gather_op;
+
+static inline uint64_t gather_mix(uint64_t z) { /* splitmix64 finaliser */
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+
+ORACLE_API void oracle_gather_apply(void *ctx, double *y, const double *x) {
+  oracle_gather_op *op = (oracle_gather_op *)ctx;
+  const int W = op->width;
+  const uint64_t salt = gather_mix(op->seed ^ (0x9e3779b97f4a7c15ull * (op->applies + 1)));
+  op->applies++;
+  for (int64_t i = 0; i < op->n; ++i) {
+    const double xi = x[i];
+    double acc = 0.0;
+    for (int k = 0; k < W; ++k) {
+      const int64_t c = op->col[i * W + k];
+      if (c >= 0) acc = fma(op->w[i * W + k], x[c] - xi, acc);
+    }
+    double v = fma(op->alpha, fma(op->ext[i], xi, acc), op->beta * xi);
+    if (op->seed != 0) {
+      const uint64_t h = gather_mix(salt + (uint64_t)i) >> 62; /* 0..3 */
+      if (h == 0) v = nextafter(v, INFINITY);
+      else if (h == 1) v = nextafter(v, -INFINITY);
+    }
+    y[i] = v;
+  }
+}
+
 /* Operator::Residual  Operator.hpp:95-99: mul(r, x); r <<= b - r. */
 static void op_residual(oracle_apply_fn apply, void *ctx, int64_t n, double *r,
                         const double *b, const double *x) {

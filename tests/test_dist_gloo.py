@@ -1,4 +1,4 @@
-"""World-size-2 (and 3) run of the N > 1 path on CPU over gloo.
+"""World-size-2, 3 and 8 runs of the N > 1 path on CPU over gloo (8 = the slab stack of BASELINE config 3).
 
 What is shared with the GPU path and therefore covered here: stormruler_amd.partition (slab
 generator, halo plans), stormruler_amd.dist (rendezvous on 127.0.0.1, id broadcast, max-reduce,
@@ -104,12 +104,12 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_two_rank_cg_matches_single_rank_oracle(tmp_path, world):
+@pytest.mark.parametrize("world,nzl", [(2, 5), (3, 5), (8, 2)])
+def test_two_rank_cg_matches_single_rank_oracle(tmp_path, world, nzl):
     from oracle import oracle
     from stormruler_amd import mesh
 
-    nx, ny, nzl = 10, 8, 5
+    nx, ny = 10, 8
     out = str(tmp_path / "x")
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT, nx=nx, ny=ny, nzl=nzl, out=out))
@@ -120,7 +120,7 @@ def test_two_rank_cg_matches_single_rank_oracle(tmp_path, world):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=240)[0] for p in procs]
+    outs = [p.communicate(timeout=480)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
 
@@ -146,3 +146,21 @@ def test_env_rank_defaults(monkeypatch):
     monkeypatch.setenv("LOCAL_RANK", "1")
     monkeypatch.setenv("WORLD_SIZE", "8")
     assert dist.env_rank() == (3, 1, 8)
+
+
+def test_bench_supervisors_walk_the_transport_chain_and_give_up_cleanly():
+    """bench.py's N > 1 launcher without a GPU: the rank supervisors (CPU only, gloo) start one child per transport
+    attempt; here every child fails ("needs an MI355X"), so the chain ipc -> host is walked with fresh children each
+    time, nothing hangs, no JSON line appears and the exit code is non-zero."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("the walk-the-whole-chain case needs a box without a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "ipc,host",
+                        "--attempt-seconds", "120,120", "--edge", "16", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=420, env=dict(env, OMP_NUM_THREADS="1"), cwd=ROOT)
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert "transport ipc:" in p.stderr and "starting fresh ranks on host" in p.stderr
+    assert "transport host:" in p.stderr and "no transport left" in p.stderr

@@ -68,24 +68,45 @@ def test_peer_window_waits_are_bounded(tmp_path):
     assert 4.0 <= r0["seconds"] <= 9.0, r0
 
 
-@pytest.mark.parametrize("world,transport", [(2, "rccl"), (3, "rccl"), (3, "ipc")])
-def test_bench_script_multi_rank_path(world, transport):
-    """bench.py's own N > 1 code path (partition, connect, the rank-uniform spin-up, barriers, max-over-ranks
-    timing, rank-0 JSON) with the ranks sharing device 0 (`--shared-device`): it must terminate -- a collective
-    that only some ranks reach hangs the 8-GPU run -- and print one JSON line on rank 0."""
-    # exactly as the driver calls it: no launcher in front -- bench.py starts its ranks itself (child processes)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--shared-device", "--edge", "48",
-           "--steps", "20", "--warmup", "3", "--spinup-seconds", "0.2", "--min-seconds", "0.05", "--transport", transport]
+def _run_bench(extra, timeout=420):
+    # exactly as the driver calls it at N = 1 ... and, for N > 1, without a launcher in front: bench.py starts its rank
+    # supervisors itself, each of which starts the measuring rank as a child
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--shared-device", "--edge", "48", "--steps", "20", "--warmup", "3",
+           "--spinup-seconds", "0.2", "--min-seconds", "0.05", *extra]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300,
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout,
                        env=dict(env, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + "\n" + p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
-    out = json.loads(lines[0])
+    return json.loads(lines[0]), p.stderr
+
+
+@pytest.mark.parametrize("world,transport", [(2, "host"), (3, "host"), (3, "ipc")])
+def test_bench_script_multi_rank_path(world, transport):
+    """bench.py's own N > 1 code path (supervisors, pre-flight, partition, connect, the rank-uniform spin-up, barriers,
+    max-over-ranks timing, rank-0 JSON) with the ranks sharing device 0 (`--shared-device`): it must terminate -- a
+    collective that only some ranks reach hangs the 8-GPU run -- and print one JSON line on rank 0."""
+    out, _ = _run_bench(["--gpus", str(world), "--transport", transport])
     assert out["n_gpus"] == world and out["steps"] == 20 and out["value"] > 0 and out["scaling"] == "weak"
-    assert out["roofline"]["launches_timed"] == 2 * (max(20, 20) + 1)  # interior + boundary launch per apply
+    assert out["transport"] == transport and out["transport_fallback"] == []
+    assert out["preflight"]["ok"] and out["preflight"]["allreduce_sum"] == out["preflight"]["expected_sum"]
+    assert out["roofline"]["launches_timed"] >= 20 + 1  # one launch per apply, or an interior + a boundary launch
     assert 0.0 < out["roofline"]["frac"] <= 1.0 and out["timing"]["repeats"] >= 1
+
+
+@pytest.mark.parametrize("how", ["exit:1", "hang:0", "wrong"])
+def test_bench_falls_back_to_the_next_transport_with_fresh_ranks(how):
+    """A transport that fails -- a rank dies, a rank hangs (budget), or the pre-flight finds wrong halo values -- costs
+    its budget, not the run: all rank processes of the attempt are ended and a FRESH set starts on the next
+    transport of the chain; the line says which transport produced the number and why the earlier one did not."""
+    out, err = _run_bench(["--gpus", "2", "--transport", "ipc,host", "--inject-fail", f"ipc={how}",
+                           "--attempt-seconds", "45,240"])
+    assert out["transport"] == "host" and out["n_gpus"] == 2 and out["value"] > 0
+    fb = out["transport_fallback"]
+    assert len(fb) == 1 and fb[0]["transport"] == "ipc"
+    assert ("budget" in fb[0]["reason"]) == how.startswith("hang")
+    assert "starting fresh ranks on host" in err
 
 
 @pytest.mark.parametrize("world", [3, 4])  # (a GPU box admits 6 processes on its card: 4 ranks + this one + slack)
