@@ -36,7 +36,7 @@ extern "C" {
 /* every declaration below is an exported symbol of libstorm_hip.so */
 #pragma GCC visibility push(default)
 
-#define STORM_HIP_ABI_VERSION 2
+#define STORM_HIP_ABI_VERSION 3
 
 enum {
   STORM_HIP_OK = 0,
@@ -285,6 +285,8 @@ typedef struct storm_hip_op_stats {
   int64_t value_dictionary_size;        /* > 0: weights stored as byte indices into this many distinct values */
   int64_t offset_dictionary_size;       /* > 0: columns stored as byte indices into this many distinct col - row */
   int64_t paired_rows;                  /* 1: two consecutive rows per lane share their 16-byte gathers; n_slices then counts 128-row groups; 2: the same with one common offset order (format 4); 3: format 5 (one byte per row) */
+  int64_t tiled_planes;                 /* > 0: an unsplit apply runs the tiled format-4 kernel (lattice offsets -b,-a,-1,+1,+a,+b): tiles of 1024 rows x this many planes */
+  int64_t spmv_blocks;                  /* workgroups of an unsplit apply */
 } storm_hip_op_stats;
 int storm_hip_op_get_stats(const storm_hip_op *op, storm_hip_op_stats *stats);
 int storm_hip_op_destroy(storm_hip_op *op);

@@ -45,7 +45,7 @@ class OpStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("n_rows", "n_cols", "nnz_offdiag", "ell_slots", "tail_nnz",
                                           "tail_rows", "n_slices", "max_row_len", "n_interior_slices",
                                           "device_bytes", "record_bytes", "value_dictionary_size",
-                                          "offset_dictionary_size", "paired_rows")]
+                                          "offset_dictionary_size", "paired_rows", "tiled_planes", "spmv_blocks")]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
@@ -134,7 +134,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-if lib.storm_hip_abi_version() != 2:
+if lib.storm_hip_abi_version() != 3:
     raise ImportError("libstorm_hip.so ABI version mismatch")
 
 

@@ -7,6 +7,8 @@
 // __shfl_down tree, then across the 4 waves of a block through LDS, then a fixed-order final
 // pass over the per-block partials (two passes when there are more than 4096 of them).  The
 // summation tree depends only on n, so results are bitwise reproducible run to run.
+#include <cstring>
+
 #include "common.hpp"
 #include "blas1_device.hpp"
 #include "ticket_device.hpp"
@@ -209,10 +211,14 @@ __global__ __launch_bounds__(kBlock) void multi_dot_kernel(int64_t n, const doub
 }
 
 // The same with the reduction finished in the kernel (ticket_device.hpp): out[j] = <a, bs.b[j]>, one launch.
+// host_words != null: the last block also stores the sums into pinned HOST memory, each as two self-validating words
+// { tag | low half }, { tag | high half } (one atomic system-scope store each: no ordering between them and a flag to
+// rely on) -- the host polls them instead of copying and waiting on the stream.
 template <int KB>
 __global__ __launch_bounds__(kBlock) void multi_dot_ticket_kernel(int64_t n, const double *__restrict__ a, DotPtrs bs,
                                                                   TicketArgs tickets, double *__restrict__ out,
-                                                                  const int *done, int nt) {
+                                                                  const int *done, int nt,
+                                                                  unsigned long long *host_words, unsigned tag) {
   if (done && *done) return;
   __shared__ double lds4[4];
   double acc[KB];
@@ -226,7 +232,14 @@ __global__ __launch_bounds__(kBlock) void multi_dot_ticket_kernel(int64_t n, con
   const unsigned bx = (nt & 2) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
   if (ticket_reduce_wave0<KB>(tickets, mine, KB, bx, gridDim.x, total) && threadIdx.x == 0) {
 #pragma unroll
-    for (int j = 0; j < KB; ++j) out[j] = total[j];
+    for (int j = 0; j < KB; ++j) {
+      out[j] = total[j];
+      if (host_words) {
+        const unsigned long long t = (unsigned long long)tag << 32;
+        __hip_atomic_store(host_words + 2 * j, t | (unsigned)__double2loint(total[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_words + 2 * j + 1, t | (unsigned)__double2hiint(total[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
 }
 
@@ -304,8 +317,14 @@ int k_multi_dot_partials(storm_hip_ctx *c, const double *a, const double *const 
   return STORM_HIP_OK;
 }
 
+static int k_multi_dot_host(storm_hip_ctx *c, const double *a, const double *const *bs, int k, int64_t n,
+                            double *d_out, const int *done, unsigned long long *host_words, unsigned tag);
 int k_multi_dot(storm_hip_ctx *c, const double *a, const double *const *bs, int k, int64_t n,
                 double *d_out, const int *done) {
+  return k_multi_dot_host(c, a, bs, k, n, d_out, done, nullptr, 0u);
+}
+static int k_multi_dot_host(storm_hip_ctx *c, const double *a, const double *const *bs, int k, int64_t n,
+                            double *d_out, const int *done, unsigned long long *host_words, unsigned tag) {
   if (c->opt_ticket_reduce != 0 && k <= kDotChunk && n > 0) {  // one launch: partials, tickets, the sums
     int nbt = stream_blocks(n);
     if ((int64_t)nbt * k > c->partials_capacity) nbt = (int)(c->partials_capacity / k);
@@ -314,7 +333,7 @@ int k_multi_dot(storm_hip_ctx *c, const double *a, const double *const *bs, int 
     for (int j = 0; j < kDotChunk; ++j) ptrs.b[j] = bs[j < k ? j : 0];
     const TicketArgs t{c->d_tickets, c->d_partials, c->d_ticket_sums};
     const dim3 g(nbt), b(kBlock);
-#define TD_GO(K_) hipLaunchKernelGGL(multi_dot_ticket_kernel<K_>, g, b, 0, c->stream, n, a, ptrs, t, d_out, done, nt)
+#define TD_GO(K_) hipLaunchKernelGGL(multi_dot_ticket_kernel<K_>, g, b, 0, c->stream, n, a, ptrs, t, d_out, done, nt, host_words, tag)
     switch (k) {
       case 1: TD_GO(1); break;
       case 2: TD_GO(2); break;
@@ -541,6 +560,32 @@ int storm_hip_multi_dot(const storm_hip_vec *a, const storm_hip_vec *const *bs, 
   if (a->n_owned == 0) {
     HIP_TRY(hipMemsetAsync(c->d_scalars, 0, sizeof(double) * (size_t)k, c->stream));
   } else {
+    // one rank, one launch: the kernel's last block leaves the sums in pinned host memory; poll them
+    const bool direct = c->comm == nullptr && c->opt_host_result != 0 && c->opt_ticket_reduce != 0 && k <= kDotChunk &&
+                        c->api_done == nullptr;
+    if (direct) {
+      const unsigned tag = ++c->result_seq ? c->result_seq : ++c->result_seq;  // never 0 (the words start zeroed)
+      STORM_TRY(k_multi_dot_host(c, a->d, ptrs, k, a->n_owned, c->d_scalars, nullptr, c->d_result_words, tag));
+      volatile unsigned long long *w = c->h_result_words;
+      for (long spin = 0;; ++spin) {
+        bool all = true;
+        for (int j = 0; j < 2 * k; ++j) all &= (unsigned)(w[j] >> 32) == tag;
+        if (all) break;
+        if ((spin & 0x3fff) == 0x3fff && hipStreamQuery(c->stream) == hipSuccess) {
+          // the stream is idle and the words never came (a failed launch): take the ordinary road, which reports it
+          bool again = true;
+          for (int j = 0; j < 2 * k; ++j) again &= (unsigned)(w[j] >> 32) == tag;
+          if (!again) return finish_reduction(c, k, out);
+          break;
+        }
+      }
+      for (int j = 0; j < k; ++j) {
+        const unsigned long long lo = w[2 * j], hi = w[2 * j + 1];
+        const unsigned long long bits = (hi << 32) | (lo & 0xffffffffull);
+        memcpy(&out[j], &bits, sizeof(double));
+      }
+      return STORM_HIP_OK;
+    }
     STORM_TRY(k_multi_dot(c, a->d, ptrs, k, a->n_owned, c->d_scalars, c->api_done));
   }
   return finish_reduction(c, k, out);

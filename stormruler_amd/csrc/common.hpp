@@ -94,6 +94,11 @@ struct storm_hip_ctx {
   int *d_tickets = nullptr;           // ticket_device.hpp: self-re-arming counters of the in-kernel reductions
   char *d_lat_slots = nullptr;        // latency path: two 256-byte all-reduce slots per block (256 blocks)
   double *h_scalars = nullptr;        // pinned mirror
+  // host-returning reductions on one rank: the kernel's last block stores the sums straight into pinned host memory
+  // as self-validating words { low half | tag }, { high half | tag } and the host polls them -- no copy, no stream wait
+  unsigned long long *h_result_words = nullptr, *d_result_words = nullptr;  // [2 * 8]
+  unsigned result_seq = 0;
+  int64_t opt_host_result = 1;        // 0: device scalars + hipMemcpyAsync + hipStreamSynchronize
   storm::SolverState *d_state = nullptr;
   storm::SolverState *h_state = nullptr;  // pinned staging copy of the state
   int *h_done_ring = nullptr;             // pinned, written by the device's step kernels
@@ -110,6 +115,8 @@ struct storm_hip_ctx {
   int stream_reverse = 0;            // ... and the same for the next elementwise kernel
   int spmv_reverse = 0;              // set around a format-4 SpMV launch by the solver: deal the tiles out from the far end
   int64_t opt_spmv_canon_groups = 2; // format-4 / 5 kernel: 128-row groups per wavefront (1 or 2)
+  int64_t opt_spmv_canon_tile_min_rows = (int64_t)1 << 20;  // ... for operators of at least this many rows
+  int64_t opt_spmv_canon_tile = 4;   // format 4 on a lattice (offsets -b,-a,-1,+1,+a,+b): tiles of 1024 rows x this many planes (4 or 2) with the +-a / +-1 neighbours from LDS and the +-b ones from registers; 0 = the plain kernel
   int64_t opt_coop_mgs_pairs = 1;    // cooperative Gram-Schmidt chain: two steps per synchronisation point
   int64_t opt_spmv_mixed = 1;        // partitioned operators: format 4 for the groups that read no halo column, format 3 for the rest
   int64_t opt_spmv_nt_y = 1;         // format-4 kernel: store y non-temporally (A/B knob)

@@ -58,6 +58,9 @@ int storm_hip_ctx_create(int device_id, storm_hip_ctx **out) {
   HIP_TRY(hipMalloc(&c->d_partials2, sizeof(double) * kMaxMulti * kStage2));
   HIP_TRY(hipMalloc(&c->d_scalars, sizeof(double) * kMaxMulti));
   HIP_TRY(hipHostMalloc((void **)&c->h_scalars, sizeof(double) * kMaxMulti, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void **)&c->h_result_words, sizeof(unsigned long long) * 16, hipHostMallocMapped));
+  memset(c->h_result_words, 0, sizeof(unsigned long long) * 16);
+  HIP_TRY(hipHostGetDevicePointer((void **)&c->d_result_words, c->h_result_words, 0));
   HIP_TRY(hipMalloc((void **)&c->d_lat_slots, 2 * 256 * 256 + 256));  // latency.hip: all-reduce slots (two per block) + the gave-up flag
   HIP_TRY(hipMemset(c->d_lat_slots, 0, 2 * 256 * 256 + 256));
   HIP_TRY(hipMalloc((void **)&c->d_ticket_sums, sizeof(double) * 8 * 2048));  // [k <= 8][kTicketMaxGroups] group sums
@@ -89,6 +92,7 @@ int storm_hip_ctx_destroy(storm_hip_ctx *c) {
   (void)hipFree(c->d_tickets);
   (void)hipFree(c->d_ticket_sums);
   (void)hipHostFree(c->h_scalars);
+  (void)hipHostFree(c->h_result_words);
   (void)hipFree(c->d_state);
   (void)hipHostFree(c->h_state);
   (void)hipHostFree(c->h_done_ring);
@@ -134,6 +138,8 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "spmv_mixed")) c->opt_spmv_mixed = value;
   else if (!strcmp(key, "sweep_alternate")) c->opt_sweep_alternate = value;
   else if (!strcmp(key, "spmv_canon_groups")) c->opt_spmv_canon_groups = value;
+  else if (!strcmp(key, "spmv_canon_tile")) c->opt_spmv_canon_tile = value;
+  else if (!strcmp(key, "spmv_canon_tile_min_rows")) c->opt_spmv_canon_tile_min_rows = value;
   else if (!strcmp(key, "fused_reduce")) c->opt_fused_reduce = (int)value;
   else if (!strcmp(key, "ticket_reduce")) c->opt_ticket_reduce = (int)value;
   else if (!strcmp(key, "lin_fuse")) c->opt_lin_fuse = (int)value;
@@ -155,6 +161,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "profile_spmv")) c->opt_profile_spmv = value;
   else if (!strcmp(key, "fuse_dot")) c->opt_fuse_dot = value;
   else if (!strcmp(key, "fold_pz")) c->opt_fold_pz = value;
+  else if (!strcmp(key, "host_result")) c->opt_host_result = value;
   else if (!strcmp(key, "fuse_mgs")) c->opt_fuse_mgs = value;
   else if (!strcmp(key, "graph")) c->opt_graph = value;
   else if (!strcmp(key, "blas1_nt")) c->opt_blas1_nt = value;

@@ -136,6 +136,26 @@ __global__ __launch_bounds__(kBlock) void reduce_stage1_kernel(const double *__r
   if (threadIdx.x == 0) out[j * gridDim.x + g] = sum;
 }
 
+// The same first pass, finished in the kernel (ticket_device.hpp): the block that draws the last ticket folds the
+// kStage2 block sums and leaves the total in *out -- the consumer (cg_r_kernel) reads one scalar instead of folding
+// kStage2 partials in every one of its 8 192 blocks before its first load.
+__global__ __launch_bounds__(kBlock) void reduce_stage1_ticket_kernel(const double *__restrict__ partials, int nblocks,
+                                                                      double *__restrict__ out, const SolverState *st,
+                                                                      TicketArgs tickets) {
+  if (st->done) return;
+  __shared__ double lds4[4];
+  const int g = blockIdx.x;
+  const int chunk = (nblocks + gridDim.x - 1) / gridDim.x;
+  const int i0 = g * chunk, i1 = min(i0 + chunk, nblocks);
+  double v = 0.0;
+  for (int i = i0 + threadIdx.x; i < i1; i += kBlock) v += partials[i];
+  const double sum = block_sum256(v, lds4);
+  if (threadIdx.x >= kWave) return;
+  const double mine[1] = {sum};
+  double total[1];
+  if (ticket_reduce_wave0<1>(tickets, mine, 1, (unsigned)g, gridDim.x, total) && threadIdx.x == 0) *out = total[0];
+}
+
 __global__ void step_kernel(int step, SolverState *st, GmresDev g, bool force) {
   if (!force && st->done) return;
   do_step(step, st, g);
@@ -940,8 +960,14 @@ int storm_hip_solve_cg(const storm_hip_op *op, double alpha, double beta, const 
       const double *bs[1] = {z};
       STORM_TRY(k_multi_dot(c, p, bs, 1, n, d.slot(S_PZ), d.done));
       if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, d.slot(S_PZ), 1));
+    } else if (tick && nb > kSinglePassPartials && c->opt_fold_pz != 0 && (int64_t)nb + kStage2 <= c->partials_capacity) {
+      // many partials, one rank: ONE small launch folds them and finishes the sum itself (tickets); cg_r_kernel reads
+      // <p,z> from the slab and starts streaming at once.  (The block sums go behind the SpMV's partials.)
+      hipLaunchKernelGGL(reduce_stage1_ticket_kernel, dim3(kStage2), dim3(kBlock), 0, c->stream, c->d_partials, nb,
+                         d.slot(S_PZ), d.st, TicketArgs{c->d_tickets, c->d_partials + nb, c->d_ticket_sums});
+      HIP_TRY(hipGetLastError());
     } else if (c->comm == nullptr && nb > kSinglePassPartials && c->opt_fold_pz != 0) {
-      // many partials, one rank: the first pass here, the fold of its kStage2 results inside cg_r_kernel
+      // ... without tickets: the first pass here, the fold of its kStage2 results inside cg_r_kernel
       hipLaunchKernelGGL(reduce_stage1_kernel, dim3(kStage2, 1), dim3(kBlock), 0, c->stream, c->d_partials, nb,
                          c->d_partials2, d.st, false);
       HIP_TRY(hipGetLastError());

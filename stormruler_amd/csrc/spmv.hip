@@ -773,6 +773,197 @@ __global__ __launch_bounds__(kBlock) void spmv_canon_kernel(SellArgs A, CanonArg
   }
 }
 
+// ---- format 4, tiled --------------------------------------------------------------------------------------------
+// What separates spmv_canon_kernel from a plain 2-read-1-write stream is its gathers: four 16-byte L2 -> L1
+// transactions per row pair (offsets -b, -a, +a, +b), as many as the whole HBM stream.  When the common offsets are
+// (-b, -a, -1, +1, +a, +b) -- a lattice: a = rows per line, b = rows per plane -- a block takes a TILE instead of 1024
+// consecutive rows: kTileRun = 1024 consecutive rows of a plane, in TZ consecutive planes.
+//   * the +-b neighbours of a row are the SAME LANE's own rows in the planes above and below: registers (only the two
+//     outer planes of a tile are gathered: 2 / TZ per row);
+//   * the +-a and +-1 neighbours come from an LDS copy of the tile's x, [TZ][a + 1024 + a] doubles: every wave writes
+//     its own rows there, and the 2 a halo rows per plane are fetched once per tile by all 256 threads together
+//     (a / 64 16-byte loads per thread);
+// Per 1024-row line and wave: TZ x (2 own + 2 record) + 4 + a / 64 vector loads instead of TZ x 14.  Arithmetic,
+// operand bit patterns and summation order per row are those of spmv_canon_kernel: y is bit-identical.
+// XCD map: the tiles of a plane are dealt to the 8 XCDs in contiguous runs (tile yt -> XCD yt / (tiles per plane / 8)),
+// chunk after chunk of planes, so that a tile's outer planes and lines were (or will be) some tile's OWN rows on the
+// same XCD's L2.
+constexpr int kTileRun = 4 * 4 * kWave;  // rows of a plane per tile: 4 waves x 2 groups x 128 rows
+struct CanonTileArgs {
+  int a, b;              // the lattice offsets (both even, 2 <= a <= 512, b >= 2 a)
+  unsigned a_magic;      // ceil(2^32 / a): h / a = umulhi(h, a_magic) for h < 4096
+  int tiles_per_plane;   // ceil(b / kTileRun)
+  int per_xcd;           // tiles_per_plane / 8 when that divides, else 0 (plain order)
+  int max_gather;        // largest guard-relative index a 16-byte gather may start at
+  int reverse;
+};
+template <bool DOT, bool WLOAD, int TZ, int HL>
+__global__ __launch_bounds__(kBlock) void spmv_canon_tile_kernel(SellArgs A, CanonTileArgs T, Scal alpha_s, Scal beta_s,
+                                                                 const double *__restrict__ x, double *__restrict__ y,
+                                                                 DotArgs dot, const int *done) {
+  const int done_flag = done ? *done : 0;
+  extern __shared__ __attribute__((aligned(16))) double tile_sh[];  // [TZ][a + kTileRun + a]
+  __shared__ double dict_sh[32];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int bidx = T.reverse ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+  int zc, yt;
+  if (T.per_xcd > 0) {
+    const int xcd = bidx & (kNumXcd - 1), j = bidx >> 3;
+    zc = j / T.per_xcd;
+    yt = xcd * T.per_xcd + (j - zc * T.per_xcd);
+  } else {
+    zc = bidx / T.tiles_per_plane;
+    yt = bidx - zc * T.tiles_per_plane;
+  }
+  const int a = T.a, b = T.b;
+  const int p0 = yt * kTileRun, z0 = zc * TZ;
+  const int ldw = kTileRun + 2 * a;  // doubles per plane of the LDS copy
+  const double alpha = ld_scal2(alpha_s), beta = ld_scal2(beta_s);
+  const uint32_t last_row = (uint32_t)(A.n_rows - 1);
+  const bool w_is_x = DOT && dot.w == x;
+  const char *xb = reinterpret_cast<const char *>(x);
+  const char *xg_base = xb - (size_t)kVecGuard * 8;
+  char *yb = reinterpret_cast<char *>(y);
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+
+  const double dict_word = A.dict[lane & 31];
+  // ---- everything this wave reads from memory, issued back to back: own rows first (the LDS copy waits for them only)
+  bool valid_a[TZ][2], valid_b[TZ][2];
+  uint32_t rc[TZ][2];
+  double2v xi[TZ][2];
+#pragma unroll
+  for (int t = 0; t < TZ; ++t)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int q = p0 + 256 * wave + 128 * g + 2 * lane;                 // row of the plane
+      const int64_t row = (int64_t)(z0 + t) * b + q;
+      const bool in_plane = q < b;
+      valid_a[t][g] = in_plane && row <= (int64_t)last_row, valid_b[t][g] = in_plane && row + 1 <= (int64_t)last_row;
+      rc[t][g] = row <= (int64_t)last_row ? (uint32_t)row : (last_row & ~1u);  // pairs past the end re-read the last pair
+      xi[t][g] = *reinterpret_cast<const double2v *>(xb + (size_t)(rc[t][g] << 3));
+    }
+  double2v halo[HL];
+  int halo_at[HL];  // LDS index (doubles) of the pair, -1: none
+#pragma unroll
+  for (int i = 0; i < HL; ++i) {
+    const unsigned h = threadIdx.x + (unsigned)kBlock * i;                // pair h of the tile's TZ * a halo pairs
+    const unsigned t = __umulhi(h, T.a_magic), u = h - t * (unsigned)a;   // plane, pair within the plane's halo
+    const bool on = t < (unsigned)TZ;
+    const int jj = (int)(2 * u) < a ? (int)(2 * u) - a : kTileRun + (int)(2 * u) - a;  // tile-relative row: [-a, 0) or [1024, 1024 + a)
+    int64_t gi = (int64_t)(z0 + (int)t) * b + p0 + jj + kVecGuard;        // guard-relative, clamped like every gather
+    gi = gi < 0 ? 0 : gi;
+    gi = gi > (int64_t)T.max_gather ? (int64_t)T.max_gather : gi;
+    halo_at[i] = on ? (int)t * ldw + a + jj : -1;
+    halo[i] = double2v{0.0, 0.0};
+    if (on) halo[i] = *reinterpret_cast<const double2v *>(xg_base + (size_t)((uint32_t)gi << 3));
+  }
+  u64x2 vw[TZ][2];
+  double2v wi[WLOAD ? TZ : 1][2];
+#pragma unroll
+  for (int t = 0; t < TZ; ++t)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      vw[t][g] = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(A.pack + (size_t)(rc[t][g] << 3)));
+      if (WLOAD) wi[t][g] = *reinterpret_cast<const double2v *>(reinterpret_cast<const char *>(dot.w) + (size_t)(rc[t][g] << 3));
+    }
+  double2v xlo[2], xhi[2];  // the planes below the first and above the last one of the tile
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    int lo = (int)rc[0][g] - b + kVecGuard, hi = (int)rc[TZ - 1][g] + b + kVecGuard;
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > T.max_gather ? T.max_gather : hi;
+    xlo[g] = *reinterpret_cast<const double2v *>(xg_base + (size_t)((uint32_t)lo << 3));
+    xhi[g] = *reinterpret_cast<const double2v *>(xg_base + (size_t)((uint32_t)hi << 3));
+  }
+  // ---- the LDS copy of the tile's x (own rows + halo rows), one barrier
+  if (lane < 32) dict_sh[lane] = dict_word;  // every wave stores the same words
+#pragma unroll
+  for (int t = 0; t < TZ; ++t)
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+      *reinterpret_cast<double2v *>(&tile_sh[t * ldw + a + 256 * wave + 128 * g + 2 * lane]) = xi[t][g];
+#pragma unroll
+  for (int i = 0; i < HL; ++i)
+    if (halo_at[i] >= 0) *reinterpret_cast<double2v *>(&tile_sh[halo_at[i]]) = halo[i];
+  __syncthreads();
+  double dot_a = 0.0, dot_b = 0.0;
+#pragma unroll
+  for (int t = 0; t < TZ; ++t)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int at = t * ldw + a + 256 * wave + 128 * g + 2 * lane;  // this pair in the LDS copy
+      double2v xg[6];
+      xg[0] = t == 0 ? xlo[g] : xi[t == 0 ? 0 : t - 1][g];
+      xg[5] = t == TZ - 1 ? xhi[g] : xi[t == TZ - 1 ? t : t + 1][g];
+      xg[1] = *reinterpret_cast<const double2v *>(&tile_sh[at - a]);
+      xg[4] = *reinterpret_cast<const double2v *>(&tile_sh[at + a]);
+      double el = 0.0;
+      if (lane == 0) el = tile_sh[at - 1];
+      if (lane == kWave - 1) el = tile_sh[at + 2];
+      const double left = dpp_shift<0x138>(xi[t][g].y);   // wave_shr:1 -- lane i receives lane i - 1
+      const double right = dpp_shift<0x130>(xi[t][g].x);  // wave_shl:1 -- lane i receives lane i + 1
+      xg[2].x = lane == 0 ? el : left;
+      xg[2].y = xi[t][g].x;
+      xg[3].x = xi[t][g].y;
+      xg[3].y = lane == kWave - 1 ? el : right;
+      double acc_a = 0.0, acc_b = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const unsigned ba = (unsigned)(vw[t][g].x >> (8 * (k + 1))) & 0xffu, bb = (unsigned)(vw[t][g].y >> (8 * (k + 1))) & 0xffu;
+        acc_a += *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + ba) * (xg[k].x - xi[t][g].x);
+        acc_b += *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + bb) * (xg[k].y - xi[t][g].y);
+      }
+      const double ext_a = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + ((unsigned)vw[t][g].x & 0xffu));
+      const double ext_b = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + ((unsigned)vw[t][g].y & 0xffu));
+      // (spelled out: beta x rounded on its own, then the two FMAs the plain kernel's expression contracts to --
+      //  `(accumulate ? y : beta x) + alpha (acc + ext x)` -- so that both kernels round alike)
+      double2v yi;
+      yi.x = __builtin_fma(alpha, __builtin_fma(ext_a, xi[t][g].x, acc_a), beta * xi[t][g].x);
+      yi.y = __builtin_fma(alpha, __builtin_fma(ext_b, xi[t][g].y, acc_b), beta * xi[t][g].y);
+      if (!done_flag) {
+        double2v *yp = reinterpret_cast<double2v *>(yb + (size_t)(rc[t][g] << 3));
+        if (valid_b[t][g]) { if (A.nt_y) __builtin_nontemporal_store(yi, yp); else *yp = yi; }
+        else if (valid_a[t][g]) y[rc[t][g]] = yi.x;  // the odd last row
+      }
+      if (DOT) {
+        yi.x = valid_a[t][g] ? yi.x : 0.0;
+        yi.y = valid_b[t][g] ? yi.y : 0.0;
+        const double2v wv = WLOAD ? wi[WLOAD ? t : 0][g] : xi[t][g];
+        const double pa = dot.w ? wv.x * yi.x + wv.y * yi.y : 0.0;
+        const double pb = yi.x * yi.x + yi.y * yi.y;
+        dot_a = (t == 0 && g == 0) ? pa : dot_a + pa;
+        dot_b = (t == 0 && g == 0) ? pb : dot_b + pb;
+      }
+    }
+  (void)w_is_x;
+  if (done_flag) return;
+  if (DOT) {
+    dot_a = wave_sum_to_lane63(dot_a);
+    if (dot.yy) dot_b = wave_sum_to_lane63(dot_b);
+    if (dot.tickets == nullptr) {
+      if (lane == kWave - 1) {
+        const int slot = dot.block_offset + bidx * (kBlock / kWave) + wave;
+        dot.partials[slot] = dot_a;
+        if (dot.yy) dot.partials[dot.nblocks_total + slot] = dot_b;
+      }
+    } else {  // the reduction finishes here: block partial, then two levels of tickets
+      __shared__ double wave_part[2 * (kBlock / kWave)];
+      if (lane == kWave - 1) wave_part[wave] = dot_a, wave_part[kBlock / kWave + wave] = dot.yy ? dot_b : 0.0;
+      __syncthreads();
+      if (wave != 0) return;
+      const double mine[2] = {(wave_part[0] + wave_part[1]) + (wave_part[2] + wave_part[3]),
+                              (wave_part[4] + wave_part[5]) + (wave_part[6] + wave_part[7])};
+      double total[2];
+      const TicketArgs tk{dot.tickets, dot.partials, dot.part2};
+      if (ticket_reduce_wave0<2>(tk, mine, dot.yy ? 2 : 1, (unsigned)bidx, gridDim.x, total) && lane == 0) {
+        *dot.out0 = total[0];
+        if (dot.yy) *dot.out1 = total[1];
+      }
+    }
+  }
+}
+
 // CSR tail: one wavefront per overflowing row; the lanes' partial products are folded
 // with __shfl_down and lane 0 adds the row's remainder to y.
 __global__ __launch_bounds__(kBlock) void spmv_tail_kernel(int64_t n_tail, const int *__restrict__ tail_row,
@@ -823,6 +1014,32 @@ static void launch_sell(const storm_hip_op *op, int nb, Scal alpha, Scal beta, c
 
 // 128-row groups per wave of the format-4 / 5 kernel.
 static inline int canon_groups(const storm_hip_op *op) { return op->ctx->opt_spmv_canon_groups == 2 ? 2 : 1; }
+
+// The tiled format-4 kernel applies to an UNSPLIT, non-accumulating launch of an operator whose common offsets are
+// (-b, -a, -1, +1, +a, +b) with a, b even, a <= 512, b >= 2 a, and enough planes to fill tiles.
+static inline int canon_tile_planes(const storm_hip_op *op) {
+  const int64_t tz = op->ctx->opt_spmv_canon_tile;
+  return tz == 2 ? 2 : 4;
+}
+static bool canon_tile_geometry(const storm_hip_op *op, CanonTileArgs *T, int *n_blocks) {
+  if (op->ctx->opt_spmv_canon_tile == 0 || op->pair != 2 || op->canon_k != 6 || op->canon_m1 != 2) return false;
+  const int *o = op->canon_off;
+  const int a = o[4], b = o[5];
+  if (o[0] != -b || o[1] != -a || o[2] != -1 || o[3] != 1) return false;
+  if (a < 2 || a > 512 || (a & 1) || (b & 1) || b < 2 * a) return false;
+  const int tz = canon_tile_planes(op);
+  if ((int64_t)sizeof(double) * tz * (kTileRun + 2 * a) > 60 * 1024) return false;  // the LDS copy of a tile (64 KiB per block)
+  const int64_t planes = (op->n_rows + b - 1) / b;
+  if (planes < 2 * tz || op->n_rows < op->ctx->opt_spmv_canon_tile_min_rows) return false;  // small operators: the plain kernel (or the latency path)
+  T->a = a, T->b = b;
+  T->a_magic = (unsigned)((((uint64_t)1 << 32) + (uint64_t)a - 1) / (uint64_t)a);
+  T->tiles_per_plane = (b + kTileRun - 1) / kTileRun;
+  T->per_xcd = (T->tiles_per_plane % kNumXcd == 0 && op->ctx->opt_spmv_xcd_remap != 0) ? T->tiles_per_plane / kNumXcd : 0;
+  T->max_gather = (int)(op->n_rows + op->n_halo) + kVecGuard + 2;
+  T->reverse = op->ctx->spmv_reverse;
+  *n_blocks = (int)(((planes + tz - 1) / tz) * T->tiles_per_plane);
+  return true;
+}
 // Slices per wave: SPW for the uniform-width value-dictionary kernel, 1 otherwise.
 static inline int op_spw(const storm_hip_op *op) {
   if (op->pair) return 1;  // a "slice" of a format-3 operator is a 128-row group, one per wave
@@ -844,6 +1061,36 @@ static void launch_pair(const storm_hip_op *op, int nb, Scal alpha, Scal beta, c
   if (boundary_of_mixed) {  // the groups that read halo columns: format-3 records of their own, in list order
     A.pack = op->d_bnd_pack, A.rec_by_pos = 1;
     width = op->bnd_width;
+  }
+  CanonTileArgs T;
+  int tile_blocks = 0;
+  if (op->pair == 2 && !boundary_of_mixed && slice_list == nullptr && !accumulate && canon_tile_geometry(op, &T, &tile_blocks) &&
+      tile_blocks == nb) {
+    const int tz = canon_tile_planes(op);
+    const int hl_need = (tz * T.a + kBlock - 1) / kBlock;
+    const size_t lds = sizeof(double) * (size_t)tz * (size_t)(kTileRun + 2 * T.a);
+    const bool wload = DOT && dot.w != nullptr && dot.w != x;
+#define TILE_GO3(WL_, TZ_, HL_)                                                                                              \
+  hipExtLaunchKernelGGL((spmv_canon_tile_kernel<DOT, WL_, TZ_, HL_>), dim3(nb), dim3(kBlock), lds, st, ev0, ev1, 0, A, T, alpha, \
+                        beta, x, y, dot, done)
+#define TILE_GO2(TZ_, HL_)              \
+  do {                                  \
+    if (wload) TILE_GO3(true, TZ_, HL_); \
+    else TILE_GO3(false, TZ_, HL_);      \
+  } while (0)
+#define TILE_GO(TZ_)                       \
+  do {                                     \
+    if (hl_need <= 1) TILE_GO2(TZ_, 1);     \
+    else if (hl_need <= 2) TILE_GO2(TZ_, 2); \
+    else if (hl_need <= 4) TILE_GO2(TZ_, 4); \
+    else TILE_GO2(TZ_, 8);                  \
+  } while (0)
+    if (tz == 2) TILE_GO(2);
+    else TILE_GO(4);
+#undef TILE_GO
+#undef TILE_GO2
+#undef TILE_GO3
+    return;
   }
   if (op->pair >= 2 && !boundary_of_mixed) {  // formats 4, 5: the common offsets travel as kernel arguments
     CanonArgs C;
@@ -944,7 +1191,12 @@ static int launch_range(const storm_hip_op *op, Scal alpha, Scal beta, const dou
     // stamped at the kernel's begin and end, the quantity rocprofv3's kernel trace reports
     ev0 = c->prof_events[c->prof_used], ev1 = c->prof_events[c->prof_used + 1];
   }
-  const int nb = blocks_for(op, n_launch, op->d_bnd_pack != nullptr && slice_list != nullptr && slice_list == op->d_boundary);
+  int nb = blocks_for(op, n_launch, op->d_bnd_pack != nullptr && slice_list != nullptr && slice_list == op->d_boundary);
+  if (slice_list == nullptr && !accumulate && n_launch == op->n_slices) {
+    CanonTileArgs T;
+    int nbt = 0;
+    if (canon_tile_geometry(op, &T, &nbt)) nb = nbt;  // the tiled format-4 kernel (launch_pair takes it on the same test)
+  }
   const bool nt = c->opt_nt != 0;
   if (op->pair) {
     if (want_dot) launch_pair<true>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1, accumulate);
@@ -983,7 +1235,12 @@ static int launch_range(const storm_hip_op *op, Scal alpha, Scal beta, const dou
   return STORM_HIP_OK;
 }
 
-int spmv_grid_blocks(const storm_hip_op *op) { return blocks_for(op, op->n_slices); }
+int spmv_grid_blocks(const storm_hip_op *op) {
+  CanonTileArgs T;
+  int nb = 0;
+  if (canon_tile_geometry(op, &T, &nb)) return nb;  // (an unsplit launch of a format-4 lattice operator)
+  return blocks_for(op, op->n_slices);
+}
 
 int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, double *y,
                 const SpmvDot *sd, const int *done, bool accumulate) {
@@ -1714,6 +1971,10 @@ int storm_hip_op_get_stats(const storm_hip_op *op, storm_hip_op_stats *s) {
   s->value_dictionary_size = op->dict_size;
   s->offset_dictionary_size = op->offs_size;
   s->paired_rows = op->pair;
+  CanonTileArgs T;
+  int nbt = 0;
+  s->tiled_planes = canon_tile_geometry(op, &T, &nbt) && op->halo.n_nbrs == 0 && op->d_bnd_pack == nullptr ? canon_tile_planes(op) : 0;
+  s->spmv_blocks = spmv_grid_blocks(op);
   return STORM_HIP_OK;
 }
 

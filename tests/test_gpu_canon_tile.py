@@ -1,0 +1,132 @@
+"""The tiled format-4 SpMV (`spmv_canon_tile_kernel`: tiles of 1024 rows x TZ planes, +-a / +-1 neighbours from an
+LDS copy of the tile, +-b neighbours from the same lane's registers) against the plain format-4 kernel: y must be
+BIT-identical for every geometry -- lattices whose line / plane sizes are no multiples of the tile, ragged last
+planes, odd row counts -- and the fused dot products, the diagonal, the sweep direction and the solver loops built
+on it must hold."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    from oracle import oracle
+    from stormruler_amd import api, mesh
+
+    ctx = api.Context(0)
+    yield api, mesh, oracle, ctx
+    ctx.set_option("spmv_canon_tile", 4)
+    ctx.set_option("spmv_canon_tile_min_rows", 1 << 20)
+    ctx.close()
+
+
+def _mat(api, ctx, g, tile, min_rows=0):
+    ctx.set_option("spmv_canon_tile", tile)
+    ctx.set_option("spmv_canon_tile_min_rows", min_rows)
+    return api.StencilMatrix.from_face_graph(ctx, g)
+
+
+def _apply(api, ctx, mat, x, alpha=-0.7, beta=0.3):
+    xv, yv = api.DeviceVector.from_numpy(ctx, x), api.DeviceVector(ctx, x.size)
+    mat.apply(alpha, beta, xv, yv)
+    return yv.to_numpy()
+
+
+# (nx, ny, nz): a = nx, b = nx * ny.  Lines shorter / longer than a wave's 256 rows, planes smaller than one tile, planes
+# of several tiles with a ragged last one, plane counts that are no multiple of TZ, a = 512 (the largest supported)
+SHAPES = [(20, 6, 9), (256, 8, 8), (128, 16, 11), (64, 40, 9), (100, 22, 13), (512, 4, 8), (34, 34, 17), (256, 12, 10)]
+
+
+@pytest.mark.parametrize("tz", [4, 2])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_tiled_kernel_is_bitwise_the_plain_kernel(env, shape, tz):
+    api, mesh, oracle, ctx = env
+    g = mesh.structured_box(*shape)
+    x = np.sin(0.37 * np.arange(g.n_cells)) + 1e-3 * np.cos(1.7 * np.arange(g.n_cells))
+    plain = _mat(api, ctx, g, 0)
+    st0 = plain.stats()
+    assert st0["paired_rows"] == 2 and st0["tiled_planes"] == 0
+    y0 = _apply(api, ctx, plain, x)
+    tiled = _mat(api, ctx, g, tz)
+    st = tiled.stats()
+    if 8 * tz * (1024 + 2 * shape[0]) > 60 * 1024:  # (a = 512 with four planes: the tile's LDS copy would not fit)
+        assert st["tiled_planes"] == 0
+        tiled.close(), plain.close()
+        return
+    assert st["tiled_planes"] == tz, st
+    planes, tiles = shape[2], (shape[0] * shape[1] + 1023) // 1024
+    assert st["spmv_blocks"] == ((planes + tz - 1) // tz) * tiles
+    y1 = _apply(api, ctx, tiled, x)
+    assert np.array_equal(y0, y1)
+    y_ref = oracle.StencilOperator(g, -0.7, 0.3).apply(x)
+    assert np.abs(y1 - y_ref).max() <= 1e-13 * np.abs(y_ref).max()
+    d0, d1 = api.DeviceVector(ctx, g.n_cells), api.DeviceVector(ctx, g.n_cells)
+    plain.diagonal(-0.7, 0.3, d0), tiled.diagonal(-0.7, 0.3, d1)
+    assert np.array_equal(d0.to_numpy(), d1.to_numpy())
+    plain.close(), tiled.close()
+
+
+def test_tiled_kernel_is_not_taken_where_it_does_not_apply(env):
+    api, mesh, oracle, ctx = env
+    # too few planes; an odd line length (16-byte LDS accesses need a even); below the row threshold
+    for shape, min_rows in (((32, 8, 5), 0), ((33, 10, 12), 0), ((32, 8, 16), 1 << 20)):
+        m = _mat(api, ctx, mesh.structured_box(*shape), 4, min_rows)
+        assert m.stats()["tiled_planes"] == 0, shape
+        m.close()
+    # renumbered cells have no common offsets at all
+    box = mesh.structured_box(32, 8, 16)
+    m = _mat(api, ctx, mesh.permute_cells(box, mesh.random_permutation(box.n_cells)), 4)
+    assert m.stats()["tiled_planes"] == 0 and m.stats()["paired_rows"] == 0
+    m.close()
+
+
+@pytest.mark.parametrize("kind", ["cg", "bicgstab", "gmres"])
+@pytest.mark.parametrize("generic", [False, True], ids=["fused", "engine"])
+def test_solvers_on_the_tiled_kernel_match_the_oracle(env, kind, generic):
+    """The fused <w, Ap> / <Ap, Ap> epilogue (w = x for CG, another vector for BiCGStab), the sweep direction bit and the
+    in-kernel ticket reduction on the tiled kernel's grid."""
+    api, mesh, oracle, ctx = env
+    g = mesh.structured_box(64, 32, 24)
+    ctx.set_option("latency_path", 0)  # (49 152 rows would take the cooperative kernels)
+    ctx.set_option("generic_solvers", int(generic))
+    try:
+        ref = oracle.solve(kind, oracle.StencilOperator(g, -1.0, 0.0), np.ones(g.n_cells), num_inner_iterations=30)
+        res = {}
+        for tile in (0, 4):
+            mat = _mat(api, ctx, g, tile)
+            assert mat.stats()["tiled_planes"] == tile
+            s = {"cg": api.CgSolver, "bicgstab": api.BiCgStabSolver, "gmres": api.GmresSolver}[kind]()
+            if kind == "gmres":
+                s.num_inner_iterations = 30
+            s.record_history = True
+            b, xs = api.DeviceVector(ctx, g.n_cells), api.DeviceVector(ctx, g.n_cells)
+            api.fill_with(b, 1.0)
+            assert s.solve(xs, b, api.HipStencilOperator(mat, -1.0, 0.0))
+            res[tile] = (s.iteration, np.array(s.history), xs.to_numpy())
+            mat.close()
+        for tile in (0, 4):
+            it, hist, xs = res[tile]
+            assert abs(it - ref.iterations) <= max(2, ref.iterations // 50), (tile, it, ref.iterations)
+            assert np.linalg.norm(xs - ref.x) <= 1e-7 * np.linalg.norm(ref.x)
+        k = 10
+        assert np.allclose(res[0][1][:k], res[4][1][:k], rtol=1e-9)
+    finally:
+        ctx.set_option("latency_path", 1)
+        ctx.set_option("generic_solvers", 0)
+
+
+def test_tiled_kernel_full_size_bits_and_direction(env):
+    """256^3 (the bench operator): 4 096 tiles, XCD-grouped map, both sweep directions -- bit-equal to the plain kernel."""
+    api, mesh, oracle, ctx = env
+    g = mesh.structured_box(256)
+    x = np.sin(0.37 * np.arange(g.n_cells))
+    plain = _mat(api, ctx, g, 0, 1 << 20)
+    y0 = _apply(api, ctx, plain, x, -1.0, 0.0)
+    plain.close()
+    for tz in (4, 2):
+        tiled = _mat(api, ctx, g, tz, 1 << 20)
+        assert tiled.stats()["tiled_planes"] == tz and tiled.stats()["spmv_blocks"] == (256 // tz) * 64
+        assert np.array_equal(_apply(api, ctx, tiled, x, -1.0, 0.0), y0)
+        # a short CG run alternates the sweep direction of consecutive SpMVs; same residuals as the plain kernel's to rounding
+        tiled.close()
