@@ -42,7 +42,8 @@ SHAPES = [(20, 6, 9), (256, 8, 8), (128, 16, 11), (64, 40, 9), (100, 22, 13), (5
 @pytest.mark.parametrize("shape", SHAPES)
 def test_tiled_kernel_is_bitwise_the_plain_kernel(env, shape, tz):
     api, mesh, oracle, ctx = env
-    g = mesh.structured_box(*shape)
+    # (spacing 1/128 in every direction: exact in binary, so the box has few distinct weights whatever its shape)
+    g = mesh.structured_box(*shape, lengths=tuple(s / 128.0 for s in shape))
     x = np.sin(0.37 * np.arange(g.n_cells)) + 1e-3 * np.cos(1.7 * np.arange(g.n_cells))
     plain = _mat(api, ctx, g, 0)
     st0 = plain.stats()
