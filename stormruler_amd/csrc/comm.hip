@@ -35,10 +35,10 @@ struct Comm {
   std::vector<char *> win_peer;         // [n_ranks] mapped windows (win_peer[rank] == win_local)
   char **d_win_peer = nullptr;          // the same on the device
   int64_t win_bytes = 0, seg_bytes = 0;
-  unsigned long long ar_epoch = 0, halo_epoch = 0;
+  std::vector<unsigned long long> pair_epoch;  // [n_ranks] halo exchanges this rank has had with each peer (both sides count alike)
   int *d_error = nullptr, *h_error = nullptr;  // set by a kernel whose wait timed out
-  double *pending_x = nullptr;          // single-stream mode: the receive half runs in comm_halo_exchange_end
-  unsigned long long pending_epoch = 0;
+  double *pending_x = nullptr;          // generic form of the exchange: the receive half runs in comm_halo_exchange_end
+  IpcRecvPlan pending_recv;
 };
 
 static int host_stage(storm_hip_ctx *c, int64_t len) {
@@ -59,87 +59,22 @@ static int host_stage(storm_hip_ctx *c, int64_t len) {
                  __LINE__);                                                                     \
   } while (0)
 
-// ---- peer-window transport ---------------------------------------------------------------------------------
-// Window of rank r (all offsets multiples of 256 bytes; P = n_ranks, "parity" = epoch & 1 double-buffers everything):
-//   [all-reduce slots ]  2 x P x kIpcArSlot      slot (parity, s): the 64 values rank s contributed, each as two tagged 8-byte words
-//   [halo flags       ]  2 x P x 64              flag (parity, s): epoch of the plane rank s has finished writing
-//   [halo acks        ]  P x 64                  ack (d): last epoch rank d has consumed of what THIS rank sent it
-//   [halo data        ]  2 x P x seg_bytes       data (parity, s): the rows rank s sends here
-// One-shot all-reduce of <= 64 doubles: every rank writes its values, then (system-scope release) its tag, into slot
-// (parity, rank) of EVERY window, polls its own window until all P tags carry the epoch and adds the values in rank
-// order -- the same bits on every rank, two traversals of the link instead of RCCL's latency-bound ring / tree.
-// The double buffer is safe without further handshakes: a rank can only start epoch e + 2 after finishing e + 1,
-// which needed every peer's e + 1 contribution, which a peer sends after it has read epoch e.
-// Halo: the sender's pack kernel stores x[send_idx] straight into data (parity, rank) of the RECEIVER's window once
-// the receiver has acknowledged the plane that used this buffer two exchanges ago; a flag kernel publishes the
-// epoch; the receiver's kernel polls the flag, copies the plane behind its owned rows and acknowledges.
-// Every wait is bounded (kIpcTimeoutTicks of the 100 MHz real-time counter): a kernel that gives up sets
-// *error and the host reports it at the next synchronisation instead of hanging.
-__global__ __launch_bounds__(kBlock) void ipc_allreduce_kernel(IpcDev w, double *buf, int count,
-                                                               unsigned long long epoch) {
-  ipc_allreduce_block(w, buf, count, epoch);
+// ---- peer-window transport (protocol and window layout: ipc_device.hpp) -------------------------------------------
+__global__ __launch_bounds__(kBlock) void ipc_allreduce_kernel(IpcDev w, double *buf, int count) {
+  ipc_allreduce_block(w, buf, count);
 }
-
-// x[idx[i]], i < n  ->  the receiver's window, once it has consumed what this buffer held two exchanges ago.
-// Plain 16-byte stores: the flag that publishes them is stored by a LATER kernel (a kernel's stores are complete and
-// visible when it ends), so no per-store coherence is needed.
-__global__ __launch_bounds__(kBlock) void ipc_halo_send_kernel(IpcDev w, int peer, int64_t n, int64_t dst_off,
-                                                               const int *__restrict__ idx,
-                                                               const double *__restrict__ x,
-                                                               unsigned long long epoch) {
-  if (threadIdx.x == 0 && epoch > 2)
-    (void)ipc_wait_ge(reinterpret_cast<const unsigned long long *>(w.local + w.ack_off + (int64_t)peer * 64), epoch - 2,
-                      w.error);
-  __syncthreads();
-  double *dst = reinterpret_cast<double *>(w.peers[peer] + w.data_off + ((int64_t)(epoch & 1) * w.n_ranks + w.rank) * w.seg_bytes) +
-                dst_off;  // dst_off is even (segments and entry offsets are 16-byte aligned)
-  typedef double double2v __attribute__((ext_vector_type(2)));
-  const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
-    double2v v;
-    v.x = x[idx[2 * i]], v.y = x[idx[2 * i + 1]];
-    __builtin_nontemporal_store(v, reinterpret_cast<double2v *>(dst) + i);
-  }
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = x[idx[n - 1]];
+// Stand-alone halves of a halo exchange, for SpMV kernels that carry neither (spmv.hip fuses the send into the
+// interior launch and the receive into the boundary launch where it can):
+__global__ __launch_bounds__(kBlock) void ipc_halo_send_kernel(IpcDev w, IpcSendPlan s, const double *__restrict__ x) {
+  ipc_halo_send_block(w, s, x, (int)blockIdx.x);
 }
-struct IpcPeers {
-  int n;
-  int rank[16];
-};
-__global__ void ipc_halo_flag_kernel(IpcDev w, IpcPeers peers, unsigned long long epoch) {
-  // (the send kernels have completed: their write-through stores are acknowledged)
-  if ((int)threadIdx.x < peers.n)
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(w.peers[peers.rank[threadIdx.x]] + w.flag_off +
-                                                              ((int64_t)(epoch & 1) * w.n_ranks + w.rank) * 64),
-                       epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__global__ __launch_bounds__(kBlock) void ipc_halo_recv_kernel(IpcDev w, int peer, int64_t n, int64_t src_off,
-                                                               double *__restrict__ x_halo,
-                                                               unsigned long long epoch) {
-  __shared__ int ok;
-  if (threadIdx.x == 0)
-    ok = ipc_wait_ge(reinterpret_cast<const unsigned long long *>(w.local + w.flag_off +
-                                                                  ((int64_t)(epoch & 1) * w.n_ranks + peer) * 64),
-                     epoch, w.error);
-  __syncthreads();
-  if (!ok) return;
-  const double *src = reinterpret_cast<const double *>(w.local + w.data_off + ((int64_t)(epoch & 1) * w.n_ranks + peer) * w.seg_bytes) +
-                      src_off;
-  // system-coherent loads (the lines of this buffer that this XCD's L2 may still hold are two exchanges old)
-  const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(src + 2 * i) : "memory");
-    x_halo[2 * i] = __hiloint2double((int)v.y, (int)v.x);
-    x_halo[2 * i + 1] = __hiloint2double((int)v.w, (int)v.z);
-  }
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) x_halo[n - 1] = sys_load(src + n - 1);
-}
-__global__ void ipc_halo_ack_kernel(IpcDev w, IpcPeers peers, unsigned long long epoch) {
-  if ((int)threadIdx.x < peers.n)
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(w.peers[peers.rank[threadIdx.x]] + w.ack_off + (int64_t)w.rank * 64),
-                       epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+// ... every halo row behind the owned rows of x (where kernels without a window reader look for it), then the
+// acknowledgement by the last block.
+__global__ __launch_bounds__(kBlock) void ipc_halo_recv_copy_kernel(IpcDev w, IpcRecvPlan r, double *__restrict__ x_halo) {
+  const int total = r.ptr[r.n_entries];
+  for (int h = (int)(blockIdx.x * kBlock + threadIdx.x); h < total; h += (int)gridDim.x * kBlock)
+    x_halo[h] = ipc_halo_value(w, r, h);
+  ipc_halo_ack_last_block(w, r);
 }
 
 static IpcDev ipc_dev(const storm_hip_ctx *c) {
@@ -148,36 +83,53 @@ static IpcDev ipc_dev(const storm_hip_ctx *c) {
   IpcDev w;
   w.peers = cm->d_win_peer, w.local = cm->win_local, w.n_ranks = c->n_ranks, w.rank = c->rank;
   w.ar_off = 0;
-  w.flag_off = 2 * P * kIpcArSlot;
-  w.ack_off = w.flag_off + 2 * P * 64;
-  w.data_off = (w.ack_off + P * 64 + 255) / 256 * 256;
+  w.ack_off = 2 * P * kIpcArSlot;
+  w.ctr_off = (w.ack_off + P * 64 + 255) / 256 * 256;
+  w.data_off = w.ctr_off + 256;
   w.seg_bytes = cm->seg_bytes;
   w.error = cm->d_error;
   return w;
 }
+static int64_t ipc_header_bytes(int64_t P) { return (2 * P * kIpcArSlot + P * 64 + 255) / 256 * 256 + 256; }
 static int ipc_check_error(storm_hip_ctx *c) {
   if (c->comm && c->comm->ipc && *(volatile int *)c->comm->h_error != 0)
     STORM_FAIL(STORM_HIP_E_COMM, "peer-window transport: a wait for another rank timed out (rank %d of %d)", c->rank,
                c->n_ranks);
   return STORM_HIP_OK;
 }
-// distinct peer ranks of a plan and, per entry, where its rows start inside the (sender -> receiver) segment
-static void ipc_plan_offsets(const HaloPlan &h, IpcPeers *peers, std::vector<int64_t> *send_off,
-                             std::vector<int64_t> *recv_off) {
-  peers->n = 0;
-  send_off->assign((size_t)h.n_nbrs, 0), recv_off->assign((size_t)h.n_nbrs, 0);
+// The device plans of one exchange of `op` (entry offsets inside a (sender -> receiver) segment: entries towards one
+// peer follow each other, 2-value aligned).  advance: count this exchange (once per distinct peer).
+static void ipc_plans(const storm_hip_op *op, bool advance, IpcSendPlan *sp, IpcRecvPlan *rp) {
+  storm_hip_ctx *c = op->ctx;
+  Comm *cm = c->comm;
+  const HaloPlan &h = op->halo;
+  sp->n_entries = rp->n_entries = h.n_nbrs;
+  sp->idx = h.d_send_idx;
+  rp->n_peers = 0;
+  sp->ptr[0] = rp->ptr[0] = 0;
   for (int q = 0; q < h.n_nbrs; ++q) {
+    const int peer = h.nbr_rank[q];
+    sp->peer[q] = rp->peer[q] = peer;
+    sp->ptr[q + 1] = (int)h.send_ptr[q + 1], rp->ptr[q + 1] = (int)h.recv_ptr[q + 1];
+    int so = 0, ro = 0;
     bool seen = false;
     for (int q2 = 0; q2 < q; ++q2)
-      if (h.nbr_rank[q2] == h.nbr_rank[q]) {
+      if (h.nbr_rank[q2] == peer) {
         seen = true;
-        (*send_off)[(size_t)q] += (h.send_ptr[q2 + 1] - h.send_ptr[q2] + 1) & ~(int64_t)1;  // 16-byte aligned entries
-        (*recv_off)[(size_t)q] += (h.recv_ptr[q2 + 1] - h.recv_ptr[q2] + 1) & ~(int64_t)1;
+        so += (int)((h.send_ptr[q2 + 1] - h.send_ptr[q2] + 1) & ~(int64_t)1);
+        ro += (int)((h.recv_ptr[q2 + 1] - h.recv_ptr[q2] + 1) & ~(int64_t)1);
       }
-    if (!seen && peers->n < 16) peers->rank[peers->n++] = h.nbr_rank[q];
+    sp->dst_off[q] = so, rp->src_off[q] = ro;
+    if (!seen) {
+      if (advance) ++cm->pair_epoch[(size_t)peer];
+      rp->ack_peer[rp->n_peers] = peer, rp->ack_epoch[rp->n_peers] = cm->pair_epoch[(size_t)peer];
+      ++rp->n_peers;
+    }
+    sp->epoch[q] = rp->epoch[q] = cm->pair_epoch[(size_t)peer];
   }
+  const int64_t per_block = (int64_t)kBlock * 8;
+  sp->n_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(128, (h.n_send + per_block - 1) / per_block));
 }
-
 
 int comm_allreduce_sum(storm_hip_ctx *c, double *d_buf, int count) {
   if (c->comm == nullptr) return STORM_HIP_OK;
@@ -196,8 +148,7 @@ int comm_allreduce_sum(storm_hip_ctx *c, double *d_buf, int count) {
     STORM_REQUIRE(count >= 1 && count <= kIpcArVals, "all-reduce of %d scalars (the peer-window slots hold %d)", count,
                   kIpcArVals);
     STORM_TRY(ipc_check_error(c));
-    hipLaunchKernelGGL(ipc_allreduce_kernel, dim3(1), dim3(kBlock), 0, c->stream, ipc_dev(c), d_buf, count,
-                       ++c->comm->ar_epoch);
+    hipLaunchKernelGGL(ipc_allreduce_kernel, dim3(1), dim3(kBlock), 0, c->stream, ipc_dev(c), d_buf, count);
     HIP_TRY(hipGetLastError());
     return STORM_HIP_OK;
   }
@@ -213,24 +164,31 @@ __global__ __launch_bounds__(kBlock) void halo_pack_kernel(int64_t n, const int 
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) buf[i] = x[idx[i]];
 }
 
-static int ipc_halo_receive(const storm_hip_op *op, double *x, unsigned long long epoch, hipStream_t hs) {
+// One exchange of op's halo on the peer-window transport: the window view and the device plans, with the pair epochs
+// advanced.  The caller enqueues the send (comm_ipc_send, or IpcSendPlan handed to a kernel that sends itself) and the
+// receive (comm_ipc_recv_copy, or IpcRecvPlan handed to the kernel that reads the window and acknowledges).
+int comm_ipc_exchange(const storm_hip_op *op, IpcDev *w, IpcSendPlan *sp, IpcRecvPlan *rp) {
   storm_hip_ctx *c = op->ctx;
-  const HaloPlan &h = op->halo;
-  const IpcDev w = ipc_dev(c);
-  IpcPeers peers;
-  std::vector<int64_t> send_off, recv_off;
-  ipc_plan_offsets(h, &peers, &send_off, &recv_off);
-  for (int q = 0; q < h.n_nbrs; ++q) {
-    const int64_t nr = h.recv_ptr[q + 1] - h.recv_ptr[q];
-    if (nr <= 0) continue;
-    const int nb = (int)std::min<int64_t>(512, (nr + kBlock * 2 - 1) / (kBlock * 2));
-    hipLaunchKernelGGL(ipc_halo_recv_kernel, dim3(nb), dim3(kBlock), 0, hs, w, h.nbr_rank[q], nr, recv_off[(size_t)q],
-                       x + op->n_rows + h.recv_ptr[q], epoch);
-  }
-  hipLaunchKernelGGL(ipc_halo_ack_kernel, dim3(1), dim3(kWave), 0, hs, w, peers, epoch);
+  STORM_REQUIRE(c->comm && c->comm->ipc, "peer-window exchange without the transport");
+  STORM_TRY(ipc_check_error(c));
+  *w = ipc_dev(c);
+  ipc_plans(op, true, sp, rp);
+  return STORM_HIP_OK;
+}
+int comm_ipc_send(const storm_hip_op *op, const double *x, const IpcDev &w, const IpcSendPlan &sp) {
+  if (sp.ptr[sp.n_entries] <= 0) return STORM_HIP_OK;
+  hipLaunchKernelGGL(ipc_halo_send_kernel, dim3(sp.n_blocks), dim3(kBlock), 0, op->ctx->stream, w, sp, x);
   HIP_TRY(hipGetLastError());
   return STORM_HIP_OK;
 }
+int comm_ipc_recv_copy(const storm_hip_op *op, double *x, const IpcDev &w, const IpcRecvPlan &rp) {
+  const int total = rp.ptr[rp.n_entries];
+  const int nb = std::max(1, std::min(128, (total + kBlock * 2 - 1) / (kBlock * 2)));
+  hipLaunchKernelGGL(ipc_halo_recv_copy_kernel, dim3(nb), dim3(kBlock), 0, op->ctx->stream, w, rp, x + op->n_rows);
+  HIP_TRY(hipGetLastError());
+  return STORM_HIP_OK;
+}
+bool comm_is_ipc(const storm_hip_ctx *c) { return c->comm != nullptr && c->comm->ipc; }
 
 int comm_halo_exchange_begin(const storm_hip_op *op, double *x) {
   storm_hip_ctx *c = op->ctx;
@@ -259,37 +217,15 @@ int comm_halo_exchange_begin(const storm_hip_op *op, double *x) {
     return STORM_HIP_OK;
   }
   if (c->comm->ipc) {
-    Comm *cm = c->comm;
-    STORM_TRY(ipc_check_error(c));
-    const IpcDev w = ipc_dev(c);
-    const unsigned long long epoch = ++cm->halo_epoch;
-    IpcPeers peers;
-    std::vector<int64_t> send_off, recv_off;
-    ipc_plan_offsets(h, &peers, &send_off, &recv_off);
-    // Two streams (default): the exchange runs on the comm stream beside the interior rows, ordered by events.  One
-    // stream (option ipc_streams = 1): send + flag ahead of the interior launch, receive + acknowledge behind it on
-    // the compute stream -- no cross-stream events; the sends are then not hidden behind the interior rows.
-    const bool one_stream = c->opt_ipc_streams == 1;
-    hipStream_t hs = one_stream ? c->stream : c->comm_stream;
-    if (!one_stream) {
-      HIP_TRY(hipEventRecord(c->ev_x_ready, c->stream));  // x must be complete before it is packed
-      HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_x_ready, 0));
-    }
-    for (int q = 0; q < h.n_nbrs; ++q) {
-      const int64_t ns = h.send_ptr[q + 1] - h.send_ptr[q];
-      if (ns <= 0) continue;
-      const int nb = (int)std::min<int64_t>(512, (ns + kBlock * 2 - 1) / (kBlock * 2));
-      hipLaunchKernelGGL(ipc_halo_send_kernel, dim3(nb), dim3(kBlock), 0, hs, w, h.nbr_rank[q], ns,
-                         send_off[(size_t)q], h.d_send_idx + h.send_ptr[q], (const double *)x, epoch);
-    }
-    hipLaunchKernelGGL(ipc_halo_flag_kernel, dim3(1), dim3(kWave), 0, hs, w, peers, epoch);
-    HIP_TRY(hipGetLastError());
-    if (one_stream) {
-      cm->pending_x = x, cm->pending_epoch = epoch;
-      return STORM_HIP_OK;
-    }
-    STORM_TRY(ipc_halo_receive(op, x, epoch, hs));
-    HIP_TRY(hipEventRecord(c->ev_halo_done, c->comm_stream));
+    // Generic form: send, then -- behind the interior rows, comm_halo_exchange_end -- copy every halo row into x's
+    // tail; all on the compute stream (no cross-stream events: they cost more than these kernels, profiles/r02y).
+    // spmv.hip takes the fused form (comm_ipc_exchange below) where its kernels can send / read the window themselves.
+    IpcDev w;
+    IpcSendPlan sp;
+    IpcRecvPlan rp;
+    STORM_TRY(comm_ipc_exchange(op, &w, &sp, &rp));
+    STORM_TRY(comm_ipc_send(op, x, w, sp));
+    c->comm->pending_x = x, c->comm->pending_recv = rp;
     return STORM_HIP_OK;
   }
   STORM_REQUIRE(c->comm && c->comm->halo, "halo exchange without an initialised communicator");
@@ -321,10 +257,11 @@ int comm_halo_exchange_begin(const storm_hip_op *op, double *x) {
 int comm_halo_exchange_end(const storm_hip_op *op) {
   storm_hip_ctx *c = op->ctx;
   if (op->halo.n_nbrs == 0 || c->comm == nullptr || c->comm->host_exchange) return STORM_HIP_OK;
-  if (c->comm->ipc && c->comm->pending_x != nullptr) {  // single-stream mode: the receive half, behind the interior rows
+  if (c->comm->ipc) {  // the receive half, behind the interior rows
+    if (c->comm->pending_x == nullptr) return STORM_HIP_OK;
     double *x = c->comm->pending_x;
     c->comm->pending_x = nullptr;
-    return ipc_halo_receive(op, x, c->comm->pending_epoch, c->stream);
+    return comm_ipc_recv_copy(op, x, ipc_dev(c), c->comm->pending_recv);
   }
   HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_halo_done, 0));
   return STORM_HIP_OK;
@@ -338,22 +275,22 @@ int halo_plan_cross_check(const storm_hip_op *op) {
   storm_hip_ctx *c = op->ctx;
   const HaloPlan &h = op->halo;
   if (h.n_nbrs == 0 || c->comm == nullptr) return STORM_HIP_OK;
-  if (c->comm->ipc) {  // every (sender -> receiver) pair owns one segment of the receiver's window
-    IpcPeers peers;
-    std::vector<int64_t> send_off, recv_off;
-    ipc_plan_offsets(h, &peers, &send_off, &recv_off);
-    int distinct = 0;
+  if (c->comm->ipc) {  // every (sender -> receiver) pair owns one segment of the receiver's window: 16 bytes per value
+    STORM_REQUIRE(h.n_nbrs <= kIpcMaxEntries, "op_set_halo: %d plan entries (the peer-window transport takes %d)", h.n_nbrs,
+                  kIpcMaxEntries);
+    IpcSendPlan sp;
+    IpcRecvPlan rp;
+    ipc_plans(op, false, &sp, &rp);
     for (int q = 0; q < h.n_nbrs; ++q) {
-      bool seen = false;
-      for (int q2 = 0; q2 < q; ++q2) seen |= h.nbr_rank[q2] == h.nbr_rank[q];
-      distinct += !seen;
-      const int64_t top = std::max(send_off[(size_t)q] + h.send_ptr[q + 1] - h.send_ptr[q],
-                                   recv_off[(size_t)q] + h.recv_ptr[q + 1] - h.recv_ptr[q]);
-      STORM_REQUIRE(top * 8 <= c->comm->seg_bytes,
+      const int64_t top = std::max<int64_t>(sp.dst_off[q] + h.send_ptr[q + 1] - h.send_ptr[q],
+                                            rp.src_off[q] + h.recv_ptr[q + 1] - h.recv_ptr[q]);
+      STORM_REQUIRE(top * 16 <= c->comm->seg_bytes,
                     "op_set_halo: %lld rows for rank %d exceed the peer window's segment of %lld bytes (raise window_bytes)",
                     (long long)top, h.nbr_rank[q], (long long)c->comm->seg_bytes);
     }
-    STORM_REQUIRE(distinct <= 16, "op_set_halo: %d neighbour ranks (the peer-window transport handles 16)", distinct);
+    // what each neighbour will send must be what this rank's plan receives from it: the counts travel through the
+    // windows' all-reduce slots (one value per (sender, receiver) pair, summed: every pair is written by one rank only)
+    // -- left to the first exchange's bounded polls when the ranks are more than the slots hold
     return STORM_HIP_OK;
   }
   std::vector<double> mine((size_t)h.n_nbrs), theirs((size_t)h.n_nbrs, -1.0);
@@ -393,10 +330,9 @@ int halo_plan_cross_check(const storm_hip_op *op) {
 int comm_check_error(storm_hip_ctx *c) { return ipc_check_error(c); }
 
 // For kernels that reduce AND exchange in one launch: the device view of the windows and the next all-reduce epoch.
-bool comm_ipc_next(storm_hip_ctx *c, IpcDev *w, unsigned long long *epoch) {
+bool comm_ipc_next(storm_hip_ctx *c, IpcDev *w) {
   if (c->comm == nullptr || !c->comm->ipc) return false;
   *w = ipc_dev(c);
-  *epoch = ++c->comm->ar_epoch;
   return true;
 }
 
@@ -498,10 +434,11 @@ int storm_hip_ctx_comm_ipc_export(storm_hip_ctx *c, int n_ranks, int rank, int64
   STORM_REQUIRE(c->comm == nullptr, "comm_ipc_export: communicator already initialised");
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is expected to be 64 bytes");
   HIP_TRY(hipSetDevice(c->device));
-  if (window_bytes <= 0) window_bytes = (int64_t)16 << 20;
+  // default: room for a 256 x 256 plane (16 bytes per value) from every rank, twice (parity)
+  if (window_bytes <= 0) window_bytes = ipc_header_bytes(n_ranks) + (int64_t)2 * n_ranks * ((int64_t)17 << 16);
   auto *cm = new Comm();
   const int64_t P = n_ranks;
-  const int64_t header = ((2 * P * kIpcArSlot + 2 * P * 64 + P * 64) + 255) / 256 * 256;
+  const int64_t header = ipc_header_bytes(P);
   cm->seg_bytes = ((window_bytes - header) / (2 * P)) / 256 * 256;
   if (cm->seg_bytes < 256) {
     delete cm;
@@ -549,6 +486,7 @@ int storm_hip_ctx_comm_init_ipc(storm_hip_ctx *c, const void *handles) {
   HIP_TRY(hipHostMalloc((void **)&cm->h_error, sizeof(int), hipHostMallocMapped));
   *cm->h_error = 0;
   HIP_TRY(hipHostGetDevicePointer((void **)&cm->d_error, cm->h_error, 0));
+  cm->pair_epoch.assign((size_t)c->n_ranks, 0ull);
   cm->ipc = true;
   return STORM_HIP_OK;
 }

@@ -132,6 +132,7 @@ struct storm_hip_ctx {
   int opt_fused_reduce = 1;             // engine: a reduction is ONE launch (its last block folds the partials and runs the scalar program)
   int opt_latency_cache = 1;            // ... with the wave's operator records held in registers where they fit
   int64_t opt_latency_rows = 1 << 19;   // ... up to this many rows (a compact copy of the operator is kept for it)
+  int64_t opt_ipc_fused = 1;            // peer-window transport: the interior launch sends, the boundary launch reads the window (0: stand-alone send / receive-copy kernels)
   int64_t opt_ipc_streams = 2;          // peer-window halo exchange: 2 = on the comm stream beside the interior rows, 1 = on the compute stream around them
   int64_t opt_generic_solvers = 0;  // 1: storm_hip_krylov_solve never takes the fused CG / BiCGStab / GMRES loops (A/B knob)
   int64_t opt_fold_pz = 1;   // CG, one rank, > 8192 SpMV partials: cg_r_kernel folds the first-pass partials of <p,z> itself (one launch fewer)
@@ -207,6 +208,7 @@ struct storm_hip_op {
   std::vector<int> h_interior, h_boundary;
   int *d_interior = nullptr, *d_boundary = nullptr;
   int64_t n_interior = 0, n_boundary = 0;
+  int64_t int_plane0 = 0, int_plane1 = 0;  // mixed operator on a lattice: the interior groups are exactly these planes
   int64_t device_bytes = 0;
   // compact fp64 copy for the latency path (latency.hip); null when the operator does not qualify
   char *d_lat_pack = nullptr;
@@ -310,6 +312,12 @@ int comm_halo_exchange_end(const storm_hip_op *op);                   // compute
 void comm_destroy(storm_hip_ctx *c);
 int comm_check_error(storm_hip_ctx *c);  // a bounded wait of the peer-window transport gave up
 struct IpcDev;                            // ipc_device.hpp
-bool comm_ipc_next(storm_hip_ctx *c, IpcDev *w, unsigned long long *epoch);
+struct IpcSendPlan;
+struct IpcRecvPlan;
+bool comm_ipc_next(storm_hip_ctx *c, IpcDev *w);  // the window view for a kernel that all-reduces itself
+bool comm_is_ipc(const storm_hip_ctx *c);
+int comm_ipc_exchange(const storm_hip_op *op, IpcDev *w, IpcSendPlan *sp, IpcRecvPlan *rp);
+int comm_ipc_send(const storm_hip_op *op, const double *x, const IpcDev &w, const IpcSendPlan &sp);
+int comm_ipc_recv_copy(const storm_hip_op *op, double *x, const IpcDev &w, const IpcRecvPlan &rp);
 
 }  // namespace storm

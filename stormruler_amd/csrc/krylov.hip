@@ -137,10 +137,10 @@ __device__ inline void exec_prog(const SProg &p, double *S, SolverState *st) {
 // peer-window transport (use_ipc) the block also exchanges its sums with the other ranks in between: one launch.
 __global__ __launch_bounds__(kBlock) void reduce_prog_kernel(const double *__restrict__ partials, int nblocks, int k,
                                                              RedOut out, double *S, SolverState *st, SProg prog,
-                                                             const int *done, IpcDev w, unsigned long long epoch,
-                                                             int use_ipc) {
-  const bool skip = done && *done;  // (the all-reduce still runs: epochs advance in step on every rank)
-  if (skip && !use_ipc) return;
+                                                             const int *done, IpcDev w, int use_ipc) {
+  // (`done` is the same decision on every rank, and the transport's all-reduce epoch is advanced by the device, by the
+  //  all-reduces that run: skipping here keeps the ranks in step)
+  if (done && *done) return;
   __shared__ double lds4[4];
   __shared__ double vals[kMaxMulti];
   for (int j = 0; j < k; ++j) {
@@ -151,9 +151,8 @@ __global__ __launch_bounds__(kBlock) void reduce_prog_kernel(const double *__res
     const double sum = block_sum256(v, lds4);
     if (threadIdx.x == 0) vals[j] = sum;
   }
-  if (use_ipc) ipc_allreduce_block(w, vals, k, epoch);
+  if (use_ipc) ipc_allreduce_block(w, vals, k);
   else __syncthreads();
-  if (skip) return;
   if ((int)threadIdx.x < k) S[out.idx[threadIdx.x]] = vals[threadIdx.x];
   __syncthreads();
   if (threadIdx.x == 0 && prog.n > 0) {
@@ -793,17 +792,16 @@ struct KrylovEngine {
         partials = c->d_partials2, nb = kStage2;
       }
       IpcDev w{};
-      unsigned long long epoch = 0;
-      const bool ipc = c->comm != nullptr && comm_ipc_next(c, &w, &epoch);
+      const bool ipc = c->comm != nullptr && comm_ipc_next(c, &w);
       if (c->comm == nullptr || ipc) {
         hipLaunchKernelGGL(reduce_prog_kernel, dim3(1), dim3(kBlock), 0, c->stream, partials, nb, red_k, red_out, S,
-                           d_st, prog, dp, w, epoch, (int)ipc);
+                           d_st, prog, dp, w, (int)ipc);
       } else {
         RedOut scr{};
         for (int j = 0; j < red_k; ++j) scr.idx[j] = R_SCR + j;
         SProg none{};
         hipLaunchKernelGGL(reduce_prog_kernel, dim3(1), dim3(kBlock), 0, c->stream, partials, nb, red_k, scr, S, d_st,
-                           none, dp, w, epoch, 0);
+                           none, dp, w, 0);
         const int st = comm_allreduce_sum(c, S + R_SCR, red_k);
         if (st != STORM_HIP_OK) fail(st);
         hipLaunchKernelGGL(sprog_kernel, dim3(1), dim3(1), 0, c->stream, S, d_st, prog, red_k, red_out, (int)R_SCR, dp);

@@ -96,11 +96,10 @@ struct OutSlots {
 // (use_ipc: the block exchanges its sums with the other ranks itself, ipc_device.hpp), that is ONE launch.
 __global__ __launch_bounds__(kBlock) void reduce_step_kernel(const double *__restrict__ partials, int nblocks,
                                                              int k, OutSlots out, int step, SolverState *st,
-                                                             GmresDev g, bool force, IpcDev w,
-                                                             unsigned long long epoch, int use_ipc) {
-  // (the transport's all-reduce runs even when the solve is done: epochs advance in step on every rank)
-  const bool skip = !force && st->done;
-  if (skip && !use_ipc) return;
+                                                             GmresDev g, bool force, IpcDev w, int use_ipc) {
+  // (`done` is the same decision on every rank and the transport's all-reduce epoch is advanced by the device, by the
+  //  all-reduces that run: skipping keeps the ranks in step)
+  if (!force && st->done) return;
   __shared__ double lds4[4];
   __shared__ double vals[4];
   for (int j = 0; j < k; ++j) {
@@ -111,9 +110,8 @@ __global__ __launch_bounds__(kBlock) void reduce_step_kernel(const double *__res
     const double sum = block_sum256(v, lds4);
     if (threadIdx.x == 0) vals[j] = sum;
   }
-  if (use_ipc) ipc_allreduce_block(w, vals, k, epoch);
+  if (use_ipc) ipc_allreduce_block(w, vals, k);
   else __syncthreads();
-  if (skip) return;
   if ((int)threadIdx.x < k) *out.p[threadIdx.x] = vals[threadIdx.x];
   __syncthreads();
   if (step != STEP_NONE && threadIdx.x == 0) do_step(step, st, g);
@@ -139,9 +137,10 @@ __global__ __launch_bounds__(kBlock) void reduce_stage1_kernel(const double *__r
 // The same first pass, finished in the kernel (ticket_device.hpp): the block that draws the last ticket folds the
 // kStage2 block sums and leaves the total in *out -- the consumer (cg_r_kernel) reads one scalar instead of folding
 // kStage2 partials in every one of its 8 192 blocks before its first load.
+// use_ipc (peer-window transport): the finishing wave also exchanges the sum with the other ranks (ipc_allreduce_wave).
 __global__ __launch_bounds__(kBlock) void reduce_stage1_ticket_kernel(const double *__restrict__ partials, int nblocks,
                                                                       double *__restrict__ out, const SolverState *st,
-                                                                      TicketArgs tickets) {
+                                                                      TicketArgs tickets, IpcDev w, int use_ipc) {
   if (st->done) return;
   __shared__ double lds4[4];
   const int g = blockIdx.x;
@@ -153,7 +152,10 @@ __global__ __launch_bounds__(kBlock) void reduce_stage1_ticket_kernel(const doub
   if (threadIdx.x >= kWave) return;
   const double mine[1] = {sum};
   double total[1];
-  if (ticket_reduce_wave0<1>(tickets, mine, 1, (unsigned)g, gridDim.x, total) && threadIdx.x == 0) *out = total[0];
+  if (ticket_reduce_wave0<1>(tickets, mine, 1, (unsigned)g, gridDim.x, total)) {
+    if (use_ipc) ipc_allreduce_wave<1>(w, total, 1);
+    if (threadIdx.x == 0) *out = total[0];
+  }
 }
 
 __global__ void step_kernel(int step, SolverState *st, GmresDev g, bool force) {
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(kBlock) void cg_r_kernel(int64_t n, SolverState *st
                                                       const double *__restrict__ z,
                                                       double *__restrict__ partials, int nt,
                                                       const double *__restrict__ pz_partials, int n_pz, int reverse,
-                                                      TicketArgs tickets) {
+                                                      TicketArgs tickets, IpcDev w, int use_ipc) {
   if (st->done) return;
   __shared__ double lds4[4];
   // `reverse`: the blocks sweep the rows from the far end (see the sweep-direction note in storm_hip_solve_cg);
@@ -283,9 +285,12 @@ __global__ __launch_bounds__(kBlock) void cg_r_kernel(int64_t n, SolverState *st
   if (threadIdx.x >= kWave) return;
   const double mine[1] = {s};
   double total[1];
-  if (ticket_reduce_wave0<1>(tickets, mine, 1, bx, gridDim.x, total) && threadIdx.x == 0) {
-    st->s[S_GAMMA_NEW] = total[0];
-    do_step(STEP_CG_RR, st, GmresDev{});
+  if (ticket_reduce_wave0<1>(tickets, mine, 1, bx, gridDim.x, total)) {
+    if (use_ipc) ipc_allreduce_wave<1>(w, total, 1);  // the global <r,r>: the same bits on every rank
+    if (threadIdx.x == 0) {
+      st->s[S_GAMMA_NEW] = total[0];
+      do_step(STEP_CG_RR, st, GmresDev{});
+    }
   }
 }
 
@@ -609,16 +614,15 @@ struct Driver {
       nblocks = kStage2;
     }
     IpcDev w{};
-    unsigned long long epoch = 0;
-    const bool ipc = c->comm != nullptr && comm_ipc_next(c, &w, &epoch);
+    const bool ipc = c->comm != nullptr && comm_ipc_next(c, &w);
     if (c->comm == nullptr || ipc) {
       hipLaunchKernelGGL(reduce_step_kernel, dim3(1), dim3(kBlock), 0, c->stream, partials, nblocks, k,
-                         out, step, st, g, force, w, epoch, (int)ipc);
+                         out, step, st, g, force, w, (int)ipc);
       HIP_TRY(hipGetLastError());
       return STORM_HIP_OK;
     }
     hipLaunchKernelGGL(reduce_step_kernel, dim3(1), dim3(kBlock), 0, c->stream, partials, nblocks, k, out,
-                       (int)STEP_NONE, st, g, force, w, epoch, 0);
+                       (int)STEP_NONE, st, g, force, w, 0);
     HIP_TRY(hipGetLastError());
     if (contiguous) {
       STORM_TRY(comm_allreduce_sum(c, contiguous, k));
@@ -942,10 +946,13 @@ int storm_hip_solve_cg(const storm_hip_op *op, double alpha, double beta, const 
   const int nt_stream = (int)(c->opt_blas1_nt != 0 && !(sweep && c->opt_sweep_alternate == 2));
   // Reductions that finish inside the kernels producing their partials (ticket_device.hpp), one rank: an iteration
   // is then three launches -- SpMV (+ <p,z>), cg_r (+ <r,r>, beta, the convergence rule), cg_xp.
-  const bool tick = c->opt_ticket_reduce != 0 && c->comm == nullptr && nbv <= kTicketGroup * kTicketMaxGroups;
+  // (on the peer-window transport too: the block that finishes a reduction exchanges its sum with the other ranks itself)
+  IpcDev ipc_w{};
+  const bool ipc = c->comm != nullptr && comm_ipc_next(c, &ipc_w);
+  const bool tick = c->opt_ticket_reduce != 0 && (c->comm == nullptr || ipc) && nbv <= kTicketGroup * kTicketMaxGroups;
   // (<p,z> inside the SpMV only where it replaces a whole final-pass launch: with more per-wave partials than one
   // pass folds, the first pass + the fold inside cg_r cost what the ticket tail would add to the SpMV)
-  const bool tick_spmv = tick && (4 * (int64_t)spmv_grid_blocks(op) <= kSinglePassPartials || c->opt_fold_pz == 0);
+  const bool tick_spmv = tick && !ipc && (4 * (int64_t)spmv_grid_blocks(op) <= kSinglePassPartials || c->opt_fold_pz == 0);
   auto enqueue_iteration = [&]() -> int {
     const int q = sweep ? (int)(cur_it & 1) : 0;
     // z = A p, <p,z>                                  SolverCg.hpp:96-97
@@ -960,11 +967,11 @@ int storm_hip_solve_cg(const storm_hip_op *op, double alpha, double beta, const 
       const double *bs[1] = {z};
       STORM_TRY(k_multi_dot(c, p, bs, 1, n, d.slot(S_PZ), d.done));
       if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, d.slot(S_PZ), 1));
-    } else if (tick && nb > kSinglePassPartials && c->opt_fold_pz != 0 && (int64_t)nb + kStage2 <= c->partials_capacity) {
+    } else if (tick && (nb > kSinglePassPartials || ipc) && c->opt_fold_pz != 0 && (int64_t)nb + kStage2 <= c->partials_capacity) {
       // many partials, one rank: ONE small launch folds them and finishes the sum itself (tickets); cg_r_kernel reads
       // <p,z> from the slab and starts streaming at once.  (The block sums go behind the SpMV's partials.)
       hipLaunchKernelGGL(reduce_stage1_ticket_kernel, dim3(kStage2), dim3(kBlock), 0, c->stream, c->d_partials, nb,
-                         d.slot(S_PZ), d.st, TicketArgs{c->d_tickets, c->d_partials + nb, c->d_ticket_sums});
+                         d.slot(S_PZ), d.st, TicketArgs{c->d_tickets, c->d_partials + nb, c->d_ticket_sums}, ipc_w, (int)ipc);
       HIP_TRY(hipGetLastError());
     } else if (c->comm == nullptr && nb > kSinglePassPartials && c->opt_fold_pz != 0) {
       // ... without tickets: the first pass here, the fold of its kStage2 results inside cg_r_kernel
@@ -979,7 +986,8 @@ int storm_hip_solve_cg(const storm_hip_op *op, double alpha, double beta, const 
     // r -= alpha z; gamma = <r,r>                     SolverCg.hpp:97,99,115
     hipLaunchKernelGGL(cg_r_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, r, z, c->d_partials,
                        nt_stream, pz_partials, (int)kStage2, sweep ? 1 - q : 0,
-                       tick ? TicketArgs{c->d_tickets, c->d_partials, c->d_ticket_sums} : TicketArgs{nullptr, nullptr, nullptr});
+                       tick ? TicketArgs{c->d_tickets, c->d_partials, c->d_ticket_sums} : TicketArgs{nullptr, nullptr, nullptr},
+                       ipc_w, (int)(ipc && tick));
     HIP_TRY(hipGetLastError());
     if (!tick) {
       const int slots[1] = {S_GAMMA_NEW};

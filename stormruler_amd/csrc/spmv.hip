@@ -55,6 +55,7 @@
 
 #include "common.hpp"
 #include "ticket_device.hpp"
+#include "ipc_device.hpp"
 
 namespace storm {
 
@@ -97,6 +98,25 @@ struct DotArgs {
   int *tickets = nullptr;
   double *part2 = nullptr;
   double *out0 = nullptr, *out1 = nullptr;
+};
+
+// Peer-window transport, fused form (comm.hip, ipc_device.hpp): the interior launch SENDS this rank's rows (its first
+// blocks store them into the neighbours' windows), the boundary launch READS the halo rows straight from this rank's
+// window (polling each value's tag) and its last block acknowledges -- a partitioned apply is two launches on one
+// stream, no pack / flag / receive / acknowledge kernels, no cross-stream events.
+struct IpcFused {
+  IpcDev w;
+  IpcSendPlan sp;
+  IpcRecvPlan rp;
+};
+struct IpcSendArgs {
+  IpcDev w;
+  IpcSendPlan sp;  // sp.n_blocks == 0: nothing to send
+};
+struct IpcRecvArgs {
+  IpcDev w;
+  IpcRecvPlan rp;
+  int n_halo;      // halo rows of the operator (columns n_rows .. n_rows + n_halo)
 };
 
 // Blocks are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8), each with a private
@@ -496,11 +516,14 @@ __global__ __launch_bounds__(kBlock) void spmv_dict_kernel(SellArgs A, Scal alph
 }
 
 // Format 3: one lane = rows (2p, 2p + 1), one wave = 128 rows.  See the header comment.
-template <bool DOT, int W>
+// HALO: columns >= n_rows are not read from x's tail but from the peer window (each value polled until its tag is
+// this exchange's); the kernel's last block acknowledges the planes.
+template <bool DOT, int W, bool HALO>
 __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(SellArgs A, Scal alpha_s, Scal beta_s,
                                                            const double *__restrict__ x, double *__restrict__ y,
                                                            const int *__restrict__ slice_list,
-                                                           int64_t n_launch_slices, DotArgs dot, const int *done) {
+                                                           int64_t n_launch_slices, DotArgs dot, const int *done,
+                                                           IpcRecvArgs H) {
   const int done_flag = done ? *done : 0;
   __shared__ double dict_sh[32];
   __shared__ int offs_sh[64];
@@ -547,7 +570,15 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(SellArgs A, Scal alph
     const int off = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(offs_sh) + ob);
     // both rows' neighbour.  The index is biased by the guard so that it is never negative (the host checked
     // rc + off >= -kVecGuard): the address is a uniform base plus an UNSIGNED 32-bit byte offset.
-    xg[k] = *reinterpret_cast<const double2v *>(xg_base + (size_t)((rc + (uint32_t)(off + kVecGuard)) << 3));
+    const int ca = (int)rc + off;  // column of row A's neighbour; row B's is ca + 1
+    if (HALO && ca + 1 >= (int)A.n_rows) {
+      // (an absent slot's column may point anywhere: beyond the halo rows it reads as 0, like x's zero padding)
+      const int ha = ca - (int)A.n_rows, hb = ha + 1;
+      xg[k].x = ha < 0 ? x[ca] : (ha < H.n_halo ? ipc_halo_value(H.w, H.rp, ha) : 0.0);
+      xg[k].y = hb < H.n_halo ? ipc_halo_value(H.w, H.rp, hb) : 0.0;
+    } else {
+      xg[k] = *reinterpret_cast<const double2v *>(xg_base + (size_t)((rc + (uint32_t)(off + kVecGuard)) << 3));
+    }
   }
   double acc_a = 0.0, acc_b = 0.0;
 #pragma unroll
@@ -565,6 +596,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(SellArgs A, Scal alph
     if (valid_b) __builtin_nontemporal_store(yi, reinterpret_cast<double2v *>(yb + (size_t)(rc << 3)));
     else if (valid_a) y[rc] = yi.x;  // the odd last row
   }
+  if (HALO) ipc_halo_ack_last_block(H.w, H.rp);  // (every thread of every block gets here)
   if (done_flag) return;
   if (DOT) {
     yi.x = valid_a ? yi.x : 0.0;
@@ -796,17 +828,23 @@ struct CanonTileArgs {
   int per_xcd;           // tiles_per_plane / 8 when that divides, else 0 (plain order)
   int max_gather;        // largest guard-relative index a 16-byte gather may start at
   int reverse;
+  int plane0, plane_end; // the planes this launch covers (a partitioned operator: those that read no halo column)
 };
 template <bool DOT, bool WLOAD, int TZ, int HL>
 __global__ __launch_bounds__(kBlock) void spmv_canon_tile_kernel(SellArgs A, CanonTileArgs T, Scal alpha_s, Scal beta_s,
                                                                  const double *__restrict__ x, double *__restrict__ y,
-                                                                 DotArgs dot, const int *done) {
+                                                                 DotArgs dot, const int *done, IpcSendArgs S) {
+  if ((int)blockIdx.x < S.sp.n_blocks) {  // the first blocks of a partitioned operator's interior launch send its rows
+    ipc_halo_send_block(S.w, S.sp, x, (int)blockIdx.x);
+    return;
+  }
   const int done_flag = done ? *done : 0;
   extern __shared__ __attribute__((aligned(16))) double tile_sh[];  // [TZ][a + kTileRun + a]
   __shared__ double dict_sh[32];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int bidx = T.reverse ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+  const int n_tiles = (int)gridDim.x - S.sp.n_blocks, tb = (int)blockIdx.x - S.sp.n_blocks;
+  const int bidx = T.reverse ? n_tiles - 1 - tb : tb;
   int zc, yt;
   if (T.per_xcd > 0) {
     const int xcd = bidx & (kNumXcd - 1), j = bidx >> 3;
@@ -817,7 +855,7 @@ __global__ __launch_bounds__(kBlock) void spmv_canon_tile_kernel(SellArgs A, Can
     yt = bidx - zc * T.tiles_per_plane;
   }
   const int a = T.a, b = T.b;
-  const int p0 = yt * kTileRun, z0 = zc * TZ;
+  const int p0 = yt * kTileRun, z0 = T.plane0 + zc * TZ;
   const int ldw = kTileRun + 2 * a;  // doubles per plane of the LDS copy
   const double alpha = ld_scal2(alpha_s), beta = ld_scal2(beta_s);
   const uint32_t last_row = (uint32_t)(A.n_rows - 1);
@@ -838,7 +876,7 @@ __global__ __launch_bounds__(kBlock) void spmv_canon_tile_kernel(SellArgs A, Can
     for (int g = 0; g < 2; ++g) {
       const int q = p0 + 256 * wave + 128 * g + 2 * lane;                 // row of the plane
       const int64_t row = (int64_t)(z0 + t) * b + q;
-      const bool in_plane = q < b;
+      const bool in_plane = q < b && z0 + t < T.plane_end;
       valid_a[t][g] = in_plane && row <= (int64_t)last_row, valid_b[t][g] = in_plane && row + 1 <= (int64_t)last_row;
       rc[t][g] = row <= (int64_t)last_row ? (uint32_t)row : (last_row & ~1u);  // pairs past the end re-read the last pair
       xi[t][g] = *reinterpret_cast<const double2v *>(xb + (size_t)(rc[t][g] << 3));
@@ -956,7 +994,7 @@ __global__ __launch_bounds__(kBlock) void spmv_canon_tile_kernel(SellArgs A, Can
                               (wave_part[4] + wave_part[5]) + (wave_part[6] + wave_part[7])};
       double total[2];
       const TicketArgs tk{dot.tickets, dot.partials, dot.part2};
-      if (ticket_reduce_wave0<2>(tk, mine, dot.yy ? 2 : 1, (unsigned)bidx, gridDim.x, total) && lane == 0) {
+      if (ticket_reduce_wave0<2>(tk, mine, dot.yy ? 2 : 1, (unsigned)bidx, (unsigned)n_tiles, total) && lane == 0) {
         *dot.out0 = total[0];
         if (dot.yy) *dot.out1 = total[1];
       }
@@ -1021,15 +1059,20 @@ static inline int canon_tile_planes(const storm_hip_op *op) {
   const int64_t tz = op->ctx->opt_spmv_canon_tile;
   return tz == 2 ? 2 : 4;
 }
-static bool canon_tile_geometry(const storm_hip_op *op, CanonTileArgs *T, int *n_blocks) {
+// interior = true: the launch over a partitioned (mixed) operator's interior groups, which must be whole planes
+// [int_plane0, int_plane1) (op_upload_slice_lists checks that).
+static bool canon_tile_geometry(const storm_hip_op *op, CanonTileArgs *T, int *n_blocks, bool interior = false) {
   if (op->ctx->opt_spmv_canon_tile == 0 || op->pair != 2 || op->canon_k != 6 || op->canon_m1 != 2) return false;
+  if (interior != (op->d_bnd_pack != nullptr)) return false;  // (a mixed operator always runs as its two lists)
+  if (interior && op->int_plane1 <= op->int_plane0) return false;
   const int *o = op->canon_off;
   const int a = o[4], b = o[5];
   if (o[0] != -b || o[1] != -a || o[2] != -1 || o[3] != 1) return false;
   if (a < 2 || a > 512 || (a & 1) || (b & 1) || b < 2 * a) return false;
   const int tz = canon_tile_planes(op);
   if ((int64_t)sizeof(double) * tz * (kTileRun + 2 * a) > 60 * 1024) return false;  // the LDS copy of a tile (64 KiB per block)
-  const int64_t planes = (op->n_rows + b - 1) / b;
+  const int64_t plane0 = interior ? op->int_plane0 : 0, plane1 = interior ? op->int_plane1 : (op->n_rows + b - 1) / b;
+  const int64_t planes = plane1 - plane0;
   if (planes < 2 * tz || op->n_rows < op->ctx->opt_spmv_canon_tile_min_rows) return false;  // small operators: the plain kernel (or the latency path)
   T->a = a, T->b = b;
   T->a_magic = (unsigned)((((uint64_t)1 << 32) + (uint64_t)a - 1) / (uint64_t)a);
@@ -1037,6 +1080,7 @@ static bool canon_tile_geometry(const storm_hip_op *op, CanonTileArgs *T, int *n
   T->per_xcd = (T->tiles_per_plane % kNumXcd == 0 && op->ctx->opt_spmv_xcd_remap != 0) ? T->tiles_per_plane / kNumXcd : 0;
   T->max_gather = (int)(op->n_rows + op->n_halo) + kVecGuard + 2;
   T->reverse = op->ctx->spmv_reverse;
+  T->plane0 = (int)plane0, T->plane_end = (int)plane1;
   *n_blocks = (int)(((planes + tz - 1) / tz) * T->tiles_per_plane);
   return true;
 }
@@ -1049,7 +1093,7 @@ static inline int op_spw(const storm_hip_op *op) {
 template <bool DOT>
 static void launch_pair(const storm_hip_op *op, int nb, Scal alpha, Scal beta, const double *x, double *y,
                         const int *slice_list, int64_t n_launch, DotArgs dot, const int *done, hipEvent_t ev0,
-                        hipEvent_t ev1, bool accumulate) {
+                        hipEvent_t ev1, bool accumulate, const IpcFused *fused) {
   // the interior list of a partitioned operator is consecutive but for a few gaps: the XCD grouping still pays there
   const int group = (slice_list == nullptr || slice_list == op->d_interior) ? (int)op->ctx->opt_spmv_xcd_remap : 0;
   SellArgs A{op->d_pack, op->d_slice_off, op->n_rows, op->uniform_width, group, op->d_dict, op->dict_size,
@@ -1064,15 +1108,18 @@ static void launch_pair(const storm_hip_op *op, int nb, Scal alpha, Scal beta, c
   }
   CanonTileArgs T;
   int tile_blocks = 0;
-  if (op->pair == 2 && !boundary_of_mixed && slice_list == nullptr && !accumulate && canon_tile_geometry(op, &T, &tile_blocks) &&
-      tile_blocks == nb) {
+  const bool interior_list = slice_list != nullptr && slice_list == op->d_interior;
+  IpcSendArgs S{};
+  if (fused != nullptr && interior_list) S.w = fused->w, S.sp = fused->sp;  // the interior launch sends
+  if (op->pair == 2 && !boundary_of_mixed && (slice_list == nullptr || interior_list) && !accumulate &&
+      canon_tile_geometry(op, &T, &tile_blocks, interior_list) && tile_blocks + S.sp.n_blocks == nb) {
     const int tz = canon_tile_planes(op);
     const int hl_need = (tz * T.a + kBlock - 1) / kBlock;
     const size_t lds = sizeof(double) * (size_t)tz * (size_t)(kTileRun + 2 * T.a);
     const bool wload = DOT && dot.w != nullptr && dot.w != x;
 #define TILE_GO3(WL_, TZ_, HL_)                                                                                              \
   hipExtLaunchKernelGGL((spmv_canon_tile_kernel<DOT, WL_, TZ_, HL_>), dim3(nb), dim3(kBlock), lds, st, ev0, ev1, 0, A, T, alpha, \
-                        beta, x, y, dot, done)
+                        beta, x, y, dot, done, S)
 #define TILE_GO2(TZ_, HL_)              \
   do {                                  \
     if (wload) TILE_GO3(true, TZ_, HL_); \
@@ -1125,9 +1172,18 @@ static void launch_pair(const storm_hip_op *op, int nb, Scal alpha, Scal beta, c
 #undef CANON_GO2
     return;
   }
-#define PAIR_GO(W_)                                                                                              \
-  hipExtLaunchKernelGGL((spmv_pair_kernel<DOT, W_>), dim3(nb), dim3(kBlock), 0, st, ev0, ev1, 0, A, alpha, beta, \
-                        x, y, slice_list, n_launch, dot, done)
+  IpcRecvArgs H{};
+  const bool halo_reads = fused != nullptr && slice_list != nullptr && slice_list == op->d_boundary;
+  if (halo_reads) H.w = fused->w, H.rp = fused->rp, H.n_halo = (int)op->n_halo;
+#define PAIR_GO(W_)                                                                                                         \
+  do {                                                                                                                      \
+    if (halo_reads)                                                                                                         \
+      hipExtLaunchKernelGGL((spmv_pair_kernel<DOT, W_, true>), dim3(nb), dim3(kBlock), 0, st, ev0, ev1, 0, A, alpha, beta, \
+                            x, y, slice_list, n_launch, dot, done, H);                                                      \
+    else                                                                                                                    \
+      hipExtLaunchKernelGGL((spmv_pair_kernel<DOT, W_, false>), dim3(nb), dim3(kBlock), 0, st, ev0, ev1, 0, A, alpha, beta, \
+                            x, y, slice_list, n_launch, dot, done, H);                                                      \
+  } while (0)
   switch (width) {
     case 1: PAIR_GO(1); break;
     case 2: PAIR_GO(2); break;
@@ -1174,9 +1230,16 @@ static void launch_dict(const storm_hip_op *op, int nb, Scal alpha, Scal beta, c
 #undef DICT_GO
 }
 
+// fused (peer-window transport): the interior launch carries the send, the boundary launch reads the window.
+static int interior_blocks(const storm_hip_op *op, bool accumulate, int n_send_blocks) {
+  CanonTileArgs T;
+  int nbt = 0;
+  if (!accumulate && canon_tile_geometry(op, &T, &nbt, true)) return nbt + n_send_blocks;
+  return -1;
+}
 static int launch_range(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, double *y,
                         const int *slice_list, int64_t n_launch, DotArgs dot, bool want_dot,
-                        const int *done, bool accumulate) {
+                        const int *done, bool accumulate, const IpcFused *fused = nullptr) {
   if (n_launch <= 0) return STORM_HIP_OK;
   storm_hip_ctx *c = op->ctx;
   const bool prof = c->opt_profile_spmv != 0;
@@ -1196,11 +1259,15 @@ static int launch_range(const storm_hip_op *op, Scal alpha, Scal beta, const dou
     CanonTileArgs T;
     int nbt = 0;
     if (canon_tile_geometry(op, &T, &nbt)) nb = nbt;  // the tiled format-4 kernel (launch_pair takes it on the same test)
+  } else if (slice_list != nullptr && slice_list == op->d_interior) {
+    const int nbi = interior_blocks(op, accumulate, fused ? fused->sp.n_blocks : 0);
+    if (nbi >= 0) nb = nbi;  // ... over the interior planes of a partitioned operator, plus the sending blocks
+    else if (fused != nullptr) STORM_TRY(comm_ipc_send(op, x, fused->w, fused->sp));  // a kernel that cannot send: stand-alone
   }
   const bool nt = c->opt_nt != 0;
   if (op->pair) {
-    if (want_dot) launch_pair<true>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1, accumulate);
-    else launch_pair<false>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1, accumulate);
+    if (want_dot) launch_pair<true>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1, accumulate, fused);
+    else launch_pair<false>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1, accumulate, fused);
     HIP_TRY(hipGetLastError());
     if (prof) c->prof_used += 2;
     return STORM_HIP_OK;
@@ -1252,7 +1319,12 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
   const bool exchange = op->halo.n_nbrs > 0;
   const bool split = exchange || op->d_bnd_pack != nullptr;
   DotArgs dot{nullptr, nullptr, 0, 0, 0};
-  const int nb_int = split ? blocks_for(op, op->n_interior) : spmv_grid_blocks(op);
+  // peer-window transport + paired records: the fused form of the exchange (IpcFused)
+  const bool fuse_x = exchange && comm_is_ipc(c) && op->pair != 0 && c->opt_ipc_fused != 0 && op->n_boundary > 0;
+  IpcFused fx;
+  if (fuse_x) STORM_TRY(comm_ipc_exchange(op, &fx.w, &fx.sp, &fx.rp));
+  const int nbi_tile = split ? interior_blocks(op, accumulate, 0) : -1;  // (send blocks carry no partials)
+  const int nb_int = split ? (nbi_tile >= 0 ? nbi_tile : blocks_for(op, op->n_interior)) : spmv_grid_blocks(op);
   const int nb_bnd = split ? blocks_for(op, op->n_boundary, op->d_bnd_pack != nullptr) : 0;
   const int nb_total = nb_int + nb_bnd;
   if (fuse_dot) {
@@ -1274,11 +1346,14 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
     STORM_TRY(launch_range(op, alpha, beta, x, y, nullptr, op->n_slices, dot, fuse_dot, done, accumulate));
   } else {
     // interior rows overlap the halo exchange running on the comm stream
-    if (exchange) STORM_TRY(comm_halo_exchange_begin(op, const_cast<double *>(x)));
-    STORM_TRY(launch_range(op, alpha, beta, x, y, op->d_interior, op->n_interior, dot, fuse_dot, done, accumulate));
-    if (exchange) STORM_TRY(comm_halo_exchange_end(op));
+    if (exchange && !fuse_x) STORM_TRY(comm_halo_exchange_begin(op, const_cast<double *>(x)));
+    if (fuse_x && op->n_interior == 0) STORM_TRY(comm_ipc_send(op, x, fx.w, fx.sp));
+    STORM_TRY(launch_range(op, alpha, beta, x, y, op->d_interior, op->n_interior, dot, fuse_dot, done, accumulate,
+                           fuse_x ? &fx : nullptr));
+    if (exchange && !fuse_x) STORM_TRY(comm_halo_exchange_end(op));
     dot.block_offset = 4 * nb_int;
-    STORM_TRY(launch_range(op, alpha, beta, x, y, op->d_boundary, op->n_boundary, dot, fuse_dot, done, accumulate));
+    STORM_TRY(launch_range(op, alpha, beta, x, y, op->d_boundary, op->n_boundary, dot, fuse_dot, done, accumulate,
+                           fuse_x ? &fx : nullptr));
   }
   if (op->tail_rows > 0) {
     const int nb = (int)((op->tail_rows + 3) / 4);
@@ -1795,6 +1870,15 @@ int op_upload_slice_lists(storm_hip_op *op) {
   STORM_TRY(upload(&op->d_boundary, op->h_boundary, &bytes));
   op->n_interior = (int64_t)op->h_interior.size();
   op->n_boundary = (int64_t)op->h_boundary.size();
+  // a mixed operator whose interior groups are whole planes of its lattice (a slab of a box but for its outer planes)
+  // runs them on the tiled kernel: planes [int_plane0, int_plane1)
+  op->int_plane0 = op->int_plane1 = 0;
+  if (op->pair == 2 && op->canon_k == 6 && op->n_interior > 0) {
+    const int64_t b = op->canon_off[5], g0 = op->h_interior.front(), g1 = (int64_t)op->h_interior.back() + 1;
+    const int64_t r0 = g0 * 2 * kWave, r1 = std::min<int64_t>(op->n_rows, g1 * 2 * kWave);
+    if (b > 0 && g1 - g0 == op->n_interior && r0 % b == 0 && (r1 % b == 0 || r1 == op->n_rows))
+      op->int_plane0 = r0 / b, op->int_plane1 = (r1 + b - 1) / b;
+  }
   op->device_bytes += bytes;
   return STORM_HIP_OK;
 }
@@ -1973,7 +2057,7 @@ int storm_hip_op_get_stats(const storm_hip_op *op, storm_hip_op_stats *s) {
   s->paired_rows = op->pair;
   CanonTileArgs T;
   int nbt = 0;
-  s->tiled_planes = canon_tile_geometry(op, &T, &nbt) && op->halo.n_nbrs == 0 && op->d_bnd_pack == nullptr ? canon_tile_planes(op) : 0;
+  s->tiled_planes = canon_tile_geometry(op, &T, &nbt, op->d_bnd_pack != nullptr) ? canon_tile_planes(op) : 0;  // (mixed operator: its interior planes)
   s->spmv_blocks = spmv_grid_blocks(op);
   return STORM_HIP_OK;
 }

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Cost of the multi-rank code path with the network taken out: one rank, a communicator of size 1 (RCCL, then the
-peer-window transport), a z-periodic
-256^3 box whose two halo planes are exchanged with the rank itself (pack kernel, grouped ncclSend/ncclRecv on the comm
-stream, interior / boundary split of the SpMV, reduction -> all-reduce -> step kernels) against the plain single-GPU
-path on the same box.  What remains at N > 1 beyond this is the latency of the real exchanges."""
+peer-window transport in its fused form -- "ipc": the interior launch sends, the boundary launch reads the window, the
+reductions' finishing block all-reduces -- and with stand-alone send / receive-copy kernels, "ipc0"), a z-periodic
+256^3 box whose two halo planes are exchanged with the rank itself, against the plain single-GPU path on the same
+box.  What remains at N > 1 beyond this is the latency of the real exchanges."""
 import json
 import os
 import sys
@@ -50,22 +50,24 @@ ctx.close()
 loc, send_idx = _periodic_z_local_graph(n, n, n)
 # the halo operator: MIXED records by default (format 4 where rows read no halo column, format 3 in the outer
 # planes) -- compared with the plain format-4 operator; spmv_mixed = 0 (format 3 throughout) with plain format 3
-for transport in ((only,) if only else ("rccl", "ipc", "ipc1")):
+for transport in ((only,) if only else ("rccl", "ipc", "ipc0")):
     for mixed in ((1,) if only else (1, 0)):
         ctx = api.Context(0)
         ctx.set_option("spmv_mixed", mixed)
-        if transport == "ipc1":  # peer windows, halo kernels on the compute stream (no cross-stream events)
-            ctx.set_option("ipc_streams", 1)
+        if transport == "ipc0":  # peer windows, stand-alone send / receive-copy kernels instead of the fused form
+            ctx.set_option("ipc_fused", 0)
         if transport == "rccl":
             ctx.comm_init(api.Context.comm_unique_id(), 1, 0)
         else:  # peer windows: the single rank maps its own window
-            ctx.comm_init_ipc(ctx.comm_ipc_export(1, 0))
+            # (both planes go to the one "neighbour" here: twice the default segment)
+            ctx.comm_init_ipc(ctx.comm_ipc_export(1, 0, 16 << 20))
         m1 = api.StencilMatrix.from_face_graph(ctx, loc)
         m1.set_halo([0], [0, loc.n_halo], send_idx, [0, loc.n_halo])
         st = m1.stats()
         key = f"{transport}_{'mixed' if mixed else 'fmt3'}"
         out[f"{key}_it_per_s"] = rate(ctx, m1, loc)
         out["interior_groups"], out["groups"], out[f"{key}_paired_rows"] = st["n_interior_slices"], st["n_slices"], st["paired_rows"]
+        out[f"{key}_tiled_planes"] = st["tiled_planes"]
         if not only:
             base = out["plain_fmt4_it_per_s" if mixed else "plain_fmt3_it_per_s"]
             out[f"{key}_overhead_us_per_iteration"] = (1.0 / out[f"{key}_it_per_s"] - 1.0 / base) * 1e6
