@@ -195,6 +195,16 @@ int storm_hip_op_create_from_faces(storm_hip_ctx *ctx, int64_t n_owned, int64_t 
                                    const double *coef, int64_t n_bfaces, const int64_t *b_cell,
                                    const double *b_coef, const double *volume, storm_hip_op **out);
 
+/* The same operator straight from the mesh arrays the reference's face loop reads (Playground.cpp:119-129): the
+ * library forms A_f / |x_outer - x_inner| itself -- squares summed left to right like `length`
+ * (MatrixAlgorithms.hpp:262-270, 303-305), threaded -- instead of taking it as `coef`.
+ *   area[F], center[(n_owned + n_halo) * dim] (row-major), b_area[B], b_center[B * dim]; dim in 1..3.
+ * Bit-identical to storm_hip_op_create_from_faces with coefficients computed that way on the host. */
+int storm_hip_op_create_from_mesh(storm_hip_ctx *ctx, int64_t n_owned, int64_t n_halo, int32_t dim, int64_t n_faces,
+                                  const int64_t *inner, const int64_t *outer, const double *area, const double *center,
+                                  int64_t n_bfaces, const int64_t *b_cell, const double *b_area, const double *b_center,
+                                  const double *volume, storm_hip_op **out);
+
 /* General (non-symmetric) face-graph operator: row inner[f] gets weight
  * w_inner[f] on (x_outer - x_inner), row outer[f] gets w_outer[f] on
  * (x_inner - x_outer); diag_extra[n_owned] may be NULL (zeros).  This is the

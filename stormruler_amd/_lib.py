@@ -100,6 +100,8 @@ SIGNATURES = {
     "storm_hip_multi_axpy": (C.c_int, [vp, f64p, C.POINTER(vp), C.c_int]),
     "storm_hip_op_create_from_faces": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int64, i64p, i64p, f64p,
                                                  C.c_int64, i64p, f64p, f64p, C.POINTER(vp)]),
+    "storm_hip_op_create_from_mesh": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int32, C.c_int64, i64p, i64p, f64p, f64p,
+                                                C.c_int64, i64p, f64p, f64p, f64p, C.POINTER(vp)]),
     "storm_hip_op_create_from_face_weights": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int64, i64p, i64p,
                                                         f64p, f64p, f64p, C.POINTER(vp)]),
     "storm_hip_op_create_csr": (C.c_int, [vp, C.c_int64, C.c_int64, i64p, i64p, f64p, C.POINTER(vp)]),

@@ -461,7 +461,29 @@ class StencilMatrix:
 
     @classmethod
     def from_face_graph(cls, ctx: Context, g: FaceGraph) -> "StencilMatrix":
-        """Diffusion stencil of ``stormDivGrad`` (Playground.cpp:115-131) from mesh quantities."""
+        """Diffusion stencil of ``stormDivGrad`` (Playground.cpp:115-131) from mesh quantities: the library forms the
+        face transmissibilities A_f / d_f itself (``storm_hip_op_create_from_mesh``; the same bits as
+        ``mesh.face_coefficients`` + ``storm_hip_op_create_from_faces``, see ``from_face_coefficients``)."""
+        h = C.c_void_p()
+        i64, f64 = _lib.i64p, _lib.f64p
+        inner = np.ascontiguousarray(g.inner, np.int64)
+        outer = np.ascontiguousarray(g.outer, np.int64)
+        b_cell = np.ascontiguousarray(g.b_cell, np.int64)
+        vol = np.ascontiguousarray(g.volume, np.float64)
+        area = np.ascontiguousarray(g.area, np.float64)
+        center = np.ascontiguousarray(g.center, np.float64)
+        b_area = np.ascontiguousarray(g.b_area, np.float64)
+        b_center = np.ascontiguousarray(g.b_center, np.float64)
+        check(lib.storm_hip_op_create_from_mesh(
+            ctx._h, g.n_cells, g.n_halo, g.dim, g.n_faces, inner.ctypes.data_as(i64), outer.ctypes.data_as(i64),
+            area.ctypes.data_as(f64), center.ctypes.data_as(f64), g.n_bfaces, b_cell.ctypes.data_as(i64),
+            b_area.ctypes.data_as(f64), b_center.ctypes.data_as(f64), vol.ctypes.data_as(f64), C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_face_coefficients(cls, ctx: Context, g: FaceGraph) -> "StencilMatrix":
+        """The same operator with A_f / d_f computed on the host (``mesh.face_coefficients``) and handed to
+        ``storm_hip_op_create_from_faces``."""
         coef, b_coef = face_coefficients(g)
         h = C.c_void_p()
         i64, f64 = _lib.i64p, _lib.f64p

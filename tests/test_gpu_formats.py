@@ -413,3 +413,64 @@ def test_random_structured_patterns_fuzz(env, seed):
         assert np.array_equal(ys[fmt], ys[(0, 1)]), (fmt, kinds)
     ref = a @ x
     assert np.abs(ys[(0, 1)] - ref).max() <= 1e-13 * np.abs(ref).max()
+
+
+def test_from_mesh_gives_the_bits_of_host_side_coefficients(env):
+    """`storm_hip_op_create_from_mesh` (the library forms A_f / d_f itself, threaded) against
+    `mesh.face_coefficients` + `storm_hip_op_create_from_faces`: the same records, bit-identical y."""
+    import os
+
+    api, mesh, oracle, ctx = env
+    from stormruler_amd import io_triangle
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tri = io_triangle.read_triangle(os.path.join(root, "tests", "golden", "mesh", "square_nb.1."))
+    rng = np.random.default_rng(5)
+    graded = mesh.structured_box(14, 9, 11)
+    graded.volume = graded.volume * (0.5 + rng.random(graded.n_total))
+    for g in (tri, graded, mesh.structured_box(33, 20, 17), mesh.structured_box(16)):
+        a = api.StencilMatrix.from_face_graph(ctx, g)
+        b = api.StencilMatrix.from_face_coefficients(ctx, g)
+        sa, sb = a.stats(), b.stats()
+        assert sa == sb
+        x = np.cos(0.11 * np.arange(g.n_cells))
+        assert np.array_equal(_apply(api, ctx, a, x), _apply(api, ctx, b, x))
+        a.close(), b.close()
+
+
+def test_the_threaded_operator_build_does_not_depend_on_the_thread_count(tmp_path):
+    """Record packing runs on up to 16 host threads (rows from faces by chunks of faces, dictionaries merged in chunk
+    order, records by row ranges): 1, 3 and 7 threads -- forced onto small inputs -- must give the same operator."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "build_once.py"
+    script.write_text(
+        "import sys, json, hashlib, os\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import numpy as np\n"
+        "from stormruler_amd import api, mesh, io_triangle\n"
+        "ctx = api.Context(0)\n"
+        "out = []\n"
+        f"tri = io_triangle.read_triangle(os.path.join({root!r}, 'tests', 'golden', 'mesh', 'square_nb.1.'))\n"
+        "box = mesh.structured_box(33, 20, 17)\n"
+        "scr = mesh.permute_cells(box, mesh.random_permutation(box.n_cells))\n"
+        "lat = mesh.structured_box(64, 16, 12)\n"
+        "for g in (tri, box, scr, lat):\n"
+        "    m = api.StencilMatrix.from_face_graph(ctx, g)\n"
+        "    x = api.DeviceVector.from_numpy(ctx, np.cos(0.11 * np.arange(g.n_cells)))\n"
+        "    y = api.DeviceVector(ctx, g.n_cells)\n"
+        "    m.apply(-0.7, 0.3, x, y)\n"
+        "    st = m.stats()\n"
+        "    out.append([st, hashlib.sha256(y.to_numpy().tobytes()).hexdigest()])\n"
+        "print(json.dumps(out))\n")
+    results = []
+    for threads in ("1", "3", "7"):
+        env = dict(os.environ, STORM_HIP_BUILD_THREADS=threads, STORM_HIP_BUILD_MIN_CHUNK="5")
+        p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        results.append(json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("[")][-1]))
+    assert results[0] == results[1] == results[2]
