@@ -323,6 +323,10 @@ typedef struct storm_hip_solver_result {
   int64_t iterations;
   double absolute_error, relative_error, initial_error;
   int32_t converged;
+  int32_t path_fallback;  /* 0: the path the library chose ran; 1: a cooperative (one-kernel) path could not be launched and
+                             the solve ran on the kernel-per-statement path instead; 2: a cooperative kernel's bounded wait
+                             gave up (the device shared with another cooperative kernel) -- x was restored and the solve
+                             re-run on the kernel-per-statement path.  Same results either way (to rounding). */
   int64_t num_applies;
 } storm_hip_solver_result;
 

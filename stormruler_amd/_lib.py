@@ -38,7 +38,8 @@ class SolverParams(C.Structure):
 
 class SolverResult(C.Structure):
     _fields_ = [("iterations", C.c_int64), ("absolute_error", C.c_double), ("relative_error", C.c_double),
-                ("initial_error", C.c_double), ("converged", C.c_int32), ("num_applies", C.c_int64)]
+                ("initial_error", C.c_double), ("converged", C.c_int32), ("path_fallback", C.c_int32),
+                ("num_applies", C.c_int64)]
 
 
 class OpStats(C.Structure):

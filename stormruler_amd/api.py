@@ -785,6 +785,9 @@ class IterativeSolver(Solver):
             self.absolute_error, self.relative_error = r.absolute_error, r.relative_error
             self.initial_error, self.num_applies, self.num_pre_applies = r.initial_error, r.num_applies, n_pre.value
             self.history = None if hist is None else hist[: r.iterations + 1]
+            # 0, or why the library left the path it had chosen (storm_hip_solver_result::path_fallback): 1 = a
+            # cooperative kernel could not be launched, 2 = one gave up waiting and the solve was re-run without
+            self.path_fallback = r.path_fallback
             self._log()
             return bool(r.converged)
         # the host loop: user-defined solvers, and the shipped ones stepwise when device_loop is off

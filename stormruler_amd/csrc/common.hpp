@@ -126,6 +126,11 @@ struct storm_hip_ctx {
   int64_t opt_fuse_mgs = 1;  // GMRES/MGS on one rank, <= 2048 blocks: each step folds the previous step's partials itself (no final-reduction launch in between)
   int64_t opt_coop_mgs_min_rows = 0;  // ... from this many rows on (0: always; with two steps per synchronisation point the chain is no slower than a launch per step even on small meshes)
   int64_t opt_coop_mgs = 1;             // GMRES: the Gram-Schmidt chain of an Arnoldi step as one cooperative kernel (latency.hip)
+  int64_t opt_latency_publish = 1;      // ... its rows published with awaited atomic exchanges (0: write-through stores, ordered by their acknowledgement)
+  int64_t opt_coop_force_fail = 0;      // test hook: 1 = cooperative launches "fail", 2 = cooperative kernels "gave up" (once per solve)
+  int coop_ran = 0;                     // a cooperative kernel of the current solve has run
+  int coop_disabled = 0;                // set while a solve is re-run without cooperative kernels
+  int coop_fallback = 0;                // what happened in the current solve (storm_hip_solver_result::path_fallback)
   int64_t opt_latency_path = 1;         // small operators: CG as one cooperative persistent kernel (latency.hip)
   int opt_lin_fuse = 1;                 // engine: two consecutive vector statements go out as one pass
   int opt_ticket_reduce = 1;            // fused CG / BiCGStab: reductions finish inside the kernels that produce their partials
@@ -291,7 +296,10 @@ int op_upload_slice_lists(storm_hip_op *op);
 int op_make_latency_copy(storm_hip_op *op, int64_t n, int64_t n_halo, const std::vector<int64_t> &row_ptr,
                          const std::vector<int> &col, const std::vector<double> &val, const std::vector<double> &ext);
 bool cg_latency_eligible(const storm_hip_op *op);
+constexpr int kStatusCoopGaveUp = 1000;  // internal status of lat_check_gave_up: the caller re-runs the solve (below)
 int lat_check_gave_up(storm_hip_ctx *c);
+// Run a solve that may use cooperative kernels; when one of them gave up, restore x and run it again without them.
+int coop_solve_with_fallback(storm_hip_ctx *c, double *x, int64_t n_total, int (*run)(void *), void *arg, int *fallback_out);
 // What the cooperative chain needs to finish an Arnoldi step itself (fused GMRES loop): the state, the Hessenberg and
 // rotation arrays, and where sqrt(<w,w>) goes.
 struct MgsGivens {
@@ -300,10 +308,11 @@ struct MgsGivens {
 };
 int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w, const double *const *q, int k, int m,
                          double *H, double *norm2_out, bool normalise, bool *taken, const MgsGivens *givens = nullptr);
+// *taken = false: no cooperative kernel ran (none fits, or the launch was refused) -- take the throughput path
 int cg_latency_solve(const storm_hip_op *op, double alpha, double beta, const double *b, double *x, double *p,
-                     double *r, SolverState *d_state);
+                     double *r, SolverState *d_state, bool *taken);
 int bicgstab_latency_solve(const storm_hip_op *op, double alpha, double beta, const double *b, double *x,
-                           double *const work[4], SolverState *d_state);
+                           double *const work[4], SolverState *d_state, bool *taken);
 
 // comm.hip
 int comm_allreduce_sum(storm_hip_ctx *c, double *d_buf, int count);  // in place, on ctx->stream

@@ -1840,11 +1840,48 @@ int storm_hip_krylov_set_real(storm_hip_krylov *k, const char *key, double value
   return STORM_HIP_OK;
 }
 
+static int krylov_solve_engine(storm_hip_krylov *k, const storm_hip_vec *b, storm_hip_vec *x,
+                               const storm_hip_solver_params *params, storm_hip_solver_result *result, double *history,
+                               int64_t *pre_applies);
+namespace {
+struct EngineSolveArgs {
+  storm_hip_krylov *k;
+  const storm_hip_vec *b;
+  storm_hip_vec *x;
+  const storm_hip_solver_params *params;
+  storm_hip_solver_result *result;
+  double *history;
+  int64_t *pre_applies;
+};
+int run_engine_body(void *p) {
+  const EngineSolveArgs &a = *static_cast<const EngineSolveArgs *>(p);
+  return krylov_solve_engine(a.k, a.b, a.x, a.params, a.result, a.history, a.pre_applies);
+}
+}  // namespace
+
 int storm_hip_krylov_solve(storm_hip_krylov *k, const storm_hip_vec *b, storm_hip_vec *x,
                            const storm_hip_solver_params *params, storm_hip_solver_result *result, double *history,
                            int64_t *pre_applies) {
   STORM_REQUIRE(k && result, "krylov_solve: null argument");
   STORM_TRY(check_ready(k, b, x, params));
+  storm_hip_ctx *c = k->c;
+  HIP_TRY(hipSetDevice(c->device));
+  // (the engine's GMRES runs its Gram-Schmidt chains as cooperative kernels where they fit: should one give up, x is
+  //  restored and the solve re-run without them -- latency.hip, coop_solve_with_fallback)
+  EngineSolveArgs a{k, b, x, params, result, history, pre_applies};
+  int fb = 0;
+  const bool fused_path = k->op != nullptr && !k->has_pre() && c->opt_generic_solvers == 0 &&
+                          (k->method == STORM_HIP_CG || k->method == STORM_HIP_BICGSTAB ||
+                           (k->method == STORM_HIP_GMRES && params->num_inner_iterations < kMaxMulti));
+  if (fused_path) return krylov_solve_engine(k, b, x, params, result, history, pre_applies);  // (has its own fallback)
+  const int st = coop_solve_with_fallback(c, x->d, x->n_owned + x->n_halo, run_engine_body, &a, &fb);
+  if (st == STORM_HIP_OK) result->path_fallback = fb;
+  return st;
+}
+
+static int krylov_solve_engine(storm_hip_krylov *k, const storm_hip_vec *b, storm_hip_vec *x,
+                               const storm_hip_solver_params *params, storm_hip_solver_result *result, double *history,
+                               int64_t *pre_applies) {
   storm_hip_ctx *c = k->c;
   // A stencil operator without preconditioner: CG / BiCGStab / GMRES have fused kernels (solvers.hip).
   if (k->op != nullptr && !k->has_pre() && c->opt_generic_solvers == 0) {

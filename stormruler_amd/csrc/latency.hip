@@ -39,6 +39,8 @@ constexpr int kLatSlices = 8;  // slices a wavefront may own (registers: 4 doubl
 constexpr int kLatBlock = 1024;  // one block per CU: a synchronisation point costs per participating BLOCK
 constexpr int kLatWaves = kLatBlock / kWave;
 
+static bool coop_launch(storm_hip_ctx *c, const void *fn, unsigned blocks, void **args);  // (below: a refused launch is a fallback, not an error)
+
 struct LatArgs {
   const char *pack;          // compact records
   const int64_t *rec_off;    // [n_slices + 1] byte offsets
@@ -50,6 +52,7 @@ struct LatArgs {
   double *v0, *v1;           // BiCGStab: published rows of v = A p of even / odd iterations
   char *slots;               // all-reduce slots, kLatSlotStride bytes per block, zeroed before the launch
   SolverState *st;
+  int publish_xchg;          // rows are published with atomic exchanges whose return is awaited (option latency_publish)
 };
 
 // Data that crosses wavefronts inside the kernel -- the published rows of r and p, the all-reduce slots -- is
@@ -62,6 +65,18 @@ __device__ __forceinline__ void co_store(double *p, double v) {
 }
 __device__ __forceinline__ double co_load(const double *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Publish one row for the other blocks' gathers.  xchg (the default): an atomic EXCHANGE whose returned value the wave
+// consumes (`seen`, at the all-reduce that follows) -- a returning read-modify-write has been performed at the point
+// of coherence, so the row is visible to every XCD before this block's all-reduce words go out, whatever else loads
+// the memory system (csrc/ticket_device.hpp: an ACKNOWLEDGED write-through store was seen not yet visible to another
+// XCD under a 256^3 streaming load).  xchg == 0: the write-through store, ordered by its acknowledgement only.
+__device__ __forceinline__ void co_publish(double *p, double v, int xchg, unsigned long long &seen) {
+  if (xchg)
+    seen ^= __hip_atomic_exchange(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else
+    co_store(p, v);
 }
 
 // All-reduce across a co-resident (cooperative) grid, which is also its barrier.  Slot (b, parity) of block b: 16
@@ -99,11 +114,12 @@ __device__ __forceinline__ double lat_wave_sum(double v) {
 // `publishes`: the block's waves have issued coherent stores (rows of r, p) that other blocks read once they are past
 // this point -- every wave then drains its own store counter before the block's words go out.
 __device__ __forceinline__ double lat_allreduce(double mine, char *slots, unsigned long long seq, double *lds,
-                                                bool publishes = true) {
+                                                bool publishes = true, unsigned long long seen = 0ull) {
   const unsigned tag = (unsigned)seq;
   double v = lat_wave_sum(mine);
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-  if (publishes) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's rows are acknowledged
+  asm volatile("" : : "v"(seen) : "memory");  // the exchanges that published this wave's rows have returned
+  if (publishes) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // ... (store variant: acknowledged)
   __syncthreads();  // (lds may still be read by the previous call)
   if (lane == 0) lds[wave] = v;
   __syncthreads();
@@ -153,10 +169,11 @@ __device__ __forceinline__ bool co_load_slot2(const char *slot, unsigned tag, do
   return w0.y == tag && w0.w == tag && w1.y == tag && w1.w == tag;
 }
 __device__ __forceinline__ void lat_allreduce2(double &s0, double &s1, char *slots, unsigned long long seq, double *lds,
-                                               bool publishes = true) {
+                                               bool publishes = true, unsigned long long seen = 0ull) {
   const unsigned tag = (unsigned)seq;
   double v0 = lat_wave_sum(s0), v1 = lat_wave_sum(s1);
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  asm volatile("" : : "v"(seen) : "memory");
   if (publishes) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
   if (lane == 0) lds[wave] = v0, lds[kLatWaves + wave] = v1;
@@ -328,7 +345,7 @@ __global__ __launch_bounds__(kLatBlock) void cg_latency_kernel(LatArgs a) {
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t wave_id = (int64_t)blockIdx.x * kLatWaves + (threadIdx.x >> 6);
   const int64_t n_waves = (int64_t)gridDim.x * kLatWaves;
-  unsigned long long seq = 0;
+  unsigned long long seq = 0, seen = 0;  // seen: what the publishing exchanges returned (consumed at the all-reduces)
   double x[S], r[S], p[S], z[S];
   LatRecords<S, W> rec;
   lat_load_records<S, W>(a, wave_id, n_waves, lane, rec);
@@ -350,11 +367,11 @@ __global__ __launch_bounds__(kLatBlock) void cg_latency_kernel(LatArgs a) {
       const double ax = apply_row(q, s, LatPlain{a.x}, x[q]);  // x is not written before the kernel's end
       r[q] = valid ? a.b[row] - ax : 0.0;
       p[q] = r[q];
-      if (valid) co_store(a.r + row, r[q]);
+      if (valid) co_publish(a.r + row, r[q], a.publish_xchg, seen);
       acc += r[q] * r[q];
     }
   }
-  double gamma = lat_allreduce(acc, a.slots, ++seq, lds);
+  double gamma = lat_allreduce(acc, a.slots, ++seq, lds, true, seen);
   const double initial_error = sqrt(gamma);
   const double abs_tol = st->abs_tol, rel_tol = st->rel_tol;
   const long long num_iterations = st->num_iterations;
@@ -388,11 +405,12 @@ __global__ __launch_bounds__(kLatBlock) void cg_latency_kernel(LatArgs a) {
       x[q] += alpha * p[q];
       r[q] -= alpha * z[q];
       acc += r[q] * r[q];
-      if (s < a.n_slices && row < a.n_rows) co_store(a.r + row, r[q]), co_store(a.p + row, p[q]);
+      if (s < a.n_slices && row < a.n_rows)
+        co_publish(a.r + row, r[q], a.publish_xchg, seen), co_publish(a.p + row, p[q], a.publish_xchg, seen);
     }
-    // the new r and the current p are out (acknowledged before a block's tag is stored) with the <r, r> partials
+    // the new r and the current p are out (at the point of coherence before a block's tag is stored) with the <r, r> partials
     const double gamma_bar = gamma;
-    gamma = lat_allreduce(acc, a.slots, ++seq, lds);
+    gamma = lat_allreduce(acc, a.slots, ++seq, lds, true, seen);
     beta = safe_divide(gamma, gamma_bar);
     abs_err = sqrt(gamma);
     rel_err = abs_err / initial_error;
@@ -454,7 +472,7 @@ __global__ __launch_bounds__(kLatBlock) void bicgstab_latency_kernel(LatArgs a) 
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t wave_id = (int64_t)blockIdx.x * kLatWaves + (threadIdx.x >> 6);
   const int64_t n_waves = (int64_t)gridDim.x * kLatWaves;
-  unsigned long long seq = 0;
+  unsigned long long seq = 0, seen = 0;  // seen: what the publishing exchanges returned (consumed at the all-reduces)
   double x[S], r[S], p[S], v[S], rt[S];
   LatRecords<S, W> rec;
   lat_load_records<S, W>(a, wave_id, n_waves, lane, rec);
@@ -476,11 +494,11 @@ __global__ __launch_bounds__(kLatBlock) void bicgstab_latency_kernel(LatArgs a) 
       const double ax = apply_row(q, s, LatPlain{a.x}, x[q]);
       r[q] = valid ? a.b[row] - ax : 0.0;
       rt[q] = r[q];
-      if (valid) co_store(a.r + row, r[q]);
+      if (valid) co_publish(a.r + row, r[q], a.publish_xchg, seen);
       acc += rt[q] * r[q];
     }
   }
-  double rho = lat_allreduce(acc, a.slots, ++seq, lds);
+  double rho = lat_allreduce(acc, a.slots, ++seq, lds, true, seen);
   const double initial_error = sqrt(rho);
   const double abs_tol = st->abs_tol, rel_tol = st->rel_tol;
   const long long num_iterations = st->num_iterations;
@@ -502,11 +520,11 @@ __global__ __launch_bounds__(kLatBlock) void bicgstab_latency_kernel(LatArgs a) 
       if (s < a.n_slices) {
         v[q] = apply_row(q, s, dir, p[q]);
         v[q] = (row < a.n_rows) ? v[q] : 0.0;
-        if (row < a.n_rows) co_store(v_cur + row, v[q]);
+        if (row < a.n_rows) co_publish(v_cur + row, v[q], a.publish_xchg, seen);
         acc += rt[q] * v[q];
       }
     }
-    alpha = safe_divide(rho, lat_allreduce(acc, a.slots, ++seq, lds));
+    alpha = safe_divide(rho, lat_allreduce(acc, a.slots, ++seq, lds, true, seen));
     // s = r - alpha v (kept in r); t = A s; omega = <t, s> / <t, t>                   :140-141, :158-160
     double t[S];
     double acc_ts = 0.0, acc_tt = 0.0;
@@ -535,9 +553,10 @@ __global__ __launch_bounds__(kLatBlock) void bicgstab_latency_kernel(LatArgs a) 
       r[q] -= omega * t[q];
       acc_rr += r[q] * r[q];
       acc_rho += rt[q] * r[q];
-      if (s < a.n_slices && row < a.n_rows) co_store(a.r + row, r[q]), co_store(a.p + row, p[q]);
+      if (s < a.n_slices && row < a.n_rows)
+        co_publish(a.r + row, r[q], a.publish_xchg, seen), co_publish(a.p + row, p[q], a.publish_xchg, seen);
     }
-    lat_allreduce2(acc_rr, acc_rho, a.slots, ++seq, lds);
+    lat_allreduce2(acc_rr, acc_rho, a.slots, ++seq, lds, true, seen);
     const double rho_bar = rho;
     rho = acc_rho;
     beta = safe_divide(alpha * rho, omega * rho_bar);  // :116-118, for the next iteration
@@ -698,8 +717,8 @@ int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w
   // (a step of the chain costs half an all-reduce, ~2.5 us, whatever the size; the kernel-per-step path costs a launch,
   //  ~3.5 us, or 32 B/row of HBM traffic, whichever is more -- measured, us per inner iteration, per-step vs chained:
   //  step.1 83..106 vs 74.5, 32^3 84..109 vs 72, 64^3 91..106 vs 93, 128^3 248 vs 147)
-  if (c->opt_coop_mgs == 0 || c->comm != nullptr || n < c->opt_coop_mgs_min_rows || k + 1 > kMgsMaxVectors ||
-      c->opt_profile_spmv != 0)
+  if (c->opt_coop_mgs == 0 || c->coop_disabled != 0 || c->comm != nullptr || n < c->opt_coop_mgs_min_rows ||
+      k + 1 > kMgsMaxVectors || c->opt_profile_spmv != 0)
     return STORM_HIP_OK;
   const int64_t n_slices = (n + kWave - 1) / kWave;
   const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(std::min(c->num_cus, 256), (n_slices + kLatWaves - 1) / kLatWaves));
@@ -728,8 +747,8 @@ int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w
   a.givens = (givens != nullptr && normalise && c->opt_coop_mgs != 2) ? *givens  // (coop_mgs = 2: A/B, rotations by the caller)
                                                                         : MgsGivens{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   void *args[] = {&a};
-  HIP_TRY(hipLaunchCooperativeKernel(fn, dim3((unsigned)blocks), dim3(kLatBlock), args, 0, c->stream));
-  *taken = true;
+  *taken = coop_launch(c, fn, (unsigned)blocks, args);
+  if (!*taken) c->lat_seq -= (unsigned long long)k + 2;
   return STORM_HIP_OK;
 }
 
@@ -778,23 +797,67 @@ int lat_check_gave_up(storm_hip_ctx *c) {
   int flag = 0;
   HIP_TRY(hipMemcpyAsync(&flag, c->d_lat_slots + (size_t)2 * 256 * kLatSlotStride, sizeof flag, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->opt_coop_force_fail == 2 && c->coop_ran && !c->coop_disabled) flag = 1;  // (test hook)
+  c->coop_ran = 0;
   if (flag != 0) {
     (void)hipMemsetAsync(c->d_lat_slots + (size_t)2 * 256 * kLatSlotStride, 0, sizeof flag, c->stream);
-    STORM_FAIL(STORM_HIP_E_HIP, "cooperative kernel: a block waited 10 s for the others (is the device shared with another "
-                                "process's cooperative kernel?)");
+    set_error("cooperative kernel: a block waited 10 s for the others (is the device shared with another process's "
+              "cooperative kernel?)");
+    return kStatusCoopGaveUp;  // coop_solve_with_fallback re-runs the solve on the kernel-per-statement path
   }
   return STORM_HIP_OK;
 }
 
+// A cooperative launch that may be refused (too many blocks for what is resident, a device that does not take them):
+// false = not launched, nothing ran, the error is cleared.
+static bool coop_launch(storm_hip_ctx *c, const void *fn, unsigned blocks, void **args) {
+  if (c->opt_coop_force_fail == 1) {
+    c->coop_fallback = 1;
+    return false;
+  }
+  if (hipLaunchCooperativeKernel(fn, dim3(blocks), dim3(kLatBlock), args, 0, c->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    c->coop_fallback = 1;
+    return false;
+  }
+  c->coop_ran = 1;
+  return true;
+}
+
+int coop_solve_with_fallback(storm_hip_ctx *c, double *x, int64_t n_total, int (*run)(void *), void *arg, int *fallback_out) {
+  c->coop_fallback = 0, c->coop_ran = 0;
+  double *x0 = nullptr;
+  const bool keep = c->comm == nullptr && c->coop_disabled == 0 && (c->opt_latency_path != 0 || c->opt_coop_mgs != 0) &&
+                    n_total <= ((int64_t)1 << 23);  // (no cooperative kernel takes more rows than that)
+  if (keep) {
+    HIP_TRY(hipMalloc((void **)&x0, sizeof(double) * (size_t)std::max<int64_t>(1, n_total)));
+    HIP_TRY(hipMemcpyAsync(x0, x, sizeof(double) * (size_t)n_total, hipMemcpyDeviceToDevice, c->stream));
+  }
+  int st = run(arg);
+  if (st == kStatusCoopGaveUp && keep) {
+    (void)hipMemcpyAsync(x, x0, sizeof(double) * (size_t)n_total, hipMemcpyDeviceToDevice, c->stream);
+    c->coop_disabled = 1;
+    st = run(arg);
+    c->coop_disabled = 0;
+    c->coop_fallback = 2;
+  }
+  if (st == kStatusCoopGaveUp) st = STORM_HIP_E_HIP;  // (the message of lat_check_gave_up stands)
+  if (x0) (void)hipStreamSynchronize(c->stream), (void)hipFree(x0);
+  if (fallback_out) *fallback_out = c->coop_fallback;
+  return st;
+}
+
 bool cg_latency_eligible(const storm_hip_op *op) {
   const storm_hip_ctx *c = op->ctx;
-  return c->opt_latency_path != 0 && c->comm == nullptr && op->d_lat_pack != nullptr && c->opt_profile_spmv == 0;
+  return c->opt_latency_path != 0 && c->coop_disabled == 0 && c->comm == nullptr && op->d_lat_pack != nullptr &&
+         c->opt_profile_spmv == 0;
 }
 
 // The whole solve; fills the SolverState on the device (the caller reads it back).  `bicgstab`: which of the two
 // kernels; work vectors p, r (CG) and p, r, v0, v1 (BiCGStab) arrive zero-filled.
-static int latency_solve(bool bicgstab, const storm_hip_op *op, LatArgs a) {
+static int latency_solve(bool bicgstab, const storm_hip_op *op, LatArgs a, bool *taken) {
   storm_hip_ctx *c = op->ctx;
+  *taken = false;
   const int64_t n_slices = (op->n_rows + kWave - 1) / kWave;
   // A co-resident grid (cooperative launch): one 1024-thread block per CU at most (<= 256 blocks: one polling
   // thread per block), at least one slice per wavefront; the smallest register variant that covers all slices.
@@ -826,27 +889,30 @@ static int latency_solve(bool bicgstab, const storm_hip_op *op, LatArgs a) {
     const int64_t waves = blocks * kLatWaves;
     if ((n_slices + waves - 1) / waves <= capacity[v]) fn = variants[v];
   }
-  STORM_REQUIRE(fn != nullptr, "latency path: %lld rows do not fit %d slices per wavefront", (long long)op->n_rows,
-                kLatSlices);
+  if (fn == nullptr) {  // no register variant holds this many rows per wavefront (latency_rows raised, few CUs): the
+    c->coop_fallback = 1;  // throughput path takes the solve
+    return STORM_HIP_OK;
+  }
   HIP_TRY(hipMemsetAsync(c->d_lat_slots, 0, (size_t)2 * 256 * kLatSlotStride + 256, c->stream));  // tags restart at 1; flag down
   a.pack = op->d_lat_pack, a.rec_off = op->d_lat_off, a.n_rows = op->n_rows, a.n_slices = n_slices, a.slots = c->d_lat_slots;
+  a.publish_xchg = (int)(c->opt_latency_publish != 0);
   void *args[] = {&a};
-  HIP_TRY(hipLaunchCooperativeKernel(fn, dim3((unsigned)blocks), dim3(kLatBlock), args, 0, c->stream));
+  *taken = coop_launch(c, fn, (unsigned)blocks, args);
   return STORM_HIP_OK;
 }
 
 int cg_latency_solve(const storm_hip_op *op, double alpha, double beta, const double *b, double *x, double *p,
-                     double *r, SolverState *d_state) {
+                     double *r, SolverState *d_state, bool *taken) {
   LatArgs a{};
   a.alpha = alpha, a.beta = beta, a.b = b, a.x = x, a.p = p, a.r = r, a.st = d_state;
-  return latency_solve(false, op, a);
+  return latency_solve(false, op, a, taken);
 }
 
 int bicgstab_latency_solve(const storm_hip_op *op, double alpha, double beta, const double *b, double *x,
-                           double *const work[4], SolverState *d_state) {
+                           double *const work[4], SolverState *d_state, bool *taken) {
   LatArgs a{};
   a.alpha = alpha, a.beta = beta, a.b = b, a.x = x, a.p = work[0], a.r = work[1], a.v0 = work[2], a.v1 = work[3], a.st = d_state;
-  return latency_solve(true, op, a);
+  return latency_solve(true, op, a, taken);
 }
 
 }  // namespace storm

@@ -702,7 +702,14 @@ static int collect(Driver &d, storm_hip_solver_result *res, double *history, int
   storm_hip_ctx *c = d.c;
   HIP_TRY(hipMemcpyAsync(&c->h_state[0], c->d_state, sizeof(SolverState), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  STORM_TRY(lat_check_gave_up(c));  // (a cooperative kernel of this solve -- CG's, a Gram-Schmidt chain -- timed out)
+  {  // (a cooperative kernel of this solve -- CG's, a Gram-Schmidt chain -- timed out: the caller re-runs the solve)
+    const int st_coop = lat_check_gave_up(c);
+    if (st_coop != STORM_HIP_OK) {
+      if (d.d_history) (void)hipFree(d.d_history), d.d_history = nullptr;
+      return st_coop;
+    }
+  }
+  res->path_fallback = c->coop_fallback;
   const SolverState &h = c->h_state[0];
   res->iterations = h.iteration;
   res->absolute_error = h.absolute_error;
@@ -907,10 +914,42 @@ void storm_hip_solver_params_default(storm_hip_solver_params *p) {
   p->gram_schmidt = 0;
 }
 
-int storm_hip_solve_cg(const storm_hip_op *op, double alpha, double beta, const storm_hip_vec *b,
-                       storm_hip_vec *x, const storm_hip_solver_params *params,
-                       storm_hip_solver_result *result, double *history) {
-  STORM_TRY(check_solve_args(op, b, x, params, result));
+}  // extern "C"
+
+namespace {
+struct FusedSolveArgs {
+  const storm_hip_op *op;
+  double alpha, beta;
+  const storm_hip_vec *b;
+  storm_hip_vec *x;
+  const storm_hip_solver_params *params;
+  storm_hip_solver_result *result;
+  double *history;
+  int (*body)(const FusedSolveArgs &);
+};
+int run_fused_body(void *p) {
+  const FusedSolveArgs &a = *static_cast<const FusedSolveArgs *>(p);
+  return a.body(a);
+}
+// A fused solve that may take a cooperative kernel, re-run without them should one give up (latency.hip)
+int fused_solve(FusedSolveArgs a) {
+  STORM_TRY(check_solve_args(a.op, a.b, a.x, a.params, a.result));
+  storm_hip_ctx *c = a.op->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  int fb = 0;
+  const int st = coop_solve_with_fallback(c, a.x->d, a.x->n_owned + a.x->n_halo, run_fused_body, &a, &fb);
+  if (st == STORM_HIP_OK) a.result->path_fallback = fb;
+  return st;
+}
+
+int solve_cg_body(const FusedSolveArgs &args) {
+  const storm_hip_op *op = args.op;
+  const double alpha = args.alpha, beta = args.beta;
+  const storm_hip_vec *b = args.b;
+  storm_hip_vec *x = args.x;
+  const storm_hip_solver_params *params = args.params;
+  storm_hip_solver_result *result = args.result;
+  double *history = args.history;
   storm_hip_ctx *c = op->ctx;
   HIP_TRY(hipSetDevice(c->device));
   const int64_t n = op->n_rows;
@@ -919,11 +958,14 @@ int storm_hip_solve_cg(const storm_hip_op *op, double alpha, double beta, const 
   VecPool pool;
   if (cg_latency_eligible(op)) {  // a small operator: the whole solve as one cooperative kernel (latency.hip)
     STORM_TRY(pool.make(x, 2));  // zero-filled: the kernel relies on that for the first direction
-    STORM_TRY(cg_latency_solve(op, alpha, beta, b->d, x->d, pool.v[0]->d, pool.v[1]->d, c->d_state));
-    return collect(d, result, history, applies_cg, 0);
+    bool taken = false;
+    STORM_TRY(cg_latency_solve(op, alpha, beta, b->d, x->d, pool.v[0]->d, pool.v[1]->d, c->d_state, &taken));
+    if (taken) return collect(d, result, history, applies_cg, 0);
+    // (the cooperative kernel could not be launched: the throughput path below, noted in result->path_fallback)
   }
+  const size_t v0 = pool.v.size();
   STORM_TRY(pool.make(x, 3));
-  double *p = pool.v[0]->d, *r = pool.v[1]->d, *z = pool.v[2]->d;
+  double *p = pool.v[v0]->d, *r = pool.v[v0 + 1]->d, *z = pool.v[v0 + 2]->d;
   const int nbv = vec_blocks(c, n);
 
   // init: r = b - A x; p = r; gamma = <r,r>          SolverCg.hpp:75-85
@@ -1009,10 +1051,14 @@ int storm_hip_solve_cg(const storm_hip_op *op, double alpha, double beta, const 
   return collect(d, result, history, applies_cg, 0);
 }
 
-int storm_hip_solve_bicgstab(const storm_hip_op *op, double alpha, double beta, const storm_hip_vec *b,
-                             storm_hip_vec *x, const storm_hip_solver_params *params,
-                             storm_hip_solver_result *result, double *history) {
-  STORM_TRY(check_solve_args(op, b, x, params, result));
+int solve_bicgstab_body(const FusedSolveArgs &args) {
+  const storm_hip_op *op = args.op;
+  const double alpha = args.alpha, beta = args.beta;
+  const storm_hip_vec *b = args.b;
+  storm_hip_vec *x = args.x;
+  const storm_hip_solver_params *params = args.params;
+  storm_hip_solver_result *result = args.result;
+  double *history = args.history;
   storm_hip_ctx *c = op->ctx;
   HIP_TRY(hipSetDevice(c->device));
   const int64_t n = op->n_rows;
@@ -1022,11 +1068,13 @@ int storm_hip_solve_bicgstab(const storm_hip_op *op, double alpha, double beta, 
   if (cg_latency_eligible(op)) {  // a small operator: the whole solve as one cooperative kernel (latency.hip)
     STORM_TRY(pool.make(x, 4));  // zero-filled: the kernel relies on that for the first direction
     double *const work[4] = {pool.v[0]->d, pool.v[1]->d, pool.v[2]->d, pool.v[3]->d};
-    STORM_TRY(bicgstab_latency_solve(op, alpha, beta, b->d, x->d, work, c->d_state));
-    return collect(d, result, history, applies_bicg, 0);
+    bool taken = false;
+    STORM_TRY(bicgstab_latency_solve(op, alpha, beta, b->d, x->d, work, c->d_state, &taken));
+    if (taken) return collect(d, result, history, applies_bicg, 0);
   }
+  const size_t v0 = pool.v.size();
   STORM_TRY(pool.make(x, 5));
-  double *p = pool.v[0]->d, *r = pool.v[1]->d, *rt = pool.v[2]->d, *t = pool.v[3]->d, *v = pool.v[4]->d;
+  double *p = pool.v[v0]->d, *r = pool.v[v0 + 1]->d, *rt = pool.v[v0 + 2]->d, *t = pool.v[v0 + 3]->d, *v = pool.v[v0 + 4]->d;
   const int nbv = vec_blocks(c, n);
   const int nbv2 = nbv;  // second half-step: one access per stream in flight, four trips per thread
   int nb = 0;
@@ -1123,10 +1171,14 @@ int storm_hip_solve_bicgstab(const storm_hip_op *op, double alpha, double beta, 
   return collect(d, result, history, applies_bicg, 0);
 }
 
-int storm_hip_solve_gmres(const storm_hip_op *op, double alpha, double beta, const storm_hip_vec *b,
-                          storm_hip_vec *x, const storm_hip_solver_params *params,
-                          storm_hip_solver_result *result, double *history) {
-  STORM_TRY(check_solve_args(op, b, x, params, result));
+int solve_gmres_body(const FusedSolveArgs &args) {
+  const storm_hip_op *op = args.op;
+  const double alpha = args.alpha, beta = args.beta;
+  const storm_hip_vec *b = args.b;
+  storm_hip_vec *x = args.x;
+  const storm_hip_solver_params *params = args.params;
+  storm_hip_solver_result *result = args.result;
+  double *history = args.history;
   storm_hip_ctx *c = op->ctx;
   HIP_TRY(hipSetDevice(c->device));
   const int64_t n = op->n_rows;
@@ -1213,6 +1265,22 @@ int storm_hip_solve_gmres(const storm_hip_op *op, double alpha, double beta, con
   const int64_t iters = c->h_state[0].iteration;
   if (iters > 0) STORM_TRY(finalize((int)((iters - 1) % m), true));
   return collect(d, result, history, applies_gmres, m);
+}
+}  // namespace
+
+extern "C" {
+
+int storm_hip_solve_cg(const storm_hip_op *op, double alpha, double beta, const storm_hip_vec *b, storm_hip_vec *x,
+                       const storm_hip_solver_params *params, storm_hip_solver_result *result, double *history) {
+  return fused_solve(FusedSolveArgs{op, alpha, beta, b, x, params, result, history, &solve_cg_body});
+}
+int storm_hip_solve_bicgstab(const storm_hip_op *op, double alpha, double beta, const storm_hip_vec *b, storm_hip_vec *x,
+                             const storm_hip_solver_params *params, storm_hip_solver_result *result, double *history) {
+  return fused_solve(FusedSolveArgs{op, alpha, beta, b, x, params, result, history, &solve_bicgstab_body});
+}
+int storm_hip_solve_gmres(const storm_hip_op *op, double alpha, double beta, const storm_hip_vec *b, storm_hip_vec *x,
+                          const storm_hip_solver_params *params, storm_hip_solver_result *result, double *history) {
+  return fused_solve(FusedSolveArgs{op, alpha, beta, b, x, params, result, history, &solve_gmres_body});
 }
 
 }  // extern "C"
