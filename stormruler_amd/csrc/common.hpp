@@ -69,6 +69,7 @@ struct SolverState {
   int converged;
   double *history;          // device buffer [num_iterations + 1] or null
   int *done_ring;           // device alias of a pinned host ring: done flag after iteration i at [i % kStateRing]
+  int verify_failed;        // option ticket_verify: an in-kernel (ticketed) reduction disagreed with its two-launch recomputation (sticky)
 };
 
 struct Comm;  // comm.hip
@@ -133,6 +134,8 @@ struct storm_hip_ctx {
   int coop_fallback = 0;                // what happened in the current solve (storm_hip_solver_result::path_fallback)
   int64_t opt_latency_path = 1;         // small operators: CG as one cooperative persistent kernel (latency.hip)
   int opt_lin_fuse = 1;                 // engine: two consecutive vector statements go out as one pass
+  int64_t opt_ticket_verify_inject = 0;  // test hook for the above
+  int64_t opt_ticket_verify = 0;        // k > 0: every k-th iteration the fused loops recompute their ticketed reductions by the two-launch path and compare on the device (sticky flag -> the solve returns an error)
   int opt_ticket_reduce = 1;            // fused CG / BiCGStab: reductions finish inside the kernels that produce their partials
   int opt_fused_reduce = 1;             // engine: a reduction is ONE launch (its last block folds the partials and runs the scalar program)
   int opt_latency_cache = 1;            // ... with the wave's operator records held in registers where they fit

@@ -145,6 +145,8 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "spmv_canon_tile_min_rows")) c->opt_spmv_canon_tile_min_rows = value;
   else if (!strcmp(key, "fused_reduce")) c->opt_fused_reduce = (int)value;
   else if (!strcmp(key, "ticket_reduce")) c->opt_ticket_reduce = (int)value;
+  else if (!strcmp(key, "ticket_verify")) c->opt_ticket_verify = value;
+  else if (!strcmp(key, "ticket_verify_inject")) c->opt_ticket_verify_inject = value;
   else if (!strcmp(key, "lin_fuse")) c->opt_lin_fuse = (int)value;
   else if (!strcmp(key, "latency_rows")) c->opt_latency_rows = value;
   else if (!strcmp(key, "latency_cache")) c->opt_latency_cache = (int)value;

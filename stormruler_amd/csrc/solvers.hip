@@ -158,6 +158,27 @@ __global__ __launch_bounds__(kBlock) void reduce_stage1_ticket_kernel(const doub
   }
 }
 
+// Option ticket_verify: sums[j] (a reduction recomputed by the two-launch path) against the slab slots the in-kernel
+// reduction filled -- they differ by rounding only (another folding order); anything else raises the sticky flag.
+// `before`: the sums were taken of the vectors as they are NOW while the step has already run (iteration count).
+struct VerifySlots {
+  const double *sum[2];
+  const double *slot[2];
+  int k;
+};
+__global__ void verify_kernel(VerifySlots v, SolverState *st, long long iteration_of_slots) {
+  // (past convergence the ticketed kernel returned early: nothing to compare)
+  if (st->iteration != iteration_of_slots) return;
+  for (int j = 0; j < v.k; ++j) {
+    const double a = *v.sum[j], b = *v.slot[j];
+    double scale = fabs(a) > fabs(b) ? fabs(a) : fabs(b);
+    // (the second sum of a pair -- <rt, r> beside <r, r> -- has terms of both signs: its rounding error scales with the
+    //  first, not with its own value; a lost block's partial is ~1/blocks of the sum, far above either bound)
+    if (j == 1 && fabs(*v.sum[0]) > scale) scale = fabs(*v.sum[0]);
+    if (!(fabs(a - b) <= (j == 0 ? 1e-10 : 1e-7) * scale)) st->verify_failed = 1;  // (also catches NaN)
+  }
+}
+
 __global__ void step_kernel(int step, SolverState *st, GmresDev g, bool force) {
   if (!force && st->done) return;
   do_step(step, st, g);
@@ -636,6 +657,24 @@ struct Driver {
     return STORM_HIP_OK;
   }
 
+  // Option ticket_verify: <a, b0> (and <a, b1>) once more by the two-launch path (per-block partials, then one block
+  // folds them) into scratch slots, compared on the device with the slab slots an in-kernel reduction filled.
+  // Single rank only (the slots then hold local sums).  `iteration_of_slots`: the value of the iteration counter for
+  // which the slots are current (the ticketed kernel may have run the scalar step already).
+  int verify(const double *a, const double *b0, const double *b1, int slot0, int slot1, long long iteration_of_slots) {
+    if (c->comm != nullptr) return STORM_HIP_OK;
+    const double *bs[2] = {b0, b1};
+    const int k = b1 ? 2 : 1;
+    int nbp = 0;
+    STORM_TRY(k_multi_dot_partials(c, a, bs, k, n, &nbp, nullptr));
+    // (test hook ticket_verify_inject: the recomputation "loses" one block's partial, as a stale read would)
+    STORM_TRY(k_reduce_final(c, c->d_partials, c->opt_ticket_verify_inject != 0 && nbp > 1 ? nbp - 1 : nbp, k, slot(S_SCRATCH + 8), nullptr));
+    VerifySlots v{{slot(S_SCRATCH + 8), slot(S_SCRATCH + 9)}, {slot(slot0), slot(slot1 >= 0 ? slot1 : slot0)}, k};
+    hipLaunchKernelGGL(verify_kernel, dim3(1), dim3(1), 0, c->stream, v, st, iteration_of_slots);
+    HIP_TRY(hipGetLastError());
+    return STORM_HIP_OK;
+  }
+
   // y = A x, optionally with fused <w, y> / <y, y> partials.  Returns nblocks of partials (0 = not fused).
   // out0 / out1 (slab slots; -1: none): where an in-kernel (ticketed) reduction may leave <w,y> / <y,y>;
   // *ticketed tells whether it did -- then there are no partials to finish (*nblocks is still their count).
@@ -710,6 +749,11 @@ static int collect(Driver &d, storm_hip_solver_result *res, double *history, int
     }
   }
   res->path_fallback = c->coop_fallback;
+  if (c->h_state[0].verify_failed) {
+    if (d.d_history) (void)hipFree(d.d_history), d.d_history = nullptr;
+    STORM_FAIL(STORM_HIP_E_HIP, "ticket_verify: an in-kernel reduction disagreed with its two-launch recomputation "
+                                "(a partial sum was not visible to the block that folded it)");
+  }
   const SolverState &h = c->h_state[0];
   res->iterations = h.iteration;
   res->absolute_error = h.absolute_error;
@@ -1035,6 +1079,11 @@ int solve_cg_body(const FusedSolveArgs &args) {
       const int slots[1] = {S_GAMMA_NEW};
       STORM_TRY(d.finish(nbv, 1, slots, STEP_CG_RR));
     }
+    if (tick && c->opt_ticket_verify > 0 && cur_it % c->opt_ticket_verify == 0) {
+      // <p, z> as the SpMV / first pass left it, <r, r> as cg_r's last block did (it has advanced the counter already)
+      STORM_TRY(d.verify(p, z, nullptr, S_PZ, -1, (long long)(cur_it + 1)));
+      STORM_TRY(d.verify(r, r, nullptr, S_GAMMA, -1, (long long)(cur_it + 1)));
+    }
     // x += alpha p; p = r + beta p                    SolverCg.hpp:98,123
     hipLaunchKernelGGL(cg_xp_kernel, dim3(xp_blocks(n)), dim3(kBlock), 0, c->stream, n, d.st, (long long)(cur_it + 1), x->d,
                        p, r, nt_stream, q);
@@ -1104,6 +1153,7 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
     return st_apply;
   };
   // Everything of an iteration after the p update (iteration-invariant arguments).
+  int64_t bi_it = 0;  // the iteration being enqueued (option ticket_verify)
   auto enqueue_rest = [&]() -> int {
     // v = A p; alpha = rho / <rt,v>                   :137-139
     STORM_TRY(apply_dir(p, v, rt, false, (int)S_RTV, -1));
@@ -1144,6 +1194,10 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
     if (!omega_in_kernel) {
       const int slots[2] = {S_RR, S_RHO_NEW};
       STORM_TRY(d.finish(nbv2, 2, slots, STEP_BICG_END));
+    } else if (c->opt_ticket_verify > 0 && bi_it % c->opt_ticket_verify == 0) {
+      // |r|^2 and the next iteration's rho = <rt, r> as the second half-step's last block left them (it has run
+      // STEP_BICG_END: rho_new sits in S_RHO, the counter is advanced)
+      STORM_TRY(d.verify(r, r, rt, S_RR, S_RHO, (long long)(bi_it + 1)));
     }
     return STORM_HIP_OK;
   };
@@ -1158,6 +1212,7 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
   IterationGraph graph;
   STORM_TRY(graph.capture(c, params->num_iterations - 1, enqueue_iteration));
   for (int64_t it = 0; it < params->num_iterations; ++it) {
+    bi_it = it;
     if (it == 0) {
       STORM_TRY(k_copy(c, p, r, n, d.done));  // :114
       STORM_TRY(enqueue_rest());

@@ -49,8 +49,12 @@ def main():
         api.fill_with(b, 1.0)
         for name, cls in (("cg", api.CgSolver), ("bicgstab", api.BiCgStabSolver)):
             lat, thr = rate(ctx, op, b, g.n_cells, True, cls=cls), rate(ctx, op, b, g.n_cells, False, cls=cls)
+            ctx.set_option("latency_publish", 0)  # rows published with write-through stores (round 2) instead of awaited exchanges
+            lat_store = rate(ctx, op, b, g.n_cells, True, cls=cls)
+            ctx.set_option("latency_publish", 1)
             line = {"solver": name, "mesh": kind if shape is None else "x".join(map(str, shape)), "rows": g.n_cells,
-                    "latency_path_us_per_iteration": lat, "throughput_path_us_per_iteration": thr, "ratio": thr / lat}
+                    "latency_path_us_per_iteration": lat, "latency_path_store_published_us": lat_store,
+                    "throughput_path_us_per_iteration": thr, "ratio": thr / lat}
             if name == "bicgstab":
                 ctx.set_option("latency_cache", 0)
                 line["latency_path_records_not_cached_us"] = rate(ctx, op, b, g.n_cells, True, cls=cls)
