@@ -244,10 +244,11 @@ static inline Scal dev_scal(const double *p, double sign = 1.0) { return Scal{p,
 // 6.47 TB/s.  So: blocks = ceil(n / 2048), each thread moves 4 double2 per stream.
 constexpr int kUnroll = 4;
 constexpr int kStreamBlockElems = kBlock * kUnroll * 2;  // doubles per block and stream
+constexpr int kMaxStreamBlocks = 32768;  // beyond: grid-stride (keeps the partial arrays -- and the ticket groups -- bounded)
 static inline int stream_blocks(int64_t n) {
   int64_t b = (n + kStreamBlockElems - 1) / kStreamBlockElems;
   if (b < 1) b = 1;
-  if (b > 32768) b = 32768;  // beyond: grid-stride (keeps the partial arrays bounded)
+  if (b > kMaxStreamBlocks) b = kMaxStreamBlocks;
   return (int)b;
 }
 

@@ -698,6 +698,11 @@ struct KrylovEngine {
   // program holds this iteration's convergence rule (the statement is then gated on the iteration counter).
   int prog_lets_queued_wait() const {
     int verdict = 1;
+    // (registers the pending REDUCTION writes directly count as written by the program that rides behind it)
+    if (red_pending)
+      for (int j = 0; j < red_k; ++j)
+        for (int t = 0; t < 4; ++t)
+          if (q_regs[t] == (int)red_out.idx[j]) return 0;
     for (int i = 0; i < prog.n; ++i) {
       const SOp &o = prog.ops[i];
       if (o.op == SC_GIVENS || o.op == SC_BACKSOLVE || o.op == SC_BEGIN) return 0;  // (macros over register ranges; init)

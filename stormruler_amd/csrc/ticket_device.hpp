@@ -20,6 +20,9 @@ namespace storm {
 constexpr int kTicketGroup = 64;
 constexpr int kTicketStride = 16;          // ints between counters (one 64-byte line each)
 constexpr int kTicketMaxGroups = 2048;     // 131 072 blocks
+// every streaming kernel that finishes its reduction with tickets (blas1.hip, krylov.hip, solvers.hip) sizes its grid
+// with stream_blocks(): whatever the row count, its blocks fit the counters and the group-sum buffer
+static_assert(kMaxStreamBlocks <= kTicketGroup * kTicketMaxGroups, "stream_blocks() may exceed the ticket counters");
 
 struct TicketArgs {
   int *cnt;       // [1 + kTicketMaxGroups] counters, kTicketStride apart; null = tickets off
