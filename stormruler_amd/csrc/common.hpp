@@ -116,8 +116,9 @@ struct storm_hip_ctx {
   int stream_reverse = 0;            // ... and the same for the next elementwise kernel
   int spmv_reverse = 0;              // set around a format-4 SpMV launch by the solver: deal the tiles out from the far end
   int64_t opt_spmv_canon_groups = 2; // format-4 / 5 kernel: 128-row groups per wavefront (1 or 2)
+  int64_t opt_spmv_tile_lds_pad = 0;   // A/B knob: extra dynamic LDS per block of the tiled kernel (fewer resident tiles per CU)
   int64_t opt_spmv_canon_tile_min_rows = (int64_t)1 << 20;  // ... for operators of at least this many rows
-  int64_t opt_spmv_canon_tile = 4;   // format 4 on a lattice (offsets -b,-a,-1,+1,+a,+b): tiles of 1024 rows x this many planes (4 or 2) with the +-a / +-1 neighbours from LDS and the +-b ones from registers; 0 = the plain kernel
+  int64_t opt_spmv_canon_tile = 2;   // format 4 on a lattice (offsets -b,-a,-1,+1,+a,+b): tiles of 1024 rows x this many planes (2, or 4) with the +-a / +-1 neighbours from LDS and the +-b ones from registers; 0 = the plain kernel.  Measured at 256^3 (profiles/r03f, r03g): CG step 242 (2 planes) / 247 (4) us per iteration, BiCGStab 496 / 510
   int64_t opt_coop_mgs_pairs = 1;    // cooperative Gram-Schmidt chain: two steps per synchronisation point
   int64_t opt_spmv_mixed = 1;        // partitioned operators: format 4 for the groups that read no halo column, format 3 for the rest
   int64_t opt_spmv_nt_y = 1;         // format-4 kernel: store y non-temporally (A/B knob)
@@ -143,6 +144,8 @@ struct storm_hip_ctx {
   int64_t opt_ipc_fused = 1;            // peer-window transport: the interior launch sends, the boundary launch reads the window (0: stand-alone send / receive-copy kernels)
   int64_t opt_ipc_streams = 2;          // peer-window halo exchange: 2 = on the comm stream beside the interior rows, 1 = on the compute stream around them
   int64_t opt_generic_solvers = 0;  // 1: storm_hip_krylov_solve never takes the fused CG / BiCGStab / GMRES loops (A/B knob)
+  int64_t opt_cg_march = 8;   // ... as blocks of 1024 rows marching through this many planes (0: tiles, spmv_canon_tile planes deep); 256^3, us per CG iteration: tiles 239, 8 planes 230, 16 234, 32 236, 64 237 (profiles/r03k)
+  int64_t opt_cg_fuse = 1;   // fused CG, one rank, tiled format-4 operator: the SpMV kernel ends the previous iteration (x += alpha p, p = r + beta p) itself
   int64_t opt_fold_pz = 1;   // CG, one rank, > 8192 SpMV partials: cg_r_kernel folds the first-pass partials of <p,z> itself (one launch fewer)
   int64_t opt_fuse_dot = 1;  // 0: reductions after an SpMV run as separate kernels (A/B knob)
   // Vector storage released by vec_destroy, kept for the next vec_create of the same size: a solve
@@ -290,10 +293,21 @@ struct SpmvDot {
   // *ticketed_out tells whether it was.
   double *out[2] = {nullptr, nullptr};
   int *ticketed_out = nullptr;
+  // Fused CG step (spmv.hip, CgFuseArgs): the kernel first ends the previous iteration -- x += alpha p, p' = r + beta p
+  // into p_out -- and applies the operator to p' (x = p is then the OLD direction; w must be x).  cg.x == null: off.
+  struct {
+    const long long *iteration = nullptr;
+    long long my_iteration = 0;
+    const double *ca = nullptr, *cb = nullptr;
+    double *x = nullptr;
+    const double *r = nullptr;
+    double *p_out = nullptr;
+  } cg;
 };
 int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, double *y,
                 const SpmvDot *dot, const int *done, bool accumulate = false);
 int spmv_grid_blocks(const storm_hip_op *op);
+bool spmv_can_fuse_cg(const storm_hip_op *op);
 int op_upload_slice_lists(storm_hip_op *op);
 
 // latency.hip

@@ -142,6 +142,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "sweep_alternate")) c->opt_sweep_alternate = value;
   else if (!strcmp(key, "spmv_canon_groups")) c->opt_spmv_canon_groups = value;
   else if (!strcmp(key, "spmv_canon_tile")) c->opt_spmv_canon_tile = value;
+  else if (!strcmp(key, "spmv_tile_lds_pad")) c->opt_spmv_tile_lds_pad = value;
   else if (!strcmp(key, "spmv_canon_tile_min_rows")) c->opt_spmv_canon_tile_min_rows = value;
   else if (!strcmp(key, "fused_reduce")) c->opt_fused_reduce = (int)value;
   else if (!strcmp(key, "ticket_reduce")) c->opt_ticket_reduce = (int)value;
@@ -166,6 +167,8 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "profile_spmv")) c->opt_profile_spmv = value;
   else if (!strcmp(key, "fuse_dot")) c->opt_fuse_dot = value;
   else if (!strcmp(key, "fold_pz")) c->opt_fold_pz = value;
+  else if (!strcmp(key, "cg_fuse")) c->opt_cg_fuse = value;
+  else if (!strcmp(key, "cg_march")) c->opt_cg_march = value;
   else if (!strcmp(key, "host_result")) c->opt_host_result = value;
   else if (!strcmp(key, "fuse_mgs")) c->opt_fuse_mgs = value;
   else if (!strcmp(key, "graph")) c->opt_graph = value;

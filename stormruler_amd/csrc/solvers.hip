@@ -678,9 +678,20 @@ struct Driver {
   // y = A x, optionally with fused <w, y> / <y, y> partials.  Returns nblocks of partials (0 = not fused).
   // out0 / out1 (slab slots; -1: none): where an in-kernel (ticketed) reduction may leave <w,y> / <y,y>;
   // *ticketed tells whether it did -- then there are no partials to finish (*nblocks is still their count).
+  struct CgStep {  // the fused CG step of spmv.hip (CgFuseArgs): end iteration my_iteration - 1, then apply to the new p
+    long long my_iteration;
+    double *x;
+    const double *r;
+    double *p_out;
+  };
   int apply(const double *x, double *y, const double *dot_w, bool dot_yy, int *nblocks, bool predicated = true,
-            int out0 = -1, int out1 = -1, int *ticketed = nullptr) {
+            int out0 = -1, int out1 = -1, int *ticketed = nullptr, const CgStep *cg = nullptr) {
     SpmvDot sd;
+    if (cg != nullptr) {
+      sd.cg.iteration = &st->iteration, sd.cg.my_iteration = cg->my_iteration;
+      sd.cg.ca = slot(S_ALPHA), sd.cg.cb = slot(S_BETA);
+      sd.cg.x = cg->x, sd.cg.r = cg->r, sd.cg.p_out = cg->p_out;
+    }
     sd.w = dot_w;
     sd.yy = dot_yy;
     sd.partials = c->d_partials;
@@ -1039,12 +1050,32 @@ int solve_cg_body(const FusedSolveArgs &args) {
   // (<p,z> inside the SpMV only where it replaces a whole final-pass launch: with more per-wave partials than one
   // pass folds, the first pass + the fold inside cg_r cost what the ticket tail would add to the SpMV)
   const bool tick_spmv = tick && !ipc && (4 * (int64_t)spmv_grid_blocks(op) <= kSinglePassPartials || c->opt_fold_pz == 0);
+  // The fused step (one rank, tiled format-4 operator): iteration k's SpMV kernel first ENDS iteration k - 1 --
+  // x += alpha p, p' = r + beta p -- on the rows it loads anyway and applies the operator to p': x and p are no longer
+  // streamed by a kernel of their own (cg_xp).  p ping-pongs between two vectors (a tile's old p is another tile's
+  // halo).  Two launches + the small first pass per iteration; the last iteration's x update runs behind the loop.
+  const bool fuse_step = c->opt_cg_fuse != 0 && c->comm == nullptr && tick && !tick_spmv && c->opt_fuse_dot != 0 &&
+                         spmv_can_fuse_cg(op);
+  double *p_alt = nullptr;
+  if (fuse_step) {
+    STORM_TRY(pool.make(x, 1));
+    p_alt = pool.v.back()->d;
+  }
+  int64_t last_enqueued = -1;
   auto enqueue_iteration = [&]() -> int {
-    const int q = sweep ? (int)(cur_it & 1) : 0;
+    const int q = fuse_step ? 0 : sweep ? (int)(cur_it & 1) : 0;  // (fused: the step kernel forward, cg_r backward, always)
     // z = A p, <p,z>                                  SolverCg.hpp:96-97
     c->spmv_reverse = q;
     int pz_done = 0;  // <p,z> finished inside the SpMV kernel (tickets): cg_r reads it from the slab
-    const int st_apply = d.apply(p, z, p, false, &nb, true, tick_spmv ? (int)S_PZ : -1, -1, &pz_done);
+    int st_apply;
+    if (fuse_step && cur_it > 0) {
+      const Driver::CgStep step{(long long)cur_it, x->d, r, p_alt};  // ends iteration cur_it - 1 (SolverCg.hpp:98, :123)
+      st_apply = d.apply(p, z, p, false, &nb, true, -1, -1, &pz_done, &step);
+      std::swap(p, p_alt);
+    } else {
+      st_apply = d.apply(p, z, p, false, &nb, true, tick_spmv ? (int)S_PZ : -1, -1, &pz_done);
+    }
+    last_enqueued = cur_it;
     c->spmv_reverse = 0;
     STORM_TRY(st_apply);
     const double *pz_partials = nullptr;
@@ -1084,6 +1115,7 @@ int solve_cg_body(const FusedSolveArgs &args) {
       STORM_TRY(d.verify(p, z, nullptr, S_PZ, -1, (long long)(cur_it + 1)));
       STORM_TRY(d.verify(r, r, nullptr, S_GAMMA, -1, (long long)(cur_it + 1)));
     }
+    if (fuse_step) return STORM_HIP_OK;  // (the next iteration's step kernel, or the tail below, ends this one)
     // x += alpha p; p = r + beta p                    SolverCg.hpp:98,123
     hipLaunchKernelGGL(cg_xp_kernel, dim3(xp_blocks(n)), dim3(kBlock), 0, c->stream, n, d.st, (long long)(cur_it + 1), x->d,
                        p, r, nt_stream, q);
@@ -1096,6 +1128,13 @@ int solve_cg_body(const FusedSolveArgs &args) {
     bool stop = false;
     STORM_TRY(post_and_poll(d, it, &stop));
     if (stop) break;
+  }
+  if (fuse_step && last_enqueued >= 0) {
+    // the x update of the last enqueued iteration (a no-op when that iteration never ran: the step kernel of the
+    // iteration behind the converging one has applied it already)
+    hipLaunchKernelGGL(cg_xp_kernel, dim3(xp_blocks(n)), dim3(kBlock), 0, c->stream, n, d.st, (long long)(last_enqueued + 1),
+                       x->d, p, r, nt_stream, 0);
+    HIP_TRY(hipGetLastError());
   }
   return collect(d, result, history, applies_cg, 0);
 }

@@ -834,15 +834,33 @@ struct CanonTileArgs {
   int reverse;
   int plane0, plane_end; // the planes this launch covers (a partitioned operator: those that read no halo column)
 };
-template <bool DOT, bool WLOAD, int TZ, int HL>
+// FUSE (fused CG loop, one rank): the kernel first performs the END of the previous CG iteration on everything it loads,
+//     x += alpha p,   p' = r + beta p                                  (SolverCg.hpp:98, :123)
+// and then applies the operator to p' -- x and p are not streamed by a kernel of their own any more (56 instead of
+// 24 + 40 B/row).  x of a row is its own lane's; p' of the tile's halo rows and outer planes is formed from THEIR r
+// and p with the owner's expression (the same bits), which is why p' goes to a SECOND vector (F.p_out): another tile
+// may still need this tile's old p.  Gated like cg_xp_kernel: on the iteration counter for x (the converging
+// iteration's update must land), on `done` for p' and the apply.
+struct CgFuseArgs {
+  const long long *iteration;  // SolverState::iteration
+  long long my_iteration;      // the update belongs to iteration my_iteration - 1: it ran iff *iteration >= my_iteration
+  const double *ca, *cb;       // alpha, beta of that iteration (device slab)
+  double *x;
+  const double *r;
+  double *p_out;
+};
+template <bool DOT, bool WLOAD, int TZ, int HL, bool FUSE = false>
 __global__ __launch_bounds__(kBlock) void spmv_canon_tile_kernel(SellArgs A, CanonTileArgs T, Scal alpha_s, Scal beta_s,
                                                                  const double *__restrict__ x, double *__restrict__ y,
-                                                                 DotArgs dot, const int *done, IpcSendArgs S) {
-  if ((int)blockIdx.x < S.sp.n_blocks) {  // the first blocks of a partitioned operator's interior launch send its rows
+                                                                 DotArgs dot, const int *done, IpcSendArgs S, CgFuseArgs F) {
+  if (!FUSE && (int)blockIdx.x < S.sp.n_blocks) {  // the first blocks of a partitioned operator's interior launch send its rows
     ipc_halo_send_block(S.w, S.sp, x, (int)blockIdx.x);
     return;
   }
+  if (FUSE && *F.iteration < F.my_iteration) return;  // enqueued past convergence: that iteration never ran
   const int done_flag = done ? *done : 0;
+  const double cg_a = FUSE ? *F.ca : 0.0, cg_b = FUSE ? *F.cb : 0.0;
+  const char *rb_ = reinterpret_cast<const char *>(F.r);
   extern __shared__ __attribute__((aligned(16))) double tile_sh[];  // [TZ][a + kTileRun + a]
   __shared__ double dict_sh[32];
   const int lane = threadIdx.x & (kWave - 1);
@@ -885,6 +903,30 @@ __global__ __launch_bounds__(kBlock) void spmv_canon_tile_kernel(SellArgs A, Can
       rc[t][g] = row <= (int64_t)last_row ? (uint32_t)row : (last_row & ~1u);  // pairs past the end re-read the last pair
       xi[t][g] = *reinterpret_cast<const double2v *>(xb + (size_t)(rc[t][g] << 3));
     }
+  if (FUSE) {
+    // x += alpha p (the OLD direction), then p' = r + beta p takes p's place in the registers
+#pragma unroll
+    for (int t = 0; t < TZ; ++t)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        double2v *xp_ = reinterpret_cast<double2v *>(reinterpret_cast<char *>(F.x) + (size_t)(rc[t][g] << 3));
+        const double2v xv = __builtin_nontemporal_load(xp_);
+        const double2v rv = *reinterpret_cast<const double2v *>(rb_ + (size_t)(rc[t][g] << 3));
+        double2v xn, pn;
+        xn.x = __builtin_fma(cg_a, xi[t][g].x, xv.x), xn.y = __builtin_fma(cg_a, xi[t][g].y, xv.y);
+        pn.x = __builtin_fma(cg_b, xi[t][g].x, rv.x), pn.y = __builtin_fma(cg_b, xi[t][g].y, rv.y);
+        if (valid_b[t][g]) __builtin_nontemporal_store(xn, xp_);
+        else if (valid_a[t][g]) F.x[rc[t][g]] = xn.x;
+        xi[t][g] = pn;
+        if (!done_flag) {
+          double2v *pp_ = reinterpret_cast<double2v *>(reinterpret_cast<char *>(F.p_out) + (size_t)(rc[t][g] << 3));
+          if (valid_b[t][g]) __builtin_nontemporal_store(pn, pp_);
+          else if (valid_a[t][g]) F.p_out[rc[t][g]] = pn.x;
+        }
+      }
+    if (done_flag) return;  // converged in that iteration: x is final, no new direction, no apply
+  }
+  const char *rg_base = FUSE ? rb_ - (size_t)kVecGuard * 8 : nullptr;
   double2v halo[HL];
   int halo_at[HL];  // LDS index (doubles) of the pair, -1: none
 #pragma unroll
@@ -899,6 +941,10 @@ __global__ __launch_bounds__(kBlock) void spmv_canon_tile_kernel(SellArgs A, Can
     halo_at[i] = on ? (int)t * ldw + a + jj : -1;
     halo[i] = double2v{0.0, 0.0};
     if (on) halo[i] = *reinterpret_cast<const double2v *>(xg_base + (size_t)((uint32_t)gi << 3));
+    if (FUSE && on) {  // the halo row's new direction, with its owner's expression
+      const double2v rv = *reinterpret_cast<const double2v *>(rg_base + (size_t)((uint32_t)gi << 3));
+      halo[i].x = __builtin_fma(cg_b, halo[i].x, rv.x), halo[i].y = __builtin_fma(cg_b, halo[i].y, rv.y);
+    }
   }
   u64x2 vw[TZ][2];
   double2v wi[WLOAD ? TZ : 1][2];
@@ -917,6 +963,12 @@ __global__ __launch_bounds__(kBlock) void spmv_canon_tile_kernel(SellArgs A, Can
     hi = hi > T.max_gather ? T.max_gather : hi;
     xlo[g] = *reinterpret_cast<const double2v *>(xg_base + (size_t)((uint32_t)lo << 3));
     xhi[g] = *reinterpret_cast<const double2v *>(xg_base + (size_t)((uint32_t)hi << 3));
+    if (FUSE) {
+      const double2v rl = *reinterpret_cast<const double2v *>(rg_base + (size_t)((uint32_t)lo << 3));
+      const double2v rh = *reinterpret_cast<const double2v *>(rg_base + (size_t)((uint32_t)hi << 3));
+      xlo[g].x = __builtin_fma(cg_b, xlo[g].x, rl.x), xlo[g].y = __builtin_fma(cg_b, xlo[g].y, rl.y);
+      xhi[g].x = __builtin_fma(cg_b, xhi[g].x, rh.x), xhi[g].y = __builtin_fma(cg_b, xhi[g].y, rh.y);
+    }
   }
   // ---- the LDS copy of the tile's x (own rows + halo rows), one barrier
   if (lane < 32) dict_sh[lane] = dict_word;  // every wave stores the same words
@@ -1006,6 +1058,220 @@ __global__ __launch_bounds__(kBlock) void spmv_canon_tile_kernel(SellArgs A, Can
   }
 }
 
+// ---- the fused CG step, marching in z ------------------------------------------------------------------------------
+// spmv_canon_tile_kernel<FUSE> forms p' = r + beta p for its tile's halo rows and outer planes from THEIR r and p: with
+// tiles two planes deep that is one extra row of r and p per row, and with ~128 tiles per XCD in flight those rows no
+// longer come from the L2 (PMC: 48 instead of 32 B/row fetched, profiles/r03i_pmc_summary.txt).  Here a block keeps
+// its 1024 rows of the plane and MARCHES through `zc_planes` planes: p' of the planes below, at and above the one
+// being applied sits in the lane's registers (each plane's p, r, x, record are loaded exactly once, prefetched one
+// plane ahead), the +-a / +-1 neighbours come from an LDS copy of the current plane (three buffers in rotation, one
+// barrier per plane), and only the two planes bounding the block's chunk are loaded for their p' alone.
+//   reads  p, r, x, records (32 B/row) + the +-a halo lines (r, p; adjacent tiles of the same XCD march in step) + 2 / zc_planes planes
+//   writes x, p', z (24 B/row)
+// Arithmetic per row exactly spmv_canon_kernel's; x += alpha p and p' = r + beta p exactly cg_xp_kernel's.
+struct MarchArgs {
+  CanonTileArgs T;   // a, b, tiles_per_plane, per_xcd, max_gather, reverse, plane_end (= number of planes)
+  int zc_planes;     // planes per block
+};
+template <int HLP>  // halo pairs per thread and plane: ceil(a / 256)
+__global__ __launch_bounds__(kBlock) void cg_step_march_kernel(SellArgs A, MarchArgs M, Scal alpha_s, Scal beta_s,
+                                                               const double *__restrict__ p_in, double *__restrict__ z_out,
+                                                               DotArgs dot, const int *done, CgFuseArgs F) {
+  if (*F.iteration < F.my_iteration) return;  // enqueued past convergence: that iteration never ran
+  const int done_flag = done ? *done : 0;
+  const CanonTileArgs &T = M.T;
+  extern __shared__ __attribute__((aligned(16))) double tile_sh[];  // [3][a + kTileRun + a]
+  __shared__ double dict_sh[32];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int bidx = T.reverse ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+  int zc, yt;
+  if (T.per_xcd > 0) {
+    const int xcd = bidx & (kNumXcd - 1), j = bidx >> 3;
+    zc = j / T.per_xcd;
+    yt = xcd * T.per_xcd + (j - zc * T.per_xcd);
+  } else {
+    zc = bidx / T.tiles_per_plane;
+    yt = bidx - zc * T.tiles_per_plane;
+  }
+  const int a = T.a, b = T.b;
+  const int p0 = yt * kTileRun;
+  const int z_begin = zc * M.zc_planes, z_end = min(z_begin + M.zc_planes, T.plane_end);
+  const int ldw = kTileRun + 2 * a;
+  const double alpha = ld_scal2(alpha_s), beta = ld_scal2(beta_s);
+  const double cg_a = *F.ca, cg_b = *F.cb;
+  const uint32_t last_row = (uint32_t)(A.n_rows - 1);
+  const char *pb = reinterpret_cast<const char *>(p_in), *rb = reinterpret_cast<const char *>(F.r);
+  const char *pg_base = pb - (size_t)kVecGuard * 8, *rg_base = rb - (size_t)kVecGuard * 8;
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  const double dict_word = A.dict[lane & 31];
+  if (lane < 32) dict_sh[lane] = dict_word;  // every wave stores the same words; the first barrier below covers them
+
+  // what is in flight for ONE plane: the own rows' p, r, x and record, and this thread's share of the halo lines
+  struct Flight {
+    double2v p[2], r[2], x[2], hp[HLP], hr[HLP];
+    u64x2 w[2];
+    uint32_t rc[2];
+    bool va[2], vb[2];
+    int hat[HLP];
+  };
+  auto issue = [&](int zp, bool own, Flight &f) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int q = p0 + 256 * wave + 128 * g + 2 * lane;
+      const int64_t row = (int64_t)zp * b + q;
+      const bool in_plane = q < b && own;
+      f.va[g] = in_plane && row <= (int64_t)last_row, f.vb[g] = in_plane && row + 1 <= (int64_t)last_row;
+      int64_t gi = row + kVecGuard;  // guard-relative, clamped: a plane below the first / above the last reads zeros or x's last rows, weight 0
+      gi = gi < 0 ? 0 : gi;
+      gi = gi > (int64_t)T.max_gather ? (int64_t)T.max_gather : gi;
+      f.rc[g] = (row >= 0 && row <= (int64_t)last_row) ? (uint32_t)row : (last_row & ~1u);
+      f.p[g] = *reinterpret_cast<const double2v *>(pg_base + (size_t)((uint32_t)gi << 3));
+      f.r[g] = *reinterpret_cast<const double2v *>(rg_base + (size_t)((uint32_t)gi << 3));
+      if (own) {
+        f.x[g] = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(reinterpret_cast<const char *>(F.x) + (size_t)(f.rc[g] << 3)));
+        f.w[g] = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(A.pack + (size_t)(f.rc[g] << 3)));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < HLP; ++i) {
+      const int u = (int)threadIdx.x + kBlock * i;  // pair u of the plane's a halo pairs
+      const bool on = own && u < a;
+      const int jj = 2 * u < a ? 2 * u - a : kTileRun + 2 * u - a;
+      int64_t gi = (int64_t)zp * b + p0 + jj + kVecGuard;
+      gi = gi < 0 ? 0 : gi;
+      gi = gi > (int64_t)T.max_gather ? (int64_t)T.max_gather : gi;
+      f.hat[i] = on ? a + jj : -1;
+      f.hp[i] = f.hr[i] = double2v{0.0, 0.0};
+      if (on) {
+        f.hp[i] = *reinterpret_cast<const double2v *>(pg_base + (size_t)((uint32_t)gi << 3));
+        f.hr[i] = *reinterpret_cast<const double2v *>(rg_base + (size_t)((uint32_t)gi << 3));
+      }
+    }
+  };
+  // the plane has arrived: p' of the own rows (-> out), x and p' stored, the LDS copy of the plane filled
+  auto consume = [&](bool own, const Flight &f, double2v (&out)[2], double *buf) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      double2v pn;
+      pn.x = __builtin_fma(cg_b, f.p[g].x, f.r[g].x), pn.y = __builtin_fma(cg_b, f.p[g].y, f.r[g].y);
+      out[g] = pn;
+      if (own) {
+        double2v xn;
+        xn.x = __builtin_fma(cg_a, f.p[g].x, f.x[g].x), xn.y = __builtin_fma(cg_a, f.p[g].y, f.x[g].y);
+        double2v *xp_ = reinterpret_cast<double2v *>(reinterpret_cast<char *>(F.x) + (size_t)(f.rc[g] << 3));
+        double2v *pp_ = reinterpret_cast<double2v *>(reinterpret_cast<char *>(F.p_out) + (size_t)(f.rc[g] << 3));
+        if (f.vb[g]) __builtin_nontemporal_store(xn, xp_), __builtin_nontemporal_store(pn, pp_);
+        else if (f.va[g]) F.x[f.rc[g]] = xn.x, F.p_out[f.rc[g]] = pn.x;
+        *reinterpret_cast<double2v *>(&buf[a + 256 * wave + 128 * g + 2 * lane]) = pn;
+      }
+    }
+    if (own) {
+#pragma unroll
+      for (int i = 0; i < HLP; ++i)
+        if (f.hat[i] >= 0) {
+          double2v hn;
+          hn.x = __builtin_fma(cg_b, f.hp[i].x, f.hr[i].x), hn.y = __builtin_fma(cg_b, f.hp[i].y, f.hr[i].y);
+          *reinterpret_cast<double2v *>(&buf[f.hat[i]]) = hn;
+        }
+    }
+  };
+
+  if (done_flag) {  // converged in that iteration: only x += alpha p is left to do
+    for (int zp = z_begin; zp < z_end; ++zp) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int q = p0 + 256 * wave + 128 * g + 2 * lane;
+        const int64_t row = (int64_t)zp * b + q;
+        if (q < b && row <= (int64_t)last_row) {
+          double2v *xp_ = reinterpret_cast<double2v *>(reinterpret_cast<char *>(F.x) + (size_t)((uint32_t)row << 3));
+          if (row + 1 <= (int64_t)last_row) {
+            const double2v pv = *reinterpret_cast<const double2v *>(pb + (size_t)((uint32_t)row << 3));
+            double2v xv = *xp_;
+            xv.x = __builtin_fma(cg_a, pv.x, xv.x), xv.y = __builtin_fma(cg_a, pv.y, xv.y);
+            *xp_ = xv;
+          } else {
+            F.x[row] = __builtin_fma(cg_a, p_in[row], F.x[row]);
+          }
+        }
+      }
+    }
+    return;
+  }
+
+  double2v pm[2], pc[2], pn[2];
+  u64x2 wc[2];
+  uint32_t rcc[2];
+  bool vac[2], vbc[2];
+  Flight fl;
+  issue(z_begin - 1, false, fl);
+  consume(false, fl, pm, nullptr);
+  issue(z_begin, true, fl);
+  consume(true, fl, pc, tile_sh + (z_begin % 3) * ldw);
+#pragma unroll
+  for (int g = 0; g < 2; ++g) wc[g] = fl.w[g], rcc[g] = fl.rc[g], vac[g] = fl.va[g], vbc[g] = fl.vb[g];
+  issue(z_begin + 1, z_begin + 1 < z_end, fl);
+  double dot_a = 0.0, dot_b = 0.0;
+  for (int zp = z_begin; zp < z_end; ++zp) {
+    const bool next_own = zp + 1 < z_end;
+    u64x2 wn[2];
+    uint32_t rcn[2];
+    bool van[2], vbn[2];
+    consume(next_own, fl, pn, tile_sh + ((zp + 1) % 3) * ldw);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) wn[g] = fl.w[g], rcn[g] = fl.rc[g], van[g] = fl.va[g], vbn[g] = fl.vb[g];
+    if (zp + 2 <= z_end) issue(zp + 2, zp + 2 < z_end, fl);  // (one plane ahead of the one consumed next)
+    __syncthreads();  // the LDS copy of plane zp is complete; the buffer two planes back is free again
+    const double *buf = tile_sh + (zp % 3) * ldw;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int at = a + 256 * wave + 128 * g + 2 * lane;
+      double2v xg[6];
+      xg[0] = pm[g], xg[5] = pn[g];
+      xg[1] = *reinterpret_cast<const double2v *>(&buf[at - a]);
+      xg[4] = *reinterpret_cast<const double2v *>(&buf[at + a]);
+      double el = 0.0;
+      if (lane == 0) el = buf[at - 1];
+      if (lane == kWave - 1) el = buf[at + 2];
+      const double left = dpp_shift<0x138>(pc[g].y);
+      const double right = dpp_shift<0x130>(pc[g].x);
+      xg[2].x = lane == 0 ? el : left;
+      xg[2].y = pc[g].x;
+      xg[3].x = pc[g].y;
+      xg[3].y = lane == kWave - 1 ? el : right;
+      double acc_a = 0.0, acc_b = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const unsigned ba = (unsigned)(wc[g].x >> (8 * (k + 1))) & 0xffu, bb = (unsigned)(wc[g].y >> (8 * (k + 1))) & 0xffu;
+        acc_a += *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + ba) * (xg[k].x - pc[g].x);
+        acc_b += *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + bb) * (xg[k].y - pc[g].y);
+      }
+      const double ext_a = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + ((unsigned)wc[g].x & 0xffu));
+      const double ext_b = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + ((unsigned)wc[g].y & 0xffu));
+      double2v yi;
+      yi.x = __builtin_fma(alpha, __builtin_fma(ext_a, pc[g].x, acc_a), beta * pc[g].x);
+      yi.y = __builtin_fma(alpha, __builtin_fma(ext_b, pc[g].y, acc_b), beta * pc[g].y);
+      double2v *yp = reinterpret_cast<double2v *>(reinterpret_cast<char *>(z_out) + (size_t)(rcc[g] << 3));
+      if (vbc[g]) { if (A.nt_y) __builtin_nontemporal_store(yi, yp); else *yp = yi; }
+      else if (vac[g]) z_out[rcc[g]] = yi.x;
+      yi.x = vac[g] ? yi.x : 0.0;
+      yi.y = vbc[g] ? yi.y : 0.0;
+      dot_a += pc[g].x * yi.x + pc[g].y * yi.y;
+      dot_b += yi.x * yi.x + yi.y * yi.y;
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+      pm[g] = pc[g], pc[g] = pn[g], wc[g] = wn[g], rcc[g] = rcn[g], vac[g] = van[g], vbc[g] = vbn[g];
+  }
+  dot_a = wave_sum_to_lane63(dot_a);
+  if (dot.yy) dot_b = wave_sum_to_lane63(dot_b);
+  if (lane == kWave - 1) {
+    const int slot = dot.block_offset + bidx * (kBlock / kWave) + wave;
+    dot.partials[slot] = dot_a;
+    if (dot.yy) dot.partials[dot.nblocks_total + slot] = dot_b;
+  }
+}
+
 // CSR tail: one wavefront per overflowing row; the lanes' partial products are folded
 // with __shfl_down and lane 0 adds the row's remainder to y.
 __global__ __launch_bounds__(kBlock) void spmv_tail_kernel(int64_t n_tail, const int *__restrict__ tail_row,
@@ -1061,7 +1327,7 @@ static inline int canon_groups(const storm_hip_op *op) { return op->ctx->opt_spm
 // (-b, -a, -1, +1, +a, +b) with a, b even, a <= 512, b >= 2 a, and enough planes to fill tiles.
 static inline int canon_tile_planes(const storm_hip_op *op) {
   const int64_t tz = op->ctx->opt_spmv_canon_tile;
-  return tz == 2 ? 2 : 4;
+  return tz == 4 ? 4 : 2;
 }
 // interior = true: the launch over a partitioned (mixed) operator's interior groups, which must be whole planes
 // [int_plane0, int_plane1) (op_upload_slice_lists checks that).
@@ -1097,7 +1363,7 @@ static inline int op_spw(const storm_hip_op *op) {
 template <bool DOT>
 static void launch_pair(const storm_hip_op *op, int nb, Scal alpha, Scal beta, const double *x, double *y,
                         const int *slice_list, int64_t n_launch, DotArgs dot, const int *done, hipEvent_t ev0,
-                        hipEvent_t ev1, bool accumulate, const IpcFused *fused) {
+                        hipEvent_t ev1, bool accumulate, const IpcFused *fused, const CgFuseArgs *cg_fuse = nullptr) {
   // the interior list of a partitioned operator is consecutive but for a few gaps: the XCD grouping still pays there
   const int group = (slice_list == nullptr || slice_list == op->d_interior) ? (int)op->ctx->opt_spmv_xcd_remap : 0;
   SellArgs A{op->d_pack, op->d_slice_off, op->n_rows, op->uniform_width, group, op->d_dict, op->dict_size,
@@ -1119,15 +1385,19 @@ static void launch_pair(const storm_hip_op *op, int nb, Scal alpha, Scal beta, c
       canon_tile_geometry(op, &T, &tile_blocks, interior_list) && tile_blocks + S.sp.n_blocks == nb) {
     const int tz = canon_tile_planes(op);
     const int hl_need = (tz * T.a + kBlock - 1) / kBlock;
-    const size_t lds = sizeof(double) * (size_t)tz * (size_t)(kTileRun + 2 * T.a);
+    const size_t lds = sizeof(double) * (size_t)tz * (size_t)(kTileRun + 2 * T.a) + (size_t)op->ctx->opt_spmv_tile_lds_pad;
     const bool wload = DOT && dot.w != nullptr && dot.w != x;
 #define TILE_GO3(WL_, TZ_, HL_)                                                                                              \
   hipExtLaunchKernelGGL((spmv_canon_tile_kernel<DOT, WL_, TZ_, HL_>), dim3(nb), dim3(kBlock), lds, st, ev0, ev1, 0, A, T, alpha, \
-                        beta, x, y, dot, done, S)
-#define TILE_GO2(TZ_, HL_)              \
-  do {                                  \
-    if (wload) TILE_GO3(true, TZ_, HL_); \
-    else TILE_GO3(false, TZ_, HL_);      \
+                        beta, x, y, dot, done, S, CgFuseArgs{})
+#define TILE_GO2(TZ_, HL_)                                                                                                   \
+  do {                                                                                                                       \
+    if (cg_fuse != nullptr) {                                                                                                \
+      if constexpr (DOT)                                                                                                     \
+        hipExtLaunchKernelGGL((spmv_canon_tile_kernel<true, false, TZ_, HL_, true>), dim3(nb), dim3(kBlock), lds, st, ev0, ev1, \
+                              0, A, T, alpha, beta, x, y, dot, done, S, *cg_fuse);                                            \
+    } else if (wload) TILE_GO3(true, TZ_, HL_);                                                                              \
+    else TILE_GO3(false, TZ_, HL_);                                                                                          \
   } while (0)
 #define TILE_GO(TZ_)                       \
   do {                                     \
@@ -1243,7 +1513,7 @@ static int interior_blocks(const storm_hip_op *op, bool accumulate, int n_send_b
 }
 static int launch_range(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, double *y,
                         const int *slice_list, int64_t n_launch, DotArgs dot, bool want_dot,
-                        const int *done, bool accumulate, const IpcFused *fused = nullptr) {
+                        const int *done, bool accumulate, const IpcFused *fused = nullptr, const CgFuseArgs *cg_fuse = nullptr) {
   if (n_launch <= 0) return STORM_HIP_OK;
   storm_hip_ctx *c = op->ctx;
   const bool prof = c->opt_profile_spmv != 0;
@@ -1270,7 +1540,7 @@ static int launch_range(const storm_hip_op *op, Scal alpha, Scal beta, const dou
   }
   const bool nt = c->opt_nt != 0;
   if (op->pair) {
-    if (want_dot) launch_pair<true>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1, accumulate, fused);
+    if (want_dot) launch_pair<true>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1, accumulate, fused, cg_fuse);
     else launch_pair<false>(op, nb, alpha, beta, x, y, slice_list, n_launch, dot, done, ev0, ev1, accumulate, fused);
     HIP_TRY(hipGetLastError());
     if (prof) c->prof_used += 2;
@@ -1304,6 +1574,27 @@ static int launch_range(const storm_hip_op *op, Scal alpha, Scal beta, const dou
   HIP_TRY(hipGetLastError());
   if (prof) c->prof_used += 2;
   return STORM_HIP_OK;
+}
+
+// The z-marching form of the fused CG step: blocks of 1024 rows x opt_cg_march planes.
+static bool cg_march_geometry(const storm_hip_op *op, MarchArgs *M, int *n_blocks) {
+  const int64_t zc = op->ctx->opt_cg_march;
+  int nbt = 0;
+  if (zc < 2 || !canon_tile_geometry(op, &M->T, &nbt)) return false;
+  if ((int64_t)sizeof(double) * 3 * (kTileRun + 2 * M->T.a) > 60 * 1024) return false;
+  const int64_t planes = (op->n_rows + M->T.b - 1) / M->T.b;
+  M->zc_planes = (int)std::min<int64_t>(zc, planes);
+  M->T.plane_end = (int)planes;
+  const int64_t chunks = (planes + M->zc_planes - 1) / M->zc_planes;
+  *n_blocks = (int)(chunks * M->T.tiles_per_plane);
+  return true;
+}
+
+// The fused CG step (CgFuseArgs) applies to an operator whose unsplit apply runs the tiled format-4 kernel.
+bool spmv_can_fuse_cg(const storm_hip_op *op) {
+  CanonTileArgs T;
+  int nb = 0;
+  return op->halo.n_nbrs == 0 && op->d_bnd_pack == nullptr && op->tail_rows == 0 && canon_tile_geometry(op, &T, &nb);
 }
 
 int spmv_grid_blocks(const storm_hip_op *op) {
@@ -1347,7 +1638,43 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
   }
 
   if (!split) {
-    STORM_TRY(launch_range(op, alpha, beta, x, y, nullptr, op->n_slices, dot, fuse_dot, done, accumulate));
+    CgFuseArgs cgf{};
+    const bool cg_fused = sd != nullptr && sd->cg.x != nullptr;
+    if (cg_fused) {
+      STORM_REQUIRE(spmv_can_fuse_cg(op) && fuse_dot && !accumulate && dot.tickets == nullptr && sd->w == x,
+                    "spmv: the fused CG step needs the tiled format-4 kernel");
+      cgf = CgFuseArgs{sd->cg.iteration, sd->cg.my_iteration, sd->cg.ca, sd->cg.cb, sd->cg.x, sd->cg.r, sd->cg.p_out};
+    }
+    MarchArgs M;
+    int nb_march = 0;
+    if (cg_fused && cg_march_geometry(op, &M, &nb_march)) {
+      // the z-marching step kernel: its own grid, its own (fewer) partial slots
+      dot.nblocks_total = 4 * nb_march;
+      if (sd->nblocks_out) *sd->nblocks_out = 4 * nb_march;
+      hipEvent_t ev0 = nullptr, ev1 = nullptr;
+      if (c->opt_profile_spmv != 0) {
+        while (c->prof_events.size() < c->prof_used + 2) {
+          hipEvent_t ev;
+          HIP_TRY(hipEventCreate(&ev));
+          c->prof_events.push_back(ev);
+        }
+        ev0 = c->prof_events[c->prof_used], ev1 = c->prof_events[c->prof_used + 1];
+        c->prof_used += 2;
+      }
+      SellArgs A{op->d_pack, op->d_slice_off, op->n_rows, op->uniform_width, 0, op->d_dict, op->dict_size, op->d_offs, op->offs_size, 0};
+      A.nt_y = (int)(c->opt_spmv_nt_y != 0);
+      const size_t lds = sizeof(double) * 3 * (size_t)(kTileRun + 2 * M.T.a);
+      if (M.T.a <= kBlock)
+        hipExtLaunchKernelGGL((cg_step_march_kernel<1>), dim3(nb_march), dim3(kBlock), lds, c->stream, ev0, ev1, 0, A, M, alpha, beta,
+                              x, y, dot, done, cgf);
+      else
+        hipExtLaunchKernelGGL((cg_step_march_kernel<2>), dim3(nb_march), dim3(kBlock), lds, c->stream, ev0, ev1, 0, A, M, alpha, beta,
+                              x, y, dot, done, cgf);
+      HIP_TRY(hipGetLastError());
+      return STORM_HIP_OK;
+    }
+    STORM_TRY(launch_range(op, alpha, beta, x, y, nullptr, op->n_slices, dot, fuse_dot, done, accumulate, nullptr,
+                           cg_fused ? &cgf : nullptr));
   } else {
     // interior rows overlap the halo exchange running on the comm stream
     if (exchange && !fuse_x) STORM_TRY(comm_halo_exchange_begin(op, const_cast<double *>(x)));

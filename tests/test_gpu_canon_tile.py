@@ -16,7 +16,7 @@ def env():
 
     ctx = api.Context(0)
     yield api, mesh, oracle, ctx
-    ctx.set_option("spmv_canon_tile", 4)
+    ctx.set_option("spmv_canon_tile", 2)
     ctx.set_option("spmv_canon_tile_min_rows", 1 << 20)
     ctx.close()
 
@@ -137,3 +137,49 @@ def test_tiled_kernel_full_size_bits_and_direction(env):
         assert np.array_equal(_apply(api, ctx, tiled, x, -1.0, 0.0), y0)
         # a short CG run alternates the sweep direction of consecutive SpMVs; same residuals as the plain kernel's to rounding
         tiled.close()
+
+
+@pytest.mark.parametrize("shape", [(64, 32, 24), (34, 34, 17), (64, 40, 9), (256, 8, 8), (20, 6, 9), (128, 16, 11)])
+def test_fused_cg_step_kernels_give_the_unfused_iteration(env, shape):
+    """CG with the SpMV kernel ending the previous iteration itself (`cg_fuse`: x += alpha p, p' = r + beta p folded into
+    the operator's loads) -- as tiles (`cg_march = 0`) and as blocks marching through the planes (`cg_march = k`, chunks
+    that do and do not divide the plane count) -- against the kernel-per-statement loop: the same residual history to
+    rounding (the partial sums of <p, Ap> group differently), the same iteration count, the same x; and the x update
+    of the converging iteration lands whichever kernel carries it."""
+    api, mesh, oracle, ctx = env
+    g = mesh.structured_box(*shape, lengths=tuple(s / 128.0 for s in shape))
+    ctx.set_option("latency_path", 0)
+    ctx.set_option("spmv_canon_tile_min_rows", 0)
+    ctx.set_option("spmv_canon_tile", 2)
+    try:
+        mat = api.StencilMatrix.from_face_graph(ctx, g)
+        assert mat.stats()["tiled_planes"] == 2
+        b = api.DeviceVector.from_numpy(ctx, 1.0 + 0.5 * np.sin(0.05 * np.arange(g.n_cells)))
+        res = {}
+        for name, fuse, march in (("unfused", 0, 0), ("tiles", 1, 0), ("march16", 1, 16), ("march5", 1, 5), ("march2", 1, 2)):
+            ctx.set_option("cg_fuse", fuse)
+            ctx.set_option("cg_march", march)
+            for iters in (None, 7):  # to convergence; and stopped by the iteration limit (the tail kernel's x update)
+                s = api.CgSolver()
+                s.record_history = True
+                if iters is not None:
+                    s.num_iterations = iters
+                x = api.DeviceVector(ctx, g.n_cells)
+                ok = s.solve(x, b, api.HipStencilOperator(mat, -1.0, 0.0))
+                res[(name, iters)] = (ok, s.iteration, np.array(s.history), x.to_numpy())
+        for iters in (None, 7):
+            ok0, it0, h0, x0 = res[("unfused", iters)]
+            assert ok0 == (iters is None)
+            for name in ("tiles", "march16", "march5", "march2"):
+                ok1, it1, h1, x1 = res[(name, iters)]
+                assert ok1 == ok0 and it1 == it0, (name, iters, it1, it0)
+                assert np.allclose(h1, h0, rtol=1e-9)
+                assert np.linalg.norm(x1 - x0) <= 1e-10 * np.linalg.norm(x0)
+        ref = oracle.solve("cg", oracle.StencilOperator(g, -1.0, 0.0), 1.0 + 0.5 * np.sin(0.05 * np.arange(g.n_cells)))
+        assert abs(res[("march16", None)][1] - ref.iterations) <= 2
+        assert np.linalg.norm(res[("march16", None)][3] - ref.x) <= 1e-8 * np.linalg.norm(ref.x)
+        mat.close()
+    finally:
+        ctx.set_option("latency_path", 1)
+        ctx.set_option("cg_fuse", 1)
+        ctx.set_option("cg_march", 8)

@@ -47,11 +47,15 @@ def main():
 
         # the launches of a CG solve: the fused-dot instantiation <true, ...> of the SpMV kernels; the byte-indexed
         # formats (headline operator) and the fp64 records (roofline_general) are reported separately
-        is_fmt = lambda k: ("spmv_canon_kernel<true" in k) or ("spmv_pair_kernel<true" in k) or ("spmv_dict_kernel<true" in k)  # noqa: E731
+        is_step = lambda k: ("spmv_canon_tile_kernel<true" in k and ", true>" in k) or "cg_step_march_kernel" in k  # noqa: E731  (the fused CG step)
+        is_fmt = lambda k: (("spmv_canon_kernel<true" in k) or ("spmv_pair_kernel<true" in k) or ("spmv_dict_kernel<true" in k) or  # noqa: E731
+                            ("spmv_canon_tile_kernel<true" in k and ", true>" not in k))
         is_sell = lambda k: "spmv_sell_kernel<true, true" in k  # noqa: E731
         method = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950)"
         out = {}
-        fetch, write = avg("FETCH_SIZE", is_fmt), avg("WRITE_SIZE", is_fmt)
+        fetch, write = avg("FETCH_SIZE", is_step), avg("WRITE_SIZE", is_step)
+        if fetch is None or write is None:  # no fused CG step in the run: the SpMV with the fused dot
+            fetch, write = avg("FETCH_SIZE", is_fmt), avg("WRITE_SIZE", is_fmt)
         if fetch is None or write is None:  # the operator did not qualify for a byte-indexed format
             fetch, write = avg("FETCH_SIZE", is_sell), avg("WRITE_SIZE", is_sell)
         if fetch is not None and write is not None:
