@@ -71,11 +71,15 @@ def main() -> int:
                     help="N > 1: comma-separated chain tried in order, each attempt with FRESH rank processes: rccl (halo "
                          "send/recv + all-reduce), ipc (the library's peer-window transport: hipIpc-mapped device memory, "
                          "direct stores over xGMI, rank-ordered all-reduce fused into the reductions' final pass), host "
-                         "(halo planes and scalars staged through host memory over gloo).  Default rccl,ipc,host "
-                         "(--shared-device: ipc,host)")
+                         "(halo planes and scalars staged through host memory over gloo).  Default ipc,rccl,host "
+                         "(--shared-device: ipc,host): the peer-window transport first -- its exchange is fused into the SpMV "
+                         "launches and its all-reduce into the reductions' last block (one rank: +17 us per CG iteration "
+                         "over the single-GPU path, RCCL: +70) -- guarded by the pre-flight before and the post-flight "
+                         "check after the timed region; RCCL next")
     ap.add_argument("--attempt-seconds", default="240,150,150",
                     help="wall-clock budget of the 1st, 2nd, 3rd transport attempt (N > 1)")
-    ap.add_argument("--inject-fail", default="", help="test hook: TRANSPORT=hang|exit|wrong[:RANK] makes that attempt fail")
+    ap.add_argument("--inject-fail", default="", help="test hook: TRANSPORT=hang|exit|wrong|post[:RANK] makes that attempt fail "
+                                                      "(a rank hangs / dies / the pre-flight / the post-flight finds wrong values)")
     ap.add_argument("--force-comm", action="store_true",
                     help="take the multi-rank code path (process group, RCCL communicator, all-reduces) even at N = 1")
     ap.add_argument("--min-seconds", type=float, default=0.25,
@@ -87,7 +91,7 @@ def main() -> int:
     ap.add_argument("--skip-permuted", action="store_true", help="skip the permuted + RCM stress variant (SURVEY.md 8d)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
-    chain = [t for t in (args.transport or ("ipc,host" if args.shared_device else "rccl,ipc,host")).split(",") if t]
+    chain = [t for t in (args.transport or ("ipc,host" if args.shared_device else "ipc,rccl,host")).split(",") if t]
     for t in chain:
         if t not in ("rccl", "ipc", "host"):
             ap.error(f"unknown transport {t!r}")
@@ -145,7 +149,7 @@ def main() -> int:
         else:
             dist.connect(ctx_)
 
-    preflight = None
+    preflight, inject_post = None, False
     if world > 1:
         inject = dict(kv.split("=") for kv in args.inject_fail.split(",") if "=" in kv).get(transport, "")
         kind, _, who = inject.partition(":")
@@ -158,6 +162,7 @@ def main() -> int:
 
             _sig.alarm(0)
             time.sleep(3600)
+        inject_post = hit and kind == "post"
         preflight = run_preflight(api, dist, mesh, partition, connect, local_rank, world, rank, wrong=hit and kind == "wrong")
     if os.environ.get("STORM_BENCH_WORKER") == "1":
         import signal
@@ -276,6 +281,37 @@ def main() -> int:
             break
     elapsed = float(np.median(repeats))
     final_residual = s.absolute_error
+
+    # ---- N > 1: post-flight.  The timed region ran the production kernels on the production transport; before its
+    # number is reported, (1) the fused CG step must agree with the kernel-per-statement loop on the same transport
+    # (same K iterations, residual to 1e-9) and (2) ONE apply of the full-size operator to x = global plane index must
+    # vanish on every row away from the walls -- which fails iff a halo plane is stale or misplaced.  Any failure ends
+    # this process with an error: the supervisors then start fresh ranks on the next transport.
+    postflight = None
+    if world > 1:
+        ctx.set_option("cg_fuse", 0)
+        s_ref, _ = run(K)
+        ctx.set_option("cg_fuse", 1)
+        res_diff = abs(s_ref.absolute_error - final_residual) / final_residual
+        kz = (np.asarray(g.global_id[:N], dtype=np.int64) // (n * n)).astype(np.float64)
+        xz = api.DeviceVector(ctx, N, g.n_halo)
+        xz.upload(kz)
+        yz = api.DeviceVector(ctx, N, g.n_halo)
+        op.mul(yz, xz)
+        gid = np.asarray(g.global_id[:N], dtype=np.int64)
+        ii, jj, kk = gid % n, (gid // n) % n, gid // (n * n)
+        away = (ii > 0) & (ii < n - 1) & (jj > 0) & (jj < n - 1) & (kk > 0) & (kk < n * world - 1)
+        # (a wrong plane shows as +-1 times a face weight ~ n^2; spacings that are not exact in binary leave ~1e-16 n^3)
+        bad_rows = int(np.count_nonzero(np.abs(yz.to_numpy()[away]) > 1e-6 * n * n))
+        ok_all = dist.allreduce_max(0.0 if (bad_rows == 0 and res_diff <= 1e-9 and np.isfinite(final_residual) and
+                                            not inject_post) else 1.0) == 0.0
+        postflight = {"ok": ok_all, "halo_rows_wrong_on_this_rank": bad_rows,
+                      "fused_vs_unfused_residual_rel_diff": res_diff, "steps_compared": K}
+        del xz, yz
+        if not ok_all:
+            print(f"bench.py: post-flight FAILED on rank {rank}: {postflight}", file=sys.stderr, flush=True)
+            dist.barrier()
+            os._exit(43)
 
     # ---- roofline of the SpMV: HIP-event pairs around every launch --------------------------------
     march_planes = 8  # the library's default for option cg_march (csrc/common.hpp)
@@ -497,6 +533,7 @@ def main() -> int:
         if world > 1:
             out["transport"] = transport
             out["preflight"] = preflight
+            out["postflight"] = postflight
         print(json.dumps(out), flush=True)
     dist.barrier()
     try:  # leave no dangling process group / communicator behind
@@ -679,7 +716,7 @@ def launch_ranks(n_ranks: int, args) -> int:
     env = dict(os.environ)
     env.setdefault("OMP_NUM_THREADS", "1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    n_chain = len((args.transport or ("ipc,host" if args.shared_device else "rccl,ipc,host")).split(","))
+    n_chain = len((args.transport or ("ipc,host" if args.shared_device else "ipc,rccl,host")).split(","))
     budgets = [float(v) for v in args.attempt_seconds.split(",")]
     total = sum(budgets[min(i, len(budgets) - 1)] for i in range(n_chain)) + 120.0
     child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)

@@ -446,7 +446,14 @@ int storm_hip_ctx_comm_ipc_export(storm_hip_ctx *c, int n_ranks, int rank, int64
                n_ranks);
   }
   cm->win_bytes = header + 2 * P * cm->seg_bytes;
-  hipError_t e = hipMalloc((void **)&cm->win_local, (size_t)cm->win_bytes);
+  // Fine-grained device memory (what collective libraries allocate for their low-latency protocols): another GPU's
+  // stores into it and this GPU's polling loads meet in memory while kernels run on both sides.  (An allocation the
+  // runtime refuses that way falls back to hipMalloc: every access to the window is a system-scope `sc0 sc1` one.)
+  hipError_t e = hipExtMallocWithFlags((void **)&cm->win_local, (size_t)cm->win_bytes, hipDeviceMallocFinegrained);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    e = hipMalloc((void **)&cm->win_local, (size_t)cm->win_bytes);
+  }
   if (e == hipSuccess) e = hipMemset(cm->win_local, 0, (size_t)cm->win_bytes);
   hipIpcMemHandle_t handle;
   if (e == hipSuccess) e = hipIpcGetMemHandle(&handle, cm->win_local);

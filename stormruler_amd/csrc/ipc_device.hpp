@@ -183,7 +183,10 @@ struct IpcRecvPlan {
 
 // Block `b` of the plan's n_blocks sending blocks (all 256 threads).  Waits (bounded) until every receiver has
 // acknowledged the plane that used this parity's segment two exchanges ago, then stores its share of the rows.
-__device__ inline void ipc_halo_send_block(const IpcDev &w, const IpcSendPlan &s, const double *__restrict__ x, int b) {
+// r != null: the rows sent are those of the NEW direction r + cb x, formed on the fly with the owner's expression (the
+// fused CG step: the direction is not in memory yet when its boundary planes must leave).
+__device__ inline void ipc_halo_send_block(const IpcDev &w, const IpcSendPlan &s, const double *__restrict__ x, int b,
+                                           const double *__restrict__ r = nullptr, double cb = 0.0) {
   if (threadIdx.x < (unsigned)s.n_entries && s.epoch[threadIdx.x] > 2)
     (void)ipc_wait_ge(reinterpret_cast<const unsigned long long *>(w.local + w.ack_off + (int64_t)s.peer[threadIdx.x] * 64),
                       s.epoch[threadIdx.x] - 2, w.error);
@@ -194,8 +197,9 @@ __device__ inline void ipc_halo_send_block(const IpcDev &w, const IpcSendPlan &s
     while (q + 1 < s.n_entries && i >= s.ptr[q + 1]) ++q;
     const unsigned long long e = s.epoch[q];
     const int64_t seg = w.data_off + ((int64_t)(e & 1) * w.n_ranks + w.rank) * w.seg_bytes;
-    ipc_store16(w.peers[s.peer[q]] + seg + 16 * (int64_t)(s.dst_off[q] + i - s.ptr[q]),
-                ipc_tagged(x[s.idx[i]], (e & 0xffffffffull) << 32));
+    const int row = s.idx[i];
+    const double v = r ? __builtin_fma(cb, x[row], r[row]) : x[row];
+    ipc_store16(w.peers[s.peer[q]] + seg + 16 * (int64_t)(s.dst_off[q] + i - s.ptr[q]), ipc_tagged(v, (e & 0xffffffffull) << 32));
   }
 }
 // Halo row h (0 <= h < ptr[n_entries]) as its sender stored it for this exchange; polls (bounded) until it is there.
@@ -206,6 +210,34 @@ __device__ __forceinline__ double ipc_halo_value(const IpcDev &w, const IpcRecvP
   const char *p = w.local + w.data_off + ((int64_t)(e & 1) * w.n_ranks + r.peer[q]) * w.seg_bytes +
                   16 * (int64_t)(r.src_off[q] + h - r.ptr[q]);
   return ipc_poll_value(p, (e & 0xffffffffull) << 32, w.error);
+}
+// Two halo rows at once (the pair a lane of the paired-row kernels gathers): both loads in flight together, one wait;
+// the bounded poll only where a tag is not there yet.  h < 0 or h >= n_halo: no such row, 0.0.
+__device__ __forceinline__ void ipc_halo_pair(const IpcDev &w, const IpcRecvPlan &r, int ha, int hb, int n_halo, double *va, double *vb) {
+  const bool oa = ha >= 0 && ha < n_halo, ob = hb >= 0 && hb < n_halo;
+  const char *pa = w.local, *pb = w.local;  // (a valid address for the lane that has nothing to read)
+  unsigned long long ta = 0ull, tb = 0ull;
+  if (oa) {
+    int q = 0;
+    while (q + 1 < r.n_entries && ha >= r.ptr[q + 1]) ++q;
+    const unsigned long long e = r.epoch[q];
+    pa = w.local + w.data_off + ((int64_t)(e & 1) * w.n_ranks + r.peer[q]) * w.seg_bytes + 16 * (int64_t)(r.src_off[q] + ha - r.ptr[q]);
+    ta = (e & 0xffffffffull) << 32;
+  }
+  if (ob) {
+    int q = 0;
+    while (q + 1 < r.n_entries && hb >= r.ptr[q + 1]) ++q;
+    const unsigned long long e = r.epoch[q];
+    pb = w.local + w.data_off + ((int64_t)(e & 1) * w.n_ranks + r.peer[q]) * w.seg_bytes + 16 * (int64_t)(r.src_off[q] + hb - r.ptr[q]);
+    tb = (e & 0xffffffffull) << 32;
+  }
+  ipc_u64x2 wa, wb;
+  asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %3, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(wa), "=&v"(wb)
+               : "v"(pa), "v"(pb)
+               : "memory");
+  *va = oa ? (ipc_tag_ok(wa, ta) ? ipc_untag(wa) : ipc_poll_value(pa, ta, w.error)) : 0.0;
+  *vb = ob ? (ipc_tag_ok(wb, tb) ? ipc_untag(wb) : ipc_poll_value(pb, tb, w.error)) : 0.0;
 }
 // Every block of a kernel that consumed halo values calls this at its end (all threads): the last block to arrive
 // tells every sender that its plane has been consumed.

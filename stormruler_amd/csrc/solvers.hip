@@ -1054,7 +1054,8 @@ int solve_cg_body(const FusedSolveArgs &args) {
   // x += alpha p, p' = r + beta p -- on the rows it loads anyway and applies the operator to p': x and p are no longer
   // streamed by a kernel of their own (cg_xp).  p ping-pongs between two vectors (a tile's old p is another tile's
   // halo).  Two launches + the small first pass per iteration; the last iteration's x update runs behind the loop.
-  const bool fuse_step = c->opt_cg_fuse != 0 && c->comm == nullptr && tick && !tick_spmv && c->opt_fuse_dot != 0 &&
+  // (on the peer-window transport too: the marching launch also sends p' of the boundary rows, spmv.hip)
+  const bool fuse_step = c->opt_cg_fuse != 0 && (c->comm == nullptr || ipc) && tick && !tick_spmv && c->opt_fuse_dot != 0 &&
                          spmv_can_fuse_cg(op);
   double *p_alt = nullptr;
   if (fuse_step) {

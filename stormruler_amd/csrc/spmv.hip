@@ -578,8 +578,10 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(SellArgs A, Scal alph
     if (HALO && ca + 1 >= (int)A.n_rows) {
       // (an absent slot's column may point anywhere: beyond the halo rows it reads as 0, like x's zero padding)
       const int ha = ca - (int)A.n_rows, hb = ha + 1;
-      xg[k].x = ha < 0 ? x[ca] : (ha < H.n_halo ? ipc_halo_value(H.w, H.rp, ha) : 0.0);
-      xg[k].y = hb < H.n_halo ? ipc_halo_value(H.w, H.rp, hb) : 0.0;
+      double va, vb;
+      ipc_halo_pair(H.w, H.rp, ha, hb, H.n_halo, &va, &vb);
+      xg[k].x = ha < 0 ? x[ca] : va;
+      xg[k].y = vb;
     } else {
       xg[k] = *reinterpret_cast<const double2v *>(xg_base + (size_t)((rc + (uint32_t)(off + kVecGuard)) << 3));
     }
@@ -1072,11 +1074,19 @@ __global__ __launch_bounds__(kBlock) void spmv_canon_tile_kernel(SellArgs A, Can
 struct MarchArgs {
   CanonTileArgs T;   // a, b, tiles_per_plane, per_xcd, max_gather, reverse, plane_end (= number of planes)
   int zc_planes;     // planes per block
+  int apply_begin, apply_end;  // planes the operator is applied to (a partitioned operator: those that read no halo
+                               // column -- the others get x and p' here and their z from the boundary launch)
 };
 template <int HLP>  // halo pairs per thread and plane: ceil(a / 256)
 __global__ __launch_bounds__(kBlock) void cg_step_march_kernel(SellArgs A, MarchArgs M, Scal alpha_s, Scal beta_s,
                                                                const double *__restrict__ p_in, double *__restrict__ z_out,
-                                                               DotArgs dot, const int *done, CgFuseArgs F) {
+                                                               DotArgs dot, const int *done, CgFuseArgs F, IpcSendArgs S) {
+  if ((int)blockIdx.x < S.sp.n_blocks) {
+    // a partitioned operator: the first blocks send the NEW direction's boundary rows (whatever the iteration gate
+    // below says: every rank enqueues the same exchanges, and the receivers poll for them)
+    ipc_halo_send_block(S.w, S.sp, p_in, (int)blockIdx.x, F.r, *F.cb);
+    return;
+  }
   if (*F.iteration < F.my_iteration) return;  // enqueued past convergence: that iteration never ran
   const int done_flag = done ? *done : 0;
   const CanonTileArgs &T = M.T;
@@ -1084,7 +1094,8 @@ __global__ __launch_bounds__(kBlock) void cg_step_march_kernel(SellArgs A, March
   __shared__ double dict_sh[32];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int bidx = T.reverse ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+  const int n_march = (int)gridDim.x - S.sp.n_blocks, mb = (int)blockIdx.x - S.sp.n_blocks;
+  const int bidx = T.reverse ? n_march - 1 - mb : mb;
   int zc, yt;
   if (T.per_xcd > 0) {
     const int xcd = bidx & (kNumXcd - 1), j = bidx >> 3;
@@ -1223,8 +1234,10 @@ __global__ __launch_bounds__(kBlock) void cg_step_march_kernel(SellArgs A, March
     if (zp + 2 <= z_end) issue(zp + 2, zp + 2 < z_end, fl);  // (one plane ahead of the one consumed next)
     __syncthreads();  // the LDS copy of plane zp is complete; the buffer two planes back is free again
     const double *buf = tile_sh + (zp % 3) * ldw;
+    const bool applies = zp >= M.apply_begin && zp < M.apply_end;  // (block-uniform)
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
+      if (!applies) break;
       const int at = a + 256 * wave + 128 * g + 2 * lane;
       double2v xg[6];
       xg[0] = pm[g], xg[5] = pn[g];
@@ -1577,14 +1590,19 @@ static int launch_range(const storm_hip_op *op, Scal alpha, Scal beta, const dou
 }
 
 // The z-marching form of the fused CG step: blocks of 1024 rows x opt_cg_march planes.
-static bool cg_march_geometry(const storm_hip_op *op, MarchArgs *M, int *n_blocks) {
+// partitioned: a mixed operator (interior planes on format 4, boundary groups on format 3): the march covers ALL owned
+// planes for x and p', applies the operator to the interior ones.
+static bool cg_march_geometry(const storm_hip_op *op, MarchArgs *M, int *n_blocks, bool partitioned = false) {
   const int64_t zc = op->ctx->opt_cg_march;
   int nbt = 0;
-  if (zc < 2 || !canon_tile_geometry(op, &M->T, &nbt)) return false;
+  if (zc < 2 || !canon_tile_geometry(op, &M->T, &nbt, partitioned)) return false;
   if ((int64_t)sizeof(double) * 3 * (kTileRun + 2 * M->T.a) > 60 * 1024) return false;
+  if (partitioned && op->n_rows % M->T.b != 0) return false;  // (whole planes only)
   const int64_t planes = (op->n_rows + M->T.b - 1) / M->T.b;
   M->zc_planes = (int)std::min<int64_t>(zc, planes);
-  M->T.plane_end = (int)planes;
+  M->apply_begin = partitioned ? (int)op->int_plane0 : 0;
+  M->apply_end = partitioned ? (int)op->int_plane1 : (int)planes;
+  M->T.plane0 = 0, M->T.plane_end = (int)planes;
   const int64_t chunks = (planes + M->zc_planes - 1) / M->zc_planes;
   *n_blocks = (int)(chunks * M->T.tiles_per_plane);
   return true;
@@ -1594,7 +1612,11 @@ static bool cg_march_geometry(const storm_hip_op *op, MarchArgs *M, int *n_block
 bool spmv_can_fuse_cg(const storm_hip_op *op) {
   CanonTileArgs T;
   int nb = 0;
-  return op->halo.n_nbrs == 0 && op->d_bnd_pack == nullptr && op->tail_rows == 0 && canon_tile_geometry(op, &T, &nb);
+  if (op->halo.n_nbrs == 0 && op->d_bnd_pack == nullptr && op->tail_rows == 0 && canon_tile_geometry(op, &T, &nb)) return true;
+  // ... or a partitioned (mixed) operator on the peer-window transport, whose boundary launch reads the window itself
+  MarchArgs M;
+  return op->halo.n_nbrs > 0 && op->d_bnd_pack != nullptr && op->tail_rows == 0 && comm_is_ipc(op->ctx) &&
+         op->ctx->opt_ipc_fused != 0 && op->n_boundary > 0 && cg_march_geometry(op, &M, &nb, true);
 }
 
 int spmv_grid_blocks(const storm_hip_op *op) {
@@ -1666,16 +1688,57 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
       const size_t lds = sizeof(double) * 3 * (size_t)(kTileRun + 2 * M.T.a);
       if (M.T.a <= kBlock)
         hipExtLaunchKernelGGL((cg_step_march_kernel<1>), dim3(nb_march), dim3(kBlock), lds, c->stream, ev0, ev1, 0, A, M, alpha, beta,
-                              x, y, dot, done, cgf);
+                              x, y, dot, done, cgf, IpcSendArgs{});
       else
         hipExtLaunchKernelGGL((cg_step_march_kernel<2>), dim3(nb_march), dim3(kBlock), lds, c->stream, ev0, ev1, 0, A, M, alpha, beta,
-                              x, y, dot, done, cgf);
+                              x, y, dot, done, cgf, IpcSendArgs{});
       HIP_TRY(hipGetLastError());
       return STORM_HIP_OK;
     }
     STORM_TRY(launch_range(op, alpha, beta, x, y, nullptr, op->n_slices, dot, fuse_dot, done, accumulate, nullptr,
                            cg_fused ? &cgf : nullptr));
   } else {
+    const bool cg_fused_part = sd != nullptr && sd->cg.x != nullptr;
+    if (cg_fused_part) {
+      // The fused CG step on a partitioned operator (peer-window transport): ONE marching launch updates x and forms
+      // p' on every owned plane, applies the operator to the interior planes and -- its first blocks -- sends p' of the
+      // boundary rows; the boundary launch then reads p' (owned columns) and the window (halo columns).
+      MarchArgs M;
+      int nb_march = 0;
+      STORM_REQUIRE(fuse_x && fuse_dot && !accumulate && sd->w == x && cg_march_geometry(op, &M, &nb_march, true),
+                    "spmv: the fused CG step on a partitioned operator needs the peer-window transport and a lattice");
+      const CgFuseArgs cgf{sd->cg.iteration, sd->cg.my_iteration, sd->cg.ca, sd->cg.cb, sd->cg.x, sd->cg.r, sd->cg.p_out};
+      const int nb_b = blocks_for(op, op->n_boundary, true);
+      STORM_REQUIRE(8 * (int64_t)(nb_march + nb_b) <= c->partials_capacity, "spmv: %d blocks exceed the partials workspace", nb_march + nb_b);
+      dot = DotArgs{sd->cg.p_out, sd->partials, sd->yy ? 1 : 0, 4 * (nb_march + nb_b), 0};
+      if (sd->nblocks_out) *sd->nblocks_out = 4 * (nb_march + nb_b);
+      hipEvent_t ev0 = nullptr, ev1 = nullptr;
+      if (c->opt_profile_spmv != 0) {
+        while (c->prof_events.size() < c->prof_used + 2) {
+          hipEvent_t ev;
+          HIP_TRY(hipEventCreate(&ev));
+          c->prof_events.push_back(ev);
+        }
+        ev0 = c->prof_events[c->prof_used], ev1 = c->prof_events[c->prof_used + 1];
+        c->prof_used += 2;
+      }
+      SellArgs A{op->d_pack, op->d_slice_off, op->n_rows, op->uniform_width, 0, op->d_dict, op->dict_size, op->d_offs, op->offs_size, 0};
+      A.nt_y = (int)(c->opt_spmv_nt_y != 0);
+      const size_t lds = sizeof(double) * 3 * (size_t)(kTileRun + 2 * M.T.a);
+      IpcSendArgs S{fx.w, fx.sp};
+      // (the march kernel's own dots use w = p' from its registers; DotArgs::w only has to be non-null there)
+      if (M.T.a <= kBlock)
+        hipExtLaunchKernelGGL((cg_step_march_kernel<1>), dim3(nb_march + S.sp.n_blocks), dim3(kBlock), lds, c->stream, ev0, ev1, 0, A, M,
+                              alpha, beta, x, y, dot, done, cgf, S);
+      else
+        hipExtLaunchKernelGGL((cg_step_march_kernel<2>), dim3(nb_march + S.sp.n_blocks), dim3(kBlock), lds, c->stream, ev0, ev1, 0, A, M,
+                              alpha, beta, x, y, dot, done, cgf, S);
+      HIP_TRY(hipGetLastError());
+      dot.block_offset = 4 * nb_march;
+      // the boundary groups: z = A p' from p_out and the window; <p', z> partials behind the march's
+      STORM_TRY(launch_range(op, alpha, beta, sd->cg.p_out, y, op->d_boundary, op->n_boundary, dot, fuse_dot, done, accumulate, &fx));
+      return STORM_HIP_OK;
+    }
     // interior rows overlap the halo exchange running on the comm stream
     if (exchange && !fuse_x) STORM_TRY(comm_halo_exchange_begin(op, const_cast<double *>(x)));
     if (fuse_x && op->n_interior == 0) STORM_TRY(comm_ipc_send(op, x, fx.w, fx.sp));

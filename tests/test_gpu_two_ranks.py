@@ -25,7 +25,7 @@ def _free_port():
 
 
 @pytest.mark.parametrize("transport", ["host", "ipc"])
-@pytest.mark.parametrize("world,dims", [(2, (16, 12, 8)), (3, (20, 8, 5)), (4, (12, 12, 4))])
+@pytest.mark.parametrize("world,dims", [(2, (16, 12, 8)), (3, (20, 8, 5)), (4, (12, 12, 4)), (2, (64, 16, 12))])
 def test_partitioned_device_path_matches_the_global_oracle(world, dims, transport, tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
@@ -91,11 +91,13 @@ def test_bench_script_multi_rank_path(world, transport):
     assert out["n_gpus"] == world and out["steps"] == 20 and out["value"] > 0 and out["scaling"] == "weak"
     assert out["transport"] == transport and out["transport_fallback"] == []
     assert out["preflight"]["ok"] and out["preflight"]["allreduce_sum"] == out["preflight"]["expected_sum"]
+    assert out["postflight"]["ok"] and out["postflight"]["halo_rows_wrong_on_this_rank"] == 0
+    assert out["postflight"]["fused_vs_unfused_residual_rel_diff"] <= 1e-9
     assert out["roofline"]["launches_timed"] >= 20 + 1  # one launch per apply, or an interior + a boundary launch
     assert 0.0 < out["roofline"]["frac"] <= 1.0 and out["timing"]["repeats"] >= 1
 
 
-@pytest.mark.parametrize("how", ["exit:1", "hang:0", "wrong"])
+@pytest.mark.parametrize("how", ["exit:1", "hang:0", "wrong", "post:1"])
 def test_bench_falls_back_to_the_next_transport_with_fresh_ranks(how):
     """A transport that fails -- a rank dies, a rank hangs (budget), or the pre-flight finds wrong halo values -- costs
     its budget, not the run: all rank processes of the attempt are ended and a FRESH set starts on the next
