@@ -152,3 +152,15 @@ def test_bench_line_contract_at_one_gpu():
     cpu = out["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0 and cpu["gpu_vs_cpu_residual_rel_diff"] <= 1e-9
     assert out["timing"]["repeats"] >= 1 and out["value"] > 10 * cpu["value"]
+
+
+def test_bench_two_ranks_on_the_production_kernels():
+    """Two ranks (sharing the one GPU, peer-window transport) at 128^3 per rank: large enough for the lattice kernels --
+    tiled interior launch with the sending blocks, the marching fused CG step, the boundary launch that reads the
+    window -- so the multi-process windows carry exactly what an N-GPU run does; the post-flight check (halo test at
+    full size + fused against unfused residual) must pass and no fallback may have happened."""
+    out, _ = _run_bench(["--gpus", "2", "--transport", "ipc,host", "--edge", "128", "--steps", "30"], timeout=600)
+    assert out["transport"] == "ipc" and out["transport_fallback"] == []
+    assert out["postflight"]["ok"] and out["postflight"]["fused_vs_unfused_residual_rel_diff"] <= 1e-9
+    assert out["op_stats"]["tiled_planes"] == 2 and out["op_stats"]["paired_rows"] == 2
+    assert out["roofline"]["launches_timed"] >= 2 * 31  # per apply: the interior / marching launch + the boundary launch
