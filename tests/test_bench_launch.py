@@ -1,8 +1,8 @@
 """`python bench.py --gpus N` as the driver calls it (no launcher in front) must start its own ranks.
 
-On a box without a GPU every rank stops at "needs an MI355X" (rc 3) -- what this checks is that the ranks WERE
-started (child processes through torch.distributed.run on 127.0.0.1) and that their exit code is relayed, instead of
-the rc 2 "launch me under torchrun" refusal of round 1."""
+On a box without a GPU every measuring rank stops at "needs an MI355X" (rc 3) -- what this checks is that the ranks WERE
+started (rank supervisors through torch.distributed.run on 127.0.0.1, each starting its measuring child per transport
+attempt) and that the failure is relayed, instead of the rc 2 "launch me under torchrun" refusal of round 1."""
 import os
 import subprocess
 import sys
@@ -21,4 +21,8 @@ def test_bench_starts_its_own_ranks():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode not in (0, 2), (p.returncode, p.stderr[-2000:])
-    assert p.stderr.count("bench.py needs an MI355X") == 2, p.stderr[-3000:]  # both ranks ran main()
+    # both ranks ran main() -- once per transport of the default chain (ipc, rccl, host): the rank supervisors start a
+    # fresh pair of children for every attempt (round 3)
+    # (a supervisor ends its child as soon as ANY rank's child has failed: between one and two messages per attempt)
+    assert 3 <= p.stderr.count("bench.py needs an MI355X") <= 2 * 3, p.stderr[-3000:]
+    assert "starting fresh ranks on rccl" in p.stderr and "no transport left" in p.stderr
