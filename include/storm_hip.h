@@ -154,6 +154,10 @@ int storm_hip_vmul_add(storm_hip_vec *y, double s, const storm_hip_vec *a, const
  * pre_op hook of Solvers/Solver.hpp:74-75 (the reference ships only IdentityPreconditioner,
  * Preconditioner.hpp:84-97).  y may alias a or b. */
 int storm_hip_vmul(storm_hip_vec *y, const storm_hip_vec *a, const storm_hip_vec *b);
+/* y = (s * a) ./ b, elementwise; a == NULL: y = s ./ b.  The quotient nodes of the reference's expression
+ * templates, `scalar / mat` and `mat1 / mat2` (Bittern/MatrixMath.hpp:261-265, :298-302; known answers
+ * tests/unit/BitternMath.cpp:160-171).  Not in the solver census.  y may alias a or b. */
+int storm_hip_vdiv(storm_hip_vec *y, double s, const storm_hip_vec *a, const storm_hip_vec *b);
 /* fill_randomly(y)  Bittern/MatrixAlgorithms.hpp:140-153: uniform [0, 1) numbers from a
  * function-static std::mt19937_64{} (default seed, state persists across calls), drawn
  * sequentially on the host in row order and uploaded -- the same engine, distribution and

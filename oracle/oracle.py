@@ -96,6 +96,7 @@ def lib(variant: str = "strict"):
         L.oracle_div_scalar.argtypes = [C.c_int64, f64p, C.c_double]
         L.oracle_mul_scalar.argtypes = [C.c_int64, f64p, C.c_double]
         L.oracle_expr1.argtypes = [C.c_int64, f64p, f64p, C.c_double, f64p, f64p]
+        L.oracle_vdiv.argtypes = [C.c_int64, f64p, C.c_double, f64p, f64p]
         L.oracle_rng_next.restype = C.c_uint64
         L.oracle_fill_randomly.argtypes = [C.c_int64, f64p]
         L.oracle_divgrad.argtypes = [C.POINTER(_Mesh), f64p, C.c_double, f64p]
@@ -214,6 +215,14 @@ def expr1(a, s, b, c) -> np.ndarray:
     a, b, c = f64(a).ravel(), f64(b).ravel(), f64(c).ravel()
     out = np.empty_like(a)
     lib().oracle_expr1(a.size, _p(out), _p(a), s, _p(b), _p(c))
+    return out
+
+
+def vdiv(s, a, b) -> np.ndarray:
+    """``(s * a) / b`` elementwise, ``a is None``: ``s / b`` (MatrixMath.hpp:261-265, :298-302)."""
+    b = f64(b).ravel()
+    out = np.empty_like(b)
+    lib().oracle_vdiv(b.size, _p(out), float(s), None if a is None else _p(f64(a).ravel()), _p(b))
     return out
 
 

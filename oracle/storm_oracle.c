@@ -164,6 +164,13 @@ ORACLE_API void oracle_expr1(int64_t n, double *out, const double *a, double s,
   for (int64_t i = 0; i < n; ++i) out[i] = a[i] + s * (b[i] - c[i]);
 }
 
+/* out <<= (s * a) / b, or s / b when a == NULL: the quotient nodes of          */
+/* Bittern/MatrixMath.hpp:261-265 (scalar / mat) and :298-302 (mat1 / mat2);   */
+/* KATs expr-3 / expr-4, tests/unit/BitternMath.cpp:160-171.                   */
+ORACLE_API void oracle_vdiv(int64_t n, double *out, double s, const double *a, const double *b) {
+  for (int64_t i = 0; i < n; ++i) out[i] = a ? (s * a[i]) / b[i] : s / b[i];
+}
+
 /* ------------------------------------------------------------------------ */
 /* The face graph: what stormDivGrad reads through the Mallard accessors     */
 /* (Mesh.hpp:240-282 FaceView::inner_cell/outer_cell/area, :290-323          */

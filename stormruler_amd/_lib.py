@@ -94,6 +94,7 @@ SIGNATURES = {
     "storm_hip_rng_reset": (None, []),
     "storm_hip_lin3": (C.c_int, [vp, vp, C.c_double, C.c_double, vp, C.c_double, vp]),
     "storm_hip_vmul_add": (C.c_int, [vp, C.c_double, vp, vp]),
+    "storm_hip_vdiv": (C.c_int, [vp, C.c_double, vp, vp]),
     "storm_hip_vmul": (C.c_int, [vp, vp, vp]),
     "storm_hip_dot": (C.c_int, [vp, vp, f64p]),
     "storm_hip_norm2": (C.c_int, [vp, f64p]),

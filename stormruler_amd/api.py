@@ -360,6 +360,11 @@ def vmul(y: DeviceVector, a: DeviceVector, b: DeviceVector) -> None:
     check(lib.storm_hip_vmul(y._h, a._h, b._h))
 
 
+def vdiv(y: DeviceVector, s: float, a: Optional[DeviceVector], b: DeviceVector) -> None:
+    """``y = (s * a) / b`` elementwise; ``a is None``: ``y = s / b`` (MatrixMath.hpp:261-265, :298-302)."""
+    check(lib.storm_hip_vdiv(y._h, float(s), None if a is None else a._h, b._h))
+
+
 def fill_randomly(a: DeviceVector) -> None:
     """Bittern/MatrixAlgorithms.hpp:140-153 (same engine / distribution / sequence as the reference)."""
     check(lib.storm_hip_fill_randomly(a._h))

@@ -127,6 +127,16 @@ struct VmulF {
   __device__ double operator()(double, double a, double b) const { return a * b; }
 };
 
+// y = (s * x0) / x1  (x0 absent: y = s / x1): the elementwise quotients of Bittern/MatrixMath.hpp:261-265, :298-302
+struct VdivF {
+  double s;
+  int has_a;
+  static constexpr bool reads_y = false;
+  static constexpr int nin = 2;
+  __device__ void prepare() {}
+  __device__ double operator()(double, double a, double b) const { return has_a ? (s * a) / b : s / b; }
+};
+
 template <class F>
 static int launch_ew(storm_hip_ctx *c, int64_t n, EwPtrs p, F f, const int *done) {
   if (n <= 0) return STORM_HIP_OK;
@@ -539,6 +549,13 @@ int storm_hip_vmul(storm_hip_vec *y, const storm_hip_vec *a, const storm_hip_vec
   STORM_TRY(check_pair(y, b, "vmul"));
   if (y->n_owned <= 0) return STORM_HIP_OK;
   return launch_ew(y->ctx, y->n_owned, EwPtrs{y->d, a->d, b->d}, VmulF{}, y->ctx->api_done);
+}
+
+int storm_hip_vdiv(storm_hip_vec *y, double s, const storm_hip_vec *a, const storm_hip_vec *b) {
+  STORM_TRY(check_pair(y, b, "vdiv"));
+  if (a) STORM_TRY(check_pair(y, a, "vdiv"));
+  if (y->n_owned <= 0) return STORM_HIP_OK;
+  return launch_ew(y->ctx, y->n_owned, EwPtrs{y->d, a ? a->d : b->d, b->d}, VdivF{s, a ? 1 : 0}, y->ctx->api_done);
 }
 
 int storm_hip_bicgstab_p(storm_hip_vec *p, const storm_hip_vec *r, double beta, double omega,

@@ -71,6 +71,20 @@ def test_blas1_reference_kats(api, ctx, golden):
     quot <<= c2 / e2["hundredth"]
     prod += quot
     assert np.array_equal(prod.to_numpy(), np.array(e2["result"]))
+    # 24 / +mat1 + (18 mat3 - 4 mat2) and 2 ((9 mat1 / mat3) - mat2), exact (BitternMath.cpp:160-171): the quotient nodes
+    e3, e4 = k["expr_3"], k["expr_4"]
+    a3, b3, c3 = (api.DeviceVector.from_numpy(ctx, np.array(e3[n])) for n in ("mat1", "mat2", "mat3"))
+    q3, t3 = api.DeviceVector(ctx, 4), api.DeviceVector(ctx, 4)
+    api.vdiv(q3, 24.0, None, a3)
+    t3 <<= 18.0 * c3
+    t3 -= 4.0 * b3
+    q3 += t3
+    assert np.array_equal(q3.to_numpy(), np.array(e3["result"]))
+    q4 = api.DeviceVector(ctx, 4)
+    api.vdiv(q4, 9.0, a3, c3)
+    q4 -= b3
+    q4 *= 2.0
+    assert np.array_equal(q4.to_numpy(), np.array(e4["result"]))
     # normalize(0) = 0 -> safe_divide
     assert api.safe_divide(1.0, 0.0) == 0.0
 

@@ -49,6 +49,22 @@ def test_product_and_quotient_expression(golden):
     assert np.array_equal(t, np.array(k["result"]))
 
 
+def test_quotient_expressions(golden):
+    """BitternMath.cpp:160-171 (expr-3, expr-4): scalar / matrix and matrix / matrix, exact on these values."""
+    k = golden["unit_tests"]["expr_3"]
+    m1, m2, m3 = (np.array(k[n]) for n in ("mat1", "mat2", "mat3"))
+    t = 18.0 * m3  # 18 mat3 - 4 mat2 through the oracle's element loops
+    oracle.lib().oracle_axmy(4, oracle._p(t), 4.0, oracle._p(m2))
+    q = oracle.vdiv(24.0, None, m1)
+    oracle.lib().oracle_axpy(4, oracle._p(q), 1.0, oracle._p(t))
+    assert np.array_equal(q, np.array(k["result"]))
+    k = golden["unit_tests"]["expr_4"]
+    q = oracle.vdiv(9.0, m1, m3)
+    oracle.lib().oracle_axmy(4, oracle._p(q), 1.0, oracle._p(m2))
+    oracle.lib().oracle_mul_scalar(4, oracle._p(q), 2.0)
+    assert np.array_equal(q, np.array(k["result"]))
+
+
 def test_normalize_and_safe_divide(golden):
     k = golden["unit_tests"]["normalize"]
     m = np.array(k["mat"])
