@@ -250,6 +250,7 @@ def main() -> int:
     # warmup steps do not cover that.  Same work as the timed region, nothing is cached from it.
     # The loop count must be the same on every rank (each run() holds collectives), so the elapsed
     # time that decides it is the max over ranks.
+    dist.barrier()  # every rank's operator is built: the first exchange's bounded waits start together
     t_spin = time.perf_counter()
     while args.spinup_seconds > 0 and dist.allreduce_max(time.perf_counter() - t_spin) < args.spinup_seconds:
         run(100)

@@ -68,4 +68,20 @@ for edge, iters, key in ((128, 60000, "long_run_128_throughput"), (32, 200000, "
     out[key] = {"iterations": s.iteration, "seconds": time.time() - t, "final_abs_err": s.absolute_error,
                 "finite": bool(np.isfinite(x2.to_numpy()).all())}
     mat2.close()
+# round 3: the lattice kernels at full size -- 40 full CG solves of the 256^3 problem (marching fused step, ticketed
+# reductions): one iteration count, bitwise the same solution every time
+g3 = mesh.structured_box(256)
+mat3 = api.StencilMatrix.from_face_graph(ctx, g3)
+b3 = api.DeviceVector.from_numpy(ctx, np.ones(g3.n_cells))
+its3, sums = set(), set()
+t = time.time()
+for k in range(40):
+    x3 = api.DeviceVector(ctx, g3.n_cells)
+    s = api.CgSolver()
+    assert s.solve(x3, b3, api.HipStencilOperator(mat3, -1.0, 0.0))
+    its3.add(s.iteration)
+    sums.add(float(api.norm_2(x3)))
+out["cg_256_marching_step"] = {"solves": 40, "seconds": time.time() - t, "iteration_counts": sorted(its3),
+                               "distinct_solution_norms": len(sums), "tiled_planes": mat3.stats()["tiled_planes"]}
+mat3.close()
 print(json.dumps(out))
