@@ -169,6 +169,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "fold_pz")) c->opt_fold_pz = value;
   else if (!strcmp(key, "cg_fuse")) c->opt_cg_fuse = value;
   else if (!strcmp(key, "cg_march")) c->opt_cg_march = value;
+  else if (!strcmp(key, "cg_march_ticket")) c->opt_cg_march_ticket = value;
   else if (!strcmp(key, "host_result")) c->opt_host_result = value;
   else if (!strcmp(key, "fuse_mgs")) c->opt_fuse_mgs = value;
   else if (!strcmp(key, "graph")) c->opt_graph = value;

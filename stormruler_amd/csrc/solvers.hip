@@ -1071,7 +1071,9 @@ int solve_cg_body(const FusedSolveArgs &args) {
     int st_apply;
     if (fuse_step && cur_it > 0) {
       const Driver::CgStep step{(long long)cur_it, x->d, r, p_alt};  // ends iteration cur_it - 1 (SolverCg.hpp:98, :123)
-      st_apply = d.apply(p, z, p, false, &nb, true, -1, -1, &pz_done, &step);
+      // (<p,z>: finished inside the marching kernel by tickets where that is on -- option cg_march_ticket --, else
+      //  per-wave partials for the final pass below)
+      st_apply = d.apply(p, z, p, false, &nb, true, (c->opt_cg_march_ticket != 0 && !ipc) ? (int)S_PZ : -1, -1, &pz_done, &step);
       std::swap(p, p_alt);
     } else {
       st_apply = d.apply(p, z, p, false, &nb, true, tick_spmv ? (int)S_PZ : -1, -1, &pz_done);

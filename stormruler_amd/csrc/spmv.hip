@@ -1278,10 +1278,26 @@ __global__ __launch_bounds__(kBlock) void cg_step_march_kernel(SellArgs A, March
   }
   dot_a = wave_sum_to_lane63(dot_a);
   if (dot.yy) dot_b = wave_sum_to_lane63(dot_b);
-  if (lane == kWave - 1) {
-    const int slot = dot.block_offset + bidx * (kBlock / kWave) + wave;
-    dot.partials[slot] = dot_a;
-    if (dot.yy) dot.partials[dot.nblocks_total + slot] = dot_b;
+  if (dot.tickets == nullptr) {
+    if (lane == kWave - 1) {
+      const int slot = dot.block_offset + bidx * (kBlock / kWave) + wave;
+      dot.partials[slot] = dot_a;
+      if (dot.yy) dot.partials[dot.nblocks_total + slot] = dot_b;
+    }
+    return;
+  }
+  // the reduction finishes here (one rank, unsplit): block partial, then two levels of tickets -- no final-pass launch
+  __shared__ double wave_part[2 * (kBlock / kWave)];
+  if (lane == kWave - 1) wave_part[wave] = dot_a, wave_part[kBlock / kWave + wave] = dot.yy ? dot_b : 0.0;
+  __syncthreads();
+  if (wave != 0) return;
+  const double mine[2] = {(wave_part[0] + wave_part[1]) + (wave_part[2] + wave_part[3]),
+                          (wave_part[4] + wave_part[5]) + (wave_part[6] + wave_part[7])};
+  double total[2];
+  const TicketArgs tk{dot.tickets, dot.partials, dot.part2};
+  if (ticket_reduce_wave0<2>(tk, mine, dot.yy ? 2 : 1, (unsigned)bidx, (unsigned)n_march, total) && lane == 0) {
+    *dot.out0 = total[0];
+    if (dot.yy) *dot.out1 = total[1];
   }
 }
 
@@ -1663,16 +1679,25 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
     CgFuseArgs cgf{};
     const bool cg_fused = sd != nullptr && sd->cg.x != nullptr;
     if (cg_fused) {
-      STORM_REQUIRE(spmv_can_fuse_cg(op) && fuse_dot && !accumulate && dot.tickets == nullptr && sd->w == x,
+      STORM_REQUIRE(spmv_can_fuse_cg(op) && fuse_dot && !accumulate && sd->w == x,
                     "spmv: the fused CG step needs the tiled format-4 kernel");
+      dot.tickets = nullptr, dot.nblocks_total = 4 * nb_total;  // (the tiled form of the step leaves per-wave partials)
+      if (sd->ticketed_out) *sd->ticketed_out = 0;
       cgf = CgFuseArgs{sd->cg.iteration, sd->cg.my_iteration, sd->cg.ca, sd->cg.cb, sd->cg.x, sd->cg.r, sd->cg.p_out};
     }
     MarchArgs M;
     int nb_march = 0;
     if (cg_fused && cg_march_geometry(op, &M, &nb_march)) {
-      // the z-marching step kernel: its own grid, its own (fewer) partial slots
+      // the z-marching step kernel: its own grid, its own (fewer) partial slots -- or, where the caller takes the sum
+      // from the slab (sd->out[0]), the reduction finished in the kernel by tickets
       dot.nblocks_total = 4 * nb_march;
       if (sd->nblocks_out) *sd->nblocks_out = 4 * nb_march;
+      if (sd->out[0] != nullptr && c->opt_ticket_reduce != 0 && c->comm == nullptr && !sd->yy &&
+          nb_march <= kTicketGroup * kTicketMaxGroups && 2 * (int64_t)nb_march <= c->partials_capacity) {
+        dot.tickets = c->d_tickets, dot.part2 = c->d_ticket_sums, dot.out0 = sd->out[0], dot.out1 = nullptr;
+        dot.nblocks_total = nb_march;
+        if (sd->ticketed_out) *sd->ticketed_out = 1;
+      }
       hipEvent_t ev0 = nullptr, ev1 = nullptr;
       if (c->opt_profile_spmv != 0) {
         while (c->prof_events.size() < c->prof_used + 2) {
