@@ -786,7 +786,7 @@ def measure_traffic(args):
                    *[f"--opt={kv}" for kv in args.opt]]
             env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
             env["TMPDIR"] = "/tmp"
-            p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=240)
+            p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=90)
             if p.returncode != 0:
                 return None, None, f"rocprofv3 --pmc {counter} exited with {p.returncode}: {p.stderr[-300:]}"
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
