@@ -372,6 +372,20 @@ public:
                                                  volume.data(), &m._h));
     return m;
   }
+  /// The same straight from the arrays the face loop reads (Playground.cpp:119-129): the library forms
+  /// area / length(center(out) - center(in)) itself (storm_hip_op_create_from_mesh).  `center` = cells x dim, row-major.
+  static StencilMatrix from_mesh(const Context& ctx, std::size_t n_owned, std::size_t n_halo, int dim,
+                                 const std::vector<int64_t>& inner, const std::vector<int64_t>& outer,
+                                 const std::vector<real_t>& area, const std::vector<real_t>& center,
+                                 const std::vector<int64_t>& b_cell, const std::vector<real_t>& b_area,
+                                 const std::vector<real_t>& b_center, const std::vector<real_t>& volume) {
+    StencilMatrix m;
+    detail::check(storm_hip_op_create_from_mesh(ctx.handle(), (int64_t)n_owned, (int64_t)n_halo, (int32_t)dim,
+                                                (int64_t)inner.size(), inner.data(), outer.data(), area.data(), center.data(),
+                                                (int64_t)b_cell.size(), b_cell.data(), b_area.data(), b_center.data(),
+                                                volume.data(), &m._h));
+    return m;
+  }
   static StencilMatrix from_face_weights(const Context& ctx, std::size_t n_owned, std::size_t n_halo,
                                          const std::vector<int64_t>& inner, const std::vector<int64_t>& outer,
                                          const std::vector<real_t>& w_inner, const std::vector<real_t>& w_outer,
@@ -597,6 +611,7 @@ public:
   // extras of this build
   bool device_loop{true};
   std::size_t num_applies{0}, num_pre_applies{0};  ///< of the last device-loop solve
+  int path_fallback{0};  ///< storm_hip_solver_result::path_fallback of the last device-loop solve (0: the chosen path ran)
 
 protected:
   virtual real_t init(const InVector& x_vec, const OutVector& b_vec, const Operator<InVector, OutVector>& any_op,
@@ -637,6 +652,7 @@ public:
         iteration = (std::size_t)r.iterations;
         absolute_error = r.absolute_error, relative_error = r.relative_error;
         num_applies = (std::size_t)r.num_applies, num_pre_applies = (std::size_t)n_pre;
+        path_fallback = r.path_fallback;
         detail::log_solve(iteration, absolute_error, relative_error);
         return r.converged != 0;
       }

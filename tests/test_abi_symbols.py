@@ -70,6 +70,13 @@ def test_host_side_argument_checks_do_not_need_a_device(built):
     assert lib.storm_hip_ctx_sync(None) == -1
     assert b"null" in lib.storm_hip_last_error()
     assert lib.storm_hip_vec_destroy(None) == 0 and lib.storm_hip_op_destroy(None) == 0
+    # round 3's entry points validate before they touch a device too
+    import ctypes as C
+
+    h = C.c_void_p()
+    assert lib.storm_hip_op_create_from_mesh(None, 1, 0, 3, 0, None, None, None, None, 0, None, None, None, None, C.byref(h)) == -1
+    assert b"null" in lib.storm_hip_last_error()
+    assert lib.storm_hip_vdiv(None, 1.0, None, None) == -1
 
 
 def test_product_code_never_touches_the_oracle():
