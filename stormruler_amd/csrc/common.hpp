@@ -281,6 +281,9 @@ int k_dot_partials(storm_hip_ctx *c, const double *a, const double *b, int64_t n
 int k_reduce_final(storm_hip_ctx *c, const double *partials, int nblocks, int k, double *d_out,
                    const int *done);
 
+// context.hip: a work vector with only its guard, halo tail and padding zeroed (the solver writes the owned rows first)
+int vec_create_work(const storm_hip_vec *like, storm_hip_vec **out);
+
 // spmv.hip
 // y = beta*x + alpha*M x over slices [s0, s1); when dot_w != null also writes
 // per-block partials of <dot_w, y> (and <y, y> when dot_yy) into partials.

@@ -212,7 +212,21 @@ int storm_hip_timer_stop(storm_hip_ctx *c, float *elapsed_ms) {
 
 // ---- vectors ---------------------------------------------------------------------
 
-int storm_hip_vec_create(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, storm_hip_vec **out) {
+}  // extern "C"
+static int vec_create_impl(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, storm_hip_vec **out, bool zero_owned);
+extern "C" int storm_hip_vec_create(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, storm_hip_vec **out) {
+  return vec_create_impl(c, n_owned, n_halo, out, true);
+}
+namespace storm {
+// A solver's WORK vector whose owned rows the solver writes before it reads them (CG's r, p, z; BiCGStab's r, rt, p, v,
+// t): only the guard in front, the halo tail and the padding behind are zeroed -- three 134 MB memsets per 256^3 CG
+// solve less (~90 us; a K = 20 solve is 4.7 ms).
+int vec_create_work(const storm_hip_vec *like, storm_hip_vec **out) {
+  STORM_REQUIRE(like, "vec_create_work: null vector");
+  return vec_create_impl(like->ctx, like->n_owned, like->n_halo, out, false);
+}
+}  // namespace storm
+static int vec_create_impl(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, storm_hip_vec **out, bool zero_owned) {
   STORM_REQUIRE(c && out, "vec_create: null argument");
   *out = nullptr;
   STORM_REQUIRE(n_owned >= 0 && n_halo >= 0, "vec_create: negative size");
@@ -255,8 +269,14 @@ int storm_hip_vec_create(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, stor
   }
   v->base = base;
   v->d = base + kVecGuard;
-  // Field::assign value-initialises (Feathers/Field.hpp:82-84): zero fill.
-  e = hipMemsetAsync(v->base, 0, bytes, c->stream);
+  // Field::assign value-initialises (Feathers/Field.hpp:82-84): zero fill.  (Work vectors: everything but the owned rows.)
+  if (zero_owned) {
+    e = hipMemsetAsync(v->base, 0, bytes, c->stream);
+  } else {
+    e = hipMemsetAsync(v->base, 0, sizeof(double) * kVecGuard, c->stream);
+    const size_t tail0 = sizeof(double) * (size_t)(kVecGuard + n_owned);
+    if (e == hipSuccess && bytes > tail0) e = hipMemsetAsync(reinterpret_cast<char *>(v->base) + tail0, 0, bytes - tail0, c->stream);
+  }
   if (e != hipSuccess) {
     (void)hipFree(v->base);
     delete v;
@@ -265,6 +285,8 @@ int storm_hip_vec_create(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, stor
   *out = v;
   return STORM_HIP_OK;
 }
+
+extern "C" {
 
 int storm_hip_vec_create_like(const storm_hip_vec *other, storm_hip_vec **out) {
   STORM_REQUIRE(other, "vec_create_like: null vector");

@@ -796,10 +796,12 @@ struct VecPool {  // work vectors: re-assigned (zeroed) on every solve like Solv
   ~VecPool() {
     for (auto *p : v) storm_hip_vec_destroy(p);
   }
-  int make(const storm_hip_vec *like, int count) {
+  // zero = false: the solver writes every owned row of these vectors before it reads it (context.hip, vec_create_work)
+  int make(const storm_hip_vec *like, int count, bool zero = true) {
     for (int i = 0; i < count; ++i) {
       storm_hip_vec *p = nullptr;
-      STORM_TRY(storm_hip_vec_create_like(like, &p));
+      if (zero) STORM_TRY(storm_hip_vec_create_like(like, &p));
+      else STORM_TRY(vec_create_work(like, &p));
       v.push_back(p);
     }
     return STORM_HIP_OK;
@@ -1019,7 +1021,7 @@ int solve_cg_body(const FusedSolveArgs &args) {
     // (the cooperative kernel could not be launched: the throughput path below, noted in result->path_fallback)
   }
   const size_t v0 = pool.v.size();
-  STORM_TRY(pool.make(x, 3));
+  STORM_TRY(pool.make(x, 3, false));  // (r: the init apply; p: init_residual's copy; z: the first SpMV -- all before any read)
   double *p = pool.v[v0]->d, *r = pool.v[v0 + 1]->d, *z = pool.v[v0 + 2]->d;
   const int nbv = vec_blocks(c, n);
 
@@ -1059,7 +1061,7 @@ int solve_cg_body(const FusedSolveArgs &args) {
                          spmv_can_fuse_cg(op);
   double *p_alt = nullptr;
   if (fuse_step) {
-    STORM_TRY(pool.make(x, 1));
+    STORM_TRY(pool.make(x, 1, false));
     p_alt = pool.v.back()->d;
   }
   int64_t last_enqueued = -1;
@@ -1164,7 +1166,7 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
     if (taken) return collect(d, result, history, applies_bicg, 0);
   }
   const size_t v0 = pool.v.size();
-  STORM_TRY(pool.make(x, 5));
+  STORM_TRY(pool.make(x, 5, false));  // (r, rt: init; p: the copy of iteration 0; v, t: the SpMVs -- all before any read)
   double *p = pool.v[v0]->d, *r = pool.v[v0 + 1]->d, *rt = pool.v[v0 + 2]->d, *t = pool.v[v0 + 3]->d, *v = pool.v[v0 + 4]->d;
   const int nbv = vec_blocks(c, n);
   const int nbv2 = nbv;  // second half-step: one access per stream in flight, four trips per thread
