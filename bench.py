@@ -826,7 +826,9 @@ def measure_traffic(args):
 def blas1_rates(api, ctx, N, reps=20):
     """Algorithmic GB/s of each BLAS-1 statement of the solver bodies at N elements (SURVEY.md 8d byte counts),
     HIP events around `reps` back-to-back calls on the library's stream.  dot / norm2 / multi_dot return their
-    result to the host, so their figure includes the final reduction pass and the 8-byte copy per call."""
+    result to the host, so their figure includes the host round trip between two calls (the kernel's last block
+    writes the sums to pinned memory, the host polls them and launches again); the "in flight" entries are the same
+    kernels without that gap."""
     from stormruler_amd._lib import check, lib
 
     v = [api.DeviceVector(ctx, N) for _ in range(10)]
@@ -855,6 +857,19 @@ def blas1_rates(api, ctx, N, reps=20):
     out["dot"] = t(lambda: api.dot_product(a, b), 16)
     out["norm2"] = t(lambda: api.norm_2(a), 8)
     out["multi_dot k=8"] = t(lambda: api.multi_dot(a, v[1:9]), 8 * 9)
+    # the same kernels with the host round trip between two synchronous calls (~9 us: result to the host, the next
+    # launch) taken out: storm_hip_multi_dot_begin / _end, four requests in flight -- the kernels' own rate
+    pending = []
+
+    def in_flight(bs):
+        pending.append(api.PendingDots(a, bs))
+        if len(pending) == 4:
+            pending.pop(0).result()
+
+    out["dot, 4 in flight (begin / end)"] = t(lambda: in_flight([b]), 16)
+    out["norm2, 4 in flight (begin / end)"] = t(lambda: in_flight([a]), 8)
+    while pending:
+        pending.pop(0).result()
     out["multi_axpy k=8"] = t(lambda: api.multi_axpy(a, [1e-9] * 8, v[1:9]), 8 * 10)
     return out
 

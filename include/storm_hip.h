@@ -170,6 +170,13 @@ int storm_hip_dot(const storm_hip_vec *a, const storm_hip_vec *b, double *result
 int storm_hip_norm2(const storm_hip_vec *a, double *result);
 /* out[i] = <a, bs[i]>, i < k: the Arnoldi multi-dot (SolverGmres.hpp:157-160 batched). */
 int storm_hip_multi_dot(const storm_hip_vec *a, const storm_hip_vec *const *bs, int k, double *out);
+/* The same reduction in two halves: _begin enqueues it and returns a request, _end waits for the
+ * sums (in pinned host memory, written by the kernel's last block) -- up to 8 requests in flight,
+ * ended in any order; the caller's host work, or further launches, overlap the ~9 us a synchronous
+ * dot spends between the end of its kernel and the start of the next one.  storm_hip_multi_dot is
+ * _begin + _end.  (With a communicator, or k > 8, _begin computes the sums and _end returns them.) */
+int storm_hip_multi_dot_begin(const storm_hip_vec *a, const storm_hip_vec *const *bs, int k, int *request);
+int storm_hip_multi_dot_end(storm_hip_ctx *ctx, int request, double *out);
 /* y += sum_i coefs[i] * xs[i]  (SolverGmres.hpp:233-236 batched) */
 int storm_hip_multi_axpy(storm_hip_vec *y, const double *coefs, const storm_hip_vec *const *xs, int k);
 

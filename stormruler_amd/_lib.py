@@ -99,6 +99,8 @@ SIGNATURES = {
     "storm_hip_dot": (C.c_int, [vp, vp, f64p]),
     "storm_hip_norm2": (C.c_int, [vp, f64p]),
     "storm_hip_multi_dot": (C.c_int, [vp, C.POINTER(vp), C.c_int, f64p]),
+    "storm_hip_multi_dot_begin": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.POINTER(C.c_int)]),
+    "storm_hip_multi_dot_end": (C.c_int, [vp, C.c_int, f64p]),
     "storm_hip_multi_axpy": (C.c_int, [vp, f64p, C.POINTER(vp), C.c_int]),
     "storm_hip_op_create_from_faces": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int64, i64p, i64p, f64p,
                                                  C.c_int64, i64p, f64p, f64p, C.POINTER(vp)]),

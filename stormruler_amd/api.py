@@ -382,6 +382,23 @@ def multi_dot(a: DeviceVector, bs: Sequence[DeviceVector]) -> np.ndarray:
     return out
 
 
+class PendingDots:
+    """``<a, bs[i]>`` enqueued, not yet awaited (``storm_hip_multi_dot_begin``): up to 8 in flight per context;
+    ``result()`` waits for the sums (once)."""
+
+    def __init__(self, a: DeviceVector, bs: Sequence[DeviceVector]):
+        self._ctx, self._k = a.ctx, len(bs)
+        arr = (C.c_void_p * self._k)(*[b._h for b in bs])
+        req = C.c_int(0)
+        check(lib.storm_hip_multi_dot_begin(a._h, arr, self._k, C.byref(req)))
+        self._req = req.value
+
+    def result(self) -> np.ndarray:
+        out = np.empty(self._k)
+        check(lib.storm_hip_multi_dot_end(self._ctx._h, self._req, out.ctypes.data_as(_lib.f64p)))
+        return out
+
+
 def multi_axpy(y: DeviceVector, coefs: Sequence[float], xs: Sequence[DeviceVector]) -> None:
     k = len(xs)
     arr = (C.c_void_p * k)(*[x._h for x in xs])

@@ -565,8 +565,8 @@ int storm_hip_bicgstab_p(storm_hip_vec *p, const storm_hip_vec *r, double beta, 
   return k_bicg_p(p->ctx, p->d, r->d, host_scal(beta), host_scal(omega), v->d, p->n_owned, p->ctx->api_done);
 }
 
-int storm_hip_multi_dot(const storm_hip_vec *a, const storm_hip_vec *const *bs, int k, double *out) {
-  STORM_REQUIRE(a && bs && out, "multi_dot: null argument");
+int storm_hip_multi_dot_begin(const storm_hip_vec *a, const storm_hip_vec *const *bs, int k, int *request) {
+  STORM_REQUIRE(a && bs && request, "multi_dot_begin: null argument");
   STORM_REQUIRE(k >= 1 && k <= kMaxMulti, "multi_dot: k = %d outside [1, %d]", k, kMaxMulti);
   const double *ptrs[kMaxMulti];
   for (int j = 0; j < k; ++j) {
@@ -574,38 +574,73 @@ int storm_hip_multi_dot(const storm_hip_vec *a, const storm_hip_vec *const *bs, 
     ptrs[j] = bs[j]->d;
   }
   storm_hip_ctx *c = a->ctx;
-  if (a->n_owned == 0) {
-    HIP_TRY(hipMemsetAsync(c->d_scalars, 0, sizeof(double) * (size_t)k, c->stream));
-  } else {
-    // one rank, one launch: the kernel's last block leaves the sums in pinned host memory; poll them
-    const bool direct = c->comm == nullptr && c->opt_host_result != 0 && c->opt_ticket_reduce != 0 && k <= kDotChunk &&
-                        c->api_done == nullptr;
-    if (direct) {
-      const unsigned tag = ++c->result_seq ? c->result_seq : ++c->result_seq;  // never 0 (the words start zeroed)
-      STORM_TRY(k_multi_dot_host(c, a->d, ptrs, k, a->n_owned, c->d_scalars, nullptr, c->d_result_words, tag));
-      volatile unsigned long long *w = c->h_result_words;
-      for (long spin = 0;; ++spin) {
-        bool all = true;
-        for (int j = 0; j < 2 * k; ++j) all &= (unsigned)(w[j] >> 32) == tag;
-        if (all) break;
-        if ((spin & 0x3fff) == 0x3fff && hipStreamQuery(c->stream) == hipSuccess) {
-          // the stream is idle and the words never came (a failed launch): take the ordinary road, which reports it
-          bool again = true;
-          for (int j = 0; j < 2 * k; ++j) again &= (unsigned)(w[j] >> 32) == tag;
-          if (!again) return finish_reduction(c, k, out);
-          break;
-        }
-      }
-      for (int j = 0; j < k; ++j) {
-        const unsigned long long lo = w[2 * j], hi = w[2 * j + 1];
-        const unsigned long long bits = (hi << 32) | (lo & 0xffffffffull);
-        memcpy(&out[j], &bits, sizeof(double));
-      }
-      return STORM_HIP_OK;
-    }
-    STORM_TRY(k_multi_dot(c, a->d, ptrs, k, a->n_owned, c->d_scalars, c->api_done));
+  const unsigned tag = ++c->result_seq ? c->result_seq : ++c->result_seq;  // never 0 (the words start zeroed)
+  const int s = (int)(tag % kResultRing);
+  storm_hip_ctx::ResultSlot &slot = c->result_ring[s];
+  if (slot.tag != 0) {
+    --c->result_seq;
+    STORM_REQUIRE(false, "multi_dot_begin: %d reductions in flight already (end one first)", kResultRing);
   }
-  return finish_reduction(c, k, out);
+  slot.k = k;
+  slot.ready = false;
+  // one rank, one launch: the kernel's last block leaves the sums in pinned host memory; _end polls them
+  const bool direct = a->n_owned > 0 && c->comm == nullptr && c->opt_host_result != 0 && c->opt_ticket_reduce != 0 &&
+                      k <= kDotChunk && c->api_done == nullptr;
+  if (direct) {
+    STORM_TRY(k_multi_dot_host(c, a->d, ptrs, k, a->n_owned, c->d_scalars, nullptr, c->d_result_words + 16 * s, tag));
+  } else {
+    if (a->n_owned == 0) {
+      HIP_TRY(hipMemsetAsync(c->d_scalars, 0, sizeof(double) * (size_t)k, c->stream));
+    } else {
+      STORM_TRY(k_multi_dot(c, a->d, ptrs, k, a->n_owned, c->d_scalars, c->api_done));
+    }
+    STORM_TRY(finish_reduction(c, k, slot.value));
+    slot.ready = true;
+  }
+  slot.tag = tag;
+  *request = (int)tag;
+  return STORM_HIP_OK;
+}
+
+int storm_hip_multi_dot_end(storm_hip_ctx *c, int request, double *out) {
+  STORM_REQUIRE(c && out, "multi_dot_end: null argument");
+  const unsigned tag = (unsigned)request;
+  const int s = (int)(tag % kResultRing);
+  storm_hip_ctx::ResultSlot &slot = c->result_ring[s];
+  STORM_REQUIRE(tag != 0 && slot.tag == tag, "multi_dot_end: request %d is not in flight", request);
+  const int k = slot.k;
+  slot.tag = 0;
+  if (slot.ready) {
+    for (int j = 0; j < k; ++j) out[j] = slot.value[j];
+    return STORM_HIP_OK;
+  }
+  volatile unsigned long long *w = c->h_result_words + 16 * s;
+  auto arrived = [&]() {
+    bool all = true;
+    for (int j = 0; j < 2 * k; ++j) all &= (unsigned)(w[j] >> 32) == tag;
+    return all;
+  };
+  for (long spin = 0; !arrived(); ++spin) {
+    if ((spin & 0x3fff) == 0x3fff && hipStreamQuery(c->stream) == hipSuccess && !arrived()) {
+      // the stream is idle and the words never came (a failed launch): the ordinary road reports it -- or, if the
+      // kernel did run, returns the sums it left in device memory (only when no later reduction has replaced them)
+      STORM_REQUIRE(c->result_seq == tag, "multi_dot_end: the result of request %d never arrived", request);
+      return finish_reduction(c, k, out);
+    }
+  }
+  for (int j = 0; j < k; ++j) {
+    const unsigned long long lo = w[2 * j], hi = w[2 * j + 1];
+    const unsigned long long bits = (hi << 32) | (lo & 0xffffffffull);
+    memcpy(&out[j], &bits, sizeof(double));
+  }
+  return STORM_HIP_OK;
+}
+
+int storm_hip_multi_dot(const storm_hip_vec *a, const storm_hip_vec *const *bs, int k, double *out) {
+  STORM_REQUIRE(out, "multi_dot: null argument");
+  int request = 0;
+  STORM_TRY(storm_hip_multi_dot_begin(a, bs, k, &request));
+  return storm_hip_multi_dot_end(a->ctx, request, out);
 }
 
 int storm_hip_dot(const storm_hip_vec *a, const storm_hip_vec *b, double *result) {

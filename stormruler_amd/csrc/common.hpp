@@ -46,6 +46,7 @@ constexpr int kBlock = 256;          // 4 waves, one per SIMD
 constexpr int kNumXcd = 8;           // MI355X: 8 XCDs, blocks dealt round-robin
 constexpr int kMaxReduceBlocks = 2048;  // 256 CUs x 8 resident 256-thread blocks
 constexpr int kMaxMulti = 64;        // widest multi-dot / multi-axpy in one launch
+constexpr int kResultRing = 8;       // host-returning reductions in flight (storm_hip_multi_dot_begin / _end)
 constexpr int kSlab = 256;           // doubles in the device scalar slab
 constexpr int kStateRing = 64;       // iterations the host may run ahead of the device's verdict
 constexpr int kStage2 = 128;         // blocks of the first pass of a two-pass final reduction
@@ -97,8 +98,15 @@ struct storm_hip_ctx {
   double *h_scalars = nullptr;        // pinned mirror
   // host-returning reductions on one rank: the kernel's last block stores the sums straight into pinned host memory
   // as self-validating words { low half | tag }, { high half | tag } and the host polls them -- no copy, no stream wait
-  unsigned long long *h_result_words = nullptr, *d_result_words = nullptr;  // [2 * 8]
+  // (a ring of kResultRing requests: storm_hip_multi_dot_begin / _end keep several reductions in flight)
+  unsigned long long *h_result_words = nullptr, *d_result_words = nullptr;  // [kResultRing][2 * 8]
   unsigned result_seq = 0;
+  struct ResultSlot {
+    unsigned tag = 0;     // 0: free
+    int k = 0;
+    bool ready = false;   // value[] holds the sums already (the ordinary road computed them in _begin)
+    double value[storm::kMaxMulti] = {};
+  } result_ring[storm::kResultRing];
   int64_t opt_host_result = 1;        // 0: device scalars + hipMemcpyAsync + hipStreamSynchronize
   storm::SolverState *d_state = nullptr;
   storm::SolverState *h_state = nullptr;  // pinned staging copy of the state

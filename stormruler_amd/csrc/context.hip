@@ -58,8 +58,8 @@ int storm_hip_ctx_create(int device_id, storm_hip_ctx **out) {
   HIP_TRY(hipMalloc(&c->d_partials2, sizeof(double) * kMaxMulti * kStage2));
   HIP_TRY(hipMalloc(&c->d_scalars, sizeof(double) * kMaxMulti));
   HIP_TRY(hipHostMalloc((void **)&c->h_scalars, sizeof(double) * kMaxMulti, hipHostMallocDefault));
-  HIP_TRY(hipHostMalloc((void **)&c->h_result_words, sizeof(unsigned long long) * 16, hipHostMallocMapped));
-  memset(c->h_result_words, 0, sizeof(unsigned long long) * 16);
+  HIP_TRY(hipHostMalloc((void **)&c->h_result_words, sizeof(unsigned long long) * 16 * 8, hipHostMallocMapped));
+  memset(c->h_result_words, 0, sizeof(unsigned long long) * 16 * 8);
   HIP_TRY(hipHostGetDevicePointer((void **)&c->d_result_words, c->h_result_words, 0));
   HIP_TRY(hipMalloc((void **)&c->d_lat_slots, 2 * 256 * 256 + 256));  // latency.hip: all-reduce slots (two per block) + the gave-up flag
   HIP_TRY(hipMemset(c->d_lat_slots, 0, 2 * 256 * 256 + 256));

@@ -77,6 +77,7 @@ def test_host_side_argument_checks_do_not_need_a_device(built):
     assert lib.storm_hip_op_create_from_mesh(None, 1, 0, 3, 0, None, None, None, None, 0, None, None, None, None, C.byref(h)) == -1
     assert b"null" in lib.storm_hip_last_error()
     assert lib.storm_hip_vdiv(None, 1.0, None, None) == -1
+    assert lib.storm_hip_multi_dot_begin(None, None, 1, None) == -1 and lib.storm_hip_multi_dot_end(None, 1, None) == -1
 
 
 def test_product_code_never_touches_the_oracle():

@@ -136,6 +136,33 @@ def test_multi_dot_and_multi_axpy(api, ctx, oracle):
     assert _rel_max(a.to_numpy(), ha) <= 1e-13
 
 
+def test_dots_in_flight(api, ctx, oracle):
+    """storm_hip_multi_dot_begin / _end: eight reductions enqueued back to back, awaited out of order, give the sums
+    the synchronous call gives (bit for bit: same kernel, same folding order); a ninth is refused, a request is
+    good for one _end."""
+    rng = np.random.default_rng(11)
+    for n in (1, 777, 300_001):
+        hs = [rng.standard_normal(n) for _ in range(9)]
+        vs = [api.DeviceVector.from_numpy(ctx, h) for h in hs]
+        sync = [api.multi_dot(vs[0], vs[1 + j:2 + j + (j % 3)]) for j in range(8)]
+        pend = [api.PendingDots(vs[0], vs[1 + j:2 + j + (j % 3)]) for j in range(8)]
+        with pytest.raises(api._lib.StormHipError):
+            api.PendingDots(vs[0], vs[1:2])
+        for j in (3, 0, 7, 1, 2, 6, 5, 4):
+            got = pend[j].result()
+            assert np.array_equal(got, sync[j])
+            want = np.array([oracle.dot(hs[0], h) for h in hs[1 + j:2 + j + (j % 3)]])
+            assert np.abs(got - want).max() <= 1e-10 * max(1.0, np.abs(want).max())
+        with pytest.raises(api._lib.StormHipError):
+            pend[3].result()
+        # the ring is free again; wide requests (k > 8) take the ordinary road inside _begin
+        wide = api.PendingDots(vs[0], [vs[1 + (j % 8)] for j in range(19)])
+        again = api.PendingDots(vs[0], vs[1:3])
+        assert np.array_equal(again.result(), api.multi_dot(vs[0], vs[1:3]))
+        assert np.array_equal(wide.result(), api.multi_dot(vs[0], [vs[1 + (j % 8)] for j in range(19)]))
+    assert api.dot_product(vs[0], vs[1]) == api.multi_dot(vs[0], vs[1:2])[0]
+
+
 def test_vector_semantics(api, ctx):
     v = api.DeviceVector.from_numpy(ctx, np.arange(10.0))
     w = api.DeviceVector()
