@@ -69,7 +69,7 @@ struct SolverState {
   int done;                 // set by the device when converged or out of iterations
   int converged;
   double *history;          // device buffer [num_iterations + 1] or null
-  int *done_ring;           // device alias of a pinned host ring: done flag after iteration i at [i % kStateRing]
+  unsigned long long *done_ring;  // device alias of a pinned host ring: after iteration i (1-based) the word (i << 1 | done) at [(i - 1) % kStateRing]; ring_wait()
   int verify_failed;        // option ticket_verify: an in-kernel (ticketed) reduction disagreed with its two-launch recomputation (sticky)
 };
 
@@ -110,9 +110,10 @@ struct storm_hip_ctx {
   int64_t opt_host_result = 1;        // 0: device scalars + hipMemcpyAsync + hipStreamSynchronize
   storm::SolverState *d_state = nullptr;
   storm::SolverState *h_state = nullptr;  // pinned staging copy of the state
-  int *h_done_ring = nullptr;             // pinned, written by the device's step kernels
-  int *d_done_ring = nullptr;             // device pointer to the same memory
-  std::vector<hipEvent_t> ev_ring;
+  unsigned long long *h_done_ring = nullptr;  // pinned, written by the device's step kernels (solver_device.hpp advance())
+  unsigned long long *d_done_ring = nullptr;  // device pointer to the same memory
+  std::vector<hipEvent_t> ev_ring;            // (option poll_events = 1: a marker behind every iteration, the r02 form)
+  int64_t opt_poll_events = 0;
   // options
   int64_t opt_ell_cap = 0;
   int64_t opt_spmv_variant = 0;      // 0 gathers from global (default), 1 + LDS x window
@@ -291,6 +292,21 @@ int k_reduce_final(storm_hip_ctx *c, const double *partials, int nblocks, int k,
 
 // context.hip: a work vector with only its guard, halo tail and padding zeroed (the solver writes the owned rows first)
 int vec_create_work(const storm_hip_vec *like, storm_hip_vec **out);
+// ... `count` of them, their edges zeroed by ONE launch (a memset is a launch of its own with ~10 us in front of it:
+// eight of them per CG solve were a quarter of a K = 0 solve's 0.34 ms)
+int vec_create_work_batch(const storm_hip_vec *like, int count, storm_hip_vec **out);
+// context.hip: the device's SolverState for a new solve, written by one small kernel (no staged copy, no stream wait)
+int state_init(storm_hip_ctx *c, SolverState *d_state, double abs_tol, double rel_tol, long long num_iterations, double *history,
+               unsigned long long *d_ring);
+
+// context.hip: the host's view of a solve's progress.  The device's step kernels post the verdict of iteration i
+// (1-based) as ONE self-validating word (i << 1 | done) into a pinned ring (solver_device.hpp advance()); the host,
+// `lag` iterations ahead, polls the word -- no marker in the stream: an event recorded behind every iteration is a
+// barrier with a system-scope release between two kernels, 5.9 us per CG iteration at 256^3
+// (profiles/r03t_event_gap.txt).  ring_post / ring_wait: option poll_events = 1 brings the markers back.
+constexpr unsigned long long kRingDoneAtOnce = ~0ull;  // begin(): nothing to iterate, every poll sees it
+int ring_post(storm_hip_ctx *c, std::vector<hipEvent_t> &events, int64_t it);
+int ring_wait(storm_hip_ctx *c, std::vector<hipEvent_t> &events, volatile unsigned long long *ring, int64_t it, bool *stop);
 
 // spmv.hip
 // y = beta*x + alpha*M x over slices [s0, s1); when dot_w != null also writes
@@ -329,7 +345,7 @@ bool cg_latency_eligible(const storm_hip_op *op);
 constexpr int kStatusCoopGaveUp = 1000;  // internal status of lat_check_gave_up: the caller re-runs the solve (below)
 int lat_check_gave_up(storm_hip_ctx *c);
 // Run a solve that may use cooperative kernels; when one of them gave up, restore x and run it again without them.
-int coop_solve_with_fallback(storm_hip_ctx *c, double *x, int64_t n_total, int (*run)(void *), void *arg, int *fallback_out);
+int coop_solve_with_fallback(storm_hip_ctx *c, storm_hip_vec *x, int (*run)(void *), void *arg, int *fallback_out);
 // What the cooperative chain needs to finish an Arnoldi step itself (fused GMRES loop): the state, the Hessenberg and
 // rotation arrays, and where sqrt(<w,w>) goes.
 struct MgsGivens {

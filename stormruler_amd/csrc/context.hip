@@ -69,7 +69,7 @@ int storm_hip_ctx_create(int device_id, storm_hip_ctx **out) {
   HIP_TRY(hipMalloc((void **)&c->d_state, sizeof(SolverState)));
   HIP_TRY(hipMemset(c->d_state, 0, sizeof(SolverState)));
   HIP_TRY(hipHostMalloc((void **)&c->h_state, sizeof(SolverState), hipHostMallocDefault));
-  HIP_TRY(hipHostMalloc((void **)&c->h_done_ring, sizeof(int) * kStateRing, hipHostMallocMapped));
+  HIP_TRY(hipHostMalloc((void **)&c->h_done_ring, sizeof(unsigned long long) * kStateRing, hipHostMallocMapped));
   HIP_TRY(hipHostGetDevicePointer((void **)&c->d_done_ring, c->h_done_ring, 0));
   c->ev_ring.resize(kStateRing);
   for (auto &ev : c->ev_ring) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -170,6 +170,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "cg_fuse")) c->opt_cg_fuse = value;
   else if (!strcmp(key, "cg_march")) c->opt_cg_march = value;
   else if (!strcmp(key, "cg_march_ticket")) c->opt_cg_march_ticket = value;
+  else if (!strcmp(key, "poll_events")) c->opt_poll_events = value;
   else if (!strcmp(key, "host_result")) c->opt_host_result = value;
   else if (!strcmp(key, "fuse_mgs")) c->opt_fuse_mgs = value;
   else if (!strcmp(key, "graph")) c->opt_graph = value;
@@ -213,20 +214,107 @@ int storm_hip_timer_stop(storm_hip_ctx *c, float *elapsed_ms) {
 // ---- vectors ---------------------------------------------------------------------
 
 }  // extern "C"
-static int vec_create_impl(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, storm_hip_vec **out, bool zero_owned);
+enum { kZeroAll = 0, kZeroEdges = 1, kZeroNothing = 2 };
+static int vec_create_impl(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, storm_hip_vec **out, int zero_mode);
 extern "C" int storm_hip_vec_create(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, storm_hip_vec **out) {
-  return vec_create_impl(c, n_owned, n_halo, out, true);
+  return vec_create_impl(c, n_owned, n_halo, out, kZeroAll);
 }
 namespace storm {
+int ring_post(storm_hip_ctx *c, std::vector<hipEvent_t> &events, int64_t it) {
+  if (c->opt_poll_events != 0) HIP_TRY(hipEventRecord(events[(size_t)(it % kStateRing)], c->stream));
+  return STORM_HIP_OK;
+}
+
+// The verdict of iteration index `it` (0-based; the device counts from 1).
+int ring_wait(storm_hip_ctx *c, std::vector<hipEvent_t> &events, volatile unsigned long long *ring, int64_t it, bool *stop) {
+  volatile unsigned long long *w = ring + it % kStateRing;
+  const unsigned long long want = (unsigned long long)(it + 1);
+  auto posted = [&](bool *s) {
+    const unsigned long long v = *w;
+    if (v == kRingDoneAtOnce) return *s = true, true;
+    if ((v >> 1) == want) return *s = (v & 1ull) != 0, true;
+    return false;
+  };
+  *stop = false;
+  if (c->opt_poll_events != 0) {
+    HIP_TRY(hipEventSynchronize(events[(size_t)(it % kStateRing)]));
+    (void)posted(stop);
+    return STORM_HIP_OK;
+  }
+  for (unsigned long spin = 1;; ++spin) {
+    if (posted(stop)) return STORM_HIP_OK;
+    if ((spin & 0x3ffful) == 0) {
+      const hipError_t e = hipStreamQuery(c->stream);
+      if (e == hipSuccess) {  // everything enqueued has run: an iteration that posted nothing has not ended the solve
+        (void)posted(stop);
+        return STORM_HIP_OK;
+      }
+      if (e != hipErrorNotReady) HIP_TRY(e);
+    } else {
+      __builtin_ia32_pause();
+    }
+  }
+}
+
 // A solver's WORK vector whose owned rows the solver writes before it reads them (CG's r, p, z; BiCGStab's r, rt, p, v,
 // t): only the guard in front, the halo tail and the padding behind are zeroed -- three 134 MB memsets per 256^3 CG
 // solve less (~90 us; a K = 20 solve is 4.7 ms).
 int vec_create_work(const storm_hip_vec *like, storm_hip_vec **out) {
   STORM_REQUIRE(like, "vec_create_work: null vector");
-  return vec_create_impl(like->ctx, like->n_owned, like->n_halo, out, false);
+  return vec_create_impl(like->ctx, like->n_owned, like->n_halo, out, kZeroEdges);
+}
+
+constexpr int kEdgeBatch = 8;
+struct EdgePtrs {
+  double *base[kEdgeBatch];
+};
+// the guard in front of element 0 and everything behind the owned rows (halo rows, padding) of `gridDim.y` vectors
+__global__ __launch_bounds__(kBlock) void zero_edges_kernel(EdgePtrs v, int64_t tail0, int64_t total) {
+  double *b = v.base[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < kVecGuard + (total - tail0); i += (int64_t)gridDim.x * kBlock)
+    b[i < kVecGuard ? i : tail0 + (i - kVecGuard)] = 0.0;
+}
+int vec_create_work_batch(const storm_hip_vec *like, int count, storm_hip_vec **out) {
+  STORM_REQUIRE(like && out && count >= 0, "vec_create_work_batch: bad argument");
+  storm_hip_ctx *c = like->ctx;
+  for (int i0 = 0; i0 < count; i0 += kEdgeBatch) {
+    const int k = std::min(kEdgeBatch, count - i0);
+    EdgePtrs e{};
+    for (int i = 0; i < k; ++i) {
+      const int st = vec_create_impl(c, like->n_owned, like->n_halo, &out[i0 + i], kZeroNothing);
+      if (st != STORM_HIP_OK) {
+        for (int j = 0; j < i0 + i; ++j) (void)storm_hip_vec_destroy(out[j]), out[j] = nullptr;
+        return st;
+      }
+      e.base[i] = out[i0 + i]->base;
+    }
+    const int64_t total = (int64_t)(out[i0]->bytes / sizeof(double)), tail0 = kVecGuard + like->n_owned;
+    const int64_t work = kVecGuard + (total - tail0);
+    hipLaunchKernelGGL(zero_edges_kernel, dim3((unsigned)std::min<int64_t>((work + kBlock - 1) / kBlock, 1024), (unsigned)k), dim3(kBlock), 0,
+                       c->stream, e, tail0, total);
+    HIP_TRY(hipGetLastError());
+  }
+  return STORM_HIP_OK;
+}
+
+__global__ void state_init_kernel(SolverState *st, double abs_tol, double rel_tol, long long num_iterations, double *history,
+                                  unsigned long long *ring) {
+  for (int i = threadIdx.x; i < kSlab; i += blockDim.x) st->s[i] = 0.0;
+  if (threadIdx.x != 0) return;
+  st->initial_error = st->absolute_error = st->relative_error = 0.0;
+  st->abs_tol = abs_tol, st->rel_tol = rel_tol;
+  st->iteration = 0, st->num_iterations = num_iterations;
+  st->done = 0, st->converged = 0, st->verify_failed = 0;
+  st->history = history, st->done_ring = ring;
+}
+int state_init(storm_hip_ctx *c, SolverState *d_state, double abs_tol, double rel_tol, long long num_iterations, double *history,
+               unsigned long long *d_ring) {
+  hipLaunchKernelGGL(state_init_kernel, dim3(1), dim3(kBlock), 0, c->stream, d_state, abs_tol, rel_tol, num_iterations, history, d_ring);
+  HIP_TRY(hipGetLastError());
+  return STORM_HIP_OK;
 }
 }  // namespace storm
-static int vec_create_impl(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, storm_hip_vec **out, bool zero_owned) {
+static int vec_create_impl(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, storm_hip_vec **out, int zero_mode) {
   STORM_REQUIRE(c && out, "vec_create: null argument");
   *out = nullptr;
   STORM_REQUIRE(n_owned >= 0 && n_halo >= 0, "vec_create: negative size");
@@ -270,9 +358,9 @@ static int vec_create_impl(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, st
   v->base = base;
   v->d = base + kVecGuard;
   // Field::assign value-initialises (Feathers/Field.hpp:82-84): zero fill.  (Work vectors: everything but the owned rows.)
-  if (zero_owned) {
+  if (zero_mode == kZeroAll) {
     e = hipMemsetAsync(v->base, 0, bytes, c->stream);
-  } else {
+  } else if (zero_mode == kZeroEdges) {
     e = hipMemsetAsync(v->base, 0, sizeof(double) * kVecGuard, c->stream);
     const size_t tail0 = sizeof(double) * (size_t)(kVecGuard + n_owned);
     if (e == hipSuccess && bytes > tail0) e = hipMemsetAsync(reinterpret_cast<char *>(v->base) + tail0, 0, bytes - tail0, c->stream);

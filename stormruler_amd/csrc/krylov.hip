@@ -615,7 +615,7 @@ struct KrylovEngine {
   double relaxation = 1.0e-4;  // SolverRichardson.hpp:45
   // device state (own: solves may nest, e.g. a solver used as another solver's preconditioner)
   SolverState *d_st = nullptr, *h_st = nullptr;
-  int *h_ring = nullptr, *d_ring = nullptr;
+  unsigned long long *h_ring = nullptr, *d_ring = nullptr;
   std::vector<hipEvent_t> ev;
   double *S = nullptr;
   int S_cap = 0, S_top = 0;
@@ -1744,21 +1744,14 @@ int begin_solve(K *k, const storm_hip_vec *b, storm_hip_vec *x, const storm_hip_
     HIP_TRY(hipMemcpyAsync(k->S + R_ONE, &one, sizeof(double), hipMemcpyHostToDevice, c->stream));
   }
   // solver state
-  SolverState h;
-  memset(&h, 0, sizeof h);
-  h.abs_tol = stepping ? 0.0 : p->absolute_error_tolerance;  // stepping: the caller owns the convergence decision
-  h.rel_tol = stepping ? 0.0 : p->relative_error_tolerance;
-  h.num_iterations = stepping ? (1LL << 62) : p->num_iterations;
-  h.done_ring = k->d_ring;
   for (int i = 0; i < kStateRing; ++i) k->h_ring[i] = 0;
   if (history && !stepping) {
     HIP_TRY(hipMalloc((void **)&k->d_history, sizeof(double) * (size_t)(p->num_iterations + 1)));
     HIP_TRY(hipMemsetAsync(k->d_history, 0, sizeof(double) * (size_t)(p->num_iterations + 1), c->stream));
-    h.history = k->d_history;
   }
-  *k->h_st = h;
-  HIP_TRY(hipMemcpyAsync(k->d_st, k->h_st, sizeof(SolverState), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  // (stepping: the caller owns the convergence decision)
+  STORM_TRY(state_init(c, k->d_st, stepping ? 0.0 : p->absolute_error_tolerance, stepping ? 0.0 : p->relative_error_tolerance,
+                       stepping ? (1LL << 62) : p->num_iterations, (history && !stepping) ? k->d_history : nullptr, k->d_ring));
   k->init();
   k->applies_after.assign(1, k->applies);
   k->pre_after.assign(1, k->pre_applies);
@@ -1789,7 +1782,7 @@ int storm_hip_krylov_create(storm_hip_ctx *ctx, int method, storm_hip_krylov **o
   HIP_TRY(hipMalloc((void **)&k->d_st, sizeof(SolverState)));
   HIP_TRY(hipMemset(k->d_st, 0, sizeof(SolverState)));
   HIP_TRY(hipHostMalloc((void **)&k->h_st, sizeof(SolverState), hipHostMallocDefault));
-  HIP_TRY(hipHostMalloc((void **)&k->h_ring, sizeof(int) * kStateRing, hipHostMallocMapped));
+  HIP_TRY(hipHostMalloc((void **)&k->h_ring, sizeof(unsigned long long) * kStateRing, hipHostMallocMapped));
   HIP_TRY(hipHostGetDevicePointer((void **)&k->d_ring, k->h_ring, 0));
   k->ev.resize(kStateRing);
   for (auto &e : k->ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1879,7 +1872,7 @@ int storm_hip_krylov_solve(storm_hip_krylov *k, const storm_hip_vec *b, storm_hi
                           (k->method == STORM_HIP_CG || k->method == STORM_HIP_BICGSTAB ||
                            (k->method == STORM_HIP_GMRES && params->num_inner_iterations < kMaxMulti));
   if (fused_path) return krylov_solve_engine(k, b, x, params, result, history, pre_applies);  // (has its own fallback)
-  const int st = coop_solve_with_fallback(c, x->d, x->n_owned + x->n_halo, run_engine_body, &a, &fb);
+  const int st = coop_solve_with_fallback(c, x, run_engine_body, &a, &fb);
   if (st == STORM_HIP_OK) result->path_fallback = fb;
   return st;
 }
@@ -1909,13 +1902,10 @@ static int krylov_solve_engine(storm_hip_krylov *k, const storm_hip_vec *b, stor
     k->applies_after.push_back(k->applies);
     k->pre_after.push_back(k->pre_applies);
     // post a marker behind this iteration; look at the verdict of iteration it - lag
-    const int slot = (int)(it % kStateRing);
-    HIP_TRY(hipEventRecord(k->ev[slot], c->stream));
-    if (it >= k->lag) {
-      const int old = (int)((it - k->lag) % kStateRing);
-      HIP_TRY(hipEventSynchronize(k->ev[old]));
-      const bool stop = *(volatile int *)&k->h_ring[old] != 0;
-      k->h_ring[old] = 0;
+    st = ring_post(c, k->ev, it);
+    if (st == STORM_HIP_OK && it >= k->lag) {
+      bool stop = false;
+      st = ring_wait(c, k->ev, k->h_ring, it - k->lag, &stop);
       if (stop) break;
     }
   }

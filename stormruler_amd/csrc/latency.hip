@@ -35,7 +35,6 @@
 
 namespace storm {
 
-constexpr int kLatSlices = 8;  // slices a wavefront may own (registers: 4 doubles per slice and lane)
 constexpr int kLatBlock = 1024;  // one block per CU: a synchronisation point costs per participating BLOCK
 constexpr int kLatWaves = kLatBlock / kWave;
 
@@ -824,25 +823,30 @@ static bool coop_launch(storm_hip_ctx *c, const void *fn, unsigned blocks, void 
   return true;
 }
 
-int coop_solve_with_fallback(storm_hip_ctx *c, double *x, int64_t n_total, int (*run)(void *), void *arg, int *fallback_out) {
+int coop_solve_with_fallback(storm_hip_ctx *c, storm_hip_vec *x, int (*run)(void *), void *arg, int *fallback_out) {
   c->coop_fallback = 0, c->coop_ran = 0;
-  double *x0 = nullptr;
+  const int64_t n_total = x->n_owned + x->n_halo;
+  storm_hip_vec *x0 = nullptr;  // the start vector, kept for the re-run (pooled storage: no allocation, no stream wait per solve)
   const bool keep = c->comm == nullptr && c->coop_disabled == 0 && (c->opt_latency_path != 0 || c->opt_coop_mgs != 0) &&
-                    n_total <= ((int64_t)1 << 23);  // (no cooperative kernel takes more rows than that)
+                    n_total > 0 && n_total <= ((int64_t)1 << 23);  // (no cooperative kernel takes more rows than that)
   if (keep) {
-    HIP_TRY(hipMalloc((void **)&x0, sizeof(double) * (size_t)std::max<int64_t>(1, n_total)));
-    HIP_TRY(hipMemcpyAsync(x0, x, sizeof(double) * (size_t)n_total, hipMemcpyDeviceToDevice, c->stream));
+    STORM_TRY(vec_create_work_batch(x, 1, &x0));
+    const hipError_t e = hipMemcpyAsync(x0->d, x->d, sizeof(double) * (size_t)n_total, hipMemcpyDeviceToDevice, c->stream);
+    if (e != hipSuccess) {
+      (void)storm_hip_vec_destroy(x0);
+      HIP_TRY(e);
+    }
   }
   int st = run(arg);
   if (st == kStatusCoopGaveUp && keep) {
-    (void)hipMemcpyAsync(x, x0, sizeof(double) * (size_t)n_total, hipMemcpyDeviceToDevice, c->stream);
+    (void)hipMemcpyAsync(x->d, x0->d, sizeof(double) * (size_t)n_total, hipMemcpyDeviceToDevice, c->stream);
     c->coop_disabled = 1;
     st = run(arg);
     c->coop_disabled = 0;
     c->coop_fallback = 2;
   }
   if (st == kStatusCoopGaveUp) st = STORM_HIP_E_HIP;  // (the message of lat_check_gave_up stands)
-  if (x0) (void)hipStreamSynchronize(c->stream), (void)hipFree(x0);
+  if (x0) (void)storm_hip_vec_destroy(x0);
   if (fallback_out) *fallback_out = c->coop_fallback;
   return st;
 }

@@ -21,9 +21,12 @@ __device__ inline void advance(SolverState *st, double abs_err) {
   if (st->history) st->history[st->iteration] = abs_err;
   if (conv) st->converged = 1;
   if (conv || st->iteration >= st->num_iterations) st->done = 1;
-  // Tell the host (it polls this pinned ring `check_lag` iterations behind; the event it waits on
-  // is recorded after this kernel, so the store is visible by then).
-  if (st->done_ring) st->done_ring[(st->iteration - 1) % kStateRing] = st->done;
+  // Tell the host (it polls this pinned ring `check_lag` iterations behind): one system-scope store of a word that
+  // names its iteration -- the host needs no event behind the kernel to trust it (common.hpp ring_wait).
+  if (st->done_ring)
+    __hip_atomic_store(st->done_ring + (st->iteration - 1) % kStateRing,
+                       ((unsigned long long)st->iteration << 1) | (unsigned long long)(st->done != 0), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // After init(): Solver.hpp:122-128.
@@ -38,7 +41,8 @@ __device__ inline void begin(SolverState *st, double initial_error) {
   if (st->abs_tol > 0.0 && initial_error < st->abs_tol) st->converged = 1, st->done = 1;
   if (st->num_iterations <= 0) st->done = 1;
   if (st->done && st->done_ring)  // no iterate() will run: every poll must see it
-    for (int i = 0; i < kStateRing; ++i) st->done_ring[i] = 1;
+    for (int i = 0; i < kStateRing; ++i)
+      __hip_atomic_store(st->done_ring + i, kRingDoneAtOnce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // The device-side state of a GMRES cycle and the Givens update of Hessenberg column k with the beta recurrence

@@ -710,22 +710,13 @@ struct Driver {
 static int prepare_state(Driver &d, const storm_hip_solver_params *p, double *history) {
   storm_hip_ctx *c = d.c;
   STORM_REQUIRE(p->num_iterations >= 0, "solve: num_iterations < 0");
-  SolverState h;
-  memset(&h, 0, sizeof h);
-  h.abs_tol = p->absolute_error_tolerance;
-  h.rel_tol = p->relative_error_tolerance;
-  h.num_iterations = p->num_iterations;
-  h.history = nullptr;
-  h.done_ring = c->d_done_ring;
-  for (int i = 0; i < kStateRing; ++i) c->h_done_ring[i] = 0;
+  for (int i = 0; i < kStateRing; ++i) c->h_done_ring[i] = 0;  // (the previous solve ended with a stream wait: nothing posts any more)
   if (history) {
     HIP_TRY(hipMalloc(&d.d_history, sizeof(double) * (size_t)(p->num_iterations + 1)));
     HIP_TRY(hipMemsetAsync(d.d_history, 0, sizeof(double) * (size_t)(p->num_iterations + 1), c->stream));
-    h.history = d.d_history;
   }
-  c->h_state[0] = h;
-  HIP_TRY(hipMemcpyAsync(c->d_state, &c->h_state[0], sizeof(SolverState), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));  // h_state[0] is reused by the ring below
+  STORM_TRY(state_init(c, c->d_state, p->absolute_error_tolerance, p->relative_error_tolerance, p->num_iterations, d.d_history,
+                       c->d_done_ring));
   d.lag = p->check_lag > 0 ? p->check_lag : 4;
   if (d.lag > kStateRing - 1) d.lag = kStateRing - 1;
   return STORM_HIP_OK;
@@ -735,15 +726,9 @@ static int prepare_state(Driver &d, const storm_hip_solver_params *p, double *hi
 // iteration it - lag says the device is done.
 static int post_and_poll(Driver &d, int64_t it, bool *stop) {
   storm_hip_ctx *c = d.c;
-  const int slot = (int)(it % kStateRing);
-  HIP_TRY(hipEventRecord(c->ev_ring[slot], c->stream));
+  STORM_TRY(ring_post(c, c->ev_ring, it));
   *stop = false;
-  if (it >= d.lag) {
-    const int old = (int)((it - d.lag) % kStateRing);
-    HIP_TRY(hipEventSynchronize(c->ev_ring[old]));
-    if (*(volatile int *)&c->h_done_ring[old]) *stop = true;
-    c->h_done_ring[old] = 0;  // slot is reused kStateRing iterations later
-  }
+  if (it >= d.lag) STORM_TRY(ring_wait(c, c->ev_ring, c->h_done_ring, it - d.lag, stop));
   return STORM_HIP_OK;
 }
 
@@ -798,10 +783,15 @@ struct VecPool {  // work vectors: re-assigned (zeroed) on every solve like Solv
   }
   // zero = false: the solver writes every owned row of these vectors before it reads it (context.hip, vec_create_work)
   int make(const storm_hip_vec *like, int count, bool zero = true) {
+    if (!zero) {
+      std::vector<storm_hip_vec *> made((size_t)count, nullptr);
+      STORM_TRY(vec_create_work_batch(like, count, made.data()));
+      v.insert(v.end(), made.begin(), made.end());
+      return STORM_HIP_OK;
+    }
     for (int i = 0; i < count; ++i) {
       storm_hip_vec *p = nullptr;
-      if (zero) STORM_TRY(storm_hip_vec_create_like(like, &p));
-      else STORM_TRY(vec_create_work(like, &p));
+      STORM_TRY(storm_hip_vec_create_like(like, &p));
       v.push_back(p);
     }
     return STORM_HIP_OK;
@@ -994,7 +984,7 @@ int fused_solve(FusedSolveArgs a) {
   storm_hip_ctx *c = a.op->ctx;
   HIP_TRY(hipSetDevice(c->device));
   int fb = 0;
-  const int st = coop_solve_with_fallback(c, a.x->d, a.x->n_owned + a.x->n_halo, run_fused_body, &a, &fb);
+  const int st = coop_solve_with_fallback(c, a.x, run_fused_body, &a, &fb);
   if (st == STORM_HIP_OK) a.result->path_fallback = fb;
   return st;
 }
@@ -1021,7 +1011,9 @@ int solve_cg_body(const FusedSolveArgs &args) {
     // (the cooperative kernel could not be launched: the throughput path below, noted in result->path_fallback)
   }
   const size_t v0 = pool.v.size();
-  STORM_TRY(pool.make(x, 3, false));  // (r: the init apply; p: init_residual's copy; z: the first SpMV -- all before any read)
+  // (r: the init apply; p: init_residual's copy; z: the first SpMV -- all before any read; the fused step's second p)
+  const bool may_fuse_step = c->opt_cg_fuse != 0 && spmv_can_fuse_cg(op);
+  STORM_TRY(pool.make(x, may_fuse_step ? 4 : 3, false));
   double *p = pool.v[v0]->d, *r = pool.v[v0 + 1]->d, *z = pool.v[v0 + 2]->d;
   const int nbv = vec_blocks(c, n);
 
@@ -1060,10 +1052,7 @@ int solve_cg_body(const FusedSolveArgs &args) {
   const bool fuse_step = c->opt_cg_fuse != 0 && (c->comm == nullptr || ipc) && tick && !tick_spmv && c->opt_fuse_dot != 0 &&
                          spmv_can_fuse_cg(op);
   double *p_alt = nullptr;
-  if (fuse_step) {
-    STORM_TRY(pool.make(x, 1, false));
-    p_alt = pool.v.back()->d;
-  }
+  if (fuse_step) p_alt = pool.v[v0 + 3]->d;
   int64_t last_enqueued = -1;
   auto enqueue_iteration = [&]() -> int {
     const int q = fuse_step ? 0 : sweep ? (int)(cur_it & 1) : 0;  // (fused: the step kernel forward, cg_r backward, always)

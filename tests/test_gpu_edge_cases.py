@@ -224,6 +224,41 @@ def test_hipgraph_replay_option_gives_the_same_solve(cls):
     assert np.array_equal(res[0][2], res[1][2])
 
 
+@pytest.mark.parametrize("cls", ["CgSolver", "BiCgStabSolver", "GmresSolver", "CgsSolver"])
+def test_host_poll_without_stream_markers_gives_the_same_solve(cls):
+    """The host follows a solve through self-validating words the step kernels post into a pinned ring (no event behind
+    every iteration: common.hpp ring_wait); option poll_events = 1 brings the markers back.  Same iteration count and
+    bits either way, for every lag, when the solve converges, runs out of iterations or has nothing to iterate."""
+    from stormruler_amd import api, mesh
+
+    g = mesh.structured_box(24)
+    res = {}
+    for events in (0, 1):
+        ctx = api.Context(0)
+        ctx.set_option("poll_events", events)
+        ctx.set_option("latency_path", 0)  # (the kernel-per-statement loops are the ones that poll)
+        mat = api.StencilMatrix.from_face_graph(ctx, g)
+        b = api.DeviceVector.from_numpy(ctx, np.ones(g.n_cells))
+        for lag in (0, 1, 7, 63, 200):
+            for iters, tol in ((2000, 1e-6), (5, 0.0), (0, 1e-6), (2000, 1e30)):
+                x = api.DeviceVector(ctx, g.n_cells)
+                s = getattr(api, cls)()
+                s.check_lag, s.num_iterations = lag, iters
+                s.absolute_error_tolerance = s.relative_error_tolerance = tol
+                ok = s.solve(x, b, api.HipStencilOperator(mat, -1.0, 0.0))
+                res[(events, lag, iters, tol)] = (ok, s.iteration, s.absolute_error, x.to_numpy())
+        ctx.close()
+    for key, v in res.items():
+        if key[0] == 1:
+            continue
+        w = res[(1,) + key[1:]]
+        assert v[0] == w[0] and v[1] == w[1] and v[2] == w[2] and np.array_equal(v[3], w[3]), key
+        if key[3] == 0.0:
+            assert v[1] == key[2]
+        if key[3] == 1e30 or key[2] == 0:
+            assert v[1] == 0
+
+
 def test_solve_logs_the_reference_line(caplog):
     """One INFO line per solve, the reference's `STORM_INFO("n_iter: ..., abs_err: ..., rel_err: ...")`
     (Solver.hpp:144-145), on the logger `stormruler_amd.solvers` -- from the native loop and the statement path."""
