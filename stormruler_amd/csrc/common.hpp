@@ -75,6 +75,17 @@ struct SolverState {
 
 struct Comm;  // comm.hip
 
+// What a storm_hip_krylov object owns on the device and in pinned host memory; a destroyed engine leaves it with its
+// context (storm_hip_ctx::krylov_free) for the next one: creating a solver object per solve -- the reference's usage,
+// Playground.cpp:199-202 -- then costs no allocation (two pinned allocations, a device one and a blocking memset were
+// most of a 0.1 ms create + destroy).
+struct KrylovRes {
+  SolverState *d_st = nullptr, *h_st = nullptr;
+  unsigned long long *h_ring = nullptr, *d_ring = nullptr;
+  double *S = nullptr;  // the engine's scalar register file
+  int S_cap = 0;
+};
+
 }  // namespace storm
 
 struct storm_hip_ctx {
@@ -112,7 +123,8 @@ struct storm_hip_ctx {
   storm::SolverState *h_state = nullptr;  // pinned staging copy of the state
   unsigned long long *h_done_ring = nullptr;  // pinned, written by the device's step kernels (solver_device.hpp advance())
   unsigned long long *d_done_ring = nullptr;  // device pointer to the same memory
-  std::vector<hipEvent_t> ev_ring;            // (option poll_events = 1: a marker behind every iteration, the r02 form)
+  std::vector<hipEvent_t> ev_ring;            // (option poll_events = 1: a marker behind every iteration, the r02 form; created on first use)
+  std::vector<storm::KrylovRes> krylov_free;   // krylov.hip: resources of destroyed engines, reused by the next create
   int64_t opt_poll_events = 0;
   // options
   int64_t opt_ell_cap = 0;
@@ -296,6 +308,9 @@ int vec_create_work(const storm_hip_vec *like, storm_hip_vec **out);
 // eight of them per CG solve were a quarter of a K = 0 solve's 0.34 ms)
 int vec_create_work_batch(const storm_hip_vec *like, int count, storm_hip_vec **out);
 // context.hip: the device's SolverState for a new solve, written by one small kernel (no staged copy, no stream wait)
+// ... and read back: one small kernel stores it into pinned host memory, then the stream wait every solve ends with (a
+// staged device-to-host copy is a launch of its own with ~30 us of idle device in front of it)
+int state_read(storm_hip_ctx *c, const SolverState *d_state, SolverState *h_pinned);
 int state_init(storm_hip_ctx *c, SolverState *d_state, double abs_tol, double rel_tol, long long num_iterations, double *history,
                unsigned long long *d_ring);
 

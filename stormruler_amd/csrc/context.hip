@@ -68,11 +68,9 @@ int storm_hip_ctx_create(int device_id, storm_hip_ctx **out) {
   HIP_TRY(hipMemset(c->d_tickets, 0, sizeof(int) * (1 + 2048) * 16));
   HIP_TRY(hipMalloc((void **)&c->d_state, sizeof(SolverState)));
   HIP_TRY(hipMemset(c->d_state, 0, sizeof(SolverState)));
-  HIP_TRY(hipHostMalloc((void **)&c->h_state, sizeof(SolverState), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void **)&c->h_state, sizeof(SolverState), hipHostMallocMapped));
   HIP_TRY(hipHostMalloc((void **)&c->h_done_ring, sizeof(unsigned long long) * kStateRing, hipHostMallocMapped));
   HIP_TRY(hipHostGetDevicePointer((void **)&c->d_done_ring, c->h_done_ring, 0));
-  c->ev_ring.resize(kStateRing);
-  for (auto &ev : c->ev_ring) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   *out = c;
   return STORM_HIP_OK;
 }
@@ -83,6 +81,12 @@ int storm_hip_ctx_destroy(storm_hip_ctx *c) {
   (void)hipDeviceSynchronize();
   comm_destroy(c);
   for (auto &ev : c->ev_ring) (void)hipEventDestroy(ev);
+  for (auto &r : c->krylov_free) {
+    if (r.S) (void)hipFree(r.S);
+    (void)hipFree(r.d_st);
+    (void)hipHostFree(r.h_st);
+    (void)hipHostFree(r.h_ring);
+  }
   for (auto &ev : c->prof_events) (void)hipEventDestroy(ev);
   for (auto &pb : c->pool) (void)hipFree(pb.second);
   (void)hipFree(c->d_partials);
@@ -221,7 +225,13 @@ extern "C" int storm_hip_vec_create(storm_hip_ctx *c, int64_t n_owned, int64_t n
 }
 namespace storm {
 int ring_post(storm_hip_ctx *c, std::vector<hipEvent_t> &events, int64_t it) {
-  if (c->opt_poll_events != 0) HIP_TRY(hipEventRecord(events[(size_t)(it % kStateRing)], c->stream));
+  if (c->opt_poll_events == 0) return STORM_HIP_OK;
+  while (events.size() < (size_t)kStateRing) {
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    events.push_back(ev);
+  }
+  HIP_TRY(hipEventRecord(events[(size_t)(it % kStateRing)], c->stream));
   return STORM_HIP_OK;
 }
 
@@ -236,7 +246,7 @@ int ring_wait(storm_hip_ctx *c, std::vector<hipEvent_t> &events, volatile unsign
     return false;
   };
   *stop = false;
-  if (c->opt_poll_events != 0) {
+  if (c->opt_poll_events != 0 && events.size() == (size_t)kStateRing) {  // (the option switched on mid-solve: poll)
     HIP_TRY(hipEventSynchronize(events[(size_t)(it % kStateRing)]));
     (void)posted(stop);
     return STORM_HIP_OK;
@@ -306,6 +316,21 @@ __global__ void state_init_kernel(SolverState *st, double abs_tol, double rel_to
   st->iteration = 0, st->num_iterations = num_iterations;
   st->done = 0, st->converged = 0, st->verify_failed = 0;
   st->history = history, st->done_ring = ring;
+}
+__global__ void state_export_kernel(const SolverState *st, SolverState *host) {
+  static_assert(sizeof(SolverState) % sizeof(unsigned long long) == 0, "SolverState is copied in 8-byte words");
+  const unsigned long long *s = reinterpret_cast<const unsigned long long *>(st);
+  unsigned long long *d = reinterpret_cast<unsigned long long *>(host);
+  for (unsigned i = threadIdx.x; i < sizeof(SolverState) / sizeof(unsigned long long); i += blockDim.x)
+    __hip_atomic_store(d + i, s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+int state_read(storm_hip_ctx *c, const SolverState *d_state, SolverState *h_pinned) {
+  SolverState *h_dev = nullptr;
+  HIP_TRY(hipHostGetDevicePointer((void **)&h_dev, h_pinned, 0));
+  hipLaunchKernelGGL(state_export_kernel, dim3(1), dim3(kBlock), 0, c->stream, d_state, h_dev);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return STORM_HIP_OK;
 }
 int state_init(storm_hip_ctx *c, SolverState *d_state, double abs_tol, double rel_tol, long long num_iterations, double *history,
                unsigned long long *d_ring) {

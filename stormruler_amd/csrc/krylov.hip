@@ -1760,9 +1760,7 @@ int begin_solve(K *k, const storm_hip_vec *b, storm_hip_vec *x, const storm_hip_
 }
 
 int read_state(K *k) {
-  HIP_TRY(hipMemcpyAsync(k->h_st, k->d_st, sizeof(SolverState), hipMemcpyDeviceToHost, k->c->stream));
-  HIP_TRY(hipStreamSynchronize(k->c->stream));
-  return STORM_HIP_OK;
+  return state_read(k->c, k->d_st, k->h_st);
 }
 
 typedef int (*fused_entry)(const storm_hip_op *, double, double, const storm_hip_vec *, storm_hip_vec *,
@@ -1779,13 +1777,24 @@ int storm_hip_krylov_create(storm_hip_ctx *ctx, int method, storm_hip_krylov **o
   HIP_TRY(hipSetDevice(ctx->device));
   auto *k = new storm_hip_krylov();
   k->c = ctx, k->method = method;
-  HIP_TRY(hipMalloc((void **)&k->d_st, sizeof(SolverState)));
-  HIP_TRY(hipMemset(k->d_st, 0, sizeof(SolverState)));
-  HIP_TRY(hipHostMalloc((void **)&k->h_st, sizeof(SolverState), hipHostMallocDefault));
-  HIP_TRY(hipHostMalloc((void **)&k->h_ring, sizeof(unsigned long long) * kStateRing, hipHostMallocMapped));
-  HIP_TRY(hipHostGetDevicePointer((void **)&k->d_ring, k->h_ring, 0));
-  k->ev.resize(kStateRing);
-  for (auto &e : k->ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  if (!ctx->krylov_free.empty()) {  // what a destroyed engine of this context left (begin_solve writes all of it anew)
+    const KrylovRes r = ctx->krylov_free.back();
+    ctx->krylov_free.pop_back();
+    k->d_st = r.d_st, k->h_st = r.h_st, k->h_ring = r.h_ring, k->d_ring = r.d_ring, k->S = r.S, k->S_cap = r.S_cap;
+  } else {
+    hipError_t e = hipMalloc((void **)&k->d_st, sizeof(SolverState));
+    if (e == hipSuccess) e = hipMemset(k->d_st, 0, sizeof(SolverState));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&k->h_st, sizeof(SolverState), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&k->h_ring, sizeof(unsigned long long) * kStateRing, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&k->d_ring, k->h_ring, 0);
+    if (e != hipSuccess) {
+      if (k->d_st) (void)hipFree(k->d_st);
+      if (k->h_st) (void)hipHostFree(k->h_st);
+      if (k->h_ring) (void)hipHostFree(k->h_ring);
+      delete k;
+      HIP_TRY(e);
+    }
+  }
   *out = k;
   return STORM_HIP_OK;
 }
@@ -1796,10 +1805,14 @@ int storm_hip_krylov_destroy(storm_hip_krylov *k) {
   (void)hipStreamSynchronize(k->c->stream);
   release_work(k);
   for (auto &e : k->ev) (void)hipEventDestroy(e);
-  if (k->S) (void)hipFree(k->S);
-  (void)hipFree(k->d_st);
-  (void)hipHostFree(k->h_st);
-  (void)hipHostFree(k->h_ring);
+  if (k->c->krylov_free.size() < 8) {  // (the stream is idle: nothing reads these any more)
+    k->c->krylov_free.push_back(KrylovRes{k->d_st, k->h_st, k->h_ring, k->d_ring, k->S, k->S_cap});
+  } else {
+    if (k->S) (void)hipFree(k->S);
+    (void)hipFree(k->d_st);
+    (void)hipHostFree(k->h_st);
+    (void)hipHostFree(k->h_ring);
+  }
   delete k;
   return STORM_HIP_OK;
 }

@@ -793,6 +793,7 @@ int op_make_latency_copy(storm_hip_op *op, int64_t n, int64_t n_halo, const std:
 
 // After a cooperative kernel has completed: did one of its waits give up?
 int lat_check_gave_up(storm_hip_ctx *c) {
+  if (!c->coop_ran) return STORM_HIP_OK;  // (no cooperative kernel since the last look: nothing to read back)
   int flag = 0;
   HIP_TRY(hipMemcpyAsync(&flag, c->d_lat_slots + (size_t)2 * 256 * kLatSlotStride, sizeof flag, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));

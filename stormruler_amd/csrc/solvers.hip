@@ -735,8 +735,7 @@ static int post_and_poll(Driver &d, int64_t it, bool *stop) {
 static int collect(Driver &d, storm_hip_solver_result *res, double *history, int64_t applies_fn(int64_t, int64_t),
                    int64_t m) {
   storm_hip_ctx *c = d.c;
-  HIP_TRY(hipMemcpyAsync(&c->h_state[0], c->d_state, sizeof(SolverState), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  STORM_TRY(state_read(c, c->d_state, &c->h_state[0]));
   {  // (a cooperative kernel of this solve -- CG's, a Gram-Schmidt chain -- timed out: the caller re-runs the solve)
     const int st_coop = lat_check_gave_up(c);
     if (st_coop != STORM_HIP_OK) {
@@ -1275,7 +1274,7 @@ int solve_gmres_body(const FusedSolveArgs &args) {
   Driver d{c, op, alpha, beta, n, c->d_state, &c->d_state->done};
   STORM_TRY(prepare_state(d, params, history));
   VecPool pool;
-  STORM_TRY(pool.make(x, m + 1));  // q_0 .. q_m                     SolverGmres.hpp:60-61
+  STORM_TRY(pool.make(x, m + 1, false));  // q_0 .. q_m (SolverGmres.hpp:60-61): q_0 written by start(), q_k+1 by the apply of iteration k
   std::vector<const double *> q(m + 1);
   for (int i = 0; i <= m; ++i) q[i] = pool.v[i]->d;
   // H, beta, cs, sn                                                  SolverGmres.hpp:56-58
@@ -1348,8 +1347,7 @@ int solve_gmres_body(const FusedSolveArgs &args) {
   // InnerOuterIterativeSolver::finalize, Solver.hpp:250-257.  The in-loop finalize of the very
   // last iteration was skipped by the `done` predicate, so it always runs here.  (When no
   // iterate() ran the reference's finalize divides by H(0,0) = 0; that is not reproduced.)
-  HIP_TRY(hipMemcpyAsync(&c->h_state[0], c->d_state, sizeof(SolverState), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  STORM_TRY(state_read(c, c->d_state, &c->h_state[0]));
   const int64_t iters = c->h_state[0].iteration;
   if (iters > 0) STORM_TRY(finalize((int)((iters - 1) % m), true));
   return collect(d, result, history, applies_gmres, m);
