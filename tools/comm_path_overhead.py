@@ -19,7 +19,7 @@ from test_gpu_comm import _periodic_z_local_graph  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 only = sys.argv[2] if len(sys.argv) > 2 else ""  # "ipc" / "rccl": that transport alone, few iterations (for a kernel trace)
-iters = 60 if only else 400
+iters = int(os.environ.get("COMM_ITERS", "60" if only else "400"))
 
 
 def rate(ctx, mat, g):
