@@ -156,9 +156,13 @@ def test_fused_cg_step_kernels_give_the_unfused_iteration(env, shape):
         assert mat.stats()["tiled_planes"] == 2
         b = api.DeviceVector.from_numpy(ctx, 1.0 + 0.5 * np.sin(0.05 * np.arange(g.n_cells)))
         res = {}
-        for name, fuse, march in (("unfused", 0, 0), ("tiles", 1, 0), ("march16", 1, 16), ("march5", 1, 5), ("march2", 1, 2)):
+        # (odd chunks march DOWN by default -- the two chunks that share a pair of planes then touch it at the same
+        #  moment; "...up": every chunk upwards, the first form of the kernel)
+        for name, fuse, march, alt in (("unfused", 0, 0, 1), ("tiles", 1, 0, 1), ("march16", 1, 16, 1), ("march5", 1, 5, 1),
+                                       ("march2", 1, 2, 1), ("march5up", 1, 5, 0), ("march3up", 1, 3, 0)):
             ctx.set_option("cg_fuse", fuse)
             ctx.set_option("cg_march", march)
+            ctx.set_option("cg_march_alternate", alt)
             for iters in (None, 7):  # to convergence; and stopped by the iteration limit (the tail kernel's x update)
                 s = api.CgSolver()
                 s.record_history = True
@@ -170,7 +174,7 @@ def test_fused_cg_step_kernels_give_the_unfused_iteration(env, shape):
         for iters in (None, 7):
             ok0, it0, h0, x0 = res[("unfused", iters)]
             assert ok0 == (iters is None)
-            for name in ("tiles", "march16", "march5", "march2"):
+            for name in ("tiles", "march16", "march5", "march2", "march5up", "march3up"):
                 ok1, it1, h1, x1 = res[(name, iters)]
                 assert ok1 == ok0 and it1 == it0, (name, iters, it1, it0)
                 assert np.allclose(h1, h0, rtol=1e-9)
@@ -183,3 +187,4 @@ def test_fused_cg_step_kernels_give_the_unfused_iteration(env, shape):
         ctx.set_option("latency_path", 1)
         ctx.set_option("cg_fuse", 1)
         ctx.set_option("cg_march", 8)
+        ctx.set_option("cg_march_alternate", 1)
