@@ -15,7 +15,8 @@ except Exception:  # pragma: no cover - torch is optional for single-GPU use
     torch = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstorm_hip.so")
+# (STORM_HIP_LIB: another build of the same library, for A/B runs of two source states on one box -- tools/)
+LIB_PATH = os.environ.get("STORM_HIP_LIB") or os.path.join(_HERE, "libstorm_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
