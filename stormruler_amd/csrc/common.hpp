@@ -165,6 +165,7 @@ struct storm_hip_ctx {
   int64_t opt_ipc_fused = 1;            // peer-window transport: the interior launch sends, the boundary launch reads the window (0: stand-alone send / receive-copy kernels)
   int64_t opt_ipc_streams = 2;          // peer-window halo exchange: 2 = on the comm stream beside the interior rows, 1 = on the compute stream around them
   int64_t opt_generic_solvers = 0;  // 1: storm_hip_krylov_solve never takes the fused CG / BiCGStab / GMRES loops (A/B knob)
+  int64_t opt_cg_march_fill = 2048;    // ... fewer planes per block on smaller lattices, so that the grid holds about this many blocks (0: cg_march as given)
   int64_t opt_cg_march_alternate = 1;  // odd z-chunks of the marching step kernel march downwards (spmv.hip MarchArgs::alternate)
   int64_t opt_cg_march_ticket = 0;  // ... which finishes <p,z> itself (tickets) instead of leaving per-wave partials for a one-block final pass: measured no gain (234 vs 233 us per iteration at 256^3: the ticket tail of 2 048 long-running blocks costs what the 4.7 us launch did), off
   int64_t opt_cg_march = 8;   // ... as blocks of 1024 rows marching through this many planes (0: tiles, spmv_canon_tile planes deep); 256^3, us per CG iteration: tiles 239, 8 planes 230, 16 234, 32 236, 64 237 (profiles/r03k)

@@ -177,6 +177,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "cg_march")) c->opt_cg_march = value;
   else if (!strcmp(key, "cg_march_ticket")) c->opt_cg_march_ticket = value;
   else if (!strcmp(key, "cg_march_alternate")) c->opt_cg_march_alternate = value;
+  else if (!strcmp(key, "cg_march_fill")) c->opt_cg_march_fill = value;
   else if (!strcmp(key, "poll_events")) c->opt_poll_events = value;
   else if (!strcmp(key, "host_result")) c->opt_host_result = value;
   else if (!strcmp(key, "fuse_mgs")) c->opt_fuse_mgs = value;

@@ -1624,7 +1624,13 @@ static bool cg_march_geometry(const storm_hip_op *op, MarchArgs *M, int *n_block
   if ((int64_t)sizeof(double) * 3 * (kTileRun + 2 * M->T.a) > 60 * 1024) return false;
   if (partitioned && op->n_rows % M->T.b != 0) return false;  // (whole planes only)
   const int64_t planes = (op->n_rows + M->T.b - 1) / M->T.b;
-  M->zc_planes = (int)std::min<int64_t>(zc, planes);
+  // (option cg_march is the chunk of a large lattice; a smaller one marches fewer planes per block, so that the grid
+  //  still holds ~2 blocks per resident slot: 192^3 with 8-plane chunks is 864 blocks for 1 024 slots -- 124 us per CG
+  //  iteration against 111 with 4-plane chunks)
+  //  (option cg_march_fill: the block count aimed at; 0 = cg_march whatever the size)
+  const int64_t want = op->ctx->opt_cg_march_fill;
+  const int64_t fill = want > 0 ? planes * M->T.tiles_per_plane / want : zc;
+  M->zc_planes = (int)std::min<int64_t>(std::min<int64_t>(zc, std::max<int64_t>(2, fill)), planes);
   M->alternate = (int)(op->ctx->opt_cg_march_alternate != 0);
   M->apply_begin = partitioned ? (int)op->int_plane0 : 0;
   M->apply_end = partitioned ? (int)op->int_plane1 : (int)planes;

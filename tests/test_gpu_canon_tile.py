@@ -151,6 +151,7 @@ def test_fused_cg_step_kernels_give_the_unfused_iteration(env, shape):
     ctx.set_option("latency_path", 0)
     ctx.set_option("spmv_canon_tile_min_rows", 0)
     ctx.set_option("spmv_canon_tile", 2)
+    ctx.set_option("cg_march_fill", 0)  # (the chunk sizes asked for below, however small the lattice)
     try:
         mat = api.StencilMatrix.from_face_graph(ctx, g)
         assert mat.stats()["tiled_planes"] == 2
@@ -188,3 +189,4 @@ def test_fused_cg_step_kernels_give_the_unfused_iteration(env, shape):
         ctx.set_option("cg_fuse", 1)
         ctx.set_option("cg_march", 8)
         ctx.set_option("cg_march_alternate", 1)
+        ctx.set_option("cg_march_fill", 2048)
