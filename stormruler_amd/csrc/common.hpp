@@ -103,6 +103,8 @@ struct storm_hip_ctx {
   double *d_partials2 = nullptr;      // [kMaxMulti * kStage2] second-stage partials
   double *d_scalars = nullptr;        // [kMaxMulti] results of host-visible reductions
   unsigned long long lat_seq = 0;     // running sequence number of the cooperative Gram-Schmidt chains' all-reduces
+  double *d_gmres = nullptr;          // GMRES' Hessenberg matrix, beta, cs, sn of the fused loop (grown on demand, kept)
+  size_t gmres_capacity = 0;
   double *d_ticket_sums = nullptr;    // ... and the groups' sums (a buffer of their own: d_partials2 may hold a first pass a kernel is still reading)
   int *d_tickets = nullptr;           // ticket_device.hpp: self-re-arming counters of the in-kernel reductions
   char *d_lat_slots = nullptr;        // latency path: two 256-byte all-reduce slots per block (256 blocks)

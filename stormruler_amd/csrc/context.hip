@@ -92,6 +92,7 @@ int storm_hip_ctx_destroy(storm_hip_ctx *c) {
   for (auto &ev : c->prof_events) (void)hipEventDestroy(ev);
   for (auto &pb : c->pool) (void)hipFree(pb.second);
   (void)hipFree(c->d_partials);
+  if (c->d_gmres) (void)hipFree(c->d_gmres);
   (void)hipFree(c->d_partials2);
   (void)hipFree(c->d_scalars);
   (void)hipFree(c->d_lat_slots);

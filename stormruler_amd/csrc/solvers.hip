@@ -1279,12 +1279,14 @@ int solve_gmres_body(const FusedSolveArgs &args) {
   for (int i = 0; i <= m; ++i) q[i] = pool.v[i]->d;
   // H, beta, cs, sn                                                  SolverGmres.hpp:56-58
   const size_t gm_doubles = (size_t)(m + 1) * m + (m + 1) + m + m;
-  double *d_gm = nullptr;
-  HIP_TRY(hipMalloc(&d_gm, sizeof(double) * gm_doubles));
-  struct Free {
-    double *p;
-    ~Free() { (void)hipFree(p); }
-  } free_gm{d_gm};
+  if (gm_doubles > c->gmres_capacity) {  // (kept by the context: no allocation, no hipFree -- a device-wide wait -- per solve)
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_gmres) (void)hipFree(c->d_gmres);
+    c->d_gmres = nullptr, c->gmres_capacity = 0;
+    HIP_TRY(hipMalloc(&c->d_gmres, sizeof(double) * gm_doubles));
+    c->gmres_capacity = gm_doubles;
+  }
+  double *d_gm = c->d_gmres;
   HIP_TRY(hipMemsetAsync(d_gm, 0, sizeof(double) * gm_doubles, c->stream));
   d.g = GmresDev{d_gm, d_gm + (size_t)(m + 1) * m, d_gm + (size_t)(m + 1) * m + (m + 1),
                  d_gm + (size_t)(m + 1) * m + (m + 1) + m, m};
