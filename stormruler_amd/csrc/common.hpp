@@ -152,6 +152,7 @@ struct storm_hip_ctx {
   int64_t opt_coop_mgs_min_rows = 0;  // ... from this many rows on (0: always; with two steps per synchronisation point the chain is no slower than a launch per step even on small meshes)
   int64_t opt_coop_mgs = 1;             // GMRES: the Gram-Schmidt chain of an Arnoldi step as one cooperative kernel (latency.hip)
   int64_t opt_latency_publish = 1;      // ... its rows published with awaited atomic exchanges (0: write-through stores, ordered by their acknowledgement)
+  int64_t opt_coop_plain = 1;           // the cooperative kernels by ordinary launches (latency.hip coop_launch; 0: hipLaunchCooperativeKernel)
   int64_t opt_coop_force_fail = 0;      // test hook: 1 = cooperative launches "fail", 2 = cooperative kernels "gave up" (once per solve)
   int coop_ran = 0;                     // a cooperative kernel of the current solve has run
   int coop_disabled = 0;                // set while a solve is re-run without cooperative kernels

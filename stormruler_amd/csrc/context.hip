@@ -142,6 +142,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "latency_path")) c->opt_latency_path = value;
   else if (!strcmp(key, "latency_publish")) c->opt_latency_publish = value;
   else if (!strcmp(key, "coop_force_fail")) c->opt_coop_force_fail = value;
+  else if (!strcmp(key, "coop_plain")) c->opt_coop_plain = value;
   else if (!strcmp(key, "coop_mgs")) c->opt_coop_mgs = value;
   else if (!strcmp(key, "coop_mgs_min_rows")) c->opt_coop_mgs_min_rows = value;
   else if (!strcmp(key, "coop_mgs_pairs")) c->opt_coop_mgs_pairs = value;

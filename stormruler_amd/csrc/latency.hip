@@ -815,7 +815,14 @@ static bool coop_launch(storm_hip_ctx *c, const void *fn, unsigned blocks, void 
     c->coop_fallback = 1;
     return false;
   }
-  if (hipLaunchCooperativeKernel(fn, dim3(blocks), dim3(kLatBlock), args, 0, c->stream) != hipSuccess) {
+  // coop_plain: an ordinary launch of the same kernel.  These kernels synchronise through memory (no grid.sync()); what
+  // they need is every block resident, which the callers size the grid for (<= one block per CU, a variant that fits) and
+  // which holds on a device this process has to itself once the kernel in front has drained -- the runtime's cooperative
+  // launch adds no more than that check, but runs on a queue of its own: 12-13 us of idle device in front of the kernel
+  // AND in front of the next ordinary one (kernel trace, GMRES(30) at 128^3: two such gaps per inner iteration of 160 us).
+  const hipError_t e = c->opt_coop_plain != 0 ? hipLaunchKernel(fn, dim3(blocks), dim3(kLatBlock), args, 0, c->stream)
+                                              : hipLaunchCooperativeKernel(fn, dim3(blocks), dim3(kLatBlock), args, 0, c->stream);
+  if (e != hipSuccess) {
     (void)hipGetLastError();
     c->coop_fallback = 1;
     return false;
