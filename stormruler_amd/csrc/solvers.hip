@@ -324,7 +324,7 @@ __global__ __launch_bounds__(kBlock) void cg_xp_kernel(int64_t n, const SolverSt
                                                        const double *__restrict__ r, int nt, int reverse) {
   if (st->iteration < my_iteration) return;  // enqueued past convergence: this iteration never ran
   const unsigned bx = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
-  const bool update_p = !st->done;
+  const bool update_p = !st->done && r != nullptr;  // (r == null: the tail of the fused loop -- only x is left to update)
   const double alpha = st->s[S_ALPHA], beta = st->s[S_BETA];
   const int64_t n2 = n >> 1;
   double2v *x2 = reinterpret_cast<double2v *>(x), *p2 = reinterpret_cast<double2v *>(p);
@@ -1141,7 +1141,7 @@ int solve_cg_body(const FusedSolveArgs &args) {
     // the x update of the last enqueued iteration (a no-op when that iteration never ran: the step kernel of the
     // iteration behind the converging one has applied it already)
     hipLaunchKernelGGL(cg_xp_kernel, dim3(xp_blocks(n)), dim3(kBlock), 0, c->stream, n, d.st, (long long)(last_enqueued + 1),
-                       x->d, p, r, nt_stream, 0);
+                       x->d, p, (const double *)nullptr, nt_stream, 0);
     HIP_TRY(hipGetLastError());
   }
   return collect(d, result, history, applies_cg, 0);
