@@ -373,7 +373,9 @@ __global__ __launch_bounds__(kBlock) void lin2_kernel(int64_t n, LinArgs a1, Lin
 
 // The same statement with reductions of its RESULT folded in: per-block partials of <y, y> (dot_yy) and / or
 // <y, w> into partials[j * gridDim.x + block] -- "r -= alpha z; gamma = <r, r>" is one pass over r, not two.
-template <int NT>
+// HASW: a second operand w is streamed for <y, w> (it counts as a stream when the accesses in flight are chosen: "r -= alpha z;
+// <r, r>" is a three-stream kernel like cg_r and runs with four, 79 -> 6x us at 256^3).
+template <int NT, bool HASW>
 __device__ __forceinline__ void lin_dot_body(int64_t n, const LinArgs &a, const double *w, int nt, double &acc_yy,
                                              double &acc_yw) {
   const unsigned bx = sweep_block(nt);
@@ -384,7 +386,7 @@ __device__ __forceinline__ void lin_dot_body(int64_t n, const LinArgs &a, const 
   const int64_t n2 = n >> 1;
   double2v *y2 = reinterpret_cast<double2v *>(a.y);
   const double2v *w2 = reinterpret_cast<const double2v *>(w);
-  constexpr int U = lin_unroll(NT + 1);
+  constexpr int U = lin_unroll(NT + (HASW ? 1 : 0));
   for (int64_t base = (int64_t)bx * (kBlock * U) + threadIdx.x; base < n2;
        base += (int64_t)gridDim.x * (kBlock * U)) {
     double2v v[U][NT], vw[U];
@@ -421,13 +423,13 @@ __device__ __forceinline__ void lin_dot_body(int64_t n, const LinArgs &a, const 
   }
 }
 
-template <int NT>
+template <int NT, bool HASW>
 __global__ __launch_bounds__(kBlock) void lin_dot_kernel(int64_t n, LinArgs a, const double *w, int dot_yy,
                                                          double *__restrict__ partials, const int *done, int nt) {
   if (done && *done) return;
   __shared__ double lds4[4];
   double acc_yy = 0.0, acc_yw = 0.0;
-  lin_dot_body<NT>(n, a, w, nt, acc_yy, acc_yw);
+  lin_dot_body<NT, HASW>(n, a, w, nt, acc_yy, acc_yw);
   int j = 0;
   if (dot_yy) {
     const double sum = block_sum256(acc_yy, lds4);
@@ -441,13 +443,13 @@ __global__ __launch_bounds__(kBlock) void lin_dot_kernel(int64_t n, LinArgs a, c
 }
 
 // ... and with the final pass in the last block (see publish_and_finish).
-template <int NT>
+template <int NT, bool HASW>
 __global__ __launch_bounds__(kBlock) void lin_dot_prog_kernel(int64_t n, LinArgs a, const double *w, int dot_yy,
                                                               double *partials, const int *done, int nt, FinalPass f) {
   if (done && *done) return;
   __shared__ double lds4[4];
   double acc_yy = 0.0, acc_yw = 0.0;
-  lin_dot_body<NT>(n, a, w, nt, acc_yy, acc_yw);
+  lin_dot_body<NT, HASW>(n, a, w, nt, acc_yy, acc_yw);
   double mine[2] = {0.0, 0.0};
   int j = 0;
   if (dot_yy) mine[j++] = block_sum256(acc_yy, lds4);
@@ -503,7 +505,7 @@ __global__ __launch_bounds__(kBlock) void vmul_dots_prog_kernel(int64_t n, doubl
 // A held-back vector statement, the statement that follows it, and the reductions of THAT statement's result, in
 // one pass (lin2_kernel + lin_dot_prog_kernel): BiCGStab's "x += alpha p + omega s;  r = s - omega t;  |r|^2, <rt, r>"
 // reads x, p, r, t, rt and writes x, r once -- the hand-fused loop's second half-step.
-template <int NT1, int NT2>
+template <int NT1, int NT2, bool HASW>
 __global__ __launch_bounds__(kBlock) void lin2_dot_prog_kernel(int64_t n, LinArgs a1, LinArgs a2, const double *w,
                                                                int dot_yy, double *partials, const int *done, int nt,
                                                                FinalPass f) {
@@ -524,7 +526,7 @@ __global__ __launch_bounds__(kBlock) void lin2_dot_prog_kernel(int64_t n, LinArg
   double acc_yy = 0.0, acc_yw = 0.0;
   // (the rows of a block and the order of a thread's terms are those of lin_dot_body for the second statement: the
   //  partial sums -- and the reduction's bits -- do not depend on whether a held-back statement rode along)
-  constexpr int U = lin_unroll(NT2 + 1);
+  constexpr int U = lin_unroll(NT2 + (HASW ? 1 : 0));
   for (int64_t base = (int64_t)bx * (kBlock * U) + threadIdx.x; base < n2; base += (int64_t)gridDim.x * (kBlock * U)) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -765,7 +767,11 @@ struct KrylovEngine {
       } else if (pend == PEND_VMUL_DOTS) {
         hipLaunchKernelGGL(vmul_dots_prog_kernel, g, b, 0, c->stream, n, pend_z, pend_d, pend_r, c->d_partials, dp, nti, f);
       } else if (pend == PEND_LIN_DOT) {
-#define LIN_GO(NT_) hipLaunchKernelGGL(lin_dot_prog_kernel<NT_>, g, b, 0, c->stream, n, pend_lin, pend_w, pend_yy, c->d_partials, dp, nti, f)
+#define LIN_GO(NT_)                                                                                                                   \
+  if (pend_w != nullptr)                                                                                                              \
+    hipLaunchKernelGGL((lin_dot_prog_kernel<NT_, true>), g, b, 0, c->stream, n, pend_lin, pend_w, pend_yy, c->d_partials, dp, nti, f); \
+  else                                                                                                                                \
+    hipLaunchKernelGGL((lin_dot_prog_kernel<NT_, false>), g, b, 0, c->stream, n, pend_lin, pend_w, pend_yy, c->d_partials, dp, nti, f)
         switch (pend_nt) {
           case 1: LIN_GO(1); break;
           case 2: LIN_GO(2); break;
@@ -773,7 +779,11 @@ struct KrylovEngine {
         }
 #undef LIN_GO
       } else {
-#define LIN2_GO(A_, B_) hipLaunchKernelGGL((lin2_dot_prog_kernel<A_, B_>), g, b, 0, c->stream, n, pend_lin0, pend_lin, pend_w, pend_yy, c->d_partials, dp, nti, f)
+#define LIN2_GO(A_, B_)                                                                                                                                  \
+  if (pend_w != nullptr)                                                                                                                                 \
+    hipLaunchKernelGGL((lin2_dot_prog_kernel<A_, B_, true>), g, b, 0, c->stream, n, pend_lin0, pend_lin, pend_w, pend_yy, c->d_partials, dp, nti, f);     \
+  else                                                                                                                                                   \
+    hipLaunchKernelGGL((lin2_dot_prog_kernel<A_, B_, false>), g, b, 0, c->stream, n, pend_lin0, pend_lin, pend_w, pend_yy, c->d_partials, dp, nti, f)
         switch (pend_nt0 * 4 + pend_nt) {
           case 5: LIN2_GO(1, 1); break;
           case 6: LIN2_GO(1, 2); break;
@@ -983,10 +993,10 @@ struct KrylovEngine {
     a.y = yv->d;
     const int nt = (int)terms.size();
     for (int t = 0; t < nt; ++t) a.v[t] = terms[(size_t)t].v->d, a.c[t] = scal(terms[(size_t)t].c);
-    const int64_t per_block = (int64_t)kBlock * lin_unroll(nt + 1) * 2;
+    const double *wd = (reg_yw >= 0 && wv != nullptr) ? wv->d : nullptr;
+    const int64_t per_block = (int64_t)kBlock * lin_unroll(nt + (wd != nullptr ? 1 : 0)) * 2;  // (the kernels' U: HASW)
     int64_t nb = std::max<int64_t>(1, (n + per_block - 1) / per_block);
     nb = std::min<int64_t>(nb, std::min<int64_t>(32768, c->partials_capacity / 2));
-    const double *wd = (reg_yw >= 0 && wv != nullptr) ? wv->d : nullptr;
     const int nti = stream_flags();
     if (with_held) {
       const int64_t nb2 = nb;  // the grid of the statement alone (same rows per block, same partial sums)
@@ -1007,9 +1017,15 @@ struct KrylovEngine {
       return;
     }
     switch (nt) {
-      case 1: hipLaunchKernelGGL((lin_dot_kernel<1>), dim3((int)nb), dim3(kBlock), 0, c->stream, n, a, wd, (int)(reg_yy >= 0), c->d_partials, dp, nti); break;
-      case 2: hipLaunchKernelGGL((lin_dot_kernel<2>), dim3((int)nb), dim3(kBlock), 0, c->stream, n, a, wd, (int)(reg_yy >= 0), c->d_partials, dp, nti); break;
-      default: hipLaunchKernelGGL((lin_dot_kernel<3>), dim3((int)nb), dim3(kBlock), 0, c->stream, n, a, wd, (int)(reg_yy >= 0), c->d_partials, dp, nti); break;
+      case 1: if (wd != nullptr) hipLaunchKernelGGL((lin_dot_kernel<1, true>), dim3((int)nb), dim3(kBlock), 0, c->stream, n, a, wd, (int)(reg_yy >= 0), c->d_partials, dp, nti);
+        else hipLaunchKernelGGL((lin_dot_kernel<1, false>), dim3((int)nb), dim3(kBlock), 0, c->stream, n, a, wd, (int)(reg_yy >= 0), c->d_partials, dp, nti);
+        break;
+      case 2: if (wd != nullptr) hipLaunchKernelGGL((lin_dot_kernel<2, true>), dim3((int)nb), dim3(kBlock), 0, c->stream, n, a, wd, (int)(reg_yy >= 0), c->d_partials, dp, nti);
+        else hipLaunchKernelGGL((lin_dot_kernel<2, false>), dim3((int)nb), dim3(kBlock), 0, c->stream, n, a, wd, (int)(reg_yy >= 0), c->d_partials, dp, nti);
+        break;
+      default: if (wd != nullptr) hipLaunchKernelGGL((lin_dot_kernel<3, true>), dim3((int)nb), dim3(kBlock), 0, c->stream, n, a, wd, (int)(reg_yy >= 0), c->d_partials, dp, nti);
+        else hipLaunchKernelGGL((lin_dot_kernel<3, false>), dim3((int)nb), dim3(kBlock), 0, c->stream, n, a, wd, (int)(reg_yy >= 0), c->d_partials, dp, nti);
+        break;
     }
     red_k = 0;
     if (reg_yy >= 0) red_out.idx[red_k++] = reg_yy;
