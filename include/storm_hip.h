@@ -253,7 +253,7 @@ int storm_hip_op_create_csr(storm_hip_ctx *ctx, int64_t n_rows, int64_t n_halo,
  *              format-3 records for the others; 0: format 3 throughout.
  * Run-time switches (A/B knobs; the defaults are the measured best):
  *   latency_path (1), latency_rows (2^19), latency_cache (1): CG / BiCGStab of a small halo-free operator as ONE
- *              cooperative kernel per solve; the size limit (latency_rows is read when the operator is built); the
+ *              cooperative kernel per solve (0: neither this nor the resident path below; 2: this path only); the size limit (latency_rows is read when the operator is built); the
  *              operator records in registers;
  *   coop_mgs (1), coop_mgs_min_rows (0), coop_mgs_pairs (1): GMRES's Gram-Schmidt chain as one cooperative kernel per
  *              Arnoldi step; from how many rows on; two steps per synchronisation point;
@@ -263,8 +263,19 @@ int storm_hip_op_create_csr(storm_hip_ctx *ctx, int64_t n_rows, int64_t n_halo,
  *   generic_solvers (0): 1 sends storm_hip_krylov_solve through the engine even where a fused loop exists;
  *   fuse_dot, fold_pz, fuse_mgs (1): the fused-reduction variants of the fused loops;
  *   ipc_streams (2): peer-window halo kernels on the comm stream (2) or on the compute stream (1);
- *   spmv_xcd_remap (8), spmv_nt_y (1), nontemporal (1), blas1_nt (1), spmv_spw, spmv_variant, graph (0), profile_spmv (0). */
+ *   spmv_xcd_remap (8), spmv_nt_y (1), nontemporal (1), blas1_nt (1), spmv_spw, spmv_variant, graph (0), profile_spmv (0);
+ *   resident_path (1), resident_min_rows (0), resident_max_rows (2^22), resident_max_planes (12), resident_planes (0 =
+ *              automatic): CG / BiCGStab of a
+ *              halo-free LATTICE operator (format-4 records) as one persistent kernel per solve in which every
+ *              block owns a box of the lattice (csrc/resident.hip). */
 int storm_hip_ctx_set_option(storm_hip_ctx *ctx, const char *key, int64_t value);
+
+/* Which path the solves of this context took so far (no reference counterpart: a diagnostic of this library; the
+ * reference logs one line per solve, Solver.hpp:144-145).  Keys: "resident_solves" (csrc/resident.hip),
+ * "latency_solves" (csrc/latency.hip: one cooperative kernel per solve), "throughput_solves" (a kernel per statement,
+ * fused loops of csrc/solvers.hip), "engine_solves" (csrc/krylov.hip), "cg_fused_steps" (solves whose CG step rode in
+ * the SpMV launch). */
+int storm_hip_ctx_get_counter(storm_hip_ctx *ctx, const char *key, int64_t *value);
 
 /* Halo plan of a row-partitioned operator.  For neighbour q
  * (rank nbr_rank[q]) the owned rows send_idx[send_ptr[q] .. send_ptr[q+1]) are

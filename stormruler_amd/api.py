@@ -74,6 +74,13 @@ class Context:
     def set_option(self, key: str, value: int):
         check(lib.storm_hip_ctx_set_option(self._h, key.encode(), int(value)))
 
+    def counter(self, key: str) -> int:
+        """How many solves of this context took a given path ("resident_solves", "latency_solves",
+        "throughput_solves", "engine_solves", "cg_fused_steps")."""
+        v = C.c_int64()
+        check(lib.storm_hip_ctx_get_counter(self._h, key.encode(), C.byref(v)))
+        return v.value
+
     def spmv_profile(self):
         """(launches, total_ms, min_ms) of the SpMV kernel since the last call (option profile_spmv)."""
         n, tot, mn = C.c_int64(), C.c_double(), C.c_double()

@@ -157,7 +157,17 @@ struct storm_hip_ctx {
   int coop_ran = 0;                     // a cooperative kernel of the current solve has run
   int coop_disabled = 0;                // set while a solve is re-run without cooperative kernels
   int coop_fallback = 0;                // what happened in the current solve (storm_hip_solver_result::path_fallback)
+  int64_t coop_skip = 0, coop_backoff = 0;  // solves still to run without cooperative kernels after one gave up; the length of the last back-off
   int64_t opt_latency_path = 1;         // small operators: CG as one cooperative persistent kernel (latency.hip)
+  // resident.hip: lattice operators as one persistent kernel per solve, every block owning a box of the lattice
+  int64_t opt_resident_path = 1;
+  int64_t opt_resident_min_rows = 0;            // ... from this many rows on (below: the latency path, where it applies)
+  int64_t opt_resident_max_rows = (int64_t)1 << 22;
+  int64_t opt_resident_planes = 0;              // ... exactly this many planes per block (0: the fewest that cover the lattice with one block per CU)
+  int64_t opt_resident_max_planes = 12;         // ... with at most this many planes per block (registers)
+  char *d_res_exch = nullptr;                   // its exchange buffer: one 16-byte granule per row (grown on demand)
+  int64_t res_exch_rows = 0;
+  char *d_res_slots = nullptr;                  // its all-reduce slots + the two sequence numbers it carries from solve to solve
   int opt_lin_fuse = 1;                 // engine: two consecutive vector statements go out as one pass
   int64_t opt_ticket_verify_inject = 0;  // test hook for the above
   int64_t opt_ticket_verify = 0;        // k > 0: every k-th iteration the fused loops recompute their ticketed reductions by the two-launch path and compare on the device (sticky flag -> the solve returns an error)
@@ -187,6 +197,8 @@ struct storm_hip_ctx {
   // Non-null while a solver is inside an operator / preconditioner callback: the device `done` flag of that
   // solve.  Public entry points predicate the kernels they enqueue on it (work past convergence is free).
   const int *api_done = nullptr;
+  // diagnostics: which path the solves took (storm_hip_ctx_get_counter)
+  int64_t n_resident_solves = 0, n_latency_solves = 0, n_throughput_solves = 0, n_engine_solves = 0, n_cg_fused_steps = 0;
   // communicator
   storm::Comm *comm = nullptr;
   int n_ranks = 1, rank = 0;
@@ -379,6 +391,11 @@ int cg_latency_solve(const storm_hip_op *op, double alpha, double beta, const do
                      double *r, SolverState *d_state, bool *taken);
 int bicgstab_latency_solve(const storm_hip_op *op, double alpha, double beta, const double *b, double *x,
                            double *const work[4], SolverState *d_state, bool *taken);
+
+// resident.hip
+bool res_eligible(const storm_hip_op *op, bool bicgstab);
+int res_solve(bool bicgstab, const storm_hip_op *op, double alpha, double beta, const double *b, double *x, double *rt,
+              SolverState *d_state, bool *taken);
 
 // comm.hip
 int comm_allreduce_sum(storm_hip_ctx *c, double *d_buf, int count);  // in place, on ctx->stream

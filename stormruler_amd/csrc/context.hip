@@ -96,6 +96,8 @@ int storm_hip_ctx_destroy(storm_hip_ctx *c) {
   (void)hipFree(c->d_partials2);
   (void)hipFree(c->d_scalars);
   (void)hipFree(c->d_lat_slots);
+  if (c->d_res_exch) (void)hipFree(c->d_res_exch);
+  if (c->d_res_slots) (void)hipFree(c->d_res_slots);
   (void)hipFree(c->d_tickets);
   (void)hipFree(c->d_ticket_sums);
   (void)hipHostFree(c->h_scalars);
@@ -140,6 +142,11 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "ipc_streams")) c->opt_ipc_streams = value;
   else if (!strcmp(key, "ipc_fused")) c->opt_ipc_fused = value;
   else if (!strcmp(key, "latency_path")) c->opt_latency_path = value;
+  else if (!strcmp(key, "resident_path")) c->opt_resident_path = value;
+  else if (!strcmp(key, "resident_min_rows")) c->opt_resident_min_rows = value;
+  else if (!strcmp(key, "resident_max_rows")) c->opt_resident_max_rows = value;
+  else if (!strcmp(key, "resident_max_planes")) c->opt_resident_max_planes = value;
+  else if (!strcmp(key, "resident_planes")) c->opt_resident_planes = value;
   else if (!strcmp(key, "latency_publish")) c->opt_latency_publish = value;
   else if (!strcmp(key, "coop_force_fail")) c->opt_coop_force_fail = value;
   else if (!strcmp(key, "coop_plain")) c->opt_coop_plain = value;
@@ -186,6 +193,17 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "graph")) c->opt_graph = value;
   else if (!strcmp(key, "blas1_nt")) c->opt_blas1_nt = value;
   else STORM_FAIL(STORM_HIP_E_INVALID, "ctx_set_option: unknown key '%s'", key);
+  return STORM_HIP_OK;
+}
+
+int storm_hip_ctx_get_counter(storm_hip_ctx *c, const char *key, int64_t *value) {
+  STORM_REQUIRE(c && key && value, "ctx_get_counter: null argument");
+  if (!strcmp(key, "resident_solves")) *value = c->n_resident_solves;
+  else if (!strcmp(key, "latency_solves")) *value = c->n_latency_solves;
+  else if (!strcmp(key, "throughput_solves")) *value = c->n_throughput_solves;
+  else if (!strcmp(key, "engine_solves")) *value = c->n_engine_solves;
+  else if (!strcmp(key, "cg_fused_steps")) *value = c->n_cg_fused_steps;
+  else STORM_FAIL(STORM_HIP_E_INVALID, "ctx_get_counter: unknown key '%s'", key);
   return STORM_HIP_OK;
 }
 

@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "coop_device.hpp"
 #include "solver_device.hpp"
 
 namespace storm {
@@ -54,61 +55,6 @@ struct LatArgs {
   int publish_xchg;          // rows are published with atomic exchanges whose return is awaited (option latency_publish)
 };
 
-// Data that crosses wavefronts inside the kernel -- the published rows of r and p, the all-reduce slots -- is
-// written and read with RELAXED AGENT-SCOPE ATOMIC accesses: single stores / loads that are coherent across the
-// XCDs' private L2s (write-through, miss-through).  Whole-cache release / acquire fences (L2 write-back and
-// invalidate, which an agent-scope fence means on this chip) are never issued: they cost ~100 us per barrier when
-// 4 096 wavefronts execute them, and would evict the operator records, which are read-only and may stay cached.
-__device__ __forceinline__ void co_store(double *p, double v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double co_load(const double *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// Publish one row for the other blocks' gathers.  xchg (the default): an atomic EXCHANGE whose returned value the wave
-// consumes (`seen`, at the all-reduce that follows) -- a returning read-modify-write has been performed at the point
-// of coherence, so the row is visible to every XCD before this block's all-reduce words go out, whatever else loads
-// the memory system (csrc/ticket_device.hpp: an ACKNOWLEDGED write-through store was seen not yet visible to another
-// XCD under a 256^3 streaming load).  xchg == 0: the write-through store, ordered by its acknowledgement only.
-__device__ __forceinline__ void co_publish(double *p, double v, int xchg, unsigned long long &seen) {
-  if (xchg)
-    seen ^= __hip_atomic_exchange(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
-                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else
-    co_store(p, v);
-}
-
-// All-reduce across a co-resident (cooperative) grid, which is also its barrier.  Slot (b, parity) of block b: 16
-// bytes at slots + (2 b + (seq & 1)) * kLatSlotStride (256 bytes apart, so the polling load of all blocks spreads
-// over the memory channels), holding the block's value in two self-validating 8-byte words
-//     { low half of the double, tag }   { high half, tag }        (tag = low 32 bits of the sequence number)
-// Each word is ONE 8-byte store -- atomic -- so the writer needs no ordering between them and no acknowledgement:
-// two stores, fire and forget; a reader's 16-byte load is good when BOTH tags are the current one.  (The scheme of
-// collective libraries' low-latency protocols.)  A synchronisation point costs: stores in flight, one polled load.
-// TWO slots per block, used alternately: a block that has passed all-reduce `seq` may publish `seq + 1` while a
-// slower block is still polling for `seq` -- into the other slot; it can only overwrite slot (seq & 1) with `seq + 2`
-// after passing `seq + 1`, which needed the slow block's `seq + 1` words, which that block stores after it has
-// finished reading `seq`.
-constexpr int kLatSlotStride = 256;
-constexpr long long kLatTimeoutTicks = 1000000000LL;  // 10 s of the 100 MHz real-time counter
-__device__ __forceinline__ bool co_load_slot(const char *slot, unsigned tag, double *value) {
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 w;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(slot) : "memory");
-  *value = __hiloint2double((int)w.z, (int)w.x);
-  return w.y == tag && w.w == tag;
-}
-__device__ __forceinline__ void co_store_slot(char *slot, unsigned tag, double value) {
-  const unsigned long long lo = ((unsigned long long)tag << 32) | (unsigned)__double2loint(value);
-  const unsigned long long hi = ((unsigned long long)tag << 32) | (unsigned)__double2hiint(value);
-  __hip_atomic_store(reinterpret_cast<unsigned long long *>(slot), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(reinterpret_cast<unsigned long long *>(slot) + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double lat_wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-  return v;
-}
 // Sum over all blocks of `mine` (a per-thread partial), identical bits in every thread of every block.
 // `publishes`: the block's waves have issued coherent stores (rows of r, p) that other blocks read once they are past
 // this point -- every wave then drains its own store counter before the block's words go out.
@@ -155,18 +101,8 @@ __device__ __forceinline__ double lat_allreduce(double mine, char *slots, unsign
   return (lds[0] + lds[1]) + (lds[2] + lds[3]);
 }
 
-// The same for TWO sums at once (BiCGStab's <t, s>, <t, t> and <r, r>, <rt, r>): the slot carries four words.
-__device__ __forceinline__ bool co_load_slot2(const char *slot, unsigned tag, double *v0, double *v1) {
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 w0, w1;
-  asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
-               : "=&v"(w0), "=&v"(w1)
-               : "v"(slot)
-               : "memory");
-  *v0 = __hiloint2double((int)w0.z, (int)w0.x);
-  *v1 = __hiloint2double((int)w1.z, (int)w1.x);
-  return w0.y == tag && w0.w == tag && w1.y == tag && w1.w == tag;
-}
+// The same for TWO sums at once (BiCGStab's <t, s>, <t, t> and <r, r>, <rt, r>): the slot carries four words
+// (co_load_slot2, coop_device.hpp).
 __device__ __forceinline__ void lat_allreduce2(double &s0, double &s1, char *slots, unsigned long long seq, double *lds,
                                                bool publishes = true, unsigned long long seen = 0ull) {
   const unsigned tag = (unsigned)seq;
@@ -833,9 +769,15 @@ static bool coop_launch(storm_hip_ctx *c, const void *fn, unsigned blocks, void 
 
 int coop_solve_with_fallback(storm_hip_ctx *c, storm_hip_vec *x, int (*run)(void *), void *arg, int *fallback_out) {
   c->coop_fallback = 0, c->coop_ran = 0;
+  // A cooperative kernel of an earlier solve gave up for real (a grid that did not become resident: a device shared
+  // with another tenant, a CU mask): the next solves run without them instead of paying the bounded wait again --
+  // 16 solves after the first give-up, twice as many after every further one.
+  const bool backing_off = c->coop_skip > 0;
+  if (backing_off) --c->coop_skip, c->coop_disabled = 1;
   const int64_t n_total = x->n_owned + x->n_halo;
   storm_hip_vec *x0 = nullptr;  // the start vector, kept for the re-run (pooled storage: no allocation, no stream wait per solve)
-  const bool keep = c->comm == nullptr && c->coop_disabled == 0 && (c->opt_latency_path != 0 || c->opt_coop_mgs != 0) &&
+  const bool keep = c->comm == nullptr && c->coop_disabled == 0 &&
+                    (c->opt_latency_path != 0 || c->opt_coop_mgs != 0 || c->opt_resident_path != 0) &&
                     n_total > 0 && n_total <= ((int64_t)1 << 23);  // (no cooperative kernel takes more rows than that)
   if (keep) {
     STORM_TRY(vec_create_work_batch(x, 1, &x0));
@@ -852,7 +794,12 @@ int coop_solve_with_fallback(storm_hip_ctx *c, storm_hip_vec *x, int (*run)(void
     st = run(arg);
     c->coop_disabled = 0;
     c->coop_fallback = 2;
+    if (c->opt_coop_force_fail != 2) {  // (the test hook gives up once per solve: no back-off)
+      c->coop_backoff = c->coop_backoff == 0 ? 16 : std::min<int64_t>(2 * c->coop_backoff, (int64_t)1 << 30);
+      c->coop_skip = c->coop_backoff;
+    }
   }
+  if (backing_off) c->coop_disabled = 0;
   if (st == kStatusCoopGaveUp) st = STORM_HIP_E_HIP;  // (the message of lat_check_gave_up stands)
   if (x0) (void)storm_hip_vec_destroy(x0);
   if (fallback_out) *fallback_out = c->coop_fallback;

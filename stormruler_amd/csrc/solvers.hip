@@ -1017,13 +1017,19 @@ int solve_cg_body(const FusedSolveArgs &args) {
   Driver d{c, op, alpha, beta, n, c->d_state, &c->d_state->done};
   STORM_TRY(prepare_state(d, params, history));
   VecPool pool;
+  if (res_eligible(op, false)) {  // a lattice operator that fits the chip's registers: one persistent kernel, a box per block (resident.hip)
+    bool taken = false;
+    STORM_TRY(res_solve(false, op, alpha, beta, b->d, x->d, nullptr, c->d_state, &taken));
+    if (taken) return ++c->n_resident_solves, collect(d, result, history, applies_cg, 0);
+  }
   if (cg_latency_eligible(op)) {  // a small operator: the whole solve as one cooperative kernel (latency.hip)
     STORM_TRY(pool.make(x, 2));  // zero-filled: the kernel relies on that for the first direction
     bool taken = false;
     STORM_TRY(cg_latency_solve(op, alpha, beta, b->d, x->d, pool.v[0]->d, pool.v[1]->d, c->d_state, &taken));
-    if (taken) return collect(d, result, history, applies_cg, 0);
+    if (taken) return ++c->n_latency_solves, collect(d, result, history, applies_cg, 0);
     // (the cooperative kernel could not be launched: the throughput path below, noted in result->path_fallback)
   }
+  ++c->n_throughput_solves;
   const size_t v0 = pool.v.size();
   // (r: the init apply; p: init_residual's copy; z: the first SpMV -- all before any read; the fused step's second p)
   const bool may_fuse_step = c->opt_cg_fuse != 0 && spmv_can_fuse_cg(op);
@@ -1066,7 +1072,7 @@ int solve_cg_body(const FusedSolveArgs &args) {
   const bool fuse_step = c->opt_cg_fuse != 0 && (c->comm == nullptr || ipc) && tick && !tick_spmv && c->opt_fuse_dot != 0 &&
                          spmv_can_fuse_cg(op);
   double *p_alt = nullptr;
-  if (fuse_step) p_alt = pool.v[v0 + 3]->d;
+  if (fuse_step) p_alt = pool.v[v0 + 3]->d, ++c->n_cg_fused_steps;
   int64_t last_enqueued = -1;
   auto enqueue_iteration = [&]() -> int {
     const int q = fuse_step ? 0 : sweep ? (int)(cur_it & 1) : 0;  // (fused: the step kernel forward, cg_r backward, always)
@@ -1161,13 +1167,20 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
   Driver d{c, op, alpha, beta, n, c->d_state, &c->d_state->done};
   STORM_TRY(prepare_state(d, params, history));
   VecPool pool;
+  if (res_eligible(op, true)) {  // (resident.hip)
+    bool taken = false;
+    STORM_TRY(pool.make(x, 1, false));  // the shadow residual
+    STORM_TRY(res_solve(true, op, alpha, beta, b->d, x->d, pool.v[0]->d, c->d_state, &taken));
+    if (taken) return ++c->n_resident_solves, collect(d, result, history, applies_bicg, 0);
+  }
   if (cg_latency_eligible(op)) {  // a small operator: the whole solve as one cooperative kernel (latency.hip)
     STORM_TRY(pool.make(x, 4));  // zero-filled: the kernel relies on that for the first direction
     double *const work[4] = {pool.v[0]->d, pool.v[1]->d, pool.v[2]->d, pool.v[3]->d};
     bool taken = false;
     STORM_TRY(bicgstab_latency_solve(op, alpha, beta, b->d, x->d, work, c->d_state, &taken));
-    if (taken) return collect(d, result, history, applies_bicg, 0);
+    if (taken) return ++c->n_latency_solves, collect(d, result, history, applies_bicg, 0);
   }
+  ++c->n_throughput_solves;
   const size_t v0 = pool.v.size();
   STORM_TRY(pool.make(x, 5, false));  // (r, rt: init; p: the copy of iteration 0; v, t: the SpMVs -- all before any read)
   double *p = pool.v[v0]->d, *r = pool.v[v0 + 1]->d, *rt = pool.v[v0 + 2]->d, *t = pool.v[v0 + 3]->d, *v = pool.v[v0 + 4]->d;

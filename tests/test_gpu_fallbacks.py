@@ -62,6 +62,7 @@ def test_the_latency_path_is_left_when_no_register_variant_fits(env):
     instead of failing (round 2: STORM_REQUIRE)."""
     api, mesh, oracle, ctx = env
     ctx.set_option("latency_rows", 1 << 23)
+    ctx.set_option("latency_path", 2)  # (the latency path itself: the resident path would take this lattice)
     try:
         g = mesh.structured_box(144, 144, 128)  # 2.65 M rows: > 256 blocks x 16 waves x 8 slices x 64 rows
         mat = api.StencilMatrix.from_face_graph(ctx, g)
@@ -74,6 +75,7 @@ def test_the_latency_path_is_left_when_no_register_variant_fits(env):
         mat.close()
     finally:
         ctx.set_option("latency_rows", 1 << 19)
+        ctx.set_option("latency_path", 1)
 
 
 @pytest.mark.parametrize("kind", ["cg", "bicgstab", "gmres"])

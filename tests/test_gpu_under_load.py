@@ -59,6 +59,7 @@ def test_latency_path_is_bitwise_reproducible_under_load(env, kind, publish):
     bh = api.DeviceVector.from_numpy(ctx, 1.0 + 0.25 * np.sin(0.01 * np.arange(g.n_cells)))
     cls, iters = (api.CgSolver, 600) if kind == "cg" else (api.BiCgStabSolver, 100)
     ctx.set_option("latency_publish", publish)
+    ctx.set_option("latency_path", 2)  # (the latency path itself; the resident path has its own test below)
     try:
         ref_h, ref_x = _history(api, ctx, cls, op, bh, g.n_cells, iters)
         assert np.all(np.isfinite(ref_h))
@@ -66,6 +67,28 @@ def test_latency_path_is_bitwise_reproducible_under_load(env, kind, publish):
             assert np.array_equal(h, ref_h) and np.array_equal(x, ref_x)
     finally:
         ctx.set_option("latency_publish", 1)
+        ctx.set_option("latency_path", 1)
+        mat.close()
+
+
+@pytest.mark.parametrize("kind,edge", [("cg", 64), ("bicgstab", 64), ("cg", 128), ("bicgstab", 128)])
+def test_resident_path_is_bitwise_reproducible_under_load(env, kind, edge):
+    """csrc/resident.hip: the surfaces of the blocks' boxes travel as self-validating granules, the reductions as tagged
+    slots -- nothing depends on the order in which stores become visible, so a second stream copying 1 GiB buffers
+    must not change a bit."""
+    api, mesh, ctx, torch, load = env
+    g = mesh.structured_box(edge)
+    mat = api.StencilMatrix.from_face_graph(ctx, g)
+    op = api.HipStencilOperator(mat, -1.0, 0.0)
+    bh = api.DeviceVector.from_numpy(ctx, 1.0 + 0.25 * np.sin(0.01 * np.arange(g.n_cells)))
+    cls, iters = (api.CgSolver, 600) if kind == "cg" else (api.BiCgStabSolver, 100)
+    try:
+        before = ctx.counter("resident_solves")
+        ref_h, ref_x = _history(api, ctx, cls, op, bh, g.n_cells, iters)
+        assert ctx.counter("resident_solves") == before + 1 and np.all(np.isfinite(ref_h))
+        for h, x in _under_load(torch, load, lambda: _history(api, ctx, cls, op, bh, g.n_cells, iters), 8):
+            assert np.array_equal(h, ref_h) and np.array_equal(x, ref_x)
+    finally:
         mat.close()
 
 
@@ -96,6 +119,7 @@ def test_ticket_verify_passes_and_catches_a_lost_partial(env, kind):
     bh = api.DeviceVector(ctx, g.n_cells)
     api.fill_with(bh, 1.0)
     cls, iters = (api.CgSolver, 120) if kind == "cg" else (api.BiCgStabSolver, 60)
+    ctx.set_option("resident_path", 0)  # (... and not the resident path)
     try:
         h0, x0 = _history(api, ctx, cls, op, bh, g.n_cells, iters)
         ctx.set_option("ticket_verify", 3)
@@ -107,4 +131,5 @@ def test_ticket_verify_passes_and_catches_a_lost_partial(env, kind):
     finally:
         ctx.set_option("ticket_verify_inject", 0)
         ctx.set_option("ticket_verify", 0)
+        ctx.set_option("resident_path", 1)
         mat.close()

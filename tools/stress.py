@@ -34,7 +34,7 @@ for k in range(n_rounds):
     for name, cls, operator, latency in cases:
         if name == "idrs/engine" and k % 10:
             continue
-        ctx.set_option("latency_path", latency)
+        ctx.set_option("latency_path", 2 if latency else 0)
         api.rng_reset()
         x = api.DeviceVector(ctx, g.n_cells)
         s = cls()
