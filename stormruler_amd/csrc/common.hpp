@@ -167,6 +167,9 @@ struct storm_hip_ctx {
   int64_t opt_resident_max_planes = 12;         // ... with at most this many planes per block (registers)
   char *d_res_exch = nullptr;                   // its exchange buffer: one 16-byte granule per row (grown on demand)
   int64_t res_exch_rows = 0;
+  int64_t opt_resident_profile = 0;             // the kernels time their phases (storm_hip_ctx_get_counter "resident_phase_max_k" / "_mean_k", ticks of 10 ns)
+  long long *d_res_prof = nullptr;
+  int res_prof_blocks = 0;
   char *d_res_slots = nullptr;                  // its all-reduce slots + the two sequence numbers it carries from solve to solve
   int opt_lin_fuse = 1;                 // engine: two consecutive vector statements go out as one pass
   int64_t opt_ticket_verify_inject = 0;  // test hook for the above

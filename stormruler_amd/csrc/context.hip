@@ -3,6 +3,7 @@
 #include <cstring>
 #include <random>
 
+#include <algorithm>
 #include "common.hpp"
 
 #include <cstddef>
@@ -98,6 +99,7 @@ int storm_hip_ctx_destroy(storm_hip_ctx *c) {
   (void)hipFree(c->d_lat_slots);
   if (c->d_res_exch) (void)hipFree(c->d_res_exch);
   if (c->d_res_slots) (void)hipFree(c->d_res_slots);
+  if (c->d_res_prof) (void)hipFree(c->d_res_prof);
   (void)hipFree(c->d_tickets);
   (void)hipFree(c->d_ticket_sums);
   (void)hipHostFree(c->h_scalars);
@@ -147,6 +149,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "resident_max_rows")) c->opt_resident_max_rows = value;
   else if (!strcmp(key, "resident_max_planes")) c->opt_resident_max_planes = value;
   else if (!strcmp(key, "resident_planes")) c->opt_resident_planes = value;
+  else if (!strcmp(key, "resident_profile")) c->opt_resident_profile = value;
   else if (!strcmp(key, "latency_publish")) c->opt_latency_publish = value;
   else if (!strcmp(key, "coop_force_fail")) c->opt_coop_force_fail = value;
   else if (!strcmp(key, "coop_plain")) c->opt_coop_plain = value;
@@ -203,6 +206,18 @@ int storm_hip_ctx_get_counter(storm_hip_ctx *c, const char *key, int64_t *value)
   else if (!strcmp(key, "throughput_solves")) *value = c->n_throughput_solves;
   else if (!strcmp(key, "engine_solves")) *value = c->n_engine_solves;
   else if (!strcmp(key, "cg_fused_steps")) *value = c->n_cg_fused_steps;
+  else if (!strncmp(key, "resident_phase_max_", 19) || !strncmp(key, "resident_phase_mean_", 20)) {
+    // (option resident_profile: ticks of 10 ns that the last resident solve's blocks spent in phase k of their loop)
+    const bool mx = key[15] == 'm' && key[16] == 'a';
+    const int k = atoi(key + (mx ? 19 : 20));
+    STORM_REQUIRE(c->d_res_prof != nullptr && c->res_prof_blocks > 0 && k >= 0 && k < 8, "ctx_get_counter: no resident profile (option resident_profile)");
+    std::vector<long long> h((size_t)c->res_prof_blocks * 8);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(h.data(), c->d_res_prof, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+    long long m = 0, sum = 0;
+    for (int b = 0; b < c->res_prof_blocks; ++b) m = std::max(m, h[(size_t)b * 8 + k]), sum += h[(size_t)b * 8 + k];
+    *value = mx ? m : sum / c->res_prof_blocks;
+  }
   else STORM_FAIL(STORM_HIP_E_INVALID, "ctx_get_counter: unknown key '%s'", key);
   return STORM_HIP_OK;
 }

@@ -65,6 +65,7 @@ struct ResArgs {
   char *exch;          // the exchange buffer: one 16-byte granule per row
   char *slots;         // all-reduce slots, kLatSlotStride bytes per (block, parity)
   int *gave_up;        // the latency path's flag (lat_check_gave_up)
+  long long *prof;     // option resident_profile: [gridDim.x][8] ticks of the 100 MHz counter per phase of the loop, summed over the solve
   unsigned long long *cnt;  // [0] all-reduce sequence number, [1] exchange sequence number: carried from solve to solve
   SolverState *st;
 };
@@ -138,7 +139,8 @@ __device__ __forceinline__ double res_value(u32x4r w) { return __hiloint2double(
 __device__ __forceinline__ void res_fetch2(const ResArgs &A, int64_t ra, int64_t rb, unsigned tag, double2r *va, double2r *vb) {
   const int64_t n = A.n_rows;
   const bool a0 = ra >= 0 && ra < n, a1 = ra >= 0 && ra + 1 < n, b0 = rb >= 0 && rb < n, b1 = rb >= 0 && rb + 1 < n;
-  const char *pa = A.exch + (size_t)16 * (size_t)(a0 ? ra : 0), *pb = A.exch + (size_t)16 * (size_t)(b0 ? rb : 0);
+  const char *xb = A.exch;
+  const char *pa = xb + (size_t)16 * (size_t)(a0 ? ra : 0), *pb = xb + (size_t)16 * (size_t)(b0 ? rb : 0);
   *va = double2r{0.0, 0.0}, *vb = double2r{0.0, 0.0};
   if (!(a0 || b0)) return;
   const long long t0 = wall_clock64();
@@ -154,6 +156,47 @@ __device__ __forceinline__ void res_fetch2(const ResArgs &A, int64_t ra, int64_t
         (!b1 || res_tag_ok(wb1, tag))) {
       va->x = a0 ? res_value(wa0) : 0.0, va->y = a1 ? res_value(wa1) : 0.0;
       vb->x = b0 ? res_value(wb0) : 0.0, vb->y = b1 ? res_value(wb1) : 0.0;
+      return;
+    }
+    __builtin_amdgcn_s_sleep(1);
+    if ((spins & 1023) == 1023 &&
+        (wall_clock64() - t0 > kLatTimeoutTicks || __hip_atomic_load(A.gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+      __hip_atomic_store(A.gave_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+  }
+}
+
+// ... four pairs, eight loads in flight: ONE round trip for a thread's share of the surface in the common geometries.
+__device__ __forceinline__ void res_fetch4(const ResArgs &A, const int64_t (&row)[4], unsigned tag, double2r (&v)[4]) {
+  const int64_t n = A.n_rows;
+  bool h0[4], h1[4], any = false;
+  const char *p[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h0[i] = row[i] >= 0 && row[i] < n, h1[i] = row[i] >= 0 && row[i] + 1 < n;
+    p[i] = A.exch + (size_t)16 * (size_t)(h0[i] ? row[i] : 0);
+    v[i] = double2r{0.0, 0.0};
+    any |= h0[i];
+  }
+  if (!any) return;
+  const long long t0 = wall_clock64();
+  for (int spins = 0;; ++spins) {
+    u32x4r w0[4], w1[4];
+    asm volatile(
+        "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
+        "global_load_dwordx4 %2, %9, off sc1\n\tglobal_load_dwordx4 %3, %9, off offset:16 sc1\n\t"
+        "global_load_dwordx4 %4, %10, off sc1\n\tglobal_load_dwordx4 %5, %10, off offset:16 sc1\n\t"
+        "global_load_dwordx4 %6, %11, off sc1\n\tglobal_load_dwordx4 %7, %11, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+        : "=&v"(w0[0]), "=&v"(w1[0]), "=&v"(w0[1]), "=&v"(w1[1]), "=&v"(w0[2]), "=&v"(w1[2]), "=&v"(w0[3]), "=&v"(w1[3])
+        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3])
+        : "memory");
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ok = ok && (!h0[i] || res_tag_ok(w0[i], tag)) && (!h1[i] || res_tag_ok(w1[i], tag));
+    if (ok) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i].x = h0[i] ? res_value(w0[i]) : 0.0, v[i].y = h1[i] ? res_value(w1[i]) : 0.0;
       return;
     }
     __builtin_amdgcn_s_sleep(1);
@@ -226,9 +269,14 @@ __device__ __forceinline__ void res_publish_pair(const ResArgs &A, const ResBox 
   }
 }
 
-// The halo of the LDS copy and the two planes bounding the box, from the granules published with `tag` (EXCH) or
-// straight from a vector in memory that no block writes meanwhile (the start vector, at init).
-template <int TZ, bool EXCH>
+// The halo of the LDS copy and the two planes bounding the box:
+//   MODE 0: straight from a vector in memory that no block writes meanwhile (the start vector, at init);
+//   MODE 1: the granules published with `tag`.
+// (Tried and dropped: CG publishing the surface of its RESIDUAL before the all-reduce that yields beta, every block forming
+//  p' = r + beta p on its halo itself, so that the exchange travels under the all-reduce -- 21 instead of 24 us at 128^3,
+//  but run-to-run differences of the histories at the 1e-10 level on the small boxes, gone again with the publish
+//  behind the all-reduce; not understood, not kept.)
+template <int TZ, int MODE>
 __device__ __forceinline__ void res_halo(const ResArgs &A, const ResBox &B, double *P, unsigned tag, const double *vec,
                                          double2r *lo, double2r *hi) {
   const int tid = threadIdx.x;
@@ -239,32 +287,47 @@ __device__ __forceinline__ void res_halo(const ResArgs &A, const ResBox &B, doub
     if (row >= 0 && row + 1 < n) v.y = vec[row + 1];
     return v;
   };
-  // the planes below and above: this thread's own column
-  const bool in = 2 * tid < B.L;
-  const int64_t rlo = (in && B.z0 > 0) ? (int64_t)B.g0 - B.b : -2,
-                rhi = (in && B.z0 + B.tzl < B.nplanes) ? (int64_t)B.g0 + (int64_t)B.tzl * B.b : -2;
-  if (EXCH) res_fetch2(A, rlo, rhi, tag, lo, hi);
-  else *lo = plain(rlo), *hi = plain(rhi);
-  // a pairs per plane: the a rows below the run and the a rows above it
+  // pair hh of the a pairs per plane (the a rows below the run and the a rows above it): its row and its place
   const int nh = B.tzl * B.a;
-#pragma unroll 1
-  for (int h = tid; h < nh; h += 2 * kResThreads) {
-    int64_t row[2];
-    int at[2];
+  auto place = [&](int hh, int64_t *row, int *at) {
+    const int t = hh / B.a, j2 = 2 * (hh - t * B.a);
+    const bool lower = j2 < B.a;
+    const int jj = lower ? j2 : j2 - B.a;
+    *at = hh < nh ? t * B.ldw + (lower ? jj : B.a + B.L + jj) : -1;
+    *row = hh < nh ? (int64_t)(B.z0 + t) * B.b + B.s0 + (lower ? jj - B.a : B.L + jj) : -2;
+  };
+  auto put = [&](int at, double2r v) {
+    if (at < 0) return;
+    *reinterpret_cast<double2r *>(&P[at]) = v;
+  };
+  // first batch: this thread's own column in the planes below and above, and its first two halo pairs
+  const bool in = 2 * tid < B.L;
+  int64_t row[4];
+  int at[2];
+  row[0] = (in && B.z0 > 0) ? (int64_t)B.g0 - B.b : -2;
+  row[1] = (in && B.z0 + B.tzl < B.nplanes) ? (int64_t)B.g0 + (int64_t)B.tzl * B.b : -2;
+  place(tid, &row[2], &at[0]);
+  place(tid + kResThreads, &row[3], &at[1]);
+  double2r v[4];
+  if (MODE == 0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int hh = h + i * kResThreads;
-      const int t = hh / B.a, j2 = 2 * (hh - t * B.a);
-      const bool lower = j2 < B.a;
-      const int jj = lower ? j2 : j2 - B.a;
-      at[i] = hh < nh ? t * B.ldw + (lower ? jj : B.a + B.L + jj) : -1;
-      row[i] = hh < nh ? (int64_t)(B.z0 + t) * B.b + B.s0 + (lower ? jj - B.a : B.L + jj) : -2;
-    }
+    for (int i = 0; i < 4; ++i) v[i] = plain(row[i]);
+  } else {
+    res_fetch4(A, row, tag, v);
+  }
+  *lo = v[0], *hi = v[1];
+  put(at[0], v[2]), put(at[1], v[3]);
+  // deep boxes with long lines: the rest of the halo, two pairs at a time
+#pragma unroll 1
+  for (int h = tid + 2 * kResThreads; h < nh; h += 2 * kResThreads) {
+    int64_t r2[2];
+    int a2[2];
+    place(h, &r2[0], &a2[0]);
+    place(h + kResThreads, &r2[1], &a2[1]);
     double2r v0, v1;
-    if (EXCH) res_fetch2(A, row[0], row[1], tag, &v0, &v1);
-    else v0 = plain(row[0]), v1 = plain(row[1]);
-    if (at[0] >= 0) *reinterpret_cast<double2r *>(&P[at[0]]) = v0;
-    if (at[1] >= 0) *reinterpret_cast<double2r *>(&P[at[1]]) = v1;
+    if (MODE == 0) v0 = plain(r2[0]), v1 = plain(r2[1]);
+    else res_fetch2(A, r2[0], r2[1], tag, &v0, &v1);
+    put(a2[0], v0), put(a2[1], v1);
   }
 }
 
@@ -340,11 +403,16 @@ __device__ __forceinline__ void res_lds_pair(const ResBox &B, double *P, int t, 
   if ((B.mask_a >> t) & 1u) *reinterpret_cast<double2r *>(&P[t * B.ldw + B.a + B.tid2]) = v;
 }
 
+__device__ __forceinline__ double2r res_cg_direction(double2r r, double2r p, double beta) {
+  return double2r{__builtin_fma(beta, p.x, r.x), __builtin_fma(beta, p.y, r.y)};  // r + beta p            SolverCg.hpp:123
+}
+
 // ---- CG ------------------------------------------------------------------------------------------------------------
-// Registers: r and the weight words of the own rows for the whole solve; z from the apply to `r -= alpha z`, then x
-// in the same place (x lives in memory -- the XCD's L2 holds its block's rows -- and is read, updated and stored once
-// per iteration, off the critical path); the direction p lives in the LDS copy alone.
-template <int TZ>
+// Registers: r and the weight words of the own rows for the whole solve; z from the apply to `r -= alpha z`; x too
+// (XREG) where the box is at most 8 planes deep -- deeper boxes keep x in memory (the XCD's L2 holds its block's rows):
+// read under the second all-reduce into z's place, updated and stored once per iteration.  The direction p lives in
+// the LDS copy alone; its surface is published behind the all-reduce that yields beta.
+template <int TZ, bool XREG>
 __global__ __launch_bounds__(kResThreads) void res_cg_kernel(ResArgs A) {
   extern __shared__ __attribute__((aligned(16))) double P[];  // [TZ][a + kResRun + a]
   __shared__ double dict_sh[32];
@@ -357,23 +425,37 @@ __global__ __launch_bounds__(kResThreads) void res_cg_kernel(ResArgs A) {
   const double abs_tol = st->abs_tol, rel_tol = st->rel_tol;
   const long long num_iterations = st->num_iterations;
   double *history = st->history;
-  double2r r[TZ], z[TZ];
+  double2r r[TZ], z[TZ], x[XREG ? TZ : 1];
   u64x2r w[TZ];
   res_load_weights<TZ>(A, B, w);
   // the start vector into the LDS copy: the first pass of the loop applies the operator to it
   double2r lo, hi;
 #pragma unroll
-  for (int t = 0; t < TZ; ++t) res_lds_pair(B, P, t, ((B.mask_a >> t) & 1u) ? res_ld_pair(A.x, res_off8(B, t)) : double2r{0.0, 0.0});
-  res_halo<TZ, false>(A, B, P, 0u, A.x, &lo, &hi);  // (x is not written before every block is past the first all-reduce)
+  for (int t = 0; t < TZ; ++t) {
+    const double2r xt = ((B.mask_a >> t) & 1u) ? res_ld_pair(A.x, res_off8(B, t)) : double2r{0.0, 0.0};
+    if (XREG) x[XREG ? t : 0] = xt;
+    res_lds_pair(B, P, t, xt);
+  }
+  res_halo<TZ, 0>(A, B, P, 0u, A.x, &lo, &hi);  // (x is not written before every block is past the first all-reduce)
 
   double gamma = 0.0, initial_error = 0.0, abs_err = 0.0, rel_err = 0.0;
   bool converged = false, started = false;
   long long it = 0;
+  // (option resident_profile: where the time of an iteration goes, per block, by thread 0's clock)
+  long long tick[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_mark = A.prof ? wall_clock64() : 0;
+  auto lap = [&](int k) {
+    if (A.prof) {
+      const long long now = wall_clock64();
+      tick[k] += now - t_mark, t_mark = now;
+    }
+  };
   for (;;) {
     B = res_fresh(B0);
     const int at0 = B.a + B.tid2;
     __syncthreads();
+    lap(0);  // the halo of the new direction: a wait for the neighbours' surfaces
     res_apply<TZ>(A, B, P, dict_sh, lo, hi, w, z);
+    lap(1);  // the apply
     double acc[1] = {0.0};
     if (!started) {
       // ---- init: r = b - A x; p = r; gamma = <r, r>                               SolverCg.hpp:54-84
@@ -386,12 +468,13 @@ __global__ __launch_bounds__(kResThreads) void res_cg_kernel(ResArgs A) {
         acc[0] += r[t].x * r[t].x;
         acc[0] += r[t].y * r[t].y;
       }
+      res_allreduce<1>(acc, A, ++seq, red);  // (its barriers: every thread is done with the copy of x)
       ++xseq;
 #pragma unroll
-      for (int t = 0; t < TZ; ++t) res_publish_pair(A, B, t, r[t], (unsigned)xseq);  // the first direction's surface travels under the all-reduce
-      res_allreduce<1>(acc, A, ++seq, red);  // (its barriers: every thread is done with the copy of x)
-#pragma unroll
-      for (int t = 0; t < TZ; ++t) res_lds_pair(B, P, t, r[t]);
+      for (int t = 0; t < TZ; ++t) {  // p = r
+        res_publish_pair(A, B, t, r[t], (unsigned)xseq);
+        res_lds_pair(B, P, t, r[t]);
+      }
       gamma = acc[0];
       initial_error = abs_err = sqrt(gamma);
       converged = abs_tol > 0.0 && initial_error < abs_tol;  // Solver.hpp:124-128
@@ -406,7 +489,9 @@ __global__ __launch_bounds__(kResThreads) void res_cg_kernel(ResArgs A) {
         acc[0] += ((B.mask_a >> t) & 1u) ? pt.x * z[t].x : 0.0;
         acc[0] += ((B.mask_b >> t) & 1u) ? pt.y * z[t].y : 0.0;
       }
+      lap(2);  // <p, z> partials
       res_allreduce<1>(acc, A, ++seq, red);
+      lap(3);  // the first all-reduce
       const double alpha = safe_divide(gamma, acc[0]);
       acc[0] = 0.0;
 #pragma unroll
@@ -415,8 +500,10 @@ __global__ __launch_bounds__(kResThreads) void res_cg_kernel(ResArgs A) {
         acc[0] += r[t].x * r[t].x;
         acc[0] += r[t].y * r[t].y;
       }
-      res_load_rows<TZ>(B, A.x, z);  // x, in z's place, travels under the all-reduce
+      if (!XREG) res_load_rows<TZ>(B, A.x, z);  // x, in z's place, travels under the all-reduce
+      lap(4);  // r -= alpha z, <r, r> partials
       res_allreduce<1>(acc, A, ++seq, red);
+      lap(5);  // the second all-reduce
       const double gamma_bar = gamma;
       gamma = acc[0];
       const double beta = safe_divide(gamma, gamma_bar);
@@ -431,20 +518,30 @@ __global__ __launch_bounds__(kResThreads) void res_cg_kernel(ResArgs A) {
 #pragma unroll
       for (int t = 0; t < TZ; ++t) {
         const double2r pt = *reinterpret_cast<const double2r *>(&P[t * B.ldw + at0]);
-        z[t].x += alpha * pt.x, z[t].y += alpha * pt.y;
-        res_st_pair(A.x, res_off8(B, t), z[t], (B.mask_a >> t) & 1u, (B.mask_b >> t) & 1u);
+        if (XREG) {
+          x[XREG ? t : 0].x += alpha * pt.x, x[XREG ? t : 0].y += alpha * pt.y;
+        } else {
+          z[t].x += alpha * pt.x, z[t].y += alpha * pt.y;
+          res_st_pair(A.x, res_off8(B, t), z[t], (B.mask_a >> t) & 1u, (B.mask_b >> t) & 1u);
+        }
         if (go_on) {
-          double2r pn;
-          pn.x = r[t].x + beta * pt.x, pn.y = r[t].y + beta * pt.y;
+          const double2r pn = res_cg_direction(r[t], pt, beta);
           res_publish_pair(A, B, t, pn, (unsigned)xseq);
           res_lds_pair(B, P, t, pn);
         }
       }
+      lap(6);  // x += alpha p, p = r + beta p, the surface out
       if (!go_on) break;
     }
     if (__hip_atomic_load(A.gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-    res_halo<TZ, true>(A, B, P, (unsigned)xseq, nullptr, &lo, &hi);
+    res_halo<TZ, 1>(A, B, P, (unsigned)xseq, nullptr, &lo, &hi);
   }
+  if (XREG) {
+#pragma unroll
+    for (int t = 0; t < TZ; ++t) res_st_pair(A.x, res_off8(B, t), x[XREG ? t : 0], (B.mask_a >> t) & 1u, (B.mask_b >> t) & 1u);
+  }
+  if (A.prof && threadIdx.x == 0)
+    for (int k = 0; k < 8; ++k) A.prof[blockIdx.x * 8 + k] = tick[k];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     A.cnt[0] = seq, A.cnt[1] = xseq;  // (every block holds the same numbers)
     st->initial_error = initial_error;
@@ -486,7 +583,7 @@ __global__ __launch_bounds__(kResThreads) void res_bicgstab_kernel(ResArgs A) {
     res_lds_pair(B, P, t, ((B.mask_a >> t) & 1u) ? res_ld_pair(A.x, res_off8(B, t)) : double2r{0.0, 0.0});
     p[t] = v[t] = double2r{0.0, 0.0};
   }
-  res_halo<TZ, false>(A, B, P, 0u, A.x, &lo, &hi);
+  res_halo<TZ, 0>(A, B, P, 0u, A.x, &lo, &hi);
   __syncthreads();
   double rho, initial_error, abs_err, rel_err = 0.0, alpha = 0.0, beta = 0.0, omega = 0.0;
   {  // ---- init: r = b - A x; rt = r; rho = <rt, r>                              SolverBiCgStab.hpp:82-90
@@ -522,7 +619,7 @@ __global__ __launch_bounds__(kResThreads) void res_bicgstab_kernel(ResArgs A) {
       res_publish_pair(A, B, t, p[t], (unsigned)xseq);
       res_lds_pair(B, P, t, p[t]);
     }
-    res_halo<TZ, true>(A, B, P, (unsigned)xseq, nullptr, &lo, &hi);
+    res_halo<TZ, 1>(A, B, P, (unsigned)xseq, nullptr, &lo, &hi);
     __syncthreads();
     res_apply<TZ>(A, B, P, dict_sh, lo, hi, w, v);
     {
@@ -546,7 +643,7 @@ __global__ __launch_bounds__(kResThreads) void res_bicgstab_kernel(ResArgs A) {
       res_publish_pair(A, B, t, r[t], (unsigned)xseq);
       res_lds_pair(B, P, t, r[t]);
     }
-    res_halo<TZ, true>(A, B, P, (unsigned)xseq, nullptr, &lo, &hi);
+    res_halo<TZ, 1>(A, B, P, (unsigned)xseq, nullptr, &lo, &hi);
     __syncthreads();
     double2r y[TZ];
     res_apply<TZ>(A, B, P, dict_sh, lo, hi, w, y);
@@ -634,7 +731,7 @@ bool res_eligible(const storm_hip_op *op, bool bicgstab) {
 
 template <int TZ>
 static const void *res_kernel(bool bicgstab) {
-  return bicgstab ? (const void *)res_bicgstab_kernel<TZ> : (const void *)res_cg_kernel<TZ>;
+  return bicgstab ? (const void *)res_bicgstab_kernel<TZ> : (const void *)res_cg_kernel<TZ, (TZ <= 8)>;
 }
 
 // The whole solve; fills the SolverState on the device (the caller reads it back).  *taken = false: nothing ran (the
@@ -695,6 +792,13 @@ int res_solve(bool bicgstab, const storm_hip_op *op, double alpha, double beta, 
   A.gave_up = reinterpret_cast<int *>(c->d_lat_slots + (size_t)2 * 256 * kLatSlotStride);
   A.cnt = reinterpret_cast<unsigned long long *>(c->d_res_slots + (size_t)2 * 256 * kLatSlotStride);
   A.st = d_state;
+  A.prof = nullptr;
+  if (c->opt_resident_profile != 0) {
+    if (c->d_res_prof == nullptr) HIP_TRY(hipMalloc((void **)&c->d_res_prof, sizeof(long long) * 256 * 8));
+    HIP_TRY(hipMemsetAsync(c->d_res_prof, 0, sizeof(long long) * 256 * 8, c->stream));
+    A.prof = c->d_res_prof;
+    c->res_prof_blocks = G.blocks;
+  }
   void *args[] = {&A};
   // (launched like any kernel: the grid is one block per CU at most and the occupancy query accepts it -- see
   //  latency.hip coop_launch; option coop_plain = 0: through the runtime's cooperative queue)
