@@ -62,7 +62,9 @@ struct ResArgs {
   const double *rhs;
   double *x;
   double *rt;          // BiCGStab: a work vector for the shadow residual
-  char *exch;          // the exchange buffer: one 16-byte granule per row
+  char *exch;          // the exchange buffer: one 16-byte granule per row -- the even rows' granules, then (exch_half bytes on) the odd
+                       // rows': a wave's pairs of rows go out, and come in, as two runs of 1 KiB (whole lines) instead of 64 half-filled ones
+  size_t exch_half;
   char *slots;         // all-reduce slots, kLatSlotStride bytes per (block, parity)
   int *gave_up;        // the latency path's flag (lat_check_gave_up)
   long long *prof;     // option resident_profile: [gridDim.x][8] ticks of the 100 MHz counter per phase of the loop, summed over the solve
@@ -139,18 +141,18 @@ __device__ __forceinline__ double res_value(u32x4r w) { return __hiloint2double(
 __device__ __forceinline__ void res_fetch2(const ResArgs &A, int64_t ra, int64_t rb, unsigned tag, double2r *va, double2r *vb) {
   const int64_t n = A.n_rows;
   const bool a0 = ra >= 0 && ra < n, a1 = ra >= 0 && ra + 1 < n, b0 = rb >= 0 && rb < n, b1 = rb >= 0 && rb + 1 < n;
-  const char *xb = A.exch;
-  const char *pa = xb + (size_t)16 * (size_t)(a0 ? ra : 0), *pb = xb + (size_t)16 * (size_t)(b0 ? rb : 0);
+  const unsigned oa = a0 ? (unsigned)ra << 3 : 0u, ob = b0 ? (unsigned)rb << 3 : 0u;  // (even rows: granule r / 2, 16 bytes each)
+  const char *even = A.exch, *odd = A.exch + A.exch_half;
   *va = double2r{0.0, 0.0}, *vb = double2r{0.0, 0.0};
   if (!(a0 || b0)) return;
   const long long t0 = wall_clock64();
   for (int spins = 0;; ++spins) {
     u32x4r wa0, wa1, wb0, wb1;
     asm volatile(
-        "global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
-        "global_load_dwordx4 %2, %5, off sc1\n\tglobal_load_dwordx4 %3, %5, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+        "global_load_dwordx4 %0, %4, %6 sc1\n\tglobal_load_dwordx4 %1, %4, %7 sc1\n\t"
+        "global_load_dwordx4 %2, %5, %6 sc1\n\tglobal_load_dwordx4 %3, %5, %7 sc1\n\ts_waitcnt vmcnt(0)"
         : "=&v"(wa0), "=&v"(wa1), "=&v"(wb0), "=&v"(wb1)
-        : "v"(pa), "v"(pb)
+        : "v"(oa), "v"(ob), "s"(even), "s"(odd)
         : "memory");
     if ((!a0 || res_tag_ok(wa0, tag)) && (!a1 || res_tag_ok(wa1, tag)) && (!b0 || res_tag_ok(wb0, tag)) &&
         (!b1 || res_tag_ok(wb1, tag))) {
@@ -171,25 +173,26 @@ __device__ __forceinline__ void res_fetch2(const ResArgs &A, int64_t ra, int64_t
 __device__ __forceinline__ void res_fetch4(const ResArgs &A, const int64_t (&row)[4], unsigned tag, double2r (&v)[4]) {
   const int64_t n = A.n_rows;
   bool h0[4], h1[4], any = false;
-  const char *p[4];
+  unsigned o[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     h0[i] = row[i] >= 0 && row[i] < n, h1[i] = row[i] >= 0 && row[i] + 1 < n;
-    p[i] = A.exch + (size_t)16 * (size_t)(h0[i] ? row[i] : 0);
+    o[i] = h0[i] ? (unsigned)row[i] << 3 : 0u;
     v[i] = double2r{0.0, 0.0};
     any |= h0[i];
   }
   if (!any) return;
+  const char *even = A.exch, *odd = A.exch + A.exch_half;
   const long long t0 = wall_clock64();
   for (int spins = 0;; ++spins) {
     u32x4r w0[4], w1[4];
     asm volatile(
-        "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
-        "global_load_dwordx4 %2, %9, off sc1\n\tglobal_load_dwordx4 %3, %9, off offset:16 sc1\n\t"
-        "global_load_dwordx4 %4, %10, off sc1\n\tglobal_load_dwordx4 %5, %10, off offset:16 sc1\n\t"
-        "global_load_dwordx4 %6, %11, off sc1\n\tglobal_load_dwordx4 %7, %11, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+        "global_load_dwordx4 %0, %8, %12 sc1\n\tglobal_load_dwordx4 %1, %8, %13 sc1\n\t"
+        "global_load_dwordx4 %2, %9, %12 sc1\n\tglobal_load_dwordx4 %3, %9, %13 sc1\n\t"
+        "global_load_dwordx4 %4, %10, %12 sc1\n\tglobal_load_dwordx4 %5, %10, %13 sc1\n\t"
+        "global_load_dwordx4 %6, %11, %12 sc1\n\tglobal_load_dwordx4 %7, %11, %13 sc1\n\ts_waitcnt vmcnt(0)"
         : "=&v"(w0[0]), "=&v"(w1[0]), "=&v"(w0[1]), "=&v"(w1[1]), "=&v"(w0[2]), "=&v"(w1[2]), "=&v"(w0[3]), "=&v"(w1[3])
-        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3])
+        : "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "s"(even), "s"(odd)
         : "memory");
     bool ok = true;
 #pragma unroll
@@ -263,9 +266,9 @@ __device__ __forceinline__ void res_st_pair(double *vec, unsigned off8, double2r
 // Publish the pair of plane t if it lies on the box's surface (first / last a rows of the run, first / last plane).
 __device__ __forceinline__ void res_publish_pair(const ResArgs &A, const ResBox &B, int t, double2r v, unsigned tag) {
   if (((B.mask_a >> t) & 1u) && (B.edge_y || t == 0 || t == B.tzl - 1)) {
-    char *e = A.exch + (size_t)(res_off8(B, t) << 1);
+    char *e = A.exch + (size_t)res_off8(B, t);  // (row g0 is even: its granule is number g0 / 2 of the even rows')
     res_store16(e, res_granule(v.x, tag));
-    if ((B.mask_b >> t) & 1u) res_store16(e + 16, res_granule(v.y, tag));
+    if ((B.mask_b >> t) & 1u) res_store16(e + A.exch_half, res_granule(v.y, tag));
   }
 }
 
@@ -556,14 +559,14 @@ __global__ __launch_bounds__(kResThreads) void res_cg_kernel(ResArgs A) {
 // ---- BiCGStab ------------------------------------------------------------------------------------------------------
 // SolverBiCgStab.hpp:60-167: three all-reduces -- <rt, v>, (<t, s>, <t, t>), (<r, r>, <rt, r>) -- and two exchanges
 // (the surfaces of p and of s = r - alpha v) per iteration.  Registers: r (s), p, v and the weight words of the own
-// rows, t from the second apply to `r = s - omega t`; x and the shadow residual rt live in memory (the XCD's L2 holds
-// the block's rows) and pass through registers where they are used.
+// rows, t from the second apply to `r = s - omega t`; x in LDS beside the copy where both fit (XLDS; 128^3: 80 + 64 KB),
+// else in memory; the shadow residual rt in memory (read-only: the XCD's L2 holds the block's rows).
 __device__ __forceinline__ double res_bicg_direction(double r, double p, double v, double beta, double omega) {
   return __builtin_fma(beta, __builtin_fma(-omega, v, p), r);  // r + beta (p - omega v)      SolverBiCgStab.hpp:119
 }
-template <int TZ>
+template <int TZ, bool XLDS>
 __global__ __launch_bounds__(kResThreads) void res_bicgstab_kernel(ResArgs A) {
-  extern __shared__ __attribute__((aligned(16))) double P[];
+  extern __shared__ __attribute__((aligned(16))) double P[];  // [TZ][a + kResRun + a] (+ XLDS: [TZ][kResRun], x of the own rows, private to its thread)
   __shared__ double dict_sh[32];
   __shared__ double red[2 * kResWaves];
   const ResBox B0 = res_box<TZ>(A);
@@ -578,9 +581,12 @@ __global__ __launch_bounds__(kResThreads) void res_bicgstab_kernel(ResArgs A) {
   u64x2r w[TZ];
   res_load_weights<TZ>(A, B, w);
   double2r lo, hi;
+  double *Q = P + TZ * B0.ldw;
 #pragma unroll
   for (int t = 0; t < TZ; ++t) {
-    res_lds_pair(B, P, t, ((B.mask_a >> t) & 1u) ? res_ld_pair(A.x, res_off8(B, t)) : double2r{0.0, 0.0});
+    const double2r xt = ((B.mask_a >> t) & 1u) ? res_ld_pair(A.x, res_off8(B, t)) : double2r{0.0, 0.0};
+    res_lds_pair(B, P, t, xt);
+    if (XLDS) *reinterpret_cast<double2r *>(&Q[t * kResRun + B.tid2]) = xt;
     p[t] = v[t] = double2r{0.0, 0.0};
   }
   res_halo<TZ, 0>(A, B, P, 0u, A.x, &lo, &hi);
@@ -606,6 +612,14 @@ __global__ __launch_bounds__(kResThreads) void res_bicgstab_kernel(ResArgs A) {
   bool converged = abs_tol > 0.0 && initial_error < abs_tol;  // Solver.hpp:124-128
   if (blockIdx.x == 0 && threadIdx.x == 0 && history) history[0] = initial_error;
   long long it = 0;
+  // (option resident_profile, as in the CG kernel)
+  long long tick[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_mark = A.prof ? wall_clock64() : 0;
+  auto lap = [&](int k) {
+    if (A.prof) {
+      const long long now = wall_clock64();
+      tick[k] += now - t_mark, t_mark = now;
+    }
+  };
   while (!converged && it < num_iterations) {
     if (__hip_atomic_load(A.gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
     // p = r + beta (p - omega v) (first iteration: p = r); v = A p; alpha = rho / <rt, v>      :114-119, :137-139
@@ -619,9 +633,12 @@ __global__ __launch_bounds__(kResThreads) void res_bicgstab_kernel(ResArgs A) {
       res_publish_pair(A, B, t, p[t], (unsigned)xseq);
       res_lds_pair(B, P, t, p[t]);
     }
+    lap(0);  // p = r + beta (p - omega v), its surface out
     res_halo<TZ, 1>(A, B, P, (unsigned)xseq, nullptr, &lo, &hi);
     __syncthreads();
+    lap(1);  // the halo of p: a wait for the neighbours' surfaces
     res_apply<TZ>(A, B, P, dict_sh, lo, hi, w, v);
+    lap(2);  // v = A p
     {
       double a1[1] = {0.0};
 #pragma unroll
@@ -632,6 +649,7 @@ __global__ __launch_bounds__(kResThreads) void res_bicgstab_kernel(ResArgs A) {
       res_allreduce<1>(a1, A, ++seq, red);
       alpha = safe_divide(rho, a1[0]);
     }
+    lap(3);  // <rt, v> (rt from memory) and its all-reduce
     // s = r - alpha v (kept in r); t = A s; omega = <t, s> / <t, t>                            :140-141, :158-160
     // (every block has read its halo of p: it is past the alpha all-reduce)
     B = res_fresh(B0);
@@ -645,8 +663,10 @@ __global__ __launch_bounds__(kResThreads) void res_bicgstab_kernel(ResArgs A) {
     }
     res_halo<TZ, 1>(A, B, P, (unsigned)xseq, nullptr, &lo, &hi);
     __syncthreads();
+    lap(4);  // s = r - alpha v, its surface out, the halo of s
     double2r y[TZ];
     res_apply<TZ>(A, B, P, dict_sh, lo, hi, w, y);
+    lap(5);  // t = A s
     double acc[2] = {0.0, 0.0};
 #pragma unroll
     for (int t = 0; t < TZ; ++t) {
@@ -654,22 +674,26 @@ __global__ __launch_bounds__(kResThreads) void res_bicgstab_kernel(ResArgs A) {
       acc[1] += y[t].x * y[t].x, acc[1] += y[t].y * y[t].y;
     }
     res_allreduce<2>(acc, A, ++seq, red);
+    lap(6);  // <t, s>, <t, t> and their all-reduce
     omega = safe_divide(acc[0], acc[1]);
     // x += alpha p + omega s; r = s - omega t; |r|, <rt, r>                                    :140, :161-164, :116
     acc[0] = acc[1] = 0.0;
     B = res_fresh(B0);
 #pragma unroll
     for (int t = 0; t < TZ; ++t) {
-      double2r xv = ((B.mask_a >> t) & 1u) ? res_ld_pair(A.x, res_off8(B, t)) : double2r{0.0, 0.0};
+      double2r xv = XLDS ? *reinterpret_cast<const double2r *>(&Q[t * kResRun + B.tid2])
+                         : ((B.mask_a >> t) & 1u) ? res_ld_pair(A.x, res_off8(B, t)) : double2r{0.0, 0.0};
       const double2r rt = ((B.mask_a >> t) & 1u) ? res_ld_pair(A.rt, res_off8(B, t)) : double2r{0.0, 0.0};
       xv.x += alpha * p[t].x, xv.y += alpha * p[t].y;
       xv.x += omega * r[t].x, xv.y += omega * r[t].y;
-      res_st_pair(A.x, res_off8(B, t), xv, (B.mask_a >> t) & 1u, (B.mask_b >> t) & 1u);
+      if (XLDS) *reinterpret_cast<double2r *>(&Q[t * kResRun + B.tid2]) = xv;
+      else res_st_pair(A.x, res_off8(B, t), xv, (B.mask_a >> t) & 1u, (B.mask_b >> t) & 1u);
       r[t].x -= omega * y[t].x, r[t].y -= omega * y[t].y;
       acc[0] += r[t].x * r[t].x, acc[0] += r[t].y * r[t].y;
       acc[1] += rt.x * r[t].x, acc[1] += ((B.mask_b >> t) & 1u) ? rt.y * r[t].y : 0.0;
     }
     res_allreduce<2>(acc, A, ++seq, red);
+    lap(7);  // x += alpha p + omega s (x, rt through memory), r = s - omega t, |r|, <rt, r> and their all-reduce
     const double rho_bar = rho;
     rho = acc[1];
     beta = safe_divide(alpha * rho, omega * rho_bar);  // :116-118, for the next iteration
@@ -679,6 +703,14 @@ __global__ __launch_bounds__(kResThreads) void res_bicgstab_kernel(ResArgs A) {
     ++it;
     if (blockIdx.x == 0 && threadIdx.x == 0 && history) history[it] = abs_err;
   }
+  if (XLDS) {
+    B = res_fresh(B0);
+#pragma unroll
+    for (int t = 0; t < TZ; ++t)
+      res_st_pair(A.x, res_off8(B, t), *reinterpret_cast<const double2r *>(&Q[t * kResRun + B.tid2]), (B.mask_a >> t) & 1u, (B.mask_b >> t) & 1u);
+  }
+  if (A.prof && threadIdx.x == 0)
+    for (int k = 0; k < 8; ++k) A.prof[blockIdx.x * 8 + k] = tick[k];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     A.cnt[0] = seq, A.cnt[1] = xseq;
     st->initial_error = initial_error;
@@ -694,6 +726,7 @@ __global__ __launch_bounds__(kResThreads) void res_bicgstab_kernel(ResArgs A) {
 struct ResGeometry {
   int a, b, nplanes, nsec, tz, blocks;
   size_t lds_bytes;
+  bool x_lds;  // BiCGStab: x of the own rows in LDS beside the copy
 };
 // Does the operator run on the resident path, and how: the smallest number of planes per block with which one block
 // per CU covers the lattice.
@@ -719,6 +752,9 @@ static bool res_geometry(const storm_hip_op *op, ResGeometry *G, bool bicgstab =
     const size_t lds = sizeof(double) * (size_t)tz * (size_t)(kResRun + 2 * a);
     if (blocks > cus || lds > (size_t)150 * 1024) continue;
     G->a = a, G->b = b, G->nplanes = (int)nplanes, G->nsec = (int)nsec, G->tz = tz, G->blocks = (int)blocks, G->lds_bytes = lds;
+    G->x_lds = false;
+    const size_t with_x = lds + sizeof(double) * (size_t)tz * kResRun;
+    if (bicgstab && with_x <= (size_t)156 * 1024) G->x_lds = true, G->lds_bytes = with_x;
     return true;
   }
   return false;
@@ -730,8 +766,9 @@ bool res_eligible(const storm_hip_op *op, bool bicgstab) {
 }
 
 template <int TZ>
-static const void *res_kernel(bool bicgstab) {
-  return bicgstab ? (const void *)res_bicgstab_kernel<TZ> : (const void *)res_cg_kernel<TZ, (TZ <= 8)>;
+static const void *res_kernel(bool bicgstab, bool x_lds) {
+  return bicgstab ? (x_lds ? (const void *)res_bicgstab_kernel<TZ, true> : (const void *)res_bicgstab_kernel<TZ, false>)
+                  : (const void *)res_cg_kernel<TZ, (TZ <= 8)>;
 }
 
 // The whole solve; fills the SolverState on the device (the caller reads it back).  *taken = false: nothing ran (the
@@ -748,13 +785,13 @@ int res_solve(bool bicgstab, const storm_hip_op *op, double alpha, double beta, 
   }
   const void *fn = nullptr;
   switch (G.tz) {
-    case 1: fn = res_kernel<1>(bicgstab); break;
-    case 2: fn = res_kernel<2>(bicgstab); break;
-    case 3: fn = res_kernel<3>(bicgstab); break;
-    case 4: fn = res_kernel<4>(bicgstab); break;
-    case 6: fn = res_kernel<6>(bicgstab); break;
-    case 8: fn = res_kernel<8>(bicgstab); break;
-    case 12: fn = res_kernel<12>(bicgstab); break;
+    case 1: fn = res_kernel<1>(bicgstab, G.x_lds); break;
+    case 2: fn = res_kernel<2>(bicgstab, G.x_lds); break;
+    case 3: fn = res_kernel<3>(bicgstab, G.x_lds); break;
+    case 4: fn = res_kernel<4>(bicgstab, G.x_lds); break;
+    case 6: fn = res_kernel<6>(bicgstab, G.x_lds); break;
+    case 8: fn = res_kernel<8>(bicgstab, G.x_lds); break;
+    case 12: fn = res_kernel<12>(bicgstab, G.x_lds); break;
     default: return STORM_HIP_OK;
   }
   // every block must be resident: one per CU with this much LDS, as the occupancy query sees it
@@ -773,12 +810,13 @@ int res_solve(bool bicgstab, const storm_hip_op *op, double alpha, double beta, 
     return STORM_HIP_OK;
   }
   // the exchange buffer (one granule per row) and the slots: zero-filled once, tags only ever grow
+  const size_t exch_half = (size_t)16 * (size_t)((op->n_rows + 3) / 2 + 8);  // (the even rows' granules; 256-byte aligned start of the odd rows')
   if (c->res_exch_rows < op->n_rows + 2) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->d_res_exch) (void)hipFree(c->d_res_exch);
     c->d_res_exch = nullptr, c->res_exch_rows = 0;
-    HIP_TRY(hipMalloc((void **)&c->d_res_exch, (size_t)16 * (size_t)(op->n_rows + 2)));
-    HIP_TRY(hipMemsetAsync(c->d_res_exch, 0, (size_t)16 * (size_t)(op->n_rows + 2), c->stream));
+    HIP_TRY(hipMalloc((void **)&c->d_res_exch, 2 * exch_half + 256));
+    HIP_TRY(hipMemsetAsync(c->d_res_exch, 0, 2 * exch_half + 256, c->stream));
     c->res_exch_rows = op->n_rows + 2;
   }
   if (c->d_res_slots == nullptr) {
@@ -788,7 +826,7 @@ int res_solve(bool bicgstab, const storm_hip_op *op, double alpha, double beta, 
   ResArgs A{};
   A.pack = op->d_pack, A.dict = op->d_dict, A.a = G.a, A.b = G.b, A.nplanes = G.nplanes, A.nsec = G.nsec, A.n_rows = op->n_rows;
   A.alpha = alpha, A.beta = beta, A.rhs = b, A.x = x, A.rt = rt;
-  A.exch = c->d_res_exch, A.slots = c->d_res_slots;
+  A.exch = c->d_res_exch, A.exch_half = (exch_half + 255) / 256 * 256, A.slots = c->d_res_slots;
   A.gave_up = reinterpret_cast<int *>(c->d_lat_slots + (size_t)2 * 256 * kLatSlotStride);
   A.cnt = reinterpret_cast<unsigned long long *>(c->d_res_slots + (size_t)2 * 256 * kLatSlotStride);
   A.st = d_state;

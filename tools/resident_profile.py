@@ -13,13 +13,16 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stormruler_amd import api, mesh  # noqa: E402
 
-PHASES = ["halo_of_new_direction", "apply", "pz_partials", "allreduce_1", "r_update_publish", "allreduce_2", "x_p_update"]
+PHASES = {"cg": ["halo_of_new_direction", "apply", "pz_partials", "allreduce_1", "r_update", "allreduce_2", "x_p_update_publish"],
+          "bicgstab": ["p_update_publish", "halo_of_p", "apply_1", "rtv_allreduce", "s_update_publish_halo", "apply_2",
+                       "ts_tt_allreduce", "x_r_update_allreduce"]}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="64,128")
     ap.add_argument("--iters", type=int, default=300)
+    ap.add_argument("--bicgstab", action="store_true")
     args = ap.parse_args()
     ctx = api.Context(0)
     ctx.set_option("resident_profile", 1)
@@ -30,13 +33,13 @@ def main():
         op = api.HipStencilOperator(mat, -1.0, 0.0)
         b = api.DeviceVector.from_numpy(ctx, 1.0 + 0.25 * np.sin(0.01 * np.arange(g.n_cells)))
         x = api.DeviceVector(ctx, g.n_cells)
-        s = api.CgSolver()
+        s = api.BiCgStabSolver() if args.bicgstab else api.CgSolver()
         s.num_iterations, s.absolute_error_tolerance, s.relative_error_tolerance = args.iters, 0.0, 0.0
         s.solve(x, b, op)
         rec = {"shape": dims, "iterations": int(s.iteration)}
         for kind in ("mean", "max"):
             rec[kind + "_us_per_iteration"] = {
-                name: round(ctx.counter(f"resident_phase_{kind}_{k}") * 0.01 / args.iters, 2) for k, name in enumerate(PHASES)}
+                name: round(ctx.counter(f"resident_phase_{kind}_{k}") * 0.01 / args.iters, 2) for k, name in enumerate(PHASES["bicgstab" if args.bicgstab else "cg"])}
         rec["sum_of_means"] = round(sum(rec["mean_us_per_iteration"].values()), 2)
         print(json.dumps(rec), flush=True)
         mat.close()
