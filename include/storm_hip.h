@@ -74,6 +74,9 @@ int storm_hip_timer_stop(storm_hip_ctx *ctx, float *elapsed_ms);
  * accumulated launch count and durations (synchronises the stream). */
 int storm_hip_ctx_get_spmv_profile(storm_hip_ctx *ctx, int64_t *launches, double *total_ms,
                                    double *min_ms);
+/* ... the same launches one by one (milliseconds each, in launch order; at most `capacity` are written, *count is
+ * how many there were); resets the profile like the call above. */
+int storm_hip_ctx_get_spmv_profile_samples(storm_hip_ctx *ctx, double *ms_out, int64_t capacity, int64_t *count);
 
 /* ---- communicator (RCCL over xGMI) -------------------------
  * rank 0 fills a 128-byte id, the host distributes it (torch.distributed /

@@ -67,6 +67,7 @@ SIGNATURES = {
     "storm_hip_ctx_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
     "storm_hip_ctx_get_counter": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_int64)]),
     "storm_hip_ctx_get_spmv_profile": (C.c_int, [vp, i64p, f64p, f64p]),
+    "storm_hip_ctx_get_spmv_profile_samples": (C.c_int, [vp, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_int64)]),
     "storm_hip_timer_start": (C.c_int, [vp]),
     "storm_hip_timer_stop": (C.c_int, [vp, C.POINTER(C.c_float)]),
     "storm_hip_comm_unique_id": (C.c_int, [vp]),

@@ -87,6 +87,13 @@ class Context:
         check(lib.storm_hip_ctx_get_spmv_profile(self._h, C.byref(n), C.byref(tot), C.byref(mn)))
         return n.value, tot.value, mn.value
 
+    def spmv_profile_samples(self, capacity: int = 1 << 16):
+        """Milliseconds of every SpMV launch since the last call, in launch order (option profile_spmv)."""
+        buf = (C.c_double * capacity)()
+        n = C.c_int64()
+        check(lib.storm_hip_ctx_get_spmv_profile_samples(self._h, buf, capacity, C.byref(n)))
+        return np.array(buf[: min(n.value, capacity)], dtype=np.float64)
+
     def timer_start(self):
         check(lib.storm_hip_timer_start(self._h))
 

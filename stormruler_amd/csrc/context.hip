@@ -240,6 +240,20 @@ int storm_hip_ctx_get_spmv_profile(storm_hip_ctx *c, int64_t *launches, double *
   return STORM_HIP_OK;
 }
 
+int storm_hip_ctx_get_spmv_profile_samples(storm_hip_ctx *c, double *ms_out, int64_t capacity, int64_t *count) {
+  STORM_REQUIRE(c && count && (ms_out || capacity == 0), "get_spmv_profile_samples: null argument");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const size_t pairs = c->prof_used / 2;
+  for (size_t i = 0; i < pairs && (int64_t)i < capacity; ++i) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->prof_events[2 * i], c->prof_events[2 * i + 1]));
+    ms_out[i] = ms;
+  }
+  *count = (int64_t)pairs;
+  c->prof_used = 0;
+  return STORM_HIP_OK;
+}
+
 int storm_hip_timer_start(storm_hip_ctx *c) {
   STORM_REQUIRE(c, "timer_start: null context");
   HIP_TRY(hipEventRecord(c->ev_t0, c->stream));

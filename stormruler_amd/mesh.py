@@ -27,6 +27,7 @@ __all__ = [
     "structured_box",
     "structured_box_slab",
     "random_permutation",
+    "jitter_geometry",
     "tile_ordering",
     "rcm_ordering",
     "permute_cells",
@@ -296,6 +297,20 @@ def structured_box_slab(nx: int, ny: int, nz_glob: int, k0: int, k1: int,
 def random_permutation(n: int, seed: int = 12345) -> np.ndarray:
     """The seeded scramble of SURVEY.md 8d ("unstructured stress variant")."""
     return np.random.default_rng(seed).permutation(n).astype(np.int64)
+
+
+def jitter_geometry(g: FaceGraph, h: float, frac: float = 0.2, seed: int = 2024) -> FaceGraph:
+    """The same face graph with a perturbed geometry: every cell centre displaced by at most ``frac * h`` per coordinate
+    and every face area scaled by 1 +- frac / 2 (seeded).  Volumes stay: the operator remains symmetric positive
+    definite, but no two of its weights ``A_f / (d_f V_i)`` are equal any more -- what a Triangle / TetGen mesh of the
+    reference looks like to the record formats (fp64 weights), at any size."""
+    rng = np.random.default_rng(seed)
+    center = g.center.copy()
+    center[: g.n_cells] += (frac * h) * (2.0 * rng.random((g.n_cells, g.dim)) - 1.0)
+    area = g.area * (1.0 + (0.5 * frac) * (2.0 * rng.random(g.n_faces) - 1.0))
+    return FaceGraph(n_cells=g.n_cells, dim=g.dim, inner=g.inner, outer=g.outer, area=area, center=center,
+                     volume=g.volume, b_cell=g.b_cell, b_area=g.b_area, b_center=g.b_center, n_halo=g.n_halo,
+                     global_id=g.global_id, halo_owner=g.halo_owner)
 
 
 def tile_ordering(nx: int, ny: int, nz: int, ty: int = 16, tz: int = 16) -> np.ndarray:

@@ -11,10 +11,10 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 python3 bench.py --skip-permuted 2>/dev/null | tail -1 > "$OUT/${TAG}_bench.json"
 rm -rf /tmp/prof_stats /tmp/prof_fetch /tmp/prof_write
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 bench.py --cpu-iters 0 --skip-blas1 --traffic off --skip-permuted 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_under_rocprof.json"
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 bench.py --cpu-iters 0 --skip-blas1 --traffic off --skip-permuted --skip-unstructured --skip-configs 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_under_rocprof.json"
 cp "$(find /tmp/prof_stats -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_kernel_stats.csv"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/prof_fetch -- python3 bench.py --cpu-iters 0 --skip-blas1 --traffic off --skip-permuted --steps 20 --warmup 2 --spinup-seconds 0 --min-seconds 0 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/prof_write -- python3 bench.py --cpu-iters 0 --skip-blas1 --traffic off --skip-permuted --steps 20 --warmup 2 --spinup-seconds 0 --min-seconds 0 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/prof_fetch -- python3 bench.py --cpu-iters 0 --skip-blas1 --traffic off --skip-permuted --skip-unstructured --skip-configs --steps 20 --warmup 2 --spinup-seconds 0 --min-seconds 0 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/prof_write -- python3 bench.py --cpu-iters 0 --skip-blas1 --traffic off --skip-permuted --skip-unstructured --skip-configs --steps 20 --warmup 2 --spinup-seconds 0 --min-seconds 0 > /dev/null 2>&1
 FMT=$(python3 -c "import json;print(json.load(open('$OUT/${TAG}_bench.json'))['roofline']['record_format'])")
 ALG=$(python3 -c "import json;print(json.load(open('$OUT/${TAG}_bench.json'))['roofline']['algorithmic_bytes_8d'])")
 FBY=$(python3 -c "import json;print(json.load(open('$OUT/${TAG}_bench.json'))['roofline']['bytes_per_launch'])")
