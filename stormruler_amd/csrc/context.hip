@@ -99,6 +99,7 @@ int storm_hip_ctx_destroy(storm_hip_ctx *c) {
   (void)hipFree(c->d_lat_slots);
   if (c->d_res_exch) (void)hipFree(c->d_res_exch);
   if (c->d_res_slots) (void)hipFree(c->d_res_slots);
+  if (c->d_quad_slots) (void)hipFree(c->d_quad_slots);
   if (c->d_res_prof) (void)hipFree(c->d_res_prof);
   (void)hipFree(c->d_tickets);
   (void)hipFree(c->d_ticket_sums);
@@ -156,6 +157,8 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "coop_mgs")) c->opt_coop_mgs = value;
   else if (!strcmp(key, "coop_mgs_min_rows")) c->opt_coop_mgs_min_rows = value;
   else if (!strcmp(key, "coop_mgs_pairs")) c->opt_coop_mgs_pairs = value;
+  else if (!strcmp(key, "coop_mgs_lds")) c->opt_coop_mgs_lds = value;
+  else if (!strcmp(key, "coop_mgs_quad")) c->opt_coop_mgs_quad = value;
   else if (!strcmp(key, "spmv_mixed")) c->opt_spmv_mixed = value;
   else if (!strcmp(key, "sweep_alternate")) c->opt_sweep_alternate = value;
   else if (!strcmp(key, "spmv_canon_groups")) c->opt_spmv_canon_groups = value;
@@ -217,6 +220,14 @@ int storm_hip_ctx_get_counter(storm_hip_ctx *c, const char *key, int64_t *value)
     long long m = 0, sum = 0;
     for (int b = 0; b < c->res_prof_blocks; ++b) m = std::max(m, h[(size_t)b * 8 + k]), sum += h[(size_t)b * 8 + k];
     *value = mx ? m : sum / c->res_prof_blocks;
+  } else if (!strncmp(key, "resident_phase_block_", 21)) {  // "resident_phase_block_<b>_<k>": block b's ticks in phase k
+    int b = 0, k = 0;
+    STORM_REQUIRE(sscanf(key + 21, "%d_%d", &b, &k) == 2 && c->d_res_prof != nullptr && b >= 0 && b < c->res_prof_blocks && k >= 0 && k < 8,
+                  "ctx_get_counter: no such block / phase");
+    long long v = 0;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(&v, c->d_res_prof + (size_t)b * 8 + k, sizeof v, hipMemcpyDeviceToHost));
+    *value = v;
   }
   else STORM_FAIL(STORM_HIP_E_INVALID, "ctx_get_counter: unknown key '%s'", key);
   return STORM_HIP_OK;

@@ -42,7 +42,14 @@ __device__ __forceinline__ void co_publish(double *p, double v, int xchg, unsign
 // slower block is still polling for `seq` -- into the other slot; it can only overwrite slot (seq & 1) with `seq + 2`
 // after passing `seq + 1`, which needed the slow block's `seq + 1` words, which that block stores after it has
 // finished reading `seq`.
-constexpr int kLatSlotStride = 256;
+constexpr int kLatSlotStride = 64;
+// Slot of block b for all-reduce `seq`: the blocks' slots of one parity are CONTIGUOUS (round 3: 512 bytes apart, "so
+// that the polling spreads over the memory channels" -- but every block polls every slot, and 256 threads reading 256
+// scattered lines are 256 requests per poll and block where 256 x 64 contiguous bytes are 128; under a streaming load
+// the requests are what a synchronisation point waits for).
+__device__ __forceinline__ size_t lat_slot_offset(unsigned block, unsigned long long seq) {
+  return ((size_t)(seq & 1) * 256 + block) * kLatSlotStride;
+}
 constexpr long long kLatTimeoutTicks = 1000000000LL;  // 10 s of the 100 MHz real-time counter
 __device__ __forceinline__ bool co_load_slot(const char *slot, unsigned tag, double *value) {
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -69,10 +76,199 @@ __device__ __forceinline__ bool co_load_slot2(const char *slot, unsigned tag, do
   *v1 = __hiloint2double((int)w1.z, (int)w1.x);
   return w0.y == tag && w0.w == tag && w1.y == tag && w1.w == tag;
 }
+// Three sums in one slot: six words, ONE round trip (round 3 polled them with two dependent loads -- the paired
+// Gram-Schmidt chain's synchronisation point cost two memory round trips per poll instead of one).
+__device__ __forceinline__ bool co_load_slot3(const char *slot, unsigned tag, double *v0, double *v1, double *v2) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 w0, w1, w2;
+  asm volatile(
+      "global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %3, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %2, %3, off offset:32 sc1\n\ts_waitcnt vmcnt(0)"
+      : "=&v"(w0), "=&v"(w1), "=&v"(w2)
+      : "v"(slot)
+      : "memory");
+  *v0 = __hiloint2double((int)w0.z, (int)w0.x);
+  *v1 = __hiloint2double((int)w1.z, (int)w1.x);
+  *v2 = __hiloint2double((int)w2.z, (int)w2.x);
+  return w0.y == tag && w0.w == tag && w1.y == tag && w1.w == tag && w2.y == tag && w2.w == tag;
+}
 __device__ __forceinline__ double lat_wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
   return v;
+}
+
+
+// N sums (N <= 10) over a co-resident grid of blocks of WAVES wavefronts, in slots `stride` bytes apart (parity-major:
+// slot of block b at ((seq & 1) * 256 + b) * stride); every value travels as two self-validating words like the
+// one- to three-value forms above, all of a slot's words are polled in ONE round trip.  Identical bits in every thread of
+// every block (fixed folding order); bounded wait -> *gave_up.
+template <int NV>
+__device__ __forceinline__ bool co_load_slot_n(const char *slot, unsigned tag, double (&v)[NV]) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 w[NV];
+  // (one base register, immediate offsets; nothing is consumed before the last load is in flight)
+  if constexpr (NV == 10) {
+    asm volatile(
+        "global_load_dwordx4 %0, %10, off sc1\n\tglobal_load_dwordx4 %1, %10, off offset:16 sc1\n\t"
+        "global_load_dwordx4 %2, %10, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %10, off offset:48 sc1\n\t"
+        "global_load_dwordx4 %4, %10, off offset:64 sc1\n\tglobal_load_dwordx4 %5, %10, off offset:80 sc1\n\t"
+        "global_load_dwordx4 %6, %10, off offset:96 sc1\n\tglobal_load_dwordx4 %7, %10, off offset:112 sc1\n\t"
+        "global_load_dwordx4 %8, %10, off offset:128 sc1\n\tglobal_load_dwordx4 %9, %10, off offset:144 sc1\n\ts_waitcnt vmcnt(0)"
+        : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7]), "=&v"(w[8]), "=&v"(w[9])
+        : "v"(slot)
+        : "memory");
+  } else if constexpr (NV == 6) {
+    asm volatile(
+        "global_load_dwordx4 %0, %6, off sc1\n\tglobal_load_dwordx4 %1, %6, off offset:16 sc1\n\t"
+        "global_load_dwordx4 %2, %6, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %6, off offset:48 sc1\n\t"
+        "global_load_dwordx4 %4, %6, off offset:64 sc1\n\tglobal_load_dwordx4 %5, %6, off offset:80 sc1\n\ts_waitcnt vmcnt(0)"
+        : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5])
+        : "v"(slot)
+        : "memory");
+  } else if constexpr (NV == 3) {
+    asm volatile(
+        "global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %3, off offset:16 sc1\n\t"
+        "global_load_dwordx4 %2, %3, off offset:32 sc1\n\ts_waitcnt vmcnt(0)"
+        : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2])
+        : "v"(slot)
+        : "memory");
+  } else if constexpr (NV == 2) {
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(w[0]), "=&v"(w[1])
+                 : "v"(slot)
+                 : "memory");
+  } else {
+    static_assert(NV == 1, "co_load_slot_n: 1, 2, 3, 6 or 10 values");
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w[0]) : "v"(slot) : "memory");
+  }
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    v[j] = __hiloint2double((int)w[j].z, (int)w[j].x);
+    ok = ok && w[j].y == tag && w[j].w == tag;
+  }
+  return ok;
+}
+template <int NV, int WAVES>
+__device__ __forceinline__ void co_allreduce_n(double (&s)[NV], char *slots, int stride, int *gave_up, unsigned long long seq,
+                                               double *lds /* [NV * WAVES] */) {
+  static_assert(NV == 1 || NV == 6 || NV == 10, "co_allreduce_n: the wait statement lists its registers");
+  const unsigned tag = (unsigned)seq;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  double v[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) v[j] = lat_wave_sum(s[j]);
+  __syncthreads();  // (lds may still be read by the previous call)
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) lds[j * WAVES + wave] = v[j];
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < NV) {  // thread j folds and stores sum j
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) t += lds[threadIdx.x * WAVES + w];
+    co_store_slot(slots + ((size_t)(seq & 1) * 256 + blockIdx.x) * stride + 16 * threadIdx.x, tag, t);
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) v[j] = 0.0;
+  if (threadIdx.x < gridDim.x) {  // gridDim.x <= 256: thread t (waves 0 .. 3) watches block t
+    const char *slot = slots + ((size_t)(seq & 1) * 256 + threadIdx.x) * stride;
+    const long long t0 = wall_clock64();
+    for (int spins = 0;; ++spins) {
+      if (co_load_slot_n<NV>(slot, tag, v)) break;
+      __builtin_amdgcn_s_sleep(1);
+      if ((spins & 1023) == 1023 &&
+          (wall_clock64() - t0 > kLatTimeoutTicks || __hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        __hip_atomic_store(gave_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) v[j] = 0.0;
+        break;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) v[j] = lat_wave_sum(v[j]);
+  __syncthreads();
+  if (lane == 0 && wave < 4) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) lds[j * WAVES + wave] = v[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NV; ++j) s[j] = (lds[j * WAVES] + lds[j * WAVES + 1]) + (lds[j * WAVES + 2] + lds[j * WAVES + 3]);
+}
+
+
+// The same in TWO LEVELS (round 4).  In the flat form above every block polls every block's slot: NV x 256 x 256 16-byte
+// requests per polling round, each one a trip through the fabric (sc1 loads miss through the XCDs' L2s) -- measured
+// 2.9 us for one value, 8.9 for three, 9.4 for six (GMRES's Gram-Schmidt chain at 128^3, the memory system otherwise
+// idle): a synchronisation point was paying for its polling traffic.  Here the blocks form groups of 32 by index; a
+// group's first block gathers its members' sums and publishes the group's sum; every block then polls the (at most 8)
+// group sums: 256 + 8 x 256 / 32 slot reads per round instead of 65 536.  Two hops instead of one, a fixed folding order
+// (lanes, then groups: the same bits in every block, run to run).  slots: [2 parities][256 blocks] of `stride` bytes, then
+// [2][8] group slots of `stride` bytes.
+constexpr int kCoGroup = 32;
+template <int NV, int WAVES>
+__device__ __forceinline__ void co_allreduce2_n(double (&s)[NV], char *slots, int stride, int *gave_up, unsigned long long seq,
+                                                double *lds /* [NV * WAVES] */) {
+  const unsigned tag = (unsigned)seq;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  double v[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) v[j] = lat_wave_sum(s[j]);
+  __syncthreads();  // (lds may still be read by the previous call)
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) lds[j * WAVES + wave] = v[j];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    char *group_slots = slots + (size_t)2 * 256 * stride;
+    const unsigned b = blockIdx.x, g = b / kCoGroup, ng = (gridDim.x + kCoGroup - 1) / kCoGroup;
+    if (lane < NV) {  // lane j folds and stores the block's sum j
+      double t = 0.0;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) t += lds[lane * WAVES + w];
+      co_store_slot(slots + ((size_t)(seq & 1) * 256 + b) * stride + 16 * lane, tag, t);
+    }
+    auto poll = [&](const char *slot, bool active) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) v[j] = 0.0;
+      if (active) {
+        const long long t0 = wall_clock64();
+        for (int spins = 0;; ++spins) {
+          if (co_load_slot_n<NV>(slot, tag, v)) break;
+          __builtin_amdgcn_s_sleep(1);
+          if ((spins & 1023) == 1023 &&
+              (wall_clock64() - t0 > kLatTimeoutTicks || __hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            __hip_atomic_store(gave_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) v[j] = 0.0;
+            break;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NV; ++j) v[j] = lat_wave_sum(v[j]);  // lanes in order: a fixed tree
+    };
+    if (b % kCoGroup == 0) {  // the group's first block: gather the members' sums, publish the group's
+      const unsigned members = min((unsigned)kCoGroup, gridDim.x - b);
+      poll(slots + ((size_t)(seq & 1) * 256 + b + lane) * stride, (unsigned)lane < members);
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+        if (lane == j) co_store_slot(group_slots + ((size_t)(seq & 1) * 8 + g) * stride + 16 * j, tag, v[j]);
+    }
+    poll(group_slots + ((size_t)(seq & 1) * 8 + lane) * stride, (unsigned)lane < ng);
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) lds[j * WAVES] = v[j];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NV; ++j) s[j] = lds[j * WAVES];
 }
 
 }  // namespace storm

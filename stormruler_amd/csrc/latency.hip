@@ -39,7 +39,7 @@ namespace storm {
 constexpr int kLatBlock = 1024;  // one block per CU: a synchronisation point costs per participating BLOCK
 constexpr int kLatWaves = kLatBlock / kWave;
 
-static bool coop_launch(storm_hip_ctx *c, const void *fn, unsigned blocks, void **args);  // (below: a refused launch is a fallback, not an error)
+static bool coop_launch(storm_hip_ctx *c, const void *fn, unsigned blocks, void **args, size_t dyn_lds = 0, unsigned threads = kLatBlock);  // (below: a refused launch is a fallback, not an error)
 
 struct LatArgs {
   const char *pack;          // compact records
@@ -72,11 +72,11 @@ __device__ __forceinline__ double lat_allreduce(double mine, char *slots, unsign
     double t = 0.0;
 #pragma unroll
     for (int w = 0; w < kLatWaves; ++w) t += lds[w];
-    co_store_slot(slots + ((size_t)blockIdx.x * 2 + (seq & 1)) * kLatSlotStride, tag, t);
+    co_store_slot(slots + lat_slot_offset(blockIdx.x, seq), tag, t);
   }
   v = 0.0;
   if (threadIdx.x < gridDim.x) {  // gridDim.x <= 256 <= blockDim.x: thread t watches block t
-    const char *slot = slots + ((size_t)threadIdx.x * 2 + (seq & 1)) * kLatSlotStride;
+    const char *slot = slots + lat_slot_offset(threadIdx.x, seq);
     // Every wait is bounded: the grid is launched cooperatively (all blocks resident), but should a block never
     // arrive -- the device shared with another process's cooperative kernel, say -- the others give up after
     // kLatTimeoutTicks instead of spinning forever, raise the flag behind the slots and fall through every later
@@ -117,11 +117,11 @@ __device__ __forceinline__ void lat_allreduce2(double &s0, double &s1, char *slo
     double t = 0.0;
 #pragma unroll
     for (int w = 0; w < kLatWaves; ++w) t += lds[threadIdx.x * kLatWaves + w];
-    co_store_slot(slots + ((size_t)blockIdx.x * 2 + (seq & 1)) * kLatSlotStride + 16 * threadIdx.x, tag, t);
+    co_store_slot(slots + lat_slot_offset(blockIdx.x, seq) + 16 * threadIdx.x, tag, t);
   }
   v0 = v1 = 0.0;
   if (threadIdx.x < gridDim.x) {
-    const char *slot = slots + ((size_t)threadIdx.x * 2 + (seq & 1)) * kLatSlotStride;
+    const char *slot = slots + lat_slot_offset(threadIdx.x, seq);
     int *gave_up = reinterpret_cast<int *>(slots + (size_t)2 * 256 * kLatSlotStride);
     const long long t0 = wall_clock64();
     for (int spins = 0;; ++spins) {
@@ -156,19 +156,15 @@ __device__ __forceinline__ void lat_allreduce3(double &s0, double &s1, double &s
     double t = 0.0;
 #pragma unroll
     for (int w = 0; w < kLatWaves; ++w) t += lds[threadIdx.x * kLatWaves + w];
-    co_store_slot(slots + ((size_t)blockIdx.x * 2 + (seq & 1)) * kLatSlotStride + 16 * threadIdx.x, tag, t);
+    co_store_slot(slots + lat_slot_offset(blockIdx.x, seq) + 16 * threadIdx.x, tag, t);
   }
   v0 = v1 = v2 = 0.0;
   if (threadIdx.x < gridDim.x) {
-    const char *slot = slots + ((size_t)threadIdx.x * 2 + (seq & 1)) * kLatSlotStride;
+    const char *slot = slots + lat_slot_offset(threadIdx.x, seq);
     int *gave_up = reinterpret_cast<int *>(slots + (size_t)2 * 256 * kLatSlotStride);
     const long long t0 = wall_clock64();
     for (int spins = 0;; ++spins) {
-      double x2 = 0.0;
-      const bool ok01 = co_load_slot2(slot, tag, &v0, &v1);
-      const bool ok2 = co_load_slot(slot + 32, tag, &x2);
-      v2 = x2;
-      if (ok01 && ok2) break;
+      if (co_load_slot3(slot, tag, &v0, &v1, &v2)) break;
       __builtin_amdgcn_s_sleep(1);
       if ((spins & 1023) == 1023 &&
           (wall_clock64() - t0 > kLatTimeoutTicks || __hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
@@ -537,6 +533,8 @@ struct MgsArgs {
   char *slots;
   const int *done;
   MgsGivens givens;  // st == nullptr: the caller applies the rotations
+  long long *prof;   // option resident_profile: [gridDim.x][8] ticks per phase of this launch (diagnostic)
+  char *quad_slots;  // mgs_chain_quad_kernel: all-reduce slots of kQuadSlotStride bytes
 };
 template <int S>
 __global__ __launch_bounds__(kLatBlock) void mgs_chain_kernel(MgsArgs a) {
@@ -552,31 +550,41 @@ __global__ __launch_bounds__(kLatBlock) void mgs_chain_kernel(MgsArgs a) {
   const int64_t n_waves = (int64_t)gridDim.x * kLatWaves;
   unsigned long long seq = a.seq_base;
   double w[S], qc[S], qn[S];
-  int64_t row[S];
+  int row[S];  // (-1: no such row; the chain takes at most 2^22 rows)
 #pragma unroll
   for (int s = 0; s < S; ++s) {
     const int64_t sl = wave_id + s * n_waves;
-    row[s] = (sl < a.n_slices && sl * kWave + lane < a.n_rows) ? sl * kWave + lane : -1;
+    row[s] = (sl < a.n_slices && sl * kWave + lane < a.n_rows) ? (int)(sl * kWave + lane) : -1;
     w[s] = row[s] >= 0 ? a.w[row[s]] : 0.0;
     qc[s] = row[s] >= 0 ? a.q[0][row[s]] : 0.0;
     qn[s] = 0.0;
   }
   int i0 = 0;
-  if (a.pairs) {
+  if constexpr (S <= 8) if (a.pairs) {  // (16 slices per wavefront leave no registers for the pair's vectors)
     // Two steps per synchronisation point.  The reference's h_{i+1} = <w - h_i q_i, q_{i+1}> is, by bilinearity,
     // <w, q_{i+1}> - h_i <q_i, q_{i+1}>: the three dot products of the right-hand side need only the w BEFORE step i,
     // so they share one all-reduce (the same algorithm; the roundings of the dot products group differently, as
     // with any other summation order).  q_{i+2} travels while the reduction is in flight.
-    double qd[S];
+    // (both vectors of the NEXT pair travel while this pair's reduction is in flight: round 3 loaded the second one at
+    //  the top of the next pass, 16.8 MB at 128^3 with nothing to hide behind -- 3.4 us per pair)
+    double qd[S], qe[S];
+    bool have_n = false;  // qn holds q_{i0+1} already
     for (; i0 + 1 <= a.k; i0 += 2) {
+      if (!have_n) {
 #pragma unroll
-      for (int s = 0; s < S; ++s) qn[s] = row[s] >= 0 ? a.q[i0 + 1][row[s]] : 0.0;
+        for (int s = 0; s < S; ++s) qn[s] = row[s] >= 0 ? a.q[i0 + 1][row[s]] : 0.0;
+      }
       double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
       for (int s = 0; s < S; ++s) s0 += w[s] * qc[s], s1 += w[s] * qn[s], s2 += qc[s] * qn[s];
       if (i0 + 2 <= a.k) {
 #pragma unroll
         for (int s = 0; s < S; ++s) qd[s] = row[s] >= 0 ? a.q[i0 + 2][row[s]] : 0.0;
+      }
+      const bool have_next = i0 + 3 <= a.k;
+      if (have_next) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) qe[s] = row[s] >= 0 ? a.q[i0 + 3][row[s]] : 0.0;
       }
       lat_allreduce3(s0, s1, s2, a.slots, ++seq, lds);
       const double h0 = s0, h1 = s1 - h0 * s2;
@@ -589,7 +597,9 @@ __global__ __launch_bounds__(kLatBlock) void mgs_chain_kernel(MgsArgs a) {
         w[s] -= h0 * qc[s];
         w[s] -= h1 * qn[s];
         qc[s] = qd[s];
+        if (have_next) qn[s] = qe[s];
       }
+      have_n = have_next;
     }
   }
   for (int i = i0; i <= a.k; ++i) {
@@ -645,6 +655,355 @@ __global__ __launch_bounds__(kLatBlock) void mgs_chain_kernel(MgsArgs a) {
   }
 }
 
+// The three-value all-reduce for a kernel with LDS-DMA in flight: __syncthreads() carries a fence that waits for every
+// outstanding vector-memory operation of the wave -- the DMAs included -- so the block's barriers here are bare
+// `s_barrier`s behind `s_waitcnt lgkmcnt(0)` (the LDS writes they order), and only the POLLING waves, which the
+// caller keeps free of DMAs until they are through, wait on the vector-memory counter.
+__device__ __forceinline__ void raw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void lat_allreduce3_raw(double &s0, double &s1, double &s2, char *slots, unsigned long long seq,
+                                                   double *lds /* [3 * kLatWaves] */) {
+  const unsigned tag = (unsigned)seq;
+  double v0 = lat_wave_sum(s0), v1 = lat_wave_sum(s1), v2 = lat_wave_sum(s2);
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  raw_barrier();
+  if (lane == 0) lds[wave] = v0, lds[kLatWaves + wave] = v1, lds[2 * kLatWaves + wave] = v2;
+  raw_barrier();
+  if (threadIdx.x < 3) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < kLatWaves; ++w) t += lds[threadIdx.x * kLatWaves + w];
+    co_store_slot(slots + lat_slot_offset(blockIdx.x, seq) + 16 * threadIdx.x, tag, t);
+  }
+  v0 = v1 = v2 = 0.0;
+  if (threadIdx.x < gridDim.x) {
+    const char *slot = slots + lat_slot_offset(threadIdx.x, seq);
+    int *gave_up = reinterpret_cast<int *>(slots + (size_t)2 * 256 * kLatSlotStride);
+    const long long t0 = wall_clock64();
+    for (int spins = 0;; ++spins) {
+      if (co_load_slot3(slot, tag, &v0, &v1, &v2)) break;
+      __builtin_amdgcn_s_sleep(1);
+      if ((spins & 1023) == 1023 &&
+          (wall_clock64() - t0 > kLatTimeoutTicks || __hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        __hip_atomic_store(gave_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v0 = v1 = v2 = 0.0;
+        break;
+      }
+    }
+  }
+  v0 = lat_wave_sum(v0), v1 = lat_wave_sum(v1), v2 = lat_wave_sum(v2);
+  raw_barrier();
+  if (lane == 0 && wave < 4) lds[wave] = v0, lds[kLatWaves + wave] = v1, lds[2 * kLatWaves + wave] = v2;
+  raw_barrier();
+  s0 = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+  s1 = (lds[kLatWaves] + lds[kLatWaves + 1]) + (lds[kLatWaves + 2] + lds[kLatWaves + 3]);
+  s2 = (lds[2 * kLatWaves] + lds[2 * kLatWaves + 1]) + (lds[2 * kLatWaves + 2] + lds[2 * kLatWaves + 3]);
+}
+
+// ---- ... with the basis vectors landing in LDS (round 4) ----------------------------------------------------------
+// The chain above is bound by what it can keep in flight: w and the current pair of basis vectors fill the registers, so
+// the next vectors' rows are requested only when a register array is free again and the HBM stream stops at every
+// all-reduce (GMRES(30) at 128^3: 2.8 TB/s over the chain).  Here the NEXT pair of basis vectors is fetched by LDS-DMA
+// (`global_load_lds_dwordx4`: no register destination) into a two-slot ring of the block's rows, 2 x SUB x 16 KiB,
+// issued the moment the current pair has been read out of the ring: the stream runs through the reduction and the
+// update of w.  A thread reads back exactly the 16 bytes its own DMA wrote (the ring is a per-thread landing zone, no
+// barrier), behind `s_waitcnt vmcnt(0)`.  Rows of a block: [blockIdx * SUB * 2048, ...), pair 2 t + j * 2048 of thread t.
+// Same steps, same values in the same order as the paired chain above; the block partials group the rows differently.
+constexpr int kMgsSub = 2 * kLatBlock;  // rows per sub-chunk: one pair per thread
+typedef double double2m __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst /* wave-uniform byte address */) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+template <int SUB>
+__global__ __launch_bounds__(kLatBlock) void mgs_chain_lds_kernel(MgsArgs a) {
+  if (a.done && *a.done) return;  // (uniform: every block reads the same flag before any of them synchronises)
+  extern __shared__ __attribute__((aligned(16))) double ring[];  // [2][SUB * kMgsSub]
+  __shared__ double lds[3 * kLatWaves];
+  __shared__ double hcol[kMgsMaxVectors + 1], cs_sh[kMgsMaxVectors], sn_sh[kMgsMaxVectors];
+  const bool rotate = a.givens.st != nullptr && blockIdx.x == 0;
+  if (rotate && (int)threadIdx.x < a.k) cs_sh[threadIdx.x] = a.givens.cs[threadIdx.x], sn_sh[threadIdx.x] = a.givens.sn[threadIdx.x];
+  const int tid = threadIdx.x, wave = tid >> 6;
+  unsigned long long seq = a.seq_base;
+  const int64_t chunk0 = (int64_t)blockIdx.x * SUB * kMgsSub;
+  int64_t row[SUB];
+  bool va[SUB], vb[SUB];
+  double2m w[SUB];
+#pragma unroll
+  for (int j = 0; j < SUB; ++j) {
+    row[j] = chunk0 + (int64_t)j * kMgsSub + 2 * tid;
+    va[j] = row[j] < a.n_rows, vb[j] = row[j] + 1 < a.n_rows;
+    w[j] = double2m{0.0, 0.0};
+    if (vb[j]) w[j] = *reinterpret_cast<const double2m *>(a.w + row[j]);
+    else if (va[j]) w[j].x = a.w[row[j]];
+  }
+  const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) void *)ring;  // the ring's LDS byte address
+  // this block's rows of basis vector q into a slot of the ring (rows past the end: any valid address, masked below)
+  auto issue = [&](int slot, const double *q) {
+#pragma unroll
+    for (int j = 0; j < SUB; ++j) {
+      const unsigned dst = __builtin_amdgcn_readfirstlane(ring_base + (unsigned)(((slot * SUB + j) * kMgsSub + wave * 2 * kWave) * 8));
+      glds16(q + (va[j] ? row[j] : 0), dst);
+    }
+  };
+  auto take = [&](int slot, double2m (&v)[SUB]) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's DMAs have landed
+#pragma unroll
+    for (int j = 0; j < SUB; ++j) {
+      const double2m t = *reinterpret_cast<const double2m *>(&ring[(slot * SUB + j) * kMgsSub + 2 * tid]);
+      v[j].x = va[j] ? t.x : 0.0, v[j].y = vb[j] ? t.y : 0.0;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and are in registers: the slot may be refilled
+  };
+  long long tick[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_mark = a.prof ? wall_clock64() : 0;
+  auto lap = [&](int p) {
+    if (a.prof) {
+      const long long now = wall_clock64();
+      tick[p] += now - t_mark, t_mark = now;
+    }
+  };
+  issue(0, a.q[0]);
+  if (a.k >= 1) issue(1, a.q[1]);
+  double2m qa[SUB], qb[SUB];
+  int i = 0;
+  for (; i + 1 <= a.k; i += 2) {
+    lap(0);  // (the update of w, loop overhead)
+    take(0, qa), take(1, qb);
+    lap(1);  // waiting for the pair's rows
+    // the next pair travels under the reduction and the update -- but for the waves that poll the other blocks' slots
+    // (vector loads return in order: a poll behind a DMA would wait for it), which ask for theirs once they are through
+    const bool polls = wave < 4;
+    if (!polls) {
+      if (i + 2 <= a.k) issue(0, a.q[i + 2]);
+      if (i + 3 <= a.k) issue(1, a.q[i + 3]);
+    }
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < SUB; ++j) {
+      s0 += w[j].x * qa[j].x, s1 += w[j].x * qb[j].x, s2 += qa[j].x * qb[j].x;
+      s0 += w[j].y * qa[j].y, s1 += w[j].y * qb[j].y, s2 += qa[j].y * qb[j].y;
+    }
+    lap(2);  // DMA issue + dot products
+    lat_allreduce3_raw(s0, s1, s2, a.slots, ++seq, lds);
+    lap(3);  // the all-reduce
+    if (polls) {
+      if (i + 2 <= a.k) issue(0, a.q[i + 2]);
+      if (i + 3 <= a.k) issue(1, a.q[i + 3]);
+    }
+    const double h0 = s0, h1 = s1 - h0 * s2;  // (mgs_chain_kernel: the reference's h_{i+1} by bilinearity)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      if (rotate) hcol[i] = h0, hcol[i + 1] = h1;
+      else a.H[(int64_t)i * a.m + a.k] = h0, a.H[(int64_t)(i + 1) * a.m + a.k] = h1;
+    }
+#pragma unroll
+    for (int j = 0; j < SUB; ++j) {
+      w[j].x -= h0 * qa[j].x, w[j].y -= h0 * qa[j].y;
+      w[j].x -= h1 * qb[j].x, w[j].y -= h1 * qb[j].y;
+    }
+  }
+  if (i <= a.k) {  // an odd vector is left: it sits in slot 0
+    take(0, qa);
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < SUB; ++j) acc += w[j].x * qa[j].x, acc += w[j].y * qa[j].y;
+    const double h = lat_allreduce(acc, a.slots, ++seq, lds, false);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      if (rotate) hcol[i] = h;
+      else a.H[(int64_t)i * a.m + a.k] = h;
+    }
+#pragma unroll
+    for (int j = 0; j < SUB; ++j) w[j].x -= h * qa[j].x, w[j].y -= h * qa[j].y;
+  }
+  double acc = 0.0;
+#pragma unroll
+  for (int j = 0; j < SUB; ++j) acc += w[j].x * w[j].x, acc += w[j].y * w[j].y;
+  const double norm2 = lat_allreduce(acc, a.slots, ++seq, lds, false);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *a.norm2_out = norm2;
+  const double hn = sqrt(norm2);
+#pragma unroll
+  for (int j = 0; j < SUB; ++j) {
+    const double2m o = a.normalise ? double2m{w[j].x / hn, w[j].y / hn} : w[j];
+    if (vb[j]) *reinterpret_cast<double2m *>(a.w + row[j]) = o;
+    else if (va[j]) a.w[row[j]] = o.x;
+  }
+  lap(4);  // the tail: odd vector, norm, store
+  if (a.prof && threadIdx.x == 0)
+    for (int p = 0; p < 8; ++p) a.prof[blockIdx.x * 8 + p] = tick[p];
+  // SolverGmres.hpp:161, :176-191 and Solver.hpp:132-140, as in mgs_chain_kernel
+  if (rotate && threadIdx.x == 0) {
+    const int k = a.k, m = a.m;
+    *a.givens.hn_slot = hn;
+    hcol[k + 1] = hn;
+    for (int t = 0; t < k; ++t) {
+      const double chi = cs_sh[t] * hcol[t] + sn_sh[t] * hcol[t + 1];
+      hcol[t + 1] = -sn_sh[t] * hcol[t] + cs_sh[t] * hcol[t + 1];
+      hcol[t] = chi;
+    }
+    const double ha = hcol[k], hb = hcol[k + 1];
+    const double rr = hypot(ha, hb);
+    double cs, sn;
+    if (rr > 0.0) cs = ha / rr, sn = hb / rr;
+    else cs = 1.0, sn = 0.0;
+    a.givens.cs[k] = cs, a.givens.sn[k] = sn;
+    hcol[k] = cs * ha + sn * hb;
+    hcol[k + 1] = 0.0;
+    for (int t = 0; t <= k + 1; ++t) a.givens.H[(int64_t)t * m + k] = hcol[t];
+    const double bk = a.givens.beta[k];
+    a.givens.beta[k + 1] = -sn * bk;
+    a.givens.beta[k] = bk * cs;
+    advance(a.givens.st, fabs(-sn * bk));
+  }
+}
+
+// ---- ... FOUR steps per synchronisation point (round 4) -----------------------------------------------------------
+// Measured (option resident_profile, GMRES(30) at 128^3, the 30-vector chain): 134 of 167 us are the 15 all-reduces,
+// 8.9 us each -- three times what the same all-reduce costs the resident CG kernel, because a poll queues behind the
+// 33 MB of basis-vector rows the chain has just asked for (the ring above does not change that: the requests are FIFO).
+// A chain is therefore (its bytes at the HBM rate) + (its synchronisation points x ~4.7 us), and what is left to take
+// are the synchronisation points: FOUR Gram-Schmidt steps share one.  By bilinearity (as for the pairs above)
+//   h_0 = <w, q_0>,   h_j = <w, q_j> - sum_{i < j} h_i <q_i, q_j>            (j = 1, 2, 3)
+// are the reference's h_j = <w - h_0 q_0 - ... - h_{j-1} q_{j-1}, q_j> (SolverGmres.hpp:157-160); the ten dot products on
+// the right need only the w before the group, and travel in one all-reduce.  Blocks of 512 threads (two wavefronts per
+// SIMD: 256 registers per lane hold w and the group's four vectors of 2 S rows); the update w -= h_0 q_0; ... -= h_3 q_3
+// runs in the reference's order.
+constexpr int kQuadThreads = 512, kQuadWaves = kQuadThreads / kWave, kQuadSub = 2 * kQuadThreads;
+constexpr int kQuadSlotStride = 256;  // ten values of 16 bytes
+template <int S, int T>  // T = 3 or 4 steps per synchronisation point
+__global__ __launch_bounds__(kQuadThreads) void mgs_chain_quad_kernel(MgsArgs a) {
+  if (a.done && *a.done) return;  // (uniform: every block reads the same flag before any of them synchronises)
+  __shared__ double lds[10 * kQuadWaves];
+  __shared__ double hcol[kMgsMaxVectors + 1], cs_sh[kMgsMaxVectors], sn_sh[kMgsMaxVectors];
+  const bool rotate = a.givens.st != nullptr && blockIdx.x == 0;
+  if (rotate && (int)threadIdx.x < a.k) cs_sh[threadIdx.x] = a.givens.cs[threadIdx.x], sn_sh[threadIdx.x] = a.givens.sn[threadIdx.x];
+  const int tid = threadIdx.x;
+  unsigned long long seq = a.seq_base;
+  int *gave_up = reinterpret_cast<int *>(a.slots + (size_t)2 * 256 * kLatSlotStride);  // (the latency path's flag)
+  char *slots = a.quad_slots;
+  const int64_t chunk0 = (int64_t)blockIdx.x * S * kQuadSub;
+  unsigned off8[S];  // byte offset of the thread's pair j (rows < 2^22)
+  bool va[S], vb[S];
+  double2m w[S];
+#pragma unroll
+  for (int j = 0; j < S; ++j) {
+    const int64_t row = chunk0 + (int64_t)j * kQuadSub + 2 * tid;
+    va[j] = row < a.n_rows, vb[j] = row + 1 < a.n_rows;
+    off8[j] = va[j] ? (unsigned)row << 3 : 0u;
+    w[j] = double2m{0.0, 0.0};
+    if (va[j]) w[j] = *reinterpret_cast<const double2m *>(reinterpret_cast<const char *>(a.w) + off8[j]);  // (>= 4 zero doubles behind the last row)
+    w[j].y = vb[j] ? w[j].y : 0.0;
+  }
+  constexpr int ND = T == 4 ? 10 : 6;
+  long long tick[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_mark = a.prof ? wall_clock64() : 0;
+  auto lap = [&](int p) {
+    if (a.prof) {
+      const long long now = wall_clock64();
+      tick[p] += now - t_mark, t_mark = now;
+    }
+  };
+  for (int i = 0; i <= a.k; i += T) {
+    lap(0);  // the update of w
+    double2m q[T][S];
+#pragma unroll
+    for (int v = 0; v < T; ++v) {
+      const bool have = i + v <= a.k;  // (uniform; a vector past the end reads as zeros: its h comes out 0)
+      const char *src = reinterpret_cast<const char *>(a.q[have ? i + v : i]);
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        q[v][j] = double2m{0.0, 0.0};
+        if (have && va[j]) q[v][j] = *reinterpret_cast<const double2m *>(src + off8[j]);
+        q[v][j].y = vb[j] ? q[v][j].y : 0.0;
+      }
+    }
+    // T = 4: <w,q0..3>, <q0,q1>, <q0,q2>, <q0,q3>, <q1,q2>, <q1,q3>, <q2,q3>;  T = 3: <w,q0..2>, <q0,q1>, <q0,q2>, <q1,q2>
+    double d[ND];
+#pragma unroll
+    for (int e = 0; e < ND; ++e) d[e] = 0.0;
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+#pragma unroll
+      for (int v = 0; v < T; ++v) d[v] += w[j].x * q[v][j].x, d[v] += w[j].y * q[v][j].y;
+      int e = T;
+#pragma unroll
+      for (int u = 0; u < T; ++u)
+#pragma unroll
+        for (int v = u + 1; v < T; ++v, ++e) d[e] += q[u][j].x * q[v][j].x, d[e] += q[u][j].y * q[v][j].y;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.prof) __syncthreads();  // (diagnostic: the whole block's rows have landed)
+    lap(1);  // the group's rows (issue -> landed) and the dot products
+    co_allreduce2_n<ND, kQuadWaves>(d, slots, kQuadSlotStride, gave_up, ++seq, lds);
+    lap(2);  // the all-reduce
+    double h[T];
+    {
+      int e = T;  // h_v = <w, q_v> - sum_{u < v} h_u <q_u, q_v>, the pairs (u, v) in the order they were summed
+      double g[T][T];
+#pragma unroll
+      for (int u = 0; u < T; ++u)
+#pragma unroll
+        for (int v = u + 1; v < T; ++v, ++e) g[u][v] = d[e];
+#pragma unroll
+      for (int v = 0; v < T; ++v) {
+        h[v] = d[v];
+#pragma unroll
+        for (int u = 0; u < v; ++u) h[v] -= h[u] * g[u][v];
+      }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      for (int v = 0; v < T && i + v <= a.k; ++v) {
+        if (rotate) hcol[i + v] = h[v];
+        else a.H[(int64_t)(i + v) * a.m + a.k] = h[v];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+#pragma unroll
+      for (int v = 0; v < T; ++v) w[j].x -= h[v] * q[v][j].x, w[j].y -= h[v] * q[v][j].y;
+    }
+  }
+  double acc[1] = {0.0};
+#pragma unroll
+  for (int j = 0; j < S; ++j) acc[0] += w[j].x * w[j].x, acc[0] += w[j].y * w[j].y;
+  co_allreduce2_n<1, kQuadWaves>(acc, slots, kQuadSlotStride, gave_up, ++seq, lds);
+  const double norm2 = acc[0];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *a.norm2_out = norm2;
+  const double hn = sqrt(norm2);
+#pragma unroll
+  for (int j = 0; j < S; ++j) {
+    const double2m o = a.normalise ? double2m{w[j].x / hn, w[j].y / hn} : w[j];
+    if (vb[j]) *reinterpret_cast<double2m *>(reinterpret_cast<char *>(a.w) + off8[j]) = o;
+    else if (va[j]) *reinterpret_cast<double *>(reinterpret_cast<char *>(a.w) + off8[j]) = o.x;
+  }
+  lap(3);  // the tail
+  if (a.prof && threadIdx.x == 0)
+    for (int p = 0; p < 8; ++p) a.prof[blockIdx.x * 8 + p] = tick[p];
+  // SolverGmres.hpp:161, :176-191 and Solver.hpp:132-140, as in mgs_chain_kernel
+  if (rotate && threadIdx.x == 0) {
+    const int k = a.k, m = a.m;
+    *a.givens.hn_slot = hn;
+    hcol[k + 1] = hn;
+    for (int t = 0; t < k; ++t) {
+      const double chi = cs_sh[t] * hcol[t] + sn_sh[t] * hcol[t + 1];
+      hcol[t + 1] = -sn_sh[t] * hcol[t] + cs_sh[t] * hcol[t + 1];
+      hcol[t] = chi;
+    }
+    const double ha = hcol[k], hb = hcol[k + 1];
+    const double rr = hypot(ha, hb);
+    double cs, sn;
+    if (rr > 0.0) cs = ha / rr, sn = hb / rr;
+    else cs = 1.0, sn = 0.0;
+    a.givens.cs[k] = cs, a.givens.sn[k] = sn;
+    hcol[k] = cs * ha + sn * hb;
+    hcol[k + 1] = 0.0;
+    for (int t = 0; t <= k + 1; ++t) a.givens.H[(int64_t)t * m + k] = hcol[t];
+    const double bk = a.givens.beta[k];
+    a.givens.beta[k + 1] = -sn * bk;
+    a.givens.beta[k] = bk * cs;
+    advance(a.givens.st, fabs(-sn * bk));
+  }
+}
+
 // Returns STORM_HIP_OK with *taken = false when the chain does not qualify (too many rows / vectors, a communicator).
 int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w, const double *const *q, int k, int m,
                          double *H, double *norm2_out, bool normalise, bool *taken, const MgsGivens *givens) {
@@ -656,20 +1015,72 @@ int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w
       k + 1 > kMgsMaxVectors || c->opt_profile_spmv != 0)
     return STORM_HIP_OK;
   const int64_t n_slices = (n + kWave - 1) / kWave;
-  const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(std::min(c->num_cus, 256), (n_slices + kLatWaves - 1) / kLatWaves));
+  int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(std::min(c->num_cus, 256), (n_slices + kLatWaves - 1) / kLatWaves));
   const int64_t waves = blocks * kLatWaves;
   const int64_t need = (n_slices + waves - 1) / waves;
-  const void *fn = need <= 1    ? (const void *)mgs_chain_kernel<1>
+  const void *fn = nullptr;
+  size_t dyn_lds = 0;
+  // the LDS-ring chain: two steps per synchronisation point, <= 4 sub-chunks of 2048 rows per block (2 x 64 KiB of ring)
+  const int cus = std::min(c->num_cus, 256);
+  const int64_t subs_total = (n + kMgsSub - 1) / kMgsSub;
+  const int sub = (int)((subs_total + cus - 1) / cus);
+  // (measured, GMRES(30) us per inner iteration, register pairs / LDS ring / triples with the two-level all-reduce:
+  //  32^3 43.0 / 43.5 / 48.3, 64^3 60.5 / 51.1 / 55.2, 128^3 104.5 / 106.3 / 100.0 -- profiles/r04p_gmres_ab.jsonl;
+  //  options coop_mgs_lds / coop_mgs_quad: 0 never, 1 by size, 2 always)
+  if ((c->opt_coop_mgs_lds == 2 || (c->opt_coop_mgs_lds == 1 && n >= ((int64_t)1 << 17))) && c->opt_coop_mgs_pairs != 0 && sub >= 1 && sub <= 4) {
+    const int sv = sub <= 1 ? 1 : sub <= 2 ? 2 : 4;
+    fn = sv == 1 ? (const void *)mgs_chain_lds_kernel<1> : sv == 2 ? (const void *)mgs_chain_lds_kernel<2> : (const void *)mgs_chain_lds_kernel<4>;
+    dyn_lds = sizeof(double) * 2 * (size_t)sv * kMgsSub;
+    static int lds_resident[3] = {-1, -1, -1};
+    int &res = lds_resident[sv == 1 ? 0 : sv == 2 ? 1 : 2];
+    if (res < 0) {
+      res = 0;
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds) == hipSuccess)
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&res, fn, kLatBlock, dyn_lds);
+      (void)hipGetLastError();
+    }
+    if (res >= 1) blocks = (subs_total + sv - 1) / sv;
+    else fn = nullptr, dyn_lds = 0;
+  }
+  // four steps per synchronisation point (blocks of 512 threads, <= 8 pairs of rows per thread): the default
+  unsigned threads = kLatBlock;
+  const int64_t qsubs_total = (n + kQuadSub - 1) / kQuadSub;
+  const int qsub = (int)((qsubs_total + cus - 1) / cus);
+  if ((c->opt_coop_mgs_quad == 2 || (c->opt_coop_mgs_quad == 1 && n >= ((int64_t)1 << 20))) && c->opt_coop_mgs_pairs != 0 && qsub >= 1 && qsub <= 8) {
+    const int sv = qsub <= 1 ? 1 : qsub <= 2 ? 2 : qsub <= 4 ? 4 : 8;
+    // (eight or sixteen rows per thread and FOUR vectors of them do not fit 256 registers beside the all-reduce: three there)
+    const void *qf = sv == 1 ? (const void *)mgs_chain_quad_kernel<1, 4> : sv == 2 ? (const void *)mgs_chain_quad_kernel<2, 4>
+                   : sv == 4 ? (const void *)mgs_chain_quad_kernel<4, 3> : (const void *)mgs_chain_quad_kernel<8, 3>;
+    static int quad_resident[4] = {-1, -1, -1, -1};
+    int &res = quad_resident[sv == 1 ? 0 : sv == 2 ? 1 : sv == 4 ? 2 : 3];
+    if (res < 0) {
+      res = 0;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&res, qf, kQuadThreads, 0);
+      (void)hipGetLastError();
+    }
+    if (res >= 1) {
+      if (c->d_quad_slots == nullptr) {
+        HIP_TRY(hipMalloc((void **)&c->d_quad_slots, (size_t)2 * (256 + 8) * kQuadSlotStride));  // block slots, then group slots
+        HIP_TRY(hipMemsetAsync(c->d_quad_slots, 0, (size_t)2 * (256 + 8) * kQuadSlotStride, c->stream));
+      }
+      fn = qf, dyn_lds = 0, threads = kQuadThreads, blocks = (qsubs_total + sv - 1) / sv;
+    }
+  }
+  const bool lds_chain = fn != nullptr;
+  if (!lds_chain)
+    fn = need <= 1    ? (const void *)mgs_chain_kernel<1>
                    : need <= 2  ? (const void *)mgs_chain_kernel<2>
                    : need <= 4  ? (const void *)mgs_chain_kernel<4>
                    : need <= 8  ? (const void *)mgs_chain_kernel<8>
                    : need <= 16 ? (const void *)mgs_chain_kernel<16>
                                 : nullptr;
   if (fn == nullptr) return STORM_HIP_OK;  // more than 16 slices per wavefront: registers cannot hold w
+  if (!lds_chain) {
   static int resident[5] = {-1, -1, -1, -1, -1};
   const int vi = need <= 1 ? 0 : need <= 2 ? 1 : need <= 4 ? 2 : need <= 8 ? 3 : 4;
   if (resident[vi] < 0) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident[vi], fn, kLatBlock, 0));
   if (resident[vi] < 1) return STORM_HIP_OK;
+  }
   MgsArgs a;
   for (int i = 0; i <= k; ++i) a.q[i] = q[i];
   for (int i = k + 1; i < kMgsMaxVectors; ++i) a.q[i] = q[0];
@@ -681,8 +1092,14 @@ int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w
   a.slots = c->d_lat_slots, a.done = done;
   a.givens = (givens != nullptr && normalise && c->opt_coop_mgs != 2) ? *givens  // (coop_mgs = 2: A/B, rotations by the caller)
                                                                         : MgsGivens{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  a.quad_slots = c->d_quad_slots;
+  a.prof = nullptr;
+  if (c->opt_resident_profile != 0 && lds_chain && k == m - 1) {  // (diagnostic: the longest chain of a cycle)
+    if (c->d_res_prof == nullptr) HIP_TRY(hipMalloc((void **)&c->d_res_prof, sizeof(long long) * 256 * 8));
+    a.prof = c->d_res_prof, c->res_prof_blocks = (int)blocks;
+  }
   void *args[] = {&a};
-  *taken = coop_launch(c, fn, (unsigned)blocks, args);
+  *taken = coop_launch(c, fn, (unsigned)blocks, args, dyn_lds, threads);
   if (!*taken) c->lat_seq -= (unsigned long long)k + 2;
   return STORM_HIP_OK;
 }
@@ -746,7 +1163,7 @@ int lat_check_gave_up(storm_hip_ctx *c) {
 
 // A cooperative launch that may be refused (too many blocks for what is resident, a device that does not take them):
 // false = not launched, nothing ran, the error is cleared.
-static bool coop_launch(storm_hip_ctx *c, const void *fn, unsigned blocks, void **args) {
+static bool coop_launch(storm_hip_ctx *c, const void *fn, unsigned blocks, void **args, size_t dyn_lds, unsigned threads) {
   if (c->opt_coop_force_fail == 1) {
     c->coop_fallback = 1;
     return false;
@@ -756,8 +1173,8 @@ static bool coop_launch(storm_hip_ctx *c, const void *fn, unsigned blocks, void 
   // which holds on a device this process has to itself once the kernel in front has drained -- the runtime's cooperative
   // launch adds no more than that check, but runs on a queue of its own: 12-13 us of idle device in front of the kernel
   // AND in front of the next ordinary one (kernel trace, GMRES(30) at 128^3: two such gaps per inner iteration of 160 us).
-  const hipError_t e = c->opt_coop_plain != 0 ? hipLaunchKernel(fn, dim3(blocks), dim3(kLatBlock), args, 0, c->stream)
-                                              : hipLaunchCooperativeKernel(fn, dim3(blocks), dim3(kLatBlock), args, 0, c->stream);
+  const hipError_t e = c->opt_coop_plain != 0 ? hipLaunchKernel(fn, dim3(blocks), dim3(threads), args, dyn_lds, c->stream)
+                                              : hipLaunchCooperativeKernel(fn, dim3(blocks), dim3(threads), args, (unsigned)dyn_lds, c->stream);
   if (e != hipSuccess) {
     (void)hipGetLastError();
     c->coop_fallback = 1;

@@ -90,12 +90,12 @@ __device__ __forceinline__ void res_allreduce(double (&s)[NV], const ResArgs &A,
     double t = 0.0;
 #pragma unroll
     for (int w = 0; w < kResWaves; ++w) t += lds[threadIdx.x * kResWaves + w];
-    co_store_slot(A.slots + ((size_t)blockIdx.x * 2 + (seq & 1)) * kLatSlotStride + 16 * threadIdx.x, tag, t);
+    co_store_slot(A.slots + lat_slot_offset(blockIdx.x, seq) + 16 * threadIdx.x, tag, t);
   }
 #pragma unroll
   for (int j = 0; j < NV; ++j) v[j] = 0.0;
   if (threadIdx.x < gridDim.x) {  // gridDim.x <= 256: thread t (waves 0 .. 3) watches block t
-    const char *slot = A.slots + ((size_t)threadIdx.x * 2 + (seq & 1)) * kLatSlotStride;
+    const char *slot = A.slots + lat_slot_offset(threadIdx.x, seq);
     const long long t0 = wall_clock64();
     for (int spins = 0;; ++spins) {
       bool ok;

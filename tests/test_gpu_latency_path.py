@@ -225,10 +225,15 @@ def test_cooperative_gram_schmidt_chain_matches_the_kernel_per_step_path(env, sh
     op = api.HipStencilOperator(mat, 1.0, 0.0)
     b_host = 1.0 + 0.25 * np.cos(0.02 * np.arange(g.n_cells))
     runs = {}
-    for coop in (1, 0):
-        for generic in (0, 1):  # the fused loop and the engine share the chain
-            ctx.set_option("coop_mgs", coop)
+    # coop: 0 the kernel-per-step path; 1 the chain the library picks for this size; "reg" / "lds" / "quad": the chain
+    # with its basis vectors through registers (two steps per synchronisation point), landing in an LDS ring by
+    # LDS-DMA (two steps), or three / four steps per point with the two-level all-reduce -- every one of them forced
+    for coop in (1, 0, "reg", "lds", "quad"):
+        for generic in ((0, 1) if coop in (0, 1) else (0,)):  # the fused loop and the engine share the chain
+            ctx.set_option("coop_mgs", 0 if coop == 0 else 1)
             ctx.set_option("coop_mgs_min_rows", 0)
+            ctx.set_option("coop_mgs_lds", {"reg": 0, "lds": 2, "quad": 0}.get(coop, 1))
+            ctx.set_option("coop_mgs_quad", {"reg": 0, "lds": 0, "quad": 2}.get(coop, 1))
             ctx.set_option("generic_solvers", generic)
             s = api.GmresSolver()
             s.num_inner_iterations, s.record_history = m, True
@@ -237,6 +242,8 @@ def test_cooperative_gram_schmidt_chain_matches_the_kernel_per_step_path(env, sh
             runs[(coop, generic)] = (ok, s.iteration, s.history.copy(), x.to_numpy())
     ctx.set_option("coop_mgs", 1)
     ctx.set_option("coop_mgs_min_rows", 0)
+    ctx.set_option("coop_mgs_lds", 1)
+    ctx.set_option("coop_mgs_quad", 1)
     ctx.set_option("generic_solvers", 0)
     ok0, it0, h0, x0 = runs[(0, 0)]
     assert ok0
