@@ -287,14 +287,55 @@ def main() -> int:
     # The driver's `--steps 20` is 6 ms of work: one interval would decide the headline.  The K-step solve is
     # repeated until the timed repeats cover --min-seconds (same count on every rank: the elapsed times are
     # already max-reduced) and the median repeat is reported; `steps` stays K.
+    IPC_KEYS = ("ipc_allreduce_wait_ticks", "ipc_allreduces", "ipc_ack_wait_ticks", "ipc_ack_waits",
+                "ipc_halo_slow_poll_ticks", "ipc_halo_slow_polls")
+
+    def ipc_counters():
+        if world == 1 and not args.force_comm or transport != "ipc":
+            return None
+        try:
+            return {k_: ctx.counter(k_) for k_ in IPC_KEYS}
+        except Exception:
+            return None
+
     repeats = []
+    comm0 = ipc_counters()
     while True:
         e_, s = timed_solve()
         repeats.append(e_)
         if sum(repeats) >= args.min_seconds or len(repeats) >= 2000:
             break
+    comm1 = ipc_counters()
     elapsed = float(np.median(repeats))
     final_residual = s.absolute_error
+    # N > 1: where the communication time of an iteration went, from the device's own clock (peer-window transport: the
+    # kernels time their waits, csrc/ipc_device.hpp IpcDev::stat); the worst rank's numbers are reported
+    comm_breakdown = None
+    if world > 1 or args.force_comm:
+        if comm0 is not None and comm1 is not None:
+            d_ = {k_: comm1[k_] - comm0[k_] for k_ in IPC_KEYS}
+            its_ = max(len(repeats) * K, 1)
+            mine = [d_["ipc_allreduce_wait_ticks"] * 0.01 / its_, d_["ipc_ack_wait_ticks"] * 0.01 / its_,
+                    d_["ipc_halo_slow_poll_ticks"] * 0.01 / max(d_["ipc_halo_slow_polls"], 1), d_["ipc_halo_slow_polls"] / its_]
+            worst = [dist.allreduce_max(v_) for v_ in mine]
+            comm_breakdown = {
+                "transport": "ipc", "iterations_covered": its_,
+                "allreduce_wait_us_per_iteration_worst_rank": worst[0],
+                "allreduces_per_iteration": d_["ipc_allreduces"] / its_,
+                "allreduce_wait_us_each_this_rank": d_["ipc_allreduce_wait_ticks"] * 0.01 / max(d_["ipc_allreduces"], 1),
+                "send_ack_wait_us_per_iteration_worst_rank": worst[1],
+                "halo_values_not_there_at_first_look_per_iteration_worst_rank": worst[3],
+                "halo_late_value_mean_wait_us_worst_rank": worst[2],
+                "note": "all-reduce wait = from a rank's own contribution being stored into every window until every rank's "
+                        "has been read from its own (link latency + the slowest rank's lead); send wait = a sending block "
+                        "waiting for the receivers' acknowledgement of the plane two exchanges back; late halo values = "
+                        "rows of the boundary launch that had to poll (thread-time each); everything else of an iteration "
+                        "is the single-GPU path's kernels (compare ms_per_step with the 1-GPU line)"}
+        else:
+            comm_breakdown = {"transport": transport,
+                              "note": "device-side waits are instrumented on the peer-window transport only; RCCL / host-staged: "
+                                      "compare ms_per_step with the 1-GPU line (tools/comm_path_overhead.py measures the path's "
+                                      "cost at one rank)"}
 
     # ---- N > 1: post-flight.  The timed region ran the production kernels on the production transport; before its
     # number is reported, (1) the fused CG step must agree with the kernel-per-statement loop on the same transport
@@ -599,6 +640,8 @@ def main() -> int:
             out["transport"] = transport
             out["preflight"] = preflight
             out["postflight"] = postflight
+        if comm_breakdown is not None:
+            out["comm_breakdown"] = comm_breakdown
         print(json.dumps(out), flush=True)
     dist.barrier()
     try:  # leave no dangling process group / communicator behind

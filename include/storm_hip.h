@@ -277,7 +277,12 @@ int storm_hip_ctx_set_option(storm_hip_ctx *ctx, const char *key, int64_t value)
  * reference logs one line per solve, Solver.hpp:144-145).  Keys: "resident_solves" (csrc/resident.hip),
  * "latency_solves" (csrc/latency.hip: one cooperative kernel per solve), "throughput_solves" (a kernel per statement,
  * fused loops of csrc/solvers.hip), "engine_solves" (csrc/krylov.hip), "cg_fused_steps" (solves whose CG step rode in
- * the SpMV launch). */
+ * the SpMV launch).  On the peer-window transport, where the time of the exchanges went (ticks of 10 ns of the device's
+ * real-time counter, and counts): "ipc_allreduce_wait_ticks" / "ipc_allreduces" (from a rank's own contribution being
+ * stored to every rank's being read), "ipc_ack_wait_ticks" / "ipc_ack_waits" (a send waiting for the receivers to have
+ * consumed the plane two exchanges back), "ipc_halo_slow_poll_ticks" / "ipc_halo_slow_polls" (halo values that had not
+ * arrived when the boundary rows asked for them; thread-ticks).  With option "resident_profile" = 1:
+ * "resident_phase_mean_<k>" / "resident_phase_max_<k>" (csrc/resident.hip). */
 int storm_hip_ctx_get_counter(storm_hip_ctx *ctx, const char *key, int64_t *value);
 
 /* Halo plan of a row-partitioned operator.  For neighbour q

@@ -37,6 +37,7 @@ struct Comm {
   int64_t win_bytes = 0, seg_bytes = 0;
   std::vector<unsigned long long> pair_epoch;  // [n_ranks] halo exchanges this rank has had with each peer (both sides count alike)
   int *d_error = nullptr, *h_error = nullptr;  // set by a kernel whose wait timed out
+  long long *d_stat = nullptr;          // ipc_device.hpp IpcDev::stat (8 counters, zeroed at init)
   double *pending_x = nullptr;          // generic form of the exchange: the receive half runs in comm_halo_exchange_end
   IpcRecvPlan pending_recv;
 };
@@ -88,6 +89,7 @@ static IpcDev ipc_dev(const storm_hip_ctx *c) {
   w.data_off = w.ctr_off + 256;
   w.seg_bytes = cm->seg_bytes;
   w.error = cm->d_error;
+  w.stat = cm->d_stat;
   return w;
 }
 static int64_t ipc_header_bytes(int64_t P) { return (2 * P * kIpcArSlot + P * 64 + 255) / 256 * 256 + 256; }
@@ -189,6 +191,14 @@ int comm_ipc_recv_copy(const storm_hip_op *op, double *x, const IpcDev &w, const
   return STORM_HIP_OK;
 }
 bool comm_is_ipc(const storm_hip_ctx *c) { return c->comm != nullptr && c->comm->ipc; }
+// The peer-window transport's wait counters (IpcDev::stat), k in [0, 8); -1 when there is no such transport.
+long long comm_ipc_stat(storm_hip_ctx *c, int k) {
+  if (c->comm == nullptr || !c->comm->ipc || c->comm->d_stat == nullptr || k < 0 || k >= 8) return -1;
+  long long v = 0;
+  (void)hipStreamSynchronize(c->stream);
+  if (hipMemcpy(&v, c->comm->d_stat + k, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return v;
+}
 
 int comm_halo_exchange_begin(const storm_hip_op *op, double *x) {
   storm_hip_ctx *c = op->ctx;
@@ -349,6 +359,7 @@ void comm_destroy(storm_hip_ctx *c) {
     (void)hipFree(c->comm->d_win_peer);
     (void)hipFree(c->comm->win_local);
     if (c->comm->h_error) (void)hipHostFree(c->comm->h_error);
+    if (c->comm->d_stat) (void)hipFree(c->comm->d_stat);
   }
   delete c->comm;
   c->comm = nullptr;
@@ -493,6 +504,8 @@ int storm_hip_ctx_comm_init_ipc(storm_hip_ctx *c, const void *handles) {
   HIP_TRY(hipHostMalloc((void **)&cm->h_error, sizeof(int), hipHostMallocMapped));
   *cm->h_error = 0;
   HIP_TRY(hipHostGetDevicePointer((void **)&cm->d_error, cm->h_error, 0));
+  HIP_TRY(hipMalloc((void **)&cm->d_stat, sizeof(long long) * 8));
+  HIP_TRY(hipMemset(cm->d_stat, 0, sizeof(long long) * 8));
   cm->pair_epoch.assign((size_t)c->n_ranks, 0ull);
   cm->ipc = true;
   return STORM_HIP_OK;

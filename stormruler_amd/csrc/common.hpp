@@ -414,6 +414,7 @@ struct IpcSendPlan;
 struct IpcRecvPlan;
 bool comm_ipc_next(storm_hip_ctx *c, IpcDev *w);  // the window view for a kernel that all-reduces itself
 bool comm_is_ipc(const storm_hip_ctx *c);
+long long comm_ipc_stat(storm_hip_ctx *c, int k);
 int comm_ipc_exchange(const storm_hip_op *op, IpcDev *w, IpcSendPlan *sp, IpcRecvPlan *rp);
 int comm_ipc_send(const storm_hip_op *op, const double *x, const IpcDev &w, const IpcSendPlan &sp);
 int comm_ipc_recv_copy(const storm_hip_op *op, double *x, const IpcDev &w, const IpcRecvPlan &rp);

@@ -209,6 +209,18 @@ int storm_hip_ctx_get_counter(storm_hip_ctx *c, const char *key, int64_t *value)
   else if (!strcmp(key, "throughput_solves")) *value = c->n_throughput_solves;
   else if (!strcmp(key, "engine_solves")) *value = c->n_engine_solves;
   else if (!strcmp(key, "cg_fused_steps")) *value = c->n_cg_fused_steps;
+  else if (!strncmp(key, "ipc_", 4)) {
+    // the peer-window transport's device-side waits (csrc/ipc_device.hpp IpcDev::stat): ticks of 10 ns and counts
+    static const char *names[6] = {"ipc_allreduce_wait_ticks", "ipc_allreduces", "ipc_ack_wait_ticks", "ipc_ack_waits",
+                                   "ipc_halo_slow_poll_ticks", "ipc_halo_slow_polls"};
+    int k = -1;
+    for (int i = 0; i < 6; ++i)
+      if (!strcmp(key, names[i])) k = i;
+    STORM_REQUIRE(k >= 0, "ctx_get_counter: unknown key '%s'", key);
+    const long long v = comm_ipc_stat(c, k);
+    STORM_REQUIRE(v >= 0, "ctx_get_counter: '%s' needs the peer-window transport", key);
+    *value = v;
+  }
   else if (!strncmp(key, "resident_phase_max_", 19) || !strncmp(key, "resident_phase_mean_", 20)) {
     // (option resident_profile: ticks of 10 ns that the last resident solve's blocks spent in phase k of their loop)
     const bool mx = key[15] == 'm' && key[16] == 'a';

@@ -34,7 +34,16 @@ struct IpcDev {
   int n_ranks, rank;
   int64_t ar_off, ack_off, ctr_off, data_off, seg_bytes;
   int *error;
+  long long *stat;  // where the time of the exchanges goes (storm_hip_ctx_get_counter "ipc_*"): [0] ticks of the 100 MHz counter spent
+                    // waiting in all-reduces, [1] all-reduces, [2] ticks waiting for acknowledgements before a send, [3] such waits,
+                    // [4] thread-ticks of halo values that were not there at the first look, [5] such values
 };
+__device__ __forceinline__ void ipc_stat_add(const IpcDev &w, int k, long long ticks) {
+  if (w.stat) {
+    __hip_atomic_fetch_add(w.stat + k, ticks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(w.stat + k + 1, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
 typedef unsigned long long ipc_u64x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ ipc_u64x2 ipc_tagged(double v, unsigned long long tag_hi) {
@@ -118,13 +127,17 @@ __device__ inline void ipc_allreduce_block(const IpcDev &w, double *buf, int cou
     ipc_store16(w.peers[q] + my_slot + 16 * j, ipc_tagged(buf[j], tag));
   }
   __syncthreads();  // buf may be overwritten below
+  const long long t_wait = w.stat ? wall_clock64() : 0;
   if ((int)threadIdx.x < count) {
     double sum = 0.0;
     for (int q = 0; q < w.n_ranks; ++q)  // rank order: the same bits everywhere
       sum += ipc_poll_value(w.local + w.ar_off + ((int64_t)par * w.n_ranks + q) * kIpcArSlot + 16 * threadIdx.x, tag, w.error);
     buf[threadIdx.x] = sum;
   }
-  if (threadIdx.x == 0) *ipc_ar_epoch_word(w) = epoch;
+  if (threadIdx.x == 0) {
+    *ipc_ar_epoch_word(w) = epoch;
+    if (w.stat) ipc_stat_add(w, 0, wall_clock64() - t_wait);
+  }
   __syncthreads();
 }
 
@@ -148,12 +161,16 @@ __device__ inline void ipc_allreduce_wave(const IpcDev &w, double (&v)[K], int c
     ipc_store16(w.peers[q] + my_slot + 16 * j, ipc_tagged(mine, tag));
   }
   double sum = 0.0;
+  const long long t_wait = w.stat ? wall_clock64() : 0;
   if (lane < count)
     for (int q = 0; q < w.n_ranks; ++q)
       sum += ipc_poll_value(w.local + w.ar_off + ((int64_t)par * w.n_ranks + q) * kIpcArSlot + 16 * lane, tag, w.error);
 #pragma unroll
   for (int t = 0; t < K; ++t) v[t] = __shfl(sum, t, kWave);
-  if (lane == 0) *ipc_ar_epoch_word(w) = epoch;
+  if (lane == 0) {
+    *ipc_ar_epoch_word(w) = epoch;
+    if (w.stat) ipc_stat_add(w, 0, wall_clock64() - t_wait);
+  }
 }
 
 // ---- halo -------------------------------------------------------------------------------------------------------
@@ -187,10 +204,12 @@ struct IpcRecvPlan {
 // fused CG step: the direction is not in memory yet when its boundary planes must leave).
 __device__ inline void ipc_halo_send_block(const IpcDev &w, const IpcSendPlan &s, const double *__restrict__ x, int b,
                                            const double *__restrict__ r = nullptr, double cb = 0.0) {
+  const long long t_ack = (w.stat && threadIdx.x == 0) ? wall_clock64() : 0;
   if (threadIdx.x < (unsigned)s.n_entries && s.epoch[threadIdx.x] > 2)
     (void)ipc_wait_ge(reinterpret_cast<const unsigned long long *>(w.local + w.ack_off + (int64_t)s.peer[threadIdx.x] * 64),
                       s.epoch[threadIdx.x] - 2, w.error);
   __syncthreads();
+  if (w.stat && threadIdx.x == 0 && b == 0) ipc_stat_add(w, 2, wall_clock64() - t_ack);  // (block 0 of the sending blocks: once per exchange)
   const int total = s.ptr[s.n_entries];
   for (int i = b * kBlock + (int)threadIdx.x; i < total; i += s.n_blocks * kBlock) {
     int q = 0;
@@ -236,8 +255,11 @@ __device__ __forceinline__ void ipc_halo_pair(const IpcDev &w, const IpcRecvPlan
                : "=&v"(wa), "=&v"(wb)
                : "v"(pa), "v"(pb)
                : "memory");
+  const bool slow = (oa && !ipc_tag_ok(wa, ta)) || (ob && !ipc_tag_ok(wb, tb));
+  const long long t_slow = (w.stat && slow) ? wall_clock64() : 0;
   *va = oa ? (ipc_tag_ok(wa, ta) ? ipc_untag(wa) : ipc_poll_value(pa, ta, w.error)) : 0.0;
   *vb = ob ? (ipc_tag_ok(wb, tb) ? ipc_untag(wb) : ipc_poll_value(pb, tb, w.error)) : 0.0;
+  if (w.stat && slow) ipc_stat_add(w, 4, wall_clock64() - t_slow);
 }
 // Every block of a kernel that consumed halo values calls this at its end (all threads): the last block to arrive
 // tells every sender that its plane has been consumed.

@@ -95,6 +95,13 @@ def test_bench_script_multi_rank_path(world, transport):
     assert out["postflight"]["fused_vs_unfused_residual_rel_diff"] <= 1e-9
     assert out["roofline"]["launches_timed"] >= 20 + 1  # one launch per apply, or an interior + a boundary launch
     assert 0.0 < out["roofline"]["frac"] <= 1.0 and out["timing"]["repeats"] >= 1
+    # where the communication time went: the peer-window transport's kernels time their own waits
+    cb = out["comm_breakdown"]
+    assert cb["transport"] == transport
+    if transport == "ipc":
+        assert 1.9 <= cb["allreduces_per_iteration"] <= 2.3  # CG: <p, Ap> and <r, r> (+ the solves' init residuals)
+        assert 0.0 < cb["allreduce_wait_us_per_iteration_worst_rank"] < 1e4
+        assert cb["send_ack_wait_us_per_iteration_worst_rank"] >= 0.0
 
 
 @pytest.mark.parametrize("how", ["exit:1", "hang:0", "wrong", "post:1"])
