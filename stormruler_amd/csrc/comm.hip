@@ -166,6 +166,17 @@ __global__ __launch_bounds__(kBlock) void halo_pack_kernel(int64_t n, const int 
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) buf[i] = x[idx[i]];
 }
 
+// The fused CG step over RCCL: the rows to send are those of the NEW direction p' = r + cb p, which is not in memory
+// yet when its boundary planes must leave -- formed here with the owner's expression (cg_xp_kernel's, the marching
+// kernel's: the same bits), cb from the device slab.
+__global__ __launch_bounds__(kBlock) void halo_pack_direction_kernel(int64_t n, const int *__restrict__ idx,
+                                                                     const double *__restrict__ p, const double *__restrict__ r,
+                                                                     const double *__restrict__ cb, double *__restrict__ buf) {
+  const double beta = *cb;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) buf[i] = __builtin_fma(beta, p[idx[i]], r[idx[i]]);
+}
+
 // One exchange of op's halo on the peer-window transport: the window view and the device plans, with the pair epochs
 // advanced.  The caller enqueues the send (comm_ipc_send, or IpcSendPlan handed to a kernel that sends itself) and the
 // receive (comm_ipc_recv_copy, or IpcRecvPlan handed to the kernel that reads the window and acknowledges).
@@ -258,6 +269,38 @@ int comm_halo_exchange_begin(const storm_hip_op *op, double *x) {
     if (nr > 0)
       NCCL_TRY(ncclRecv(x + op->n_rows + h.recv_ptr[q], (size_t)nr, ncclDouble, h.nbr_rank[q], c->comm->halo,
                         c->comm_stream));
+  }
+  NCCL_TRY(ncclGroupEnd());
+  HIP_TRY(hipEventRecord(c->ev_halo_done, c->comm_stream));
+  return STORM_HIP_OK;
+}
+
+bool comm_is_rccl(const storm_hip_ctx *c) {
+  return c->comm != nullptr && !c->comm->ipc && c->comm->host_exchange == nullptr && c->comm->halo != nullptr;
+}
+
+// The exchange of the fused CG step on the RCCL transport: pack p' = r + cb p of the send rows on the comm stream, send,
+// receive into p_out's halo tail -- while the marching launch forms p' on the owned rows and applies the operator to the
+// interior planes on the compute stream; comm_halo_exchange_end makes the boundary launch wait for it.
+int comm_halo_exchange_begin_direction(const storm_hip_op *op, const double *p, const double *r, const double *cb, double *p_out) {
+  storm_hip_ctx *c = op->ctx;
+  const HaloPlan &h = op->halo;
+  STORM_REQUIRE(comm_is_rccl(c) && h.n_nbrs > 0, "fused exchange: needs the RCCL transport and a halo plan");
+  HIP_TRY(hipEventRecord(c->ev_x_ready, c->stream));  // beta of the ending iteration is in the slab, r and p are complete
+  HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_x_ready, 0));
+  if (h.n_send > 0) {
+    const int64_t need = (h.n_send + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(halo_pack_direction_kernel, dim3((int)(need > 1024 ? 1024 : need)), dim3(kBlock), 0, c->comm_stream, h.n_send,
+                       h.d_send_idx, p, r, cb, h.d_sendbuf);
+    HIP_TRY(hipGetLastError());
+  }
+  NCCL_TRY(ncclGroupStart());
+  for (int q = 0; q < h.n_nbrs; ++q) {
+    const int64_t ns = h.send_ptr[q + 1] - h.send_ptr[q], nr = h.recv_ptr[q + 1] - h.recv_ptr[q];
+    if (ns > 0)
+      NCCL_TRY(ncclSend(h.d_sendbuf + h.send_ptr[q], (size_t)ns, ncclDouble, h.nbr_rank[q], c->comm->halo, c->comm_stream));
+    if (nr > 0)
+      NCCL_TRY(ncclRecv(p_out + op->n_rows + h.recv_ptr[q], (size_t)nr, ncclDouble, h.nbr_rank[q], c->comm->halo, c->comm_stream));
   }
   NCCL_TRY(ncclGroupEnd());
   HIP_TRY(hipEventRecord(c->ev_halo_done, c->comm_stream));

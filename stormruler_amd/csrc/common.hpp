@@ -181,6 +181,7 @@ struct storm_hip_ctx {
   int opt_fused_reduce = 1;             // engine: a reduction is ONE launch (its last block folds the partials and runs the scalar program)
   int opt_latency_cache = 1;            // ... with the wave's operator records held in registers where they fit
   int64_t opt_latency_rows = 1 << 19;   // ... up to this many rows (a compact copy of the operator is kept for it)
+  int64_t opt_rccl_fused = 1;           // RCCL transport: the fused CG step on a partitioned lattice operator (boundary planes of the new direction packed by a small kernel, sent under the marching launch)
   int64_t opt_ipc_fused = 1;            // peer-window transport: the interior launch sends, the boundary launch reads the window (0: stand-alone send / receive-copy kernels)
   int64_t opt_ipc_streams = 2;          // peer-window halo exchange: 2 = on the comm stream beside the interior rows, 1 = on the compute stream around them
   int64_t opt_generic_solvers = 0;  // 1: storm_hip_krylov_solve never takes the fused CG / BiCGStab / GMRES loops (A/B knob)
@@ -407,6 +408,8 @@ int res_solve(bool bicgstab, const storm_hip_op *op, double alpha, double beta, 
 int comm_allreduce_sum(storm_hip_ctx *c, double *d_buf, int count);  // in place, on ctx->stream
 int comm_halo_exchange_begin(const storm_hip_op *op, double *x);      // pack + send/recv on comm stream
 int comm_halo_exchange_end(const storm_hip_op *op);                   // compute stream waits
+bool comm_is_rccl(const storm_hip_ctx *c);
+int comm_halo_exchange_begin_direction(const storm_hip_op *op, const double *p, const double *r, const double *cb, double *p_out);
 void comm_destroy(storm_hip_ctx *c);
 int comm_check_error(storm_hip_ctx *c);  // a bounded wait of the peer-window transport gave up
 struct IpcDev;                            // ipc_device.hpp

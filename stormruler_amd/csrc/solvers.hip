@@ -1069,8 +1069,11 @@ int solve_cg_body(const FusedSolveArgs &args) {
   // streamed by a kernel of their own (cg_xp).  p ping-pongs between two vectors (a tile's old p is another tile's
   // halo).  Two launches + the small first pass per iteration; the last iteration's x update runs behind the loop.
   // (on the peer-window transport too: the marching launch also sends p' of the boundary rows, spmv.hip)
-  const bool fuse_step = c->opt_cg_fuse != 0 && (c->comm == nullptr || ipc) && tick && !tick_spmv && c->opt_fuse_dot != 0 &&
-                         spmv_can_fuse_cg(op);
+  // (on RCCL too, round 4: there the reductions keep their all-reduce between partials and step -- no tickets --, the
+  //  step kernel reads alpha, beta and the iteration counter from the slab exactly as cg_xp_kernel does)
+  const bool rccl = c->comm != nullptr && comm_is_rccl(c);
+  const bool fuse_step = c->opt_cg_fuse != 0 && c->opt_fuse_dot != 0 && spmv_can_fuse_cg(op) &&
+                         (rccl ? true : ((c->comm == nullptr || ipc) && tick && !tick_spmv));
   double *p_alt = nullptr;
   if (fuse_step) p_alt = pool.v[v0 + 3]->d, ++c->n_cg_fused_steps;
   int64_t last_enqueued = -1;

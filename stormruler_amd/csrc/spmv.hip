@@ -1647,8 +1647,10 @@ bool spmv_can_fuse_cg(const storm_hip_op *op) {
   if (op->halo.n_nbrs == 0 && op->d_bnd_pack == nullptr && op->tail_rows == 0 && canon_tile_geometry(op, &T, &nb)) return true;
   // ... or a partitioned (mixed) operator on the peer-window transport, whose boundary launch reads the window itself
   MarchArgs M;
-  return op->halo.n_nbrs > 0 && op->d_bnd_pack != nullptr && op->tail_rows == 0 && comm_is_ipc(op->ctx) &&
-         op->ctx->opt_ipc_fused != 0 && op->n_boundary > 0 && cg_march_geometry(op, &M, &nb, true);
+  // ... or on RCCL: the boundary planes of p' are packed by a small kernel and travel on the comm stream under the march
+  return op->halo.n_nbrs > 0 && op->d_bnd_pack != nullptr && op->tail_rows == 0 &&
+         ((comm_is_ipc(op->ctx) && op->ctx->opt_ipc_fused != 0) || (comm_is_rccl(op->ctx) && op->ctx->opt_rccl_fused != 0)) &&
+         op->n_boundary > 0 && cg_march_geometry(op, &M, &nb, true);
 }
 
 int spmv_grid_blocks(const storm_hip_op *op) {
@@ -1746,8 +1748,12 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
       // boundary rows; the boundary launch then reads p' (owned columns) and the window (halo columns).
       MarchArgs M;
       int nb_march = 0;
-      STORM_REQUIRE(fuse_x && fuse_dot && !accumulate && sd->w == x && cg_march_geometry(op, &M, &nb_march, true),
-                    "spmv: the fused CG step on a partitioned operator needs the peer-window transport and a lattice");
+      const bool over_rccl = !fuse_x && comm_is_rccl(c);
+      STORM_REQUIRE((fuse_x || over_rccl) && fuse_dot && !accumulate && sd->w == x && cg_march_geometry(op, &M, &nb_march, true),
+                    "spmv: the fused CG step on a partitioned operator needs the peer-window or the RCCL transport and a lattice");
+      // RCCL: p' = r + beta p of the rows to send is formed by a small kernel on the comm stream and travels while the march
+      // below runs; the boundary launch waits for the planes (they land in p_out's halo tail)
+      if (over_rccl) STORM_TRY(comm_halo_exchange_begin_direction(op, x, sd->cg.r, sd->cg.cb, sd->cg.p_out));
       const CgFuseArgs cgf{sd->cg.iteration, sd->cg.my_iteration, sd->cg.ca, sd->cg.cb, sd->cg.x, sd->cg.r, sd->cg.p_out};
       const int nb_b = blocks_for(op, op->n_boundary, true);
       STORM_REQUIRE(8 * (int64_t)(nb_march + nb_b) <= c->partials_capacity, "spmv: %d blocks exceed the partials workspace", nb_march + nb_b);
@@ -1766,7 +1772,8 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
       SellArgs A{op->d_pack, op->d_slice_off, op->n_rows, op->uniform_width, 0, op->d_dict, op->dict_size, op->d_offs, op->offs_size, 0};
       A.nt_y = (int)(c->opt_spmv_nt_y != 0);
       const size_t lds = sizeof(double) * 3 * (size_t)(kTileRun + 2 * M.T.a);
-      IpcSendArgs S{fx.w, fx.sp};
+      IpcSendArgs S{};
+      if (fuse_x) S = IpcSendArgs{fx.w, fx.sp};  // (RCCL: no sending blocks in the march)
       // (the march kernel's own dots use w = p' from its registers; DotArgs::w only has to be non-null there)
       if (M.T.a <= kBlock)
         hipExtLaunchKernelGGL((cg_step_march_kernel<1>), dim3(nb_march + S.sp.n_blocks), dim3(kBlock), lds, c->stream, ev0, ev1, 0, A, M,
@@ -1776,8 +1783,10 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
                               alpha, beta, x, y, dot, done, cgf, S);
       HIP_TRY(hipGetLastError());
       dot.block_offset = 4 * nb_march;
-      // the boundary groups: z = A p' from p_out and the window; <p', z> partials behind the march's
-      STORM_TRY(launch_range(op, alpha, beta, sd->cg.p_out, y, op->d_boundary, op->n_boundary, dot, fuse_dot, done, accumulate, &fx));
+      // the boundary groups: z = A p' from p_out and the window (RCCL: p_out's halo tail); <p', z> partials behind the march's
+      if (over_rccl) STORM_TRY(comm_halo_exchange_end(op));
+      STORM_TRY(launch_range(op, alpha, beta, sd->cg.p_out, y, op->d_boundary, op->n_boundary, dot, fuse_dot, done, accumulate,
+                             fuse_x ? &fx : nullptr));
       return STORM_HIP_OK;
     }
     // interior rows overlap the halo exchange running on the comm stream

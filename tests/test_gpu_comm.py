@@ -120,3 +120,54 @@ def test_gmres_cgs2_through_the_comm_path(setup):
     ref = oracle.solve("gmres", oracle.CallbackOperator(loc.n_cells, ref_apply), b_host, num_inner_iterations=15)
     assert abs(s.iteration - ref.iterations) <= max(2, int(0.05 * ref.iterations))
     assert np.linalg.norm(x.to_numpy() - ref.x) <= 5e-6 * np.linalg.norm(ref.x)
+
+
+@pytest.mark.parametrize("shape", [(32, 32, 24), (64, 16, 40)])
+def test_fused_cg_step_over_rccl_gives_the_unfused_iteration(shape):
+    """Round 4: on the RCCL transport too the SpMV launch ends the previous CG iteration (x += alpha p, p' = r + beta p)
+    -- the boundary planes of p' are formed and packed by a small kernel on the comm stream and travel while the
+    marching launch runs the interior planes; the boundary launch waits for them.  Same iteration counts, histories to
+    1e-9 and solutions as the kernel-per-statement loop on the same transport (option rccl_fused = 0), and as the
+    oracle on the periodic operator."""
+    from oracle import oracle
+    from stormruler_amd import api
+
+    loc, send_idx = _periodic_z_local_graph(*shape)
+    ref_op = oracle.StencilOperator(loc, -1.0, 0.05)
+
+    def ref_apply(x_owned):
+        return ref_op.apply(np.concatenate([x_owned, x_owned[send_idx]]))[: loc.n_cells]
+
+    b_host = np.cos(0.05 * np.arange(loc.n_cells)) + 0.3
+    runs = {}
+    for fused in (1, 0):
+        ctx = api.Context(0)
+        ctx.set_option("spmv_canon_tile_min_rows", 0)  # (the lattice kernels on a slab this small)
+        ctx.set_option("rccl_fused", fused)
+        ctx.comm_init(api.Context.comm_unique_id(), 1, 0)
+        mat = api.StencilMatrix.from_face_graph(ctx, loc)
+        mat.set_halo([0], [0, loc.n_halo], send_idx, [0, loc.n_halo])
+        s = api.CgSolver()
+        s.record_history = True
+        b = api.DeviceVector.from_numpy(ctx, b_host, n_halo=loc.n_halo)
+        x = api.DeviceVector(ctx, loc.n_cells, loc.n_halo)
+        before = ctx.counter("cg_fused_steps")
+        assert s.solve(x, b, api.HipStencilOperator(mat, -1.0, 0.05))
+        runs[fused] = (s.iteration, np.array(s.history), x.to_numpy(), ctx.counter("cg_fused_steps") - before)
+        # ... and a solve stopped by the iteration limit (the x update of the last iteration runs behind the loop)
+        s2 = api.CgSolver()
+        s2.num_iterations, s2.absolute_error_tolerance, s2.relative_error_tolerance = 7, 0.0, 0.0
+        x2 = api.DeviceVector(ctx, loc.n_cells, loc.n_halo)
+        s2.solve(x2, b, api.HipStencilOperator(mat, -1.0, 0.05))
+        runs[(fused, "limit")] = (s2.absolute_error, x2.to_numpy())
+        mat.close()
+        ctx.close()
+    assert runs[1][3] == 1 and runs[0][3] == 0
+    assert runs[1][0] == runs[0][0]
+    assert np.allclose(runs[1][1], runs[0][1], rtol=1e-9)
+    assert np.linalg.norm(runs[1][2] - runs[0][2]) <= 1e-10 * np.linalg.norm(runs[0][2])
+    assert np.isclose(runs[(1, "limit")][0], runs[(0, "limit")][0], rtol=1e-10)
+    assert np.linalg.norm(runs[(1, "limit")][1] - runs[(0, "limit")][1]) <= 1e-10 * np.linalg.norm(runs[(0, "limit")][1])
+    ref = oracle.solve("cg", oracle.CallbackOperator(loc.n_cells, ref_apply), b_host)
+    assert abs(runs[1][0] - ref.iterations) <= max(2, int(0.02 * ref.iterations))
+    assert np.linalg.norm(runs[1][2] - ref.x) <= 1e-8 * np.linalg.norm(ref.x)
