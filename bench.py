@@ -24,7 +24,8 @@ Prints ONE JSON line on rank 0.
                     (may exceed the peak: the byte-indexed formats do not move those bytes -- not a bandwidth);
   roofline_general  the same for the fp64-record kernel, where streamed bytes == 8d's algorithmic bytes;
   roofline_permuted_rcm  SURVEY.md 8d's unstructured stress variant: cells renumbered by the seeded permutation,
-                    then reverse Cuthill-McKee; whatever record format that operator gets;
+                    then the library's ordering from the cell centres (round 3: reverse Cuthill-McKee -- the key keeps its
+                    name); whatever record format that operator gets;
   roofline_unstructured  the 256^3 graph with a jittered geometry (no two weights equal => fp64 records, SURVEY 8d's
                     bytes), cells renumbered by the seeded permutation, then the library's ordering: the number a
                     Triangle / TetGen mesh of this size would get;
@@ -441,8 +442,15 @@ def main() -> int:
             g0 = g if perm is None else mesh.structured_box(n)
             perm0 = mesh.random_permutation(N)
             gs = mesh.permute_cells(g0, perm0)
-            order = mesh.rcm_ordering(gs)
-            stress_order = perm0[order]
+            # the library's ordering (storm_hip_order_cells, native + threaded): the lexicographic order of a lattice where
+            # the cell centres form one -- the scrambled box gets its natural order, and the lattice records, back --, the
+            # Z-order curve of the centres otherwise; the jittered variant below is FORCED onto the curve (a Triangle /
+            # TetGen mesh has no lattice to find).  Reverse Cuthill-McKee for comparison: tools/ordering_probe.py
+            t_o = time.time()
+            order, order_kind = mesh.geometric_ordering(gs, "auto")
+            order_m, _ = mesh.geometric_ordering(gs, "morton")
+            t_o = time.time() - t_o
+            stress_order = perm0[order_m]
             t_order = time.time() - tp
             if not args.skip_permuted:
                 gr = mesh.permute_cells(gs, order)
@@ -483,8 +491,10 @@ def main() -> int:
             tp = time.time()
             permuted = stress_variant(gr, None, final_residual)
             permuted["host_seconds_permute_order_build"] = t_order + (time.time() - tp)
-            permuted["ordering"] = ("numpy.random.default_rng(12345).permutation(N), then reverse Cuthill-McKee "
-                                    "(stormruler_amd.mesh.rcm_ordering)")
+            permuted["ordering"] = ("numpy.random.default_rng(12345).permutation(N), then the library's ordering from the cell "
+                                    f"centres (stormruler_amd.mesh.geometric_ordering -> storm_hip_order_cells): {order_kind}")
+            permuted["ordering_kind"] = order_kind
+            permuted["host_seconds_ordering_alone_both_modes"] = t_o
             del gr
         except Exception as e:
             permuted = {"error": repr(e)}
@@ -503,7 +513,8 @@ def main() -> int:
             unstructured["host_seconds_permute_order_build"] = t_order + (time.time() - tp)
             unstructured["geometry"] = ("cell centres displaced by <= 0.2 h per coordinate, face areas scaled by 1 +- 0.1 "
                                         "(numpy.random.default_rng(2024)): all weights distinct")
-            unstructured["ordering"] = "the same seeded permutation, then reverse Cuthill-McKee"
+            unstructured["ordering"] = ("the same seeded permutation, then the Z-order (Morton) curve of the cell centres "
+                                        "(stormruler_amd.mesh.geometric_ordering(mode='morton'))")
             del gu
         except Exception as e:
             unstructured = {"error": repr(e)}
@@ -758,7 +769,8 @@ def record_format_name(st) -> str:
 
 
 def kernel_name(st) -> str:
-    return ("spmv_canon_kernel" if st["paired_rows"] >= 2 else "spmv_pair_kernel" if st["paired_rows"] else
+    return ("cg_step_march_kernel (fused CG step) / spmv_canon_tile_kernel" if st["paired_rows"] >= 2 and st.get("tiled_planes") else
+            "spmv_canon_kernel" if st["paired_rows"] >= 2 else "spmv_pair_kernel" if st["paired_rows"] else
             "spmv_dict_kernel" if st["value_dictionary_size"] and st.get("uniform_width", 1) else
             "spmv_sell_kernel")
 

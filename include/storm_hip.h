@@ -285,6 +285,16 @@ int storm_hip_ctx_set_option(storm_hip_ctx *ctx, const char *key, int64_t value)
  * "resident_phase_mean_<k>" / "resident_phase_max_<k>" (csrc/resident.hip). */
 int storm_hip_ctx_get_counter(storm_hip_ctx *ctx, const char *key, int64_t *value);
 
+/* A cell ordering from geometry: host preprocessing in the role METIS plays in the north star; the reference's hook
+ * is UnstructuredMesh::permute (Mallard/MeshUnstructured.hpp:443-459, 557-612: entities renumbered, adjacency rows keep
+ * their order).  centers: [n_cells][dim] cell centres (CellView::center, Mallard/Mesh.hpp:304-311).  order_out[i] = the
+ * cell that becomes cell i.  mode 0: the lexicographic order of a LATTICE where the centres form a tensor-product
+ * grid (a renumbered structured mesh gets its natural order -- and the lattice record formats -- back), else the
+ * Z-order (Morton) curve of the centres; 1: Morton always; 2: lattice or an error.  *kind_out (nullable): 1 lattice,
+ * 2 Morton.  No device is touched. */
+int storm_hip_order_cells(int32_t dim, int64_t n_cells, const double *centers, int32_t mode, int64_t *order_out,
+                          int32_t *kind_out);
+
 /* Halo plan of a row-partitioned operator.  For neighbour q
  * (rank nbr_rank[q]) the owned rows send_idx[send_ptr[q] .. send_ptr[q+1]) are
  * sent, and the halo rows n_owned + [recv_ptr[q] .. recv_ptr[q+1]) received;

@@ -65,6 +65,8 @@ SIGNATURES = {
     "storm_hip_ctx_sync": (C.c_int, [vp]),
     "storm_hip_ctx_info": (C.c_int, [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), i64p]),
     "storm_hip_ctx_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
+    "storm_hip_order_cells": (C.c_int, [C.c_int32, C.c_int64, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_int64),
+                                        C.POINTER(C.c_int32)]),
     "storm_hip_ctx_get_counter": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_int64)]),
     "storm_hip_ctx_get_spmv_profile": (C.c_int, [vp, i64p, f64p, f64p]),
     "storm_hip_ctx_get_spmv_profile_samples": (C.c_int, [vp, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_int64)]),

@@ -30,6 +30,7 @@ __all__ = [
     "jitter_geometry",
     "tile_ordering",
     "rcm_ordering",
+    "geometric_ordering",
     "permute_cells",
     "face_coefficients",
     "convection_diffusion_weights",
@@ -377,6 +378,27 @@ def rcm_ordering(g: FaceGraph) -> np.ndarray:
                 out[pos:pos + nb.size] = nb
                 pos += nb.size
     return out[::-1].copy()
+
+
+def geometric_ordering(g: FaceGraph, mode: str = "auto") -> Tuple[np.ndarray, str]:
+    """The library's ordering from the cell centres (``storm_hip_order_cells``, native and threaded: 0.3 - 0.5 s at
+    256^3 where scipy's reverse Cuthill-McKee takes 6 - 11 s): ``"auto"`` returns the lexicographic order of a lattice
+    where the centres form a tensor-product grid -- a renumbered structured mesh gets its natural order, and with it
+    the lattice record formats, back -- and the Z-order (Morton) curve of the centres otherwise; ``"morton"`` forces
+    the curve (what a Triangle / TetGen mesh gets).  Returns ``(order, kind)``: new cell ``i`` is old cell ``order[i]``
+    (the argument of ``permute_cells``), ``kind`` is ``"lattice"`` or ``"morton"``.  No device is touched."""
+    import ctypes as C
+
+    from ._lib import check, lib
+
+    n = g.n_cells
+    centers = np.ascontiguousarray(g.center[:n], dtype=np.float64)
+    order = np.empty(n, np.int64)
+    kind = C.c_int32(0)
+    check(lib.storm_hip_order_cells(g.dim, n, centers.ctypes.data_as(C.POINTER(C.c_double)),
+                                    {"auto": 0, "morton": 1, "lattice": 2}[mode],
+                                    order.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(kind)))
+    return order, {1: "lattice", 2: "morton"}.get(kind.value, "none")
 
 
 def permute_cells(g: FaceGraph, perm: np.ndarray) -> FaceGraph:

@@ -202,6 +202,60 @@ def test_in_kernel_reductions_are_reproducible_at_full_size(env, poisson256, kin
     assert np.allclose(runs[0][:k], runs[2][:k], rtol=1e-6 if kind == "cg" else 1e-5)
 
 
+def test_library_ordering_at_256_restores_the_lattice_and_orders_a_jittered_mesh(env, poisson256):
+    """Round 4: the library's ordering from the cell centres (storm_hip_order_cells) at full size.  (i) The scrambled
+    256^3 box gets its natural order back: the operator built from the re-ordered mesh has the natural one's records
+    (format 4, tiled) and applies BITWISE like it.  (ii) The jittered geometry (all weights distinct: fp64 records) on the
+    Z-order curve: P A P^T of the natural order's operator to 1e-13, and the same CG residuals."""
+    api, mesh, ctx = env
+    g, mat = poisson256
+    n = g.n_cells
+    perm = mesh.random_permutation(n)
+    gs = mesh.permute_cells(g, perm)
+    order, kind = mesh.geometric_ordering(gs)
+    assert kind == "lattice" and np.array_equal(perm[order], np.arange(n))
+    gr = mesh.permute_cells(gs, order)
+    del gs
+    matr = api.StencilMatrix.from_face_graph(ctx, gr)
+    st, st0 = matr.stats(), mat.stats()
+    assert st["paired_rows"] == 2 and st["tiled_planes"] == st0["tiled_planes"] and st["record_bytes"] == st0["record_bytes"]
+    x = api.DeviceVector.from_numpy(ctx, np.sin(0.37 * np.arange(n)))
+    y0, y1 = api.DeviceVector(ctx, n), api.DeviceVector(ctx, n)
+    mat.apply(-1.0, 0.0, x, y0), matr.apply(-1.0, 0.0, x, y1)
+    assert np.array_equal(y0.to_numpy(), y1.to_numpy())
+    matr.close()
+    del gr
+    # (ii)
+    gj = mesh.jitter_geometry(g, 1.0 / 256)
+    matj = api.StencilMatrix.from_face_graph(ctx, gj)
+    assert matj.stats()["value_dictionary_size"] == 0 and matj.stats()["paired_rows"] == 0  # fp64 weights + int32 columns
+    gjs = mesh.permute_cells(gj, perm)
+    order_m, kind_m = mesh.geometric_ordering(gjs, "morton")
+    assert kind_m == "morton"
+    gm = mesh.permute_cells(gjs, order_m)
+    del gjs, gj
+    new_to_old = perm[order_m]
+    matm = api.StencilMatrix.from_face_graph(ctx, gm)
+    del gm
+    xh = np.sin(0.37 * np.arange(n))
+    yj, ym = api.DeviceVector(ctx, n), api.DeviceVector(ctx, n)
+    matj.apply(-1.0, 0.0, api.DeviceVector.from_numpy(ctx, xh), yj)
+    matm.apply(-1.0, 0.0, api.DeviceVector.from_numpy(ctx, xh[new_to_old]), ym)
+    y_nat, y_m = yj.to_numpy(), ym.to_numpy()
+    assert np.abs(y_m - y_nat[new_to_old]).max() <= 1e-13 * np.abs(y_nat).max()
+    hist = {}
+    for name, m in (("natural", matj), ("morton", matm)):
+        s = api.CgSolver()
+        s.record_history, s.num_iterations = True, 40
+        s.absolute_error_tolerance = s.relative_error_tolerance = 0.0
+        b, xs = api.DeviceVector(ctx, n), api.DeviceVector(ctx, n)
+        api.fill_with(b, 1.0)
+        s.solve(xs, b, api.HipStencilOperator(m, -1.0, 0.0))
+        hist[name] = np.array(s.history)
+    assert np.allclose(hist["natural"], hist["morton"], rtol=1e-10)
+    matj.close(), matm.close()
+
+
 def test_permuted_rcm_256_is_the_natural_operator_conjugated(env, poisson256):
     """SURVEY.md 8d "unstructured stress variant", full size: P A P^T from the renumbered mesh (whatever record format it
     gets: byte-indexed weights + int32 columns) against A from the natural ordering -- y' = P y to 1e-13, the operator
