@@ -145,7 +145,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-if lib.storm_hip_abi_version() != 3:
+if lib.storm_hip_abi_version() != 4:
     raise ImportError("libstorm_hip.so ABI version mismatch")
 
 
