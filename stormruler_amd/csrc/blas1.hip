@@ -574,13 +574,14 @@ int storm_hip_multi_dot_begin(const storm_hip_vec *a, const storm_hip_vec *const
     ptrs[j] = bs[j]->d;
   }
   storm_hip_ctx *c = a->ctx;
+  // any free slot (requests may be ended in any order: round 3 derived the slot from the tag, so that eight requests
+  // begun and the third ended left "no" slot for the ninth); the request id names its slot
+  int s = -1;
+  for (int i = 0; i < kResultRing && s < 0; ++i)
+    if (c->result_ring[i].tag == 0) s = i;
+  STORM_REQUIRE(s >= 0, "multi_dot_begin: %d reductions in flight already (end one first)", kResultRing);
   const unsigned tag = ++c->result_seq ? c->result_seq : ++c->result_seq;  // never 0 (the words start zeroed)
-  const int s = (int)(tag % kResultRing);
   storm_hip_ctx::ResultSlot &slot = c->result_ring[s];
-  if (slot.tag != 0) {
-    --c->result_seq;
-    STORM_REQUIRE(false, "multi_dot_begin: %d reductions in flight already (end one first)", kResultRing);
-  }
   slot.k = k;
   slot.ready = false;
   // one rank, one launch: the kernel's last block leaves the sums in pinned host memory; _end polls them
@@ -598,16 +599,18 @@ int storm_hip_multi_dot_begin(const storm_hip_vec *a, const storm_hip_vec *const
     slot.ready = true;
   }
   slot.tag = tag;
-  *request = (int)tag;
+  *request = (int)(((tag & 0x0fffffffu) << 3) | (unsigned)s);  // slot in the low three bits, the tag's low 28 above
   return STORM_HIP_OK;
 }
 
 int storm_hip_multi_dot_end(storm_hip_ctx *c, int request, double *out) {
   STORM_REQUIRE(c && out, "multi_dot_end: null argument");
-  const unsigned tag = (unsigned)request;
-  const int s = (int)(tag % kResultRing);
+  static_assert(kResultRing == 8, "a request id carries its slot in three bits");
+  const int s = request & 7;
   storm_hip_ctx::ResultSlot &slot = c->result_ring[s];
-  STORM_REQUIRE(tag != 0 && slot.tag == tag, "multi_dot_end: request %d is not in flight", request);
+  STORM_REQUIRE(request > 0 && slot.tag != 0 && (slot.tag & 0x0fffffffu) == (((unsigned)request >> 3) & 0x0fffffffu),
+                "multi_dot_end: request %d is not in flight", request);
+  const unsigned tag = slot.tag;
   const int k = slot.k;
   slot.tag = 0;
   if (slot.ready) {

@@ -69,9 +69,16 @@ struct SolverState {
   int done;                 // set by the device when converged or out of iterations
   int converged;
   double *history;          // device buffer [num_iterations + 1] or null
-  unsigned long long *done_ring;  // device alias of a pinned host ring: after iteration i (1-based) the word (i << 1 | done) at [(i - 1) % kStateRing]; ring_wait()
+  unsigned long long *done_ring;  // device alias of a pinned host ring: after iteration i (1-based) the word ring_word(gen, i, done) at [(i - 1) % kStateRing]; ring_wait()
   int verify_failed;        // option ticket_verify: an in-kernel (ticketed) reduction disagreed with its two-launch recomputation (sticky)
+  unsigned long long ring_gen;  // this solve's generation (20 bits): every word posted into the ring carries it, so that a kernel of an
+                                // ABORTED solve that posts late cannot be taken for this solve's iteration of the same number (ring_word)
 };
+// The word iteration i (1-based) of generation g posts: g << 44 | i << 1 | done; i = all ones: "done at once" (begin()).
+constexpr unsigned long long kRingIterMask = (1ull << 43) - 1;
+__host__ __device__ inline unsigned long long ring_word(unsigned long long gen, unsigned long long iteration, bool done) {
+  return ((gen & 0xfffffull) << 44) | ((iteration & kRingIterMask) << 1) | (done ? 1ull : 0ull);
+}
 
 struct Comm;  // comm.hip
 
@@ -128,6 +135,7 @@ struct storm_hip_ctx {
   std::vector<hipEvent_t> ev_ring;            // (option poll_events = 1: a marker behind every iteration, the r02 form; created on first use)
   std::vector<storm::KrylovRes> krylov_free;   // krylov.hip: resources of destroyed engines, reused by the next create
   int64_t opt_poll_events = 0;
+  unsigned long long ring_gen = 0;            // generation of the current solve's ring words (state_init draws the next one)
   // options
   int64_t opt_ell_cap = 0;
   int64_t opt_spmv_variant = 0;      // 0 gathers from global (default), 1 + LDS x window
@@ -336,16 +344,15 @@ int vec_create_work_batch(const storm_hip_vec *like, int count, storm_hip_vec **
 // staged device-to-host copy is a launch of its own with ~30 us of idle device in front of it)
 int state_read(storm_hip_ctx *c, const SolverState *d_state, SolverState *h_pinned);
 int state_init(storm_hip_ctx *c, SolverState *d_state, double abs_tol, double rel_tol, long long num_iterations, double *history,
-               unsigned long long *d_ring);
+               unsigned long long *d_ring);  // (draws the solve's generation: storm_hip_ctx::ring_gen)
 
 // context.hip: the host's view of a solve's progress.  The device's step kernels post the verdict of iteration i
 // (1-based) as ONE self-validating word (i << 1 | done) into a pinned ring (solver_device.hpp advance()); the host,
 // `lag` iterations ahead, polls the word -- no marker in the stream: an event recorded behind every iteration is a
 // barrier with a system-scope release between two kernels, 5.9 us per CG iteration at 256^3
 // (profiles/r03t_event_gap.txt).  ring_post / ring_wait: option poll_events = 1 brings the markers back.
-constexpr unsigned long long kRingDoneAtOnce = ~0ull;  // begin(): nothing to iterate, every poll sees it
 int ring_post(storm_hip_ctx *c, std::vector<hipEvent_t> &events, int64_t it);
-int ring_wait(storm_hip_ctx *c, std::vector<hipEvent_t> &events, volatile unsigned long long *ring, int64_t it, bool *stop);
+int ring_wait(storm_hip_ctx *c, std::vector<hipEvent_t> &events, volatile unsigned long long *ring, int64_t it, bool *stop);  // (words of c->ring_gen only)
 
 // spmv.hip
 // y = beta*x + alpha*M x over slices [s0, s1); when dot_w != null also writes

@@ -316,10 +316,13 @@ int ring_post(storm_hip_ctx *c, std::vector<hipEvent_t> &events, int64_t it) {
 int ring_wait(storm_hip_ctx *c, std::vector<hipEvent_t> &events, volatile unsigned long long *ring, int64_t it, bool *stop) {
   volatile unsigned long long *w = ring + it % kStateRing;
   const unsigned long long want = (unsigned long long)(it + 1);
-  auto posted = [&](bool *s) {
+  const unsigned long long gen = c->ring_gen & 0xfffffull;
+  auto posted = [&](bool *s) {  // (a word of another generation -- a late post of an aborted solve -- is not this solve's)
     const unsigned long long v = *w;
-    if (v == kRingDoneAtOnce) return *s = true, true;
-    if ((v >> 1) == want) return *s = (v & 1ull) != 0, true;
+    if ((v >> 44) != gen) return false;
+    const unsigned long long i = (v >> 1) & kRingIterMask;
+    if (i == kRingIterMask) return *s = true, true;  // begin(): nothing to iterate
+    if (i == want) return *s = (v & 1ull) != 0, true;
     return false;
   };
   *stop = false;
@@ -385,14 +388,14 @@ int vec_create_work_batch(const storm_hip_vec *like, int count, storm_hip_vec **
 }
 
 __global__ void state_init_kernel(SolverState *st, double abs_tol, double rel_tol, long long num_iterations, double *history,
-                                  unsigned long long *ring) {
+                                  unsigned long long *ring, unsigned long long gen) {
   for (int i = threadIdx.x; i < kSlab; i += blockDim.x) st->s[i] = 0.0;
   if (threadIdx.x != 0) return;
   st->initial_error = st->absolute_error = st->relative_error = 0.0;
   st->abs_tol = abs_tol, st->rel_tol = rel_tol;
   st->iteration = 0, st->num_iterations = num_iterations;
   st->done = 0, st->converged = 0, st->verify_failed = 0;
-  st->history = history, st->done_ring = ring;
+  st->history = history, st->done_ring = ring, st->ring_gen = gen;
 }
 // (the named fields behind the scalar slab: the host never reads the slab, and 2 KB of 8-byte stores over PCIe cost
 //  ~16 us -- the stepping interface reads the state once per iteration)
@@ -417,7 +420,10 @@ int state_read(storm_hip_ctx *c, const SolverState *d_state, SolverState *h_pinn
 }
 int state_init(storm_hip_ctx *c, SolverState *d_state, double abs_tol, double rel_tol, long long num_iterations, double *history,
                unsigned long long *d_ring) {
-  hipLaunchKernelGGL(state_init_kernel, dim3(1), dim3(kBlock), 0, c->stream, d_state, abs_tol, rel_tol, num_iterations, history, d_ring);
+  c->ring_gen = (c->ring_gen + 1) & 0xfffffull;
+  if (c->ring_gen == 0) c->ring_gen = 1;  // (0: the ring's cleared words)
+  hipLaunchKernelGGL(state_init_kernel, dim3(1), dim3(kBlock), 0, c->stream, d_state, abs_tol, rel_tol, num_iterations, history, d_ring,
+                     c->ring_gen);
   HIP_TRY(hipGetLastError());
   return STORM_HIP_OK;
 }

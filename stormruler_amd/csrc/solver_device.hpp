@@ -25,7 +25,7 @@ __device__ inline void advance(SolverState *st, double abs_err) {
   // names its iteration -- the host needs no event behind the kernel to trust it (common.hpp ring_wait).
   if (st->done_ring)
     __hip_atomic_store(st->done_ring + (st->iteration - 1) % kStateRing,
-                       ((unsigned long long)st->iteration << 1) | (unsigned long long)(st->done != 0), __ATOMIC_RELAXED,
+                       ring_word(st->ring_gen, (unsigned long long)st->iteration, st->done != 0), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -42,7 +42,7 @@ __device__ inline void begin(SolverState *st, double initial_error) {
   if (st->num_iterations <= 0) st->done = 1;
   if (st->done && st->done_ring)  // no iterate() will run: every poll must see it
     for (int i = 0; i < kStateRing; ++i)
-      __hip_atomic_store(st->done_ring + i, kRingDoneAtOnce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(st->done_ring + i, ring_word(st->ring_gen, kRingIterMask, true), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // The device-side state of a GMRES cycle and the Givens update of Hessenberg column k with the beta recurrence

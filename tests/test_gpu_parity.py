@@ -136,6 +136,10 @@ def test_multi_dot_and_multi_axpy(api, ctx, oracle):
     assert _rel_max(a.to_numpy(), ha) <= 1e-13
 
 
+def api_sync(api, vs, j):
+    return api.multi_dot(vs[0], vs[1 + j:2 + j])
+
+
 def test_dots_in_flight(api, ctx, oracle):
     """storm_hip_multi_dot_begin / _end: eight reductions enqueued back to back, awaited out of order, give the sums
     the synchronous call gives (bit for bit: same kernel, same folding order); a ninth is refused, a request is
@@ -155,6 +159,14 @@ def test_dots_in_flight(api, ctx, oracle):
             assert np.abs(got - want).max() <= 1e-10 * max(1.0, np.abs(want).max())
         with pytest.raises(api._lib.StormHipError):
             pend[3].result()
+        # a slot freed in the MIDDLE is taken by the next request (round 3 derived the slot from the tag: eight begun,
+        # the third ended, and the ninth found "no" slot free)
+        pend = [api.PendingDots(vs[0], vs[1 + j:2 + j]) for j in range(8)]
+        assert np.array_equal(pend[2].result(), api_sync(api, vs, 2))
+        ninth = api.PendingDots(vs[0], vs[4:6])
+        assert np.array_equal(ninth.result(), api.multi_dot(vs[0], vs[4:6]))
+        for j in (7, 6, 5, 4, 3, 1, 0):
+            assert np.array_equal(pend[j].result(), api_sync(api, vs, j))
         # the ring is free again; wide requests (k > 8) take the ordinary road inside _begin
         wide = api.PendingDots(vs[0], [vs[1 + (j % 8)] for j in range(19)])
         again = api.PendingDots(vs[0], vs[1:3])
