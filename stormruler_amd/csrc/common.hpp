@@ -151,6 +151,7 @@ struct storm_hip_ctx {
   int64_t opt_spmv_canon_tile_min_rows = (int64_t)1 << 20;  // ... for operators of at least this many rows
   int64_t opt_spmv_canon_tile = 2;   // format 4 on a lattice (offsets -b,-a,-1,+1,+a,+b): tiles of 1024 rows x this many planes (2, or 4) with the +-a / +-1 neighbours from LDS and the +-b ones from registers; 0 = the plain kernel.  Measured at 256^3 (profiles/r03f, r03g): CG step 242 (2 planes) / 247 (4) us per iteration, BiCGStab 496 / 510
   int64_t opt_coop_mgs_pairs = 1;    // cooperative Gram-Schmidt chain: two steps per synchronisation point
+  int64_t opt_coop_dense = 1;        // the multi-step Gram-Schmidt chain's all-reduce with dense value-major slots (0: the two-level form; 2: the resident kernels too)
   int64_t opt_coop_mgs_quad = 1;     // ... FOUR steps per synchronisation point (blocks of 512 threads; <= 2^21 rows)
   char *d_quad_slots = nullptr;      // ... its all-reduce slots (ten values each)
   int64_t opt_coop_mgs_lds = 1;      // ... with the next pair of basis vectors fetched by LDS-DMA into a ring (<= 2^21 rows)

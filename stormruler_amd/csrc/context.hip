@@ -160,6 +160,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "coop_mgs_pairs")) c->opt_coop_mgs_pairs = value;
   else if (!strcmp(key, "coop_mgs_lds")) c->opt_coop_mgs_lds = value;
   else if (!strcmp(key, "coop_mgs_quad")) c->opt_coop_mgs_quad = value;
+  else if (!strcmp(key, "coop_dense")) c->opt_coop_dense = value;
   else if (!strcmp(key, "spmv_mixed")) c->opt_spmv_mixed = value;
   else if (!strcmp(key, "sweep_alternate")) c->opt_sweep_alternate = value;
   else if (!strcmp(key, "spmv_canon_groups")) c->opt_spmv_canon_groups = value;

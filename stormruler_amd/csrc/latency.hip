@@ -534,7 +534,8 @@ struct MgsArgs {
   const int *done;
   MgsGivens givens;  // st == nullptr: the caller applies the rotations
   long long *prof;   // option resident_profile: [gridDim.x][8] ticks per phase of this launch (diagnostic)
-  char *quad_slots;  // mgs_chain_quad_kernel: all-reduce slots of kQuadSlotStride bytes
+  char *quad_slots;  // mgs_chain_quad_kernel: all-reduce slots of kQuadSlotStride bytes (two-level form) / dense granules
+  int dense;         // ... the flat all-reduce with dense value-major slots instead of the two-level one
 };
 template <int S>
 __global__ __launch_bounds__(kLatBlock) void mgs_chain_kernel(MgsArgs a) {
@@ -873,7 +874,7 @@ constexpr int kQuadSlotStride = 256;  // ten values of 16 bytes
 template <int S, int T>  // T = 3 or 4 steps per synchronisation point
 __global__ __launch_bounds__(kQuadThreads) void mgs_chain_quad_kernel(MgsArgs a) {
   if (a.done && *a.done) return;  // (uniform: every block reads the same flag before any of them synchronises)
-  __shared__ double lds[10 * kQuadWaves];
+  __shared__ double lds[10 * 256 + 16];  // co_allreduce_dense: NV x 256 polled values + the NV results
   __shared__ double hcol[kMgsMaxVectors + 1], cs_sh[kMgsMaxVectors], sn_sh[kMgsMaxVectors];
   const bool rotate = a.givens.st != nullptr && blockIdx.x == 0;
   if (rotate && (int)threadIdx.x < a.k) cs_sh[threadIdx.x] = a.givens.cs[threadIdx.x], sn_sh[threadIdx.x] = a.givens.sn[threadIdx.x];
@@ -933,7 +934,8 @@ __global__ __launch_bounds__(kQuadThreads) void mgs_chain_quad_kernel(MgsArgs a)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (a.prof) __syncthreads();  // (diagnostic: the whole block's rows have landed)
     lap(1);  // the group's rows (issue -> landed) and the dot products
-    co_allreduce2_n<ND, kQuadWaves>(d, slots, kQuadSlotStride, gave_up, ++seq, lds);
+    if (a.dense) co_allreduce_dense<ND, kQuadWaves>(d, slots, gave_up, ++seq, lds);
+    else co_allreduce2_n<ND, kQuadWaves>(d, slots, kQuadSlotStride, gave_up, ++seq, lds);
     lap(2);  // the all-reduce
     double h[T];
     {
@@ -965,7 +967,8 @@ __global__ __launch_bounds__(kQuadThreads) void mgs_chain_quad_kernel(MgsArgs a)
   double acc[1] = {0.0};
 #pragma unroll
   for (int j = 0; j < S; ++j) acc[0] += w[j].x * w[j].x, acc[0] += w[j].y * w[j].y;
-  co_allreduce2_n<1, kQuadWaves>(acc, slots, kQuadSlotStride, gave_up, ++seq, lds);
+  if (a.dense) co_allreduce_dense<1, kQuadWaves>(acc, slots, gave_up, ++seq, lds);
+  else co_allreduce2_n<1, kQuadWaves>(acc, slots, kQuadSlotStride, gave_up, ++seq, lds);
   const double norm2 = acc[0];
   if (blockIdx.x == 0 && threadIdx.x == 0) *a.norm2_out = norm2;
   const double hn = sqrt(norm2);
@@ -1025,9 +1028,11 @@ int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w
   const int64_t subs_total = (n + kMgsSub - 1) / kMgsSub;
   const int sub = (int)((subs_total + cus - 1) / cus);
   // (measured, GMRES(30) us per inner iteration, register pairs / LDS ring / triples with the two-level all-reduce:
-  //  32^3 43.0 / 43.5 / 48.3, 64^3 60.5 / 51.1 / 55.2, 128^3 104.5 / 106.3 / 100.0 -- profiles/r04p_gmres_ab.jsonl;
-  //  options coop_mgs_lds / coop_mgs_quad: 0 never, 1 by size, 2 always)
-  if ((c->opt_coop_mgs_lds == 2 || (c->opt_coop_mgs_lds == 1 && n >= ((int64_t)1 << 17))) && c->opt_coop_mgs_pairs != 0 && sub >= 1 && sub <= 4) {
+  //  32^3 43.0 / 43.5 / 48.3, 64^3 60.5 / 51.1 / 55.2, 128^3 104.5 / 106.3 / 100.0 -- profiles/r04p_gmres_chain_ab.jsonl; with the
+  //  dense flat all-reduce the triples / quadruples take 38.9 / 52.6 / 97.2 and are the default wherever they fit;
+  //  options coop_mgs_quad: 0 off, else on; coop_mgs_lds: 0 never, 1 where the quadruples are off, 2 always)
+  if ((c->opt_coop_mgs_lds == 2 || (c->opt_coop_mgs_lds == 1 && c->opt_coop_mgs_quad == 0 && n >= ((int64_t)1 << 17))) && c->opt_coop_mgs_pairs != 0 &&
+      sub >= 1 && sub <= 4) {
     const int sv = sub <= 1 ? 1 : sub <= 2 ? 2 : 4;
     fn = sv == 1 ? (const void *)mgs_chain_lds_kernel<1> : sv == 2 ? (const void *)mgs_chain_lds_kernel<2> : (const void *)mgs_chain_lds_kernel<4>;
     dyn_lds = sizeof(double) * 2 * (size_t)sv * kMgsSub;
@@ -1046,7 +1051,7 @@ int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w
   unsigned threads = kLatBlock;
   const int64_t qsubs_total = (n + kQuadSub - 1) / kQuadSub;
   const int qsub = (int)((qsubs_total + cus - 1) / cus);
-  if ((c->opt_coop_mgs_quad == 2 || (c->opt_coop_mgs_quad == 1 && n >= ((int64_t)1 << 20))) && c->opt_coop_mgs_pairs != 0 && qsub >= 1 && qsub <= 8) {
+  if (c->opt_coop_mgs_quad != 0 && c->opt_coop_mgs_pairs != 0 && qsub >= 1 && qsub <= 8) {
     const int sv = qsub <= 1 ? 1 : qsub <= 2 ? 2 : qsub <= 4 ? 4 : 8;
     // (eight or sixteen rows per thread and FOUR vectors of them do not fit 256 registers beside the all-reduce: three there)
     const void *qf = sv == 1 ? (const void *)mgs_chain_quad_kernel<1, 4> : sv == 2 ? (const void *)mgs_chain_quad_kernel<2, 4>
@@ -1060,8 +1065,9 @@ int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w
     }
     if (res >= 1) {
       if (c->d_quad_slots == nullptr) {
-        HIP_TRY(hipMalloc((void **)&c->d_quad_slots, (size_t)2 * (256 + 8) * kQuadSlotStride));  // block slots, then group slots
-        HIP_TRY(hipMemsetAsync(c->d_quad_slots, 0, (size_t)2 * (256 + 8) * kQuadSlotStride, c->stream));
+        const size_t bytes = std::max((size_t)2 * (256 + 8) * kQuadSlotStride, (size_t)2 * kDenseMaxValues * 256 * 16);  // either form
+        HIP_TRY(hipMalloc((void **)&c->d_quad_slots, bytes));
+        HIP_TRY(hipMemsetAsync(c->d_quad_slots, 0, bytes, c->stream));
       }
       fn = qf, dyn_lds = 0, threads = kQuadThreads, blocks = (qsubs_total + sv - 1) / sv;
     }
@@ -1093,6 +1099,7 @@ int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w
   a.givens = (givens != nullptr && normalise && c->opt_coop_mgs != 2) ? *givens  // (coop_mgs = 2: A/B, rotations by the caller)
                                                                         : MgsGivens{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   a.quad_slots = c->d_quad_slots;
+  a.dense = (int)(c->opt_coop_dense != 0);
   a.prof = nullptr;
   if (c->opt_resident_profile != 0 && lds_chain && k == m - 1) {  // (diagnostic: the longest chain of a cycle)
     if (c->d_res_prof == nullptr) HIP_TRY(hipMalloc((void **)&c->d_res_prof, sizeof(long long) * 256 * 8));

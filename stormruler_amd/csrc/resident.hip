@@ -66,6 +66,7 @@ struct ResArgs {
                        // rows': a wave's pairs of rows go out, and come in, as two runs of 1 KiB (whole lines) instead of 64 half-filled ones
   size_t exch_half;
   char *slots;         // all-reduce slots, kLatSlotStride bytes per (block, parity)
+  char *dense;         // ... or (non-null) dense value-major granules: co_allreduce_dense, coop_device.hpp
   int *gave_up;        // the latency path's flag (lat_check_gave_up)
   long long *prof;     // option resident_profile: [gridDim.x][8] ticks of the 100 MHz counter per phase of the loop, summed over the solve
   unsigned long long *cnt;  // [0] all-reduce sequence number, [1] exchange sequence number: carried from solve to solve
@@ -75,6 +76,10 @@ struct ResArgs {
 // ---- all-reduce over the co-resident grid (latency.hip's scheme for 8 waves per block) --------------------------
 template <int NV>
 __device__ __forceinline__ void res_allreduce(double (&s)[NV], const ResArgs &A, unsigned long long seq, double *lds) {
+  if (A.dense) {  // one 16-byte load per thread and poll, whole lines
+    co_allreduce_dense<NV, kResWaves>(s, A.dense, A.gave_up, seq, lds);
+    return;
+  }
   const unsigned tag = (unsigned)seq;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   double v[NV];
@@ -419,7 +424,7 @@ template <int TZ, bool XREG>
 __global__ __launch_bounds__(kResThreads) void res_cg_kernel(ResArgs A) {
   extern __shared__ __attribute__((aligned(16))) double P[];  // [TZ][a + kResRun + a]
   __shared__ double dict_sh[32];
-  __shared__ double red[2 * kResWaves];
+  __shared__ double red[2 * 256 + 16];  // (co_allreduce_dense: NV x 256 polled values + the results)
   const ResBox B0 = res_box<TZ>(A);
   ResBox B = B0;
   SolverState *st = A.st;
@@ -568,7 +573,7 @@ template <int TZ, bool XLDS>
 __global__ __launch_bounds__(kResThreads) void res_bicgstab_kernel(ResArgs A) {
   extern __shared__ __attribute__((aligned(16))) double P[];  // [TZ][a + kResRun + a] (+ XLDS: [TZ][kResRun], x of the own rows, private to its thread)
   __shared__ double dict_sh[32];
-  __shared__ double red[2 * kResWaves];
+  __shared__ double red[2 * 256 + 16];  // (co_allreduce_dense: NV x 256 polled values + the results)
   const ResBox B0 = res_box<TZ>(A);
   ResBox B = B0;
   SolverState *st = A.st;
@@ -820,8 +825,9 @@ int res_solve(bool bicgstab, const storm_hip_op *op, double alpha, double beta, 
     c->res_exch_rows = op->n_rows + 2;
   }
   if (c->d_res_slots == nullptr) {
-    HIP_TRY(hipMalloc((void **)&c->d_res_slots, (size_t)2 * 256 * kLatSlotStride + 256));
-    HIP_TRY(hipMemsetAsync(c->d_res_slots, 0, (size_t)2 * 256 * kLatSlotStride + 256, c->stream));
+    const size_t bytes = (size_t)2 * 256 * kLatSlotStride + 256 + (size_t)2 * kDenseMaxValues * 256 * 16;  // flat slots, counters, dense granules
+    HIP_TRY(hipMalloc((void **)&c->d_res_slots, bytes));
+    HIP_TRY(hipMemsetAsync(c->d_res_slots, 0, bytes, c->stream));
   }
   ResArgs A{};
   A.pack = op->d_pack, A.dict = op->d_dict, A.a = G.a, A.b = G.b, A.nplanes = G.nplanes, A.nsec = G.nsec, A.n_rows = op->n_rows;
@@ -829,6 +835,10 @@ int res_solve(bool bicgstab, const storm_hip_op *op, double alpha, double beta, 
   A.exch = c->d_res_exch, A.exch_half = (exch_half + 255) / 256 * 256, A.slots = c->d_res_slots;
   A.gave_up = reinterpret_cast<int *>(c->d_lat_slots + (size_t)2 * 256 * kLatSlotStride);
   A.cnt = reinterpret_cast<unsigned long long *>(c->d_res_slots + (size_t)2 * 256 * kLatSlotStride);
+  // (measured A/B, CG us per iteration with the dense form / the 64-byte slots: 64^3 10.0 / 8.9, 128^3 16.9 / 15.8 -- with ONE
+  //  or two values the extra barrier and the trip through LDS cost more than the fewer requests save; the Gram-Schmidt
+  //  chains, six and ten values, are the dense form's case.  coop_dense = 2 forces it here, for that A/B.)
+  A.dense = c->opt_coop_dense == 2 ? c->d_res_slots + (size_t)2 * 256 * kLatSlotStride + 256 : nullptr;
   A.st = d_state;
   A.prof = nullptr;
   if (c->opt_resident_profile != 0) {
