@@ -17,10 +17,6 @@ namespace storm {
 
 
 __device__ __forceinline__ double ld_scal(const Scal &s) { return s.p ? (*s.p) * s.sign : s.v; }
-__device__ __forceinline__ void st2(double2v *p, double2v v, bool nt) {
-  if (nt) __builtin_nontemporal_store(v, p);
-  else *p = v;
-}
 
 // ---- elementwise ---------------------------------------------------------------------
 struct EwPtrs {
@@ -37,6 +33,7 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(int64_t n, EwPtrs p, F f, co
   double2v *__restrict__ y2 = reinterpret_cast<double2v *>(p.y);
   const double2v *__restrict__ a2 = reinterpret_cast<const double2v *>(p.x0);
   const double2v *__restrict__ b2 = reinterpret_cast<const double2v *>(p.x1);
+  nt_dispatch(nt, [&](auto nt) {
   for (int64_t base = (int64_t)bx * (kBlock * kUnroll) + threadIdx.x; base < n2;
        base += (int64_t)gridDim.x * (kBlock * kUnroll)) {
     double2v vy[kUnroll], va[kUnroll], vb[kUnroll];
@@ -60,6 +57,7 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(int64_t n, EwPtrs p, F f, co
       }
     }
   }
+  });
   if ((n & 1) && bx == 0 && threadIdx.x == 0) {
     const int64_t i = n - 1;
     const double vy = F::reads_y ? p.y[i] : 0.0;
@@ -141,7 +139,7 @@ template <class F>
 static int launch_ew(storm_hip_ctx *c, int64_t n, EwPtrs p, F f, const int *done) {
   if (n <= 0) return STORM_HIP_OK;
   hipLaunchKernelGGL(ew_kernel<F>, dim3(stream_blocks(n)), dim3(kBlock), 0, c->stream, n, p, f, done,
-                     (int)(c->opt_blas1_nt != 0), c->stream_reverse);
+                     stream_nt(c, n), c->stream_reverse);
   HIP_TRY(hipGetLastError());
   return STORM_HIP_OK;
 }
@@ -172,6 +170,7 @@ __global__ __launch_bounds__(kBlock) void lin3_kernel(int64_t n, double *y, cons
   double2v *y2 = reinterpret_cast<double2v *>(y);
   const double2v *r2 = reinterpret_cast<const double2v *>(r), *x2 = reinterpret_cast<const double2v *>(x),
                  *z2 = reinterpret_cast<const double2v *>(z);
+  nt_dispatch(nt, [&](auto nt) {
   for (int64_t base = (int64_t)blockIdx.x * (kBlock * kUnroll) + threadIdx.x; base < n2;
        base += (int64_t)gridDim.x * (kBlock * kUnroll)) {
     double2v vr[kUnroll], vx[kUnroll], vz[kUnroll];
@@ -186,6 +185,7 @@ __global__ __launch_bounds__(kBlock) void lin3_kernel(int64_t n, double *y, cons
       if (i < n2) st2(y2 + i, vr[u] + s * (a * vx[u] + b * vz[u]), nt);
     }
   }
+  });
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = r[n - 1] + s * (a * x[n - 1] + b * z[n - 1]);
 }
 
@@ -304,7 +304,7 @@ int k_multi_dot_partials(storm_hip_ctx *c, const double *a, const double *const 
   STORM_REQUIRE(k >= 1 && k <= kMaxMulti, "multi_dot: k = %d outside [1, %d]", k, kMaxMulti);
   int nb = stream_blocks(n);
   if ((int64_t)nb * k > c->partials_capacity) nb = (int)(c->partials_capacity / k);  // grid-stride covers the rest
-  const int nt = (int)(c->opt_blas1_nt != 0) | (c->stream_reverse << 1);
+  const int nt = stream_nt(c, n) | (c->stream_reverse << 1);
   for (int j0 = 0; j0 < k; j0 += kDotChunk) {
     const int kb = (k - j0) < kDotChunk ? (k - j0) : kDotChunk;
     DotPtrs ptrs;
@@ -338,7 +338,7 @@ static int k_multi_dot_host(storm_hip_ctx *c, const double *a, const double *con
   if (c->opt_ticket_reduce != 0 && k <= kDotChunk && n > 0) {  // one launch: partials, tickets, the sums
     int nbt = stream_blocks(n);
     if ((int64_t)nbt * k > c->partials_capacity) nbt = (int)(c->partials_capacity / k);
-    const int nt = (int)(c->opt_blas1_nt != 0) | (c->stream_reverse << 1);
+    const int nt = stream_nt(c, n) | (c->stream_reverse << 1);
     DotPtrs ptrs;
     for (int j = 0; j < kDotChunk; ++j) ptrs.b[j] = bs[j < k ? j : 0];
     const TicketArgs t{c->d_tickets, c->d_partials, c->d_ticket_sums};
@@ -369,7 +369,7 @@ int k_dot_partials(storm_hip_ctx *c, const double *a, const double *b, int64_t n
   DotPtrs ptrs;
   for (int j = 0; j < kDotChunk; ++j) ptrs.b[j] = b;
   hipLaunchKernelGGL(multi_dot_kernel<1>, dim3(nb), dim3(kBlock), 0, c->stream, n, a, ptrs, partials, done,
-                     (int)(c->opt_blas1_nt != 0));
+                     stream_nt(c, n));
   HIP_TRY(hipGetLastError());
   return STORM_HIP_OK;
 }
@@ -393,6 +393,7 @@ __global__ __launch_bounds__(kBlock) void multi_axpy_kernel(int64_t n, double *_
   const int64_t n2 = n >> 1;
   double2v *__restrict__ y2 = reinterpret_cast<double2v *>(y);
   constexpr int U = KB <= 2 ? kUnroll : (KB <= 4 ? 2 : 1);
+  nt_dispatch(nt, [&](auto nt) {
   for (int64_t base = (int64_t)blockIdx.x * (kBlock * kUnroll) + threadIdx.x; base < n2;
        base += (int64_t)gridDim.x * (kBlock * kUnroll)) {
 #pragma unroll
@@ -421,6 +422,7 @@ __global__ __launch_bounds__(kBlock) void multi_axpy_kernel(int64_t n, double *_
       }
     }
   }
+  });
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     double vy = y[n - 1];
 #pragma unroll
@@ -433,7 +435,7 @@ static int multi_axpy_impl(storm_hip_ctx *c, double *y, const double *h_coef, co
                            double sign, const double *const *xs, int k, int64_t n, const int *done) {
   if (n <= 0 || k <= 0) return STORM_HIP_OK;
   const dim3 g(stream_blocks(n)), b(kBlock);
-  const int nt = (int)(c->opt_blas1_nt != 0);
+  const int nt = stream_nt(c, n);
   for (int j0 = 0; j0 < k; j0 += kAxpyChunk) {
     const int kb = (k - j0) < kAxpyChunk ? (k - j0) : kAxpyChunk;
     AxpyArgs a;
@@ -532,7 +534,7 @@ int storm_hip_lin3(storm_hip_vec *y, const storm_hip_vec *r, double s, double a,
   if (y->n_owned <= 0) return STORM_HIP_OK;
   storm_hip_ctx *c = y->ctx;
   hipLaunchKernelGGL(lin3_kernel, dim3(stream_blocks(y->n_owned)), dim3(kBlock), 0, c->stream, y->n_owned, y->d,
-                     r->d, s, a, x->d, b, z->d, c->api_done, (int)(c->opt_blas1_nt != 0));
+                     r->d, s, a, x->d, b, z->d, c->api_done, stream_nt(c, y->n_owned));
   HIP_TRY(hipGetLastError());
   return STORM_HIP_OK;
 }

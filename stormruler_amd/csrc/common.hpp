@@ -150,6 +150,7 @@ struct storm_hip_ctx {
   int64_t opt_spmv_tile_lds_pad = 0;   // A/B knob: extra dynamic LDS per block of the tiled kernel (fewer resident tiles per CU)
   int64_t opt_spmv_canon_tile_min_rows = (int64_t)1 << 20;  // ... for operators of at least this many rows
   int64_t opt_spmv_canon_tile = 2;   // format 4 on a lattice (offsets -b,-a,-1,+1,+a,+b): tiles of 1024 rows x this many planes (2, or 4) with the +-a / +-1 neighbours from LDS and the +-b ones from registers; 0 = the plain kernel.  Measured at 256^3 (profiles/r03f, r03g): CG step 242 (2 planes) / 247 (4) us per iteration, BiCGStab 496 / 510
+  int64_t opt_mgs_steps = 4;          // throughput-path Gram-Schmidt: steps per pass over w (2: mgs_pair_kernel; 3, 4: mgs_multi_kernel)
   int64_t opt_coop_mgs_pairs = 1;    // cooperative Gram-Schmidt chain: two steps per synchronisation point
   int64_t opt_coop_dense = 1;        // the multi-step Gram-Schmidt chain's all-reduce with dense value-major slots (0: the two-level form; 2: the resident kernels too)
   int64_t opt_coop_mgs_quad = 1;     // ... FOUR steps per synchronisation point (blocks of 512 threads; <= 2^21 rows)
@@ -158,7 +159,8 @@ struct storm_hip_ctx {
   int64_t opt_spmv_mixed = 1;        // partitioned operators: format 4 for the groups that read no halo column, format 3 for the rest
   int64_t opt_spmv_nt_y = 1;         // format-4 kernel: store y non-temporally (A/B knob)
   int64_t opt_profile_spmv = 0;
-  int64_t opt_blas1_nt = 1;  // non-temporal loads/stores in the streaming kernels
+  int64_t opt_blas1_nt = 1;  // non-temporal loads/stores in the streaming kernels: 0 never, 1 for vectors of at least blas1_nt_rows rows, 2 always
+  int64_t opt_blas1_nt_rows = (int64_t)6 << 20;  // (48 MiB per vector: beyond, a solver's vectors no longer stay in the 256 MiB Infinity Cache between kernels)
   int64_t opt_graph = 0;     // replay CG / BiCGStab iterations from a captured hipGraph: measured slower than eager launches (profiles/r01_notes.md), off
   int64_t opt_fuse_mgs = 1;  // GMRES/MGS on one rank, <= 2048 blocks: each step folds the previous step's partials itself (no final-reduction launch in between)
   int64_t opt_coop_mgs_min_rows = 0;  // ... from this many rows on (0: always; with two steps per synchronisation point the chain is no slower than a launch per step even on small meshes)
@@ -308,6 +310,11 @@ static inline int stream_blocks(int64_t n) {
   if (b < 1) b = 1;
   if (b > kMaxStreamBlocks) b = kMaxStreamBlocks;
   return (int)b;
+}
+
+// Non-temporal accesses for a streaming kernel over n rows?  (blas1_device.hpp: nt_dispatch)
+static inline int stream_nt(const storm_hip_ctx *c, int64_t n) {
+  return (c->opt_blas1_nt == 2 || (c->opt_blas1_nt == 1 && n >= c->opt_blas1_nt_rows)) ? 1 : 0;
 }
 
 // blas1.hip -- all asynchronous on ctx->stream, owned rows only.

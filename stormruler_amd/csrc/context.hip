@@ -56,7 +56,7 @@ int storm_hip_ctx_create(int device_id, storm_hip_ctx **out) {
   HIP_TRY(hipEventCreateWithFlags(&c->ev_halo_done, hipEventDisableTiming));
   HIP_TRY(hipEventCreate(&c->ev_t0));
   HIP_TRY(hipEventCreate(&c->ev_t1));
-  c->partials_capacity = (int64_t)kMaxReduceBlocks * kMaxMulti;
+  c->partials_capacity = (int64_t)kMaxReduceBlocks * kMaxMulti * 2;  // (2 MiB; the widest user: ten sums x 16 384 blocks of mgs_multi_kernel)
   HIP_TRY(hipMalloc(&c->d_partials, sizeof(double) * (size_t)c->partials_capacity));
   HIP_TRY(hipMalloc(&c->d_partials2, sizeof(double) * kMaxMulti * kStage2));
   HIP_TRY(hipMalloc(&c->d_scalars, sizeof(double) * kMaxMulti));
@@ -158,6 +158,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "coop_mgs")) c->opt_coop_mgs = value;
   else if (!strcmp(key, "coop_mgs_min_rows")) c->opt_coop_mgs_min_rows = value;
   else if (!strcmp(key, "coop_mgs_pairs")) c->opt_coop_mgs_pairs = value;
+  else if (!strcmp(key, "mgs_steps")) c->opt_mgs_steps = value;
   else if (!strcmp(key, "coop_mgs_lds")) c->opt_coop_mgs_lds = value;
   else if (!strcmp(key, "coop_mgs_quad")) c->opt_coop_mgs_quad = value;
   else if (!strcmp(key, "coop_dense")) c->opt_coop_dense = value;
@@ -200,6 +201,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "fuse_mgs")) c->opt_fuse_mgs = value;
   else if (!strcmp(key, "graph")) c->opt_graph = value;
   else if (!strcmp(key, "blas1_nt")) c->opt_blas1_nt = value;
+  else if (!strcmp(key, "blas1_nt_rows")) c->opt_blas1_nt_rows = value;
   else STORM_FAIL(STORM_HIP_E_INVALID, "ctx_set_option: unknown key '%s'", key);
   return STORM_HIP_OK;
 }

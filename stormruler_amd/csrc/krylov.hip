@@ -241,12 +241,6 @@ __global__ __launch_bounds__(kBlock) void dots_prog_kernel(int64_t n, const doub
 }
 
 // ---- vector statements ------------------------------------------------------------------------------------
-typedef double double2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ double2v ldv(const double2v *p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
-__device__ __forceinline__ void stv(double2v *p, double2v v, bool nt) {
-  if (nt) __builtin_nontemporal_store(v, p);
-  else *p = v;
-}
 __device__ __forceinline__ double ld_coef(const Scal &s) { return s.p ? (*s.p) * s.sign : s.v; }
 
 struct LinArgs {
@@ -278,6 +272,7 @@ __global__ __launch_bounds__(kBlock) void lin_kernel(int64_t n, LinArgs a, const
   const int64_t n2 = n >> 1;
   double2v *y2 = reinterpret_cast<double2v *>(a.y);
   constexpr int U = lin_unroll(NT);
+  nt_dispatch(nt, [&](auto nt) {
   for (int64_t base = (int64_t)bx * (kBlock * U) + threadIdx.x; base < n2;
        base += (int64_t)gridDim.x * (kBlock * U)) {
     double2v v[U][NT];
@@ -305,6 +300,7 @@ __global__ __launch_bounds__(kBlock) void lin_kernel(int64_t n, LinArgs a, const
       }
     }
   }
+  });
   if ((n & 1) && bx == 0 && threadIdx.x == 0) {
     const int64_t i = n - 1;
     double o;
@@ -342,6 +338,7 @@ __global__ __launch_bounds__(kBlock) void lin2_kernel(int64_t n, LinArgs a1, Lin
   for (int t = 0; t < NT2; ++t) c2[t] = ld_coef(a2.c[t]), from1[t] = run1 && a2.v[t] == a1.y;
   const int64_t n2 = n >> 1;
   double2v *y1 = reinterpret_cast<double2v *>(a1.y), *y2 = reinterpret_cast<double2v *>(a2.y);
+  nt_dispatch(nt, [&](auto nt) {
   for (int64_t i = (int64_t)bx * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
     double2v v1[NT1], v2[NT2];
 #pragma unroll
@@ -357,6 +354,7 @@ __global__ __launch_bounds__(kBlock) void lin2_kernel(int64_t n, LinArgs a1, Lin
     if (run1) stv(y1 + i, o1, nt);
     if (run2) stv(y2 + i, o2, nt);
   }
+  });
   if ((n & 1) && bx == 0 && threadIdx.x == 0) {
     const int64_t i = n - 1;
     double w1[NT1], w2[NT2];
@@ -387,6 +385,7 @@ __device__ __forceinline__ void lin_dot_body(int64_t n, const LinArgs &a, const 
   double2v *y2 = reinterpret_cast<double2v *>(a.y);
   const double2v *w2 = reinterpret_cast<const double2v *>(w);
   constexpr int U = lin_unroll(NT + (HASW ? 1 : 0));
+  nt_dispatch(nt, [&](auto nt) {
   for (int64_t base = (int64_t)bx * (kBlock * U) + threadIdx.x; base < n2;
        base += (int64_t)gridDim.x * (kBlock * U)) {
     double2v v[U][NT], vw[U];
@@ -413,6 +412,7 @@ __device__ __forceinline__ void lin_dot_body(int64_t n, const LinArgs &a, const 
       }
     }
   }
+  });
   if ((n & 1) && bx == 0 && threadIdx.x == 0) {
     const int64_t i = n - 1;
     double o = c[0] * a.v[0][i];
@@ -467,24 +467,24 @@ __global__ __launch_bounds__(kBlock) void vmul_dots_prog_kernel(int64_t n, doubl
   if (done && *done) return;
   __shared__ double lds4[4];
   const unsigned bx = sweep_block(nt);
-  const bool ntl = nt & 1;
   const int64_t n2 = n >> 1;
   double2v *z2 = reinterpret_cast<double2v *>(z);
   const double2v *d2 = reinterpret_cast<const double2v *>(d), *r2 = reinterpret_cast<const double2v *>(r);
   double acc_rz = 0.0, acc_rr = 0.0;
+  nt_dispatch(nt, [&](auto nt) {
   for (int64_t base = (int64_t)bx * (kBlock * kUnroll) + threadIdx.x; base < n2; base += (int64_t)gridDim.x * (kBlock * kUnroll)) {
     double2v vd[kUnroll], vr[kUnroll];
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       const int64_t i = base + u * kBlock;
-      if (i < n2) vd[u] = ldv(d2 + i, ntl), vr[u] = ldv(r2 + i, ntl);
+      if (i < n2) vd[u] = ldv(d2 + i, nt), vr[u] = ldv(r2 + i, nt);
     }
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       const int64_t i = base + u * kBlock;
       if (i < n2) {
         const double2v vz = vd[u] * vr[u];
-        stv(z2 + i, vz, ntl);
+        stv(z2 + i, vz, nt);
         acc_rz += vr[u].x * vz.x;
         acc_rz += vr[u].y * vz.y;
         acc_rr += vr[u].x * vr[u].x;
@@ -492,6 +492,7 @@ __global__ __launch_bounds__(kBlock) void vmul_dots_prog_kernel(int64_t n, doubl
       }
     }
   }
+  });
   if ((n & 1) && bx == 0 && threadIdx.x == 0) {
     const double vz = d[n - 1] * r[n - 1];
     z[n - 1] = vz;
@@ -512,7 +513,6 @@ __global__ __launch_bounds__(kBlock) void lin2_dot_prog_kernel(int64_t n, LinArg
   if (done && *done) return;
   __shared__ double lds4[4];
   const unsigned bx = sweep_block(nt);
-  const bool ntl = nt & 1;
   double c1[NT1], c2[NT2];
   bool from1[NT2];
 #pragma unroll
@@ -527,6 +527,7 @@ __global__ __launch_bounds__(kBlock) void lin2_dot_prog_kernel(int64_t n, LinArg
   // (the rows of a block and the order of a thread's terms are those of lin_dot_body for the second statement: the
   //  partial sums -- and the reduction's bits -- do not depend on whether a held-back statement rode along)
   constexpr int U = lin_unroll(NT2 + (HASW ? 1 : 0));
+  nt_dispatch(nt, [&](auto nt) {
   for (int64_t base = (int64_t)bx * (kBlock * U) + threadIdx.x; base < n2; base += (int64_t)gridDim.x * (kBlock * U)) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -534,18 +535,18 @@ __global__ __launch_bounds__(kBlock) void lin2_dot_prog_kernel(int64_t n, LinArg
       if (i < n2) {
         double2v v1[NT1], v2[NT2], vw = {0.0, 0.0};
 #pragma unroll
-        for (int t = 0; t < NT1; ++t) v1[t] = ldv(reinterpret_cast<const double2v *>(a1.v[t]) + i, ntl);
+        for (int t = 0; t < NT1; ++t) v1[t] = ldv(reinterpret_cast<const double2v *>(a1.v[t]) + i, nt);
 #pragma unroll
-        for (int t = 0; t < NT2; ++t) v2[t] = ldv(reinterpret_cast<const double2v *>(a2.v[t]) + i, ntl);
-        if (w) vw = ldv(w2 + i, ntl);
+        for (int t = 0; t < NT2; ++t) v2[t] = ldv(reinterpret_cast<const double2v *>(a2.v[t]) + i, nt);
+        if (w) vw = ldv(w2 + i, nt);
         double2v o1 = c1[0] * v1[0];
 #pragma unroll
         for (int t = 1; t < NT1; ++t) o1 = fma2(c1[t], v1[t], o1);
         double2v o2 = c2[0] * (from1[0] ? o1 : v2[0]);
 #pragma unroll
         for (int t = 1; t < NT2; ++t) o2 = fma2(c2[t], from1[t] ? o1 : v2[t], o2);
-        stv(y1 + i, o1, ntl);
-        stv(y2 + i, o2, ntl);
+        stv(y1 + i, o1, nt);
+        stv(y2 + i, o2, nt);
         if (w_from1) vw = o1;
         acc_yy += o2.x * o2.x;
         acc_yy += o2.y * o2.y;
@@ -553,6 +554,7 @@ __global__ __launch_bounds__(kBlock) void lin2_dot_prog_kernel(int64_t n, LinArg
       }
     }
   }
+  });
   if ((n & 1) && bx == 0 && threadIdx.x == 0) {
     const int64_t i = n - 1;
     double w1[NT1], w2v[NT2];
@@ -662,7 +664,7 @@ struct KrylovEngine {
   // rows where the previous one stopped -- what the Infinity Cache still holds.  Same rows and slots per block.
   int sweep_dir = 1;
   int flip() { return (c->opt_sweep_alternate != 0) ? (sweep_dir ^= 1) : 0; }
-  int stream_flags() { return (int)(c->opt_blas1_nt != 0) | (flip() << 1); }
+  int stream_flags() { return stream_nt(c, n) | (flip() << 1); }
   // per-method vectors and registers
   V p = nullptr, q = nullptr, r = nullptr, rt = nullptr, t = nullptr, u = nullptr, v = nullptr, y = nullptr, z = nullptr,
     d = nullptr, s_ = nullptr;

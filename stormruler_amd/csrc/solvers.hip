@@ -18,6 +18,8 @@
 #include <cstring>
 
 #include "common.hpp"
+#include "blas1_device.hpp"
+#include "wave_device.hpp"
 #include "solver_device.hpp"
 #include "ticket_device.hpp"
 #include "ipc_device.hpp"
@@ -186,12 +188,6 @@ __global__ void step_kernel(int step, SolverState *st, GmresDev g, bool force) {
 
 // ---- fused vector kernels ------------------------------------------------------------------------
 // Same streaming shape as blas1.hip: one trip per thread, kUnroll x 16 bytes per stream in flight.
-typedef double double2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ double2v ldv(const double2v *p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
-__device__ __forceinline__ void stv(double2v *p, double2v v, bool nt) {
-  if (nt) __builtin_nontemporal_store(v, p);
-  else *p = v;
-}
 static inline int vec_blocks(const storm_hip_ctx *, int64_t n) { return stream_blocks(n); }
 
 #define STORM_STREAM_FOR(base, n2) \
@@ -209,6 +205,7 @@ __global__ __launch_bounds__(kBlock) void init_residual_kernel(int64_t n, double
   const int64_t n2 = n >> 1;
   double2v *r2 = reinterpret_cast<double2v *>(r), *c2 = reinterpret_cast<double2v *>(copy_to);
   const double2v *b2 = reinterpret_cast<const double2v *>(b);
+  nt_dispatch(nt, [&](auto nt) {
   STORM_STREAM_FOR(base, n2) {
     double2v vb[kUnroll], vr[kUnroll];
 #pragma unroll
@@ -228,6 +225,7 @@ __global__ __launch_bounds__(kBlock) void init_residual_kernel(int64_t n, double
       }
     }
   }
+  });
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const double v = b[n - 1] - r[n - 1];
     r[n - 1] = v;
@@ -272,6 +270,7 @@ __global__ __launch_bounds__(kBlock) void cg_r_kernel(int64_t n, SolverState *st
   const int64_t n2 = n >> 1;
   double2v *r2 = reinterpret_cast<double2v *>(r);
   const double2v *z2 = reinterpret_cast<const double2v *>(z);
+  nt_dispatch(nt, [&](auto nt) {
   for (int64_t base = (int64_t)bx * (kBlock * kUnroll) + threadIdx.x; base < n2;
        base += (int64_t)gridDim.x * (kBlock * kUnroll)) {
     double2v vr[kUnroll], vz[kUnroll];
@@ -291,6 +290,7 @@ __global__ __launch_bounds__(kBlock) void cg_r_kernel(int64_t n, SolverState *st
       }
     }
   }
+  });
   if ((n & 1) && bx == 0 && threadIdx.x == 0) {
     const double vr = r[n - 1] - alpha * z[n - 1];
     r[n - 1] = vr;
@@ -329,6 +329,7 @@ __global__ __launch_bounds__(kBlock) void cg_xp_kernel(int64_t n, const SolverSt
   const int64_t n2 = n >> 1;
   double2v *x2 = reinterpret_cast<double2v *>(x), *p2 = reinterpret_cast<double2v *>(p);
   const double2v *r2 = reinterpret_cast<const double2v *>(r);
+  nt_dispatch(nt, [&](auto nt) {
   for (int64_t base = (int64_t)bx * (kBlock * kUnrollXp) + threadIdx.x; base < n2;
        base += (int64_t)gridDim.x * (kBlock * kUnrollXp)) {
     double2v vx[kUnrollXp], vp[kUnrollXp], vr[kUnrollXp];
@@ -350,6 +351,7 @@ __global__ __launch_bounds__(kBlock) void cg_xp_kernel(int64_t n, const SolverSt
       }
     }
   }
+  });
   if ((n & 1) && bx == 0 && threadIdx.x == 0) {
     const int64_t i = n - 1;
     x[i] += alpha * p[i];
@@ -394,6 +396,7 @@ __global__ __launch_bounds__(kBlock) void bicg_update_kernel(int64_t n, SolverSt
   const double2v *p2 = reinterpret_cast<const double2v *>(p), *w2 = reinterpret_cast<const double2v *>(w);
   const double2v *rt2 = reinterpret_cast<const double2v *>(rt);
   constexpr int U = SECOND ? 1 : kUnroll;  // 7 streams: one access per stream in flight (see cg_xp_kernel)
+  nt_dispatch(nt, [&](auto nt) {
   for (int64_t base = (int64_t)bx * (kBlock * U) + threadIdx.x; base < n2;
        base += (int64_t)gridDim.x * (kBlock * U)) {
     double2v vx[U], vr[U], vw[U], vp[U], vt[U];
@@ -426,6 +429,7 @@ __global__ __launch_bounds__(kBlock) void bicg_update_kernel(int64_t n, SolverSt
       }
     }
   }
+  });
   if ((n & 1) && bx == 0 && threadIdx.x == 0) {
     const int64_t i = n - 1;
     if (!SECOND) {
@@ -484,6 +488,7 @@ __global__ __launch_bounds__(kBlock) void mgs_step_kernel(int64_t n, const int *
   const int64_t n2 = n >> 1;
   double2v *w2 = reinterpret_cast<double2v *>(w);
   const double2v *a2 = reinterpret_cast<const double2v *>(qa), *b2 = reinterpret_cast<const double2v *>(qb);
+  nt_dispatch(nt, [&](auto nt) {
   STORM_STREAM_FOR(base, n2) {
     double2v vw[kUnroll], va[kUnroll], vb[kUnroll];
 #pragma unroll
@@ -506,6 +511,7 @@ __global__ __launch_bounds__(kBlock) void mgs_step_kernel(int64_t n, const int *
       }
     }
   }
+  });
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const double v = w[n - 1] - hv * qa[n - 1];
     w[n - 1] = v;
@@ -541,6 +547,7 @@ __global__ __launch_bounds__(kBlock) void mgs_pair_kernel(int64_t n, const int *
   double2v *w2 = reinterpret_cast<double2v *>(w);
   const double2v *a2 = reinterpret_cast<const double2v *>(qa), *b2 = reinterpret_cast<const double2v *>(qb);
   const double2v *c2 = reinterpret_cast<const double2v *>(qc), *d2 = reinterpret_cast<const double2v *>(qd);
+  nt_dispatch(nt, [&](auto nt) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
     double2v vw = ldv(w2 + i, nt), xa = {0.0, 0.0}, xb = {0.0, 0.0}, xc = {0.0, 0.0}, xd = {0.0, 0.0};
     if (qa) xa = ldv(a2 + i, nt);
@@ -559,6 +566,7 @@ __global__ __launch_bounds__(kBlock) void mgs_pair_kernel(int64_t n, const int *
       s0 += vw.x * vw.x, s0 += vw.y * vw.y;
     }
   }
+  });
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const int64_t i = n - 1;
     double vw = w[i];
@@ -580,6 +588,116 @@ __global__ __launch_bounds__(kBlock) void mgs_pair_kernel(int64_t n, const int *
   if (ticket_reduce_wave0<3>(tickets, mine, qd ? 3 : 1, blockIdx.x, gridDim.x, total) && threadIdx.x == 0) {
     *out_c = total[0];
     if (qd) *out_d = total[1] - total[0] * total[2];
+  }
+}
+
+// T modified-Gram-Schmidt steps per pass (T = 3, 4): the pair kernel's scheme with more vectors per trip over w.
+//   w -= h[0] qa[0]; ... ; w -= h[na-1] qa[na-1]       (the previous pass's coefficients, in the reference's order)
+//   then, of the updated w:  c_j = <w, qc_j>,  g_ij = <qc_i, qc_j> (i < j < nc)
+//   ->  out[j] = c_j - sum_{i<j} out[i] g_ij           (= <w - sum_{i<j} h_i qc_i, qc_j>, by bilinearity, j ascending)
+//   nc == 0: out[0] = <w, w> (SolverGmres.hpp:161).
+// 8 (2 + na + nc) B/row per pass: 20 B/row/step at T = 4 against the pair kernel's 24.  Shape: the streaming kernels'
+// (stream_blocks(n) blocks, kUnroll trips per thread), one access per stream and trip in flight -- with up to ten streams
+// that is as many as the pair kernel's five with two; the block's partials (up to T + T (T - 1) / 2) are folded once, after
+// the last trip, through LDS with one barrier, and finished by tickets.
+template <int T>
+struct MgsMultiArgs {
+  const double *h[T];   // coefficients of the vectors to subtract (device, finished by the previous pass)
+  const double *qa[T];  // the vectors to subtract
+  const double *qc[T];  // the vectors to project on next
+  double *out[T];       // where their coefficients go (nc == 0: out[0] = the norm's square)
+  int na, nc;
+};
+template <int T, int TRIPS>
+__global__ __launch_bounds__(kBlock) void mgs_multi_kernel(int64_t n, const int *done, double *__restrict__ w, MgsMultiArgs<T> a,
+                                                           TicketArgs tickets, int nt) {
+  if (done && *done) return;
+  constexpr int NG = T * (T - 1) / 2, NV = T + NG;
+  __shared__ double lds[4][NV];
+  double hv[T];
+#pragma unroll
+  for (int j = 0; j < T; ++j) hv[j] = j < a.na ? *a.h[j] : 0.0;
+  double acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+  const int64_t n2 = n >> 1;
+  double2v *w2 = reinterpret_cast<double2v *>(w);
+  auto fold = [&](double wx, double wy, const double2v (&xc)[T]) {
+    if (a.nc == 0) {
+      acc[0] += wx * wx, acc[0] += wy * wy;
+      return;
+    }
+    int g = T;
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+      acc[j] += wx * xc[j].x, acc[j] += wy * xc[j].y;
+#pragma unroll
+      for (int i = 0; i < j; ++i, ++g) acc[g] += xc[i].x * xc[j].x, acc[g] += xc[i].y * xc[j].y;
+    }
+  };
+  nt_dispatch(nt, [&](auto nt) {
+  for (int64_t base = (int64_t)blockIdx.x * (kBlock * TRIPS) + threadIdx.x; base < n2;
+       base += (int64_t)gridDim.x * (kBlock * TRIPS)) {
+#pragma unroll
+    for (int u = 0; u < TRIPS; ++u) {
+      const int64_t i = base + u * kBlock;
+      if (i >= n2) break;
+      double2v vw = ldv(w2 + i, nt), xa[T], xc[T];
+#pragma unroll
+      for (int j = 0; j < T; ++j) {
+        xa[j] = double2v{0.0, 0.0}, xc[j] = double2v{0.0, 0.0};
+        if (j < a.na) xa[j] = ldv(reinterpret_cast<const double2v *>(a.qa[j]) + i, nt);
+        if (j < a.nc) xc[j] = ldv(reinterpret_cast<const double2v *>(a.qc[j]) + i, nt);
+      }
+      if (a.na > 0) {
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+          if (j < a.na) vw -= hv[j] * xa[j];
+        stv(w2 + i, vw, nt);
+      }
+      fold(vw.x, vw.y, xc);
+    }
+  }
+  });
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    double vw = w[i];
+    double2v xc[T];
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+      if (j < a.na) vw -= hv[j] * a.qa[j][i];
+      xc[j] = double2v{j < a.nc ? a.qc[j][i] : 0.0, 0.0};
+    }
+    if (a.na > 0) w[i] = vw;
+    fold(vw, 0.0, xc);
+  }
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const double s = wave_sum_to_lane63(acc[v]);  // (DPP: ten shuffle trees through the LDS crossbar cost ~1 us per wave)
+    if (lane == kWave - 1) lds[wave][v] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x >= kWave) return;
+  double mine[NV], total[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) mine[v] = (lds[0][v] + lds[1][v]) + (lds[2][v] + lds[3][v]);
+  const int nv = a.nc == 0 ? 1 : NV;
+  if (ticket_reduce_wave0<NV>(tickets, mine, nv, blockIdx.x, gridDim.x, total) && threadIdx.x == 0) {
+    if (a.nc == 0) {
+      *a.out[0] = total[0];
+      return;
+    }
+    double hn[T];
+    int g = T;
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+      double v = total[j];
+#pragma unroll
+      for (int i = 0; i < j; ++i, ++g) v -= hn[i] * total[g];
+      hn[j] = v;
+      if (j < a.nc) *a.out[j] = v;
+    }
   }
 }
 
@@ -890,7 +1008,7 @@ int gmres_orthogonalize(storm_hip_ctx *c, int64_t n, const SolverState *st, cons
     const int nbp = (int)std::min<int64_t>(std::max<int64_t>(1, ((n >> 1) + kBlock - 1) / kBlock),
                                            std::min<int64_t>(32768, c->partials_capacity / 3));
     const TicketArgs t{c->d_tickets, c->d_partials, c->d_ticket_sums};
-    const int nti = (int)(c->opt_blas1_nt != 0);
+    const int nti = stream_nt(c, n);
     auto h_of = [&](int i) { return &H[(int64_t)i * m + k]; };
     auto launch = [&](int sub, int nsub, int nxt) {  // subtract q[sub .. sub + nsub), then the dots of q[nxt], q[nxt + 1]
       const int nnext = std::min(2, k + 1 - nxt);    // 2: a pair; 1: one vector; 0: the norm
@@ -900,6 +1018,33 @@ int gmres_orthogonalize(storm_hip_ctx *c, int64_t n, const SolverState *st, cons
                          nnext >= 1 ? q[nxt] : nullptr, nnext >= 2 ? q[nxt + 1] : nullptr,
                          nnext >= 1 ? h_of(nxt) : norm2_out, nnext >= 2 ? h_of(nxt + 1) : (double *)nullptr, t, nti);
     };
+    const int64_t steps = c->opt_mgs_steps;
+    // (two trips per thread: tools/multi_stream_bench.hip -- 5.47 TB/s against 5.35 with four and 5.45 with one)
+    constexpr int kMgsTrips = 2;
+    const int nbm = (int)std::min<int64_t>(std::max<int64_t>(1, ((n >> 1) + kBlock * kMgsTrips - 1) / (kBlock * kMgsTrips)), kMaxStreamBlocks);
+    if ((steps == 3 || steps == 4) && k >= 2 && 10 * (int64_t)nbm <= c->partials_capacity &&
+        10 * (int64_t)((nbm + kTicketGroup - 1) / kTicketGroup) <= 8 * 2048) {
+      // three or four steps per pass (mgs_multi_kernel): ceil((k + 1) / T) + 1 launches
+      auto go = [&](auto tag, int sub, int nsub, int nxt) {
+        constexpr int T = decltype(tag)::value;
+        MgsMultiArgs<T> a{};
+        a.na = nsub, a.nc = std::max(0, std::min(T, k + 1 - nxt));
+        for (int j = 0; j < T; ++j) {
+          a.h[j] = h_of(sub + std::min(j, std::max(nsub - 1, 0))), a.qa[j] = q[std::min(sub + j, k)];
+          a.qc[j] = q[std::min(nxt + j, k)], a.out[j] = j < a.nc ? h_of(nxt + j) : norm2_out;
+        }
+        hipLaunchKernelGGL((mgs_multi_kernel<T, kMgsTrips>), dim3(nbm), dim3(kBlock), 0, c->stream, n, done, qn, a, t, nti);
+      };
+      if (steps == 4) {
+        go(std::integral_constant<int, 4>{}, 0, 0, 0);
+        for (int i = 0; i <= k; i += 4) go(std::integral_constant<int, 4>{}, i, std::min(4, k + 1 - i), i + 4);
+      } else {
+        go(std::integral_constant<int, 3>{}, 0, 0, 0);
+        for (int i = 0; i <= k; i += 3) go(std::integral_constant<int, 3>{}, i, std::min(3, k + 1 - i), i + 3);
+      }
+      HIP_TRY(hipGetLastError());
+      return STORM_HIP_OK;
+    }
     launch(0, 0, 0);
     for (int i = 0; i <= k; i += 2) launch(i, std::min(2, k + 1 - i), i + 2);
     HIP_TRY(hipGetLastError());
@@ -916,7 +1061,7 @@ int gmres_orthogonalize(storm_hip_ctx *c, int64_t n, const SolverState *st, cons
         const double *qb = i < k ? q[i + 1] : nullptr;
         hipLaunchKernelGGL(mgs_step_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, done, qn,
                            (const double *)nullptr, cur, nbv, &H[i * m + k], q[i], qb, nxt,
-                           (int)(c->opt_blas1_nt != 0));
+                           stream_nt(c, n));
         HIP_TRY(hipGetLastError());
         std::swap(cur, nxt);
       }
@@ -933,7 +1078,7 @@ int gmres_orthogonalize(storm_hip_ctx *c, int64_t n, const SolverState *st, cons
       double *out = i < k ? &H[(i + 1) * m + k] : norm2_out;
       hipLaunchKernelGGL(mgs_step_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, done, qn, h,
                          (const double *)nullptr, 0, (double *)nullptr, q[i], qb, c->d_partials,
-                         (int)(c->opt_blas1_nt != 0));
+                         stream_nt(c, n));
       HIP_TRY(hipGetLastError());
       STORM_TRY(k_reduce_final(c, c->d_partials, nbv, 1, out, done));
       if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, out, 1));
@@ -1041,7 +1186,7 @@ int solve_cg_body(const FusedSolveArgs &args) {
   int nb = 0;
   STORM_TRY(d.apply(x->d, r, nullptr, false, &nb, false));
   hipLaunchKernelGGL(init_residual_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, r, b->d, p, c->d_partials,
-                     (int)(c->opt_blas1_nt != 0));
+                     stream_nt(c, n));
   HIP_TRY(hipGetLastError());
   {
     const int slots[1] = {S_GAMMA};
@@ -1054,7 +1199,7 @@ int solve_cg_body(const FusedSolveArgs &args) {
   // predecessor stopped: iteration k even -- SpMV forward, cg_r backward, cg_xp forward; k odd -- the mirror image.
   // Blocks keep their rows and their partial slots: the same bits either way.
   const bool sweep = c->opt_sweep_alternate != 0;  // (per rank: with a communicator too)
-  const int nt_stream = (int)(c->opt_blas1_nt != 0 && !(sweep && c->opt_sweep_alternate == 2));
+  const int nt_stream = (int)(stream_nt(c, n) != 0 && !(sweep && c->opt_sweep_alternate == 2));
   // Reductions that finish inside the kernels producing their partials (ticket_device.hpp), one rank: an iteration
   // is then three launches -- SpMV (+ <p,z>), cg_r (+ <r,r>, beta, the convergence rule), cg_xp.
   // (on the peer-window transport too: the block that finishes a reduction exchanges its sum with the other ranks itself)
@@ -1194,7 +1339,7 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
   // init: r = b - A x; rt = r; rho = <rt,r>           SolverBiCgStab.hpp:82-90
   STORM_TRY(d.apply(x->d, r, nullptr, false, &nb, false));
   hipLaunchKernelGGL(init_residual_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, r, b->d, rt, c->d_partials,
-                     (int)(c->opt_blas1_nt != 0));
+                     stream_nt(c, n));
   HIP_TRY(hipGetLastError());
   {
     const int slots[1] = {S_RHO};
@@ -1234,7 +1379,7 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
     }
     // r -= alpha v   (x += alpha p is applied in the second half-step)      :140-141
     hipLaunchKernelGGL(bicg_update_kernel<false>, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, x->d, r, p, v,
-                       rt, c->d_partials, (int)(c->opt_blas1_nt != 0), flip(), alpha_in_kernel ? tickets : no_tickets);
+                       rt, c->d_partials, stream_nt(c, n), flip(), alpha_in_kernel ? tickets : no_tickets);
     HIP_TRY(hipGetLastError());
     // t = A r; omega = <t,r> / <t,t>                  :158-160
     STORM_TRY(apply_dir(r, t, r, true, (int)S_TR, (int)S_TT));
@@ -1252,7 +1397,7 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
     }
     // x = (x + alpha p) + omega r; r -= omega t; |r|, <rt,r>    :140, :161-164 (+ :116 of the next iteration)
     hipLaunchKernelGGL(bicg_update_kernel<true>, dim3(nbv2), dim3(kBlock), 0, c->stream, n, d.st, x->d, r,
-                       p, t, rt, c->d_partials, (int)(c->opt_blas1_nt != 0), flip(), omega_in_kernel ? tickets : no_tickets);
+                       p, t, rt, c->d_partials, stream_nt(c, n), flip(), omega_in_kernel ? tickets : no_tickets);
     HIP_TRY(hipGetLastError());
     if (!omega_in_kernel) {
       const int slots[2] = {S_RR, S_RHO_NEW};
@@ -1330,7 +1475,7 @@ int solve_gmres_body(const FusedSolveArgs &args) {
     STORM_TRY(d.apply(x->d, q0, nullptr, false, &nb, !outer));
     if (outer) {
       hipLaunchKernelGGL(init_residual_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, q0, b->d,
-                         (double *)nullptr, c->d_partials, (int)(c->opt_blas1_nt != 0));
+                         (double *)nullptr, c->d_partials, stream_nt(c, n));
       HIP_TRY(hipGetLastError());
       const int slots[1] = {S_TMP};
       STORM_TRY(d.finish(nbv, 1, slots, STEP_GMRES_BETA0_OUTER, true));

@@ -80,13 +80,16 @@ __device__ __forceinline__ bool ticket_reduce_wave0(const TicketArgs &t, const d
   go = __shfl(go, 0, kWave);
   if (!go) return false;
   double gp[KMAX];
+  // (all loads first, then the sums: a load per value waited for in turn costs a trip to memory each -- with ten values
+  //  that was 12 us per group, and 24 - 57 us of serial tail in the last fold below)
 #pragma unroll
   for (int j = 0; j < KMAX; ++j) {
-    double v = 0.0;
+    gp[j] = 0.0;
     if (j < k && lane < gsize)
-      v = __hip_atomic_load(t.part1 + (size_t)j * nb + (size_t)g * kTicketGroup + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    gp[j] = ticket_wave_sum(v);
+      gp[j] = __hip_atomic_load(t.part1 + (size_t)j * nb + (size_t)g * kTicketGroup + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) gp[j] = ticket_wave_sum(gp[j]);
   go = 0;
   if (lane == 0) {
     ticket_publish<KMAX>(t.part2 + g, ng, gp, k);
@@ -97,14 +100,29 @@ __device__ __forceinline__ bool ticket_reduce_wave0(const TicketArgs &t, const d
   }
   go = __shfl(go, 0, kWave);
   if (!go) return false;
+  // lane i takes groups i, i + 64, ... in ascending order (the order of the sums is fixed); four groups per lane and
+  // value are loaded before the first is added
+  constexpr int kAhead = KMAX <= 4 ? 4 : 2;
 #pragma unroll
-  for (int j = 0; j < KMAX; ++j) {
-    double v = 0.0;
-    if (j < k)
-      for (unsigned i = lane; i < ng; i += kWave)
-        v += __hip_atomic_load(t.part2 + (size_t)j * ng + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    total[j] = ticket_wave_sum(v);
+  for (int j = 0; j < KMAX; ++j) total[j] = 0.0;
+  for (unsigned i0 = lane; i0 < ng; i0 += kWave * kAhead) {
+    double v[KMAX][kAhead];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j)
+#pragma unroll
+      for (int u = 0; u < kAhead; ++u) {
+        const unsigned i = i0 + u * kWave;
+        v[j][u] = 0.0;
+        if (j < k && i < ng) v[j][u] = __hip_atomic_load(t.part2 + (size_t)j * ng + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j)
+#pragma unroll
+      for (int u = 0; u < kAhead; ++u)
+        if (i0 + u * kWave < ng) total[j] += v[j][u];
   }
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) total[j] = ticket_wave_sum(total[j]);
   return true;
 }
 

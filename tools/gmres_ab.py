@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GMRES(30) / CG / BiCGStab microseconds per iteration on small and mid-size boxes against a library option
-(default: coop_plain = 0 / 1): python tools/gmres_ab.py [key=value ...]"""
+(default: coop_plain = 0 / 1): python tools/gmres_ab.py [sizes:32,64,128] [solvers:gmres30,cg,bicgstab] [key=value ...]"""
 import json
 import os
 import sys
@@ -9,8 +9,11 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stormruler_amd import api, mesh  # noqa: E402
 
-sets = sys.argv[1:] or ["coop_plain=0", "coop_plain=1"]
-for n in (32, 64, 128):
+argv = sys.argv[1:]
+sizes = [int(v) for a in argv if a.startswith("sizes:") for v in a[6:].split(",")] or [32, 64, 128]
+wanted = [v for a in argv if a.startswith("solvers:") for v in a[8:].split(",")] or ["gmres30", "cg", "bicgstab"]
+sets = [a for a in argv if ":" not in a] or ["coop_plain=0", "coop_plain=1"]
+for n in sizes:
     g = mesh.structured_box(n)
     row = {"n": n}
     for spec in sets:
@@ -22,6 +25,10 @@ for n in (32, 64, 128):
         b = api.DeviceVector(ctx, g.n_cells)
         api.fill_with(b, 1.0)
         for name, cls, iters in (("gmres30", api.GmresSolver, 300), ("cg", api.CgSolver, 600), ("bicgstab", api.BiCgStabSolver, 400)):
+            if name not in wanted:
+                continue
+            if n > 128:
+                iters = max(60, iters // 5)
             best = None
             for _ in range(4):
                 s = cls()

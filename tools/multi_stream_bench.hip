@@ -1,0 +1,393 @@
+// Micro-benchmark: a kernel that reads w and K more vectors at the same index and writes w back (the shape of the
+// Gram-Schmidt passes, multi-dot and multi-axpy) -- what decides its HBM rate on MI355X?
+//   * SKEW  : bytes between the vectors' base addresses beyond the vector length (0 = the same alignment for all)
+//   * shape : trips per thread (U sequential trips of one 16-byte access per stream) and blocks
+//   * one thread block = 256 threads
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -D__HIP_PLATFORM_AMD__ -Istormruler_amd/csrc -Iinclude tools/multi_stream_bench.hip -o tools/multi_stream_bench
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <type_traits>
+#include <vector>
+#include "common.hpp"
+#include "blas1_device.hpp"
+using storm::double2v;
+
+
+
+// ---- the library's own kernels (text copied from csrc/solvers.hip when this tool was last edited: keep in step) --------
+#include "ticket_device.hpp"
+#include "solver_device.hpp"
+#include "wave_device.hpp"
+namespace storm {
+__global__ __launch_bounds__(kBlock) void mgs_pair_kernel(int64_t n, const int *done, double *__restrict__ w,
+                                                          const double *ha, const double *hb,
+                                                          const double *__restrict__ qa, const double *__restrict__ qb,
+                                                          const double *__restrict__ qc, const double *__restrict__ qd,
+                                                          double *out_c, double *out_d, TicketArgs tickets, int nt) {
+  if (done && *done) return;
+  __shared__ double lds4[4];
+  const double va = qa ? *ha : 0.0, vb = qb ? *hb : 0.0;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  const int64_t n2 = n >> 1;
+  double2v *w2 = reinterpret_cast<double2v *>(w);
+  const double2v *a2 = reinterpret_cast<const double2v *>(qa), *b2 = reinterpret_cast<const double2v *>(qb);
+  const double2v *c2 = reinterpret_cast<const double2v *>(qc), *d2 = reinterpret_cast<const double2v *>(qd);
+  nt_dispatch(nt, [&](auto nt) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
+    double2v vw = ldv(w2 + i, nt), xa = {0.0, 0.0}, xb = {0.0, 0.0}, xc = {0.0, 0.0}, xd = {0.0, 0.0};
+    if (qa) xa = ldv(a2 + i, nt);
+    if (qb) xb = ldv(b2 + i, nt);
+    if (qc) xc = ldv(c2 + i, nt);
+    if (qd) xd = ldv(d2 + i, nt);
+    if (qa) {
+      vw -= va * xa;
+      if (qb) vw -= vb * xb;
+      stv(w2 + i, vw, nt);
+    }
+    if (qc) {
+      s0 += vw.x * xc.x, s0 += vw.y * xc.y;
+      if (qd) s1 += vw.x * xd.x, s1 += vw.y * xd.y, s2 += xc.x * xd.x, s2 += xc.y * xd.y;
+    } else {
+      s0 += vw.x * vw.x, s0 += vw.y * vw.y;
+    }
+  }
+  });
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    double vw = w[i];
+    if (qa) {
+      vw -= va * qa[i];
+      if (qb) vw -= vb * qb[i];
+      w[i] = vw;
+    }
+    if (qc) {
+      s0 += vw * qc[i];
+      if (qd) s1 += vw * qd[i], s2 += qc[i] * qd[i];
+    } else {
+      s0 += vw * vw;
+    }
+  }
+  const double mine[3] = {block_sum256(s0, lds4), block_sum256(s1, lds4), block_sum256(s2, lds4)};
+  if (threadIdx.x >= kWave) return;
+  double total[3];
+  if (ticket_reduce_wave0<3>(tickets, mine, qd ? 3 : 1, blockIdx.x, gridDim.x, total) && threadIdx.x == 0) {
+    *out_c = total[0];
+    if (qd) *out_d = total[1] - total[0] * total[2];
+  }
+}
+
+template <int T>
+struct MgsMultiArgs {
+  const double *h[T];   // coefficients of the vectors to subtract (device, finished by the previous pass)
+  const double *qa[T];  // the vectors to subtract
+  const double *qc[T];  // the vectors to project on next
+  double *out[T];       // where their coefficients go (nc == 0: out[0] = the norm's square)
+  int na, nc;
+};
+template <int T, int TRIPS>
+__global__ __launch_bounds__(kBlock) void mgs_multi_kernel(int64_t n, const int *done, double *__restrict__ w, MgsMultiArgs<T> a,
+                                                           TicketArgs tickets, int nt) {
+  if (done && *done) return;
+  constexpr int NG = T * (T - 1) / 2, NV = T + NG;
+  __shared__ double lds[4][NV];
+  double hv[T];
+#pragma unroll
+  for (int j = 0; j < T; ++j) hv[j] = j < a.na ? *a.h[j] : 0.0;
+  double acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+  const int64_t n2 = n >> 1;
+  double2v *w2 = reinterpret_cast<double2v *>(w);
+  auto fold = [&](double wx, double wy, const double2v (&xc)[T]) {
+    if (a.nc == 0) {
+      acc[0] += wx * wx, acc[0] += wy * wy;
+      return;
+    }
+    int g = T;
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+      acc[j] += wx * xc[j].x, acc[j] += wy * xc[j].y;
+#pragma unroll
+      for (int i = 0; i < j; ++i, ++g) acc[g] += xc[i].x * xc[j].x, acc[g] += xc[i].y * xc[j].y;
+    }
+  };
+  nt_dispatch(nt, [&](auto nt) {
+  for (int64_t base = (int64_t)blockIdx.x * (kBlock * TRIPS) + threadIdx.x; base < n2;
+       base += (int64_t)gridDim.x * (kBlock * TRIPS)) {
+#pragma unroll
+    for (int u = 0; u < TRIPS; ++u) {
+      const int64_t i = base + u * kBlock;
+      if (i >= n2) break;
+      double2v vw = ldv(w2 + i, nt), xa[T], xc[T];
+#pragma unroll
+      for (int j = 0; j < T; ++j) {
+        xa[j] = double2v{0.0, 0.0}, xc[j] = double2v{0.0, 0.0};
+        if (j < a.na) xa[j] = ldv(reinterpret_cast<const double2v *>(a.qa[j]) + i, nt);
+        if (j < a.nc) xc[j] = ldv(reinterpret_cast<const double2v *>(a.qc[j]) + i, nt);
+      }
+      if (a.na > 0) {
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+          if (j < a.na) vw -= hv[j] * xa[j];
+        stv(w2 + i, vw, nt);
+      }
+      fold(vw.x, vw.y, xc);
+    }
+  }
+  });
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    double vw = w[i];
+    double2v xc[T];
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+      if (j < a.na) vw -= hv[j] * a.qa[j][i];
+      xc[j] = double2v{j < a.nc ? a.qc[j][i] : 0.0, 0.0};
+    }
+    if (a.na > 0) w[i] = vw;
+    fold(vw, 0.0, xc);
+  }
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const double s = wave_sum_to_lane63(acc[v]);  // (DPP: ten shuffle trees through the LDS crossbar cost ~1 us per wave)
+    if (lane == kWave - 1) lds[wave][v] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x >= kWave) return;
+  double mine[NV], total[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) mine[v] = (lds[0][v] + lds[1][v]) + (lds[2][v] + lds[3][v]);
+  const int nv = a.nc == 0 ? 1 : NV;
+  if (ticket_reduce_wave0<NV>(tickets, mine, nv, blockIdx.x, gridDim.x, total) && threadIdx.x == 0) {
+    if (a.nc == 0) {
+      *a.out[0] = total[0];
+      return;
+    }
+    double hn[T];
+    int g = T;
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+      double v = total[j];
+#pragma unroll
+      for (int i = 0; i < j; ++i, ++g) v -= hn[i] * total[g];
+      hn[j] = v;
+      if (j < a.nc) *a.out[j] = v;
+    }
+  }
+}
+
+
+}  // namespace storm
+
+template <int K>
+struct Ptrs {
+  const double2v *q[K];
+};
+
+// MODE 0: U sequential trips (loads of trip u + 1 after the arithmetic of trip u); MODE 1: all loads of U trips first
+// PRO: the solver kernels' prologue (a device flag read before anything else); EPI: their epilogue (NV block sums through LDS,
+// published with returning atomic exchanges, a ticket drawn with a returning atomic add, the last of 64 folds the group)
+template <int K, int U, int MODE, bool WRITE, bool PRO = false, int EPI = 0>
+__global__ __launch_bounds__(256) void multi_k(double2v *__restrict__ w, Ptrs<K> p, long n2, double *out, const int *flag = nullptr,
+                                               double *part = nullptr, int *cnt = nullptr) {
+  if (PRO && flag && *flag) return;
+  __shared__ double lds[4][12];
+  double acc = 0.0;
+  for (long base = (long)blockIdx.x * (256 * U) + threadIdx.x; base < n2; base += (long)gridDim.x * (256 * U)) {
+    if (MODE == 0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long i = base + u * 256;
+        if (i >= n2) break;
+        double2v vw = __builtin_nontemporal_load(w + i), x[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) x[j] = __builtin_nontemporal_load(p.q[j] + i);
+#pragma unroll
+        for (int j = 0; j < K; ++j) vw -= 1e-9 * x[j], acc += vw.x * x[j].x + vw.y * x[j].y;
+        if (WRITE) __builtin_nontemporal_store(vw, w + i);
+      }
+    } else {
+      double2v vw[U], x[U][K];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long i = base + u * 256;
+        if (i < n2) {
+          vw[u] = __builtin_nontemporal_load(w + i);
+#pragma unroll
+          for (int j = 0; j < K; ++j) x[u][j] = __builtin_nontemporal_load(p.q[j] + i);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long i = base + u * 256;
+        if (i < n2) {
+#pragma unroll
+          for (int j = 0; j < K; ++j) vw[u] -= 1e-9 * x[u][j], acc += vw[u].x * x[u][j].x + vw[u].y * x[u][j].y;
+          if (WRITE) __builtin_nontemporal_store(vw[u], w + i);
+        }
+      }
+    }
+  }
+  if (EPI > 0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int v = 0; v < EPI; ++v) {
+      double sv = acc * (v + 1);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) sv += __shfl_down(sv, off, 64);
+      if (lane == 0) lds[wave][v] = sv;
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    int go = 0;
+    if (lane == 0) {
+      unsigned long long seen = 0;
+#pragma unroll
+      for (int v = 0; v < EPI; ++v)
+        seen ^= __hip_atomic_exchange(reinterpret_cast<unsigned long long *>(part + (size_t)v * gridDim.x + blockIdx.x),
+                                      (unsigned long long)__double_as_longlong((lds[0][v] + lds[1][v]) + (lds[2][v] + lds[3][v])),
+                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" : : "v"(seen) : "memory");
+      int *c = cnt + (size_t)(1 + blockIdx.x / 64) * 16;
+      if (__hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 63) {
+        __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        go = 1;
+      }
+    }
+    go = __shfl(go, 0, 64);
+    if (go) {
+      double tot = 0.0;
+      for (int v = 0; v < EPI; ++v)
+        tot += __hip_atomic_load(part + (size_t)v * gridDim.x + (blockIdx.x / 64) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tot == 1.2345e300) *out = tot;
+    }
+    return;
+  }
+  if (acc == 1.2345e300) *out = acc;
+}
+
+static int *g_flag, *g_cnt;
+static int g_pool_vectors = 0;
+static size_t g_pitch = 0;
+static double *g_part;
+template <int K, int U, int MODE, bool WRITE, bool PRO = false, int EPI = 0>
+static double run(double2v *w, Ptrs<K> p0, long n2, int blocks, double *out) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0), hipEventCreate(&e1);
+  const int reps = 24;
+  // like a Gram-Schmidt sweep: every launch reads the NEXT K vectors of the pool (g_pool_vectors of them, g_pitch apart)
+  auto ptrs = [&](int rep) {
+    Ptrs<K> p = p0;
+    if (g_pool_vectors > 0)
+      for (int j = 0; j < K; ++j)
+        p.q[j] = reinterpret_cast<const double2v *>(reinterpret_cast<const char *>(w) + (size_t)(1 + (rep * K + j) % g_pool_vectors) * g_pitch);
+    return p;
+  };
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((multi_k<K, U, MODE, WRITE, PRO, EPI>), dim3(blocks), dim3(256), 0, 0, w, ptrs(i), n2, out, g_flag, g_part, g_cnt);
+  hipEventRecord(e0, 0);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((multi_k<K, U, MODE, WRITE, PRO, EPI>), dim3(blocks), dim3(256), 0, 0, w, ptrs(3 + i), n2, out, g_flag, g_part, g_cnt);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  hipEventDestroy(e0), hipEventDestroy(e1);
+  const double bytes = 16.0 * n2 * (K + 1 + (WRITE ? 1 : 0));
+  return bytes * reps / (ms * 1e-3) / 1e12;
+}
+
+template <int K>
+static void sweep(char *pool, long n, long skew, double *out) {
+  const long n2 = n / 2;
+  const long pitch = n * 8 + skew;
+  g_pitch = (size_t)pitch;
+  double2v *w = reinterpret_cast<double2v *>(pool);
+  Ptrs<K> p;
+  for (int j = 0; j < K; ++j) p.q[j] = reinterpret_cast<const double2v *>(pool + (j + 1) * pitch);
+  const int b1 = (int)((n2 + 255) / 256), b2 = (int)((n2 + 511) / 512), b4 = (int)((n2 + 1023) / 1024);
+  printf("K=%d skew=%7ld | rw: 1 trip %.2f  2 trips %.2f  4 trips %.2f  4 trips/2048 blocks %.2f | 2 ahead %.2f  4 ahead %.2f | read-only: 1 trip %.2f 4 trips %.2f 2 ahead %.2f\n",
+         K, skew, run<K, 1, 0, true>(w, p, n2, b1, out), run<K, 2, 0, true>(w, p, n2, b2, out), run<K, 4, 0, true>(w, p, n2, b4, out),
+         run<K, 4, 0, true>(w, p, n2, 2048, out), run<K, 2, 1, true>(w, p, n2, b2, out), run<K, 4, 1, true>(w, p, n2, b4, out),
+         run<K, 1, 0, false>(w, p, n2, b1, out), run<K, 4, 0, false>(w, p, n2, b4, out), run<K, 2, 1, false>(w, p, n2, b2, out));
+  printf("      with the solvers' prologue / epilogue | rw 1 trip: plain %.2f  flag %.2f  3 sums %.2f  10 sums %.2f  flag + 3 sums %.2f | rw 4 trips: plain %.2f  flag + 10 sums %.2f | 2 ahead: flag + 3 sums %.2f  flag + 10 sums %.2f\n",
+         run<K, 1, 0, true>(w, p, n2, b1, out), run<K, 1, 0, true, true, 0>(w, p, n2, b1, out), run<K, 1, 0, true, false, 3>(w, p, n2, b1, out),
+         run<K, 1, 0, true, false, 10>(w, p, n2, b1, out), run<K, 1, 0, true, true, 3>(w, p, n2, b1, out), run<K, 4, 0, true>(w, p, n2, b4, out),
+         run<K, 4, 0, true, true, 10>(w, p, n2, b4, out), run<K, 2, 1, true, true, 3>(w, p, n2, b2, out), run<K, 2, 1, true, true, 10>(w, p, n2, b2, out));
+  fflush(stdout);
+}
+
+static double time_launches(int reps, const std::function<void(int)> &launch) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0), hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) launch(i);
+  hipEventRecord(e0, 0);
+  for (int i = 0; i < reps; ++i) launch(3 + i);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  return ms * 1e-3 / reps;
+}
+
+static void library_kernels(char *pool, long n, double *out) {
+  using namespace storm;
+  double *w = reinterpret_cast<double *>(pool);
+  auto vec = [&](int i) { return reinterpret_cast<const double *>(pool + (size_t)(1 + i % g_pool_vectors) * g_pitch); };
+  double *h;
+  hipMalloc((void **)&h, 8 * 64), hipMemset(h, 0, 8 * 64);
+  double *part1, *part2;
+  hipMalloc((void **)&part1, 8 * 12 * 40000), hipMalloc((void **)&part2, 8 * 12 * 2048);
+  TicketArgs t{g_cnt, part1, part2};
+  const int64_t n2 = n / 2;
+  for (int nt : {1, 0}) {
+    for (int nbp : {32768, 21845, 16384, 8192}) {
+      const double s = time_launches(24, [&](int r) {
+        hipLaunchKernelGGL(mgs_pair_kernel, dim3(nbp), dim3(256), 0, 0, (int64_t)n, g_flag, w, h, h + 1, vec(4 * r), vec(4 * r + 1),
+                           vec(4 * r + 2), vec(4 * r + 3), h + 2, h + 3, t, nt);
+      });
+      printf("mgs_pair_kernel (2 subtracted, 2 projected: 6 streams) nt=%d blocks=%5d: %.1f us  %.2f TB/s\n", nt, nbp, s * 1e6, 48.0 * n / s / 1e12);
+    }
+    auto multi = [&](auto trips_tag, int nbm) {
+      constexpr int TRIPS = decltype(trips_tag)::value;
+      MgsMultiArgs<4> a{};
+      a.na = 4, a.nc = 4;
+      const double s = time_launches(24, [&](int r) {
+        for (int j = 0; j < 4; ++j) a.h[j] = h + j, a.qa[j] = vec(8 * r + j), a.qc[j] = vec(8 * r + 4 + j), a.out[j] = h + 8 + j;
+        hipLaunchKernelGGL((mgs_multi_kernel<4, TRIPS>), dim3(nbm), dim3(256), 0, 0, (int64_t)n, g_flag, w, a, t, nt);
+      });
+      printf("mgs_multi_kernel<4, %d trips> (4 + 4: 10 streams) nt=%d blocks=%5d: %.1f us  %.2f TB/s\n", TRIPS, nt, nbm, s * 1e6, 80.0 * n / s / 1e12);
+    };
+    multi(std::integral_constant<int, 4>{}, 8192);
+    multi(std::integral_constant<int, 2>{}, 16384);
+    multi(std::integral_constant<int, 1>{}, 32768);
+  }
+  fflush(stdout);
+  (void)n2, (void)out;
+}
+
+int main(int argc, char **argv) {
+  const long n = argc > 1 ? atol(argv[1]) : (1L << 24);  // doubles per vector (256^3)
+  const long max_skew = 1 << 17;
+  g_pool_vectors = argc > 2 ? atoi(argv[2]) : 30;  // 0: the same K vectors every launch (the Infinity Cache then serves part of them)
+  const int nvec = 1 + (g_pool_vectors > 8 ? g_pool_vectors : 8);
+  char *pool;
+  double *out;
+  if (hipMalloc((void **)&pool, (size_t)(n * 8 + max_skew) * nvec) != hipSuccess) return 1;
+  hipMalloc((void **)&out, 8);
+  hipMalloc((void **)&g_flag, 4), hipMemset(g_flag, 0, 4);
+  hipMalloc((void **)&g_cnt, 4 * 16 * 2049), hipMemset(g_cnt, 0, 4 * 16 * 2049);
+  hipMalloc((void **)&g_part, 8 * 12 * 40000);
+  hipMemset(pool, 0, (size_t)(n * 8 + max_skew) * nvec);
+  g_pitch = (size_t)(n * 8);
+  library_kernels(pool, n, out);
+  for (long skew : {0L}) {
+    sweep<1>(pool, n, skew, out);
+    sweep<2>(pool, n, skew, out);
+    sweep<4>(pool, n, skew, out);
+    sweep<8>(pool, n, skew, out);
+  }
+  return 0;
+}
