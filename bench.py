@@ -30,6 +30,7 @@ Prints ONE JSON line on rank 0.
                     bytes), cells renumbered by the seeded permutation, then the library's ordering: the number a
                     Triangle / TetGen mesh of this size would get;
   config3_bicgstab256, config4_gmres30_convdiff128, config5_cavity128   BASELINE configs 3, 4, 5 on this GPU, bounded;
+  extra_gmres30_poisson256   GMRES(30) at the headline size (kernel-per-statement path: the Gram-Schmidt passes at HBM scale);
   cpu_baseline      the CPU oracle (single thread, the reference is single-threaded) on a bounded sample.
 
 N > 1: every rank process is a SUPERVISOR that never touches the GPU; it starts the measuring rank as a child with
@@ -628,6 +629,7 @@ def main() -> int:
             "config3_bicgstab256": (configs or {}).get("config3_bicgstab256") if isinstance(configs, dict) else None,
             "config4_gmres30_convdiff128": (configs or {}).get("config4_gmres30_convdiff128") if isinstance(configs, dict) else None,
             "config5_cavity128": (configs or {}).get("config5_cavity128") if isinstance(configs, dict) else None,
+            "extra_gmres30_poisson256": (configs or {}).get("extra_gmres30_poisson256") if isinstance(configs, dict) else None,
             "configs_error": configs.get("error") if isinstance(configs, dict) else None,
             "value_general": general.get("cg_iter_per_s") if isinstance(general, dict) else None,
             "general_mesh_path": general,
@@ -707,6 +709,24 @@ def baseline_configs(api, mesh, ctx, op, b, N, n, st, min_seconds):
             "repeats": reps}
     except Exception as e:
         out["config3_bicgstab256"] = {"error": repr(e)}
+    # ---- (not a BASELINE config: the kernel-per-statement GMRES at the headline size -- the Gram-Schmidt passes of
+    #       csrc/solvers.hip, mgs_multi_kernel, at HBM scale)
+    try:
+        def m30h(s_):
+            s_.num_inner_iterations = 30
+
+        sec, reps = rate(api.GmresSolver, op, b, N, 60, m30h)
+        # inner iteration k with four steps per pass: the apply, (k + 1) basis vectors read twice (projected on, subtracted),
+        # w read and written once per pass (ceil((k + 1) / 4) + 1 passes), the normalised q_{k+1} written; mean over k
+        passes = float(np.mean([-(-(k + 1) // 4) + 1 for k in range(30)]))
+        moved = (st["record_bytes"] + 16 * N) + 16 * N * 15.5 + 16 * N * passes + 16 * N
+        out["extra_gmres30_poisson256"] = {
+            "workload": f"GMRES(30), {n}^3 Poisson block, 60 inner iterations (two restarts), tolerances off",
+            "iter_per_s": 1.0 / sec, "us_per_inner_iteration": sec * 1e6, "bytes_really_moved_per_inner_iteration_mean": moved,
+            "frac": moved / sec / 1e9 / HBM_PEAK_GBS,
+            "reference_mgs_bytes_per_inner_iteration_mean": (24 * N + 12 * st["nnz_offdiag"]) + 15.5 * 40 * N + 24 * N, "repeats": reps}
+    except Exception as e:
+        out["extra_gmres30_poisson256"] = {"error": repr(e)}
     # ---- config 4
     try:
         g4 = mesh.structured_box(128)

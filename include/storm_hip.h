@@ -266,7 +266,13 @@ int storm_hip_op_create_csr(storm_hip_ctx *ctx, int64_t n_rows, int64_t n_halo,
  *   generic_solvers (0): 1 sends storm_hip_krylov_solve through the engine even where a fused loop exists;
  *   fuse_dot, fold_pz, fuse_mgs (1): the fused-reduction variants of the fused loops;
  *   ipc_streams (2): peer-window halo kernels on the comm stream (2) or on the compute stream (1);
- *   spmv_xcd_remap (8), spmv_nt_y (1), nontemporal (1), blas1_nt (1), spmv_spw, spmv_variant, graph (0), profile_spmv (0);
+ *   spmv_xcd_remap (8), spmv_nt_y (0), nontemporal (1), spmv_spw, spmv_variant, graph (0), profile_spmv (0);
+ *   blas1_nt (1), blas1_nt_rows (6 * 2^20): non-temporal loads and stores in the BLAS-1 and solver kernels -- 0 never,
+ *              2 always, 1 for vectors of at least blas1_nt_rows rows (longer vectors do not survive in the Infinity
+ *              Cache between two kernels of a solve anyway; shorter ones do, and non-temporal accesses cost 3 - 7 %
+ *              there).  Same values either way;
+ *   mgs_steps (4): modified-Gram-Schmidt steps per pass over w in GMRES's orthogonalisation on the kernel-per-statement
+ *              path (2, 3, 4; coefficients of a pass follow from bilinearity);
  *   resident_path (1), resident_min_rows (0), resident_max_rows (2^22), resident_max_planes (12), resident_planes (0 =
  *              automatic): CG / BiCGStab of a
  *              halo-free LATTICE operator (format-4 records) as one persistent kernel per solve in which every

@@ -157,7 +157,7 @@ struct storm_hip_ctx {
   char *d_quad_slots = nullptr;      // ... its all-reduce slots (ten values each)
   int64_t opt_coop_mgs_lds = 1;      // ... with the next pair of basis vectors fetched by LDS-DMA into a ring (<= 2^21 rows)
   int64_t opt_spmv_mixed = 1;        // partitioned operators: format 4 for the groups that read no halo column, format 3 for the rest
-  int64_t opt_spmv_nt_y = 1;         // format-4 kernel: store y non-temporally (A/B knob)
+  int64_t opt_spmv_nt_y = 0;         // format-4 kernels: store y non-temporally (A/B knob; until round 4 the compiler merged both paths into the plain store -- store_y, spmv_device.hpp -- so 0 is what every earlier number was measured with; 256^3 CG: 4 300 it/s with 1, 4 190 - 4 470 with 0)
   int64_t opt_profile_spmv = 0;
   int64_t opt_blas1_nt = 1;  // non-temporal loads/stores in the streaming kernels: 0 never, 1 for vectors of at least blas1_nt_rows rows, 2 always
   int64_t opt_blas1_nt_rows = (int64_t)6 << 20;  // (48 MiB per vector: beyond, a solver's vectors no longer stay in the 256 MiB Infinity Cache between kernels)

@@ -198,6 +198,18 @@ struct MarchArgs {
                      // Infinity Cache instead of HBM (the z-halo planes were most of the kernel's 8.7 % over-fetch)
 };
 
+// y stored non-temporally or not, by a RUNTIME flag: the two stores must not look alike to the compiler -- an if / else of a
+// non-temporal and a plain store of the same value to the same address is merged into one plain store (what rounds 1-3
+// shipped: option spmv_nt_y did nothing).  The plain path goes through a laundered pointer.
+__device__ __forceinline__ void store_y(double2v *p, double2v v, int nt) {
+  if (nt) {
+    __builtin_nontemporal_store(v, p);
+  } else {
+    asm volatile("" : "+v"(p));
+    *p = v;
+  }
+}
+
 // ---- the launch interface ------------------------------------------------------------------------------------------
 // One kernel launch of the apply over all slices (slice_list == nullptr) or over one of a partitioned operator's
 // two lists.  Filled by launch_range (spmv.hip), consumed by the per-format units.

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kBlock) void spmv_canon_tile_kernel(SellArgs A, Can
       yi.y = __builtin_fma(alpha, __builtin_fma(ext_b, xi[t][g].y, acc_b), beta * xi[t][g].y);
       if (!done_flag) {
         double2v *yp = reinterpret_cast<double2v *>(yb + (size_t)(rc[t][g] << 3));
-        if (valid_b[t][g]) { if (A.nt_y) __builtin_nontemporal_store(yi, yp); else *yp = yi; }
+        if (valid_b[t][g]) store_y(yp, yi, A.nt_y);
         else if (valid_a[t][g]) y[rc[t][g]] = yi.x;  // the odd last row
       }
       if (DOT) {
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(kBlock) void cg_step_march_kernel(SellArgs A, March
       yi.x = __builtin_fma(alpha, __builtin_fma(ext_a, pc[g].x, acc_a), beta * pc[g].x);
       yi.y = __builtin_fma(alpha, __builtin_fma(ext_b, pc[g].y, acc_b), beta * pc[g].y);
       double2v *yp = reinterpret_cast<double2v *>(reinterpret_cast<char *>(z_out) + (size_t)(rcc[g] << 3));
-      if (vbc[g]) { if (A.nt_y) __builtin_nontemporal_store(yi, yp); else *yp = yi; }
+      if (vbc[g]) store_y(yp, yi, A.nt_y);
       else if (vac[g]) z_out[rcc[g]] = yi.x;
       yi.x = vac[g] ? yi.x : 0.0;
       yi.y = vbc[g] ? yi.y : 0.0;

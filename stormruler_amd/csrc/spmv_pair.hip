@@ -222,7 +222,7 @@ __global__ __launch_bounds__(kBlock) void spmv_canon_kernel(SellArgs A, CanonArg
     yi.y = (A.accumulate ? yo[g].y : beta * xi[g].y) + alpha * (acc_b + ext_b * xi[g].y);
     if (!done_flag) {
       double2v *yp = reinterpret_cast<double2v *>(yb + (size_t)(rc[g] << 3));
-      if (valid_b[g]) { if (A.nt_y) __builtin_nontemporal_store(yi, yp); else *yp = yi; }
+      if (valid_b[g]) store_y(yp, yi, A.nt_y);
       else if (valid_a[g]) y[rc[g]] = yi.x;  // the odd last row
     }
     if (DOT) {
