@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void multi_k(double2v *__restrict__ w, Ptrs<K>
 }
 
 static int *g_flag, *g_cnt;
-static int g_pool_vectors = 0;
+static int g_pool_vectors = 0, g_rotate_w = 0;
 static size_t g_pitch = 0;
 static double *g_part;
 template <int K, int U, int MODE, bool WRITE, bool PRO = false, int EPI = 0>
@@ -284,12 +284,17 @@ static double run(double2v *w, Ptrs<K> p0, long n2, int blocks, double *out) {
     Ptrs<K> p = p0;
     if (g_pool_vectors > 0)
       for (int j = 0; j < K; ++j)
-        p.q[j] = reinterpret_cast<const double2v *>(reinterpret_cast<const char *>(w) + (size_t)(1 + (rep * K + j) % g_pool_vectors) * g_pitch);
+        p.q[j] = reinterpret_cast<const double2v *>(reinterpret_cast<const char *>(w) + (size_t)(1 + (rep * (K + 1) + j) % g_pool_vectors) * g_pitch);
     return p;
   };
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((multi_k<K, U, MODE, WRITE, PRO, EPI>), dim3(blocks), dim3(256), 0, 0, w, ptrs(i), n2, out, g_flag, g_part, g_cnt);
+  // g_rotate_w: w too is another vector of the pool every launch (nothing is served by the Infinity Cache)
+  auto wptr = [&](int rep) {
+    if (!g_rotate_w || g_pool_vectors <= 0) return w;
+    return reinterpret_cast<double2v *>(reinterpret_cast<char *>(w) + (size_t)(1 + (rep * (K + 1) + K) % g_pool_vectors) * g_pitch);
+  };
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((multi_k<K, U, MODE, WRITE, PRO, EPI>), dim3(blocks), dim3(256), 0, 0, wptr(i), ptrs(i), n2, out, g_flag, g_part, g_cnt);
   hipEventRecord(e0, 0);
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((multi_k<K, U, MODE, WRITE, PRO, EPI>), dim3(blocks), dim3(256), 0, 0, w, ptrs(3 + i), n2, out, g_flag, g_part, g_cnt);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((multi_k<K, U, MODE, WRITE, PRO, EPI>), dim3(blocks), dim3(256), 0, 0, wptr(3 + i), ptrs(3 + i), n2, out, g_flag, g_part, g_cnt);
   hipEventRecord(e1, 0);
   hipEventSynchronize(e1);
   float ms;
@@ -383,11 +388,13 @@ int main(int argc, char **argv) {
   hipMemset(pool, 0, (size_t)(n * 8 + max_skew) * nvec);
   g_pitch = (size_t)(n * 8);
   library_kernels(pool, n, out);
-  for (long skew : {0L}) {
+  for (long skew : {0L, 0L}) {
+    printf("---- w %s\n", g_rotate_w ? "rotates through the pool too (no Infinity Cache reuse at all)" : "is the same vector every launch (as in a Gram-Schmidt sweep)");
     sweep<1>(pool, n, skew, out);
     sweep<2>(pool, n, skew, out);
     sweep<4>(pool, n, skew, out);
     sweep<8>(pool, n, skew, out);
+    g_rotate_w = 1;
   }
   return 0;
 }
