@@ -193,8 +193,7 @@ __global__ __launch_bounds__(kBlock) void lin3_kernel(int64_t n, double *y, cons
 
 // Sum over the 256 threads of a block, fixed order; result valid in thread 0.
 __device__ __forceinline__ double block_sum(double v, double *lds4) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+  v = wave_sum_down(v);  // (the __shfl_down tree's order and bits, without the LDS crossbar: wave_device.hpp)
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   __syncthreads();  // lds4 may still be read by a previous call
   if (lane == 0) lds4[wave] = v;
@@ -202,21 +201,39 @@ __device__ __forceinline__ double block_sum(double v, double *lds4) {
   return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
 }
 
+// KB sums at once, ONE pair of barriers: the same wave trees and the same (w0 + w1) + (w2 + w3) as block_sum, so the same
+// bits; sums[j] valid in every thread.
+template <int KB>
+__device__ __forceinline__ void block_sum_multi(const double (&v)[KB], double (*lds)[4], double (&sums)[KB]) {
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  double w[KB];
+#pragma unroll
+  for (int j = 0; j < KB; ++j) w[j] = wave_sum_down(v[j]);
+  __syncthreads();  // (the buffer may still be read by a previous call)
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < KB; ++j) lds[j][wave] = w[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < KB; ++j) sums[j] = (lds[j][0] + lds[j][1]) + (lds[j][2] + lds[j][3]);
+}
+
 template <int KB>
 __global__ __launch_bounds__(kBlock) void multi_dot_kernel(int64_t n, const double *__restrict__ a,
                                                            DotPtrs bs, double *__restrict__ partials,
                                                            const int *done, int nt) {
   if (done && *done) return;
-  __shared__ double lds4[4];
-  double acc[KB];
+  __shared__ double lds[KB][4];
+  double acc[KB], sums[KB];
 #pragma unroll
   for (int j = 0; j < KB; ++j) acc[j] = 0.0;
   multi_dot_accumulate<KB>(n, a, bs, nt, acc);
   const unsigned bx = (nt & 2) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+  block_sum_multi<KB>(acc, lds, sums);
+  if (threadIdx.x == 0) {
 #pragma unroll
-  for (int j = 0; j < KB; ++j) {
-    const double s = block_sum(acc[j], lds4);
-    if (threadIdx.x == 0) partials[(int64_t)j * gridDim.x + bx] = s;
+    for (int j = 0; j < KB; ++j) partials[(int64_t)j * gridDim.x + bx] = sums[j];
   }
 }
 
@@ -230,14 +247,13 @@ __global__ __launch_bounds__(kBlock) void multi_dot_ticket_kernel(int64_t n, con
                                                                   const int *done, int nt,
                                                                   unsigned long long *host_words, unsigned tag) {
   if (done && *done) return;
-  __shared__ double lds4[4];
+  __shared__ double lds[KB][4];
   double acc[KB];
 #pragma unroll
   for (int j = 0; j < KB; ++j) acc[j] = 0.0;
   multi_dot_accumulate<KB>(n, a, bs, nt, acc);
   double mine[KB], total[KB];
-#pragma unroll
-  for (int j = 0; j < KB; ++j) mine[j] = block_sum(acc[j], lds4);
+  block_sum_multi<KB>(acc, lds, mine);
   if (threadIdx.x >= kWave) return;
   const unsigned bx = (nt & 2) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
   if (ticket_reduce_wave0<KB>(tickets, mine, KB, bx, gridDim.x, total) && threadIdx.x == 0) {

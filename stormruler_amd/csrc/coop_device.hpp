@@ -4,6 +4,7 @@
 #pragma once
 
 #include "common.hpp"
+#include "wave_device.hpp"
 
 namespace storm {
 
@@ -93,9 +94,7 @@ __device__ __forceinline__ bool co_load_slot3(const char *slot, unsigned tag, do
   return w0.y == tag && w0.w == tag && w1.y == tag && w1.w == tag && w2.y == tag && w2.w == tag;
 }
 __device__ __forceinline__ double lat_wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-  return v;
+  return wave_sum_all(v);  // (= the xor butterfly's value in every lane, bit for bit: wave_device.hpp)
 }
 
 

@@ -4,6 +4,7 @@
 #pragma once
 
 #include "common.hpp"
+#include "wave_device.hpp"
 
 namespace storm {
 
@@ -75,8 +76,7 @@ __device__ inline void gmres_givens_update(SolverState *st, GmresDev g, int k, d
 }
 
 __device__ __forceinline__ double block_sum256(double v, double *lds4) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+  v = wave_sum_down(v);  // (the __shfl_down tree's order and bits, without the LDS crossbar: wave_device.hpp)
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   __syncthreads();
   if (lane == 0) lds4[wave] = v;

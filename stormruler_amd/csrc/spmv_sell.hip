@@ -240,8 +240,7 @@ __global__ __launch_bounds__(kBlock) void spmv_tail_kernel(int64_t n_tail, const
   double acc = 0.0;
   for (int64_t k = tail_ptr[t] + lane; k < tail_ptr[t + 1]; k += kWave)
     acc += tail_val[k] * (x[tail_col[k]] - xi);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, kWave);
+  acc = wave_sum_down(acc);
   if (lane == 0) y[r] += alpha * acc;
 }
 

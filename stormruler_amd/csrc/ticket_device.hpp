@@ -14,6 +14,7 @@
 //   * fixed folding order (lane i takes entry i, i + 64, ...; xor-shuffle tree): run-to-run reproducible.
 #pragma once
 #include "common.hpp"
+#include "wave_device.hpp"
 
 namespace storm {
 
@@ -55,9 +56,7 @@ __device__ __forceinline__ void ticket_publish(double *p, size_t stride, const d
   asm volatile("" : : "v"(seen) : "memory");
 }
 __device__ __forceinline__ double ticket_wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-  return v;
+  return wave_sum_all(v);  // (= the xor butterfly's value in every lane, bit for bit: wave_device.hpp)
 }
 
 // Wave 0 of every block calls this (all 64 lanes) with the block's partials `mine[0 .. k)` (k <= KMAX).

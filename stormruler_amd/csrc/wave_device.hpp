@@ -23,4 +23,36 @@ __device__ __forceinline__ double wave_sum_to_lane63(double v) {
   return v;
 }
 
+
+// The 64-lane sum in the order of the tree
+//     for (off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);          (result in lane 0)
+// -- the order every block / ticket fold of this library has had since round 1, so the bits of every reduction stay --
+// without the LDS crossbar: the two long-distance steps are gfx950's permlane swaps (lanes 0..31 receive lanes 32..63;
+// rows 0 and 2 receive rows 1 and 3), the four short ones DPP row shifts.  Lanes that take no part in lane 0's tree hold
+// garbage afterwards.  (tools/wave_sum_check.hip compares it with the __shfl_down tree bit for bit.)
+__device__ __forceinline__ double wave_sum_down(double v) {
+  {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    v += __hiloint2double((int)rh[1], (int)rl[1]);  // lanes 0..31: += lane + 32
+  }
+  {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v += __hiloint2double((int)rh[1], (int)rl[1]);  // lanes 0..15: += lane + 16
+  }
+  v += dpp_mov<0x108, 0xf>(v);  // row_shl:8
+  v += dpp_mov<0x104, 0xf>(v);  // row_shl:4
+  v += dpp_mov<0x102, 0xf>(v);  // row_shl:2
+  v += dpp_mov<0x101, 0xf>(v);  // row_shl:1
+  return v;
+}
+// ... and in every lane (the value of lane 0 of the tree above = of the xor-butterfly `v += __shfl_xor(v, off)`).
+__device__ __forceinline__ double wave_sum_all(double v) {
+  v = wave_sum_down(v);
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
 }  // namespace storm

@@ -17,7 +17,8 @@ using storm::double2v;
 
 
 
-// ---- the library's own kernels (text copied from csrc/solvers.hip when this tool was last edited: keep in step) --------
+// ---- the library's own kernels (text copied from csrc/solvers.hip and csrc/blas1.hip when this tool was last edited: keep
+// in step) ----------------------------------------------------------------------------------------------------------
 #include "ticket_device.hpp"
 #include "solver_device.hpp"
 #include "wave_device.hpp"
@@ -176,6 +177,85 @@ __global__ __launch_bounds__(kBlock) void mgs_multi_kernel(int64_t n, const int 
       for (int i = 0; i < j; ++i, ++g) v -= hn[i] * total[g];
       hn[j] = v;
       if (j < a.nc) *a.out[j] = v;
+    }
+  }
+}
+
+// (csrc/blas1.hip)
+// Sum over the 256 threads of a block, fixed order; result valid in thread 0.
+__device__ __forceinline__ double block_sum(double v, double *lds4) {
+  v = wave_sum_down(v);  // (the __shfl_down tree's order and bits, without the LDS crossbar: wave_device.hpp)
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  __syncthreads();  // lds4 may still be read by a previous call
+  if (lane == 0) lds4[wave] = v;
+  __syncthreads();
+  return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+}
+
+// KB sums at once, ONE pair of barriers: the same wave trees and the same (w0 + w1) + (w2 + w3) as block_sum, so the same
+// bits; sums[j] valid in every thread.
+template <int KB>
+__device__ __forceinline__ void block_sum_multi(const double (&v)[KB], double (*lds)[4], double (&sums)[KB]) {
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  double w[KB];
+#pragma unroll
+  for (int j = 0; j < KB; ++j) w[j] = wave_sum_down(v[j]);
+  __syncthreads();  // (the buffer may still be read by a previous call)
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < KB; ++j) lds[j][wave] = w[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < KB; ++j) sums[j] = (lds[j][0] + lds[j][1]) + (lds[j][2] + lds[j][3]);
+}
+
+template <int KB>
+__global__ __launch_bounds__(kBlock) void multi_dot_kernel(int64_t n, const double *__restrict__ a,
+                                                           DotPtrs bs, double *__restrict__ partials,
+                                                           const int *done, int nt) {
+  if (done && *done) return;
+  __shared__ double lds[KB][4];
+  double acc[KB], sums[KB];
+#pragma unroll
+  for (int j = 0; j < KB; ++j) acc[j] = 0.0;
+  multi_dot_accumulate<KB>(n, a, bs, nt, acc);
+  const unsigned bx = (nt & 2) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+  block_sum_multi<KB>(acc, lds, sums);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < KB; ++j) partials[(int64_t)j * gridDim.x + bx] = sums[j];
+  }
+}
+
+// The same with the reduction finished in the kernel (ticket_device.hpp): out[j] = <a, bs.b[j]>, one launch.
+// host_words != null: the last block also stores the sums into pinned HOST memory, each as two self-validating words
+// { tag | low half }, { tag | high half } (one atomic system-scope store each: no ordering between them and a flag to
+// rely on) -- the host polls them instead of copying and waiting on the stream.
+template <int KB>
+__global__ __launch_bounds__(kBlock) void multi_dot_ticket_kernel(int64_t n, const double *__restrict__ a, DotPtrs bs,
+                                                                  TicketArgs tickets, double *__restrict__ out,
+                                                                  const int *done, int nt,
+                                                                  unsigned long long *host_words, unsigned tag) {
+  if (done && *done) return;
+  __shared__ double lds[KB][4];
+  double acc[KB];
+#pragma unroll
+  for (int j = 0; j < KB; ++j) acc[j] = 0.0;
+  multi_dot_accumulate<KB>(n, a, bs, nt, acc);
+  double mine[KB], total[KB];
+  block_sum_multi<KB>(acc, lds, mine);
+  if (threadIdx.x >= kWave) return;
+  const unsigned bx = (nt & 2) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+  if (ticket_reduce_wave0<KB>(tickets, mine, KB, bx, gridDim.x, total) && threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+      out[j] = total[j];
+      if (host_words) {
+        const unsigned long long t = (unsigned long long)tag << 32;
+        __hip_atomic_store(host_words + 2 * j, t | (unsigned)__double2loint(total[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_words + 2 * j + 1, t | (unsigned)__double2hiint(total[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
 }
@@ -369,8 +449,26 @@ static void library_kernels(char *pool, long n, double *out) {
     multi(std::integral_constant<int, 2>{}, 16384);
     multi(std::integral_constant<int, 1>{}, 32768);
   }
+  for (int nt : {1, 0})
+    for (int nb : {8192, 4096, 2048}) {
+      DotPtrs bp;
+      const double s8 = time_launches(24, [&](int r) {
+        for (int j = 0; j < 8; ++j) bp.b[j] = vec(9 * r + 1 + j);
+        hipLaunchKernelGGL(multi_dot_ticket_kernel<8>, dim3(nb), dim3(256), 0, 0, (int64_t)n, vec(9 * r), bp, t, h, g_flag, nt, (unsigned long long *)nullptr, 0u);
+      });
+      const double s1 = time_launches(24, [&](int r) {
+        for (int j = 0; j < 8; ++j) bp.b[j] = vec(2 * r + 1);
+        hipLaunchKernelGGL(multi_dot_ticket_kernel<1>, dim3(nb), dim3(256), 0, 0, (int64_t)n, vec(2 * r), bp, t, h, g_flag, nt, (unsigned long long *)nullptr, 0u);
+      });
+      const double s0 = time_launches(24, [&](int r) {
+        for (int j = 0; j < 8; ++j) bp.b[j] = vec(r);
+        hipLaunchKernelGGL(multi_dot_ticket_kernel<1>, dim3(nb), dim3(256), 0, 0, (int64_t)n, vec(r), bp, t, h, g_flag, nt, (unsigned long long *)nullptr, 0u);
+      });
+      printf("multi_dot_ticket_kernel nt=%d blocks=%5d: k=8 %.1f us %.2f TB/s | dot %.1f us %.2f TB/s | norm2 %.1f us %.2f TB/s\n", nt, nb, s8 * 1e6,
+             72.0 * n / s8 / 1e12, s1 * 1e6, 16.0 * n / s1 / 1e12, s0 * 1e6, 8.0 * n / s0 / 1e12);
+    }
   fflush(stdout);
-  (void)n2, (void)out;
+  (void)out;
 }
 
 int main(int argc, char **argv) {
