@@ -9,7 +9,7 @@ TAG=${1:-round}
 OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-python3 bench.py --skip-permuted 2>/dev/null | tail -1 > "$OUT/${TAG}_bench.json"
+python3 bench.py 2>/dev/null | tail -1 > "$OUT/${TAG}_bench.json"
 rm -rf /tmp/prof_stats /tmp/prof_fetch /tmp/prof_write
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 bench.py --cpu-iters 0 --skip-blas1 --traffic off --skip-permuted --skip-unstructured --skip-configs 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_under_rocprof.json"
 cp "$(find /tmp/prof_stats -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_kernel_stats.csv"
