@@ -910,8 +910,8 @@ static int check_solve_args(const storm_hip_op *op, const storm_hip_vec *b, stor
 
 struct VecPool {  // work vectors: re-assigned (zeroed) on every solve like SolverCg.hpp:57-59
   std::vector<storm_hip_vec *> v;
-  ~VecPool() {
-    for (auto *p : v) storm_hip_vec_destroy(p);
+  ~VecPool() {  // (in reverse: the context's pool is a stack -- the next solve finds every vector in its old role)
+    for (size_t i = v.size(); i-- > 0;) storm_hip_vec_destroy(v[i]);
   }
   // zero = false: the solver writes every owned row of these vectors before it reads it (context.hip, vec_create_work)
   int make(const storm_hip_vec *like, int count, bool zero = true) {

@@ -8,6 +8,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <type_traits>
 #include <vector>
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(256) void multi_k(double2v *__restrict__ w, Ptrs<K>
 
 static int *g_flag, *g_cnt;
 static int g_pool_vectors = 0, g_rotate_w = 0;
-static size_t g_pitch = 0;
+static size_t g_pitch = 0, g_pool_bytes = 0;
 static double *g_part;
 template <int K, int U, int MODE, bool WRITE, bool PRO = false, int EPI = 0>
 static double run(double2v *w, Ptrs<K> p0, long n2, int blocks, double *out) {
@@ -471,6 +472,27 @@ static void library_kernels(char *pool, long n, double *out) {
   (void)out;
 }
 
+// Does the DISTANCE between the vectors matter at the megabyte scale (the library's vectors are separate allocations of
+// 128 MiB + a little, 2 MiB aligned)?  K + 1 vectors `pitch` apart, all read at the same index, one written.
+template <int K>
+static void pitch_sweep(char *pool, long n, double *out) {
+  const long n2 = n / 2;
+  const int b2 = (int)((n2 + 511) / 512);
+  const int pool_vectors = g_pool_vectors;
+  g_pool_vectors = 0;  // (fixed vectors: the question is their placement)
+  for (long extra_kib : {0L, 2L, 64L, 2048L, 4096L, 6144L, 8192L, 16384L, 32768L, 49152L, 65536L, 98304L}) {
+    const long pitch = n * 8 + extra_kib * 1024;
+    if ((size_t)pitch * (K + 1) > g_pool_bytes) continue;
+    double2v *w = reinterpret_cast<double2v *>(pool);
+    Ptrs<K> p;
+    for (int j = 0; j < K; ++j) p.q[j] = reinterpret_cast<const double2v *>(pool + (j + 1) * pitch);
+    printf("K=%d pitch = vector + %6ld KiB: rw 2 ahead %.2f  1 trip %.2f | read-only 4 trips %.2f TB/s\n", K, extra_kib,
+           run<K, 2, 1, true>(w, p, n2, b2, out), run<K, 1, 0, true>(w, p, n2, 2 * b2, out), run<K, 4, 0, false>(w, p, n2, b2 / 2, out));
+    fflush(stdout);
+  }
+  g_pool_vectors = pool_vectors;
+}
+
 int main(int argc, char **argv) {
   const long n = argc > 1 ? atol(argv[1]) : (1L << 24);  // doubles per vector (256^3)
   const long max_skew = 1 << 17;
@@ -484,6 +506,12 @@ int main(int argc, char **argv) {
   hipMalloc((void **)&g_cnt, 4 * 16 * 2049), hipMemset(g_cnt, 0, 4 * 16 * 2049);
   hipMalloc((void **)&g_part, 8 * 12 * 40000);
   hipMemset(pool, 0, (size_t)(n * 8 + max_skew) * nvec);
+  g_pool_bytes = (size_t)(n * 8 + max_skew) * nvec;
+  if (argc > 3 && !strcmp(argv[3], "pitch")) {
+    pitch_sweep<3>(pool, n, out);
+    pitch_sweep<6>(pool, n, out);
+    return 0;
+  }
   g_pitch = (size_t)(n * 8);
   library_kernels(pool, n, out);
   for (long skew : {0L, 0L}) {
