@@ -271,6 +271,12 @@ int storm_hip_op_create_csr(storm_hip_ctx *ctx, int64_t n_rows, int64_t n_halo,
  *              2 always, 1 for vectors of at least blas1_nt_rows rows (longer vectors do not survive in the Infinity
  *              Cache between two kernels of a solve anyway; shorter ones do, and non-temporal accesses cost 3 - 7 %
  *              there).  Same values either way;
+ *   vec_arena (1), vec_arena_slots (8), vec_arena_skew_kib (0): the vectors of one size (of at least 1 MiB) are slots of
+ *              ONE physically contiguous allocation, a fixed distance apart (the smallest distance = 2 MiB modulo 4 MiB
+ *              that holds the vector, + skew) -- separate allocations land 132 MiB apart at 256^3, a multiple of 4 MiB,
+ *              which costs a multi-stream kernel 3 - 4 %; a released vector returns to the context's pool (a stack:
+ *              a solver finds each work vector in its old role), arenas are freed with the context;
+ *   vec_contiguous (0): vectors outside arenas in physically contiguous memory too;
  *   mgs_steps (4): modified-Gram-Schmidt steps per pass over w in GMRES's orthogonalisation on the kernel-per-statement
  *              path (2, 3, 4; coefficients of a pass follow from bilinearity);
  *   resident_path (1), resident_min_rows (0), resident_max_rows (2^22), resident_max_planes (12), resident_planes (0 =

@@ -150,6 +150,7 @@ struct storm_hip_ctx {
   int64_t opt_spmv_tile_lds_pad = 0;   // A/B knob: extra dynamic LDS per block of the tiled kernel (fewer resident tiles per CU)
   int64_t opt_spmv_canon_tile_min_rows = (int64_t)1 << 20;  // ... for operators of at least this many rows
   int64_t opt_spmv_canon_tile = 2;   // format 4 on a lattice (offsets -b,-a,-1,+1,+a,+b): tiles of 1024 rows x this many planes (2, or 4) with the +-a / +-1 neighbours from LDS and the +-b ones from registers; 0 = the plain kernel.  Measured at 256^3 (profiles/r03f, r03g): CG step 242 (2 planes) / 247 (4) us per iteration, BiCGStab 496 / 510
+  int64_t opt_vec_contiguous = 0;     // vectors in physically contiguous device memory (hipDeviceMallocContiguous)
   int64_t opt_mgs_steps = 4;          // throughput-path Gram-Schmidt: steps per pass over w (2: mgs_pair_kernel; 3, 4: mgs_multi_kernel)
   int64_t opt_coop_mgs_pairs = 1;    // cooperative Gram-Schmidt chain: two steps per synchronisation point
   int64_t opt_coop_dense = 1;        // the multi-step Gram-Schmidt chain's all-reduce with dense value-major slots (0: the two-level form; 2: the resident kernels too)
@@ -208,6 +209,18 @@ struct storm_hip_ctx {
   // every init, SolverCg.hpp:57-59); hipMalloc + hipFree of three 134 MB vectors cost ~7 ms per solve.
   // Reuse is ordered by the compute stream.  Bounded by opt_pool_bytes; freed with the context.
   std::vector<std::pair<size_t, double *>> pool;
+  // Arenas: the vectors of one size are slots of ONE (physically contiguous) allocation, `pitch` bytes apart -- where a
+  // solver's vectors lie relative to each other decides a few per cent of a multi-stream kernel's rate, and separate
+  // allocations land wherever the driver puts them (context.hip: vec_create_impl; tools/placement_probe.py).
+  struct VecArena {
+    char *base = nullptr;
+    size_t bytes = 0, pitch = 0;  // size class (= storm_hip_vec::bytes), distance between slots
+    int slots = 0, used = 0;
+  };
+  std::vector<VecArena> arenas;
+  int64_t opt_vec_arena = 1;            // 0: every vector an allocation of its own
+  int64_t opt_vec_arena_slots = 8;
+  int64_t opt_vec_arena_skew_kib = 0;   // pitch = the vector rounded up to 2 MiB + this
   size_t pool_bytes = 0;
   int64_t opt_pool_bytes = (int64_t)16 << 30;
   std::vector<hipEvent_t> prof_events;  // pairs (start, stop), grown on demand

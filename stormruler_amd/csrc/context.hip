@@ -23,6 +23,8 @@ void set_error(const char *fmt, ...) {
 
 using namespace storm;
 
+static void pool_release(storm_hip_ctx *c);
+
 extern "C" {
 
 int storm_hip_abi_version(void) { return STORM_HIP_ABI_VERSION; }
@@ -91,7 +93,8 @@ int storm_hip_ctx_destroy(storm_hip_ctx *c) {
     (void)hipHostFree(r.h_ring);
   }
   for (auto &ev : c->prof_events) (void)hipEventDestroy(ev);
-  for (auto &pb : c->pool) (void)hipFree(pb.second);
+  pool_release(c);
+  for (auto &a : c->arenas) (void)hipFree(a.base);
   (void)hipFree(c->d_partials);
   if (c->d_gmres) (void)hipFree(c->d_gmres);
   (void)hipFree(c->d_partials2);
@@ -159,6 +162,10 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "coop_mgs_min_rows")) c->opt_coop_mgs_min_rows = value;
   else if (!strcmp(key, "coop_mgs_pairs")) c->opt_coop_mgs_pairs = value;
   else if (!strcmp(key, "mgs_steps")) c->opt_mgs_steps = value;
+  else if (!strcmp(key, "vec_contiguous")) c->opt_vec_contiguous = value;
+  else if (!strcmp(key, "vec_arena")) c->opt_vec_arena = value;
+  else if (!strcmp(key, "vec_arena_slots")) c->opt_vec_arena_slots = value;
+  else if (!strcmp(key, "vec_arena_skew_kib")) c->opt_vec_arena_skew_kib = value;
   else if (!strcmp(key, "coop_mgs_lds")) c->opt_coop_mgs_lds = value;
   else if (!strcmp(key, "coop_mgs_quad")) c->opt_coop_mgs_quad = value;
   else if (!strcmp(key, "coop_dense")) c->opt_coop_dense = value;
@@ -183,8 +190,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
     c->opt_pool_bytes = value;
     if ((int64_t)c->pool_bytes > value) {  // trim now
       (void)hipStreamSynchronize(c->stream);
-      for (auto &pb : c->pool) (void)hipFree(pb.second);
-      c->pool.clear(), c->pool_bytes = 0;
+      pool_release(c);
     }
   }
   else if (!strcmp(key, "spmv_spw")) c->opt_spmv_spw = value;
@@ -431,6 +437,54 @@ int state_init(storm_hip_ctx *c, SolverState *d_state, double abs_tol, double re
   return STORM_HIP_OK;
 }
 }  // namespace storm
+static bool in_arena(const storm_hip_ctx *c, const void *p) {
+  for (const auto &a : c->arenas)
+    if ((const char *)p >= a.base && (const char *)p < a.base + (size_t)a.slots * a.pitch) return true;
+  return false;
+}
+// Give the pooled storage back to the driver (slots of an arena stay pooled: an arena is freed with the context).
+static void pool_release(storm_hip_ctx *c) {
+  std::vector<std::pair<size_t, double *>> keep;
+  size_t kept = 0;
+  for (auto &pb : c->pool) {
+    if (in_arena(c, pb.second)) keep.push_back(pb), kept += pb.first;
+    else (void)hipFree(pb.second);
+  }
+  c->pool.swap(keep), c->pool_bytes = kept;
+}
+// A slot of an arena of this size class (a new arena when all are taken); null: no arena (too small, too large, off,
+// or the allocation failed) -- the caller allocates the vector by itself.
+static double *arena_take(storm_hip_ctx *c, size_t bytes) {
+  if (c->opt_vec_arena == 0 || bytes < ((size_t)1 << 20)) return nullptr;
+  // The distance between two vectors: the smallest one = 2 MiB (mod 4 MiB) that holds the vector.  Measured on the
+  // 256^3 CG (tools/arena_sweep.py, vectors of 128 MiB + 288 B): 130, 131, 133, 134, 138, 142 MiB apart 4 500 - 4 550
+  // it/s; 132 and 136 MiB apart -- multiples of 4 MiB; 132 MiB is where separate hipMalloc calls put them -- 4 360 - 4 380.
+  constexpr size_t kMiB = (size_t)1 << 20;
+  size_t pitch = (bytes + 4 * kMiB - 1) / (4 * kMiB) * (4 * kMiB);  // a multiple of 4 MiB
+  pitch = pitch - 2 * kMiB >= bytes ? pitch - 2 * kMiB : pitch + 2 * kMiB;
+  pitch += (size_t)c->opt_vec_arena_skew_kib * 1024;
+  int slots = (int)std::max<int64_t>(2, c->opt_vec_arena_slots);
+  for (auto &a : c->arenas) {
+    if (a.bytes != bytes || a.pitch != pitch) continue;
+    if (a.used < a.slots) return reinterpret_cast<double *>(a.base + (size_t)(a.used++) * pitch);
+    slots = std::min(64, std::max(slots, 2 * a.slots));  // (a solver with a long basis: the next arena twice as long)
+  }
+  while (slots > 1 && (size_t)slots * pitch > ((size_t)12 << 30)) slots /= 2;  // (an arena of at most 12 GiB)
+  if (slots < 2) return nullptr;
+  storm_hip_ctx::VecArena a;
+  a.bytes = bytes, a.pitch = pitch, a.slots = slots, a.used = 1;
+  const size_t total = (size_t)slots * pitch;
+  if (hipExtMallocWithFlags((void **)&a.base, total, hipDeviceMallocContiguous) != hipSuccess) {
+    (void)hipGetLastError();
+    if (hipMalloc((void **)&a.base, total) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+  }
+  c->arenas.push_back(a);
+  return reinterpret_cast<double *>(a.base);
+}
+
 static int vec_create_impl(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, storm_hip_vec **out, int zero_mode) {
   STORM_REQUIRE(c && out, "vec_create: null argument");
   *out = nullptr;
@@ -461,13 +515,21 @@ static int vec_create_impl(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, st
       break;
     }
   }
+  // (option vec_contiguous: physically contiguous storage -- the largest page-table fragments the driver can give)
+  auto device_malloc = [&](double **p) {
+    if (c->opt_vec_contiguous != 0 && bytes >= ((size_t)1 << 21)) {
+      if (hipExtMallocWithFlags((void **)p, bytes, hipDeviceMallocContiguous) == hipSuccess) return hipSuccess;
+      (void)hipGetLastError();
+    }
+    return hipMalloc(p, bytes);
+  };
+  if (base == nullptr) base = arena_take(c, bytes);
   if (base == nullptr) {
-    e = hipMalloc(&base, bytes);
+    e = device_malloc(&base);
     if (e != hipSuccess && !c->pool.empty()) {  // give the pooled storage back and retry
       (void)hipStreamSynchronize(c->stream);
-      for (auto &pb : c->pool) (void)hipFree(pb.second);
-      c->pool.clear(), c->pool_bytes = 0;
-      e = hipMalloc(&base, bytes);
+      pool_release(c);
+      e = device_malloc(&base);
     }
   }
   if (e != hipSuccess) {
@@ -485,7 +547,7 @@ static int vec_create_impl(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, st
     if (e == hipSuccess && bytes > tail0) e = hipMemsetAsync(reinterpret_cast<char *>(v->base) + tail0, 0, bytes - tail0, c->stream);
   }
   if (e != hipSuccess) {
-    (void)hipFree(v->base);
+    if (!in_arena(c, v->base)) (void)hipFree(v->base);
     delete v;
     STORM_FAIL(STORM_HIP_E_HIP, "vec_create: memset failed: %s", hipGetErrorString(e));
   }
@@ -503,7 +565,7 @@ int storm_hip_vec_create_like(const storm_hip_vec *other, storm_hip_vec **out) {
 int storm_hip_vec_destroy(storm_hip_vec *v) {
   if (!v) return STORM_HIP_OK;
   storm_hip_ctx *c = v->ctx;
-  if (v->base && (int64_t)(c->pool_bytes + v->bytes) <= c->opt_pool_bytes) {
+  if (v->base && ((int64_t)(c->pool_bytes + v->bytes) <= c->opt_pool_bytes || in_arena(c, v->base))) {
     // later users of this storage are ordered behind its pending kernels by the compute stream; the
     // comm stream only touches a vector between two events of one SpMV (comm.hip)
     c->pool.emplace_back(v->bytes, v->base);

@@ -113,3 +113,34 @@ def test_gram_schmidt_pass_widths_agree_to_rounding(env, shape):
         assert np.max(np.abs(hs / h2 - 1.0)) < 1e-8, steps
         assert np.linalg.norm(runs[steps][1] - runs[2][1]) <= 1e-9 * np.linalg.norm(runs[2][1]), steps
     mat.close()
+
+
+def test_vector_arenas_change_where_vectors_lie_and_nothing_else():
+    """Option vec_arena (context.hip): vectors of one size are slots of one allocation.  Same solves bit for bit; more
+    vectors than an arena has slots, the pool trimmed under them, release in any order: all fine."""
+    from stormruler_amd import api, mesh
+
+    g = mesh.structured_box(64)  # 2 MiB vectors: arena-backed
+    b_host = 1.0 + 0.25 * np.sin(0.05 * np.arange(g.n_cells))
+    runs = []
+    for arena in (0, 1):
+        ctx = api.Context(0)
+        ctx.set_option("vec_arena", arena)
+        ctx.set_option("resident_path", 0)
+        ctx.set_option("latency_path", 0)
+        mat = api.StencilMatrix.from_face_graph(ctx, g)
+        for cls, iters, knobs in ((api.CgSolver, 40, {}), (api.GmresSolver, 70, {"num_inner_iterations": 30})):
+            runs.append(_history(api, ctx, cls, mat, b_host, iters, **knobs))
+        vs = [api.DeviceVector.from_numpy(ctx, b_host + k) for k in range(21)]  # 8 + 16 slots: two arenas and a third begun
+        ctx.set_option("pool_bytes", 0)  # trim: nothing of an arena may be handed back to the driver
+        for k in (20, 0, 7, 13):
+            assert np.array_equal(vs[k].to_numpy(), b_host + k)
+        del vs[3:17]
+        ws = [api.DeviceVector.from_numpy(ctx, b_host - k) for k in range(9)]  # released slots come back
+        assert all(np.array_equal(w.to_numpy(), b_host - k) for k, w in enumerate(ws))
+        assert np.array_equal(vs[-1].to_numpy(), b_host + 20)
+        del ws, vs
+        mat.close()
+        ctx.close()
+    for (h0, x0), (h1, x1) in zip(runs[:2], runs[2:]):
+        assert np.array_equal(h0, h1) and np.array_equal(x0, x1)

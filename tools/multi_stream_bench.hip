@@ -480,7 +480,10 @@ static void pitch_sweep(char *pool, long n, double *out) {
   const int b2 = (int)((n2 + 511) / 512);
   const int pool_vectors = g_pool_vectors;
   g_pool_vectors = 0;  // (fixed vectors: the question is their placement)
-  for (long extra_kib : {0L, 2L, 64L, 2048L, 4096L, 6144L, 8192L, 16384L, 32768L, 49152L, 65536L, 98304L}) {
+  std::vector<long> extras = {0L, 2L, 64L};
+  for (long m = 1; m <= 40; ++m) extras.push_back(m * 1024);
+  for (long m : {48L, 64L, 96L}) extras.push_back(m * 1024);
+  for (long extra_kib : extras) {
     const long pitch = n * 8 + extra_kib * 1024;
     if ((size_t)pitch * (K + 1) > g_pool_bytes) continue;
     double2v *w = reinterpret_cast<double2v *>(pool);
@@ -500,7 +503,13 @@ int main(int argc, char **argv) {
   const int nvec = 1 + (g_pool_vectors > 8 ? g_pool_vectors : 8);
   char *pool;
   double *out;
-  if (hipMalloc((void **)&pool, (size_t)(n * 8 + max_skew) * nvec) != hipSuccess) return 1;
+  const bool contiguous = argc > 4 && atoi(argv[4]) != 0;  // physically contiguous pool (hipDeviceMallocContiguous)
+  if (contiguous) {
+    if (hipExtMallocWithFlags((void **)&pool, (size_t)(n * 8 + max_skew) * nvec, hipDeviceMallocContiguous) != hipSuccess) return 2;
+    printf("(physically contiguous pool)\n");
+  } else if (hipMalloc((void **)&pool, (size_t)(n * 8 + max_skew) * nvec) != hipSuccess) {
+    return 1;
+  }
   hipMalloc((void **)&out, 8);
   hipMalloc((void **)&g_flag, 4), hipMemset(g_flag, 0, 4);
   hipMalloc((void **)&g_cnt, 4 * 16 * 2049), hipMemset(g_cnt, 0, 4 * 16 * 2049);
@@ -508,7 +517,6 @@ int main(int argc, char **argv) {
   hipMemset(pool, 0, (size_t)(n * 8 + max_skew) * nvec);
   g_pool_bytes = (size_t)(n * 8 + max_skew) * nvec;
   if (argc > 3 && !strcmp(argv[3], "pitch")) {
-    pitch_sweep<3>(pool, n, out);
     pitch_sweep<6>(pool, n, out);
     return 0;
   }

@@ -8,7 +8,16 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes  # noqa: E402
+
 from stormruler_amd import api, mesh  # noqa: E402
+from stormruler_amd._lib import lib  # noqa: E402
+
+
+def addr(v):
+    p = ctypes.c_void_p()
+    lib.storm_hip_vec_device_ptr(v._h, ctypes.byref(p))
+    return p.value
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 300
@@ -35,10 +44,12 @@ out = {"fresh_x": [], "same_x": [], "iters": iters}
 keep = []
 for k in range(12):
     x = api.DeviceVector(ctx, g.n_cells)
-    out["fresh_x"].append(round(one(x), 1))
+    out["fresh_x"].append([round(one(x), 1), hex(addr(x))])
     if k % 3 == 0:
         keep.append(x)  # (every third stays allocated: the next one lands elsewhere)
 x = api.DeviceVector(ctx, g.n_cells)
+out["same_x_address"] = hex(addr(x))
+out["b_address"] = hex(addr(b))
 for k in range(12):
     out["same_x"].append(round(one(x), 1))
 for odd in (iters + 1, iters):
