@@ -219,6 +219,7 @@ struct storm_hip_ctx {
   };
   std::vector<VecArena> arenas;
   int64_t opt_vec_arena = 1;            // 0: every vector an allocation of its own
+  int64_t opt_pack_arena = 0;           // an operator's records in a slot of its vectors' arena (where they fit)
   int64_t opt_vec_arena_slots = 8;
   int64_t opt_vec_arena_skew_kib = 0;   // pitch = the vector rounded up to 2 MiB + this
   size_t pool_bytes = 0;
@@ -404,6 +405,8 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
 int spmv_grid_blocks(const storm_hip_op *op);
 bool spmv_can_fuse_cg(const storm_hip_op *op);
 int op_upload_slice_lists(storm_hip_op *op);
+void *vec_slot_take(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, size_t bytes);  // context.hip
+bool vec_slot_give(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, void *p);
 
 // latency.hip
 int op_make_latency_copy(storm_hip_op *op, int64_t n, int64_t n_halo, const std::vector<int64_t> &row_ptr,

@@ -164,6 +164,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "mgs_steps")) c->opt_mgs_steps = value;
   else if (!strcmp(key, "vec_contiguous")) c->opt_vec_contiguous = value;
   else if (!strcmp(key, "vec_arena")) c->opt_vec_arena = value;
+  else if (!strcmp(key, "pack_arena")) c->opt_pack_arena = value;
   else if (!strcmp(key, "vec_arena_slots")) c->opt_vec_arena_slots = value;
   else if (!strcmp(key, "vec_arena_skew_kib")) c->opt_vec_arena_skew_kib = value;
   else if (!strcmp(key, "coop_mgs_lds")) c->opt_coop_mgs_lds = value;
@@ -484,6 +485,32 @@ static double *arena_take(storm_hip_ctx *c, size_t bytes) {
   c->arenas.push_back(a);
   return reinterpret_cast<double *>(a.base);
 }
+
+namespace storm {
+// Storage for an operator's records from the arena of the vectors it is applied to (spmv_build.hip): `bytes` must not
+// exceed such a vector's allocation.  Null: no arena -- the caller allocates.  Give it back with vec_slot_give.
+size_t vec_alloc_bytes(int64_t n_owned, int64_t n_halo) { return sizeof(double) * (size_t)(kVecGuard + (n_owned + n_halo + 3) / 4 * 4 + 4); }
+void *vec_slot_take(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, size_t bytes) {
+  const size_t vb = vec_alloc_bytes(n_owned, n_halo);
+  if (bytes > vb) return nullptr;
+  for (size_t i = c->pool.size(); i-- > 0;) {
+    if (c->pool[i].first == vb && in_arena(c, c->pool[i].second)) {
+      void *p = c->pool[i].second;
+      c->pool_bytes -= vb;
+      c->pool.erase(c->pool.begin() + (std::ptrdiff_t)i);
+      return p;
+    }
+  }
+  return arena_take(c, vb);
+}
+bool vec_slot_give(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, void *p) {
+  if (p == nullptr || !in_arena(c, p)) return false;
+  const size_t vb = vec_alloc_bytes(n_owned, n_halo);
+  c->pool.emplace_back(vb, (double *)p);
+  c->pool_bytes += vb;
+  return true;
+}
+}  // namespace storm
 
 static int vec_create_impl(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, storm_hip_vec **out, int zero_mode) {
   STORM_REQUIRE(c && out, "vec_create: null argument");

@@ -382,7 +382,7 @@ int storm_hip_op_destroy(storm_hip_op *op) {
   (void)hipFree(op->d_interior);
   (void)hipFree(op->d_boundary);
   (void)hipFree(op->d_slice_off);
-  (void)hipFree(op->d_pack);
+  if (!(op->ctx && vec_slot_give(op->ctx, op->n_rows, op->n_halo, op->d_pack))) (void)hipFree(op->d_pack);
   (void)hipFree(op->d_bnd_pack);
   (void)hipFree(op->d_types);
   (void)hipFree(op->d_dict);

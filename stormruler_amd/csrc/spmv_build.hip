@@ -67,6 +67,22 @@ static int upload(T **dst, const std::vector<T> &src, int64_t *bytes) {
   return STORM_HIP_OK;
 }
 
+// The records of a paired-row operator: in a slot of the arena of the vectors the operator is applied to, where they fit
+// (8 B/row records are 288 bytes shorter than such a vector) -- their distance from the vectors is then the arena's.
+static int upload_pack(storm_hip_op *op, const std::vector<char> &src, int64_t *bytes) {
+  storm_hip_ctx *c = op->ctx;
+  if (c->opt_pack_arena != 0 && !src.empty()) {
+    void *p = vec_slot_take(c, op->n_rows, op->n_halo, src.size());
+    if (p != nullptr) {
+      op->d_pack = (char *)p;
+      HIP_TRY(hipMemcpy(op->d_pack, src.data(), src.size(), hipMemcpyHostToDevice));
+      *bytes += (int64_t)src.size();
+      return STORM_HIP_OK;
+    }
+  }
+  return upload(&op->d_pack, src, bytes);
+}
+
 // The distinct fp64 bit patterns of an operator, while there are at most 256 of them.
 struct ValueDict {
   std::vector<uint64_t> values;               // index -> bit pattern
@@ -447,7 +463,7 @@ static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vect
     std::vector<int64_t> one_zero(1, 0);
     std::vector<double> no_d;
     if ((st3 = upload(&op->d_dict, vtab, &bytes3)) || (st3 = upload(&op->d_offs, otab, &bytes3)) ||
-        (st3 = upload(&op->d_slice_off, goff, &bytes3)) || (st3 = upload(&op->d_pack, pair_pack, &bytes3)) ||
+        (st3 = upload(&op->d_slice_off, goff, &bytes3)) || (st3 = upload_pack(op, pair_pack, &bytes3)) ||
         (st3 = upload(&op->d_tail_row, no_i, &bytes3)) || (st3 = upload(&op->d_tail_ptr, one_zero, &bytes3)) ||
         (st3 = upload(&op->d_tail_col, no_i, &bytes3)) || (st3 = upload(&op->d_tail_val, no_d, &bytes3))) {
       storm_hip_op_destroy(op);
