@@ -165,6 +165,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "vec_contiguous")) c->opt_vec_contiguous = value;
   else if (!strcmp(key, "vec_arena")) c->opt_vec_arena = value;
   else if (!strcmp(key, "pack_arena")) c->opt_pack_arena = value;
+  else if (!strcmp(key, "vec_arena_contiguous")) c->opt_vec_arena_contiguous = value;
   else if (!strcmp(key, "vec_arena_slots")) c->opt_vec_arena_slots = value;
   else if (!strcmp(key, "vec_arena_skew_kib")) c->opt_vec_arena_skew_kib = value;
   else if (!strcmp(key, "coop_mgs_lds")) c->opt_coop_mgs_lds = value;
@@ -475,7 +476,7 @@ static double *arena_take(storm_hip_ctx *c, size_t bytes) {
   storm_hip_ctx::VecArena a;
   a.bytes = bytes, a.pitch = pitch, a.slots = slots, a.used = 1;
   const size_t total = (size_t)slots * pitch;
-  if (hipExtMallocWithFlags((void **)&a.base, total, hipDeviceMallocContiguous) != hipSuccess) {
+  if (c->opt_vec_arena_contiguous == 0 || hipExtMallocWithFlags((void **)&a.base, total, hipDeviceMallocContiguous) != hipSuccess) {
     (void)hipGetLastError();
     if (hipMalloc((void **)&a.base, total) != hipSuccess) {
       (void)hipGetLastError();
