@@ -13,6 +13,7 @@
 // state `check_lag` iterations behind; once the device has set `done`, every later kernel
 // returns at its first instruction, so the result is exactly the reference's: same
 // iteration count, x frozen at the iteration that met the tolerance.
+#include <algorithm>
 #include <cmath>
 #include <cstddef>
 #include <cstring>
@@ -1179,7 +1180,12 @@ int solve_cg_body(const FusedSolveArgs &args) {
   // (r: the init apply; p: init_residual's copy; z: the first SpMV -- all before any read; the fused step's second p)
   const bool may_fuse_step = c->opt_cg_fuse != 0 && spmv_can_fuse_cg(op);
   STORM_TRY(pool.make(x, may_fuse_step ? 4 : 3, false));
-  double *p = pool.v[v0]->d, *r = pool.v[v0 + 1]->d, *z = pool.v[v0 + 2]->d;
+  // (option cg_roles: which of the four work vectors -- consecutive slots of the context's arena -- plays p, r, z and the
+  //  second direction vector: the k-th permutation of (0, 1, 2, 3) in lexicographic order; an A/B knob for placement)
+  int role[4] = {0, 1, 2, 3};
+  for (int64_t k = 0; k < c->opt_cg_roles % 24; ++k) std::next_permutation(role, role + 4);
+  if (!may_fuse_step) role[0] = 0, role[1] = 1, role[2] = 2;
+  double *p = pool.v[v0 + role[0]]->d, *r = pool.v[v0 + role[1]]->d, *z = pool.v[v0 + role[2]]->d;
   const int nbv = vec_blocks(c, n);
 
   // init: r = b - A x; p = r; gamma = <r,r>          SolverCg.hpp:75-85
@@ -1220,7 +1226,7 @@ int solve_cg_body(const FusedSolveArgs &args) {
   const bool fuse_step = c->opt_cg_fuse != 0 && c->opt_fuse_dot != 0 && spmv_can_fuse_cg(op) &&
                          (rccl ? true : ((c->comm == nullptr || ipc) && tick && !tick_spmv));
   double *p_alt = nullptr;
-  if (fuse_step) p_alt = pool.v[v0 + 3]->d, ++c->n_cg_fused_steps;
+  if (fuse_step) p_alt = pool.v[v0 + role[3]]->d, ++c->n_cg_fused_steps;
   int64_t last_enqueued = -1;
   auto enqueue_iteration = [&]() -> int {
     const int q = fuse_step ? 0 : sweep ? (int)(cur_it & 1) : 0;  // (fused: the step kernel forward, cg_r backward, always)
