@@ -221,7 +221,7 @@ struct storm_hip_ctx {
   int64_t opt_vec_arena = 1;            // 0: every vector an allocation of its own
   int64_t opt_pack_arena = 0;           // an operator's records in a slot of its vectors' arena (where they fit)
   int64_t opt_vec_arena_contiguous = 1; // arenas in physically contiguous memory (hipDeviceMallocContiguous)
-XX
+  int64_t opt_cg_roles = 8;             // solve_cg_body: permutation of the work vectors' roles over their arena slots (A/B knob; 24 permutations at 256^3: 4 505 - 4 570 it/s, profiles/r05z_roles.txt)
   int64_t opt_vec_arena_slots = 8;
   int64_t opt_vec_arena_skew_kib = 0;   // pitch = the vector rounded up to 2 MiB + this
   size_t pool_bytes = 0;
