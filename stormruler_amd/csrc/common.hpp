@@ -221,6 +221,7 @@ struct storm_hip_ctx {
   int64_t opt_vec_arena = 1;            // 0: every vector an allocation of its own
   int64_t opt_pack_arena = 0;           // an operator's records in a slot of its vectors' arena (where they fit)
   int64_t opt_vec_arena_contiguous = 1; // arenas in physically contiguous memory (hipDeviceMallocContiguous)
+  int64_t opt_bicg_fuse = 0;            // BiCGStab on a lattice: s = r - alpha v formed inside the apply t = A s (the marching kernel without its x update).  Measured at 256^3: the launch pair it replaces 61.5 + 67.2 us, the fused launch 117.9 us -- but the second half-step behind it then finds less of s and t in the Infinity Cache (139 -> 167 us): 452 against 445 us per iteration, so off
   int64_t opt_cg_roles = 8;             // solve_cg_body: permutation of the work vectors' roles over their arena slots (A/B knob; 24 permutations at 256^3: 4 505 - 4 570 it/s, profiles/r05z_roles.txt)
   int64_t opt_vec_arena_slots = 8;
   int64_t opt_vec_arena_skew_kib = 0;   // pitch = the vector rounded up to 2 MiB + this
@@ -400,12 +401,18 @@ struct SpmvDot {
     double *x = nullptr;
     const double *r = nullptr;
     double *p_out = nullptr;
+    // r != null, x == null: the marching kernel without the x update -- p' = r + c p into p_out, y = A p', <p',y> (and
+    // <y,y>); c = *cb, or cb_scale * safe_divide(*cb, *cb_den) with the quotient stored to *cb_store (BiCGStab)
+    const double *cb_den = nullptr;
+    double cb_scale = 1.0;
+    double *cb_store = nullptr;
   } cg;
 };
 int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, double *y,
                 const SpmvDot *dot, const int *done, bool accumulate = false);
 int spmv_grid_blocks(const storm_hip_op *op);
 bool spmv_can_fuse_cg(const storm_hip_op *op);
+bool spmv_can_march(const storm_hip_op *op);  // the z-marching kernel applies to an unsplit launch of this operator
 int op_upload_slice_lists(storm_hip_op *op);
 void *vec_slot_take(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, size_t bytes);  // context.hip
 bool vec_slot_give(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, void *p);

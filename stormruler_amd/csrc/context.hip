@@ -166,6 +166,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "vec_arena")) c->opt_vec_arena = value;
   else if (!strcmp(key, "pack_arena")) c->opt_pack_arena = value;
   else if (!strcmp(key, "cg_roles")) c->opt_cg_roles = value;
+  else if (!strcmp(key, "bicg_fuse")) c->opt_bicg_fuse = value;
   else if (!strcmp(key, "vec_arena_contiguous")) c->opt_vec_arena_contiguous = value;
   else if (!strcmp(key, "vec_arena_slots")) c->opt_vec_arena_slots = value;
   else if (!strcmp(key, "vec_arena_skew_kib")) c->opt_vec_arena_skew_kib = value;

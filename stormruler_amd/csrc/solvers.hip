@@ -375,7 +375,9 @@ __global__ __launch_bounds__(kBlock) void bicg_update_kernel(int64_t n, SolverSt
                                                              const double *__restrict__ w,
                                                              const double *__restrict__ rt,
                                                              double *__restrict__ partials, int nt, int reverse,
-                                                             TicketArgs tickets) {
+                                                             TicketArgs tickets, const double *r_in = nullptr) {
+  // r_in (second half-step): the vector r is READ from (s = r - alpha v, where the apply formed it into a vector of its
+  // own); null: r itself
   if (st->done) return;
   const unsigned bx = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;  // the same rows and slots, dealt out from the far end
   __shared__ double lds4[4];
@@ -394,6 +396,7 @@ __global__ __launch_bounds__(kBlock) void bicg_update_kernel(int64_t n, SolverSt
   double acc_rr = 0.0, acc_rho = 0.0;
   const int64_t n2 = n >> 1;
   double2v *x2 = reinterpret_cast<double2v *>(x), *r2 = reinterpret_cast<double2v *>(r);
+  const double2v *ri2 = r_in ? reinterpret_cast<const double2v *>(r_in) : r2;
   const double2v *p2 = reinterpret_cast<const double2v *>(p), *w2 = reinterpret_cast<const double2v *>(w);
   const double2v *rt2 = reinterpret_cast<const double2v *>(rt);
   constexpr int U = SECOND ? 1 : kUnroll;  // 7 streams: one access per stream in flight (see cg_xp_kernel)
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(kBlock) void bicg_update_kernel(int64_t n, SolverSt
     for (int q = 0; q < U; ++q) {
       const int64_t i = base + q * kBlock;
       if (i < n2) {
-        vr[q] = ldv(r2 + i, nt), vw[q] = ldv(w2 + i, nt);
+        vr[q] = ldv(ri2 + i, nt), vw[q] = ldv(w2 + i, nt);
         if (SECOND) vx[q] = ldv(x2 + i, nt), vp[q] = ldv(p2 + i, nt), vt[q] = ldv(rt2 + i, nt);
       }
     }
@@ -436,9 +439,10 @@ __global__ __launch_bounds__(kBlock) void bicg_update_kernel(int64_t n, SolverSt
     if (!SECOND) {
       r[i] -= alpha * w[i];
     } else {
+      const double ri = r_in ? r_in[i] : r[i];
       double vx = x[i] + alpha * p[i];
-      vx += omega * r[i];
-      const double vr = r[i] - omega * w[i];
+      vx += omega * ri;
+      const double vr = ri - omega * w[i];
       x[i] = vx, r[i] = vr;
       acc_rr += vr * vr;
       acc_rho += rt[i] * vr;
@@ -814,9 +818,12 @@ struct Driver {
   // *ticketed tells whether it did -- then there are no partials to finish (*nblocks is still their count).
   struct CgStep {  // the fused CG step of spmv.hip (CgFuseArgs): end iteration my_iteration - 1, then apply to the new p
     long long my_iteration;
-    double *x;
+    double *x;  // null: no x update; p' = r + c p with c from the fields below
     const double *r;
     double *p_out;
+    const double *cb = nullptr, *cb_den = nullptr;  // (cb == null: beta of the slab)
+    double cb_scale = 1.0;
+    double *cb_store = nullptr;
   };
   int apply(const double *x, double *y, const double *dot_w, bool dot_yy, int *nblocks, bool predicated = true,
             int out0 = -1, int out1 = -1, int *ticketed = nullptr, const CgStep *cg = nullptr) {
@@ -825,6 +832,7 @@ struct Driver {
       sd.cg.iteration = &st->iteration, sd.cg.my_iteration = cg->my_iteration;
       sd.cg.ca = slot(S_ALPHA), sd.cg.cb = slot(S_BETA);
       sd.cg.x = cg->x, sd.cg.r = cg->r, sd.cg.p_out = cg->p_out;
+      if (cg->cb != nullptr) sd.cg.cb = cg->cb, sd.cg.cb_den = cg->cb_den, sd.cg.cb_scale = cg->cb_scale, sd.cg.cb_store = cg->cb_store;
     }
     sd.w = dot_w;
     sd.yy = dot_yy;
@@ -1336,8 +1344,14 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
   }
   ++c->n_throughput_solves;
   const size_t v0 = pool.v.size();
-  STORM_TRY(pool.make(x, 5, false));  // (r, rt: init; p: the copy of iteration 0; v, t: the SpMVs -- all before any read)
+  // On a lattice operator (one rank) the first half-step rides in the second apply: the marching kernel forms
+  // s = r - alpha v for the rows it loads (and their neighbours, from THEIR r and v: the same bits), writes it into a
+  // vector of its own and applies the operator to it -- 40 instead of 24 + 32 B/row and one launch fewer.
+  const bool fuse_s = c->opt_bicg_fuse != 0 && c->comm == nullptr && c->opt_fuse_dot != 0 && c->opt_ticket_reduce != 0 &&
+                      c->opt_ticket_verify == 0 && c->opt_graph == 0 && spmv_can_march(op);
+  STORM_TRY(pool.make(x, fuse_s ? 6 : 5, false));  // (r, rt: init; p: the copy of iteration 0; v, t: the SpMVs -- all before any read)
   double *p = pool.v[v0]->d, *r = pool.v[v0 + 1]->d, *rt = pool.v[v0 + 2]->d, *t = pool.v[v0 + 3]->d, *v = pool.v[v0 + 4]->d;
+  double *s_vec = fuse_s ? pool.v[v0 + 5]->d : nullptr;
   const int nbv = vec_blocks(c, n);
   const int nbv2 = nbv;  // second half-step: one access per stream in flight, four trips per thread
   int nb = 0;
@@ -1383,12 +1397,23 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
       const int slots[1] = {S_RTV};
       STORM_TRY(d.finish(nb, 1, slots, STEP_BICG_ALPHA));
     }
-    // r -= alpha v   (x += alpha p is applied in the second half-step)      :140-141
-    hipLaunchKernelGGL(bicg_update_kernel<false>, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, x->d, r, p, v,
-                       rt, c->d_partials, stream_nt(c, n), flip(), alpha_in_kernel ? tickets : no_tickets);
-    HIP_TRY(hipGetLastError());
-    // t = A r; omega = <t,r> / <t,t>                  :158-160
-    STORM_TRY(apply_dir(r, t, r, true, (int)S_TR, (int)S_TT));
+    const bool s_in_apply = fuse_s && alpha_in_kernel;
+    if (s_in_apply) {
+      // s = r - alpha v and t = A s in one launch; alpha = rho / <rt,v> formed by every block, stored by the first   :139-141, :158
+      Driver::CgStep step{0, nullptr, r, s_vec};
+      step.cb = d.slot(S_RHO), step.cb_den = d.slot(S_RTV), step.cb_scale = -1.0, step.cb_store = d.slot(S_ALPHA);
+      c->spmv_reverse = flip();
+      const int st_apply = d.apply(v, t, v, true, &nb, true, (int)S_TR, (int)S_TT, &ticketed, &step);
+      c->spmv_reverse = 0;
+      STORM_TRY(st_apply);
+    } else {
+      // r -= alpha v   (x += alpha p is applied in the second half-step)      :140-141
+      hipLaunchKernelGGL(bicg_update_kernel<false>, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, x->d, r, p, v,
+                         rt, c->d_partials, stream_nt(c, n), flip(), alpha_in_kernel ? tickets : no_tickets);
+      HIP_TRY(hipGetLastError());
+      // t = A r; omega = <t,r> / <t,t>                  :158-160
+      STORM_TRY(apply_dir(r, t, r, true, (int)S_TR, (int)S_TT));
+    }
     const bool omega_in_kernel = ticketed != 0;
     if (omega_in_kernel) {
     } else if (nb == 0) {
@@ -1402,6 +1427,10 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
       STORM_TRY(d.finish(nb, 2, slots, STEP_BICG_OMEGA));
     }
     // x = (x + alpha p) + omega r; r -= omega t; |r|, <rt,r>    :140, :161-164 (+ :116 of the next iteration)
+    // (s sits in a vector of its own when the apply formed it: the half-step then updates THAT vector in place -- a
+    //  read-modify-write of one vector is cheaper than reading one and writing another: 142 against 165 us at 256^3 --
+    //  and the two vectors swap roles: the residual of the next iteration lives where s did)
+    if (s_in_apply) std::swap(r, s_vec);
     hipLaunchKernelGGL(bicg_update_kernel<true>, dim3(nbv2), dim3(kBlock), 0, c->stream, n, d.st, x->d, r,
                        p, t, rt, c->d_partials, stream_nt(c, n), flip(), omega_in_kernel ? tickets : no_tickets);
     HIP_TRY(hipGetLastError());

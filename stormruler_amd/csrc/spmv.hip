@@ -130,6 +130,12 @@ bool spmv_can_fuse_cg(const storm_hip_op *op) {
          op->n_boundary > 0 && cg_march_geometry(op, &M, &nb, true);
 }
 
+bool spmv_can_march(const storm_hip_op *op) {
+  MarchArgs M;
+  int nb = 0;
+  return op->halo.n_nbrs == 0 && op->d_bnd_pack == nullptr && op->tail_rows == 0 && cg_march_geometry(op, &M, &nb);
+}
+
 int spmv_grid_blocks(const storm_hip_op *op) {
   CanonTileArgs T;
   int nb = 0;
@@ -172,13 +178,15 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
 
   if (!split) {
     CgFuseArgs cgf{};
-    const bool cg_fused = sd != nullptr && sd->cg.x != nullptr;
+    const bool cg_fused = sd != nullptr && sd->cg.r != nullptr;
     if (cg_fused) {
       STORM_REQUIRE(spmv_can_fuse_cg(op) && fuse_dot && !accumulate && sd->w == x,
                     "spmv: the fused CG step needs the tiled format-4 kernel");
+      STORM_REQUIRE(sd->cg.x != nullptr || spmv_can_march(op), "spmv: the step without an x update needs the marching kernel");
       dot.tickets = nullptr, dot.nblocks_total = 4 * nb_total;  // (the tiled form of the step leaves per-wave partials)
       if (sd->ticketed_out) *sd->ticketed_out = 0;
-      cgf = CgFuseArgs{sd->cg.iteration, sd->cg.my_iteration, sd->cg.ca, sd->cg.cb, sd->cg.x, sd->cg.r, sd->cg.p_out};
+      cgf = CgFuseArgs{sd->cg.iteration, sd->cg.my_iteration, sd->cg.ca, sd->cg.cb, sd->cg.x, sd->cg.r, sd->cg.p_out,
+                       sd->cg.cb_den, sd->cg.cb_scale, sd->cg.cb_store};
     }
     MarchArgs M;
     int nb_march = 0;
@@ -187,9 +195,9 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
       // from the slab (sd->out[0]), the reduction finished in the kernel by tickets
       dot.nblocks_total = 4 * nb_march;
       if (sd->nblocks_out) *sd->nblocks_out = 4 * nb_march;
-      if (sd->out[0] != nullptr && c->opt_ticket_reduce != 0 && c->comm == nullptr && !sd->yy &&
+      if (sd->out[0] != nullptr && c->opt_ticket_reduce != 0 && c->comm == nullptr && (!sd->yy || sd->out[1] != nullptr) &&
           nb_march <= kTicketGroup * kTicketMaxGroups && 2 * (int64_t)nb_march <= c->partials_capacity) {
-        dot.tickets = c->d_tickets, dot.part2 = c->d_ticket_sums, dot.out0 = sd->out[0], dot.out1 = nullptr;
+        dot.tickets = c->d_tickets, dot.part2 = c->d_ticket_sums, dot.out0 = sd->out[0], dot.out1 = sd->yy ? sd->out[1] : nullptr;
         dot.nblocks_total = nb_march;
         if (sd->ticketed_out) *sd->ticketed_out = 1;
       }
@@ -198,7 +206,8 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
     STORM_TRY(launch_range(op, alpha, beta, x, y, nullptr, op->n_slices, dot, fuse_dot, done, accumulate, nullptr,
                            cg_fused ? &cgf : nullptr));
   } else {
-    const bool cg_fused_part = sd != nullptr && sd->cg.x != nullptr;
+    const bool cg_fused_part = sd != nullptr && sd->cg.r != nullptr;
+    STORM_REQUIRE(!cg_fused_part || sd->cg.x != nullptr, "spmv: the step without an x update is for unsplit operators");
     if (cg_fused_part) {
       // The fused CG step on a partitioned operator (peer-window transport): ONE marching launch updates x and forms
       // p' on every owned plane, applies the operator to the interior planes and -- its first blocks -- sends p' of the

@@ -171,9 +171,15 @@ struct CgFuseArgs {
   const long long *iteration;  // SolverState::iteration
   long long my_iteration;      // the update belongs to iteration my_iteration - 1: it ran iff *iteration >= my_iteration
   const double *ca, *cb;       // alpha, beta of that iteration (device slab)
-  double *x;
+  double *x;                   // null (marching kernel only): no x update -- the kernel forms p' = r + c p and applies the
+                               // operator to it, nothing else (BiCGStab's s = r - alpha v; t = A s)
   const double *r;
   double *p_out;
+  // BiCGStab's form of the coefficient: cb_den != null -> c = cb_scale * safe_divide(*cb, *cb_den), and the first block
+  // stores safe_divide(*cb, *cb_den) to *cb_store for the kernels behind (alpha = rho / <rt,v>, SolverBiCgStab.hpp:139)
+  const double *cb_den = nullptr;
+  double cb_scale = 1.0;
+  double *cb_store = nullptr;
 };
 
 // ---- the fused CG step, marching in z ------------------------------------------------------------------------------
@@ -239,7 +245,7 @@ bool spmv_sell_run(const RangeLaunch &L);   // spmv_sell.hip: sliced-ELL records
 int spmv_tail_run(const storm_hip_op *op, Scal alpha, const double *x, double *y, const int *done);  // spmv_sell.hip: CSR tail
 // spmv_lattice.hip: the z-marching fused CG step (its own grid: n_blocks marching blocks + the sending blocks of S)
 int spmv_march_run(const storm_hip_op *op, const MarchArgs &M, int n_blocks, Scal alpha, Scal beta, const double *x, double *y,
-                   const DotArgs &dot, const int *done, const CgFuseArgs &cgf, const IpcSendArgs &S);
+                   const DotArgs &dot, const int *done, const CgFuseArgs &cgf, const IpcSendArgs &S);  // (cgf.x == null: no x update)
 // spmv.hip: diagonal of beta I + alpha M; spmv_build.hip calls nothing of the kernels.
 
 // ---- geometry shared by dispatch and launchers -----------------------------------------------------------------------

@@ -215,7 +215,8 @@ __global__ __launch_bounds__(kBlock) void spmv_canon_tile_kernel(SellArgs A, Can
   }
 }
 
-template <int HLP>  // halo pairs per thread and plane: ceil(a / 256)
+// XUP = false: no x update, no iteration gate (CgFuseArgs::x == null)
+template <int HLP, bool XUP = true>  // HLP: halo pairs per thread and plane: ceil(a / 256)
 __global__ __launch_bounds__(kBlock) void cg_step_march_kernel(SellArgs A, MarchArgs M, Scal alpha_s, Scal beta_s,
                                                                const double *__restrict__ p_in, double *__restrict__ z_out,
                                                                DotArgs dot, const int *done, CgFuseArgs F, IpcSendArgs S) {
@@ -225,8 +226,9 @@ __global__ __launch_bounds__(kBlock) void cg_step_march_kernel(SellArgs A, March
     ipc_halo_send_block(S.w, S.sp, p_in, (int)blockIdx.x, F.r, *F.cb);
     return;
   }
-  if (*F.iteration < F.my_iteration) return;  // enqueued past convergence: that iteration never ran
+  if (XUP && *F.iteration < F.my_iteration) return;  // enqueued past convergence: that iteration never ran
   const int done_flag = done ? *done : 0;
+  if (!XUP && done_flag) return;
   const CanonTileArgs &T = M.T;
   extern __shared__ __attribute__((aligned(16))) double tile_sh[];  // [3][a + kTileRun + a]
   __shared__ double dict_sh[32];
@@ -248,7 +250,15 @@ __global__ __launch_bounds__(kBlock) void cg_step_march_kernel(SellArgs A, March
   const int z_begin = zc * M.zc_planes, z_end = min(z_begin + M.zc_planes, T.plane_end);
   const int ldw = kTileRun + 2 * a;
   const double alpha = ld_scal2(alpha_s), beta = ld_scal2(beta_s);
-  const double cg_a = *F.ca, cg_b = *F.cb;
+  double cg_a = 0.0, cg_b;
+  if (XUP) {
+    cg_a = *F.ca, cg_b = *F.cb;
+  } else {
+    const double num = *F.cb, den = F.cb_den ? *F.cb_den : 1.0;
+    const double quot = F.cb_den ? ((den == 0.0) ? 0.0 : num / den) : num;  // safe_divide, Crow/MathUtils.hpp:54-58
+    cg_b = F.cb_scale * quot;
+    if (F.cb_store != nullptr && mb == 0 && threadIdx.x == 0) *F.cb_store = quot;
+  }
   const uint32_t last_row = (uint32_t)(A.n_rows - 1);
   const char *pb = reinterpret_cast<const char *>(p_in), *rb = reinterpret_cast<const char *>(F.r);
   const char *pg_base = pb - (size_t)kVecGuard * 8, *rg_base = rb - (size_t)kVecGuard * 8;
@@ -278,7 +288,8 @@ __global__ __launch_bounds__(kBlock) void cg_step_march_kernel(SellArgs A, March
       f.p[g] = *reinterpret_cast<const double2v *>(pg_base + (size_t)((uint32_t)gi << 3));
       f.r[g] = *reinterpret_cast<const double2v *>(rg_base + (size_t)((uint32_t)gi << 3));
       if (own) {
-        f.x[g] = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(reinterpret_cast<const char *>(F.x) + (size_t)(f.rc[g] << 3)));
+        if constexpr (XUP)
+          f.x[g] = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(reinterpret_cast<const char *>(F.x) + (size_t)(f.rc[g] << 3)));
         f.w[g] = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(A.pack + (size_t)(f.rc[g] << 3)));
       }
     }
@@ -306,12 +317,17 @@ __global__ __launch_bounds__(kBlock) void cg_step_march_kernel(SellArgs A, March
       pn.x = __builtin_fma(cg_b, f.p[g].x, f.r[g].x), pn.y = __builtin_fma(cg_b, f.p[g].y, f.r[g].y);
       out[g] = pn;
       if (own) {
-        double2v xn;
-        xn.x = __builtin_fma(cg_a, f.p[g].x, f.x[g].x), xn.y = __builtin_fma(cg_a, f.p[g].y, f.x[g].y);
-        double2v *xp_ = reinterpret_cast<double2v *>(reinterpret_cast<char *>(F.x) + (size_t)(f.rc[g] << 3));
         double2v *pp_ = reinterpret_cast<double2v *>(reinterpret_cast<char *>(F.p_out) + (size_t)(f.rc[g] << 3));
-        if (f.vb[g]) __builtin_nontemporal_store(xn, xp_), __builtin_nontemporal_store(pn, pp_);
-        else if (f.va[g]) F.x[f.rc[g]] = xn.x, F.p_out[f.rc[g]] = pn.x;
+        if constexpr (XUP) {
+          double2v xn;
+          xn.x = __builtin_fma(cg_a, f.p[g].x, f.x[g].x), xn.y = __builtin_fma(cg_a, f.p[g].y, f.x[g].y);
+          double2v *xp_ = reinterpret_cast<double2v *>(reinterpret_cast<char *>(F.x) + (size_t)(f.rc[g] << 3));
+          if (f.vb[g]) __builtin_nontemporal_store(xn, xp_), __builtin_nontemporal_store(pn, pp_);
+          else if (f.va[g]) F.x[f.rc[g]] = xn.x, F.p_out[f.rc[g]] = pn.x;
+        } else {  // (a plain store: the next kernel reads s)
+          if (f.vb[g]) *pp_ = pn;
+          else if (f.va[g]) F.p_out[f.rc[g]] = pn.x;
+        }
         *reinterpret_cast<double2v *>(&buf[a + 256 * wave + 128 * g + 2 * lane]) = pn;
       }
     }
@@ -326,7 +342,7 @@ __global__ __launch_bounds__(kBlock) void cg_step_march_kernel(SellArgs A, March
     }
   };
 
-  if (done_flag) {  // converged in that iteration: only x += alpha p is left to do
+  if (XUP && done_flag) {  // converged in that iteration: only x += alpha p is left to do
     for (int zp = z_begin; zp < z_end; ++zp) {
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
@@ -578,12 +594,17 @@ int spmv_march_run(const storm_hip_op *op, const MarchArgs &M, int n_blocks, Sca
   A.nt_y = (int)(c->opt_spmv_nt_y != 0);
   const size_t lds = sizeof(double) * 3 * (size_t)(kTileRun + 2 * M.T.a);
   const int nb = n_blocks + S.sp.n_blocks;
-  if (M.T.a <= kBlock)
-    hipExtLaunchKernelGGL((cg_step_march_kernel<1>), dim3(nb), dim3(kBlock), lds, c->stream, ev0, ev1, 0, A, M, alpha, beta, x, y,
-                          dot, done, cgf, S);
-  else
-    hipExtLaunchKernelGGL((cg_step_march_kernel<2>), dim3(nb), dim3(kBlock), lds, c->stream, ev0, ev1, 0, A, M, alpha, beta, x, y,
-                          dot, done, cgf, S);
+#define MARCH_GO(HLP_, XUP_)                                                                                                \
+  hipExtLaunchKernelGGL((cg_step_march_kernel<HLP_, XUP_>), dim3(nb), dim3(kBlock), lds, c->stream, ev0, ev1, 0, A, M, alpha, \
+                        beta, x, y, dot, done, cgf, S)
+  if (cgf.x != nullptr) {
+    if (M.T.a <= kBlock) MARCH_GO(1, true);
+    else MARCH_GO(2, true);
+  } else {
+    if (M.T.a <= kBlock) MARCH_GO(1, false);
+    else MARCH_GO(2, false);
+  }
+#undef MARCH_GO
   HIP_TRY(hipGetLastError());
   return STORM_HIP_OK;
 }
