@@ -152,6 +152,7 @@ struct storm_hip_ctx {
   int64_t opt_spmv_canon_tile = 2;   // format 4 on a lattice (offsets -b,-a,-1,+1,+a,+b): tiles of 1024 rows x this many planes (2, or 4) with the +-a / +-1 neighbours from LDS and the +-b ones from registers; 0 = the plain kernel.  Measured at 256^3 (profiles/r03f, r03g): CG step 242 (2 planes) / 247 (4) us per iteration, BiCGStab 496 / 510
   int64_t opt_vec_contiguous = 0;     // vectors in physically contiguous device memory (hipDeviceMallocContiguous)
   int64_t opt_mgs_steps = 4;          // throughput-path Gram-Schmidt: steps per pass over w (2: mgs_pair_kernel; 3, 4: mgs_multi_kernel)
+  int64_t opt_coop_mgs_apply = 1;    // ... with the operator apply in front of it done by the chain kernel itself (format-4 lattice operators)
   int64_t opt_coop_mgs_pairs = 1;    // cooperative Gram-Schmidt chain: two steps per synchronisation point
   int64_t opt_coop_dense = 1;        // the multi-step Gram-Schmidt chain's all-reduce with dense value-major slots (0: the two-level form; 2: the resident kernels too)
   int64_t opt_coop_mgs_quad = 1;     // ... FOUR steps per synchronisation point (blocks of 512 threads; <= 2^21 rows)
@@ -431,8 +432,15 @@ struct MgsGivens {
   SolverState *st;
   double *H, *beta, *cs, *sn, *hn_slot;
 };
+// The operator apply GMRES performs before its Gram-Schmidt chain (SolverGmres.hpp:155), for the chain kernel to do itself.
+struct ChainApply {
+  const storm_hip_op *op;
+  double alpha, beta;  // y = beta x + alpha M(x)
+  const double *x;     // = q[k]
+};
 int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w, const double *const *q, int k, int m,
-                         double *H, double *norm2_out, bool normalise, bool *taken, const MgsGivens *givens = nullptr);
+                         double *H, double *norm2_out, bool normalise, bool *taken, const MgsGivens *givens,
+                         const ChainApply *apply = nullptr, bool *applied = nullptr);
 // *taken = false: no cooperative kernel ran (none fits, or the launch was refused) -- take the throughput path
 int cg_latency_solve(const storm_hip_op *op, double alpha, double beta, const double *b, double *x, double *p,
                      double *r, SolverState *d_state, bool *taken);

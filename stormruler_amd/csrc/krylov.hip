@@ -1286,7 +1286,7 @@ namespace storm {
 int gmres_orthogonalize(storm_hip_ctx *c, int64_t n, const SolverState *st, const int *done, double *qn,
                         const double *const *q, int k, int m, double *H, double *norm2_out, double *scratch,
                         int gram_schmidt, bool *normalised, const MgsGivens *givens = nullptr,
-                        bool *givens_done = nullptr);
+                        bool *givens_done = nullptr, const ChainApply *apply = nullptr);
 }  // namespace storm
 
 void K::init() {

@@ -32,6 +32,7 @@
 
 #include "common.hpp"
 #include "coop_device.hpp"
+#include "spmv_device.hpp"
 #include "solver_device.hpp"
 
 namespace storm {
@@ -536,6 +537,13 @@ struct MgsArgs {
   long long *prof;   // option resident_profile: [gridDim.x][8] ticks per phase of this launch (diagnostic)
   char *quad_slots;  // mgs_chain_quad_kernel: all-reduce slots of kQuadSlotStride bytes (two-level form) / dense granules
   int dense;         // ... the flat all-reduce with dense value-major slots instead of the two-level one
+  // mgs_chain_quad_kernel<S, T, true>: w is not read but FORMED -- w = beta x + alpha M(x), x = ap_x (the newest basis
+  // vector), from the operator's format-4 records with spmv_canon_kernel's arithmetic (the same bits): the apply's
+  // launch and the round trip of w through memory disappear (SolverGmres.hpp:155 inside the kernel that consumes it)
+  const char *ap_pack;
+  const double *ap_dict, *ap_x;
+  int ap_off[6], ap_max_gather;
+  double ap_alpha, ap_beta;
 };
 template <int S>
 __global__ __launch_bounds__(kLatBlock) void mgs_chain_kernel(MgsArgs a) {
@@ -871,10 +879,11 @@ __global__ __launch_bounds__(kLatBlock) void mgs_chain_lds_kernel(MgsArgs a) {
 // runs in the reference's order.
 constexpr int kQuadThreads = 512, kQuadWaves = kQuadThreads / kWave, kQuadSub = 2 * kQuadThreads;
 constexpr int kQuadSlotStride = 256;  // ten values of 16 bytes
-template <int S, int T>  // T = 3 or 4 steps per synchronisation point
+template <int S, int T, bool APPLY = false>  // T = 3 or 4 steps per synchronisation point
 __global__ __launch_bounds__(kQuadThreads) void mgs_chain_quad_kernel(MgsArgs a) {
   if (a.done && *a.done) return;  // (uniform: every block reads the same flag before any of them synchronises)
   __shared__ double lds[10 * 256 + 16];  // co_allreduce_dense: NV x 256 polled values + the NV results
+  __shared__ double dict_sh[32];
   __shared__ double hcol[kMgsMaxVectors + 1], cs_sh[kMgsMaxVectors], sn_sh[kMgsMaxVectors];
   const bool rotate = a.givens.st != nullptr && blockIdx.x == 0;
   if (rotate && (int)threadIdx.x < a.k) cs_sh[threadIdx.x] = a.givens.cs[threadIdx.x], sn_sh[threadIdx.x] = a.givens.sn[threadIdx.x];
@@ -892,8 +901,70 @@ __global__ __launch_bounds__(kQuadThreads) void mgs_chain_quad_kernel(MgsArgs a)
     va[j] = row < a.n_rows, vb[j] = row + 1 < a.n_rows;
     off8[j] = va[j] ? (unsigned)row << 3 : 0u;
     w[j] = double2m{0.0, 0.0};
-    if (va[j]) w[j] = *reinterpret_cast<const double2m *>(reinterpret_cast<const char *>(a.w) + off8[j]);  // (>= 4 zero doubles behind the last row)
+    if (!APPLY && va[j]) w[j] = *reinterpret_cast<const double2m *>(reinterpret_cast<const char *>(a.w) + off8[j]);  // (>= 4 zero doubles behind the last row)
     w[j].y = vb[j] ? w[j].y : 0.0;
+  }
+  if constexpr (APPLY) {
+    // w = beta x + alpha M(x) of the thread's row pairs: spmv_canon_kernel<false, 6, 2, false, G> (spmv_pair.hip) -- the
+    // record word, the own pair, the four 16-byte gathers of offsets 0, 1, 4, 5, the +-1 neighbours from the adjacent
+    // lanes (lanes 0 and 63 load theirs); two pairs' loads in flight at a time (registers)
+    typedef unsigned long long u64x2m __attribute__((ext_vector_type(2)));
+    const int lane = tid & (kWave - 1);
+    if (lane < 32) dict_sh[lane] = a.ap_dict[lane];  // every wave stores the same words: no barrier (same-wave LDS order)
+    __builtin_amdgcn_wave_barrier();
+    const char *xb = reinterpret_cast<const char *>(a.ap_x);
+    const char *xg_base = xb - (size_t)kVecGuard * 8;
+    const double alpha = a.ap_alpha, beta = a.ap_beta;
+    constexpr int JB = S >= 2 ? 2 : 1;
+#pragma unroll
+    for (int j0 = 0; j0 < S; j0 += JB) {
+      u64x2m vw[JB];
+      double2m xi[JB], xg[JB][6];
+      double e[JB];
+#pragma unroll
+      for (int jj = 0; jj < JB; ++jj) {
+        const unsigned rc = off8[j0 + jj] >> 3;  // (an absent pair re-reads pair 0: masked below)
+        vw[jj] = __builtin_nontemporal_load(reinterpret_cast<const u64x2m *>(a.ap_pack + off8[j0 + jj]));
+        xi[jj] = *reinterpret_cast<const double2m *>(xb + off8[j0 + jj]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          if (k == 2 || k == 3) continue;
+          int t = (int)rc + a.ap_off[k] + kVecGuard;  // guard-relative, clamped: an absent neighbour may point anywhere
+          t = t < 0 ? 0 : t;
+          t = t > a.ap_max_gather ? a.ap_max_gather : t;
+          xg[jj][k] = *reinterpret_cast<const double2m *>(xg_base + (size_t)((unsigned)t << 3));
+        }
+        e[jj] = 0.0;
+        if (lane == 0 || lane == kWave - 1)  // x[rc - 1] of lane 0, x[rc + 2] of lane 63
+          e[jj] = *reinterpret_cast<const double *>(xg_base + (size_t)((rc + (unsigned)(kVecGuard + (lane == 0 ? -1 : 2))) << 3));
+      }
+#pragma unroll
+      for (int jj = 0; jj < JB; ++jj) {
+        const double left = dpp_shift<0x138>(xi[jj].y);   // wave_shr:1 -- lane i receives lane i - 1
+        const double right = dpp_shift<0x130>(xi[jj].x);  // wave_shl:1 -- lane i receives lane i + 1
+        xg[jj][2].x = lane == 0 ? e[jj] : left;
+        xg[jj][2].y = xi[jj].x;
+        xg[jj][3].x = xi[jj].y;
+        xg[jj][3].y = lane == kWave - 1 ? e[jj] : right;
+        double acc_a = 0.0, acc_b = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          const unsigned ba = (unsigned)(vw[jj].x >> (8 * (k + 1))) & 0xffu, bb = (unsigned)(vw[jj].y >> (8 * (k + 1))) & 0xffu;
+          acc_a += *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + ba) * (xg[jj][k].x - xi[jj].x);
+          acc_b += *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + bb) * (xg[jj][k].y - xi[jj].y);
+        }
+        const double ext_a = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + ((unsigned)vw[jj].x & 0xffu));
+        const double ext_b = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(dict_sh) + ((unsigned)vw[jj].y & 0xffu));
+        double2m yi;
+        yi.x = __builtin_fma(alpha, __builtin_fma(ext_a, xi[jj].x, acc_a), beta * xi[jj].x);  // (spmv_canon_tile_kernel's form)
+        yi.y = __builtin_fma(alpha, __builtin_fma(ext_b, xi[jj].y, acc_b), beta * xi[jj].y);
+        w[j0 + jj].x = va[j0 + jj] ? yi.x : 0.0;
+        w[j0 + jj].y = vb[j0 + jj] ? yi.y : 0.0;
+        asm volatile("" : "+v"(w[j0 + jj].x), "+v"(w[j0 + jj].y));  // (the pair is finished HERE: nothing of it stays live)
+      }
+      // (group after group: with all S pairs' loads hoisted to the front the S = 8 kernel spilled 207 registers)
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   constexpr int ND = T == 4 ? 10 : 6;
   long long tick[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_mark = a.prof ? wall_clock64() : 0;
@@ -1008,9 +1079,15 @@ __global__ __launch_bounds__(kQuadThreads) void mgs_chain_quad_kernel(MgsArgs a)
 }
 
 // Returns STORM_HIP_OK with *taken = false when the chain does not qualify (too many rows / vectors, a communicator).
+// apply (nullable): w has not been formed yet, w = beta x + alpha M(x) with x = q[k] (ChainApply, common.hpp): the quad
+// kernels do it themselves, in front of any other variant it is launched here; *applied tells whether w exists when this
+// returns -- if not (the chain did not qualify or could not be launched) the caller applies the operator itself.
 int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w, const double *const *q, int k, int m,
-                         double *H, double *norm2_out, bool normalise, bool *taken, const MgsGivens *givens) {
+                         double *H, double *norm2_out, bool normalise, bool *taken, const MgsGivens *givens,
+                         const ChainApply *apply, bool *applied) {
   *taken = false;
+  if (applied) *applied = false;
+  bool with_apply = false;
   // (a step of the chain costs half an all-reduce, ~2.5 us, whatever the size; the kernel-per-step path costs a launch,
   //  ~3.5 us, or 32 B/row of HBM traffic, whichever is more -- measured, us per inner iteration, per-step vs chained:
   //  step.1 83..106 vs 74.5, 32^3 84..109 vs 72, 64^3 91..106 vs 93, 128^3 248 vs 147)
@@ -1054,10 +1131,19 @@ int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w
   if (c->opt_coop_mgs_quad != 0 && c->opt_coop_mgs_pairs != 0 && qsub >= 1 && qsub <= 8) {
     const int sv = qsub <= 1 ? 1 : qsub <= 2 ? 2 : qsub <= 4 ? 4 : 8;
     // (eight or sixteen rows per thread and FOUR vectors of them do not fit 256 registers beside the all-reduce: three there)
+    // the operator applied inside the kernel: format-4 records with the six common offsets of a 3-D lattice numbering,
+    // the dictionary within 32 values, no halo, no tail -- and the caller wanting the newest basis vector applied to
+    const storm_hip_op *aop = apply ? apply->op : nullptr;
+    with_apply = aop != nullptr && applied != nullptr && c->opt_coop_mgs_apply != 0 && aop->pair == 2 && aop->canon_k == 6 &&
+                 aop->canon_m1 == 2 && aop->n_halo == 0 && aop->tail_rows == 0 && aop->d_bnd_pack == nullptr &&
+                 aop->dict_size <= 32 && aop->n_rows == n && apply->x == q[k];
     const void *qf = sv == 1 ? (const void *)mgs_chain_quad_kernel<1, 4> : sv == 2 ? (const void *)mgs_chain_quad_kernel<2, 4>
                    : sv == 4 ? (const void *)mgs_chain_quad_kernel<4, 3> : (const void *)mgs_chain_quad_kernel<8, 3>;
-    static int quad_resident[4] = {-1, -1, -1, -1};
-    int &res = quad_resident[sv == 1 ? 0 : sv == 2 ? 1 : sv == 4 ? 2 : 3];
+    if (with_apply)
+      qf = sv == 1 ? (const void *)mgs_chain_quad_kernel<1, 4, true> : sv == 2 ? (const void *)mgs_chain_quad_kernel<2, 4, true>
+         : sv == 4 ? (const void *)mgs_chain_quad_kernel<4, 3, true> : (const void *)mgs_chain_quad_kernel<8, 3, true>;
+    static int quad_resident[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    int &res = quad_resident[(sv == 1 ? 0 : sv == 2 ? 1 : sv == 4 ? 2 : 3) + (with_apply ? 4 : 0)];
     if (res < 0) {
       res = 0;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&res, qf, kQuadThreads, 0);
@@ -1070,7 +1156,11 @@ int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w
         HIP_TRY(hipMemsetAsync(c->d_quad_slots, 0, bytes, c->stream));
       }
       fn = qf, dyn_lds = 0, threads = kQuadThreads, blocks = (qsubs_total + sv - 1) / sv;
+    } else {
+      with_apply = false;
     }
+  } else {
+    with_apply = false;
   }
   const bool lds_chain = fn != nullptr;
   if (!lds_chain)
@@ -1100,14 +1190,29 @@ int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w
                                                                         : MgsGivens{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   a.quad_slots = c->d_quad_slots;
   a.dense = (int)(c->opt_coop_dense != 0);
+  a.ap_pack = nullptr, a.ap_dict = nullptr, a.ap_x = nullptr, a.ap_max_gather = 0, a.ap_alpha = 0.0, a.ap_beta = 0.0;
+  for (int i = 0; i < 6; ++i) a.ap_off[i] = 0;
+  if (with_apply) {
+    const storm_hip_op *aop = apply->op;
+    a.ap_pack = aop->d_pack, a.ap_dict = aop->d_dict, a.ap_x = apply->x;
+    for (int i = 0; i < 6; ++i) a.ap_off[i] = aop->canon_off[i];
+    a.ap_max_gather = (int)(aop->n_rows + aop->n_halo) + kVecGuard + 2;
+    a.ap_alpha = apply->alpha, a.ap_beta = apply->beta;
+  }
   a.prof = nullptr;
   if (c->opt_resident_profile != 0 && lds_chain && k == m - 1) {  // (diagnostic: the longest chain of a cycle)
     if (c->d_res_prof == nullptr) HIP_TRY(hipMalloc((void **)&c->d_res_prof, sizeof(long long) * 256 * 8));
     a.prof = c->d_res_prof, c->res_prof_blocks = (int)blocks;
   }
+  bool formed = false;
+  if (apply != nullptr && applied != nullptr && !with_apply) {  // a chain variant that READS w: the apply goes first
+    STORM_TRY(spmv_launch(apply->op, host_scal(apply->alpha), host_scal(apply->beta), apply->x, w, nullptr, done));
+    formed = true;
+  }
   void *args[] = {&a};
   *taken = coop_launch(c, fn, (unsigned)blocks, args, dyn_lds, threads);
   if (!*taken) c->lat_seq -= (unsigned long long)k + 2;
+  if (applied) *applied = formed || (*taken && with_apply);
   return STORM_HIP_OK;
 }
 

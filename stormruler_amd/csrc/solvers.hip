@@ -1017,18 +1017,24 @@ namespace storm {
 // *normalised (nullable) = true when qn has already been divided by its norm (the cooperative chain does that).
 int gmres_orthogonalize(storm_hip_ctx *c, int64_t n, const SolverState *st, const int *done, double *qn,
                         const double *const *q, int k, int m, double *H, double *norm2_out, double *scratch,
-                        int gram_schmidt, bool *normalised, const MgsGivens *givens, bool *givens_done) {
+                        int gram_schmidt, bool *normalised, const MgsGivens *givens, bool *givens_done,
+                        const ChainApply *apply) {
+  // apply (nullable): qn = beta q[k] + alpha M(q[k]) has NOT been formed yet -- the cooperative chain does it itself where
+  // it can (latency.hip: mgs_chain_quad_kernel<S, T, true>), otherwise it is formed here, before anything reads qn
   if (normalised) *normalised = false;
   if (givens_done) *givens_done = false;
+  bool applied = false;
   if (gram_schmidt == 0 && n > 0) {  // small enough for registers: the whole chain as one cooperative kernel
     bool taken = false;
-    STORM_TRY(gmres_mgs_chain_coop(c, n, done, qn, q, k, m, H, norm2_out, normalised != nullptr, &taken, givens));
+    STORM_TRY(gmres_mgs_chain_coop(c, n, done, qn, q, k, m, H, norm2_out, normalised != nullptr, &taken, givens, apply, &applied));
     if (taken && givens != nullptr && givens_done && c->opt_coop_mgs != 2) *givens_done = true;
     if (taken) {
       if (normalised) *normalised = true;
       return STORM_HIP_OK;
     }
   }
+  if (apply != nullptr && !applied)
+    STORM_TRY(spmv_launch(apply->op, host_scal(apply->alpha), host_scal(apply->beta), apply->x, qn, nullptr, done));
   const int nbv = stream_blocks(n);
   if (n <= 0) {  // an empty rank: zeros (and its share of the all-reduces)
     for (int i = 0; i <= k; ++i) {
@@ -1565,13 +1571,18 @@ int solve_gmres_body(const FusedSolveArgs &args) {
     const int k = (int)(it % m);                         // Solver.hpp:239
     if (k == 0) STORM_TRY(start(false));                 // Solver.hpp:240-242
     double *qn = const_cast<double *>(q[k + 1]);
-    STORM_TRY(d.apply(q[k], qn, nullptr, false, &nb));   // SolverGmres.hpp:155
+    // SolverGmres.hpp:155 -- by the chain kernel itself where the operator is a format-4 lattice one (one launch per inner
+    // iteration, and qn = A q_k never travels through memory); gmres_orthogonalize applies it otherwise
+    const ChainApply chain_apply{op, alpha, beta, q[k]};
+    const bool defer_apply = params->gram_schmidt == 0 && c->comm == nullptr && c->opt_coop_mgs != 0 && c->opt_coop_mgs_apply != 0 &&
+                             op->halo.n_nbrs == 0;
+    if (!defer_apply) STORM_TRY(d.apply(q[k], qn, nullptr, false, &nb));
     bool normalised = false, givens_done = false;
     // (the cooperative Gram-Schmidt chain, when it runs, also takes the root, normalises, applies the Givens
     //  rotations and the convergence rule in its last instructions: an inner iteration is then two launches)
     const MgsGivens givens{d.st, d.g.H, d.g.beta, d.g.cs, d.g.sn, d.slot(S_HN)};
     STORM_TRY(gmres_orthogonalize(c, n, d.st, d.done, qn, q.data(), k, m, d.g.H, d.slot(S_TMP), d.slot(S_SCRATCH),
-                                  params->gram_schmidt, &normalised, &givens, &givens_done));
+                                  params->gram_schmidt, &normalised, &givens, &givens_done, defer_apply ? &chain_apply : nullptr));
     if (!givens_done) {
       hipLaunchKernelGGL(step_kernel, dim3(1), dim3(1), 0, c->stream, (int)STEP_GMRES_HN, d.st, d.g, false);
       HIP_TRY(hipGetLastError());
