@@ -915,7 +915,7 @@ __global__ __launch_bounds__(kQuadThreads) void mgs_chain_quad_kernel(MgsArgs a)
     const char *xb = reinterpret_cast<const char *>(a.ap_x);
     const char *xg_base = xb - (size_t)kVecGuard * 8;
     const double alpha = a.ap_alpha, beta = a.ap_beta;
-    constexpr int JB = S >= 2 ? 2 : 1;
+    constexpr int JB = S >= 2 ? 2 : 1;  // (four pairs in flight at S = 8: 89.0 against 88.0 us per inner iteration at 128^3)
 #pragma unroll
     for (int j0 = 0; j0 < S; j0 += JB) {
       u64x2m vw[JB];

@@ -282,3 +282,39 @@ def test_latency_path_is_bitwise_reproducible(env, kind, shape):
     for h, x in runs[1:]:
         assert np.array_equal(h, runs[0][0]) and np.array_equal(x, runs[0][1])
     mat.close()
+
+
+@pytest.mark.parametrize("shape", [(48, 40, 36), (64, 64, 33), (20, 18, 16)])
+def test_chain_kernel_applies_the_operator_itself_with_the_same_bits(shape):
+    """GMRES's Arnoldi step w = A q_k (SolverGmres.hpp:155) inside the Gram-Schmidt chain kernel (option coop_mgs_apply;
+    latency.hip: mgs_chain_quad_kernel<S, T, true>) -- spmv_canon_kernel's arithmetic on the thread's own row pairs: the
+    residual histories and the solutions are BITWISE those of the launch-then-chain form, for the symmetric and the
+    convection-diffusion operator; a chain variant that cannot apply gets the launch in front of it."""
+    from stormruler_amd import api, mesh
+    from test_gpu_convdiff import NU, VEL
+
+    ctx = api.Context(0)
+    g = mesh.structured_box(*shape, lengths=tuple(s / 64.0 for s in shape))  # (cubic cells: few distinct weights)
+    wi, wo, de = mesh.convection_diffusion_weights(g, NU, VEL)
+    mats = {"poisson": (api.StencilMatrix.from_face_graph(ctx, g), -1.0),
+            "convdiff": (api.StencilMatrix.from_face_weights(ctx, g.n_cells, g.n_halo, g.inner, g.outer, wi, wo, de), 1.0)}
+    b_host = 1.0 + 0.3 * np.sin(0.02 * np.arange(g.n_cells))
+    ctx.set_option("coop_mgs_min_rows", 0)
+    for name, (mat, alpha) in mats.items():
+        assert mat.stats()["paired_rows"] == 2
+        runs = {}
+        for key, apply_opt, quad in (("launch", 0, 1), ("fused", 1, 1), ("register chain", 1, 0)):
+            ctx.set_option("coop_mgs_apply", apply_opt)
+            ctx.set_option("coop_mgs_quad", quad)
+            s = api.GmresSolver()
+            s.num_inner_iterations, s.record_history, s.num_iterations = 20, True, 55
+            s.absolute_error_tolerance = s.relative_error_tolerance = 0.0
+            b, x = api.DeviceVector.from_numpy(ctx, b_host), api.DeviceVector(ctx, g.n_cells)
+            s.solve(x, b, api.HipStencilOperator(mat, alpha, 0.0))
+            assert s.path_fallback == 0
+            runs[key] = (np.asarray(s.history), x.to_numpy())
+        assert np.array_equal(runs["launch"][0], runs["fused"][0]) and np.array_equal(runs["launch"][1], runs["fused"][1]), name
+        # (the register chain groups its sums differently from the quadruples: to rounding)
+        assert np.allclose(runs["register chain"][0], runs["launch"][0], rtol=1e-9), name
+        mat.close()
+    ctx.close()
