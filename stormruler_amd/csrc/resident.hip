@@ -71,6 +71,7 @@ struct ResArgs {
   long long *prof;     // option resident_profile: [gridDim.x][8] ticks of the 100 MHz counter per phase of the loop, summed over the solve
   unsigned long long *cnt;  // [0] all-reduce sequence number, [1] exchange sequence number: carried from solve to solve
   SolverState *st;
+  int early_publish;  // CG: the residual's surface before the second all-reduce (res_halo MODE 2)
 };
 
 // ---- all-reduce over the co-resident grid (latency.hip's scheme for 8 waves per block) --------------------------
@@ -277,16 +278,29 @@ __device__ __forceinline__ void res_publish_pair(const ResArgs &A, const ResBox 
   }
 }
 
+__device__ __forceinline__ double2r res_cg_direction(double2r r, double2r p, double beta) {
+  return double2r{__builtin_fma(beta, p.x, r.x), __builtin_fma(beta, p.y, r.y)};  // r + beta p            SolverCg.hpp:123
+}
+
 // The halo of the LDS copy and the two planes bounding the box:
 //   MODE 0: straight from a vector in memory that no block writes meanwhile (the start vector, at init);
 //   MODE 1: the granules published with `tag`.
-// (Tried and dropped: CG publishing the surface of its RESIDUAL before the all-reduce that yields beta, every block forming
-//  p' = r + beta p on its halo itself, so that the exchange travels under the all-reduce -- 21 instead of 24 us at 128^3,
-//  but run-to-run differences of the histories at the 1e-10 level on the small boxes, gone again with the publish
-//  behind the all-reduce; not understood, not kept.)
+// (Round 4, first half: CG publishing the surface of its RESIDUAL before the all-reduce that yields beta showed run-to-run
+//  differences at the 1e-10 level and was dropped "not understood".  Understood in the second half: the tag of an early
+//  publish was only counted when the solve went on -- the LAST residual of a solve stayed in the buffer under a tag that
+//  the NEXT solve's first exchange used again, and a fast reader took it for the new surface.  Every publish now takes a
+//  fresh tag, consumed or not, and MODE 2 below is bitwise the late publish (tests/test_gpu_resident.py).  One more trap:
+//  with the publish INSIDE the loop that updates r the build hung in every box with neighbours above and below (and
+//  stopped hanging with any change to the polling loops' cold paths -- a debugging printf was enough); with a loop of
+//  its own behind the update it does not.  Measured, us per iteration late / early: 16^3 5.7 / 5.3, 32^3 6.3 / 6.0,
+//  64^3 9.8 / 9.5, 100^3 14.4 / 14.8, 128^3 16.7 / 17.9 -- since the granules travel as whole lines the wait it hides is
+//  short, and forming the halo of p' costs more than it at the larger boxes: option resident_early, off.)
+//   MODE 2 (CG): the granules hold the neighbours' RESIDUAL, published before the all-reduce that yields beta; the halo of
+//   the direction is formed here, p' = r + beta p, from it and the halo of the old direction that the LDS copy / lo / hi
+//   still hold -- the owner's own expression on the owner's own operands: the same bits.
 template <int TZ, int MODE>
 __device__ __forceinline__ void res_halo(const ResArgs &A, const ResBox &B, double *P, unsigned tag, const double *vec,
-                                         double2r *lo, double2r *hi) {
+                                         double2r *lo, double2r *hi, double beta = 0.0) {
   const int tid = threadIdx.x;
   const int64_t n = A.n_rows;
   auto plain = [&](int64_t row) -> double2r {
@@ -306,6 +320,7 @@ __device__ __forceinline__ void res_halo(const ResArgs &A, const ResBox &B, doub
   };
   auto put = [&](int at, double2r v) {
     if (at < 0) return;
+    if (MODE == 2) v = res_cg_direction(v, *reinterpret_cast<const double2r *>(&P[at]), beta);
     *reinterpret_cast<double2r *>(&P[at]) = v;
   };
   // first batch: this thread's own column in the planes below and above, and its first two halo pairs
@@ -323,7 +338,8 @@ __device__ __forceinline__ void res_halo(const ResArgs &A, const ResBox &B, doub
   } else {
     res_fetch4(A, row, tag, v);
   }
-  *lo = v[0], *hi = v[1];
+  if (MODE == 2) *lo = res_cg_direction(v[0], *lo, beta), *hi = res_cg_direction(v[1], *hi, beta);
+  else *lo = v[0], *hi = v[1];
   put(at[0], v[2]), put(at[1], v[3]);
   // deep boxes with long lines: the rest of the halo, two pairs at a time
 #pragma unroll 1
@@ -411,9 +427,6 @@ __device__ __forceinline__ void res_lds_pair(const ResBox &B, double *P, int t, 
   if ((B.mask_a >> t) & 1u) *reinterpret_cast<double2r *>(&P[t * B.ldw + B.a + B.tid2]) = v;
 }
 
-__device__ __forceinline__ double2r res_cg_direction(double2r r, double2r p, double beta) {
-  return double2r{__builtin_fma(beta, p.x, r.x), __builtin_fma(beta, p.y, r.y)};  // r + beta p            SolverCg.hpp:123
-}
 
 // ---- CG ------------------------------------------------------------------------------------------------------------
 // Registers: r and the weight words of the own rows for the whole solve; z from the apply to `r -= alpha z`; x too
@@ -502,11 +515,19 @@ __global__ __launch_bounds__(kResThreads) void res_cg_kernel(ResArgs A) {
       lap(3);  // the first all-reduce
       const double alpha = safe_divide(gamma, acc[0]);
       acc[0] = 0.0;
+      const bool early = A.early_publish != 0;
+      if (early) ++xseq;  // (a fresh tag whether or not anybody will read the surface: see res_halo)
 #pragma unroll
       for (int t = 0; t < TZ; ++t) {
         r[t].x -= alpha * z[t].x, r[t].y -= alpha * z[t].y;
         acc[0] += r[t].x * r[t].x;
         acc[0] += r[t].y * r[t].y;
+      }
+      // the surface of the new residual travels under the all-reduce below; the neighbours form p' = r + beta p on it
+      if (early) {
+        const unsigned rtag = (unsigned)xseq;
+#pragma unroll
+        for (int t = 0; t < TZ; ++t) res_publish_pair(A, B, t, r[t], rtag);
       }
       if (!XREG) res_load_rows<TZ>(B, A.x, z);  // x, in z's place, travels under the all-reduce
       lap(4);  // r -= alpha z, <r, r> partials
@@ -521,7 +542,7 @@ __global__ __launch_bounds__(kResThreads) void res_cg_kernel(ResArgs A) {
       ++it;
       if (blockIdx.x == 0 && threadIdx.x == 0 && history) history[it] = abs_err;
       const bool go_on = !converged && it < num_iterations;
-      if (go_on) ++xseq;
+      if (go_on && !early) ++xseq;
       // x += alpha p; p = r + beta p (own rows: nobody else reads them before the next barrier)     :98, :123
 #pragma unroll
       for (int t = 0; t < TZ; ++t) {
@@ -534,12 +555,17 @@ __global__ __launch_bounds__(kResThreads) void res_cg_kernel(ResArgs A) {
         }
         if (go_on) {
           const double2r pn = res_cg_direction(r[t], pt, beta);
-          res_publish_pair(A, B, t, pn, (unsigned)xseq);
+          if (!early) res_publish_pair(A, B, t, pn, (unsigned)xseq);
           res_lds_pair(B, P, t, pn);
         }
       }
       lap(6);  // x += alpha p, p = r + beta p, the surface out
       if (!go_on) break;
+      if (early) {
+        if (__hip_atomic_load(A.gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        res_halo<TZ, 2>(A, B, P, (unsigned)xseq, nullptr, &lo, &hi, beta);
+        continue;
+      }
     }
     if (__hip_atomic_load(A.gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
     res_halo<TZ, 1>(A, B, P, (unsigned)xseq, nullptr, &lo, &hi);
@@ -839,6 +865,7 @@ int res_solve(bool bicgstab, const storm_hip_op *op, double alpha, double beta, 
   //  or two values the extra barrier and the trip through LDS cost more than the fewer requests save; the Gram-Schmidt
   //  chains, six and ten values, are the dense form's case.  coop_dense = 2 forces it here, for that A/B.)
   A.dense = c->opt_coop_dense == 2 ? c->d_res_slots + (size_t)2 * 256 * kLatSlotStride + 256 : nullptr;
+  A.early_publish = (int)(c->opt_resident_early != 0);
   A.st = d_state;
   A.prof = nullptr;
   if (c->opt_resident_profile != 0) {

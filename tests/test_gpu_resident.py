@@ -191,3 +191,32 @@ def test_resident_path_is_bitwise_reproducible_and_survives_many_solves(env, kin
     for h, x in runs[1:]:
         assert np.array_equal(h, runs[0][0]) and np.array_equal(x, runs[0][1])
     ma.close(), mb.close()
+
+
+@pytest.mark.parametrize("shape,planes", [c for c in CASES if c[1] <= 8][:6] + [((64, 64, 64), 0), ((100, 100, 100), 0)])
+def test_cg_residual_surface_published_early_is_bitwise_the_late_publish(env, shape, planes):
+    """CG's exchange under its second all-reduce (option resident_early; resident.hip: res_halo MODE 2): the surface of the
+    new RESIDUAL goes out before beta is known and every block forms p' = r + beta p on its halo itself -- the owner's
+    expression on the owner's operands.  Histories and solutions are BITWISE those of the publish behind the all-reduce,
+    solve after solve: each publish takes a fresh tag whether or not the solve goes on (the unconsumed last surface of a
+    solve under a tag the next solve reuses was the defect of the first attempt) -- so short solves are interleaved."""
+    api, mesh, oracle, ctx = env
+    g = mesh.structured_box(*shape, lengths=tuple(s / 64.0 for s in shape))
+    mat = api.StencilMatrix.from_face_graph(ctx, g)
+    op = api.HipStencilOperator(mat, -1.0, 0.0)
+    b_host = 1.0 + 0.25 * np.sin(0.01 * np.arange(g.n_cells))
+    try:
+        ctx.set_option("resident_early", 0)
+        ok0, s0, x0, taken0 = _solve(api, ctx, api.CgSolver, op, b_host, True, planes)
+        assert taken0 == 1
+        ctx.set_option("resident_early", 1)
+        for rep in range(5):
+            ok1, s1, x1, taken1 = _solve(api, ctx, api.CgSolver, op, b_host, True, planes)
+            assert taken1 == 1 and ok1 == ok0 and s1.iteration == s0.iteration
+            assert np.array_equal(np.asarray(s1.history), np.asarray(s0.history)), rep
+            assert np.array_equal(x1, x0), rep
+            # a solve that stops after a few iterations leaves an unconsumed surface behind
+            _solve(api, ctx, api.CgSolver, op, b_host + rep, True, planes, num_iterations=2 + rep)
+    finally:
+        ctx.set_option("resident_early", 0)
+        mat.close()
