@@ -152,7 +152,7 @@ struct storm_hip_ctx {
   int64_t opt_spmv_canon_tile = 2;   // format 4 on a lattice (offsets -b,-a,-1,+1,+a,+b): tiles of 1024 rows x this many planes (2, or 4) with the +-a / +-1 neighbours from LDS and the +-b ones from registers; 0 = the plain kernel.  Measured at 256^3 (profiles/r03f, r03g): CG step 242 (2 planes) / 247 (4) us per iteration, BiCGStab 496 / 510
   int64_t opt_vec_contiguous = 0;     // vectors in physically contiguous device memory (hipDeviceMallocContiguous)
   int64_t opt_mgs_steps = 4;          // throughput-path Gram-Schmidt: steps per pass over w (2: mgs_pair_kernel; 3, 4: mgs_multi_kernel)
-  int64_t opt_resident_early = 0;    // resident CG: the residual's surface published before the all-reduce that yields beta (res_halo MODE 2): bitwise the same solve, 3 - 7 % faster up to 64^3, 3 - 7 % slower from 100^3 on; off
+  int64_t opt_resident_early = 1;    // resident CG: the residual's surface published under the all-reduce that yields beta (res_halo MODE 2; behind the block's own arrival at that all-reduce): bitwise the same solve, 7 - 12 % faster (128^3: 16.8 -> 15.4 us per iteration)
   int64_t opt_coop_mgs_apply = 1;    // ... with the operator apply in front of it done by the chain kernel itself (format-4 lattice operators)
   int64_t opt_coop_mgs_pairs = 1;    // cooperative Gram-Schmidt chain: two steps per synchronisation point
   int64_t opt_coop_dense = 1;        // the multi-step Gram-Schmidt chain's all-reduce with dense value-major slots (0: the two-level form; 2: the resident kernels too)

@@ -75,12 +75,11 @@ struct ResArgs {
 };
 
 // ---- all-reduce over the co-resident grid (latency.hip's scheme for 8 waves per block) --------------------------
+// Two halves: ARRIVE (the block's sums folded and stored to its slot) and WAIT (every block's slot polled, the same tree in
+// every block) -- a caller may put stores of its own between them (CG's early publish: behind the block's slot in the
+// memory pipeline, not in front of it, or every block's arrival is late by the time those stores take to drain).
 template <int NV>
-__device__ __forceinline__ void res_allreduce(double (&s)[NV], const ResArgs &A, unsigned long long seq, double *lds) {
-  if (A.dense) {  // one 16-byte load per thread and poll, whole lines
-    co_allreduce_dense<NV, kResWaves>(s, A.dense, A.gave_up, seq, lds);
-    return;
-  }
+__device__ __forceinline__ void res_allreduce_arrive(const double (&s)[NV], const ResArgs &A, unsigned long long seq, double *lds) {
   const unsigned tag = (unsigned)seq;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   double v[NV];
@@ -98,6 +97,12 @@ __device__ __forceinline__ void res_allreduce(double (&s)[NV], const ResArgs &A,
     for (int w = 0; w < kResWaves; ++w) t += lds[threadIdx.x * kResWaves + w];
     co_store_slot(A.slots + lat_slot_offset(blockIdx.x, seq) + 16 * threadIdx.x, tag, t);
   }
+}
+template <int NV>
+__device__ __forceinline__ void res_allreduce_wait(double (&s)[NV], const ResArgs &A, unsigned long long seq, double *lds) {
+  const unsigned tag = (unsigned)seq;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  double v[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) v[j] = 0.0;
   if (threadIdx.x < gridDim.x) {  // gridDim.x <= 256: thread t (waves 0 .. 3) watches block t
@@ -130,6 +135,15 @@ __device__ __forceinline__ void res_allreduce(double (&s)[NV], const ResArgs &A,
 #pragma unroll
   for (int j = 0; j < NV; ++j)
     s[j] = (lds[j * kResWaves] + lds[j * kResWaves + 1]) + (lds[j * kResWaves + 2] + lds[j * kResWaves + 3]);
+}
+template <int NV>
+__device__ __forceinline__ void res_allreduce(double (&s)[NV], const ResArgs &A, unsigned long long seq, double *lds) {
+  if (A.dense) {  // one 16-byte load per thread and poll, whole lines
+    co_allreduce_dense<NV, kResWaves>(s, A.dense, A.gave_up, seq, lds);
+    return;
+  }
+  res_allreduce_arrive<NV>(s, A, seq, lds);
+  res_allreduce_wait<NV>(s, A, seq, lds);
 }
 
 // ---- the exchange: self-validating granules ---------------------------------------------------------------------
@@ -523,7 +537,11 @@ __global__ __launch_bounds__(kResThreads) void res_cg_kernel(ResArgs A) {
         acc[0] += r[t].x * r[t].x;
         acc[0] += r[t].y * r[t].y;
       }
-      // the surface of the new residual travels under the all-reduce below; the neighbours form p' = r + beta p on it
+      // the surface of the new residual travels under the all-reduce below; the neighbours form p' = r + beta p on it --
+      // BEHIND the block's own arrival at that all-reduce (in front of it every block arrives late by the time the
+      // surface's stores take to drain: 2.7 -> 5.2 us for the all-reduce at 128^3)
+      const bool split = early && A.dense == nullptr;
+      if (split) res_allreduce_arrive<1>(acc, A, seq + 1, red);
       if (early) {
         const unsigned rtag = (unsigned)xseq;
 #pragma unroll
@@ -531,7 +549,9 @@ __global__ __launch_bounds__(kResThreads) void res_cg_kernel(ResArgs A) {
       }
       if (!XREG) res_load_rows<TZ>(B, A.x, z);  // x, in z's place, travels under the all-reduce
       lap(4);  // r -= alpha z, <r, r> partials
-      res_allreduce<1>(acc, A, ++seq, red);
+      ++seq;
+      if (split) res_allreduce_wait<1>(acc, A, seq, red);
+      else res_allreduce<1>(acc, A, seq, red);
       lap(5);  // the second all-reduce
       const double gamma_bar = gamma;
       gamma = acc[0];

@@ -218,5 +218,5 @@ def test_cg_residual_surface_published_early_is_bitwise_the_late_publish(env, sh
             # a solve that stops after a few iterations leaves an unconsumed surface behind
             _solve(api, ctx, api.CgSolver, op, b_host + rep, True, planes, num_iterations=2 + rep)
     finally:
-        ctx.set_option("resident_early", 0)
+        ctx.set_option("resident_early", 1)
         mat.close()

@@ -23,9 +23,11 @@ def main():
     ap.add_argument("--shapes", default="64,128")
     ap.add_argument("--iters", type=int, default=300)
     ap.add_argument("--bicgstab", action="store_true")
+    ap.add_argument("--early", type=int, default=0, help="option resident_early (CG: the exchange under the second all-reduce)")
     args = ap.parse_args()
     ctx = api.Context(0)
     ctx.set_option("resident_profile", 1)
+    ctx.set_option("resident_early", args.early)
     for tok in args.shapes.split(","):
         dims = [int(v) for v in tok.split("x")]
         g = mesh.structured_box(*dims)
