@@ -442,6 +442,57 @@ __device__ __forceinline__ void res_lds_pair(const ResBox &B, double *P, int t, 
 }
 
 
+// MODE 2 in two steps (CG's early publish): the first batch of the halo -- everything, but for deep boxes with long lines
+// -- is fetched while the all-reduce that yields beta is still under way (the neighbours publish right behind their own
+// arrival at it: nobody waits for this block to do so), and turned into the halo of p' = r + beta p once beta is there.
+template <int TZ>
+__device__ __forceinline__ void res_halo2_fetch(const ResArgs &A, const ResBox &B, unsigned tag, double2r (&v)[4], int (&at)[2]) {
+  const int tid = threadIdx.x;
+  const int nh = B.tzl * B.a;
+  auto place = [&](int hh, int64_t *row, int *where) {
+    const int t = hh / B.a, j2 = 2 * (hh - t * B.a);
+    const bool lower = j2 < B.a;
+    const int jj = lower ? j2 : j2 - B.a;
+    *where = hh < nh ? t * B.ldw + (lower ? jj : B.a + B.L + jj) : -1;
+    *row = hh < nh ? (int64_t)(B.z0 + t) * B.b + B.s0 + (lower ? jj - B.a : B.L + jj) : -2;
+  };
+  const bool in = 2 * tid < B.L;
+  int64_t row[4];
+  row[0] = (in && B.z0 > 0) ? (int64_t)B.g0 - B.b : -2;
+  row[1] = (in && B.z0 + B.tzl < B.nplanes) ? (int64_t)B.g0 + (int64_t)B.tzl * B.b : -2;
+  place(tid, &row[2], &at[0]);
+  place(tid + kResThreads, &row[3], &at[1]);
+  res_fetch4(A, row, tag, v);
+}
+template <int TZ>
+__device__ __forceinline__ void res_halo2_finish(const ResArgs &A, const ResBox &B, double *P, unsigned tag, const double2r (&v)[4],
+                                                 const int (&at)[2], double2r *lo, double2r *hi, double beta) {
+  const int tid = threadIdx.x;
+  const int nh = B.tzl * B.a;
+  auto put = [&](int where, double2r val) {
+    if (where < 0) return;
+    *reinterpret_cast<double2r *>(&P[where]) = res_cg_direction(val, *reinterpret_cast<const double2r *>(&P[where]), beta);
+  };
+  *lo = res_cg_direction(v[0], *lo, beta), *hi = res_cg_direction(v[1], *hi, beta);
+  put(at[0], v[2]), put(at[1], v[3]);
+#pragma unroll 1
+  for (int h = tid + 2 * kResThreads; h < nh; h += 2 * kResThreads) {  // deep boxes with long lines: as res_halo
+    int64_t r2[2];
+    int a2[2];
+    for (int q = 0; q < 2; ++q) {
+      const int hh = h + q * kResThreads;
+      const int t = hh / B.a, j2 = 2 * (hh - t * B.a);
+      const bool lower = j2 < B.a;
+      const int jj = lower ? j2 : j2 - B.a;
+      a2[q] = hh < nh ? t * B.ldw + (lower ? jj : B.a + B.L + jj) : -1;
+      r2[q] = hh < nh ? (int64_t)(B.z0 + t) * B.b + B.s0 + (lower ? jj - B.a : B.L + jj) : -2;
+    }
+    double2r v0, v1;
+    res_fetch2(A, r2[0], r2[1], tag, &v0, &v1);
+    put(a2[0], v0), put(a2[1], v1);
+  }
+}
+
 // ---- CG ------------------------------------------------------------------------------------------------------------
 // Registers: r and the weight words of the own rows for the whole solve; z from the apply to `r -= alpha z`; x too
 // (XREG) where the box is at most 8 planes deep -- deeper boxes keep x in memory (the XCD's L2 holds its block's rows):
@@ -550,6 +601,13 @@ __global__ __launch_bounds__(kResThreads) void res_cg_kernel(ResArgs A) {
       if (!XREG) res_load_rows<TZ>(B, A.x, z);  // x, in z's place, travels under the all-reduce
       lap(4);  // r -= alpha z, <r, r> partials
       ++seq;
+      double2r hv[4] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
+      int hat[2] = {-1, -1};
+      // (shallow boxes only: at 128^3, eight planes per box and 3 584 surface rows per block, polling for the neighbours'
+      //  surfaces this early costs the all-reduce more than it saves behind it -- 16.9 against 15.4 us per iteration;
+      //  64^3, one plane per box: 8.4 against 9.2)
+      constexpr bool kFetchUnderAllreduce = TZ <= 2;
+      if (split && kFetchUnderAllreduce) res_halo2_fetch<TZ>(A, B, (unsigned)xseq, hv, hat);
       if (split) res_allreduce_wait<1>(acc, A, seq, red);
       else res_allreduce<1>(acc, A, seq, red);
       lap(5);  // the second all-reduce
@@ -583,7 +641,8 @@ __global__ __launch_bounds__(kResThreads) void res_cg_kernel(ResArgs A) {
       if (!go_on) break;
       if (early) {
         if (__hip_atomic_load(A.gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-        res_halo<TZ, 2>(A, B, P, (unsigned)xseq, nullptr, &lo, &hi, beta);
+        if (split && TZ <= 2) res_halo2_finish<TZ>(A, B, P, (unsigned)xseq, hv, hat, &lo, &hi, beta);
+        else res_halo<TZ, 2>(A, B, P, (unsigned)xseq, nullptr, &lo, &hi, beta);
         continue;
       }
     }
