@@ -272,7 +272,7 @@ int storm_hip_op_create_csr(storm_hip_ctx *ctx, int64_t n_rows, int64_t n_halo,
  *              2 always, 1 for vectors of at least blas1_nt_rows rows (longer vectors do not survive in the Infinity
  *              Cache between two kernels of a solve anyway; shorter ones do, and non-temporal accesses cost 3 - 7 %
  *              there).  Same values either way;
- *   vec_arena (1), vec_arena_slots (8), vec_arena_skew_kib (0): the vectors of one size (of at least 1 MiB) are slots of
+ *   vec_arena (1), vec_arena_slots (8), vec_arena_skew_kib (0), vec_arena_max_bytes (64 GiB: all arenas of a context): the vectors of one size (of at least 1 MiB) are slots of
  *              ONE physically contiguous allocation, a fixed distance apart (the smallest distance = 2 MiB modulo 4 MiB
  *              that holds the vector, + skew) -- separate allocations land 132 MiB apart at 256^3, a multiple of 4 MiB,
  *              which costs a multi-stream kernel 3 - 4 %; a released vector returns to the context's pool (a stack:

@@ -226,6 +226,7 @@ struct storm_hip_ctx {
   int64_t opt_bicg_fuse = 0;            // BiCGStab on a lattice: s = r - alpha v formed inside the apply t = A s (the marching kernel without its x update).  Measured at 256^3: the launch pair it replaces 61.5 + 67.2 us, the fused launch 117.9 us -- but the second half-step behind it then finds less of s and t in the Infinity Cache (139 -> 167 us): 452 against 445 us per iteration, so off
   int64_t opt_cg_roles = 8;             // solve_cg_body: permutation of the work vectors' roles over their arena slots (A/B knob; 24 permutations at 256^3: 4 505 - 4 570 it/s, profiles/r05z_roles.txt)
   int64_t opt_vec_arena_slots = 8;
+  int64_t opt_vec_arena_max_bytes = (int64_t)64 << 30;  // all arenas of a context together; beyond: vectors allocated one by one
   int64_t opt_vec_arena_skew_kib = 0;   // pitch = the vector rounded up to 2 MiB + this
   size_t pool_bytes = 0;
   int64_t opt_pool_bytes = (int64_t)16 << 30;

@@ -171,6 +171,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "bicg_fuse")) c->opt_bicg_fuse = value;
   else if (!strcmp(key, "vec_arena_contiguous")) c->opt_vec_arena_contiguous = value;
   else if (!strcmp(key, "vec_arena_slots")) c->opt_vec_arena_slots = value;
+  else if (!strcmp(key, "vec_arena_max_bytes")) c->opt_vec_arena_max_bytes = value;
   else if (!strcmp(key, "vec_arena_skew_kib")) c->opt_vec_arena_skew_kib = value;
   else if (!strcmp(key, "coop_mgs_lds")) c->opt_coop_mgs_lds = value;
   else if (!strcmp(key, "coop_mgs_quad")) c->opt_coop_mgs_quad = value;
@@ -477,6 +478,9 @@ static double *arena_take(storm_hip_ctx *c, size_t bytes) {
   }
   while (slots > 1 && (size_t)slots * pitch > ((size_t)12 << 30)) slots /= 2;  // (an arena of at most 12 GiB)
   if (slots < 2) return nullptr;
+  size_t held = 0;
+  for (const auto &h : c->arenas) held += (size_t)h.slots * h.pitch;
+  if (held + (size_t)slots * pitch > (size_t)c->opt_vec_arena_max_bytes) return nullptr;  // (many sizes in one context: enough reserved)
   storm_hip_ctx::VecArena a;
   a.bytes = bytes, a.pitch = pitch, a.slots = slots, a.used = 1;
   const size_t total = (size_t)slots * pitch;
