@@ -46,6 +46,7 @@ __device__ __forceinline__ void multi_dot_accumulate(int64_t n, const double *__
   const int64_t n2 = n >> 1;
   const double2v *__restrict__ a2 = reinterpret_cast<const double2v *>(a);
   constexpr int U = KB <= 2 ? kUnroll : (KB <= 4 ? 2 : 1);  // many streams: few accesses per stream in flight (tools/cg_kernels_bench.hip)
+  const bool same_vector = KB == 1 && bs.b[0] == a;
   nt_dispatch(nt, [&](auto nt) {
   for (int64_t base = (int64_t)bx * (kBlock * kUnroll) + threadIdx.x; base < n2;
        base += (int64_t)gridDim.x * (kBlock * kUnroll)) {
@@ -58,7 +59,11 @@ __device__ __forceinline__ void multi_dot_accumulate(int64_t n, const double *__
         if (i < n2) {
           va[u] = ld2(a2 + i, nt);
 #pragma unroll
-          for (int j = 0; j < KB; ++j) vb[u][j] = ld2(reinterpret_cast<const double2v *>(bs.b[j]) + i, nt);
+          for (int j = 0; j < KB; ++j) {
+            // (<a, a>: one load, not two of the same address -- the same operands, the same sum)
+            if (KB == 1 && same_vector) vb[u][j] = va[u];
+            else vb[u][j] = ld2(reinterpret_cast<const double2v *>(bs.b[j]) + i, nt);
+          }
         }
       }
 #pragma unroll
