@@ -29,7 +29,7 @@ Prints ONE JSON line on rank 0.
   roofline_unstructured  the 256^3 graph with a jittered geometry (no two weights equal => fp64 records, SURVEY 8d's
                     bytes), cells renumbered by the seeded permutation, then the library's ordering: the number a
                     Triangle / TetGen mesh of this size would get;
-  config3_bicgstab256, config4_gmres30_convdiff128, config5_cavity128   BASELINE configs 3, 4, 5 on this GPU, bounded;
+  config1_cg64, config3_bicgstab256, config4_gmres30_convdiff128, config5_cavity128   BASELINE configs 1, 3, 4, 5 on this GPU, bounded;
   extra_gmres30_poisson256   GMRES(30) at the headline size (kernel-per-statement path: the Gram-Schmidt passes at HBM scale);
   cpu_baseline      the CPU oracle (single thread, the reference is single-threaded) on a bounded sample.
 
@@ -626,6 +626,7 @@ def main() -> int:
             "roofline_general": general_roof,
             "roofline_permuted_rcm": permuted,
             "roofline_unstructured": unstructured,
+            "config1_cg64": (configs or {}).get("config1_cg64") if isinstance(configs, dict) else None,
             "config3_bicgstab256": (configs or {}).get("config3_bicgstab256") if isinstance(configs, dict) else None,
             "config4_gmres30_convdiff128": (configs or {}).get("config4_gmres30_convdiff128") if isinstance(configs, dict) else None,
             "config5_cavity128": (configs or {}).get("config5_cavity128") if isinstance(configs, dict) else None,
@@ -700,6 +701,21 @@ def baseline_configs(api, mesh, ctx, op, b, N, n, st, min_seconds):
             reps.append(time.perf_counter() - t0)
         return float(np.median(reps[1:])) / iters, len(reps) - 1
 
+    # ---- config 1 (the reference's own CPU-runnable case: CG on the 64^3 box; the CPU side of it is in cpu_baseline's sample)
+    try:
+        g1 = mesh.structured_box(64)
+        m1 = api.StencilMatrix.from_face_graph(ctx, g1)
+        b1 = api.DeviceVector(ctx, g1.n_cells)
+        api.fill_with(b1, 1.0)
+        r0 = ctx.counter("resident_solves")
+        sec, reps = rate(api.CgSolver, api.HipStencilOperator(m1, -1.0, 0.0), b1, g1.n_cells, 2000)
+        out["config1_cg64"] = {
+            "workload": "CG, 64^3 Poisson (BASELINE configs[0]), 2 000 iterations, tolerances off",
+            "iter_per_s": 1.0 / sec, "us_per_iteration": sec * 1e6,
+            "path": "resident (one persistent kernel per solve)" if ctx.counter("resident_solves") > r0 else "other", "repeats": reps}
+        m1.close()
+    except Exception as e:
+        out["config1_cg64"] = {"error": repr(e)}
     # ---- config 3
     try:
         sec, reps = rate(api.BiCgStabSolver, op, b, N, 60)
