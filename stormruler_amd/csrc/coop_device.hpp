@@ -278,6 +278,108 @@ __device__ __forceinline__ void co_allreduce2_n(double (&s)[NV], char *slots, in
 // go through LDS; value j is folded by lanes over the blocks in a fixed order (the same bits in every block, run to
 // run).  lds: NV x 256 + NV doubles.  slots: 2 x 16 x 256 x 16 bytes.  T = WAVES x 64 threads, all of them poll.
 constexpr int kDenseMaxValues = 16;
+// (in two halves, like res_allreduce: a caller may request loads of its own between the block's arrival and its wait for
+//  the others -- the Gram-Schmidt chain asks for the next group's vectors there)
+template <int NV, int WAVES>
+__device__ __forceinline__ void co_allreduce_dense_arrive(const double (&s)[NV], char *slots, unsigned long long seq, double *lds) {
+  static_assert(NV <= kDenseMaxValues && NV <= 2 * WAVES, "co_allreduce_dense: too many values");
+  constexpr int T = WAVES * kWave;
+  constexpr int MAXG = (256 * NV + T - 1) / T;  // granules per thread, at most
+  static_assert(MAXG <= 5, "co_allreduce_dense: at most five granules per thread");
+  const unsigned tag = (unsigned)seq;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  double v[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) v[j] = lat_wave_sum(s[j]);
+  __syncthreads();  // (lds may still be read by the previous call)
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) lds[j * WAVES + wave] = v[j];
+  }
+  __syncthreads();
+  char *base = slots + (size_t)(seq & 1) * kDenseMaxValues * 256 * 16;
+  if ((int)threadIdx.x < NV) {  // thread j folds and stores the block's sum j
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) t += lds[threadIdx.x * WAVES + w];
+    co_store_slot(base + ((size_t)threadIdx.x * 256 + blockIdx.x) * 16, tag, t);
+  }
+  __syncthreads();  // (the partials in lds are consumed: the polled values take their place)
+}
+template <int NV, int WAVES>
+__device__ __forceinline__ void co_allreduce_dense_wait(double (&s)[NV], char *slots, int *gave_up, unsigned long long seq, double *lds) {
+  constexpr int T = WAVES * kWave;
+  constexpr int MAXG = (256 * NV + T - 1) / T;  // granules per thread, at most
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const unsigned tag = (unsigned)seq;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const int nb = gridDim.x;
+  char *base = slots + (size_t)(seq & 1) * kDenseMaxValues * 256 * 16;
+  // this thread's granules: index g = t + T i over [value][block 0 .. 255]; blocks >= nb do not exist
+  const char *p[MAXG];
+  bool need[MAXG];
+#pragma unroll
+  for (int i = 0; i < MAXG; ++i) {
+    const int g = (int)threadIdx.x + T * i;
+    need[i] = g < 256 * NV && (g & 255) < nb;
+    p[i] = base + (size_t)(need[i] ? g : 0) * 16;
+  }
+  u32x4 w[MAXG];
+  const long long t0 = wall_clock64();
+  for (int spins = 0;; ++spins) {
+    if constexpr (MAXG == 1)
+      asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w[0]) : "v"(p[0]) : "memory");
+    else if constexpr (MAXG == 2)
+      asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                   : "=&v"(w[0]), "=&v"(w[1]) : "v"(p[0]), "v"(p[1]) : "memory");
+    else if constexpr (MAXG == 3)
+      asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\tglobal_load_dwordx4 %2, %5, off sc1\n\t"
+                   "s_waitcnt vmcnt(0)"
+                   : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]) : "v"(p[0]), "v"(p[1]), "v"(p[2]) : "memory");
+    else if constexpr (MAXG == 4)
+      asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off sc1\n\t"
+                   "global_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                   : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]) : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]) : "memory");
+    else
+      asm volatile("global_load_dwordx4 %0, %5, off sc1\n\tglobal_load_dwordx4 %1, %6, off sc1\n\tglobal_load_dwordx4 %2, %7, off sc1\n\t"
+                   "global_load_dwordx4 %3, %8, off sc1\n\tglobal_load_dwordx4 %4, %9, off sc1\n\ts_waitcnt vmcnt(0)"
+                   : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4])
+                   : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]) : "memory");
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i) ok = ok && (!need[i] || (w[i].y == tag && w[i].w == tag));
+    if (ok) break;
+    __builtin_amdgcn_s_sleep(1);
+    if ((spins & 1023) == 1023 &&
+        (wall_clock64() - t0 > kLatTimeoutTicks || __hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+      __hip_atomic_store(gave_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+  }
+  double *vals = lds;  // [NV][256]
+#pragma unroll
+  for (int i = 0; i < MAXG; ++i) {
+    const int g = (int)threadIdx.x + T * i;
+    if (g < 256 * NV) vals[g] = need[i] ? __hiloint2double((int)w[i].z, (int)w[i].x) : 0.0;
+  }
+  __syncthreads();
+  // value j by wave j % WAVES: lanes over the blocks l, l + 64, l + 128, l + 192, then the wave's tree -- a fixed order
+  double *res = lds + NV * 256;
+#pragma unroll
+  for (int r = 0; r < (NV + WAVES - 1) / WAVES; ++r) {
+    const int j = wave + r * WAVES;
+    if (j < NV) {
+      double t = (vals[j * 256 + lane] + vals[j * 256 + 64 + lane]) + (vals[j * 256 + 128 + lane] + vals[j * 256 + 192 + lane]);
+      t = lat_wave_sum(t);
+      if (lane == 0) res[j] = t;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NV; ++j) s[j] = res[j];
+}
+// (the two halves in one piece, as it was before the split: composing it from them cost the S = 8 chain kernel 2 us per
+//  inner iteration at 128^3 -- code placement, not instructions)
 template <int NV, int WAVES>
 __device__ __forceinline__ void co_allreduce_dense(double (&s)[NV], char *slots, int *gave_up, unsigned long long seq, double *lds) {
   static_assert(NV <= kDenseMaxValues && NV <= 2 * WAVES, "co_allreduce_dense: too many values");

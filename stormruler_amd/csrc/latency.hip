@@ -537,6 +537,7 @@ struct MgsArgs {
   long long *prof;   // option resident_profile: [gridDim.x][8] ticks per phase of this launch (diagnostic)
   char *quad_slots;  // mgs_chain_quad_kernel: all-reduce slots of kQuadSlotStride bytes (two-level form) / dense granules
   int dense;         // ... the flat all-reduce with dense value-major slots instead of the two-level one
+  int prefetch;      // ... with the next group's vectors requested between its halves (S <= 4)
   // mgs_chain_quad_kernel<S, T, true>: w is not read but FORMED -- w = beta x + alpha M(x), x = ap_x (the newest basis
   // vector), from the operator's format-4 records with spmv_canon_kernel's arithmetic (the same bits): the apply's
   // launch and the round trip of w through memory disappear (SolverGmres.hpp:155 inside the kernel that consumes it)
@@ -974,20 +975,33 @@ __global__ __launch_bounds__(kQuadThreads) void mgs_chain_quad_kernel(MgsArgs a)
       tick[p] += now - t_mark, t_mark = now;
     }
   };
+  // Where the registers allow it (S <= 4) the NEXT group's vectors are requested between the block's arrival at the
+  // all-reduce and its wait for the others (co_allreduce_dense_arrive / _wait): their latency hides in the wait.
+  constexpr bool kPrefetch = S <= 4;
+  double2m qn[kPrefetch ? T : 1][kPrefetch ? S : 1];
+  bool prefetched = false;
   for (int i = 0; i <= a.k; i += T) {
     lap(0);  // the update of w
     double2m q[T][S];
+    if (kPrefetch && prefetched) {
 #pragma unroll
-    for (int v = 0; v < T; ++v) {
-      const bool have = i + v <= a.k;  // (uniform; a vector past the end reads as zeros: its h comes out 0)
-      const char *src = reinterpret_cast<const char *>(a.q[have ? i + v : i]);
+      for (int v = 0; v < T; ++v)
 #pragma unroll
-      for (int j = 0; j < S; ++j) {
-        q[v][j] = double2m{0.0, 0.0};
-        if (have && va[j]) q[v][j] = *reinterpret_cast<const double2m *>(src + off8[j]);
-        q[v][j].y = vb[j] ? q[v][j].y : 0.0;
+        for (int j = 0; j < S; ++j) q[v][j] = qn[kPrefetch ? v : 0][kPrefetch ? j : 0];
+    } else {
+#pragma unroll
+      for (int v = 0; v < T; ++v) {
+        const bool have = i + v <= a.k;  // (uniform; a vector past the end reads as zeros: its h comes out 0)
+        const char *src = reinterpret_cast<const char *>(a.q[have ? i + v : i]);
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+          q[v][j] = double2m{0.0, 0.0};
+          if (have && va[j]) q[v][j] = *reinterpret_cast<const double2m *>(src + off8[j]);
+          q[v][j].y = vb[j] ? q[v][j].y : 0.0;
+        }
       }
     }
+    prefetched = false;
     // T = 4: <w,q0..3>, <q0,q1>, <q0,q2>, <q0,q3>, <q1,q2>, <q1,q3>, <q2,q3>;  T = 3: <w,q0..2>, <q0,q1>, <q0,q2>, <q1,q2>
     double d[ND];
 #pragma unroll
@@ -1005,8 +1019,31 @@ __global__ __launch_bounds__(kQuadThreads) void mgs_chain_quad_kernel(MgsArgs a)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (a.prof) __syncthreads();  // (diagnostic: the whole block's rows have landed)
     lap(1);  // the group's rows (issue -> landed) and the dot products
-    if (a.dense) co_allreduce_dense<ND, kQuadWaves>(d, slots, gave_up, ++seq, lds);
-    else co_allreduce2_n<ND, kQuadWaves>(d, slots, kQuadSlotStride, gave_up, ++seq, lds);
+    if (a.dense && kPrefetch && a.prefetch != 0) {
+      ++seq;
+      co_allreduce_dense_arrive<ND, kQuadWaves>(d, slots, seq, lds);
+      if (i + T <= a.k) {
+        if constexpr (kPrefetch) {
+#pragma unroll
+          for (int v = 0; v < T; ++v) {
+            const bool have = i + T + v <= a.k;
+            const char *src = reinterpret_cast<const char *>(a.q[have ? i + T + v : i + T]);
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+              qn[v][j] = double2m{0.0, 0.0};
+              if (have && va[j]) qn[v][j] = *reinterpret_cast<const double2m *>(src + off8[j]);
+              qn[v][j].y = vb[j] ? qn[v][j].y : 0.0;
+            }
+          }
+        }
+        prefetched = true;
+      }
+      co_allreduce_dense_wait<ND, kQuadWaves>(d, slots, gave_up, seq, lds);
+    } else if (a.dense) {
+      co_allreduce_dense<ND, kQuadWaves>(d, slots, gave_up, ++seq, lds);
+    } else {
+      co_allreduce2_n<ND, kQuadWaves>(d, slots, kQuadSlotStride, gave_up, ++seq, lds);
+    }
     lap(2);  // the all-reduce
     double h[T];
     {
@@ -1190,6 +1227,7 @@ int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w
                                                                         : MgsGivens{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   a.quad_slots = c->d_quad_slots;
   a.dense = (int)(c->opt_coop_dense != 0);
+  a.prefetch = (int)(c->opt_coop_mgs_prefetch != 0);
   a.ap_pack = nullptr, a.ap_dict = nullptr, a.ap_x = nullptr, a.ap_max_gather = 0, a.ap_alpha = 0.0, a.ap_beta = 0.0;
   for (int i = 0; i < 6; ++i) a.ap_off[i] = 0;
   if (with_apply) {

@@ -318,3 +318,30 @@ def test_chain_kernel_applies_the_operator_itself_with_the_same_bits(shape):
         assert np.allclose(runs["register chain"][0], runs["launch"][0], rtol=1e-9), name
         mat.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 33), (100, 50, 40), (20, 18, 16)])
+def test_chain_prefetch_under_the_all_reduce_changes_no_bit(shape):
+    """Option coop_mgs_prefetch: the next group's basis vectors requested between the block's arrival at the all-reduce and
+    its wait for the others (co_allreduce_dense_arrive / _wait; up to four row pairs per thread) -- loads moved, nothing
+    else: histories and solutions bitwise equal."""
+    from stormruler_amd import api, mesh
+
+    ctx = api.Context(0)
+    g = mesh.structured_box(*shape, lengths=tuple(s / 64.0 for s in shape))
+    mat = api.StencilMatrix.from_face_graph(ctx, g)
+    b_host = 1.0 + 0.3 * np.sin(0.02 * np.arange(g.n_cells))
+    ctx.set_option("coop_mgs_min_rows", 0)
+    runs = []
+    for pf in (0, 1):
+        ctx.set_option("coop_mgs_prefetch", pf)
+        s = api.GmresSolver()
+        s.num_inner_iterations, s.record_history, s.num_iterations = 30, True, 75
+        s.absolute_error_tolerance = s.relative_error_tolerance = 0.0
+        b, x = api.DeviceVector.from_numpy(ctx, b_host), api.DeviceVector(ctx, g.n_cells)
+        s.solve(x, b, api.HipStencilOperator(mat, -1.0, 0.0))
+        assert s.path_fallback == 0
+        runs.append((np.asarray(s.history), x.to_numpy()))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+    mat.close()
+    ctx.close()
