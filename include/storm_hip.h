@@ -258,10 +258,11 @@ int storm_hip_op_create_csr(storm_hip_ctx *ctx, int64_t n_rows, int64_t n_halo,
  *   latency_path (1), latency_rows (2^19), latency_cache (1): CG / BiCGStab of a small halo-free operator as ONE
  *              cooperative kernel per solve (0: neither this nor the resident path below; 2: this path only); the size limit (latency_rows is read when the operator is built); the
  *              operator records in registers;
- *   coop_mgs (1), coop_mgs_min_rows (0), coop_mgs_pairs (1), coop_mgs_apply (1), coop_mgs_prefetch (1): GMRES's Gram-Schmidt chain as one
+ *   coop_mgs (1), coop_mgs_min_rows (0), coop_mgs_pairs (1), coop_mgs_apply (1), coop_mgs_prefetch (1), coop_mgs_lds_prefetch (1): GMRES's Gram-Schmidt chain as one
  *              cooperative kernel per Arnoldi step; from how many rows on; several steps per synchronisation point; the
  *              operator apply in front of the chain done by the same kernel (format-4 lattice operators); the next
- *              group's basis vectors requested under the all-reduce (up to four row pairs per thread);
+ *              group's basis vectors requested under the all-reduce (into registers up to four row pairs per thread,
+ *              through LDS at eight);
  *   fused_reduce (1): engine reductions of at most 256 partial blocks finish in the partials kernel's last block;
  *   sweep_alternate (1): consecutive streaming kernels of a solve sweep the rows from opposite ends (Infinity Cache);
  *   spmv_canon_groups (2): 128-row groups per wavefront of the format-4 / 5 kernel;

@@ -880,11 +880,15 @@ __global__ __launch_bounds__(kLatBlock) void mgs_chain_lds_kernel(MgsArgs a) {
 // runs in the reference's order.
 constexpr int kQuadThreads = 512, kQuadWaves = kQuadThreads / kWave, kQuadSub = 2 * kQuadThreads;
 constexpr int kQuadSlotStride = 256;  // ten values of 16 bytes
-template <int S, int T, bool APPLY = false>  // T = 3 or 4 steps per synchronisation point
+// LDSPF (S = 8, where no second set of vectors fits the registers): of the NEXT group's T vectors the first lands in
+// registers and the others in LDS (LDS-DMA, 64 KiB per vector: `global_load_lds_dwordx4` has no register destination),
+// all requested between the halves of the all-reduce; a thread reads back exactly the 16 bytes its own DMA wrote.
+template <int S, int T, bool APPLY = false, bool LDSPF = false>  // T = 3 or 4 steps per synchronisation point
 __global__ __launch_bounds__(kQuadThreads) void mgs_chain_quad_kernel(MgsArgs a) {
   if (a.done && *a.done) return;  // (uniform: every block reads the same flag before any of them synchronises)
   __shared__ double lds[10 * 256 + 16];  // co_allreduce_dense: NV x 256 polled values + the NV results
   __shared__ double dict_sh[32];
+  extern __shared__ __attribute__((aligned(16))) double pf_ring[];  // LDSPF: [T - 1][S][kQuadSub] doubles
   __shared__ double hcol[kMgsMaxVectors + 1], cs_sh[kMgsMaxVectors], sn_sh[kMgsMaxVectors];
   const bool rotate = a.givens.st != nullptr && blockIdx.x == 0;
   if (rotate && (int)threadIdx.x < a.k) cs_sh[threadIdx.x] = a.givens.cs[threadIdx.x], sn_sh[threadIdx.x] = a.givens.sn[threadIdx.x];
@@ -978,12 +982,28 @@ __global__ __launch_bounds__(kQuadThreads) void mgs_chain_quad_kernel(MgsArgs a)
   // Where the registers allow it (S <= 4) the NEXT group's vectors are requested between the block's arrival at the
   // all-reduce and its wait for the others (co_allreduce_dense_arrive / _wait): their latency hides in the wait.
   constexpr bool kPrefetch = S <= 4;
-  double2m qn[kPrefetch ? T : 1][kPrefetch ? S : 1];
+  double2m qn[kPrefetch ? T : 1][(kPrefetch || LDSPF) ? S : 1];
   bool prefetched = false;
+  const unsigned pf_base = LDSPF ? (unsigned)(size_t)(__attribute__((address_space(3))) void *)pf_ring : 0u;
+  const int pf_wave = tid >> 6;
   for (int i = 0; i <= a.k; i += T) {
     lap(0);  // the update of w
     double2m q[T][S];
-    if (kPrefetch && prefetched) {
+    if (LDSPF && prefetched) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's DMAs (and register loads) have landed
+#pragma unroll
+      for (int j = 0; j < S; ++j) q[0][j] = qn[0][LDSPF ? j : 0];
+#pragma unroll
+      for (int v = 1; v < T; ++v) {
+        const bool have = i + v <= a.k;
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+          const double2m t = *reinterpret_cast<const double2m *>(&pf_ring[((v - 1) * S + j) * kQuadSub + 2 * tid]);
+          q[v][j].x = (have && va[j]) ? t.x : 0.0, q[v][j].y = (have && vb[j]) ? t.y : 0.0;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and are in registers: the landing zone may be refilled
+    } else if (kPrefetch && prefetched) {
 #pragma unroll
       for (int v = 0; v < T; ++v)
 #pragma unroll
@@ -1019,10 +1039,32 @@ __global__ __launch_bounds__(kQuadThreads) void mgs_chain_quad_kernel(MgsArgs a)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (a.prof) __syncthreads();  // (diagnostic: the whole block's rows have landed)
     lap(1);  // the group's rows (issue -> landed) and the dot products
-    if (a.dense && kPrefetch && a.prefetch != 0) {
+    if (a.dense && (kPrefetch || LDSPF) && a.prefetch != 0) {
       ++seq;
       co_allreduce_dense_arrive<ND, kQuadWaves>(d, slots, seq, lds);
       if (i + T <= a.k) {
+        if constexpr (LDSPF) {
+          {  // the group's first vector: registers
+            const char *src = reinterpret_cast<const char *>(a.q[i + T]);
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+              qn[0][j] = double2m{0.0, 0.0};
+              if (va[j]) qn[0][j] = *reinterpret_cast<const double2m *>(src + off8[j]);
+              qn[0][j].y = vb[j] ? qn[0][j].y : 0.0;
+            }
+          }
+#pragma unroll
+          for (int v = 1; v < T; ++v) {  // the others: LDS-DMA (rows past the end: any valid address, masked when read back)
+            if (i + T + v <= a.k) {
+              const char *src = reinterpret_cast<const char *>(a.q[i + T + v]);
+#pragma unroll
+              for (int j = 0; j < S; ++j) {
+                const unsigned dst = __builtin_amdgcn_readfirstlane(pf_base + (unsigned)((((v - 1) * S + j) * kQuadSub + pf_wave * 2 * kWave) * 8));
+                glds16(src + off8[j], dst);
+              }
+            }
+          }
+        }
         if constexpr (kPrefetch) {
 #pragma unroll
           for (int v = 0; v < T; ++v) {
@@ -1179,11 +1221,20 @@ int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w
     if (with_apply)
       qf = sv == 1 ? (const void *)mgs_chain_quad_kernel<1, 4, true> : sv == 2 ? (const void *)mgs_chain_quad_kernel<2, 4, true>
          : sv == 4 ? (const void *)mgs_chain_quad_kernel<4, 3, true> : (const void *)mgs_chain_quad_kernel<8, 3, true>;
-    static int quad_resident[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
-    int &res = quad_resident[(sv == 1 ? 0 : sv == 2 ? 1 : sv == 4 ? 2 : 3) + (with_apply ? 4 : 0)];
+    // eight row pairs per thread: the next group's vectors through LDS (mgs_chain_quad_kernel<8, 3, APPLY, true>)
+    size_t quad_lds = 0;
+    // (with the apply only: the kernel that reads w instead has no registers left for the first vector -- 65 spills)
+    const bool lds_pf = sv == 8 && with_apply && c->opt_coop_dense != 0 && c->opt_coop_mgs_prefetch != 0 && c->opt_coop_mgs_lds_prefetch != 0;
+    if (lds_pf) {
+      qf = (const void *)mgs_chain_quad_kernel<8, 3, true, true>;
+      quad_lds = sizeof(double) * 2 * 8 * (size_t)kQuadSub;
+    }
+    static int quad_resident[12] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+    int &res = quad_resident[lds_pf ? 8 : (sv == 1 ? 0 : sv == 2 ? 1 : sv == 4 ? 2 : 3) + (with_apply ? 4 : 0)];
     if (res < 0) {
       res = 0;
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&res, qf, kQuadThreads, 0);
+      if (quad_lds == 0 || hipFuncSetAttribute(qf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_lds) == hipSuccess)
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&res, qf, kQuadThreads, quad_lds);
       (void)hipGetLastError();
     }
     if (res >= 1) {
@@ -1192,7 +1243,7 @@ int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w
         HIP_TRY(hipMalloc((void **)&c->d_quad_slots, bytes));
         HIP_TRY(hipMemsetAsync(c->d_quad_slots, 0, bytes, c->stream));
       }
-      fn = qf, dyn_lds = 0, threads = kQuadThreads, blocks = (qsubs_total + sv - 1) / sv;
+      fn = qf, dyn_lds = quad_lds, threads = kQuadThreads, blocks = (qsubs_total + sv - 1) / sv;
     } else {
       with_apply = false;
     }

@@ -320,11 +320,12 @@ def test_chain_kernel_applies_the_operator_itself_with_the_same_bits(shape):
     ctx.close()
 
 
-@pytest.mark.parametrize("shape", [(64, 64, 33), (100, 50, 40), (20, 18, 16)])
+@pytest.mark.parametrize("shape", [(64, 64, 33), (100, 50, 40), (20, 18, 16), (128, 128, 112), (128, 128, 128)])
 def test_chain_prefetch_under_the_all_reduce_changes_no_bit(shape):
-    """Option coop_mgs_prefetch: the next group's basis vectors requested between the block's arrival at the all-reduce and
-    its wait for the others (co_allreduce_dense_arrive / _wait; up to four row pairs per thread) -- loads moved, nothing
-    else: histories and solutions bitwise equal."""
+    """Options coop_mgs_prefetch / coop_mgs_lds_prefetch: the next group's basis vectors requested between the block's
+    arrival at the all-reduce and its wait for the others (co_allreduce_dense_arrive / _wait) -- into registers up to four
+    row pairs per thread, the first vector into registers and the others through LDS (LDS-DMA) at eight (the 128^3 of
+    BASELINE config 4; ragged last block at 112 planes) -- loads moved, nothing else: histories and solutions bitwise equal."""
     from stormruler_amd import api, mesh
 
     ctx = api.Context(0)
@@ -335,6 +336,7 @@ def test_chain_prefetch_under_the_all_reduce_changes_no_bit(shape):
     runs = []
     for pf in (0, 1):
         ctx.set_option("coop_mgs_prefetch", pf)
+        ctx.set_option("coop_mgs_lds_prefetch", pf)
         s = api.GmresSolver()
         s.num_inner_iterations, s.record_history, s.num_iterations = 30, True, 75
         s.absolute_error_tolerance = s.relative_error_tolerance = 0.0
