@@ -198,6 +198,7 @@ struct storm_hip_ctx {
   int opt_latency_cache = 1;            // ... with the wave's operator records held in registers where they fit
   int64_t opt_latency_rows = 1 << 19;   // ... up to this many rows (a compact copy of the operator is kept for it)
   int64_t opt_rccl_fused = 1;           // RCCL transport: the fused CG step on a partitioned lattice operator (boundary planes of the new direction packed by a small kernel, sent under the marching launch)
+  int64_t opt_rccl_ticket = 1;          // ... with the LOCAL sums of <p,z> and <r,r> finished inside the kernels that produce them (tickets); the all-reduce and the scalar step stay launches
   int64_t opt_ipc_fused = 1;            // peer-window transport: the interior launch sends, the boundary launch reads the window (0: stand-alone send / receive-copy kernels)
   int64_t opt_ipc_streams = 2;          // peer-window halo exchange: 2 = on the comm stream beside the interior rows, 1 = on the compute stream around them
   int64_t opt_generic_solvers = 0;  // 1: storm_hip_krylov_solve never takes the fused CG / BiCGStab / GMRES loops (A/B knob)

@@ -308,10 +308,11 @@ __global__ __launch_bounds__(kBlock) void cg_r_kernel(int64_t n, SolverState *st
   const double mine[1] = {s};
   double total[1];
   if (ticket_reduce_wave0<1>(tickets, mine, 1, bx, gridDim.x, total)) {
-    if (use_ipc) ipc_allreduce_wave<1>(w, total, 1);  // the global <r,r>: the same bits on every rank
+    if (use_ipc == 1) ipc_allreduce_wave<1>(w, total, 1);  // the global <r,r>: the same bits on every rank
     if (threadIdx.x == 0) {
       st->s[S_GAMMA_NEW] = total[0];
-      do_step(STEP_CG_RR, st, GmresDev{});
+      // (use_ipc == 2: this rank's sum only -- the host enqueues the all-reduce and the step behind this kernel)
+      if (use_ipc != 2) do_step(STEP_CG_RR, st, GmresDev{});
     }
   }
 }
@@ -1266,6 +1267,10 @@ int solve_cg_body(const FusedSolveArgs &args) {
   const bool rccl = c->comm != nullptr && comm_is_rccl(c);
   const bool fuse_step = c->opt_cg_fuse != 0 && c->opt_fuse_dot != 0 && spmv_can_fuse_cg(op) &&
                          (rccl ? true : ((c->comm == nullptr || ipc) && tick && !tick_spmv));
+  // RCCL: the local sums still finish inside the kernels that produce them (tickets) -- the library all-reduce and the
+  // scalar step follow as launches of their own; two small launches per iteration fewer than partials + final pass
+  const bool rtick = rccl && fuse_step && c->opt_ticket_reduce != 0 && c->opt_rccl_ticket != 0 &&
+                     nbv <= kTicketGroup * kTicketMaxGroups;
   double *p_alt = nullptr;
   if (fuse_step) p_alt = pool.v[v0 + role[3]]->d, ++c->n_cg_fused_steps;
   int64_t last_enqueued = -1;
@@ -1293,6 +1298,11 @@ int solve_cg_body(const FusedSolveArgs &args) {
       const double *bs[1] = {z};
       STORM_TRY(k_multi_dot(c, p, bs, 1, n, d.slot(S_PZ), d.done));
       if (c->comm != nullptr) STORM_TRY(comm_allreduce_sum(c, d.slot(S_PZ), 1));
+    } else if (rtick && (int64_t)nb + kStage2 <= c->partials_capacity) {
+      hipLaunchKernelGGL(reduce_stage1_ticket_kernel, dim3(kStage2), dim3(kBlock), 0, c->stream, c->d_partials, nb,
+                         d.slot(S_PZ), d.st, TicketArgs{c->d_tickets, c->d_partials + nb, c->d_ticket_sums}, ipc_w, 0);
+      HIP_TRY(hipGetLastError());
+      STORM_TRY(comm_allreduce_sum(c, d.slot(S_PZ), 1));
     } else if (tick && (nb > kSinglePassPartials || ipc) && c->opt_fold_pz != 0 && (int64_t)nb + kStage2 <= c->partials_capacity) {
       // many partials, one rank: ONE small launch folds them and finishes the sum itself (tickets); cg_r_kernel reads
       // <p,z> from the slab and starts streaming at once.  (The block sums go behind the SpMV's partials.)
@@ -1312,10 +1322,14 @@ int solve_cg_body(const FusedSolveArgs &args) {
     // r -= alpha z; gamma = <r,r>                     SolverCg.hpp:97,99,115
     hipLaunchKernelGGL(cg_r_kernel, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, r, z, c->d_partials,
                        nt_stream, pz_partials, (int)kStage2, sweep ? 1 - q : 0,
-                       tick ? TicketArgs{c->d_tickets, c->d_partials, c->d_ticket_sums} : TicketArgs{nullptr, nullptr, nullptr},
-                       ipc_w, (int)(ipc && tick));
+                       (tick || rtick) ? TicketArgs{c->d_tickets, c->d_partials, c->d_ticket_sums} : TicketArgs{nullptr, nullptr, nullptr},
+                       ipc_w, rtick ? 2 : (int)(ipc && tick));
     HIP_TRY(hipGetLastError());
-    if (!tick) {
+    if (rtick) {
+      STORM_TRY(comm_allreduce_sum(c, d.slot(S_GAMMA_NEW), 1));
+      hipLaunchKernelGGL(step_kernel, dim3(1), dim3(1), 0, c->stream, (int)STEP_CG_RR, d.st, d.g, false);
+      HIP_TRY(hipGetLastError());
+    } else if (!tick) {
       const int slots[1] = {S_GAMMA_NEW};
       STORM_TRY(d.finish(nbv, 1, slots, STEP_CG_RR));
     }

@@ -140,10 +140,11 @@ def test_fused_cg_step_over_rccl_gives_the_unfused_iteration(shape):
 
     b_host = np.cos(0.05 * np.arange(loc.n_cells)) + 0.3
     runs = {}
-    for fused in (1, 0):
+    for fused in (1, 2, 0):  # (2: fused, the local sums by partials + a final pass instead of tickets)
         ctx = api.Context(0)
         ctx.set_option("spmv_canon_tile_min_rows", 0)  # (the lattice kernels on a slab this small)
-        ctx.set_option("rccl_fused", fused)
+        ctx.set_option("rccl_fused", min(fused, 1))
+        ctx.set_option("rccl_ticket", int(fused == 1))
         ctx.comm_init(api.Context.comm_unique_id(), 1, 0)
         mat = api.StencilMatrix.from_face_graph(ctx, loc)
         mat.set_halo([0], [0, loc.n_halo], send_idx, [0, loc.n_halo])
@@ -162,12 +163,13 @@ def test_fused_cg_step_over_rccl_gives_the_unfused_iteration(shape):
         runs[(fused, "limit")] = (s2.absolute_error, x2.to_numpy())
         mat.close()
         ctx.close()
-    assert runs[1][3] == 1 and runs[0][3] == 0
-    assert runs[1][0] == runs[0][0]
-    assert np.allclose(runs[1][1], runs[0][1], rtol=1e-9)
-    assert np.linalg.norm(runs[1][2] - runs[0][2]) <= 1e-10 * np.linalg.norm(runs[0][2])
-    assert np.isclose(runs[(1, "limit")][0], runs[(0, "limit")][0], rtol=1e-10)
-    assert np.linalg.norm(runs[(1, "limit")][1] - runs[(0, "limit")][1]) <= 1e-10 * np.linalg.norm(runs[(0, "limit")][1])
+    assert runs[1][3] == 1 and runs[2][3] == 1 and runs[0][3] == 0
+    for f in (1, 2):
+        assert runs[f][0] == runs[0][0]
+        assert np.allclose(runs[f][1], runs[0][1], rtol=1e-9)
+        assert np.linalg.norm(runs[f][2] - runs[0][2]) <= 1e-10 * np.linalg.norm(runs[0][2])
+        assert np.isclose(runs[(f, "limit")][0], runs[(0, "limit")][0], rtol=1e-10)
+        assert np.linalg.norm(runs[(f, "limit")][1] - runs[(0, "limit")][1]) <= 1e-10 * np.linalg.norm(runs[(0, "limit")][1])
     ref = oracle.solve("cg", oracle.CallbackOperator(loc.n_cells, ref_apply), b_host)
     assert abs(runs[1][0] - ref.iterations) <= max(2, int(0.02 * ref.iterations))
     assert np.linalg.norm(runs[1][2] - ref.x) <= 1e-8 * np.linalg.norm(ref.x)

@@ -20,6 +20,7 @@ from test_gpu_comm import _periodic_z_local_graph  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 only = sys.argv[2] if len(sys.argv) > 2 else ""  # "ipc" / "rccl": that transport alone, few iterations (for a kernel trace)
 iters = int(os.environ.get("COMM_ITERS", "60" if only else "400"))
+solver = os.environ.get("COMM_SOLVER", "cg")  # "bicgstab": BASELINE config 2's loop
 
 
 def rate(ctx, mat, g):
@@ -28,7 +29,7 @@ def rate(ctx, mat, g):
     best = 0.0
     for _ in range(3):
         x = api.DeviceVector(ctx, g.n_cells, g.n_halo)
-        s = api.CgSolver()
+        s = api.BiCgStabSolver() if solver == "bicgstab" else api.CgSolver()
         s.num_iterations, s.absolute_error_tolerance, s.relative_error_tolerance = iters, 0.0, 0.0
         ctx.sync()
         t0 = time.perf_counter()
@@ -38,7 +39,7 @@ def rate(ctx, mat, g):
     return best
 
 
-out = {"n": n}
+out = {"n": n, "solver": solver}
 ctx = api.Context(0)
 g0 = mesh.structured_box(n)
 for fmt in (() if only else (4, 3)):
