@@ -57,7 +57,7 @@ __device__ __forceinline__ bool ipc_tag_ok(ipc_u64x2 w, unsigned long long tag_h
 }
 // one 16-byte write-through store at system scope (each 8-byte half single-copy atomic)
 __device__ __forceinline__ void ipc_store16(void *p, ipc_u64x2 w) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(w) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(w) : "memory");  // (s_nop 1: the store-data hazard the compiler does not see inside asm, resident.hip res_store16)
 }
 // one 16-byte load that bypasses the caches of this device (a line of the window this XCD's L2 may hold is stale)
 __device__ __forceinline__ ipc_u64x2 ipc_load16(const void *p) {

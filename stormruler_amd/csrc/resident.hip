@@ -46,6 +46,7 @@ constexpr int kResThreads = 512;                // 8 waves: two per SIMD, 256 re
 constexpr int kResWaves = kResThreads / kWave;
 constexpr int kResRun = 2 * kResThreads;        // rows of a plane per block: one pair per thread
 constexpr int kResMaxPlanes = 12;               // planes per block, at most (registers)
+constexpr int kResMaxPlanesBicgEarly = 4;       // ... of its early-publish form
 constexpr int kResMaxPlanesBicg = 8;            // ... of the BiCGStab kernel (r, p, v and the result of an apply: 227 registers at 8 planes)
 
 typedef double double2r __attribute__((ext_vector_type(2)));
@@ -65,13 +66,14 @@ struct ResArgs {
   char *exch;          // the exchange buffer: one 16-byte granule per row -- the even rows' granules, then (exch_half bytes on) the odd
                        // rows': a wave's pairs of rows go out, and come in, as two runs of 1 KiB (whole lines) instead of 64 half-filled ones
   size_t exch_half;
+  size_t exch_stride;   // a second exchange buffer this many bytes on (BiCGStab's early publish: one per travelling vector)
   char *slots;         // all-reduce slots, kLatSlotStride bytes per (block, parity)
   char *dense;         // ... or (non-null) dense value-major granules: co_allreduce_dense, coop_device.hpp
   int *gave_up;        // the latency path's flag (lat_check_gave_up)
   long long *prof;     // option resident_profile: [gridDim.x][8] ticks of the 100 MHz counter per phase of the loop, summed over the solve
   unsigned long long *cnt;  // [0] all-reduce sequence number, [1] exchange sequence number: carried from solve to solve
   SolverState *st;
-  int early_publish;  // CG: the residual's surface before the second all-reduce (res_halo MODE 2)
+  int early_publish;  // CG: the residual's surface before the second all-reduce (res_halo MODE 2); BiCGStab: res_bicgstab_early_kernel
 };
 
 // ---- all-reduce over the co-resident grid (latency.hip's scheme for 8 waves per block) --------------------------
@@ -150,8 +152,13 @@ __device__ __forceinline__ void res_allreduce(double (&s)[NV], const ResArgs &A,
 __device__ __forceinline__ u32x4r res_granule(double v, unsigned tag) {
   return u32x4r{(unsigned)__double2loint(v), tag, (unsigned)__double2hiint(v), tag};
 }
+// (s_nop 1: a store of more than 8 bytes must be two wait states ahead of a VALU write to its data registers on gfx940+; the
+//  compiler keeps that distance for its own stores but does not look inside an asm statement -- round 4 found
+//  `v_mov_b64 v[8:9], -2` ONE wait state behind this store in res_bicgstab_early_kernel<1>: the granule went out with a
+//  clobbered upper half, its tag never validated and the reader timed out.  The same pattern sat in res_cg_kernel<12>, and
+//  it is the likely cause of the "hang that any change to a cold path cures" met in CG's early publish.)
 __device__ __forceinline__ void res_store16(char *p, u32x4r w) {  // one write-through store, each 8-byte half single-copy atomic
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(w) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(w) : "memory");
 }
 __device__ __forceinline__ bool res_tag_ok(u32x4r w, unsigned tag) { return w.y == tag && w.w == tag; }
 __device__ __forceinline__ double res_value(u32x4r w) { return __hiloint2double((int)w.z, (int)w.x); }
@@ -832,11 +839,267 @@ __global__ __launch_bounds__(kResThreads) void res_bicgstab_kernel(ResArgs A) {
   }
 }
 
+// ---- BiCGStab, early publish (round 4) -----------------------------------------------------------------------------
+// The loop above waits for its neighbours five times per iteration: three all-reduces and the halos of p and of s.  Both
+// halos can be FORMED instead of fetched: p' = r + beta (p - omega v) and s = r - alpha v hold on the halo rows as on the
+// own rows, with the owner's own expressions on the owner's own operands -- the same bits -- if the block keeps the halos
+// of r, p and v.  What must travel is what an apply produced: the surface of v = A p, published right behind the block's
+// arrival at the all-reduce of <rt, v> and fetched while that all-reduce is under way; and the surface of the new
+// residual r = s - omega t, published and fetched under the all-reduce of |r|, <rt, r> (at init: under that of <r, r>).
+// Three waits per iteration instead of five.  The two surfaces use two exchange buffers: a block that has passed the
+// last all-reduce goes on to publish v without another synchronisation, while a neighbour may still be reading r.
+// Halo sets (LDS, behind the copy): Hr, Hp, Hv, [tzl][2 a] doubles each, pair hh always handled by the same thread; the
+// pairs of the planes below / above in registers.  Boxes of at most 4 planes (registers and LDS to spare there).
+template <int TZ>
+__device__ __forceinline__ void res_halo_place(const ResBox &B, int hh, int64_t *row, int *at) {
+  const int nh = B.tzl * B.a;
+  const int t = hh / B.a, j2 = 2 * (hh - t * B.a);
+  const bool lower = j2 < B.a;
+  const int jj = lower ? j2 : j2 - B.a;
+  *at = hh < nh ? t * B.ldw + (lower ? jj : B.a + B.L + jj) : -1;
+  *row = hh < nh ? (int64_t)(B.z0 + t) * B.b + B.s0 + (lower ? jj - B.a : B.L + jj) : -2;
+}
+// the surface published with `tag` -> the halo set H and the pairs below / above
+template <int TZ>
+__device__ __forceinline__ void res_halo_fetch_set(const ResArgs &A, const ResBox &B, unsigned tag, double *H, double2r *lo, double2r *hi) {
+  const int tid = threadIdx.x;
+  const int nh = B.tzl * B.a;
+  const bool in = 2 * tid < B.L;
+  int64_t row[4];
+  int at[2];
+  row[0] = (in && B.z0 > 0) ? (int64_t)B.g0 - B.b : -2;
+  row[1] = (in && B.z0 + B.tzl < B.nplanes) ? (int64_t)B.g0 + (int64_t)B.tzl * B.b : -2;
+  res_halo_place<TZ>(B, tid, &row[2], &at[0]);
+  res_halo_place<TZ>(B, tid + kResThreads, &row[3], &at[1]);
+  double2r v[4];
+  res_fetch4(A, row, tag, v);
+  *lo = v[0], *hi = v[1];
+  if (at[0] >= 0) *reinterpret_cast<double2r *>(&H[2 * tid]) = v[2];
+  if (at[1] >= 0) *reinterpret_cast<double2r *>(&H[2 * (tid + kResThreads)]) = v[3];
+#pragma unroll 1
+  for (int h = tid + 2 * kResThreads; h < nh; h += 2 * kResThreads) {
+    int64_t r2[2];
+    int a2[2];
+    res_halo_place<TZ>(B, h, &r2[0], &a2[0]);
+    res_halo_place<TZ>(B, h + kResThreads, &r2[1], &a2[1]);
+    double2r v0, v1;
+    res_fetch2(A, r2[0], r2[1], tag, &v0, &v1);
+    if (a2[0] >= 0) *reinterpret_cast<double2r *>(&H[2 * h]) = v0;
+    if (a2[1] >= 0) *reinterpret_cast<double2r *>(&H[2 * (h + kResThreads)]) = v1;
+  }
+}
+__device__ __forceinline__ void res_publish_surface_pair(char *exch, size_t exch_half, const ResBox &B, int t, double2r v, unsigned tag) {
+  if (((B.mask_a >> t) & 1u) && (B.edge_y || t == 0 || t == B.tzl - 1)) {
+    char *e = exch + (size_t)res_off8(B, t);
+    res_store16(e, res_granule(v.x, tag));
+    if ((B.mask_b >> t) & 1u) res_store16(e + exch_half, res_granule(v.y, tag));
+  }
+}
+
+template <int TZ, bool XLDS>
+__global__ __launch_bounds__(kResThreads) void res_bicgstab_early_kernel(ResArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double P[];  // the copy, [XLDS: x of the own rows,] Hr, Hp, Hv
+  __shared__ double dict_sh[32];
+  __shared__ double red[2 * 256 + 16];
+  const ResBox B0 = res_box<TZ>(A);
+  ResBox B = B0;
+  SolverState *st = A.st;
+  if (threadIdx.x < 32) dict_sh[threadIdx.x] = A.dict[threadIdx.x];
+  unsigned long long seq = A.cnt[0], xseq = A.cnt[1];
+  const double abs_tol = st->abs_tol, rel_tol = st->rel_tol;
+  const long long num_iterations = st->num_iterations;
+  double *history = st->history;
+  char *const exch_v = A.exch, *const exch_r = A.exch + A.exch_stride;
+  double2r r[TZ], p[TZ], v[TZ];
+  u64x2r w[TZ];
+  res_load_weights<TZ>(A, B, w);
+  double2r lo, hi;  // of the vector in the copy
+  double2r r_lo, r_hi, p_lo{0.0, 0.0}, p_hi{0.0, 0.0}, v_lo{0.0, 0.0}, v_hi{0.0, 0.0};
+  double *Q = P + TZ * B0.ldw;
+  double *Hr = Q + (XLDS ? TZ * kResRun : 0), *Hp = Hr + TZ * 2 * A.a, *Hv = Hp + TZ * 2 * A.a;
+  const int nh = B0.tzl * B0.a;
+  for (int h = threadIdx.x; h < nh; h += kResThreads)
+    *reinterpret_cast<double2r *>(&Hp[2 * h]) = *reinterpret_cast<double2r *>(&Hv[2 * h]) = double2r{0.0, 0.0};
+#pragma unroll
+  for (int t = 0; t < TZ; ++t) {
+    const double2r xt = ((B.mask_a >> t) & 1u) ? res_ld_pair(A.x, res_off8(B, t)) : double2r{0.0, 0.0};
+    res_lds_pair(B, P, t, xt);
+    if (XLDS) *reinterpret_cast<double2r *>(&Q[t * kResRun + B.tid2]) = xt;
+    p[t] = v[t] = double2r{0.0, 0.0};
+  }
+  res_halo<TZ, 0>(A, B, P, 0u, A.x, &lo, &hi);
+  __syncthreads();
+  double rho, initial_error, abs_err, rel_err = 0.0, alpha = 0.0, beta = 0.0, omega = 0.0;
+  {  // ---- init: r = b - A x; rt = r; rho = <rt, r>                              SolverBiCgStab.hpp:82-90
+    double2r y[TZ];
+    res_apply<TZ>(A, B, P, dict_sh, lo, hi, w, y);
+    res_load_rows<TZ>(B, A.rhs, r);
+    double a1[1] = {0.0};
+#pragma unroll
+    for (int t = 0; t < TZ; ++t) {
+      r[t].x = ((B.mask_a >> t) & 1u) ? r[t].x - y[t].x : 0.0;
+      r[t].y = ((B.mask_b >> t) & 1u) ? r[t].y - y[t].y : 0.0;
+      res_st_pair(A.rt, res_off8(B, t), r[t], (B.mask_a >> t) & 1u, (B.mask_b >> t) & 1u);
+      a1[0] += r[t].x * r[t].x;
+      a1[0] += r[t].y * r[t].y;
+    }
+    res_allreduce_arrive<1>(a1, A, ++seq, red);
+    ++xseq;
+#pragma unroll
+    for (int t = 0; t < TZ; ++t) res_publish_surface_pair(exch_r, A.exch_half, B, t, r[t], (unsigned)xseq);
+    A.exch = exch_r;
+    res_halo_fetch_set<TZ>(A, B, (unsigned)xseq, Hr, &r_lo, &r_hi);
+    res_allreduce_wait<1>(a1, A, seq, red);
+    rho = a1[0];
+  }
+  initial_error = abs_err = sqrt(rho);
+  bool converged = abs_tol > 0.0 && initial_error < abs_tol;  // Solver.hpp:124-128
+  if (blockIdx.x == 0 && threadIdx.x == 0 && history) history[0] = initial_error;
+  long long it = 0;
+  long long tick[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_mark = A.prof ? wall_clock64() : 0;
+  auto lap = [&](int k) {
+    if (A.prof) {
+      const long long now = wall_clock64();
+      tick[k] += now - t_mark, t_mark = now;
+    }
+  };
+  while (!converged && it < num_iterations) {
+    if (__hip_atomic_load(A.gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    // p = r + beta (p - omega v) (first iteration: p = r) on the own rows AND on the halo; v = A p      :114-119, :137-139
+    // (the copy's last readers -- of s -- are behind two all-reduces)
+    B = res_fresh(B0);
+#pragma unroll
+    for (int t = 0; t < TZ; ++t) {
+      p[t].x = res_bicg_direction(r[t].x, p[t].x, v[t].x, beta, omega);
+      p[t].y = res_bicg_direction(r[t].y, p[t].y, v[t].y, beta, omega);
+      res_lds_pair(B, P, t, p[t]);
+    }
+    p_lo.x = res_bicg_direction(r_lo.x, p_lo.x, v_lo.x, beta, omega), p_lo.y = res_bicg_direction(r_lo.y, p_lo.y, v_lo.y, beta, omega);
+    p_hi.x = res_bicg_direction(r_hi.x, p_hi.x, v_hi.x, beta, omega), p_hi.y = res_bicg_direction(r_hi.y, p_hi.y, v_hi.y, beta, omega);
+#pragma unroll 1
+    for (int h = threadIdx.x; h < nh; h += kResThreads) {
+      int64_t row;
+      int at;
+      res_halo_place<TZ>(B, h, &row, &at);
+      const double2r hr = *reinterpret_cast<const double2r *>(&Hr[2 * h]), hv = *reinterpret_cast<const double2r *>(&Hv[2 * h]);
+      double2r hp = *reinterpret_cast<const double2r *>(&Hp[2 * h]);
+      hp.x = res_bicg_direction(hr.x, hp.x, hv.x, beta, omega), hp.y = res_bicg_direction(hr.y, hp.y, hv.y, beta, omega);
+      *reinterpret_cast<double2r *>(&Hp[2 * h]) = hp;
+      *reinterpret_cast<double2r *>(&P[at]) = hp;
+    }
+    __syncthreads();
+    lap(0);  // p = r + beta (p - omega v), own rows and halo
+    lap(1);
+    res_apply<TZ>(A, B, P, dict_sh, p_lo, p_hi, w, v);
+    lap(2);  // v = A p
+    {
+      double a1[1] = {0.0};
+#pragma unroll
+      for (int t = 0; t < TZ; ++t) {
+        const double2r rt = ((B.mask_a >> t) & 1u) ? res_ld_pair(A.rt, res_off8(B, t)) : double2r{0.0, 0.0};
+        a1[0] += rt.x * v[t].x, a1[0] += ((B.mask_b >> t) & 1u) ? rt.y * v[t].y : 0.0;
+      }
+      res_allreduce_arrive<1>(a1, A, ++seq, red);
+      ++xseq;
+#pragma unroll
+      for (int t = 0; t < TZ; ++t) res_publish_surface_pair(exch_v, A.exch_half, B, t, v[t], (unsigned)xseq);
+      A.exch = exch_v;
+      res_halo_fetch_set<TZ>(A, B, (unsigned)xseq, Hv, &v_lo, &v_hi);
+      res_allreduce_wait<1>(a1, A, seq, red);
+      alpha = safe_divide(rho, a1[0]);
+    }
+    lap(3);  // <rt, v> (rt from memory), its all-reduce; under it the surface of v out and the neighbours' in
+    // s = r - alpha v (kept in r) on the own rows and on the halo; t = A s; omega = <t, s> / <t, t>        :140-141, :158-160
+    // (every block is past the alpha all-reduce: nobody reads the copy of p any more)
+    B = res_fresh(B0);
+#pragma unroll
+    for (int t = 0; t < TZ; ++t) {
+      r[t].x = __builtin_fma(-alpha, v[t].x, r[t].x);
+      r[t].y = __builtin_fma(-alpha, v[t].y, r[t].y);
+      res_lds_pair(B, P, t, r[t]);
+    }
+    lo = double2r{__builtin_fma(-alpha, v_lo.x, r_lo.x), __builtin_fma(-alpha, v_lo.y, r_lo.y)};
+    hi = double2r{__builtin_fma(-alpha, v_hi.x, r_hi.x), __builtin_fma(-alpha, v_hi.y, r_hi.y)};
+#pragma unroll 1
+    for (int h = threadIdx.x; h < nh; h += kResThreads) {
+      int64_t row;
+      int at;
+      res_halo_place<TZ>(B, h, &row, &at);
+      const double2r hr = *reinterpret_cast<const double2r *>(&Hr[2 * h]), hv = *reinterpret_cast<const double2r *>(&Hv[2 * h]);
+      *reinterpret_cast<double2r *>(&P[at]) = double2r{__builtin_fma(-alpha, hv.x, hr.x), __builtin_fma(-alpha, hv.y, hr.y)};
+    }
+    __syncthreads();
+    lap(4);  // s = r - alpha v, own rows and halo
+    double2r y[TZ];
+    res_apply<TZ>(A, B, P, dict_sh, lo, hi, w, y);
+    lap(5);  // t = A s
+    double acc[2] = {0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < TZ; ++t) {
+      acc[0] += y[t].x * r[t].x, acc[0] += y[t].y * r[t].y;
+      acc[1] += y[t].x * y[t].x, acc[1] += y[t].y * y[t].y;
+    }
+    res_allreduce<2>(acc, A, ++seq, red);
+    lap(6);  // <t, s>, <t, t> and their all-reduce
+    omega = safe_divide(acc[0], acc[1]);
+    // x += alpha p + omega s; r = s - omega t; |r|, <rt, r>                                    :140, :161-164, :116
+    acc[0] = acc[1] = 0.0;
+    B = res_fresh(B0);
+#pragma unroll
+    for (int t = 0; t < TZ; ++t) {
+      double2r xv = XLDS ? *reinterpret_cast<const double2r *>(&Q[t * kResRun + B.tid2])
+                         : ((B.mask_a >> t) & 1u) ? res_ld_pair(A.x, res_off8(B, t)) : double2r{0.0, 0.0};
+      const double2r rt = ((B.mask_a >> t) & 1u) ? res_ld_pair(A.rt, res_off8(B, t)) : double2r{0.0, 0.0};
+      xv.x += alpha * p[t].x, xv.y += alpha * p[t].y;
+      xv.x += omega * r[t].x, xv.y += omega * r[t].y;
+      if (XLDS) *reinterpret_cast<double2r *>(&Q[t * kResRun + B.tid2]) = xv;
+      else res_st_pair(A.x, res_off8(B, t), xv, (B.mask_a >> t) & 1u, (B.mask_b >> t) & 1u);
+      r[t].x -= omega * y[t].x, r[t].y -= omega * y[t].y;
+      acc[0] += r[t].x * r[t].x, acc[0] += r[t].y * r[t].y;
+      acc[1] += rt.x * r[t].x, acc[1] += ((B.mask_b >> t) & 1u) ? rt.y * r[t].y : 0.0;
+    }
+    res_allreduce_arrive<2>(acc, A, ++seq, red);
+    ++xseq;  // (a fresh tag whether or not the solve goes on: see res_halo)
+#pragma unroll
+    for (int t = 0; t < TZ; ++t) res_publish_surface_pair(exch_r, A.exch_half, B, t, r[t], (unsigned)xseq);
+    A.exch = exch_r;
+    res_halo_fetch_set<TZ>(A, B, (unsigned)xseq, Hr, &r_lo, &r_hi);
+    res_allreduce_wait<2>(acc, A, seq, red);
+    lap(7);  // x += alpha p + omega s, r = s - omega t, |r|, <rt, r>, their all-reduce; under it the surface of r out and in
+    const double rho_bar = rho;
+    rho = acc[1];
+    beta = safe_divide(alpha * rho, omega * rho_bar);  // :116-118, for the next iteration
+    abs_err = sqrt(acc[0]);
+    rel_err = abs_err / initial_error;
+    converged = (abs_tol > 0.0 && abs_err < abs_tol) || (rel_tol > 0.0 && rel_err < rel_tol);  // Solver.hpp:132-140
+    ++it;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && history) history[it] = abs_err;
+  }
+  if (XLDS) {
+    B = res_fresh(B0);
+#pragma unroll
+    for (int t = 0; t < TZ; ++t)
+      res_st_pair(A.x, res_off8(B, t), *reinterpret_cast<const double2r *>(&Q[t * kResRun + B.tid2]), (B.mask_a >> t) & 1u, (B.mask_b >> t) & 1u);
+  }
+  if (A.prof && threadIdx.x == 0)
+    for (int k = 0; k < 8; ++k) A.prof[blockIdx.x * 8 + k] = tick[k];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    A.cnt[0] = seq, A.cnt[1] = xseq;
+    st->initial_error = initial_error;
+    st->absolute_error = abs_err;
+    st->relative_error = rel_err;
+    st->iteration = it;
+    st->converged = converged ? 1 : 0;
+    st->done = 1;
+  }
+}
+
 // ---- host ----------------------------------------------------------------------------------------------------------
 struct ResGeometry {
   int a, b, nplanes, nsec, tz, blocks;
   size_t lds_bytes;
   bool x_lds;  // BiCGStab: x of the own rows in LDS beside the copy
+  bool early;  // BiCGStab: res_bicgstab_early_kernel (halo sets of r, p, v behind the copy)
 };
 // Does the operator run on the resident path, and how: the smallest number of planes per block with which one block
 // per CU covers the lattice.
@@ -862,9 +1125,12 @@ static bool res_geometry(const storm_hip_op *op, ResGeometry *G, bool bicgstab =
     const size_t lds = sizeof(double) * (size_t)tz * (size_t)(kResRun + 2 * a);
     if (blocks > cus || lds > (size_t)150 * 1024) continue;
     G->a = a, G->b = b, G->nplanes = (int)nplanes, G->nsec = (int)nsec, G->tz = tz, G->blocks = (int)blocks, G->lds_bytes = lds;
-    G->x_lds = false;
+    G->x_lds = false, G->early = false;
     const size_t with_x = lds + sizeof(double) * (size_t)tz * kResRun;
     if (bicgstab && with_x <= (size_t)156 * 1024) G->x_lds = true, G->lds_bytes = with_x;
+    const size_t sets = sizeof(double) * (size_t)3 * (size_t)tz * (size_t)(2 * a);
+    if (bicgstab && c->opt_resident_early != 0 && tz <= kResMaxPlanesBicgEarly && G->lds_bytes + sets <= (size_t)156 * 1024)
+      G->early = true, G->lds_bytes += sets;
     return true;
   }
   return false;
@@ -876,7 +1142,9 @@ bool res_eligible(const storm_hip_op *op, bool bicgstab) {
 }
 
 template <int TZ>
-static const void *res_kernel(bool bicgstab, bool x_lds) {
+static const void *res_kernel(bool bicgstab, bool x_lds, bool early = false) {
+  if constexpr (TZ <= kResMaxPlanesBicgEarly)
+    if (bicgstab && early) return x_lds ? (const void *)res_bicgstab_early_kernel<TZ, true> : (const void *)res_bicgstab_early_kernel<TZ, false>;
   return bicgstab ? (x_lds ? (const void *)res_bicgstab_kernel<TZ, true> : (const void *)res_bicgstab_kernel<TZ, false>)
                   : (const void *)res_cg_kernel<TZ, (TZ <= 8)>;
 }
@@ -895,10 +1163,10 @@ int res_solve(bool bicgstab, const storm_hip_op *op, double alpha, double beta, 
   }
   const void *fn = nullptr;
   switch (G.tz) {
-    case 1: fn = res_kernel<1>(bicgstab, G.x_lds); break;
-    case 2: fn = res_kernel<2>(bicgstab, G.x_lds); break;
-    case 3: fn = res_kernel<3>(bicgstab, G.x_lds); break;
-    case 4: fn = res_kernel<4>(bicgstab, G.x_lds); break;
+    case 1: fn = res_kernel<1>(bicgstab, G.x_lds, G.early); break;
+    case 2: fn = res_kernel<2>(bicgstab, G.x_lds, G.early); break;
+    case 3: fn = res_kernel<3>(bicgstab, G.x_lds, G.early); break;
+    case 4: fn = res_kernel<4>(bicgstab, G.x_lds, G.early); break;
     case 6: fn = res_kernel<6>(bicgstab, G.x_lds); break;
     case 8: fn = res_kernel<8>(bicgstab, G.x_lds); break;
     case 12: fn = res_kernel<12>(bicgstab, G.x_lds); break;
@@ -921,12 +1189,13 @@ int res_solve(bool bicgstab, const storm_hip_op *op, double alpha, double beta, 
   }
   // the exchange buffer (one granule per row) and the slots: zero-filled once, tags only ever grow
   const size_t exch_half = (size_t)16 * (size_t)((op->n_rows + 3) / 2 + 8);  // (the even rows' granules; 256-byte aligned start of the odd rows')
+  const size_t exch_stride = (2 * exch_half + 256 + 255) / 256 * 256;  // (two buffers: BiCGStab's early publish)
   if (c->res_exch_rows < op->n_rows + 2) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->d_res_exch) (void)hipFree(c->d_res_exch);
     c->d_res_exch = nullptr, c->res_exch_rows = 0;
-    HIP_TRY(hipMalloc((void **)&c->d_res_exch, 2 * exch_half + 256));
-    HIP_TRY(hipMemsetAsync(c->d_res_exch, 0, 2 * exch_half + 256, c->stream));
+    HIP_TRY(hipMalloc((void **)&c->d_res_exch, 2 * exch_stride));
+    HIP_TRY(hipMemsetAsync(c->d_res_exch, 0, 2 * exch_stride, c->stream));
     c->res_exch_rows = op->n_rows + 2;
   }
   if (c->d_res_slots == nullptr) {
@@ -937,7 +1206,7 @@ int res_solve(bool bicgstab, const storm_hip_op *op, double alpha, double beta, 
   ResArgs A{};
   A.pack = op->d_pack, A.dict = op->d_dict, A.a = G.a, A.b = G.b, A.nplanes = G.nplanes, A.nsec = G.nsec, A.n_rows = op->n_rows;
   A.alpha = alpha, A.beta = beta, A.rhs = b, A.x = x, A.rt = rt;
-  A.exch = c->d_res_exch, A.exch_half = (exch_half + 255) / 256 * 256, A.slots = c->d_res_slots;
+  A.exch = c->d_res_exch, A.exch_half = (exch_half + 255) / 256 * 256, A.exch_stride = exch_stride, A.slots = c->d_res_slots;
   A.gave_up = reinterpret_cast<int *>(c->d_lat_slots + (size_t)2 * 256 * kLatSlotStride);
   A.cnt = reinterpret_cast<unsigned long long *>(c->d_res_slots + (size_t)2 * 256 * kLatSlotStride);
   // (measured A/B, CG us per iteration with the dense form / the 64-byte slots: 64^3 10.0 / 8.9, 128^3 16.9 / 15.8 -- with ONE

@@ -220,3 +220,35 @@ def test_cg_residual_surface_published_early_is_bitwise_the_late_publish(env, sh
     finally:
         ctx.set_option("resident_early", 1)
         mat.close()
+
+
+@pytest.mark.parametrize("shape,planes", [c for c in CASES if c[1] <= 4 and c[0] != (128, 128, 128)] + [((64, 64, 9), 1), ((36, 30, 8), 1)])
+def test_bicgstab_halos_formed_from_early_surfaces_are_bitwise_the_exchanged_ones(env, shape, planes):
+    """BiCGStab's early publish (resident.hip: res_bicgstab_early_kernel, boxes of at most 4 planes): the halos of
+    p' = r + beta (p - omega v) and of s = r - alpha v are FORMED by every block from the halos of r, p and v it keeps -- the
+    owner's expressions on the owner's operands --; what travels are the surfaces of v = A p and of the new residual,
+    under the all-reduces that follow them (three waits per iteration instead of five).  Histories and solutions BITWISE
+    those of the exchanged halos (option resident_early = 0), solve after solve with short solves in between (every
+    publish takes a fresh tag), on a non-symmetric operator."""
+    api, mesh, oracle, ctx = env
+    g = mesh.structured_box(*shape, lengths=tuple(n / 64.0 for n in shape))
+    wi, wo, de = mesh.convection_diffusion_weights(g, 1e-2, (1.0, 0.5, 0.25))
+    mat = api.StencilMatrix.from_face_weights(ctx, g.n_cells, g.n_halo, g.inner, g.outer, wi, wo, de)
+    op = api.HipStencilOperator(mat, 1.0, 0.0)
+    b_host = 1.0 + 0.25 * np.sin(0.01 * np.arange(g.n_cells))
+    try:
+        ctx.set_option("resident_early", 0)
+        ok0, s0, x0, taken0 = _solve(api, ctx, api.BiCgStabSolver, op, b_host, True, planes)
+        assert taken0 == 1 and s0.path_fallback == 0
+        ctx.set_option("resident_early", 1)
+        for rep in range(4):
+            ok1, s1, x1, taken1 = _solve(api, ctx, api.BiCgStabSolver, op, b_host, True, planes)
+            assert taken1 == 1 and s1.path_fallback == 0 and ok1 == ok0 and s1.iteration == s0.iteration
+            assert np.array_equal(np.asarray(s1.history), np.asarray(s0.history)), rep
+            assert np.array_equal(x1, x0), rep
+            _solve(api, ctx, api.BiCgStabSolver, op, b_host + rep, True, planes, num_iterations=1 + rep)
+            # ... and a CG solve in between shares the exchange buffer and the tag counter
+            _solve(api, ctx, api.CgSolver, api.HipStencilOperator(mat, 1.0, 0.0), b_host, True, planes, num_iterations=3)
+    finally:
+        ctx.set_option("resident_early", 1)
+        mat.close()
