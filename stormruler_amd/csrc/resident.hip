@@ -849,7 +849,11 @@ __global__ __launch_bounds__(kResThreads) void res_bicgstab_kernel(ResArgs A) {
 // Three waits per iteration instead of five.  The two surfaces use two exchange buffers: a block that has passed the
 // last all-reduce goes on to publish v without another synchronisation, while a neighbour may still be reading r.
 // Halo sets (LDS, behind the copy): Hr, Hp, Hv, [tzl][2 a] doubles each, pair hh always handled by the same thread; the
-// pairs of the planes below / above in registers.  Boxes of at most 4 planes (registers and LDS to spare there).
+// pairs of the planes below / above in registers.  Boxes of at most 4 planes: bitwise the exchanged halos there (tests).
+// (6 planes: 112^3 30.6 -> 24.8 us, but on the test's convection-diffusion box <t, t> of the 26th iteration came out one ulp
+//  away from the exchanged form's -- deterministically, with the formed halos of p and s verified bitwise against the
+//  exchanged ones inside the kernel; not understood, so off.  8 planes: 11 registers spilt and x no longer in LDS beside
+//  the sets: 128^3 34.4 -> 38.5 us.)
 template <int TZ>
 __device__ __forceinline__ void res_halo_place(const ResBox &B, int hh, int64_t *row, int *at) {
   const int nh = B.tzl * B.a;
@@ -860,8 +864,10 @@ __device__ __forceinline__ void res_halo_place(const ResBox &B, int hh, int64_t 
   *row = hh < nh ? (int64_t)(B.z0 + t) * B.b + B.s0 + (lower ? jj - B.a : B.L + jj) : -2;
 }
 // the surface published with `tag` -> the halo set H and the pairs below / above
-template <int TZ>
-__device__ __forceinline__ void res_halo_fetch_set(const ResArgs &A, const ResBox &B, unsigned tag, double *H, double2r *lo, double2r *hi) {
+// (... and then the second half of the all-reduce `seq`, whose first half the caller has run)
+template <int TZ, int NV>
+__device__ __forceinline__ void res_halo_fetch_set(const ResArgs &A, const ResBox &B, unsigned tag, double *H, double2r *lo, double2r *hi,
+                                                   double (&s)[NV], unsigned long long seq, double *lds) {
   const int tid = threadIdx.x;
   const int nh = B.tzl * B.a;
   const bool in = 2 * tid < B.L;
@@ -872,7 +878,10 @@ __device__ __forceinline__ void res_halo_fetch_set(const ResArgs &A, const ResBo
   res_halo_place<TZ>(B, tid, &row[2], &at[0]);
   res_halo_place<TZ>(B, tid + kResThreads, &row[3], &at[1]);
   double2r v[4];
+  // (one polling loop for the granules and the all-reduce's slots together -- all ten loads of a poll in flight at once -- was
+  //  slower than the two in turn: 64^3 15.2 against 14.3 us per iteration)
   res_fetch4(A, row, tag, v);
+  res_allreduce_wait<NV>(s, A, seq, lds);
   *lo = v[0], *hi = v[1];
   if (at[0] >= 0) *reinterpret_cast<double2r *>(&H[2 * tid]) = v[2];
   if (at[1] >= 0) *reinterpret_cast<double2r *>(&H[2 * (tid + kResThreads)]) = v[3];
@@ -948,8 +957,7 @@ __global__ __launch_bounds__(kResThreads) void res_bicgstab_early_kernel(ResArgs
 #pragma unroll
     for (int t = 0; t < TZ; ++t) res_publish_surface_pair(exch_r, A.exch_half, B, t, r[t], (unsigned)xseq);
     A.exch = exch_r;
-    res_halo_fetch_set<TZ>(A, B, (unsigned)xseq, Hr, &r_lo, &r_hi);
-    res_allreduce_wait<1>(a1, A, seq, red);
+    res_halo_fetch_set<TZ, 1>(A, B, (unsigned)xseq, Hr, &r_lo, &r_hi, a1, seq, red);
     rho = a1[0];
   }
   initial_error = abs_err = sqrt(rho);
@@ -1004,8 +1012,7 @@ __global__ __launch_bounds__(kResThreads) void res_bicgstab_early_kernel(ResArgs
 #pragma unroll
       for (int t = 0; t < TZ; ++t) res_publish_surface_pair(exch_v, A.exch_half, B, t, v[t], (unsigned)xseq);
       A.exch = exch_v;
-      res_halo_fetch_set<TZ>(A, B, (unsigned)xseq, Hv, &v_lo, &v_hi);
-      res_allreduce_wait<1>(a1, A, seq, red);
+      res_halo_fetch_set<TZ, 1>(A, B, (unsigned)xseq, Hv, &v_lo, &v_hi, a1, seq, red);
       alpha = safe_divide(rho, a1[0]);
     }
     lap(3);  // <rt, v> (rt from memory), its all-reduce; under it the surface of v out and the neighbours' in
@@ -1063,8 +1070,7 @@ __global__ __launch_bounds__(kResThreads) void res_bicgstab_early_kernel(ResArgs
 #pragma unroll
     for (int t = 0; t < TZ; ++t) res_publish_surface_pair(exch_r, A.exch_half, B, t, r[t], (unsigned)xseq);
     A.exch = exch_r;
-    res_halo_fetch_set<TZ>(A, B, (unsigned)xseq, Hr, &r_lo, &r_hi);
-    res_allreduce_wait<2>(acc, A, seq, red);
+    res_halo_fetch_set<TZ, 2>(A, B, (unsigned)xseq, Hr, &r_lo, &r_hi, acc, seq, red);
     lap(7);  // x += alpha p + omega s, r = s - omega t, |r|, <rt, r>, their all-reduce; under it the surface of r out and in
     const double rho_bar = rho;
     rho = acc[1];
@@ -1129,8 +1135,11 @@ static bool res_geometry(const storm_hip_op *op, ResGeometry *G, bool bicgstab =
     const size_t with_x = lds + sizeof(double) * (size_t)tz * kResRun;
     if (bicgstab && with_x <= (size_t)156 * 1024) G->x_lds = true, G->lds_bytes = with_x;
     const size_t sets = sizeof(double) * (size_t)3 * (size_t)tz * (size_t)(2 * a);
-    if (bicgstab && c->opt_resident_early != 0 && tz <= kResMaxPlanesBicgEarly && G->lds_bytes + sets <= (size_t)156 * 1024)
-      G->early = true, G->lds_bytes += sets;
+    if (bicgstab && c->opt_resident_early != 0 && tz <= kResMaxPlanesBicgEarly) {
+      if (G->lds_bytes + sets <= (size_t)156 * 1024) G->early = true, G->lds_bytes += sets;
+      else if (lds + sets <= (size_t)156 * 1024)  // (rather the halo sets than x in LDS)
+        G->early = true, G->x_lds = false, G->lds_bytes = lds + sets;
+    }
     return true;
   }
   return false;
@@ -1167,8 +1176,8 @@ int res_solve(bool bicgstab, const storm_hip_op *op, double alpha, double beta, 
     case 2: fn = res_kernel<2>(bicgstab, G.x_lds, G.early); break;
     case 3: fn = res_kernel<3>(bicgstab, G.x_lds, G.early); break;
     case 4: fn = res_kernel<4>(bicgstab, G.x_lds, G.early); break;
-    case 6: fn = res_kernel<6>(bicgstab, G.x_lds); break;
-    case 8: fn = res_kernel<8>(bicgstab, G.x_lds); break;
+    case 6: fn = res_kernel<6>(bicgstab, G.x_lds, G.early); break;
+    case 8: fn = res_kernel<8>(bicgstab, G.x_lds, G.early); break;
     case 12: fn = res_kernel<12>(bicgstab, G.x_lds); break;
     default: return STORM_HIP_OK;
   }
