@@ -313,7 +313,7 @@ __device__ __forceinline__ double2r res_cg_direction(double2r r, double2r p, dou
 //  fresh tag, consumed or not, and MODE 2 below is bitwise the late publish (tests/test_gpu_resident.py).  One more trap:
 //  with the publish INSIDE the loop that updates r the build hung in every box with neighbours above and below (and
 //  stopped hanging with any change to the polling loops' cold paths -- a debugging printf was enough); with a loop of
-//  its own behind the update it does not.  Measured, us per iteration late / early: 16^3 5.7 / 5.3, 32^3 6.3 / 6.0,
+//  its own behind the update it does not (the likely cause, found later: res_store16's store-data hazard, see there).  Measured, us per iteration late / early: 16^3 5.7 / 5.3, 32^3 6.3 / 6.0,
 //  64^3 9.8 / 9.5, 100^3 14.4 / 14.8, 128^3 16.7 / 17.9 -- since the granules travel as whole lines the wait it hides is
 //  short, and forming the halo of p' costs more than it at the larger boxes: option resident_early, off.)
 //   MODE 2 (CG): the granules hold the neighbours' RESIDUAL, published before the all-reduce that yields beta; the halo of
