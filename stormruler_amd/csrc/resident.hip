@@ -176,6 +176,7 @@ __device__ __forceinline__ void res_fetch2(const ResArgs &A, int64_t ra, int64_t
   for (int spins = 0;; ++spins) {
     u32x4r wa0, wa1, wb0, wb1;
     asm volatile(
+        "s_nop 4\n\t"  // (the bases may come straight out of a v_readlane -- a spilt SGPR --: five wait states before a VMEM reads it, which the compiler does not count for an asm statement)
         "global_load_dwordx4 %0, %4, %6 sc1\n\tglobal_load_dwordx4 %1, %4, %7 sc1\n\t"
         "global_load_dwordx4 %2, %5, %6 sc1\n\tglobal_load_dwordx4 %3, %5, %7 sc1\n\ts_waitcnt vmcnt(0)"
         : "=&v"(wa0), "=&v"(wa1), "=&v"(wb0), "=&v"(wb1)
@@ -214,6 +215,7 @@ __device__ __forceinline__ void res_fetch4(const ResArgs &A, const int64_t (&row
   for (int spins = 0;; ++spins) {
     u32x4r w0[4], w1[4];
     asm volatile(
+        "s_nop 4\n\t"  // (as in res_fetch2)
         "global_load_dwordx4 %0, %8, %12 sc1\n\tglobal_load_dwordx4 %1, %8, %13 sc1\n\t"
         "global_load_dwordx4 %2, %9, %12 sc1\n\tglobal_load_dwordx4 %3, %9, %13 sc1\n\t"
         "global_load_dwordx4 %4, %10, %12 sc1\n\tglobal_load_dwordx4 %5, %10, %13 sc1\n\t"
