@@ -46,7 +46,7 @@ constexpr int kResThreads = 512;                // 8 waves: two per SIMD, 256 re
 constexpr int kResWaves = kResThreads / kWave;
 constexpr int kResRun = 2 * kResThreads;        // rows of a plane per block: one pair per thread
 constexpr int kResMaxPlanes = 12;               // planes per block, at most (registers)
-constexpr int kResMaxPlanesBicgEarly = 4;       // ... of its early-publish form
+constexpr int kResMaxPlanesBicgEarly = 6;       // ... of its early-publish form
 constexpr int kResMaxPlanesBicg = 8;            // ... of the BiCGStab kernel (r, p, v and the result of an apply: 227 registers at 8 planes)
 
 typedef double double2r __attribute__((ext_vector_type(2)));
@@ -851,11 +851,11 @@ __global__ __launch_bounds__(kResThreads) void res_bicgstab_kernel(ResArgs A) {
 // Three waits per iteration instead of five.  The two surfaces use two exchange buffers: a block that has passed the
 // last all-reduce goes on to publish v without another synchronisation, while a neighbour may still be reading r.
 // Halo sets (LDS, behind the copy): Hr, Hp, Hv, [tzl][2 a] doubles each, pair hh always handled by the same thread; the
-// pairs of the planes below / above in registers.  Boxes of at most 4 planes: bitwise the exchanged halos there (tests).
-// (6 planes: 112^3 30.6 -> 24.8 us, but on the test's convection-diffusion box <t, t> of the 26th iteration came out one ulp
-//  away from the exchanged form's -- deterministically, with the formed halos of p and s verified bitwise against the
-//  exchanged ones inside the kernel; not understood, so off.  8 planes: 11 registers spilt and x no longer in LDS beside
-//  the sets: 128^3 34.4 -> 38.5 us.)
+// pairs of the planes below / above in registers.  Boxes of at most 6 planes: bitwise the exchanged halos (tests).
+// (At 6 planes the two kernels first disagreed by an ulp in <t, t> of some iteration although every formed halo was verified
+//  bitwise against the exchanged one inside the kernel: under -ffp-contract=fast the backend had fused a multiply and an add
+//  of different statements in one kernel and not in the other.  This unit is compiled with -ffp-contract=on (Makefile).
+//  8 planes: 11 registers spilt and x no longer in LDS beside the sets: 128^3 34.4 -> 38.5 us, not taken.)
 template <int TZ>
 __device__ __forceinline__ void res_halo_place(const ResBox &B, int hh, int64_t *row, int *at) {
   const int nh = B.tzl * B.a;

@@ -222,9 +222,9 @@ def test_cg_residual_surface_published_early_is_bitwise_the_late_publish(env, sh
         mat.close()
 
 
-@pytest.mark.parametrize("shape,planes", [c for c in CASES if c[1] <= 4 and c[0] != (128, 128, 128)] + [((64, 64, 9), 1), ((36, 30, 8), 1), ((112, 112, 30), 0)])
+@pytest.mark.parametrize("shape,planes", [c for c in CASES if c[1] <= 6 and c[0] != (128, 128, 128)] + [((64, 64, 9), 1), ((36, 30, 8), 1), ((112, 112, 30), 0), ((64, 64, 6), 6), ((32, 32, 12), 6)])
 def test_bicgstab_halos_formed_from_early_surfaces_are_bitwise_the_exchanged_ones(env, shape, planes):
-    """BiCGStab's early publish (resident.hip: res_bicgstab_early_kernel, boxes of at most 4 planes): the halos of
+    """BiCGStab's early publish (resident.hip: res_bicgstab_early_kernel, boxes of at most 6 planes): the halos of
     p' = r + beta (p - omega v) and of s = r - alpha v are FORMED by every block from the halos of r, p and v it keeps -- the
     owner's expressions on the owner's operands --; what travels are the surfaces of v = A p and of the new residual,
     under the all-reduces that follow them (three waits per iteration instead of five).  Histories and solutions BITWISE
