@@ -46,6 +46,7 @@ constexpr int kResThreads = 512;                // 8 waves: two per SIMD, 256 re
 constexpr int kResWaves = kResThreads / kWave;
 constexpr int kResRun = 2 * kResThreads;        // rows of a plane per block: one pair per thread
 constexpr int kResMaxPlanes = 12;               // planes per block, at most (registers)
+constexpr bool kResApplyCacheCg(int tz) { return tz >= 3 && tz <= 8; }  // (res_apply CACHE: where the registers allow it)
 constexpr int kResMaxPlanesBicgEarly = 6;       // ... of its early-publish form
 constexpr int kResMaxPlanesBicg = 8;            // ... of the BiCGStab kernel (r, p, v and the result of an apply: 227 registers at 8 planes)
 
@@ -382,12 +383,17 @@ __device__ __forceinline__ void res_halo(const ResArgs &A, const ResBox &B, doub
 // in the planes below / above the box.  spmv_canon_tile_kernel's arithmetic, plane by plane with the planes below /
 // at / above in three register pairs.  (ONE instance per kernel: the solvers below run init and iterations through
 // the same call -- an inlined copy per call site costs registers the rows need.)
-template <int TZ>
+// CACHE: the fourteen coefficients of a pair of rows stay in registers from plane to plane while the weight words do not
+// change (wave-uniform test) -- in a box away from the lattice's top and bottom they are the same in every plane of a
+// thread's column, and the byte-indexed look-ups are 14 of the 20 LDS reads a pair of rows costs: the apply is bound by the
+// LDS read rate.  The same values either way: the same bits.
+template <int TZ, bool CACHE = false>
 __device__ __forceinline__ void res_apply(const ResArgs &A, const ResBox &B, const double *P, const double *dict_sh,
                                           double2r lo, double2r hi, const u64x2r (&w)[TZ], double2r (&out)[TZ]) {
   const int at0 = B.a + B.tid2;
   const char *dsh = reinterpret_cast<const char *>(dict_sh);
   double2r prev = lo, cur = *reinterpret_cast<const double2r *>(&P[at0]);
+  double ca[7], cb[7];  // (CACHE) the coefficients of the current weight words: ext, then the six neighbours'
 #pragma unroll
   for (int t = 0; t < TZ; ++t) {
     const int at = t * B.ldw + at0;
@@ -407,14 +413,33 @@ __device__ __forceinline__ void res_apply(const ResArgs &A, const ResBox &B, con
     xg[2].x = P[at - 1], xg[2].y = cur.x;
     xg[3].x = cur.y, xg[3].y = P[at + 2];
     double acc_a = 0.0, acc_b = 0.0;
+    double ext_a, ext_b;
+    if (CACHE) {
+      bool fresh = true;
+      if (t > 0) fresh = __builtin_amdgcn_ballot_w64(w[t].x != w[t - 1].x || w[t].y != w[t - 1].y) != 0ull;
+      if (fresh) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const unsigned ba = (unsigned)(wa >> (8 * (k + 1))) & 0xffu, bb = (unsigned)(wb >> (8 * (k + 1))) & 0xffu;
-      acc_a += *reinterpret_cast<const double *>(dsh + ba) * (xg[k].x - cur.x);
-      acc_b += *reinterpret_cast<const double *>(dsh + bb) * (xg[k].y - cur.y);
+        for (int k = 0; k < 7; ++k) {
+          ca[k] = *reinterpret_cast<const double *>(dsh + ((unsigned)(wa >> (8 * k)) & 0xffu));
+          cb[k] = *reinterpret_cast<const double *>(dsh + ((unsigned)(wb >> (8 * k)) & 0xffu));
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        acc_a += ca[k + 1] * (xg[k].x - cur.x);
+        acc_b += cb[k + 1] * (xg[k].y - cur.y);
+      }
+      ext_a = ca[0], ext_b = cb[0];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const unsigned ba = (unsigned)(wa >> (8 * (k + 1))) & 0xffu, bb = (unsigned)(wb >> (8 * (k + 1))) & 0xffu;
+        acc_a += *reinterpret_cast<const double *>(dsh + ba) * (xg[k].x - cur.x);
+        acc_b += *reinterpret_cast<const double *>(dsh + bb) * (xg[k].y - cur.y);
+      }
+      ext_a = *reinterpret_cast<const double *>(dsh + ((unsigned)wa & 0xffu));
+      ext_b = *reinterpret_cast<const double *>(dsh + ((unsigned)wb & 0xffu));
     }
-    const double ext_a = *reinterpret_cast<const double *>(dsh + ((unsigned)wa & 0xffu));
-    const double ext_b = *reinterpret_cast<const double *>(dsh + ((unsigned)wb & 0xffu));
     const double ya = __builtin_fma(A.alpha, __builtin_fma(ext_a, cur.x, acc_a), A.beta * cur.x);
     const double yb = __builtin_fma(A.alpha, __builtin_fma(ext_b, cur.y, acc_b), A.beta * cur.y);
     out[t].x = ((B.mask_a >> t) & 1u) ? ya : 0.0;  // (rows that do not exist may have read anything: selected away)
@@ -549,7 +574,7 @@ __global__ __launch_bounds__(kResThreads) void res_cg_kernel(ResArgs A) {
     const int at0 = B.a + B.tid2;
     __syncthreads();
     lap(0);  // the halo of the new direction: a wait for the neighbours' surfaces
-    res_apply<TZ>(A, B, P, dict_sh, lo, hi, w, z);
+    res_apply<TZ, kResApplyCacheCg(TZ)>(A, B, P, dict_sh, lo, hi, w, z);
     lap(1);  // the apply
     double acc[1] = {0.0};
     if (!started) {
@@ -713,7 +738,7 @@ __global__ __launch_bounds__(kResThreads) void res_bicgstab_kernel(ResArgs A) {
   double rho, initial_error, abs_err, rel_err = 0.0, alpha = 0.0, beta = 0.0, omega = 0.0;
   {  // ---- init: r = b - A x; rt = r; rho = <rt, r>                              SolverBiCgStab.hpp:82-90
     double2r y[TZ];
-    res_apply<TZ>(A, B, P, dict_sh, lo, hi, w, y);
+    res_apply<TZ, kResApplyCacheCg(TZ)>(A, B, P, dict_sh, lo, hi, w, y);
     res_load_rows<TZ>(B, A.rhs, r);
     double a1[1] = {0.0};
 #pragma unroll
@@ -756,7 +781,7 @@ __global__ __launch_bounds__(kResThreads) void res_bicgstab_kernel(ResArgs A) {
     res_halo<TZ, 1>(A, B, P, (unsigned)xseq, nullptr, &lo, &hi);
     __syncthreads();
     lap(1);  // the halo of p: a wait for the neighbours' surfaces
-    res_apply<TZ>(A, B, P, dict_sh, lo, hi, w, v);
+    res_apply<TZ, kResApplyCacheCg(TZ)>(A, B, P, dict_sh, lo, hi, w, v);
     lap(2);  // v = A p
     {
       double a1[1] = {0.0};
@@ -784,7 +809,7 @@ __global__ __launch_bounds__(kResThreads) void res_bicgstab_kernel(ResArgs A) {
     __syncthreads();
     lap(4);  // s = r - alpha v, its surface out, the halo of s
     double2r y[TZ];
-    res_apply<TZ>(A, B, P, dict_sh, lo, hi, w, y);
+    res_apply<TZ, kResApplyCacheCg(TZ)>(A, B, P, dict_sh, lo, hi, w, y);
     lap(5);  // t = A s
     double acc[2] = {0.0, 0.0};
 #pragma unroll
@@ -943,7 +968,7 @@ __global__ __launch_bounds__(kResThreads) void res_bicgstab_early_kernel(ResArgs
   double rho, initial_error, abs_err, rel_err = 0.0, alpha = 0.0, beta = 0.0, omega = 0.0;
   {  // ---- init: r = b - A x; rt = r; rho = <rt, r>                              SolverBiCgStab.hpp:82-90
     double2r y[TZ];
-    res_apply<TZ>(A, B, P, dict_sh, lo, hi, w, y);
+    res_apply<TZ, kResApplyCacheCg(TZ)>(A, B, P, dict_sh, lo, hi, w, y);
     res_load_rows<TZ>(B, A.rhs, r);
     double a1[1] = {0.0};
 #pragma unroll
@@ -1000,7 +1025,7 @@ __global__ __launch_bounds__(kResThreads) void res_bicgstab_early_kernel(ResArgs
     __syncthreads();
     lap(0);  // p = r + beta (p - omega v), own rows and halo
     lap(1);
-    res_apply<TZ>(A, B, P, dict_sh, p_lo, p_hi, w, v);
+    res_apply<TZ, kResApplyCacheCg(TZ)>(A, B, P, dict_sh, p_lo, p_hi, w, v);
     lap(2);  // v = A p
     {
       double a1[1] = {0.0};
@@ -1040,7 +1065,7 @@ __global__ __launch_bounds__(kResThreads) void res_bicgstab_early_kernel(ResArgs
     __syncthreads();
     lap(4);  // s = r - alpha v, own rows and halo
     double2r y[TZ];
-    res_apply<TZ>(A, B, P, dict_sh, lo, hi, w, y);
+    res_apply<TZ, kResApplyCacheCg(TZ)>(A, B, P, dict_sh, lo, hi, w, y);
     lap(5);  // t = A s
     double acc[2] = {0.0, 0.0};
 #pragma unroll
