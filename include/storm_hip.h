@@ -285,7 +285,14 @@ int storm_hip_op_create_csr(storm_hip_ctx *ctx, int64_t n_rows, int64_t n_halo,
  *   resident_path (1), resident_min_rows (0), resident_max_rows (2^22), resident_max_planes (12), resident_planes (0 =
  *              automatic): CG / BiCGStab of a
  *              halo-free LATTICE operator (format-4 records) as one persistent kernel per solve in which every
- *              block owns a box of the lattice (csrc/resident.hip). */
+ *              block owns a box of the lattice (csrc/resident.hip);
+ *   resident_early (1): on that path, surfaces travel under the all-reduces -- CG publishes its residual's surface before
+ *              beta is known and forms p' = r + beta p on its halo itself; BiCGStab (boxes of at most six planes) keeps the
+ *              halos of r, p, v and forms those of p and s, exchanging the surfaces of v = A p and of the new residual.
+ *              Bitwise the same solves as 0 (halos exchanged behind the all-reduces);
+ *   rccl_fused (1), rccl_ticket (1): RCCL transport -- the fused CG step on a partitioned lattice operator (the boundary
+ *              planes of the new direction packed by a small kernel and sent under the marching launch), with the local
+ *              sums finished inside the kernels that produce them. */
 int storm_hip_ctx_set_option(storm_hip_ctx *ctx, const char *key, int64_t value);
 
 /* Which path the solves of this context took so far (no reference counterpart: a diagnostic of this library; the
