@@ -74,6 +74,7 @@ struct ResArgs {
   long long *prof;     // option resident_profile: [gridDim.x][8] ticks of the 100 MHz counter per phase of the loop, summed over the solve
   unsigned long long *cnt;  // [0] all-reduce sequence number, [1] exchange sequence number: carried from solve to solve
   SolverState *st;
+  int apply_cache;    // res_apply CACHE on (option resident_apply_cache; 0: every plane decodes its coefficients -- the A/B of the tests)
   int early_publish;  // CG: the residual's surface before the second all-reduce (res_halo MODE 2); BiCGStab: res_bicgstab_early_kernel
 };
 
@@ -416,7 +417,7 @@ __device__ __forceinline__ void res_apply(const ResArgs &A, const ResBox &B, con
     double ext_a, ext_b;
     if (CACHE) {
       bool fresh = true;
-      if (t > 0) fresh = __builtin_amdgcn_ballot_w64(w[t].x != w[t - 1].x || w[t].y != w[t - 1].y) != 0ull;
+      if (t > 0) fresh = A.apply_cache == 0 || __builtin_amdgcn_ballot_w64(w[t].x != w[t - 1].x || w[t].y != w[t - 1].y) != 0ull;
       if (fresh) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
@@ -1250,6 +1251,7 @@ int res_solve(bool bicgstab, const storm_hip_op *op, double alpha, double beta, 
   //  chains, six and ten values, are the dense form's case.  coop_dense = 2 forces it here, for that A/B.)
   A.dense = c->opt_coop_dense == 2 ? c->d_res_slots + (size_t)2 * 256 * kLatSlotStride + 256 : nullptr;
   A.early_publish = (int)(c->opt_resident_early != 0);
+  A.apply_cache = (int)(c->opt_resident_apply_cache != 0);
   A.st = d_state;
   A.prof = nullptr;
   if (c->opt_resident_profile != 0) {

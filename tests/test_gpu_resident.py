@@ -252,3 +252,32 @@ def test_bicgstab_halos_formed_from_early_surfaces_are_bitwise_the_exchanged_one
     finally:
         ctx.set_option("resident_early", 1)
         mat.close()
+
+
+@pytest.mark.parametrize("shape,planes", [((64, 64, 9), 3), ((64, 64, 9), 4), ((64, 64, 12), 6), ((36, 30, 8), 3), ((128, 128, 32), 8), ((100, 100, 12), 4)])
+def test_coefficients_kept_from_plane_to_plane_give_the_same_bits(env, shape, planes):
+    """`res_apply<TZ, CACHE>`: the fourteen coefficients of a pair of rows stay in registers from plane to plane while the weight
+    words do not change (wave-uniform test) -- the byte-indexed look-ups were most of the apply's LDS reads.  Option
+    resident_apply_cache = 0 decodes them in every plane: histories and solutions must agree to the bit, CG on the Poisson box
+    (identical words in all interior planes) and BiCGStab on the convection-diffusion box, boxes at the lattice's top and
+    bottom included (their words change between planes)."""
+    api, mesh, oracle, ctx = env
+    g = mesh.structured_box(*shape, lengths=tuple(n / 64.0 for n in shape))
+    wi, wo, de = mesh.convection_diffusion_weights(g, 1e-2, (1.0, 0.5, 0.25))
+    mats = {"cg": api.StencilMatrix.from_face_graph(ctx, g),
+            "bicgstab": api.StencilMatrix.from_face_weights(ctx, g.n_cells, g.n_halo, g.inner, g.outer, wi, wo, de)}
+    b_host = 1.0 + 0.25 * np.sin(0.01 * np.arange(g.n_cells))
+    try:
+        for kind, cls, alpha in (("cg", api.CgSolver, -1.0), ("bicgstab", api.BiCgStabSolver, 1.0)):
+            op = api.HipStencilOperator(mats[kind], alpha, 0.0)
+            runs = {}
+            for cache in (0, 1):
+                ctx.set_option("resident_apply_cache", cache)
+                ok, s, x, taken = _solve(api, ctx, cls, op, b_host, True, planes, num_iterations=60)
+                assert taken == 1 and s.path_fallback == 0
+                runs[cache] = (np.asarray(s.history), x)
+            assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1]), kind
+    finally:
+        ctx.set_option("resident_apply_cache", 1)
+        for m in mats.values():
+            m.close()
