@@ -290,7 +290,7 @@ int storm_hip_op_create_csr(storm_hip_ctx *ctx, int64_t n_rows, int64_t n_halo,
  *              beta is known and forms p' = r + beta p on its halo itself; BiCGStab (boxes of at most six planes) keeps the
  *              halos of r, p, v and forms those of p and s, exchanging the surfaces of v = A p and of the new residual.
  *              Bitwise the same solves as 0 (halos exchanged behind the all-reduces);
- *   resident_apply_cache (1): on that path (boxes of 3 - 8 planes) the coefficients of a pair of rows stay in registers from plane
+ *   resident_apply_cache (1): on that path (boxes of 3 - 12 planes) the coefficients of a pair of rows stay in registers from plane
  *              to plane while its weight words do not change; 0 decodes them per plane.  The same bits;
  *   rccl_fused (1), rccl_ticket (1): RCCL transport -- the fused CG step on a partitioned lattice operator (the boundary
  *              planes of the new direction packed by a small kernel and sent under the marching launch), with the local

@@ -46,7 +46,7 @@ constexpr int kResThreads = 512;                // 8 waves: two per SIMD, 256 re
 constexpr int kResWaves = kResThreads / kWave;
 constexpr int kResRun = 2 * kResThreads;        // rows of a plane per block: one pair per thread
 constexpr int kResMaxPlanes = 12;               // planes per block, at most (registers)
-constexpr bool kResApplyCacheCg(int tz) { return tz >= 3 && tz <= 8; }  // (res_apply CACHE: where the registers allow it)
+constexpr bool kResApplyCacheCg(int tz) { return tz >= 3 && tz <= 12; }  // (res_apply CACHE: where the registers allow it)
 constexpr int kResMaxPlanesBicgEarly = 6;       // ... of its early-publish form
 constexpr int kResMaxPlanesBicg = 8;            // ... of the BiCGStab kernel (r, p, v and the result of an apply: 227 registers at 8 planes)
 
@@ -388,7 +388,7 @@ __device__ __forceinline__ void res_halo(const ResArgs &A, const ResBox &B, doub
 // change (wave-uniform test) -- in a box away from the lattice's top and bottom they are the same in every plane of a
 // thread's column, and the byte-indexed look-ups are 14 of the 20 LDS reads a pair of rows costs: the apply is bound by the
 // LDS read rate.  The same values either way: the same bits.
-template <int TZ, bool CACHE = false>
+template <int TZ, bool CACHE = false>  // (CACHE: boxes of 3 - 12 planes, kResApplyCacheCg)
 __device__ __forceinline__ void res_apply(const ResArgs &A, const ResBox &B, const double *P, const double *dict_sh,
                                           double2r lo, double2r hi, const u64x2r (&w)[TZ], double2r (&out)[TZ]) {
   const int at0 = B.a + B.tid2;

@@ -254,7 +254,7 @@ def test_bicgstab_halos_formed_from_early_surfaces_are_bitwise_the_exchanged_one
         mat.close()
 
 
-@pytest.mark.parametrize("shape,planes", [((64, 64, 9), 3), ((64, 64, 9), 4), ((64, 64, 12), 6), ((36, 30, 8), 3), ((128, 128, 32), 8), ((100, 100, 12), 4)])
+@pytest.mark.parametrize("shape,planes", [((64, 64, 9), 3), ((64, 64, 9), 4), ((64, 64, 12), 6), ((36, 30, 8), 3), ((128, 128, 32), 8), ((100, 100, 12), 4), ((64, 64, 24), 12)])
 def test_coefficients_kept_from_plane_to_plane_give_the_same_bits(env, shape, planes):
     """`res_apply<TZ, CACHE>`: the fourteen coefficients of a pair of rows stay in registers from plane to plane while the weight
     words do not change (wave-uniform test) -- the byte-indexed look-ups were most of the apply's LDS reads.  Option
@@ -269,6 +269,8 @@ def test_coefficients_kept_from_plane_to_plane_give_the_same_bits(env, shape, pl
     b_host = 1.0 + 0.25 * np.sin(0.01 * np.arange(g.n_cells))
     try:
         for kind, cls, alpha in (("cg", api.CgSolver, -1.0), ("bicgstab", api.BiCgStabSolver, 1.0)):
+            if kind == "bicgstab" and planes > 8:  # (BiCGStab's boxes are at most 8 planes deep)
+                continue
             op = api.HipStencilOperator(mats[kind], alpha, 0.0)
             runs = {}
             for cache in (0, 1):
