@@ -18,6 +18,12 @@ PHASES = {"cg": ["halo_of_new_direction", "apply", "pz_partials", "allreduce_1",
                        "ts_tt_allreduce", "x_r_update_allreduce"]}
 
 
+# (BiCGStab with --early 1, boxes of at most six planes -- res_bicgstab_early_kernel: "p_update_publish" is the update of p on
+#  the own rows AND on the halo (nothing is published there), "halo_of_p" is empty, "rtv_allreduce" includes the surface of v
+#  going out and coming in, "s_update_publish_halo" is the update of s on own rows and halo, "x_r_update_allreduce" includes
+#  the surface of the new residual going out and coming in.)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="64,128")
