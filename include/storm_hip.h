@@ -292,6 +292,8 @@ int storm_hip_op_create_csr(storm_hip_ctx *ctx, int64_t n_rows, int64_t n_halo,
  *              Bitwise the same solves as 0 (halos exchanged behind the all-reduces);
  *   resident_apply_cache (1): on that path (boxes of 3 - 12 planes) the coefficients of a pair of rows stay in registers from plane
  *              to plane while its weight words do not change; 0 decodes them per plane.  The same bits;
+ *   resident_halo_interleave (1): CG on that path, boxes of more than two planes: half of a block's waves form the halo of the
+ *              new direction before updating their own rows, half behind it.  The same bits;
  *   rccl_fused (1), rccl_ticket (1): RCCL transport -- the fused CG step on a partitioned lattice operator (the boundary
  *              planes of the new direction packed by a small kernel and sent under the marching launch), with the local
  *              sums finished inside the kernels that produce them. */

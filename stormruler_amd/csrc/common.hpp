@@ -154,6 +154,7 @@ struct storm_hip_ctx {
   int64_t opt_mgs_steps = 4;          // throughput-path Gram-Schmidt: steps per pass over w (2: mgs_pair_kernel; 3, 4: mgs_multi_kernel)
   int64_t opt_resident_early = 1;    // resident CG: the residual's surface published under the all-reduce that yields beta (res_halo MODE 2; behind the block's own arrival at that all-reduce): bitwise the same solve, 7 - 12 % faster (128^3: 16.8 -> 15.4 us per iteration)
   int64_t opt_resident_apply_cache = 1;  // resident path: a pair of rows' coefficients stay in registers from plane to plane while the weight words do not change (0: decoded per plane; the same bits)
+  int64_t opt_resident_halo_interleave = 1;  // resident CG, boxes of more than 2 planes: the second wave of every SIMD forms the halo of p' before the update of its own rows
   int64_t opt_coop_mgs_prefetch = 1; // ... the next group's basis vectors requested under the all-reduce (up to 4 row pairs per thread)
   int64_t opt_coop_mgs_lds_prefetch = 1; // ... eight row pairs per thread (128^3): the next group's vectors through LDS (LDS-DMA)
   int64_t opt_coop_mgs_apply = 1;    // ... with the operator apply in front of it done by the chain kernel itself (format-4 lattice operators)

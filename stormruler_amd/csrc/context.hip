@@ -167,6 +167,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "coop_mgs_lds_prefetch")) c->opt_coop_mgs_lds_prefetch = value;
   else if (!strcmp(key, "resident_early")) c->opt_resident_early = value;
   else if (!strcmp(key, "resident_apply_cache")) c->opt_resident_apply_cache = value;
+  else if (!strcmp(key, "resident_halo_interleave")) c->opt_resident_halo_interleave = value;
   else if (!strcmp(key, "mgs_steps")) c->opt_mgs_steps = value;
   else if (!strcmp(key, "vec_contiguous")) c->opt_vec_contiguous = value;
   else if (!strcmp(key, "vec_arena")) c->opt_vec_arena = value;

@@ -74,6 +74,7 @@ struct ResArgs {
   long long *prof;     // option resident_profile: [gridDim.x][8] ticks of the 100 MHz counter per phase of the loop, summed over the solve
   unsigned long long *cnt;  // [0] all-reduce sequence number, [1] exchange sequence number: carried from solve to solve
   SolverState *st;
+  int halo_interleave;  // CG, deeper boxes: half the waves form the halo of p' before the update of the own rows (option resident_halo_interleave)
   int apply_cache;    // res_apply CACHE on (option resident_apply_cache; 0: every plane decodes its coefficients -- the A/B of the tests)
   int early_publish;  // CG: the residual's surface before the second all-reduce (res_halo MODE 2); BiCGStab: res_bicgstab_early_kernel
 };
@@ -656,6 +657,11 @@ __global__ __launch_bounds__(kResThreads) void res_cg_kernel(ResArgs A) {
       if (blockIdx.x == 0 && threadIdx.x == 0 && history) history[it] = abs_err;
       const bool go_on = !converged && it < num_iterations;
       if (go_on && !early) ++xseq;
+      // (deeper boxes: the second wave of every SIMD fetches the neighbours' surfaces and forms the halo of p' BEFORE its
+      //  part of the update below, the first one behind it -- while one waits for its granules the other computes; own rows
+      //  and halo entries are disjoint)
+      const bool halo_first = early && go_on && TZ > 2 && A.halo_interleave != 0 && ((threadIdx.x >> 8) & 1) != 0;
+      if (halo_first) res_halo<TZ, 2>(A, B, P, (unsigned)xseq, nullptr, &lo, &hi, beta);
       // x += alpha p; p = r + beta p (own rows: nobody else reads them before the next barrier)     :98, :123
 #pragma unroll
       for (int t = 0; t < TZ; ++t) {
@@ -677,7 +683,7 @@ __global__ __launch_bounds__(kResThreads) void res_cg_kernel(ResArgs A) {
       if (early) {
         if (__hip_atomic_load(A.gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
         if (split && TZ <= 2) res_halo2_finish<TZ>(A, B, P, (unsigned)xseq, hv, hat, &lo, &hi, beta);
-        else res_halo<TZ, 2>(A, B, P, (unsigned)xseq, nullptr, &lo, &hi, beta);
+        else if (!halo_first) res_halo<TZ, 2>(A, B, P, (unsigned)xseq, nullptr, &lo, &hi, beta);
         continue;
       }
     }
@@ -1252,6 +1258,7 @@ int res_solve(bool bicgstab, const storm_hip_op *op, double alpha, double beta, 
   A.dense = c->opt_coop_dense == 2 ? c->d_res_slots + (size_t)2 * 256 * kLatSlotStride + 256 : nullptr;
   A.early_publish = (int)(c->opt_resident_early != 0);
   A.apply_cache = (int)(c->opt_resident_apply_cache != 0);
+  A.halo_interleave = (int)(c->opt_resident_halo_interleave != 0);
   A.st = d_state;
   A.prof = nullptr;
   if (c->opt_resident_profile != 0) {
