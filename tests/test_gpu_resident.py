@@ -283,3 +283,26 @@ def test_coefficients_kept_from_plane_to_plane_give_the_same_bits(env, shape, pl
         ctx.set_option("resident_apply_cache", 1)
         for m in mats.values():
             m.close()
+
+
+@pytest.mark.parametrize("shape,planes", [((64, 64, 9), 3), ((36, 30, 8), 3), ((64, 64, 12), 6), ((128, 128, 32), 8)])
+def test_halo_formed_before_or_behind_the_update_of_the_own_rows_gives_the_same_bits(env, shape, planes):
+    """CG, boxes of more than two planes (option resident_halo_interleave): behind the second all-reduce half of a block's waves
+    fetch the neighbours' surfaces and form the halo of p' = r + beta p BEFORE `x += alpha p; p = r + beta p` on their own rows,
+    half behind it (own rows and halo entries of the LDS copy are disjoint).  Bitwise the uniform order."""
+    api, mesh, oracle, ctx = env
+    g = mesh.structured_box(*shape, lengths=tuple(n / 64.0 for n in shape))
+    mat = api.StencilMatrix.from_face_graph(ctx, g)
+    op = api.HipStencilOperator(mat, -1.0, 0.0)
+    b_host = 1.0 + 0.25 * np.sin(0.01 * np.arange(g.n_cells))
+    try:
+        runs = {}
+        for il in (0, 1):
+            ctx.set_option("resident_halo_interleave", il)
+            ok, s, x, taken = _solve(api, ctx, api.CgSolver, op, b_host, True, planes)
+            assert taken == 1 and s.path_fallback == 0 and ok
+            runs[il] = (np.asarray(s.history), x)
+        assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+    finally:
+        ctx.set_option("resident_halo_interleave", 1)
+        mat.close()
