@@ -54,8 +54,10 @@ int storm_hip_ctx_create(int device_id, storm_hip_ctx **out) {
   c->total_mem = (int64_t)prop.totalGlobalMem;
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreateWithFlags(&c->ev_x_ready, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&c->ev_halo_done, hipEventDisableTiming));
+  // (the two events that order the compute and the comm stream of ONE device: a device-scope release -- the default, a
+  //  system-scope fence with cache write-back and invalidation, showed as 7 - 9 us in front of the launch behind the record)
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_x_ready, hipEventDisableTiming | hipEventReleaseToDevice));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_halo_done, hipEventDisableTiming | hipEventReleaseToDevice));
   HIP_TRY(hipEventCreate(&c->ev_t0));
   HIP_TRY(hipEventCreate(&c->ev_t1));
   c->partials_capacity = (int64_t)kMaxReduceBlocks * kMaxMulti * 2;  // (2 MiB; the widest user: ten sums x 16 384 blocks of mgs_multi_kernel)
