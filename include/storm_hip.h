@@ -296,7 +296,9 @@ int storm_hip_op_create_csr(storm_hip_ctx *ctx, int64_t n_rows, int64_t n_halo,
  *              new direction before updating their own rows, half behind it.  The same bits;
  *   rccl_fused (1), rccl_ticket (1): RCCL transport -- the fused CG step on a partitioned lattice operator (the boundary
  *              planes of the new direction packed by a small kernel and sent under the marching launch), with the local
- *              sums finished inside the kernels that produce them. */
+ *              sums finished inside the kernels that produce them;
+ *   rccl_early_halo (1): RCCL transport, BiCGStab -- the boundary planes of s and of the new direction are formed by a small
+ *              kernel and sent before the update kernel that forms the vector runs.  The same bits. */
 int storm_hip_ctx_set_option(storm_hip_ctx *ctx, const char *key, int64_t value);
 
 /* Which path the solves of this context took so far (no reference counterpart: a diagnostic of this library; the

@@ -39,6 +39,7 @@ struct Comm {
   int *d_error = nullptr, *h_error = nullptr;  // set by a kernel whose wait timed out
   long long *d_stat = nullptr;          // ipc_device.hpp IpcDev::stat (8 counters, zeroed at init)
   double *pending_x = nullptr;          // generic form of the exchange: the receive half runs in comm_halo_exchange_end
+  const double *prebegun = nullptr;     // RCCL: the exchange of THIS vector's halo is in flight already (comm_halo_exchange_begin_formed)
   IpcRecvPlan pending_recv;
 };
 
@@ -250,6 +251,12 @@ int comm_halo_exchange_begin(const storm_hip_op *op, double *x) {
     return STORM_HIP_OK;
   }
   STORM_REQUIRE(c->comm && c->comm->halo, "halo exchange without an initialised communicator");
+  if (c->comm->prebegun != nullptr) {  // begun by comm_halo_exchange_begin_formed, for this very vector
+    const bool mine = c->comm->prebegun == x;
+    c->comm->prebegun = nullptr;
+    STORM_REQUIRE(mine, "halo exchange: another vector's exchange is in flight");
+    return STORM_HIP_OK;
+  }
   // x must be complete before it is packed
   HIP_TRY(hipEventRecord(c->ev_x_ready, c->stream));
   HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_x_ready, 0));
@@ -304,6 +311,49 @@ int comm_halo_exchange_begin_direction(const storm_hip_op *op, const double *p, 
   }
   NCCL_TRY(ncclGroupEnd());
   HIP_TRY(hipEventRecord(c->ev_halo_done, c->comm_stream));
+  return STORM_HIP_OK;
+}
+
+// BiCGStab over RCCL: the halo of the vector that the NEXT update kernel will form -- s = r - alpha v (MODE 0, in r's place) or
+// p' = r + beta (p - omega v) (MODE 1, in p's place) -- leaves before that kernel runs: the rows to send are formed here with
+// the owner's expression (bicg_update_kernel<false>'s, BicgPF's: the same bits) from the operands as they are NOW, on the
+// COMPUTE stream (the update overwrites an operand in place), and travel on the comm stream under the update and the
+// interior rows of the apply that follows.  comm_halo_exchange_begin finds the exchange begun (prebegun) and returns.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void halo_pack_bicg_kernel(int64_t n, const int *__restrict__ idx, const double *__restrict__ r,
+                                                                const double *__restrict__ p, const double *__restrict__ v,
+                                                                const double *__restrict__ sa, const double *__restrict__ sb,
+                                                                double *__restrict__ buf) {
+  const double a = *sa, b = sb ? *sb : 0.0;  // MODE 0: alpha; MODE 1: beta, omega
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const int j = idx[i];
+    buf[i] = MODE == 0 ? __builtin_fma(-a, v[j], r[j]) : __builtin_fma(a, __builtin_fma(-b, v[j], p[j]), r[j]);
+  }
+}
+int comm_halo_exchange_begin_formed(const storm_hip_op *op, int mode, const double *r, const double *p, const double *v,
+                                    const double *sa, const double *sb, double *target) {
+  storm_hip_ctx *c = op->ctx;
+  const HaloPlan &h = op->halo;
+  STORM_REQUIRE(comm_is_rccl(c) && h.n_nbrs > 0, "formed exchange: needs the RCCL transport and a halo plan");
+  if (h.n_send > 0) {
+    const int64_t need = (h.n_send + kBlock - 1) / kBlock;
+    const dim3 grid((int)(need > 1024 ? 1024 : need));
+    if (mode == 0) hipLaunchKernelGGL(halo_pack_bicg_kernel<0>, grid, dim3(kBlock), 0, c->stream, h.n_send, h.d_send_idx, r, p, v, sa, sb, h.d_sendbuf);
+    else hipLaunchKernelGGL(halo_pack_bicg_kernel<1>, grid, dim3(kBlock), 0, c->stream, h.n_send, h.d_send_idx, r, p, v, sa, sb, h.d_sendbuf);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipEventRecord(c->ev_x_ready, c->stream));  // the rows to send are packed
+  HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_x_ready, 0));
+  NCCL_TRY(ncclGroupStart());
+  for (int q = 0; q < h.n_nbrs; ++q) {
+    const int64_t ns = h.send_ptr[q + 1] - h.send_ptr[q], nr = h.recv_ptr[q + 1] - h.recv_ptr[q];
+    if (ns > 0) NCCL_TRY(ncclSend(h.d_sendbuf + h.send_ptr[q], (size_t)ns, ncclDouble, h.nbr_rank[q], c->comm->halo, c->comm_stream));
+    if (nr > 0) NCCL_TRY(ncclRecv(target + op->n_rows + h.recv_ptr[q], (size_t)nr, ncclDouble, h.nbr_rank[q], c->comm->halo, c->comm_stream));
+  }
+  NCCL_TRY(ncclGroupEnd());
+  HIP_TRY(hipEventRecord(c->ev_halo_done, c->comm_stream));
+  c->comm->prebegun = target;
   return STORM_HIP_OK;
 }
 

@@ -201,6 +201,7 @@ struct storm_hip_ctx {
   int64_t opt_latency_rows = 1 << 19;   // ... up to this many rows (a compact copy of the operator is kept for it)
   int64_t opt_rccl_fused = 1;           // RCCL transport: the fused CG step on a partitioned lattice operator (boundary planes of the new direction packed by a small kernel, sent under the marching launch)
   int64_t opt_rccl_ticket = 1;          // ... with the LOCAL sums of <p,z> and <r,r> finished inside the kernels that produce them (tickets); the all-reduce and the scalar step stay launches
+  int64_t opt_rccl_early_halo = 1;      // RCCL, BiCGStab: the halo of s / p' leaves before the kernel that forms the vector runs (rows to send formed by a small kernel)
   int64_t opt_ipc_fused = 1;            // peer-window transport: the interior launch sends, the boundary launch reads the window (0: stand-alone send / receive-copy kernels)
   int64_t opt_ipc_streams = 2;          // peer-window halo exchange: 2 = on the comm stream beside the interior rows, 1 = on the compute stream around them
   int64_t opt_generic_solvers = 0;  // 1: storm_hip_krylov_solve never takes the fused CG / BiCGStab / GMRES loops (A/B knob)
@@ -465,6 +466,9 @@ int comm_halo_exchange_begin(const storm_hip_op *op, double *x);      // pack + 
 int comm_halo_exchange_end(const storm_hip_op *op);                   // compute stream waits
 bool comm_is_rccl(const storm_hip_ctx *c);
 int comm_halo_exchange_begin_direction(const storm_hip_op *op, const double *p, const double *r, const double *cb, double *p_out);
+// ... of BiCGStab's s (mode 0, target = r) / p' (mode 1, target = p), formed from the operands before the update kernel runs
+int comm_halo_exchange_begin_formed(const storm_hip_op *op, int mode, const double *r, const double *p, const double *v,
+                                    const double *sa, const double *sb, double *target);
 void comm_destroy(storm_hip_ctx *c);
 int comm_check_error(storm_hip_ctx *c);  // a bounded wait of the peer-window transport gave up
 struct IpcDev;                            // ipc_device.hpp

@@ -1420,6 +1420,8 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
   // ... and reductions finished in-kernel (see storm_hip_solve_cg): five launches per iteration instead of eleven.
   const bool tick = c->opt_ticket_reduce != 0 && c->comm == nullptr && nbv <= kTicketGroup * kTicketMaxGroups;
   const TicketArgs no_tickets{nullptr, nullptr, nullptr}, tickets{c->d_tickets, c->d_partials, c->d_ticket_sums};
+  // RCCL: the halo of the vector an update kernel is about to form leaves BEFORE that kernel (comm.hip)
+  const bool early_halo = c->comm != nullptr && comm_is_rccl(c) && c->opt_rccl_early_halo != 0 && op->halo.n_nbrs > 0 && !fuse_s;
   int ticketed = 0;
   auto apply_dir = [&](const double *xin, double *yout, const double *w, bool yy, int out0, int out1) -> int {
     c->spmv_reverse = flip();
@@ -1454,6 +1456,8 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
       c->spmv_reverse = 0;
       STORM_TRY(st_apply);
     } else {
+      // (RCCL: the halo of s leaves now, under this update and the interior rows of the apply)
+      if (early_halo && !alpha_in_kernel) STORM_TRY(comm_halo_exchange_begin_formed(op, 0, r, nullptr, v, d.slot(S_ALPHA), nullptr, r));
       // r -= alpha v   (x += alpha p is applied in the second half-step)      :140-141
       hipLaunchKernelGGL(bicg_update_kernel<false>, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, x->d, r, p, v,
                          rt, c->d_partials, stream_nt(c, n), flip(), alpha_in_kernel ? tickets : no_tickets);
@@ -1493,6 +1497,7 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
   };
   auto enqueue_iteration = [&]() -> int {  // iterations >= 1
     // rho, beta were formed by STEP_BICG_END of the previous iteration (same r): :116-119
+    if (early_halo) STORM_TRY(comm_halo_exchange_begin_formed(op, 1, r, p, v, d.slot(S_BETA), d.slot(S_OMEGA), p));
     c->stream_reverse = flip();
     const int st_p = k_bicg_p(c, p, r, dev_scal(d.slot(S_BETA)), dev_scal(d.slot(S_OMEGA)), v, n, d.done);
     c->stream_reverse = 0;

@@ -173,3 +173,43 @@ def test_fused_cg_step_over_rccl_gives_the_unfused_iteration(shape):
     ref = oracle.solve("cg", oracle.CallbackOperator(loc.n_cells, ref_apply), b_host)
     assert abs(runs[1][0] - ref.iterations) <= max(2, int(0.02 * ref.iterations))
     assert np.linalg.norm(runs[1][2] - ref.x) <= 1e-8 * np.linalg.norm(ref.x)
+
+
+@pytest.mark.parametrize("shape", [(32, 32, 24), (64, 16, 40)])
+def test_bicgstab_over_rccl_sends_the_halo_of_s_and_p_before_the_update_kernels(shape):
+    """Round 4: on the RCCL transport the halo of s = r - alpha v and of p' = r + beta (p - omega v) leaves BEFORE the kernel that
+    forms the vector on the owned rows runs -- the rows to send are formed by a small kernel with the owner's expression from
+    the operands as they are, and travel under the update and the interior rows of the apply (option rccl_early_halo).
+    Bitwise the exchange begun by the apply itself, and the oracle's solve on the periodic operator."""
+    from oracle import oracle
+    from stormruler_amd import api
+
+    loc, send_idx = _periodic_z_local_graph(*shape)
+    ref_op = oracle.StencilOperator(loc, -1.0, 0.05)
+
+    def ref_apply(x_owned):
+        return ref_op.apply(np.concatenate([x_owned, x_owned[send_idx]]))[: loc.n_cells]
+
+    b_host = np.cos(0.05 * np.arange(loc.n_cells)) + 0.3
+    runs = {}
+    for early in (1, 0):
+        ctx = api.Context(0)
+        ctx.set_option("spmv_canon_tile_min_rows", 0)
+        ctx.set_option("rccl_early_halo", early)
+        ctx.comm_init(api.Context.comm_unique_id(), 1, 0)
+        mat = api.StencilMatrix.from_face_graph(ctx, loc)
+        mat.set_halo([0], [0, loc.n_halo], send_idx, [0, loc.n_halo])
+        s = api.BiCgStabSolver()
+        s.record_history = True
+        b = api.DeviceVector.from_numpy(ctx, b_host, n_halo=loc.n_halo)
+        x = api.DeviceVector(ctx, loc.n_cells, loc.n_halo)
+        assert s.solve(x, b, api.HipStencilOperator(mat, -1.0, 0.05))
+        runs[early] = (s.iteration, np.array(s.history), x.to_numpy())
+        mat.close()
+        ctx.close()
+    assert runs[1][0] == runs[0][0]
+    assert np.array_equal(runs[1][1], runs[0][1]) and np.array_equal(runs[1][2], runs[0][2])
+    ref = oracle.solve("bicgstab", oracle.CallbackOperator(loc.n_cells, ref_apply), b_host)
+    # (BiCGStab's iteration count is a draw among roundings -- DESIGN 5c --: the solution is what is compared)
+    assert abs(runs[1][0] - ref.iterations) <= max(3, int(0.2 * ref.iterations))
+    assert np.linalg.norm(runs[1][2] - ref.x) <= 1e-5 * np.linalg.norm(ref.x)
