@@ -252,10 +252,11 @@ int comm_halo_exchange_begin(const storm_hip_op *op, double *x) {
   }
   STORM_REQUIRE(c->comm && c->comm->halo, "halo exchange without an initialised communicator");
   if (c->comm->prebegun != nullptr) {  // begun by comm_halo_exchange_begin_formed, for this very vector
+    // (another vector's: the last enqueued iteration of a solve sent a halo nobody asked for -- this exchange queues behind
+    //  it on the comm stream)
     const bool mine = c->comm->prebegun == x;
     c->comm->prebegun = nullptr;
-    STORM_REQUIRE(mine, "halo exchange: another vector's exchange is in flight");
-    return STORM_HIP_OK;
+    if (mine) return STORM_HIP_OK;
   }
   // x must be complete before it is packed
   HIP_TRY(hipEventRecord(c->ev_x_ready, c->stream));
@@ -314,8 +315,8 @@ int comm_halo_exchange_begin_direction(const storm_hip_op *op, const double *p, 
   return STORM_HIP_OK;
 }
 
-// BiCGStab over RCCL: the halo of the vector that the NEXT update kernel will form -- s = r - alpha v (MODE 0, in r's place) or
-// p' = r + beta (p - omega v) (MODE 1, in p's place) -- leaves before that kernel runs: the rows to send are formed here with
+// BiCGStab (and the kernel-per-statement CG) over RCCL: the halo of the vector that the NEXT update kernel will form -- s = r - alpha v
+// (MODE 0, in r's place), p' = r + beta (p - omega v) (MODE 1, in p's place), CG's p' = r + beta p (MODE 2) -- leaves before that kernel runs: the rows to send are formed here with
 // the owner's expression (bicg_update_kernel<false>'s, BicgPF's: the same bits) from the operands as they are NOW, on the
 // COMPUTE stream (the update overwrites an operand in place), and travel on the comm stream under the update and the
 // interior rows of the apply that follows.  comm_halo_exchange_begin finds the exchange begun (prebegun) and returns.
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(kBlock) void halo_pack_bicg_kernel(int64_t n, const
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
     const int j = idx[i];
-    buf[i] = MODE == 0 ? __builtin_fma(-a, v[j], r[j]) : __builtin_fma(a, __builtin_fma(-b, v[j], p[j]), r[j]);
+    buf[i] = MODE == 0 ? __builtin_fma(-a, v[j], r[j]) : MODE == 1 ? __builtin_fma(a, __builtin_fma(-b, v[j], p[j]), r[j]) : __builtin_fma(a, p[j], r[j]);
   }
 }
 int comm_halo_exchange_begin_formed(const storm_hip_op *op, int mode, const double *r, const double *p, const double *v,
@@ -340,7 +341,8 @@ int comm_halo_exchange_begin_formed(const storm_hip_op *op, int mode, const doub
     const int64_t need = (h.n_send + kBlock - 1) / kBlock;
     const dim3 grid((int)(need > 1024 ? 1024 : need));
     if (mode == 0) hipLaunchKernelGGL(halo_pack_bicg_kernel<0>, grid, dim3(kBlock), 0, c->stream, h.n_send, h.d_send_idx, r, p, v, sa, sb, h.d_sendbuf);
-    else hipLaunchKernelGGL(halo_pack_bicg_kernel<1>, grid, dim3(kBlock), 0, c->stream, h.n_send, h.d_send_idx, r, p, v, sa, sb, h.d_sendbuf);
+    else if (mode == 1) hipLaunchKernelGGL(halo_pack_bicg_kernel<1>, grid, dim3(kBlock), 0, c->stream, h.n_send, h.d_send_idx, r, p, v, sa, sb, h.d_sendbuf);
+    else hipLaunchKernelGGL(halo_pack_bicg_kernel<2>, grid, dim3(kBlock), 0, c->stream, h.n_send, h.d_send_idx, r, p, v, sa, sb, h.d_sendbuf);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(c->ev_x_ready, c->stream));  // the rows to send are packed

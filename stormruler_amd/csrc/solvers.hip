@@ -1339,6 +1339,9 @@ int solve_cg_body(const FusedSolveArgs &args) {
       STORM_TRY(d.verify(r, r, nullptr, S_GAMMA, -1, (long long)(cur_it + 1)));
     }
     if (fuse_step) return STORM_HIP_OK;  // (the next iteration's step kernel, or the tail below, ends this one)
+    // (RCCL, no fused step: the halo of the new direction leaves before cg_xp forms it, comm.hip)
+    if (rccl && c->opt_rccl_early_halo != 0 && op->halo.n_nbrs > 0)
+      STORM_TRY(comm_halo_exchange_begin_formed(op, 2, r, p, nullptr, d.slot(S_BETA), nullptr, p));
     // x += alpha p; p = r + beta p                    SolverCg.hpp:98,123
     hipLaunchKernelGGL(cg_xp_kernel, dim3(xp_blocks(n)), dim3(kBlock), 0, c->stream, n, d.st, (long long)(cur_it + 1), x->d,
                        p, r, nt_stream, q);

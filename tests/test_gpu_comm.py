@@ -175,12 +175,15 @@ def test_fused_cg_step_over_rccl_gives_the_unfused_iteration(shape):
     assert np.linalg.norm(runs[1][2] - ref.x) <= 1e-8 * np.linalg.norm(ref.x)
 
 
+@pytest.mark.parametrize("kind", ["bicgstab", "cg"])
 @pytest.mark.parametrize("shape", [(32, 32, 24), (64, 16, 40)])
-def test_bicgstab_over_rccl_sends_the_halo_of_s_and_p_before_the_update_kernels(shape):
+def test_bicgstab_over_rccl_sends_the_halo_of_s_and_p_before_the_update_kernels(shape, kind):
     """Round 4: on the RCCL transport the halo of s = r - alpha v and of p' = r + beta (p - omega v) leaves BEFORE the kernel that
     forms the vector on the owned rows runs -- the rows to send are formed by a small kernel with the owner's expression from
     the operands as they are, and travel under the update and the interior rows of the apply (option rccl_early_halo).
-    Bitwise the exchange begun by the apply itself, and the oracle's solve on the periodic operator."""
+    Bitwise the exchange begun by the apply itself, and the oracle's solve on the periodic operator.  kind = "cg": the
+    kernel-per-statement CG loop (rccl_fused = 0: what a general operator gets) sends the halo of p' = r + beta p before
+    cg_xp_kernel forms it."""
     from oracle import oracle
     from stormruler_amd import api
 
@@ -196,10 +199,11 @@ def test_bicgstab_over_rccl_sends_the_halo_of_s_and_p_before_the_update_kernels(
         ctx = api.Context(0)
         ctx.set_option("spmv_canon_tile_min_rows", 0)
         ctx.set_option("rccl_early_halo", early)
+        ctx.set_option("rccl_fused", 0)
         ctx.comm_init(api.Context.comm_unique_id(), 1, 0)
         mat = api.StencilMatrix.from_face_graph(ctx, loc)
         mat.set_halo([0], [0, loc.n_halo], send_idx, [0, loc.n_halo])
-        s = api.BiCgStabSolver()
+        s = api.BiCgStabSolver() if kind == "bicgstab" else api.CgSolver()
         s.record_history = True
         b = api.DeviceVector.from_numpy(ctx, b_host, n_halo=loc.n_halo)
         x = api.DeviceVector(ctx, loc.n_cells, loc.n_halo)
@@ -209,7 +213,7 @@ def test_bicgstab_over_rccl_sends_the_halo_of_s_and_p_before_the_update_kernels(
         ctx.close()
     assert runs[1][0] == runs[0][0]
     assert np.array_equal(runs[1][1], runs[0][1]) and np.array_equal(runs[1][2], runs[0][2])
-    ref = oracle.solve("bicgstab", oracle.CallbackOperator(loc.n_cells, ref_apply), b_host)
+    ref = oracle.solve(kind, oracle.CallbackOperator(loc.n_cells, ref_apply), b_host)
     # (BiCGStab's iteration count is a draw among roundings -- DESIGN 5c --: the solution is what is compared)
     assert abs(runs[1][0] - ref.iterations) <= max(3, int(0.2 * ref.iterations))
     assert np.linalg.norm(runs[1][2] - ref.x) <= 1e-5 * np.linalg.norm(ref.x)
