@@ -359,6 +359,12 @@ int comm_halo_exchange_begin_formed(const storm_hip_op *op, int mode, const doub
   return STORM_HIP_OK;
 }
 
+// A solve is over (or begins): no exchange begun ahead of its vector may outlive it -- the vector goes back to the pool and
+// another one may get its address.
+void comm_forget_prebegun(storm_hip_ctx *c) {
+  if (c->comm != nullptr) c->comm->prebegun = nullptr;
+}
+
 int comm_halo_exchange_end(const storm_hip_op *op) {
   storm_hip_ctx *c = op->ctx;
   if (op->halo.n_nbrs == 0 || c->comm == nullptr || c->comm->host_exchange) return STORM_HIP_OK;

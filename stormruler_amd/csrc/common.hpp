@@ -467,6 +467,7 @@ int comm_halo_exchange_end(const storm_hip_op *op);                   // compute
 bool comm_is_rccl(const storm_hip_ctx *c);
 int comm_halo_exchange_begin_direction(const storm_hip_op *op, const double *p, const double *r, const double *cb, double *p_out);
 // ... of BiCGStab's s (mode 0, target = r) / p' (mode 1, target = p), formed from the operands before the update kernel runs
+void comm_forget_prebegun(storm_hip_ctx *c);  // at the ends of a solve
 int comm_halo_exchange_begin_formed(const storm_hip_op *op, int mode, const double *r, const double *p, const double *v,
                                     const double *sa, const double *sb, double *target);
 void comm_destroy(storm_hip_ctx *c);

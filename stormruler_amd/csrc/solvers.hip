@@ -878,6 +878,7 @@ struct Driver {
 };
 
 static int prepare_state(Driver &d, const storm_hip_solver_params *p, double *history) {
+  comm_forget_prebegun(d.c);
   storm_hip_ctx *c = d.c;
   STORM_REQUIRE(p->num_iterations >= 0, "solve: num_iterations < 0");
   for (int i = 0; i < kStateRing; ++i) c->h_done_ring[i] = 0;  // (the previous solve ended with a stream wait: nothing posts any more)
@@ -1362,6 +1363,7 @@ int solve_cg_body(const FusedSolveArgs &args) {
                        x->d, p, (const double *)nullptr, nt_stream, 0);
     HIP_TRY(hipGetLastError());
   }
+  comm_forget_prebegun(c);
   return collect(d, result, history, applies_cg, 0);
 }
 
@@ -1521,6 +1523,7 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
     STORM_TRY(post_and_poll(d, it, &stop));
     if (stop) break;
   }
+  comm_forget_prebegun(c);
   return collect(d, result, history, applies_bicg, 0);
 }
 
