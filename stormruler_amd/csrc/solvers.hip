@@ -161,6 +161,28 @@ __global__ __launch_bounds__(kBlock) void reduce_stage1_ticket_kernel(const doub
   }
 }
 
+// ... two sums at once (BiCGStab's <t,s>, <t,t> on the peer-window transport): partials[j * nblocks + i], results in out0 / out1.
+__global__ __launch_bounds__(kBlock) void reduce_stage1_ticket2_kernel(const double *__restrict__ partials, int nblocks,
+                                                                       double *__restrict__ out0, double *__restrict__ out1,
+                                                                       const SolverState *st, TicketArgs tickets, IpcDev w, int use_ipc) {
+  if (st->done) return;
+  __shared__ double lds4[4];
+  const int g = blockIdx.x;
+  const int chunk = (nblocks + gridDim.x - 1) / gridDim.x;
+  const int i0 = g * chunk, i1 = min(i0 + chunk, nblocks);
+  double v0 = 0.0, v1 = 0.0;
+  for (int i = i0 + threadIdx.x; i < i1; i += kBlock) v0 += partials[i], v1 += partials[nblocks + i];
+  const double s0 = block_sum256(v0, lds4);
+  const double s1 = block_sum256(v1, lds4);
+  if (threadIdx.x >= kWave) return;
+  const double mine[2] = {s0, s1};
+  double total[2];
+  if (ticket_reduce_wave0<2>(tickets, mine, 2, (unsigned)g, gridDim.x, total)) {
+    if (use_ipc) ipc_allreduce_wave<2>(w, total, 2);
+    if (threadIdx.x == 0) *out0 = total[0], *out1 = total[1];
+  }
+}
+
 // Option ticket_verify: sums[j] (a reduction recomputed by the two-launch path) against the slab slots the in-kernel
 // reduction filled -- they differ by rounding only (another folding order); anything else raises the sticky flag.
 // `before`: the sums were taken of the vectors as they are NOW while the step has already run (iteration count).
@@ -376,7 +398,8 @@ __global__ __launch_bounds__(kBlock) void bicg_update_kernel(int64_t n, SolverSt
                                                              const double *__restrict__ w,
                                                              const double *__restrict__ rt,
                                                              double *__restrict__ partials, int nt, int reverse,
-                                                             TicketArgs tickets, const double *r_in = nullptr) {
+                                                             TicketArgs tickets, const double *r_in = nullptr,
+                                                             IpcDev ipc_w = IpcDev{}, int use_ipc = 0) {
   // r_in (second half-step): the vector r is READ from (s = r - alpha v, where the apply formed it into a vector of its
   // own); null: r itself
   if (st->done) return;
@@ -459,10 +482,13 @@ __global__ __launch_bounds__(kBlock) void bicg_update_kernel(int64_t n, SolverSt
     if (threadIdx.x >= kWave) return;
     const double mine[2] = {s0, s1};
     double total[2];
-    if (ticket_reduce_wave0<2>(tickets, mine, 2, bx, gridDim.x, total) && threadIdx.x == 0) {
-      st->s[S_RR] = total[0], st->s[S_RHO_NEW] = total[1];
-      st->s[S_OMEGA] = omega;  // (block 0's store of the same value need not be visible to this block yet)
-      do_step(STEP_BICG_END, st, GmresDev{});  // :164, :116-118 and the convergence rule
+    if (ticket_reduce_wave0<2>(tickets, mine, 2, bx, gridDim.x, total)) {
+      if (use_ipc) ipc_allreduce_wave<2>(ipc_w, total, 2);  // (peer windows: the global sums, the same bits on every rank)
+      if (threadIdx.x == 0) {
+        st->s[S_RR] = total[0], st->s[S_RHO_NEW] = total[1];
+        st->s[S_OMEGA] = omega;  // (block 0's store of the same value need not be visible to this block yet)
+        do_step(STEP_BICG_END, st, GmresDev{});  // :164, :116-118 and the convergence rule
+      }
     }
   }
 }
@@ -1425,6 +1451,12 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
   // ... and reductions finished in-kernel (see storm_hip_solve_cg): five launches per iteration instead of eleven.
   const bool tick = c->opt_ticket_reduce != 0 && c->comm == nullptr && nbv <= kTicketGroup * kTicketMaxGroups;
   const TicketArgs no_tickets{nullptr, nullptr, nullptr}, tickets{c->d_tickets, c->d_partials, c->d_ticket_sums};
+  // Peer windows: the applies leave per-wave partials; ONE small launch folds them, finishes the sum by tickets and exchanges
+  // it with the other ranks (ipc_device.hpp); the update kernels form alpha / omega themselves and the second half-step's
+  // last block all-reduces |r|^2, <rt, r> and runs the scalar step -- as on one rank, plus two small launches per iteration.
+  IpcDev ipc_w{};
+  const bool ipc_tick = c->opt_ticket_reduce != 0 && c->opt_ipc_bicg_ticket != 0 && c->comm != nullptr && comm_ipc_next(c, &ipc_w) &&
+                        nbv <= kTicketGroup * kTicketMaxGroups && !fuse_s;
   // RCCL: the halo of the vector an update kernel is about to form leaves BEFORE that kernel (comm.hip)
   const bool early_halo = c->comm != nullptr && comm_is_rccl(c) && c->opt_rccl_early_halo != 0 && op->halo.n_nbrs > 0 && !fuse_s;
   int ticketed = 0;
@@ -1439,8 +1471,13 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
   auto enqueue_rest = [&]() -> int {
     // v = A p; alpha = rho / <rt,v>                   :137-139
     STORM_TRY(apply_dir(p, v, rt, false, (int)S_RTV, -1));
-    const bool alpha_in_kernel = ticketed != 0;  // <rt,v> is in the slab; bicg_update forms alpha itself
+    bool alpha_in_kernel = ticketed != 0;  // <rt,v> is in the slab; bicg_update forms alpha itself
     if (alpha_in_kernel) {
+    } else if (ipc_tick && nb > 0 && (int64_t)nb + kStage2 <= c->partials_capacity) {
+      hipLaunchKernelGGL(reduce_stage1_ticket_kernel, dim3(kStage2), dim3(kBlock), 0, c->stream, c->d_partials, nb,
+                         d.slot(S_RTV), d.st, TicketArgs{c->d_tickets, c->d_partials + nb, c->d_ticket_sums}, ipc_w, 1);
+      HIP_TRY(hipGetLastError());
+      alpha_in_kernel = true;
     } else if (nb == 0) {
       const double *bs[1] = {v};
       STORM_TRY(k_multi_dot(c, rt, bs, 1, n, d.slot(S_RTV), d.done));
@@ -1470,8 +1507,14 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
       // t = A r; omega = <t,r> / <t,t>                  :158-160
       STORM_TRY(apply_dir(r, t, r, true, (int)S_TR, (int)S_TT));
     }
-    const bool omega_in_kernel = ticketed != 0;
+    bool omega_in_kernel = ticketed != 0;
     if (omega_in_kernel) {
+    } else if (ipc_tick && nb > 0 && 2 * (int64_t)nb + 2 * kStage2 <= c->partials_capacity) {
+      hipLaunchKernelGGL(reduce_stage1_ticket2_kernel, dim3(kStage2), dim3(kBlock), 0, c->stream, c->d_partials, nb,
+                         d.slot(S_TR), d.slot(S_TT), d.st, TicketArgs{c->d_tickets, c->d_partials + 2 * (size_t)nb, c->d_ticket_sums},
+                         ipc_w, 1);
+      HIP_TRY(hipGetLastError());
+      omega_in_kernel = true;
     } else if (nb == 0) {
       const double *bs[2] = {r, t};
       STORM_TRY(k_multi_dot(c, t, bs, 2, n, d.slot(S_TR), d.done));
@@ -1488,7 +1531,8 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
     //  and the two vectors swap roles: the residual of the next iteration lives where s did)
     if (s_in_apply) std::swap(r, s_vec);
     hipLaunchKernelGGL(bicg_update_kernel<true>, dim3(nbv2), dim3(kBlock), 0, c->stream, n, d.st, x->d, r,
-                       p, t, rt, c->d_partials, stream_nt(c, n), flip(), omega_in_kernel ? tickets : no_tickets);
+                       p, t, rt, c->d_partials, stream_nt(c, n), flip(), omega_in_kernel ? tickets : no_tickets,
+                       (const double *)nullptr, ipc_w, (int)(ipc_tick && omega_in_kernel));
     HIP_TRY(hipGetLastError());
     if (!omega_in_kernel) {
       const int slots[2] = {S_RR, S_RHO_NEW};
