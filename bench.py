@@ -22,6 +22,11 @@ Prints ONE JSON line on rank 0.
                     `traffic` is null and `traffic_from_profile` quotes the committed profile with its file hash.
                     SURVEY.md 8d's fp64-weight + int32-column bytes over the same time are `effective_vs_8d_GBs`
                     (may exceed the peak: the byte-indexed formats do not move those bytes -- not a bandwidth);
+  spmv              the SpMV ALONE as SURVEY.md 8d specifies it (the "SpMV achieved HBM GB/s" half of the metric): >= 50
+                    stand-alone storm_hip_op_apply launches on x_i = sin(0.37 i) after warm-up, HIP-event median and mean,
+                    for the lattice records (`spmv.lattice`) and the fp64 records any mesh gets (`spmv.general`), priced by
+                    8d's bytes, by the streamed bytes and by PMC traffic; once back to back on one (x, y) pair and once
+                    rotating three pairs (so the Infinity Cache's share shows);
   roofline_general  the same for the fp64-record kernel, where streamed bytes == 8d's algorithmic bytes;
   roofline_permuted_rcm  SURVEY.md 8d's unstructured stress variant: cells renumbered by the seeded permutation,
                     then the library's ordering from the cell centres (round 3: reverse Cuthill-McKee -- the key keeps its
@@ -99,6 +104,9 @@ def main() -> int:
     ap.add_argument("--skip-configs", action="store_true", help="skip BASELINE configs 3, 4, 5")
     ap.add_argument("--roofline-launches", type=int, default=200,
                     help="launches of the dominant kernel timed for `roofline` (at least this many, whatever --steps is)")
+    ap.add_argument("--skip-spmv", action="store_true", help="skip the stand-alone SpMV block (`spmv` in the line)")
+    ap.add_argument("--spmv-launches", type=int, default=60, help="stand-alone SpMV launches timed per mode (SURVEY.md 8d: >= 50)")
+    ap.add_argument("--spmv-only", action="store_true", help="run only the stand-alone SpMV block (for a clean rocprofv3 --stats comparison)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     chain = [t for t in (args.transport or ("ipc,host" if args.shared_device else "ipc,rccl,host")).split(",") if t]
@@ -108,6 +116,8 @@ def main() -> int:
 
     if args.pmc_child:
         return pmc_child(args)
+    if args.spmv_only:
+        return spmv_only(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args.gpus, args)
     if args.gpus > 1 and os.environ.get("STORM_BENCH_WORKER") != "1":
@@ -246,9 +256,11 @@ def main() -> int:
             step_bytes = stats["record_bytes"] + 48 * N
             gbs = step_bytes / (ms * 1e-3) / 1e9
             return {"achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "bytes_per_launch": step_bytes, "fused_cg_step": True,
-                    "plain_spmv_launch_ms": min_ms, "plain_spmv_bytes": fmt_bytes,
-                    "plain_spmv_frac": fmt_bytes / (min_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "algorithmic_bytes_8d": alg, "effective_vs_8d_GBs": (alg + 40 * N) / (ms * 1e-3) / 1e9,
+                    # SURVEY 8d's bytes of the reference statements this ONE launch covers: the apply (24 N + 12 nnz),
+                    # x += alpha p (24 N), p = r + beta p (24 N), <p, z> (16 N)
+                    "algorithmic_bytes_8d": alg, "bytes_8d_of_the_fused_statements": alg + 64 * N,
+                    "effective_vs_8d_GBs": (alg + 64 * N) / (ms * 1e-3) / 1e9,
+                    "frac_8d": (alg + 64 * N) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "avg_launch_ms": ms, "median_launch_ms": float(np.median(rest)), "min_launch_ms": min_ms,
                     "frac_by_median": step_bytes / (float(np.median(rest)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "launches_timed": launches}
@@ -257,6 +269,7 @@ def main() -> int:
         gbs = fmt_bytes / (ms * 1e-3) / 1e9
         return {"achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "bytes_per_launch": fmt_bytes, "fused_cg_step": False,
                 "algorithmic_bytes_8d": alg, "effective_vs_8d_GBs": alg / (ms * 1e-3) / 1e9,
+                "frac_8d": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "avg_launch_ms": ms, "median_launch_ms": float(np.median(samples)) * launches / max(iters + 1, 1),
                 "min_launch_ms": min_ms, "launches_timed": launches}
 
@@ -381,10 +394,19 @@ def main() -> int:
     # HBM bytes per launch by PMC: measured by a child of THIS run (two rocprofv3 --pmc passes over a short solve of
     # the same operator), else quoted from the committed profile -- under its own name, with the file's hash
     tfile = os.path.join(ROOT, "profiles", "spmv_hbm_traffic.json")
-    traffic, traffic_general, traffic_note = None, None, None
+    traffic, traffic_general, traffic_note, traffic_plain = None, None, None, {}
     if args.traffic == "measure" and n == 256 and world == 1 and rank == 0:
         ctx.sync()
-        traffic, traffic_general, traffic_note = measure_traffic(args)
+        traffic, traffic_general, traffic_note, traffic_plain = measure_traffic(args)
+    # ---- the SpMV alone: >= 50 stand-alone applies on x_i = sin(0.37 i), median, three byte counts ----
+    spmv_block = None
+    if world == 1 and not args.force_comm and not args.skip_spmv:
+        try:
+            cell_ids = np.arange(N) if perm is None else perm
+            spmv_block = {"lattice" if st["value_dictionary_size"] else "general":
+                          spmv_standalone(api, ctx, mat, st, cell_ids, args.spmv_launches, traffic_plain.get("lattice" if st["value_dictionary_size"] else "general"))}
+        except Exception as e:
+            spmv_block = {"error": repr(e)}
     traffic_from_profile = None
     if args.traffic != "off" and os.path.exists(tfile) and n == 256 and world == 1:
         try:
@@ -426,9 +448,15 @@ def main() -> int:
             gt = traffic_general
             general_roof = {"kernel": "spmv_sell_kernel (fp64 records: the format any mesh gets) + fused <p,Ap> partials",
                             "bound": "hbm", "achieved": r0["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": r0["frac"], "traffic": gt, "bytes_per_launch": r0["bytes_per_launch"],
+                            "frac": r0["frac"], "frac_8d": r0.get("frac_8d"), "traffic": gt, "bytes_per_launch": r0["bytes_per_launch"],
                             "algorithmic_bytes_8d": r0["algorithmic_bytes_8d"], "avg_launch_ms": r0["avg_launch_ms"],
                             "min_launch_ms": r0["min_launch_ms"], "launches_timed": r0["launches_timed"]}
+            if mat0 is not mat and isinstance(spmv_block, dict) and not args.skip_spmv:
+                try:
+                    spmv_block["general"] = spmv_standalone(api, ctx, mat0, mat0.stats(), np.arange(N) if perm is None else perm,
+                                                            args.spmv_launches, traffic_plain.get("general"))
+                except Exception as e:
+                    spmv_block["general"] = {"error": repr(e)}
             if mat0 is not mat:
                 mat0.close()
         except Exception as e:
@@ -477,7 +505,7 @@ def main() -> int:
         rp = spmv_roofline(opp, stp, prof_iters)
         band = np.abs(np.asarray(graph.inner) - np.asarray(graph.outer))
         out_ = {"kernel": kernel_name(stp), "record_format": record_format_name(stp), "bound": "hbm",
-                "achieved": rp["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rp["frac"], "traffic": None,
+                "achieved": rp["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rp["frac"], "frac_8d": rp.get("frac_8d"), "traffic": None,
                 "bytes_per_launch": rp["bytes_per_launch"], "algorithmic_bytes_8d": rp["algorithmic_bytes_8d"],
                 "effective_vs_8d_GBs": rp["effective_vs_8d_GBs"], "avg_launch_ms": rp["avg_launch_ms"],
                 "median_launch_ms": rp.get("median_launch_ms"), "min_launch_ms": rp["min_launch_ms"],
@@ -603,10 +631,11 @@ def main() -> int:
                             "<p',z> partials; tiles of 1024 rows x %d planes)" % st["tiled_planes"]) if roof.get("fused_cg_step") else
                            ("spmv_canon_tile_kernel (tiles of 1024 rows x %d planes) + fused <p,Ap> partials" % st["tiled_planes"])
                            if st.get("tiled_planes") else kernel_name(st) + " (sliced-ELL gather SpMV + fused <p,Ap> partials)"),
-                "fused_cg_step": roof.get("fused_cg_step"), "plain_spmv_launch_ms": roof.get("plain_spmv_launch_ms"),
-                "plain_spmv_bytes": roof.get("plain_spmv_bytes"), "plain_spmv_frac": roof.get("plain_spmv_frac"),
+                "fused_cg_step": roof.get("fused_cg_step"),
                 "bound": "hbm", "achieved": roof["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": roof["frac"], "traffic": traffic, "traffic_method": traffic_note,
+                "frac": roof["frac"], "frac_8d": roof.get("frac_8d"),
+                "bytes_8d_of_the_fused_statements": roof.get("bytes_8d_of_the_fused_statements"),
+                "traffic": traffic, "traffic_method": traffic_note,
                 "traffic_from_profile": traffic_from_profile,
                 "bytes_per_launch": roof["bytes_per_launch"], "record_format": fmt_name,
                 "avg_launch_ms": roof["avg_launch_ms"], "median_launch_ms": roof.get("median_launch_ms"),
@@ -618,11 +647,14 @@ def main() -> int:
                 "effective_vs_8d_GBs": roof["effective_vs_8d_GBs"],
                 "note": "achieved/frac = bytes the dominant kernel streams per launch (plain SpMV: records + x + y; fused CG "
                         "step: records + p, r, x read + x, p', z written; `traffic` = the same by PMC) / launch time: a "
-                        "physical HBM fraction.  plain_spmv_* = the solve's first apply (the SpMV alone).  effective_vs_8d_GBs "
-                        "divides SURVEY 8d's fp64-weight + int32-column bytes by the same time and may exceed the "
-                        "peak for the lossless byte-indexed formats; roofline_general is the fp64-record kernel "
-                        "every mesh can use, where the two byte counts coincide",
+                        "physical HBM fraction.  frac_8d / effective_vs_8d_GBs divide SURVEY 8d's bytes of the reference "
+                        "statements the launch covers (fp64 weights + int32 columns; the fused step: + 64 B/row of vector "
+                        "statements) by the same time: > 1 for the lossless byte-indexed lattice format, which does not move "
+                        "those bytes -- NOT a bandwidth, and it says nothing about a mesh with distinct weights.  The SpMV "
+                        "alone is the `spmv` block (stand-alone applies, median of >= 50); roofline_general / "
+                        "roofline_unstructured3d are the fp64-record kernel every mesh can use, where frac == frac_8d",
             },
+            "spmv": spmv_block,
             "roofline_general": general_roof,
             "roofline_permuted_rcm": permuted,
             "roofline_unstructured": unstructured,
@@ -793,6 +825,96 @@ def baseline_configs(api, mesh, ctx, op, b, N, n, st, min_seconds):
     except Exception as e:
         out["config5_cavity128"] = {"error": repr(e)}
     return out
+
+
+def spmv_standalone(api, ctx, matrix, stats, cell_ids, launches, traffic_bytes=None):
+    """The "SpMV achieved HBM GB/s" half of BASELINE.json's metric as SURVEY.md 8d specifies it: stand-alone
+    `storm_hip_op_apply` launches (y = -L x, nothing fused in) on x_i = sin(0.37 i), i = global cell id, after a
+    warm-up; one HIP-event pair per launch on the library's compute stream; MEDIAN and mean.  Measured twice:
+    `back_to_back` on one (x, y) pair -- part of whose 2 x 8 B/row may be served by the 256 MiB Infinity Cache from
+    one launch to the next -- and `rotating` over three pairs (6 vectors: > 800 MB at 256^3, every launch finds its x
+    and y evicted).  Each time is priced three ways: SURVEY 8d's algorithmic bytes (24 N + 12 nnz: fp64 weights +
+    int32 columns, may exceed the peak for the byte-indexed formats -- those do not move these bytes), the bytes the
+    record format really streams (records + x + y), and the PMC-measured HBM traffic of the same kernel."""
+    import numpy as np
+
+    n_rows = stats["n_rows"]
+    alg = 24 * n_rows + 12 * stats["nnz_offdiag"]
+    streamed = stats["record_bytes"] + 16 * n_rows
+    xh = np.sin(0.37 * np.asarray(cell_ids, dtype=np.float64))
+    n_h = stats["n_cols"] - n_rows
+    xs_ = [api.DeviceVector(ctx, n_rows, n_h) for _ in range(3)]
+    ys_ = [api.DeviceVector(ctx, n_rows, n_h) for _ in range(3)]
+    for v_ in xs_:
+        v_.upload(xh)
+    ctx.set_option("profile_spmv", 1)
+    for i_ in range(12):  # warm-up (timed only for `all_launches_mean_ms`, the figure a rocprofv3 --stats average of a
+        matrix.apply(-1.0, 0.0, xs_[i_ % 3], ys_[i_ % 3])  # --spmv-only run compares with)
+    all_ms = [ctx.spmv_profile_samples()]
+    ctx.set_option("profile_spmv", 0)
+
+    def timed(pairs):
+        ctx.set_option("profile_spmv", 1)
+        for i_ in range(launches):
+            matrix.apply(-1.0, 0.0, xs_[i_ % pairs], ys_[i_ % pairs])
+        smp = ctx.spmv_profile_samples()
+        ctx.set_option("profile_spmv", 0)
+        all_ms.append(smp)
+        per_apply = smp.size // launches  # (a partitioned operator: interior + boundary launch per apply)
+        t_ = smp[: per_apply * launches].reshape(launches, per_apply).sum(axis=1)
+        med, mean = float(np.median(t_)), float(t_.mean())
+
+        def gbs(b_, ms_):
+            return b_ / (ms_ * 1e-3) / 1e9
+
+        o_ = {"launches": launches, "median_ms": med, "mean_ms": mean, "min_ms": float(t_.min()), "max_ms": float(t_.max()),
+              "GBs_8d_bytes": gbs(alg, med), "frac_8d": gbs(alg, med) / HBM_PEAK_GBS,
+              "GBs_streamed_bytes": gbs(streamed, med), "frac_streamed": gbs(streamed, med) / HBM_PEAK_GBS,
+              "GBs_8d_bytes_by_mean": gbs(alg, mean), "GBs_streamed_bytes_by_mean": gbs(streamed, mean)}
+        if traffic_bytes:
+            o_["GBs_pmc_traffic"] = gbs(traffic_bytes, med)
+            o_["frac_pmc_traffic"] = gbs(traffic_bytes, med) / HBM_PEAK_GBS
+        return o_
+
+    out_ = {"kernel": kernel_name(stats).split(" / ")[-1], "record_format": record_format_name(stats),
+            "input": "x_i = sin(0.37 i), i = global cell id; y = -L x (alpha = -1, beta = 0); storm_hip_op_apply alone",
+            "rows": n_rows, "nnz_offdiag": stats["nnz_offdiag"], "algorithmic_bytes_8d": alg, "streamed_bytes": streamed,
+            "pmc_traffic_bytes": traffic_bytes, "ell_padding_ratio": stats["ell_slots"] / max(stats["nnz_offdiag"] - stats["tail_nnz"], 1) - 1.0,
+            "tail_nnz": stats["tail_nnz"],
+            "back_to_back": timed(1), "rotating_3_pairs": timed(3)}
+    # the y of the last launch against a second evaluation order is not a parity check (tests/ hold those): only
+    # that the launches did something -- |y| is finite and non-zero
+    out_["y_norm"] = float(api.norm_2(ys_[0]))
+    cat = np.concatenate(all_ms)
+    out_["all_launches"] = int(cat.size)
+    out_["all_launches_mean_ms"] = float(cat.mean())
+    return out_
+
+
+def spmv_only(args) -> int:
+    """`--spmv-only`: nothing but the `spmv` block (lattice records, then fp64 records) in a process of its own, so that a
+    `rocprofv3 --kernel-trace --stats` of this command holds exactly these launches per kernel: its AverageNs for
+    spmv_canon_tile_kernel<false, ...> / spmv_sell_kernel<true, false, ...> is `all_launches_mean_ms`."""
+    import numpy as np
+
+    from stormruler_amd import api, mesh
+
+    g = mesh.structured_box(args.n)
+    ctx = api.Context(0)
+    for kv in args.opt:
+        k_, v_ = kv.split("=")
+        ctx.set_option(k_, int(v_))
+    out = {}
+    for name, level in (("lattice", None), ("general", 0)):
+        if level is not None:
+            ctx.set_option("spmv_dict", level)
+        mat = api.StencilMatrix.from_face_graph(ctx, g)
+        out[name] = spmv_standalone(api, ctx, mat, mat.stats(), np.arange(g.n_cells), args.spmv_launches)
+        mat.close()
+    print(json.dumps({"spmv": out, "n": args.n, "device": ctx.info()["name"]}), flush=True)
+    ctx.close()
+    return 0
+
 
 
 def record_format_name(st) -> str:
@@ -985,6 +1107,8 @@ def launch_ranks(n_ranks: int, args) -> int:
 def pmc_child(args) -> int:
     """The process rocprofv3 wraps for `roofline.traffic`: the headline operator and its fp64-record twin, a short CG
     solve each (SpMV launches with the fused-dot epilogue, like the timed region's)."""
+    import numpy as np
+
     from stormruler_amd import api, mesh
 
     g = mesh.structured_box(args.n)
@@ -1002,6 +1126,13 @@ def pmc_child(args) -> int:
         s.num_iterations, s.absolute_error_tolerance, s.relative_error_tolerance = 12, 0.0, 0.0
         s.solve(api.DeviceVector(ctx, g.n_cells), b, api.HipStencilOperator(mat, -1.0, 0.0))
         ctx.sync()
+        # ... and the stand-alone apply of the `spmv` block (no fused dot: a kernel instance of its own), rotating vectors
+        xs = [api.DeviceVector.from_numpy(ctx, np.sin(0.37 * np.arange(g.n_cells, dtype=np.float64))) for _ in range(3)]
+        ys = [api.DeviceVector(ctx, g.n_cells) for _ in range(3)]
+        for i in range(9):
+            mat.apply(-1.0, 0.0, xs[i % 3], ys[i % 3])
+        ctx.sync()
+        del xs, ys
         mat.close()
     ctx.close()
     return 0
@@ -1021,7 +1152,7 @@ def measure_traffic(args):
 
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
-        return None, None, "rocprofv3 not found"
+        return None, None, "rocprofv3 not found", {}
     # Never from inside a profiled process: the inner launcher would inherit the outer profiler's preloaded tool
     # library, which initialises the GPU in the launcher before it execs the target -- the forbidden exec hop.
     def profiler_var(k, v):
@@ -1029,7 +1160,7 @@ def measure_traffic(args):
                 (k == "LD_PRELOAD" and any(t in v for t in ("rocprof", "roctracer", "rocprofiler"))))
 
     if any(profiler_var(k, v) for k, v in os.environ.items()):
-        return None, None, "running under a profiler: no nested rocprofv3 (traffic not measured in this run)"
+        return None, None, "running under a profiler: no nested rocprofv3 (traffic not measured in this run)", {}
     sums = {}
     tmp = tempfile.mkdtemp(prefix="storm_pmc_", dir="/tmp")
     try:
@@ -1053,9 +1184,9 @@ def measure_traffic(args):
                 except ProcessLookupError:
                     pass
                 proc.communicate()
-                return None, None, f"rocprofv3 --pmc {counter}: no result within 90 s (the process group was ended)"
+                return None, None, f"rocprofv3 --pmc {counter}: no result within 90 s (the process group was ended)", {}
             if proc.returncode != 0:
-                return None, None, f"rocprofv3 --pmc {counter} exited with {proc.returncode}: {(err or '')[-300:]}"
+                return None, None, f"rocprofv3 --pmc {counter} exited with {proc.returncode}: {(err or '')[-300:]}", {}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(f, newline="") as fh:
                     for row in csv.DictReader(fh):
@@ -1065,7 +1196,11 @@ def measure_traffic(args):
                         tile = "spmv_canon_tile_kernel<true" in k
                         kind = ("step" if (tile and ", true>(" in k) or "cg_step_march_kernel" in k else  # the fused CG step (the dominant kernel of the headline run)
                                 "fmt" if (tile or "spmv_canon_kernel<true" in k or "spmv_pair_kernel<true" in k or "spmv_dict_kernel<true" in k)
-                                else "sell" if "spmv_sell_kernel<true, true" in k else None)
+                                else "sell" if "spmv_sell_kernel<true, true" in k
+                                # the stand-alone applies (no fused dot) of the `spmv` block
+                                else "plain_lattice" if ("spmv_canon_tile_kernel<false" in k or "spmv_canon_kernel<false" in k or
+                                                         "spmv_pair_kernel<false" in k or "spmv_dict_kernel<false" in k)
+                                else "plain_sell" if "spmv_sell_kernel<true, false" in k else None)
                         if kind:
                             a = sums.setdefault((counter, kind), [0, 0.0])
                             a[0] += 1
@@ -1083,9 +1218,12 @@ def measure_traffic(args):
                 f"(12-iteration CG, {sums.get(('FETCH_SIZE', head), [0])[0]} launches of the "
                 f"{'fused CG step kernel' if head == 'step' else 'SpMV kernel'} averaged); FETCH_SIZE doubled (gfx950), KiB"
                 + (f"; the plain SpMV launch of the same operator: {fmt:.0f} B" if step is not None and fmt is not None else ""))
-        return (step if step is not None else fmt if fmt is not None else sell), sell, note
+        plain = {"lattice": per_launch("plain_lattice"), "general": per_launch("plain_sell"),
+                 "launches": {"lattice": sums.get(("FETCH_SIZE", "plain_lattice"), [0])[0],
+                              "general": sums.get(("FETCH_SIZE", "plain_sell"), [0])[0]}}
+        return (step if step is not None else fmt if fmt is not None else sell), sell, note, plain
     except Exception as e:  # the measurement must never cost the headline line
-        return None, None, f"traffic measurement failed: {e!r}"
+        return None, None, f"traffic measurement failed: {e!r}", {}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

@@ -362,7 +362,11 @@ int comm_halo_exchange_begin_formed(const storm_hip_op *op, int mode, const doub
 // A solve is over (or begins): no exchange begun ahead of its vector may outlive it -- the vector goes back to the pool and
 // another one may get its address.
 void comm_forget_prebegun(storm_hip_ctx *c) {
-  if (c->comm != nullptr) c->comm->prebegun = nullptr;
+  if (c->comm == nullptr) return;
+  // An exchange begun ahead that nobody consumed (the solve's last iteration) still has a receive in flight on the comm
+  // stream that writes the halo tail of that vector: whatever takes the storage next on the compute stream waits for it.
+  if (c->comm->prebegun != nullptr) (void)hipStreamWaitEvent(c->stream, c->ev_halo_done, 0);
+  c->comm->prebegun = nullptr;
 }
 
 int comm_halo_exchange_end(const storm_hip_op *op) {

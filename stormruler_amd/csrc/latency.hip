@@ -1355,6 +1355,13 @@ int lat_check_gave_up(storm_hip_ctx *c) {
   c->coop_ran = 0;
   if (flag != 0) {
     (void)hipMemsetAsync(c->d_lat_slots + (size_t)2 * 256 * kLatSlotStride, 0, sizeof flag, c->stream);
+    // The resident kernels carry their all-reduce / exchange sequence numbers from solve to solve in d_res_slots and
+    // trust every block to leave with the same pair.  After a give-up that no longer holds (blocks left at different
+    // checks, some never started): a later solve could find a slot or granule of the aborted one already at "its" number.
+    // The stream is idle here: drop both buffers, the next resident solve allocates them zero-filled and restarts at 0.
+    if (c->d_res_slots) (void)hipFree(c->d_res_slots);
+    if (c->d_res_exch) (void)hipFree(c->d_res_exch);
+    c->d_res_slots = nullptr, c->d_res_exch = nullptr, c->res_exch_rows = 0;
     set_error("cooperative kernel: a block waited 10 s for the others (is the device shared with another process's "
               "cooperative kernel?)");
     return kStatusCoopGaveUp;  // coop_solve_with_fallback re-runs the solve on the kernel-per-statement path

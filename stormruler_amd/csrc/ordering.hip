@@ -16,6 +16,8 @@
 #include <atomic>
 #include <cmath>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <thread>
 #include <vector>
 
@@ -149,8 +151,20 @@ void morton_order(int dim, int64_t n, const double *c, const double *lo, const d
 
 using namespace storm;
 
+static int order_cells_impl(int32_t dim, int64_t n_cells, const double *centers, int32_t mode, int64_t *order, int32_t *kind);
+
 extern "C" int storm_hip_order_cells(int32_t dim, int64_t n_cells, const double *centers, int32_t mode, int64_t *order,
                                       int32_t *kind) {
+  try {  // (vectors and threads: nothing may leave an extern "C" entry point)
+    return order_cells_impl(dim, n_cells, centers, mode, order, kind);
+  } catch (const std::bad_alloc &) {
+    STORM_FAIL(STORM_HIP_E_ALLOC, "order_cells: out of host memory");
+  } catch (const std::exception &e) {
+    STORM_FAIL(STORM_HIP_E_INVALID, "order_cells: %s", e.what());
+  }
+}
+
+static int order_cells_impl(int32_t dim, int64_t n_cells, const double *centers, int32_t mode, int64_t *order, int32_t *kind) {
   STORM_REQUIRE(dim >= 1 && dim <= 3 && n_cells >= 0 && (centers || n_cells == 0) && (order || n_cells == 0),
                 "order_cells: bad argument");
   STORM_REQUIRE(mode >= 0 && mode <= 2, "order_cells: mode 0 (lattice, else Morton), 1 (Morton), 2 (lattice or fail)");
@@ -162,15 +176,18 @@ extern "C" int storm_hip_order_cells(int32_t dim, int64_t n_cells, const double 
   {
     const int T = nt;
     std::vector<double> tlo((size_t)T * 3, 1e300), thi((size_t)T * 3, -1e300);
+    std::atomic<int> bad{0};  // (min / max drop a NaN: every coordinate is looked at)
     par_for(n_cells, T, [&](int t, int64_t b, int64_t e) {
       for (int64_t i = b; i < e; ++i)
         for (int d = 0; d < dim; ++d) {
           const double v = centers[i * dim + d];
+          if (!std::isfinite(v)) bad.store(1, std::memory_order_relaxed);
           tlo[(size_t)t * 3 + d] = std::min(tlo[(size_t)t * 3 + d], v), thi[(size_t)t * 3 + d] = std::max(thi[(size_t)t * 3 + d], v);
         }
     });
     for (int t = 0; t < T; ++t)
       for (int d = 0; d < dim; ++d) lo[d] = std::min(lo[d], tlo[(size_t)t * 3 + d]), hi[d] = std::max(hi[d], thi[(size_t)t * 3 + d]);
+    STORM_REQUIRE(bad.load() == 0, "order_cells: non-finite cell centre");
   }
   for (int d = 0; d < dim; ++d)
     STORM_REQUIRE(std::isfinite(lo[d]) && std::isfinite(hi[d]), "order_cells: non-finite cell centre");

@@ -74,6 +74,15 @@ def main():
                               "method": method}
             if args.algorithmic_bytes:
                 out["general"]["ratio_to_algorithmic_bytes"] = traffic / args.algorithmic_bytes
+        # the stand-alone applies of bench.py's `spmv` block (no fused dot)
+        is_plain_lat = lambda k: any(t in k for t in ("spmv_canon_tile_kernel<false", "spmv_canon_kernel<false",  # noqa: E731
+                                                      "spmv_pair_kernel<false", "spmv_dict_kernel<false"))
+        is_plain_sell = lambda k: "spmv_sell_kernel<true, false" in k  # noqa: E731
+        for name, pred in (("spmv_alone_lattice", is_plain_lat), ("spmv_alone_general", is_plain_sell)):
+            fetch, write = avg("FETCH_SIZE", pred), avg("WRITE_SIZE", pred)
+            if fetch is not None and write is not None:
+                out[name] = {"traffic_bytes_per_launch": (2.0 * fetch + write) * 1024.0, "FETCH_SIZE_KiB_raw": fetch,
+                             "WRITE_SIZE_KiB": write, "method": method}
         if out:
             with open(args.traffic_json, "w") as fh:
                 json.dump(out, fh, indent=1)
