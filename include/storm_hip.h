@@ -36,7 +36,7 @@ extern "C" {
 /* every declaration below is an exported symbol of libstorm_hip.so */
 #pragma GCC visibility push(default)
 
-#define STORM_HIP_ABI_VERSION 4
+#define STORM_HIP_ABI_VERSION 5
 
 enum {
   STORM_HIP_OK = 0,
@@ -322,6 +322,76 @@ int storm_hip_ctx_get_counter(storm_hip_ctx *ctx, const char *key, int64_t *valu
  * 2 Morton.  No device is touched. */
 int storm_hip_order_cells(int32_t dim, int64_t n_cells, const double *centers, int32_t mode, int64_t *order_out,
                           int32_t *kind_out);
+
+/* ---- host-side meshes: the data either side of the path (SURVEY.md 8f row 4, 8e "Partitioning") -----------------
+ * A storm_hip_mesh is a face graph in host memory -- exactly the arrays stormDivGrad's face loop reads
+ * (Playground.cpp:119-129: face -> inner / outer cell, face area, cell centre, cell volume) plus the boundary faces,
+ * and, for a rank's part of a partitioned mesh, its halo cells and halo plan.  No device is touched by any of these
+ * calls; all are threaded (STORM_HIP_BUILD_THREADS).  stormruler_amd/io_tetgen.py and partition.py are the numpy
+ * restatements they are checked against array for array. */
+typedef struct storm_hip_mesh storm_hip_mesh;
+typedef struct storm_hip_mesh_view {
+  int32_t dim, n_nbrs;
+  int64_t n_cells, n_halo, n_faces, n_bfaces;
+  const int64_t *inner, *outer;   /* [n_faces] local cell ids in [0, n_cells + n_halo)             Mesh.hpp:269-280 */
+  const double *area;             /* [n_faces]                                                      Mesh.hpp:254 */
+  const double *center, *volume;  /* [(n_cells + n_halo) * dim], [n_cells + n_halo]                 Mesh.hpp:304-311 */
+  const int64_t *b_cell;          /* [n_bfaces] owning cell of a labelled (boundary) face */
+  const double *b_area, *b_center;/* [n_bfaces], [n_bfaces * dim] */
+  const int64_t *global_id;       /* [n_cells + n_halo] or NULL (an unpermuted single-rank mesh: the identity) */
+  const int32_t *halo_owner;      /* [n_halo] or NULL */
+  const int32_t *nbr_rank;        /* halo plan, as storm_hip_op_set_halo takes it */
+  const int64_t *send_ptr, *send_idx, *recv_ptr;
+} storm_hip_mesh_view;
+
+/* `read_mesh_from_tetgen(mesh, path)`  Mallard/IoTetgen.hpp:44-235, both branches: <prefix>.node / .edge / [.face] /
+ * .ele (prefix ends with ".1." or ".1"; '#' comments; zero-based ids used as written), then the face graph the
+ * reference's insert() calls build (MeshUnstructured.hpp:350-425, 509-554: listed sides keep file order and their
+ * marker as label, unlisted ones are created by the first cell that owns them in the order of Triangle::edges() /
+ * Tetrahedron::faces() with label 0; inner = first owner, outer = second, which must see the side reversed;
+ * interior = label 0).  dim = mesh_dim_v<Mesh> the caller expects (2, 3; 0 = what the node file says): a mismatch is the
+ * reference's I/O error.  Errors (missing file, short file, bad header, bad topology) return STORM_HIP_E_INVALID with
+ * the reference's message (STORM_THROW_IO -> std::runtime_error, Crow/Base/Exception.hpp:35-44).  Geometry:
+ * Shape.hpp:155-167, 242-247, 309-321, 598-607; the tetrahedron's volume |det| / 6 is this build's own (the reference
+ * has no volume(Tetrahedron): SURVEY.md headline fact 4). */
+int storm_hip_mesh_read_tetgen(const char *prefix, int32_t dim, storm_hip_mesh **out);
+/* The same face graph from arrays in memory: pos[n_nodes * dim], listed[n_listed * dim] (+ listed_label[n_listed] or
+ * NULL = all 0), cells[n_cells * (dim + 1)]. */
+int storm_hip_mesh_from_simplices(int32_t dim, int64_t n_nodes, const double *pos, int64_t n_listed, const int64_t *listed,
+                                  const int64_t *listed_label, int64_t n_cells, const int64_t *cells, storm_hip_mesh **out);
+/* Writes the four files in the format above (doubles in the shortest form that round-trips; 3-D: an .edge file
+ * with no entries).  Test / bench infrastructure: the reference only reads. */
+int storm_hip_mesh_write_tetgen(const char *prefix, int32_t dim, int64_t n_nodes, const double *pos, int64_t n_listed,
+                                const int64_t *listed, const int64_t *listed_label, int64_t n_cells, const int64_t *cells);
+/* A mesh from face-graph arrays the caller already has (copied); global_id / halo_owner may be NULL when n_halo == 0. */
+int storm_hip_mesh_create(int32_t dim, int64_t n_cells, int64_t n_halo, int64_t n_faces, const int64_t *inner,
+                          const int64_t *outer, const double *area, const double *center, const double *volume,
+                          int64_t n_bfaces, const int64_t *b_cell, const double *b_area, const double *b_center,
+                          const int64_t *global_id, const int32_t *halo_owner, storm_hip_mesh **out);
+/* Pointers into the mesh's own arrays: valid until the mesh is permuted or destroyed. */
+int storm_hip_mesh_get_view(const storm_hip_mesh *mesh, storm_hip_mesh_view *view);
+/* `UnstructuredMesh::permute`  MeshUnstructured.hpp:443-459 for cells: new cell i is old cell order[i]; faces keep
+ * their order and their inner / outer roles; halo cells keep their slot; global_id follows (and is created for a
+ * single-rank mesh, so a later partition still knows the original ids). */
+int storm_hip_mesh_permute_cells(storm_hip_mesh *mesh, const int64_t *order);
+/* Cell -> rank maps (the reference has no partitioner, METIS is not in the image): recursive coordinate
+ * bisection -- the longest axis of a part's bounding box cut at the k-th smallest (coordinate, cell id), k
+ * proportional to the ranks on either side, any n_parts -- and slabs along one axis (contiguous ranges of the cells
+ * ordered by (coordinate, cell id): k whole planes per rank for a structured box of k * n_parts planes). */
+int storm_hip_partition_rcb(int32_t dim, int64_t n_cells, const double *centers, int32_t n_parts, int32_t *part_out);
+int storm_hip_partition_slabs(int32_t dim, int64_t n_cells, const double *centers, int32_t axis, int32_t n_parts,
+                              int32_t *part_out);
+/* A rank's part of a single-rank mesh: its owned cells in ascending id, then the halo cells grouped by owner rank,
+ * each group in ascending global id; every face that touches an owned cell, in mesh order; the boundary faces of the
+ * owned cells; and the halo plan -- towards neighbour q the owned cells that share a face with one of q's cells, in
+ * ascending global id (= q's halo group for this rank: no index lists are ever exchanged). */
+int storm_hip_mesh_partition(const storm_hip_mesh *global_mesh, const int32_t *part, int32_t n_parts, int32_t rank,
+                             storm_hip_mesh **out);
+/* (Re)computes the halo plan of a local mesh built with storm_hip_mesh_create from its global ids and halo owners. */
+int storm_hip_mesh_halo_plan(storm_hip_mesh *mesh, int32_t rank);
+/* storm_hip_op_create_from_mesh on the mesh's arrays + storm_hip_op_set_halo with its halo plan. */
+int storm_hip_op_create_from_mesh_object(storm_hip_ctx *ctx, const storm_hip_mesh *mesh, storm_hip_op **out);
+int storm_hip_mesh_destroy(storm_hip_mesh *mesh);
 
 /* Halo plan of a row-partitioned operator.  For neighbour q
  * (rank nbr_rank[q]) the owned rows send_idx[send_ptr[q] .. send_ptr[q+1]) are

@@ -50,6 +50,14 @@ class OpStats(C.Structure):
                                           "offset_dictionary_size", "paired_rows", "tiled_planes", "spmv_blocks")]
 
 
+class MeshView(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("n_nbrs", C.c_int32), ("n_cells", C.c_int64), ("n_halo", C.c_int64),
+                ("n_faces", C.c_int64), ("n_bfaces", C.c_int64), ("inner", i64p), ("outer", i64p), ("area", f64p),
+                ("center", f64p), ("volume", f64p), ("b_cell", i64p), ("b_area", f64p), ("b_center", f64p),
+                ("global_id", i64p), ("halo_owner", i32p), ("nbr_rank", i32p), ("send_ptr", i64p), ("send_idx", i64p),
+                ("recv_ptr", i64p)]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int64),
                           C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double))
@@ -115,6 +123,19 @@ SIGNATURES = {
                                                         f64p, f64p, f64p, C.POINTER(vp)]),
     "storm_hip_op_create_csr": (C.c_int, [vp, C.c_int64, C.c_int64, i64p, i64p, f64p, C.POINTER(vp)]),
     "storm_hip_op_set_halo": (C.c_int, [vp, C.c_int, i32p, i64p, i64p, i64p]),
+    "storm_hip_mesh_read_tetgen": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(vp)]),
+    "storm_hip_mesh_from_simplices": (C.c_int, [C.c_int32, C.c_int64, f64p, C.c_int64, i64p, i64p, C.c_int64, i64p, C.POINTER(vp)]),
+    "storm_hip_mesh_write_tetgen": (C.c_int, [C.c_char_p, C.c_int32, C.c_int64, f64p, C.c_int64, i64p, i64p, C.c_int64, i64p]),
+    "storm_hip_mesh_create": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_int64, i64p, i64p, f64p, f64p, f64p, C.c_int64,
+                                        i64p, f64p, f64p, i64p, i32p, C.POINTER(vp)]),
+    "storm_hip_mesh_get_view": (C.c_int, [vp, C.POINTER(MeshView)]),
+    "storm_hip_mesh_permute_cells": (C.c_int, [vp, i64p]),
+    "storm_hip_partition_rcb": (C.c_int, [C.c_int32, C.c_int64, f64p, C.c_int32, i32p]),
+    "storm_hip_partition_slabs": (C.c_int, [C.c_int32, C.c_int64, f64p, C.c_int32, C.c_int32, i32p]),
+    "storm_hip_mesh_partition": (C.c_int, [vp, i32p, C.c_int32, C.c_int32, C.POINTER(vp)]),
+    "storm_hip_mesh_halo_plan": (C.c_int, [vp, C.c_int32]),
+    "storm_hip_op_create_from_mesh_object": (C.c_int, [vp, vp, C.POINTER(vp)]),
+    "storm_hip_mesh_destroy": (C.c_int, [vp]),
     "storm_hip_op_apply": (C.c_int, [vp, C.c_double, C.c_double, vp, vp]),
     "storm_hip_op_apply_add": (C.c_int, [vp, C.c_double, vp, vp]),
     "storm_hip_op_get_diagonal": (C.c_int, [vp, C.c_double, C.c_double, C.c_int, vp]),
@@ -145,7 +166,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-if lib.storm_hip_abi_version() != 4:
+if lib.storm_hip_abi_version() != 5:
     raise ImportError("libstorm_hip.so ABI version mismatch")
 
 

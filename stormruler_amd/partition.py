@@ -107,7 +107,8 @@ def rcb_partition(center: np.ndarray, n_parts: int) -> np.ndarray:
     """Recursive coordinate bisection of the cell centres into ``n_parts`` balanced parts.
 
     The build's own k-way partitioner for general meshes (METIS is not available): split
-    the longest axis of the bounding box at the weighted median, recurse.  Part sizes differ by at most
+    the longest axis of the bounding box at the k-th smallest (coordinate, cell id), recurse
+    (``storm_hip_partition_rcb`` is the same rule natively: csrc/mesh_host.hip).  Part sizes differ by at most
     one cell per level; works for any ``n_parts`` (the split is proportional, not only powers of two).
     Returns the cell -> rank map for :func:`partition_graph`.
     """
@@ -122,7 +123,7 @@ def rcb_partition(center: np.ndarray, n_parts: int) -> np.ndarray:
         pts = center[idx]
         axis = int(np.argmax(pts.max(axis=0) - pts.min(axis=0)))
         k = (idx.size * left_parts) // count
-        order = np.argsort(pts[:, axis], kind="stable")
+        order = np.lexsort((idx, pts[:, axis]))  # ties by cell id: the cut does not depend on the recursion's history
         split(idx[order[:k]], first, left_parts)
         split(idx[order[k:]], first + left_parts, count - left_parts)
 
