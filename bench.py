@@ -34,6 +34,11 @@ Prints ONE JSON line on rank 0.
   roofline_unstructured  the 256^3 graph with a jittered geometry (no two weights equal => fp64 records, SURVEY 8d's
                     bytes), cells renumbered by the seeded permutation, then the library's ordering: the number a
                     Triangle / TetGen mesh of this size would get;
+  roofline_unstructured3d  a genuinely unstructured 3-D mesh at HBM scale: 12.6 M tetrahedra (seeded: six shapes of cells,
+                    rows of 2 - 4 neighbours, all weights distinct) written as TetGen files, read back by the library's
+                    reader (3-D branch of read_mesh_from_tetgen), Z-order numbering, fp64 records: SpMV fraction by SURVEY
+                    8d's bytes (fused-dot launches of a CG solve AND the stand-alone `spmv` block), PMC traffic, ELL
+                    padding, CSR tail, CG it/s;
   config1_cg64, config3_bicgstab256, config4_gmres30_convdiff128, config5_cavity128   BASELINE configs 1, 3, 4, 5 on this GPU, bounded;
   extra_gmres30_poisson256   GMRES(30) at the headline size (kernel-per-statement path: the Gram-Schmidt passes at HBM scale);
   cpu_baseline      the CPU oracle (single thread, the reference is single-threaded) on a bounded sample.
@@ -104,6 +109,9 @@ def main() -> int:
     ap.add_argument("--skip-configs", action="store_true", help="skip BASELINE configs 3, 4, 5")
     ap.add_argument("--roofline-launches", type=int, default=200,
                     help="launches of the dominant kernel timed for `roofline` (at least this many, whatever --steps is)")
+    ap.add_argument("--skip-unstructured3d", action="store_true", help="skip the tetrahedral mesh (roofline_unstructured3d)")
+    ap.add_argument("--tet-edge", type=int, default=128, help="cubes per edge of the tetrahedral box (6 n^3 cells: 128 -> 12.6 M)")
+    ap.add_argument("--tet-prefix", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--skip-spmv", action="store_true", help="skip the stand-alone SpMV block (`spmv` in the line)")
     ap.add_argument("--spmv-launches", type=int, default=60, help="stand-alone SpMV launches timed per mode (SURVEY.md 8d: >= 50)")
     ap.add_argument("--spmv-only", action="store_true", help="run only the stand-alone SpMV block (for a clean rocprofv3 --stats comparison)")
@@ -346,11 +354,23 @@ def main() -> int:
                         "waiting for the receivers' acknowledgement of the plane two exchanges back; late halo values = "
                         "rows of the boundary launch that had to poll (thread-time each); everything else of an iteration "
                         "is the single-GPU path's kernels (compare ms_per_step with the 1-GPU line)"}
+        elif transport == "rccl" and not args.shared_device:
+            # RCCL: an instrumented solve beside the timed ones (stamp kernels around every step of the exchange and the
+            # all-reduces, csrc/comm.hip); the worst rank's figures
+            try:
+                ctx.set_option("profile_comm", 1)
+                run(K)
+                ctx.sync()
+                comm_breakdown = ctx.rccl_profile(K)
+                ctx.set_option("profile_comm", 0)
+                for k_ in list(comm_breakdown):
+                    if k_.endswith(("_each", "_per_iteration")) and k_ not in ("halo_exchanges_per_iteration", "allreduces_per_iteration"):
+                        comm_breakdown[k_ + "_worst_rank"] = dist.allreduce_max(comm_breakdown.pop(k_))
+            except Exception as e:
+                comm_breakdown = {"transport": transport, "error": repr(e)}
         else:
             comm_breakdown = {"transport": transport,
-                              "note": "device-side waits are instrumented on the peer-window transport only; RCCL / host-staged: "
-                                      "compare ms_per_step with the 1-GPU line (tools/comm_path_overhead.py measures the path's "
-                                      "cost at one rank)"}
+                              "note": "host-staged transport: synchronous, nothing to overlap; compare ms_per_step with the 1-GPU line"}
 
     # ---- N > 1: post-flight.  The timed region ran the production kernels on the production transport; before its
     # number is reported, (1) the fused CG step must agree with the kernel-per-statement loop on the same transport
@@ -395,9 +415,18 @@ def main() -> int:
     # the same operator), else quoted from the committed profile -- under its own name, with the file's hash
     tfile = os.path.join(ROOT, "profiles", "spmv_hbm_traffic.json")
     traffic, traffic_general, traffic_note, traffic_plain = None, None, None, {}
+    tet_dir, tet_prefix, tet_file_seconds, tet_file_bytes = None, None, None, None
+    if world == 1 and not args.force_comm and not args.skip_unstructured3d:
+        try:
+            import tempfile
+
+            tet_dir = tempfile.mkdtemp(prefix="storm_tet_", dir=os.environ.get("TMPDIR", "/tmp"))
+            tet_prefix, tet_file_seconds, tet_file_bytes = tet_files(args.tet_edge, tet_dir)
+        except Exception as e:
+            tet_prefix, tet_file_seconds = None, {"error": repr(e)}
     if args.traffic == "measure" and n == 256 and world == 1 and rank == 0:
         ctx.sync()
-        traffic, traffic_general, traffic_note, traffic_plain = measure_traffic(args)
+        traffic, traffic_general, traffic_note, traffic_plain = measure_traffic(args, tet_prefix)
     # ---- the SpMV alone: >= 50 stand-alone applies on x_i = sin(0.37 i), median, three byte counts ----
     spmv_block = None
     if world == 1 and not args.force_comm and not args.skip_spmv:
@@ -548,6 +577,21 @@ def main() -> int:
         except Exception as e:
             unstructured = {"error": repr(e)}
 
+    # ---- a genuinely unstructured 3-D mesh: tetrahedra from TetGen files (variable row degree, fp64 records) ----
+    unstructured3d = None
+    if tet_prefix is not None:
+        try:
+            unstructured3d = tet_variant(api, ctx, args, tet_prefix, tet_file_seconds, tet_file_bytes,
+                                         traffic_plain.get("tet"), traffic_plain.get("tet_dot"))
+        except Exception as e:
+            unstructured3d = {"error": repr(e)}
+    elif isinstance(tet_file_seconds, dict) and "error" in tet_file_seconds:
+        unstructured3d = tet_file_seconds
+    if tet_dir is not None:
+        import shutil
+
+        shutil.rmtree(tet_dir, ignore_errors=True)
+
     # ---- BASELINE configs 3, 4, 5 on this GPU (bounded: a few hundred milliseconds of device time each) ----
     configs = None
     if world == 1 and not args.skip_configs and not args.force_comm:
@@ -658,6 +702,7 @@ def main() -> int:
             "roofline_general": general_roof,
             "roofline_permuted_rcm": permuted,
             "roofline_unstructured": unstructured,
+            "roofline_unstructured3d": unstructured3d,
             "config1_cg64": (configs or {}).get("config1_cg64") if isinstance(configs, dict) else None,
             "config3_bicgstab256": (configs or {}).get("config3_bicgstab256") if isinstance(configs, dict) else None,
             "config4_gmres30_convdiff128": (configs or {}).get("config4_gmres30_convdiff128") if isinstance(configs, dict) else None,
@@ -917,6 +962,115 @@ def spmv_only(args) -> int:
 
 
 
+def tet_files(n3, workdir):
+    """The seeded tetrahedral box (stormruler_amd.io_tetgen.tet_box: 6 n3^3 cells) written as TetGen files by the library's
+    writer.  Returns (prefix, seconds by step, bytes on disk)."""
+    import numpy as np
+
+    from stormruler_amd import host_mesh, io_tetgen
+
+    sec = {}
+    t0 = time.time()
+    pos, bf, cells = io_tetgen.tet_box(n3)
+    sec["generate_numpy"] = time.time() - t0
+    prefix = os.path.join(workdir, "tetbox.1")
+    t0 = time.time()
+    host_mesh.write_tetgen(prefix, pos, bf, np.ones(len(bf), np.int64), cells)
+    sec["write_tetgen_files"] = time.time() - t0
+    size = sum(os.path.getsize(prefix + e) for e in (".node", ".edge", ".face", ".ele"))
+    return prefix, sec, size
+
+
+def tet_operator(api, ctx, prefix):
+    """<prefix>.node/.edge/.face/.ele -> the library's reader (3-D branch of read_mesh_from_tetgen) -> Morton order of the
+    cell centres -> the operator.  Returns (host mesh, operator, seconds by step)."""
+    from stormruler_amd import host_mesh
+
+    sec = {}
+    t0 = time.time()
+    hm = host_mesh.HostMesh.read_tetgen(prefix + ".", 3)
+    sec["read_files_and_build_face_graph"] = time.time() - t0
+    t0 = time.time()
+    kind = hm.order_cells("morton")
+    sec["morton_ordering"] = time.time() - t0
+    assert kind == "morton"
+    t0 = time.time()
+    mat = hm.create_operator(ctx)
+    sec["operator_build"] = time.time() - t0
+    return hm, mat, sec
+
+
+def tet_variant(api, ctx, args, prefix, file_seconds, file_bytes, traffic_bytes, traffic_dot_bytes):
+    """`roofline_unstructured3d`: a genuinely unstructured 3-D mesh at HBM scale -- tetrahedra read from TetGen files,
+    rows of 2 - 4 neighbours with all-distinct fp64 weights, Z-order numbering -- through the kernel every mesh gets
+    (spmv_sell_kernel, fp64 records: streamed bytes == SURVEY 8d's algorithmic bytes, but for the ELL padding)."""
+    import numpy as np
+
+    hm, mat, sec = tet_operator(api, ctx, prefix)
+    sec = dict(file_seconds, **sec)
+    st = mat.stats()
+    v = hm.view()
+    n_rows = st["n_rows"]
+    gid = np.ctypeslib.as_array(v.global_id, shape=(n_rows,)).copy()  # row i is cell gid[i] of the files
+    op = api.HipStencilOperator(mat, alpha=-1.0, beta=0.0)
+    b = api.DeviceVector(ctx, n_rows)
+    api.fill_with(b, 1.0)
+    K = args.steps
+
+    def run(iters):
+        x = api.DeviceVector(ctx, n_rows)
+        s_ = api.CgSolver()
+        s_.num_iterations, s_.absolute_error_tolerance, s_.relative_error_tolerance = iters, 0.0, 0.0
+        s_.solve(x, b, op)
+        assert s_.iteration == iters
+        return s_
+
+    run(max(args.warmup, 20))
+    ctx.sync()
+    reps = []
+    while sum(reps) < args.min_seconds and len(reps) < 2000:
+        t1 = time.perf_counter()
+        s_ = run(K)
+        ctx.sync()
+        reps.append(time.perf_counter() - t1)
+    t1 = float(np.median(reps))
+    # the SpMV launches of a CG solve (fused <p, Ap> partials), HIP-event pairs
+    iters = max(K, args.roofline_launches)
+    ctx.set_option("profile_spmv", 1)
+    run(iters)
+    smp = ctx.spmv_profile_samples()
+    ctx.set_option("profile_spmv", 0)
+    alg = 24 * n_rows + 12 * st["nnz_offdiag"]
+    streamed = st["record_bytes"] + 16 * n_rows
+    ms, med = float(smp.mean()), float(np.median(smp))
+    out = {"kernel": "spmv_sell_kernel (fp64 records) + fused <p,Ap> partials", "record_format": record_format_name(st),
+           "mesh": f"tetrahedral box, {st['n_rows']} cells (6 x {args.tet_edge}^3: Kuhn's six tetrahedra per cube, interior nodes "
+                   "jittered by <= 0.15 h, seeded), written as TetGen .node/.edge/.face/.ele by storm_hip_mesh_write_tetgen, read back by "
+                   "storm_hip_mesh_read_tetgen (3-D branch of Mallard/IoTetgen.hpp), cells renumbered along the Z-order curve of "
+                   "their centres (storm_hip_order_cells), operator by storm_hip_op_create_from_mesh_object",
+           "bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_8d": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "frac_by_median": alg / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "frac_streamed_bytes": streamed / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "traffic": traffic_dot_bytes, "traffic_over_8d_bytes": (traffic_dot_bytes / alg) if traffic_dot_bytes else None,
+           "algorithmic_bytes_8d": alg, "streamed_bytes": streamed, "avg_launch_ms": ms, "median_launch_ms": med,
+           "min_launch_ms": float(smp.min()), "launches_timed": int(smp.size),
+           "rows": n_rows, "interior_faces": int(v.n_faces), "boundary_faces": int(v.n_bfaces), "nnz_offdiag": st["nnz_offdiag"],
+           "max_row_len": st["max_row_len"], "ell_slots": st["ell_slots"],
+           "ell_padding_ratio": st["ell_slots"] / max(st["nnz_offdiag"] - st["tail_nnz"], 1) - 1.0, "tail_nnz": st["tail_nnz"],
+           "cg_iter_per_s": K / t1, "ms_per_step": t1 / K * 1e3, "cg_final_residual": s_.absolute_error,
+           "cg_reference_op_list_bytes_per_iteration": alg + 96 * n_rows,
+           "host_seconds": sec, "tetgen_files_bytes": file_bytes}
+    band = np.abs(np.ctypeslib.as_array(v.inner, shape=(v.n_faces,)) - np.ctypeslib.as_array(v.outer, shape=(v.n_faces,)))
+    out["column_distance_median"], out["column_distance_p99"], out["column_distance_max"] = (
+        int(np.median(band)), int(np.percentile(band, 99)), int(band.max()))
+    if not args.skip_spmv:
+        out["spmv"] = spmv_standalone(api, ctx, mat, st, gid, args.spmv_launches, traffic_bytes)
+    mat.close()
+    hm.close()
+    return out
+
+
 def record_format_name(st) -> str:
     return ("typed canonical paired rows: one byte per row into a table of weight words, one common offset order (1 B/row)"
             if st["paired_rows"] == 3 else
@@ -1134,11 +1288,26 @@ def pmc_child(args) -> int:
         ctx.sync()
         del xs, ys
         mat.close()
+    if args.tet_prefix:  # the tetrahedral mesh of roofline_unstructured3d: a CG solve (fused dot) and stand-alone applies
+        hm, mat, _ = tet_operator(api, ctx, args.tet_prefix)
+        nt = mat.stats()["n_rows"]
+        # (the kernel instances are the fp64-record ones of the box above: told apart by their grid size)
+        bt = api.DeviceVector(ctx, nt)
+        api.fill_with(bt, 1.0)
+        s = api.CgSolver()
+        s.num_iterations, s.absolute_error_tolerance, s.relative_error_tolerance = 12, 0.0, 0.0
+        s.solve(api.DeviceVector(ctx, nt), bt, api.HipStencilOperator(mat, -1.0, 0.0))
+        xs = [api.DeviceVector.from_numpy(ctx, np.sin(0.37 * np.arange(nt, dtype=np.float64))) for _ in range(3)]
+        ys = [api.DeviceVector(ctx, nt) for _ in range(3)]
+        for i in range(9):
+            mat.apply(-1.0, 0.0, xs[i % 3], ys[i % 3])
+        ctx.sync()
+        mat.close()
     ctx.close()
     return 0
 
 
-def measure_traffic(args):
+def measure_traffic(args, tet_prefix=None):
     """HBM bytes per SpMV launch by PMC, as /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE
     in SEPARATE rocprofv3 passes (--pmc with --kernel-trace only), FETCH_SIZE doubled (on gfx950 it reports exactly half the
     bytes of a wide coalesced streaming read: 128-byte requests tallied at 64 B), both in KiB.  Returns (headline kernel, fp64-record kernel,
@@ -1162,13 +1331,15 @@ def measure_traffic(args):
     if any(profiler_var(k, v) for k, v in os.environ.items()):
         return None, None, "running under a profiler: no nested rocprofv3 (traffic not measured in this run)", {}
     sums = {}
+    # the fp64-record kernel runs on the box AND on the tetrahedral mesh: told apart by the grid (threads) of the launch
+    box_grid = ((args.n ** 3 + 255) // 256) * 256
     tmp = tempfile.mkdtemp(prefix="storm_pmc_", dir="/tmp")
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
                    sys.executable, os.path.abspath(__file__), "--pmc-child", "--edge", str(args.n),
-                   *[f"--opt={kv}" for kv in args.opt]]
+                   *[f"--opt={kv}" for kv in args.opt], *(["--tet-prefix", tet_prefix] if tet_prefix else [])]
             env = {k: v for k, v in os.environ.items()
                    if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK") and not profiler_var(k, v)}
             env["TMPDIR"] = "/tmp"
@@ -1177,14 +1348,14 @@ def measure_traffic(args):
             proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
                                     start_new_session=True)
             try:
-                _, err = proc.communicate(timeout=90)
+                _, err = proc.communicate(timeout=90 + (90 if tet_prefix else 0))
             except subprocess.TimeoutExpired:
                 try:
                     os.killpg(proc.pid, signal.SIGKILL)
                 except ProcessLookupError:
                     pass
                 proc.communicate()
-                return None, None, f"rocprofv3 --pmc {counter}: no result within 90 s (the process group was ended)", {}
+                return None, None, f"rocprofv3 --pmc {counter}: no result within its time limit (the process group was ended)", {}
             if proc.returncode != 0:
                 return None, None, f"rocprofv3 --pmc {counter} exited with {proc.returncode}: {(err or '')[-300:]}", {}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -1193,6 +1364,11 @@ def measure_traffic(args):
                         if row["Counter_Name"] != counter:
                             continue
                         k = row["Kernel_Name"]
+                        if "spmv_sell_kernel<true" in k and row.get("Grid_Size") and box_grid is not None and int(row["Grid_Size"]) != box_grid:
+                            a = sums.setdefault((counter, "tet_dot" if "spmv_sell_kernel<true, true" in k else "tet_plain"), [0, 0.0])
+                            a[0] += 1
+                            a[1] += float(row["Counter_Value"])
+                            continue
                         tile = "spmv_canon_tile_kernel<true" in k
                         kind = ("step" if (tile and ", true>(" in k) or "cg_step_march_kernel" in k else  # the fused CG step (the dominant kernel of the headline run)
                                 "fmt" if (tile or "spmv_canon_kernel<true" in k or "spmv_pair_kernel<true" in k or "spmv_dict_kernel<true" in k)
@@ -1219,6 +1395,7 @@ def measure_traffic(args):
                 f"{'fused CG step kernel' if head == 'step' else 'SpMV kernel'} averaged); FETCH_SIZE doubled (gfx950), KiB"
                 + (f"; the plain SpMV launch of the same operator: {fmt:.0f} B" if step is not None and fmt is not None else ""))
         plain = {"lattice": per_launch("plain_lattice"), "general": per_launch("plain_sell"),
+                 "tet": per_launch("tet_plain"), "tet_dot": per_launch("tet_dot"),
                  "launches": {"lattice": sums.get(("FETCH_SIZE", "plain_lattice"), [0])[0],
                               "general": sums.get(("FETCH_SIZE", "plain_sell"), [0])[0]}}
         return (step if step is not None else fmt if fmt is not None else sell), sell, note, plain

@@ -269,7 +269,7 @@ int storm_hip_op_create_csr(storm_hip_ctx *ctx, int64_t n_rows, int64_t n_halo,
  *   generic_solvers (0): 1 sends storm_hip_krylov_solve through the engine even where a fused loop exists;
  *   fuse_dot, fold_pz, fuse_mgs (1): the fused-reduction variants of the fused loops;
  *   ipc_streams (2): peer-window halo kernels on the comm stream (2) or on the compute stream (1);
- *   spmv_xcd_remap (8), spmv_nt_y (0), nontemporal (1), spmv_spw, spmv_variant, graph (0), profile_spmv (0);
+ *   spmv_xcd_remap (8), spmv_nt_y (0), nontemporal (1), spmv_spw, spmv_variant, graph (0), profile_spmv (0), profile_comm (0);
  *   blas1_nt (1), blas1_nt_rows (6 * 2^20): non-temporal loads and stores in the BLAS-1 and solver kernels -- 0 never,
  *              2 always, 1 for vectors of at least blas1_nt_rows rows (longer vectors do not survive in the Infinity
  *              Cache between two kernels of a solve anyway; shorter ones do, and non-temporal accesses cost 3 - 7 %
@@ -309,7 +309,12 @@ int storm_hip_ctx_set_option(storm_hip_ctx *ctx, const char *key, int64_t value)
  * real-time counter, and counts): "ipc_allreduce_wait_ticks" / "ipc_allreduces" (from a rank's own contribution being
  * stored to every rank's being read), "ipc_ack_wait_ticks" / "ipc_ack_waits" (a send waiting for the receivers to have
  * consumed the plane two exchanges back), "ipc_halo_slow_poll_ticks" / "ipc_halo_slow_polls" (halo values that had not
- * arrived when the boundary rows asked for them; thread-ticks).  With option "resident_profile" = 1:
+ * arrived when the boundary rows asked for them; thread-ticks).  On the RCCL transport with option "profile_comm" = 1
+ * (one-thread stamp kernels around every step, both streams; setting the option restarts the sums): "rccl_prof_exchanges",
+ * "rccl_prof_event_to_comm_ticks" (the compute stream has the vector ready -> the comm stream starts),
+ * "rccl_prof_pack_ticks", "rccl_prof_sendrecv_ticks", "rccl_prof_unhidden_wait_ticks" (the exchange still running when the
+ * interior rows had ended), "rccl_prof_resume_ticks" (exchange and interior rows done -> the boundary rows start),
+ * "rccl_prof_allreduces", "rccl_prof_allreduce_ticks".  With option "resident_profile" = 1:
  * "resident_phase_mean_<k>" / "resident_phase_max_<k>" (csrc/resident.hip). */
 int storm_hip_ctx_get_counter(storm_hip_ctx *ctx, const char *key, int64_t *value);
 

@@ -81,6 +81,38 @@ class Context:
         check(lib.storm_hip_ctx_get_counter(self._h, key.encode(), C.byref(v)))
         return v.value
 
+    RCCL_PROFILE_KEYS = ("rccl_prof_exchanges", "rccl_prof_event_to_comm_ticks", "rccl_prof_pack_ticks",
+                         "rccl_prof_sendrecv_ticks", "rccl_prof_unhidden_wait_ticks", "rccl_prof_resume_ticks",
+                         "rccl_prof_allreduces", "rccl_prof_allreduce_ticks")
+
+    def rccl_profile(self, iterations: int) -> dict:
+        """What the solves since ``set_option("profile_comm", 1)`` spent in the RCCL transport's halo exchanges and
+        all-reduces, from device timestamps (one-thread stamp kernels between the launches of the compute and the comm
+        stream, csrc/comm.hip): microseconds per exchange / per all-reduce and per iteration."""
+        c = {k: self.counter(k) for k in self.RCCL_PROFILE_KEYS}
+        ne, na, it = max(c["rccl_prof_exchanges"], 1), max(c["rccl_prof_allreduces"], 1), max(iterations, 1)
+        us = 0.01  # ticks of 10 ns
+        return {
+            "transport": "rccl", "iterations_covered": iterations,
+            "halo_exchanges_per_iteration": c["rccl_prof_exchanges"] / it,
+            "allreduces_per_iteration": c["rccl_prof_allreduces"] / it,
+            "event_to_comm_stream_us_each": c["rccl_prof_event_to_comm_ticks"] * us / ne,
+            "pack_us_each": c["rccl_prof_pack_ticks"] * us / ne,
+            "sendrecv_us_each": c["rccl_prof_sendrecv_ticks"] * us / ne,
+            "halo_unhidden_wait_us_each": c["rccl_prof_unhidden_wait_ticks"] * us / ne,
+            "halo_done_to_boundary_rows_us_each": c["rccl_prof_resume_ticks"] * us / ne,
+            "allreduce_us_each": c["rccl_prof_allreduce_ticks"] * us / na,
+            "halo_unhidden_us_per_iteration": (c["rccl_prof_unhidden_wait_ticks"] + c["rccl_prof_resume_ticks"]) * us / it,
+            "allreduce_us_per_iteration": c["rccl_prof_allreduce_ticks"] * us / it,
+            "note": "device timestamps of an INSTRUMENTED solve (a one-thread stamp kernel in front of and behind every step, "
+                    "~2 us each on its stream): event_to_comm_stream = the compute stream has the vector ready -> the comm "
+                    "stream starts (cross-stream event); pack; sendrecv = the grouped ncclSend / ncclRecv; halo_unhidden_wait = "
+                    "the exchange still running when the interior rows had ended; halo_done_to_boundary_rows = exchange and "
+                    "interior rows both done -> the compute stream resumes (the second cross-stream event); allreduce = "
+                    "stamp to stamp around ncclAllReduce on the compute stream.  What an iteration loses to the transport is "
+                    "halo_unhidden_us_per_iteration + allreduce_us_per_iteration (+ the pack kernel where it runs on the "
+                    "compute stream)"}
+
     def spmv_profile(self):
         """(launches, total_ms, min_ms) of the SpMV kernel since the last call (option profile_spmv)."""
         n, tot, mn = C.c_int64(), C.c_double(), C.c_double()

@@ -41,7 +41,20 @@ struct Comm {
   double *pending_x = nullptr;          // generic form of the exchange: the receive half runs in comm_halo_exchange_end
   const double *prebegun = nullptr;     // RCCL: the exchange of THIS vector's halo is in flight already (comm_halo_exchange_begin_formed)
   IpcRecvPlan pending_recv;
+  // RCCL transport, option profile_comm: where an exchange and an all-reduce spend their time, from the device's own clock.
+  // One-thread stamp kernels between the launches of BOTH streams store wall_clock64() (ticks of 10 ns) into these rings --
+  // an instrumented solve, run beside the timed one (every stamp is a launch of its own, ~2 us on its stream).
+  long long *d_prof = nullptr;          // [kProfRing][8] exchanges: A, P, Q, R, B, C, -, - ; then [kProfRing][2] all-reduces: E, F
+  long long prof_ex = 0, prof_ar = 0;   // exchanges / all-reduces stamped since profile_comm was set
+  std::vector<unsigned char> prof_mode; // per exchange: 0 = packed on the comm stream, 1 = packed (formed) on the compute stream
 };
+constexpr int kProfRing = 8192;
+__global__ void comm_stamp_kernel(long long *slot) { *slot = wall_clock64(); }
+static inline void prof_stamp(storm_hip_ctx *c, hipStream_t st, long long idx, int k) {
+  if (idx < 0 || idx >= kProfRing) return;
+  hipLaunchKernelGGL(comm_stamp_kernel, dim3(1), dim3(1), 0, st, c->comm->d_prof + idx * 8 + k);
+}
+static inline bool prof_on(const storm_hip_ctx *c) { return c->opt_profile_comm != 0 && c->comm != nullptr && c->comm->d_prof != nullptr; }
 
 static int host_stage(storm_hip_ctx *c, int64_t len) {
   Comm *cm = c->comm;
@@ -156,7 +169,14 @@ int comm_allreduce_sum(storm_hip_ctx *c, double *d_buf, int count) {
     return STORM_HIP_OK;
   }
   STORM_REQUIRE(c->comm && c->comm->red, "all-reduce without an initialised communicator");
+  const bool prof = prof_on(c) && c->comm->prof_ar < kProfRing;
+  long long *ar = prof ? c->comm->d_prof + (size_t)kProfRing * 8 + c->comm->prof_ar * 2 : nullptr;
+  if (prof) hipLaunchKernelGGL(comm_stamp_kernel, dim3(1), dim3(1), 0, c->stream, ar);
   NCCL_TRY(ncclAllReduce(d_buf, d_buf, (size_t)count, ncclDouble, ncclSum, c->comm->red, c->stream));
+  if (prof) {
+    hipLaunchKernelGGL(comm_stamp_kernel, dim3(1), dim3(1), 0, c->stream, ar + 1);
+    ++c->comm->prof_ar;
+  }
   return STORM_HIP_OK;
 }
 
@@ -259,8 +279,11 @@ int comm_halo_exchange_begin(const storm_hip_op *op, double *x) {
     if (mine) return STORM_HIP_OK;
   }
   // x must be complete before it is packed
+  const long long pe = prof_on(c) ? c->comm->prof_ex++ : -1;
+  if (pe >= 0) c->comm->prof_mode.push_back(0), prof_stamp(c, c->stream, pe, 0);
   HIP_TRY(hipEventRecord(c->ev_x_ready, c->stream));
   HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_x_ready, 0));
+  if (pe >= 0) prof_stamp(c, c->comm_stream, pe, 1);
   if (h.n_send > 0) {
     const int64_t need = (h.n_send + kBlock - 1) / kBlock;
     const int nb = (int)(need > 1024 ? 1024 : need);
@@ -268,6 +291,7 @@ int comm_halo_exchange_begin(const storm_hip_op *op, double *x) {
                        h.d_sendbuf);
     HIP_TRY(hipGetLastError());
   }
+  if (pe >= 0) prof_stamp(c, c->comm_stream, pe, 2);
   NCCL_TRY(ncclGroupStart());
   for (int q = 0; q < h.n_nbrs; ++q) {
     const int64_t ns = h.send_ptr[q + 1] - h.send_ptr[q], nr = h.recv_ptr[q + 1] - h.recv_ptr[q];
@@ -279,6 +303,7 @@ int comm_halo_exchange_begin(const storm_hip_op *op, double *x) {
                         c->comm_stream));
   }
   NCCL_TRY(ncclGroupEnd());
+  if (pe >= 0) prof_stamp(c, c->comm_stream, pe, 3);
   HIP_TRY(hipEventRecord(c->ev_halo_done, c->comm_stream));
   return STORM_HIP_OK;
 }
@@ -294,14 +319,18 @@ int comm_halo_exchange_begin_direction(const storm_hip_op *op, const double *p, 
   storm_hip_ctx *c = op->ctx;
   const HaloPlan &h = op->halo;
   STORM_REQUIRE(comm_is_rccl(c) && h.n_nbrs > 0, "fused exchange: needs the RCCL transport and a halo plan");
+  const long long pe = prof_on(c) ? c->comm->prof_ex++ : -1;
+  if (pe >= 0) c->comm->prof_mode.push_back(0), prof_stamp(c, c->stream, pe, 0);
   HIP_TRY(hipEventRecord(c->ev_x_ready, c->stream));  // beta of the ending iteration is in the slab, r and p are complete
   HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_x_ready, 0));
+  if (pe >= 0) prof_stamp(c, c->comm_stream, pe, 1);
   if (h.n_send > 0) {
     const int64_t need = (h.n_send + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(halo_pack_direction_kernel, dim3((int)(need > 1024 ? 1024 : need)), dim3(kBlock), 0, c->comm_stream, h.n_send,
                        h.d_send_idx, p, r, cb, h.d_sendbuf);
     HIP_TRY(hipGetLastError());
   }
+  if (pe >= 0) prof_stamp(c, c->comm_stream, pe, 2);
   NCCL_TRY(ncclGroupStart());
   for (int q = 0; q < h.n_nbrs; ++q) {
     const int64_t ns = h.send_ptr[q + 1] - h.send_ptr[q], nr = h.recv_ptr[q + 1] - h.recv_ptr[q];
@@ -311,6 +340,7 @@ int comm_halo_exchange_begin_direction(const storm_hip_op *op, const double *p, 
       NCCL_TRY(ncclRecv(p_out + op->n_rows + h.recv_ptr[q], (size_t)nr, ncclDouble, h.nbr_rank[q], c->comm->halo, c->comm_stream));
   }
   NCCL_TRY(ncclGroupEnd());
+  if (pe >= 0) prof_stamp(c, c->comm_stream, pe, 3);
   HIP_TRY(hipEventRecord(c->ev_halo_done, c->comm_stream));
   return STORM_HIP_OK;
 }
@@ -337,6 +367,8 @@ int comm_halo_exchange_begin_formed(const storm_hip_op *op, int mode, const doub
   storm_hip_ctx *c = op->ctx;
   const HaloPlan &h = op->halo;
   STORM_REQUIRE(comm_is_rccl(c) && h.n_nbrs > 0, "formed exchange: needs the RCCL transport and a halo plan");
+  const long long pe = prof_on(c) ? c->comm->prof_ex++ : -1;
+  if (pe >= 0) c->comm->prof_mode.push_back(1), prof_stamp(c, c->stream, pe, 0);
   if (h.n_send > 0) {
     const int64_t need = (h.n_send + kBlock - 1) / kBlock;
     const dim3 grid((int)(need > 1024 ? 1024 : need));
@@ -345,8 +377,10 @@ int comm_halo_exchange_begin_formed(const storm_hip_op *op, int mode, const doub
     else hipLaunchKernelGGL(halo_pack_bicg_kernel<2>, grid, dim3(kBlock), 0, c->stream, h.n_send, h.d_send_idx, r, p, v, sa, sb, h.d_sendbuf);
     HIP_TRY(hipGetLastError());
   }
+  if (pe >= 0) prof_stamp(c, c->stream, pe, 2);
   HIP_TRY(hipEventRecord(c->ev_x_ready, c->stream));  // the rows to send are packed
   HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_x_ready, 0));
+  if (pe >= 0) prof_stamp(c, c->comm_stream, pe, 1);
   NCCL_TRY(ncclGroupStart());
   for (int q = 0; q < h.n_nbrs; ++q) {
     const int64_t ns = h.send_ptr[q + 1] - h.send_ptr[q], nr = h.recv_ptr[q + 1] - h.recv_ptr[q];
@@ -354,6 +388,7 @@ int comm_halo_exchange_begin_formed(const storm_hip_op *op, int mode, const doub
     if (nr > 0) NCCL_TRY(ncclRecv(target + op->n_rows + h.recv_ptr[q], (size_t)nr, ncclDouble, h.nbr_rank[q], c->comm->halo, c->comm_stream));
   }
   NCCL_TRY(ncclGroupEnd());
+  if (pe >= 0) prof_stamp(c, c->comm_stream, pe, 3);
   HIP_TRY(hipEventRecord(c->ev_halo_done, c->comm_stream));
   c->comm->prebegun = target;
   return STORM_HIP_OK;
@@ -378,8 +413,56 @@ int comm_halo_exchange_end(const storm_hip_op *op) {
     c->comm->pending_x = nullptr;
     return comm_ipc_recv_copy(op, x, ipc_dev(c), c->comm->pending_recv);
   }
+  const long long pe = prof_on(c) ? c->comm->prof_ex - 1 : -1;  // (the exchange begun last is the one this launch waits for)
+  if (pe >= 0) prof_stamp(c, c->stream, pe, 4);
   HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_halo_done, 0));
+  if (pe >= 0) prof_stamp(c, c->stream, pe, 5);
   return STORM_HIP_OK;
+}
+
+// Option profile_comm: (re)start the RCCL-path profile / read it.  Sums of ticks (10 ns) over the stamped exchanges and
+// all-reduces: k = 0 exchanges, 1 cross-stream event in front of the exchange (compute stream ready -> comm stream runs),
+// 2 pack, 3 send/recv, 4 the halo still in flight when the interior rows had ended (the un-hidden part), 5 both done ->
+// the compute stream resumes (the second cross-stream event), 6 all-reduces, 7 all-reduce ticks (stamp to stamp).
+int comm_profile_reset(storm_hip_ctx *c) {
+  if (c->comm == nullptr || !comm_is_rccl(c)) return STORM_HIP_OK;
+  const size_t bytes = sizeof(long long) * ((size_t)kProfRing * 8 + (size_t)kProfRing * 2);
+  if (c->comm->d_prof == nullptr) HIP_TRY(hipMalloc((void **)&c->comm->d_prof, bytes));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipStreamSynchronize(c->comm_stream));
+  HIP_TRY(hipMemset(c->comm->d_prof, 0, bytes));
+  c->comm->prof_ex = c->comm->prof_ar = 0;
+  c->comm->prof_mode.clear();
+  return STORM_HIP_OK;
+}
+long long comm_profile_read(storm_hip_ctx *c, int k) {
+  if (c->comm == nullptr || c->comm->d_prof == nullptr || k < 0 || k > 7) return -1;
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipStreamSynchronize(c->comm_stream);
+  const long long n_ex = std::min<long long>(c->comm->prof_ex, kProfRing), n_ar = std::min<long long>(c->comm->prof_ar, kProfRing);
+  if (k == 0) return n_ex;
+  if (k == 6) return n_ar;
+  std::vector<long long> h((size_t)kProfRing * 10);
+  if (hipMemcpy(h.data(), c->comm->d_prof, sizeof(long long) * h.size(), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  long long sum = 0;
+  if (k == 7) {
+    for (long long i = 0; i < n_ar; ++i) sum += h[(size_t)kProfRing * 8 + (size_t)i * 2 + 1] - h[(size_t)kProfRing * 8 + (size_t)i * 2];
+    return sum;
+  }
+  for (long long i = 0; i < n_ex; ++i) {
+    const long long *e = h.data() + (size_t)i * 8;
+    const long long A = e[0], P = e[1], Q = e[2], R = e[3], B = e[4], C = e[5];
+    const bool formed = c->comm->prof_mode[(size_t)i] != 0;
+    if (A == 0 || P == 0 || Q == 0 || R == 0) continue;
+    if (k == 1) sum += formed ? P - Q : P - A;
+    else if (k == 2) sum += formed ? Q - A : Q - P;
+    else if (k == 3) sum += formed ? R - P : R - Q;
+    else if (B != 0 && C != 0) {
+      if (k == 4) sum += std::max<long long>(0, R - B);
+      else if (k == 5) sum += C - std::max(R, B);
+    }
+  }
+  return sum;
 }
 
 
@@ -456,6 +539,7 @@ void comm_destroy(storm_hip_ctx *c) {
   if (c->comm->red && c->comm->red != c->comm->halo) (void)ncclCommDestroy(c->comm->red);
   if (c->comm->halo) (void)ncclCommDestroy(c->comm->halo);
   if (c->comm->h_stage) (void)hipHostFree(c->comm->h_stage);
+  if (c->comm->d_prof) (void)hipFree(c->comm->d_prof);
   if (c->comm->ipc || c->comm->win_local) {
     (void)hipDeviceSynchronize();
     for (int q = 0; q < (int)c->comm->win_peer.size(); ++q)

@@ -166,6 +166,7 @@ struct storm_hip_ctx {
   int64_t opt_spmv_mixed = 1;        // partitioned operators: format 4 for the groups that read no halo column, format 3 for the rest
   int64_t opt_spmv_nt_y = 0;         // format-4 kernels: store y non-temporally (A/B knob; until round 4 the compiler merged both paths into the plain store -- store_y, spmv_device.hpp -- so 0 is what every earlier number was measured with; 256^3 CG: 4 300 it/s with 1, 4 190 - 4 470 with 0)
   int64_t opt_profile_spmv = 0;
+  int64_t opt_profile_comm = 0;       // RCCL transport: stamp kernels around the halo exchange and the all-reduces (comm.hip comm_profile_*)
   int64_t opt_blas1_nt = 1;  // non-temporal loads/stores in the streaming kernels: 0 never, 1 for vectors of at least blas1_nt_rows rows, 2 always
   int64_t opt_blas1_nt_rows = (int64_t)6 << 20;  // (48 MiB per vector: beyond, a solver's vectors no longer stay in the 256 MiB Infinity Cache between kernels)
   int64_t opt_graph = 0;     // replay CG / BiCGStab iterations from a captured hipGraph: measured slower than eager launches (profiles/r01_notes.md), off
@@ -479,6 +480,8 @@ struct IpcRecvPlan;
 bool comm_ipc_next(storm_hip_ctx *c, IpcDev *w);  // the window view for a kernel that all-reduces itself
 bool comm_is_ipc(const storm_hip_ctx *c);
 long long comm_ipc_stat(storm_hip_ctx *c, int k);
+int comm_profile_reset(storm_hip_ctx *c);           // option profile_comm (RCCL transport)
+long long comm_profile_read(storm_hip_ctx *c, int k);
 int comm_ipc_exchange(const storm_hip_op *op, IpcDev *w, IpcSendPlan *sp, IpcRecvPlan *rp);
 int comm_ipc_send(const storm_hip_op *op, const double *x, const IpcDev &w, const IpcSendPlan &sp);
 int comm_ipc_recv_copy(const storm_hip_op *op, double *x, const IpcDev &w, const IpcRecvPlan &rp);

@@ -211,6 +211,10 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   }
   else if (!strcmp(key, "spmv_spw")) c->opt_spmv_spw = value;
   else if (!strcmp(key, "profile_spmv")) c->opt_profile_spmv = value;
+  else if (!strcmp(key, "profile_comm")) {
+    c->opt_profile_comm = value;
+    if (value != 0) STORM_TRY(comm_profile_reset(c));
+  }
   else if (!strcmp(key, "fuse_dot")) c->opt_fuse_dot = value;
   else if (!strcmp(key, "fold_pz")) c->opt_fold_pz = value;
   else if (!strcmp(key, "cg_fuse")) c->opt_cg_fuse = value;
@@ -245,6 +249,19 @@ int storm_hip_ctx_get_counter(storm_hip_ctx *c, const char *key, int64_t *value)
     STORM_REQUIRE(k >= 0, "ctx_get_counter: unknown key '%s'", key);
     const long long v = comm_ipc_stat(c, k);
     STORM_REQUIRE(v >= 0, "ctx_get_counter: '%s' needs the peer-window transport", key);
+    *value = v;
+  }
+  else if (!strncmp(key, "rccl_prof_", 10)) {
+    // option profile_comm on the RCCL transport (csrc/comm.hip): sums over the stamped exchanges / all-reduces, ticks of 10 ns
+    static const char *names[8] = {"rccl_prof_exchanges", "rccl_prof_event_to_comm_ticks", "rccl_prof_pack_ticks",
+                                   "rccl_prof_sendrecv_ticks", "rccl_prof_unhidden_wait_ticks", "rccl_prof_resume_ticks",
+                                   "rccl_prof_allreduces", "rccl_prof_allreduce_ticks"};
+    int k = -1;
+    for (int i = 0; i < 8; ++i)
+      if (!strcmp(key, names[i])) k = i;
+    STORM_REQUIRE(k >= 0, "ctx_get_counter: unknown key '%s'", key);
+    const long long v = comm_profile_read(c, k);
+    STORM_REQUIRE(v >= 0, "ctx_get_counter: '%s' needs the RCCL transport with option profile_comm = 1", key);
     *value = v;
   }
   else if (!strncmp(key, "resident_phase_max_", 19) || !strncmp(key, "resident_phase_mean_", 20)) {

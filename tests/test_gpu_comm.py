@@ -109,6 +109,42 @@ def test_solvers_through_the_comm_path(setup, kind, tol):
     assert np.linalg.norm(x.to_numpy() - ref.x) <= tol * np.linalg.norm(ref.x)
 
 
+@pytest.mark.parametrize("kind", ["cg", "bicgstab"])
+def test_rccl_comm_breakdown_on_the_size_one_communicator(setup, kind):
+    """Option profile_comm: device timestamps around every step of the RCCL transport's halo exchange and all-reduces
+    (csrc/comm.hip) -- the `comm_breakdown` of an N > 1 bench line on this transport (bench.py).  On the size-1
+    communicator every key must be there, the counts must be those of the loop, and the times plausible."""
+    api, ctx, loc, mat, ref_apply, oracle = setup
+    K = 40
+    b = api.DeviceVector(ctx, loc.n_cells, loc.n_halo)
+    api.fill_with(b, 1.0)
+    s = (api.CgSolver if kind == "cg" else api.BiCgStabSolver)()
+    s.num_iterations, s.absolute_error_tolerance, s.relative_error_tolerance = K, 0.0, 0.0
+    x = api.DeviceVector(ctx, loc.n_cells, loc.n_halo)
+    s.solve(x, b, api.HipStencilOperator(mat, -1.0, 0.05))
+    plain = x.to_numpy()
+    ctx.set_option("profile_comm", 1)
+    x2 = api.DeviceVector(ctx, loc.n_cells, loc.n_halo)
+    s.solve(x2, b, api.HipStencilOperator(mat, -1.0, 0.05))
+    bd = ctx.rccl_profile(K)
+    ctx.set_option("profile_comm", 0)
+    assert np.array_equal(x2.to_numpy(), plain)  # the stamps change no value
+    for k in ("transport", "iterations_covered", "halo_exchanges_per_iteration", "allreduces_per_iteration",
+              "event_to_comm_stream_us_each", "pack_us_each", "sendrecv_us_each", "halo_unhidden_wait_us_each",
+              "halo_done_to_boundary_rows_us_each", "allreduce_us_each", "halo_unhidden_us_per_iteration",
+              "allreduce_us_per_iteration", "note"):
+        assert k in bd, k
+    applies = 1 if kind == "cg" else 2
+    assert abs(bd["halo_exchanges_per_iteration"] - applies) <= 3.0 / K  # (+ the initial residual's apply)
+    # SURVEY 8e: CG 1 + 1 all-reduces per iteration; BiCGStab's five reductions batched to 3 calls
+    assert (1.9 if kind == "cg" else 2.9) <= bd["allreduces_per_iteration"] <= (2.2 if kind == "cg" else 3.2), bd
+    for k in ("event_to_comm_stream_us_each", "pack_us_each", "sendrecv_us_each", "halo_done_to_boundary_rows_us_each", "allreduce_us_each"):
+        assert 0.0 < bd[k] < 500.0, (k, bd[k])
+    assert bd["halo_unhidden_wait_us_each"] >= 0.0
+    with pytest.raises(api._lib.StormHipError):
+        api.Context(0).counter("rccl_prof_exchanges")  # needs the transport and the option
+
+
 def test_gmres_cgs2_through_the_comm_path(setup):
     api, ctx, loc, mat, ref_apply, oracle = setup
     b_host = np.ones(loc.n_cells)

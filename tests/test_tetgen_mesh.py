@@ -234,3 +234,41 @@ def test_hip_bicgstab_and_gmres_on_a_tetrahedral_mesh():
         assert ref.converged and abs(s.iteration - ref.iterations) <= max(2, int(tol * ref.iterations)), (kind, s.iteration, ref.iterations)
         assert np.linalg.norm(x.to_numpy() - ref.x) <= 5e-6 * np.linalg.norm(ref.x)
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_c_driver_partitions_and_solves_without_python(ranks, tmp_path):
+    """tests/c/abi_two_ranks.c: TetGen files -> storm_hip_mesh_read_tetgen -> storm_hip_partition_rcb ->
+    storm_hip_mesh_partition -> storm_hip_ctx_comm_init_host over pipes -> CG; against the same solve on one rank (in
+    the driver) and against the oracle (here)."""
+    import json
+    import subprocess
+
+    exe = os.path.join(ROOT, "tests", "c", "abi_two_ranks")
+    pos, bf, lab, cells = _box(8)
+    io_tetgen.write_tetgen(str(tmp_path / "box.1"), pos, bf, lab, cells)
+    p = subprocess.run([exe, str(tmp_path / "box.1"), "3", str(ranks)], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0, p.stdout + p.stderr
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    g = io_tetgen.face_graph_from_simplices(pos, bf, lab, cells)
+    ref = oracle.solve("cg", oracle.StencilOperator(g, -1.0, 0.0), np.ones(g.n_cells))
+    assert out["ranks"] == ranks and out["cells"] == g.n_cells and out["converged"] == 1
+    assert 0 < out["halo_rank0"] < out["owned_rank0"] and out["nbrs_rank0"] >= 1
+    assert abs(out["iterations"] - ref.iterations) <= max(2, int(0.02 * ref.iterations))
+    assert out["solution_rel_diff"] <= 1e-8
+    assert abs(out["x_norm2"] - np.linalg.norm(ref.x)) <= 1e-8 * np.linalg.norm(ref.x)
+
+
+@pytest.mark.gpu
+def test_c_driver_on_the_reference_2d_mesh(golden):
+    import json
+    import subprocess
+
+    u = golden["baseline_md_probe"]["unstructured"]
+    exe = os.path.join(ROOT, "tests", "c", "abi_two_ranks")
+    p = subprocess.run([exe, os.path.join(ROOT, u["mesh"]), "2", "2"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["cells"] == u["n_cells"] and out["converged"] == 1 and out["solution_rel_diff"] <= 1e-8

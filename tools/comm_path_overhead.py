@@ -69,6 +69,17 @@ for transport in ((only,) if only else ("rccl", "ipc", "ipc0")):
         out[f"{key}_it_per_s"] = rate(ctx, m1, loc)
         out["interior_groups"], out["groups"], out[f"{key}_paired_rows"] = st["n_interior_slices"], st["n_slices"], st["paired_rows"]
         out[f"{key}_tiled_planes"] = st["tiled_planes"]
+        if transport == "rccl":  # where the RCCL path's time goes, by device timestamps (an instrumented solve)
+            ctx.set_option("profile_comm", 1)
+            rate_iters = iters
+            b_ = api.DeviceVector(ctx, loc.n_cells, loc.n_halo)
+            api.fill_with(b_, 1.0)
+            s_ = api.BiCgStabSolver() if solver == "bicgstab" else api.CgSolver()
+            s_.num_iterations, s_.absolute_error_tolerance, s_.relative_error_tolerance = rate_iters, 0.0, 0.0
+            s_.solve(api.DeviceVector(ctx, loc.n_cells, loc.n_halo), b_, api.HipStencilOperator(m1, -1.0, 0.05))
+            ctx.sync()
+            out[f"{key}_comm_breakdown"] = ctx.rccl_profile(rate_iters)
+            ctx.set_option("profile_comm", 0)
         if not only:
             base = out["plain_fmt4_it_per_s" if mixed else "plain_fmt3_it_per_s"]
             out[f"{key}_overhead_us_per_iteration"] = (1.0 / out[f"{key}_it_per_s"] - 1.0 / base) * 1e6
