@@ -46,8 +46,9 @@ Prints ONE JSON line on rank 0.
 N > 1: every rank process is a SUPERVISOR that never touches the GPU; it starts the measuring rank as a child with
 a wall-clock budget.  The child runs a bounded pre-flight (one halo exchange + one all-reduce on a tiny slab stack,
 checked numerically) before the 256^3 setup.  If any rank's child fails or exceeds the budget, all children are
-killed and a FRESH set starts on the next transport of the chain (rccl -> ipc -> host-staged); the line records
-`transport` and `transport_fallback`.
+killed and a FRESH set starts on the next transport of the chain.  The chain is rccl, ipc, host-staged: RCCL (the
+transport north_star names) and the peer windows are BOTH measured, `value` is the better, `transports_measured` holds
+both; host-staged runs only if neither worked.  The line records `transport`, `transports_measured`, `transport_fallback`.
 """
 from __future__ import annotations
 
@@ -84,14 +85,14 @@ def main() -> int:
                     help="debug: all ranks on device 0 (transport chain ipc,host); exercises the N > 1 code path of this "
                          "script on a one-GPU box -- the rates it prints mean nothing")
     ap.add_argument("--transport", default=None,
-                    help="N > 1: comma-separated chain tried in order, each attempt with FRESH rank processes: rccl (halo "
-                         "send/recv + all-reduce), ipc (the library's peer-window transport: hipIpc-mapped device memory, "
-                         "direct stores over xGMI, rank-ordered all-reduce fused into the reductions' final pass), host "
-                         "(halo planes and scalars staged through host memory over gloo).  Default ipc,rccl,host "
-                         "(--shared-device: ipc,host): the peer-window transport first -- its exchange is fused into the SpMV "
-                         "launches and its all-reduce into the reductions' last block (one rank: +17 us per CG iteration "
-                         "over the single-GPU path, RCCL: +70) -- guarded by the pre-flight before and the post-flight "
-                         "check after the timed region; RCCL next")
+                    help="N > 1: comma-separated chain, each entry run by FRESH rank processes: rccl (halo send/recv + "
+                         "all-reduce over RCCL: the transport BASELINE.json's north_star names), ipc (the library's peer-window "
+                         "transport: hipIpc-mapped device memory, direct stores over xGMI, rank-ordered all-reduce fused into "
+                         "the reductions' final pass), host (halo planes and scalars staged through host memory over gloo).  "
+                         "Default rccl,ipc,host (--shared-device: ipc,host): rccl AND ipc are both measured -- `value` is the "
+                         "better one, `transports_measured` holds both with their comm_breakdown --, each guarded by the "
+                         "pre-flight before and the post-flight check after its timed region; host only if neither worked")
+    ap.add_argument("--one-transport", action="store_true", help="N > 1: stop at the first transport of the chain that works")
     ap.add_argument("--attempt-seconds", default="240,150,150",
                     help="wall-clock budget of the 1st, 2nd, 3rd transport attempt (N > 1)")
     ap.add_argument("--inject-fail", default="", help="test hook: TRANSPORT=hang|exit|wrong|post[:RANK] makes that attempt fail "
@@ -117,7 +118,7 @@ def main() -> int:
     ap.add_argument("--spmv-only", action="store_true", help="run only the stand-alone SpMV block (for a clean rocprofv3 --stats comparison)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
-    chain = [t for t in (args.transport or ("ipc,host" if args.shared_device else "ipc,rccl,host")).split(",") if t]
+    chain = [t for t in (args.transport or ("ipc,host" if args.shared_device else "rccl,ipc,host")).split(",") if t]
     for t in chain:
         if t not in ("rccl", "ipc", "host"):
             ap.error(f"unknown transport {t!r}")
@@ -1150,7 +1151,10 @@ def supervise(args, chain) -> int:
     td.init_process_group("gloo", rank=rank, world_size=world)
     budgets = [float(v) for v in args.attempt_seconds.split(",")]
     fallbacks, line = [], None
+    measured, n_measured = {}, 0  # transport -> parsed line (rank 0 holds the lines, every rank the count)
     for attempt, transport in enumerate(chain):
+        if n_measured and (transport == "host" or args.one_transport):
+            break  # host-staged is a fallback only; --one-transport: the first transport that works
         budget = budgets[min(attempt, len(budgets) - 1)]
         port = torch.zeros(1, dtype=torch.int64)
         if rank == 0:
@@ -1196,7 +1200,11 @@ def supervise(args, chain) -> int:
         except OSError:
             pass
         if reason is None:
-            break
+            n_measured += 1
+            if rank == 0:
+                measured[transport] = json.loads(line)
+            td.barrier()
+            continue  # ... on to the next transport of the chain: both RCCL and the peer windows are measured
         if child.poll() is None:  # end exactly the process group this supervisor started
             try:
                 os.killpg(child.pid, signal.SIGKILL)
@@ -1210,9 +1218,15 @@ def supervise(args, chain) -> int:
                   file=sys.stderr, flush=True)
         line = None
         td.barrier()
-    status = 0 if line is not None or rank != 0 else 1
-    if rank == 0 and line is not None:
-        out = json.loads(line)
+    status = 0 if n_measured else 1
+    if rank == 0 and measured:
+        best = max(measured, key=lambda t: measured[t]["value"])
+        out = measured[best]
+        out["transports_measured"] = {
+            t: {k: m.get(k) for k in ("value", "ms_per_step", "timing", "comm_breakdown", "postflight")} for t, m in measured.items()}
+        out["transport_choice"] = ("`value` / `ms_per_step` are the better of the transports measured in this run (each by fresh rank "
+                                   "processes: rccl = the transport BASELINE.json's north_star names, ipc = the library's "
+                                   "peer windows); `transports_measured` holds every one")
         out["transport_fallback"] = fallbacks
         print(json.dumps(out), flush=True)
     flag = torch.tensor([float(status)], dtype=torch.float64)
@@ -1238,7 +1252,7 @@ def launch_ranks(n_ranks: int, args) -> int:
     env = dict(os.environ)
     env.setdefault("OMP_NUM_THREADS", "1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    n_chain = len((args.transport or ("ipc,host" if args.shared_device else "ipc,rccl,host")).split(","))
+    n_chain = len((args.transport or ("ipc,host" if args.shared_device else "rccl,ipc,host")).split(","))
     budgets = [float(v) for v in args.attempt_seconds.split(",")]
     total = sum(budgets[min(i, len(budgets) - 1)] for i in range(n_chain)) + 120.0
     child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)

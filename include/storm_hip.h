@@ -294,6 +294,15 @@ int storm_hip_op_create_csr(storm_hip_ctx *ctx, int64_t n_rows, int64_t n_halo,
  *              to plane while its weight words do not change; 0 decodes them per plane.  The same bits;
  *   resident_halo_interleave (1): CG on that path, boxes of more than two planes: half of a block's waves form the halo of the
  *              new direction before updating their own rows, half behind it.  The same bits;
+ *   lazy_statements (0): HOST loops -- storm_hip_copy / _scale / _axpy / _xpay / _axpbz and storm_hip_op_apply are not
+ *              launched when called but wait, in program order, for the call that needs their result; two consecutive linear
+ *              statements leave as ONE pass, and a storm_hip_dot / _norm2 over a vector the last waiting statement writes
+ *              rides in that statement's kernel (`x += alpha p; r -= alpha z; <r, r>`: one kernel; `z = A p; <p, z>`: the
+ *              apply with its fused-dot epilogue).  Every other entry point launches what waits first, so nothing is
+ *              observed out of order; nothing waits inside a solver's operator / preconditioner callback.  The
+ *              linear statements and their reductions give the eager kernels' values bit for bit; the apply's fused dot
+ *              sums in the SpMV kernel's order (equal to rounding) (csrc/lazy.hip).  The host loops of Storm.hpp / api.py switch it on for their duration
+ *              (IterativeSolver::lazy_statements);
  *   rccl_fused (1), rccl_ticket (1): RCCL transport -- the fused CG step on a partitioned lattice operator (the boundary
  *              planes of the new direction packed by a small kernel and sent under the marching launch), with the local
  *              sums finished inside the kernels that produce them;
@@ -305,7 +314,9 @@ int storm_hip_ctx_set_option(storm_hip_ctx *ctx, const char *key, int64_t value)
  * reference logs one line per solve, Solver.hpp:144-145).  Keys: "resident_solves" (csrc/resident.hip),
  * "latency_solves" (csrc/latency.hip: one cooperative kernel per solve), "throughput_solves" (a kernel per statement,
  * fused loops of csrc/solvers.hip), "engine_solves" (csrc/krylov.hip), "cg_fused_steps" (solves whose CG step rode in
- * the SpMV launch).  On the peer-window transport, where the time of the exchanges went (ticks of 10 ns of the device's
+ * the SpMV launch), "lazy_fused_dots" / "lazy_fused_pairs" / "lazy_apply_dots" / "lazy_waiting" (option lazy_statements:
+ * reductions that rode in a statement's kernel, pairs of statements that left as one pass, applies that left with a fused
+ * dot, statements waiting now).  On the peer-window transport, where the time of the exchanges went (ticks of 10 ns of the device's
  * real-time counter, and counts): "ipc_allreduce_wait_ticks" / "ipc_allreduces" (from a rank's own contribution being
  * stored to every rank's being read), "ipc_ack_wait_ticks" / "ipc_ack_waits" (a send waiting for the receivers to have
  * consumed the plane two exchanges back), "ipc_halo_slow_poll_ticks" / "ipc_halo_slow_polls" (halo values that had not

@@ -586,6 +586,25 @@ private:
 /// line (e.g. `Storm::set_log_sink([](const std::string& s) { spdlog::info(s); })`); none installed = silent.
 inline void set_log_sink(std::function<void(const std::string&)> sink) { detail::log_sink() = std::move(sink); }
 
+namespace detail {
+/// Option `lazy_statements` on the vector's context for the lifetime of the scope (leaving it launches what still waits).
+struct LazyScope {
+  storm_hip_ctx* ctx = nullptr;
+  template<class V>
+  LazyScope(const V& v, bool on) {
+    if constexpr (std::is_same_v<V, DeviceVector>) {
+      if (on && v.handle() != nullptr && storm_hip_vec_context(v.handle(), &ctx) == STORM_HIP_OK && ctx != nullptr)
+        (void)storm_hip_ctx_set_option(ctx, "lazy_statements", 1);
+    }
+  }
+  ~LazyScope() {
+    if (ctx != nullptr) (void)storm_hip_ctx_set_option(ctx, "lazy_statements", 0);
+  }
+  LazyScope(const LazyScope&) = delete;
+  LazyScope& operator=(const LazyScope&) = delete;
+};
+}  // namespace detail
+
 /// Solvers/Solver.hpp:62-149: the public knobs (names, defaults), the protected stepping hooks and `solve`.
 ///
 /// The solvers this header ships name a library method (`device_method()`); their `solve` is ONE call,
@@ -610,6 +629,12 @@ public:
 
   // extras of this build
   bool device_loop{true};
+  /// The HOST loop (a user-defined solver, or `device_loop = false`) runs with the library's option `lazy_statements`:
+  /// the linear vector statements and operator applies of an `iterate()` body wait for the call that needs their result,
+  /// consecutive statements leave as one pass and a `dot_product` / `norm_2` over a vector the last waiting statement
+  /// writes rides in that statement's kernel (`x += alpha * p; r -= alpha * z; dot_product(r, r)`: ONE kernel).  Same
+  /// values, bit for bit; `false`: every statement is a launch of its own when it is called.
+  bool lazy_statements{true};
   std::size_t num_applies{0}, num_pre_applies{0};  ///< of the last device-loop solve
   int path_fallback{0};  ///< storm_hip_solver_result::path_fallback of the last device-loop solve (0: the chosen path ran)
 
@@ -658,6 +683,7 @@ public:
       }
     }
     // Host loop with the reference's rule: stop on abs_tol > 0 && abs < abs_tol, or rel_tol > 0 && abs / initial < rel_tol.
+    detail::LazyScope lazy(x_vec, lazy_statements);
     const real_t initial_error = init(x_vec, b_vec, any_op, pre_op.get());
     absolute_error = initial_error;
     const auto met = [this](real_t value, real_t tolerance) { return tolerance > 0.0 && value < tolerance; };

@@ -789,6 +789,7 @@ class IterativeSolver(Solver):
         self.num_pre_applies = 0    # preconditioner applications, likewise
         self.initial_error = 0.0
         self.device_loop = True
+        self.lazy_statements = True  # the host loop runs with the library's option of that name (csrc/lazy.hip)
         self._engine: Optional[_Engine] = None
 
     # -- the reference's stepping hooks ------------------------------------------------------
@@ -858,7 +859,19 @@ class IterativeSolver(Solver):
             self.path_fallback = r.path_fallback
             self._log()
             return bool(r.converged)
-        # the host loop: user-defined solvers, and the shipped ones stepwise when device_loop is off
+        # the host loop: user-defined solvers, and the shipped ones stepwise when device_loop is off.  It runs with the
+        # library's option lazy_statements (csrc/lazy.hip): the body's linear statements and applies wait for the call that
+        # needs them, and a reduction over what the last one writes rides in its kernel -- the same values, bit for bit
+        lazy_ctx = x_vec.ctx if (self.lazy_statements and getattr(x_vec, "ctx", None) is not None) else None
+        if lazy_ctx is not None:
+            lazy_ctx.set_option("lazy_statements", 1)
+        try:
+            return self._host_loop(x_vec, b_vec, any_op)
+        finally:
+            if lazy_ctx is not None:
+                lazy_ctx.set_option("lazy_statements", 0)
+
+    def _host_loop(self, x_vec, b_vec, any_op) -> bool:
         initial_error = self.init(x_vec, b_vec, any_op, self.pre_op)
         self.initial_error = self.absolute_error = initial_error
         hist = [initial_error]

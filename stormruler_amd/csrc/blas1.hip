@@ -201,24 +201,6 @@ __device__ __forceinline__ double block_sum(double v, double *lds4) {
   return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
 }
 
-// KB sums at once, ONE pair of barriers: the same wave trees and the same (w0 + w1) + (w2 + w3) as block_sum, so the same
-// bits; sums[j] valid in every thread.
-template <int KB>
-__device__ __forceinline__ void block_sum_multi(const double (&v)[KB], double (*lds)[4], double (&sums)[KB]) {
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-  double w[KB];
-#pragma unroll
-  for (int j = 0; j < KB; ++j) w[j] = wave_sum_down(v[j]);
-  __syncthreads();  // (the buffer may still be read by a previous call)
-  if (lane == 0) {
-#pragma unroll
-    for (int j = 0; j < KB; ++j) lds[j][wave] = w[j];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < KB; ++j) sums[j] = (lds[j][0] + lds[j][1]) + (lds[j][2] + lds[j][3]);
-}
-
 template <int KB>
 __global__ __launch_bounds__(kBlock) void multi_dot_kernel(int64_t n, const double *__restrict__ a,
                                                            DotPtrs bs, double *__restrict__ partials,
@@ -506,39 +488,54 @@ static int finish_reduction(storm_hip_ctx *c, int k, double *out) {
 
 extern "C" {
 
+// option lazy_statements (lazy.hip): linear statements wait for the call that needs them -- outside solver callbacks only
+static inline bool lazy_on(const storm_hip_ctx *c) { return c->opt_lazy != 0 && c->callback_depth == 0 && c->api_done == nullptr; }
+
 int storm_hip_fill(storm_hip_vec *y, double value) {
   STORM_REQUIRE(y, "fill: null vector");
+  STORM_TRY(lazy_sync(y->ctx));
   return launch_ew(y->ctx, y->n_owned, EwPtrs{y->d, nullptr, nullptr}, FillF{value}, y->ctx->api_done);
 }
 
 int storm_hip_copy(storm_hip_vec *y, const storm_hip_vec *x) {
   STORM_TRY(check_pair(y, x, "copy"));
+  if (lazy_on(y->ctx) && y->d != x->d) return lazy_push_lin(y->ctx, y->d, 1.0, x->d, 0.0, nullptr, 1, y->n_owned);
+  STORM_TRY(lazy_sync(y->ctx));
   return k_copy(y->ctx, y->d, x->d, y->n_owned, y->ctx->api_done);
 }
 
 int storm_hip_scale(storm_hip_vec *y, double s) {
   STORM_REQUIRE(y, "scale: null vector");
+  if (lazy_on(y->ctx)) return lazy_push_lin(y->ctx, y->d, s, y->d, 0.0, nullptr, 1, y->n_owned);
+  STORM_TRY(lazy_sync(y->ctx));
   return k_scale(y->ctx, y->d, y->n_owned, host_scal(s), false, nullptr);
 }
 
 int storm_hip_div_scalar(storm_hip_vec *y, double s) {
   STORM_REQUIRE(y, "div_scalar: null vector");
+  STORM_TRY(lazy_sync(y->ctx));
   return k_scale(y->ctx, y->d, y->n_owned, host_scal(s), true, nullptr);
 }
 
 int storm_hip_axpy(storm_hip_vec *y, double a, const storm_hip_vec *x) {
   STORM_TRY(check_pair(y, x, "axpy"));
+  if (lazy_on(y->ctx)) return lazy_push_lin(y->ctx, y->d, a, x->d, 1.0, y->d, 2, y->n_owned);
+  STORM_TRY(lazy_sync(y->ctx));
   return k_axpbz(y->ctx, y->d, host_scal(a), x->d, host_scal(1.0), y->d, y->n_owned, y->ctx->api_done);
 }
 
 int storm_hip_xpay(storm_hip_vec *y, const storm_hip_vec *x, double b) {
   STORM_TRY(check_pair(y, x, "xpay"));
+  if (lazy_on(y->ctx)) return lazy_push_lin(y->ctx, y->d, 1.0, x->d, b, y->d, 2, y->n_owned);
+  STORM_TRY(lazy_sync(y->ctx));
   return k_axpbz(y->ctx, y->d, host_scal(1.0), x->d, host_scal(b), y->d, y->n_owned, y->ctx->api_done);
 }
 
 int storm_hip_axpbz(storm_hip_vec *y, double a, const storm_hip_vec *x, double b, const storm_hip_vec *z) {
   STORM_TRY(check_pair(y, x, "axpbz"));
   STORM_TRY(check_pair(y, z, "axpbz"));
+  if (lazy_on(y->ctx)) return lazy_push_lin(y->ctx, y->d, a, x->d, b, z->d, 2, y->n_owned);
+  STORM_TRY(lazy_sync(y->ctx));
   return k_axpbz(y->ctx, y->d, host_scal(a), x->d, host_scal(b), z->d, y->n_owned, y->ctx->api_done);
 }
 
@@ -547,6 +544,7 @@ int storm_hip_lin3(storm_hip_vec *y, const storm_hip_vec *r, double s, double a,
   STORM_TRY(check_pair(y, r, "lin3"));
   STORM_TRY(check_pair(y, x, "lin3"));
   STORM_TRY(check_pair(y, z, "lin3"));
+  STORM_TRY(lazy_sync(y->ctx));
   if (y->n_owned <= 0) return STORM_HIP_OK;
   storm_hip_ctx *c = y->ctx;
   hipLaunchKernelGGL(lin3_kernel, dim3(stream_blocks(y->n_owned)), dim3(kBlock), 0, c->stream, y->n_owned, y->d,
@@ -558,6 +556,7 @@ int storm_hip_lin3(storm_hip_vec *y, const storm_hip_vec *r, double s, double a,
 int storm_hip_vmul_add(storm_hip_vec *y, double s, const storm_hip_vec *a, const storm_hip_vec *b) {
   STORM_TRY(check_pair(y, a, "vmul_add"));
   STORM_TRY(check_pair(y, b, "vmul_add"));
+  STORM_TRY(lazy_sync(y->ctx));
   if (y->n_owned <= 0) return STORM_HIP_OK;
   return launch_ew(y->ctx, y->n_owned, EwPtrs{y->d, a->d, b->d}, VmulAddF{s}, y->ctx->api_done);
 }
@@ -565,6 +564,7 @@ int storm_hip_vmul_add(storm_hip_vec *y, double s, const storm_hip_vec *a, const
 int storm_hip_vmul(storm_hip_vec *y, const storm_hip_vec *a, const storm_hip_vec *b) {
   STORM_TRY(check_pair(y, a, "vmul"));
   STORM_TRY(check_pair(y, b, "vmul"));
+  STORM_TRY(lazy_sync(y->ctx));
   if (y->n_owned <= 0) return STORM_HIP_OK;
   return launch_ew(y->ctx, y->n_owned, EwPtrs{y->d, a->d, b->d}, VmulF{}, y->ctx->api_done);
 }
@@ -572,6 +572,7 @@ int storm_hip_vmul(storm_hip_vec *y, const storm_hip_vec *a, const storm_hip_vec
 int storm_hip_vdiv(storm_hip_vec *y, double s, const storm_hip_vec *a, const storm_hip_vec *b) {
   STORM_TRY(check_pair(y, b, "vdiv"));
   if (a) STORM_TRY(check_pair(y, a, "vdiv"));
+  STORM_TRY(lazy_sync(y->ctx));
   if (y->n_owned <= 0) return STORM_HIP_OK;
   return launch_ew(y->ctx, y->n_owned, EwPtrs{y->d, a ? a->d : b->d, b->d}, VdivF{s, a ? 1 : 0}, y->ctx->api_done);
 }
@@ -580,6 +581,7 @@ int storm_hip_bicgstab_p(storm_hip_vec *p, const storm_hip_vec *r, double beta, 
                          const storm_hip_vec *v) {
   STORM_TRY(check_pair(p, r, "bicgstab_p"));
   STORM_TRY(check_pair(p, v, "bicgstab_p"));
+  STORM_TRY(lazy_sync(p->ctx));
   return k_bicg_p(p->ctx, p->d, r->d, host_scal(beta), host_scal(omega), v->d, p->n_owned, p->ctx->api_done);
 }
 
@@ -592,6 +594,7 @@ int storm_hip_multi_dot_begin(const storm_hip_vec *a, const storm_hip_vec *const
     ptrs[j] = bs[j]->d;
   }
   storm_hip_ctx *c = a->ctx;
+  STORM_TRY(lazy_sync(c));
   // any free slot (requests may be ended in any order: round 3 derived the slot from the tag, so that eight requests
   // begun and the third ended left "no" slot for the ninth); the request id names its slot
   int s = -1;
@@ -659,6 +662,12 @@ int storm_hip_multi_dot_end(storm_hip_ctx *c, int request, double *out) {
 
 int storm_hip_multi_dot(const storm_hip_vec *a, const storm_hip_vec *const *bs, int k, double *out) {
   STORM_REQUIRE(out, "multi_dot: null argument");
+  if (a && bs && k == 1 && bs[0] && a->ctx == bs[0]->ctx && a->n_owned == bs[0]->n_owned && !a->ctx->lazy_q.empty()) {
+    // statements wait (option lazy_statements): the reduction rides in the kernel of the one that writes its operand
+    int st = STORM_HIP_OK;
+    if (lazy_try_dot(a->ctx, a->d, bs[0]->d, a->n_owned, out, &st)) return st;
+    STORM_TRY(st);
+  }
   int request = 0;
   STORM_TRY(storm_hip_multi_dot_begin(a, bs, k, &request));
   return storm_hip_multi_dot_end(a->ctx, request, out);
@@ -685,6 +694,7 @@ int storm_hip_multi_axpy(storm_hip_vec *y, const double *coefs, const storm_hip_
     STORM_TRY(check_pair(y, xs[j], "multi_axpy"));
     ptrs[j] = xs[j]->d;
   }
+  STORM_TRY(lazy_sync(y->ctx));
   return multi_axpy_impl(y->ctx, y->d, coefs, nullptr, 1.0, ptrs, k, y->n_owned, y->ctx->api_done);
 }
 

@@ -4,6 +4,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "wave_device.hpp"
 
 namespace storm {
 
@@ -29,6 +30,24 @@ template <class Body>
 __device__ __forceinline__ void nt_dispatch(int nt, Body &&body) {  // bit 0 of nt decides (other bits: the caller's)
   if (nt & 1) body(std::true_type{});
   else body(std::false_type{});
+}
+
+// KB sums at once, ONE pair of barriers: the same wave trees and the same (w0 + w1) + (w2 + w3) as block_sum, so the same
+// bits; sums[j] valid in every thread.
+template <int KB>
+__device__ __forceinline__ void block_sum_multi(const double (&v)[KB], double (*lds)[4], double (&sums)[KB]) {
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  double w[KB];
+#pragma unroll
+  for (int j = 0; j < KB; ++j) w[j] = wave_sum_down(v[j]);
+  __syncthreads();  // (the buffer may still be read by a previous call)
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < KB; ++j) lds[j][wave] = w[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < KB; ++j) sums[j] = (lds[j][0] + lds[j][1]) + (lds[j][2] + lds[j][3]);
 }
 
 constexpr int kDotChunk = 8;

@@ -82,6 +82,19 @@ __host__ __device__ inline unsigned long long ring_word(unsigned long long gen, 
 
 struct Comm;  // comm.hip
 
+// lazy.hip -- a vector statement / an operator apply whose launch is held back (option lazy_statements)
+struct LazyStmt {
+  int kind = 0;              // 0: y = c0 v0 [+ c1 v1] over n rows; 1: y = beta x + alpha M(x)
+  double *y = nullptr;
+  const double *v[2] = {nullptr, nullptr};
+  double c[2] = {0.0, 0.0};
+  int nt = 0;
+  int64_t n = 0;
+  const storm_hip_op *op = nullptr;
+  double alpha = 0.0, beta = 0.0;
+  const double *x = nullptr;
+};
+
 // What a storm_hip_krylov object owns on the device and in pinned host memory; a destroyed engine leaves it with its
 // context (storm_hip_ctx::krylov_free) for the next one: creating a solver object per solve -- the reference's usage,
 // Playground.cpp:199-202 -- then costs no allocation (two pinned allocations, a device one and a blocking memset were
@@ -166,6 +179,10 @@ struct storm_hip_ctx {
   int64_t opt_spmv_mixed = 1;        // partitioned operators: format 4 for the groups that read no halo column, format 3 for the rest
   int64_t opt_spmv_nt_y = 0;         // format-4 kernels: store y non-temporally (A/B knob; until round 4 the compiler merged both paths into the plain store -- store_y, spmv_device.hpp -- so 0 is what every earlier number was measured with; 256^3 CG: 4 300 it/s with 1, 4 190 - 4 470 with 0)
   int64_t opt_profile_spmv = 0;
+  std::vector<storm::LazyStmt> lazy_q;  // held-back statements (lazy.hip), in program order
+  int64_t opt_lazy = 0;                 // option lazy_statements
+  int callback_depth = 0;               // > 0 while a solver is inside an operator / preconditioner callback (nothing waits there)
+  int64_t n_lazy_fused_dots = 0, n_lazy_fused_pairs = 0, n_lazy_apply_dots = 0;
   int64_t opt_profile_comm = 0;       // RCCL transport: stamp kernels around the halo exchange and the all-reduces (comm.hip comm_profile_*)
   int64_t opt_blas1_nt = 1;  // non-temporal loads/stores in the streaming kernels: 0 never, 1 for vectors of at least blas1_nt_rows rows, 2 always
   int64_t opt_blas1_nt_rows = (int64_t)6 << 20;  // (48 MiB per vector: beyond, a solver's vectors no longer stay in the 256 MiB Infinity Cache between kernels)
@@ -461,6 +478,13 @@ int bicgstab_latency_solve(const storm_hip_op *op, double alpha, double beta, co
 bool res_eligible(const storm_hip_op *op, bool bicgstab);
 int res_solve(bool bicgstab, const storm_hip_op *op, double alpha, double beta, const double *b, double *x, double *rt,
               SolverState *d_state, bool *taken);
+
+// lazy.hip
+int lazy_flush(storm_hip_ctx *c);  // launch whatever is held back (a no-op when nothing is)
+static inline int lazy_sync(storm_hip_ctx *c) { return (c != nullptr && !c->lazy_q.empty()) ? lazy_flush(c) : 0; }
+int lazy_push_lin(storm_hip_ctx *c, double *y, double c0, const double *v0, double c1, const double *v1, int nt, int64_t n);
+int lazy_push_apply(const storm_hip_op *op, double alpha, double beta, const double *x, double *y);
+bool lazy_try_dot(storm_hip_ctx *c, const double *a, const double *b, int64_t n, double *result, int *status);
 
 // comm.hip
 int comm_allreduce_sum(storm_hip_ctx *c, double *d_buf, int count);  // in place, on ctx->stream

@@ -85,6 +85,7 @@ int storm_hip_ctx_create(int device_id, storm_hip_ctx **out) {
 int storm_hip_ctx_destroy(storm_hip_ctx *c) {
   if (!c) return STORM_HIP_OK;
   (void)hipSetDevice(c->device);
+  c->lazy_q.clear();  // (statements nobody asked the result of)
   (void)hipDeviceSynchronize();
   comm_destroy(c);
   for (auto &ev : c->ev_ring) (void)hipEventDestroy(ev);
@@ -125,6 +126,7 @@ int storm_hip_ctx_destroy(storm_hip_ctx *c) {
 
 int storm_hip_ctx_sync(storm_hip_ctx *c) {
   STORM_REQUIRE(c, "ctx_sync: null context");
+  STORM_TRY(lazy_sync(c));
   HIP_TRY(hipStreamSynchronize(c->comm_stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return comm_check_error(c);
@@ -210,6 +212,10 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
     }
   }
   else if (!strcmp(key, "spmv_spw")) c->opt_spmv_spw = value;
+  else if (!strcmp(key, "lazy_statements")) {
+    if (value == 0) STORM_TRY(lazy_sync(c));
+    c->opt_lazy = value;
+  }
   else if (!strcmp(key, "profile_spmv")) c->opt_profile_spmv = value;
   else if (!strcmp(key, "profile_comm")) {
     c->opt_profile_comm = value;
@@ -239,6 +245,10 @@ int storm_hip_ctx_get_counter(storm_hip_ctx *c, const char *key, int64_t *value)
   else if (!strcmp(key, "throughput_solves")) *value = c->n_throughput_solves;
   else if (!strcmp(key, "engine_solves")) *value = c->n_engine_solves;
   else if (!strcmp(key, "cg_fused_steps")) *value = c->n_cg_fused_steps;
+  else if (!strcmp(key, "lazy_fused_dots")) *value = c->n_lazy_fused_dots;
+  else if (!strcmp(key, "lazy_fused_pairs")) *value = c->n_lazy_fused_pairs;
+  else if (!strcmp(key, "lazy_apply_dots")) *value = c->n_lazy_apply_dots;
+  else if (!strcmp(key, "lazy_waiting")) *value = (int64_t)c->lazy_q.size();
   else if (!strncmp(key, "ipc_", 4)) {
     // the peer-window transport's device-side waits (csrc/ipc_device.hpp IpcDev::stat): ticks of 10 ns and counts
     static const char *names[6] = {"ipc_allreduce_wait_ticks", "ipc_allreduces", "ipc_ack_wait_ticks", "ipc_ack_waits",
@@ -322,12 +332,14 @@ int storm_hip_ctx_get_spmv_profile_samples(storm_hip_ctx *c, double *ms_out, int
 
 int storm_hip_timer_start(storm_hip_ctx *c) {
   STORM_REQUIRE(c, "timer_start: null context");
+  STORM_TRY(lazy_sync(c));
   HIP_TRY(hipEventRecord(c->ev_t0, c->stream));
   return STORM_HIP_OK;
 }
 
 int storm_hip_timer_stop(storm_hip_ctx *c, float *elapsed_ms) {
   STORM_REQUIRE(c && elapsed_ms, "timer_stop: null argument");
+  STORM_TRY(lazy_sync(c));
   HIP_TRY(hipEventRecord(c->ev_t1, c->stream));
   HIP_TRY(hipEventSynchronize(c->ev_t1));
   HIP_TRY(hipEventElapsedTime(elapsed_ms, c->ev_t0, c->ev_t1));
@@ -627,6 +639,7 @@ int storm_hip_vec_create_like(const storm_hip_vec *other, storm_hip_vec **out) {
 int storm_hip_vec_destroy(storm_hip_vec *v) {
   if (!v) return STORM_HIP_OK;
   storm_hip_ctx *c = v->ctx;
+  (void)lazy_sync(c);  // (a waiting statement may read or write this storage)
   if (v->base && ((int64_t)(c->pool_bytes + v->bytes) <= c->opt_pool_bytes || in_arena(c, v->base))) {
     // later users of this storage are ordered behind its pending kernels by the compute stream; the
     // comm stream only touches a vector between two events of one SpMV (comm.hip)
@@ -651,6 +664,7 @@ int storm_hip_vec_upload(storm_hip_vec *v, const double *host, int64_t n) {
   STORM_REQUIRE(v && (host || n == 0), "vec_upload: null argument");
   STORM_REQUIRE(n == v->n_owned, "vec_upload: %lld values for a vector of %lld owned rows",
                 (long long)n, (long long)v->n_owned);
+  STORM_TRY(lazy_sync(v->ctx));
   HIP_TRY(hipMemcpyAsync(v->d, host, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, v->ctx->stream));
   HIP_TRY(hipStreamSynchronize(v->ctx->stream));
   return STORM_HIP_OK;
@@ -661,6 +675,7 @@ int storm_hip_vec_download(const storm_hip_vec *v, double *host, int64_t n) {
   STORM_REQUIRE(n == v->n_owned || n == v->n_owned + v->n_halo,
                 "vec_download: %lld values requested from a vector of %lld(+%lld) rows", (long long)n,
                 (long long)v->n_owned, (long long)v->n_halo);
+  STORM_TRY(lazy_sync(v->ctx));
   HIP_TRY(hipMemcpyAsync(host, v->d, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, v->ctx->stream));
   HIP_TRY(hipStreamSynchronize(v->ctx->stream));
   return STORM_HIP_OK;
@@ -684,6 +699,7 @@ int storm_hip_fill_randomly(storm_hip_vec *v) {
 
 int storm_hip_vec_device_ptr(storm_hip_vec *v, void **dev_ptr) {
   STORM_REQUIRE(v && dev_ptr, "vec_device_ptr: null argument");
+  STORM_TRY(lazy_sync(v->ctx));  // (the caller is about to touch the memory itself)
   *dev_ptr = v->d;
   return STORM_HIP_OK;
 }
@@ -699,6 +715,7 @@ int storm_hip_vec_get(const storm_hip_vec *v, int64_t row, double *value) {
   STORM_REQUIRE(row >= 0 && row < v->n_owned + v->n_halo, "vec_get: row %lld outside [0, %lld)", (long long)row,
                 (long long)(v->n_owned + v->n_halo));
   HIP_TRY(hipSetDevice(v->ctx->device));
+  STORM_TRY(lazy_sync(v->ctx));
   HIP_TRY(hipMemcpyAsync(value, v->d + row, sizeof(double), hipMemcpyDeviceToHost, v->ctx->stream));
   HIP_TRY(hipStreamSynchronize(v->ctx->stream));
   return STORM_HIP_OK;

@@ -1072,8 +1072,8 @@ struct KrylovEngine {
   struct ApiDone {  // library calls a callback makes are predicated on this solve's flag
     storm_hip_ctx *c;
     const int *saved;
-    ApiDone(storm_hip_ctx *c_, const int *dp_) : c(c_), saved(c_->api_done) { c->api_done = dp_; }
-    ~ApiDone() { c->api_done = saved; }
+    ApiDone(storm_hip_ctx *c_, const int *dp_) : c(c_), saved(c_->api_done) { c->api_done = dp_, ++c->callback_depth; }
+    ~ApiDone() { c->api_done = saved, --c->callback_depth; }
   };
   void apply(V yv, const storm_hip_vec *xv) {  // y = A(x)          Operator::mul, Operator.hpp:74
     flush();
@@ -1892,6 +1892,7 @@ int storm_hip_krylov_solve(storm_hip_krylov *k, const storm_hip_vec *b, storm_hi
                            const storm_hip_solver_params *params, storm_hip_solver_result *result, double *history,
                            int64_t *pre_applies) {
   STORM_REQUIRE(k && result, "krylov_solve: null argument");
+  STORM_TRY(lazy_sync(k->c));
   STORM_TRY(check_ready(k, b, x, params));
   storm_hip_ctx *c = k->c;
   HIP_TRY(hipSetDevice(c->device));
@@ -1967,6 +1968,7 @@ static int krylov_solve_engine(storm_hip_krylov *k, const storm_hip_vec *b, stor
 int storm_hip_krylov_init(storm_hip_krylov *k, const storm_hip_vec *b, storm_hip_vec *x,
                           const storm_hip_solver_params *params, double *initial_error) {
   STORM_REQUIRE(k && initial_error, "krylov_init: null argument");
+  STORM_TRY(lazy_sync(k->c));
   int st = begin_solve(k, b, x, params, true, nullptr);
   if (st == STORM_HIP_OK) st = read_state(k);
   if (st != STORM_HIP_OK) {
@@ -1981,6 +1983,7 @@ int storm_hip_krylov_iterate(storm_hip_krylov *k, double *error) {
   STORM_REQUIRE(k && error, "krylov_iterate: null argument");
   STORM_REQUIRE(k->active && k->stepping, "krylov_iterate: no storm_hip_krylov_init before");
   HIP_TRY(hipSetDevice(k->c->device));
+  STORM_TRY(lazy_sync(k->c));
   k->iterate(k->it_enqueued);
   if (!k->ok()) return k->status;
   k->it_enqueued += 1;
@@ -1993,6 +1996,7 @@ int storm_hip_krylov_finalize(storm_hip_krylov *k) {
   STORM_REQUIRE(k, "krylov_finalize: null solver");
   STORM_REQUIRE(k->active && k->stepping, "krylov_finalize: no storm_hip_krylov_init before");
   HIP_TRY(hipSetDevice(k->c->device));
+  STORM_TRY(lazy_sync(k->c));
   k->finalize(k->it_enqueued, false);
   const int st = k->status;
   (void)hipStreamSynchronize(k->c->stream);

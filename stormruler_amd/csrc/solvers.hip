@@ -1678,14 +1678,17 @@ extern "C" {
 
 int storm_hip_solve_cg(const storm_hip_op *op, double alpha, double beta, const storm_hip_vec *b, storm_hip_vec *x,
                        const storm_hip_solver_params *params, storm_hip_solver_result *result, double *history) {
+  if (op) STORM_TRY(lazy_sync(op->ctx));
   return fused_solve(FusedSolveArgs{op, alpha, beta, b, x, params, result, history, &solve_cg_body});
 }
 int storm_hip_solve_bicgstab(const storm_hip_op *op, double alpha, double beta, const storm_hip_vec *b, storm_hip_vec *x,
                              const storm_hip_solver_params *params, storm_hip_solver_result *result, double *history) {
+  if (op) STORM_TRY(lazy_sync(op->ctx));
   return fused_solve(FusedSolveArgs{op, alpha, beta, b, x, params, result, history, &solve_bicgstab_body});
 }
 int storm_hip_solve_gmres(const storm_hip_op *op, double alpha, double beta, const storm_hip_vec *b, storm_hip_vec *x,
                           const storm_hip_solver_params *params, storm_hip_solver_result *result, double *history) {
+  if (op) STORM_TRY(lazy_sync(op->ctx));
   return fused_solve(FusedSolveArgs{op, alpha, beta, b, x, params, result, history, &solve_gmres_body});
 }
 

