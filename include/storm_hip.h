@@ -306,6 +306,10 @@ int storm_hip_op_create_csr(storm_hip_ctx *ctx, int64_t n_rows, int64_t n_halo,
  *   rccl_fused (1), rccl_ticket (1): RCCL transport -- the fused CG step on a partitioned lattice operator (the boundary
  *              planes of the new direction packed by a small kernel and sent under the marching launch), with the local
  *              sums finished inside the kernels that produce them;
+ *   rccl_flag_wait (1): RCCL transport -- the boundary rows of an apply are released by a flag in device memory (set by a
+ *              one-thread kernel behind the send / recv group on the comm stream, polled by a one-thread kernel in front of
+ *              the boundary launch; bounded: 10 s, then STORM_HIP_E_COMM from the next call) instead of a cross-stream event,
+ *              which costs ~13 us between "exchange done" and "boundary rows start" on this platform.  The same bits;
  *   rccl_early_halo (1): RCCL transport, BiCGStab -- the boundary planes of s and of the new direction are formed by a small
  *              kernel and sent before the update kernel that forms the vector runs.  The same bits. */
 int storm_hip_ctx_set_option(storm_hip_ctx *ctx, const char *key, int64_t value);

@@ -44,12 +44,39 @@ struct Comm {
   // RCCL transport, option profile_comm: where an exchange and an all-reduce spend their time, from the device's own clock.
   // One-thread stamp kernels between the launches of BOTH streams store wall_clock64() (ticks of 10 ns) into these rings --
   // an instrumented solve, run beside the timed one (every stamp is a launch of its own, ~2 us on its stream).
+  // RCCL transport, option rccl_flag_wait: the boundary rows are released by a FLAG in device memory instead of a
+  // cross-stream event -- a one-thread kernel behind the send / recv group on the comm stream stores the exchange's number,
+  // a one-thread kernel in front of the boundary launch on the compute stream polls for it (bounded).  The event costs ~13 us
+  // between "exchange done" and "boundary rows start" (profile_comm: halo_done_to_boundary_rows); the flag ~3 us.
+  unsigned long long *d_flag = nullptr;  // [0]: number of the last completed exchange
+  unsigned long long flag_seq = 0;       // exchanges begun
   long long *d_prof = nullptr;          // [kProfRing][8] exchanges: A, P, Q, R, B, C, -, - ; then [kProfRing][2] all-reduces: E, F
   long long prof_ex = 0, prof_ar = 0;   // exchanges / all-reduces stamped since profile_comm was set
   std::vector<unsigned char> prof_mode; // per exchange: 0 = packed on the comm stream, 1 = packed (formed) on the compute stream
 };
 constexpr int kProfRing = 8192;
 __global__ void comm_stamp_kernel(long long *slot) { *slot = wall_clock64(); }
+__global__ void comm_flag_set_kernel(unsigned long long *flag, unsigned long long seq) {
+  __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// (the receive kernel of the exchange ended before the setter started, on the comm stream: what it wrote is visible to
+//  the kernel launched behind this one on the compute stream)
+__global__ void comm_flag_wait_kernel(const unsigned long long *flag, unsigned long long seq, int *error) {
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
+    if (wall_clock64() - t0 > 1000000000ll) {  // 10 s: the exchange never completed
+      if (error) __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+static inline bool flag_on(const storm_hip_ctx *c) { return c->opt_rccl_flag_wait != 0 && c->comm->d_flag != nullptr; }
+// behind the send / recv group of an exchange, on the comm stream
+static inline void flag_publish(storm_hip_ctx *c) {
+  ++c->comm->flag_seq;
+  if (flag_on(c)) hipLaunchKernelGGL(comm_flag_set_kernel, dim3(1), dim3(1), 0, c->comm_stream, c->comm->d_flag, c->comm->flag_seq);
+}
 static inline void prof_stamp(storm_hip_ctx *c, hipStream_t st, long long idx, int k) {
   if (idx < 0 || idx >= kProfRing) return;
   hipLaunchKernelGGL(comm_stamp_kernel, dim3(1), dim3(1), 0, st, c->comm->d_prof + idx * 8 + k);
@@ -108,6 +135,8 @@ static IpcDev ipc_dev(const storm_hip_ctx *c) {
 }
 static int64_t ipc_header_bytes(int64_t P) { return (2 * P * kIpcArSlot + P * 64 + 255) / 256 * 256 + 256; }
 static int ipc_check_error(storm_hip_ctx *c) {
+  if (c->comm && !c->comm->ipc && c->comm->h_error != nullptr && *(volatile int *)c->comm->h_error != 0)
+    STORM_FAIL(STORM_HIP_E_COMM, "RCCL transport: a halo exchange did not complete within 10 s (rank %d of %d)", c->rank, c->n_ranks);
   if (c->comm && c->comm->ipc && *(volatile int *)c->comm->h_error != 0)
     STORM_FAIL(STORM_HIP_E_COMM, "peer-window transport: a wait for another rank timed out (rank %d of %d)", c->rank,
                c->n_ranks);
@@ -304,6 +333,7 @@ int comm_halo_exchange_begin(const storm_hip_op *op, double *x) {
   }
   NCCL_TRY(ncclGroupEnd());
   if (pe >= 0) prof_stamp(c, c->comm_stream, pe, 3);
+  flag_publish(c);
   HIP_TRY(hipEventRecord(c->ev_halo_done, c->comm_stream));
   return STORM_HIP_OK;
 }
@@ -341,6 +371,7 @@ int comm_halo_exchange_begin_direction(const storm_hip_op *op, const double *p, 
   }
   NCCL_TRY(ncclGroupEnd());
   if (pe >= 0) prof_stamp(c, c->comm_stream, pe, 3);
+  flag_publish(c);
   HIP_TRY(hipEventRecord(c->ev_halo_done, c->comm_stream));
   return STORM_HIP_OK;
 }
@@ -389,6 +420,7 @@ int comm_halo_exchange_begin_formed(const storm_hip_op *op, int mode, const doub
   }
   NCCL_TRY(ncclGroupEnd());
   if (pe >= 0) prof_stamp(c, c->comm_stream, pe, 3);
+  flag_publish(c);
   HIP_TRY(hipEventRecord(c->ev_halo_done, c->comm_stream));
   c->comm->prebegun = target;
   return STORM_HIP_OK;
@@ -415,7 +447,12 @@ int comm_halo_exchange_end(const storm_hip_op *op) {
   }
   const long long pe = prof_on(c) ? c->comm->prof_ex - 1 : -1;  // (the exchange begun last is the one this launch waits for)
   if (pe >= 0) prof_stamp(c, c->stream, pe, 4);
-  HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_halo_done, 0));
+  if (flag_on(c)) {
+    hipLaunchKernelGGL(comm_flag_wait_kernel, dim3(1), dim3(1), 0, c->stream, c->comm->d_flag, c->comm->flag_seq, c->comm->d_error);
+    HIP_TRY(hipGetLastError());
+  } else {
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_halo_done, 0));
+  }
   if (pe >= 0) prof_stamp(c, c->stream, pe, 5);
   return STORM_HIP_OK;
 }
@@ -540,6 +577,10 @@ void comm_destroy(storm_hip_ctx *c) {
   if (c->comm->halo) (void)ncclCommDestroy(c->comm->halo);
   if (c->comm->h_stage) (void)hipHostFree(c->comm->h_stage);
   if (c->comm->d_prof) (void)hipFree(c->comm->d_prof);
+  if (c->comm->d_flag) {
+    (void)hipFree(c->comm->d_flag);
+    if (!c->comm->ipc && c->comm->h_error) (void)hipHostFree(c->comm->h_error);
+  }
   if (c->comm->ipc || c->comm->win_local) {
     (void)hipDeviceSynchronize();
     for (int q = 0; q < (int)c->comm->win_peer.size(); ++q)
@@ -609,6 +650,16 @@ int storm_hip_ctx_comm_init(storm_hip_ctx *c, const void *id128, int n_ranks, in
   if (!split_ok) {
     if (cm->red && cm->red != cm->halo) (void)ncclCommDestroy(cm->red);
     cm->red = cm->halo;
+  }
+  // the flag of option rccl_flag_wait (and where a wait that timed out is reported); without them: cross-stream events
+  if (hipMalloc((void **)&cm->d_flag, 256) == hipSuccess && hipMemset(cm->d_flag, 0, 256) == hipSuccess &&
+      hipHostMalloc((void **)&cm->h_error, sizeof(int), hipHostMallocMapped) == hipSuccess) {
+    *cm->h_error = 0;
+    if (hipHostGetDevicePointer((void **)&cm->d_error, cm->h_error, 0) != hipSuccess) cm->d_error = nullptr;
+  } else {
+    (void)hipGetLastError();
+    if (cm->d_flag) (void)hipFree(cm->d_flag);
+    cm->d_flag = nullptr;
   }
   c->comm = cm;
   return STORM_HIP_OK;

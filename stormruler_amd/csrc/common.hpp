@@ -219,6 +219,7 @@ struct storm_hip_ctx {
   int64_t opt_latency_rows = 1 << 19;   // ... up to this many rows (a compact copy of the operator is kept for it)
   int64_t opt_rccl_fused = 1;           // RCCL transport: the fused CG step on a partitioned lattice operator (boundary planes of the new direction packed by a small kernel, sent under the marching launch)
   int64_t opt_rccl_ticket = 1;          // ... with the LOCAL sums of <p,z> and <r,r> finished inside the kernels that produce them (tickets); the all-reduce and the scalar step stay launches
+  int64_t opt_rccl_flag_wait = 1;       // RCCL: the boundary rows wait for a flag in device memory set behind the exchange, not for a cross-stream event (comm.hip)
   int64_t opt_rccl_early_halo = 1;      // RCCL, BiCGStab: the halo of s / p' leaves before the kernel that forms the vector runs (rows to send formed by a small kernel)
   int64_t opt_ipc_bicg_ticket = 1;      // peer windows, BiCGStab: sums finished by tickets and exchanged by the finishing block (as CG does)
   int64_t opt_ipc_fused = 1;            // peer-window transport: the interior launch sends, the boundary launch reads the window (0: stand-alone send / receive-copy kernels)

@@ -154,6 +154,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "rccl_fused")) c->opt_rccl_fused = value;
   else if (!strcmp(key, "rccl_ticket")) c->opt_rccl_ticket = value;
   else if (!strcmp(key, "rccl_early_halo")) c->opt_rccl_early_halo = value;
+  else if (!strcmp(key, "rccl_flag_wait")) c->opt_rccl_flag_wait = value;
   else if (!strcmp(key, "ipc_bicg_ticket")) c->opt_ipc_bicg_ticket = value;
   else if (!strcmp(key, "latency_path")) c->opt_latency_path = value;
   else if (!strcmp(key, "resident_path")) c->opt_resident_path = value;

@@ -36,10 +36,6 @@ struct LazyArgs {
   int sa, sb;             // -1: load; k: the value statement k produced
 };
 
-template <class NT>
-__device__ __forceinline__ double2v lazy_operand(const LazyLin &L, int t, const double2v *val, int64_t i, NT nt) {
-  return L.src[t] >= 0 ? val[L.src[t]] : ld2(reinterpret_cast<const double2v *>(L.v[t]) + i, nt);
-}
 __device__ __forceinline__ double lazy_eval(const LazyLin &L, double x0, double x1) {
   return L.nt == 2 ? L.c[0] * x0 + L.c[1] * x1 : L.c[0] * x0;  // (AxpbzF's expression: blas1.hip)
 }
@@ -124,6 +120,13 @@ __global__ __launch_bounds__(kBlock) void lazy_lin_kernel(int64_t n, LazyArgs A,
       __hip_atomic_store(host_words + 1, t | (unsigned)__double2hiint(total[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+}
+
+__global__ void lazy_result_kernel(const double *value, unsigned long long *host_words, unsigned tag) {
+  const double v = *value;
+  const unsigned long long t = (unsigned long long)tag << 32;
+  __hip_atomic_store(host_words, t | (unsigned)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(host_words + 1, t | (unsigned)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 namespace {
@@ -291,16 +294,24 @@ bool lazy_try_dot(storm_hip_ctx *c, const double *a, const double *b, int64_t n,
   if (nblocks <= 0) return false;  // the launch did not fuse after all: the ordinary reduction follows
   if (!ticketed) *status = k_reduce_final(c, c->d_partials, nblocks, yy ? 2 : 1, c->d_scalars, nullptr);
   if (*status != STORM_HIP_OK) return true;
-  double h[2] = {0.0, 0.0};
-  const hipError_t e1 = hipMemcpyAsync(c->h_scalars, c->d_scalars, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream);
-  const hipError_t e2 = e1 == hipSuccess ? hipStreamSynchronize(c->stream) : e1;
-  if (e2 != hipSuccess) {
-    set_error("lazy dot: %s", hipGetErrorString(e2));
+  // the sum to the host as two self-validating words the host polls (no copy, no stream wait: ~10 us less per reduction)
+  const unsigned tag = ++c->result_seq ? c->result_seq : ++c->result_seq;
+  hipLaunchKernelGGL(lazy_result_kernel, dim3(1), dim3(1), 0, c->stream, c->d_scalars + (yy ? 1 : 0), c->d_result_words + 16 * kLazySlot, tag);
+  if (hipGetLastError() != hipSuccess) {
+    set_error("lazy dot: launch failed");
     *status = STORM_HIP_E_HIP;
     return true;
   }
-  h[0] = c->h_scalars[0], h[1] = c->h_scalars[1];
-  *result = yy ? h[1] : h[0];
+  volatile unsigned long long *hw = c->h_result_words + 16 * kLazySlot;
+  for (long spin = 0; (unsigned)(hw[0] >> 32) != tag || (unsigned)(hw[1] >> 32) != tag; ++spin)
+    if ((spin & 0x3fff) == 0x3fff && hipStreamQuery(c->stream) == hipSuccess &&
+        ((unsigned)(hw[0] >> 32) != tag || (unsigned)(hw[1] >> 32) != tag)) {
+      if (hipMemcpy(result, c->d_scalars + (yy ? 1 : 0), sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) *status = STORM_HIP_E_HIP;
+      ++c->n_lazy_apply_dots;
+      return true;
+    }
+  const unsigned long long bits = (hw[1] << 32) | (hw[0] & 0xffffffffull);
+  memcpy(result, &bits, sizeof(double));
   ++c->n_lazy_apply_dots;
   return true;
 }

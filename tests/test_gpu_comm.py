@@ -145,6 +145,27 @@ def test_rccl_comm_breakdown_on_the_size_one_communicator(setup, kind):
         api.Context(0).counter("rccl_prof_exchanges")  # needs the transport and the option
 
 
+@pytest.mark.parametrize("kind", ["cg", "bicgstab", "gmres"])
+def test_flag_wait_and_event_wait_give_the_same_solve(setup, kind):
+    """Option rccl_flag_wait (default 1): the boundary rows are released by a flag in device memory that a one-thread kernel
+    sets behind the exchange on the comm stream, instead of a cross-stream event.  Only WHEN the boundary launch starts
+    changes: the same bits either way."""
+    api, ctx, loc, mat, ref_apply, oracle = setup
+    b = api.DeviceVector.from_numpy(ctx, np.cos(0.05 * np.arange(loc.n_cells)) + 0.3, n_halo=loc.n_halo)
+    cls = {"cg": api.CgSolver, "bicgstab": api.BiCgStabSolver, "gmres": api.GmresSolver}[kind]
+    out = {}
+    for flag in (1, 0, 1):
+        ctx.set_option("rccl_flag_wait", flag)
+        s = cls()
+        s.num_iterations, s.absolute_error_tolerance, s.relative_error_tolerance = 25, 0.0, 0.0
+        x = api.DeviceVector(ctx, loc.n_cells, loc.n_halo)
+        s.solve(x, b, api.HipStencilOperator(mat, -1.0, 0.05))
+        out.setdefault(flag, []).append((s.absolute_error, x.to_numpy()))
+    ctx.set_option("rccl_flag_wait", 1)
+    for err, xs in out[1][1:] + out[0]:
+        assert err == out[1][0][0] and np.array_equal(xs, out[1][0][1])
+
+
 def test_gmres_cgs2_through_the_comm_path(setup):
     api, ctx, loc, mat, ref_apply, oracle = setup
     b_host = np.ones(loc.n_cells)

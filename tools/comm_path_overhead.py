@@ -55,6 +55,9 @@ for transport in ((only,) if only else ("rccl", "ipc", "ipc0")):
     for mixed in ((1,) if only else (1, 0)):
         ctx = api.Context(0)
         ctx.set_option("spmv_mixed", mixed)
+        for kv in os.environ.get("COMM_OPTS", "").split(","):  # e.g. COMM_OPTS=rccl_flag_wait=0
+            if "=" in kv:
+                ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         if transport == "ipc0":  # peer windows, stand-alone send / receive-copy kernels instead of the fused form
             ctx.set_option("ipc_fused", 0)
         if transport == "rccl":
