@@ -75,7 +75,6 @@ def main() -> int:
                          "claims the abbreviation --n)")
     ap.add_argument("--cpu-iters", type=int, default=20, help="CPU-baseline sample (CG iterations); 0 = skip")
     ap.add_argument("--ordering", default="natural", choices=["natural", "tile"])
-    ap.add_argument("--variant", type=int, default=-1, help="SpMV kernel variant override")
     ap.add_argument("--nontemporal", type=int, default=-1)
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (repeatable)")
     ap.add_argument("--spinup-seconds", type=float, default=1.5, help="untimed device spin-up before the warmup steps")
@@ -212,8 +211,6 @@ def main() -> int:
         g = mesh.permute_cells(g, perm)
 
     ctx = api.Context(local_rank)
-    if args.variant >= 0:
-        ctx.set_option("spmv_variant", args.variant)
     if args.nontemporal >= 0:
         ctx.set_option("nontemporal", args.nontemporal)
     for kv in args.opt:
@@ -1073,9 +1070,7 @@ def tet_variant(api, ctx, args, prefix, file_seconds, file_bytes, traffic_bytes,
 
 
 def record_format_name(st) -> str:
-    return ("typed canonical paired rows: one byte per row into a table of weight words, one common offset order (1 B/row)"
-            if st["paired_rows"] == 3 else
-            "canonical paired rows: byte-indexed weights, one common offset order (8 B/row)" if st["paired_rows"] == 2 else
+    return ("canonical paired rows: byte-indexed weights, one common offset order (8 B/row)" if st["paired_rows"] == 2 else
             "paired rows: byte-indexed weights + shared column offsets (12 B/row)" if st["paired_rows"] else
             "byte-indexed weights + column offsets (16 B/row)" if st["offset_dictionary_size"] else
             "byte-indexed weights (8 B/row + int32 columns)" if st["value_dictionary_size"] else

@@ -235,65 +235,40 @@ int storm_hip_op_create_csr(storm_hip_ctx *ctx, int64_t n_rows, int64_t n_halo,
                             const int64_t *row_ptr, const int64_t *col, const double *val,
                             storm_hip_op **out);
 
-/* Build knobs, set before create (0 = library default):
- *   ell_cap:   rows longer than this spill their remaining entries to the CSR tail;
- *   pool_bytes: vector storage released by vec_destroy is kept (up to this many bytes, default
- *              16 GiB) for the next vec_create of the same size, so the work vectors a solve
- *              allocates on entry cost nothing from the second solve on; 0 frees immediately;
- *   spmv_dict: >= 1 stores the weights of an operator whose ext / weight values take at most 256
- *              distinct fp64 bit patterns (and whose rows have at most 7 neighbours) as byte indices
- *              into that dictionary -- lossless, half the bytes per row; 2 does the same
- *              for the column offsets col - row when they take at most 256 distinct values (a third
- *              of the bytes per row); 3 additionally lets two consecutive rows share one
- *              merged neighbour list and their 16-byte gathers when that list has at most 7 entries
- *              and the tables are small (<= 32 values, <= 64 offsets); 4 (default) additionally drops the
- *              per-lane offsets when every row lists its neighbours in one common order of offsets (a
- *              structured box in natural ordering) and takes the +-1 neighbours from the adjacent lanes;
- *              5 (opt-in) additionally stores ONE byte per row when the rows' weight words take at most 32
- *              distinct values (a box with spacings exact in binary);
- *              0 always stores fp64 weights and int32 columns.
- *   spmv_mixed (1): a partitioned operator keeps format 4 for the row groups that read no halo column and
- *              format-3 records for the others; 0: format 3 throughout.
- * Run-time switches (A/B knobs; the defaults are the measured best):
- *   latency_path (1), latency_rows (2^19), latency_cache (1): CG / BiCGStab of a small halo-free operator as ONE
- *              cooperative kernel per solve (0: neither this nor the resident path below; 2: this path only); the size limit (latency_rows is read when the operator is built); the
- *              operator records in registers;
- *   coop_mgs (1), coop_mgs_min_rows (0), coop_mgs_pairs (1), coop_mgs_apply (1), coop_mgs_prefetch (1), coop_mgs_lds_prefetch (1): GMRES's Gram-Schmidt chain as one
- *              cooperative kernel per Arnoldi step; from how many rows on; several steps per synchronisation point; the
- *              operator apply in front of the chain done by the same kernel (format-4 lattice operators); the next
- *              group's basis vectors requested under the all-reduce (into registers up to four row pairs per thread,
- *              through LDS at eight);
- *   fused_reduce (1): engine reductions of at most 256 partial blocks finish in the partials kernel's last block;
- *   sweep_alternate (1): consecutive streaming kernels of a solve sweep the rows from opposite ends (Infinity Cache);
- *   spmv_canon_groups (2): 128-row groups per wavefront of the format-4 / 5 kernel;
+/* Options: 40 keys (csrc/context.hip), all with measured defaults.  Refinements that were measured and dropped are not
+ * switches any more: their patch is profiles/experiments/r08_pruned_experiments.patch.
+ *
+ * Build knobs, read when an operator / vector is created:
+ *   ell_cap (0 = none): rows longer than this spill their remaining entries to the CSR tail;
+ *   spmv_dict (4): the most compact LOSSLESS record format an operator may take -- 0 fp64 weights + int32 columns (what any
+ *              mesh gets); 1 byte-indexed weights (<= 256 distinct fp64 bit patterns, <= 7 neighbours per row); 2 + byte-indexed
+ *              column offsets; 3 + two consecutive rows share one merged neighbour list and their 16-byte gathers; 4 + one
+ *              common offset order for the whole operator (a structured box in natural ordering), +-1 neighbours from the
+ *              adjacent lanes.  Every format gives the same bits (tests/test_gpu_formats.py);
+ *   spmv_mixed (1): a partitioned operator keeps format 4 for the row groups that read no halo column, format 3 elsewhere;
+ *   spmv_spw (0 = automatic): slices per wavefront of the byte-indexed kernel (1, 2, 4);
+ *   spmv_canon_tile (2), spmv_canon_tile_min_rows (2^20): format 4 on a lattice -- tiles of 1024 rows x 2 (4) planes with the
+ *              in-plane neighbours from LDS and the out-of-plane ones from registers, from this many rows on (0 = plain kernel);
+ *   latency_rows (2^19): operators up to this size keep a compact fp64 copy for the one-kernel CG / BiCGStab;
+ *   pool_bytes (16 GiB): vector storage released by vec_destroy is kept for the next vec_create of the same size;
+ *   vec_arena (1): the vectors of one size are slots of ONE physically contiguous allocation a fixed distance apart.
+ * Paths (which loop a solve takes; every path gives the reference's iteration to rounding):
+ *   latency_path (1), latency_cache (1): CG / BiCGStab of a small halo-free operator as ONE cooperative kernel per solve
+ *              (0: neither this nor the resident path; 2: this path only); operator records held in registers where they fit;
+ *   resident_path (1), resident_max_rows (2^22), resident_planes (0 = automatic), resident_early (1): CG / BiCGStab of a
+ *              halo-free LATTICE operator as one persistent kernel in which every block owns a box of the lattice
+ *              (csrc/resident.hip); surfaces travelling under the all-reduces;
+ *   coop_mgs (1), coop_mgs_lds (1), coop_mgs_quad (1): GMRES's Gram-Schmidt chain as one cooperative kernel per Arnoldi step;
+ *              its LDS-ring and four-steps-per-synchronisation forms (2 = forced, for tests; 0 = off);
+ *   mgs_steps (4): modified-Gram-Schmidt steps per pass over w on the kernel-per-statement path (2, 3, 4);
  *   generic_solvers (0): 1 sends storm_hip_krylov_solve through the engine even where a fused loop exists;
- *   fuse_dot, fold_pz, fuse_mgs (1): the fused-reduction variants of the fused loops;
- *   ipc_streams (2): peer-window halo kernels on the comm stream (2) or on the compute stream (1);
- *   spmv_xcd_remap (8), spmv_nt_y (0), nontemporal (1), spmv_spw, spmv_variant, graph (0), profile_spmv (0), profile_comm (0);
- *   blas1_nt (1), blas1_nt_rows (6 * 2^20): non-temporal loads and stores in the BLAS-1 and solver kernels -- 0 never,
- *              2 always, 1 for vectors of at least blas1_nt_rows rows (longer vectors do not survive in the Infinity
- *              Cache between two kernels of a solve anyway; shorter ones do, and non-temporal accesses cost 3 - 7 %
- *              there).  Same values either way;
- *   vec_arena (1), vec_arena_slots (8), vec_arena_skew_kib (0), vec_arena_max_bytes (64 GiB: all arenas of a context): the vectors of one size (of at least 1 MiB) are slots of
- *              ONE physically contiguous allocation, a fixed distance apart (the smallest distance = 2 MiB modulo 4 MiB
- *              that holds the vector, + skew) -- separate allocations land 132 MiB apart at 256^3, a multiple of 4 MiB,
- *              which costs a multi-stream kernel 3 - 4 %; a released vector returns to the context's pool (a stack:
- *              a solver finds each work vector in its old role), arenas are freed with the context;
- *   vec_contiguous (0): vectors outside arenas in physically contiguous memory too;
- *   mgs_steps (4): modified-Gram-Schmidt steps per pass over w in GMRES's orthogonalisation on the kernel-per-statement
- *              path (2, 3, 4; coefficients of a pass follow from bilinearity);
- *   resident_path (1), resident_min_rows (0), resident_max_rows (2^22), resident_max_planes (12), resident_planes (0 =
- *              automatic): CG / BiCGStab of a
- *              halo-free LATTICE operator (format-4 records) as one persistent kernel per solve in which every
- *              block owns a box of the lattice (csrc/resident.hip);
- *   resident_early (1): on that path, surfaces travel under the all-reduces -- CG publishes its residual's surface before
- *              beta is known and forms p' = r + beta p on its halo itself; BiCGStab (boxes of at most six planes) keeps the
- *              halos of r, p, v and forms those of p and s, exchanging the surfaces of v = A p and of the new residual.
- *              Bitwise the same solves as 0 (halos exchanged behind the all-reduces);
- *   resident_apply_cache (1): on that path (boxes of 3 - 12 planes) the coefficients of a pair of rows stay in registers from plane
- *              to plane while its weight words do not change; 0 decodes them per plane.  The same bits;
- *   resident_halo_interleave (1): CG on that path, boxes of more than two planes: half of a block's waves form the halo of the
- *              new direction before updating their own rows, half behind it.  The same bits;
+ *   cg_fuse (1), cg_march (8), cg_march_fill (2048): the SpMV launch of a tiled format-4 operator ends the previous CG
+ *              iteration (x += alpha p, p = r + beta p) itself, as blocks marching through this many planes (0: tiles), fewer
+ *              planes per block on small lattices so that the grid holds about cg_march_fill blocks (0: as given);
+ *   fused_reduce (1), lin_fuse (1), ticket_reduce (1): engine reductions finished by the partials kernel's last block; two
+ *              consecutive vector statements as one pass; fused-loop reductions finished inside the producing kernels;
+ *   nontemporal (1), blas1_nt (1): non-temporal record / y traffic of the SpMV; of the BLAS-1 and solver kernels (0 never,
+ *              2 always, 1 for vectors of at least 6 * 2^20 rows: shorter ones survive in the Infinity Cache between kernels);
  *   lazy_statements (0): HOST loops -- storm_hip_copy / _scale / _axpy / _xpay / _axpbz and storm_hip_op_apply are not
  *              launched when called but wait, in program order, for the call that needs their result; two consecutive linear
  *              statements leave as ONE pass, and a storm_hip_dot / _norm2 over a vector the last waiting statement writes
@@ -301,17 +276,27 @@ int storm_hip_op_create_csr(storm_hip_ctx *ctx, int64_t n_rows, int64_t n_halo,
  *              apply with its fused-dot epilogue).  Every other entry point launches what waits first, so nothing is
  *              observed out of order; nothing waits inside a solver's operator / preconditioner callback.  The
  *              linear statements and their reductions give the eager kernels' values bit for bit; the apply's fused dot
- *              sums in the SpMV kernel's order (equal to rounding) (csrc/lazy.hip).  The host loops of Storm.hpp / api.py switch it on for their duration
- *              (IterativeSolver::lazy_statements);
- *   rccl_fused (1), rccl_ticket (1): RCCL transport -- the fused CG step on a partitioned lattice operator (the boundary
- *              planes of the new direction packed by a small kernel and sent under the marching launch), with the local
- *              sums finished inside the kernels that produce them;
- *   rccl_flag_wait (1): RCCL transport -- the boundary rows of an apply are released by a flag in device memory (set by a
- *              one-thread kernel behind the send / recv group on the comm stream, polled by a one-thread kernel in front of
- *              the boundary launch; bounded: 10 s, then STORM_HIP_E_COMM from the next call) instead of a cross-stream event,
- *              which costs ~13 us between "exchange done" and "boundary rows start" on this platform.  The same bits;
- *   rccl_early_halo (1): RCCL transport, BiCGStab -- the boundary planes of s and of the new direction are formed by a small
- *              kernel and sent before the update kernel that forms the vector runs.  The same bits. */
+ *              sums in the SpMV kernel's order (equal to rounding) (csrc/lazy.hip).  The host loops of Storm.hpp / api.py
+ *              switch it on for their duration (IterativeSolver::lazy_statements).
+ * RCCL transport:
+ *   rccl_fused (1), rccl_ticket (1): the fused CG step on a partitioned lattice operator (the boundary planes of the new
+ *              direction packed by a small kernel and sent under the marching launch); local sums finished in the kernels;
+ *   rccl_early_halo (1): BiCGStab -- the boundary planes of s and of the new direction are formed by a small kernel and sent
+ *              before the update kernel that forms the vector runs.  The same bits;
+ *   rccl_flag_wait (1): the boundary rows of an apply are released by a flag in device memory (set by a one-thread kernel
+ *              behind the send / recv group on the comm stream, polled by a one-thread kernel in front of the boundary
+ *              launch; bounded: 10 s, then STORM_HIP_E_COMM from the next call) instead of a cross-stream event, which costs
+ *              ~15 us between "exchange done" and "boundary rows start" on this platform (5 us with the flag).  The same bits.
+ * Instrumentation: profile_spmv (HIP-event pair around every SpMV launch), profile_comm (RCCL path: device timestamps
+ *   around every step of an exchange and every all-reduce), resident_profile (the resident kernels time their phases),
+ *   ticket_verify (k > 0: every k-th iteration the fused loops recompute their in-kernel reductions by the two-launch path
+ *   and compare on the device).
+ * Test hooks (not options: they exist so that tests can force a path or compare a kernel with its plainer form):
+ *   coop_force_fail (1: cooperative launches "fail"; 2: cooperative kernels "gave up"), ticket_verify_inject,
+ *   test_disable (a bit mask; every bit switches ONE refinement off, the plain form must give the same bits: 1 the chain
+ *   kernel's own operator apply, 2 its prefetch under the all-reduce, 4 the resident path's coefficient cache, 8 its halo
+ *   interleave, 16 awaited publishing exchanges of the latency path, 32 ordinary launch of the one-kernel paths, 64 downward
+ *   marching of odd z-chunks). */
 int storm_hip_ctx_set_option(storm_hip_ctx *ctx, const char *key, int64_t value);
 
 /* Which path the solves of this context took so far (no reference counterpart: a diagnostic of this library; the

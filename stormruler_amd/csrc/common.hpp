@@ -140,30 +140,29 @@ struct storm_hip_ctx {
     bool ready = false;   // value[] holds the sums already (the ordinary road computed them in _begin)
     double value[storm::kMaxMulti] = {};
   } result_ring[storm::kResultRing];
-  int64_t opt_host_result = 1;        // 0: device scalars + hipMemcpyAsync + hipStreamSynchronize
+  static constexpr int64_t opt_host_result = 1;        // 0: device scalars + hipMemcpyAsync + hipStreamSynchronize
   storm::SolverState *d_state = nullptr;
   storm::SolverState *h_state = nullptr;  // pinned staging copy of the state
   unsigned long long *h_done_ring = nullptr;  // pinned, written by the device's step kernels (solver_device.hpp advance())
   unsigned long long *d_done_ring = nullptr;  // device pointer to the same memory
   std::vector<hipEvent_t> ev_ring;            // (option poll_events = 1: a marker behind every iteration, the r02 form; created on first use)
   std::vector<storm::KrylovRes> krylov_free;   // krylov.hip: resources of destroyed engines, reused by the next create
-  int64_t opt_poll_events = 0;
+  static constexpr int64_t opt_poll_events = 0;
   unsigned long long ring_gen = 0;            // generation of the current solve's ring words (state_init draws the next one)
   // options
   int64_t opt_ell_cap = 0;
-  int64_t opt_spmv_variant = 0;      // 0 gathers from global (default), 1 + LDS x window
   int64_t opt_spmv_dict = 4;         // dictionary records whenever an operator qualifies (lossless): 3 + paired rows, 2 values + column offsets, 1 values only, 0 never
   int64_t opt_spmv_spw = 0;          // slices per wave of the dictionary kernel: 1, 2 or 4 (0 = default)
-  int64_t opt_spmv_xcd_remap = 8;    // 0 off; 1 one contiguous run per XCD (slower); G > 1: runs of G tiles per XCD
+  static constexpr int64_t opt_spmv_xcd_remap = 8;    // 0 off; 1 one contiguous run per XCD (slower); G > 1: runs of G tiles per XCD
   int64_t opt_nt = 1;
-  int64_t opt_sweep_alternate = 1;   // fused CG: consecutive kernels sweep the rows in opposite directions (2: and without non-temporal hints)
+  static constexpr int64_t opt_sweep_alternate = 1;   // fused CG: consecutive kernels sweep the rows in opposite directions (2: and without non-temporal hints)
   int stream_reverse = 0;            // ... and the same for the next elementwise kernel
   int spmv_reverse = 0;              // set around a format-4 SpMV launch by the solver: deal the tiles out from the far end
-  int64_t opt_spmv_canon_groups = 2; // format-4 / 5 kernel: 128-row groups per wavefront (1 or 2)
-  int64_t opt_spmv_tile_lds_pad = 0;   // A/B knob: extra dynamic LDS per block of the tiled kernel (fewer resident tiles per CU)
+  static constexpr int64_t opt_spmv_canon_groups = 2; // format-4 / 5 kernel: 128-row groups per wavefront (1 or 2)
+  static constexpr int64_t opt_spmv_tile_lds_pad = 0;   // A/B knob: extra dynamic LDS per block of the tiled kernel (fewer resident tiles per CU)
   int64_t opt_spmv_canon_tile_min_rows = (int64_t)1 << 20;  // ... for operators of at least this many rows
   int64_t opt_spmv_canon_tile = 2;   // format 4 on a lattice (offsets -b,-a,-1,+1,+a,+b): tiles of 1024 rows x this many planes (2, or 4) with the +-a / +-1 neighbours from LDS and the +-b ones from registers; 0 = the plain kernel.  Measured at 256^3 (profiles/r03f, r03g): CG step 242 (2 planes) / 247 (4) us per iteration, BiCGStab 496 / 510
-  int64_t opt_vec_contiguous = 0;     // vectors in physically contiguous device memory (hipDeviceMallocContiguous)
+  static constexpr int64_t opt_vec_contiguous = 0;     // vectors in physically contiguous device memory (hipDeviceMallocContiguous)
   int64_t opt_mgs_steps = 4;          // throughput-path Gram-Schmidt: steps per pass over w (2: mgs_pair_kernel; 3, 4: mgs_multi_kernel)
   int64_t opt_resident_early = 1;    // resident CG: the residual's surface published under the all-reduce that yields beta (res_halo MODE 2; behind the block's own arrival at that all-reduce): bitwise the same solve, 7 - 12 % faster (128^3: 16.8 -> 15.4 us per iteration)
   int64_t opt_resident_apply_cache = 1;  // resident path: a pair of rows' coefficients stay in registers from plane to plane while the weight words do not change (0: decoded per plane; the same bits)
@@ -171,24 +170,24 @@ struct storm_hip_ctx {
   int64_t opt_coop_mgs_prefetch = 1; // ... the next group's basis vectors requested under the all-reduce (up to 4 row pairs per thread)
   int64_t opt_coop_mgs_lds_prefetch = 1; // ... eight row pairs per thread (128^3): the next group's vectors through LDS (LDS-DMA)
   int64_t opt_coop_mgs_apply = 1;    // ... with the operator apply in front of it done by the chain kernel itself (format-4 lattice operators)
-  int64_t opt_coop_mgs_pairs = 1;    // cooperative Gram-Schmidt chain: two steps per synchronisation point
-  int64_t opt_coop_dense = 1;        // the multi-step Gram-Schmidt chain's all-reduce with dense value-major slots (0: the two-level form; 2: the resident kernels too)
+  static constexpr int64_t opt_coop_mgs_pairs = 1;    // cooperative Gram-Schmidt chain: two steps per synchronisation point
+  static constexpr int64_t opt_coop_dense = 1;        // the multi-step Gram-Schmidt chain's all-reduce with dense value-major slots (0: the two-level form; 2: the resident kernels too)
   int64_t opt_coop_mgs_quad = 1;     // ... FOUR steps per synchronisation point (blocks of 512 threads; <= 2^21 rows)
   char *d_quad_slots = nullptr;      // ... its all-reduce slots (ten values each)
   int64_t opt_coop_mgs_lds = 1;      // ... with the next pair of basis vectors fetched by LDS-DMA into a ring (<= 2^21 rows)
   int64_t opt_spmv_mixed = 1;        // partitioned operators: format 4 for the groups that read no halo column, format 3 for the rest
-  int64_t opt_spmv_nt_y = 0;         // format-4 kernels: store y non-temporally (A/B knob; until round 4 the compiler merged both paths into the plain store -- store_y, spmv_device.hpp -- so 0 is what every earlier number was measured with; 256^3 CG: 4 300 it/s with 1, 4 190 - 4 470 with 0)
   int64_t opt_profile_spmv = 0;
   std::vector<storm::LazyStmt> lazy_q;  // held-back statements (lazy.hip), in program order
+  int64_t opt_test_disable = 0;         // option test_disable (context.hip): a bit mask that switches single refinements OFF so that tests can compare a kernel with its plainer form, bit for bit
   int64_t opt_lazy = 0;                 // option lazy_statements
   int callback_depth = 0;               // > 0 while a solver is inside an operator / preconditioner callback (nothing waits there)
   int64_t n_lazy_fused_dots = 0, n_lazy_fused_pairs = 0, n_lazy_apply_dots = 0;
   int64_t opt_profile_comm = 0;       // RCCL transport: stamp kernels around the halo exchange and the all-reduces (comm.hip comm_profile_*)
   int64_t opt_blas1_nt = 1;  // non-temporal loads/stores in the streaming kernels: 0 never, 1 for vectors of at least blas1_nt_rows rows, 2 always
-  int64_t opt_blas1_nt_rows = (int64_t)6 << 20;  // (48 MiB per vector: beyond, a solver's vectors no longer stay in the 256 MiB Infinity Cache between kernels)
-  int64_t opt_graph = 0;     // replay CG / BiCGStab iterations from a captured hipGraph: measured slower than eager launches (profiles/r01_notes.md), off
-  int64_t opt_fuse_mgs = 1;  // GMRES/MGS on one rank, <= 2048 blocks: each step folds the previous step's partials itself (no final-reduction launch in between)
-  int64_t opt_coop_mgs_min_rows = 0;  // ... from this many rows on (0: always; with two steps per synchronisation point the chain is no slower than a launch per step even on small meshes)
+  static constexpr int64_t opt_blas1_nt_rows = (int64_t)6 << 20;  // (48 MiB per vector: beyond, a solver's vectors no longer stay in the 256 MiB Infinity Cache between kernels)
+  static constexpr int64_t opt_graph = 0;     // replay CG / BiCGStab iterations from a captured hipGraph: measured slower than eager launches (profiles/r01_notes.md), off
+  static constexpr int64_t opt_fuse_mgs = 1;  // GMRES/MGS on one rank, <= 2048 blocks: each step folds the previous step's partials itself (no final-reduction launch in between)
+  static constexpr int64_t opt_coop_mgs_min_rows = 0;  // ... from this many rows on (0: always; with two steps per synchronisation point the chain is no slower than a launch per step even on small meshes)
   int64_t opt_coop_mgs = 1;             // GMRES: the Gram-Schmidt chain of an Arnoldi step as one cooperative kernel (latency.hip)
   int64_t opt_latency_publish = 1;      // ... its rows published with awaited atomic exchanges (0: write-through stores, ordered by their acknowledgement)
   int64_t opt_coop_plain = 1;           // the cooperative kernels by ordinary launches (latency.hip coop_launch; 0: hipLaunchCooperativeKernel)
@@ -200,10 +199,10 @@ struct storm_hip_ctx {
   int64_t opt_latency_path = 1;         // small operators: CG as one cooperative persistent kernel (latency.hip)
   // resident.hip: lattice operators as one persistent kernel per solve, every block owning a box of the lattice
   int64_t opt_resident_path = 1;
-  int64_t opt_resident_min_rows = 0;            // ... from this many rows on (below: the latency path, where it applies)
+  static constexpr int64_t opt_resident_min_rows = 0;            // ... from this many rows on (below: the latency path, where it applies)
   int64_t opt_resident_max_rows = (int64_t)1 << 22;
   int64_t opt_resident_planes = 0;              // ... exactly this many planes per block (0: the fewest that cover the lattice with one block per CU)
-  int64_t opt_resident_max_planes = 12;         // ... with at most this many planes per block (registers)
+  static constexpr int64_t opt_resident_max_planes = 12;         // ... with at most this many planes per block (registers)
   char *d_res_exch = nullptr;                   // its exchange buffer: one 16-byte granule per row (grown on demand)
   int64_t res_exch_rows = 0;
   int64_t opt_resident_profile = 0;             // the kernels time their phases (storm_hip_ctx_get_counter "resident_phase_max_k" / "_mean_k", ticks of 10 ns)
@@ -221,17 +220,16 @@ struct storm_hip_ctx {
   int64_t opt_rccl_ticket = 1;          // ... with the LOCAL sums of <p,z> and <r,r> finished inside the kernels that produce them (tickets); the all-reduce and the scalar step stay launches
   int64_t opt_rccl_flag_wait = 1;       // RCCL: the boundary rows wait for a flag in device memory set behind the exchange, not for a cross-stream event (comm.hip)
   int64_t opt_rccl_early_halo = 1;      // RCCL, BiCGStab: the halo of s / p' leaves before the kernel that forms the vector runs (rows to send formed by a small kernel)
-  int64_t opt_ipc_bicg_ticket = 1;      // peer windows, BiCGStab: sums finished by tickets and exchanged by the finishing block (as CG does)
-  int64_t opt_ipc_fused = 1;            // peer-window transport: the interior launch sends, the boundary launch reads the window (0: stand-alone send / receive-copy kernels)
-  int64_t opt_ipc_streams = 2;          // peer-window halo exchange: 2 = on the comm stream beside the interior rows, 1 = on the compute stream around them
+  static constexpr int64_t opt_ipc_bicg_ticket = 1;      // peer windows, BiCGStab: sums finished by tickets and exchanged by the finishing block (as CG does)
+  static constexpr int64_t opt_ipc_fused = 1;            // peer-window transport: the interior launch sends, the boundary launch reads the window (0: stand-alone send / receive-copy kernels)
+  static constexpr int64_t opt_ipc_streams = 2;          // peer-window halo exchange: 2 = on the comm stream beside the interior rows, 1 = on the compute stream around them
   int64_t opt_generic_solvers = 0;  // 1: storm_hip_krylov_solve never takes the fused CG / BiCGStab / GMRES loops (A/B knob)
   int64_t opt_cg_march_fill = 2048;    // ... fewer planes per block on smaller lattices, so that the grid holds about this many blocks (0: cg_march as given)
   int64_t opt_cg_march_alternate = 1;  // odd z-chunks of the marching step kernel march downwards (spmv.hip MarchArgs::alternate)
-  int64_t opt_cg_march_ticket = 0;  // ... which finishes <p,z> itself (tickets) instead of leaving per-wave partials for a one-block final pass: measured no gain (234 vs 233 us per iteration at 256^3: the ticket tail of 2 048 long-running blocks costs what the 4.7 us launch did), off
   int64_t opt_cg_march = 8;   // ... as blocks of 1024 rows marching through this many planes (0: tiles, spmv_canon_tile planes deep); 256^3, us per CG iteration: tiles 239, 8 planes 230, 16 234, 32 236, 64 237 (profiles/r03k)
   int64_t opt_cg_fuse = 1;   // fused CG, one rank, tiled format-4 operator: the SpMV kernel ends the previous iteration (x += alpha p, p = r + beta p) itself
-  int64_t opt_fold_pz = 1;   // CG, one rank, > 8192 SpMV partials: cg_r_kernel folds the first-pass partials of <p,z> itself (one launch fewer)
-  int64_t opt_fuse_dot = 1;  // 0: reductions after an SpMV run as separate kernels (A/B knob)
+  static constexpr int64_t opt_fold_pz = 1;   // CG, one rank, > 8192 SpMV partials: cg_r_kernel folds the first-pass partials of <p,z> itself (one launch fewer)
+  static constexpr int64_t opt_fuse_dot = 1;  // 0: reductions after an SpMV run as separate kernels (A/B knob)
   // Vector storage released by vec_destroy, kept for the next vec_create of the same size: a solve
   // allocates its work vectors on entry and frees them on return (the reference re-assigns them in
   // every init, SolverCg.hpp:57-59); hipMalloc + hipFree of three 134 MB vectors cost ~7 ms per solve.
@@ -247,13 +245,11 @@ struct storm_hip_ctx {
   };
   std::vector<VecArena> arenas;
   int64_t opt_vec_arena = 1;            // 0: every vector an allocation of its own
-  int64_t opt_pack_arena = 0;           // an operator's records in a slot of its vectors' arena (where they fit)
-  int64_t opt_vec_arena_contiguous = 1; // arenas in physically contiguous memory (hipDeviceMallocContiguous)
-  int64_t opt_bicg_fuse = 0;            // BiCGStab on a lattice: s = r - alpha v formed inside the apply t = A s (the marching kernel without its x update).  Measured at 256^3: the launch pair it replaces 61.5 + 67.2 us, the fused launch 117.9 us -- but the second half-step behind it then finds less of s and t in the Infinity Cache (139 -> 167 us): 452 against 445 us per iteration, so off
-  int64_t opt_cg_roles = 8;             // solve_cg_body: permutation of the work vectors' roles over their arena slots (A/B knob; 24 permutations at 256^3: 4 505 - 4 570 it/s, profiles/r05z_roles.txt)
-  int64_t opt_vec_arena_slots = 8;
-  int64_t opt_vec_arena_max_bytes = (int64_t)64 << 30;  // all arenas of a context together; beyond: vectors allocated one by one
-  int64_t opt_vec_arena_skew_kib = 0;   // pitch = the vector rounded up to 2 MiB + this
+  static constexpr int64_t opt_vec_arena_contiguous = 1; // arenas in physically contiguous memory (hipDeviceMallocContiguous)
+  static constexpr int64_t opt_cg_roles = 8;             // solve_cg_body: permutation of the work vectors' roles over their arena slots (A/B knob; 24 permutations at 256^3: 4 505 - 4 570 it/s, profiles/r05z_roles.txt)
+  static constexpr int64_t opt_vec_arena_slots = 8;
+  static constexpr int64_t opt_vec_arena_max_bytes = (int64_t)64 << 30;  // all arenas of a context together; beyond: vectors allocated one by one
+  static constexpr int64_t opt_vec_arena_skew_kib = 0;   // pitch = the vector rounded up to 2 MiB + this
   size_t pool_bytes = 0;
   int64_t opt_pool_bytes = (int64_t)16 << 30;
   std::vector<hipEvent_t> prof_events;  // pairs (start, stop), grown on demand
@@ -303,8 +299,7 @@ struct storm_hip_op {
   int dict_size = 0;               // > 0: records are [idx 64 u64][col W*64 i32]
   int *d_offs = nullptr;           // format 2: the 256-entry column-offset table
   int offs_size = 0;               // > 0: records are 64 x 16-byte words (values + offsets as byte indices)
-  int pair = 0;                    // 1: format 3 -- 128-row groups of paired rows, n_slices counts those groups; 2: format 4 (common offset order); 3: format 5 (+ one byte per row)
-  unsigned long long *d_types = nullptr;  // format 5: the distinct weight words (kMaxRowTypes entries)
+  int pair = 0;                    // 1: format 3 -- 128-row groups of paired rows, n_slices counts those groups; 2: format 4 (common offset order)
   char *d_bnd_pack = nullptr;      // mixed operator: format-3 records of the boundary groups, in d_boundary order
   int bnd_width = 0;               // ... and their merged width
   int canon_k = 0, canon_m1 = -1;  // format 4: number of common offsets, slot of offset -1 (+1 follows)
@@ -430,11 +425,6 @@ struct SpmvDot {
     double *x = nullptr;
     const double *r = nullptr;
     double *p_out = nullptr;
-    // r != null, x == null: the marching kernel without the x update -- p' = r + c p into p_out, y = A p', <p',y> (and
-    // <y,y>); c = *cb, or cb_scale * safe_divide(*cb, *cb_den) with the quotient stored to *cb_store (BiCGStab)
-    const double *cb_den = nullptr;
-    double cb_scale = 1.0;
-    double *cb_store = nullptr;
   } cg;
 };
 int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, double *y,
@@ -443,8 +433,6 @@ int spmv_grid_blocks(const storm_hip_op *op);
 bool spmv_can_fuse_cg(const storm_hip_op *op);
 bool spmv_can_march(const storm_hip_op *op);  // the z-marching kernel applies to an unsplit launch of this operator
 int op_upload_slice_lists(storm_hip_op *op);
-void *vec_slot_take(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, size_t bytes);  // context.hip
-bool vec_slot_give(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, void *p);
 
 // latency.hip
 int op_make_latency_copy(storm_hip_op *op, int64_t n, int64_t n_halo, const std::vector<int64_t> &row_ptr,

@@ -147,52 +147,26 @@ int storm_hip_ctx_info(storm_hip_ctx *c, char *name, int name_len, int *num_cus,
 int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   STORM_REQUIRE(c && key, "ctx_set_option: null argument");
   if (!strcmp(key, "ell_cap")) c->opt_ell_cap = value;
-  else if (!strcmp(key, "spmv_variant")) c->opt_spmv_variant = value;
   else if (!strcmp(key, "generic_solvers")) c->opt_generic_solvers = value;
-  else if (!strcmp(key, "ipc_streams")) c->opt_ipc_streams = value;
-  else if (!strcmp(key, "ipc_fused")) c->opt_ipc_fused = value;
   else if (!strcmp(key, "rccl_fused")) c->opt_rccl_fused = value;
   else if (!strcmp(key, "rccl_ticket")) c->opt_rccl_ticket = value;
   else if (!strcmp(key, "rccl_early_halo")) c->opt_rccl_early_halo = value;
   else if (!strcmp(key, "rccl_flag_wait")) c->opt_rccl_flag_wait = value;
-  else if (!strcmp(key, "ipc_bicg_ticket")) c->opt_ipc_bicg_ticket = value;
   else if (!strcmp(key, "latency_path")) c->opt_latency_path = value;
   else if (!strcmp(key, "resident_path")) c->opt_resident_path = value;
-  else if (!strcmp(key, "resident_min_rows")) c->opt_resident_min_rows = value;
   else if (!strcmp(key, "resident_max_rows")) c->opt_resident_max_rows = value;
-  else if (!strcmp(key, "resident_max_planes")) c->opt_resident_max_planes = value;
   else if (!strcmp(key, "resident_planes")) c->opt_resident_planes = value;
   else if (!strcmp(key, "resident_profile")) c->opt_resident_profile = value;
-  else if (!strcmp(key, "latency_publish")) c->opt_latency_publish = value;
   else if (!strcmp(key, "coop_force_fail")) c->opt_coop_force_fail = value;
-  else if (!strcmp(key, "coop_plain")) c->opt_coop_plain = value;
   else if (!strcmp(key, "coop_mgs")) c->opt_coop_mgs = value;
-  else if (!strcmp(key, "coop_mgs_min_rows")) c->opt_coop_mgs_min_rows = value;
-  else if (!strcmp(key, "coop_mgs_pairs")) c->opt_coop_mgs_pairs = value;
-  else if (!strcmp(key, "coop_mgs_apply")) c->opt_coop_mgs_apply = value;
-  else if (!strcmp(key, "coop_mgs_prefetch")) c->opt_coop_mgs_prefetch = value;
-  else if (!strcmp(key, "coop_mgs_lds_prefetch")) c->opt_coop_mgs_lds_prefetch = value;
-  else if (!strcmp(key, "resident_early")) c->opt_resident_early = value;
-  else if (!strcmp(key, "resident_apply_cache")) c->opt_resident_apply_cache = value;
-  else if (!strcmp(key, "resident_halo_interleave")) c->opt_resident_halo_interleave = value;
-  else if (!strcmp(key, "mgs_steps")) c->opt_mgs_steps = value;
-  else if (!strcmp(key, "vec_contiguous")) c->opt_vec_contiguous = value;
-  else if (!strcmp(key, "vec_arena")) c->opt_vec_arena = value;
-  else if (!strcmp(key, "pack_arena")) c->opt_pack_arena = value;
-  else if (!strcmp(key, "cg_roles")) c->opt_cg_roles = value;
-  else if (!strcmp(key, "bicg_fuse")) c->opt_bicg_fuse = value;
-  else if (!strcmp(key, "vec_arena_contiguous")) c->opt_vec_arena_contiguous = value;
-  else if (!strcmp(key, "vec_arena_slots")) c->opt_vec_arena_slots = value;
-  else if (!strcmp(key, "vec_arena_max_bytes")) c->opt_vec_arena_max_bytes = value;
-  else if (!strcmp(key, "vec_arena_skew_kib")) c->opt_vec_arena_skew_kib = value;
   else if (!strcmp(key, "coop_mgs_lds")) c->opt_coop_mgs_lds = value;
   else if (!strcmp(key, "coop_mgs_quad")) c->opt_coop_mgs_quad = value;
-  else if (!strcmp(key, "coop_dense")) c->opt_coop_dense = value;
+  else if (!strcmp(key, "cg_march_fill")) c->opt_cg_march_fill = value;
+  else if (!strcmp(key, "resident_early")) c->opt_resident_early = value;
+  else if (!strcmp(key, "mgs_steps")) c->opt_mgs_steps = value;
+  else if (!strcmp(key, "vec_arena")) c->opt_vec_arena = value;
   else if (!strcmp(key, "spmv_mixed")) c->opt_spmv_mixed = value;
-  else if (!strcmp(key, "sweep_alternate")) c->opt_sweep_alternate = value;
-  else if (!strcmp(key, "spmv_canon_groups")) c->opt_spmv_canon_groups = value;
   else if (!strcmp(key, "spmv_canon_tile")) c->opt_spmv_canon_tile = value;
-  else if (!strcmp(key, "spmv_tile_lds_pad")) c->opt_spmv_tile_lds_pad = value;
   else if (!strcmp(key, "spmv_canon_tile_min_rows")) c->opt_spmv_canon_tile_min_rows = value;
   else if (!strcmp(key, "fused_reduce")) c->opt_fused_reduce = (int)value;
   else if (!strcmp(key, "ticket_reduce")) c->opt_ticket_reduce = (int)value;
@@ -202,8 +176,6 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "latency_rows")) c->opt_latency_rows = value;
   else if (!strcmp(key, "latency_cache")) c->opt_latency_cache = (int)value;
   else if (!strcmp(key, "nontemporal")) c->opt_nt = value;
-  else if (!strcmp(key, "spmv_nt_y")) c->opt_spmv_nt_y = value;
-  else if (!strcmp(key, "spmv_xcd_remap")) c->opt_spmv_xcd_remap = value;
   else if (!strcmp(key, "spmv_dict")) c->opt_spmv_dict = value;
   else if (!strcmp(key, "pool_bytes")) {
     c->opt_pool_bytes = value;
@@ -213,6 +185,21 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
     }
   }
   else if (!strcmp(key, "spmv_spw")) c->opt_spmv_spw = value;
+  else if (!strcmp(key, "test_disable")) {
+    // TEST HOOK, not an option: every bit switches one refinement of a kernel off, so that a test can run the refined and
+    // the plain form side by side and demand the same bits (the plain forms exist for that purpose only).
+    //   1  GMRES chain kernel applies the operator itself (0: the apply is a launch in front of the chain)
+    //   2  the chain's prefetch of the next group's basis vectors under its all-reduce (registers / LDS-DMA)
+    //   4  resident path: a row pair's coefficients kept in registers from plane to plane
+    //   8  resident CG: half of the waves form the halo of the new direction before their own update
+    //  16  latency path: rows published with awaited atomic exchanges (off: write-through stores)
+    //  32  one-kernel paths launched like any kernel (off: hipLaunchCooperativeKernel)
+    //  64  marching CG step: odd z-chunks march downwards
+    c->opt_test_disable = value;
+    c->opt_coop_mgs_apply = !(value & 1), c->opt_coop_mgs_prefetch = c->opt_coop_mgs_lds_prefetch = !(value & 2);
+    c->opt_resident_apply_cache = !(value & 4), c->opt_resident_halo_interleave = !(value & 8);
+    c->opt_latency_publish = !(value & 16), c->opt_coop_plain = !(value & 32), c->opt_cg_march_alternate = !(value & 64);
+  }
   else if (!strcmp(key, "lazy_statements")) {
     if (value == 0) STORM_TRY(lazy_sync(c));
     c->opt_lazy = value;
@@ -222,19 +209,9 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
     c->opt_profile_comm = value;
     if (value != 0) STORM_TRY(comm_profile_reset(c));
   }
-  else if (!strcmp(key, "fuse_dot")) c->opt_fuse_dot = value;
-  else if (!strcmp(key, "fold_pz")) c->opt_fold_pz = value;
   else if (!strcmp(key, "cg_fuse")) c->opt_cg_fuse = value;
   else if (!strcmp(key, "cg_march")) c->opt_cg_march = value;
-  else if (!strcmp(key, "cg_march_ticket")) c->opt_cg_march_ticket = value;
-  else if (!strcmp(key, "cg_march_alternate")) c->opt_cg_march_alternate = value;
-  else if (!strcmp(key, "cg_march_fill")) c->opt_cg_march_fill = value;
-  else if (!strcmp(key, "poll_events")) c->opt_poll_events = value;
-  else if (!strcmp(key, "host_result")) c->opt_host_result = value;
-  else if (!strcmp(key, "fuse_mgs")) c->opt_fuse_mgs = value;
-  else if (!strcmp(key, "graph")) c->opt_graph = value;
   else if (!strcmp(key, "blas1_nt")) c->opt_blas1_nt = value;
-  else if (!strcmp(key, "blas1_nt_rows")) c->opt_blas1_nt_rows = value;
   else STORM_FAIL(STORM_HIP_E_INVALID, "ctx_set_option: unknown key '%s'", key);
   return STORM_HIP_OK;
 }
@@ -534,31 +511,6 @@ static double *arena_take(storm_hip_ctx *c, size_t bytes) {
   return reinterpret_cast<double *>(a.base);
 }
 
-namespace storm {
-// Storage for an operator's records from the arena of the vectors it is applied to (spmv_build.hip): `bytes` must not
-// exceed such a vector's allocation.  Null: no arena -- the caller allocates.  Give it back with vec_slot_give.
-size_t vec_alloc_bytes(int64_t n_owned, int64_t n_halo) { return sizeof(double) * (size_t)(kVecGuard + (n_owned + n_halo + 3) / 4 * 4 + 4); }
-void *vec_slot_take(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, size_t bytes) {
-  const size_t vb = vec_alloc_bytes(n_owned, n_halo);
-  if (bytes > vb) return nullptr;
-  for (size_t i = c->pool.size(); i-- > 0;) {
-    if (c->pool[i].first == vb && in_arena(c, c->pool[i].second)) {
-      void *p = c->pool[i].second;
-      c->pool_bytes -= vb;
-      c->pool.erase(c->pool.begin() + (std::ptrdiff_t)i);
-      return p;
-    }
-  }
-  return arena_take(c, vb);
-}
-bool vec_slot_give(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, void *p) {
-  if (p == nullptr || !in_arena(c, p)) return false;
-  const size_t vb = vec_alloc_bytes(n_owned, n_halo);
-  c->pool.emplace_back(vb, (double *)p);
-  c->pool_bytes += vb;
-  return true;
-}
-}  // namespace storm
 
 static int vec_create_impl(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, storm_hip_vec **out, int zero_mode) {
   STORM_REQUIRE(c && out, "vec_create: null argument");

@@ -872,12 +872,9 @@ struct Driver {
   // *ticketed tells whether it did -- then there are no partials to finish (*nblocks is still their count).
   struct CgStep {  // the fused CG step of spmv.hip (CgFuseArgs): end iteration my_iteration - 1, then apply to the new p
     long long my_iteration;
-    double *x;  // null: no x update; p' = r + c p with c from the fields below
+    double *x;
     const double *r;
     double *p_out;
-    const double *cb = nullptr, *cb_den = nullptr;  // (cb == null: beta of the slab)
-    double cb_scale = 1.0;
-    double *cb_store = nullptr;
   };
   int apply(const double *x, double *y, const double *dot_w, bool dot_yy, int *nblocks, bool predicated = true,
             int out0 = -1, int out1 = -1, int *ticketed = nullptr, const CgStep *cg = nullptr) {
@@ -886,7 +883,6 @@ struct Driver {
       sd.cg.iteration = &st->iteration, sd.cg.my_iteration = cg->my_iteration;
       sd.cg.ca = slot(S_ALPHA), sd.cg.cb = slot(S_BETA);
       sd.cg.x = cg->x, sd.cg.r = cg->r, sd.cg.p_out = cg->p_out;
-      if (cg->cb != nullptr) sd.cg.cb = cg->cb, sd.cg.cb_den = cg->cb_den, sd.cg.cb_scale = cg->cb_scale, sd.cg.cb_store = cg->cb_store;
     }
     sd.w = dot_w;
     sd.yy = dot_yy;
@@ -1311,7 +1307,7 @@ int solve_cg_body(const FusedSolveArgs &args) {
       const Driver::CgStep step{(long long)cur_it, x->d, r, p_alt};  // ends iteration cur_it - 1 (SolverCg.hpp:98, :123)
       // (<p,z>: finished inside the marching kernel by tickets where that is on -- option cg_march_ticket --, else
       //  per-wave partials for the final pass below)
-      st_apply = d.apply(p, z, p, false, &nb, true, (c->opt_cg_march_ticket != 0 && !ipc) ? (int)S_PZ : -1, -1, &pz_done, &step);
+      st_apply = d.apply(p, z, p, false, &nb, true, -1, -1, &pz_done, &step);
       std::swap(p, p_alt);
     } else {
       st_apply = d.apply(p, z, p, false, &nb, true, tick_spmv ? (int)S_PZ : -1, -1, &pz_done);
@@ -1422,14 +1418,10 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
   }
   ++c->n_throughput_solves;
   const size_t v0 = pool.v.size();
-  // On a lattice operator (one rank) the first half-step rides in the second apply: the marching kernel forms
-  // s = r - alpha v for the rows it loads (and their neighbours, from THEIR r and v: the same bits), writes it into a
-  // vector of its own and applies the operator to it -- 40 instead of 24 + 32 B/row and one launch fewer.
-  const bool fuse_s = c->opt_bicg_fuse != 0 && c->comm == nullptr && c->opt_fuse_dot != 0 && c->opt_ticket_reduce != 0 &&
-                      c->opt_ticket_verify == 0 && c->opt_graph == 0 && spmv_can_march(op);
-  STORM_TRY(pool.make(x, fuse_s ? 6 : 5, false));  // (r, rt: init; p: the copy of iteration 0; v, t: the SpMVs -- all before any read)
+  // (s = r - alpha v formed inside the second apply -- the marching kernel without its x update -- was measured and dropped:
+  //  452 against 445 us per iteration at 256^3; profiles/experiments/r08_pruned_experiments.patch)
+  STORM_TRY(pool.make(x, 5, false));  // (r, rt: init; p: the copy of iteration 0; v, t: the SpMVs -- all before any read)
   double *p = pool.v[v0]->d, *r = pool.v[v0 + 1]->d, *rt = pool.v[v0 + 2]->d, *t = pool.v[v0 + 3]->d, *v = pool.v[v0 + 4]->d;
-  double *s_vec = fuse_s ? pool.v[v0 + 5]->d : nullptr;
   const int nbv = vec_blocks(c, n);
   const int nbv2 = nbv;  // second half-step: one access per stream in flight, four trips per thread
   int nb = 0;
@@ -1456,9 +1448,9 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
   // last block all-reduces |r|^2, <rt, r> and runs the scalar step -- as on one rank, plus two small launches per iteration.
   IpcDev ipc_w{};
   const bool ipc_tick = c->opt_ticket_reduce != 0 && c->opt_ipc_bicg_ticket != 0 && c->comm != nullptr && comm_ipc_next(c, &ipc_w) &&
-                        nbv <= kTicketGroup * kTicketMaxGroups && !fuse_s;
+                        nbv <= kTicketGroup * kTicketMaxGroups;
   // RCCL: the halo of the vector an update kernel is about to form leaves BEFORE that kernel (comm.hip)
-  const bool early_halo = c->comm != nullptr && comm_is_rccl(c) && c->opt_rccl_early_halo != 0 && op->halo.n_nbrs > 0 && !fuse_s;
+  const bool early_halo = c->comm != nullptr && comm_is_rccl(c) && c->opt_rccl_early_halo != 0 && op->halo.n_nbrs > 0;
   int ticketed = 0;
   auto apply_dir = [&](const double *xin, double *yout, const double *w, bool yy, int out0, int out1) -> int {
     c->spmv_reverse = flip();
@@ -1488,16 +1480,7 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
       const int slots[1] = {S_RTV};
       STORM_TRY(d.finish(nb, 1, slots, STEP_BICG_ALPHA));
     }
-    const bool s_in_apply = fuse_s && alpha_in_kernel;
-    if (s_in_apply) {
-      // s = r - alpha v and t = A s in one launch; alpha = rho / <rt,v> formed by every block, stored by the first   :139-141, :158
-      Driver::CgStep step{0, nullptr, r, s_vec};
-      step.cb = d.slot(S_RHO), step.cb_den = d.slot(S_RTV), step.cb_scale = -1.0, step.cb_store = d.slot(S_ALPHA);
-      c->spmv_reverse = flip();
-      const int st_apply = d.apply(v, t, v, true, &nb, true, (int)S_TR, (int)S_TT, &ticketed, &step);
-      c->spmv_reverse = 0;
-      STORM_TRY(st_apply);
-    } else {
+    {
       // (RCCL: the halo of s leaves now, under this update and the interior rows of the apply)
       if (early_halo && !alpha_in_kernel) STORM_TRY(comm_halo_exchange_begin_formed(op, 0, r, nullptr, v, d.slot(S_ALPHA), nullptr, r));
       // r -= alpha v   (x += alpha p is applied in the second half-step)      :140-141
@@ -1526,10 +1509,6 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
       STORM_TRY(d.finish(nb, 2, slots, STEP_BICG_OMEGA));
     }
     // x = (x + alpha p) + omega r; r -= omega t; |r|, <rt,r>    :140, :161-164 (+ :116 of the next iteration)
-    // (s sits in a vector of its own when the apply formed it: the half-step then updates THAT vector in place -- a
-    //  read-modify-write of one vector is cheaper than reading one and writing another: 142 against 165 us at 256^3 --
-    //  and the two vectors swap roles: the residual of the next iteration lives where s did)
-    if (s_in_apply) std::swap(r, s_vec);
     hipLaunchKernelGGL(bicg_update_kernel<true>, dim3(nbv2), dim3(kBlock), 0, c->stream, n, d.st, x->d, r,
                        p, t, rt, c->d_partials, stream_nt(c, n), flip(), omega_in_kernel ? tickets : no_tickets,
                        (const double *)nullptr, ipc_w, (int)(ipc_tick && omega_in_kernel));

@@ -182,11 +182,10 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
     if (cg_fused) {
       STORM_REQUIRE(spmv_can_fuse_cg(op) && fuse_dot && !accumulate && sd->w == x,
                     "spmv: the fused CG step needs the tiled format-4 kernel");
-      STORM_REQUIRE(sd->cg.x != nullptr || spmv_can_march(op), "spmv: the step without an x update needs the marching kernel");
+      STORM_REQUIRE(sd->cg.x != nullptr, "spmv: the fused CG step updates x");
       dot.tickets = nullptr, dot.nblocks_total = 4 * nb_total;  // (the tiled form of the step leaves per-wave partials)
       if (sd->ticketed_out) *sd->ticketed_out = 0;
-      cgf = CgFuseArgs{sd->cg.iteration, sd->cg.my_iteration, sd->cg.ca, sd->cg.cb, sd->cg.x, sd->cg.r, sd->cg.p_out,
-                       sd->cg.cb_den, sd->cg.cb_scale, sd->cg.cb_store};
+      cgf = CgFuseArgs{sd->cg.iteration, sd->cg.my_iteration, sd->cg.ca, sd->cg.cb, sd->cg.x, sd->cg.r, sd->cg.p_out};
     }
     MarchArgs M;
     int nb_march = 0;
@@ -207,7 +206,6 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
                            cg_fused ? &cgf : nullptr));
   } else {
     const bool cg_fused_part = sd != nullptr && sd->cg.r != nullptr;
-    STORM_REQUIRE(!cg_fused_part || sd->cg.x != nullptr, "spmv: the step without an x update is for unsplit operators");
     if (cg_fused_part) {
       // The fused CG step on a partitioned operator (peer-window transport): ONE marching launch updates x and forms
       // p' on every owned plane, applies the operator to the interior planes and -- its first blocks -- sends p' of the
@@ -260,15 +258,13 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
 __global__ __launch_bounds__(kBlock) void diag_sell_kernel(const char *__restrict__ pack,
                                                            const int64_t *__restrict__ slice_off, int64_t n_rows,
                                                            const double *__restrict__ dict, int fmt2, double alpha,
-                                                           double beta, double *__restrict__ d,
-                                                           const unsigned long long *__restrict__ types) {
+                                                           double beta, double *__restrict__ d) {
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t s = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
   const int64_t r = s * kWave + lane;
   if (r >= n_rows) return;
   if (fmt2 >= 3) {  // paired rows: 128-row groups, weights of row r in word (r % 128), bytes pre-scaled by 8
-    const uint64_t iw = fmt2 == 5 ? types[reinterpret_cast<const unsigned char *>(pack)[r] >> 3]
-                                  : reinterpret_cast<const uint64_t *>(pack + (r >> 7) * (fmt2 == 4 ? kCanonRecBytes : kPairRecBytes))[r & 127];
+    const uint64_t iw = reinterpret_cast<const uint64_t *>(pack + (r >> 7) * (fmt2 == 4 ? kCanonRecBytes : kPairRecBytes))[r & 127];
     double sum = 0.0;
     for (int k = 0; k < 7; ++k) sum += dict[((unsigned)(iw >> (8 * (k + 1))) & 0xffu) >> 3];
     d[r] = beta + alpha * (dict[((unsigned)iw & 0xffu) >> 3] - sum);
@@ -355,8 +351,7 @@ int storm_hip_op_get_diagonal(const storm_hip_op *op, double alpha, double beta,
   const int64_t n64 = (op->n_rows + kWave - 1) / kWave;  // the kernel walks 64-row groups whatever the format
   const int nb = (int)((n64 + (kBlock / kWave) - 1) / (kBlock / kWave));
   hipLaunchKernelGGL(diag_sell_kernel, dim3(nb), dim3(kBlock), 0, c->stream, op->d_pack, op->d_slice_off, op->n_rows,
-                     op->d_dict, op->pair >= 2 ? op->pair + 2 : op->pair ? 3 : (int)(op->offs_size > 0), alpha, beta, d->d,
-                     op->d_types);
+                     op->d_dict, op->pair >= 2 ? op->pair + 2 : op->pair ? 3 : (int)(op->offs_size > 0), alpha, beta, d->d);
   if (op->tail_rows > 0)
     hipLaunchKernelGGL(diag_tail_kernel, dim3((int)((op->tail_rows + 255) / 256)), dim3(256), 0, c->stream,
                        op->tail_rows, op->d_tail_row, op->d_tail_ptr, op->d_tail_val, alpha, d->d);
@@ -396,9 +391,8 @@ int storm_hip_op_destroy(storm_hip_op *op) {
   (void)hipFree(op->d_interior);
   (void)hipFree(op->d_boundary);
   (void)hipFree(op->d_slice_off);
-  if (!(op->ctx && vec_slot_give(op->ctx, op->n_rows, op->n_halo, op->d_pack))) (void)hipFree(op->d_pack);
+  (void)hipFree(op->d_pack);
   (void)hipFree(op->d_bnd_pack);
-  (void)hipFree(op->d_types);
   (void)hipFree(op->d_dict);
   (void)hipFree(op->d_offs);
   (void)hipFree(op->d_tail_row);

@@ -67,21 +67,9 @@ static int upload(T **dst, const std::vector<T> &src, int64_t *bytes) {
   return STORM_HIP_OK;
 }
 
-// The records of a paired-row operator: in a slot of the arena of the vectors the operator is applied to, where they fit
-// (8 B/row records are 288 bytes shorter than such a vector) -- their distance from the vectors is then the arena's.
-static int upload_pack(storm_hip_op *op, const std::vector<char> &src, int64_t *bytes) {
-  storm_hip_ctx *c = op->ctx;
-  if (c->opt_pack_arena != 0 && !src.empty()) {
-    void *p = vec_slot_take(c, op->n_rows, op->n_halo, src.size());
-    if (p != nullptr) {
-      op->d_pack = (char *)p;
-      HIP_TRY(hipMemcpy(op->d_pack, src.data(), src.size(), hipMemcpyHostToDevice));
-      *bytes += (int64_t)src.size();
-      return STORM_HIP_OK;
-    }
-  }
-  return upload(&op->d_pack, src, bytes);
-}
+// (the records in a slot of their vectors' arena -- option pack_arena -- gave no gain: profiles/r05v_pack_arena.jsonl,
+//  profiles/experiments/r08_pruned_experiments.patch)
+static int upload_pack(storm_hip_op *op, const std::vector<char> &src, int64_t *bytes) { return upload(&op->d_pack, src, bytes); }
 
 // The distinct fp64 bit patterns of an operator, while there are at most 256 of them.
 struct ValueDict {
@@ -307,7 +295,6 @@ static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vect
   int canon_len = 0, canon_m1 = -1;
   bool cn = pr && c->opt_spmv_dict >= 4 && 2 * n_bnd_groups <= n_groups && (n_bnd_groups == 0 || c->opt_spmv_mixed != 0);
   std::vector<char> bnd_pack;
-  std::vector<unsigned long long> row_types;  // format 5
   if (cn) {
     // the distinct offsets and who precedes whom in some row; a common order = a linear extension of that relation
     int64_t dist[8];
@@ -409,36 +396,10 @@ static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vect
     timer.lap("canonical order + records");
     op->canon_k = canon_len, op->canon_m1 = canon_m1;
     for (int k = 0; k < 7; ++k) op->canon_off[k] = k < canon_len ? (int)canon[k] : 0;
-    // ... and whether the rows' weight words take few distinct values (format 5): one byte per row
-    if (c->opt_spmv_dict >= 5) {
-      const uint64_t *words = reinterpret_cast<const uint64_t *>(pair_pack.data());
-      const int64_t n_words = n_groups * 2 * kWave;
-      std::vector<unsigned char> typed((size_t)n_words);
-      bool ty = true;
-      uint64_t last = ~0ull;
-      int last_idx = -1;
-      for (int64_t r = 0; ty && r < n_words; ++r) {
-        const uint64_t w = words[r];
-        int idx = (w == last) ? last_idx : -1;
-        for (int t = 0; idx < 0 && t < (int)row_types.size(); ++t) idx = row_types[(size_t)t] == w ? t : -1;
-        if (idx < 0) {
-          if ((int)row_types.size() == kMaxRowTypes) ty = false;
-          else idx = (int)row_types.size(), row_types.push_back(w);
-        }
-        last = w, last_idx = idx;
-        typed[(size_t)r] = (unsigned char)(idx << 3);
-      }
-      if (ty) {
-        pair_pack.assign(reinterpret_cast<const char *>(typed.data()), reinterpret_cast<const char *>(typed.data()) + typed.size());
-        row_types.resize(kMaxRowTypes, 0ull);
-      } else {
-        row_types.clear();
-      }
-    }
   }
   if (pr) {
     // format 3 (or 4) it is: a "slice" of this operator is a 128-row group
-    op->pair = cn ? (row_types.empty() ? 2 : 3) : 1;
+    op->pair = cn ? 2 : 1;
     op->bnd_width = pair_width;
     if (cn) pair_width = canon_len;
     op->n_slices = n_groups;
@@ -446,7 +407,7 @@ static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vect
     op->ell_slots = n_groups * 2 * kWave * pair_width;
     std::vector<int64_t> goff((size_t)n_groups + 1);
     for (int64_t s = 0; s <= n_groups; ++s)
-      goff[(size_t)s] = s * (cn ? (row_types.empty() ? kCanonRecBytes : kTypedRecBytes) : kPairRecBytes);
+      goff[(size_t)s] = s * (cn ? kCanonRecBytes : kPairRecBytes);
     for (int64_t s = 0; s < n_groups; ++s) (grp_bnd[(size_t)s] ? op->h_boundary : op->h_interior).push_back((int)s);
     op->n_interior_slices = (int64_t)op->h_interior.size();
     int st3 = STORM_HIP_OK;
@@ -466,10 +427,6 @@ static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vect
         (st3 = upload(&op->d_slice_off, goff, &bytes3)) || (st3 = upload_pack(op, pair_pack, &bytes3)) ||
         (st3 = upload(&op->d_tail_row, no_i, &bytes3)) || (st3 = upload(&op->d_tail_ptr, one_zero, &bytes3)) ||
         (st3 = upload(&op->d_tail_col, no_i, &bytes3)) || (st3 = upload(&op->d_tail_val, no_d, &bytes3))) {
-      storm_hip_op_destroy(op);
-      return st3;
-    }
-    if (!row_types.empty() && (st3 = upload(&op->d_types, row_types, &bytes3))) {
       storm_hip_op_destroy(op);
       return st3;
     }

@@ -30,9 +30,7 @@ struct SellArgs {
   const int *__restrict__ offs;           // format 2: the column-offset dictionary
   int offs_size;
   int accumulate;                         // y += alpha*M(x) (stormDivGrad's own form) instead of y = beta*x + alpha*M(x)
-  int nt_y = 1;                           // y stored non-temporally (0: it may stay in the Infinity Cache for the consumer)
   int rec_by_pos = 0;                     // paired records stored in slice-LIST order (the boundary groups of a mixed operator)
-  const unsigned long long *types = nullptr;  // format 5: the (<= 32) distinct weight words of the operator's rows
 };
 
 constexpr int kDictSize = 256;
@@ -127,11 +125,6 @@ __device__ __forceinline__ double dpp_shift(double v) {  // lanes without a sour
   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
-// TYPED (format 5): the rows' 8-byte weight words take at most 32 distinct values (a box with uniform spacing: the 27
-// combinations of "which walls does the cell touch") -- a row stores ONE byte, the index of its word in a table held
-// in LDS beside the value table: 1 + 8 + 8 = 17 B/row.
-constexpr int kTypedRecBytes = 2 * kWave;
-constexpr int kMaxRowTypes = 32;
 // G: consecutive 128-row groups per wavefront (1 or 2).  With two, every load of both groups is in flight before the
 // first use, the prologue (tile mapping, tables) and the fused-dot's wave reduction are paid once per 256 rows.
 
@@ -175,11 +168,6 @@ struct CgFuseArgs {
                                // operator to it, nothing else (BiCGStab's s = r - alpha v; t = A s)
   const double *r;
   double *p_out;
-  // BiCGStab's form of the coefficient: cb_den != null -> c = cb_scale * safe_divide(*cb, *cb_den), and the first block
-  // stores safe_divide(*cb, *cb_den) to *cb_store for the kernels behind (alpha = rho / <rt,v>, SolverBiCgStab.hpp:139)
-  const double *cb_den = nullptr;
-  double cb_scale = 1.0;
-  double *cb_store = nullptr;
 };
 
 // ---- the fused CG step, marching in z ------------------------------------------------------------------------------
@@ -203,18 +191,6 @@ struct MarchArgs {
                      // their marches -- instead of a whole march apart, and the second reader finds them in the L2 /
                      // Infinity Cache instead of HBM (the z-halo planes were most of the kernel's 8.7 % over-fetch)
 };
-
-// y stored non-temporally or not, by a RUNTIME flag: the two stores must not look alike to the compiler -- an if / else of a
-// non-temporal and a plain store of the same value to the same address is merged into one plain store (what rounds 1-3
-// shipped: option spmv_nt_y did nothing).  The plain path goes through a laundered pointer.
-__device__ __forceinline__ void store_y(double2v *p, double2v v, int nt) {
-  if (nt) {
-    __builtin_nontemporal_store(v, p);
-  } else {
-    asm volatile("" : "+v"(p));
-    *p = v;
-  }
-}
 
 // ---- the launch interface ------------------------------------------------------------------------------------------
 // One kernel launch of the apply over all slices (slice_list == nullptr) or over one of a partitioned operator's
@@ -271,7 +247,6 @@ static inline SellArgs paired_args(const RangeLaunch &L, int *width) {
   const int group = (L.slice_list == nullptr || L.slice_list == op->d_interior) ? (int)op->ctx->opt_spmv_xcd_remap : 0;
   SellArgs A{op->d_pack, op->d_slice_off, op->n_rows, op->uniform_width, group, op->d_dict, op->dict_size,
              op->d_offs, op->offs_size, (int)L.accumulate};
-  A.nt_y = (int)(op->ctx->opt_spmv_nt_y != 0);
   *width = op->uniform_width;
   if (boundary_of_mixed(L)) {  // the groups that read halo columns: format-3 records of their own, in list order
     A.pack = op->d_bnd_pack, A.rec_by_pos = 1;

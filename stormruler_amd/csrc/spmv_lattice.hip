@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kBlock) void spmv_canon_tile_kernel(SellArgs A, Can
       yi.y = __builtin_fma(alpha, __builtin_fma(ext_b, xi[t][g].y, acc_b), beta * xi[t][g].y);
       if (!done_flag) {
         double2v *yp = reinterpret_cast<double2v *>(yb + (size_t)(rc[t][g] << 3));
-        if (valid_b[t][g]) store_y(yp, yi, A.nt_y);
+        if (valid_b[t][g]) *yp = yi;
         else if (valid_a[t][g]) y[rc[t][g]] = yi.x;  // the odd last row
       }
       if (DOT) {
@@ -215,8 +215,7 @@ __global__ __launch_bounds__(kBlock) void spmv_canon_tile_kernel(SellArgs A, Can
   }
 }
 
-// XUP = false: no x update, no iteration gate (CgFuseArgs::x == null)
-template <int HLP, bool XUP = true>  // HLP: halo pairs per thread and plane: ceil(a / 256)
+template <int HLP>  // HLP: halo pairs per thread and plane: ceil(a / 256)
 __global__ __launch_bounds__(kBlock) void cg_step_march_kernel(SellArgs A, MarchArgs M, Scal alpha_s, Scal beta_s,
                                                                const double *__restrict__ p_in, double *__restrict__ z_out,
                                                                DotArgs dot, const int *done, CgFuseArgs F, IpcSendArgs S) {
@@ -226,9 +225,8 @@ __global__ __launch_bounds__(kBlock) void cg_step_march_kernel(SellArgs A, March
     ipc_halo_send_block(S.w, S.sp, p_in, (int)blockIdx.x, F.r, *F.cb);
     return;
   }
-  if (XUP && *F.iteration < F.my_iteration) return;  // enqueued past convergence: that iteration never ran
+  if (*F.iteration < F.my_iteration) return;  // enqueued past convergence: that iteration never ran
   const int done_flag = done ? *done : 0;
-  if (!XUP && done_flag) return;
   const CanonTileArgs &T = M.T;
   extern __shared__ __attribute__((aligned(16))) double tile_sh[];  // [3][a + kTileRun + a]
   __shared__ double dict_sh[32];
@@ -250,15 +248,7 @@ __global__ __launch_bounds__(kBlock) void cg_step_march_kernel(SellArgs A, March
   const int z_begin = zc * M.zc_planes, z_end = min(z_begin + M.zc_planes, T.plane_end);
   const int ldw = kTileRun + 2 * a;
   const double alpha = ld_scal2(alpha_s), beta = ld_scal2(beta_s);
-  double cg_a = 0.0, cg_b;
-  if (XUP) {
-    cg_a = *F.ca, cg_b = *F.cb;
-  } else {
-    const double num = *F.cb, den = F.cb_den ? *F.cb_den : 1.0;
-    const double quot = F.cb_den ? ((den == 0.0) ? 0.0 : num / den) : num;  // safe_divide, Crow/MathUtils.hpp:54-58
-    cg_b = F.cb_scale * quot;
-    if (F.cb_store != nullptr && mb == 0 && threadIdx.x == 0) *F.cb_store = quot;
-  }
+  const double cg_a = *F.ca, cg_b = *F.cb;
   const uint32_t last_row = (uint32_t)(A.n_rows - 1);
   const char *pb = reinterpret_cast<const char *>(p_in), *rb = reinterpret_cast<const char *>(F.r);
   const char *pg_base = pb - (size_t)kVecGuard * 8, *rg_base = rb - (size_t)kVecGuard * 8;
@@ -288,8 +278,7 @@ __global__ __launch_bounds__(kBlock) void cg_step_march_kernel(SellArgs A, March
       f.p[g] = *reinterpret_cast<const double2v *>(pg_base + (size_t)((uint32_t)gi << 3));
       f.r[g] = *reinterpret_cast<const double2v *>(rg_base + (size_t)((uint32_t)gi << 3));
       if (own) {
-        if constexpr (XUP)
-          f.x[g] = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(reinterpret_cast<const char *>(F.x) + (size_t)(f.rc[g] << 3)));
+        f.x[g] = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(reinterpret_cast<const char *>(F.x) + (size_t)(f.rc[g] << 3)));
         f.w[g] = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(A.pack + (size_t)(f.rc[g] << 3)));
       }
     }
@@ -318,16 +307,11 @@ __global__ __launch_bounds__(kBlock) void cg_step_march_kernel(SellArgs A, March
       out[g] = pn;
       if (own) {
         double2v *pp_ = reinterpret_cast<double2v *>(reinterpret_cast<char *>(F.p_out) + (size_t)(f.rc[g] << 3));
-        if constexpr (XUP) {
-          double2v xn;
-          xn.x = __builtin_fma(cg_a, f.p[g].x, f.x[g].x), xn.y = __builtin_fma(cg_a, f.p[g].y, f.x[g].y);
-          double2v *xp_ = reinterpret_cast<double2v *>(reinterpret_cast<char *>(F.x) + (size_t)(f.rc[g] << 3));
-          if (f.vb[g]) __builtin_nontemporal_store(xn, xp_), __builtin_nontemporal_store(pn, pp_);
-          else if (f.va[g]) F.x[f.rc[g]] = xn.x, F.p_out[f.rc[g]] = pn.x;
-        } else {  // (a plain store: the next kernel reads s)
-          if (f.vb[g]) *pp_ = pn;
-          else if (f.va[g]) F.p_out[f.rc[g]] = pn.x;
-        }
+        double2v xn;
+        xn.x = __builtin_fma(cg_a, f.p[g].x, f.x[g].x), xn.y = __builtin_fma(cg_a, f.p[g].y, f.x[g].y);
+        double2v *xp_ = reinterpret_cast<double2v *>(reinterpret_cast<char *>(F.x) + (size_t)(f.rc[g] << 3));
+        if (f.vb[g]) __builtin_nontemporal_store(xn, xp_), __builtin_nontemporal_store(pn, pp_);
+        else if (f.va[g]) F.x[f.rc[g]] = xn.x, F.p_out[f.rc[g]] = pn.x;
         *reinterpret_cast<double2v *>(&buf[a + 256 * wave + 128 * g + 2 * lane]) = pn;
       }
     }
@@ -342,7 +326,7 @@ __global__ __launch_bounds__(kBlock) void cg_step_march_kernel(SellArgs A, March
     }
   };
 
-  if (XUP && done_flag) {  // converged in that iteration: only x += alpha p is left to do
+  if (done_flag) {  // converged in that iteration: only x += alpha p is left to do
     for (int zp = z_begin; zp < z_end; ++zp) {
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
@@ -424,7 +408,7 @@ __global__ __launch_bounds__(kBlock) void cg_step_march_kernel(SellArgs A, March
       yi.x = __builtin_fma(alpha, __builtin_fma(ext_a, pc[g].x, acc_a), beta * pc[g].x);
       yi.y = __builtin_fma(alpha, __builtin_fma(ext_b, pc[g].y, acc_b), beta * pc[g].y);
       double2v *yp = reinterpret_cast<double2v *>(reinterpret_cast<char *>(z_out) + (size_t)(rcc[g] << 3));
-      if (vbc[g]) store_y(yp, yi, A.nt_y);
+      if (vbc[g]) *yp = yi;
       else if (vac[g]) z_out[rcc[g]] = yi.x;
       yi.x = vac[g] ? yi.x : 0.0;
       yi.y = vbc[g] ? yi.y : 0.0;
@@ -591,19 +575,14 @@ int spmv_march_run(const storm_hip_op *op, const MarchArgs &M, int n_blocks, Sca
     c->prof_used += 2;
   }
   SellArgs A{op->d_pack, op->d_slice_off, op->n_rows, op->uniform_width, 0, op->d_dict, op->dict_size, op->d_offs, op->offs_size, 0};
-  A.nt_y = (int)(c->opt_spmv_nt_y != 0);
   const size_t lds = sizeof(double) * 3 * (size_t)(kTileRun + 2 * M.T.a);
   const int nb = n_blocks + S.sp.n_blocks;
-#define MARCH_GO(HLP_, XUP_)                                                                                                \
-  hipExtLaunchKernelGGL((cg_step_march_kernel<HLP_, XUP_>), dim3(nb), dim3(kBlock), lds, c->stream, ev0, ev1, 0, A, M, alpha, \
+#define MARCH_GO(HLP_)                                                                                                \
+  hipExtLaunchKernelGGL((cg_step_march_kernel<HLP_>), dim3(nb), dim3(kBlock), lds, c->stream, ev0, ev1, 0, A, M, alpha, \
                         beta, x, y, dot, done, cgf, S)
-  if (cgf.x != nullptr) {
-    if (M.T.a <= kBlock) MARCH_GO(1, true);
-    else MARCH_GO(2, true);
-  } else {
-    if (M.T.a <= kBlock) MARCH_GO(1, false);
-    else MARCH_GO(2, false);
-  }
+  STORM_REQUIRE(cgf.x != nullptr, "spmv: the marching step updates x");
+  if (M.T.a <= kBlock) MARCH_GO(1);
+  else MARCH_GO(2);
 #undef MARCH_GO
   HIP_TRY(hipGetLastError());
   return STORM_HIP_OK;

@@ -105,14 +105,13 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(SellArgs A, Scal alph
   }
 }
 
-template <bool DOT, int K, int M1, bool TYPED, int G>
+template <bool DOT, int K, int M1, int G>
 __global__ __launch_bounds__(kBlock) void spmv_canon_kernel(SellArgs A, CanonArgs C, Scal alpha_s, Scal beta_s,
                                                             const double *__restrict__ x, double *__restrict__ y,
                                                             const int *__restrict__ slice_list,
                                                             int64_t n_launch_slices, DotArgs dot, const int *done) {
   const int done_flag = done ? *done : 0;
   __shared__ double dict_sh[32];
-  __shared__ unsigned long long types_sh[TYPED ? kMaxRowTypes : 1];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bidx = C.reverse ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
@@ -141,12 +140,9 @@ __global__ __launch_bounds__(kBlock) void spmv_canon_kernel(SellArgs A, CanonArg
   // -- their LDS copies are needed before anything else can be consumed -- then per group the record, the own rows,
   // all gathers and the two outer neighbours back to back; nothing is consumed before the last load is in flight.
   const double dict_word = A.dict[lane & 31];
-  unsigned long long type_word = 0ull;
-  if (TYPED) type_word = A.types[lane & (kMaxRowTypes - 1)];
   bool valid_a[G], valid_b[G];
   uint32_t rc[G];
   u64x2 vw[G];
-  unsigned type_pair[G];  // (type of row A) | (type of row B) << 8, both pre-scaled by 8
   double2v xi[G], yo[G], wi[G], xg[G][K];
   double e[G];
 #pragma unroll
@@ -156,12 +152,7 @@ __global__ __launch_bounds__(kBlock) void spmv_canon_kernel(SellArgs A, CanonArg
     const uint32_t r0 = slice * (2 * kWave) + 2 * lane;  // row A; row B = r0 + 1
     valid_a[g] = active && r0 <= last_row, valid_b[g] = active && r0 + 1 <= last_row;
     rc[g] = r0 <= last_row ? r0 : (last_row & ~1u);  // pairs past the end re-read the last pair
-    vw[g] = u64x2{0ull, 0ull};
-    type_pair[g] = 0u;
-    if (TYPED)
-      type_pair[g] = __builtin_nontemporal_load(reinterpret_cast<const unsigned short *>(A.pack + (size_t)slice * kTypedRecBytes) + lane);
-    else
-      vw[g] = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(A.pack + (size_t)slice * kCanonRecBytes) + lane);
+    vw[g] = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(A.pack + (size_t)slice * kCanonRecBytes) + lane);
     xi[g] = *reinterpret_cast<const double2v *>(xb + (size_t)(rc[g] << 3));
     yo[g] = double2v{0.0, 0.0}, wi[g] = double2v{0.0, 0.0};
     if (A.accumulate) yo[g] = *reinterpret_cast<const double2v *>(yb + (size_t)(rc[g] << 3));
@@ -184,7 +175,6 @@ __global__ __launch_bounds__(kBlock) void spmv_canon_kernel(SellArgs A, CanonArg
       e[g] = *reinterpret_cast<const double *>(xg_base + (size_t)((rc[g] + (uint32_t)(kVecGuard + (lane == 0 ? -1 : 2))) << 3));
   }
   if (lane < 32) dict_sh[lane] = dict_word;  // one copy per block, every wave stores the same words: no barrier
-  if (TYPED && lane < kMaxRowTypes) types_sh[lane] = type_word;
   __builtin_amdgcn_wave_barrier();  // this wave's copy of the tables is complete (same-wave LDS order)
   double dot_a = 0.0, dot_b = 0.0;
 #pragma unroll
@@ -197,10 +187,6 @@ __global__ __launch_bounds__(kBlock) void spmv_canon_kernel(SellArgs A, CanonArg
       xg[g][M1 >= 0 ? M1 : 0].y = xi[g].x;
       xg[g][M1 >= 0 ? M1 + 1 : 0].x = xi[g].y;
       xg[g][M1 >= 0 ? M1 + 1 : 0].y = lane == kWave - 1 ? e[g] : right;
-    }
-    if (TYPED) {
-      vw[g].x = *reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(types_sh) + (type_pair[g] & 0xffu));
-      vw[g].y = *reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(types_sh) + (type_pair[g] >> 8));
     }
     double acc_a = 0.0, acc_b = 0.0;
 #ifdef STORM_CANON_EXPERIMENT  // (measurement only: the kernel's memory floor -- no table lookups, one add per neighbour)
@@ -222,7 +208,7 @@ __global__ __launch_bounds__(kBlock) void spmv_canon_kernel(SellArgs A, CanonArg
     yi.y = (A.accumulate ? yo[g].y : beta * xi[g].y) + alpha * (acc_b + ext_b * xi[g].y);
     if (!done_flag) {
       double2v *yp = reinterpret_cast<double2v *>(yb + (size_t)(rc[g] << 3));
-      if (valid_b[g]) store_y(yp, yi, A.nt_y);
+      if (valid_b[g]) *yp = yi;
       else if (valid_a[g]) y[rc[g]] = yi.x;  // the odd last row
     }
     if (DOT) {
@@ -285,20 +271,14 @@ static void launch_canon(const RangeLaunch &L, SellArgs A) {
     const int span = kNumXcd * group;
     C.xcd_full = (nb / span) * span;
   }
-  A.types = op->d_types;
-#define CANON_GO2(K_, M1_, T_, G_)                                                                                       \
-  hipExtLaunchKernelGGL((spmv_canon_kernel<DOT, K_, M1_, T_, G_>), dim3(nb), dim3(kBlock), 0, st, ev0, ev1, 0, A, C, alpha, \
+#define CANON_GO2(K_, M1_, G_)                                                                                       \
+  hipExtLaunchKernelGGL((spmv_canon_kernel<DOT, K_, M1_, G_>), dim3(nb), dim3(kBlock), 0, st, ev0, ev1, 0, A, C, alpha, \
                       beta, x, y, slice_list, n_launch, dot, done)
 #define CANON_GO(K_, M1_)                                      \
   do {                                                         \
   const bool two = canon_groups(op) == 2;                    \
-  if (op->pair == 3) {                                       \
-    if (two) CANON_GO2(K_, M1_, true, 2);                    \
-    else CANON_GO2(K_, M1_, true, 1);                        \
-  } else {                                                   \
-    if (two) CANON_GO2(K_, M1_, false, 2);                   \
-    else CANON_GO2(K_, M1_, false, 1);                       \
-  }                                                          \
+  if (two) CANON_GO2(K_, M1_, 2);                            \
+  else CANON_GO2(K_, M1_, 1);                                \
   } while (0)
   if (op->canon_k == 6) CANON_GO(6, 2);
   else if (op->canon_k == 4) CANON_GO(4, 1);

@@ -1,26 +1,16 @@
-// Operator apply, sliced-ELL records: formats 0 (fp64 records, optional LDS window) and 1 / 2 of mixed width through the
-// general kernel, and the CSR tail.  Record layout: the header of spmv.hip.
+// Operator apply, sliced-ELL records: formats 0 (fp64 records) and 1 / 2 of mixed width through the general kernel, and
+// the CSR tail.  Record layout: the header of spmv.hip.
 #include "spmv_device.hpp"
 
 namespace storm {
 
 
 
-// x[c], or the block's LDS copy of it when VARIANT == 1 and c lies in the block's own 256 rows.
-template <int VARIANT>
-__device__ __forceinline__ double gather_x(const double *__restrict__ x, int c, const double *xwin, int64_t row0) {
-  if (VARIANT == 1) {
-    const int64_t d = (int64_t)c - row0;
-    return ((uint64_t)d < (uint64_t)kBlock) ? xwin[d] : x[c];
-  }
-  return x[c];
-}
-
 // sum_k w_k (x[col_k] - x_i) over slots [S0, S0 + W) of a record whose slice has `width` slots
 // (W compile-time, S0 even).  Pairs are read as int2 / double2, an odd last slot unpaired.
-template <bool NT, int VARIANT, int W>
+template <bool NT, int W>
 __device__ __forceinline__ double row_sum(const char *rec, int width, int lane, const double *__restrict__ x,
-                                          double xi, const double *xwin, int64_t row0, int s0 = 0) {
+                                          double xi, int s0 = 0) {
   constexpr int NP = W / 2;
   const int npair_total = width >> 1;
   const int2v *cp2 = reinterpret_cast<const int2v *>(rec + kExtBytes) + lane + (s0 >> 1) * kWave;
@@ -42,10 +32,10 @@ __device__ __forceinline__ double row_sum(const char *rec, int width, int lane, 
   double xg[W > 0 ? W : 1];
 #pragma unroll
   for (int q = 0; q < NP; ++q) {
-    xg[2 * q] = gather_x<VARIANT>(x, c[q].x, xwin, row0);
-    xg[2 * q + 1] = gather_x<VARIANT>(x, c[q].y, xwin, row0);
+    xg[2 * q] = x[c[q].x];
+    xg[2 * q + 1] = x[c[q].y];
   }
-  if (W & 1) xg[W - 1] = gather_x<VARIANT>(x, ct, xwin, row0);
+  if (W & 1) xg[W - 1] = x[ct];
   double acc = 0.0;
 #pragma unroll
   for (int q = 0; q < NP; ++q) {
@@ -57,20 +47,20 @@ __device__ __forceinline__ double row_sum(const char *rec, int width, int lane, 
 }
 
 // Rows wider than 8 slots: chunks of 8, then the remainder.
-template <bool NT, int VARIANT>
+template <bool NT>
 __device__ __forceinline__ double row_sum_wide(const char *rec, int width, int lane, const double *__restrict__ x,
-                                               double xi, const double *xwin, int64_t row0) {
+                                               double xi) {
   double acc = 0.0;
   int s0 = 0;
-  for (; s0 + 8 <= width; s0 += 8) acc += row_sum<NT, VARIANT, 8>(rec, width, lane, x, xi, xwin, row0, s0);
+  for (; s0 + 8 <= width; s0 += 8) acc += row_sum<NT, 8>(rec, width, lane, x, xi, s0);
   switch (width - s0) {
-    case 1: acc += row_sum<NT, VARIANT, 1>(rec, width, lane, x, xi, xwin, row0, s0); break;
-    case 2: acc += row_sum<NT, VARIANT, 2>(rec, width, lane, x, xi, xwin, row0, s0); break;
-    case 3: acc += row_sum<NT, VARIANT, 3>(rec, width, lane, x, xi, xwin, row0, s0); break;
-    case 4: acc += row_sum<NT, VARIANT, 4>(rec, width, lane, x, xi, xwin, row0, s0); break;
-    case 5: acc += row_sum<NT, VARIANT, 5>(rec, width, lane, x, xi, xwin, row0, s0); break;
-    case 6: acc += row_sum<NT, VARIANT, 6>(rec, width, lane, x, xi, xwin, row0, s0); break;
-    case 7: acc += row_sum<NT, VARIANT, 7>(rec, width, lane, x, xi, xwin, row0, s0); break;
+    case 1: acc += row_sum<NT, 1>(rec, width, lane, x, xi, s0); break;
+    case 2: acc += row_sum<NT, 2>(rec, width, lane, x, xi, s0); break;
+    case 3: acc += row_sum<NT, 3>(rec, width, lane, x, xi, s0); break;
+    case 4: acc += row_sum<NT, 4>(rec, width, lane, x, xi, s0); break;
+    case 5: acc += row_sum<NT, 5>(rec, width, lane, x, xi, s0); break;
+    case 6: acc += row_sum<NT, 6>(rec, width, lane, x, xi, s0); break;
+    case 7: acc += row_sum<NT, 7>(rec, width, lane, x, xi, s0); break;
     default: break;
   }
   return acc;
@@ -104,9 +94,8 @@ __device__ __forceinline__ double row_sum_cv(const char *rec, int width, int lan
 // One wavefront per slice, one row per lane, 4 slices per 256-thread block.
 //   NT      : record / y traffic marked non-temporal so it does not evict x from L2 (+15 %).
 //   DOT     : epilogue writes per-block partials of <w, y> and <y, y> (fused reductions).
-//   VARIANT : 0 gathers x straight from global memory (L1/L2/Infinity Cache serve the reuse);
-//             1 stages the block's own 256 x rows in LDS and reads in-window neighbours there
-//               (measured: no gain over 0 -- the +-1 neighbours already hit L1).
+//   VARIANT : 0 fp64 records, 2 value-dictionary records (x is gathered straight from global memory: L1 / L2 / the
+//             Infinity Cache serve the reuse; staging the block's own rows in LDS gave no gain and is gone)
 template <bool NT, bool DOT, int VARIANT, bool XCD>
 __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SellArgs A, Scal alpha_s, Scal beta_s,
                                                            const double *__restrict__ x,
@@ -117,7 +106,6 @@ __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SellArgs A, Scal alph
   // The `done` predicate is only needed before the first store: issue its (scalar) load now and
   // test it after the gathers, so it never sits at the head of a wave's dependency chain.
   const int done_flag = done ? *done : 0;
-  __shared__ double xwin[VARIANT == 1 ? kBlock : 1];
   __shared__ double dict_s[VARIANT == 2 ? kDictSize : 1];
   if (VARIANT == 2) {
     static_assert(kDictSize == kBlock, "one dictionary entry per thread");
@@ -144,13 +132,6 @@ __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SellArgs A, Scal alph
     valid = row < A.n_rows;
     xi = valid ? x[row] : 0.0;
     if (DOT && dot.w) wi = (dot.w == x) ? xi : (valid ? dot.w[row] : 0.0);  // early: off the tail of the chain
-  }
-  int64_t row0 = 0;
-  if (VARIANT == 1) {
-    // Only meaningful when the block's 4 slices are consecutive (no slice list).
-    row0 = (int64_t)lb * kBlock;
-    xwin[threadIdx.x] = xi;
-    __syncthreads();
   }
   if (wave_active) {
     constexpr int kSlot = (VARIANT == 2) ? kColSlotBytes : kSlotBytes;
@@ -186,15 +167,15 @@ __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SellArgs A, Scal alph
     // FMAs -- no branch (and no s_waitcnt) between the gathers of one row.
     switch (width) {
       case 0: acc = 0.0; break;
-      case 1: acc = row_sum<NT, VARIANT, 1>(rec, 1, lane, x, xi, xwin, row0); break;
-      case 2: acc = row_sum<NT, VARIANT, 2>(rec, 2, lane, x, xi, xwin, row0); break;
-      case 3: acc = row_sum<NT, VARIANT, 3>(rec, 3, lane, x, xi, xwin, row0); break;
-      case 4: acc = row_sum<NT, VARIANT, 4>(rec, 4, lane, x, xi, xwin, row0); break;
-      case 5: acc = row_sum<NT, VARIANT, 5>(rec, 5, lane, x, xi, xwin, row0); break;
-      case 6: acc = row_sum<NT, VARIANT, 6>(rec, 6, lane, x, xi, xwin, row0); break;
-      case 7: acc = row_sum<NT, VARIANT, 7>(rec, 7, lane, x, xi, xwin, row0); break;
-      case 8: acc = row_sum<NT, VARIANT, 8>(rec, 8, lane, x, xi, xwin, row0); break;
-      default: acc = row_sum_wide<NT, VARIANT>(rec, width, lane, x, xi, xwin, row0); break;
+      case 1: acc = row_sum<NT, 1>(rec, 1, lane, x, xi); break;
+      case 2: acc = row_sum<NT, 2>(rec, 2, lane, x, xi); break;
+      case 3: acc = row_sum<NT, 3>(rec, 3, lane, x, xi); break;
+      case 4: acc = row_sum<NT, 4>(rec, 4, lane, x, xi); break;
+      case 5: acc = row_sum<NT, 5>(rec, 5, lane, x, xi); break;
+      case 6: acc = row_sum<NT, 6>(rec, 6, lane, x, xi); break;
+      case 7: acc = row_sum<NT, 7>(rec, 7, lane, x, xi); break;
+      case 8: acc = row_sum<NT, 8>(rec, 8, lane, x, xi); break;
+      default: acc = row_sum_wide<NT>(rec, width, lane, x, xi); break;
     }
     }
     yi = (A.accumulate ? (valid ? y[row] : 0.0) : beta * xi) + alpha * (acc + ext * xi);
@@ -250,7 +231,7 @@ static void launch_sell(const storm_hip_op *op, int nb, Scal alpha, Scal beta, c
                         hipEvent_t ev1, bool accumulate) {
   SellArgs A{op->d_pack, op->d_slice_off, op->n_rows, op->uniform_width, (int)op->ctx->opt_spmv_xcd_remap, op->d_dict, op->dict_size,
              op->d_offs, op->offs_size, (int)accumulate};
-  constexpr int LV = (VARIANT == 2) ? 2 : 0;  // listed slices: no LDS window, but the record format stays
+  constexpr int LV = VARIANT;
   hipStream_t st = op->ctx->stream;
   if (slice_list == nullptr && op->ctx->opt_spmv_xcd_remap != 0) {
     hipExtLaunchKernelGGL((spmv_sell_kernel<NT, DOT, VARIANT, true>), dim3(nb), dim3(kBlock), 0, st, ev0, ev1, 0, A, alpha,
@@ -280,7 +261,6 @@ bool spmv_sell_run(const RangeLaunch &L) {
     else    { if (L.want_dot) SPMV_GO(false, true, VAR_); else SPMV_GO(false, false, VAR_); } \
   } while (0)
   if (op->dict_size > 0) SPMV_VAR(2);
-  else if (op->ctx->opt_spmv_variant == 1) SPMV_VAR(1);
   else SPMV_VAR(0);
 #undef SPMV_VAR
 #undef SPMV_GO

@@ -163,7 +163,7 @@ def test_fused_cg_step_kernels_give_the_unfused_iteration(env, shape):
                                        ("march2", 1, 2, 1), ("march5up", 1, 5, 0), ("march3up", 1, 3, 0)):
             ctx.set_option("cg_fuse", fuse)
             ctx.set_option("cg_march", march)
-            ctx.set_option("cg_march_alternate", alt)
+            ctx.set_option("test_disable", 0 if alt else 64)  # (64: every chunk marches upwards)
             for iters in (None, 7):  # to convergence; and stopped by the iteration limit (the tail kernel's x update)
                 s = api.CgSolver()
                 s.record_history = True
@@ -188,58 +188,7 @@ def test_fused_cg_step_kernels_give_the_unfused_iteration(env, shape):
         ctx.set_option("latency_path", 1)
         ctx.set_option("cg_fuse", 1)
         ctx.set_option("cg_march", 8)
-        ctx.set_option("cg_march_alternate", 1)
+        ctx.set_option("test_disable", 0)
         ctx.set_option("cg_march_fill", 2048)
 
 
-@pytest.mark.parametrize("shape", [(64, 32, 24), (34, 34, 17), (256, 8, 8), (20, 6, 9), (128, 16, 11)])
-def test_bicgstab_first_half_step_inside_the_second_apply(env, shape):
-    """BiCGStab on a lattice (`bicg_fuse`): the marching kernel forms s = r - alpha v for the rows it loads, writes it to a
-    vector of its own and applies the operator to it (SolverBiCgStab.hpp:139-141, :158) -- against the loop with the
-    half-step as a kernel of its own: the same residual history to rounding (the partial sums of <t,s>, <t,t> group
-    differently), the same iteration count, the same x; chunks that do and do not divide the plane count; stopped by the
-    iteration limit as well as by convergence."""
-    api, mesh, oracle, ctx = env
-    g = mesh.structured_box(*shape, lengths=tuple(s / 128.0 for s in shape))
-    ctx.set_option("latency_path", 0)
-    ctx.set_option("spmv_canon_tile_min_rows", 0)
-    ctx.set_option("spmv_canon_tile", 2)
-    ctx.set_option("cg_march_fill", 0)
-    try:
-        mat = api.StencilMatrix.from_face_graph(ctx, g)
-        assert mat.stats()["tiled_planes"] == 2
-        b_host = 1.0 + 0.5 * np.sin(0.05 * np.arange(g.n_cells))
-        b = api.DeviceVector.from_numpy(ctx, b_host)
-        res = {}
-        for name, fuse, march in (("unfused", 0, 8), ("march8", 1, 8), ("march5", 1, 5), ("march2", 1, 2)):
-            ctx.set_option("bicg_fuse", fuse)
-            ctx.set_option("cg_march", march)
-            for iters in (None, 6):
-                s = api.BiCgStabSolver()
-                s.record_history = True
-                if iters is not None:
-                    s.num_iterations = iters
-                x = api.DeviceVector(ctx, g.n_cells)
-                ok = s.solve(x, b, api.HipStencilOperator(mat, -1.0, 0.0))
-                res[(name, iters)] = (ok, s.iteration, np.array(s.history), x.to_numpy())
-        for iters in (None, 6):
-            ok0, it0, h0, x0 = res[("unfused", iters)]
-            assert ok0 == (iters is None)
-            for name in ("march8", "march5", "march2"):
-                ok1, it1, h1, x1 = res[(name, iters)]
-                # (BiCGStab amplifies a last-place difference by ~10x every two iterations -- DESIGN 5c: the first dozen
-                #  residuals agree to rounding; on these small, badly scaled boxes the iteration counts differ by up to ~12 %)
-                m = min(len(h0), len(h1), 7)
-                assert np.allclose(h1[:m], h0[:m], rtol=1e-11), name
-                assert ok1 == ok0 and abs(it1 - it0) <= (max(3, it0 // 6) if iters is None else 0), (name, iters, it1, it0)
-                assert np.linalg.norm(x1 - x0) <= 2e-6 * np.linalg.norm(x0), name
-        ref = oracle.solve("bicgstab", oracle.StencilOperator(g, -1.0, 0.0), b_host)
-        assert abs(res[("march8", None)][1] - ref.iterations) <= max(3, ref.iterations // 6)
-        assert np.linalg.norm(res[("march8", None)][3] - ref.x) <= 2e-6 * np.linalg.norm(ref.x)
-        mat.close()
-    finally:
-        ctx.set_option("latency_path", 1)
-        ctx.set_option("bicg_fuse", 0)
-        ctx.set_option("cg_march", 8)
-        ctx.set_option("cg_march_fill", 2048)
-        ctx.set_option("spmv_canon_tile_min_rows", 1 << 20)

@@ -202,40 +202,17 @@ def test_vector_storage_pool_reuse_is_invisible():
     ctx.close()
 
 
-@pytest.mark.parametrize("cls", ["CgSolver", "BiCgStabSolver"])
-def test_hipgraph_replay_option_gives_the_same_solve(cls):
-    """Option `graph` (off by default: measured slower than eager launches) replays captured iterations; the
-    device-side `done` predicate and the iteration-keyed kernels must behave identically under replay."""
-    from stormruler_amd import api, mesh
-
-    g = mesh.structured_box(20)
-    res = {}
-    for graph in (0, 1):
-        ctx = api.Context(0)
-        ctx.set_option("graph", graph)
-        mat = api.StencilMatrix.from_face_graph(ctx, g)
-        b = api.DeviceVector.from_numpy(ctx, np.ones(g.n_cells))
-        x = api.DeviceVector(ctx, g.n_cells)
-        s = getattr(api, cls)()
-        assert s.solve(x, b, api.HipStencilOperator(mat, -1.0, 0.0))
-        res[graph] = (s.iteration, s.absolute_error, x.to_numpy())
-        ctx.close()
-    assert res[0][0] == res[1][0]
-    assert np.array_equal(res[0][2], res[1][2])
-
-
 @pytest.mark.parametrize("cls", ["CgSolver", "BiCgStabSolver", "GmresSolver", "CgsSolver"])
 def test_host_poll_without_stream_markers_gives_the_same_solve(cls):
     """The host follows a solve through self-validating words the step kernels post into a pinned ring (no event behind
-    every iteration: common.hpp ring_wait); option poll_events = 1 brings the markers back.  Same iteration count and
-    bits either way, for every lag, when the solve converges, runs out of iterations or has nothing to iterate."""
+    every iteration: common.hpp ring_wait).  Same iteration count and bits for every lag, when the solve converges, runs
+    out of iterations or has nothing to iterate."""
     from stormruler_amd import api, mesh
 
     g = mesh.structured_box(24)
     res = {}
-    for events in (0, 1):
+    for events in (0,):
         ctx = api.Context(0)
-        ctx.set_option("poll_events", events)
         ctx.set_option("latency_path", 0)  # (the kernel-per-statement loops are the ones that poll)
         mat = api.StencilMatrix.from_face_graph(ctx, g)
         b = api.DeviceVector.from_numpy(ctx, np.ones(g.n_cells))
@@ -249,9 +226,7 @@ def test_host_poll_without_stream_markers_gives_the_same_solve(cls):
                 res[(events, lag, iters, tol)] = (ok, s.iteration, s.absolute_error, x.to_numpy())
         ctx.close()
     for key, v in res.items():
-        if key[0] == 1:
-            continue
-        w = res[(1,) + key[1:]]
+        w = res[(0, 4) + key[2:]] if (0, 4) + key[2:] in res else res[(0, 7) + key[2:]]  # (the same solve with another lag)
         assert v[0] == w[0] and v[1] == w[1] and v[2] == w[2] and np.array_equal(v[3], w[3]), key
         if key[3] == 0.0:
             assert v[1] == key[2]

@@ -82,7 +82,7 @@ def test_the_latency_path_is_left_when_no_register_variant_fits(env):
 def test_ordinary_and_cooperative_launch_of_the_one_kernel_paths_agree(env, kind):
     """The one-kernel paths synchronise through memory; by default they are launched like any kernel (the runtime's
     cooperative launch runs on a queue of its own and costs two ~12 us gaps around every launch -- once per Arnoldi
-    step for GMRES).  Option `coop_plain = 0` brings hipLaunchCooperativeKernel back: the same bits either way, and
+    step for GMRES).  Test hook `test_disable` bit 32 brings hipLaunchCooperativeKernel back: the same bits either way, and
     neither is a fallback."""
     api, mesh, oracle, ctx = env
     g = mesh.structured_box(24, 20, 18)
@@ -91,11 +91,11 @@ def test_ordinary_and_cooperative_launch_of_the_one_kernel_paths_agree(env, kind
     res = {}
     try:
         for plain in (1, 0):
-            ctx.set_option("coop_plain", plain)
+            ctx.set_option("test_disable", 0 if plain else 32)
             ok, s, x = _solve(api, ctx, kind, mat, g, x0)
             assert ok and s.path_fallback == 0
             res[plain] = (s.iteration, s.absolute_error, x)
     finally:
-        ctx.set_option("coop_plain", 1)
+        ctx.set_option("test_disable", 0)
         mat.close()
     assert res[0][0] == res[1][0] and res[0][1] == res[1][1] and np.array_equal(res[0][2], res[1][2])

@@ -231,7 +231,6 @@ def test_cooperative_gram_schmidt_chain_matches_the_kernel_per_step_path(env, sh
     for coop in (1, 0, "reg", "lds", "quad"):
         for generic in ((0, 1) if coop in (0, 1) else (0,)):  # the fused loop and the engine share the chain
             ctx.set_option("coop_mgs", 0 if coop == 0 else 1)
-            ctx.set_option("coop_mgs_min_rows", 0)
             ctx.set_option("coop_mgs_lds", {"reg": 0, "lds": 2, "quad": 0}.get(coop, 1))
             ctx.set_option("coop_mgs_quad", {"reg": 0, "lds": 0, "quad": 2}.get(coop, 1))
             ctx.set_option("generic_solvers", generic)
@@ -241,7 +240,6 @@ def test_cooperative_gram_schmidt_chain_matches_the_kernel_per_step_path(env, sh
             ok = s.solve(x, b, op)
             runs[(coop, generic)] = (ok, s.iteration, s.history.copy(), x.to_numpy())
     ctx.set_option("coop_mgs", 1)
-    ctx.set_option("coop_mgs_min_rows", 0)
     ctx.set_option("coop_mgs_lds", 1)
     ctx.set_option("coop_mgs_quad", 1)
     ctx.set_option("generic_solvers", 0)
@@ -286,7 +284,7 @@ def test_latency_path_is_bitwise_reproducible(env, kind, shape):
 
 @pytest.mark.parametrize("shape", [(48, 40, 36), (64, 64, 33), (20, 18, 16)])
 def test_chain_kernel_applies_the_operator_itself_with_the_same_bits(shape):
-    """GMRES's Arnoldi step w = A q_k (SolverGmres.hpp:155) inside the Gram-Schmidt chain kernel (option coop_mgs_apply;
+    """GMRES's Arnoldi step w = A q_k (SolverGmres.hpp:155) inside the Gram-Schmidt chain kernel (test hook test_disable bit 1 switches it off;
     latency.hip: mgs_chain_quad_kernel<S, T, true>) -- spmv_canon_kernel's arithmetic on the thread's own row pairs: the
     residual histories and the solutions are BITWISE those of the launch-then-chain form, for the symmetric and the
     convection-diffusion operator; a chain variant that cannot apply gets the launch in front of it."""
@@ -299,12 +297,11 @@ def test_chain_kernel_applies_the_operator_itself_with_the_same_bits(shape):
     mats = {"poisson": (api.StencilMatrix.from_face_graph(ctx, g), -1.0),
             "convdiff": (api.StencilMatrix.from_face_weights(ctx, g.n_cells, g.n_halo, g.inner, g.outer, wi, wo, de), 1.0)}
     b_host = 1.0 + 0.3 * np.sin(0.02 * np.arange(g.n_cells))
-    ctx.set_option("coop_mgs_min_rows", 0)
     for name, (mat, alpha) in mats.items():
         assert mat.stats()["paired_rows"] == 2
         runs = {}
         for key, apply_opt, quad in (("launch", 0, 1), ("fused", 1, 1), ("register chain", 1, 0)):
-            ctx.set_option("coop_mgs_apply", apply_opt)
+            ctx.set_option("test_disable", 0 if apply_opt else 1)  # (1: the apply as a launch in front of the chain)
             ctx.set_option("coop_mgs_quad", quad)
             s = api.GmresSolver()
             s.num_inner_iterations, s.record_history, s.num_iterations = 20, True, 55
@@ -322,7 +319,7 @@ def test_chain_kernel_applies_the_operator_itself_with_the_same_bits(shape):
 
 @pytest.mark.parametrize("shape", [(64, 64, 33), (100, 50, 40), (20, 18, 16), (128, 128, 112), (128, 128, 128)])
 def test_chain_prefetch_under_the_all_reduce_changes_no_bit(shape):
-    """Options coop_mgs_prefetch / coop_mgs_lds_prefetch: the next group's basis vectors requested between the block's
+    """Test hook test_disable bit 2 off / on: the next group's basis vectors requested between the block's
     arrival at the all-reduce and its wait for the others (co_allreduce_dense_arrive / _wait) -- into registers up to four
     row pairs per thread, the first vector into registers and the others through LDS (LDS-DMA) at eight (the 128^3 of
     BASELINE config 4; ragged last block at 112 planes) -- loads moved, nothing else: histories and solutions bitwise equal."""
@@ -332,11 +329,9 @@ def test_chain_prefetch_under_the_all_reduce_changes_no_bit(shape):
     g = mesh.structured_box(*shape, lengths=tuple(s / 64.0 for s in shape))
     mat = api.StencilMatrix.from_face_graph(ctx, g)
     b_host = 1.0 + 0.3 * np.sin(0.02 * np.arange(g.n_cells))
-    ctx.set_option("coop_mgs_min_rows", 0)
     runs = []
     for pf in (0, 1):
-        ctx.set_option("coop_mgs_prefetch", pf)
-        ctx.set_option("coop_mgs_lds_prefetch", pf)
+        ctx.set_option("test_disable", 0 if pf else 2)  # (2: no prefetch under the all-reduce)
         s = api.GmresSolver()
         s.num_inner_iterations, s.record_history, s.num_iterations = 30, True, 75
         s.absolute_error_tolerance = s.relative_error_tolerance = 0.0

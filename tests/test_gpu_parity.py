@@ -280,10 +280,9 @@ def test_spmv_forced_small_ell_cap(api, oracle):
     c2.close()
 
 
-@pytest.mark.parametrize("variant,nt", [(0, 0), (0, 1), (1, 0), (1, 1)])
-def test_spmv_kernel_variants_agree(api, oracle, variant, nt):
+@pytest.mark.parametrize("nt", [0, 1])
+def test_spmv_kernel_variants_agree(api, oracle, nt):
     c2 = api.Context(0)
-    c2.set_option("spmv_variant", variant)
     c2.set_option("nontemporal", nt)
     g = _mesh().structured_box(40, 33, 17)
     x = np.sin(0.37 * np.arange(g.n_cells))

@@ -274,13 +274,13 @@ def test_coefficients_kept_from_plane_to_plane_give_the_same_bits(env, shape, pl
             op = api.HipStencilOperator(mats[kind], alpha, 0.0)
             runs = {}
             for cache in (0, 1):
-                ctx.set_option("resident_apply_cache", cache)
+                ctx.set_option("test_disable", 0 if cache else 4)
                 ok, s, x, taken = _solve(api, ctx, cls, op, b_host, True, planes, num_iterations=60)
                 assert taken == 1 and s.path_fallback == 0
                 runs[cache] = (np.asarray(s.history), x)
             assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1]), kind
     finally:
-        ctx.set_option("resident_apply_cache", 1)
+        ctx.set_option("test_disable", 0)
         for m in mats.values():
             m.close()
 
@@ -298,11 +298,11 @@ def test_halo_formed_before_or_behind_the_update_of_the_own_rows_gives_the_same_
     try:
         runs = {}
         for il in (0, 1):
-            ctx.set_option("resident_halo_interleave", il)
+            ctx.set_option("test_disable", 0 if il else 8)
             ok, s, x, taken = _solve(api, ctx, api.CgSolver, op, b_host, True, planes)
             assert taken == 1 and s.path_fallback == 0 and ok
             runs[il] = (np.asarray(s.history), x)
         assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
     finally:
-        ctx.set_option("resident_halo_interleave", 1)
+        ctx.set_option("test_disable", 0)
         mat.close()

@@ -2,7 +2,7 @@
 
 * blas1_nt (csrc/blas1_device.hpp: nt_dispatch): non-temporal or plain loads and stores of the BLAS-1 / solver kernels --
   the same values, the same order of every sum: solver histories and BLAS-1 results are BITWISE equal in both modes;
-  the default mode switches at blas1_nt_rows rows per vector.
+  the default mode switches at 6 * 2^20 rows per vector.
 * mgs_steps (csrc/solvers.hip: mgs_pair_kernel / mgs_multi_kernel): two, three or four modified-Gram-Schmidt steps per
   pass over w (SolverGmres.hpp:157-161) -- the coefficients follow from bilinearity, so the histories agree to rounding,
   not bitwise.
@@ -76,21 +76,6 @@ def test_nontemporal_mode_of_the_blas1_entry_points_is_bitwise_equal(env):
     assert out[0][2] == out[1][2] and out[0][3] == out[1][3]
 
 
-def test_default_mode_switches_to_nontemporal_at_blas1_nt_rows(env):
-    """blas1_nt = 1 (default): plain below blas1_nt_rows rows, non-temporal from there on -- checked through the values
-    (identical either way) and through the option round trip; the measured effect is in DESIGN.md section 4."""
-    api, mesh, ctx = env
-    g = mesh.structured_box(24)
-    mat = api.StencilMatrix.from_face_graph(ctx, g)
-    b_host = np.ones(g.n_cells)
-    ref = _history(api, ctx, api.CgSolver, mat, b_host, 30)
-    ctx.set_option("blas1_nt_rows", 1000)  # this 13 824-row problem now streams non-temporally
-    got = _history(api, ctx, api.CgSolver, mat, b_host, 30)
-    ctx.set_option("blas1_nt_rows", 6 << 20)
-    assert np.array_equal(ref[0], got[0]) and np.array_equal(ref[1], got[1])
-    mat.close()
-
-
 @pytest.mark.parametrize("shape", [(48, 40, 36), (31, 29, 23)])
 def test_gram_schmidt_pass_widths_agree_to_rounding(env, shape):
     from stormruler_amd import mesh as mesh_mod
@@ -146,28 +131,4 @@ def test_vector_arenas_change_where_vectors_lie_and_nothing_else():
         assert np.array_equal(h0, h1) and np.array_equal(x0, x1)
 
 
-def test_operator_records_in_the_vectors_arena_option():
-    """Option pack_arena (off by default: measured, no gain): a format-4 operator's records take a slot of the arena of
-    the vectors it is applied to and give it back when the operator is destroyed."""
-    from stormruler_amd import api, mesh
 
-    g = mesh.structured_box(64)
-    x_host = np.sin(0.37 * np.arange(g.n_cells))
-    ys = []
-    for opt in (0, 1):
-        ctx = api.Context(0)
-        ctx.set_option("pack_arena", opt)
-        for _ in range(3):  # build, apply, destroy: the slot returns to the pool and is taken again
-            mat = api.StencilMatrix.from_face_graph(ctx, g)
-            assert mat.stats()["paired_rows"] == 2
-            x, y = api.DeviceVector.from_numpy(ctx, x_host), api.DeviceVector(ctx, g.n_cells)
-            mat.apply(-1.0, 0.0, x, y)
-            ys.append(y.to_numpy())
-            vs = [api.DeviceVector.from_numpy(ctx, x_host + k) for k in range(9)]  # crowd the arena around the records
-            mat.apply(-1.0, 0.0, x, y)
-            assert np.array_equal(y.to_numpy(), ys[-1])
-            assert np.array_equal(vs[8].to_numpy(), x_host + 8)
-            del vs, x, y
-            mat.close()
-        ctx.close()
-    assert all(np.array_equal(ys[0], v) for v in ys[1:])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Cost of the multi-rank code path with the network taken out: one rank, a communicator of size 1 (RCCL, then the
-peer-window transport in its fused form -- "ipc": the interior launch sends, the boundary launch reads the window, the
-reductions' finishing block all-reduces -- and with stand-alone send / receive-copy kernels, "ipc0"), a z-periodic
+peer-window transport -- "ipc": the interior launch sends, the boundary launch reads the window, the reductions'
+finishing block all-reduces), a z-periodic
 256^3 box whose two halo planes are exchanged with the rank itself, against the plain single-GPU path on the same
 box.  What remains at N > 1 beyond this is the latency of the real exchanges."""
 import json
@@ -51,15 +51,13 @@ ctx.close()
 loc, send_idx = _periodic_z_local_graph(n, n, n)
 # the halo operator: MIXED records by default (format 4 where rows read no halo column, format 3 in the outer
 # planes) -- compared with the plain format-4 operator; spmv_mixed = 0 (format 3 throughout) with plain format 3
-for transport in ((only,) if only else ("rccl", "ipc", "ipc0")):
+for transport in ((only,) if only else ("rccl", "ipc")):
     for mixed in ((1,) if only else (1, 0)):
         ctx = api.Context(0)
         ctx.set_option("spmv_mixed", mixed)
         for kv in os.environ.get("COMM_OPTS", "").split(","):  # e.g. COMM_OPTS=rccl_flag_wait=0
             if "=" in kv:
                 ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
-        if transport == "ipc0":  # peer windows, stand-alone send / receive-copy kernels instead of the fused form
-            ctx.set_option("ipc_fused", 0)
         if transport == "rccl":
             ctx.comm_init(api.Context.comm_unique_id(), 1, 0)
         else:  # peer windows: the single rank maps its own window

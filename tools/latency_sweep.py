@@ -60,9 +60,9 @@ def main():
             thr = rate(ctx, op, b, g.n_cells, False, cls=cls)
             res = rate(ctx, op, b, g.n_cells, True, cls=cls, mode="resident")
             dflt = rate(ctx, op, b, g.n_cells, True, cls=cls, mode="default")
-            ctx.set_option("latency_publish", 0)  # rows published with write-through stores (round 2) instead of awaited exchanges
+            ctx.set_option("test_disable", 16)  # rows published with write-through stores (round 2) instead of awaited exchanges
             lat_store = None if big else rate(ctx, op, b, g.n_cells, True, cls=cls)
-            ctx.set_option("latency_publish", 1)
+            ctx.set_option("test_disable", 0)
             line = {"solver": name, "mesh": kind if shape is None else "x".join(map(str, shape)), "rows": g.n_cells,
                     "resident_path_us_per_iteration": res, "default_path_us_per_iteration": dflt,
                     "latency_path_us_per_iteration": lat, "latency_path_store_published_us": lat_store,
