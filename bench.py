@@ -794,7 +794,7 @@ def baseline_configs(api, mesh, ctx, op, b, N, n, st, min_seconds):
     # ---- config 3
     try:
         sec, reps = rate(api.BiCgStabSolver, op, b, N, 60)
-        moved = 2 * (st["record_bytes"] + 16 * N) + 104 * N  # two applies + the fused vector passes
+        moved = 2 * (st["record_bytes"] + 16 * N) + 104 * N  # two applies + the fused vector passes (NOTES.md section 4)
         out["config3_bicgstab256"] = {
             "workload": f"BiCGStab, {n}^3 Poisson block (BASELINE configs[2]'s per-GPU problem), 60 iterations, tolerances off",
             "iter_per_s": 1.0 / sec, "us_per_iteration": sec * 1e6, "bytes_really_moved_per_iteration": moved,
@@ -979,7 +979,7 @@ def tet_files(n3, workdir):
     return prefix, sec, size
 
 
-def tet_operator(api, ctx, prefix):
+def tet_operator(api, ctx, prefix, file_order_probe=None):
     """<prefix>.node/.edge/.face/.ele -> the library's reader (3-D branch of read_mesh_from_tetgen) -> Morton order of the
     cell centres -> the operator.  Returns (host mesh, operator, seconds by step)."""
     from stormruler_amd import host_mesh
@@ -988,6 +988,10 @@ def tet_operator(api, ctx, prefix):
     t0 = time.time()
     hm = host_mesh.HostMesh.read_tetgen(prefix + ".", 3)
     sec["read_files_and_build_face_graph"] = time.time() - t0
+    if file_order_probe is not None:  # the operator in FILE order first: what the ordering must conjugate, not change
+        m0 = hm.create_operator(ctx)
+        file_order_probe(m0)
+        m0.close()
     t0 = time.time()
     kind = hm.order_cells("morton")
     sec["morton_ordering"] = time.time() - t0
@@ -1004,7 +1008,18 @@ def tet_variant(api, ctx, args, prefix, file_seconds, file_bytes, traffic_bytes,
     (spmv_sell_kernel, fp64 records: streamed bytes == SURVEY 8d's algorithmic bytes, but for the ELL padding)."""
     import numpy as np
 
-    hm, mat, sec = tet_operator(api, ctx, prefix)
+    probe = {}
+
+    def file_order_probe(m0):  # K CG iterations on the operator as the files number it
+        n0 = m0.stats()["n_rows"]
+        b0, x0 = api.DeviceVector(ctx, n0), api.DeviceVector(ctx, n0)
+        api.fill_with(b0, 1.0)
+        s0 = api.CgSolver()
+        s0.num_iterations, s0.absolute_error_tolerance, s0.relative_error_tolerance = args.steps, 0.0, 0.0
+        s0.solve(x0, b0, api.HipStencilOperator(m0, -1.0, 0.0))
+        probe["residual"] = s0.absolute_error
+
+    hm, mat, sec = tet_operator(api, ctx, prefix, file_order_probe)
     sec = dict(file_seconds, **sec)
     st = mat.stats()
     v = hm.view()
@@ -1057,6 +1072,9 @@ def tet_variant(api, ctx, args, prefix, file_seconds, file_bytes, traffic_bytes,
            "max_row_len": st["max_row_len"], "ell_slots": st["ell_slots"],
            "ell_padding_ratio": st["ell_slots"] / max(st["nnz_offdiag"] - st["tail_nnz"], 1) - 1.0, "tail_nnz": st["tail_nnz"],
            "cg_iter_per_s": K / t1, "ms_per_step": t1 / K * 1e3, "cg_final_residual": s_.absolute_error,
+           # b = 1 is invariant under a renumbering: the ordered operator is the file-order one conjugated by a permutation, so
+           # K iterations leave the same residual (to the rounding of differently grouped sums)
+           "final_residual_rel_diff_vs_file_order": abs(s_.absolute_error - probe["residual"]) / probe["residual"] if probe else None,
            "cg_reference_op_list_bytes_per_iteration": alg + 96 * n_rows,
            "host_seconds": sec, "tetgen_files_bytes": file_bytes}
     band = np.abs(np.ctypeslib.as_array(v.inner, shape=(v.n_faces,)) - np.ctypeslib.as_array(v.outer, shape=(v.n_faces,)))

@@ -88,7 +88,7 @@ bool lattice_order(int dim, int64_t n, const double *c, const double *lo, const 
   return clash.load() == 0;
 }
 
-void morton_order(int dim, int64_t n, const double *c, const double *lo, const double *hi, int nt, int64_t *order) {
+void morton_order(int dim, int64_t n, const double *c, const double *lo, const double *hi, int nt, int64_t *order, bool hilbert = false) {
   const int bits = dim >= 3 ? 21 : dim == 2 ? 31 : 62;
   double scale[3] = {0, 0, 0};
   for (int d = 0; d < dim; ++d) scale[d] = hi[d] > lo[d] ? (double)(((uint64_t)1 << bits) - 1) / (hi[d] - lo[d]) : 0.0;
@@ -105,8 +105,32 @@ void morton_order(int dim, int64_t n, const double *c, const double *lo, const d
   };
   par_for(n, nt, [&](int, int64_t s, int64_t e) {
     for (int64_t i = s; i < e; ++i) {
+      uint64_t X[3] = {0, 0, 0};
+      for (int d = 0; d < dim; ++d) X[d] = (uint64_t)((c[i * dim + d] - lo[d]) * scale[d] + 0.5);
       uint64_t key = 0;
-      for (int d = 0; d < dim; ++d) key |= spread((uint64_t)((c[i * dim + d] - lo[d]) * scale[d] + 0.5)) << d;
+      if (hilbert && dim > 1) {
+        // the Hilbert curve through the same quantised points (J. Skilling, "Programming the Hilbert curve", 2004:
+        // axes -> transposed index): consecutive keys are always face-adjacent boxes -- no jumps across the domain
+        const uint64_t M = 1ull << (bits - 1);
+        for (uint64_t Q = M; Q > 1; Q >>= 1) {
+          const uint64_t P = Q - 1;
+          for (int d = 0; d < dim; ++d) {
+            if (X[d] & Q) X[0] ^= P;
+            else {
+              const uint64_t t = (X[0] ^ X[d]) & P;
+              X[0] ^= t, X[d] ^= t;
+            }
+          }
+        }
+        for (int d = 1; d < dim; ++d) X[d] ^= X[d - 1];
+        uint64_t t = 0;
+        for (uint64_t Q = M; Q > 1; Q >>= 1)
+          if (X[dim - 1] & Q) t ^= Q - 1;
+        for (int d = 0; d < dim; ++d) X[d] ^= t;
+        for (int d = 0; d < dim; ++d) key |= spread(X[d]) << (dim - 1 - d);  // (axis 0 carries the leading bit of a group)
+      } else {
+        for (int d = 0; d < dim; ++d) key |= spread(X[d]) << d;
+      }
       a[(size_t)i] = KV{key, i};
     }
   });
@@ -167,7 +191,7 @@ extern "C" int storm_hip_order_cells(int32_t dim, int64_t n_cells, const double 
 static int order_cells_impl(int32_t dim, int64_t n_cells, const double *centers, int32_t mode, int64_t *order, int32_t *kind) {
   STORM_REQUIRE(dim >= 1 && dim <= 3 && n_cells >= 0 && (centers || n_cells == 0) && (order || n_cells == 0),
                 "order_cells: bad argument");
-  STORM_REQUIRE(mode >= 0 && mode <= 2, "order_cells: mode 0 (lattice, else Morton), 1 (Morton), 2 (lattice or fail)");
+  STORM_REQUIRE(mode >= 0 && mode <= 3, "order_cells: mode 0 (lattice, else Morton), 1 (Morton), 2 (lattice or fail), 3 (Hilbert)");
   if (kind) *kind = 0;
   if (n_cells == 0) return STORM_HIP_OK;
   const int nt = order_threads();
@@ -191,6 +215,11 @@ static int order_cells_impl(int32_t dim, int64_t n_cells, const double *centers,
   }
   for (int d = 0; d < dim; ++d)
     STORM_REQUIRE(std::isfinite(lo[d]) && std::isfinite(hi[d]), "order_cells: non-finite cell centre");
+  if (mode == 3) {
+    morton_order(dim, n_cells, centers, lo, hi, nt, order, true);
+    if (kind) *kind = 3;
+    return STORM_HIP_OK;
+  }
   if (mode != 1 && lattice_order(dim, n_cells, centers, lo, hi, nt, order)) {
     if (kind) *kind = 1;
     return STORM_HIP_OK;

@@ -46,7 +46,7 @@
 //   -- the difference form of the reference's flux  (c[out] - c[in]), which keeps the
 //   cancellation behaviour of the face loop (no large diagonal * x_i term).
 //
-// Translation units (DESIGN.md section 3 has the table): spmv_device.hpp -- argument structs, helpers, the launch
+// Translation units (NOTES.md, "Source layout and dispatch of the apply", has the table): spmv_device.hpp -- argument structs, helpers, the launch
 // interface; spmv_sell.hip, spmv_dict.hip, spmv_pair.hip, spmv_lattice.hip -- one per kernel family, each exporting
 // launchers that take a RangeLaunch; spmv_build.hip -- the host-side build and the create entry points; this file --
 // the dispatch (which launches make up an apply, which format takes each), the diagonal and the apply entry points.

@@ -1,6 +1,6 @@
 // Shared by the translation units of the operator apply (spmv.hip and spmv_*.hip): record constants, kernel argument
 // structs, the small device helpers every format's kernel uses, and the launch interface between the dispatch in
-// spmv.hip and the per-format units.  DESIGN.md section 3 has the table of formats and who owns which.
+// spmv.hip and the per-format units.  DESIGN.md section 3 lists the formats, NOTES.md ("Source layout and dispatch of the apply") who owns which.
 #pragma once
 #include <hip/hip_ext.h>
 

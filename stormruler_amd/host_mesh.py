@@ -99,10 +99,10 @@ class HostMesh:
         v = self.view()
         order = np.empty(v.n_cells, np.int64)
         kind = C.c_int32(0)
-        check(lib.storm_hip_order_cells(v.dim, v.n_cells, v.center, {"auto": 0, "morton": 1, "lattice": 2}[mode],
+        check(lib.storm_hip_order_cells(v.dim, v.n_cells, v.center, {"auto": 0, "morton": 1, "lattice": 2, "hilbert": 3}[mode],
                                         _p(order, C.c_int64), C.byref(kind)))
         self.permute_cells(order)
-        return {1: "lattice", 2: "morton"}.get(kind.value, "none")
+        return {1: "lattice", 2: "morton", 3: "hilbert"}.get(kind.value, "none")
 
     def partition(self, part: np.ndarray, n_parts: int, rank: int) -> "HostMesh":
         part = np.ascontiguousarray(part, np.int32)

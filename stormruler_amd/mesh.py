@@ -396,9 +396,9 @@ def geometric_ordering(g: FaceGraph, mode: str = "auto") -> Tuple[np.ndarray, st
     order = np.empty(n, np.int64)
     kind = C.c_int32(0)
     check(lib.storm_hip_order_cells(g.dim, n, centers.ctypes.data_as(C.POINTER(C.c_double)),
-                                    {"auto": 0, "morton": 1, "lattice": 2}[mode],
+                                    {"auto": 0, "morton": 1, "lattice": 2, "hilbert": 3}[mode],
                                     order.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(kind)))
-    return order, {1: "lattice", 2: "morton"}.get(kind.value, "none")
+    return order, {1: "lattice", 2: "morton", 3: "hilbert"}.get(kind.value, "none")
 
 
 def permute_cells(g: FaceGraph, perm: np.ndarray) -> FaceGraph:

@@ -87,7 +87,7 @@ def main():
             assert s.solve(x, b, op), (kind, fmt)
             ref = oracle.solve(kind, ref_op, np.ones(glob.n_cells), num_inner_iterations=kw.get("num_inner_iterations", 50))
             assert ref.converged
-            # (BiCGStab's count is a draw among roundings -- DESIGN 5c.  On the 64 x 16 x 24 box the ORACLE itself gives 54
+            # (BiCGStab's count is a draw among roundings -- NOTES.md 5c.  On the 64 x 16 x 24 box the ORACLE itself gives 54
             #  (strict build), 62 (the same source with FMA contraction) and 53 ... 63 over sixteen runs whose applies are
             #  perturbed by one unit in the last place (oracle.GatherOperator seeds 1-8, strict / devlike); the device: 59
             #  with the backend's free contraction, 64 with -ffp-contract=on.  The solution parity below is the check.)

@@ -108,7 +108,7 @@ def test_solvers_on_the_tiled_kernel_match_the_oracle(env, kind, generic):
             mat.close()
         for tile in (0, 4):
             it, hist, xs = res[tile]
-            # (the bounds of tests/test_gpu_parity.py: SURVEY 8d's +-2 % / +-5 %, min +-2; BiCGStab +-5 %)
+            # (the bounds of tests/test_gpu_parity.py: SURVEY 8d's +-2 % / +-5 %, min +-2; BiCGStab +-5 %, see NOTES.md 5c)
             # (BiCGStab's count is a draw among roundings -- tests/golden/full_size_bicgstab256.json:perturbation_study;
             #  what this test is about is that both kernels give the same draw, below)
             tol = 0.02 if kind == "cg" else 0.05 if kind == "gmres" else 0.10

@@ -271,6 +271,6 @@ def test_bicgstab_over_rccl_sends_the_halo_of_s_and_p_before_the_update_kernels(
     assert runs[1][0] == runs[0][0]
     assert np.array_equal(runs[1][1], runs[0][1]) and np.array_equal(runs[1][2], runs[0][2])
     ref = oracle.solve(kind, oracle.CallbackOperator(loc.n_cells, ref_apply), b_host)
-    # (BiCGStab's iteration count is a draw among roundings -- DESIGN 5c --: the solution is what is compared)
+    # (BiCGStab's iteration count is a draw among roundings -- NOTES.md 5c --: the solution is what is compared)
     assert abs(runs[1][0] - ref.iterations) <= max(3, int(0.2 * ref.iterations))
     assert np.linalg.norm(runs[1][2] - ref.x) <= 1e-5 * np.linalg.norm(ref.x)

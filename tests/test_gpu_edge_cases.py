@@ -255,7 +255,7 @@ def test_solve_logs_the_reference_line(caplog):
     ctx.close()
 
 
-# ---- documented deviations, pinned (DESIGN.md "Deviations") -----------------------------------------------------
+# ---- documented deviations, pinned (NOTES.md section 5c "Deviations") -----------------------------------------------------
 
 def test_non_finite_input_reaches_at_most_the_stencil_offsets_in_paired_records(env):
     """Precondition of the paired record format (storm_hip.h, storm_hip_op_apply): x is finite.  With fp64 records an
