@@ -50,6 +50,7 @@ struct Comm {
   // between "exchange done" and "boundary rows start" (profile_comm: halo_done_to_boundary_rows); the flag ~3 us.
   unsigned long long *d_flag = nullptr;  // [0]: number of the last completed exchange
   unsigned long long flag_seq = 0;       // exchanges begun
+  unsigned long long ready_seq = 0;      // [8]: hand-offs compute stream -> comm stream
   long long *d_prof = nullptr;          // [kProfRing][8] exchanges: A, P, Q, R, B, C, -, - ; then [kProfRing][2] all-reduces: E, F
   long long prof_ex = 0, prof_ar = 0;   // exchanges / all-reduces stamped since profile_comm was set
   std::vector<unsigned char> prof_mode; // per exchange: 0 = packed on the comm stream, 1 = packed (formed) on the compute stream
@@ -72,6 +73,21 @@ __global__ void comm_flag_wait_kernel(const unsigned long long *flag, unsigned l
   }
 }
 static inline bool flag_on(const storm_hip_ctx *c) { return c->opt_rccl_flag_wait != 0 && c->comm->d_flag != nullptr; }
+// "the vector is ready" from the compute stream to the comm stream: a flag too (a recorded event is a barrier with a
+// system-scope release between two kernels of the compute stream, ~6 us; the one-thread setter ~2).  Both kernels are
+// submitted in this order, so the waiter can never sit in front of its setter in a shared hardware queue.
+static inline int ready_handoff(storm_hip_ctx *c) {
+  if (flag_on(c)) {
+    const unsigned long long seq = ++c->comm->ready_seq;
+    hipLaunchKernelGGL(comm_flag_set_kernel, dim3(1), dim3(1), 0, c->stream, c->comm->d_flag + 8, seq);
+    hipLaunchKernelGGL(comm_flag_wait_kernel, dim3(1), dim3(1), 0, c->comm_stream, c->comm->d_flag + 8, seq, c->comm->d_error);
+    HIP_TRY(hipGetLastError());
+    return STORM_HIP_OK;
+  }
+  HIP_TRY(hipEventRecord(c->ev_x_ready, c->stream));
+  HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_x_ready, 0));
+  return STORM_HIP_OK;
+}
 // behind the send / recv group of an exchange, on the comm stream
 static inline void flag_publish(storm_hip_ctx *c) {
   ++c->comm->flag_seq;
@@ -310,8 +326,7 @@ int comm_halo_exchange_begin(const storm_hip_op *op, double *x) {
   // x must be complete before it is packed
   const long long pe = prof_on(c) ? c->comm->prof_ex++ : -1;
   if (pe >= 0) c->comm->prof_mode.push_back(0), prof_stamp(c, c->stream, pe, 0);
-  HIP_TRY(hipEventRecord(c->ev_x_ready, c->stream));
-  HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_x_ready, 0));
+  STORM_TRY(ready_handoff(c));
   if (pe >= 0) prof_stamp(c, c->comm_stream, pe, 1);
   if (h.n_send > 0) {
     const int64_t need = (h.n_send + kBlock - 1) / kBlock;
@@ -351,8 +366,7 @@ int comm_halo_exchange_begin_direction(const storm_hip_op *op, const double *p, 
   STORM_REQUIRE(comm_is_rccl(c) && h.n_nbrs > 0, "fused exchange: needs the RCCL transport and a halo plan");
   const long long pe = prof_on(c) ? c->comm->prof_ex++ : -1;
   if (pe >= 0) c->comm->prof_mode.push_back(0), prof_stamp(c, c->stream, pe, 0);
-  HIP_TRY(hipEventRecord(c->ev_x_ready, c->stream));  // beta of the ending iteration is in the slab, r and p are complete
-  HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_x_ready, 0));
+  STORM_TRY(ready_handoff(c));  // beta of the ending iteration is in the slab, r and p are complete
   if (pe >= 0) prof_stamp(c, c->comm_stream, pe, 1);
   if (h.n_send > 0) {
     const int64_t need = (h.n_send + kBlock - 1) / kBlock;
@@ -409,8 +423,7 @@ int comm_halo_exchange_begin_formed(const storm_hip_op *op, int mode, const doub
     HIP_TRY(hipGetLastError());
   }
   if (pe >= 0) prof_stamp(c, c->stream, pe, 2);
-  HIP_TRY(hipEventRecord(c->ev_x_ready, c->stream));  // the rows to send are packed
-  HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_x_ready, 0));
+  STORM_TRY(ready_handoff(c));  // the rows to send are packed
   if (pe >= 0) prof_stamp(c, c->comm_stream, pe, 1);
   NCCL_TRY(ncclGroupStart());
   for (int q = 0; q < h.n_nbrs; ++q) {
