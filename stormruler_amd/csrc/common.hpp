@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/storm_hip.h"
@@ -178,6 +179,7 @@ struct storm_hip_ctx {
   int64_t opt_spmv_mixed = 1;        // partitioned operators: format 4 for the groups that read no halo column, format 3 for the rest
   int64_t opt_profile_spmv = 0;
   std::vector<storm::LazyStmt> lazy_q;  // held-back statements (lazy.hip), in program order
+  std::unordered_map<const void *, int> occupancy;  // latency.hip: blocks per CU of a cooperative kernel on THIS context's device
   int64_t opt_test_disable = 0;         // option test_disable (context.hip): a bit mask that switches single refinements OFF so that tests can compare a kernel with its plainer form, bit for bit
   int64_t opt_lazy = 0;                 // option lazy_statements
   int callback_depth = 0;               // > 0 while a solver is inside an operator / preconditioner callback (nothing waits there)

@@ -465,15 +465,36 @@ static bool in_arena(const storm_hip_ctx *c, const void *p) {
     if ((const char *)p >= a.base && (const char *)p < a.base + (size_t)a.slots * a.pitch) return true;
   return false;
 }
-// Give the pooled storage back to the driver (slots of an arena stay pooled: an arena is freed with the context).
+// Give pooled storage back to the driver (an allocation failed, or the pool budget shrank; the caller has synchronised
+// the stream): every vector allocated by itself, and every ARENA whose slots are all back in the pool -- an arena with a
+// slot still in use stays, with its free slots pooled.  pool_bytes counts the stand-alone vectors only: arena slots have
+// the arenas' own budget (vec_arena_max_bytes) and must not crowd the others out of the pool.
 static void pool_release(storm_hip_ctx *c) {
-  std::vector<std::pair<size_t, double *>> keep;
-  size_t kept = 0;
+  std::vector<int> pooled(c->arenas.size(), 0);
+  auto arena_of = [&](const void *p) {
+    for (size_t i = 0; i < c->arenas.size(); ++i) {
+      const auto &a = c->arenas[i];
+      if ((const char *)p >= a.base && (const char *)p < a.base + (size_t)a.slots * a.pitch) return (int)i;
+    }
+    return -1;
+  };
   for (auto &pb : c->pool) {
-    if (in_arena(c, pb.second)) keep.push_back(pb), kept += pb.first;
-    else (void)hipFree(pb.second);
+    const int i = arena_of(pb.second);
+    if (i >= 0) ++pooled[(size_t)i];
   }
-  c->pool.swap(keep), c->pool_bytes = kept;
+  std::vector<std::pair<size_t, double *>> keep;
+  for (auto &pb : c->pool) {
+    const int i = arena_of(pb.second);
+    if (i < 0) (void)hipFree(pb.second);
+    else if (pooled[(size_t)i] < c->arenas[(size_t)i].used) keep.push_back(pb);  // (its arena still has a slot in use)
+  }
+  std::vector<storm_hip_ctx::VecArena> live;
+  for (size_t i = 0; i < c->arenas.size(); ++i) {
+    if (c->arenas[i].used > 0 && pooled[i] == c->arenas[i].used) (void)hipFree(c->arenas[i].base);  // idle: every handed-out slot is back
+    else live.push_back(c->arenas[i]);
+  }
+  c->arenas.swap(live);
+  c->pool.swap(keep), c->pool_bytes = 0;
 }
 // A slot of an arena of this size class (a new arena when all are taken); null: no arena (too small, too large, off,
 // or the allocation failed) -- the caller allocates the vector by itself.
@@ -537,7 +558,7 @@ static int vec_create_impl(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, st
   for (size_t i = c->pool.size(); i-- > 0;) {
     if (c->pool[i].first == bytes) {
       base = c->pool[i].second;
-      c->pool_bytes -= bytes;
+      if (!in_arena(c, base)) c->pool_bytes -= bytes;
       c->pool.erase(c->pool.begin() + (std::ptrdiff_t)i);
       break;
     }
@@ -575,6 +596,7 @@ static int vec_create_impl(storm_hip_ctx *c, int64_t n_owned, int64_t n_halo, st
   }
   if (e != hipSuccess) {
     if (!in_arena(c, v->base)) (void)hipFree(v->base);
+    else c->pool.emplace_back(bytes, v->base);  // (an arena slot goes back to the pool, not into the void)
     delete v;
     STORM_FAIL(STORM_HIP_E_HIP, "vec_create: memset failed: %s", hipGetErrorString(e));
   }
@@ -593,11 +615,12 @@ int storm_hip_vec_destroy(storm_hip_vec *v) {
   if (!v) return STORM_HIP_OK;
   storm_hip_ctx *c = v->ctx;
   (void)lazy_sync(c);  // (a waiting statement may read or write this storage)
-  if (v->base && ((int64_t)(c->pool_bytes + v->bytes) <= c->opt_pool_bytes || in_arena(c, v->base))) {
+  const bool arena_slot = v->base && in_arena(c, v->base);
+  if (v->base && (arena_slot || (int64_t)(c->pool_bytes + v->bytes) <= c->opt_pool_bytes)) {
     // later users of this storage are ordered behind its pending kernels by the compute stream; the
     // comm stream only touches a vector between two events of one SpMV (comm.hip)
     c->pool.emplace_back(v->bytes, v->base);
-    c->pool_bytes += v->bytes;
+    if (!arena_slot) c->pool_bytes += v->bytes;
   } else {
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(v->base);

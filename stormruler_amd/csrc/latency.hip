@@ -37,6 +37,21 @@
 
 namespace storm {
 
+// Blocks of `fn` that fit a CU (0: the kernel cannot run with this much dynamic LDS), asked once PER CONTEXT: the answer --
+// and the hipFuncAttributeMaxDynamicSharedMemorySize it needs -- belong to the device, a context is one device and one
+// host thread (a process-wide static cache served a second device with the first one's answer and raced between threads).
+static int occupancy_cached(storm_hip_ctx *c, const void *fn, int threads, size_t dyn_lds) {
+  const auto it = c->occupancy.find(fn);
+  if (it != c->occupancy.end()) return it->second;
+  int res = 0;
+  if (dyn_lds == 0 || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds) == hipSuccess)
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&res, fn, threads, dyn_lds);
+  (void)hipGetLastError();
+  c->occupancy[fn] = res;
+  return res;
+}
+
+
 constexpr int kLatBlock = 1024;  // one block per CU: a synchronisation point costs per participating BLOCK
 constexpr int kLatWaves = kLatBlock / kWave;
 
@@ -1192,14 +1207,7 @@ int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w
     const int sv = sub <= 1 ? 1 : sub <= 2 ? 2 : 4;
     fn = sv == 1 ? (const void *)mgs_chain_lds_kernel<1> : sv == 2 ? (const void *)mgs_chain_lds_kernel<2> : (const void *)mgs_chain_lds_kernel<4>;
     dyn_lds = sizeof(double) * 2 * (size_t)sv * kMgsSub;
-    static int lds_resident[3] = {-1, -1, -1};
-    int &res = lds_resident[sv == 1 ? 0 : sv == 2 ? 1 : 2];
-    if (res < 0) {
-      res = 0;
-      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds) == hipSuccess)
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&res, fn, kLatBlock, dyn_lds);
-      (void)hipGetLastError();
-    }
+    const int res = occupancy_cached(c, fn, kLatBlock, dyn_lds);
     if (res >= 1) blocks = (subs_total + sv - 1) / sv;
     else fn = nullptr, dyn_lds = 0;
   }
@@ -1229,14 +1237,7 @@ int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w
       qf = (const void *)mgs_chain_quad_kernel<8, 3, true, true>;
       quad_lds = sizeof(double) * 2 * 8 * (size_t)kQuadSub;
     }
-    static int quad_resident[12] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
-    int &res = quad_resident[lds_pf ? 8 : (sv == 1 ? 0 : sv == 2 ? 1 : sv == 4 ? 2 : 3) + (with_apply ? 4 : 0)];
-    if (res < 0) {
-      res = 0;
-      if (quad_lds == 0 || hipFuncSetAttribute(qf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_lds) == hipSuccess)
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&res, qf, kQuadThreads, quad_lds);
-      (void)hipGetLastError();
-    }
+    const int res = occupancy_cached(c, qf, kQuadThreads, quad_lds);
     if (res >= 1) {
       if (c->d_quad_slots == nullptr) {
         const size_t bytes = std::max((size_t)2 * (256 + 8) * kQuadSlotStride, (size_t)2 * kDenseMaxValues * 256 * 16);  // either form
@@ -1260,10 +1261,7 @@ int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w
                                 : nullptr;
   if (fn == nullptr) return STORM_HIP_OK;  // more than 16 slices per wavefront: registers cannot hold w
   if (!lds_chain) {
-  static int resident[5] = {-1, -1, -1, -1, -1};
-  const int vi = need <= 1 ? 0 : need <= 2 ? 1 : need <= 4 ? 2 : need <= 8 ? 3 : 4;
-  if (resident[vi] < 0) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident[vi], fn, kLatBlock, 0));
-  if (resident[vi] < 1) return STORM_HIP_OK;
+  if (occupancy_cached(c, fn, kLatBlock, 0) < 1) return STORM_HIP_OK;
   }
   MgsArgs a;
   for (int i = 0; i <= k; ++i) a.q[i] = q[i];
@@ -1460,15 +1458,8 @@ static int latency_solve(bool bicgstab, const storm_hip_op *op, LatArgs a, bool 
   const int capacity[4] = {1, 2, 4, 8};
   const void *fn = nullptr;
   int64_t blocks = 0;
-  static int resident[2][3][4];  // blocks per CU of each variant + 1, asked once (0: not yet)
   for (int v = 0; v < 4 && fn == nullptr; ++v) {
-    int &asked = resident[bicgstab ? 1 : 0][w == 0 ? 0 : w == 4 ? 1 : 2][v];
-    if (asked == 0) {
-      int per_cu = 0;
-      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, variants[v], kLatBlock, 0));
-      asked = per_cu + 1;
-    }
-    if (asked < 2) continue;
+    if (occupancy_cached(c, variants[v], kLatBlock, 0) < 1) continue;
     blocks = std::max<int64_t>(1, std::min<int64_t>(std::min(c->num_cus, 256), (n_slices + kLatWaves - 1) / kLatWaves));
     const int64_t waves = blocks * kLatWaves;
     if ((n_slices + waves - 1) / waves <= capacity[v]) fn = variants[v];
