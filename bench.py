@@ -115,6 +115,7 @@ def main() -> int:
     ap.add_argument("--skip-spmv", action="store_true", help="skip the stand-alone SpMV block (`spmv` in the line)")
     ap.add_argument("--spmv-launches", type=int, default=60, help="stand-alone SpMV launches timed per mode (SURVEY.md 8d: >= 50)")
     ap.add_argument("--spmv-only", action="store_true", help="run only the stand-alone SpMV block (for a clean rocprofv3 --stats comparison)")
+    ap.add_argument("--spmv-what", default="lattice,general", help="--spmv-only: which operators (lattice, general, tets)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     chain = [t for t in (args.transport or ("ipc,host" if args.shared_device else "rccl,ipc,host")).split(",") if t]
@@ -948,12 +949,30 @@ def spmv_only(args) -> int:
         k_, v_ = kv.split("=")
         ctx.set_option(k_, int(v_))
     out = {}
+    what = args.spmv_what.split(",")
     for name, level in (("lattice", None), ("general", 0)):
+        if name not in what:
+            continue
         if level is not None:
             ctx.set_option("spmv_dict", level)
         mat = api.StencilMatrix.from_face_graph(ctx, g)
         out[name] = spmv_standalone(api, ctx, mat, mat.stats(), np.arange(g.n_cells), args.spmv_launches)
         mat.close()
+    if "tets" in what:  # the tetrahedral mesh of roofline_unstructured3d (a run of its own: the kernel is `general`'s)
+        import shutil
+        import tempfile
+
+        d = tempfile.mkdtemp(prefix="storm_tet_", dir=os.environ.get("TMPDIR", "/tmp"))
+        try:
+            prefix, _, _ = tet_files(args.tet_edge, d)
+            hm, mat, _ = tet_operator(api, ctx, prefix)
+            st = mat.stats()
+            gid = np.ctypeslib.as_array(hm.view().global_id, shape=(st["n_rows"],)).copy()
+            out["tets"] = spmv_standalone(api, ctx, mat, st, gid, args.spmv_launches)
+            mat.close()
+            hm.close()
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
     print(json.dumps({"spmv": out, "n": args.n, "device": ctx.info()["name"]}), flush=True)
     ctx.close()
     return 0
