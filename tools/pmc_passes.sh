@@ -7,7 +7,7 @@ dirs=""
 for grp in "$@"; do
   d=/tmp/pmc_pass_$i
   rm -rf $d
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $d -- python3 bench.py --cpu-iters 0 --skip-general --skip-blas1 --steps 20 --warmup 2 --spinup-seconds 0 --min-seconds 0 --traffic off --skip-permuted --skip-unstructured --skip-configs > /dev/null 2>&1
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $d -- python3 bench.py --cpu-iters 0 --skip-general --skip-blas1 --steps 20 --warmup 2 --spinup-seconds 0 --min-seconds 0 --traffic off --skip-permuted --skip-unstructured --skip-unstructured3d --skip-configs > /dev/null 2>&1
   dirs="$dirs $d"
   i=$((i+1))
 done
