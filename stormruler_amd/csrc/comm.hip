@@ -64,8 +64,11 @@ __global__ void comm_flag_set_kernel(unsigned long long *flag, unsigned long lon
 //  the kernel launched behind this one on the compute stream)
 __global__ void comm_flag_wait_kernel(const unsigned long long *flag, unsigned long long seq, int *error) {
   const long long t0 = wall_clock64();
+  // 10 s (ticks of 10 ns): the exchange never completed.  The first exchanges of a communicator get 60 s: RCCL sets its
+  // point-to-point connections up inside the first send / recv of every pair.
+  const long long limit = seq <= 4 ? 6000000000ll : 1000000000ll;
   while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
-    if (wall_clock64() - t0 > 1000000000ll) {  // 10 s: the exchange never completed
+    if (wall_clock64() - t0 > limit) {
       if (error) __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       return;
     }

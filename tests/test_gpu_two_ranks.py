@@ -104,6 +104,19 @@ def test_bench_script_multi_rank_path(world, transport):
         assert cb["send_ack_wait_us_per_iteration_worst_rank"] >= 0.0
 
 
+def test_bench_measures_two_transports_and_reports_the_better():
+    """N > 1: every data-path transport of the chain is measured by fresh rank processes (on N devices: RCCL and the peer
+    windows; here, ranks sharing one device: host-staged and the peer windows); `value` is the better one and
+    `transports_measured` holds both with their breakdowns."""
+    out, _ = _run_bench(["--gpus", "2", "--transport", "host,ipc"], timeout=600)
+    tm = out["transports_measured"]
+    assert set(tm) == {"host", "ipc"} and out["transport_fallback"] == []
+    best = max(tm, key=lambda t: tm[t]["value"])
+    assert out["transport"] == best and out["value"] == tm[best]["value"] and out["ms_per_step"] == tm[best]["ms_per_step"]
+    for t in tm.values():
+        assert t["value"] > 0 and t["postflight"]["ok"] and "comm_breakdown" in t
+
+
 @pytest.mark.parametrize("how", ["exit:1", "hang:0", "wrong", "post:1"])
 def test_bench_falls_back_to_the_next_transport_with_fresh_ranks(how):
     """A transport that fails -- a rank dies, a rank hangs (budget), or the pre-flight finds wrong halo values -- costs
