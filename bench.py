@@ -1538,7 +1538,12 @@ def cpu_baseline(args, n, g, perm, run, ctx):
     # the init apply counts as work: iterations + 1 applies were done
     cpu = {"value": args.cpu_iters / tc, "unit": "iter/s", "cores": 1, "kind": "port",
            "sample": f"{args.cpu_iters} CG iterations (+ init residual) of the same {n}^3 Poisson problem, "
-                     f"oracle/liboracle.so (gcc -O2 -ffp-contract=off), host has {os.cpu_count()} cpus",
+                     f"oracle/liboracle.so, host has {os.cpu_count()} cpus.  Flags: gcc -O2 -ffp-contract=off -- the parity "
+                     "checker's build (the reference's statement order with strict IEEE rounding, what the GPU path is compared "
+                     "with), not SURVEY 8d's -O3 -march=native: the .so is built in a container that does not know this box's "
+                     "CPU, and fast-math reassociation would make the baseline a different algorithm; `value_fma_build` is the "
+                     "same source at -O3 -mavx2 -mfma -ffp-contract=fast (the closest portable stand-in for the reference's "
+                     "Release flags -Ofast -march=native, CMakeLists.txt:194-195)",
            "seconds": tc}
     # parity spot check at bench size: same iteration count of CG from the same start gives the
     # same residual (GPU sums in a different order: tolerance, not bits)
