@@ -490,35 +490,30 @@ def main() -> int:
         except Exception as e:
             general = {"error": repr(e)}
 
-    # ---- SURVEY.md 8d's unstructured stress variant: seeded permutation -> RCM, whatever format that gets ----
+    # ---- SURVEY.md 8d's unstructured stress variant: the cells renumbered by the seeded permutation, then the library's
+    # ordering -- all on the library's host meshes (storm_hip_mesh_*: threaded; round 4 did this in numpy: 7.4 s) ----
     permuted, unstructured = None, None
-    stress_order = None  # new cell i of the re-ordered mesh is cell stress_order[i] of the natural one
-    if world == 1 and not args.skip_general and not (args.skip_permuted and args.skip_unstructured):
-        try:
-            tp = time.time()
-            g0 = g if perm is None else mesh.structured_box(n)
-            perm0 = mesh.random_permutation(N)
-            gs = mesh.permute_cells(g0, perm0)
-            # the library's ordering (storm_hip_order_cells, native + threaded): the lexicographic order of a lattice where
-            # the cell centres form one -- the scrambled box gets its natural order, and the lattice records, back --, the
-            # Z-order curve of the centres otherwise; the jittered variant below is FORCED onto the curve (a Triangle /
-            # TetGen mesh has no lattice to find).  Reverse Cuthill-McKee for comparison: tools/ordering_probe.py
-            t_o = time.time()
-            order, order_kind = mesh.geometric_ordering(gs, "auto")
-            order_m, _ = mesh.geometric_ordering(gs, "morton")
-            t_o = time.time() - t_o
-            stress_order = perm0[order_m]
-            t_order = time.time() - tp
-            if not args.skip_permuted:
-                gr = mesh.permute_cells(gs, order)
-            del gs
-        except Exception as e:
-            permuted = unstructured = {"error": repr(e)}
+    stress_ready = world == 1 and not args.skip_general and not (args.skip_permuted and args.skip_unstructured)
+    if stress_ready:
+        from stormruler_amd import host_mesh
 
-    def stress_variant(graph, host_seconds, reference_residual):
-        """Build, time and profile one re-ordered variant of the problem; the residual after K iterations must be the
-        natural order's (the same operator conjugated by a permutation)."""
-        matp = api.StencilMatrix.from_face_graph(ctx, graph)
+        g0 = g if perm is None else mesh.structured_box(n)
+        perm0 = mesh.random_permutation(N)
+
+    def stress_variant(graph, mode, reference_residual):
+        """Scramble, order (`mode`), build, time and profile one variant of the problem; the residual after K iterations must
+        be the natural order's (the same operator conjugated by a permutation)."""
+        sec = {}
+        t0 = time.time()
+        hm = host_mesh.HostMesh.from_face_graph(graph)
+        hm.permute_cells(perm0)
+        sec["copy_and_scramble"] = time.time() - t0
+        t0 = time.time()
+        kind = hm.order_cells(mode)
+        sec["ordering"] = time.time() - t0
+        t0 = time.time()
+        matp = hm.create_operator(ctx)
+        sec["operator_build"] = time.time() - t0
         stp = matp.stats()
         opp = api.HipStencilOperator(matp, alpha=-1.0, beta=0.0)
         run(max(W, 20), opp)
@@ -531,7 +526,8 @@ def main() -> int:
             repsp.append(time.perf_counter() - t1)
         t1 = float(np.median(repsp))
         rp = spmv_roofline(opp, stp, prof_iters)
-        band = np.abs(np.asarray(graph.inner) - np.asarray(graph.outer))
+        v_ = hm.view()
+        band = np.abs(np.ctypeslib.as_array(v_.inner, shape=(v_.n_faces,)) - np.ctypeslib.as_array(v_.outer, shape=(v_.n_faces,)))
         out_ = {"kernel": kernel_name(stp), "record_format": record_format_name(stp), "bound": "hbm",
                 "achieved": rp["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rp["frac"], "frac_8d": rp.get("frac_8d"), "traffic": None,
                 "bytes_per_launch": rp["bytes_per_launch"], "algorithmic_bytes_8d": rp["algorithmic_bytes_8d"],
@@ -539,40 +535,39 @@ def main() -> int:
                 "median_launch_ms": rp.get("median_launch_ms"), "min_launch_ms": rp["min_launch_ms"],
                 "launches_timed": rp["launches_timed"], "cg_iter_per_s": K / t1, "ms_per_step": t1 / K * 1e3,
                 "final_residual_rel_diff_vs_natural_order": abs(sp_.absolute_error - reference_residual) / reference_residual,
-                "max_column_distance": int(band.max()), "host_seconds_permute_order_build": host_seconds}
+                "max_column_distance": int(band.max()), "ordering_kind": kind, "host_seconds": sec,
+                "host_seconds_permute_order_build": sum(sec.values())}
         matp.close()
+        hm.close()
         return out_
 
-    if stress_order is not None and not args.skip_permuted:
+    if stress_ready and not args.skip_permuted:
         try:
-            tp = time.time()
-            permuted = stress_variant(gr, None, final_residual)
-            permuted["host_seconds_permute_order_build"] = t_order + (time.time() - tp)
-            permuted["ordering"] = ("numpy.random.default_rng(12345).permutation(N), then the library's ordering from the cell "
-                                    f"centres (stormruler_amd.mesh.geometric_ordering -> storm_hip_order_cells): {order_kind}")
-            permuted["ordering_kind"] = order_kind
-            permuted["host_seconds_ordering_alone_both_modes"] = t_o
-            del gr
+            # the library's ordering (storm_hip_order_cells): the lexicographic order of a lattice where the cell centres form
+            # one -- the scrambled box gets its natural order, and the lattice records, back
+            permuted = stress_variant(g0, "auto", final_residual)
+            permuted["ordering"] = ("numpy.random.default_rng(12345).permutation(N) (storm_hip_mesh_permute_cells), then the "
+                                    f"library's ordering from the cell centres (storm_hip_order_cells, mode auto): {permuted['ordering_kind']}")
         except Exception as e:
             permuted = {"error": repr(e)}
     # ---- ... and the same with a jittered geometry: no two weights equal, so the records are fp64 weights + int32
-    # columns (SURVEY.md 8d's bytes) AND the ordering is not the lattice's -- a Triangle / TetGen mesh of this size
-    if stress_order is not None and not args.skip_unstructured:
+    # columns (SURVEY.md 8d's bytes) AND the ordering is FORCED onto the Z-order curve (a Triangle / TetGen mesh has no
+    # lattice to find)
+    if stress_ready and not args.skip_unstructured:
         try:
-            tp = time.time()
+            tj = time.time()
             gj = mesh.jitter_geometry(g0, 1.0 / n)
+            tj = time.time() - tj
             matj = api.StencilMatrix.from_face_graph(ctx, gj)
             sj, _ = run(K, api.HipStencilOperator(matj, alpha=-1.0, beta=0.0))  # the natural order's residual
             matj.close()
-            gu = mesh.permute_cells(gj, stress_order)
+            unstructured = stress_variant(gj, "morton", sj.absolute_error)
             del gj
-            unstructured = stress_variant(gu, None, sj.absolute_error)
-            unstructured["host_seconds_permute_order_build"] = t_order + (time.time() - tp)
+            unstructured["host_seconds"]["jitter_geometry_numpy"] = tj
             unstructured["geometry"] = ("cell centres displaced by <= 0.2 h per coordinate, face areas scaled by 1 +- 0.1 "
                                         "(numpy.random.default_rng(2024)): all weights distinct")
             unstructured["ordering"] = ("the same seeded permutation, then the Z-order (Morton) curve of the cell centres "
-                                        "(stormruler_amd.mesh.geometric_ordering(mode='morton'))")
-            del gu
+                                        "(storm_hip_order_cells, mode morton)")
         except Exception as e:
             unstructured = {"error": repr(e)}
 

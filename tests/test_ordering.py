@@ -57,3 +57,45 @@ def test_morton_order_is_a_permutation_that_keeps_neighbours_close():
     t = io_triangle.read_triangle(root)
     order, kind = mesh.geometric_ordering(t)
     assert kind == "morton" and np.array_equal(np.sort(order), np.arange(t.n_cells))
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_hilbert_order_visits_face_adjacent_cells(dim):
+    """Mode 3: the Hilbert curve of the cell centres (Skilling's transposed index).  On a 2^k grid consecutive cells of the
+    curve are always face neighbours -- no jump anywhere, where the Z-order curve jumps across the domain."""
+    n = 16
+    g = mesh.structured_box(n, n, n if dim == 3 else 1)
+    if dim == 2:
+        class G:
+            pass
+
+        g2 = G()
+        g2.n_cells, g2.dim, g2.center = g.n_cells, 2, np.ascontiguousarray(g.center[:, :2])
+        g = g2
+    scr = np.random.default_rng(5).permutation(g.n_cells)
+    c = np.ascontiguousarray(g.center[scr])
+
+    class S:
+        pass
+
+    s = S()
+    s.n_cells, s.dim, s.center = g.n_cells, dim, c
+    order, kind = mesh.geometric_ordering(s, "hilbert")
+    assert kind == "hilbert" and np.array_equal(np.sort(order), np.arange(g.n_cells))
+    steps = np.abs(np.diff(c[order], axis=0)).sum(axis=1) * n
+    assert np.allclose(steps, 1.0)
+    order_m, kind_m = mesh.geometric_ordering(s, "morton")
+    assert kind_m == "morton" and (np.abs(np.diff(c[order_m], axis=0)).sum(axis=1) * n).max() > 3.0
+
+
+def test_non_finite_centres_are_rejected_not_indexed():
+    class S:
+        pass
+
+    s = S()
+    s.n_cells, s.dim = 1000, 3
+    s.center = np.random.default_rng(1).random((1000, 3))
+    s.center[417, 1] = np.nan
+    for mode in ("auto", "morton", "hilbert"):
+        with pytest.raises(Exception, match="non-finite"):
+            mesh.geometric_ordering(s, mode)
