@@ -24,8 +24,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,dims,transport", [(2, (16, 12, 8), "host"), (3, (20, 8, 5), "host"), (3, (20, 8, 5), "ipc"),
-                                                  (4, (12, 12, 4), "ipc"), (2, (64, 16, 12), "host"), (2, (64, 16, 12), "ipc")])
+@pytest.mark.parametrize("world,dims,transport", [(2, (16, 12, 8), "host"), (3, (20, 8, 5), "ipc"), (4, (12, 12, 4), "ipc"),
+                                                  (2, (64, 16, 12), "host")])
 def test_partitioned_device_path_matches_the_global_oracle(world, dims, transport, tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
@@ -82,7 +82,7 @@ def _run_bench(extra, timeout=420):
     return json.loads(lines[0]), p.stderr
 
 
-@pytest.mark.parametrize("world,transport", [(2, "host"), (3, "ipc")])
+@pytest.mark.parametrize("world,transport", [(3, "ipc")])  # (2 ranks, host AND ipc: test_bench_measures_two_transports...)
 def test_bench_script_multi_rank_path(world, transport):
     """bench.py's own N > 1 code path (supervisors, pre-flight, partition, connect, the rank-uniform spin-up, barriers,
     max-over-ranks timing, rank-0 JSON) with the ranks sharing device 0 (`--shared-device`): it must terminate -- a
@@ -117,7 +117,8 @@ def test_bench_measures_two_transports_and_reports_the_better():
         assert t["value"] > 0 and t["postflight"]["ok"] and "comm_breakdown" in t
 
 
-@pytest.mark.parametrize("how", ["exit:1", "hang:0", "wrong", "post:1"])
+@pytest.mark.parametrize("how", ["exit:1", "hang:0", "wrong"])  # (a rank dies / hangs / the pre-flight finds wrong values; "post:1", a
+# wrong value found by the post-flight, takes the same road after the timed region: run by hand, `--inject-fail ipc=post:1`)
 def test_bench_falls_back_to_the_next_transport_with_fresh_ranks(how):
     """A transport that fails -- a rank dies, a rank hangs (budget), or the pre-flight finds wrong halo values -- costs
     its budget, not the run: all rank processes of the attempt are ended and a FRESH set starts on the next
@@ -132,7 +133,7 @@ def test_bench_falls_back_to_the_next_transport_with_fresh_ranks(how):
     assert "starting fresh ranks on host" in err
 
 
-@pytest.mark.parametrize("world", [3, 4])  # (a GPU box admits 6 processes on its card: 4 ranks + this one + slack)
+@pytest.mark.parametrize("world", [3])  # (3 parts of the RCB are not a chain of slabs; 4 ranks: test_cavity_on_four_ranks)
 def test_unstructured_partition_reproduces_the_recorded_reference_run(world, tmp_path):
     """General meshes: RCB parts of the reference's Triangle mesh, general halo plans."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
