@@ -125,7 +125,7 @@ def test_bench_falls_back_to_the_next_transport_with_fresh_ranks(how):
     transport of the chain; the line says which transport produced the number and why the earlier one did not."""
     # (a hanging rank costs the whole budget of its attempt: a short one for that case)
     out, err = _run_bench(["--gpus", "2", "--transport", "ipc,host", "--inject-fail", f"ipc={how}",
-                           "--attempt-seconds", "18,240" if how.startswith("hang") else "45,240"])
+                           "--attempt-seconds", "12,240" if how.startswith("hang") else "45,240"])
     assert out["transport"] == "host" and out["n_gpus"] == 2 and out["value"] > 0
     fb = out["transport_fallback"]
     assert len(fb) == 1 and fb[0]["transport"] == "ipc"
