@@ -111,6 +111,33 @@ def test_the_cg_body_statement_by_statement(setup, which):
     assert runs[1][2] == {"lazy_fused_dots": 12, "lazy_fused_pairs": 6, "lazy_apply_dots": 6}
 
 
+@pytest.mark.parametrize("which", ["lattice", "fp64"])
+def test_reductions_that_ride_in_the_apply(setup, which):
+    """`z = A p` waiting, then <z, z> (norm_2), <z, p> and <p, z>: each leaves as the apply with its fused-dot epilogue; the
+    values are the eager ones to rounding and z is the eager z to the bit."""
+    api, ctx, g, mat, mat0 = setup
+    m = mat if which == "lattice" else mat0
+    n = g.n_cells
+    p, = _vectors(api, ctx, n, 21, 1)
+    ph = p.to_numpy()
+    z_ref = api.DeviceVector(ctx, n)
+    m.apply(-1.0, 0.3, p, z_ref)
+    zh = z_ref.to_numpy()
+    want = {"zz": float(np.sqrt(zh @ zh)), "zp": float(zh @ ph)}
+    ctx.set_option("lazy_statements", 1)
+    before = ctx.counter("lazy_apply_dots")
+    for kind in ("zz", "zp", "pz"):
+        z = api.DeviceVector(ctx, n)
+        m.apply(-1.0, 0.3, p, z)
+        assert ctx.counter("lazy_waiting") == 1
+        got = api.norm_2(z) if kind == "zz" else api.dot_product(z, p) if kind == "zp" else api.dot_product(p, z)
+        assert ctx.counter("lazy_waiting") == 0
+        assert abs(got - want["zz" if kind == "zz" else "zp"]) <= 1e-12 * abs(want["zz" if kind == "zz" else "zp"]), kind
+        assert np.array_equal(z.to_numpy(), zh), kind
+    assert ctx.counter("lazy_apply_dots") - before == 3
+    ctx.set_option("lazy_statements", 0)
+
+
 def test_every_other_call_launches_what_waits(setup):
     api, ctx, g, mat, mat0 = setup
     n = g.n_cells
