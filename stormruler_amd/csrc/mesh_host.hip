@@ -574,8 +574,10 @@ void local_graph(const storm_hip_mesh &G, const int32_t *part, int rank, storm_h
     if (!oi) halo.push_back(i);
     if (!oo) halo.push_back(o);
   }
-  std::sort(halo.begin(), halo.end(), [&](int64_t x, int64_t y) { return part[x] != part[y] ? part[x] < part[y] : x < y; });
-  halo.erase(std::unique(halo.begin(), halo.end()), halo.end());  // by owner, then global id
+  // by owner, then global id -- the id the send lists are sorted by too, i.e. through a permuted mesh's own map
+  auto id_of = [&](int64_t x) { return G.global_id.empty() ? x : G.global_id[(size_t)x]; };
+  std::sort(halo.begin(), halo.end(), [&](int64_t x, int64_t y) { return part[x] != part[y] ? part[x] < part[y] : id_of(x) < id_of(y); });
+  halo.erase(std::unique(halo.begin(), halo.end()), halo.end());
   for (int64_t h = 0; h < (int64_t)halo.size(); ++h) loc[(size_t)halo[(size_t)h]] = n_own + h;
   gid.insert(gid.end(), halo.begin(), halo.end());
   const int64_t nt = (int64_t)gid.size();

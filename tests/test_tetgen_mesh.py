@@ -170,6 +170,35 @@ def test_permute_and_morton_order_keep_the_operator():
     assert np.array_equal(yp, y[order])  # faces keep their order: the very same sums
 
 
+@pytest.mark.parametrize("n_parts", [2, 5])
+def test_partition_of_a_renumbered_mesh_speaks_the_original_ids(n_parts):
+    """A mesh renumbered along the Hilbert curve and then partitioned natively: the parts' global ids are the
+    file's, what rank r sends to q is in order what q's halo group expects, and the partitioned apply is the
+    global one.  (Halo groups sorted by position in the renumbered mesh would not pair with send lists sorted by id.)"""
+    pos, bf, lab, cells = _box(5)
+    m = host_mesh.HostMesh.from_simplices(pos, bf, lab, cells)
+    g = m.face_graph()
+    assert m.order_cells("hilbert") == "hilbert"
+    center = m.face_graph().center
+    part = host_mesh.partition_rcb(center, n_parts)
+    locs = [m.partition(part, n_parts, r) for r in range(n_parts)]
+    graphs = [l.face_graph() for l in locs]
+    plans = [l.halo_plan() for l in locs]
+    x = np.sin(0.37 * np.arange(g.n_cells))
+    y_glob = oracle.StencilOperator(g, -1e-2, 1.0).apply(x)
+    y = np.full_like(x, np.nan)
+    for r in range(n_parts):
+        pr, lr = plans[r], graphs[r]
+        for qi, q in enumerate(pr.nbr_rank):
+            sent = lr.global_id[pr.send_idx[pr.send_ptr[qi]:pr.send_ptr[qi + 1]]]
+            pq, lq = plans[q], graphs[q]
+            j = list(pq.nbr_rank).index(r)
+            assert np.array_equal(sent, lq.global_id[lq.n_cells + pq.recv_ptr[j]: lq.n_cells + pq.recv_ptr[j + 1]])
+        yl = oracle.StencilOperator(lr, -1e-2, 1.0).apply(x[lr.global_id])
+        y[lr.global_id[: lr.n_cells]] = yl[: lr.n_cells]
+    assert np.abs(y - y_glob).max() <= 1e-13 * np.abs(y_glob).max()
+
+
 # ---- the HIP path ------------------------------------------------------------------------------------------------
 
 
