@@ -122,7 +122,8 @@ int storm_hip_vec_destroy(storm_hip_vec *v);
 int storm_hip_vec_size(const storm_hip_vec *v, int64_t *n_owned, int64_t *n_halo);
 int storm_hip_vec_upload(storm_hip_vec *v, const double *host, int64_t n);
 int storm_hip_vec_download(const storm_hip_vec *v, double *host, int64_t n);
-/* Raw device pointer (n_owned + n_halo doubles), for zero-copy interop. */
+/* Raw device pointer (n_owned + n_halo doubles), for zero-copy interop.  The address stays valid until the vector is
+ * destroyed (a vector that has given its address out is never one whose storage option lazy_statements = 2 exchanges). */
 int storm_hip_vec_device_ptr(storm_hip_vec *v, void **dev_ptr);
 /* The context a vector lives on. */
 int storm_hip_vec_context(const storm_hip_vec *v, storm_hip_ctx **ctx);
@@ -276,8 +277,13 @@ int storm_hip_op_create_csr(storm_hip_ctx *ctx, int64_t n_rows, int64_t n_halo,
  *              apply with its fused-dot epilogue).  Every other entry point launches what waits first, so nothing is
  *              observed out of order; nothing waits inside a solver's operator / preconditioner callback.  The
  *              linear statements and their reductions give the eager kernels' values bit for bit; the apply's fused dot
- *              sums in the SpMV kernel's order (equal to rounding) (csrc/lazy.hip).  The host loops of Storm.hpp / api.py
- *              switch it on for their duration (IterativeSolver::lazy_statements).
+ *              sums in the SpMV kernel's order (equal to rounding) (csrc/lazy.hip).  A statement neither the last one
+ *              nor the sum depends on keeps waiting (the x-update above, when `<r, r>` is asked for).  Value 2 adds the
+ *              library's fused CG step for a host loop: `x += alpha p; ...; p <<= r + beta p; z = A p; <p, z>` on a lattice
+ *              operator is ONE launch (x, the new p, z and the sum: 56 B/row, the device loop's kernel, its FMA roundings);
+ *              the new p is written to a spare vector whose storage p's handle then takes over -- never for a vector whose
+ *              address storm_hip_vec_device_ptr has handed out.  The host loops of Storm.hpp / api.py switch level 2 on
+ *              for their duration (IterativeSolver::lazy_statements).
  * RCCL transport:
  *   rccl_fused (1), rccl_ticket (1): the fused CG step on a partitioned lattice operator (the boundary planes of the new
  *              direction packed by a small kernel and sent under the marching launch); local sums finished in the kernels;
@@ -303,9 +309,9 @@ int storm_hip_ctx_set_option(storm_hip_ctx *ctx, const char *key, int64_t value)
  * reference logs one line per solve, Solver.hpp:144-145).  Keys: "resident_solves" (csrc/resident.hip),
  * "latency_solves" (csrc/latency.hip: one cooperative kernel per solve), "throughput_solves" (a kernel per statement,
  * fused loops of csrc/solvers.hip), "engine_solves" (csrc/krylov.hip), "cg_fused_steps" (solves whose CG step rode in
- * the SpMV launch), "lazy_fused_dots" / "lazy_fused_pairs" / "lazy_apply_dots" / "lazy_waiting" (option lazy_statements:
- * reductions that rode in a statement's kernel, pairs of statements that left as one pass, applies that left with a fused
- * dot, statements waiting now).  On the peer-window transport, where the time of the exchanges went (ticks of 10 ns of the device's
+ * the SpMV launch), "lazy_fused_dots" / "lazy_fused_pairs" / "lazy_apply_dots" / "lazy_cg_steps" / "lazy_waiting" (option
+ * lazy_statements: reductions that rode in a statement's kernel, pairs of statements that left as one pass, applies that
+ * left with a fused dot, fused CG steps, statements waiting now).  On the peer-window transport, where the time of the exchanges went (ticks of 10 ns of the device's
  * real-time counter, and counts): "ipc_allreduce_wait_ticks" / "ipc_allreduces" (from a rank's own contribution being
  * stored to every rank's being read), "ipc_ack_wait_ticks" / "ipc_ack_waits" (a send waiting for the receivers to have
  * consumed the plane two exchanges back), "ipc_halo_slow_poll_ticks" / "ipc_halo_slow_polls" (halo values that had not

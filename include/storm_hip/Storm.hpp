@@ -594,7 +594,7 @@ struct LazyScope {
   LazyScope(const V& v, bool on) {
     if constexpr (std::is_same_v<V, DeviceVector>) {
       if (on && v.handle() != nullptr && storm_hip_vec_context(v.handle(), &ctx) == STORM_HIP_OK && ctx != nullptr)
-        (void)storm_hip_ctx_set_option(ctx, "lazy_statements", 1);
+        (void)storm_hip_ctx_set_option(ctx, "lazy_statements", 2);
     }
   }
   ~LazyScope() {

@@ -864,7 +864,7 @@ class IterativeSolver(Solver):
         # needs them, and a reduction over what the last one writes rides in its kernel -- the same values, bit for bit
         lazy_ctx = x_vec.ctx if (self.lazy_statements and getattr(x_vec, "ctx", None) is not None) else None
         if lazy_ctx is not None:
-            lazy_ctx.set_option("lazy_statements", 1)
+            lazy_ctx.set_option("lazy_statements", 2)
         try:
             return self._host_loop(x_vec, b_vec, any_op)
         finally:

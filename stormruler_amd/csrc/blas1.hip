@@ -499,14 +499,14 @@ int storm_hip_fill(storm_hip_vec *y, double value) {
 
 int storm_hip_copy(storm_hip_vec *y, const storm_hip_vec *x) {
   STORM_TRY(check_pair(y, x, "copy"));
-  if (lazy_on(y->ctx) && y->d != x->d) return lazy_push_lin(y->ctx, y->d, 1.0, x->d, 0.0, nullptr, 1, y->n_owned);
+  if (lazy_on(y->ctx) && y->d != x->d) return lazy_push_lin(y->ctx, y, 1.0, x->d, 0.0, nullptr, 1, y->n_owned);
   STORM_TRY(lazy_sync(y->ctx));
   return k_copy(y->ctx, y->d, x->d, y->n_owned, y->ctx->api_done);
 }
 
 int storm_hip_scale(storm_hip_vec *y, double s) {
   STORM_REQUIRE(y, "scale: null vector");
-  if (lazy_on(y->ctx)) return lazy_push_lin(y->ctx, y->d, s, y->d, 0.0, nullptr, 1, y->n_owned);
+  if (lazy_on(y->ctx)) return lazy_push_lin(y->ctx, y, s, y->d, 0.0, nullptr, 1, y->n_owned);
   STORM_TRY(lazy_sync(y->ctx));
   return k_scale(y->ctx, y->d, y->n_owned, host_scal(s), false, nullptr);
 }
@@ -519,14 +519,14 @@ int storm_hip_div_scalar(storm_hip_vec *y, double s) {
 
 int storm_hip_axpy(storm_hip_vec *y, double a, const storm_hip_vec *x) {
   STORM_TRY(check_pair(y, x, "axpy"));
-  if (lazy_on(y->ctx)) return lazy_push_lin(y->ctx, y->d, a, x->d, 1.0, y->d, 2, y->n_owned);
+  if (lazy_on(y->ctx)) return lazy_push_lin(y->ctx, y, a, x->d, 1.0, y->d, 2, y->n_owned);
   STORM_TRY(lazy_sync(y->ctx));
   return k_axpbz(y->ctx, y->d, host_scal(a), x->d, host_scal(1.0), y->d, y->n_owned, y->ctx->api_done);
 }
 
 int storm_hip_xpay(storm_hip_vec *y, const storm_hip_vec *x, double b) {
   STORM_TRY(check_pair(y, x, "xpay"));
-  if (lazy_on(y->ctx)) return lazy_push_lin(y->ctx, y->d, 1.0, x->d, b, y->d, 2, y->n_owned);
+  if (lazy_on(y->ctx)) return lazy_push_lin(y->ctx, y, 1.0, x->d, b, y->d, 2, y->n_owned);
   STORM_TRY(lazy_sync(y->ctx));
   return k_axpbz(y->ctx, y->d, host_scal(1.0), x->d, host_scal(b), y->d, y->n_owned, y->ctx->api_done);
 }
@@ -534,7 +534,7 @@ int storm_hip_xpay(storm_hip_vec *y, const storm_hip_vec *x, double b) {
 int storm_hip_axpbz(storm_hip_vec *y, double a, const storm_hip_vec *x, double b, const storm_hip_vec *z) {
   STORM_TRY(check_pair(y, x, "axpbz"));
   STORM_TRY(check_pair(y, z, "axpbz"));
-  if (lazy_on(y->ctx)) return lazy_push_lin(y->ctx, y->d, a, x->d, b, z->d, 2, y->n_owned);
+  if (lazy_on(y->ctx)) return lazy_push_lin(y->ctx, y, a, x->d, b, z->d, 2, y->n_owned);
   STORM_TRY(lazy_sync(y->ctx));
   return k_axpbz(y->ctx, y->d, host_scal(a), x->d, host_scal(b), z->d, y->n_owned, y->ctx->api_done);
 }

@@ -94,6 +94,7 @@ struct LazyStmt {
   const storm_hip_op *op = nullptr;
   double alpha = 0.0, beta = 0.0;
   const double *x = nullptr;
+  storm_hip_vec *yvec = nullptr;  // the vector y is the storage of (kind 0)
 };
 
 // What a storm_hip_krylov object owns on the device and in pinned host memory; a destroyed engine leaves it with its
@@ -183,7 +184,8 @@ struct storm_hip_ctx {
   int64_t opt_test_disable = 0;         // option test_disable (context.hip): a bit mask that switches single refinements OFF so that tests can compare a kernel with its plainer form, bit for bit
   int64_t opt_lazy = 0;                 // option lazy_statements
   int callback_depth = 0;               // > 0 while a solver is inside an operator / preconditioner callback (nothing waits there)
-  int64_t n_lazy_fused_dots = 0, n_lazy_fused_pairs = 0, n_lazy_apply_dots = 0;
+  int64_t n_lazy_fused_dots = 0, n_lazy_fused_pairs = 0, n_lazy_apply_dots = 0, n_lazy_cg_steps = 0;
+  storm_hip_vec *lazy_spare = nullptr;  // where a fused CG step writes the new direction (lazy.hip: try_cg_step)
   int64_t opt_profile_comm = 0;       // RCCL transport: stamp kernels around the halo exchange and the all-reduces (comm.hip comm_profile_*)
   int64_t opt_blas1_nt = 1;  // non-temporal loads/stores in the streaming kernels: 0 never, 1 for vectors of at least blas1_nt_rows rows, 2 always
   static constexpr int64_t opt_blas1_nt_rows = (int64_t)6 << 20;  // (48 MiB per vector: beyond, a solver's vectors no longer stay in the 256 MiB Infinity Cache between kernels)
@@ -272,6 +274,7 @@ struct storm_hip_vec {
   double *d = nullptr;     // element 0 (kVecGuard zero doubles sit in front of it, >= 4 behind the last row)
   double *base = nullptr;  // the allocation
   size_t bytes = 0;        // allocation size (pool key)
+  bool exposed = false;    // storm_hip_vec_device_ptr has handed d out: the storage is never exchanged (lazy.hip)
 };
 constexpr int kVecGuard = 32;
 
@@ -427,6 +430,7 @@ struct SpmvDot {
     double *x = nullptr;
     const double *r = nullptr;
     double *p_out = nullptr;
+    double ca_imm = 0.0, cb_imm = 0.0;  // with ca / cb null: the values themselves (unsplit marching launch only)
   } cg;
 };
 int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, double *y,
@@ -473,7 +477,7 @@ int res_solve(bool bicgstab, const storm_hip_op *op, double alpha, double beta, 
 // lazy.hip
 int lazy_flush(storm_hip_ctx *c);  // launch whatever is held back (a no-op when nothing is)
 static inline int lazy_sync(storm_hip_ctx *c) { return (c != nullptr && !c->lazy_q.empty()) ? lazy_flush(c) : 0; }
-int lazy_push_lin(storm_hip_ctx *c, double *y, double c0, const double *v0, double c1, const double *v1, int nt, int64_t n);
+int lazy_push_lin(storm_hip_ctx *c, storm_hip_vec *y, double c0, const double *v0, double c1, const double *v1, int nt, int64_t n);
 int lazy_push_apply(const storm_hip_op *op, double alpha, double beta, const double *x, double *y);
 bool lazy_try_dot(storm_hip_ctx *c, const double *a, const double *b, int64_t n, double *result, int *status);
 

@@ -86,6 +86,7 @@ int storm_hip_ctx_destroy(storm_hip_ctx *c) {
   if (!c) return STORM_HIP_OK;
   (void)hipSetDevice(c->device);
   c->lazy_q.clear();  // (statements nobody asked the result of)
+  if (c->lazy_spare) (void)storm_hip_vec_destroy(c->lazy_spare), c->lazy_spare = nullptr;
   (void)hipDeviceSynchronize();
   comm_destroy(c);
   for (auto &ev : c->ev_ring) (void)hipEventDestroy(ev);
@@ -226,6 +227,7 @@ int storm_hip_ctx_get_counter(storm_hip_ctx *c, const char *key, int64_t *value)
   else if (!strcmp(key, "lazy_fused_dots")) *value = c->n_lazy_fused_dots;
   else if (!strcmp(key, "lazy_fused_pairs")) *value = c->n_lazy_fused_pairs;
   else if (!strcmp(key, "lazy_apply_dots")) *value = c->n_lazy_apply_dots;
+  else if (!strcmp(key, "lazy_cg_steps")) *value = c->n_lazy_cg_steps;
   else if (!strcmp(key, "lazy_waiting")) *value = (int64_t)c->lazy_q.size();
   else if (!strncmp(key, "ipc_", 4)) {
     // the peer-window transport's device-side waits (csrc/ipc_device.hpp IpcDev::stat): ticks of 10 ns and counts
@@ -676,6 +678,7 @@ int storm_hip_fill_randomly(storm_hip_vec *v) {
 int storm_hip_vec_device_ptr(storm_hip_vec *v, void **dev_ptr) {
   STORM_REQUIRE(v && dev_ptr, "vec_device_ptr: null argument");
   STORM_TRY(lazy_sync(v->ctx));  // (the caller is about to touch the memory itself)
+  v->exposed = true;             // (... and may keep the address: this vector's storage stays where it is)
   *dev_ptr = v->d;
   return STORM_HIP_OK;
 }

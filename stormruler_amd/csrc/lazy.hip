@@ -8,12 +8,21 @@
 // that statement's kernel:
 //     x += alpha p;  r -= alpha z;  <r, r>       ONE pass: both updates and the sum (lazy_lin_kernel<2, true>)
 //     z = A p;  <p, z>                           the apply with its fused-dot epilogue (spmv_launch with SpmvDot)
+//     x += alpha p;  [r -= alpha z;  <r, r>;]  p <<= r + beta p;  z = A p;  <p, z>
+//                                                on a lattice operator the library's own fused CG step
+//                                                (cg_step_march_kernel: x, p', z = A p' and the sum in one pass):
+//                                                a statement the reduction does not depend on keeps waiting
+//                                                (x += alpha p above), and p' is written to a spare vector whose
+//                                                storage then BECOMES p's (never for a vector whose address
+//                                                storm_hip_vec_device_ptr has handed out)
 // Two consecutive linear statements always leave as one pass (statement 2 sees statement 1's values: elementwise, in
 // order).  Every other entry point of the library launches the waiting statements first (lazy_sync), so nothing is ever
 // observed out of order; with the option off the queue is always empty.  Arithmetic: for the linear statements and their
 // reductions the expressions, the block / thread mapping and the summation trees of the eager kernels (blas1.hip
 // ew_kernel<AxpbzF>, multi_dot_ticket_kernel) -- the same bits, statement by statement; the apply's fused dot sums in the
-// SpMV kernel's own order (per wave, as in the library's fused solver loops): equal to rounding (tests/test_gpu_lazy.py).
+// SpMV kernel's own order (per wave, as in the library's fused solver loops), and the fused CG step rounds x + alpha p
+// and r + beta p once (an FMA, as the library's device loop does) where the statements round the product first: equal to
+// rounding (tests/test_gpu_lazy.py).
 #include <cmath>
 #include <cstring>
 
@@ -212,6 +221,72 @@ int launch_apply(storm_hip_ctx *c, const LazyStmt &a) {
   return spmv_launch(a.op, host_scal(a.alpha), host_scal(a.beta), a.x, a.y, nullptr, nullptr);
 }
 
+// Two linear statements that may run in either order: neither writes what the other reads or writes.
+bool commute(const LazyStmt &s, const LazyStmt &t) {
+  if (s.y == t.y) return false;
+  for (int k = 0; k < 2; ++k)
+    if ((k < t.nt && t.v[k] == s.y) || (k < s.nt && s.v[k] == t.y)) return false;
+  return true;
+}
+
+// the sum a kernel left in device memory, to the host as two self-validating words the host polls (no copy, no stream
+// wait: ~10 us less per reduction)
+int fetch_sum(storm_hip_ctx *c, const double *d_value, double *result) {
+  const unsigned tag = ++c->result_seq ? c->result_seq : ++c->result_seq;
+  hipLaunchKernelGGL(lazy_result_kernel, dim3(1), dim3(1), 0, c->stream, d_value, c->d_result_words + 16 * kLazySlot, tag);
+  HIP_TRY(hipGetLastError());
+  volatile unsigned long long *hw = c->h_result_words + 16 * kLazySlot;
+  for (long spin = 0; (unsigned)(hw[0] >> 32) != tag || (unsigned)(hw[1] >> 32) != tag; ++spin)
+    if ((spin & 0x3fff) == 0x3fff && hipStreamQuery(c->stream) == hipSuccess &&
+        ((unsigned)(hw[0] >> 32) != tag || (unsigned)(hw[1] >> 32) != tag)) {
+      HIP_TRY(hipMemcpy(result, d_value, sizeof(double), hipMemcpyDeviceToHost));
+      return STORM_HIP_OK;
+    }
+  const unsigned long long bits = (hw[1] << 32) | (hw[0] & 0xffffffffull);
+  memcpy(result, &bits, sizeof(double));
+  return STORM_HIP_OK;
+}
+
+// q = [..., x += ca p, p = r + cb p, z = beta p + alpha M(p)] and the sum asked for is <p, z>, M a lattice operator the
+// marching kernel takes: the library's fused CG step.  p' goes to the spare vector, whose storage p's handle takes over.
+// false: not that shape (nothing launched, q untouched).
+bool try_cg_step(storm_hip_ctx *c, std::vector<LazyStmt> &q, const double *a, const double *b, double *result, int *status) {
+  if (q.size() < 3 || c->opt_fuse_dot == 0 || c->opt_lazy < 2) return false;  // (lazy_statements = 2)
+  const LazyStmt &ap = q[q.size() - 1], &sp = q[q.size() - 2], &sx = q[q.size() - 3];
+  if (ap.kind != 1 || sp.kind != 0 || sx.kind != 0) return false;
+  const int64_t n = ap.n;
+  double *p = sp.y, *x = sx.y, *z = ap.y;
+  const double *r = sp.v[0];
+  if (sp.n != n || sx.n != n || sp.nt != 2 || sx.nt != 2) return false;
+  if (sp.v[1] != p || sp.c[0] != 1.0 || r == p) return false;        // p = r + cb p
+  if (sx.v[1] != x || sx.c[1] != 1.0 || sx.v[0] != p) return false;  // x = ca p + x
+  if (ap.x != p || !((a == p && b == z) || (a == z && b == p))) return false;
+  if (x == p || x == r || x == z || z == p || z == r) return false;
+  storm_hip_vec *pv = sp.yvec;
+  if (pv == nullptr || pv->d != p || pv->exposed || pv->n_halo != 0 || pv->n_owned != n || !spmv_can_march(ap.op)) return false;
+  if (c->lazy_spare != nullptr && (c->lazy_spare->n_owned != pv->n_owned || c->lazy_spare->bytes != pv->bytes)) {
+    (void)storm_hip_vec_destroy(c->lazy_spare);
+    c->lazy_spare = nullptr;
+  }
+  if (c->lazy_spare == nullptr && vec_create_work(pv, &c->lazy_spare) != STORM_HIP_OK) return false;
+  const LazyStmt step[3] = {sx, sp, ap};
+  c->lazy_q.assign(q.begin(), q.end() - 3);
+  *status = lazy_flush(c);
+  if (*status != STORM_HIP_OK) return true;
+  int nblocks = 0, ticketed = 0;
+  SpmvDot sd;
+  sd.w = p, sd.yy = false, sd.partials = c->d_partials, sd.nblocks_out = &nblocks;
+  sd.out[0] = c->d_scalars, sd.ticketed_out = &ticketed;
+  sd.cg.x = x, sd.cg.r = r, sd.cg.p_out = c->lazy_spare->d, sd.cg.ca_imm = step[0].c[0], sd.cg.cb_imm = step[1].c[1];
+  *status = spmv_launch(step[2].op, host_scal(step[2].alpha), host_scal(step[2].beta), p, z, &sd, nullptr);
+  if (*status != STORM_HIP_OK) return true;
+  std::swap(pv->d, c->lazy_spare->d), std::swap(pv->base, c->lazy_spare->base);  // (same size, same pool key)
+  if (!ticketed) *status = k_reduce_final(c, c->d_partials, nblocks, 1, c->d_scalars, nullptr);
+  if (*status == STORM_HIP_OK) *status = fetch_sum(c, c->d_scalars, result);
+  ++c->n_lazy_cg_steps;
+  return true;
+}
+
 }  // namespace
 
 int lazy_flush(storm_hip_ctx *c) {
@@ -233,10 +308,12 @@ int lazy_flush(storm_hip_ctx *c) {
   return STORM_HIP_OK;
 }
 
-int lazy_push_lin(storm_hip_ctx *c, double *y, double c0, const double *v0, double c1, const double *v1, int nt, int64_t n) {
+int lazy_push_lin(storm_hip_ctx *c, storm_hip_vec *yv, double c0, const double *v0, double c1, const double *v1, int nt, int64_t n) {
   // at most two linear statements wait, and none behind an apply (the apply's x may be what this one writes)
   if (!c->lazy_q.empty() && (c->lazy_q.back().kind == 1 || c->lazy_q.size() >= 2 || c->lazy_q.back().n != n)) STORM_TRY(lazy_flush(c));
+  double *y = yv->d;
   LazyStmt s;
+  s.yvec = yv;
   s.kind = 0, s.y = y, s.v[0] = v0, s.v[1] = nt == 2 ? v1 : nullptr, s.c[0] = c0, s.c[1] = nt == 2 ? c1 : 0.0, s.nt = nt, s.n = n;
   c->lazy_q.push_back(s);
   return STORM_HIP_OK;
@@ -269,11 +346,19 @@ bool lazy_try_dot(storm_hip_ctx *c, const double *a, const double *b, int64_t n,
     // everything before the last one or two linear statements goes out first; those ride with the reduction
     size_t first = q.size() - 1;
     if (first > 0 && q[first - 1].kind == 0 && q[first - 1].n == n) --first;
+    if (first + 2 == q.size() && first == 0 && commute(q[0], q[1]) && a != q[0].y && b != q[0].y) {
+      // the statement in front has nothing to do with the last one or the sum: it keeps waiting (the same bytes
+      // either way; what follows may take it along -- the fused CG step above)
+      *status = launch_lins(c, q.data() + 1, 1, a, b, result);
+      c->lazy_q.assign(q.begin(), q.begin() + 1);
+      return true;
+    }
     c->lazy_q.assign(q.begin(), q.begin() + (long)first);
     *status = lazy_flush(c);
     if (*status == STORM_HIP_OK) *status = launch_lins(c, q.data() + first, (int)(q.size() - first), a, b, result);
     return true;
   }
+  if (try_cg_step(c, q, a, b, result, status)) return true;
   // an apply: everything before it goes out, then y = beta x + alpha M(x) with <w, y> (w the other operand, or y itself)
   c->lazy_q.assign(q.begin(), q.end() - 1);
   *status = lazy_flush(c);
@@ -294,24 +379,7 @@ bool lazy_try_dot(storm_hip_ctx *c, const double *a, const double *b, int64_t n,
   if (nblocks <= 0) return false;  // the launch did not fuse after all: the ordinary reduction follows
   if (!ticketed) *status = k_reduce_final(c, c->d_partials, nblocks, yy ? 2 : 1, c->d_scalars, nullptr);
   if (*status != STORM_HIP_OK) return true;
-  // the sum to the host as two self-validating words the host polls (no copy, no stream wait: ~10 us less per reduction)
-  const unsigned tag = ++c->result_seq ? c->result_seq : ++c->result_seq;
-  hipLaunchKernelGGL(lazy_result_kernel, dim3(1), dim3(1), 0, c->stream, c->d_scalars + (yy ? 1 : 0), c->d_result_words + 16 * kLazySlot, tag);
-  if (hipGetLastError() != hipSuccess) {
-    set_error("lazy dot: launch failed");
-    *status = STORM_HIP_E_HIP;
-    return true;
-  }
-  volatile unsigned long long *hw = c->h_result_words + 16 * kLazySlot;
-  for (long spin = 0; (unsigned)(hw[0] >> 32) != tag || (unsigned)(hw[1] >> 32) != tag; ++spin)
-    if ((spin & 0x3fff) == 0x3fff && hipStreamQuery(c->stream) == hipSuccess &&
-        ((unsigned)(hw[0] >> 32) != tag || (unsigned)(hw[1] >> 32) != tag)) {
-      if (hipMemcpy(result, c->d_scalars + (yy ? 1 : 0), sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) *status = STORM_HIP_E_HIP;
-      ++c->n_lazy_apply_dots;
-      return true;
-    }
-  const unsigned long long bits = (hw[1] << 32) | (hw[0] & 0xffffffffull);
-  memcpy(result, &bits, sizeof(double));
+  *status = fetch_sum(c, c->d_scalars + (yy ? 1 : 0), result);
   ++c->n_lazy_apply_dots;
   return true;
 }

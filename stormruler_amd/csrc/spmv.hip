@@ -185,7 +185,7 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
       STORM_REQUIRE(sd->cg.x != nullptr, "spmv: the fused CG step updates x");
       dot.tickets = nullptr, dot.nblocks_total = 4 * nb_total;  // (the tiled form of the step leaves per-wave partials)
       if (sd->ticketed_out) *sd->ticketed_out = 0;
-      cgf = CgFuseArgs{sd->cg.iteration, sd->cg.my_iteration, sd->cg.ca, sd->cg.cb, sd->cg.x, sd->cg.r, sd->cg.p_out};
+      cgf = CgFuseArgs{sd->cg.iteration, sd->cg.my_iteration, sd->cg.ca, sd->cg.cb, sd->cg.x, sd->cg.r, sd->cg.p_out, sd->cg.ca_imm, sd->cg.cb_imm};
     }
     MarchArgs M;
     int nb_march = 0;
@@ -202,6 +202,8 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
       }
       return spmv_march_run(op, M, nb_march, alpha, beta, x, y, dot, done, cgf, IpcSendArgs{});
     }
+    STORM_REQUIRE(!cg_fused || (cgf.ca != nullptr && cgf.cb != nullptr && cgf.iteration != nullptr),
+                  "spmv: a fused CG step with immediate coefficients needs the marching kernel");
     STORM_TRY(launch_range(op, alpha, beta, x, y, nullptr, op->n_slices, dot, fuse_dot, done, accumulate, nullptr,
                            cg_fused ? &cgf : nullptr));
   } else {

@@ -168,6 +168,7 @@ struct CgFuseArgs {
                                // operator to it, nothing else (BiCGStab's s = r - alpha v; t = A s)
   const double *r;
   double *p_out;
+  double ca_imm, cb_imm;       // marching kernel only: alpha, beta themselves where ca / cb are null (a HOST loop's step: lazy.hip)
 };
 
 // ---- the fused CG step, marching in z ------------------------------------------------------------------------------

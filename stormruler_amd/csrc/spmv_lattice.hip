@@ -225,7 +225,7 @@ __global__ __launch_bounds__(kBlock) void cg_step_march_kernel(SellArgs A, March
     ipc_halo_send_block(S.w, S.sp, p_in, (int)blockIdx.x, F.r, *F.cb);
     return;
   }
-  if (*F.iteration < F.my_iteration) return;  // enqueued past convergence: that iteration never ran
+  if (F.iteration != nullptr && *F.iteration < F.my_iteration) return;  // enqueued past convergence: that iteration never ran
   const int done_flag = done ? *done : 0;
   const CanonTileArgs &T = M.T;
   extern __shared__ __attribute__((aligned(16))) double tile_sh[];  // [3][a + kTileRun + a]
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(kBlock) void cg_step_march_kernel(SellArgs A, March
   const int z_begin = zc * M.zc_planes, z_end = min(z_begin + M.zc_planes, T.plane_end);
   const int ldw = kTileRun + 2 * a;
   const double alpha = ld_scal2(alpha_s), beta = ld_scal2(beta_s);
-  const double cg_a = *F.ca, cg_b = *F.cb;
+  const double cg_a = F.ca ? *F.ca : F.ca_imm, cg_b = F.cb ? *F.cb : F.cb_imm;
   const uint32_t last_row = (uint32_t)(A.n_rows - 1);
   const char *pb = reinterpret_cast<const char *>(p_in), *rb = reinterpret_cast<const char *>(F.r);
   const char *pg_base = pb - (size_t)kVecGuard * 8, *rg_base = rb - (size_t)kVecGuard * 8;

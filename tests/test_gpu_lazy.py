@@ -233,6 +233,70 @@ def test_a_users_host_loop_gets_the_fused_kernels_unchanged(setup):
     assert abs(out[True][0] - ref.iterations) <= 2 and np.linalg.norm(out[True][2] - ref.x) <= 1e-8 * np.linalg.norm(ref.x)
 
 
+def _reference_cg_body(api, op, vs, steps):
+    """SolverCg.hpp:96-123 exactly: no reduction between `p <<= r + beta p` and the next `z = A p`."""
+    x, p, r, z = vs
+    seen = []
+    gamma = api.dot_product(r, r)
+    for _ in range(steps):
+        op.mul(z, p)
+        pz = api.dot_product(p, z)
+        alpha = api.safe_divide(gamma, pz)
+        x += alpha * p
+        r -= alpha * z
+        gamma_bar, gamma = gamma, api.dot_product(r, r)
+        beta = api.safe_divide(gamma, gamma_bar)
+        p <<= r + beta * p
+        seen += [pz, gamma]
+    return seen
+
+
+def test_level_two_runs_the_librarys_fused_cg_step_for_a_host_loop():
+    """lazy_statements = 2 on a lattice operator: `x += alpha p` keeps waiting while `<r, r>` leaves with `r -= alpha z`,
+    and `x += alpha p; p <<= r + beta p; z = A p; <p, z>` is ONE launch of the marching step kernel, the new p written to a
+    spare vector whose storage p's handle takes over.  Values: the statements' to rounding (the kernel's FMAs round once).
+    A vector whose address has been handed out is never exchanged: the statements then leave as pair + apply."""
+    import ctypes as C
+
+    from stormruler_amd import _lib, api, mesh
+
+    ctx = api.Context(0)
+    ctx.set_option("spmv_canon_tile_min_rows", 0)  # (a 15 k-row lattice on the kernels of the large ones)
+    g = mesh.structured_box(32, 24, 20)
+    mat = api.StencilMatrix.from_face_graph(ctx, g)
+    op = api.HipStencilOperator(mat, -1.0, 0.0)
+    n, steps = g.n_cells, 7
+    keys = ("lazy_cg_steps", "lazy_apply_dots", "lazy_fused_dots", "lazy_fused_pairs")
+    runs = {}
+    for mode in ("eager", "level1", "level2", "exposed"):
+        vs = _vectors(api, ctx, n, 5, 4)
+        if mode == "exposed":
+            ptr = C.c_void_p()
+            assert _lib.lib.storm_hip_vec_device_ptr(vs[1]._h, C.byref(ptr)) == 0
+        before = {k: ctx.counter(k) for k in keys}
+        ctx.set_option("lazy_statements", {"eager": 0, "level1": 1}.get(mode, 2))
+        seen = _reference_cg_body(api, op, vs, steps)
+        assert ctx.counter("lazy_waiting") == (0 if mode == "eager" else 2)  # the last x += alpha p and p <<= r + beta p
+        ctx.set_option("lazy_statements", 0)
+        assert ctx.counter("lazy_waiting") == 0
+        if mode == "exposed":
+            again = C.c_void_p()
+            assert _lib.lib.storm_hip_vec_device_ptr(vs[1]._h, C.byref(again)) == 0 and again.value == ptr.value
+        runs[mode] = (seen, [v.to_numpy() for v in vs], {k: ctx.counter(k) - before[k] for k in keys})
+    for mode in ("level1", "level2", "exposed"):
+        assert np.allclose(runs["eager"][0], runs[mode][0], rtol=1e-11, atol=0), mode
+        for a, b in zip(runs["eager"][1], runs[mode][1]):
+            assert np.linalg.norm(a - b) <= 1e-11 * np.linalg.norm(a), mode
+    # the first apply has no statements in front of it; every later step is the fused one
+    assert runs["level2"][2] == {"lazy_cg_steps": steps - 1, "lazy_apply_dots": 1, "lazy_fused_dots": steps, "lazy_fused_pairs": 1}
+    for mode in ("level1", "exposed"):
+        assert runs[mode][2] == {"lazy_cg_steps": 0, "lazy_apply_dots": steps, "lazy_fused_dots": steps, "lazy_fused_pairs": steps}, mode
+    # levels 1 and 2 without the exchange launch the same statements' kernels: the same bits
+    assert runs["level1"][0] == runs["exposed"][0]
+    mat.close()
+    ctx.close()
+
+
 def test_nothing_waits_inside_a_solver_callback(setup):
     """A device-loop solve whose operator is a callback: the calls the callback makes are launched at once (the engine's
     own kernels follow them on the stream)."""

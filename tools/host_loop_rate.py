@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """What a HOST loop costs: the reference's CG body typed statement by statement against Storm.hpp by a user
 (tests/cpp/poisson_driver.cpp `user-cg`) at n^3, with the library's lazy statements (csrc/lazy.hip: `x += alpha p;
-r -= alpha z; <r, r>` one kernel, `z = A p; <p, z>` the apply with its fused dot) and without (every statement a launch
+r -= alpha z; <r, r>` one kernel, `x += alpha p; p <<= r + beta p; z = A p; <p, z>` the fused CG step) and without (every statement a launch
 when it is called), against the library's own device-resident CG loop.  us per iteration, fixed iteration count."""
 import json
 import os
