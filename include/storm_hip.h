@@ -286,7 +286,9 @@ int storm_hip_op_create_csr(storm_hip_ctx *ctx, int64_t n_rows, int64_t n_halo,
  *              for their duration (IterativeSolver::lazy_statements).
  * RCCL transport:
  *   rccl_fused (1), rccl_ticket (1): the fused CG step on a partitioned lattice operator (the boundary planes of the new
- *              direction packed by a small kernel and sent under the marching launch); local sums finished in the kernels;
+ *              direction packed by a small kernel and sent under the marching launch); local sums finished in the kernels
+ *              (CG's <r, r>; BiCGStab's |r|^2 and <rt, r>, whose alpha and omega the update kernels form themselves from
+ *              the all-reduced sums -- no scalar-step launch behind those all-reduces);
  *   rccl_early_halo (1): BiCGStab -- the boundary planes of s and of the new direction are formed by a small kernel and sent
  *              before the update kernel that forms the vector runs.  The same bits;
  *   rccl_flag_wait (1): the boundary rows of an apply are released by a flag in device memory (set by a one-thread kernel

@@ -13,6 +13,7 @@
 
 #include "common.hpp"
 #include "ipc_device.hpp"
+#include "solver_device.hpp"
 
 namespace storm {
 
@@ -403,7 +404,8 @@ __global__ __launch_bounds__(kBlock) void halo_pack_bicg_kernel(int64_t n, const
                                                                 const double *__restrict__ p, const double *__restrict__ v,
                                                                 const double *__restrict__ sa, const double *__restrict__ sb,
                                                                 double *__restrict__ buf) {
-  const double a = *sa, b = sb ? *sb : 0.0;  // MODE 0: alpha; MODE 1: beta, omega
+  // MODE 0: alpha (sb given: rho and <rt, v> -- alpha is formed here, with the update kernel's expression); MODE 1: beta, omega
+  const double a = (MODE == 0 && sb) ? safe_divide(*sa, *sb) : *sa, b = sb ? *sb : 0.0;
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
     const int j = idx[i];
@@ -426,6 +428,8 @@ int comm_halo_exchange_begin_formed(const storm_hip_op *op, int mode, const doub
     HIP_TRY(hipGetLastError());
   }
   if (pe >= 0) prof_stamp(c, c->stream, pe, 2);
+  // (the forming kernel's last block setting the flag itself was measured: +20 us per BiCGStab iteration -- an agent-scope
+  //  release per block writes its XCD's L2 back each time; the kernel boundary in front of the one-thread setter does it once)
   STORM_TRY(ready_handoff(c));  // the rows to send are packed
   if (pe >= 0) prof_stamp(c, c->comm_stream, pe, 1);
   NCCL_TRY(ncclGroupStart());

@@ -483,11 +483,12 @@ __global__ __launch_bounds__(kBlock) void bicg_update_kernel(int64_t n, SolverSt
     const double mine[2] = {s0, s1};
     double total[2];
     if (ticket_reduce_wave0<2>(tickets, mine, 2, bx, gridDim.x, total)) {
-      if (use_ipc) ipc_allreduce_wave<2>(ipc_w, total, 2);  // (peer windows: the global sums, the same bits on every rank)
+      if (use_ipc == 1) ipc_allreduce_wave<2>(ipc_w, total, 2);  // (peer windows: the global sums, the same bits on every rank)
       if (threadIdx.x == 0) {
         st->s[S_RR] = total[0], st->s[S_RHO_NEW] = total[1];
         st->s[S_OMEGA] = omega;  // (block 0's store of the same value need not be visible to this block yet)
-        do_step(STEP_BICG_END, st, GmresDev{});  // :164, :116-118 and the convergence rule
+        // (use_ipc == 2, RCCL: this rank's sums only -- the host enqueues the all-reduce and the step behind this kernel)
+        if (use_ipc != 2) do_step(STEP_BICG_END, st, GmresDev{});  // :164, :116-118 and the convergence rule
       }
     }
   }
@@ -1451,6 +1452,11 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
                         nbv <= kTicketGroup * kTicketMaxGroups;
   // RCCL: the halo of the vector an update kernel is about to form leaves BEFORE that kernel (comm.hip)
   const bool early_halo = c->comm != nullptr && comm_is_rccl(c) && c->opt_rccl_early_halo != 0 && op->halo.n_nbrs > 0;
+  // RCCL (option rccl_ticket): no scalar-step launch behind the all-reduces of <rt, v> and (<t, r>, <t, t>) -- the update
+  // kernels (and the kernel that forms the halo of s) form alpha / omega themselves, as on one rank; the second half-step
+  // finishes this rank's |r|^2 and <rt, r> by tickets, the all-reduce and the step follow it: four launches less per iteration
+  const bool rccl_tick = c->opt_ticket_reduce != 0 && c->opt_rccl_ticket != 0 && c->comm != nullptr && comm_is_rccl(c) &&
+                         nbv <= kTicketGroup * kTicketMaxGroups;
   int ticketed = 0;
   auto apply_dir = [&](const double *xin, double *yout, const double *w, bool yy, int out0, int out1) -> int {
     c->spmv_reverse = flip();
@@ -1470,6 +1476,18 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
                          d.slot(S_RTV), d.st, TicketArgs{c->d_tickets, c->d_partials + nb, c->d_ticket_sums}, ipc_w, 1);
       HIP_TRY(hipGetLastError());
       alpha_in_kernel = true;
+    } else if (rccl_tick && nb > 0) {
+      // ONE launch folds the per-wave partials (tickets), the all-reduce follows; alpha is formed by its consumers
+      if ((int64_t)nb + kStage2 <= c->partials_capacity) {
+        hipLaunchKernelGGL(reduce_stage1_ticket_kernel, dim3(kStage2), dim3(kBlock), 0, c->stream, c->d_partials, nb,
+                           d.slot(S_RTV), d.st, TicketArgs{c->d_tickets, c->d_partials + nb, c->d_ticket_sums}, IpcDev{}, 0);
+        HIP_TRY(hipGetLastError());
+        STORM_TRY(comm_allreduce_sum(c, d.slot(S_RTV), 1));
+      } else {
+        const int slots[1] = {S_RTV};
+        STORM_TRY(d.finish(nb, 1, slots, STEP_NONE));
+      }
+      alpha_in_kernel = true;
     } else if (nb == 0) {
       const double *bs[1] = {v};
       STORM_TRY(k_multi_dot(c, rt, bs, 1, n, d.slot(S_RTV), d.done));
@@ -1482,7 +1500,10 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
     }
     {
       // (RCCL: the halo of s leaves now, under this update and the interior rows of the apply)
-      if (early_halo && !alpha_in_kernel) STORM_TRY(comm_halo_exchange_begin_formed(op, 0, r, nullptr, v, d.slot(S_ALPHA), nullptr, r));
+      //  (alpha not formed yet: the kernel that forms the rows to send divides rho by <rt, v> itself)
+      if (early_halo)
+        STORM_TRY(comm_halo_exchange_begin_formed(op, 0, r, nullptr, v, alpha_in_kernel ? d.slot(S_RHO) : d.slot(S_ALPHA),
+                                                  alpha_in_kernel ? d.slot(S_RTV) : nullptr, r));
       // r -= alpha v   (x += alpha p is applied in the second half-step)      :140-141
       hipLaunchKernelGGL(bicg_update_kernel<false>, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, x->d, r, p, v,
                          rt, c->d_partials, stream_nt(c, n), flip(), alpha_in_kernel ? tickets : no_tickets);
@@ -1490,8 +1511,20 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
       // t = A r; omega = <t,r> / <t,t>                  :158-160
       STORM_TRY(apply_dir(r, t, r, true, (int)S_TR, (int)S_TT));
     }
-    bool omega_in_kernel = ticketed != 0;
+    bool omega_in_kernel = ticketed != 0, rccl_end = false;
     if (omega_in_kernel) {
+    } else if (rccl_tick && nb > 0) {
+      if (2 * (int64_t)nb + 2 * kStage2 <= c->partials_capacity) {
+        hipLaunchKernelGGL(reduce_stage1_ticket2_kernel, dim3(kStage2), dim3(kBlock), 0, c->stream, c->d_partials, nb,
+                           d.slot(S_TR), d.slot(S_TT), d.st, TicketArgs{c->d_tickets, c->d_partials + 2 * (size_t)nb, c->d_ticket_sums},
+                           IpcDev{}, 0);
+        HIP_TRY(hipGetLastError());
+        STORM_TRY(comm_allreduce_sum(c, d.slot(S_TR), 2));
+      } else {
+        const int slots[2] = {S_TR, S_TT};
+        STORM_TRY(d.finish(nb, 2, slots, STEP_NONE));
+      }
+      omega_in_kernel = rccl_end = true;
     } else if (ipc_tick && nb > 0 && 2 * (int64_t)nb + 2 * kStage2 <= c->partials_capacity) {
       hipLaunchKernelGGL(reduce_stage1_ticket2_kernel, dim3(kStage2), dim3(kBlock), 0, c->stream, c->d_partials, nb,
                          d.slot(S_TR), d.slot(S_TT), d.st, TicketArgs{c->d_tickets, c->d_partials + 2 * (size_t)nb, c->d_ticket_sums},
@@ -1511,11 +1544,15 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
     // x = (x + alpha p) + omega r; r -= omega t; |r|, <rt,r>    :140, :161-164 (+ :116 of the next iteration)
     hipLaunchKernelGGL(bicg_update_kernel<true>, dim3(nbv2), dim3(kBlock), 0, c->stream, n, d.st, x->d, r,
                        p, t, rt, c->d_partials, stream_nt(c, n), flip(), omega_in_kernel ? tickets : no_tickets,
-                       (const double *)nullptr, ipc_w, (int)(ipc_tick && omega_in_kernel));
+                       (const double *)nullptr, ipc_w, rccl_end ? 2 : (int)(ipc_tick && omega_in_kernel));
     HIP_TRY(hipGetLastError());
     if (!omega_in_kernel) {
       const int slots[2] = {S_RR, S_RHO_NEW};
       STORM_TRY(d.finish(nbv2, 2, slots, STEP_BICG_END));
+    } else if (rccl_end) {
+      STORM_TRY(comm_allreduce_sum(c, d.slot(S_RR), 2));
+      hipLaunchKernelGGL(step_kernel, dim3(1), dim3(1), 0, c->stream, (int)STEP_BICG_END, d.st, d.g, false);
+      HIP_TRY(hipGetLastError());
     } else if (c->opt_ticket_verify > 0 && bi_it % c->opt_ticket_verify == 0) {
       // |r|^2 and the next iteration's rho = <rt, r> as the second half-step's last block left them (it has run
       // STEP_BICG_END: rho_new sits in S_RHO, the counter is advanced)
