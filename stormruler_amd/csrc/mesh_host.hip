@@ -212,12 +212,16 @@ Simplices read_files(std::string prefix, int want_dim) {
     const std::string path = prefix + ".node";
     const auto t = parse_numbers<double>(slurp(path, "node"), "nodes", path);
     if (t.size() < 4) fail("Cannot read the node file '%s' header!", path.c_str());
+    // (header fields are counts: anything else -- a fraction, a NaN, 1e300 -- is not a header; the cast of such a double is undefined)
+    for (int k = 0; k < 3; ++k)
+      if (!(t[(size_t)k] >= 0.0 && t[(size_t)k] <= 9007199254740992.0 && std::floor(t[(size_t)k]) == t[(size_t)k]))
+        fail("Cannot read the node file '%s' header!", path.c_str());
     const int64_t n = (int64_t)t[0], dim = (int64_t)t[1], n_attr = (int64_t)t[2], marker = t[3] != 0 ? 1 : 0;
     if ((dim != 2 && dim != 3) || (want_dim != 0 && dim != want_dim))
       fail("Unexpected number of the dimensions in node file '%s' header! Expected %s, got %lld.", path.c_str(),
            want_dim == 2 ? "2" : want_dim == 3 ? "3" : "2 or 3", (long long)dim);
     const int64_t stride = 1 + dim + n_attr + marker;
-    if (n < 0 || n_attr < 0 || (int64_t)t.size() - 4 < n * stride) fail("Cannot read the nodes from file '%s'!", path.c_str());
+    if (n_attr > (int64_t)t.size() || n > ((int64_t)t.size() - 4) / stride) fail("Cannot read the nodes from file '%s'!", path.c_str());
     T.lap("read: .node parsed");
     S.dim = (int)dim, S.n_nodes = n;
     S.pos.resize((size_t)(n * dim));
@@ -233,7 +237,7 @@ Simplices read_files(std::string prefix, int want_dim) {
     const auto t = parse_numbers<int64_t>(slurp(path, what), whats, path);
     if (t.size() < 2) fail("Cannot read the %s file '%s' header!", what, path.c_str());
     const int64_t n = t[0], marker = t[1] != 0 ? 1 : 0, stride = 1 + npn + marker;
-    if (n < 0 || (int64_t)t.size() - 2 < n * stride) fail("Cannot read the %s from file '%s'!", whats, path.c_str());
+    if (n < 0 || n > ((int64_t)t.size() - 2) / stride) fail("Cannot read the %s from file '%s'!", whats, path.c_str());
     count = n;
     nodes.resize((size_t)(n * npn));
     label.clear();
@@ -263,7 +267,7 @@ Simplices read_files(std::string prefix, int want_dim) {
     if (npc != dim + 1)
       fail("Unexpected number of the nodes per cell in the cell file '%s' header! Expected %d, got %lld.", path.c_str(),
            dim + 1, (long long)npc);
-    if (n < 0 || (int64_t)t.size() - 3 < n * stride) fail("Cannot read the cells from file '%s'!", path.c_str());
+    if (n < 0 || n > ((int64_t)t.size() - 3) / stride) fail("Cannot read the cells from file '%s'!", path.c_str());
     T.lap("read: .ele parsed");
     S.n_cells = n;
     S.cells.resize((size_t)(n * npc));

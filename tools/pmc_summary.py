@@ -75,8 +75,10 @@ def main():
             if args.algorithmic_bytes:
                 out["general"]["ratio_to_algorithmic_bytes"] = traffic / args.algorithmic_bytes
         # the stand-alone applies of bench.py's `spmv` block (no fused dot)
-        is_plain_lat = lambda k: any(t in k for t in ("spmv_canon_tile_kernel<false", "spmv_canon_kernel<false",  # noqa: E731
-                                                      "spmv_pair_kernel<false", "spmv_dict_kernel<false"))
+        # (the tiled kernel where it ran: bench.py's event-pair floor launches spmv_canon_kernel<false on a tiny operator)
+        plain_names = ("spmv_canon_tile_kernel<false",) if any("spmv_canon_tile_kernel<false" in k for _, k in acc) else (
+            "spmv_canon_kernel<false", "spmv_pair_kernel<false", "spmv_dict_kernel<false")
+        is_plain_lat = lambda k: any(t in k for t in plain_names)  # noqa: E731
         is_plain_sell = lambda k: "spmv_sell_kernel<true, false" in k  # noqa: E731
         for name, pred in (("spmv_alone_lattice", is_plain_lat), ("spmv_alone_general", is_plain_sell)):
             fetch, write = avg("FETCH_SIZE", pred), avg("WRITE_SIZE", pred)
