@@ -80,6 +80,12 @@ public:
   storm_hip_ctx* handle() const noexcept { return _h; }
   void sync() const { detail::check(storm_hip_ctx_sync(_h)); }
   void set_option(const char* key, long long value) { detail::check(storm_hip_ctx_set_option(_h, key, value)); }
+  /// Which path the context's solves took, what its host loops fused ... (`storm_hip_ctx_get_counter`).
+  long long counter(const char* key) const {
+    int64_t value = 0;
+    detail::check(storm_hip_ctx_get_counter(_h, key, &value));
+    return (long long)value;
+  }
   void comm_init(const void* id128, int n_ranks, int rank) {
     detail::check(storm_hip_ctx_comm_init(_h, id128, n_ranks, rank));
   }

@@ -81,7 +81,8 @@ class SteepestDescentSolver final : public IterativeSolver<Vector> {
 
 // ... and the reference's CgSolver body typed against the interface, statement for statement (SolverCg.hpp:54-126): what a
 // maintainer's own CG looks like.  Its host loop runs with the library's lazy statements (IterativeSolver::lazy_statements):
-// `x += alpha p; r -= alpha z; dot_product(r, r)` is ONE kernel, `mul(z, p); dot_product(p, z)` the apply with its fused dot.
+// `r -= alpha z; dot_product(r, r)` is ONE kernel, `mul(z, p); dot_product(p, z)` the apply with its fused dot, and on a large
+// lattice `x += alpha p; p <<= r + beta p; mul(z, p); dot_product(p, z)` the library's own fused CG step (csrc/lazy.hip).
 template<class Vector>
 class StatementCgSolver final : public IterativeSolver<Vector> {
   real_t _gamma{0.0};
@@ -158,9 +159,11 @@ static int run(int n, const std::string& mode, size_t restart) {
   const std::vector<real_t> xh = x.to_host();
   const size_t c = ((size_t)(n / 2) * n + n / 2) * n + n / 2;
   std::printf("{\"n\": %d, \"converged\": %s, \"iterations\": %zu, \"absolute_error\": %.17g, "
-              "\"relative_error\": %.17g, \"x_centre\": %.17g, \"x_norm2\": %.17g, \"x0\": %.17g, \"solve_seconds\": %.6f}\n",
+              "\"relative_error\": %.17g, \"x_centre\": %.17g, \"x_norm2\": %.17g, \"x0\": %.17g, \"solve_seconds\": %.6f, "
+              "\"lazy_cg_steps\": %lld, \"lazy_fused_dots\": %lld, \"lazy_apply_dots\": %lld}\n",
               n, converged ? "true" : "false", solver.iteration, solver.absolute_error, solver.relative_error,
-              xh[c], norm_2(x), xh[0], seconds);
+              xh[c], norm_2(x), xh[0], seconds, ctx.counter("lazy_cg_steps"), ctx.counter("lazy_fused_dots"),
+              ctx.counter("lazy_apply_dots"));
   if (logged.rfind("n_iter:", 0) != 0) return 4;  // Solver.hpp:144-145
   // error conventions: conj_mul of a plain operator throws std::runtime_error (Operator.hpp:116-118)
   try {

@@ -117,3 +117,19 @@ def test_a_users_statement_by_statement_cg(mode):
     ref = oracle.solve("cg", oracle.StencilOperator(g, -1.0, 0.0), np.ones(g.n_cells))
     assert got["converged"] and abs(got["iterations"] - ref.iterations) <= 2
     assert abs(got["x_norm2"] - np.linalg.norm(ref.x)) <= 1e-8 * np.linalg.norm(ref.x)
+    if mode == "eager":
+        assert got["lazy_fused_dots"] == got["lazy_apply_dots"] == got["lazy_cg_steps"] == 0
+    else:  # both reductions of every iteration rode in a statement's kernel (a 24^3 box is no marching-kernel lattice)
+        assert got["lazy_fused_dots"] == got["iterations"] and got["lazy_apply_dots"] == got["iterations"]
+
+
+def test_a_users_cg_on_a_large_lattice_runs_the_fused_cg_step():
+    """104^3 (1.1 M rows: the size from which lattice operators get the tiled / marching kernels): every iteration but the
+    first of the user's `iterate()` is the library's fused CG step -- the kernels of the library's own device loop, whose
+    solve (checked against the oracle at 256^3 in test_gpu_full_size.py) it must reproduce."""
+    n = 104
+    got, dev = _run(n, "user-cg", "native"), _run(n, "cg", "native")
+    assert got["converged"] and dev["converged"] and abs(got["iterations"] - dev["iterations"]) <= 1
+    assert abs(got["x_norm2"] - dev["x_norm2"]) <= 1e-9 * dev["x_norm2"] and abs(got["x_centre"] - dev["x_centre"]) <= 1e-8 * abs(dev["x_centre"])
+    assert got["lazy_cg_steps"] == got["iterations"] - 1 and got["lazy_apply_dots"] == 1
+    assert got["lazy_fused_dots"] == got["iterations"]
