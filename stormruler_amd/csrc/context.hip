@@ -202,7 +202,11 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
     c->opt_latency_publish = !(value & 16), c->opt_coop_plain = !(value & 32), c->opt_cg_march_alternate = !(value & 64);
   }
   else if (!strcmp(key, "lazy_statements")) {
-    if (value == 0) STORM_TRY(lazy_sync(c));
+    if (value == 0) {
+      STORM_TRY(lazy_sync(c));
+      // (the spare vector of the fused CG step goes back to the pool: the next host loop finds it there)
+      if (c->lazy_spare) (void)storm_hip_vec_destroy(c->lazy_spare), c->lazy_spare = nullptr;
+    }
     c->opt_lazy = value;
   }
   else if (!strcmp(key, "profile_spmv")) c->opt_profile_spmv = value;

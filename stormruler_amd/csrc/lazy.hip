@@ -251,7 +251,7 @@ int fetch_sum(storm_hip_ctx *c, const double *d_value, double *result) {
 // marching kernel takes: the library's fused CG step.  p' goes to the spare vector, whose storage p's handle takes over.
 // false: not that shape (nothing launched, q untouched).
 bool try_cg_step(storm_hip_ctx *c, std::vector<LazyStmt> &q, const double *a, const double *b, double *result, int *status) {
-  if (q.size() < 3 || c->opt_fuse_dot == 0 || c->opt_lazy < 2) return false;  // (lazy_statements = 2)
+  if (q.size() < 3 || c->opt_fuse_dot == 0 || c->opt_cg_fuse == 0 || c->opt_lazy < 2) return false;  // (lazy_statements = 2)
   const LazyStmt &ap = q[q.size() - 1], &sp = q[q.size() - 2], &sx = q[q.size() - 3];
   if (ap.kind != 1 || sp.kind != 0 || sx.kind != 0) return false;
   const int64_t n = ap.n;
