@@ -118,6 +118,30 @@ def test_native_reader_on_the_reference_2d_mesh(golden):
     _same(g, host_mesh.HostMesh.read_tetgen(os.path.join(ROOT, u["mesh"]), 2).face_graph())
 
 
+@pytest.mark.parametrize("name,nodes,cells,edges", [("rectangle.1", 6725, 12776, 19500), ("step.1", 40303, 79672, 119974)])
+def test_native_reader_on_the_references_other_2d_meshes(name, nodes, cells, edges, tmp_path):
+    """rectangle.1.* and step.1.* (tests/_data/mesh of the reference; stored gzip-compressed here): the native reader
+    against the numpy restatement array for array, the counts of the files' headers, Euler's formula for a triangulated
+    region with holes (V - E + F = 1 - holes) and the area as the sum of the cells'."""
+    import gzip
+    import shutil
+
+    for e in ("node", "ele", "edge"):
+        with gzip.open(os.path.join(ROOT, "tests", "golden", "mesh", f"{name}.{e}.gz"), "rb") as src, open(tmp_path / f"{name}.{e}", "wb") as dst:
+            shutil.copyfileobj(src, dst)
+    g = io_tetgen.read_triangle(str(tmp_path / name) + ".")
+    m = host_mesh.HostMesh.read_tetgen(str(tmp_path / name) + ".", 2)
+    _same(g, m.face_graph())
+    assert g.n_cells == cells and g.n_faces + g.n_bfaces == edges
+    holes = 1 - (nodes - edges + cells)
+    assert holes in (0, 1, 2)  # (rectangle: a plain rectangle; step: the channel with its step is still simply connected)
+    assert np.all(g.volume > 0) and np.all(g.area > 0) and np.all(g.inner != g.outer)
+    x = np.sin(0.37 * np.arange(g.n_cells))
+    gn = mesh.FaceGraph(g.n_cells, 2, g.inner, g.outer, g.area, g.center, g.volume)
+    y = oracle.StencilOperator(gn, 1.0, 0.0).apply(x)
+    assert abs(np.dot(g.volume, y)) <= 1e-11 * np.abs(g.volume * y).sum()  # the Neumann operator conserves
+
+
 def test_reader_errors(tmp_path):
     pos, bf, lab, cells = _box(2)
     io_tetgen.write_tetgen(str(tmp_path / "b.1"), pos, bf, lab, cells)
