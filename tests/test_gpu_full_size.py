@@ -207,16 +207,19 @@ def test_library_ordering_at_256_restores_the_lattice_and_orders_a_jittered_mesh
     256^3 box gets its natural order back: the operator built from the re-ordered mesh has the natural one's records
     (format 4, tiled) and applies BITWISE like it.  (ii) The jittered geometry (all weights distinct: fp64 records) on the
     Z-order curve: P A P^T of the natural order's operator to 1e-13, and the same CG residuals."""
+    from stormruler_amd import host_mesh
+
     api, mesh, ctx = env
     g, mat = poisson256
     n = g.n_cells
     perm = mesh.random_permutation(n)
-    gs = mesh.permute_cells(g, perm)
-    order, kind = mesh.geometric_ordering(gs)
-    assert kind == "lattice" and np.array_equal(perm[order], np.arange(n))
-    gr = mesh.permute_cells(gs, order)
-    del gs
-    matr = api.StencilMatrix.from_face_graph(ctx, gr)
+    # (the library's own host mesh: scramble, order and operator build without a numpy pass over the faces)
+    hm = host_mesh.HostMesh.from_face_graph(g)
+    hm.permute_cells(perm)
+    assert hm.order_cells("auto") == "lattice"
+    assert np.array_equal(np.ctypeslib.as_array(hm.view().global_id, shape=(n,)), np.arange(n))
+    matr = hm.create_operator(ctx)
+    hm.close()
     st, st0 = matr.stats(), mat.stats()
     assert st["paired_rows"] == 2 and st["tiled_planes"] == st0["tiled_planes"] and st["record_bytes"] == st0["record_bytes"]
     x = api.DeviceVector.from_numpy(ctx, np.sin(0.37 * np.arange(n)))
@@ -224,19 +227,18 @@ def test_library_ordering_at_256_restores_the_lattice_and_orders_a_jittered_mesh
     mat.apply(-1.0, 0.0, x, y0), matr.apply(-1.0, 0.0, x, y1)
     assert np.array_equal(y0.to_numpy(), y1.to_numpy())
     matr.close()
-    del gr
     # (ii)
     gj = mesh.jitter_geometry(g, 1.0 / 256)
     matj = api.StencilMatrix.from_face_graph(ctx, gj)
     assert matj.stats()["value_dictionary_size"] == 0 and matj.stats()["paired_rows"] == 0  # fp64 weights + int32 columns
-    gjs = mesh.permute_cells(gj, perm)
-    order_m, kind_m = mesh.geometric_ordering(gjs, "morton")
-    assert kind_m == "morton"
-    gm = mesh.permute_cells(gjs, order_m)
-    del gjs, gj
-    new_to_old = perm[order_m]
-    matm = api.StencilMatrix.from_face_graph(ctx, gm)
-    del gm
+    hmj = host_mesh.HostMesh.from_face_graph(gj)
+    del gj
+    hmj.permute_cells(perm)
+    assert hmj.order_cells("morton") == "morton"
+    new_to_old = np.ctypeslib.as_array(hmj.view().global_id, shape=(n,)).copy()
+    assert np.array_equal(np.sort(new_to_old), np.arange(n))
+    matm = hmj.create_operator(ctx)
+    hmj.close()
     xh = np.sin(0.37 * np.arange(n))
     yj, ym = api.DeviceVector(ctx, n), api.DeviceVector(ctx, n)
     matj.apply(-1.0, 0.0, api.DeviceVector.from_numpy(ctx, xh), yj)
@@ -261,19 +263,25 @@ def test_permuted_rcm_256_is_the_natural_operator_conjugated(env, poisson256):
     gets: byte-indexed weights + int32 columns) against A from the natural ordering -- y' = P y to 1e-13, the operator
     symmetric to rounding, and 40 CG iterations give the same residual norms (a permutation changes no sum's terms,
     only their order)."""
+    from stormruler_amd import host_mesh
+
     api, mesh, ctx = env
     g, mat = poisson256
     n = g.n_cells
     perm = mesh.random_permutation(n)
-    gs = mesh.permute_cells(g, perm)
-    rcm = mesh.rcm_ordering(gs)
-    gr = mesh.permute_cells(gs, rcm)
-    del gs
-    new_to_old = perm[rcm]  # cell i of the renumbered mesh is cell new_to_old[i] of the natural one
-    matp = api.StencilMatrix.from_face_graph(ctx, gr)
+    hm = host_mesh.HostMesh.from_face_graph(g)
+    hm.permute_cells(perm)
+    rcm = mesh.rcm_ordering(hm.face_graph())
+    hm.permute_cells(rcm)
+    new_to_old = np.ctypeslib.as_array(hm.view().global_id, shape=(n,)).copy()  # cell i of the renumbered mesh is cell new_to_old[i] of the natural one
+    assert np.array_equal(new_to_old, perm[rcm])
+    v_ = hm.view()
+    nf = int(v_.n_faces)
+    band = int(np.abs(np.ctypeslib.as_array(v_.inner, shape=(nf,)) - np.ctypeslib.as_array(v_.outer, shape=(nf,))).max())
+    matp = hm.create_operator(ctx)
+    hm.close()
     st = matp.stats()
     assert st["n_rows"] == n and st["paired_rows"] == 0 and st["tiled_planes"] == 0 and st["tail_rows"] == 0
-    band = int(np.abs(np.asarray(gr.inner) - np.asarray(gr.outer)).max())
     assert band < 60_000  # (RCM: ~49 000; the scramble alone: ~n)
     x = np.sin(0.37 * np.arange(n))
     y = api.DeviceVector(ctx, n)
