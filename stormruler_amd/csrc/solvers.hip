@@ -1306,8 +1306,9 @@ int solve_cg_body(const FusedSolveArgs &args) {
     int st_apply;
     if (fuse_step && cur_it > 0) {
       const Driver::CgStep step{(long long)cur_it, x->d, r, p_alt};  // ends iteration cur_it - 1 (SolverCg.hpp:98, :123)
-      // (<p,z>: finished inside the marching kernel by tickets where that is on -- option cg_march_ticket --, else
-      //  per-wave partials for the final pass below)
+      // (<p,z>: per-wave partials for the final pass below -- finishing it inside the marching kernel by tickets was
+      //  measured for this loop and dropped; the host loop's fused step, lazy.hip, does finish it there: one launch less
+      //  in front of a host wait)
       st_apply = d.apply(p, z, p, false, &nb, true, -1, -1, &pz_done, &step);
       std::swap(p, p_alt);
     } else {
