@@ -320,3 +320,81 @@ def test_nothing_waits_inside_a_solver_callback(setup):
     assert calls and set(calls) == {0}
     ref = oracle.solve("cg", oracle.StencilOperator(g, -1.0, 0.05), np.ones(n))
     assert abs(s.iteration - ref.iterations) <= 2 and np.linalg.norm(x.to_numpy() - ref.x) <= 1e-8 * np.linalg.norm(ref.x)
+
+
+def test_random_programs_give_the_eager_values_at_every_level():
+    """Random straight-line programs over five vectors -- linear statements in every aliasing the ABI allows, applies,
+    reductions, downloads -- with the CG-step shape (`x += a p; ...; p <<= r + b p; z = A p; <p, z>`) planted under random
+    vector roles, ALIASED ones included (x = r, z = r ...: the fused step must decline, the statements must still come out
+    right).  Levels 1 and 2 against the eager run: every scalar and every final vector to 1e-10."""
+    from stormruler_amd import api, mesh
+
+    ctx = api.Context(0)
+    ctx.set_option("spmv_canon_tile_min_rows", 0)
+    g = mesh.structured_box(32, 24, 20)
+    mat = api.StencilMatrix.from_face_graph(ctx, g)
+    n = g.n_cells
+    rng = np.random.default_rng(2024)
+
+    def program(seed):
+        r_ = np.random.default_rng(seed)
+        ops = []
+        for _ in range(int(r_.integers(10, 40))):
+            kind = r_.choice(["axpy", "xpay", "copy", "scale", "axpbz", "apply", "dot", "norm", "cgstep", "get"], p=[.16, .14, .07, .07, .1, .12, .1, .06, .14, .04])
+            v = [int(i) for i in r_.integers(0, 5, 4)]
+            if kind == "cgstep" and r_.random() < 0.7:  # (mostly distinct roles: the fused step applies)
+                v = [int(i) for i in r_.permutation(5)[:4]]
+            c = [float(f) for f in r_.uniform(-0.9, 0.9, 2)]
+            ops.append((kind, v, c))
+        return ops
+
+    def run(ops, level, start):
+        vs = [api.DeviceVector.from_numpy(ctx, h) for h in start]
+        seen = []
+        ctx.set_option("lazy_statements", level)
+        for kind, v, c in ops:
+            a, b, d, e = (vs[i] for i in v)
+            if kind == "axpy":
+                a += c[0] * b
+            elif kind == "xpay":
+                a <<= b + c[0] * a
+            elif kind == "copy" and v[0] != v[1]:
+                a <<= b
+            elif kind == "scale":
+                a *= 1.0 + 0.1 * c[0]
+            elif kind == "axpbz":
+                a <<= c[0] * b + c[1] * d
+            elif kind == "apply" and v[0] != v[1]:
+                mat.apply(-0.05, 0.9, b, a)
+            elif kind == "dot":
+                seen.append(api.dot_product(a, b))
+            elif kind == "norm":
+                seen.append(api.norm_2(a))
+            elif kind == "get":
+                seen.append(float(a.to_numpy()[17]))
+            elif kind == "cgstep" and v[3] != v[1]:  # x = a, p = b, r = d, z = e (any of them may coincide -- except z = p: no in-place apply)
+                a += c[0] * b
+                if seen and len(seen) % 2:
+                    seen.append(api.dot_product(d, d))
+                b <<= d + c[1] * b
+                mat.apply(-0.05, 0.0, b, e)
+                seen.append(api.dot_product(b, e))
+        ctx.set_option("lazy_statements", 0)
+        return seen, [x.to_numpy() for x in vs]
+
+    steps = 0
+    for seed in range(60):
+        ops = program(seed)
+        start = [rng.standard_normal(n) for _ in range(5)]
+        want = run(ops, 0, start)
+        before = ctx.counter("lazy_cg_steps")
+        for level in (1, 2):
+            got = run(ops, level, start)
+            assert len(got[0]) == len(want[0])
+            assert np.allclose(got[0], want[0], rtol=1e-10, atol=1e-12), (seed, level)
+            for x, y in zip(got[1], want[1]):
+                assert np.linalg.norm(x - y) <= 1e-10 * max(np.linalg.norm(y), 1e-300), (seed, level)
+        steps += ctx.counter("lazy_cg_steps") - before
+    assert steps >= 40  # (the planted shape was taken where the roles allowed it)
+    mat.close()
+    ctx.close()
