@@ -41,6 +41,8 @@ Prints ONE JSON line on rank 0.
                     padding, CSR tail, CG it/s;
   config1_cg64, config3_bicgstab256, config4_gmres30_convdiff128, config5_cavity128   BASELINE configs 1, 3, 4, 5 on this GPU, bounded;
   extra_gmres30_poisson256   GMRES(30) at the headline size (kernel-per-statement path: the Gram-Schmidt passes at HBM scale);
+  host_loop_cg256   a USER's statement-by-statement CG (the reference's iterate() typed against Storm.hpp) with the library's lazy
+                    statements / with every statement a launch / the library's device loop, us per iteration;
   cpu_baseline      the CPU oracle (single thread, the reference is single-threaded) on a bounded sample.
 
 N > 1: every rank process is a SUPERVISOR that never touches the GPU; it starts the measuring rank as a child with
@@ -702,6 +704,7 @@ def main() -> int:
             "config4_gmres30_convdiff128": (configs or {}).get("config4_gmres30_convdiff128") if isinstance(configs, dict) else None,
             "config5_cavity128": (configs or {}).get("config5_cavity128") if isinstance(configs, dict) else None,
             "extra_gmres30_poisson256": (configs or {}).get("extra_gmres30_poisson256") if isinstance(configs, dict) else None,
+            "host_loop_cg256": (configs or {}).get("host_loop_cg256") if isinstance(configs, dict) else None,
             "configs_error": configs.get("error") if isinstance(configs, dict) else None,
             "value_general": general.get("cg_iter_per_s") if isinstance(general, dict) else None,
             "general_mesh_path": general,
@@ -863,7 +866,40 @@ def baseline_configs(api, mesh, ctx, op, b, N, n, st, min_seconds):
         del dev
     except Exception as e:
         out["config5_cavity128"] = {"error": repr(e)}
+    # ---- a USER's host loop: the reference's CG body typed statement by statement against Storm.hpp (the C++ driver's
+    # `user-cg`, tests/cpp/poisson_driver.cpp; SolverCg.hpp:86-126) with the library's lazy statements, with every statement a
+    # launch of its own, and the library's device loop -- child processes of this one, one after the other ----
+    try:
+        out["host_loop_cg256"] = host_loop_rates(n)
+    except Exception as e:
+        out["host_loop_cg256"] = {"error": repr(e)}
     return out
+
+
+def host_loop_rates(n, iterations=200):
+    import subprocess
+
+    driver = os.path.join(ROOT, "tests", "cpp", "poisson_driver")
+    if not os.path.exists(driver):
+        return {"error": "tests/cpp/poisson_driver is not built (__graft_entry__.build() builds it)"}
+
+    def run(kind, mode):
+        p = subprocess.run([driver, str(n), kind, mode], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, DRIVER_FIXED_ITERATIONS=str(iterations)))
+        if p.returncode != 0:
+            raise RuntimeError((p.stdout + p.stderr)[-500:])
+        for ln in p.stdout.splitlines():
+            if "timed_solve_seconds" in ln:
+                d = json.loads(ln)
+                return d["timed_solve_seconds"] / d["timed_iterations"] * 1e6
+        raise RuntimeError(p.stdout[-500:])
+
+    o = {"workload": f"CG, {n}^3 Poisson, {iterations} iterations, tolerances off; `tests/cpp/poisson_driver {n} user-cg|cg native|eager`",
+         "device_loop_us_per_iteration": run("cg", "native"),
+         "host_loop_lazy_statements_us_per_iteration": run("user-cg", "native"),
+         "host_loop_eager_statements_us_per_iteration": run("user-cg", "eager")}
+    o["host_loop_lazy_over_device_loop"] = o["host_loop_lazy_statements_us_per_iteration"] / o["device_loop_us_per_iteration"]
+    return o
 
 
 def spmv_standalone(api, ctx, matrix, stats, cell_ids, launches, traffic_bytes=None):

@@ -187,6 +187,11 @@ def test_bench_line_contract_at_one_gpu():
     assert u["rows"] == 6 * 12 ** 3 and u["max_row_len"] == 4 and u["tail_nnz"] == 0 and u["record_format"].startswith("fp64")
     assert u["nnz_offdiag"] == 2 * u["interior_faces"] and 0 <= u["ell_padding_ratio"] < 0.2
     assert 0.0 < u["frac"] <= 1.0 and u["cg_iter_per_s"] > 0 and u["spmv"]["rotating_3_pairs"]["launches"] >= 50
+    # a user's statement-by-statement CG against the library's device loop (child processes: the C++ driver)
+    h = out["host_loop_cg256"]
+    assert "error" not in h, h
+    assert 0 < h["device_loop_us_per_iteration"] <= h["host_loop_lazy_statements_us_per_iteration"] * 1.5
+    assert h["host_loop_lazy_statements_us_per_iteration"] < h["host_loop_eager_statements_us_per_iteration"]
     cpu = out["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0 and cpu["gpu_vs_cpu_residual_rel_diff"] <= 1e-9
     assert out["timing"]["repeats"] >= 1 and out["value"] > 10 * cpu["value"]
