@@ -109,6 +109,8 @@ def main() -> int:
     ap.add_argument("--skip-permuted", action="store_true", help="skip the permuted + RCM stress variant (SURVEY.md 8d)")
     ap.add_argument("--skip-unstructured", action="store_true", help="skip the jittered-geometry (fp64 records) variant")
     ap.add_argument("--skip-configs", action="store_true", help="skip BASELINE configs 3, 4, 5")
+    ap.add_argument("--self-exchange", default="cg,bicgstab",
+                    help="N = 1: solvers of the multi_rank_path_at_one_rank block (a size-1 RCCL communicator, child processes); '' = skip")
     ap.add_argument("--roofline-launches", type=int, default=200,
                     help="launches of the dominant kernel timed for `roofline` (at least this many, whatever --steps is)")
     ap.add_argument("--skip-unstructured3d", action="store_true", help="skip the tetrahedral mesh (roofline_unstructured3d)")
@@ -592,7 +594,8 @@ def main() -> int:
     configs = None
     if world == 1 and not args.skip_configs and not args.force_comm:
         try:
-            configs = baseline_configs(api, mesh, ctx, op, b, N, n, st, args.min_seconds)
+            configs = baseline_configs(api, mesh, ctx, op, b, N, n, st, args.min_seconds,
+                                       tuple(v for v in args.self_exchange.split(",") if v))
         except Exception as e:
             configs = {"error": repr(e)}
 
@@ -705,6 +708,7 @@ def main() -> int:
             "config5_cavity128": (configs or {}).get("config5_cavity128") if isinstance(configs, dict) else None,
             "extra_gmres30_poisson256": (configs or {}).get("extra_gmres30_poisson256") if isinstance(configs, dict) else None,
             "host_loop_cg256": (configs or {}).get("host_loop_cg256") if isinstance(configs, dict) else None,
+            "multi_rank_path_at_one_rank": (configs or {}).get("multi_rank_path_at_one_rank") if isinstance(configs, dict) else None,
             "configs_error": configs.get("error") if isinstance(configs, dict) else None,
             "value_general": general.get("cg_iter_per_s") if isinstance(general, dict) else None,
             "general_mesh_path": general,
@@ -730,6 +734,10 @@ def main() -> int:
             out["postflight"] = postflight
         if comm_breakdown is not None:
             out["comm_breakdown"] = comm_breakdown
+        mr = out.get("multi_rank_path_at_one_rank")
+        if isinstance(mr, dict) and isinstance(mr.get("cg"), dict):  # against this run's own one-rank step
+            mr["cg"]["us_per_iteration_plain"] = out["ms_per_step"] * 1e3
+            mr["cg"]["overhead_us_per_iteration"] = mr["cg"]["us_per_iteration_over_rccl"] - out["ms_per_step"] * 1e3
         print(json.dumps(out), flush=True)
     dist.barrier()
     try:  # leave no dangling process group / communicator behind
@@ -746,7 +754,7 @@ def main() -> int:
     return 0
 
 
-def baseline_configs(api, mesh, ctx, op, b, N, n, st, min_seconds):
+def baseline_configs(api, mesh, ctx, op, b, N, n, st, min_seconds, self_exchange=("cg", "bicgstab")):
     """BASELINE configs 3, 4 and 5 on one GPU, each bounded to a few hundred milliseconds of device time:
       3  BiCGStab on the headline 256^3 block (the per-GPU problem of the 8-GPU config; SolverBiCgStab.hpp:93-165);
       4  GMRES(30) on the 128^3 convection-diffusion operator (SolverGmres.hpp:119-249);
@@ -873,7 +881,38 @@ def baseline_configs(api, mesh, ctx, op, b, N, n, st, min_seconds):
         out["host_loop_cg256"] = host_loop_rates(n)
     except Exception as e:
         out["host_loop_cg256"] = {"error": repr(e)}
+    # ---- what the multi-rank code path costs with the network taken out: ONE rank on a size-1 RCCL communicator, a
+    # z-periodic box whose two halo planes it exchanges with itself (tools/comm_path_overhead.py, child processes) ----
+    try:
+        if self_exchange:
+            out["multi_rank_path_at_one_rank"] = self_exchange_rates(n, out, self_exchange)
+    except Exception as e:
+        out["multi_rank_path_at_one_rank"] = {"error": repr(e)}
     return out
+
+
+def self_exchange_rates(n, configs, solvers=("cg", "bicgstab")):
+    import subprocess
+
+    tool = os.path.join(ROOT, "tools", "comm_path_overhead.py")
+    o = {"workload": f"{n}^3 z-periodic box on ONE rank, communicator of size 1 (RCCL): both halo planes exchanged with the rank "
+                     "itself, every reduction through the all-reduce; 400 iterations, tolerances off; "
+                     "`COMM_SOLVER=... COMM_ITERS=400 python tools/comm_path_overhead.py <n> rccl`"}
+    for solver in solvers:
+        p = subprocess.run([sys.executable, tool, str(n), "rccl"], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                           env=dict(os.environ, COMM_SOLVER=solver, COMM_ITERS="400"))
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        if p.returncode != 0 or not lines:
+            raise RuntimeError((p.stdout + p.stderr)[-500:])
+        d = json.loads(lines[-1])
+        br = d.get("rccl_mixed_comm_breakdown") or {}
+        o[solver] = {"us_per_iteration_over_rccl": 1e6 / d["rccl_mixed_it_per_s"],
+                     "comm_breakdown": {k: v for k, v in br.items() if k != "note"}}
+    plain_bicg = (configs.get("config3_bicgstab256") or {}).get("us_per_iteration")
+    if plain_bicg and "bicgstab" in o:
+        o["bicgstab"]["us_per_iteration_plain"] = plain_bicg
+        o["bicgstab"]["overhead_us_per_iteration"] = o["bicgstab"]["us_per_iteration_over_rccl"] - plain_bicg
+    return o
 
 
 def host_loop_rates(n, iterations=200):

@@ -125,7 +125,7 @@ def test_bench_falls_back_to_the_next_transport_with_fresh_ranks(how):
     transport of the chain; the line says which transport produced the number and why the earlier one did not."""
     # (a hanging rank costs the whole budget of its attempt: a short one for that case)
     out, err = _run_bench(["--gpus", "2", "--transport", "ipc,host", "--inject-fail", f"ipc={how}",
-                           "--attempt-seconds", "12,240" if how.startswith("hang") else "45,240"])
+                           "--attempt-seconds", "7,240" if how.startswith("hang") else "45,240"])
     assert out["transport"] == "host" and out["n_gpus"] == 2 and out["value"] > 0
     fb = out["transport_fallback"]
     assert len(fb) == 1 and fb[0]["transport"] == "ipc"
@@ -152,7 +152,7 @@ def test_bench_line_contract_at_one_gpu():
     """`python bench.py` (N = 1) on a small edge: ONE JSON line carrying the contract's fields -- `roofline` with a
     physical fraction <= 1 that follows from its own bytes and time, `roofline_general`, `cpu_baseline`, `timing`."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--edge", "96", "--steps", "20", "--warmup", "3",
-           "--spinup-seconds", "0.2", "--min-seconds", "0.05", "--cpu-iters", "3", "--tet-edge", "12"]
+           "--spinup-seconds", "0.2", "--min-seconds", "0.05", "--cpu-iters", "3", "--tet-edge", "12", "--self-exchange", "cg"]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(env, OMP_NUM_THREADS="1"), cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + "\n" + p.stderr[-3000:]
@@ -192,6 +192,12 @@ def test_bench_line_contract_at_one_gpu():
     assert "error" not in h, h
     assert 0 < h["device_loop_us_per_iteration"] <= h["host_loop_lazy_statements_us_per_iteration"] * 1.5
     assert h["host_loop_lazy_statements_us_per_iteration"] < h["host_loop_eager_statements_us_per_iteration"]
+    # the multi-rank code path at one rank: a size-1 RCCL communicator, the planes exchanged with the rank itself
+    mr = out["multi_rank_path_at_one_rank"]
+    assert "error" not in mr, mr
+    assert mr["cg"]["us_per_iteration_over_rccl"] > 0 and abs(mr["cg"]["us_per_iteration_plain"] - out["ms_per_step"] * 1e3) <= 1e-9
+    br = mr["cg"]["comm_breakdown"]
+    assert br["transport"] == "rccl" and 0.9 <= br["halo_exchanges_per_iteration"] <= 1.1 and 1.9 <= br["allreduces_per_iteration"] <= 2.1
     cpu = out["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0 and cpu["gpu_vs_cpu_residual_rel_diff"] <= 1e-9
     assert out["timing"]["repeats"] >= 1 and out["value"] > 10 * cpu["value"]
