@@ -43,6 +43,9 @@ Prints ONE JSON line on rank 0.
   extra_gmres30_poisson256   GMRES(30) at the headline size (kernel-per-statement path: the Gram-Schmidt passes at HBM scale);
   host_loop_cg256   a USER's statement-by-statement CG (the reference's iterate() typed against Storm.hpp) with the library's lazy
                     statements / with every statement a launch / the library's device loop, us per iteration;
+  multi_rank_path_at_one_rank   CG and BiCGStab on ONE rank over a size-1 RCCL communicator (a z-periodic box: both halo planes
+                    exchanged with the rank itself, every reduction through the all-reduce) against the plain path, with the
+                    device-timestamp comm_breakdown: what the N > 1 code path costs before any link latency;
   cpu_baseline      the CPU oracle (single thread, the reference is single-threaded) on a bounded sample.
 
 N > 1: every rank process is a SUPERVISOR that never touches the GPU; it starts the measuring rank as a child with
