@@ -68,10 +68,14 @@ def test_peer_window_waits_are_bounded(tmp_path):
     assert 4.0 <= r0["seconds"] <= 9.0, r0
 
 
-def _run_bench(extra, timeout=420):
-    # exactly as the driver calls it at N = 1 ... and, for N > 1, without a launcher in front: bench.py starts its rank
-    # supervisors itself, each of which starts the measuring rank as a child
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--shared-device", "--edge", "48", "--steps", "20", "--warmup", "3",
+def _run_bench(extra, timeout=420, launcher_ranks=0):
+    # launcher_ranks = 0: without a launcher in front -- bench.py starts its rank supervisors itself, each of which starts
+    # the measuring rank as a child; launcher_ranks = N: exactly as the driver calls it for N > 1,
+    # `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`
+    # (every launched process is then the supervisor of its rank)
+    front = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={launcher_ranks}", "--master-addr",
+             "127.0.0.1", "--master-port", str(_free_port())] if launcher_ranks else [sys.executable]
+    cmd = [*front, os.path.join(ROOT, "bench.py"), "--shared-device", "--edge", "48", "--steps", "20", "--warmup", "3",
            "--spinup-seconds", "0.2", "--min-seconds", "0.05", *extra]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout,
@@ -87,7 +91,7 @@ def test_bench_script_multi_rank_path(world, transport):
     """bench.py's own N > 1 code path (supervisors, pre-flight, partition, connect, the rank-uniform spin-up, barriers,
     max-over-ranks timing, rank-0 JSON) with the ranks sharing device 0 (`--shared-device`): it must terminate -- a
     collective that only some ranks reach hangs the 8-GPU run -- and print one JSON line on rank 0."""
-    out, _ = _run_bench(["--gpus", str(world), "--transport", transport])
+    out, _ = _run_bench(["--gpus", str(world), "--transport", transport], launcher_ranks=world)  # (the driver's own command line)
     assert out["n_gpus"] == world and out["steps"] == 20 and out["value"] > 0 and out["scaling"] == "weak"
     assert out["transport"] == transport and out["transport_fallback"] == []
     assert out["preflight"]["ok"] and out["preflight"]["allreduce_sum"] == out["preflight"]["expected_sum"]
