@@ -220,7 +220,7 @@ int spmv_launch(const storm_hip_op *op, Scal alpha, Scal beta, const double *x, 
       // RCCL: p' = r + beta p of the rows to send is formed by a small kernel on the comm stream and travels while the march
       // below runs; the boundary launch waits for the planes (they land in p_out's halo tail)
       if (over_rccl) STORM_TRY(comm_halo_exchange_begin_direction(op, x, sd->cg.r, sd->cg.cb, sd->cg.p_out));
-      const CgFuseArgs cgf{sd->cg.iteration, sd->cg.my_iteration, sd->cg.ca, sd->cg.cb, sd->cg.x, sd->cg.r, sd->cg.p_out};
+      const CgFuseArgs cgf{sd->cg.iteration, sd->cg.my_iteration, sd->cg.ca, sd->cg.cb, sd->cg.x, sd->cg.r, sd->cg.p_out, 0.0, 0.0};
       const int nb_b = blocks_for(op, op->n_boundary, true);
       STORM_REQUIRE(8 * (int64_t)(nb_march + nb_b) <= c->partials_capacity, "spmv: %d blocks exceed the partials workspace", nb_march + nb_b);
       dot = DotArgs{sd->cg.p_out, sd->partials, sd->yy ? 1 : 0, 4 * (nb_march + nb_b), 0};
