@@ -25,7 +25,10 @@ for d in drive fuzz_reader fuzz_partition; do
   $CXX "$HERE/$d.cpp" "$WORK/stubs.o" "$WORK/mesh_host.o" "$WORK/ordering.o" -o "$WORK/$d" -lpthread
 done
 export STORM_HIP_BUILD_THREADS=${STORM_HIP_BUILD_THREADS:-4}
-"$WORK/drive" "$ROOT" "$WORK" "${BOX_EDGE:-9}"
+# (ThreadSanitizer: a box large enough for the threaded parse / sort / bisection paths -- 384 000 tetrahedra)
+EDGE=${BOX_EDGE:-9}
+[ "${TSAN:-0}" = "1" ] && EDGE=${BOX_EDGE:-40}
+"$WORK/drive" "$ROOT" "$WORK" "$EDGE"
 python3 "$HERE/make_fuzz_files.py" "$ROOT" "$WORK" "$SEED" "$CASES"
 "$WORK/fuzz_reader" "$WORK" | tail -3
 "$WORK/fuzz_partition" "$ROOT" | tail -2
