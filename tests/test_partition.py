@@ -103,3 +103,54 @@ def test_rcb_partition_on_the_unstructured_reference_mesh(n_parts):
         y[loc.global_id[: loc.n_cells]] = yl[: loc.n_cells]
     assert np.abs(y - y_glob).max() <= 1e-13 * np.abs(y_glob).max()
     assert cut < 0.25 * g.n_cells  # geometric cuts keep the halo small
+
+
+def _mesh_for(kind):
+    import os
+
+    from stormruler_amd import io_tetgen, io_triangle
+
+    if kind == "triangles":
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        return io_triangle.read_triangle(os.path.join(root, "tests", "golden", "mesh", "square_nb.1."))
+    if kind == "tetrahedra":
+        pos, bf, cells = io_tetgen.tet_box(6)
+        return io_tetgen.face_graph_from_simplices(pos, bf, np.ones(len(bf), np.int64), cells)
+    return mesh.structured_box(9, 7, 12)
+
+
+@pytest.mark.parametrize("kind", ["triangles", "tetrahedra", "box"])
+@pytest.mark.parametrize("n_parts", [2, 3, 5, 8])
+def test_native_partition_equals_the_numpy_restatement_array_for_array(kind, n_parts):
+    """csrc/mesh_host.hip against stormruler_amd/partition.py: the cell -> rank map of the recursive coordinate bisection,
+    every rank's local graph (owned cells, halo cells grouped by owner in ascending global id, faces, boundary faces,
+    geometry) and every halo plan (neighbours, send lists, receive ranges) -- identical arrays."""
+    from stormruler_amd import host_mesh
+
+    g = _mesh_for(kind)
+    part = partition.rcb_partition(g.center, n_parts)
+    assert np.array_equal(host_mesh.partition_rcb(g.center, n_parts), part)
+    hm = host_mesh.HostMesh.from_face_graph(g)
+    for r in range(n_parts):
+        want = partition.partition_graph(g, part, r)
+        plan = partition.halo_plan(want, r)
+        loc = hm.partition(part, n_parts, r)
+        got, got_plan = loc.face_graph(), loc.halo_plan()
+        assert (got.n_cells, got.n_halo, got.dim) == (want.n_cells, want.n_halo, want.dim)
+        for name in ("inner", "outer", "area", "center", "volume", "b_cell", "b_area", "b_center", "global_id", "halo_owner"):
+            a, b = np.asarray(getattr(got, name)), np.asarray(getattr(want, name))
+            assert a.shape == b.shape and np.array_equal(a, b), (name, r)
+        for name in ("nbr_rank", "send_ptr", "send_idx", "recv_ptr"):
+            assert np.array_equal(np.asarray(getattr(got_plan, name)), np.asarray(getattr(plan, name))), (name, r)
+        loc.close()
+    hm.close()
+
+
+def test_native_slabs_cut_a_box_into_its_planes():
+    from stormruler_amd import host_mesh
+
+    g = mesh.structured_box(6, 5, 12)
+    for n_parts in (2, 3, 4):
+        part = host_mesh.partition_slabs(g.center, 2, n_parts)
+        want = (np.arange(g.n_cells) // (6 * 5)) // (12 // n_parts)
+        assert np.array_equal(part, want)
