@@ -307,3 +307,39 @@ def test_permuted_rcm_256_is_the_natural_operator_conjugated(env, poisson256):
         hist[name] = np.array(s.history)
     assert np.allclose(hist["rcm"], hist["natural"], rtol=1e-9)
     matp.close()
+
+
+def test_tetrahedral_mesh_at_full_size_against_the_oracle_and_under_renumbering(env):
+    """The unstructured 3-D workload of the bench line at its full size: 12 582 912 tetrahedra (io_tetgen.tet_box(128): six
+    shapes of cells, all weights distinct, rows of 2 - 4 neighbours) built by the library's host mesh.  (i) the HIP SpMV
+    against the ORACLE's face loop over the same 25 M faces, <= 1e-13; (ii) the cells renumbered along the Z-order curve:
+    the operator is the file order's conjugated by the permutation -- y' == y[order] to the last bit (faces keep their
+    order: every row sums the same terms in the same order)."""
+    from oracle import oracle
+    from stormruler_amd import host_mesh, io_tetgen
+
+    api, mesh, ctx = env
+    pos, bf, cells = io_tetgen.tet_box(128)
+    hm = host_mesh.HostMesh.from_simplices(pos, bf, np.ones(len(bf), np.int64), cells)
+    del pos, bf, cells
+    g = hm.face_graph()
+    n = g.n_cells
+    assert n == 6 * 128 ** 3 and g.n_faces == 25_067_520
+    x = np.sin(0.37 * np.arange(n))
+    y_ref = oracle.StencilOperator(g, -1.0, 0.0).apply(x)
+    del g
+    mat = hm.create_operator(ctx)
+    st = mat.stats()
+    assert st["max_row_len"] == 4 and st["tail_nnz"] == 0 and st["value_dictionary_size"] == 0
+    y = api.DeviceVector(ctx, n)
+    mat.apply(-1.0, 0.0, api.DeviceVector.from_numpy(ctx, x), y)
+    y_file = y.to_numpy()
+    assert np.abs(y_file - y_ref).max() <= 1e-13 * np.abs(y_ref).max()
+    mat.close()
+    assert hm.order_cells("morton") == "morton"
+    order = np.ctypeslib.as_array(hm.view().global_id, shape=(n,)).copy()
+    mat = hm.create_operator(ctx)
+    hm.close()
+    mat.apply(-1.0, 0.0, api.DeviceVector.from_numpy(ctx, x[order]), y)
+    assert np.array_equal(y.to_numpy(), y_file[order])
+    mat.close()
