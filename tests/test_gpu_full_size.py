@@ -326,8 +326,10 @@ def test_tetrahedral_mesh_at_full_size_against_the_oracle_and_under_renumbering(
     n = g.n_cells
     assert n == 6 * 128 ** 3 and g.n_faces == 25_067_520
     x = np.sin(0.37 * np.arange(n))
-    y_ref = oracle.StencilOperator(g, -1.0, 0.0).apply(x)
-    del g
+    ref_op = oracle.StencilOperator(g, -1.0, 0.0)
+    y_ref = ref_op.apply(x)
+    ref = oracle.solve("cg", ref_op, np.ones(n), num_iterations=12, abs_tol=0.0, rel_tol=0.0)  # (the reference's loop, 12 iterations)
+    del g, ref_op
     mat = hm.create_operator(ctx)
     st = mat.stats()
     assert st["max_row_len"] == 4 and st["tail_nnz"] == 0 and st["value_dictionary_size"] == 0
@@ -335,6 +337,17 @@ def test_tetrahedral_mesh_at_full_size_against_the_oracle_and_under_renumbering(
     mat.apply(-1.0, 0.0, api.DeviceVector.from_numpy(ctx, x), y)
     y_file = y.to_numpy()
     assert np.abs(y_file - y_ref).max() <= 1e-13 * np.abs(y_ref).max()
+    # ... and CG's first 12 residual norms and iterate against the oracle's solve of the same 12.6 M unknowns
+    s = api.CgSolver()
+    s.record_history, s.num_iterations = True, 12
+    s.absolute_error_tolerance = s.relative_error_tolerance = 0.0
+    b, xs = api.DeviceVector(ctx, n), api.DeviceVector(ctx, n)
+    api.fill_with(b, 1.0)
+    s.solve(xs, b, api.HipStencilOperator(mat, -1.0, 0.0))
+    assert s.iteration == ref.iterations == 12
+    assert np.allclose(np.array(s.history), ref.history, rtol=1e-10, atol=0.0)
+    assert np.linalg.norm(xs.to_numpy() - ref.x) <= 1e-10 * np.linalg.norm(ref.x)
+    del b, xs
     mat.close()
     assert hm.order_cells("morton") == "morton"
     order = np.ctypeslib.as_array(hm.view().global_id, shape=(n,)).copy()
