@@ -86,7 +86,7 @@ def _run_bench(extra, timeout=420, launcher_ranks=0):
     return json.loads(lines[0]), p.stderr
 
 
-@pytest.mark.parametrize("world,transport", [(3, "ipc")])  # (2 ranks, host AND ipc: test_bench_measures_two_transports...)
+@pytest.mark.parametrize("world,transport", [(3, "ipc")])  # (2 ranks, host AND ipc: test_bench_two_ranks_on_the_production_kernels_measures_both_transports)
 def test_bench_script_multi_rank_path(world, transport):
     """bench.py's own N > 1 code path (supervisors, pre-flight, partition, connect, the rank-uniform spin-up, barriers,
     max-over-ranks timing, rank-0 JSON) with the ranks sharing device 0 (`--shared-device`): it must terminate -- a
@@ -108,19 +108,6 @@ def test_bench_script_multi_rank_path(world, transport):
         assert cb["send_ack_wait_us_per_iteration_worst_rank"] >= 0.0
 
 
-def test_bench_measures_two_transports_and_reports_the_better():
-    """N > 1: every data-path transport of the chain is measured by fresh rank processes (on N devices: RCCL and the peer
-    windows; here, ranks sharing one device: host-staged and the peer windows); `value` is the better one and
-    `transports_measured` holds both with their breakdowns."""
-    out, _ = _run_bench(["--gpus", "2", "--transport", "host,ipc"], timeout=600)
-    tm = out["transports_measured"]
-    assert set(tm) == {"host", "ipc"} and out["transport_fallback"] == []
-    best = max(tm, key=lambda t: tm[t]["value"])
-    assert out["transport"] == best and out["value"] == tm[best]["value"] and out["ms_per_step"] == tm[best]["ms_per_step"]
-    for t in tm.values():
-        assert t["value"] > 0 and t["postflight"]["ok"] and "comm_breakdown" in t
-
-
 @pytest.mark.parametrize("how", ["exit:1", "hang:0", "wrong"])  # (a rank dies / hangs / the pre-flight finds wrong values; "post:1", a
 # wrong value found by the post-flight, takes the same road after the timed region: run by hand, `--inject-fail ipc=post:1`)
 def test_bench_falls_back_to_the_next_transport_with_fresh_ranks(how):
@@ -129,7 +116,7 @@ def test_bench_falls_back_to_the_next_transport_with_fresh_ranks(how):
     transport of the chain; the line says which transport produced the number and why the earlier one did not."""
     # (a hanging rank costs the whole budget of its attempt: a short one for that case)
     out, err = _run_bench(["--gpus", "2", "--transport", "ipc,host", "--inject-fail", f"ipc={how}",
-                           "--attempt-seconds", "7,240" if how.startswith("hang") else "45,240"])
+                           "--attempt-seconds", "5,240" if how.startswith("hang") else "45,240"])
     assert out["transport"] == "host" and out["n_gpus"] == 2 and out["value"] > 0
     fb = out["transport_fallback"]
     assert len(fb) == 1 and fb[0]["transport"] == "ipc"
@@ -207,13 +194,20 @@ def test_bench_line_contract_at_one_gpu():
     assert out["timing"]["repeats"] >= 1 and out["value"] > 10 * cpu["value"]
 
 
-def test_bench_two_ranks_on_the_production_kernels():
-    """Two ranks (sharing the one GPU, peer-window transport) at 128^3 per rank: large enough for the lattice kernels --
-    tiled interior launch with the sending blocks, the marching fused CG step, the boundary launch that reads the
-    window -- so the multi-process windows carry exactly what an N-GPU run does; the post-flight check (halo test at
-    full size + fused against unfused residual) must pass and no fallback may have happened."""
-    out, _ = _run_bench(["--gpus", "2", "--transport", "ipc,host", "--edge", "128", "--steps", "30"], timeout=600)
-    assert out["transport"] == "ipc" and out["transport_fallback"] == []
+def test_bench_two_ranks_on_the_production_kernels_measures_both_transports():
+    """Two ranks (sharing the one GPU) at 128^3 per rank: large enough for the lattice kernels -- tiled interior launch with
+    the sending blocks, the marching fused CG step, the boundary launch that reads the window -- so the multi-process
+    windows carry exactly what an N-GPU run does; the post-flight check (halo test at full size + fused against unfused
+    residual) must pass and no fallback may have happened.  And N > 1 measures every data-path transport of the chain by
+    fresh rank processes (on N devices: RCCL and the peer windows; here, ranks sharing one device: host-staged and the peer
+    windows): `value` is the better one, `transports_measured` holds both with their breakdowns."""
+    out, _ = _run_bench(["--gpus", "2", "--transport", "host,ipc", "--edge", "128", "--steps", "30"], timeout=600)
+    tm = out["transports_measured"]
+    assert set(tm) == {"host", "ipc"} and out["transport_fallback"] == []
+    best = max(tm, key=lambda t: tm[t]["value"])
+    assert out["transport"] == best == "ipc" and out["value"] == tm[best]["value"] and out["ms_per_step"] == tm[best]["ms_per_step"]
+    for t in tm.values():
+        assert t["value"] > 0 and t["postflight"]["ok"] and "comm_breakdown" in t
     assert out["postflight"]["ok"] and out["postflight"]["fused_vs_unfused_residual_rel_diff"] <= 1e-9
     assert out["op_stats"]["tiled_planes"] == 2 and out["op_stats"]["paired_rows"] == 2
     assert out["roofline"]["launches_timed"] >= 2 * 31  # per apply: the interior / marching launch + the boundary launch
