@@ -331,6 +331,8 @@ def test_tetrahedral_mesh_at_full_size_against_the_oracle_and_under_renumbering(
     ref_op = oracle.StencilOperator(g, -1.0, 0.0)
     y_ref = ref_op.apply(x)
     ref = oracle.solve("cg", ref_op, np.ones(n), num_iterations=12, abs_tol=0.0, rel_tol=0.0)  # (the reference's loop, 12 iterations)
+    ref_b = oracle.solve("bicgstab", ref_op, np.ones(n), num_iterations=3, abs_tol=0.0, rel_tol=0.0)
+    ref_g = oracle.solve("gmres", ref_op, np.ones(n), num_iterations=5, abs_tol=0.0, rel_tol=0.0, num_inner_iterations=5)
     del g, ref_op
     mat = hm.create_operator(ctx)
     st = mat.stats()
@@ -349,6 +351,17 @@ def test_tetrahedral_mesh_at_full_size_against_the_oracle_and_under_renumbering(
     assert s.iteration == ref.iterations == 12
     assert np.allclose(np.array(s.history), ref.history, rtol=1e-10, atol=0.0)
     assert np.linalg.norm(xs.to_numpy() - ref.x) <= 1e-10 * np.linalg.norm(ref.x)
+    for cls, want in ((api.BiCgStabSolver, ref_b), (api.GmresSolver, ref_g)):  # ... and the other two loops of the path, briefly
+        s = cls()
+        s.record_history, s.num_iterations = True, want.iterations
+        if cls is api.GmresSolver:
+            s.num_inner_iterations = 5
+        s.absolute_error_tolerance = s.relative_error_tolerance = 0.0
+        xs = api.DeviceVector(ctx, n)
+        s.solve(xs, b, api.HipStencilOperator(mat, -1.0, 0.0))
+        assert s.iteration == want.iterations
+        assert np.allclose(np.array(s.history), want.history, rtol=1e-9, atol=0.0), cls.__name__
+        assert np.linalg.norm(xs.to_numpy() - want.x) <= 1e-9 * np.linalg.norm(want.x), cls.__name__
     del b, xs
     mat.close()
     assert hm.order_cells("morton") == "morton"
