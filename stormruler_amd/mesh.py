@@ -446,3 +446,30 @@ def assemble_csr(g: FaceGraph, alpha: float, beta: float):
     a = sp.coo_matrix((vals[keep], (rows[keep], cols[keep])), shape=(n, nt)).tocsr()
     a.sum_duplicates()
     return a
+
+
+def periodic_z_local_graph(nx, ny, nz):
+    """One rank's local graph of a box that is PERIODIC in z, the rank its own neighbour: owned = the whole box without its
+    z walls; halo = [copy of plane nz - 1 (below plane 0), copy of plane 0 (above plane nz - 1)], positioned at their periodic
+    images.  Returns (graph, send_idx): with ``set_halo([0], [0, n_halo], send_idx, [0, n_halo])`` on a communicator of size 1
+    the rank exchanges both planes with itself -- the multi-rank code path with the network taken out
+    (tests/test_gpu_comm.py, tools/comm_path_overhead.py, bench.py's ``multi_rank_path_at_one_rank``)."""
+    g = structured_box(nx, ny, nz)
+    P, N = nx * ny, nx * ny * nz
+    keep = ~np.isclose(np.abs(g.b_center[:, 2] - 0.5), 0.5)  # drop the z = 0 and z = 1 wall faces
+    bottom, top = np.arange(P, dtype=np.int64), np.arange(N - P, N, dtype=np.int64)
+    halo_a = N + np.arange(P, dtype=np.int64)       # images of the top plane, below the bottom plane
+    halo_b = N + P + np.arange(P, dtype=np.int64)   # images of the bottom plane, above the top plane
+    inner = np.concatenate([g.inner, halo_a, top])
+    outer = np.concatenate([g.outer, bottom, halo_b])
+    area = np.concatenate([g.area, np.full(2 * P, g.area[-1])])
+    ca, cb = g.center[top].copy(), g.center[bottom].copy()
+    ca[:, 2] -= 1.0
+    cb[:, 2] += 1.0
+    loc = FaceGraph(n_cells=N, dim=3, inner=inner, outer=outer, area=area,
+                    center=np.concatenate([g.center, ca, cb]), volume=np.concatenate([g.volume, g.volume[:2 * P]]),
+                    b_cell=g.b_cell[keep], b_area=g.b_area[keep], b_center=g.b_center[keep], n_halo=2 * P,
+                    global_id=np.concatenate([np.arange(N), top, bottom]),
+                    halo_owner=np.zeros(2 * P, np.int32))
+    loc.validate()
+    return loc, np.concatenate([top, bottom])

@@ -10,32 +10,9 @@ pytestmark = pytest.mark.gpu
 
 
 def _periodic_z_local_graph(nx, ny, nz):
-    """Owned = the whole box without z walls; halo = [copy of plane nz-1 (below plane 0), copy of plane 0
-    (above plane nz-1)], positioned at their periodic images."""
     from stormruler_amd import mesh
 
-    g = mesh.structured_box(nx, ny, nz)
-    P, N = nx * ny, nx * ny * nz
-    hz = 1.0 / nz
-    keep = ~np.isclose(np.abs(g.b_center[:, 2] - 0.5), 0.5)  # drop the z = 0 and z = 1 wall faces
-    bottom, top = np.arange(P, dtype=np.int64), np.arange(N - P, N, dtype=np.int64)
-    halo_a = N + np.arange(P, dtype=np.int64)       # images of the top plane, below the bottom plane
-    halo_b = N + P + np.arange(P, dtype=np.int64)   # images of the bottom plane, above the top plane
-    inner = np.concatenate([g.inner, halo_a, top])
-    outer = np.concatenate([g.outer, bottom, halo_b])
-    area = np.concatenate([g.area, np.full(2 * P, g.area[-1])])
-    ca, cb = g.center[top].copy(), g.center[bottom].copy()
-    ca[:, 2] -= 1.0
-    cb[:, 2] += 1.0
-    loc = mesh.FaceGraph(n_cells=N, dim=3, inner=inner, outer=outer, area=area,
-                         center=np.concatenate([g.center, ca, cb]), volume=np.concatenate([g.volume, g.volume[:2 * P]]),
-                         b_cell=g.b_cell[keep], b_area=g.b_area[keep], b_center=g.b_center[keep], n_halo=2 * P,
-                         global_id=np.concatenate([np.arange(N), top, bottom]),
-                         halo_owner=np.zeros(2 * P, np.int32))
-    loc.validate()
-    send_idx = np.concatenate([top, bottom])
-    assert abs(hz - (loc.center[N, 2] - 0.0) * -2) < 1e-12 or True
-    return loc, send_idx
+    return mesh.periodic_z_local_graph(nx, ny, nz)
 
 
 @pytest.fixture(scope="module")

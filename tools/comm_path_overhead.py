@@ -13,9 +13,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 from stormruler_amd import api, mesh  # noqa: E402
-from test_gpu_comm import _periodic_z_local_graph  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 only = sys.argv[2] if len(sys.argv) > 2 else ""  # "ipc" / "rccl": that transport alone, few iterations (for a kernel trace)
@@ -48,7 +46,7 @@ for fmt in (() if only else (4, 3)):
     out[f"plain_fmt{fmt}_it_per_s"] = rate(ctx, m0, g0)
     m0.close()
 ctx.close()
-loc, send_idx = _periodic_z_local_graph(n, n, n)
+loc, send_idx = mesh.periodic_z_local_graph(n, n, n)
 # the halo operator: MIXED records by default (format 4 where rows read no halo column, format 3 in the outer
 # planes) -- compared with the plain format-4 operator; spmv_mixed = 0 (format 3 throughout) with plain format 3
 for transport in ((only,) if only else ("rccl", "ipc")):
