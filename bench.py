@@ -75,10 +75,12 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--n", "--edge", dest="n", type=int, default=256,
+    ap.add_argument("--n", "--edge", dest="n", type=int, default=None,
                     help="cells per edge of the per-GPU block (use --edge under torch.distributed.run, whose own parser "
-                         "claims the abbreviation --n)")
+                         "claims the abbreviation --n); default 256 (--contact: 64)")
     ap.add_argument("--cpu-iters", type=int, default=20, help="CPU-baseline sample (CG iterations); 0 = skip")
+    ap.add_argument("--cpu-parallel", action="store_true",
+                    help="also time the OpenMP variant of the CPU baseline (3 runs; not the reference's loop order)")
     ap.add_argument("--ordering", default="natural", choices=["natural", "tile"])
     ap.add_argument("--nontemporal", type=int, default=-1)
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (repeatable)")
@@ -124,10 +126,20 @@ def main() -> int:
     ap.add_argument("--spmv-only", action="store_true", help="run only the stand-alone SpMV block (for a clean rocprofv3 --stats comparison)")
     ap.add_argument("--spmv-what", default="lattice,general", help="--spmv-only: which operators (lattice, general, tets)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--detail-path", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="where the full record goes (everything the compact stdout line leaves out); '' = nowhere")
+    ap.add_argument("--contact", action="store_true",
+                    help="first-contact mode for a short multi-GPU lease (< 20 s of GPU work per transport): edge 64 unless "
+                         "--edge is given, pre-flight, one RCCL CG and one RCCL BiCGStab with the device-timestamp breakdown, the "
+                         "compact line; no stand-alone SpMV / stress / config blocks")
     args = ap.parse_args()
-    chain = [t for t in (args.transport or ("ipc,host" if args.shared_device else "rccl,ipc,host")).split(",") if t]
+    if args.contact:
+        contact_defaults(args)
+    if args.n is None:
+        args.n = 256
+    chain = [t for t in (args.transport or default_chain(args)).split(",") if t]
     for t in chain:
-        if t not in ("rccl", "ipc", "host"):
+        if t not in ("rccl", "rccl-plain", "ipc", "host"):
             ap.error(f"unknown transport {t!r}")
 
     if args.pmc_child:
@@ -170,7 +182,7 @@ def main() -> int:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"), os.environ.setdefault("MASTER_PORT", "29533")
         # torch.distributed only bootstraps (ids, window handles, barriers, the max of timings): gloo whenever the data
         # path itself is not RCCL, so that a rank pair RCCL cannot serve still has a control plane
-        dist.init_process_group("nccl" if (transport == "rccl" and not args.shared_device) else "gloo")
+        dist.init_process_group("nccl" if (transport in ("rccl", "rccl-plain") and not args.shared_device) else "gloo")
 
     def connect(ctx_):
         if world == 1:
@@ -224,7 +236,19 @@ def main() -> int:
     for kv in args.opt:
         k_, v_ = kv.split("=")
         ctx.set_option(k_, int(v_))
+    if transport == "rccl-plain":
+        for k_ in RCCL_PLAIN_OPTIONS:
+            ctx.set_option(k_, 0)
     connect(ctx)
+    # RCCL's own account of the communicator, per rank (ncclCommCount / ncclCommUserRank / device / PCI bus id): a reader
+    # of the line can check that RCCL saw N ranks on N distinct devices -- not what this script passed in
+    rccl_view_all = None
+    if world > 1 or args.force_comm:
+        try:
+            mine_ = dict(ctx.rccl_view(), rank=rank, local_rank=local_rank, transport=transport)
+        except Exception as e:
+            mine_ = {"rank": rank, "error": repr(e)[:300]}
+        rccl_view_all = dist.all_gather_object(mine_)
     t_op = time.time()
     mat = api.StencilMatrix.from_face_graph(ctx, g)
     setup_breakdown["operator_build"] = time.time() - t_op
@@ -360,7 +384,7 @@ def main() -> int:
                         "waiting for the receivers' acknowledgement of the plane two exchanges back; late halo values = "
                         "rows of the boundary launch that had to poll (thread-time each); everything else of an iteration "
                         "is the single-GPU path's kernels (compare ms_per_step with the 1-GPU line)"}
-        elif transport == "rccl" and not args.shared_device:
+        elif transport in ("rccl", "rccl-plain") and not args.shared_device:
             # RCCL: an instrumented solve beside the timed ones (stamp kernels around every step of the exchange and the
             # all-reduces, csrc/comm.hip); the worst rank's figures
             try:
@@ -377,6 +401,36 @@ def main() -> int:
         else:
             comm_breakdown = {"transport": transport,
                               "note": "host-staged transport: synchronous, nothing to overlap; compare ms_per_step with the 1-GPU line"}
+
+    # ---- --contact: BASELINE configs[2]'s solver once over the same transport, with its breakdown ----
+    contact_bicgstab = None
+    if args.contact and (world > 1 or args.force_comm):
+        try:
+            def run_bicg(iters):
+                x_ = api.DeviceVector(ctx, N, g.n_halo)
+                s_ = api.BiCgStabSolver()
+                s_.num_iterations, s_.absolute_error_tolerance, s_.relative_error_tolerance = iters, 0.0, 0.0
+                s_.solve(x_, b, op)
+                return s_
+
+            run_bicg(max(W, 3))
+            ctx.sync()
+            dist.barrier()
+            t0 = time.perf_counter()
+            sb_ = run_bicg(K)
+            ctx.sync()
+            tb_ = dist.allreduce_max(time.perf_counter() - t0)
+            contact_bicgstab = {"iterations": sb_.iteration, "us_per_iteration": tb_ / K * 1e6, "final_residual": sb_.absolute_error}
+            if transport in ("rccl", "rccl-plain") and not args.shared_device:
+                ctx.set_option("profile_comm", 1)
+                run_bicg(K)
+                ctx.sync()
+                br_ = ctx.rccl_profile(K)
+                ctx.set_option("profile_comm", 0)
+                contact_bicgstab["comm_breakdown"] = {k_: (dist.allreduce_max(v_) if isinstance(v_, float) else v_)
+                                                      for k_, v_ in br_.items() if k_ != "note"}
+        except Exception as e:
+            contact_bicgstab = {"error": repr(e)[:300]}
 
     # ---- N > 1: post-flight.  The timed region ran the production kernels on the production transport; before its
     # number is reported, (1) the fused CG step must agree with the kernel-per-statement loop on the same transport
@@ -665,6 +719,8 @@ def main() -> int:
                              (("DEBUG, ranks share ONE device: " if args.shared_device else "") + f"z-slabs, {world} ranks, " +
                               {"ipc": "peer-window halo + all-reduce (hipIpc-mapped windows, direct stores over xGMI)",
                                "rccl": "RCCL halo send/recv + all-reduce over xGMI",
+                               "rccl-plain": "RCCL halo send/recv + all-reduce over xGMI, the plain form (cross-stream events, "
+                                             "two-launch reductions, no early halo, no fused step)",
                                "host": "halo planes and scalars staged through host memory (gloo)"}[transport]),
                 "value_definition": "n_gpus x K / max-over-ranks wall time of a K-iteration solve (init residual included; "
                                     "barrier + synchronize, clock, K steps, synchronize, clock, barrier); median over the "
@@ -741,7 +797,16 @@ def main() -> int:
         if isinstance(mr, dict) and isinstance(mr.get("cg"), dict):  # against this run's own one-rank step
             mr["cg"]["us_per_iteration_plain"] = out["ms_per_step"] * 1e3
             mr["cg"]["overhead_us_per_iteration"] = mr["cg"]["us_per_iteration_over_rccl"] - out["ms_per_step"] * 1e3
-        print(json.dumps(out), flush=True)
+        if world > 1 or args.force_comm:
+            out["rccl_view"] = rccl_view_all
+        if contact_bicgstab is not None:
+            out["contact_bicgstab"] = contact_bicgstab
+        if os.environ.get("STORM_BENCH_WORKER") == "1":
+            # one rank of an N > 1 run: the whole record goes to the supervisor (a file of its own, not the driver's
+            # stdout), which merges the transports and prints the compact line
+            print(json.dumps(out), flush=True)
+        else:
+            emit(out, args.detail_path)
     dist.barrier()
     try:  # leave no dangling process group / communicator behind
         mat.close()
@@ -755,6 +820,230 @@ def main() -> int:
     except Exception:
         pass
     return 0
+
+
+LINE_CAP = 8000  # the driver keeps ~8 KB of stdout tail: a longer line is not parsed (BENCH_r05.json: parsed = null)
+
+
+def _num(v, digits=6):
+    """Floats to `digits` significant digits (the line is a summary; bench_detail.json keeps every digit)."""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        return float(f"{v:.{digits}g}")
+    if isinstance(v, dict):
+        return {k: _num(x, digits) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_num(x, digits) for x in v]
+    return str(v)
+
+
+def _get(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def _short(text, n):
+    text = "" if text is None else str(text)
+    return text if len(text) <= n else text[: n - 3] + "..."
+
+
+def compact_record(full: dict) -> dict:
+    """The ONE line the driver parses: the contract's fields, `roofline` (dominant kernel + the SURVEY-8d-comparable
+    fp64-record SpMV figures inside it), `cpu_baseline`, `value_general`, one or two numbers per BASELINE config, and for
+    N > 1 the transports, RCCL's own view of the ranks and the breakdown's numbers.  Everything else -- every block of the
+    full record, with its notes -- is in bench_detail.json (`detail`)."""
+    r = full.get("roofline") or {}
+    sg = _get(full, "spmv", "general") or {}
+    sl = _get(full, "spmv", "lattice") or {}
+    u3 = full.get("roofline_unstructured3d") or {}
+    cfg = full.get("config") or {}
+    roof = {
+        "kernel": _short(r.get("kernel"), 60).split(" (")[0], "bound": r.get("bound"), "achieved": r.get("achieved"), "peak": r.get("peak"),
+        "unit": r.get("unit"), "frac": r.get("frac"), "traffic": r.get("traffic"),
+        "bytes_per_launch": r.get("bytes_per_launch"), "avg_launch_ms": r.get("avg_launch_ms"),
+        "launches_timed": r.get("launches_timed"), "frac_8d": r.get("frac_8d"),
+        "record_format": _short(r.get("record_format"), 80),
+        # SURVEY 8d's own figure: the SpMV alone on fp64 records (streamed bytes == 8d's algorithmic bytes)
+        "spmv_general_kernel": sg.get("kernel"),
+        "spmv_general_bytes_8d": sg.get("algorithmic_bytes_8d"),
+        "spmv_general_ms": _get(sg, "rotating_3_pairs", "median_ms"),
+        "spmv_general_frac_8d_rotating": _get(sg, "rotating_3_pairs", "frac_8d"),
+        "spmv_general_frac_8d_back_to_back": _get(sg, "back_to_back", "frac_8d"),
+        "spmv_general_traffic": sg.get("pmc_traffic_bytes"),
+        "spmv_lattice_ms": _get(sl, "rotating_3_pairs", "median_ms"),
+        "spmv_lattice_frac_streamed_rotating": _get(sl, "rotating_3_pairs", "frac_streamed"),
+        "spmv_lattice_traffic": sl.get("pmc_traffic_bytes"),
+        "cg_general_frac_8d": _get(full, "roofline_general", "frac_8d"),
+        "tets_frac_8d": u3.get("frac_8d"), "tets_spmv_frac_8d_rotating": _get(u3, "spmv", "rotating_3_pairs", "frac_8d"),
+        "tets_traffic_over_8d": u3.get("traffic_over_8d_bytes"),
+        "measured_copy_GBs": r.get("measured_copy_GBs"),
+        "note": "frac: streamed bytes of the dominant kernel / time / peak; frac_8d > 1 on the lattice records is not a "
+                "bandwidth; spmv_general_*: stand-alone fp64-record SpMV, SURVEY 8d bytes, median of >= 50",
+    }
+    cpu_full = full.get("cpu_baseline")
+    cpu = None
+    if isinstance(cpu_full, dict):
+        cpu = {k: cpu_full.get(k) for k in ("value", "unit", "cores", "kind") if k in cpu_full}
+        cpu["sample"] = _short(cpu_full.get("sample"), 200)
+        for k in ("value_fma_build", "value_native_O3", "value_native_O3_fast_math", "native_flags", "gpu_vs_cpu_residual_rel_diff", "error"):
+            if cpu_full.get(k) is not None:
+                cpu[k] = _short(cpu_full[k], 120) if isinstance(cpu_full[k], str) else cpu_full[k]
+        par = cpu_full.get("parallel")
+        if isinstance(par, dict) and "value" in par:
+            cpu["openmp_value"], cpu["openmp_cores"] = par.get("value"), par.get("cores")
+            if par.get("value_min") is not None:
+                cpu["openmp_value_min"] = par.get("value_min")
+        c1 = cpu_full.get("config1_64cubed")
+        if isinstance(c1, dict):
+            cpu["config1_64cubed"] = {k: c1.get(k) for k in ("cpu_iterations", "gpu_iterations", "cpu_seconds", "gpu_seconds", "solution_rel_diff")}
+    line = {
+        "metric": full.get("metric"), "value": full.get("value"), "unit": full.get("unit"), "n_gpus": full.get("n_gpus"),
+        "steps": full.get("steps"), "warmup": full.get("warmup"), "ms_per_step": full.get("ms_per_step"),
+        "higher_is_better": full.get("higher_is_better"), "scaling": full.get("scaling"), "vs_baseline": full.get("vs_baseline"),
+        "dtype": full.get("dtype"), "data": full.get("data"),
+        "config": {"workload": _short(cfg.get("workload"), 220), "cells_per_gpu": cfg.get("cells_per_gpu"),
+                   "partition": _short(cfg.get("partition"), 160), "ordering": cfg.get("ordering")},
+        "roofline": roof, "cpu_baseline": cpu, "value_general": full.get("value_general"),
+    }
+    configs = {}
+    for key, fields in (("config1_cg64", ("us_per_iteration",)), ("config3_bicgstab256", ("us_per_iteration", "frac")),
+                        ("config4_gmres30_convdiff128", ("us_per_inner_iteration", "frac")),
+                        ("config5_cavity128", ("s_per_step",)), ("extra_gmres30_poisson256", ("us_per_inner_iteration", "frac")),
+                        ("host_loop_cg256", ("host_loop_lazy_over_device_loop",))):
+        blk = full.get(key)
+        if isinstance(blk, dict):
+            configs[key] = {"error": _short(blk["error"], 100)} if "error" in blk else {f: blk.get(f) for f in fields}
+    mr = full.get("multi_rank_path_at_one_rank")
+    if isinstance(mr, dict):
+        configs["multi_rank_path_at_one_rank"] = ({"error": _short(mr["error"], 100)} if "error" in mr else
+                                                  {s_: _get(mr, s_, "overhead_us_per_iteration") for s_ in ("cg", "bicgstab") if s_ in mr})
+    if configs:
+        line["configs"] = configs
+    b1 = full.get("blas1")
+    if isinstance(b1, dict) and "error" not in b1:
+        line["blas1_frac"] = {k.split(" (")[0].replace(",", "").replace(" ", "_"): v.get("frac_of_peak") for k, v in b1.items() if isinstance(v, dict)}
+    if isinstance(full.get("timing"), dict):
+        line["timing"] = {k: full["timing"].get(k) for k in ("repeats", "ms_per_step_min", "ms_per_step_median", "ms_per_step_max")}
+    line["final_residual"] = _get(full, "cg", "final_residual")
+    line["device"] = full.get("device")
+    if (full.get("n_gpus") or 1) > 1 or full.get("rccl_view") is not None:
+        line["transport"] = full.get("transport")
+        rv = full.get("rccl_view")
+        if isinstance(rv, list):
+            counts = sorted({v.get("nccl_comm_count") for v in rv if isinstance(v, dict) and "nccl_comm_count" in v})
+            line["rccl"] = {"nccl_comm_count": counts[0] if len(counts) == 1 else counts,
+                            "distinct_devices": len({v.get("pci_bus_id") for v in rv if isinstance(v, dict) and v.get("pci_bus_id")}),
+                            "ranks": [[v.get("rank"), v.get("nccl_user_rank"), v.get("hip_device"), v.get("pci_bus_id")]
+                                      if isinstance(v, dict) and "error" not in v else [_get(v, "rank"), _short(_get(v, "error"), 60)]
+                                      for v in rv][:16],
+                            "ranks_columns": "rank, ncclCommUserRank, hip device, pci bus id"}
+        tm = full.get("transports_measured")
+        if isinstance(tm, dict):
+            line["transports_measured"] = {
+                t: {"value": m.get("value"), "ms_per_step": m.get("ms_per_step"), "postflight_ok": _get(m, "postflight", "ok"),
+                    "comm_breakdown": _numbers_only(m.get("comm_breakdown"))} for t, m in tm.items()}
+        elif full.get("comm_breakdown") is not None:
+            line["comm_breakdown"] = _numbers_only(full.get("comm_breakdown"))
+        fb = full.get("transport_fallback")
+        if fb:
+            line["transport_fallback"] = [{"transport": f.get("transport"), "reason": _short(f.get("reason"), 120)} for f in fb][:4]
+        for k in ("preflight", "postflight"):
+            if isinstance(full.get(k), dict):
+                line[k + "_ok"] = full[k].get("ok")
+        cb = full.get("contact_bicgstab")
+        if isinstance(cb, dict):
+            line["contact_bicgstab"] = {k: (_numbers_only(v) if k == "comm_breakdown" else _short(v, 100) if isinstance(v, str) else v)
+                                        for k, v in cb.items()}
+    line["detail"] = full.get("detail_file", "bench_detail.json")
+    return _num(line)
+
+
+def _numbers_only(d):
+    if not isinstance(d, dict):
+        return None
+    # (keys without their `_worst_rank` suffix: N > 1 breakdowns are the worst rank's figures throughout; 4 digits)
+    out = {k.replace("_worst_rank", ""): _num(v, 4) for k, v in d.items()
+           if isinstance(v, (int, float)) and not isinstance(v, bool) and k != "iterations_covered"}
+    if "error" in d:
+        out["error"] = _short(d["error"], 100)
+    if "transport" in d:
+        out["transport"] = d["transport"]
+    return out
+
+
+def compact_line(full: dict, cap: int = LINE_CAP) -> str:
+    """json.dumps(compact_record(full)) -- never longer than `cap`.  Should a record outgrow the cap all the same, optional blocks
+    are dropped in a fixed order (and named in `dropped`) until it fits: the contract's fields, `roofline` and
+    `cpu_baseline` always stay."""
+    rec = compact_record(full)
+    optional = ["blas1_frac", "contact_bicgstab", "comm_breakdown", "configs", "timing", "transport_fallback", "rccl", "transports_measured"]
+    dropped = []
+    line = json.dumps(rec, separators=(",", ":"), allow_nan=False)
+    while len(line) > cap and optional:
+        k = optional.pop(0)
+        if k in rec:
+            del rec[k]
+            dropped.append(k)
+            rec["dropped"] = dropped
+            line = json.dumps(rec, separators=(",", ":"), allow_nan=False)
+    if len(line) > cap:  # (cannot happen with the fixed-size blocks that are left; never print a line the driver cannot parse)
+        rec["roofline"].pop("note", None)
+        if isinstance(rec.get("cpu_baseline"), dict):
+            rec["cpu_baseline"].pop("sample", None)
+        line = json.dumps(rec, separators=(",", ":"), allow_nan=False)
+    assert len(line) <= cap, len(line)
+    return line
+
+
+def emit(full: dict, detail_path) -> None:
+    """The full record to `detail_path` (and, as one line, to stderr); the compact line -- the LAST line of stdout."""
+    if detail_path:
+        full["detail_file"] = os.path.relpath(detail_path, ROOT) if os.path.abspath(detail_path).startswith(ROOT) else detail_path
+        try:
+            with open(detail_path, "w") as fh:
+                json.dump(full, fh, indent=1)
+        except OSError as e:
+            full["detail_file"] = f"not written ({e.strerror}); see stderr"
+    else:
+        full["detail_file"] = "stderr only"
+    try:
+        print("bench_detail " + json.dumps(full), file=sys.stderr, flush=True)
+    except Exception:
+        pass
+    print(compact_line(full), flush=True)
+
+
+RCCL_PLAIN_OPTIONS = ("rccl_flag_wait", "rccl_ticket", "rccl_early_halo", "rccl_fused")
+
+
+def default_chain(args) -> str:
+    """rccl = the transport BASELINE.json's north_star names, with the library's defaults; rccl-plain = the same transport
+    with every refinement that has only ever run on a size-1 communicator switched off (RCCL_PLAIN_OPTIONS: cross-stream
+    events instead of flag waits, two-launch reductions, no early halo, no fused step) -- run ONLY when rccl did not
+    produce a number; ipc = the peer windows; host = staged through host memory, only if nothing else worked."""
+    if args.shared_device:
+        return "ipc,host"
+    return "rccl,rccl-plain" if args.contact else "rccl,rccl-plain,ipc,host"
+
+
+def contact_defaults(args) -> None:
+    """--contact: a short lease on N devices must still yield a parsed record.  Small blocks, no side measurements."""
+    if args.n is None:
+        args.n = 64
+    args.skip_general = args.skip_blas1 = args.skip_permuted = args.skip_unstructured = True
+    args.skip_unstructured3d = args.skip_spmv = args.skip_configs = True
+    args.traffic, args.cpu_iters = "off", 0
+    args.spinup_seconds = min(args.spinup_seconds, 0.2)
+    args.min_seconds = min(args.min_seconds, 0.05)
+    args.roofline_launches = min(args.roofline_launches, 50)
+    if args.attempt_seconds == "240,150,150":
+        args.attempt_seconds = "90,90,60"
 
 
 def baseline_configs(api, mesh, ctx, op, b, N, n, st, min_seconds, self_exchange=("cg", "bicgstab")):
@@ -1285,10 +1574,12 @@ def supervise(args, chain) -> int:
     td.init_process_group("gloo", rank=rank, world_size=world)
     budgets = [float(v) for v in args.attempt_seconds.split(",")]
     fallbacks, line = [], None
-    measured, n_measured = {}, 0  # transport -> parsed line (rank 0 holds the lines, every rank the count)
+    measured, n_measured, measured_names = {}, 0, []  # transport -> parsed record (rank 0 holds them, every rank the names)
     for attempt, transport in enumerate(chain):
         if n_measured and (transport == "host" or args.one_transport):
             break  # host-staged is a fallback only; --one-transport: the first transport that works
+        if transport == "rccl-plain" and "rccl" in measured_names:
+            continue  # the plain form of the RCCL transport: only when the default form gave no number
         budget = budgets[min(attempt, len(budgets) - 1)]
         port = torch.zeros(1, dtype=torch.int64)
         if rank == 0:
@@ -1335,6 +1626,7 @@ def supervise(args, chain) -> int:
             pass
         if reason is None:
             n_measured += 1
+            measured_names.append(transport)
             if rank == 0:
                 measured[transport] = json.loads(line)
             td.barrier()
@@ -1362,7 +1654,7 @@ def supervise(args, chain) -> int:
                                    "processes: rccl = the transport BASELINE.json's north_star names, ipc = the library's "
                                    "peer windows); `transports_measured` holds every one")
         out["transport_fallback"] = fallbacks
-        print(json.dumps(out), flush=True)
+        emit(out, args.detail_path)
     flag = torch.tensor([float(status)], dtype=torch.float64)
     td.all_reduce(flag, op=td.ReduceOp.MAX)
     td.destroy_process_group()
@@ -1386,7 +1678,7 @@ def launch_ranks(n_ranks: int, args) -> int:
     env = dict(os.environ)
     env.setdefault("OMP_NUM_THREADS", "1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    n_chain = len((args.transport or ("ipc,host" if args.shared_device else "rccl,ipc,host")).split(","))
+    n_chain = len((args.transport or default_chain(args)).split(","))
     budgets = [float(v) for v in args.attempt_seconds.split(",")]
     total = sum(budgets[min(i, len(budgets) - 1)] for i in range(n_chain)) + 120.0
     child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
@@ -1605,58 +1897,73 @@ def blas1_rates(api, ctx, N, reps=20):
 
 
 def cpu_baseline(args, n, g, perm, run, ctx):
-    """The oracle (port of the reference path) on the GPU box's host cores: 1 thread, bounded sample."""
+    """The oracle (port of the reference path) on the GPU box's host cores: 1 thread, bounded sample.  `value` is the
+    strict build (the parity checker: gcc -O2 -ffp-contract=off, built in the container); beside it, when this machine has a
+    C compiler, SURVEY 8d's flags built HERE: -O3 -march=native and the same with -ffast-math (the reference's Release is
+    -Ofast -march=native, CMakeLists.txt:194-195).  Labelled extras -- never the checker."""
     import numpy as np
 
     from oracle import oracle
     from stormruler_amd import api, mesh
 
     g_cpu = g if perm is None else mesh.structured_box(n)
-    o_op = oracle.StencilOperator(g_cpu, -1.0, 0.0)
-    tc = time.perf_counter()
-    r = oracle.solve("cg", o_op, np.ones(g_cpu.n_cells), num_iterations=args.cpu_iters, abs_tol=0.0, rel_tol=0.0)
-    tc = time.perf_counter() - tc
+    ones = np.ones(g_cpu.n_cells)
+
+    extra_iters = max(args.cpu_iters // 2, 1)  # the labelled extras: half the sample (the bench's wall time)
+
+    def sample(variant, iters=None):
+        iters = iters or extra_iters
+        o_ = oracle.StencilOperator(g_cpu, -1.0, 0.0, variant=variant)
+        t_ = time.perf_counter()
+        r_ = oracle.solve("cg", o_, ones, num_iterations=iters, abs_tol=0.0, rel_tol=0.0, variant=variant)
+        return r_, time.perf_counter() - t_
+
+    r, tc = sample("strict", args.cpu_iters)
     # the init apply counts as work: iterations + 1 applies were done
     cpu = {"value": args.cpu_iters / tc, "unit": "iter/s", "cores": 1, "kind": "port",
-           "sample": f"{args.cpu_iters} CG iterations (+ init residual) of the same {n}^3 Poisson problem, "
-                     f"oracle/liboracle.so, host has {os.cpu_count()} cpus.  Flags: gcc -O2 -ffp-contract=off -- the parity "
-                     "checker's build (the reference's statement order with strict IEEE rounding, what the GPU path is compared "
-                     "with), not SURVEY 8d's -O3 -march=native: the .so is built in a container that does not know this box's "
-                     "CPU, and fast-math reassociation would make the baseline a different algorithm; `value_fma_build` is the "
-                     "same source at -O3 -mavx2 -mfma -ffp-contract=fast (the closest portable stand-in for the reference's "
-                     "Release flags -Ofast -march=native, CMakeLists.txt:194-195)",
-           "seconds": tc}
+           "sample": f"{args.cpu_iters} CG iterations (+ init residual) of the same {n}^3 problem; oracle/liboracle.so, gcc -O2 "
+                     f"-ffp-contract=off (the parity checker's build); 1 thread of {os.cpu_count()} cpus",
+           "sample_long": "Flags of `value`: gcc -O2 -ffp-contract=off -- the reference's statement order with strict IEEE rounding, what "
+                          "the GPU path is compared with; built in a container that does not know this box's CPU.  `value_fma_build`: "
+                          "the same source at -O3 -mavx2 -mfma -ffp-contract=fast, prebuilt.  `value_native_O3` / "
+                          "`value_native_O3_fast_math`: SURVEY 8d's flags (gcc -O3 -march=native, and with -ffast-math: the reference's "
+                          "Release is -Ofast -march=native, CMakeLists.txt:194-195), compiled on THIS machine when it has a compiler; "
+                          "fast-math reassociates the sums -- a different rounding, so never the checker",
+           "seconds": tc, "extras_sample_iterations": extra_iters}
     # parity spot check at bench size: same iteration count of CG from the same start gives the
     # same residual (GPU sums in a different order: tolerance, not bits)
     sg, _ = run(args.cpu_iters)
     cpu["gpu_vs_cpu_residual_rel_diff"] = abs(sg.absolute_error - r.absolute_error) / r.absolute_error
-    # the same sample with FMA contraction allowed (the reference's Release build is -Ofast,
-    # CMakeLists.txt:194-195); reported beside the strict build, SURVEY.md 8d
     try:
-        o_fma = oracle.StencilOperator(g_cpu, -1.0, 0.0, variant="fma")
-        tf = time.perf_counter()
-        oracle.solve("cg", o_fma, np.ones(g_cpu.n_cells), num_iterations=args.cpu_iters, abs_tol=0.0,
-                     rel_tol=0.0, variant="fma")
-        cpu["value_fma_build"] = args.cpu_iters / (time.perf_counter() - tf)
+        cpu["value_fma_build"] = extra_iters / sample("fma")[1]
     except Exception:
         pass
-    # "What the host CPU could do" (SURVEY.md 8d, optional): OpenMP CG on the same box -- NOT the reference's
-    # algorithm order (gather SpMV on assembled rows, parallel reductions; oracle/storm_oracle_omp.c), reported
-    # beside the faithful single-threaded port, never instead of it.
-    try:
-        best = None
-        ncpu = os.cpu_count() or 1
-        for th in sorted({min(ncpu, 32), min(ncpu, 64), min(ncpu, 128), ncpu}):
-            res, sec, used = oracle.omp_cg_box(n, args.cpu_iters, th)
-            rate = args.cpu_iters / sec
-            if best is None or rate > best["value"]:
-                best = {"value": rate, "unit": "iter/s", "cores": used, "residual_rel_diff_vs_port":
-                        abs(res - r.absolute_error) / r.absolute_error}
-        best["kind"] = "OpenMP port, gather SpMV + parallel reductions (not the reference's single-threaded loop order)"
-        best["sample"] = f"{args.cpu_iters} CG iterations of the same {n}^3 problem, best of 32/64/128/all threads"
-        cpu["parallel"] = best
-    except Exception as e:
-        cpu["parallel"] = {"error": repr(e)}
+    for variant, key in (("native", "value_native_O3"), ("native_fast", "value_native_O3_fast_math")):
+        try:
+            rn, tn = sample(variant)
+            cpu[key] = extra_iters / tn
+            ref_half = float(r.history[extra_iters])  # (history[0] is the initial residual: entry k = after k iterations)
+            cpu[key + "_residual_rel_diff_vs_strict"] = abs(rn.absolute_error - ref_half) / ref_half
+            cpu["native_flags"] = "built on this machine: " + oracle.native_flags("native") + " [-ffast-math]"
+        except Exception as e:
+            cpu[key + "_error"] = repr(e)[:200]
+    # "What the host CPU could do" (SURVEY.md 8d, optional; --cpu-parallel): OpenMP CG on the same box -- NOT the
+    # reference's algorithm order (gather SpMV on assembled rows, parallel reductions; oracle/storm_oracle_omp.c), reported
+    # beside the faithful single-threaded port, never instead of it.  Min / median of 3 runs: one run is noise-dominated.
+    if args.cpu_parallel:
+        try:
+            ncpu = os.cpu_count() or 1
+            rates, used, res = [], None, None
+            th = min(ncpu, 64)
+            for _ in range(3):
+                res, sec, used = oracle.omp_cg_box(n, args.cpu_iters, th)
+                rates.append(args.cpu_iters / sec)
+            cpu["parallel"] = {"value": float(np.median(rates)), "value_min": min(rates), "value_max": max(rates), "unit": "iter/s",
+                               "cores": used, "residual_rel_diff_vs_port": abs(res - r.absolute_error) / r.absolute_error,
+                               "kind": "OpenMP port, gather SpMV + parallel reductions (not the reference's single-threaded loop order)",
+                               "sample": f"{args.cpu_iters} CG iterations of the same {n}^3 problem, {th} threads, median of 3 runs"}
+        except Exception as e:
+            cpu["parallel"] = {"error": repr(e)}
     # BASELINE config 1 (the reference's CPU-runnable case): 64^3, full solve to the default
     # tolerances, CPU oracle vs this library -- iteration counts and solutions must agree
     g64 = mesh.structured_box(64)

@@ -84,6 +84,14 @@ int storm_hip_ctx_get_spmv_profile_samples(storm_hip_ctx *ctx, double *ms_out, i
 int storm_hip_comm_unique_id(void *id128);
 int storm_hip_ctx_comm_init(storm_hip_ctx *ctx, const void *id128, int n_ranks, int rank);
 int storm_hip_ctx_comm_size(storm_hip_ctx *ctx, int *n_ranks, int *rank);
+/* What RCCL ITSELF says about this context's communicators (not what the host passed to comm_init): ncclCommCount /
+ * ncclCommUserRank / ncclCommCuDevice of the halo communicator, ncclCommCount of the reduction communicator, the HIP
+ * device of the context and its PCI bus id (>= 16 bytes).  All counts are 0 on a context without an RCCL communicator
+ * (one rank, or the host-staged / peer-window transports).  Fails with STORM_HIP_E_COMM when RCCL reports an asynchronous
+ * error.  For a run's record: a reader can check that RCCL saw N ranks on N distinct devices.  Nothing in the reference
+ * corresponds to it (single process). */
+int storm_hip_ctx_comm_rccl_view(storm_hip_ctx *ctx, int *halo_count, int *halo_user_rank, int *halo_device, int *red_count,
+                                 int *hip_device, char *pci_bus_id, int pci_bus_id_len);
 /* Host-staged transport: the same multi-rank protocol (halo planes before the boundary rows of an SpMV,
  * global sums behind every reduction) with the bytes moved by the host program's own messaging layer
  * instead of RCCL -- for hosts that already run MPI / gloo, and for putting several ranks on ONE device.

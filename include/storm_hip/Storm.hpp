@@ -638,8 +638,15 @@ public:
   /// The HOST loop (a user-defined solver, or `device_loop = false`) runs with the library's option `lazy_statements`:
   /// the linear vector statements and operator applies of an `iterate()` body wait for the call that needs their result,
   /// consecutive statements leave as one pass and a `dot_product` / `norm_2` over a vector the last waiting statement
-  /// writes rides in that statement's kernel (`x += alpha * p; r -= alpha * z; dot_product(r, r)`: ONE kernel).  Same
-  /// values, bit for bit; `false`: every statement is a launch of its own when it is called.
+  /// writes rides in that statement's kernel (`x += alpha * p; r -= alpha * z; dot_product(r, r)`: ONE kernel).  The
+  /// linear statements and their reductions give the eager kernels' bits; two things do not: a dot product riding in an
+  /// operator apply sums in the SpMV kernel's order, and (level 2, what this switch selects) `x += alpha p; p <<= r +
+  /// beta p; z = A p; <p, z>` on a lattice operator is ONE launch of the device loop's fused step, whose updates round
+  /// as fused multiply-adds -- equal to the eager statements to rounding, not to the bit (tests/test_gpu_lazy.py).
+  /// Caveat: statements wait until a library call needs their result.  A kernel of YOUR OWN that reads a vector through a
+  /// pointer from `storm_hip_vec_device_ptr` must be preceded by `storm_hip_ctx_sync` (or any reduction), which flushes
+  /// what waits; level 2 never exchanges the storage of a vector whose address has been handed out.
+  /// `false`: every statement is a launch of its own when it is called.
   bool lazy_statements{true};
   std::size_t num_applies{0}, num_pre_applies{0};  ///< of the last device-loop solve
   int path_fallback{0};  ///< storm_hip_solver_result::path_fallback of the last device-loop solve (0: the chosen path ran)

@@ -21,6 +21,10 @@ _LIB_PATHS = {"strict": os.path.join(_HERE, "liboracle.so"),
               "longdouble": os.path.join(_HERE, "liboracle_longdouble.so"),
               "devlike": os.path.join(_HERE, "liboracle_devlike.so")}
 _INVESTIGATION = ("pairwise", "longdouble", "devlike")
+# SURVEY.md 8d's CPU-baseline flags, built ON THE MACHINE THAT RUNS THEM (never in-tree: -march=native code does not
+# travel): bench.py's cpu_baseline reports these beside the strict build, which stays the parity checker.
+_NATIVE_FLAGS = {"native": ["-O3", "-march=native"],
+                 "native_fast": ["-O3", "-march=native", "-ffast-math"]}  # (the reference's Release: -Ofast -march=native, CMakeLists.txt:194-195)
 
 f64p = C.POINTER(C.c_double)
 i64p = C.POINTER(C.c_int64)
@@ -72,9 +76,31 @@ APPLY_FN = C.CFUNCTYPE(None, C.c_void_p, f64p, f64p)
 _libs = {}
 
 
+def build_native(variant: str) -> str:
+    """`gcc -O3 -march=native [-ffast-math]` of storm_oracle.c into a scratch directory of THIS machine; returns the path.
+    Raises when there is no compiler."""
+    import shutil
+    import tempfile
+
+    cc = shutil.which(os.environ.get("CC", "gcc")) or shutil.which("cc")
+    if cc is None:
+        raise RuntimeError("no C compiler on this machine")
+    out = os.path.join(tempfile.gettempdir(), f"liboracle_{variant}_{os.getuid()}_{os.getpid()}.so")
+    subprocess.check_call([cc, *_NATIVE_FLAGS[variant], "-fPIC", "-fvisibility=hidden", "-std=c11", "-shared", "-o", out,
+                           os.path.join(_HERE, "storm_oracle.c"), "-lm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    _LIB_PATHS[variant] = out
+    return out
+
+
+def native_flags(variant: str) -> str:
+    return "gcc " + " ".join(_NATIVE_FLAGS[variant])
+
+
 def lib(variant: str = "strict"):
     if variant not in _libs:
         build()
+        if variant in _NATIVE_FLAGS and variant not in _LIB_PATHS:
+            build_native(variant)
         if variant in _INVESTIGATION and not os.path.exists(_LIB_PATHS[variant]):
             subprocess.check_call(["make", "-C", _HERE, "variants"], stdout=subprocess.DEVNULL)
         L = _libs[variant] = C.CDLL(_LIB_PATHS[variant])

@@ -84,6 +84,8 @@ SIGNATURES = {
     "storm_hip_ctx_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int]),
     "storm_hip_ctx_comm_init_host": (C.c_int, [vp, C.c_int, C.c_int, ALLREDUCE_FN, EXCHANGE_FN, vp]),
     "storm_hip_ctx_comm_size": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "storm_hip_ctx_comm_rccl_view": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                               C.POINTER(C.c_int), C.c_char_p, C.c_int]),
     "storm_hip_ctx_comm_ipc_export": (C.c_int, [vp, C.c_int, C.c_int, C.c_int64, vp]),
     "storm_hip_ctx_comm_init_ipc": (C.c_int, [vp, vp]),
     "storm_hip_vec_create": (C.c_int, [vp, C.c_int64, C.c_int64, C.POINTER(vp)]),

@@ -146,6 +146,16 @@ class Context:
         check(lib.storm_hip_ctx_comm_init(self._h, buf, n_ranks, rank))
         self.n_ranks, self.rank = n_ranks, rank
 
+    def rccl_view(self) -> dict:
+        """What RCCL itself reports for this context's communicators (``storm_hip_ctx_comm_rccl_view``): rank count, this
+        rank's number and device as the halo communicator sees them, the reduction communicator's rank count, the HIP
+        device and its PCI bus id.  Counts of 0: no RCCL communicator on this context."""
+        v = [C.c_int() for _ in range(5)]
+        bus = C.create_string_buffer(32)
+        check(lib.storm_hip_ctx_comm_rccl_view(self._h, *[C.byref(x) for x in v], bus, 32))
+        return {"nccl_comm_count": v[0].value, "nccl_user_rank": v[1].value, "nccl_device": v[2].value,
+                "reduction_comm_count": v[3].value, "hip_device": v[4].value, "pci_bus_id": bus.value.decode()}
+
     def comm_ipc_export(self, n_ranks: int, rank: int, window_bytes: int = 0) -> bytes:
         """Allocate this rank's peer window (``storm_hip_ctx_comm_ipc_export``); returns its 64-byte IPC handle."""
         buf = C.create_string_buffer(64)

@@ -63,18 +63,26 @@ __global__ void comm_flag_set_kernel(unsigned long long *flag, unsigned long lon
 }
 // (the receive kernel of the exchange ended before the setter started, on the comm stream: what it wrote is visible to
 //  the kernel launched behind this one on the compute stream)
-__global__ void comm_flag_wait_kernel(const unsigned long long *flag, unsigned long long seq, int *error) {
+__global__ void comm_flag_wait_kernel(const unsigned long long *flag, unsigned long long seq, int *error, long long limit) {
   const long long t0 = wall_clock64();
-  // 10 s (ticks of 10 ns): the exchange never completed.  The first exchanges of a communicator get 60 s: RCCL sets its
-  // point-to-point connections up inside the first send / recv of every pair.
-  const long long limit = seq <= 4 ? 6000000000ll : 1000000000ll;
+  // `limit` ticks of 10 ns (option comm_wait_seconds: 120 s; the first exchanges of a communicator at least 180 s -- RCCL
+  // sets its point-to-point connections up inside the first send / recv of every pair): the peer never came.  What runs
+  // behind this kernel then reads a stale halo -- the error word makes the solve's next checked call, at the latest its
+  // end, return STORM_HIP_E_COMM instead of that result.
+  int spins = 0;
   while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
     if (wall_clock64() - t0 > limit) {
       if (error) __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       return;
     }
-    __builtin_amdgcn_s_sleep(2);
+    // (short naps while the hand-off is a matter of microseconds; long ones once it clearly is not)
+    if (++spins < 4096) __builtin_amdgcn_s_sleep(2);
+    else __builtin_amdgcn_s_sleep(127);
   }
+}
+static inline long long flag_wait_limit(const storm_hip_ctx *c, unsigned long long seq) {
+  const long long s = seq <= 4 ? std::max<long long>(c->opt_comm_wait_seconds, 180) : c->opt_comm_wait_seconds;
+  return s * 100000000ll;
 }
 static inline bool flag_on(const storm_hip_ctx *c) { return c->opt_rccl_flag_wait != 0 && c->comm->d_flag != nullptr; }
 // "the vector is ready" from the compute stream to the comm stream: a flag too (a recorded event is a barrier with a
@@ -84,7 +92,8 @@ static inline int ready_handoff(storm_hip_ctx *c) {
   if (flag_on(c)) {
     const unsigned long long seq = ++c->comm->ready_seq;
     hipLaunchKernelGGL(comm_flag_set_kernel, dim3(1), dim3(1), 0, c->stream, c->comm->d_flag + 8, seq);
-    hipLaunchKernelGGL(comm_flag_wait_kernel, dim3(1), dim3(1), 0, c->comm_stream, c->comm->d_flag + 8, seq, c->comm->d_error);
+    hipLaunchKernelGGL(comm_flag_wait_kernel, dim3(1), dim3(1), 0, c->comm_stream, c->comm->d_flag + 8, seq, c->comm->d_error,
+                       flag_wait_limit(c, seq));
     HIP_TRY(hipGetLastError());
     return STORM_HIP_OK;
   }
@@ -155,8 +164,15 @@ static IpcDev ipc_dev(const storm_hip_ctx *c) {
 }
 static int64_t ipc_header_bytes(int64_t P) { return (2 * P * kIpcArSlot + P * 64 + 255) / 256 * 256 + 256; }
 static int ipc_check_error(storm_hip_ctx *c) {
-  if (c->comm && !c->comm->ipc && c->comm->h_error != nullptr && *(volatile int *)c->comm->h_error != 0)
-    STORM_FAIL(STORM_HIP_E_COMM, "RCCL transport: a halo exchange did not complete within 10 s (rank %d of %d)", c->rank, c->n_ranks);
+  if (c->comm && !c->comm->ipc && c->comm->h_error != nullptr && *(volatile int *)c->comm->h_error != 0) {
+    // Reported ONCE, to the call that suffered it: the sequence numbers of the flags only grow, so the late exchange still
+    // completes its own number and the next solve starts clean -- one skewed rank does not poison the context.
+    *(volatile int *)c->comm->h_error = 0;
+    STORM_FAIL(STORM_HIP_E_COMM,
+               "RCCL transport: a stream hand-off (halo exchange done / vector ready) was not seen within %lld s (option "
+               "comm_wait_seconds; rank %d of %d): the result of the call in flight is not valid",
+               (long long)c->opt_comm_wait_seconds, c->rank, c->n_ranks);
+  }
   if (c->comm && c->comm->ipc && *(volatile int *)c->comm->h_error != 0)
     STORM_FAIL(STORM_HIP_E_COMM, "peer-window transport: a wait for another rank timed out (rank %d of %d)", c->rank,
                c->n_ranks);
@@ -468,7 +484,8 @@ int comm_halo_exchange_end(const storm_hip_op *op) {
   const long long pe = prof_on(c) ? c->comm->prof_ex - 1 : -1;  // (the exchange begun last is the one this launch waits for)
   if (pe >= 0) prof_stamp(c, c->stream, pe, 4);
   if (flag_on(c)) {
-    hipLaunchKernelGGL(comm_flag_wait_kernel, dim3(1), dim3(1), 0, c->stream, c->comm->d_flag, c->comm->flag_seq, c->comm->d_error);
+    hipLaunchKernelGGL(comm_flag_wait_kernel, dim3(1), dim3(1), 0, c->stream, c->comm->d_flag, c->comm->flag_seq, c->comm->d_error,
+                       flag_wait_limit(c, c->comm->flag_seq));
     HIP_TRY(hipGetLastError());
   } else {
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_halo_done, 0));
@@ -775,6 +792,42 @@ int storm_hip_ctx_comm_size(storm_hip_ctx *c, int *n_ranks, int *rank) {
   STORM_REQUIRE(c, "comm_size: null context");
   if (n_ranks) *n_ranks = c->n_ranks;
   if (rank) *rank = c->rank;
+  return STORM_HIP_OK;
+}
+
+int storm_hip_ctx_comm_rccl_view(storm_hip_ctx *c, int *halo_count, int *halo_user_rank, int *halo_device, int *red_count,
+                                 int *hip_device, char *pci_bus_id, int pci_bus_id_len) {
+  STORM_REQUIRE(c, "comm_rccl_view: null context");
+  if (halo_count) *halo_count = 0;
+  if (halo_user_rank) *halo_user_rank = -1;
+  if (halo_device) *halo_device = -1;
+  if (red_count) *red_count = 0;
+  if (hip_device) *hip_device = c->device;
+  if (pci_bus_id && pci_bus_id_len > 0) {
+    pci_bus_id[0] = 0;
+    if (hipDeviceGetPCIBusId(pci_bus_id, pci_bus_id_len, c->device) != hipSuccess) (void)hipGetLastError(), pci_bus_id[0] = 0;
+  }
+  if (!comm_is_rccl(c)) return STORM_HIP_OK;  // no RCCL communicator on this context: the counts stay 0
+  int v = 0;
+  if (halo_count) {
+    NCCL_TRY(ncclCommCount(c->comm->halo, &v));
+    *halo_count = v;
+  }
+  if (halo_user_rank) {
+    NCCL_TRY(ncclCommUserRank(c->comm->halo, &v));
+    *halo_user_rank = v;
+  }
+  if (halo_device) {
+    NCCL_TRY(ncclCommCuDevice(c->comm->halo, &v));
+    *halo_device = v;
+  }
+  if (red_count && c->comm->red) {
+    NCCL_TRY(ncclCommCount(c->comm->red, &v));
+    *red_count = v;
+  }
+  ncclResult_t async = ncclSuccess;
+  NCCL_TRY(ncclCommGetAsyncError(c->comm->halo, &async));
+  if (async != ncclSuccess) STORM_FAIL(STORM_HIP_E_COMM, "RCCL reports an asynchronous error on the halo communicator: %s", ncclGetErrorString(async));
   return STORM_HIP_OK;
 }
 

@@ -222,6 +222,7 @@ struct storm_hip_ctx {
   int64_t opt_latency_rows = 1 << 19;   // ... up to this many rows (a compact copy of the operator is kept for it)
   int64_t opt_rccl_fused = 1;           // RCCL transport: the fused CG step on a partitioned lattice operator (boundary planes of the new direction packed by a small kernel, sent under the marching launch)
   int64_t opt_rccl_ticket = 1;          // ... with the LOCAL sums of <p,z> and <r,r> finished inside the kernels that produce them (tickets); the all-reduce and the scalar step stay launches
+  int64_t opt_comm_wait_seconds = 120;  // RCCL transport, flag hand-offs: how long a one-thread waiter polls before it gives up (STORM_HIP_E_COMM from the next checked call; the first 4 exchanges of a communicator, inside which RCCL connects its peers: at least 180 s).  A cross-stream event waits for ever; a kernel must not, but a rank that builds an operator or reads a mesh between two solves may well be tens of seconds late
   int64_t opt_rccl_flag_wait = 1;       // RCCL: the boundary rows wait for a flag in device memory set behind the exchange, not for a cross-stream event (comm.hip)
   int64_t opt_rccl_early_halo = 1;      // RCCL, BiCGStab: the halo of s / p' leaves before the kernel that forms the vector runs (rows to send formed by a small kernel)
   static constexpr int64_t opt_ipc_bicg_ticket = 1;      // peer windows, BiCGStab: sums finished by tickets and exchanged by the finishing block (as CG does)

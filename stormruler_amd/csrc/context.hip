@@ -153,6 +153,10 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "rccl_ticket")) c->opt_rccl_ticket = value;
   else if (!strcmp(key, "rccl_early_halo")) c->opt_rccl_early_halo = value;
   else if (!strcmp(key, "rccl_flag_wait")) c->opt_rccl_flag_wait = value;
+  else if (!strcmp(key, "comm_wait_seconds")) {
+    STORM_REQUIRE(value >= 1 && value <= 3600, "ctx_set_option: comm_wait_seconds %lld (1 .. 3600)", (long long)value);
+    c->opt_comm_wait_seconds = value;
+  }
   else if (!strcmp(key, "latency_path")) c->opt_latency_path = value;
   else if (!strcmp(key, "resident_path")) c->opt_resident_path = value;
   else if (!strcmp(key, "resident_max_rows")) c->opt_resident_max_rows = value;
@@ -180,7 +184,9 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
   else if (!strcmp(key, "spmv_dict")) c->opt_spmv_dict = value;
   else if (!strcmp(key, "pool_bytes")) {
     c->opt_pool_bytes = value;
-    if ((int64_t)c->pool_bytes > value) {  // trim now
+    // trim now; 0 = give everything back at once -- idle arenas too, which pool_bytes does not count (a context
+    // whose pool holds only arena slots has pool_bytes == 0)
+    if ((int64_t)c->pool_bytes > value || (value == 0 && !c->pool.empty())) {
       (void)hipStreamSynchronize(c->stream);
       pool_release(c);
     }

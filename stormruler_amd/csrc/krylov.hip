@@ -1962,6 +1962,7 @@ static int krylov_solve_engine(storm_hip_krylov *k, const storm_hip_vec *b, stor
   }
   (void)hipStreamSynchronize(c->stream);
   release_work(k);
+  if (st == STORM_HIP_OK) st = comm_check_error(c);  // (a transport's bounded wait gave up during this solve)
   return st;
 }
 

@@ -1210,8 +1210,10 @@ int fused_solve(FusedSolveArgs a) {
   storm_hip_ctx *c = a.op->ctx;
   HIP_TRY(hipSetDevice(c->device));
   int fb = 0;
-  const int st = coop_solve_with_fallback(c, a.x, run_fused_body, &a, &fb);
+  int st = coop_solve_with_fallback(c, a.x, run_fused_body, &a, &fb);
   if (st == STORM_HIP_OK) a.result->path_fallback = fb;
+  // a bounded wait of a transport gave up during this solve (a hand-off flag, a peer window): its result is not one
+  if (st == STORM_HIP_OK) st = comm_check_error(c);
   return st;
 }
 

@@ -127,3 +127,14 @@ def barrier() -> None:
 
     if td.is_available() and td.is_initialized() and td.get_world_size() > 1:
         td.barrier()
+
+
+def all_gather_object(obj) -> list:
+    """Every rank's ``obj`` (anything picklable), in rank order, on every rank."""
+    import torch.distributed as td
+
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+        return [obj]
+    out = [None] * td.get_world_size()
+    td.all_gather_object(out, obj)
+    return out

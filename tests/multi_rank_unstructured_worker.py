@@ -14,14 +14,14 @@ sys.path.insert(0, ROOT)
 
 import torch.distributed as td  # noqa: E402
 
-from stormruler_amd import api, dist, io_triangle, mesh, partition  # noqa: E402
+from stormruler_amd import api, dist, io_tetgen, mesh, partition  # noqa: E402
 
 
 def main():
     dist.init_process_group("gloo")
     rank, world = td.get_rank(), td.get_world_size()
     golden = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_kats.json")))["baseline_md_probe"]["unstructured"]
-    g = io_triangle.read_triangle(os.path.join(ROOT, golden["mesh"]))
+    g = io_tetgen.read_triangle(os.path.join(ROOT, golden["mesh"]))
     g = mesh.FaceGraph(g.n_cells, 2, g.inner, g.outer, g.area, g.center, g.volume, b_center=np.zeros((0, 2)))  # Neumann
     part = partition.rcb_partition(g.center, world)
     loc = partition.partition_graph(g, part, rank)

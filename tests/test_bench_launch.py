@@ -21,8 +21,10 @@ def test_bench_starts_its_own_ranks():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode not in (0, 2), (p.returncode, p.stderr[-2000:])
-    # both ranks ran main() -- once per transport of the default chain (rccl, ipc, host): the rank supervisors start a
-    # fresh pair of children for every attempt (round 3)
+    # both ranks ran main() -- once per transport of the default chain (rccl, rccl-plain -- the RCCL transport's plain form,
+    # tried because rccl gave no number --, ipc, host): the rank supervisors start a fresh pair of children for every attempt
     # (a supervisor ends its child as soon as ANY rank's child has failed: between one and two messages per attempt)
-    assert 3 <= p.stderr.count("bench.py needs an MI355X") <= 2 * 3, p.stderr[-3000:]
-    assert "starting fresh ranks on ipc" in p.stderr and "starting fresh ranks on host" in p.stderr and "no transport left" in p.stderr
+    assert 4 <= p.stderr.count("bench.py needs an MI355X") <= 2 * 4, p.stderr[-3000:]
+    assert "starting fresh ranks on rccl-plain" in p.stderr and "starting fresh ranks on ipc" in p.stderr
+    assert "starting fresh ranks on host" in p.stderr and "no transport left" in p.stderr
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]  # no number, no line

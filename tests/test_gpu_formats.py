@@ -84,10 +84,10 @@ def test_operators_that_do_not_qualify_keep_fp64_records(env):
     import os
 
     api, mesh, oracle, ctx = env
-    from stormruler_amd import io_triangle
+    from stormruler_amd import io_tetgen
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    tri = io_triangle.read_triangle(os.path.join(root, "tests", "golden", "mesh", "square_nb.1."))
+    tri = io_tetgen.read_triangle(os.path.join(root, "tests", "golden", "mesh", "square_nb.1."))
     box = mesh.structured_box(12)
     rng = np.random.default_rng(3)
     graded = mesh.structured_box(12)
@@ -299,10 +299,10 @@ def test_stormDivGrad_accumulate_form(env, fmt, mesh_kind):
     if mesh_kind == "box":
         g = mesh.structured_box(22, 13, 10)
     elif mesh_kind == "triangle":
-        from stormruler_amd import io_triangle
+        from stormruler_amd import io_tetgen
 
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        g = io_triangle.read_triangle(os.path.join(root, "tests", "golden", "mesh", "square_nb.1."))
+        g = io_tetgen.read_triangle(os.path.join(root, "tests", "golden", "mesh", "square_nb.1."))
     else:
         from test_gpu_comm import _periodic_z_local_graph
 
@@ -330,11 +330,11 @@ def test_playground_operator_lambda(env):
     `f <<= map(dF_dc, c)` (:142-148) from elementwise kernels, bit for bit."""
     import os
 
-    from stormruler_amd import io_triangle
+    from stormruler_amd import io_tetgen
 
     api, mesh, oracle, ctx = env
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    g = io_triangle.read_triangle(os.path.join(root, "tests", "golden", "mesh", "square_nb.1."))
+    g = io_tetgen.read_triangle(os.path.join(root, "tests", "golden", "mesh", "square_nb.1."))
     tau, Gamma, sigma = 1.0e-3, 1.0e-4, 2.0  # Playground.cpp:113
     n = g.n_cells
     rng = np.random.default_rng(1)
@@ -415,10 +415,10 @@ def test_from_mesh_gives_the_bits_of_host_side_coefficients(env):
     import os
 
     api, mesh, oracle, ctx = env
-    from stormruler_amd import io_triangle
+    from stormruler_amd import io_tetgen
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    tri = io_triangle.read_triangle(os.path.join(root, "tests", "golden", "mesh", "square_nb.1."))
+    tri = io_tetgen.read_triangle(os.path.join(root, "tests", "golden", "mesh", "square_nb.1."))
     rng = np.random.default_rng(5)
     graded = mesh.structured_box(14, 9, 11)
     graded.volume = graded.volume * (0.5 + rng.random(graded.n_total))
@@ -446,10 +446,10 @@ def test_the_threaded_operator_build_does_not_depend_on_the_thread_count(tmp_pat
         "import sys, json, hashlib, os\n"
         f"sys.path.insert(0, {root!r})\n"
         "import numpy as np\n"
-        "from stormruler_amd import api, mesh, io_triangle\n"
+        "from stormruler_amd import api, mesh, io_tetgen\n"
         "ctx = api.Context(0)\n"
         "out = []\n"
-        f"tri = io_triangle.read_triangle(os.path.join({root!r}, 'tests', 'golden', 'mesh', 'square_nb.1.'))\n"
+        f"tri = io_tetgen.read_triangle(os.path.join({root!r}, 'tests', 'golden', 'mesh', 'square_nb.1.'))\n"
         "box = mesh.structured_box(33, 20, 17)\n"
         "scr = mesh.permute_cells(box, mesh.random_permutation(box.n_cells))\n"
         "lat = mesh.structured_box(64, 16, 12)\n"

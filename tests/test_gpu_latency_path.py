@@ -143,10 +143,10 @@ def test_the_reference_mesh_runs_on_the_latency_path(env):
     import os
 
     api, mesh, oracle, ctx = env
-    from stormruler_amd import io_triangle
+    from stormruler_amd import io_tetgen
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    g = io_triangle.read_triangle(os.path.join(root, "tests", "golden", "mesh", "step.1."))
+    g = io_tetgen.read_triangle(os.path.join(root, "tests", "golden", "mesh", "step.1."))
     g = mesh.FaceGraph(g.n_cells, 2, g.inner, g.outer, g.area, g.center, g.volume, b_center=np.zeros((0, 2)))
     mat = api.StencilMatrix.from_face_graph(ctx, g)
     b_host = np.sin(3 * g.center[:, 0]) * np.cos(7 * g.center[:, 1])

@@ -74,15 +74,39 @@ def _run_bench(extra, timeout=420, launcher_ranks=0):
     # (every launched process is then the supervisor of its rank)
     front = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={launcher_ranks}", "--master-addr",
              "127.0.0.1", "--master-port", str(_free_port())] if launcher_ranks else [sys.executable]
-    cmd = [*front, os.path.join(ROOT, "bench.py"), "--shared-device", "--edge", "48", "--steps", "20", "--warmup", "3",
-           "--spinup-seconds", "0.2", "--min-seconds", "0.05", *extra]
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout,
-                       env=dict(env, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=ROOT)
-    assert p.returncode == 0, p.stdout[-2000:] + "\n" + p.stderr[-3000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    return json.loads(lines[0]), p.stderr
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as tmp:
+        detail_path = os.path.join(tmp, "bench_detail.json")
+        cmd = [*front, os.path.join(ROOT, "bench.py"), "--shared-device", "--edge", "48", "--steps", "20", "--warmup", "3",
+               "--spinup-seconds", "0.2", "--min-seconds", "0.05", "--detail-path", detail_path, *extra]
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout,
+                           env=dict(env, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=ROOT)
+        assert p.returncode == 0, p.stdout[-2000:] + "\n" + p.stderr[-3000:]
+        detail = json.load(open(detail_path))
+    detail["_line"] = _the_one_compact_line(p.stdout)
+    return detail, p.stderr
+
+
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline")
+
+
+def _the_one_compact_line(stdout):
+    """stdout holds ONE JSON line, short enough for the driver's 8 KB tail (BENCH_r05.json: a 21 KB line was not parsed),
+    strict JSON, with the contract's fields; everything else is in the detail file."""
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and stdout.rstrip().endswith(lines[0])
+    assert len(lines[0]) <= 8000, len(lines[0])
+    line = json.loads(lines[0], parse_constant=lambda c: pytest.fail(f"non-strict JSON constant {c}"))
+    for key in CONTRACT:
+        assert key in line, key
+    assert "dropped" not in line
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and 0.0 < r["frac"] <= 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-4
+    return line
 
 
 @pytest.mark.parametrize("world,transport", [(3, "ipc")])  # (2 ranks, host AND ipc: test_bench_two_ranks_on_the_production_kernels_measures_both_transports)
@@ -98,6 +122,12 @@ def test_bench_script_multi_rank_path(world, transport):
     assert out["postflight"]["fused_vs_unfused_residual_rel_diff"] <= 1e-9
     assert out["roofline"]["launches_timed"] >= 20 + 1  # one launch per apply, or an interior + a boundary launch
     assert 0.0 < out["roofline"]["frac"] <= 1.0 and out["timing"]["repeats"] >= 1
+    line = out["_line"]
+    assert line["n_gpus"] == world and line["transport"] == transport and line["preflight_ok"] and line["postflight_ok"]
+    assert abs(line["value"] - out["value"]) <= 1e-5 * out["value"]
+    # (ranks sharing one device on the peer windows: no RCCL communicator -- RCCL's own view says so)
+    assert line["rccl"]["nccl_comm_count"] == 0 and len(line["rccl"]["ranks"]) == world
+    assert line["transports_measured"][transport]["comm_breakdown"]["allreduces_per_iteration"] > 1.9
     # where the communication time went: the peer-window transport's kernels time their own waits
     cb = out["comm_breakdown"]
     assert cb["transport"] == transport
@@ -138,17 +168,30 @@ def test_unstructured_partition_reproduces_the_recorded_reference_run(world, tmp
     assert max(len(r["nbrs"]) for r in reports) >= 2  # not a chain of slabs
 
 
-def test_bench_line_contract_at_one_gpu():
+def test_bench_line_contract_at_one_gpu(tmp_path):
     """`python bench.py` (N = 1) on a small edge: ONE JSON line carrying the contract's fields -- `roofline` with a
     physical fraction <= 1 that follows from its own bytes and time, `roofline_general`, `cpu_baseline`, `timing`."""
+    detail_path = os.path.join(str(tmp_path), "bench_detail.json")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--edge", "96", "--steps", "20", "--warmup", "3",
-           "--spinup-seconds", "0.2", "--min-seconds", "0.05", "--cpu-iters", "3", "--tet-edge", "12", "--self-exchange", "cg"]
+           "--spinup-seconds", "0.2", "--min-seconds", "0.05", "--cpu-iters", "4", "--tet-edge", "12", "--self-exchange", "cg",
+           "--detail-path", detail_path]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(env, OMP_NUM_THREADS="1"), cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + "\n" + p.stderr[-3000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    out = json.loads(lines[0])
+    line = _the_one_compact_line(p.stdout)
+    out = json.load(open(detail_path))  # the full record
+    # ---- the compact line: the contract + roofline (with the 8d-comparable SpMV figure inside) + cpu_baseline ----
+    assert line["n_gpus"] == 1 and line["steps"] == 20 and line["dtype"] == "f64" and line["vs_baseline"] is None
+    assert "workload" in line["config"] and "model" not in line["config"] and line["detail"]
+    assert abs(line["value"] - out["value"]) <= 1e-5 * out["value"] and abs(line["value_general"] - out["value_general"]) <= 1e-5 * out["value_general"]
+    lr = line["roofline"]
+    assert abs(lr["spmv_general_frac_8d_rotating"] - out["spmv"]["general"]["rotating_3_pairs"]["frac_8d"]) <= 1e-5
+    assert abs(lr["spmv_general_ms"] - out["spmv"]["general"]["rotating_3_pairs"]["median_ms"]) <= 1e-5 * lr["spmv_general_ms"]
+    assert lr["spmv_general_bytes_8d"] == out["spmv"]["general"]["algorithmic_bytes_8d"] and lr["kernel"]
+    lc = line["cpu_baseline"]
+    assert lc["kind"] == "port" and lc["cores"] == 1 and lc["value"] > 0 and len(lc["sample"]) <= 200 and lc["unit"] == "iter/s"
+    for k in ("config1_cg64", "config3_bicgstab256", "config4_gmres30_convdiff128", "config5_cavity128"):
+        assert k in line["configs"] and "error" not in line["configs"][k], line["configs"]
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in out, key
@@ -190,6 +233,9 @@ def test_bench_line_contract_at_one_gpu():
     assert br["transport"] == "rccl" and 0.9 <= br["halo_exchanges_per_iteration"] <= 1.1 and 1.9 <= br["allreduces_per_iteration"] <= 2.1
     cpu = out["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0 and cpu["gpu_vs_cpu_residual_rel_diff"] <= 1e-9
+    # SURVEY 8d's flags, built on THIS machine (it has gcc: the tests' C hosts are built with it), beside the strict build
+    assert cpu["value_native_O3"] > 0 and cpu["value_native_O3_fast_math"] > 0 and lc["value_native_O3"] > 0
+    assert cpu["value_native_O3_residual_rel_diff_vs_strict"] <= 1e-9 and cpu["value_native_O3_fast_math_residual_rel_diff_vs_strict"] <= 1e-6
     assert out["timing"]["repeats"] >= 1 and out["value"] > 10 * cpu["value"]
 
 
@@ -210,3 +256,6 @@ def test_bench_two_ranks_on_the_production_kernels_measures_both_transports():
     assert out["postflight"]["ok"] and out["postflight"]["fused_vs_unfused_residual_rel_diff"] <= 1e-9
     assert out["op_stats"]["tiled_planes"] == 2 and out["op_stats"]["paired_rows"] == 2
     assert out["roofline"]["launches_timed"] >= 2 * 31  # per apply: the interior / marching launch + the boundary launch
+    line = out["_line"]
+    assert set(line["transports_measured"]) == {"host", "ipc"} and line["transport"] == "ipc" and line["postflight_ok"]
+    assert line["transports_measured"]["ipc"]["value"] == pytest.approx(tm["ipc"]["value"], rel=1e-5)

@@ -51,10 +51,10 @@ def test_morton_order_is_a_permutation_that_keeps_neighbours_close():
     # the Triangle mesh of the reference (2-D, no lattice): the automatic mode takes the curve
     import os
 
-    from stormruler_amd import io_triangle
+    from stormruler_amd import io_tetgen
 
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mesh", "square_nb.1.")
-    t = io_triangle.read_triangle(root)
+    t = io_tetgen.read_triangle(root)
     order, kind = mesh.geometric_ordering(t)
     assert kind == "morton" and np.array_equal(np.sort(order), np.arange(t.n_cells))
 

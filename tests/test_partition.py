@@ -82,10 +82,10 @@ def test_rcb_partition_on_the_unstructured_reference_mesh(n_parts):
     Triangle mesh; balanced parts, pairing halo plans, partitioned apply == global apply."""
     import os
 
-    from stormruler_amd import io_triangle
+    from stormruler_amd import io_tetgen
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    g = io_triangle.read_triangle(os.path.join(root, "tests", "golden", "mesh", "square_nb.1."))
+    g = io_tetgen.read_triangle(os.path.join(root, "tests", "golden", "mesh", "square_nb.1."))
     part = partition.rcb_partition(g.center, n_parts)
     sizes = np.bincount(part, minlength=n_parts)
     assert sizes.sum() == g.n_cells and sizes.max() - sizes.min() <= n_parts
@@ -108,11 +108,11 @@ def test_rcb_partition_on_the_unstructured_reference_mesh(n_parts):
 def _mesh_for(kind):
     import os
 
-    from stormruler_amd import io_tetgen, io_triangle
+    from stormruler_amd import io_tetgen
 
     if kind == "triangles":
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        return io_triangle.read_triangle(os.path.join(root, "tests", "golden", "mesh", "square_nb.1."))
+        return io_tetgen.read_triangle(os.path.join(root, "tests", "golden", "mesh", "square_nb.1."))
     if kind == "tetrahedra":
         pos, bf, cells = io_tetgen.tet_box(6)
         return io_tetgen.face_graph_from_simplices(pos, bf, np.ones(len(bf), np.int64), cells)

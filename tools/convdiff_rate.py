@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE config 4's shape on one GPU: GMRES(30) on the 128^3 convection-diffusion operator, iterations per second
-(fixed 600 iterations, tolerances off), per option set:  python tools/convdiff_rate.py "coop_plain=0" "coop_plain=1" """
+(fixed 600 iterations, tolerances off), per option set:  python tools/convdiff_rate.py "test_disable=32" "test_disable=0" """
 import json
 import os
 import sys

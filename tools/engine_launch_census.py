@@ -9,12 +9,12 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from stormruler_amd import api, io_triangle, mesh  # noqa: E402
+from stormruler_amd import api, io_tetgen, mesh  # noqa: E402
 from tools.solver_paths import SOLVERS, make  # noqa: E402
 
 kind = sys.argv[1]
 ctx = api.Context(0)
-g = io_triangle.read_triangle(os.path.join(ROOT, "tests", "golden", "mesh", "step.1."))
+g = io_tetgen.read_triangle(os.path.join(ROOT, "tests", "golden", "mesh", "step.1."))
 g = mesh.FaceGraph(g.n_cells, 2, g.inner, g.outer, g.area, g.center, g.volume, b_center=np.zeros((0, 2)))
 mat = api.StencilMatrix.from_face_graph(ctx, g)
 lam = api.make_operator(lambda y, x: mat.apply(-1e-2, 1.0, x, y))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GMRES(30) / CG / BiCGStab microseconds per iteration on small and mid-size boxes against a library option
-(default: coop_plain = 0 / 1): python tools/gmres_ab.py [sizes:32,64,128] [solvers:gmres30,cg,bicgstab] [key=value ...]"""
+(default: test_disable = 32 / 0, i.e. cooperative launches against ordinary ones): python tools/gmres_ab.py [sizes:32,64,128] [solvers:gmres30,cg,bicgstab] [key=value ...]"""
 import json
 import os
 import sys
@@ -12,7 +12,7 @@ from stormruler_amd import api, mesh  # noqa: E402
 argv = sys.argv[1:]
 sizes = [int(v) for a in argv if a.startswith("sizes:") for v in a[6:].split(",")] or [32, 64, 128]
 wanted = [v for a in argv if a.startswith("solvers:") for v in a[8:].split(",")] or ["gmres30", "cg", "bicgstab"]
-sets = [a for a in argv if ":" not in a] or ["coop_plain=0", "coop_plain=1"]
+sets = [a for a in argv if ":" not in a] or ["test_disable=32", "test_disable=0"]
 for n in sizes:
     g = mesh.structured_box(n)
     row = {"n": n}

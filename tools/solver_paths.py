@@ -23,7 +23,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from stormruler_amd import api, io_triangle, mesh  # noqa: E402
+from stormruler_amd import api, io_tetgen, mesh  # noqa: E402
 
 SOLVERS = {"cg": api.CgSolver, "bicgstab": api.BiCgStabSolver, "gmres30": api.GmresSolver, "cgs": api.CgsSolver,
            "tfqmr": api.TfqmrSolver, "tfqmr1": api.Tfqmr1Solver, "bicgstabl2": api.BiCgStabLSolver,
@@ -76,7 +76,7 @@ def main():
             alpha, beta, iters = -1.0, 0.0, (200 if n >= 128 else 400)
             b_host = np.ones(g.n_cells)
         else:
-            g = io_triangle.read_triangle(os.path.join(ROOT, "tests", "golden", "mesh", "step.1."))
+            g = io_tetgen.read_triangle(os.path.join(ROOT, "tests", "golden", "mesh", "step.1."))
             g = mesh.FaceGraph(g.n_cells, 2, g.inner, g.outer, g.area, g.center, g.volume, b_center=np.zeros((0, 2)))
             alpha, beta, iters = -1.0e-2, 1.0, 400
             b_host = np.sin(3 * g.center[:, 0]) * np.cos(7 * g.center[:, 1])

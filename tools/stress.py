@@ -13,7 +13,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
-from stormruler_amd import api, io_triangle, mesh  # noqa: E402
+from stormruler_amd import api, io_tetgen, mesh  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ctx = api.Context(0)
@@ -43,7 +43,7 @@ for k in range(n_rounds):
 ctx.set_option("latency_path", 1)
 out["repeat_solves"] = {"rounds": n_rounds, "seconds": time.time() - t, "distinct_iteration_counts": sorted(its),
                         "one_count_per_case": len(its) == len(cases), "free_mem_delta": free0 - torch.cuda.mem_get_info()[0]}
-tri = io_triangle.read_triangle(os.path.join(ROOT, "tests", "golden", "mesh", "step.1."))
+tri = io_tetgen.read_triangle(os.path.join(ROOT, "tests", "golden", "mesh", "step.1."))
 tri = mesh.FaceGraph(tri.n_cells, 2, tri.inner, tri.outer, tri.area, tri.center, tri.volume, b_center=np.zeros((0, 2)))
 mt = api.StencilMatrix.from_face_graph(ctx, tri)
 bt = api.DeviceVector.from_numpy(ctx, np.sin(3 * tri.center[:, 0]) * np.cos(7 * tri.center[:, 1]))
