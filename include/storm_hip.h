@@ -162,6 +162,22 @@ int storm_hip_lin3(storm_hip_vec *y, const storm_hip_vec *r, double s, double a,
 /* y += s * (a .* b), elementwise.  Not in the solver census: the nonlinear term a time-step
  * driver forms between solves (cf. `f <<= map(dF_dc, c)`, Playground.cpp:148). */
 int storm_hip_vmul_add(storm_hip_vec *y, double s, const storm_hip_vec *a, const storm_hip_vec *b);
+/* `out <<= map(func, mats...)`  Bittern/MatrixMath.hpp:44-105 (MapMatrixView, map) evaluated by the element loop of
+ * MatrixAlgorithms.hpp:75-79, 120-124 -- the playground's `f <<= map(dF_dc, c)`, Playground.cpp:142-148.  `func` arrives as
+ * a program in reverse Polish notation over the elements x0[i], x1[i], y[i] (the old value of the target) and up to 16
+ * constants: program[k] = opcode | (constant index << 8), at most 48 operations, at most 8 operands at once; it must leave
+ * exactly one value.  Only exactly-rounded operations (+ - * / sqrt abs neg min max), each rounded on its own, no
+ * contraction: y[i] is what the host's scalar evaluation of the same expression in the same order gives, BIT FOR BIT.
+ * x0 / x1 may be NULL when the program does not read them and may alias y.  include/storm_hip/Storm.hpp builds the
+ * program by tracing a generic lambda: `f <<= map([](auto c) { return 2.0 * c * (c - 1.0) * (2.0 * c - 1.0); }, c)`. */
+enum {
+  STORM_HIP_MAP_X0 = 0, STORM_HIP_MAP_X1 = 1, STORM_HIP_MAP_Y = 2, STORM_HIP_MAP_CONST = 3, /* push an operand */
+  STORM_HIP_MAP_NEG = 8, STORM_HIP_MAP_ABS = 9, STORM_HIP_MAP_SQRT = 10,                    /* top = op(top) */
+  STORM_HIP_MAP_ADD = 16, STORM_HIP_MAP_SUB = 17, STORM_HIP_MAP_MUL = 18, STORM_HIP_MAP_DIV = 19, /* second OP top */
+  STORM_HIP_MAP_MIN = 20, STORM_HIP_MAP_MAX = 21
+};
+int storm_hip_map(storm_hip_vec *y, const storm_hip_vec *x0, const storm_hip_vec *x1, const int32_t *program, int n_ops,
+                  const double *constants, int n_constants);
 /* y = a .* b, elementwise: `Preconditioner::mul` of a diagonal (Jacobi) preconditioner behind the
  * pre_op hook of Solvers/Solver.hpp:74-75 (the reference ships only IdentityPreconditioner,
  * Preconditioner.hpp:84-97).  y may alias a or b. */

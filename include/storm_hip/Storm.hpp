@@ -34,6 +34,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstddef>
+#include <cstring>
 #include <exception>
 #include <functional>
 #include <initializer_list>
@@ -251,6 +252,116 @@ inline DeviceVector& operator<<=(DeviceVector& out, const expr::Quot& e) {  // p
   return out;
 }
 
+// out <<= map(func, mats...)   (Bittern/MatrixMath.hpp:44-105, evaluated by MatrixAlgorithms.hpp:75-79, 120-124)
+//
+// `func` runs on the device, so it cannot be handed over as a host callable: it is TRACED.  Called once with operands of
+// type expr::Sym, a generic lambda records the operations it performs, in the order it performs them, as a short program
+// for storm_hip_map -- each operation rounded on its own, so the device's result equals the host's evaluation of the same
+// expression bit for bit.  The playground's (Playground.cpp:142-148)
+//     constexpr auto dF_dc = [](real_t c) noexcept { return 2.0 * c * (c - 1.0) * (2.0 * c - 1.0); };
+//     f <<= map(dF_dc, c);
+// needs ONE token changed: `real_t c` -> `auto c`.  Supported: + - * /, unary -, abs, sqrt, min, max, mixed with
+// real_t constants; one or two vector operands, or three when one of them is the target itself (`y <<= map(f, y, a, b)`);
+// no data-dependent branches (a traced value has no truth value).
+namespace expr {
+class Sym {
+public:
+  Sym(real_t constant) { _consts.push_back(constant), _code.push_back(STORM_HIP_MAP_CONST); }  // NOLINT: `2.0 * c`
+  static Sym input(int slot) {  // (slot k is recorded as opcode k; `<<=` assigns the slots to x0 / x1 / y)
+    Sym s;
+    s._code.push_back(slot);
+    return s;
+  }
+  static Sym unary(int op, const Sym& a) {
+    Sym s = a;
+    s._code.push_back(op);
+    return s;
+  }
+  static Sym binary(int op, const Sym& a, const Sym& b) {
+    Sym s = a;
+    for (int32_t word : b._code) {
+      if ((word & 0xff) == STORM_HIP_MAP_CONST) word = STORM_HIP_MAP_CONST | (s.constant(b._consts[(std::size_t)(word >> 8)]) << 8);
+      s._code.push_back(word);
+    }
+    s._code.push_back(op);
+    return s;
+  }
+  const std::vector<int32_t>& code() const noexcept { return _code; }
+  const std::vector<real_t>& constants() const noexcept { return _consts; }
+
+private:
+  Sym() = default;
+  int32_t constant(real_t value) {  // one slot per distinct bit pattern
+    for (std::size_t k = 0; k < _consts.size(); ++k)
+      if (std::memcmp(&_consts[k], &value, sizeof value) == 0) return (int32_t)k;
+    _consts.push_back(value);
+    return (int32_t)_consts.size() - 1;
+  }
+  std::vector<int32_t> _code;  // a lone constant's word carries index 0: Sym(real_t) pushes it first
+  std::vector<real_t> _consts;
+};
+inline Sym operator+(const Sym& a, const Sym& b) { return Sym::binary(STORM_HIP_MAP_ADD, a, b); }
+inline Sym operator-(const Sym& a, const Sym& b) { return Sym::binary(STORM_HIP_MAP_SUB, a, b); }
+inline Sym operator*(const Sym& a, const Sym& b) { return Sym::binary(STORM_HIP_MAP_MUL, a, b); }
+inline Sym operator/(const Sym& a, const Sym& b) { return Sym::binary(STORM_HIP_MAP_DIV, a, b); }
+inline Sym operator-(const Sym& a) { return Sym::unary(STORM_HIP_MAP_NEG, a); }
+inline Sym operator+(const Sym& a) { return a; }
+inline Sym abs(const Sym& a) { return Sym::unary(STORM_HIP_MAP_ABS, a); }
+inline Sym sqrt(const Sym& a) { return Sym::unary(STORM_HIP_MAP_SQRT, a); }
+inline Sym min(const Sym& a, const Sym& b) { return Sym::binary(STORM_HIP_MAP_MIN, a, b); }
+inline Sym max(const Sym& a, const Sym& b) { return Sym::binary(STORM_HIP_MAP_MAX, a, b); }
+
+struct Mapped {  // map(func, mats...): the traced program and its operands (slot k of the program reads x[k])
+  Sym program;
+  const DeviceVector* x[3];
+};
+}  // namespace expr
+
+#define STORM_HIP_MAP1(V)                                        \
+  template<class Func>                                           \
+  inline expr::Mapped map(Func func, V x0) {                     \
+    return {func(expr::Sym::input(0)), {&x0, nullptr, nullptr}}; \
+  }
+STORM_HIP_CV1(STORM_HIP_MAP1)
+#define STORM_HIP_MAP2(X, Z)                                                            \
+  template<class Func>                                                                  \
+  inline expr::Mapped map(Func func, X x0, Z x1) {                                      \
+    return {func(expr::Sym::input(0), expr::Sym::input(1)), {&x0, &x1, nullptr}};       \
+  }
+STORM_HIP_CV2(STORM_HIP_MAP2)
+#undef STORM_HIP_MAP1
+#undef STORM_HIP_MAP2
+/// Three operands (one of which must be the target of the `<<=` that consumes the node: the device kernel streams the
+/// target and two more vectors).
+template<class Func>
+inline expr::Mapped map(Func func, const DeviceVector& x0, const DeviceVector& x1, const DeviceVector& x2) {
+  return {func(expr::Sym::input(0), expr::Sym::input(1), expr::Sym::input(2)), {&x0, &x1, &x2}};
+}
+inline DeviceVector& operator<<=(DeviceVector& out, const expr::Mapped& e) {
+  // the program's slots -> the kernel's operands: the target itself is `y`, the others x0, x1 in their order
+  int opcode_of[3] = {-1, -1, -1};
+  const DeviceVector* xs[2] = {nullptr, nullptr};
+  int used = 0;
+  for (int k = 0; k < 3; ++k) {
+    if (e.x[k] == nullptr) continue;
+    if (e.x[k] == &out) {
+      opcode_of[k] = STORM_HIP_MAP_Y;
+    } else {
+      if (used == 2) throw std::invalid_argument("map: three operands, none of which is the target of `<<=`");
+      xs[used] = e.x[k];
+      opcode_of[k] = used == 0 ? STORM_HIP_MAP_X0 : STORM_HIP_MAP_X1;
+      ++used;
+    }
+  }
+  std::vector<int32_t> code = e.program.code();
+  for (int32_t& word : code)
+    if ((word & 0xff) < STORM_HIP_MAP_CONST) word = opcode_of[word & 0xff];
+  const auto& consts = e.program.constants();
+  detail::check(storm_hip_map(out.handle(), xs[0] ? xs[0]->handle() : nullptr, xs[1] ? xs[1]->handle() : nullptr, code.data(),
+                              (int)code.size(), consts.data(), (int)consts.size()));
+  return out;
+}
+
 /// Bittern/MatrixAlgorithms.hpp:140-153: the reference's engine, distribution and sequence.
 inline void fill_randomly(DeviceVector& a) { detail::check(storm_hip_fill_randomly(a.handle())); }
 
@@ -402,6 +513,12 @@ public:
                                                         w_inner.data(), w_outer.data(), diag_extra, &m._h));
     return m;
   }
+  /// Takes ownership of an operator handle made through the C ABI.
+  static StencilMatrix adopt(storm_hip_op* handle) noexcept {
+    StencilMatrix m;
+    m._h = handle;
+    return m;
+  }
   StencilMatrix(StencilMatrix&& o) noexcept : _h(std::exchange(o._h, nullptr)) {}
   StencilMatrix& operator=(StencilMatrix&& o) noexcept {
     if (this != &o) {
@@ -436,6 +553,63 @@ private:
 inline void stormDivGrad(const StencilMatrix& matrix, DeviceVector& u, real_t dt, const DeviceVector& c) {
   matrix.apply_add(dt, c, u);
 }
+
+/// A mesh in host memory: exactly what stormDivGrad's face loop reads (`storm_hip_mesh`).  `read_mesh_from_tetgen`
+/// (Mallard/IoTetgen.hpp:44-235) is `HostMesh::read_tetgen`; the operator over it `matrix()`.  As Playground.cpp:248-255:
+///     auto mesh = HostMesh::read_tetgen("mesh/step.1.");   StencilMatrix L = mesh.matrix(ctx);
+class HostMesh {
+public:
+  /// dim: mesh_dim_v<Mesh> the caller expects (2, 3; 0: what the node file says).  I/O errors throw std::runtime_error with
+  /// the reference's message (STORM_THROW_IO, Crow/Base/Exception.hpp:35-44).
+  static HostMesh read_tetgen(const std::string& prefix, int dim = 0) {
+    HostMesh m;
+    detail::check(storm_hip_mesh_read_tetgen(prefix.c_str(), (int32_t)dim, &m._h));
+    return m;
+  }
+  HostMesh(HostMesh&& o) noexcept : _h(std::exchange(o._h, nullptr)) {}
+  HostMesh& operator=(HostMesh&& o) noexcept {
+    if (this != &o) {
+      storm_hip_mesh_destroy(_h);
+      _h = std::exchange(o._h, nullptr);
+    }
+    return *this;
+  }
+  HostMesh(const HostMesh&) = delete;
+  HostMesh& operator=(const HostMesh&) = delete;
+  ~HostMesh() { storm_hip_mesh_destroy(_h); }
+
+  storm_hip_mesh_view view() const {
+    storm_hip_mesh_view v;
+    detail::check(storm_hip_mesh_get_view(_h, &v));
+    return v;
+  }
+  std::size_t num_cells() const { return (std::size_t)view().n_cells; }
+  std::size_t num_halo_cells() const { return (std::size_t)view().n_halo; }
+  /// The gather-form operator of the face loop over this mesh (boundary faces skipped like `interior_faces()`,
+  /// Playground.cpp:119, when `neumann`; otherwise they carry a homogeneous Dirichlet ghost value).
+  StencilMatrix matrix(const Context& ctx, bool neumann = false) const {
+    if (!neumann) return StencilMatrix::adopt(create(ctx, _h));
+    const storm_hip_mesh_view v = view();
+    storm_hip_mesh* interior = nullptr;  // the same mesh without its labelled faces
+    detail::check(storm_hip_mesh_create(v.dim, v.n_cells, v.n_halo, v.n_faces, v.inner, v.outer, v.area, v.center, v.volume, 0,
+                                        nullptr, nullptr, nullptr, v.global_id, v.halo_owner, &interior));
+    storm_hip_op* op = nullptr;
+    const int st = storm_hip_op_create_from_mesh_object(ctx.handle(), interior, &op);
+    storm_hip_mesh_destroy(interior);
+    detail::check(st);
+    return StencilMatrix::adopt(op);
+  }
+  storm_hip_mesh* handle() const noexcept { return _h; }
+
+private:
+  HostMesh() = default;
+  static storm_hip_op* create(const Context& ctx, const storm_hip_mesh* mesh) {
+    storm_hip_op* op = nullptr;
+    detail::check(storm_hip_op_create_from_mesh_object(ctx.handle(), mesh, &op));
+    return op;
+  }
+  storm_hip_mesh* _h = nullptr;
+};
 
 /// A = beta I + alpha M as an Operator<DeviceVector> (the caller keeps `matrix` alive, as the
 /// reference's operator lambdas capture the mesh by reference, Playground.cpp:152-167).

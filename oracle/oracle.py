@@ -478,6 +478,36 @@ def ch_operator_apply(g_or_mesh, f, c, c_in, tau: float = 1.0e-3, Gamma: float =
     return c_hat, w_hat
 
 
+class ChOperator:
+    """The playground's operator lambda (Playground.cpp:153-167) as an operator ``solve`` can take: what
+    ``cahn_hilliard_step`` hands to ``solve<CgSolver>`` (:151).  ``f`` and ``c`` are captured by reference like the
+    lambda's: the arrays passed in are the ones read at every application."""
+
+    def __init__(self, g_or_mesh, f, c, tau: float = 1.0e-3, Gamma: float = 1.0e-4, sigma: float = 2.0, variant: str = "strict"):
+        self.mesh = g_or_mesh if isinstance(g_or_mesh, Mesh) else Mesh(g_or_mesh)
+        self.f, self.c = f64(f), f64(c)
+        self.w_hat = np.empty_like(self.c)
+        self.op = _ChOp(C.pointer(self.mesh.c), _p(self.f), _p(self.c), _p(self.w_hat), tau, Gamma, sigma)
+        self.variant = variant
+        self.fn = C.cast(lib(variant).oracle_ch_apply, C.c_void_p)
+        self.ctx = C.cast(C.pointer(self.op), C.c_void_p)
+
+    def apply(self, c_in):
+        c_in = f64(c_in)
+        c_hat = np.empty_like(c_in)
+        lib(self.variant).oracle_ch_apply(self.ctx, _p(c_hat), _p(c_in))
+        return c_hat
+
+
+def cahn_hilliard_step(g_or_mesh, c, **solver_knobs):
+    """``cahn_hilliard_step`` (Playground.cpp:133-174): ``f <<= map(dF_dc, c)``; ``c_hat <<= c`` (the warm start, :150);
+    ``solve<CgSolver>(c_hat, c, lambda)``.  Returns ``(c_hat, SolveResult)``."""
+    c = f64(c)
+    op = ChOperator(g_or_mesh, dF_dc(c), c)
+    res = solve("cg", op, c, x0=c, **solver_knobs)
+    return res.x, res
+
+
 def dF_dc(c):
     """``map(dF_dc, c)``, Playground.cpp:142-148."""
     c = f64(c)

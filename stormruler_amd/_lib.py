@@ -83,6 +83,7 @@ SIGNATURES = {
     "storm_hip_comm_unique_id": (C.c_int, [vp]),
     "storm_hip_ctx_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int]),
     "storm_hip_ctx_comm_init_host": (C.c_int, [vp, C.c_int, C.c_int, ALLREDUCE_FN, EXCHANGE_FN, vp]),
+    "storm_hip_map": (C.c_int, [vp, vp, vp, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_double), C.c_int]),
     "storm_hip_ctx_comm_size": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "storm_hip_ctx_comm_rccl_view": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                                C.POINTER(C.c_int), C.c_char_p, C.c_int]),

@@ -242,6 +242,74 @@ class _Lin3:  # r + s * (a*x + b*z)
         self.r, self.s, self.lin = r, s, lin
 
 
+# ``out <<= map(func, mats...)`` (Bittern/MatrixMath.hpp:44-105; the playground's ``f <<= map(dF_dc, c)``,
+# Playground.cpp:142-148).  ``func`` runs on the device, so it is TRACED: called once with :class:`Sym` operands it
+# records its arithmetic, in order, as a reverse-Polish program for ``storm_hip_map`` -- every operation rounded on its
+# own, so the device's values equal numpy's evaluation of the same expression bit for bit.
+MAP_X0, MAP_X1, MAP_Y, MAP_CONST, MAP_NEG, MAP_ABS, MAP_SQRT = 0, 1, 2, 3, 8, 9, 10
+MAP_ADD, MAP_SUB, MAP_MUL, MAP_DIV, MAP_MIN, MAP_MAX = 16, 17, 18, 19, 20, 21
+
+
+class Sym:
+    """A traced scalar of an element map: supports + - * /, unary -, abs, ``sqrt()``, ``min()`` / ``max()`` with
+    floats and other traced values.  No truth value (no data-dependent branches)."""
+
+    __array_ufunc__ = None
+
+    def __init__(self, code, consts):
+        self.code, self.consts = list(code), list(consts)
+
+    @staticmethod
+    def of(v) -> "Sym":
+        return v if isinstance(v, Sym) else Sym([MAP_CONST], [float(v)])
+
+    def _bin(self, op, other, swap=False):
+        a, b = (Sym.of(other), self) if swap else (self, Sym.of(other))
+        code, consts = list(a.code), list(a.consts)
+        for word in b.code:
+            if word & 0xff == MAP_CONST:
+                v = b.consts[word >> 8]
+                for k, have in enumerate(consts):  # one slot per distinct bit pattern
+                    if np.float64(have).tobytes() == np.float64(v).tobytes():
+                        break
+                else:
+                    consts.append(v)
+                    k = len(consts) - 1
+                word = MAP_CONST | (k << 8)
+            code.append(word)
+        return Sym(code + [op], consts)
+
+    def __add__(self, o): return self._bin(MAP_ADD, o)
+    def __radd__(self, o): return self._bin(MAP_ADD, o, True)
+    def __sub__(self, o): return self._bin(MAP_SUB, o)
+    def __rsub__(self, o): return self._bin(MAP_SUB, o, True)
+    def __mul__(self, o): return self._bin(MAP_MUL, o)
+    def __rmul__(self, o): return self._bin(MAP_MUL, o, True)
+    def __truediv__(self, o): return self._bin(MAP_DIV, o)
+    def __rtruediv__(self, o): return self._bin(MAP_DIV, o, True)
+    def __neg__(self): return Sym(self.code + [MAP_NEG], self.consts)
+    def __pos__(self): return self
+    def __abs__(self): return Sym(self.code + [MAP_ABS], self.consts)
+    def sqrt(self): return Sym(self.code + [MAP_SQRT], self.consts)
+    def min(self, o): return self._bin(MAP_MIN, o)
+    def max(self, o): return self._bin(MAP_MAX, o)
+
+    def __bool__(self):
+        raise TypeError("a traced element has no truth value: an element map cannot branch on its data")
+
+
+class _Mapped:  # map(func, x0 [, x1 [, x2]])
+    def __init__(self, program: Sym, xs):
+        self.program, self.xs = program, list(xs)
+
+
+def map(func, *xs: "DeviceVector") -> _Mapped:  # noqa: A001 -- the reference's name (Bittern/MatrixMath.hpp:103)
+    """``map(func, mats...)``: consumed by ``out <<= ...``.  One or two vectors, or three when one is the target."""
+    if not 1 <= len(xs) <= 3:
+        raise ValueError("map: one to three vector operands")
+    return _Mapped(Sym.of(func(*[Sym([k], []) for k in range(len(xs))])), xs)
+
+
 class DeviceVector:
     """N doubles in HBM (+ halo tail); the solver ``Vector`` (concept legacy_vector_like,
     Solvers/Operator.hpp:39-45)."""
@@ -356,6 +424,22 @@ class DeviceVector:
             # the scaling, as the reference's expression tree evaluates it
             check(lib.storm_hip_axpbz(self._h, e.lin.a, e.lin.x._h, e.lin.b, e.lin.z._h))
             check(lib.storm_hip_scale(self._h, e.s))
+        elif isinstance(e, _Mapped):
+            # the program's slots -> the kernel's operands: the target itself is `y`, the others x0, x1 in their order
+            opcode_of, others = {}, []
+            for k, x in enumerate(e.xs):
+                if x is self:
+                    opcode_of[k] = MAP_Y
+                else:
+                    if len(others) == 2:
+                        raise ValueError("map: three operands, none of which is the target of `<<=`")
+                    opcode_of[k] = MAP_X0 if not others else MAP_X1
+                    others.append(x)
+            code = [opcode_of[w] if (w & 0xff) < MAP_CONST else w for w in e.program.code]
+            prog = (C.c_int32 * len(code))(*code)
+            consts = (C.c_double * max(len(e.program.consts), 1))(*e.program.consts)
+            check(lib.storm_hip_map(self._h, others[0]._h if others else None, others[1]._h if len(others) > 1 else None,
+                                    prog, len(code), consts, len(e.program.consts)))
         else:
             raise NotImplementedError(f"no device kernel for `<<=` of {type(e).__name__}")
         return self

@@ -135,6 +135,45 @@ struct VdivF {
   __device__ double operator()(double, double a, double b) const { return has_a ? (s * a) / b : s / b; }
 };
 
+// y = func(x0, x1, y) elementwise, func a short arithmetic program in reverse Polish notation (storm_hip_map): the
+// element map `out <<= map(func, mats...)` of Bittern/MatrixMath.hpp:44-105 for callables made of exactly-rounded
+// operations.  The operand stack lives in NAMED registers (a push shifts them): no dynamically indexed array, no scratch.
+// Every operation is a statement of its own, so nothing contracts (-ffp-contract=on fuses within a statement only): the
+// value is what the host's scalar evaluation of the same expression gives, bit for bit.
+constexpr int kMapMaxOps = 48, kMapMaxConsts = 16, kMapMaxDepth = 8;
+struct MapF {
+  static constexpr bool reads_y = true;
+  static constexpr int nin = 2;
+  int n_ops;
+  int code[kMapMaxOps];
+  double consts[kMapMaxConsts];
+  __device__ void prepare() {}
+  __device__ double operator()(double y, double a, double b) const {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
+    for (int k = 0; k < n_ops; ++k) {
+      const int op = code[k] & 0xff, arg = code[k] >> 8;
+      if (op < STORM_HIP_MAP_NEG) {
+        const double v = op == STORM_HIP_MAP_X0 ? a : op == STORM_HIP_MAP_X1 ? b : op == STORM_HIP_MAP_Y ? y : consts[arg];
+        s7 = s6, s6 = s5, s5 = s4, s4 = s3, s3 = s2, s2 = s1, s1 = s0, s0 = v;
+      } else if (op < STORM_HIP_MAP_ADD) {
+        if (op == STORM_HIP_MAP_NEG) s0 = -s0;
+        else if (op == STORM_HIP_MAP_ABS) s0 = __builtin_fabs(s0);
+        else s0 = __builtin_sqrt(s0);
+      } else {
+        double r;
+        if (op == STORM_HIP_MAP_ADD) r = s1 + s0;
+        else if (op == STORM_HIP_MAP_SUB) r = s1 - s0;
+        else if (op == STORM_HIP_MAP_MUL) r = s1 * s0;
+        else if (op == STORM_HIP_MAP_DIV) r = s1 / s0;
+        else if (op == STORM_HIP_MAP_MIN) r = s0 < s1 ? s0 : s1;  // std::min(s1, s0)
+        else r = s1 < s0 ? s0 : s1;                               // std::max(s1, s0)
+        s0 = r, s1 = s2, s2 = s3, s3 = s4, s4 = s5, s5 = s6, s6 = s7;
+      }
+    }
+    return s0;
+  }
+};
+
 template <class F>
 static int launch_ew(storm_hip_ctx *c, int64_t n, EwPtrs p, F f, const int *done) {
   if (n <= 0) return STORM_HIP_OK;
@@ -559,6 +598,43 @@ int storm_hip_vmul_add(storm_hip_vec *y, double s, const storm_hip_vec *a, const
   STORM_TRY(lazy_sync(y->ctx));
   if (y->n_owned <= 0) return STORM_HIP_OK;
   return launch_ew(y->ctx, y->n_owned, EwPtrs{y->d, a->d, b->d}, VmulAddF{s}, y->ctx->api_done);
+}
+
+int storm_hip_map(storm_hip_vec *y, const storm_hip_vec *x0, const storm_hip_vec *x1, const int32_t *program, int n_ops,
+                  const double *constants, int n_constants) {
+  STORM_REQUIRE(y && program, "map: null argument");
+  STORM_REQUIRE(n_ops >= 1 && n_ops <= kMapMaxOps, "map: a program of %d operations (1 .. %d)", n_ops, kMapMaxOps);
+  STORM_REQUIRE(n_constants >= 0 && n_constants <= kMapMaxConsts && (n_constants == 0 || constants),
+                "map: %d constants (0 .. %d)", n_constants, kMapMaxConsts);
+  if (x0) STORM_TRY(check_pair(y, x0, "map"));
+  if (x1) STORM_TRY(check_pair(y, x1, "map"));
+  MapF f;
+  f.n_ops = n_ops;
+  int depth = 0;
+  for (int k = 0; k < n_ops; ++k) {  // the program is checked here, once: the kernel trusts it
+    const int op = program[k] & 0xff, arg = program[k] >> 8;
+    if (op == STORM_HIP_MAP_X0 || op == STORM_HIP_MAP_X1 || op == STORM_HIP_MAP_Y || op == STORM_HIP_MAP_CONST) {
+      STORM_REQUIRE(op != STORM_HIP_MAP_X0 || x0, "map: operation %d reads x0, which is null", k);
+      STORM_REQUIRE(op != STORM_HIP_MAP_X1 || x1, "map: operation %d reads x1, which is null", k);
+      STORM_REQUIRE(op != STORM_HIP_MAP_CONST || (arg >= 0 && arg < n_constants), "map: operation %d: constant %d of %d", k, arg,
+                    n_constants);
+      ++depth;
+      STORM_REQUIRE(depth <= kMapMaxDepth, "map: the expression needs more than %d operands at once (operation %d)", kMapMaxDepth, k);
+    } else if (op == STORM_HIP_MAP_NEG || op == STORM_HIP_MAP_ABS || op == STORM_HIP_MAP_SQRT) {
+      STORM_REQUIRE(depth >= 1, "map: operation %d has no operand", k);
+    } else if (op >= STORM_HIP_MAP_ADD && op <= STORM_HIP_MAP_MAX) {
+      STORM_REQUIRE(depth >= 2, "map: operation %d has fewer than two operands", k);
+      --depth;
+    } else {
+      STORM_FAIL(STORM_HIP_E_INVALID, "map: unknown operation code %d at %d", op, k);
+    }
+    f.code[k] = program[k];
+  }
+  STORM_REQUIRE(depth == 1, "map: the program leaves %d values (it must leave one)", depth);
+  for (int k = 0; k < n_constants; ++k) f.consts[k] = constants[k];
+  STORM_TRY(lazy_sync(y->ctx));
+  if (y->n_owned <= 0) return STORM_HIP_OK;
+  return launch_ew(y->ctx, y->n_owned, EwPtrs{y->d, x0 ? x0->d : y->d, x1 ? x1->d : y->d}, f, y->ctx->api_done);
 }
 
 int storm_hip_vmul(storm_hip_vec *y, const storm_hip_vec *a, const storm_hip_vec *b) {
