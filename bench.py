@@ -827,8 +827,9 @@ def main() -> int:
             "setup_breakdown_seconds": setup_breakdown,
             "phase_seconds": phases,
         }
-        if world > 1:
+        if world > 1 or args.force_comm:
             out["transport"] = transport
+        if world > 1:
             out["preflight"] = preflight
             out["postflight"] = postflight
         if comm_breakdown is not None:

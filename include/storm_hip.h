@@ -36,7 +36,7 @@ extern "C" {
 /* every declaration below is an exported symbol of libstorm_hip.so */
 #pragma GCC visibility push(default)
 
-#define STORM_HIP_ABI_VERSION 5
+#define STORM_HIP_ABI_VERSION 6
 
 enum {
   STORM_HIP_OK = 0,

@@ -169,7 +169,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-if lib.storm_hip_abi_version() != 5:
+if lib.storm_hip_abi_version() != 6:
     raise ImportError("libstorm_hip.so ABI version mismatch")
 
 

@@ -419,9 +419,11 @@ template <int MODE>
 __global__ __launch_bounds__(kBlock) void halo_pack_bicg_kernel(int64_t n, const int *__restrict__ idx, const double *__restrict__ r,
                                                                 const double *__restrict__ p, const double *__restrict__ v,
                                                                 const double *__restrict__ sa, const double *__restrict__ sb,
-                                                                double *__restrict__ buf) {
+                                                                double *__restrict__ buf, double *alpha_seen) {
   // MODE 0: alpha (sb given: rho and <rt, v> -- alpha is formed here, with the update kernel's expression); MODE 1: beta, omega
   const double a = (MODE == 0 && sb) ? safe_divide(*sa, *sb) : *sa, b = sb ? *sb : 0.0;
+  // (option ticket_verify: the alpha the rows that LEAVE were formed with, for bicg_update_kernel to compare with its own)
+  if (MODE == 0 && alpha_seen != nullptr && blockIdx.x == 0 && threadIdx.x == 0) alpha_seen[0] = a, alpha_seen[1] = 1.0;  // (value, armed)
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
     const int j = idx[i];
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(kBlock) void halo_pack_bicg_kernel(int64_t n, const
   }
 }
 int comm_halo_exchange_begin_formed(const storm_hip_op *op, int mode, const double *r, const double *p, const double *v,
-                                    const double *sa, const double *sb, double *target) {
+                                    const double *sa, const double *sb, double *target, double *alpha_seen) {
   storm_hip_ctx *c = op->ctx;
   const HaloPlan &h = op->halo;
   STORM_REQUIRE(comm_is_rccl(c) && h.n_nbrs > 0, "formed exchange: needs the RCCL transport and a halo plan");
@@ -438,9 +440,10 @@ int comm_halo_exchange_begin_formed(const storm_hip_op *op, int mode, const doub
   if (h.n_send > 0) {
     const int64_t need = (h.n_send + kBlock - 1) / kBlock;
     const dim3 grid((int)(need > 1024 ? 1024 : need));
-    if (mode == 0) hipLaunchKernelGGL(halo_pack_bicg_kernel<0>, grid, dim3(kBlock), 0, c->stream, h.n_send, h.d_send_idx, r, p, v, sa, sb, h.d_sendbuf);
-    else if (mode == 1) hipLaunchKernelGGL(halo_pack_bicg_kernel<1>, grid, dim3(kBlock), 0, c->stream, h.n_send, h.d_send_idx, r, p, v, sa, sb, h.d_sendbuf);
-    else hipLaunchKernelGGL(halo_pack_bicg_kernel<2>, grid, dim3(kBlock), 0, c->stream, h.n_send, h.d_send_idx, r, p, v, sa, sb, h.d_sendbuf);
+    double *no_alpha = nullptr;
+    if (mode == 0) hipLaunchKernelGGL(halo_pack_bicg_kernel<0>, grid, dim3(kBlock), 0, c->stream, h.n_send, h.d_send_idx, r, p, v, sa, sb, h.d_sendbuf, alpha_seen);
+    else if (mode == 1) hipLaunchKernelGGL(halo_pack_bicg_kernel<1>, grid, dim3(kBlock), 0, c->stream, h.n_send, h.d_send_idx, r, p, v, sa, sb, h.d_sendbuf, no_alpha);
+    else hipLaunchKernelGGL(halo_pack_bicg_kernel<2>, grid, dim3(kBlock), 0, c->stream, h.n_send, h.d_send_idx, r, p, v, sa, sb, h.d_sendbuf, no_alpha);
     HIP_TRY(hipGetLastError());
   }
   if (pe >= 0) prof_stamp(c, c->stream, pe, 2);

@@ -155,7 +155,13 @@ struct storm_hip_ctx {
   int64_t opt_ell_cap = 0;
   int64_t opt_spmv_dict = 4;         // dictionary records whenever an operator qualifies (lossless): 3 + paired rows, 2 values + column offsets, 1 values only, 0 never
   int64_t opt_spmv_spw = 0;          // slices per wave of the dictionary kernel: 1, 2 or 4 (0 = default)
-  static constexpr int64_t opt_spmv_xcd_remap = 8;    // 0 off; 1 one contiguous run per XCD (slower); G > 1: runs of G tiles per XCD
+  int64_t opt_spmv_xcd_remap = 8;    // 0 off; 1 one contiguous run per XCD (slower); G > 1: runs of G tiles per XCD (A/B knob, option spmv_xcd_remap: tools/tet_traffic_ab.py)
+  // ... of the fp64-record kernel (spmv_sell_kernel: what any mesh gets): runs of 64 blocks = 16 384 rows per XCD.  Round 6,
+  // profiles/r10f_tet_traffic_ab.jsonl, r10g_xcd_group_sweep.jsonl: a row of x that two XCDs gather is fetched into two L2s;
+  // on the 12.6 M tetrahedra (Z-order numbering) runs of 8 blocks move 1.19 x the algorithmic bytes (0.779 of the peak),
+  // of 32: 1.12 x, of 128: 1.075 x, ONE run per XCD 1.02 x but slower (eight distant streams); 64 is the fastest on both the
+  // tetrahedra (0.813) and the 256^3 box (0.801 against 0.778).
+  int64_t opt_spmv_xcd_remap_sell = 64;
   int64_t opt_nt = 1;
   static constexpr int64_t opt_sweep_alternate = 1;   // fused CG: consecutive kernels sweep the rows in opposite directions (2: and without non-temporal hints)
   int stream_reverse = 0;            // ... and the same for the next elementwise kernel
@@ -491,7 +497,7 @@ int comm_halo_exchange_begin_direction(const storm_hip_op *op, const double *p, 
 // ... of BiCGStab's s (mode 0, target = r) / p' (mode 1, target = p), formed from the operands before the update kernel runs
 void comm_forget_prebegun(storm_hip_ctx *c);  // at the ends of a solve
 int comm_halo_exchange_begin_formed(const storm_hip_op *op, int mode, const double *r, const double *p, const double *v,
-                                    const double *sa, const double *sb, double *target);
+                                    const double *sa, const double *sb, double *target, double *alpha_seen = nullptr);
 void comm_destroy(storm_hip_ctx *c);
 int comm_check_error(storm_hip_ctx *c);  // a bounded wait of the peer-window transport gave up
 struct IpcDev;                            // ipc_device.hpp

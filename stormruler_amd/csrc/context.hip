@@ -192,6 +192,10 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
     }
   }
   else if (!strcmp(key, "spmv_spw")) c->opt_spmv_spw = value;
+  else if (!strcmp(key, "spmv_xcd_remap")) {
+    STORM_REQUIRE(value >= 0 && value <= 4096, "ctx_set_option: spmv_xcd_remap %lld (0 .. 4096)", (long long)value);
+    c->opt_spmv_xcd_remap = c->opt_spmv_xcd_remap_sell = value;  // (A/B knob: every kernel's run length at once)
+  }
   else if (!strcmp(key, "test_disable")) {
     // TEST HOOK, not an option: every bit switches one refinement of a kernel off, so that a test can run the refined and
     // the plain form side by side and demand the same bits (the plain forms exist for that purpose only).

@@ -33,6 +33,7 @@ enum Slot {
   S_RHO, S_RTV, S_TR, S_TT, S_OMEGA, S_RR, S_RHO_NEW,  // (TR,TT) and (RR,RHO_NEW) stay adjacent: one all-reduce each
   S_TMP, S_HN,
   S_SCRATCH = 32,
+  S_ALPHA_SEEN = 48,  // (+ 1: armed) option ticket_verify, RCCL BiCGStab: the alpha the early halo of s was formed with
 };
 
 enum StepKind {
@@ -411,7 +412,15 @@ __global__ __launch_bounds__(kBlock) void bicg_update_kernel(int64_t n, SolverSt
   if (tickets.cnt != nullptr) {
     if (!SECOND) {
       alpha = safe_divide(st->s[S_RHO], st->s[S_RTV]);
-      if (blockIdx.x == 0 && threadIdx.x == 0) st->s[S_ALPHA] = alpha;
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->s[S_ALPHA] = alpha;
+        // Option ticket_verify over RCCL: the halo of s left BEFORE this kernel, its rows formed by halo_pack_bicg_kernel
+        // with an alpha of its own division -- the bits of what the neighbours received depend on it being THIS alpha.
+        if (st->s[S_ALPHA_SEEN + 1] != 0.0) {
+          if (__double_as_longlong(st->s[S_ALPHA_SEEN]) != __double_as_longlong(alpha)) st->verify_failed = 1;
+          st->s[S_ALPHA_SEEN + 1] = 0.0;
+        }
+      }
     } else {
       omega = safe_divide(st->s[S_TR], st->s[S_TT]);
       if (blockIdx.x == 0 && threadIdx.x == 0) st->s[S_OMEGA] = omega;
@@ -1506,7 +1515,8 @@ int solve_bicgstab_body(const FusedSolveArgs &args) {
       //  (alpha not formed yet: the kernel that forms the rows to send divides rho by <rt, v> itself)
       if (early_halo)
         STORM_TRY(comm_halo_exchange_begin_formed(op, 0, r, nullptr, v, alpha_in_kernel ? d.slot(S_RHO) : d.slot(S_ALPHA),
-                                                  alpha_in_kernel ? d.slot(S_RTV) : nullptr, r));
+                                                  alpha_in_kernel ? d.slot(S_RTV) : nullptr, r,
+                                                  (alpha_in_kernel && c->opt_ticket_verify > 0) ? d.slot(S_ALPHA_SEEN) : nullptr));
       // r -= alpha v   (x += alpha p is applied in the second half-step)      :140-141
       hipLaunchKernelGGL(bicg_update_kernel<false>, dim3(nbv), dim3(kBlock), 0, c->stream, n, d.st, x->d, r, p, v,
                          rt, c->d_partials, stream_nt(c, n), flip(), alpha_in_kernel ? tickets : no_tickets);

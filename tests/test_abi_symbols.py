@@ -41,7 +41,7 @@ def test_binding_table_matches_header(built):
     from stormruler_amd import _lib
 
     assert sorted(_lib.SIGNATURES) == _declared()
-    assert _lib.lib.storm_hip_abi_version() == 5
+    assert _lib.lib.storm_hip_abi_version() == 6
 
 
 def test_library_carries_gfx950_code_only(built):

@@ -259,3 +259,32 @@ def test_bench_two_ranks_on_the_production_kernels_measures_both_transports():
     line = out["_line"]
     assert set(line["transports_measured"]) == {"host", "ipc"} and line["transport"] == "ipc" and line["postflight_ok"]
     assert line["transports_measured"]["ipc"]["value"] == pytest.approx(tm["ipc"]["value"], rel=1e-5)
+
+def test_bench_contact_mode_over_rccl_at_one_rank_and_on_two_ranks(tmp_path):
+    """`--contact`: what a short lease on N devices runs -- edge 64, pre-flight, one CG and one
+    BiCGStab over the transport with the device-timestamp breakdown, the compact line.  Here (one device): over RCCL on a
+    size-1 communicator (`--force-comm`: RCCL's own view must say 1 rank on this device), and on two ranks sharing the
+    device over the peer windows.  Both within the budget of a short lease."""
+    import time
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env = dict(env, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    detail = os.path.join(str(tmp_path), "contact.json")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--contact", "--force-comm", "--steps", "10", "--detail-path", detail],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    wall = time.time() - t0
+    assert p.returncode == 0, p.stdout[-2000:] + "\n" + p.stderr[-3000:]
+    line = _the_one_compact_line(p.stdout)
+    assert line["n_gpus"] == 1 and line["steps"] == 10 and line["config"]["cells_per_gpu"] == 64 ** 3
+    assert line["rccl"]["nccl_comm_count"] == 1 and line["rccl"]["distinct_devices"] == 1 and line["rccl"]["ranks"][0][:3] == [0, 0, 0]
+    assert line["transport"] == "rccl" and line["comm_breakdown"]["transport"] == "rccl" and line["comm_breakdown"]["allreduces_per_iteration"] > 1.9
+    cb = line["contact_bicgstab"]
+    assert "error" not in cb and cb["iterations"] == 10 and cb["us_per_iteration"] > 0
+    assert cb["comm_breakdown"]["allreduces_per_iteration"] >= 2.9 and cb["comm_breakdown"]["allreduce_us_each"] > 0
+    assert wall < 90, wall  # (python + torch start-up included: the GPU work is a fraction of a second)
+    # two ranks (sharing the device: peer windows), through the supervisors
+    out, _ = _run_bench(["--gpus", "2", "--contact", "--steps", "10"], timeout=300)
+    line = out["_line"]
+    assert line["n_gpus"] == 2 and line["transport"] == "ipc" and line["preflight_ok"] and line["postflight_ok"]
+    assert line["contact_bicgstab"]["iterations"] == 10 and len(line["rccl"]["ranks"]) == 2
