@@ -553,6 +553,7 @@ struct MgsArgs {
   char *quad_slots;  // mgs_chain_quad_kernel: all-reduce slots of kQuadSlotStride bytes (two-level form) / dense granules
   int dense;         // ... the flat all-reduce with dense value-major slots instead of the two-level one
   int prefetch;      // ... with the next group's vectors requested between its halves (S <= 4)
+  int xcd_runs;      // ... and the blocks' chunks of rows dealt out in ONE contiguous run per XCD (see the kernel)
   // mgs_chain_quad_kernel<S, T, true>: w is not read but FORMED -- w = beta x + alpha M(x), x = ap_x (the newest basis
   // vector), from the operator's format-4 records with spmv_canon_kernel's arithmetic (the same bits): the apply's
   // launch and the round trip of w through memory disappear (SolverGmres.hpp:155 inside the kernel that consumes it)
@@ -911,7 +912,12 @@ __global__ __launch_bounds__(kQuadThreads) void mgs_chain_quad_kernel(MgsArgs a)
   unsigned long long seq = a.seq_base;
   int *gave_up = reinterpret_cast<int *>(a.slots + (size_t)2 * 256 * kLatSlotStride);  // (the latency path's flag)
   char *slots = a.quad_slots;
-  const int64_t chunk0 = (int64_t)blockIdx.x * S * kQuadSub;
+  // Which chunk of rows a block owns.  Blocks are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8); with the
+  // apply in the kernel a chunk's +-b neighbours (the planes below and above: two chunks away at 128^3) are gathered from
+  // rows that OTHER blocks load as their own -- given to blocks of the same XCD (one contiguous run of chunks per XCD)
+  // those gathers meet the owner's load in that XCD's L2 instead of fetching the line a second and third time.  The
+  // all-reduce slots stay indexed by blockIdx.x: the same sums in another, equally fixed order.
+  const int64_t chunk0 = (int64_t)(a.xcd_runs ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x) * S * kQuadSub;
   unsigned off8[S];  // byte offset of the thread's pair j (rows < 2^22)
   bool va[S], vb[S];
   double2m w[S];
@@ -1277,6 +1283,7 @@ int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w
   a.quad_slots = c->d_quad_slots;
   a.dense = (int)(c->opt_coop_dense != 0);
   a.prefetch = (int)(c->opt_coop_mgs_prefetch != 0);
+  a.xcd_runs = (int)(c->opt_coop_mgs_xcd_runs != 0);
   a.ap_pack = nullptr, a.ap_dict = nullptr, a.ap_x = nullptr, a.ap_max_gather = 0, a.ap_alpha = 0.0, a.ap_beta = 0.0;
   for (int i = 0; i < 6; ++i) a.ap_off[i] = 0;
   if (with_apply) {
