@@ -472,6 +472,7 @@ typedef struct storm_hip_op_stats {
   int64_t paired_rows;                  /* 1: two consecutive rows per lane share their 16-byte gathers; n_slices then counts 128-row groups; 2: the same with one common offset order (format 4); 3: format 5 (one byte per row) */
   int64_t tiled_planes;                 /* > 0: an unsplit apply runs the tiled format-4 kernel (lattice offsets -b,-a,-1,+1,+a,+b): tiles of 1024 rows x this many planes */
   int64_t spmv_blocks;                  /* workgroups of an unsplit apply */
+  int64_t xcd_run_blocks;               /* (ABI 6) fp64-record kernel: runs of this many workgroups (256 rows each) go to one XCD */
 } storm_hip_op_stats;
 int storm_hip_op_get_stats(const storm_hip_op *op, storm_hip_op_stats *stats);
 int storm_hip_op_destroy(storm_hip_op *op);

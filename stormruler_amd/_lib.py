@@ -47,7 +47,7 @@ class OpStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("n_rows", "n_cols", "nnz_offdiag", "ell_slots", "tail_nnz",
                                           "tail_rows", "n_slices", "max_row_len", "n_interior_slices",
                                           "device_bytes", "record_bytes", "value_dictionary_size",
-                                          "offset_dictionary_size", "paired_rows", "tiled_planes", "spmv_blocks")]
+                                          "offset_dictionary_size", "paired_rows", "tiled_planes", "spmv_blocks", "xcd_run_blocks")]
 
 
 class MeshView(C.Structure):

@@ -160,7 +160,11 @@ struct storm_hip_ctx {
   // profiles/r10f_tet_traffic_ab.jsonl, r10g_xcd_group_sweep.jsonl: a row of x that two XCDs gather is fetched into two L2s;
   // on the 12.6 M tetrahedra (Z-order numbering) runs of 8 blocks move 1.19 x the algorithmic bytes (0.779 of the peak),
   // of 32: 1.12 x, of 128: 1.075 x, ONE run per XCD 1.02 x but slower (eight distant streams); 64 is the fastest on both the
-  // tetrahedra (0.813) and the 256^3 box (0.801 against 0.778).
+  // tetrahedra (0.811) and the 256^3 box in natural order (0.796 against 0.774; 16 and 32: 0.784; twice each,
+  // r10i_sell_xcd_group_sweep_fine.jsonl).  On the box runs of 64 put every +-plane neighbour (256 blocks away) on ANOTHER XCD
+  // -- the counter reads 1.09 x the algorithmic bytes where runs of 8 / 16 / 32 read 1.025 x (256 = 0 mod 8 G: the same XCD) --
+  // and are still the fastest: those bytes are hits in the Infinity Cache, what costs time is how far apart in DRAM the eight
+  // XCDs' streams run.  A chooser that counted cross-XCD columns per operator was written and removed: it picks 8 - 32 there.
   int64_t opt_spmv_xcd_remap_sell = 64;
   int64_t opt_nt = 1;
   static constexpr int64_t opt_sweep_alternate = 1;   // fused CG: consecutive kernels sweep the rows in opposite directions (2: and without non-temporal hints)
@@ -312,6 +316,7 @@ struct storm_hip_op {
   int dict_size = 0;               // > 0: records are [idx 64 u64][col W*64 i32]
   int *d_offs = nullptr;           // format 2: the 256-entry column-offset table
   int offs_size = 0;               // > 0: records are 64 x 16-byte words (values + offsets as byte indices)
+  int xcd_group_sell = 0;          // spmv_sell_kernel: runs of this many blocks per XCD (option spmv_xcd_remap at build time)
   int pair = 0;                    // 1: format 3 -- 128-row groups of paired rows, n_slices counts those groups; 2: format 4 (common offset order)
   char *d_bnd_pack = nullptr;      // mixed operator: format-3 records of the boundary groups, in d_boundary order
   int bnd_width = 0;               // ... and their merged width

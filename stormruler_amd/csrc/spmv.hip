@@ -384,6 +384,7 @@ int storm_hip_op_get_stats(const storm_hip_op *op, storm_hip_op_stats *s) {
   int nbt = 0;
   s->tiled_planes = canon_tile_geometry(op, &T, &nbt, op->d_bnd_pack != nullptr) ? canon_tile_planes(op) : 0;  // (mixed operator: its interior planes)
   s->spmv_blocks = spmv_grid_blocks(op);
+  s->xcd_run_blocks = op->xcd_group_sell;
   return STORM_HIP_OK;
 }
 

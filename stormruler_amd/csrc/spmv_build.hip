@@ -172,6 +172,7 @@ static int build_op(storm_hip_ctx *c, int64_t n, int64_t n_halo, const std::vect
     for (int64_t m : ml) max_len = std::max(max_len, m);
   }
   op->max_row_len = max_len;
+  op->xcd_group_sell = (int)c->opt_spmv_xcd_remap_sell;
   {
     const int st_lat = op_make_latency_copy(op, n, n_halo, row_ptr, col, val, ext);
     if (st_lat != STORM_HIP_OK) {

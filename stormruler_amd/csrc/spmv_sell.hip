@@ -229,17 +229,17 @@ template <bool NT, bool DOT, int VARIANT>
 static void launch_sell(const storm_hip_op *op, int nb, Scal alpha, Scal beta, const double *x, double *y,
                         const int *slice_list, int64_t n_launch, DotArgs dot, const int *done, hipEvent_t ev0,
                         hipEvent_t ev1, bool accumulate) {
-  SellArgs A{op->d_pack, op->d_slice_off, op->n_rows, op->uniform_width, (int)op->ctx->opt_spmv_xcd_remap_sell, op->d_dict, op->dict_size,
+  SellArgs A{op->d_pack, op->d_slice_off, op->n_rows, op->uniform_width, op->xcd_group_sell, op->d_dict, op->dict_size,
              op->d_offs, op->offs_size, (int)accumulate};
   constexpr int LV = VARIANT;
   hipStream_t st = op->ctx->stream;
-  if (slice_list == nullptr && op->ctx->opt_spmv_xcd_remap_sell != 0) {
+  if (slice_list == nullptr && op->xcd_group_sell != 0) {
     hipExtLaunchKernelGGL((spmv_sell_kernel<NT, DOT, VARIANT, true>), dim3(nb), dim3(kBlock), 0, st, ev0, ev1, 0, A, alpha,
                        beta, x, y, slice_list, n_launch, dot, done);
   } else if (slice_list == nullptr) {
     hipExtLaunchKernelGGL((spmv_sell_kernel<NT, DOT, VARIANT, false>), dim3(nb), dim3(kBlock), 0, st, ev0, ev1, 0, A, alpha,
                        beta, x, y, slice_list, n_launch, dot, done);
-  } else if (op->ctx->opt_spmv_xcd_remap_sell != 0) {
+  } else if (op->xcd_group_sell != 0) {
     // listed slices (interior / boundary sets of a partitioned operator): the LDS window does not
     // apply, the XCD grouping still does -- the interior list is consecutive but for a few gaps
     hipExtLaunchKernelGGL((spmv_sell_kernel<NT, DOT, LV, true>), dim3(nb), dim3(kBlock), 0, st, ev0, ev1, 0, A, alpha, beta,

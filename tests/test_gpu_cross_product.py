@@ -1,0 +1,107 @@
+"""The cross-product the single-feature tests do not pin: every record format (option spmv_dict 0 .. 4) x every solver
+path the dispatch can take (resident -> latency -> fused kernel-per-statement loops -> the general engine) x the three
+solvers of the path (CG, BiCGStab, GMRES(10)), each a converged solve of a small box against the oracle -- 60 solves; and
+the knobs that change what a launch looks like (XCD run lengths, non-temporal streams, ticket reductions, cooperative
+kernels off) on top of the default format and path.  Small sizes on purpose: what is checked here is that no COMBINATION
+is wrong, not how fast any of them is (tests/test_gpu_dispatch.py pins which combination each BASELINE config gets)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PATHS = {
+    "default": {},
+    "no_resident": {"resident_path": 0},
+    "no_resident_no_latency": {"resident_path": 0, "latency_path": 0},
+    "engine": {"generic_solvers": 1},
+}
+SOLVERS = ("cg", "bicgstab", "gmres")
+
+
+@pytest.fixture(scope="module")
+def problem():
+    from oracle import oracle
+    from stormruler_amd import mesh
+
+    g = mesh.structured_box(20, 18, 16)  # (not a cube: the lattice offsets differ per axis)
+    b = np.sin(3 * g.center[:, 0]) * np.cos(7 * g.center[:, 1]) * np.cos(2 * g.center[:, 2])
+    ref_op = oracle.StencilOperator(g, -1.0, 0.0)
+    refs = {k: oracle.solve(k, ref_op, b, num_inner_iterations=10) for k in SOLVERS}
+    assert all(r.converged for r in refs.values())
+    return g, b, refs
+
+
+def _solve(api, ctx, kind, mat, b_host):
+    cls = {"cg": api.CgSolver, "bicgstab": api.BiCgStabSolver, "gmres": api.GmresSolver}[kind]
+    s = cls()
+    if kind == "gmres":
+        s.num_inner_iterations = 10
+    b, x = api.DeviceVector.from_numpy(ctx, b_host), api.DeviceVector(ctx, b_host.size)
+    ok = s.solve(x, b, api.HipStencilOperator(mat, -1.0, 0.0))
+    return ok, s, x.to_numpy()
+
+
+def _check(kind, ok, s, x, ref, what):
+    assert ok, what
+    assert abs(s.iteration - ref.iterations) <= max(2, int(0.05 * ref.iterations)), (what, s.iteration, ref.iterations)
+    err = np.linalg.norm(x - ref.x) / np.linalg.norm(ref.x)
+    assert err <= 5e-6, (what, err)  # (two solves that each stop at rel 1e-6: tests/test_gpu_fixed_k.py holds the loops tight)
+
+
+@pytest.mark.parametrize("path", list(PATHS))
+@pytest.mark.parametrize("dict_level", [0, 1, 2, 3, 4])
+def test_every_record_format_on_every_solver_path(problem, dict_level, path):
+    from stormruler_amd import api
+
+    g, b, refs = problem
+    ctx = api.Context(0)
+    try:
+        ctx.set_option("spmv_dict", dict_level)
+        for k, v in PATHS[path].items():
+            ctx.set_option(k, v)
+        mat = api.StencilMatrix.from_face_graph(ctx, g)
+        st = mat.stats()
+        # the format the level asks for is the format the operator got (a uniform box qualifies for every one of them)
+        assert (st["value_dictionary_size"] > 0) == (dict_level >= 1) and (st["paired_rows"] > 0) == (dict_level >= 3)
+        assert (st["paired_rows"] == 2) == (dict_level == 4)
+        # the apply itself, then the three solvers
+        xh = np.sin(0.37 * np.arange(g.n_cells))
+        y = api.DeviceVector(ctx, g.n_cells)
+        mat.apply(-1.0, 0.0, api.DeviceVector.from_numpy(ctx, xh), y)
+        from oracle import oracle
+
+        y_ref = oracle.StencilOperator(g, -1.0, 0.0).apply(xh)
+        assert np.abs(y.to_numpy() - y_ref).max() <= 1e-13 * np.abs(y_ref).max(), (dict_level, path)
+        for kind in SOLVERS:
+            ok, s, x = _solve(api, ctx, kind, mat, b)
+            _check(kind, ok, s, x, refs[kind], (dict_level, path, kind))
+        mat.close()
+    finally:
+        ctx.close()
+
+
+KNOBS = [
+    {"spmv_xcd_remap": 0}, {"spmv_xcd_remap": 1}, {"spmv_xcd_remap": 64}, {"nontemporal": 0}, {"ticket_reduce": 0},
+    {"fused_reduce": 0}, {"coop_mgs": 0}, {"coop_mgs_quad": 0}, {"test_disable": 32}, {"test_disable": 128},
+    {"vec_arena": 0}, {"lin_fuse": 0}, {"ticket_verify": 1}, {"latency_cache": 0}, {"resident_early": 0},
+]
+
+
+@pytest.mark.parametrize("knobs", KNOBS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
+@pytest.mark.parametrize("dict_level", [0, 4])
+def test_launch_shaping_knobs_do_not_change_results(problem, dict_level, knobs):
+    from stormruler_amd import api
+
+    g, b, refs = problem
+    ctx = api.Context(0)
+    try:
+        ctx.set_option("spmv_dict", dict_level)
+        for k, v in knobs.items():
+            ctx.set_option(k, v)
+        mat = api.StencilMatrix.from_face_graph(ctx, g)
+        for kind in SOLVERS:
+            ok, s, x = _solve(api, ctx, kind, mat, b)
+            _check(kind, ok, s, x, refs[kind], (dict_level, knobs, kind))
+        mat.close()
+    finally:
+        ctx.close()
