@@ -43,7 +43,12 @@ def _solve(api, ctx, kind, mat, b_host):
 
 def _check(kind, ok, s, x, ref, what):
     assert ok, what
-    assert abs(s.iteration - ref.iterations) <= max(2, int(0.05 * ref.iterations)), (what, s.iteration, ref.iterations)
+    # (BiCGStab's count is a draw among roundings, DESIGN.md section 2: on this problem the oracle's relative residual sits at
+    #  5e-6 ... 8e-6 over iterations 40 - 43 before it drops below 1e-6 at 44 -- not monotone --, and a last-place difference
+    #  in a sum decides which dip crosses the tolerance: the ORACLE with pairwise sums stops at 41, with long-double sums at 45,
+    #  left to right at 44 (`make -C oracle variants`); every device path stops at 41)
+    band = max(4, int(0.1 * ref.iterations)) if kind == "bicgstab" else max(2, int(0.05 * ref.iterations))
+    assert abs(s.iteration - ref.iterations) <= band, (what, s.iteration, ref.iterations)
     err = np.linalg.norm(x - ref.x) / np.linalg.norm(ref.x)
     assert err <= 5e-6, (what, err)  # (two solves that each stop at rel 1e-6: tests/test_gpu_fixed_k.py holds the loops tight)
 
