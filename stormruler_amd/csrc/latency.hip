@@ -554,6 +554,7 @@ struct MgsArgs {
   int dense;         // ... the flat all-reduce with dense value-major slots instead of the two-level one
   int prefetch;      // ... with the next group's vectors requested between its halves (S <= 4)
   int xcd_runs;      // ... and the blocks' chunks of rows dealt out in ONE contiguous run per XCD (see the kernel)
+  int descend;       // ... the basis vectors taken in the order k, k - 1, ..., 0 (odd k: see the kernel)
   // mgs_chain_quad_kernel<S, T, true>: w is not read but FORMED -- w = beta x + alpha M(x), x = ap_x (the newest basis
   // vector), from the operator's format-4 records with spmv_canon_kernel's arithmetic (the same bits): the apply's
   // launch and the round trip of w through memory disappear (SolverGmres.hpp:155 inside the kernel that consumes it)
@@ -1007,6 +1008,14 @@ __global__ __launch_bounds__(kQuadThreads) void mgs_chain_quad_kernel(MgsArgs a)
   bool prefetched = false;
   const unsigned pf_base = LDSPF ? (unsigned)(size_t)(__attribute__((address_space(3))) void *)pf_ring : 0u;
   const int pf_wave = tid >> 6;
+  // The ORDER in which w is orthogonalised against q_0 .. q_k alternates with k (round 6): ascending for even k, descending
+  // for odd k.  A cycle's basis outgrows the 256 MB Infinity Cache from k = 15 on at 128^3 (16.8 MB per vector); read in the
+  // same order every time, each vector has been evicted by the time it comes round again -- every read an HBM read.  Read
+  // back and forth, an iteration starts with the vectors the previous one ended with: ~14 of them are still there.  The
+  // reference's loop runs i = 0 .. k (SolverGmres.hpp:157-160); against an orthonormal basis the h_i of modified Gram-Schmidt
+  // do not depend on the order but for their roundings (the fixed-K tests hold either order to 1e-10 / 1e-9), and the order
+  // is a function of k alone: every run, every variant of this kernel takes the same one.
+  const auto vidx = [&](int p) { return a.descend ? a.k - p : p; };  // position in the chain -> basis vector
   for (int i = 0; i <= a.k; i += T) {
     lap(0);  // the update of w
     double2m q[T][S];
@@ -1033,7 +1042,7 @@ __global__ __launch_bounds__(kQuadThreads) void mgs_chain_quad_kernel(MgsArgs a)
 #pragma unroll
       for (int v = 0; v < T; ++v) {
         const bool have = i + v <= a.k;  // (uniform; a vector past the end reads as zeros: its h comes out 0)
-        const char *src = reinterpret_cast<const char *>(a.q[have ? i + v : i]);
+        const char *src = reinterpret_cast<const char *>(a.q[vidx(have ? i + v : i)]);
 #pragma unroll
         for (int j = 0; j < S; ++j) {
           q[v][j] = double2m{0.0, 0.0};
@@ -1066,7 +1075,7 @@ __global__ __launch_bounds__(kQuadThreads) void mgs_chain_quad_kernel(MgsArgs a)
       if (i + T <= a.k) {
         if constexpr (LDSPF) {
           {  // the group's first vector: registers
-            const char *src = reinterpret_cast<const char *>(a.q[i + T]);
+            const char *src = reinterpret_cast<const char *>(a.q[vidx(i + T)]);
 #pragma unroll
             for (int j = 0; j < S; ++j) {
               qn[0][j] = double2m{0.0, 0.0};
@@ -1077,7 +1086,7 @@ __global__ __launch_bounds__(kQuadThreads) void mgs_chain_quad_kernel(MgsArgs a)
 #pragma unroll
           for (int v = 1; v < T; ++v) {  // the others: LDS-DMA (rows past the end: any valid address, masked when read back)
             if (i + T + v <= a.k) {
-              const char *src = reinterpret_cast<const char *>(a.q[i + T + v]);
+              const char *src = reinterpret_cast<const char *>(a.q[vidx(i + T + v)]);
 #pragma unroll
               for (int j = 0; j < S; ++j) {
                 const unsigned dst = __builtin_amdgcn_readfirstlane(pf_base + (unsigned)((((v - 1) * S + j) * kQuadSub + pf_wave * 2 * kWave) * 8));
@@ -1090,7 +1099,7 @@ __global__ __launch_bounds__(kQuadThreads) void mgs_chain_quad_kernel(MgsArgs a)
 #pragma unroll
           for (int v = 0; v < T; ++v) {
             const bool have = i + T + v <= a.k;
-            const char *src = reinterpret_cast<const char *>(a.q[have ? i + T + v : i + T]);
+            const char *src = reinterpret_cast<const char *>(a.q[vidx(have ? i + T + v : i + T)]);
 #pragma unroll
             for (int j = 0; j < S; ++j) {
               qn[v][j] = double2m{0.0, 0.0};
@@ -1125,8 +1134,8 @@ __global__ __launch_bounds__(kQuadThreads) void mgs_chain_quad_kernel(MgsArgs a)
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       for (int v = 0; v < T && i + v <= a.k; ++v) {
-        if (rotate) hcol[i + v] = h[v];
-        else a.H[(int64_t)(i + v) * a.m + a.k] = h[v];
+        if (rotate) hcol[vidx(i + v)] = h[v];
+        else a.H[(int64_t)vidx(i + v) * a.m + a.k] = h[v];
       }
     }
 #pragma unroll
@@ -1284,6 +1293,7 @@ int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w
   a.dense = (int)(c->opt_coop_dense != 0);
   a.prefetch = (int)(c->opt_coop_mgs_prefetch != 0);
   a.xcd_runs = (int)(c->opt_coop_mgs_xcd_runs != 0);
+  a.descend = (int)(c->opt_coop_mgs_alternate != 0 && (k & 1) != 0);
   a.ap_pack = nullptr, a.ap_dict = nullptr, a.ap_x = nullptr, a.ap_max_gather = 0, a.ap_alpha = 0.0, a.ap_beta = 0.0;
   for (int i = 0; i < 6; ++i) a.ap_off[i] = 0;
   if (with_apply) {
