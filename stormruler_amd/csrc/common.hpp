@@ -181,6 +181,7 @@ struct storm_hip_ctx {
   int64_t opt_resident_halo_interleave = 1;  // resident CG, boxes of more than 2 planes: the second wave of every SIMD forms the halo of p' before the update of its own rows
   int64_t opt_coop_mgs_prefetch = 1; // ... the next group's basis vectors requested under the all-reduce (up to 4 row pairs per thread)
   int64_t opt_coop_mgs_lds_prefetch = 1; // ... eight row pairs per thread (128^3): the next group's vectors through LDS (LDS-DMA)
+  int64_t opt_coop_mgs_rotate_early = 1;  // ... block 0 applies the column's earlier rotations under the norm's all-reduce (test_disable bit 512: off)
   int64_t opt_coop_mgs_alternate = 1;  // ... the chain's vector order alternates with k: ascending / descending (test_disable bit 256: off)
   int64_t opt_coop_mgs_xcd_runs = 1;  // ... the chain's blocks own ONE contiguous run of row chunks per XCD (test_disable bit 128: off)
   int64_t opt_coop_mgs_apply = 1;    // ... with the operator apply in front of it done by the chain kernel itself (format-4 lattice operators)

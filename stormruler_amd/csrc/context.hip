@@ -208,11 +208,13 @@ int storm_hip_ctx_set_option(storm_hip_ctx *c, const char *key, int64_t value) {
     //  64  marching CG step: odd z-chunks march downwards
     // 128  GMRES chain kernel: one contiguous run of row chunks per XCD (off: chunk = block index)
     // 256  GMRES chain kernel: the order of the basis vectors alternates with k (off: ascending, the reference's)
+    // 512  GMRES chain kernel: the column's earlier rotations under the norm's all-reduce (off: after everything else)
     c->opt_test_disable = value;
     c->opt_coop_mgs_apply = !(value & 1), c->opt_coop_mgs_prefetch = c->opt_coop_mgs_lds_prefetch = !(value & 2);
     c->opt_resident_apply_cache = !(value & 4), c->opt_resident_halo_interleave = !(value & 8);
     c->opt_latency_publish = !(value & 16), c->opt_coop_plain = !(value & 32), c->opt_cg_march_alternate = !(value & 64);
     c->opt_coop_mgs_xcd_runs = !(value & 128), c->opt_coop_mgs_alternate = !(value & 256);
+    c->opt_coop_mgs_rotate_early = !(value & 512);
   }
   else if (!strcmp(key, "lazy_statements")) {
     if (value == 0) {

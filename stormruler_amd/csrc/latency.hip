@@ -555,6 +555,7 @@ struct MgsArgs {
   int prefetch;      // ... with the next group's vectors requested between its halves (S <= 4)
   int xcd_runs;      // ... and the blocks' chunks of rows dealt out in ONE contiguous run per XCD (see the kernel)
   int descend;       // ... the basis vectors taken in the order k, k - 1, ..., 0 (odd k: see the kernel)
+  int rotate_early;  // ... the k earlier rotations of the column under the norm's all-reduce (block 0)
   // mgs_chain_quad_kernel<S, T, true>: w is not read but FORMED -- w = beta x + alpha M(x), x = ap_x (the newest basis
   // vector), from the operator's format-4 records with spmv_canon_kernel's arithmetic (the same bits): the apply's
   // launch and the round trip of w through memory disappear (SolverGmres.hpp:155 inside the kernel that consumes it)
@@ -1147,8 +1148,28 @@ __global__ __launch_bounds__(kQuadThreads) void mgs_chain_quad_kernel(MgsArgs a)
   double acc[1] = {0.0};
 #pragma unroll
   for (int j = 0; j < S; ++j) acc[0] += w[j].x * w[j].x, acc[0] += w[j].y * w[j].y;
-  if (a.dense) co_allreduce_dense<1, kQuadWaves>(acc, slots, gave_up, ++seq, lds);
-  else co_allreduce2_n<1, kQuadWaves>(acc, slots, kQuadSlotStride, gave_up, ++seq, lds);
+  bool rotated = false;
+  if (a.dense && a.rotate_early != 0) {
+    // The k earlier rotations of column k (SolverGmres.hpp:176-180) need every h of the chain and not the norm: block 0's
+    // first thread applies them between the block's arrival at the norm's all-reduce and its wait for the others -- ~1.5 us
+    // of a dependent chain through LDS that used to run after everything else, with the whole chip waiting for the kernel
+    // to end.
+    ++seq;
+    co_allreduce_dense_arrive<1, kQuadWaves>(acc, slots, seq, lds);
+    if (rotate && threadIdx.x == 0) {
+      for (int t = 0; t < a.k; ++t) {
+        const double chi = cs_sh[t] * hcol[t] + sn_sh[t] * hcol[t + 1];
+        hcol[t + 1] = -sn_sh[t] * hcol[t] + cs_sh[t] * hcol[t + 1];
+        hcol[t] = chi;
+      }
+      rotated = true;
+    }
+    co_allreduce_dense_wait<1, kQuadWaves>(acc, slots, gave_up, seq, lds);
+  } else if (a.dense) {
+    co_allreduce_dense<1, kQuadWaves>(acc, slots, gave_up, ++seq, lds);
+  } else {
+    co_allreduce2_n<1, kQuadWaves>(acc, slots, kQuadSlotStride, gave_up, ++seq, lds);
+  }
   const double norm2 = acc[0];
   if (blockIdx.x == 0 && threadIdx.x == 0) *a.norm2_out = norm2;
   const double hn = sqrt(norm2);
@@ -1166,10 +1187,12 @@ __global__ __launch_bounds__(kQuadThreads) void mgs_chain_quad_kernel(MgsArgs a)
     const int k = a.k, m = a.m;
     *a.givens.hn_slot = hn;
     hcol[k + 1] = hn;
-    for (int t = 0; t < k; ++t) {
-      const double chi = cs_sh[t] * hcol[t] + sn_sh[t] * hcol[t + 1];
-      hcol[t + 1] = -sn_sh[t] * hcol[t] + cs_sh[t] * hcol[t + 1];
-      hcol[t] = chi;
+    if (!rotated) {
+      for (int t = 0; t < k; ++t) {
+        const double chi = cs_sh[t] * hcol[t] + sn_sh[t] * hcol[t + 1];
+        hcol[t + 1] = -sn_sh[t] * hcol[t] + cs_sh[t] * hcol[t + 1];
+        hcol[t] = chi;
+      }
     }
     const double ha = hcol[k], hb = hcol[k + 1];
     const double rr = hypot(ha, hb);
@@ -1294,6 +1317,7 @@ int gmres_mgs_chain_coop(storm_hip_ctx *c, int64_t n, const int *done, double *w
   a.prefetch = (int)(c->opt_coop_mgs_prefetch != 0);
   a.xcd_runs = (int)(c->opt_coop_mgs_xcd_runs != 0);
   a.descend = (int)(c->opt_coop_mgs_alternate != 0 && (k & 1) != 0);
+  a.rotate_early = (int)(c->opt_coop_mgs_rotate_early != 0);
   a.ap_pack = nullptr, a.ap_dict = nullptr, a.ap_x = nullptr, a.ap_max_gather = 0, a.ap_alpha = 0.0, a.ap_beta = 0.0;
   for (int i = 0; i < 6; ++i) a.ap_off[i] = 0;
   if (with_apply) {
