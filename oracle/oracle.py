@@ -508,6 +508,24 @@ def cahn_hilliard_step(g_or_mesh, c, **solver_knobs):
     return res.x, res
 
 
+def solve_non_uniform(kind: str, op, b, x0=None, **knobs) -> SolveResult:
+    """``solve_non_uniform(solver, x, b, op)`` (Solvers/Solver.hpp:271-292) for an operator with ``op.apply``: ``z = A(0)``;
+    ``f = b - z``; solve with the operator ``y = A(x); y -= z``."""
+    b = f64(b)
+    z = op.apply(np.zeros_like(b))                               # :279-282
+    f = b - z                                                    # :283
+    uni = CallbackOperator(b.size, lambda x: op.apply(x) - z)    # :285-289
+    return solve(kind, uni, f, x0=x0, **knobs)                   # :291
+
+
+def cahn_hilliard_step_non_uniform(g_or_mesh, c, **solver_knobs):
+    """``cahn_hilliard_step`` (Playground.cpp:133-174) with ``solve_non_uniform`` in place of ``solve``: what the affine
+    lambda calls for.  Returns ``(c_hat, SolveResult)``."""
+    c = f64(c)
+    res = solve_non_uniform("cg", ChOperator(g_or_mesh, dF_dc(c), c), c, x0=c, **solver_knobs)
+    return res.x, res
+
+
 def dF_dc(c):
     """``map(dF_dc, c)``, Playground.cpp:142-148."""
     c = f64(c)

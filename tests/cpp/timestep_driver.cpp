@@ -6,6 +6,10 @@
 //       `c_hat <<= c` (:150), `solve<CgSolver>(c_hat, c, *make_operator<...>(lambda))` (:151-167) with the lambda's two
 //       stormDivGrad calls, a clock_gettime pair around every step (:186-200), `std::swap(c, c_hat)` (:202).  The mesh is
 //       read once (`read_mesh_from_tetgen`, :252), the operator built once and reused by every step and every apply.
+//   timestep_driver ch-nonuniform <mesh prefix> <c0.f64> <steps> <out prefix>
+//       the same loop with the ONE call changed that makes it converge: the playground's lambda is affine in c_in (it adds
+//       -tau L (f - sigma c)), which is what `solve_non_uniform` (Solver.hpp:271-292) is for -- `solve_non_uniform(solver,
+//       c_hat, c, *op)` solves A(x) - A(0) = b - A(0) with the same CgSolver: 50 - 56 iterations per step on `square_nb.1`.
 //   timestep_driver cavity <n> <nu> <steps> <out prefix>
 //       BASELINE config 5's caller on the same interface: lid-driven cavity by Chorin projection (the scheme of
 //       stormruler_amd/cavity.py -- the reference has no incompressible solver at this commit), 18 operator applies and one
@@ -31,6 +35,7 @@ namespace {
 
 double tau = 1.0e-3, Gamma = 1.0e-4, sigma = 2.0;  // Playground.cpp:113
 std::size_t num_iterations_cap = 0;                  // DRIVER_NUM_ITERATIONS: 0 = the solver's default (2 000)
+bool non_uniform = false;                            // mode ch-nonuniform: solve_non_uniform instead of solve
 
 std::vector<real_t> read_f64(const std::string& path, std::size_t n) {
   std::vector<real_t> v(n);
@@ -86,7 +91,10 @@ void cahn_hilliard_step(const StencilMatrix& mesh,  //
     c_hat <<= c_in;
     stormDivGrad(mesh, c_hat, -tau, w_hat);
   });
-  if (num_iterations_cap == 0) {
+  if (non_uniform) {
+    CgSolver<DeviceVector> solver;
+    converged = solve_non_uniform(solver, c_hat, c, *op);  // Solver.hpp:271-292: A(x) - A(0) = b - A(0)
+  } else if (num_iterations_cap == 0) {
     converged = solve<CgSolver>(c_hat, c, *op);  // the playground's call, :151
   } else {
     // The lambda is AFFINE in c_in (it adds -tau L (f - sigma c)), and the playground hands it to plain `solve`, not to
@@ -287,11 +295,15 @@ int main(int argc, char** argv) {
     install_log_sink();
     if (const char* cap = std::getenv("DRIVER_NUM_ITERATIONS")) num_iterations_cap = (std::size_t)std::atol(cap);
     if (argc == 6 && !std::strcmp(argv[1], "ch")) return cahn_hilliard_solve(argv[2], argv[3], std::atoi(argv[4]), argv[5]);
+    if (argc == 6 && !std::strcmp(argv[1], "ch-nonuniform")) {
+      non_uniform = true;
+      return cahn_hilliard_solve(argv[2], argv[3], std::atoi(argv[4]), argv[5]);
+    }
     if (argc == 6 && !std::strcmp(argv[1], "cavity")) return cavity_solve(std::atoi(argv[2]), std::atof(argv[3]), std::atoi(argv[4]), argv[5]);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "error: %s\n", e.what());
     return 1;
   }
-  std::fprintf(stderr, "usage: %s ch <mesh prefix> <c0.f64> <steps> <out prefix> | cavity <n> <nu> <steps> <out prefix>\n", argv[0]);
+  std::fprintf(stderr, "usage: %s ch|ch-nonuniform <mesh prefix> <c0.f64> <steps> <out prefix> | cavity <n> <nu> <steps> <out prefix>\n", argv[0]);
   return 2;
 }

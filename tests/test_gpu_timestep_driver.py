@@ -157,6 +157,35 @@ def test_cahn_hilliard_time_loop_matches_the_oracle_step_by_step(tmp_path):
     assert all(r["iterations"] > 0 for r in rows) and abs(last["total_time"] - sum(r["seconds"] for r in rows)) <= 1e-5
 
 
+def test_cahn_hilliard_time_loop_through_solve_non_uniform_converges_like_the_oracle(tmp_path):
+    """The playground's loop with the one call changed that its affine lambda calls for -- `solve_non_uniform`
+    (Solver.hpp:271-292: z = A(0), f = b - z, the operator y = A(x) - z) -- converges: 50 - 56 CG iterations per step on
+    `square_nb.1`.  Per step: the oracle's iteration count +-1, the residual the solve stopped at to the log line's six
+    digits when the counts agree, the field to 1e-8 (two solves that each stop at rel 1e-6 of a residual of ~1e-2)."""
+    from oracle import oracle
+    from stormruler_amd import io_tetgen, mesh
+
+    prefix = os.path.join(ROOT, "tests", "golden", "mesh", "square_nb.1.")
+    g = io_tetgen.read_triangle(prefix)
+    g = mesh.FaceGraph(g.n_cells, 2, g.inner, g.outer, g.area, g.center, g.volume, b_center=np.zeros((0, 2)))
+    steps = 6
+    c = np.random.default_rng(2024).random(g.n_cells)
+    c0_path = tmp_path / "c0.f64"
+    c.tofile(c0_path)
+    rows, last = _run_driver(["ch-nonuniform", prefix, str(c0_path), str(steps), str(tmp_path / "chn")])
+    assert len(rows) == steps and last["operator_builds"] == 1
+    m = oracle.Mesh(g)
+    for k, row in enumerate(rows, 1):
+        c, res = oracle.cahn_hilliard_step_non_uniform(m, c)
+        assert res.converged and row["converged"] and 20 <= res.iterations <= 200, (k, res.iterations)
+        assert abs(row["iterations"] - res.iterations) <= 1, (k, row["iterations"], res.iterations)
+        if row["iterations"] == res.iterations:
+            assert abs(row["absolute_error"] - res.absolute_error) <= 1e-4 * res.absolute_error, (k, row["absolute_error"], res.absolute_error)
+        dev = np.fromfile(tmp_path / f"chn.step{k}.c.f64")
+        assert np.abs(dev - c).max() <= 1e-8 * np.abs(c).max(), (k, np.abs(dev - c).max())
+        c = dev  # (the next step starts from the DEVICE's field on both sides: the comparison is per step, not accumulated)
+
+
 def test_cavity_time_loop_matches_the_cpu_restatement_step_by_step(tmp_path):
     """BASELINE config 5's caller in C++: the projection step of stormruler_amd/cavity.py typed against Storm.hpp, eight
     operators built once, a warm-started pressure-Poisson CG per step -- against tests/test_cavity_driver.CpuCavity."""
