@@ -234,6 +234,9 @@ def test_bicgstab_over_rccl_sends_the_halo_of_s_and_p_before_the_update_kernels(
         ctx.set_option("spmv_canon_tile_min_rows", 0)
         ctx.set_option("rccl_early_halo", early)
         ctx.set_option("rccl_fused", 0)
+        # every iteration's ticketed sums are recomputed and compared on the device, AND (BiCGStab) the alpha the early halo
+        # of s was formed with must be, to the bit, the update kernel's: a mismatch fails the solve
+        ctx.set_option("ticket_verify", 1)
         ctx.comm_init(api.Context.comm_unique_id(), 1, 0)
         mat = api.StencilMatrix.from_face_graph(ctx, loc)
         mat.set_halo([0], [0, loc.n_halo], send_idx, [0, loc.n_halo])
