@@ -329,14 +329,19 @@ STORM_HIP_CV1(STORM_HIP_MAP1)
     return {func(expr::Sym::input(0), expr::Sym::input(1)), {&x0, &x1, nullptr}};       \
   }
 STORM_HIP_CV2(STORM_HIP_MAP2)
-#undef STORM_HIP_MAP1
-#undef STORM_HIP_MAP2
 /// Three operands (one of which must be the target of the `<<=` that consumes the node: the device kernel streams the
 /// target and two more vectors).
-template<class Func>
-inline expr::Mapped map(Func func, const DeviceVector& x0, const DeviceVector& x1, const DeviceVector& x2) {
-  return {func(expr::Sym::input(0), expr::Sym::input(1), expr::Sym::input(2)), {&x0, &x1, &x2}};
-}
+#define STORM_HIP_MAP3(X, Y, Z)                                                                                \
+  template<class Func>                                                                                         \
+  inline expr::Mapped map(Func func, X x0, Y x1, Z x2) {                                                       \
+    return {func(expr::Sym::input(0), expr::Sym::input(1), expr::Sym::input(2)), {&x0, &x1, &x2}};             \
+  }
+#define STORM_HIP_MAP3_Z(X, Y) STORM_HIP_MAP3(X, Y, const DeviceVector&) STORM_HIP_MAP3(X, Y, DeviceVector&)
+STORM_HIP_CV2(STORM_HIP_MAP3_Z)
+#undef STORM_HIP_MAP1
+#undef STORM_HIP_MAP2
+#undef STORM_HIP_MAP3
+#undef STORM_HIP_MAP3_Z
 inline DeviceVector& operator<<=(DeviceVector& out, const expr::Mapped& e) {
   // the program's slots -> the kernel's operands: the target itself is `y`, the others x0, x1 in their order
   int opcode_of[3] = {-1, -1, -1};

@@ -50,6 +50,8 @@ template<probe::matrix_like A>
 probe::Generic norm_2(A&&);
 template<probe::matrix_like A>
 probe::Generic fill_randomly(A&&);
+template<class Func, probe::matrix_like... Ms>  // Bittern/MatrixMath.hpp:100-105
+probe::Generic map(Func, Ms&&...);
 }  // namespace Storm
 
 using Storm::DeviceVector;
@@ -108,5 +110,15 @@ SAME(norm_2(V), real_t);
 SAME(norm_2(CV), real_t);
 SAME(fill_randomly(V), void);
 SAME(fill_with(V, 0.0), void);
+// f <<= map(dF_dc, c)                               Playground.cpp:142-148 (Bittern/MatrixMath.hpp:100-105): the traced map
+constexpr auto dF_dc = [](auto c) noexcept { return 2.0 * c * (c - 1.0) * (2.0 * c - 1.0); };
+SAME(map(dF_dc, V), expr::Mapped);
+SAME(map(dF_dc, CV), expr::Mapped);
+SAME(map([](auto x, auto y) { return x * y + 1.0; }, V, CV), expr::Mapped);
+SAME(map([](auto x, auto y) { return x * y + 1.0; }, CV, V), expr::Mapped);
+SAME(map([](auto y, auto x, auto z) { return y + x * z; }, V, V, CV), expr::Mapped);  // (three operands: one is the target)
+SAME(map([](auto y, auto x, auto z) { return y + x * z; }, V, CV, V), expr::Mapped);
+SAME(V <<= map(dF_dc, CV), DeviceVector);
+SAME(dF_dc(expr::Sym::input(0)), expr::Sym);
 
 int main() { return 0; }
