@@ -89,6 +89,9 @@ def build_native(variant: str) -> str:
     subprocess.check_call([cc, *_NATIVE_FLAGS[variant], "-fPIC", "-fvisibility=hidden", "-std=c11", "-shared", "-o", out,
                            os.path.join(_HERE, "storm_oracle.c"), "-lm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     _LIB_PATHS[variant] = out
+    import atexit
+
+    atexit.register(lambda path=out: os.path.exists(path) and os.remove(path))  # (scratch of this process only)
     return out
 
 
