@@ -1057,7 +1057,20 @@ def emit(full: dict, detail_path) -> None:
         print("bench_detail " + json.dumps(full), file=sys.stderr, flush=True)
     except Exception:
         pass
-    print(compact_line(full), flush=True)
+    try:
+        line = compact_line(full)
+    except Exception as e:  # (never lose the run to its own summary: the contract's fields alone)
+        print(f"bench.py: compact_line failed ({e!r}); printing the contract's fields only", file=sys.stderr, flush=True)
+        r = full.get("roofline") or {}
+        c = full.get("cpu_baseline") or {}
+        line = json.dumps(_num({
+            **{k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                       "scaling", "vs_baseline", "dtype", "data")},
+            "config": {"workload": _short((full.get("config") or {}).get("workload"), 200)},
+            "roofline": {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")},
+            "cpu_baseline": {k: c.get(k) for k in ("value", "unit", "cores", "kind")} if isinstance(c, dict) else None,
+            "detail": full.get("detail_file")}), separators=(",", ":"))[:LINE_CAP]
+    print(line, flush=True)
 
 
 RCCL_PLAIN_OPTIONS = ("rccl_flag_wait", "rccl_ticket", "rccl_early_halo", "rccl_fused")
