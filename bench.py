@@ -1644,6 +1644,10 @@ def supervise(args, chain) -> int:
         env = dict(os.environ, STORM_BENCH_WORKER="1", STORM_BENCH_TRANSPORT=transport, MASTER_PORT=str(int(port[0])),
                    STORM_BENCH_PREFLIGHT_SECONDS=str(int(min(120, budget))))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # RCCL's own words when something goes wrong (bootstrap, peer access, a refused split): warnings only, to stderr
+        # (the child's stdout is the record the supervisor parses)
+        env.setdefault("NCCL_DEBUG", "WARN")
+        env.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
         for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE"):  # the child makes its own rendezvous on `port`
             env.pop(k, None)
         out_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"storm_bench_{os.getpid()}_{attempt}.out")
