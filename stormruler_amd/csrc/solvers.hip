@@ -785,9 +785,15 @@ __global__ __launch_bounds__(kWave) void gmres_backsolve_kernel(SolverState *st,
   if (!force && st->done) return;
   __shared__ double Hs[kMaxMulti * kMaxMulti], bs[kMaxMulti];
   const int m = g.m, n = k + 1, lane = threadIdx.x;
-  for (int idx = lane; idx < n * n; idx += kWave) {
-    const int r = idx / n, cidx = idx - r * n;
-    Hs[r * kMaxMulti + cidx] = g.H[r * m + cidx];
+  // (every load of the lane issued before the first is stored: one after the other they cost a trip to memory each --
+  //  fifteen of the kernel's 21 us at k = 29; the upper triangle is all the substitution reads)
+  for (int r0 = 0; r0 < n; r0 += 8) {
+    double hv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) hv[u] = (r0 + u < n && lane < n && lane >= r0 + u) ? g.H[(r0 + u) * m + lane] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (r0 + u < n && lane < n) Hs[(r0 + u) * kMaxMulti + lane] = hv[u];
   }
   if (lane < n) bs[lane] = g.beta[lane];
   __syncthreads();
