@@ -1934,6 +1934,9 @@ def blas1_rates(api, ctx, N, reps=20):
     out["xpay (a <<= b + s a)"] = t(lambda: a.__ilshift__(b + 0.5 * a), 24)
     out["sub (a <<= b - c)"] = t(lambda: a.__ilshift__(b - c), 24)
     out["bicgstab p (a <<= b + s (a - w c))"] = t(lambda: check(lib.storm_hip_bicgstab_p(a._h, b._h, 0.5, 0.25, c._h)), 32)
+    # the element map of the playground's time loop (`f <<= map(dF_dc, c)`, Playground.cpp:148): a traced 13-operation program
+    dF = api.map(lambda c_: 2.0 * c_ * (c_ - 1.0) * (2.0 * c_ - 1.0), b)
+    out["map dF_dc (a <<= map(f, b))"] = t(lambda: a.__ilshift__(dF), 16)
     out["dot"] = t(lambda: api.dot_product(a, b), 16)
     out["norm2"] = t(lambda: api.norm_2(a), 8)
     out["multi_dot k=8"] = t(lambda: api.multi_dot(a, v[1:9]), 8 * 9)

@@ -137,42 +137,166 @@ struct VdivF {
 
 // y = func(x0, x1, y) elementwise, func a short arithmetic program in reverse Polish notation (storm_hip_map): the
 // element map `out <<= map(func, mats...)` of Bittern/MatrixMath.hpp:44-105 for callables made of exactly-rounded
-// operations.  The operand stack lives in NAMED registers (a push shifts them): no dynamically indexed array, no scratch.
-// Every operation is a statement of its own, so nothing contracts (-ffp-contract=on fuses within a statement only): the
-// value is what the host's scalar evaluation of the same expression gives, bit for bit.
+// operations.  Every operation is a statement of its own, so nothing contracts (-ffp-contract=on fuses within a statement
+// only): the value is what the host's scalar evaluation of the same expression gives, bit for bit.
+//
+// The program the kernel runs is the caller's after one peephole pass on the host (map_compile): a push that is
+// followed by a binary operation disappears into it -- `top = top OP operand` --, so a
+// left-deep expression like 2 c (c - 1)(2 c - 1) runs in 9 steps with 3 pushes instead of 13 with 7.  The operand stack
+// lives in NAMED registers, as many as the program needs (2, 4 or 8: a push or a pop shifts them; no dynamically indexed
+// array, no scratch), and the kernel streams only the vectors the program reads.  Round 6: the first version (always three
+// input streams, eight registers shifted at every push, 13 steps) ran `map(dF_dc, c)` at 0.20 of the HBM peak.
 constexpr int kMapMaxOps = 48, kMapMaxConsts = 16, kMapMaxDepth = 8;
-struct MapF {
-  static constexpr bool reads_y = true;
-  static constexpr int nin = 2;
+enum { kMapFuse = 32 };  // internal opcodes kMapFuse + (OP - ADD): top = top OP src
+struct MapProgram {
   int n_ops;
-  int code[kMapMaxOps];
+  int code[kMapMaxOps];  // opcode | source kind << 8 | constant index << 16
   double consts[kMapMaxConsts];
-  __device__ void prepare() {}
-  __device__ double operator()(double y, double a, double b) const {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
-    for (int k = 0; k < n_ops; ++k) {
-      const int op = code[k] & 0xff, arg = code[k] >> 8;
-      if (op < STORM_HIP_MAP_NEG) {
-        const double v = op == STORM_HIP_MAP_X0 ? a : op == STORM_HIP_MAP_X1 ? b : op == STORM_HIP_MAP_Y ? y : consts[arg];
-        s7 = s6, s6 = s5, s5 = s4, s4 = s3, s3 = s2, s2 = s1, s1 = s0, s0 = v;
+};
+// One thread: kUnroll pairs of rows (E = 8 elements), ONE pass of the interpreter over all of them -- a step is decoded
+// once (scalar: the program sits in the kernel's arguments) and applied to eight elements; the stack is DEPTH x E named
+// registers.  The streaming shape is ew_kernel's.
+template <int DEPTH, bool READS_Y, int NIN>
+__global__ __launch_bounds__(kBlock) void map_kernel(int64_t n, EwPtrs p, MapProgram prog, const int *done, int nt, int reverse) {
+  if (done && *done) return;
+  constexpr int E = 2 * kUnroll;
+  const unsigned bx = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+  const int64_t n2 = n >> 1;
+  double2v *__restrict__ y2 = reinterpret_cast<double2v *>(p.y);
+  const double2v *__restrict__ a2 = reinterpret_cast<const double2v *>(p.x0);
+  const double2v *__restrict__ b2 = reinterpret_cast<const double2v *>(p.x1);
+  auto run = [&](const double (&vy)[E], const double (&va)[E], const double (&vb)[E], double (&out)[E]) {
+    double s[DEPTH][E];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+      for (int e = 0; e < E; ++e) s[d][e] = 0.0;
+    for (int k = 0; k < prog.n_ops; ++k) {
+      const int word = prog.code[k], op = word & 0xff, kind = (word >> 8) & 0xff;
+      const double cst = prog.consts[(word >> 16) & 0xff];
+      // the step's operand for element e (a uniform choice: one scalar branch per step, not per element)
+      auto with_src = [&](auto &&fn) {
+        if (kind == STORM_HIP_MAP_X0) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) fn(e, va[e]);
+        } else if (kind == STORM_HIP_MAP_X1) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) fn(e, vb[e]);
+        } else if (kind == STORM_HIP_MAP_Y) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) fn(e, vy[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < E; ++e) fn(e, cst);
+        }
+      };
+      auto with_binary = [&](int opc, auto &&apply) {  // apply(f) with f(l, r) the operation: chosen once per step
+        if (opc == STORM_HIP_MAP_ADD) apply([](double l, double r) { return l + r; });
+        else if (opc == STORM_HIP_MAP_SUB) apply([](double l, double r) { return l - r; });
+        else if (opc == STORM_HIP_MAP_MUL) apply([](double l, double r) { return l * r; });
+        else if (opc == STORM_HIP_MAP_DIV) apply([](double l, double r) { return l / r; });
+        else if (opc == STORM_HIP_MAP_MIN) apply([](double l, double r) { return r < l ? r : l; });  // std::min(l, r)
+        else apply([](double l, double r) { return l < r ? r : l; });                               // std::max(l, r)
+      };
+      if (op >= kMapFuse) {  // top = top OP operand
+        with_binary(op - kMapFuse + STORM_HIP_MAP_ADD, [&](auto f) { with_src([&](int e, double v) { s[0][e] = f(s[0][e], v); }); });
+      } else if (op < STORM_HIP_MAP_NEG) {  // push
+#pragma unroll
+        for (int d = DEPTH - 1; d >= 1; --d)
+#pragma unroll
+          for (int e = 0; e < E; ++e) s[d][e] = s[d - 1][e];
+        with_src([&](int e, double v) { s[0][e] = v; });
       } else if (op < STORM_HIP_MAP_ADD) {
-        if (op == STORM_HIP_MAP_NEG) s0 = -s0;
-        else if (op == STORM_HIP_MAP_ABS) s0 = __builtin_fabs(s0);
-        else s0 = __builtin_sqrt(s0);
-      } else {
-        double r;
-        if (op == STORM_HIP_MAP_ADD) r = s1 + s0;
-        else if (op == STORM_HIP_MAP_SUB) r = s1 - s0;
-        else if (op == STORM_HIP_MAP_MUL) r = s1 * s0;
-        else if (op == STORM_HIP_MAP_DIV) r = s1 / s0;
-        else if (op == STORM_HIP_MAP_MIN) r = s0 < s1 ? s0 : s1;  // std::min(s1, s0)
-        else r = s1 < s0 ? s0 : s1;                               // std::max(s1, s0)
-        s0 = r, s1 = s2, s2 = s3, s3 = s4, s4 = s5, s5 = s6, s6 = s7;
+        if (op == STORM_HIP_MAP_NEG) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) s[0][e] = -s[0][e];
+        } else if (op == STORM_HIP_MAP_ABS) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) s[0][e] = __builtin_fabs(s[0][e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < E; ++e) s[0][e] = __builtin_sqrt(s[0][e]);
+        }
+      } else {  // second OP top, pop
+        with_binary(op, [&](auto f) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) s[0][e] = f(s[1 < DEPTH ? 1 : 0][e], s[0][e]);
+        });
+#pragma unroll
+        for (int d = 1; d + 1 < DEPTH; ++d)
+#pragma unroll
+          for (int e = 0; e < E; ++e) s[d][e] = s[d + 1][e];
       }
     }
-    return s0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) out[e] = s[0][e];
+  };
+  nt_dispatch(nt, [&](auto nt) {
+  for (int64_t base = (int64_t)bx * (kBlock * kUnroll) + threadIdx.x; base < n2;
+       base += (int64_t)gridDim.x * (kBlock * kUnroll)) {
+    double vy[E], va[E], vb[E], out[E];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t i = base + u * kBlock;
+      double2v ty{0.0, 0.0}, ta{0.0, 0.0}, tb{0.0, 0.0};
+      if (i < n2) {
+        if (READS_Y) ty = ld2(y2 + i, nt);
+        if (NIN > 0) ta = ld2(a2 + i, nt);
+        if (NIN > 1) tb = ld2(b2 + i, nt);
+      }
+      vy[2 * u] = ty.x, vy[2 * u + 1] = ty.y, va[2 * u] = ta.x, va[2 * u + 1] = ta.y, vb[2 * u] = tb.x, vb[2 * u + 1] = tb.y;
+    }
+    run(vy, va, vb, out);
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t i = base + u * kBlock;
+      if (i < n2) st2(y2 + i, double2v{out[2 * u], out[2 * u + 1]}, nt);
+    }
   }
-};
+  });
+  if ((n & 1) && bx == 0 && threadIdx.x == 0) {  // the odd last row: the same interpreter, seven idle elements
+    const int64_t i = n - 1;
+    double vy[E], va[E], vb[E], out[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) vy[e] = va[e] = vb[e] = 0.0;
+    vy[0] = READS_Y ? p.y[i] : 0.0, va[0] = NIN > 0 ? p.x0[i] : 0.0, vb[0] = NIN > 1 ? p.x1[i] : 0.0;
+    run(vy, va, vb, out);
+    p.y[i] = out[0];
+  }
+}
+
+// The caller's program (validated by storm_hip_map) -> the kernel's: pushes folded into the binary operation behind them.
+// Returns the operand-stack depth the result needs; *reads: bit 0 x0, bit 1 x1, bit 2 y.
+static int map_compile(const int32_t *program, int n_ops, int *code_out, int *n_out, int *reads) {
+  int n = 0, depth = 0, max_depth = 0;
+  *reads = 0;
+  auto is_push = [](int op) { return op == STORM_HIP_MAP_X0 || op == STORM_HIP_MAP_X1 || op == STORM_HIP_MAP_Y || op == STORM_HIP_MAP_CONST; };
+  auto is_binary = [](int op) { return op >= STORM_HIP_MAP_ADD && op <= STORM_HIP_MAP_MAX; };
+  for (int k = 0; k < n_ops; ++k) {
+    const int op = program[k] & 0xff, arg = program[k] >> 8;
+    if (is_push(op)) {
+      if (op != STORM_HIP_MAP_CONST) *reads |= 1 << op;
+      const int src = (op << 8) | ((op == STORM_HIP_MAP_CONST ? arg : 0) << 16);
+      // `... S OP`: the push of S and the operation in one step, top = top OP S (needs something under S: depth >= 1)
+      if (k + 1 < n_ops && is_binary(program[k + 1] & 0xff) && depth >= 1) {
+        code_out[n++] = (kMapFuse + (program[k + 1] & 0xff) - STORM_HIP_MAP_ADD) | src;
+        ++k;
+        continue;
+      }
+      code_out[n++] = op | src;  // (a plain push keeps its opcode; the source travels in the same fields)
+      max_depth = std::max(max_depth, ++depth);
+    } else if (is_binary(op)) {
+      // `S <expression> OP` where the expression was just finished and S was pushed right under it cannot be seen from here
+      // without a stack of provenances: only the operand-LAST form is folded (what a left-deep expression produces)
+      code_out[n++] = op;
+      --depth;
+    } else {
+      code_out[n++] = op;
+    }
+  }
+  *n_out = n;
+  return max_depth;
+}
 
 template <class F>
 static int launch_ew(storm_hip_ctx *c, int64_t n, EwPtrs p, F f, const int *done) {
@@ -608,8 +732,6 @@ int storm_hip_map(storm_hip_vec *y, const storm_hip_vec *x0, const storm_hip_vec
                 "map: %d constants (0 .. %d)", n_constants, kMapMaxConsts);
   if (x0) STORM_TRY(check_pair(y, x0, "map"));
   if (x1) STORM_TRY(check_pair(y, x1, "map"));
-  MapF f;
-  f.n_ops = n_ops;
   int depth = 0;
   for (int k = 0; k < n_ops; ++k) {  // the program is checked here, once: the kernel trusts it
     const int op = program[k] & 0xff, arg = program[k] >> 8;
@@ -628,13 +750,38 @@ int storm_hip_map(storm_hip_vec *y, const storm_hip_vec *x0, const storm_hip_vec
     } else {
       STORM_FAIL(STORM_HIP_E_INVALID, "map: unknown operation code %d at %d", op, k);
     }
-    f.code[k] = program[k];
   }
   STORM_REQUIRE(depth == 1, "map: the program leaves %d values (it must leave one)", depth);
-  for (int k = 0; k < n_constants; ++k) f.consts[k] = constants[k];
+  int code[kMapMaxOps], n_code = 0, reads = 0;
+  const int need = map_compile(program, n_ops, code, &n_code, &reads);
   STORM_TRY(lazy_sync(y->ctx));
   if (y->n_owned <= 0) return STORM_HIP_OK;
-  return launch_ew(y->ctx, y->n_owned, EwPtrs{y->d, x0 ? x0->d : y->d, x1 ? x1->d : y->d}, f, y->ctx->api_done);
+  storm_hip_ctx *c = y->ctx;
+  const bool ry = (reads & 4) != 0;
+  const int nin = (reads & 2) ? 2 : 1;  // (a program that reads no vector at all still streams one: the kernel's shape)
+  const EwPtrs ptrs{y->d, x0 ? x0->d : y->d, x1 ? x1->d : y->d};
+  MapProgram prog{};
+  prog.n_ops = n_code;
+  for (int k = 0; k < n_code; ++k) prog.code[k] = code[k];
+  for (int k = 0; k < n_constants; ++k) prog.consts[k] = constants[k];
+  const dim3 grid(stream_blocks(y->n_owned)), block(kBlock);
+  const int nt = stream_nt(c, y->n_owned), rev = c->stream_reverse;
+#define STORM_MAP_GO(D, RY, NI) \
+  hipLaunchKernelGGL((map_kernel<D, RY, NI>), grid, block, 0, c->stream, y->n_owned, ptrs, prog, c->api_done, nt, rev)
+#define STORM_MAP_D(D)                                               \
+  do {                                                               \
+    if (ry && nin == 2) STORM_MAP_GO(D, true, 2);                    \
+    else if (ry) STORM_MAP_GO(D, true, 1);                           \
+    else if (nin == 2) STORM_MAP_GO(D, false, 2);                    \
+    else STORM_MAP_GO(D, false, 1);                                  \
+  } while (0)
+  if (need <= 2) STORM_MAP_D(2);
+  else if (need <= 4) STORM_MAP_D(4);
+  else STORM_MAP_D(8);
+#undef STORM_MAP_D
+#undef STORM_MAP_GO
+  HIP_TRY(hipGetLastError());
+  return STORM_HIP_OK;
 }
 
 int storm_hip_vmul(storm_hip_vec *y, const storm_hip_vec *a, const storm_hip_vec *b) {
