@@ -94,13 +94,15 @@ def main() -> int:
                     help="N > 1: comma-separated chain, each entry run by FRESH rank processes: rccl (halo send/recv + "
                          "all-reduce over RCCL: the transport BASELINE.json's north_star names), ipc (the library's peer-window "
                          "transport: hipIpc-mapped device memory, direct stores over xGMI, rank-ordered all-reduce fused into "
-                         "the reductions' final pass), host (halo planes and scalars staged through host memory over gloo).  "
-                         "Default rccl,ipc,host (--shared-device: ipc,host): rccl AND ipc are both measured -- `value` is the "
-                         "better one, `transports_measured` holds both with their comm_breakdown --, each guarded by the "
-                         "pre-flight before and the post-flight check after its timed region; host only if neither worked")
+                         "the reductions' final pass), host (halo planes and scalars staged through host memory over gloo), "
+                         "rccl-plain (rccl with cross-stream events, two-launch reductions, no early halo, no fused step: "
+                         "run only if rccl gave no number).  Default rccl,rccl-plain,ipc,host (--contact: rccl,rccl-plain; "
+                         "--shared-device: ipc,host): rccl AND ipc are both measured -- `value` is the better one, "
+                         "`transports_measured` holds both with their comm_breakdown --, each guarded by the pre-flight before "
+                         "and the post-flight check after its timed region; host only if neither worked")
     ap.add_argument("--one-transport", action="store_true", help="N > 1: stop at the first transport of the chain that works")
     ap.add_argument("--attempt-seconds", default="240,150,150",
-                    help="wall-clock budget of the 1st, 2nd, 3rd transport attempt (N > 1)")
+                    help="wall-clock budget of the 1st, 2nd, 3rd (and every later) transport attempt (N > 1)")
     ap.add_argument("--inject-fail", default="", help="test hook: TRANSPORT=hang|exit|wrong|post[:RANK] makes that attempt fail "
                                                       "(a rank hangs / dies / the pre-flight / the post-flight finds wrong values)")
     ap.add_argument("--force-comm", action="store_true",
