@@ -891,6 +891,13 @@ def _get(d, *path):
     return d
 
 
+def _ratio(a, b):
+    try:
+        return float(a) / float(b) if a is not None and b else None
+    except (TypeError, ValueError, ZeroDivisionError):
+        return None
+
+
 def _short(text, n):
     text = "" if text is None else str(text)
     return text if len(text) <= n else text[: n - 3] + "..."
@@ -926,6 +933,10 @@ def compact_record(full: dict) -> dict:
         "tets_frac_8d": u3.get("frac_8d"), "tets_spmv_frac_8d_rotating": _get(u3, "spmv", "rotating_3_pairs", "frac_8d"),
         "tets_traffic_over_8d": u3.get("traffic_over_8d_bytes"),
         "measured_copy_GBs": r.get("measured_copy_GBs"),
+        # "report both fractions" -- of the 8 TB/s peak (frac, spmv_general_frac_8d_rotating) and of what a
+        # device copy reaches in this very run
+        "frac_of_measured_copy": _ratio(r.get("achieved"), r.get("measured_copy_GBs")),
+        "spmv_general_frac_of_measured_copy": _ratio(_get(sg, "rotating_3_pairs", "GBs_8d_bytes"), r.get("measured_copy_GBs")),
         "note": "frac: streamed bytes of the dominant kernel / time / peak; frac_8d > 1 on the lattice records is not a "
                 "bandwidth; spmv_general_*: stand-alone fp64-record SpMV, SURVEY 8d bytes, median of >= 50",
     }
