@@ -108,6 +108,97 @@ def test_map_rejects_what_the_kernel_cannot_run(ctx):
         out <<= api.map(lambda s: s + 1.0, short)
 
 
+def _random_tree(rng, budget):
+    """A random expression over the leaves 0 / 1 / 2 (operands) and constants: nested tuples (op, child...)."""
+    if budget <= 1 or rng.random() < 0.25:
+        return ("leaf", int(rng.integers(0, 3))) if rng.random() < 0.7 else ("const", float(rng.choice([0.5, -1.25, 3.0, 0.1, 7.0])))
+    kind = rng.random()
+    if kind < 0.2:
+        return (str(rng.choice(["neg", "abs", "sqrtabs"])), _random_tree(rng, budget - 1))
+    left = int(rng.integers(1, budget))
+    # (a divisor is kept away from zero: |.| + 0.5 -- 0 / 0 and the sign of a NaN are not what is being compared)
+    return (str(rng.choice(["add", "sub", "mul", "div", "min", "max"])), _random_tree(rng, left), _random_tree(rng, budget - left))
+
+
+def _leaves_of(tree):
+    if tree[0] == "leaf":
+        return {tree[1]}
+    if tree[0] == "const":
+        return set()
+    return set().union(*[_leaves_of(t) for t in tree[1:]])
+
+
+def _evaluate(tree, leaves, traced):
+    """The tree on traced scalars (api.Sym) or on numpy arrays: the same operations in the same order."""
+    from stormruler_amd import api
+
+    op = tree[0]
+    if op == "leaf":
+        return leaves[tree[1]]
+    if op == "const":
+        return tree[1]
+    v = [_evaluate(t, leaves, traced) for t in tree[1:]]
+    is_sym = lambda z: isinstance(z, api.Sym)  # noqa: E731
+    if op == "neg":
+        return -v[0]
+    if op == "abs":
+        return abs(v[0])
+    if op == "sqrtabs":
+        return abs(v[0]).sqrt() if is_sym(v[0]) else np.sqrt(np.abs(v[0]))
+    if op == "add":
+        return v[0] + v[1]
+    if op == "sub":
+        return v[0] - v[1]
+    if op == "mul":
+        return v[0] * v[1]
+    if op == "div":
+        return v[0] / (abs(v[1]) + 0.5)
+    lo = op == "min"
+    if is_sym(v[0]) or is_sym(v[1]):
+        l = api.Sym.of(v[0])
+        return l.min(v[1]) if lo else l.max(v[1])
+    l, r = np.asarray(v[0], dtype=np.float64), np.asarray(v[1], dtype=np.float64)
+    return np.where(r < l, r, l) if lo else np.where(l < r, r, l)  # std::min / std::max (FunctionalUtils' operands order)
+
+
+def test_random_map_programs_equal_numpy_bit_for_bit(ctx):
+    """120 random expressions (up to 21 leaves: every stack depth the kernel specialises for, folded and unfolded pushes,
+    programs that read one, two or all three operands, the target among them or not) against numpy's evaluation of the same
+    tree -- equal to the bit; lengths with and without the odd tail."""
+    from stormruler_amd import api
+    from stormruler_amd._lib import StormHipError
+
+    rng = np.random.default_rng(2026)
+    ran = rejected = 0
+    depths = set()
+    for case in range(120):
+        n = int(rng.choice([1, 7, 64, 4099, 65536, 100001]))
+        host = [rng.standard_normal(n), rng.random(n) * 4.0 - 1.0, rng.standard_normal(n) * 10.0]
+        tree = _random_tree(rng, int(rng.integers(2, 22)))
+        n_operands = int(rng.integers(1, 4))
+        tree_leaves = _leaves_of(tree)
+        if any(k >= n_operands for k in tree_leaves):
+            n_operands = max(tree_leaves) + 1
+        vecs = [_vec(ctx, h) for h in host[:n_operands]]
+        # the target: one of the operands (always, with three), or a fresh vector
+        target_is = int(rng.integers(0, n_operands)) if (n_operands == 3 or rng.random() < 0.4) else -1
+        out = vecs[target_is] if target_is >= 0 else api.DeviceVector(ctx, n)
+        fn = lambda *xs: _evaluate(tree, xs, True)  # noqa: E731
+        try:
+            out <<= api.map(fn, *vecs)
+        except StormHipError as e:  # (a right-deep draw can need more than 8 operands at once: rejected, not wrong)
+            assert any(w in str(e) for w in ("operands at once", "operations", "constants")), (case, tree, str(e))
+            rejected += 1
+            continue
+        with np.errstate(all="ignore"):
+            ref = np.broadcast_to(np.asarray(_evaluate(tree, host[:n_operands], False), dtype=np.float64), (n,))
+        got = out.to_numpy()
+        assert np.array_equal(got.view(np.int64), np.ascontiguousarray(ref).view(np.int64)), (case, n, tree, np.abs(got - ref).max())
+        ran += 1
+        depths.add(len(tree_leaves))
+    assert ran >= 100 and rejected <= 20, (ran, rejected)
+
+
 # ---- the time loops ---------------------------------------------------------------------------------------------------
 def _run_driver(args, timeout=600, **env):
     assert os.path.exists(DRIVER), "tests/cpp/timestep_driver is not built (__graft_entry__.build() builds it)"
