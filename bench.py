@@ -184,7 +184,8 @@ def main() -> int:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"), os.environ.setdefault("MASTER_PORT", "29533")
         # torch.distributed only bootstraps (ids, window handles, barriers, the max of timings): gloo whenever the data
         # path itself is not RCCL, so that a rank pair RCCL cannot serve still has a control plane
-        dist.init_process_group("nccl" if (transport in ("rccl", "rccl-plain") and not args.shared_device) else "gloo")
+        with stdout_to_stderr():  # (gloo announces its connections on stdout)
+            dist.init_process_group("nccl" if (transport in ("rccl", "rccl-plain") and not args.shared_device) else "gloo")
 
     def connect(ctx_):
         if world == 1:
@@ -963,8 +964,10 @@ def compact_record(full: dict) -> dict:
         "dtype": full.get("dtype"), "data": full.get("data"),
         "config": {"workload": _short(cfg.get("workload"), 220), "cells_per_gpu": cfg.get("cells_per_gpu"),
                    "partition": _short(cfg.get("partition"), 160), "ordering": cfg.get("ordering")},
-        "roofline": roof, "cpu_baseline": cpu, "value_general": full.get("value_general"),
+        "roofline": roof if full.get("roofline") is not None else None, "cpu_baseline": cpu, "value_general": full.get("value_general"),
     }
+    if full.get("error"):  # (a run that measured nothing says why: failure_record)
+        line["error"] = _short(full["error"], 600)
     configs = {}
     for key, fields in (("config1_cg64", ("us_per_iteration",)), ("config3_bicgstab256", ("us_per_iteration", "frac")),
                         ("config4_gmres30_convdiff128", ("us_per_inner_iteration", "frac")),
@@ -1084,6 +1087,38 @@ def emit(full: dict, detail_path) -> None:
             "cpu_baseline": {k: c.get(k) for k in ("value", "unit", "cores", "kind")} if isinstance(c, dict) else None,
             "detail": full.get("detail_file")}), separators=(",", ":"))[:LINE_CAP]
     print(line, flush=True)
+
+
+class stdout_to_stderr:
+    """gloo announces its connections on STDOUT ("[Gloo] Rank 0 is connected to 1 peer ranks...", from C++): while a
+    process group is being set up, file descriptor 1 points at stderr, so stdout stays the ONE line the driver parses."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
+def failure_record(args, world, fallbacks) -> dict:
+    """What rank 0 prints when NO transport produced a number: the contract's fields with `value` null and what happened."""
+    edge = args.n or 256
+    return {
+        "metric": "CG iterations/sec, 256^3 Poisson per GPU (+ SpMV achieved HBM GB/s in `roofline`)", "value": None,
+        "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"3D 7-point Poisson {edge}^3 per GPU, fp64 CG [BASELINE.json configs[1]] -- NOT MEASURED",
+                   "partition": f"z-slabs, {world} ranks"},
+        "roofline": None, "cpu_baseline": None,
+        "error": "no transport of the chain produced a result: " + "; ".join(f"{f['transport']}: {f['reason']}" for f in fallbacks),
+        "transport_fallback": fallbacks,
+    }
 
 
 RCCL_PLAIN_OPTIONS = ("rccl_flag_wait", "rccl_ticket", "rccl_early_halo", "rccl_fused")
@@ -1638,7 +1673,15 @@ def supervise(args, chain) -> int:
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    td.init_process_group("gloo", rank=rank, world_size=world)
+
+    def cpu_barrier():
+        # (NOT td.barrier(): that one asks torch for "the accelerator on the machine" first, which opens the GPU -- and a
+        #  supervisor never does: N of them beside N measuring ranks would double the processes that hold the device)
+        td.all_reduce(torch.zeros(1, dtype=torch.float64))
+
+    with stdout_to_stderr():
+        td.init_process_group("gloo", rank=rank, world_size=world)
+        cpu_barrier()  # (the connections are made -- and announced -- at the first collective)
     budgets = [float(v) for v in args.attempt_seconds.split(",")]
     fallbacks, line = [], None
     measured, n_measured, measured_names = {}, 0, []  # transport -> parsed record (rank 0 holds them, every rank the names)
@@ -1700,7 +1743,7 @@ def supervise(args, chain) -> int:
             measured_names.append(transport)
             if rank == 0:
                 measured[transport] = json.loads(line)
-            td.barrier()
+            cpu_barrier()
             continue  # ... on to the next transport of the chain: both RCCL and the peer windows are measured
         if child.poll() is None:  # end exactly the process group this supervisor started
             try:
@@ -1714,7 +1757,7 @@ def supervise(args, chain) -> int:
                   (f"starting fresh ranks on {chain[attempt + 1]}" if attempt + 1 < len(chain) else "no transport left"),
                   file=sys.stderr, flush=True)
         line = None
-        td.barrier()
+        cpu_barrier()
     status = 0 if n_measured else 1
     if rank == 0 and measured:
         best = max(measured, key=lambda t: measured[t]["value"])
@@ -1726,6 +1769,8 @@ def supervise(args, chain) -> int:
                                    "peer windows); `transports_measured` holds every one")
         out["transport_fallback"] = fallbacks
         emit(out, args.detail_path)
+    elif rank == 0:  # nothing measured: still ONE line, saying so (the exit code stays non-zero)
+        emit(failure_record(args, world, fallbacks), args.detail_path)
     flag = torch.tensor([float(status)], dtype=torch.float64)
     td.all_reduce(flag, op=td.ReduceOp.MAX)
     td.destroy_process_group()

@@ -2,7 +2,8 @@
 
 On a box without a GPU every measuring rank stops at "needs an MI355X" (rc 3) -- what this checks is that the ranks WERE
 started (rank supervisors through torch.distributed.run on 127.0.0.1, each starting its measuring child per transport
-attempt) and that the failure is relayed, instead of the rc 2 "launch me under torchrun" refusal of round 1."""
+attempt) and that the failure is relayed -- on stderr and as ONE stdout line with `value` null --, instead of the rc 2 "launch me
+under torchrun" refusal of round 1."""
 import os
 import subprocess
 import sys
@@ -27,4 +28,14 @@ def test_bench_starts_its_own_ranks():
     assert 4 <= p.stderr.count("bench.py needs an MI355X") <= 2 * 4, p.stderr[-3000:]
     assert "starting fresh ranks on rccl-plain" in p.stderr and "starting fresh ranks on ipc" in p.stderr
     assert "starting fresh ranks on host" in p.stderr and "no transport left" in p.stderr
-    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]  # no number, no line
+    # no number -- and still exactly ONE line on stdout, the contract's fields with `value` null and what happened (gloo's
+    # "[Gloo] Rank 0 is connected to ..." goes to stderr: the supervisors set their group up with fd 1 pointing there)
+    import json
+
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["value"] is None and rec["n_gpus"] == 2 and rec["roofline"] is None and rec["cpu_baseline"] is None
+    assert rec["error"].startswith("no transport of the chain produced a result: rccl: ")
+    assert [f["transport"] for f in rec["transport_fallback"]] == ["rccl", "rccl-plain", "ipc", "host"]
+    assert len(lines[0]) <= 8000
