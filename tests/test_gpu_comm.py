@@ -143,6 +143,48 @@ def test_flag_wait_and_event_wait_give_the_same_solve(setup, kind):
         assert err == out[1][0][0] and np.array_equal(xs, out[1][0][1])
 
 
+@pytest.mark.parametrize("shape", [(20, 12, 9), (32, 32, 24)])
+def test_the_plain_form_of_the_rccl_transport_against_the_oracle(shape):
+    """bench.py's `rccl-plain` fallback = the RCCL transport with every refinement that has only ever run on a size-1
+    communicator switched off AT ONCE (bench.RCCL_PLAIN_OPTIONS: cross-stream events instead of flag waits, two-launch
+    reductions, no early halo, no fused step).  Each switch has its own test here; this one holds the combination the
+    fallback actually runs -- CG, BiCGStab and GMRES against the oracle, on a box that gets the general records and on one
+    whose interior planes get the lattice records."""
+    import os
+    import sys
+
+    from oracle import oracle
+    from stormruler_amd import api
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    ctx = api.Context(0)
+    try:
+        for key in bench.RCCL_PLAIN_OPTIONS:
+            ctx.set_option(key, 0)
+        ctx.comm_init(api.Context.comm_unique_id(), 1, 0)
+        loc, send_idx = _periodic_z_local_graph(*shape)
+        mat = api.StencilMatrix.from_face_graph(ctx, loc)
+        mat.set_halo([0], [0, loc.n_halo], send_idx, [0, loc.n_halo])
+        ref_op = oracle.StencilOperator(loc, -1.0, 0.05)
+        ref_apply = lambda x: ref_op.apply(np.concatenate([x, x[send_idx]]))[: loc.n_cells]  # noqa: E731
+        b_host = np.cos(0.05 * np.arange(loc.n_cells)) + 0.3
+        for kind, tol in (("cg", 1e-8), ("bicgstab", 5e-6), ("gmres", 5e-6)):
+            s = {"cg": api.CgSolver, "bicgstab": api.BiCgStabSolver, "gmres": api.GmresSolver}[kind]()
+            if kind == "gmres":
+                s.num_inner_iterations = 20
+            b = api.DeviceVector.from_numpy(ctx, b_host, n_halo=loc.n_halo)
+            x = api.DeviceVector(ctx, loc.n_cells, loc.n_halo)
+            assert s.solve(x, b, api.HipStencilOperator(mat, -1.0, 0.05)), kind
+            ref = oracle.solve(kind, oracle.CallbackOperator(loc.n_cells, ref_apply), b_host, num_inner_iterations=20)
+            assert ref.converged and abs(s.iteration - ref.iterations) <= max(2, int(0.05 * ref.iterations)), (kind, s.iteration, ref.iterations)
+            assert np.linalg.norm(x.to_numpy() - ref.x) <= tol * np.linalg.norm(ref.x), kind
+        mat.close()
+    finally:
+        ctx.close()
+
+
 def test_gmres_cgs2_through_the_comm_path(setup):
     api, ctx, loc, mat, ref_apply, oracle = setup
     b_host = np.ones(loc.n_cells)
