@@ -1195,7 +1195,12 @@ def baseline_configs(api, mesh, ctx, op, b, N, n, st, min_seconds, self_exchange
     # ---- config 3
     try:
         sec, reps = rate(api.BiCgStabSolver, op, b, N, 60)
-        moved = 2 * (st["record_bytes"] + 16 * N) + 104 * N  # two applies + the fused vector passes (NOTES.md section 4)
+        # what the five kernels of an iteration stream: two applies (records + x + y), r~ beside the first one for <r~, v>,
+        # p = r + beta (p - omega v) 32 N, s = r - alpha v 24 N, the second half-step 56 N (x, p, s, t, r~ read; x, r written:
+        # seven streams) = records x 2 + 152 N = 168 B/row on the lattice records.  (Until round 6 this line counted
+        # 104 N for the vector passes -- NOTES.md section 5b's figure, which leaves r~'s two reads to the dots -- and
+        # under-reported `frac` by a tenth.)
+        moved = 2 * (st["record_bytes"] + 16 * N) + 8 * N + 32 * N + 24 * N + 56 * N
         out["config3_bicgstab256"] = {
             "workload": f"BiCGStab, {n}^3 Poisson block (BASELINE configs[2]'s per-GPU problem), 60 iterations, tolerances off",
             "iter_per_s": 1.0 / sec, "us_per_iteration": sec * 1e6, "bytes_really_moved_per_iteration": moved,
