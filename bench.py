@@ -1241,9 +1241,10 @@ def baseline_configs(api, mesh, ctx, op, b, N, n, st, min_seconds, self_exchange
 
         sec, reps = rate(api.GmresSolver, op4, b4, g4.n_cells, 600, m30)
         n4 = g4.n_cells
-        # inner iteration k: the apply (records + x + y), every basis vector q_0 .. q_k once (8 B/row each), w in, q_{k+1}
-        # out; mean over k = 0 .. 29
-        moved = (st4["record_bytes"] + 16 * n4) + 8 * n4 * 15.5 + 16 * n4
+        # inner iteration k, ONE chain launch: the apply's records and its gathers of q_k, every basis vector q_0 .. q_k once
+        # (8 B/row each; mean over k = 0 .. 29: 15.5), q_{k+1} out -- w never leaves the registers; per cycle of 30 the
+        # restart: x += sum beta_i q_i (30 vectors, x in and out once per launch of eight) and r = b - A x, its norm, q_0
+        moved = (st4["record_bytes"] + 8 * n4) + 8 * n4 * 15.5 + 8 * n4 + (30 * 8 * n4 + 4 * 16 * n4 + (st4["record_bytes"] + 16 * n4 + 24 * n4 + 8 * n4 + 16 * n4)) / 30.0
         out["config4_gmres30_convdiff128"] = {
             "workload": "GMRES(30), 128^3 convection-diffusion (nu = 1e-2, v = (1, 0.5, 0.25), first-order upwind), 600 "
                         "inner iterations, tolerances off [BASELINE configs[3]]",
