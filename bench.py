@@ -1094,15 +1094,25 @@ class stdout_to_stderr:
     process group is being set up, file descriptor 1 points at stderr, so stdout stays the ONE line the driver parses."""
 
     def __enter__(self):
-        sys.stdout.flush()
-        self.saved = os.dup(1)
-        os.dup2(2, 1)
+        self.saved = None
+        try:
+            sys.stdout.flush()
+            self.saved = os.dup(1)
+            os.dup2(2, 1)
+        except (OSError, ValueError):  # (no usable descriptor 1 or 2: nothing to protect, nothing to redirect)
+            if self.saved is not None:
+                os.close(self.saved)
+                self.saved = None
         return self
 
     def __exit__(self, *exc):
-        sys.stdout.flush()
-        os.dup2(self.saved, 1)
-        os.close(self.saved)
+        if self.saved is not None:
+            try:
+                sys.stdout.flush()
+            except (OSError, ValueError):
+                pass
+            os.dup2(self.saved, 1)
+            os.close(self.saved)
         return False
 
 
